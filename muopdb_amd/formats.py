@@ -1,0 +1,309 @@
+"""Producers for the reference's on-disk index formats (numpy, vectorised).
+
+These write byte-for-byte what the reference writers emit, so that a segment built here
+can be opened by the reference readers and — the use on this path — by
+`libmuopdb_hip.so`'s loaders (`mdb_ivf_load`, `mdb_hnsw_load`, ...), which parse exactly
+these layouts out of the mmapped files:
+
+* vector file            rs/index/src/vector/file.rs:213-225, async_storage.rs:112-136
+* Elias-Fano posting list rs/compression/src/elias_fano/ef.rs:34-71, 129-215
+* IVF `index` container  rs/index/src/ivf/writer.rs:255-355, posting_list/combined_file.rs:16-25
+* HNSW `index` container rs/index/src/hnsw/writer.rs:24-33, 43-265
+* multi-user concat      rs/index/src/multi_spann/writer.rs:171-250, user_index_info.rs:26-42
+
+The byte layouts are pinned by the reference's own writer tests (SURVEY.md §8c K1-K3, K5,
+K7, K13), re-encoded in tests/test_formats_kat.py.
+"""
+import struct
+
+import numpy as np
+
+U64_MAX = (1 << 64) - 1
+
+
+# --------------------------------------------------------------------------- helpers
+def pad_to(n, alignment):
+    """rs/utils/src/io.rs:48-60 write_pad: number of zero bytes to reach `alignment`."""
+    r = n % alignment
+    return 0 if r == 0 else alignment - r
+
+
+def doc_ids_to_array(doc_ids):
+    """Python ints / (n,2) u64 array -> (n,2) little-endian u64 [lo, hi]."""
+    if isinstance(doc_ids, np.ndarray) and doc_ids.ndim == 2 and doc_ids.dtype == np.uint64:
+        return np.ascontiguousarray(doc_ids)
+    if isinstance(doc_ids, np.ndarray) and doc_ids.ndim == 1:
+        out = np.zeros((doc_ids.size, 2), np.uint64)
+        out[:, 0] = doc_ids.astype(np.uint64)
+        return out
+    out = np.zeros((len(doc_ids), 2), np.uint64)
+    for i, d in enumerate(doc_ids):
+        out[i, 0] = d & U64_MAX
+        out[i, 1] = d >> 64
+    return out
+
+
+def u128_bytes(v):
+    return struct.pack("<QQ", v & U64_MAX, v >> 64)
+
+
+# --------------------------------------------------------------------------- vector file (V1)
+def write_vector_file(vectors):
+    """`u64 n` + row-major little-endian values (f32 or u8)."""
+    v = np.ascontiguousarray(vectors)
+    if v.dtype not in (np.float32, np.uint8):
+        raise TypeError("vector files hold f32 or u8 (PQ codes)")
+    return struct.pack("<Q", v.shape[0]) + v.tobytes()
+
+
+# --------------------------------------------------------------------------- Elias-Fano (E1)
+def ef_lower_bit_length(universe, num_elem):
+    """ef.rs:37-42: msb(universe / n) if universe > n else 0."""
+    if universe > num_elem and num_elem > 0:
+        return int(universe // num_elem).bit_length() - 1
+    return 0
+
+
+def ef_encode(values, universe=None):
+    """Serialized posting list: `u64 n, u64 L, u64 lower_words, u64 upper_words, words...`.
+
+    `universe` defaults to the last element — what the IVF writer passes
+    (rs/index/src/ivf/writer.rs:271 `posting_list.last().unwrap_or(0)`).
+    """
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    n = int(v.size)
+    if universe is None:
+        universe = int(v[-1]) if n else 0
+    if n and (np.any(v[1:] < v[:-1]) or int(v[-1]) > universe):
+        raise ValueError("Sequence is not sorted / exceeds universe")
+    L = ef_lower_bit_length(universe, n)
+    # lower bits, Lsb0 inside u64 words
+    if L > 0 and n > 0:
+        bits = ((v[:, None] >> np.arange(L, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.uint8).reshape(-1)
+        lower = np.packbits(bits, bitorder="little")
+    else:
+        lower = np.zeros(0, np.uint8)
+    lower_words = (n * L + 63) // 64
+    lower = np.concatenate([lower, np.zeros(lower_words * 8 - lower.size, np.uint8)])
+    # upper bits: element i sets bit (high_i + i)
+    if n > 0:
+        high = (v >> np.uint64(L)) if L < 64 else np.zeros(n, np.uint64)
+        pos = high + np.arange(n, dtype=np.uint64)
+        nbits = int(pos[-1]) + 1
+        ub = np.zeros(nbits, np.uint8)
+        ub[pos.astype(np.int64)] = 1
+        upper = np.packbits(ub, bitorder="little")
+    else:
+        nbits = 0
+        upper = np.zeros(0, np.uint8)
+    upper_words = (nbits + 63) // 64
+    upper = np.concatenate([upper, np.zeros(upper_words * 8 - upper.size, np.uint8)])
+    return struct.pack("<QQQQ", n, L, lower_words, upper_words) + lower.tobytes() + upper.tobytes()
+
+
+def ef_bits(values, universe):
+    """(L, lower bit list, upper bit list) — the encoder's raw bit vectors (K1)."""
+    blob = ef_encode(values, universe)
+    n, L, lw, uw = struct.unpack_from("<QQQQ", blob, 0)
+    lower = np.unpackbits(np.frombuffer(blob, np.uint8, lw * 8, 32), bitorder="little")[: n * L]
+    v = np.asarray(values, np.uint64)
+    nup = int((int(v[-1]) >> L) + n) if n else 0
+    upper = np.unpackbits(np.frombuffer(blob, np.uint8, uw * 8, 32 + lw * 8), bitorder="little")[:nup]
+    return int(L), lower.tolist(), upper.tolist()
+
+
+# --------------------------------------------------------------------------- IVF container (I1)
+def write_ivf_header(num_features, quantized_dimension, num_clusters, num_vectors, doc_id_mapping_len,
+                     centroids_len, posting_lists_and_metadata_len):
+    """ivf/writer.rs:280-295 (45 bytes, version 0)."""
+    return struct.pack("<BIIIQQQQ", 0, num_features, quantized_dimension, num_clusters, num_vectors,
+                       doc_id_mapping_len, centroids_len, posting_lists_and_metadata_len)
+
+
+def write_posting_lists_and_metadata(posting_lists):
+    """ivf/writer.rs:255-297: (metadata bytes, posting-list bytes)."""
+    meta = [struct.pack("<Q", len(posting_lists))]
+    pls = []
+    off = 0
+    for pl in posting_lists:
+        blob = ef_encode(pl)
+        meta.append(struct.pack("<QQ", len(blob), off))
+        pls.append(blob)
+        off += len(blob)
+    return b"".join(meta), b"".join(pls)
+
+
+def write_ivf_index(centroids, doc_ids, posting_lists, quantized_dimension=None):
+    """The combined IVF `index` file (ivf/writer.rs:300-355)."""
+    c = np.ascontiguousarray(centroids, dtype=np.float32)
+    num_clusters, num_features = c.shape
+    if len(posting_lists) != num_clusters:
+        raise ValueError("Mismatch between number of clusters and number of posting lists")
+    ids = doc_ids_to_array(doc_ids)
+    n = ids.shape[0]
+    qd = num_features if quantized_dimension is None else quantized_dimension
+    doc_map = u128_bytes(n) + ids.tobytes()
+    cent = struct.pack("<Q", num_clusters) + c.tobytes()
+    meta, pls = write_posting_lists_and_metadata(posting_lists)
+    out = bytearray(write_ivf_header(num_features, qd, num_clusters, n, len(doc_map), len(cent),
+                                     len(meta) + len(pls)))
+    out += b"\0" * pad_to(len(out), 16)
+    out += doc_map
+    out += cent
+    out += b"\0" * pad_to(len(out), 8)
+    out += meta
+    out += pls
+    return bytes(out)
+
+
+# --------------------------------------------------------------------------- HNSW container (H1)
+def write_hnsw_index(layers, doc_ids, quantized_dimension):
+    """The HNSW `index` file (hnsw/writer.rs:43-265).
+
+    layers[0] is the bottom layer, layers[-1] the top.  Each layer is either a dict
+    {point_id: iterable of neighbour ids} or a CSR tuple (points, indptr, edges) where
+    `points` is None for layer 0 (slot == point id).  Upper-layer points are written in the
+    order given (the reference iterates a HashSet: arbitrary); the FIRST point of the top
+    layer is the entry point (graph_storage.rs:552-557).
+    """
+    edges_parts, points_parts, flat, level_offsets = [], [], [], []
+    num_edges = 0   # running index into the edges section
+    count = 0       # running number of edge_offsets ENTRIES (what level_offsets index)
+    for layer_idx in range(len(layers) - 1, -1, -1):   # top layer first (:93-150)
+        level_offsets.append(count)
+        layer = layers[layer_idx]
+        if isinstance(layer, dict):
+            if layer_idx > 0:
+                pts = list(layer.keys())
+                nbrs = [layer[p] for p in pts]
+                points = np.asarray(pts, np.uint32)
+            else:
+                max_point = max(layer.keys()) if layer else 0   # :124
+                nbrs = [layer.get(p, ()) for p in range(max_point + 1)]
+                points = None
+            lens = [len(x) for x in nbrs]
+            edges = (np.concatenate([np.asarray(x, np.uint32) for x in nbrs])
+                     if nbrs else np.zeros(0, np.uint32))
+            indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        else:
+            points, indptr, edges = layer
+            indptr = np.asarray(indptr, np.uint64)
+            edges = np.asarray(edges, np.uint32)
+            points = None if points is None else np.asarray(points, np.uint32)
+        flat.append(indptr[:-1] + np.uint64(num_edges))
+        count += indptr.size - 1
+        num_edges += int(indptr[-1])
+        edges_parts.append(edges.astype("<u4").tobytes())
+        if layer_idx > 0:
+            points_parts.append(points.astype("<u4").tobytes())
+        else:
+            flat.append(np.array([num_edges], np.uint64))  # sentinel after layer 0 (:140-142)
+            count += 1
+            level_offsets.append(count)
+    eo = np.concatenate(flat).astype("<u8") if flat else np.zeros(0, "<u8")
+    lo = np.asarray(level_offsets, "<u8")
+    ids = doc_ids_to_array(doc_ids)
+    edges_b, points_b = b"".join(edges_parts), b"".join(points_parts)
+    eo_b, lo_b, ids_b = eo.tobytes(), lo.tobytes(), ids.tobytes()
+    out = bytearray(struct.pack("<BIIQQQQQ", 0, quantized_dimension, len(layers), len(edges_b), len(points_b),
+                                len(eo_b), len(lo_b), len(ids_b)))
+    out += b"\0" * pad_to(len(out), 4)
+    out += edges_b
+    out += points_b
+    out += b"\0" * pad_to(len(out), 8)
+    out += eo_b
+    out += lo_b
+    out += b"\0" * pad_to(len(out), 16)
+    out += ids_b
+    return bytes(out)
+
+
+# --------------------------------------------------------------------------- multi-user concat (M1)
+USER_INDEX_INFO_FIELDS = (
+    "centroid_vector_offset", "centroid_vector_len", "centroid_index_offset", "centroid_index_len",
+    "ivf_vectors_offset", "ivf_vectors_len", "ivf_raw_vectors_offset", "ivf_raw_vectors_len",
+    "ivf_index_offset", "ivf_index_len", "ivf_pq_codebook_offset", "ivf_pq_codebook_len")
+
+
+def pack_user_index_info(user_id, **fields):
+    """112-byte LE record (multi_spann/user_index_info.rs:26-42)."""
+    return u128_bytes(user_id) + struct.pack("<12Q", *[int(fields.get(f, 0)) for f in USER_INDEX_INFO_FIELDS])
+
+
+def unpack_user_index_info(rec):
+    lo, hi = struct.unpack_from("<QQ", rec, 0)
+    vals = struct.unpack_from("<12Q", rec, 16)
+    d = dict(zip(USER_INDEX_INFO_FIELDS, vals))
+    d["user_id"] = (hi << 64) | lo
+    return d
+
+
+def concat_multi_spann(users):
+    """Concatenate per-user SPANN files into the 5 shared files (multi_spann/writer.rs:171-250).
+
+    users: dict user_id -> dict(hnsw_index, hnsw_vectors, ivf_index, ivf_vectors,
+                                 [ivf_raw_vectors], [codebook])  (bytes each)
+    Returns dict(hnsw_index, hnsw_vectors, ivf_index, ivf_vectors, ivf_raw_vectors, codebook,
+                 user_table) where user_table is this build's flat table: the 112-byte
+    records sorted by user id (the reference stores the same records in an `odht` 0.3.1
+    hash table whose byte format is not under /root/reference — SURVEY.md §8c).
+    """
+    out = {k: bytearray() for k in ("hnsw_index", "hnsw_vectors", "ivf_index", "ivf_vectors", "ivf_raw_vectors",
+                                    "codebook")}
+    recs = []
+    for uid in sorted(users.keys()):
+        u = users[uid]
+        f = {}
+        out["hnsw_index"] += b"\0" * pad_to(len(out["hnsw_index"]), 16)
+        f["centroid_index_offset"] = len(out["hnsw_index"])
+        out["hnsw_index"] += u["hnsw_index"]
+        f["centroid_index_len"] = len(u["hnsw_index"])
+        out["hnsw_vectors"] += b"\0" * pad_to(len(out["hnsw_vectors"]), 8)
+        f["centroid_vector_offset"] = len(out["hnsw_vectors"])
+        out["hnsw_vectors"] += u["hnsw_vectors"]
+        f["centroid_vector_len"] = len(u["hnsw_vectors"])
+        out["ivf_index"] += b"\0" * pad_to(len(out["ivf_index"]), 16)
+        f["ivf_index_offset"] = len(out["ivf_index"])
+        out["ivf_index"] += u["ivf_index"]
+        f["ivf_index_len"] = len(u["ivf_index"])
+        out["ivf_vectors"] += b"\0" * pad_to(len(out["ivf_vectors"]), 8)
+        f["ivf_vectors_offset"] = len(out["ivf_vectors"])
+        out["ivf_vectors"] += u["ivf_vectors"]
+        f["ivf_vectors_len"] = len(u["ivf_vectors"])
+        raw = u.get("ivf_raw_vectors", b"")
+        f["ivf_raw_vectors_offset"] = len(out["ivf_raw_vectors"])  # no pad (:230-235)
+        out["ivf_raw_vectors"] += raw
+        f["ivf_raw_vectors_len"] = len(raw)
+        cb = u.get("codebook")
+        if cb:
+            out["codebook"] += b"\0" * pad_to(len(out["codebook"]), 8)
+            f["ivf_pq_codebook_offset"] = len(out["codebook"])
+            out["codebook"] += cb
+            f["ivf_pq_codebook_len"] = len(cb)
+        recs.append(pack_user_index_info(uid, **f))
+    res = {k: bytes(v) for k, v in out.items()}
+    res["user_table"] = b"".join(recs)
+    return res
+
+
+# --------------------------------------------------------------------------- quantizer configs
+def no_op_quantizer_config_yaml(dimension):
+    """rs/quantization/src/noq/mod.rs:64-73 (`no_op_quantizer_config.yaml`)."""
+    return "dimension: %d\n" % dimension
+
+
+def product_quantizer_config_yaml(dimension, subvector_dimension, num_bits):
+    """rs/quantization/src/pq/mod.rs:34-39 (`product_quantizer_config.yaml`)."""
+    return "dimension: %d\nsubvector_dimension: %d\nnum_bits: %d\n" % (dimension, subvector_dimension, num_bits)
+
+
+def parse_simple_yaml(text):
+    """The quantizer configs are flat `key: int` maps."""
+    out = {}
+    for line in text.splitlines():
+        line = line.strip()
+        if not line or line.startswith("#") or line == "---":
+            continue
+        k, v = line.split(":", 1)
+        out[k.strip()] = int(v.strip())
+    return out
