@@ -1,0 +1,239 @@
+/*
+ * muopdb_hip.h — C ABI of libmuopdb_hip.so: the MI355X (gfx950) implementation of MuopDB's
+ * ANN distance / traversal hot path.
+ *
+ * The reference (hicder/muopdb, Rust) has NO FFI layer today; these are the
+ * entry points a Rust shim (bindgen / cxx) would bind to replace the reference functions
+ * cited on each declaration.  Conventions follow the reference's own:
+ *   - inputs are BORROWED for the duration of the call (Rust `&[f32]`, `&[u8]`): host mmaps of
+ *     the reference's on-disk files are parsed and copied to HBM inside `*_load`;
+ *   - outputs are CALLER-ALLOCATED, row-major [B][k]; short rows are padded with
+ *     doc id = 2^128-1 (point id = UINT32_MAX) / score = +inf and the true length is in
+ *     counts_out (the reference returns `Vec`s of variable length);
+ *   - errors are status codes, never exceptions (`anyhow::Result` / `Option`): a NaN distance
+ *     — where the reference panics in `NotNan::new(..).unwrap()` (rs/index/src/utils.rs:79) —
+ *     is MDB_ERR_NAN; `None` results (missing user, empty centroid result) are found_out[i]=0;
+ *   - handles are immutable after load except tombstones (`invalidate`), like the reference's
+ *     `invalid_point_ids: DashSet<u32>` (rs/index/src/ivf/block_based/index.rs:30).
+ *   - `mem` says where the query / output buffers live: MDB_MEM_HOST (plain host pointers, the
+ *     call copies and synchronises) or MDB_MEM_DEVICE (HBM pointers, e.g. torch tensors'
+ *     data_ptr(); the call only enqueues on the context's stream — call mdb_sync to wait and to
+ *     collect deferred errors).
+ *
+ * All kernels behind these symbols are hand-written HIP for gfx950; there is no CPU fallback:
+ * every entry point fails with MDB_ERR_HIP when no device is present.
+ */
+#ifndef MUOPDB_HIP_H
+#define MUOPDB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MDB_OK = 0,
+    MDB_ERR_INVALID_ARG = 1,
+    MDB_ERR_FORMAT = 2,      /* malformed index / vector file */
+    MDB_ERR_OOM = 3,
+    MDB_ERR_HIP = 4,         /* HIP runtime error / no device */
+    MDB_ERR_NAN = 5,         /* a distance evaluated to NaN (reference panics) */
+    MDB_ERR_NOT_FOUND = 6,
+    MDB_ERR_UNSUPPORTED = 7, /* e.g. traversal state exceeded the on-chip capacity */
+    MDB_ERR_OUT_OF_RANGE = 8 /* num_probes == 0 or > num_clusters (reference panics) */
+} mdb_status;
+
+typedef enum { MDB_METRIC_L2 = 0, MDB_METRIC_DOT = 1 } mdb_metric;
+typedef enum { MDB_QUANT_NONE = 0, MDB_QUANT_PQ = 1 } mdb_quant_kind;
+typedef enum { MDB_MEM_HOST = 0, MDB_MEM_DEVICE = 1 } mdb_mem;
+/* rs/utils/src/distance/l2.rs:9-14 L2DistanceCalculatorImpl (PQ distance seam only) */
+typedef enum { MDB_IMPL_SCALAR = 0, MDB_IMPL_SIMD = 1, MDB_IMPL_STREAMING_SIMD = 2 } mdb_distance_impl;
+
+/* u128 doc / user ids, little-endian halves (HIP has no native 128-bit integer) */
+typedef struct { uint64_t lo, hi; } mdb_u128;
+
+/* rs/quantization/src/quantization.rs:6-38 (trait Quantizer), noq/mod.rs, pq/mod.rs:23-39.
+ * `codebook` = the `codebook` file contents (raw LE f32 [m][2^num_bits][subdim]); for a
+ * multi-user collection pass the file from byte 0: the reference reader ignores
+ * ivf_pq_codebook_offset and uses the first user's codebook (pq/mod.rs:101-126). */
+typedef struct {
+    mdb_quant_kind kind;
+    mdb_metric metric;
+    uint32_t dimension;
+    uint32_t subvector_dimension; /* PQ only */
+    uint32_t num_bits;            /* PQ only */
+    const float* codebook;        /* PQ only, host pointer, borrowed */
+    size_t codebook_len;          /* number of floats */
+} mdb_quant_desc;
+
+/* rs/config/src/search_params.rs:1-34 */
+typedef struct {
+    size_t top_k;
+    uint32_t ef_construction;
+    int record_pages;               /* accepted, ignored: num_pages_accessed is always 0 (utils.rs:52-54) */
+    int64_t num_explored_centroids; /* < 0 = None => top_k */
+    float centroid_distance_ratio;  /* default 0.1 */
+} mdb_search_params;
+
+/* rs/index/src/multi_spann/user_index_info.rs:4-18 (112-byte LE record, same field order) */
+typedef struct {
+    mdb_u128 user_id;
+    uint64_t centroid_vector_offset, centroid_vector_len;
+    uint64_t centroid_index_offset, centroid_index_len;
+    uint64_t ivf_vectors_offset, ivf_vectors_len;
+    uint64_t ivf_raw_vectors_offset, ivf_raw_vectors_len;
+    uint64_t ivf_index_offset, ivf_index_len;
+    uint64_t ivf_pq_codebook_offset, ivf_pq_codebook_len;
+} mdb_user_index_info;
+
+/* counters of the last search call on a context (for GB/s accounting) */
+typedef struct {
+    uint64_t scored_vectors;    /* posting-list / flat vectors scored */
+    uint64_t distance_evals;    /* HNSW distance evaluations */
+    uint64_t expanded_nodes;    /* HNSW nodes whose adjacency was read */
+    uint64_t algorithmic_bytes; /* SURVEY.md §8d per-unit bytes x units of the last call */
+} mdb_stats;
+
+typedef struct mdb_ctx mdb_ctx;
+typedef struct mdb_flat mdb_flat;
+typedef struct mdb_ivf mdb_ivf;
+typedef struct mdb_hnsw mdb_hnsw;
+typedef struct mdb_spann mdb_spann;
+typedef struct mdb_multi_spann mdb_multi_spann;
+
+/* ---------------------------------------------------------------- context */
+mdb_status mdb_device_open(int gpu, mdb_ctx** out);
+void mdb_device_close(mdb_ctx* ctx);
+/* run on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+mdb_status mdb_set_stream(mdb_ctx* ctx, void* hip_stream);
+/* wait for the stream; returns the first deferred error of MDB_MEM_DEVICE calls (e.g. MDB_ERR_NAN) */
+mdb_status mdb_sync(mdb_ctx* ctx);
+const char* mdb_last_error(mdb_ctx* ctx);
+mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out);
+const char* mdb_version(void);
+
+/* ---------------------------------------------------------------- D1/D2/Q3 unit seams
+ * L2DistanceCalculator::{calculate_squared,calculate} rs/utils/src/distance/l2.rs:32-74;
+ * DotProductDistanceCalculator::calculate dot_product.rs:38-71.  n pairs of rows a[i], b[i]
+ * (row-major [n][d], host pointers).  Same lane association as the reference (16/8/4/scalar
+ * cascade, per-lane partial sums, ordered horizontal sum, no FMA). */
+mdb_status mdb_l2_distance(mdb_ctx* ctx, const float* a, const float* b, size_t n, size_t d, int squared, float* out);
+mdb_status mdb_dot_distance(mdb_ctx* ctx, const float* a, const float* b, size_t n, size_t d, float* out);
+/* ProductQuantizer::quantize pq/mod.rs:152-177 — vectors [n][dimension] -> codes [n][m] */
+mdb_status mdb_pq_quantize(mdb_ctx* ctx, const mdb_quant_desc* pq, const float* vectors, size_t n, uint8_t* codes_out);
+/* ProductQuantizer::distance pq/mod.rs:202-278 — code pairs a[i], b[i] ([n][m]) */
+mdb_status mdb_pq_distance(mdb_ctx* ctx, const mdb_quant_desc* pq, const uint8_t* a, const uint8_t* b, size_t n,
+                           mdb_distance_impl impl, float* out);
+/* Elias-Fano posting-list decode (block_based_decoder.rs:241-270 iterator): blob = one
+ * serialized list; out receives up to cap values; *n_out = num_elem */
+mdb_status mdb_ef_decode(mdb_ctx* ctx, const uint8_t* blob, size_t blob_len, uint64_t* out, size_t cap, size_t* n_out);
+
+/* ---------------------------------------------------------------- flat (brute force)
+ * The reference has no flat index type; this is BlockBasedIvf::find_nearest_centroids'
+ * loop (ivf/block_based/index.rs:147-163) over an arbitrary base: distances by
+ * DistanceCalculator::calculate (sqrt L2 / negated dot), top-k ordered by (distance, row). */
+mdb_status mdb_flat_create(mdb_ctx* ctx, const float* base, size_t n, size_t d, mdb_metric metric, mdb_mem base_mem,
+                           mdb_flat** out);
+void mdb_flat_free(mdb_flat* flat);
+mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_t k, mdb_mem mem, uint32_t* ids_out,
+                           float* dist_out, uint32_t* counts_out);
+/* one-shot convenience: create + search + free, host buffers */
+mdb_status mdb_flat_topk(mdb_ctx* ctx, const float* base, size_t n, size_t d, const float* queries, size_t b,
+                         mdb_metric metric, size_t k, uint32_t* ids_out, float* dist_out);
+
+/* ---------------------------------------------------------------- IVF
+ * BlockBasedIvf::new_with_offset ivf/block_based/index.rs:94-138: `index_bytes` is the IVF
+ * `index` file (container: ivf/block_based/storage.rs:52-138), `vectors_bytes` the `vectors`
+ * file (vector/async_storage.rs:67-136); both host pointers, borrowed.  Posting lists are
+ * Elias-Fano-decoded on the GPU and the vectors re-laid list-contiguous in HBM.
+ * shard_rank/shard_world: keep only the posting lists this rank owns (list sharding for the
+ * multi-GPU path; 0/1 = everything). */
+mdb_status mdb_ivf_load(mdb_ctx* ctx, const void* index_bytes, size_t index_len, size_t index_offset,
+                        const void* vectors_bytes, size_t vectors_len, size_t vectors_offset,
+                        const mdb_quant_desc* quant, uint32_t shard_rank, uint32_t shard_world, mdb_ivf** out);
+void mdb_ivf_free(mdb_ivf* ivf);
+size_t mdb_ivf_num_clusters(const mdb_ivf* ivf);
+size_t mdb_ivf_num_vectors(const mdb_ivf* ivf);
+size_t mdb_ivf_num_features(const mdb_ivf* ivf);
+/* find_nearest_centroids :147-163 — out [B][num_probes] centroid indices (nearest first).
+ * MDB_ERR_OUT_OF_RANGE when num_probes == 0 or > num_clusters (reference panics). */
+mdb_status mdb_ivf_find_nearest_centroids(mdb_ivf* ivf, const float* queries, size_t b, size_t num_probes, mdb_mem mem,
+                                          uint32_t* out);
+/* BlockBasedIvf::search :396-413 (probes == NULL) or search_with_centroids_and_remap :298-332
+ * (probes = [B][num_probes] centroid ids).  Results ordered by IdWithScore (score, doc_id). */
+mdb_status mdb_ivf_search(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes,
+                          size_t k, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out);
+/* same, stopping before the doc-id remap: the per-shard top-k by (distance, point id) —
+ * BlockBasedIvf::search_with_centroids :250-286 — used by the sharded multi-GPU merge */
+mdb_status mdb_ivf_search_points(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes,
+                                 size_t num_probes, size_t k, mdb_mem mem, uint32_t* point_ids_out, float* scores_out,
+                                 uint32_t* counts_out);
+/* BlockBasedIvf::invalidate / invalidate_batch / is_invalidated :421-470; flags_out[i] = 1 if
+ * newly invalidated (resp. currently invalid) */
+mdb_status mdb_ivf_invalidate(mdb_ivf* ivf, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
+mdb_status mdb_ivf_is_invalidated(mdb_ivf* ivf, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
+
+/* ---------------------------------------------------------------- HNSW
+ * BlockBasedHnsw (hnsw/block_based/index.rs); graph file hnsw/block_based/graph_storage.rs,
+ * vector file `hnsw/vector_storage`. */
+mdb_status mdb_hnsw_load(mdb_ctx* ctx, const void* index_bytes, size_t index_len, size_t index_offset,
+                         const void* vectors_bytes, size_t vectors_len, size_t vectors_offset,
+                         const mdb_quant_desc* quant, mdb_hnsw** out);
+void mdb_hnsw_free(mdb_hnsw* hnsw);
+size_t mdb_hnsw_num_vectors(const mdb_hnsw* hnsw);
+/* ann_search :159-210 — results ordered by (distance, point id), truncated to k */
+mdb_status mdb_hnsw_ann_search(mdb_hnsw* hnsw, const float* queries, size_t b, size_t k, uint32_t ef, mdb_mem mem,
+                               mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out);
+
+/* ---------------------------------------------------------------- SPANN
+ * SpannReader::new_with_offsets + Spann::search (spann/reader.rs, spann/index.rs:211-266):
+ * centroid HNSW (always NoQuantizer<L2>) + IVF posting lists (quant). */
+mdb_status mdb_spann_load(mdb_ctx* ctx, const void* hnsw_index, size_t hnsw_index_len, size_t hnsw_index_offset,
+                          const void* hnsw_vectors, size_t hnsw_vectors_len, size_t hnsw_vectors_offset,
+                          const void* ivf_index, size_t ivf_index_len, size_t ivf_index_offset,
+                          const void* ivf_vectors, size_t ivf_vectors_len, size_t ivf_vectors_offset,
+                          const mdb_quant_desc* quant, mdb_spann** out);
+void mdb_spann_free(mdb_spann* spann);
+/* found_out[i] = 0 mirrors `None` (empty centroid result, spann/index.rs:229-231) */
+mdb_status mdb_spann_search(mdb_spann* spann, const float* queries, size_t b, const mdb_search_params* params,
+                            mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out,
+                            uint8_t* found_out);
+mdb_status mdb_spann_invalidate(mdb_spann* spann, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
+mdb_status mdb_spann_is_invalidated(mdb_spann* spann, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
+
+/* ---------------------------------------------------------------- multi-user SPANN
+ * MultiSpannIndex (multi_spann/index.rs:21-131, :282-293): all users concatenated in 4 shared
+ * files (centroids/hnsw/{index,vector_storage}, ivf/{index,vectors}); `users` = the
+ * UserIndexInfo records (the reference keeps them in an odht table, user_index_info.rs:84-140).
+ * Every user's graph + posting lists are uploaded once; a batch may mix users freely.
+ * shard_rank/shard_world shard every user's posting lists across GPUs. */
+mdb_status mdb_multi_spann_load(mdb_ctx* ctx, const mdb_user_index_info* users, size_t n_users, uint32_t num_features,
+                                const void* hnsw_index, size_t hnsw_index_len, const void* hnsw_vectors,
+                                size_t hnsw_vectors_len, const void* ivf_index, size_t ivf_index_len,
+                                const void* ivf_vectors, size_t ivf_vectors_len, const mdb_quant_desc* quant,
+                                uint32_t shard_rank, uint32_t shard_world, mdb_multi_spann** out);
+void mdb_multi_spann_free(mdb_multi_spann* ms);
+size_t mdb_multi_spann_num_users(const mdb_multi_spann* ms);
+/* search_for_user :282-293 for a batch of (user_ids[i], queries[i]) pairs; unknown user =>
+ * found_out[i] = 0 (`Err(_) => None`) */
+mdb_status mdb_multi_spann_search(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                  const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out,
+                                  float* scores_out, uint32_t* counts_out, uint8_t* found_out);
+/* per-shard variant for the multi-GPU merge: top-k by (score, doc id) of THIS rank's lists */
+mdb_status mdb_multi_spann_invalidate(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,
+                                      uint8_t* flags_out);
+
+/* ---------------------------------------------------------------- shard merge
+ * Merge `world` per-shard result blocks ([world][B][k] records gathered by RCCL all-gather)
+ * into the global top-k per query, ordered by IdWithScore (score, doc_id) like
+ * Snapshot::search_for_users (collection/snapshot.rs:60-63).  Device buffers. */
+mdb_status mdb_merge_shards(mdb_ctx* ctx, const mdb_u128* doc_ids, const float* scores, const uint32_t* counts,
+                            size_t world, size_t b, size_t k, mdb_u128* doc_ids_out, float* scores_out,
+                            uint32_t* counts_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUOPDB_HIP_H */

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds libmuopdb_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+# -ffp-contract=off: the exact-association distance code must never be contracted into FMAs.
+set -e
+cd "$(dirname "$0")"
+OUT=../libmuopdb_hip.so
+SRCS="mdb_core.hip mdb_flat.hip mdb_ef.hip mdb_ivf.hip mdb_hnsw.hip mdb_spann.hip"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-variable"
+mkdir -p build
+objs=""
+for s in $SRCS; do
+  [ -f "$s" ] || continue
+  o=build/${s%.hip}.o
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ mdb_device.cuh -nt "$o" ] || [ mdb_common.h -nt "$o" ] || [ mdb_kernels.h -nt "$o" ] || [ ../../include/muopdb_hip.h -nt "$o" ]; then
+    echo "hipcc $s"
+    hipcc $FLAGS -c "$s" -o "$o" &
+  fi
+  objs="$objs $o"
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
+echo "built $OUT"

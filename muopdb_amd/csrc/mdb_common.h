@@ -1,0 +1,142 @@
+// mdb_common.h — internal definitions shared by the HIP translation units of libmuopdb_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/muopdb_hip.h"
+
+#define MDB_WAVE 64
+#define MDB_TILE 64          // vectors per tile of the list-contiguous SoA layout (one per lane)
+#define MDB_BLOCK 256        // threads per scan block (4 tiles per round)
+#define MDB_KEY_MAX 0xFFFFFFFFFFFFFFFFull
+#define MDB_MAX_K 2048       // largest top-k / ef served by the on-chip selectors
+
+struct mdb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    mdb_status deferred = MDB_OK;
+    mdb_stats stats{};
+    uint32_t* d_flags = nullptr;   // device word: bit0 NaN seen, bit1 capacity overflow
+    uint32_t* h_flags = nullptr;   // pinned host mirror
+    // growable device scratch (never shrinks; no allocation in steady state)
+    void* scratch[8] = {nullptr};
+    size_t scratch_cap[8] = {0};
+    std::mutex mu;
+};
+
+#define MDB_FLAG_NAN 1u
+#define MDB_FLAG_OVERFLOW 2u
+#define MDB_FLAG_RANGE 4u
+
+mdb_status mdb_fail(mdb_ctx* ctx, mdb_status st, const char* fmt, ...);
+
+#define MDB_HIP(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return mdb_fail((ctx), MDB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                            __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define MDB_TRY(expr)                    \
+    do {                                 \
+        mdb_status _s = (expr);          \
+        if (_s != MDB_OK) return _s;     \
+    } while (0)
+
+// grow-only scratch slot
+mdb_status mdb_scratch(mdb_ctx* ctx, int slot, size_t bytes, void** out);
+// check the device flag word after a synchronising call
+mdb_status mdb_check_flags(mdb_ctx* ctx);
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// exact-association distance plan (host computed, passed by value to kernels)
+//   L2  : rs/utils/src/distance/l2.rs:32-67   passes where len/16>0, len/8>0, len/4>0, tail
+//   dot : rs/utils/src/distance/dot_product.rs:38-71  passes where len>16, len>8, len>4, tail
+// all pass offsets are multiples of 4, so every chunk is a whole number of float4s.
+// ------------------------------------------------------------------------------------------
+struct DistPlan {
+    int d;            // true dimension
+    int d4;           // float4s per vector (ceil(d/4))
+    int n16, n8, n4;  // chunks per pass
+    int off8, off4, offt;  // element offsets of the 8-pass, 4-pass and scalar tail
+    int ntail;
+};
+
+inline DistPlan make_plan(int d, int metric) {
+    DistPlan p{};
+    p.d = d;
+    p.d4 = (d + 3) / 4;
+    int rem = d, off = 0;
+    if (metric == MDB_METRIC_L2) {
+        p.n16 = rem / 16; off += p.n16 * 16; rem -= p.n16 * 16;
+        p.off8 = off; p.n8 = rem / 8; off += p.n8 * 8; rem -= p.n8 * 8;
+        p.off4 = off; p.n4 = rem / 4; off += p.n4 * 4; rem -= p.n4 * 4;
+    } else {
+        p.n16 = rem > 16 ? rem / 16 : 0; off += p.n16 * 16; rem -= p.n16 * 16;
+        p.off8 = off; p.n8 = rem > 8 ? rem / 8 : 0; off += p.n8 * 8; rem -= p.n8 * 8;
+        p.off4 = off; p.n4 = rem > 4 ? rem / 4 : 0; off += p.n4 * 4; rem -= p.n4 * 4;
+    }
+    p.offt = off;
+    p.ntail = rem;
+    return p;
+}
+
+// device-resident list-contiguous SoA store of f32 vectors:
+//   float4 index of (vector v, float4 c4) = ((v / 64) * d4 + c4) * 64 + (v % 64)
+struct TileStore {
+    DevBuf<float> data;
+    size_t n = 0;       // valid vectors
+    size_t ntiles = 0;
+    int d = 0, d4 = 0;
+};
+
+// non-owning view of a tile store (kernels and cross-module calls take this)
+struct TileView {
+    const float* data = nullptr;
+    size_t n = 0, ntiles = 0;
+    int d = 0, d4 = 0;
+};
+inline TileView view_of(const TileStore& t) { return TileView{t.data.p, t.n, t.ntiles, t.d, t.d4}; }
+
+// product-quantizer state on the device
+struct PqDev {
+    int metric = 0, dimension = 0, subdim = 0, num_bits = 0, m = 0, K = 0;
+    DevBuf<float> codebook;            // [m][K][subdim]
+    std::vector<float> h_codebook;
+};
+
+// host-side byte readers (little-endian files)
+static inline uint32_t rd_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static inline uint64_t rd_u64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) & ~(a - 1); }

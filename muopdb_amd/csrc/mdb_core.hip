@@ -1,0 +1,293 @@
+// mdb_core.hip — context, scratch, error plumbing and the unit-test seams of the C ABI
+// (distance pairs, PQ quantize / distance, Elias-Fano decode).
+#include <cstdarg>
+
+#include "mdb_device.cuh"
+#include "mdb_kernels.h"
+
+mdb_status mdb_fail(mdb_ctx* ctx, mdb_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = buf;
+    return st;
+}
+
+mdb_status mdb_scratch(mdb_ctx* ctx, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->scratch_cap[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            MDB_HIP(ctx, hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_cap[slot] = 0;
+        }
+        size_t cap = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&ctx->scratch[slot], cap);
+        if (e != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        ctx->scratch_cap[slot] = cap;
+    }
+    *out = ctx->scratch[slot];
+    return MDB_OK;
+}
+
+mdb_status mdb_check_flags(mdb_ctx* ctx) {
+    MDB_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4, ctx->stream));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t f = *ctx->h_flags;
+    if (f & MDB_FLAG_NAN) return mdb_fail(ctx, MDB_ERR_NAN, "a distance evaluated to NaN (reference: NotNan::new(..).unwrap() panics)");
+    if (f & MDB_FLAG_OVERFLOW) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "traversal state exceeded the on-chip capacity");
+    if (f & MDB_FLAG_RANGE) return mdb_fail(ctx, MDB_ERR_FORMAT, "index refers to a point id outside the vector storage");
+    return MDB_OK;
+}
+
+extern "C" {
+
+const char* mdb_version(void) { return "muopdb-hip 0.1 (gfx950)"; }
+
+mdb_status mdb_device_open(int gpu, mdb_ctx** out) {
+    if (!out) return MDB_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || gpu < 0 || gpu >= count) return MDB_ERR_HIP;
+    mdb_ctx* ctx = new mdb_ctx();
+    ctx->device = gpu;
+    if (hipSetDevice(gpu) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_flags, 4) != hipSuccess || hipHostMalloc((void**)&ctx->h_flags, 4) != hipSuccess ||
+        hipMemset(ctx->d_flags, 0, 4) != hipSuccess) {
+        delete ctx;
+        return MDB_ERR_HIP;
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return MDB_OK;
+}
+
+void mdb_device_close(mdb_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 8; ++i)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+mdb_status mdb_set_stream(mdb_ctx* ctx, void* hip_stream) {
+    if (!ctx) return MDB_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        MDB_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return MDB_OK;
+}
+
+mdb_status mdb_sync(mdb_ctx* ctx) {
+    if (!ctx) return MDB_ERR_INVALID_ARG;
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    mdb_status st = mdb_check_flags(ctx);
+    if (st == MDB_OK && ctx->deferred != MDB_OK) st = ctx->deferred;
+    ctx->deferred = MDB_OK;
+    return st;
+}
+
+const char* mdb_last_error(mdb_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "no context"; }
+
+mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out) {
+    if (!ctx || !out) return MDB_ERR_INVALID_ARG;
+    *out = ctx->stats;
+    return MDB_OK;
+}
+
+}  // extern "C"
+
+// ============================================================================================
+// D1/D2 pair seams
+// ============================================================================================
+template <int METRIC>
+__global__ __launch_bounds__(256) void pair_distance_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            size_t n, DistPlan p, int mode, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // the "query" side is per-thread here (not uniform), so use a row loader for both operands:
+    // stage a's row through exact_sums' q pointer (plain global loads, still exact)
+    RowLoader lb{b + i * p.d, p.d};
+    float raw[1];
+    exact_sums<METRIC, 1>(lb, a + i * p.d, 0, p, raw);
+    float r = raw[0];
+    if (METRIC == MDB_METRIC_L2) out[i] = mode ? r : __fsqrt_rn(r);
+    else out[i] = -r;
+}
+
+static mdb_status pair_distance(mdb_ctx* ctx, int metric, const float* a, const float* b, size_t n, size_t d, int squared,
+                                float* out) {
+    if (!ctx || !a || !b || !out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return MDB_OK;
+    // q pointer reads up to 4 floats past a row's tail chunk only when ntail>0 and j<ntail is false -> never
+    // dereferenced beyond d; b uses the bounds-checked RowLoader.  Pad `a` by 4 floats to be safe.
+    void *da, *db, *dout;
+    MDB_TRY(mdb_scratch(ctx, 0, (n * d + 4) * 4, &da));
+    MDB_TRY(mdb_scratch(ctx, 1, (n * d + 4) * 4, &db));
+    MDB_TRY(mdb_scratch(ctx, 2, n * 4, &dout));
+    MDB_HIP(ctx, hipMemcpyAsync(da, a, n * d * 4, hipMemcpyHostToDevice, ctx->stream));
+    MDB_HIP(ctx, hipMemcpyAsync(db, b, n * d * 4, hipMemcpyHostToDevice, ctx->stream));
+    DistPlan p = make_plan((int)d, metric);
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (metric == MDB_METRIC_L2)
+        pair_distance_kernel<MDB_METRIC_L2><<<grid, 256, 0, ctx->stream>>>((float*)da, (float*)db, n, p, squared, (float*)dout);
+    else
+        pair_distance_kernel<MDB_METRIC_DOT><<<grid, 256, 0, ctx->stream>>>((float*)da, (float*)db, n, p, 0, (float*)dout);
+    MDB_HIP(ctx, hipGetLastError());
+    MDB_HIP(ctx, hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MDB_OK;
+}
+
+extern "C" mdb_status mdb_l2_distance(mdb_ctx* ctx, const float* a, const float* b, size_t n, size_t d, int squared,
+                                      float* out) {
+    return pair_distance(ctx, MDB_METRIC_L2, a, b, n, d, squared, out);
+}
+extern "C" mdb_status mdb_dot_distance(mdb_ctx* ctx, const float* a, const float* b, size_t n, size_t d, float* out) {
+    return pair_distance(ctx, MDB_METRIC_DOT, a, b, n, d, 0, out);
+}
+
+// ============================================================================================
+// Q3 seams: PQ quantize / distance
+// ============================================================================================
+mdb_status pq_upload(mdb_ctx* ctx, const mdb_quant_desc* q, PqDev& pq) {
+    if (!q || q->kind != MDB_QUANT_PQ) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "not a product quantizer");
+    if (q->subvector_dimension == 0 || q->dimension % q->subvector_dimension != 0)
+        return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "Vector dimension needs to be divisible by the subvector dimension.");
+    if (q->num_bits == 0 || q->num_bits > 8)
+        return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "PQ codes are u8: num_bits must be 1..8");
+    pq.metric = q->metric; pq.dimension = q->dimension; pq.subdim = q->subvector_dimension; pq.num_bits = q->num_bits;
+    pq.m = pq.dimension / pq.subdim; pq.K = 1 << pq.num_bits;
+    size_t need = (size_t)pq.m * pq.K * pq.subdim;
+    if (!q->codebook || q->codebook_len < need) return mdb_fail(ctx, MDB_ERR_FORMAT, "codebook too short");
+    pq.h_codebook.assign(q->codebook, q->codebook + need);
+    if (pq.codebook.alloc(need + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "codebook alloc");
+    MDB_HIP(ctx, hipMemcpyAsync(pq.codebook.p, pq.h_codebook.data(), need * 4, hipMemcpyHostToDevice, ctx->stream));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MDB_OK;
+}
+
+// ProductQuantizer::quantize pq/mod.rs:152-177: one thread per (vector, subspace); argmin over K
+// centroids of the EXACT squared-L2 cascade, first minimum wins (strict <), start f32::MAX.
+__global__ __launch_bounds__(256) void pq_quantize_kernel(const float* __restrict__ vecs, size_t n, int row_stride, int subdim,
+                                                          int m, int K, const float* __restrict__ cb, DistPlan sp,
+                                                          uint8_t* __restrict__ codes) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * (size_t)m) return;
+    size_t v = t / m;
+    int s = (int)(t % m);
+    const float* sub = vecs + v * (size_t)row_stride + (size_t)s * subdim;
+    const float* cbs = cb + (size_t)s * K * subdim;
+    float best = 3.402823466e+38f;
+    int bi = 0;
+    for (int c = 0; c < K; ++c) {
+        RowLoader lc{cbs + (size_t)c * subdim, subdim};
+        float raw[1];
+        exact_sums<MDB_METRIC_L2, 1>(lc, sub, 0, sp, raw);
+        if (raw[0] < best) { best = raw[0]; bi = c; }
+    }
+    codes[t] = (uint8_t)bi;
+}
+
+mdb_status pq_quantize_device(mdb_ctx* ctx, const PqDev& pq, const float* d_vecs, size_t n, uint8_t* d_codes, int row_stride) {
+    if (n == 0) return MDB_OK;
+    DistPlan sp = make_plan(pq.subdim, MDB_METRIC_L2);  // quantize always uses squared L2 (pq/mod.rs:167)
+    size_t total = n * (size_t)pq.m;
+    pq_quantize_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(d_vecs, n, row_stride ? row_stride : pq.dimension, pq.subdim, pq.m,
+                                                                                   pq.K, pq.codebook.p, sp, d_codes);
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+// ProductQuantizer::distance pq/mod.rs:202-278, all three impls, one thread per pair
+__global__ __launch_bounds__(256) void pq_pair_distance_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                               size_t n, int metric, int subdim, int m, int K,
+                                                               const float* __restrict__ cb, DistPlan sp, DistPlan spl2,
+                                                               int impl, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* ca = a + i * m;
+    const uint8_t* cbp = b + i * m;
+    if (impl == MDB_IMPL_STREAMING_SIMD) {
+        out[i] = pq_streaming_distance(ca, cbp, metric, subdim, m, K, cb, spl2);
+        return;
+    }
+    float sum = 0.0f;
+    for (int s = 0; s < m; ++s) {
+        const float* av = cb + ((size_t)s * K + ca[s]) * subdim;
+        const float* bv = cb + ((size_t)s * K + cbp[s]) * subdim;
+        float dist;
+        if (impl == MDB_IMPL_SCALAR) {  // calculate_scalar: sequential sum, sqrt (l2.rs:21-27)
+            float t = 0.0f;
+            for (int e = 0; e < subdim; ++e) {
+                float df = __fsub_rn(av[e], bv[e]);
+                t = __fadd_rn(t, __fmul_rn(df, df));
+            }
+            dist = __fsqrt_rn(t);
+        } else {  // SIMD: D::calculate
+            RowLoader lb{bv, subdim};
+            float raw[1];
+            if (metric == MDB_METRIC_L2) { exact_sums<MDB_METRIC_L2, 1>(lb, av, 0, spl2, raw); dist = __fsqrt_rn(raw[0]); }
+            else { exact_sums<MDB_METRIC_DOT, 1>(lb, av, 0, sp, raw); dist = -raw[0]; }
+        }
+        sum = __fadd_rn(sum, __fmul_rn(dist, dist));
+    }
+    out[i] = sum;
+}
+
+extern "C" mdb_status mdb_pq_quantize(mdb_ctx* ctx, const mdb_quant_desc* q, const float* vectors, size_t n,
+                                      uint8_t* codes_out) {
+    if (!ctx || !q || !vectors || !codes_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    PqDev pq;
+    MDB_TRY(pq_upload(ctx, q, pq));
+    if (n == 0) return MDB_OK;
+    void *dv, *dc;
+    MDB_TRY(mdb_scratch(ctx, 0, (n * pq.dimension + 4) * 4, &dv));
+    MDB_TRY(mdb_scratch(ctx, 1, n * pq.m, &dc));
+    MDB_HIP(ctx, hipMemcpyAsync(dv, vectors, n * pq.dimension * 4, hipMemcpyHostToDevice, ctx->stream));
+    MDB_TRY(pq_quantize_device(ctx, pq, (float*)dv, n, (uint8_t*)dc));
+    MDB_HIP(ctx, hipMemcpyAsync(codes_out, dc, n * pq.m, hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MDB_OK;
+}
+
+extern "C" mdb_status mdb_pq_distance(mdb_ctx* ctx, const mdb_quant_desc* q, const uint8_t* a, const uint8_t* b, size_t n,
+                                      mdb_distance_impl impl, float* out) {
+    if (!ctx || !q || !a || !b || !out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    PqDev pq;
+    MDB_TRY(pq_upload(ctx, q, pq));
+    if (n == 0) return MDB_OK;
+    void *da, *db, *dout;
+    MDB_TRY(mdb_scratch(ctx, 0, n * pq.m, &da));
+    MDB_TRY(mdb_scratch(ctx, 1, n * pq.m, &db));
+    MDB_TRY(mdb_scratch(ctx, 2, n * 4, &dout));
+    MDB_HIP(ctx, hipMemcpyAsync(da, a, n * pq.m, hipMemcpyHostToDevice, ctx->stream));
+    MDB_HIP(ctx, hipMemcpyAsync(db, b, n * pq.m, hipMemcpyHostToDevice, ctx->stream));
+    DistPlan sp = make_plan(pq.subdim, pq.metric), spl2 = make_plan(pq.subdim, MDB_METRIC_L2);
+    pq_pair_distance_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(
+        (uint8_t*)da, (uint8_t*)db, n, pq.metric, pq.subdim, pq.m, pq.K, pq.codebook.p, sp, spl2, (int)impl, (float*)dout);
+    MDB_HIP(ctx, hipGetLastError());
+    MDB_HIP(ctx, hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MDB_OK;
+}

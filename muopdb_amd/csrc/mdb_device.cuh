@@ -1,0 +1,273 @@
+// mdb_device.cuh — device-side building blocks (gfx950, wave64):
+//   * exact-association distances: the reference's 16/8/4/scalar lane cascade
+//     (rs/utils/src/distance/l2.rs:32-89, dot_product.rs:38-89) with per-lane partial sums,
+//     separately rounded mul/add (__fmul_rn/__fadd_rn: never contracted to FMA) and an
+//     ordered horizontal sum — so GPU distances are bit-identical to the CPU path and the
+//     neighbour ids cannot flip on near-ties;
+//   * order-preserving (distance, id) -> u64 keys (PointAndDistance order, rs/index/src/utils.rs:71-75);
+//   * BlockSelect: streaming block-wide k-smallest selection (threshold filter + LDS queue +
+//     bitonic flush) used by every scan kernel and by the merge kernels.
+#pragma once
+#include "mdb_common.h"
+
+// ------------------------------------------------------------------------------------------ keys
+__device__ __forceinline__ uint32_t f32_orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_orderable(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+// ascending u64 order == (distance, id) ascending
+__device__ __forceinline__ uint64_t make_key(float dist, uint32_t id) {
+    return ((uint64_t)f32_orderable(dist) << 32) | id;
+}
+__device__ __forceinline__ float key_dist(uint64_t k) { return f32_from_orderable((uint32_t)(k >> 32)); }
+__device__ __forceinline__ uint32_t key_id(uint64_t k) { return (uint32_t)k; }
+
+// ------------------------------------------------------------------------------------------ exact distances
+template <int METRIC>
+__device__ __forceinline__ float acc_term(float acc, float a, float b) {
+    if (METRIC == MDB_METRIC_L2) {
+        float diff = __fsub_rn(a, b);
+        return __fadd_rn(acc, __fmul_rn(diff, diff));
+    } else {
+        return __fadd_rn(acc, __fmul_rn(a, b));
+    }
+}
+
+template <int L>
+__device__ __forceinline__ float reduce_ordered(const float (&acc)[L]) {
+    float s = 0.0f;  // simd_reduce_add_ordered(v, 0.0)
+#pragma unroll
+    for (int j = 0; j < L; ++j) s = __fadd_rn(s, acc[j]);
+    return s;
+}
+
+// Loader concept: float4 get4(int c4) returns elements 4*c4 .. 4*c4+3 of the stored vector.
+struct TileLoader {  // list-contiguous SoA tile, this lane's vector
+    const float4* p;  // &tile4[(tile * d4) * 64 + lane]
+    __device__ __forceinline__ float4 get4(int c4) const { return p[(size_t)c4 * MDB_TILE]; }
+};
+struct RowLoader {  // plain row-major row, arbitrary alignment
+    const float* p;
+    int d;
+    __device__ __forceinline__ float4 get4(int c4) const {
+        float4 r;
+        int e = c4 * 4;
+        r.x = e + 0 < d ? p[e + 0] : 0.f;
+        r.y = e + 1 < d ? p[e + 1] : 0.f;
+        r.z = e + 2 < d ? p[e + 2] : 0.f;
+        r.w = e + 3 < d ? p[e + 3] : 0.f;
+        return r;
+    }
+};
+
+// QT queries against ONE stored vector (this thread's).  q[i] = qbase + i*qstride must be
+// wave-uniform (scalar loads).  Returns the raw cascade sum (squared L2 / positive dot).
+template <int METRIC, int QT, class Loader>
+__device__ __forceinline__ void exact_sums(const Loader& ld, const float* __restrict__ qbase, int qstride,
+                                           const DistPlan& p, float (&out)[QT]) {
+    float ret[QT];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) ret[i] = 0.0f;
+    if (p.n16 > 0) {
+        float acc[QT][16];
+#pragma unroll
+        for (int i = 0; i < QT; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
+        for (int c = 0; c < p.n16; ++c) {
+            float4 x0 = ld.get4(4 * c + 0), x1 = ld.get4(4 * c + 1), x2 = ld.get4(4 * c + 2), x3 = ld.get4(4 * c + 3);
+            float xv[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
+                            x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+#pragma unroll
+            for (int i = 0; i < QT; ++i) {
+                const float* q = qbase + (size_t)i * qstride + 16 * c;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[i][j] = acc_term<METRIC>(acc[i][j], q[j], xv[j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < QT; ++i) ret[i] = __fadd_rn(ret[i], reduce_ordered<16>(acc[i]));
+    }
+    if (p.n8 > 0) {
+        float acc[QT][8];
+#pragma unroll
+        for (int i = 0; i < QT; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = 0.0f;
+        for (int c = 0; c < p.n8; ++c) {
+            int e = p.off8 + 8 * c;
+            float4 x0 = ld.get4(e / 4), x1 = ld.get4(e / 4 + 1);
+            float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int i = 0; i < QT; ++i) {
+                const float* q = qbase + (size_t)i * qstride + e;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = acc_term<METRIC>(acc[i][j], q[j], xv[j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < QT; ++i) ret[i] = __fadd_rn(ret[i], reduce_ordered<8>(acc[i]));
+    }
+    if (p.n4 > 0) {
+        float acc[QT][4];
+#pragma unroll
+        for (int i = 0; i < QT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+        for (int c = 0; c < p.n4; ++c) {
+            int e = p.off4 + 4 * c;
+            float4 x0 = ld.get4(e / 4);
+            float xv[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+            for (int i = 0; i < QT; ++i) {
+                const float* q = qbase + (size_t)i * qstride + e;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = acc_term<METRIC>(acc[i][j], q[j], xv[j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < QT; ++i) ret[i] = __fadd_rn(ret[i], reduce_ordered<4>(acc[i]));
+    }
+    if (p.ntail > 0) {
+        float4 x0 = ld.get4(p.offt / 4);
+        float xv[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            const float* q = qbase + (size_t)i * qstride + p.offt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < p.ntail) ret[i] = acc_term<METRIC>(ret[i], q[j], xv[j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QT; ++i) out[i] = ret[i];
+}
+
+// DistanceCalculator::calculate: sqrt for L2 (l2.rs:72-74), negation for dot (dot_product.rs:25-27)
+template <int METRIC>
+__device__ __forceinline__ float finish_distance(float raw) {
+    return METRIC == MDB_METRIC_L2 ? __fsqrt_rn(raw) : -raw;
+}
+
+// ------------------------------------------------------------------------------------------ BlockSelect
+// Streaming selection of the k smallest u64 keys seen by a block.  Usage per block:
+//   sel.init(...); loop { sel.offer(key) by every thread (MDB_KEY_MAX = nothing); sel.round_end(); }
+//   sel.finish();  -> buf[0 .. count()) ascending
+// LDS: cap u64 keys + 2 words.  Requires cap = pow2 >= k + BLOCK.
+template <int BLOCK>
+struct BlockSelect {
+    uint64_t* buf;
+    uint32_t* cnt;       // number of valid keys in buf
+    uint64_t* thr;       // admission threshold: key must be < thr
+    int k, cap;
+
+    static __host__ __device__ int cap_for(int k) {
+        int c = 2;
+        while (c < k + BLOCK) c <<= 1;
+        return c;
+    }
+    static __host__ __device__ size_t lds_bytes(int k) { return (size_t)cap_for(k) * 8 + 16; }
+
+    __device__ void init(void* lds, int k_) {
+        k = k_;
+        cap = cap_for(k_);
+        buf = (uint64_t*)lds;
+        thr = (uint64_t*)((char*)lds + (size_t)cap * 8);
+        cnt = (uint32_t*)((char*)lds + (size_t)cap * 8 + 8);
+        if (threadIdx.x == 0) { *cnt = 0; *thr = k_ > 0 ? MDB_KEY_MAX : 0ull; }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void offer(uint64_t key) {
+        if (key < *thr) {
+            uint32_t pos = atomicAdd(cnt, 1u);
+            buf[pos] = key;
+        }
+    }
+    __device__ void sort_and_trim() {
+        // bitonic sort of the first n = pow2 >= *cnt entries (padded with KEY_MAX)
+        uint32_t c = *cnt;
+        int n = 2;
+        while (n < (int)c) n <<= 1;
+        for (int i = c + threadIdx.x; i < n; i += BLOCK) buf[i] = MDB_KEY_MAX;
+        __syncthreads();
+        for (int size = 2; size <= n; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = threadIdx.x; t < (n >> 1); t += BLOCK) {
+                    int lo = ((t / stride) * stride * 2) + (t % stride);
+                    int hi = lo + stride;
+                    bool up = ((lo & size) == 0);
+                    uint64_t a = buf[lo], b = buf[hi];
+                    if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        if (threadIdx.x == 0) {
+            uint32_t nc = c < (uint32_t)k ? c : (uint32_t)k;
+            *cnt = nc;
+            *thr = (nc == (uint32_t)k && k > 0) ? buf[k - 1] : MDB_KEY_MAX;
+            if (k == 0) *thr = 0ull;  // nothing is ever admitted
+        }
+        __syncthreads();
+    }
+    // call after every offer() round (uniform control flow)
+    __device__ __forceinline__ void round_end() {
+        __syncthreads();
+        uint32_t c = *cnt;
+        __syncthreads();  // nobody may start the next round's atomicAdd before everyone has read cnt
+        if (c > (uint32_t)(cap - BLOCK)) sort_and_trim();
+    }
+    __device__ void finish() {
+        __syncthreads();
+        sort_and_trim();
+    }
+    __device__ __forceinline__ uint32_t count() const { return *cnt; }
+};
+
+// ------------------------------------------------------------------------------------------ PQ (symmetric) distance
+// ProductQuantizer::distance, StreamingSIMD arm — rs/quantization/src/pq/mod.rs:231-266.
+// The accumulators sum_16/sum_8/sum_4 are SHARED across subspaces (per-lane sums over s), the
+// pass thresholds are the L2-style `len/16 > 0` ones for every metric, sum_1 is OVERWRITTEN by
+// the last subspace's sub-4 tail (:259-261), and the four partial results are added left to
+// right before D::outermost_op.  `sp` = make_plan(subdim, MDB_METRIC_L2).
+template <int METRIC>
+__device__ __forceinline__ float pq_streaming_distance_t(const uint8_t* a, const uint8_t* b, int subdim, int m, int K,
+                                                         const float* __restrict__ cb, const DistPlan& sp) {
+    float s16[16], s8[8], s4[4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s16[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s8[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s4[j] = 0.0f;
+    float s1 = 0.0f;
+    for (int s = 0; s < m; ++s) {
+        const float* av = cb + ((size_t)s * K + a[s]) * subdim;
+        const float* bv = cb + ((size_t)s * K + b[s]) * subdim;
+        for (int c = 0; c < sp.n16; ++c)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s16[j] = acc_term<METRIC>(s16[j], av[16 * c + j], bv[16 * c + j]);
+        for (int c = 0; c < sp.n8; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s8[j] = acc_term<METRIC>(s8[j], av[sp.off8 + 8 * c + j], bv[sp.off8 + 8 * c + j]);
+        for (int c = 0; c < sp.n4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s4[j] = acc_term<METRIC>(s4[j], av[sp.off4 + 4 * c + j], bv[sp.off4 + 4 * c + j]);
+        if (sp.ntail > 0) {
+            float t = 0.0f;
+            for (int i = 0; i < sp.ntail; ++i) t = acc_term<METRIC>(t, av[sp.offt + i], bv[sp.offt + i]);
+            s1 = t;
+        }
+    }
+    float r = __fadd_rn(__fadd_rn(__fadd_rn(reduce_ordered<16>(s16), reduce_ordered<8>(s8)), reduce_ordered<4>(s4)), s1);
+    return METRIC == MDB_METRIC_L2 ? r : -r;
+}
+
+__device__ __forceinline__ float pq_streaming_distance(const uint8_t* a, const uint8_t* b, int metric, int subdim, int m,
+                                                       int K, const float* __restrict__ cb, const DistPlan& sp) {
+    return metric == MDB_METRIC_L2 ? pq_streaming_distance_t<MDB_METRIC_L2>(a, b, subdim, m, K, cb, sp)
+                                   : pq_streaming_distance_t<MDB_METRIC_DOT>(a, b, subdim, m, K, cb, sp);
+}

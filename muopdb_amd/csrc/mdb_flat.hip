@@ -1,0 +1,308 @@
+// mdb_flat.hip — batched brute-force distance scan with fused per-query top-k
+// (L2DistanceCalculator::calculate / DotProductDistanceCalculator
+// ::calculate over every row, `find_nearest_centroids` ordering — rs/index/src/ivf/block_based/
+// index.rs:147-163 — generalised to top-k by (distance, row)).
+//
+// HBM layout: list-contiguous SoA tiles of 64 vectors; float4 #c4 of the 64 vectors of a tile
+// is one contiguous 1 KiB line, so lane v of a wave streams ITS vector with fully coalesced
+// 16 B loads while keeping the reference's 16 partial sums in registers (one thread = one
+// vector = bit-exact lane association, no cross-lane reduction).  Queries are wave-uniform
+// (scalar loads).  Bound: HBM (N*d*4 bytes per pass); VALU = 3 ops per element per query.
+#include "mdb_device.cuh"
+#include "mdb_kernels.h"
+
+// ------------------------------------------------------------------------------------------ relayout
+__global__ __launch_bounds__(256) void rows_to_tiles_kernel(const float* __restrict__ rows, size_t n, int d, int d4,
+                                                            float4* __restrict__ tiles, size_t total4) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per stored float4
+    if (t >= total4) return;
+    size_t lane = t % MDB_TILE;
+    size_t c4 = (t / MDB_TILE) % d4;
+    size_t tile = t / ((size_t)MDB_TILE * d4);
+    size_t v = tile * MDB_TILE + lane;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v < n) {
+        const float* p = rows + v * d;
+        int e = (int)c4 * 4;
+        r.x = e + 0 < d ? p[e + 0] : 0.f;
+        r.y = e + 1 < d ? p[e + 1] : 0.f;
+        r.z = e + 2 < d ? p[e + 2] : 0.f;
+        r.w = e + 3 < d ? p[e + 3] : 0.f;
+    }
+    tiles[t] = r;
+}
+
+mdb_status tiles_from_rows(mdb_ctx* ctx, const float* d_rows, size_t n, int d, TileStore& out) {
+    out.n = n;
+    out.d = d;
+    out.d4 = (d + 3) / 4;
+    out.ntiles = (n + MDB_TILE - 1) / MDB_TILE;
+    size_t total4 = out.ntiles * MDB_TILE * (size_t)out.d4;
+    if (out.data.alloc(total4 * 4 + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "tile store alloc (%zu floats)", total4 * 4);
+    if (total4 == 0) return MDB_OK;
+    rows_to_tiles_kernel<<<dim3((unsigned)((total4 + 255) / 256)), 256, 0, ctx->stream>>>(d_rows, n, d, out.d4,
+                                                                                     (float4*)out.data.p, total4);
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+// ------------------------------------------------------------------------------------------ query staging
+__global__ void pad_queries_kernel(const float* __restrict__ q, size_t b, int d, int qstride, size_t bpad,
+                                   float* __restrict__ out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= bpad * qstride) return;
+    size_t row = t / qstride;
+    int e = (int)(t % qstride);
+    out[t] = (row < b && e < d) ? q[row * d + e] : 0.0f;
+}
+
+mdb_status stage_queries(mdb_ctx* ctx, int slot, const float* queries, size_t b, int d, mdb_mem mem, size_t bpad,
+                         float** d_out, int* qstride) {
+    int qs = ((d + 3) / 4) * 4 + 16;  // +16: exact_sums may form (never dereference) pointers past the row
+    void* dq;
+    MDB_TRY(mdb_scratch(ctx, slot, bpad * (size_t)qs * 4 + 64, &dq));
+    const float* src = queries;
+    if (mem == MDB_MEM_HOST) {
+        void* raw;
+        MDB_TRY(mdb_scratch(ctx, slot + 1, b * (size_t)d * 4 + 16, &raw));
+        MDB_HIP(ctx, hipMemcpyAsync(raw, queries, b * (size_t)d * 4, hipMemcpyHostToDevice, ctx->stream));
+        src = (const float*)raw;
+    }
+    size_t total = bpad * (size_t)qs;
+    pad_queries_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(src, b, d, qs, bpad, (float*)dq);
+    MDB_HIP(ctx, hipGetLastError());
+    *d_out = (float*)dq;
+    *qstride = qs;
+    return MDB_OK;
+}
+
+// ------------------------------------------------------------------------------------------ scan
+// grid (nblk, ceil(B/QT)); block = 4 waves = 4 tiles per round; QT queries share every load.
+template <int METRIC, int QT>
+__global__ __launch_bounds__(MDB_BLOCK) void flat_scan_kernel(const float4* __restrict__ tiles, size_t n, size_t ntiles,
+                                                              DistPlan p, const float* __restrict__ q, int qstride, int k,
+                                                              uint64_t* __restrict__ partial, uint32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    BlockSelect<MDB_BLOCK> sel[QT];
+    const size_t sel_bytes = BlockSelect<MDB_BLOCK>::lds_bytes(k);
+#pragma unroll
+    for (int i = 0; i < QT; ++i) sel[i].init(lds + i * sel_bytes, k);
+    const int wave = threadIdx.x / MDB_WAVE, lane = threadIdx.x % MDB_WAVE;
+    const size_t q0 = (size_t)blockIdx.y * QT;
+    const float* qb = q + q0 * qstride;
+    const size_t ngroups = (ntiles + 3) / 4;
+    bool nan_seen = false;
+    for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        size_t tile = g * 4 + wave;
+        size_t v = tile * MDB_TILE + lane;
+        bool valid = tile < ntiles && v < n;
+        float raw[QT];
+        if (valid) {
+            TileLoader ld{tiles + tile * (size_t)p.d4 * MDB_TILE + lane};
+            exact_sums<METRIC, QT>(ld, qb, qstride, p, raw);
+        }
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            uint64_t key = MDB_KEY_MAX;
+            if (valid) {
+                float dist = finish_distance<METRIC>(raw[i]);
+                if (dist != dist) nan_seen = true;
+                key = make_key(dist, (uint32_t)v);
+            }
+            sel[i].offer(key);
+        }
+#pragma unroll
+        for (int i = 0; i < QT; ++i) sel[i].round_end();
+    }
+    if (nan_seen) atomicOr(flags, MDB_FLAG_NAN);
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        sel[i].finish();
+        uint64_t* dst = partial + ((q0 + i) * gridDim.x + blockIdx.x) * (size_t)k;
+        uint32_t c = sel[i].count();
+        for (int j = threadIdx.x; j < k; j += MDB_BLOCK) dst[j] = j < (int)c ? sel[i].buf[j] : MDB_KEY_MAX;
+    }
+}
+
+// one block per query: stream `per_query` candidate keys, keep the k smallest, ascending
+__global__ __launch_bounds__(MDB_BLOCK) void merge_keys_kernel(const uint64_t* __restrict__ partial, size_t per_query,
+                                                               int k, uint64_t* __restrict__ out, uint32_t* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    BlockSelect<MDB_BLOCK> sel;
+    sel.init(lds, k);
+    const uint64_t* src = partial + (size_t)blockIdx.x * per_query;
+    for (size_t base = 0; base < per_query; base += MDB_BLOCK) {
+        size_t i = base + threadIdx.x;
+        sel.offer(i < per_query ? src[i] : MDB_KEY_MAX);
+        sel.round_end();
+    }
+    sel.finish();
+    uint32_t c = sel.count();
+    for (int j = threadIdx.x; j < k; j += MDB_BLOCK) out[(size_t)blockIdx.x * k + j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+    if (threadIdx.x == 0 && counts) counts[blockIdx.x] = c;
+}
+
+__global__ void unpack_keys_kernel(const uint64_t* __restrict__ keys, size_t total, uint32_t* __restrict__ ids,
+                                   float* __restrict__ dist) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint64_t k = keys[t];
+    if (k == MDB_KEY_MAX) {
+        ids[t] = 0xFFFFFFFFu;
+        dist[t] = __uint_as_float(0x7F800000u);
+    } else {
+        ids[t] = key_id(k);
+        dist[t] = key_dist(k);
+    }
+}
+
+mdb_status merge_keys(mdb_ctx* ctx, const uint64_t* d_partial, size_t per_query, size_t b, size_t k, uint64_t* d_out,
+                      uint32_t* d_counts) {
+    if (b == 0) return MDB_OK;
+    merge_keys_kernel<<<dim3((unsigned)b), MDB_BLOCK, BlockSelect<MDB_BLOCK>::lds_bytes((int)k), ctx->stream>>>(
+        d_partial, per_query, (int)k, d_out, d_counts);
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+mdb_status unpack_keys(mdb_ctx* ctx, const uint64_t* d_keys, size_t total, uint32_t* d_ids, float* d_dist) {
+    if (total == 0) return MDB_OK;
+    unpack_keys_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(d_keys, total, d_ids, d_dist);
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+template <int METRIC>
+static mdb_status launch_flat_scan(mdb_ctx* ctx, const TileView& ts, const DistPlan& p, const float* dq, int qstride,
+                                   size_t b, size_t bpad, int qt, int k, unsigned nblk, uint64_t* partial) {
+    dim3 grid(nblk, (unsigned)(bpad / qt));
+    size_t lds = BlockSelect<MDB_BLOCK>::lds_bytes(k) * qt;
+    const float4* tiles = (const float4*)ts.data;
+#define MDB_LAUNCH(QT)                                                                                              \
+    flat_scan_kernel<METRIC, QT><<<grid, MDB_BLOCK, lds, ctx->stream>>>(tiles, ts.n, ts.ntiles, p, dq, qstride, k, \
+                                                                          partial, ctx->d_flags)
+    if (qt == 4) MDB_LAUNCH(4);
+    else if (qt == 2) MDB_LAUNCH(2);
+    else MDB_LAUNCH(1);
+#undef MDB_LAUNCH
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+static int flat_choose_qt(size_t b, int k) {
+    int qt = b >= 4 ? 4 : (b >= 2 ? 2 : 1);
+    while (qt > 1 && BlockSelect<MDB_BLOCK>::lds_bytes(k) * qt > 60 * 1024) qt >>= 1;
+    return qt;
+}
+
+mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const float* dq, int qstride, size_t b, size_t k,
+                          uint64_t* d_keys, uint32_t* d_counts) {
+    if (b == 0) return MDB_OK;
+    if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
+    int qt = flat_choose_qt(b, (int)k);
+    size_t bpad = (b + qt - 1) / qt * qt;
+    size_t ngroups = (ts.ntiles + 3) / 4;
+    unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(ngroups, 1), 1024);
+    // keep the partial buffer bounded (<= 256 MiB)
+    while (nblk > 32 && (size_t)nblk * bpad * std::max<size_t>(k, 1) * 8 > (256u << 20)) nblk /= 2;
+    void* partial;
+    MDB_TRY(mdb_scratch(ctx, 4, (size_t)nblk * bpad * std::max<size_t>(k, 1) * 8, &partial));
+    DistPlan p = make_plan(ts.d, metric);
+    if (metric == MDB_METRIC_L2)
+        MDB_TRY(launch_flat_scan<MDB_METRIC_L2>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial));
+    else
+        MDB_TRY(launch_flat_scan<MDB_METRIC_DOT>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial));
+    merge_keys_kernel<<<dim3((unsigned)b), MDB_BLOCK, BlockSelect<MDB_BLOCK>::lds_bytes((int)k), ctx->stream>>>(
+        (const uint64_t*)partial, (size_t)nblk * k, (int)k, d_keys, d_counts);
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+// ============================================================================================
+// C ABI: flat index
+// ============================================================================================
+struct mdb_flat {
+    mdb_ctx* ctx;
+    TileStore ts;
+    int metric;
+};
+
+extern "C" {
+
+mdb_status mdb_flat_create(mdb_ctx* ctx, const float* base, size_t n, size_t d, mdb_metric metric, mdb_mem base_mem,
+                           mdb_flat** out) {
+    if (!ctx || !out || (!base && n) || d == 0) return MDB_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    mdb_flat* f = new mdb_flat{ctx, {}, (int)metric};
+    const float* d_rows = base;
+    DevBuf<float> staging;
+    if (base_mem == MDB_MEM_HOST && n) {
+        if (staging.alloc(n * d) != hipSuccess) { delete f; return mdb_fail(ctx, MDB_ERR_OOM, "flat staging alloc"); }
+        hipError_t e = hipMemcpyAsync(staging.p, base, n * d * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { delete f; return mdb_fail(ctx, MDB_ERR_HIP, "H2D failed: %s", hipGetErrorString(e)); }
+        d_rows = staging.p;
+    }
+    mdb_status st = tiles_from_rows(ctx, d_rows, n, (int)d, f->ts);
+    if (st == MDB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = mdb_fail(ctx, MDB_ERR_HIP, "sync failed");
+    if (st != MDB_OK) { delete f; return st; }
+    *out = f;
+    return MDB_OK;
+}
+
+void mdb_flat_free(mdb_flat* flat) {
+    if (!flat) return;
+    (void)hipSetDevice(flat->ctx->device);
+    (void)hipStreamSynchronize(flat->ctx->stream);
+    delete flat;
+}
+
+mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_t k, mdb_mem mem, uint32_t* ids_out,
+                           float* dist_out, uint32_t* counts_out) {
+    if (!flat || (!queries && b) || !ids_out || !dist_out) return MDB_ERR_INVALID_ARG;
+    mdb_ctx* ctx = flat->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    if (b == 0) return MDB_OK;
+    if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
+    float* dq;
+    int qstride;
+    MDB_TRY(stage_queries(ctx, 0, queries, b, flat->ts.d, mem, (b + 3) / 4 * 4, &dq, &qstride));
+    void *keys, *cnts;
+    MDB_TRY(mdb_scratch(ctx, 5, b * std::max<size_t>(k, 1) * 8, &keys));
+    MDB_TRY(mdb_scratch(ctx, 6, b * 4, &cnts));
+    MDB_TRY(flat_topk_keys(ctx, view_of(flat->ts), flat->metric, dq, qstride, b, k, (uint64_t*)keys, (uint32_t*)cnts));
+    ctx->stats = mdb_stats{};
+    ctx->stats.scored_vectors = (uint64_t)b * flat->ts.n;
+    ctx->stats.algorithmic_bytes = (uint64_t)flat->ts.n * flat->ts.d * 4 + (uint64_t)b * flat->ts.d * 4 + (uint64_t)b * k * 8;
+    size_t total = b * k;
+    if (mem == MDB_MEM_DEVICE) {
+        if (total) unpack_keys_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((uint64_t*)keys, total, ids_out, dist_out);
+        if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts, b * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        MDB_HIP(ctx, hipGetLastError());
+        return MDB_OK;
+    }
+    void *dids, *ddist;
+    MDB_TRY(mdb_scratch(ctx, 2, total * 4, &dids));
+    MDB_TRY(mdb_scratch(ctx, 3, total * 4, &ddist));
+    if (total) unpack_keys_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((uint64_t*)keys, total, (uint32_t*)dids, (float*)ddist);
+    MDB_HIP(ctx, hipGetLastError());
+    if (total) {
+        MDB_HIP(ctx, hipMemcpyAsync(ids_out, dids, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP(ctx, hipMemcpyAsync(dist_out, ddist, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts, b * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return mdb_check_flags(ctx);
+}
+
+mdb_status mdb_flat_topk(mdb_ctx* ctx, const float* base, size_t n, size_t d, const float* queries, size_t b,
+                         mdb_metric metric, size_t k, uint32_t* ids_out, float* dist_out) {
+    mdb_flat* f = nullptr;
+    MDB_TRY(mdb_flat_create(ctx, base, n, d, metric, MDB_MEM_HOST, &f));
+    mdb_status st = mdb_flat_search(f, queries, b, k, MDB_MEM_HOST, ids_out, dist_out, nullptr);
+    mdb_flat_free(f);
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// mdb_ivf.h — IvfSet: one or many (multi-user) IVF blobs resident in HBM, shared by the
+// single-index, SPANN and multi-user SPANN handles.
+#pragma once
+#include <unordered_map>
+#include <utility>
+
+#include "mdb_common.h"
+
+// per-user (per-blob) descriptor read by the kernels
+struct IvfUserDev {
+    uint32_t valid;           // 0 for an unknown user (search returns None)
+    uint32_t list_base;       // global index of the user's list 0
+    uint32_t num_lists;       // = num_clusters
+    uint32_t num_vectors;
+    uint32_t tomb_base;       // word offset into the tombstone arena
+    uint32_t cent_tile_base;  // first tile of the user's centroids in the centroid tile arena
+    uint64_t doc_ids_off;     // byte offset of doc id 0 inside the uploaded index bytes
+};
+
+// host-side parse of one blob (rs/index/src/ivf/block_based/storage.rs:52-138)
+struct IvfBlobInfo {
+    uint32_t num_features = 0, quantized_dimension = 0, num_clusters = 0;
+    uint64_t num_vectors = 0, num_posting_lists = 0;
+    size_t doc_id_mapping_offset = 0, centroid_offset = 0, pl_metadata_offset = 0, pl_start_offset = 0;
+    uint64_t vec_num_vectors = 0;
+    size_t vec_data_offset = 0;
+};
+
+struct U128Key {
+    uint64_t lo, hi;
+    bool operator==(const U128Key& o) const { return lo == o.lo && hi == o.hi; }
+};
+struct U128Hash {
+    size_t operator()(const U128Key& k) const { return (size_t)(k.lo * 0x9E3779B97F4A7C15ull ^ (k.hi + 0x7F4A7C15ull + (k.lo << 6))); }
+};
+
+struct IvfSet {
+    mdb_ctx* ctx = nullptr;
+    int kind = MDB_QUANT_NONE, metric = MDB_METRIC_L2;
+    uint32_t num_features = 0, quantized_dimension = 0;
+    std::vector<IvfBlobInfo> blobs;
+    std::vector<IvfUserDev> h_users;
+    size_t G = 0, total_tiles = 0, total_slots_valid = 0;
+    DevBuf<uint8_t> d_index;          // the uploaded `index` file (doc ids are read from it)
+    DevBuf<uint32_t> d_list_tile_off; // [G+1]
+    DevBuf<IvfUserDev> d_users;
+    DevBuf<uint32_t> d_tomb;
+    std::vector<uint32_t> h_tomb;
+    DevBuf<uint32_t> d_slot_ids;
+    DevBuf<uint32_t> d_codes;         // PQ: [tiles][mw][64] 4-byte code words
+    DevBuf<float> d_tiles;            // NoQ: [tiles][d4][64] float4
+    DevBuf<float> d_cent_tiles;       // centroids, per user, SoA tiles
+    PqDev pq;
+    int mw = 0;
+    std::vector<std::unordered_map<U128Key, uint32_t, U128Hash>> doc_maps;
+
+    mdb_status load(mdb_ctx* ctx, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
+                    const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant,
+                    uint32_t shard_rank, uint32_t shard_world);
+    mdb_status build_doc_map(size_t ui);
+    mdb_status invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out, bool test_only);
+    mdb_status coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes);
+    mdb_status scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
+                    const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts);
+    mdb_status remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,
+                     mdb_u128* d_doc, float* d_score, uint32_t* d_counts_out);
+    // algorithmic bytes per scored vector
+    size_t bytes_per_scored() const { return (kind == MDB_QUANT_PQ ? (size_t)pq.m : (size_t)num_features * 4) + 4; }
+};

@@ -1,0 +1,741 @@
+// mdb_ivf.hip — IVF / SPANN posting-list scoring.
+//
+// Load (BlockBasedIvf::new_with_offset, rs/index/src/ivf/block_based/index.rs:94-138): the
+// `index` and `vectors` files are uploaded to HBM in one bulk copy each; posting lists are
+// Elias-Fano-decoded on the GPU (mdb_ef.hip) and the vectors are re-laid LIST-CONTIGUOUS:
+// list g owns whole tiles of 64 slots; tile t stores float4 #c4 of its 64 vectors as one
+// 1 KiB line (f32) or the 64 16-byte code words as one 1 KiB line (PQ m%16==0).  A point that
+// sits in several lists is stored once per list (the reference does not dedup across lists
+// either, index.rs:250-286).  Point ids live in a side array (4 B per slot).
+//
+// Search (scan_posting_list :175-237, search_with_centroids :250-286, ..._and_remap :298-332):
+// one block per (query, probe-split); one thread per posting-list slot keeps the reference's
+// lane association in registers (bit-exact distances); tombstones are a bitmap; the block
+// keeps its k best (distance, point id) keys with BlockSelect; a merge kernel combines the
+// splits; a final kernel maps point ids to u128 doc ids and orders by IdWithScore
+// (score, doc id) — rs/index/src/utils.rs:95-114.
+// Bound: HBM — (d*4+4) B per scored vector (NoQ) or (m+4) B (PQ), SURVEY.md §8d.
+#include <unordered_map>
+
+#include "mdb_device.cuh"
+#include "mdb_ivf.h"
+#include "mdb_kernels.h"
+
+// ------------------------------------------------------------------------------------------ load-time kernels
+__global__ void fill_u32_kernel(uint32_t* p, size_t n, uint32_t v) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = v;
+}
+
+// Gather f32 vectors (row-major, 4-byte aligned, arbitrary base) into SoA tiles.
+// tile_src[t] = byte offset in `src` of vector 0 of the store the tile reads from;
+// ids == nullptr => vector index = tile_first[t] + lane, valid if < tile_count[t].
+__global__ __launch_bounds__(256) void gather_f32_tiles_kernel(const uint8_t* __restrict__ src,
+                                                               const uint64_t* __restrict__ tile_src,
+                                                               const uint32_t* __restrict__ tile_limit,
+                                                               const uint32_t* __restrict__ ids,
+                                                               const uint32_t* __restrict__ tile_first, int d, int d4,
+                                                               float4* __restrict__ tiles, size_t total4,
+                                                               uint32_t* __restrict__ flags) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    size_t lane = t % MDB_TILE;
+    size_t c4 = (t / MDB_TILE) % d4;
+    size_t tile = t / ((size_t)MDB_TILE * d4);
+    uint32_t id = ids ? ids[tile * MDB_TILE + lane] : tile_first[tile] + (uint32_t)lane;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool valid = ids ? (id != 0xFFFFFFFFu) : (id < tile_limit[tile]);
+    if (valid && ids && id >= tile_limit[tile]) {
+        atomicOr(flags, MDB_FLAG_RANGE);  // "index out of bounds" (async_storage.rs:113-115)
+        valid = false;
+    }
+    if (valid) {
+        const float* p = (const float*)(src + tile_src[tile] + (size_t)id * d * 4);
+        int e = (int)c4 * 4;
+        r.x = e + 0 < d ? p[e + 0] : 0.f;
+        r.y = e + 1 < d ? p[e + 1] : 0.f;
+        r.z = e + 2 < d ? p[e + 2] : 0.f;
+        r.w = e + 3 < d ? p[e + 3] : 0.f;
+    }
+    tiles[t] = r;
+}
+
+// Gather PQ codes (m bytes per vector) into tiles of 64 slots x mw 4-byte words:
+// word index of (tile, w, lane) = (tile*mw + w)*64 + lane, zero padded.
+__global__ __launch_bounds__(256) void gather_code_tiles_kernel(const uint8_t* __restrict__ src,
+                                                                const uint64_t* __restrict__ tile_src,
+                                                                const uint32_t* __restrict__ tile_limit,
+                                                                const uint32_t* __restrict__ ids, int m, int mw,
+                                                                uint32_t* __restrict__ codes, size_t total,
+                                                                uint32_t* __restrict__ flags) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    size_t lane = t % MDB_TILE;
+    size_t w = (t / MDB_TILE) % mw;
+    size_t tile = t / ((size_t)MDB_TILE * mw);
+    uint32_t id = ids[tile * MDB_TILE + lane];
+    uint32_t v = 0;
+    if (id != 0xFFFFFFFFu) {
+        if (id >= tile_limit[tile]) {
+            atomicOr(flags, MDB_FLAG_RANGE);
+        } else {
+            const uint8_t* p = src + tile_src[tile] + (size_t)id * m;
+            for (int i = 0; i < 4; ++i) {
+                int e = (int)w * 4 + i;
+                if (e < m) v |= (uint32_t)p[e] << (8 * i);
+            }
+        }
+    }
+    codes[t] = v;
+}
+
+// ------------------------------------------------------------------------------------------ scan kernels
+struct ScanArgs {
+    const IvfUserDev* users;
+    const uint32_t* q_user;        // nullptr => user 0
+    const uint32_t* list_tile_off; // [G+1] tile index of each global list
+    const uint32_t* slot_ids;      // [tiles*64]
+    const uint32_t* tomb;          // tombstone bitmap arena
+    const uint32_t* probes;        // [B][probe_stride] centroid (list) ids local to the user
+    const uint32_t* probe_cnt;     // nullptr => probe_stride probes for every query
+    int probe_stride;
+    int k;
+    uint64_t* partial;             // [B][nsplit][k]
+    uint32_t* flags;
+};
+
+__device__ __forceinline__ bool tomb_test(const uint32_t* tomb, uint32_t base_word, uint32_t pid) {
+    return (tomb[base_word + (pid >> 5)] >> (pid & 31)) & 1u;
+}
+
+// NoQuantizer<D>: distance = D::calculate(query, vector) (noq/mod.rs:44-51): sqrt L2 / neg dot
+template <int METRIC>
+__global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, const float4* __restrict__ tiles, DistPlan p,
+                                                                 const float* __restrict__ q, int qstride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    BlockSelect<MDB_BLOCK> sel;
+    sel.init(lds, a.k);
+    const int qi = blockIdx.y, split = blockIdx.x, nsplit = gridDim.x;
+    const int wave = threadIdx.x / MDB_WAVE, lane = threadIdx.x % MDB_WAVE;
+    const IvfUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
+    const float* qb = q + (size_t)qi * qstride;
+    const int np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
+    bool nan_seen = false, bad = false;
+    if (u.valid) {
+        for (int j = split; j < np; j += nsplit) {
+            uint32_t c = a.probes[(size_t)qi * a.probe_stride + j];
+            if (c >= u.num_lists) { bad = true; continue; }  // "Index out of bound" (storage.rs:280-286)
+            uint32_t g = u.list_base + c;
+            uint32_t t0 = a.list_tile_off[g], t1 = a.list_tile_off[g + 1];
+            for (uint32_t tb = t0; tb < t1; tb += 4) {
+                uint32_t tile = tb + wave;
+                uint64_t key = MDB_KEY_MAX;
+                if (tile < t1) {
+                    uint32_t pid = a.slot_ids[(size_t)tile * MDB_TILE + lane];
+                    if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid)) {
+                        TileLoader ld{tiles + (size_t)tile * p.d4 * MDB_TILE + lane};
+                        float raw[1];
+                        exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
+                        float dist = finish_distance<METRIC>(raw[0]);
+                        if (dist != dist) nan_seen = true;
+                        key = make_key(dist, pid);
+                    }
+                }
+                sel.offer(key);
+                sel.round_end();
+            }
+        }
+    }
+    if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
+    if (bad) atomicOr(a.flags, MDB_FLAG_RANGE);
+    sel.finish();
+    uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
+    uint32_t c = sel.count();
+    for (int j = threadIdx.x; j < a.k; j += MDB_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+}
+
+// ProductQuantizer: symmetric distance between the QUANTIZED query and the stored codes
+// (pq/mod.rs:231-266).  The per-query table T[s][c][e] = term(cb[s][q_s][e], cb[s][c][e]) holds
+// the individually rounded per-element terms, so summing rows of T per lane in subspace order
+// reproduces the reference's shared sum_16/8/4 accumulators bit for bit.
+// LUT_LDS: table in LDS (d*K*4 bytes); otherwise terms are recomputed from the L2-resident codebook.
+template <int METRIC, bool LUT_LDS>
+__global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_pq_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m,
+                                                                int mw, int K, int subdim, DistPlan sp,
+                                                                const float* __restrict__ cb,
+                                                                const uint8_t* __restrict__ qcodes) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    BlockSelect<MDB_BLOCK> sel;
+    sel.init(lds, a.k);
+    float* lut = (float*)(lds + ((BlockSelect<MDB_BLOCK>::lds_bytes(a.k) + 15) & ~(size_t)15));
+    const int qi = blockIdx.y, split = blockIdx.x, nsplit = gridDim.x;
+    const int wave = threadIdx.x / MDB_WAVE, lane = threadIdx.x % MDB_WAVE;
+    const IvfUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
+    const uint8_t* qc = qcodes + (size_t)qi * m;
+    const int np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
+    bool nan_seen = false, bad = false;
+    if (LUT_LDS) {
+        const int rowlen = K * subdim, total = m * rowlen;
+        for (int i = threadIdx.x; i < total; i += MDB_BLOCK) {
+            int s = i / rowlen, e = i % subdim;
+            float av = cb[((size_t)s * K + qc[s]) * subdim + e];
+            lut[i] = acc_term<METRIC>(0.0f, av, cb[i]) ;  // 0 + term == term exactly (term >= +0 or any finite)
+        }
+        __syncthreads();
+    }
+    if (u.valid) {
+        for (int j = split; j < np; j += nsplit) {
+            uint32_t c = a.probes[(size_t)qi * a.probe_stride + j];
+            if (c >= u.num_lists) { bad = true; continue; }
+            uint32_t g = u.list_base + c;
+            uint32_t t0 = a.list_tile_off[g], t1 = a.list_tile_off[g + 1];
+            for (uint32_t tb = t0; tb < t1; tb += 4) {
+                uint32_t tile = tb + wave;
+                uint64_t key = MDB_KEY_MAX;
+                if (tile < t1) {
+                    uint32_t pid = a.slot_ids[(size_t)tile * MDB_TILE + lane];
+                    if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid)) {
+                        const uint32_t* cw = codes + (size_t)tile * mw * MDB_TILE + lane;
+                        float s16[16], s8[8], s4[4], s1 = 0.0f;
+#pragma unroll
+                        for (int x = 0; x < 16; ++x) s16[x] = 0.0f;
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) s8[x] = 0.0f;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) s4[x] = 0.0f;
+                        for (int w = 0; w < mw; ++w) {
+                            uint32_t word = cw[(size_t)w * MDB_TILE];
+#pragma unroll
+                            for (int bi = 0; bi < 4; ++bi) {
+                                int s = w * 4 + bi;
+                                if (s < m) {
+                                    uint32_t code = (word >> (8 * bi)) & 0xFFu;
+                                    const float* row;
+                                    const float* arow = nullptr;
+                                    if (LUT_LDS) row = lut + ((size_t)s * K + code) * subdim;
+                                    else {
+                                        row = cb + ((size_t)s * K + code) * subdim;
+                                        arow = cb + ((size_t)s * K + qc[s]) * subdim;
+                                    }
+                                    // per-element term, either pre-rounded (LUT) or computed here
+#define MDB_TERM(acc, e) (LUT_LDS ? __fadd_rn((acc), row[(e)]) : acc_term<METRIC>((acc), arow[(e)], row[(e)]))
+                                    for (int cc = 0; cc < sp.n16; ++cc)
+#pragma unroll
+                                        for (int x = 0; x < 16; ++x) s16[x] = MDB_TERM(s16[x], 16 * cc + x);
+                                    for (int cc = 0; cc < sp.n8; ++cc)
+#pragma unroll
+                                        for (int x = 0; x < 8; ++x) s8[x] = MDB_TERM(s8[x], sp.off8 + 8 * cc + x);
+                                    for (int cc = 0; cc < sp.n4; ++cc)
+#pragma unroll
+                                        for (int x = 0; x < 4; ++x) s4[x] = MDB_TERM(s4[x], sp.off4 + 4 * cc + x);
+                                    if (sp.ntail > 0) {
+                                        float tt = 0.0f;
+                                        for (int x = 0; x < sp.ntail; ++x) tt = MDB_TERM(tt, sp.offt + x);
+                                        s1 = tt;  // overwritten, not accumulated (pq/mod.rs:259-261)
+                                    }
+#undef MDB_TERM
+                                }
+                            }
+                        }
+                        float r = __fadd_rn(__fadd_rn(__fadd_rn(reduce_ordered<16>(s16), reduce_ordered<8>(s8)),
+                                                      reduce_ordered<4>(s4)), s1);
+                        float dist = METRIC == MDB_METRIC_L2 ? r : -r;
+                        if (dist != dist) nan_seen = true;
+                        key = make_key(dist, pid);
+                    }
+                }
+                sel.offer(key);
+                sel.round_end();
+            }
+        }
+    }
+    if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
+    if (bad) atomicOr(a.flags, MDB_FLAG_RANGE);
+    sel.finish();
+    uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
+    uint32_t c = sel.count();
+    for (int j = threadIdx.x; j < a.k; j += MDB_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+}
+
+// keys (distance, point id) -> (u128 doc id, score) rows ordered by IdWithScore (score, doc id).
+// One block per query; rank sort (k <= MDB_MAX_K).
+__global__ __launch_bounds__(256) void remap_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts,
+                                                    int k, const IvfUserDev* __restrict__ users,
+                                                    const uint32_t* __restrict__ q_user,
+                                                    const uint8_t* __restrict__ index_bytes, mdb_u128* __restrict__ doc_out,
+                                                    float* __restrict__ score_out, uint32_t* __restrict__ counts_out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint64_t* lo = (uint64_t*)lds;
+    uint64_t* hi = lo + k;
+    float* sc = (float*)(hi + k);
+    const int qi = blockIdx.x;
+    const IvfUserDev u = users[q_user ? q_user[qi] : 0];
+    const int c = (int)counts[qi];
+    for (int j = threadIdx.x; j < c; j += blockDim.x) {
+        uint64_t key = keys[(size_t)qi * k + j];
+        uint32_t pid = key_id(key);
+        const uint64_t* dp = (const uint64_t*)(index_bytes + u.doc_ids_off + (size_t)pid * 16);
+        lo[j] = dp[0];
+        hi[j] = dp[1];
+        sc[j] = key_dist(key);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        if (j < c) {
+            int rank = 0;
+            float s = sc[j];
+            uint64_t l = lo[j], h = hi[j];
+            for (int i = 0; i < c; ++i) {
+                float si = sc[i];
+                bool less = si < s || (si == s && (hi[i] < h || (hi[i] == h && (lo[i] < l || (lo[i] == l && i < j)))));
+                rank += less ? 1 : 0;
+            }
+            doc_out[(size_t)qi * k + rank] = mdb_u128{l, h};
+            score_out[(size_t)qi * k + rank] = s;
+        } else {
+            doc_out[(size_t)qi * k + j] = mdb_u128{~0ull, ~0ull};
+            score_out[(size_t)qi * k + j] = __uint_as_float(0x7F800000u);
+        }
+    }
+    if (threadIdx.x == 0 && counts_out) counts_out[qi] = (uint32_t)c;
+}
+
+__global__ void keys_to_probes_kernel(const uint64_t* __restrict__ keys, size_t total, uint32_t* __restrict__ probes) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) probes[t] = key_id(keys[t]);
+}
+
+// ------------------------------------------------------------------------------------------ IvfSet: load
+static mdb_status parse_ivf_blob(mdb_ctx* ctx, const uint8_t* b, size_t len, size_t offset, IvfBlobInfo& o) {
+    if (offset + 45 > len) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: header out of bounds");
+    const uint8_t* h = b + offset;
+    if (h[0] != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "Unknown version: %d", (int)h[0]);
+    o.num_features = rd_u32(h + 1);
+    o.quantized_dimension = rd_u32(h + 5);
+    o.num_clusters = rd_u32(h + 9);
+    o.num_vectors = rd_u64(h + 13);
+    uint64_t doc_len = rd_u64(h + 21), cent_len = rd_u64(h + 29);
+    o.doc_id_mapping_offset = offset + align_up(45, 16);                 // storage.rs:66-67
+    o.centroid_offset = align_up(o.doc_id_mapping_offset + doc_len, 8);  // :69-72
+    size_t meta = align_up(o.centroid_offset + cent_len, 8);             // :74-75
+    if (meta + 8 > len) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: metadata out of bounds");
+    o.num_posting_lists = rd_u64(b + meta);
+    o.pl_metadata_offset = meta + 8;
+    o.pl_start_offset = o.pl_metadata_offset + o.num_posting_lists * 16;  // :80-82
+    if (o.pl_start_offset > len) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: posting lists out of bounds");
+    if (o.doc_id_mapping_offset + 16 + o.num_vectors * 16 > len ||
+        o.centroid_offset + 8 + (uint64_t)o.num_clusters * o.num_features * 4 > len)
+        return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: sections out of bounds");
+    if (o.num_vectors > 0xFFFFFFFEull) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "point ids are u32");
+    return MDB_OK;
+}
+
+mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
+                        const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant,
+                        uint32_t shard_rank, uint32_t shard_world) {
+    ctx = ctx_;
+    if (shard_world == 0) shard_world = 1;
+    if (shard_rank >= shard_world) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "shard_rank >= shard_world");
+    kind = quant ? quant->kind : MDB_QUANT_NONE;
+    metric = quant ? quant->metric : MDB_METRIC_L2;
+    const size_t U = offsets.size();
+    blobs.resize(U);
+    h_users.assign(U, IvfUserDev{});
+    std::vector<uint64_t> list_byte_off;   // per global list (or ~0 when not owned / empty)
+    std::vector<uint32_t> list_len;
+    std::vector<uint32_t> h_list_tile_off(1, 0);
+    std::vector<uint64_t> tile_src;        // per tile: byte offset of the user's vector 0
+    std::vector<uint32_t> tile_limit;      // per tile: user's num_vectors
+    std::vector<uint64_t> cent_tile_src;
+    std::vector<uint32_t> cent_tile_first, cent_tile_limit;
+    size_t tomb_words = 0;
+    for (size_t ui = 0; ui < U; ++ui) {
+        IvfBlobInfo& bi = blobs[ui];
+        MDB_TRY(parse_ivf_blob(ctx, index, index_len, offsets[ui].first, bi));
+        if (ui == 0) { num_features = bi.num_features; quantized_dimension = bi.quantized_dimension; }
+        if (bi.num_features != num_features || bi.quantized_dimension != quantized_dimension)
+            return mdb_fail(ctx, MDB_ERR_FORMAT, "users disagree on num_features / quantized_dimension");
+        if (bi.num_posting_lists != bi.num_clusters)
+            return mdb_fail(ctx, MDB_ERR_FORMAT, "Mismatch between number of clusters (%u) and number of posting lists (%zu)",
+                            bi.num_clusters, (size_t)bi.num_posting_lists);
+        const size_t esz = kind == MDB_QUANT_PQ ? 1 : 4;
+        size_t voff = offsets[ui].second;
+        if (voff + 8 > vectors_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file: header out of bounds");
+        uint64_t nv = rd_u64(vectors + voff);  // async_storage.rs:83-87
+        if (voff + 8 + nv * quantized_dimension * esz > vectors_len)
+            return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file: %zu vectors of %u x %zu B exceed the file", (size_t)nv,
+                            quantized_dimension, esz);
+        bi.vec_num_vectors = nv;
+        bi.vec_data_offset = voff + 8;
+        IvfUserDev& u = h_users[ui];
+        u.valid = 1;
+        u.list_base = (uint32_t)list_len.size();
+        u.num_lists = bi.num_clusters;
+        u.num_vectors = (uint32_t)bi.num_vectors;
+        u.doc_ids_off = bi.doc_id_mapping_offset + 16;
+        u.tomb_base = (uint32_t)tomb_words;
+        tomb_words += (std::max<uint64_t>(bi.num_vectors, nv) + 31) / 32 + 1;
+        u.cent_tile_base = (uint32_t)cent_tile_src.size();
+        for (uint32_t c0 = 0; c0 < bi.num_clusters; c0 += MDB_TILE) {
+            cent_tile_src.push_back(bi.centroid_offset + 8);
+            cent_tile_first.push_back(c0);
+            cent_tile_limit.push_back(bi.num_clusters);
+        }
+        for (uint32_t l = 0; l < bi.num_clusters; ++l) {
+            const uint8_t* md = index + bi.pl_metadata_offset + (size_t)l * 16;
+            size_t pl_off = rd_u64(md + 8) + bi.pl_start_offset;  // storage.rs:293-294
+            if (pl_off + 32 > index_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list %u out of bounds", l);
+            uint64_t ne = rd_u64(index + pl_off), lw = rd_u64(index + pl_off + 16), uw = rd_u64(index + pl_off + 24);
+            if (pl_off + 32 + (lw + uw) * 8 > index_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list %u truncated", l);
+            if (pl_off % 8 != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list %u is not 8-byte aligned", l);
+            bool owned = (l % shard_world) == shard_rank;
+            if (!owned) ne = 0;
+            if (ne > 0xFFFFFFFFull) return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list too long");
+            list_byte_off.push_back(ne ? pl_off : ~0ull);
+            list_len.push_back((uint32_t)ne);
+            uint32_t nt = (uint32_t)((ne + MDB_TILE - 1) / MDB_TILE);
+            for (uint32_t t = 0; t < nt; ++t) { tile_src.push_back(bi.vec_data_offset); tile_limit.push_back((uint32_t)nv); }
+            h_list_tile_off.push_back(h_list_tile_off.back() + nt);
+            total_slots_valid += ne;
+        }
+    }
+    G = list_len.size();
+    const size_t ntiles = h_list_tile_off.back();
+    total_tiles = ntiles;
+    if (ntiles > 0x7FFFFFFFull / MDB_TILE) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "too many posting-list slots");
+    // ---- uploads
+    DevBuf<uint8_t> d_vec;
+    if (d_index.alloc(index_len + 16) != hipSuccess || d_vec.alloc(vectors_len + 16) != hipSuccess)
+        return mdb_fail(ctx, MDB_ERR_OOM, "index/vector upload alloc");
+    MDB_HIP(ctx, hipMemcpyAsync(d_index.p, index, index_len, hipMemcpyHostToDevice, ctx->stream));
+    MDB_HIP(ctx, hipMemcpyAsync(d_vec.p, vectors, vectors_len, hipMemcpyHostToDevice, ctx->stream));
+    DevBuf<uint64_t> d_lbo, d_oo, d_tsrc, d_ctsrc;
+    DevBuf<uint32_t> d_tlim, d_ctfirst, d_ctlim;
+    std::vector<uint64_t> out_off(G);
+    for (size_t g = 0; g < G; ++g) out_off[g] = (uint64_t)h_list_tile_off[g] * MDB_TILE;
+    auto up64 = [&](DevBuf<uint64_t>& d, const std::vector<uint64_t>& h) -> mdb_status {
+        if (d.alloc(h.size() + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
+        if (!h.empty()) MDB_HIP(ctx, hipMemcpyAsync(d.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        return MDB_OK;
+    };
+    auto up32 = [&](DevBuf<uint32_t>& d, const std::vector<uint32_t>& h) -> mdb_status {
+        if (d.alloc(h.size() + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
+        if (!h.empty()) MDB_HIP(ctx, hipMemcpyAsync(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        return MDB_OK;
+    };
+    // compact the owned, non-empty lists for the decode launch
+    std::vector<uint64_t> dec_off, dec_out;
+    for (size_t g = 0; g < G; ++g)
+        if (list_len[g]) { dec_off.push_back(list_byte_off[g]); dec_out.push_back(out_off[g]); }
+    MDB_TRY(up64(d_lbo, dec_off));
+    MDB_TRY(up64(d_oo, dec_out));
+    MDB_TRY(up64(d_tsrc, tile_src));
+    MDB_TRY(up32(d_tlim, tile_limit));
+    MDB_TRY(up64(d_ctsrc, cent_tile_src));
+    MDB_TRY(up32(d_ctfirst, cent_tile_first));
+    MDB_TRY(up32(d_ctlim, cent_tile_limit));
+    MDB_TRY(up32(d_list_tile_off, h_list_tile_off));
+    if (d_users.alloc(U + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
+    MDB_HIP(ctx, hipMemcpyAsync(d_users.p, h_users.data(), U * sizeof(IvfUserDev), hipMemcpyHostToDevice, ctx->stream));
+    h_tomb.assign(tomb_words + 1, 0);
+    if (d_tomb.alloc(tomb_words + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
+    MDB_HIP(ctx, hipMemsetAsync(d_tomb.p, 0, (tomb_words + 1) * 4, ctx->stream));
+    // ---- decode posting lists into the slot id array
+    const size_t nslots = ntiles * MDB_TILE;
+    if (d_slot_ids.alloc(nslots + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "slot ids alloc");
+    if (nslots) fill_u32_kernel<<<dim3((unsigned)((nslots + 255) / 256)), 256, 0, ctx->stream>>>(d_slot_ids.p, nslots, 0xFFFFFFFFu);
+    MDB_TRY(ef_decode_lists(ctx, d_index.p, d_lbo.p, d_oo.p, dec_off.size(), d_slot_ids.p));
+    // ---- re-lay the vectors list-contiguous
+    if (kind == MDB_QUANT_PQ) {
+        MDB_TRY(pq_upload(ctx, quant, pq));
+        if ((uint32_t)pq.m != quantized_dimension) return mdb_fail(ctx, MDB_ERR_FORMAT, "quantized_dimension != dimension / subvector_dimension");
+        if ((uint32_t)pq.dimension != num_features) return mdb_fail(ctx, MDB_ERR_FORMAT, "quantizer dimension != num_features");
+        mw = (pq.m + 3) / 4;
+        size_t total = ntiles * MDB_TILE * (size_t)mw;
+        if (d_codes.alloc(total + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "code tiles alloc");
+        if (total)
+            gather_code_tiles_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(
+                d_vec.p, d_tsrc.p, d_tlim.p, d_slot_ids.p, pq.m, mw, d_codes.p, total, ctx->d_flags);
+    } else {
+        if (quant && quant->dimension && quant->dimension != num_features)
+            return mdb_fail(ctx, MDB_ERR_FORMAT, "quantizer dimension != num_features");
+        if (quantized_dimension != num_features) return mdb_fail(ctx, MDB_ERR_FORMAT, "NoQuantizer: quantized_dimension != num_features");
+        for (auto& o : offsets)
+            if ((o.second + 8) % 4 != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "f32 vector file is not 4-byte aligned");
+        int d4 = ((int)num_features + 3) / 4;
+        size_t total4 = ntiles * MDB_TILE * (size_t)d4;
+        if (d_tiles.alloc(total4 * 4 + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "vector tiles alloc (%zu MiB)", total4 * 16 >> 20);
+        if (total4)
+            gather_f32_tiles_kernel<<<dim3((unsigned)((total4 + 255) / 256)), 256, 0, ctx->stream>>>(
+                d_vec.p, d_tsrc.p, d_tlim.p, d_slot_ids.p, nullptr, (int)num_features, d4, (float4*)d_tiles.p, total4,
+                ctx->d_flags);
+    }
+    MDB_HIP(ctx, hipGetLastError());
+    // ---- centroids into tiles (coarse quantizer scan, find_nearest_centroids)
+    {
+        int d4 = ((int)num_features + 3) / 4;
+        size_t nct = cent_tile_src.size();
+        size_t total4 = nct * MDB_TILE * (size_t)d4;
+        if (d_cent_tiles.alloc(total4 * 4 + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "centroid tiles alloc");
+        if (total4)
+            gather_f32_tiles_kernel<<<dim3((unsigned)((total4 + 255) / 256)), 256, 0, ctx->stream>>>(
+                d_index.p, d_ctsrc.p, d_ctlim.p, nullptr, d_ctfirst.p, (int)num_features, d4, (float4*)d_cent_tiles.p, total4,
+                ctx->d_flags);
+        MDB_HIP(ctx, hipGetLastError());
+    }
+    mdb_status st = mdb_check_flags(ctx);  // synchronises: temporaries may now be released
+    if (st != MDB_OK) return st;
+    doc_maps.resize(U);
+    return MDB_OK;
+}
+
+// doc id -> point id map of one user, built on first use (BlockBasedIvf::new builds it eagerly,
+// index.rs:67-73; here it is only needed by invalidate / is_invalidated)
+mdb_status IvfSet::build_doc_map(size_t ui) {
+    if (!doc_maps[ui].empty() || blobs[ui].num_vectors == 0) return MDB_OK;
+    const IvfBlobInfo& bi = blobs[ui];
+    std::vector<uint64_t> ids(bi.num_vectors * 2);
+    MDB_HIP(ctx, hipMemcpy(ids.data(), d_index.p + bi.doc_id_mapping_offset + 16, bi.num_vectors * 16, hipMemcpyDeviceToHost));
+    auto& m = doc_maps[ui];
+    m.reserve(bi.num_vectors * 2);
+    for (uint64_t i = 0; i < bi.num_vectors; ++i) m[U128Key{ids[2 * i], ids[2 * i + 1]}] = (uint32_t)i;  // later ids win, like HashMap::collect
+    return MDB_OK;
+}
+
+mdb_status IvfSet::invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out, bool test_only) {
+    if (ui >= blobs.size()) { for (size_t i = 0; i < n; ++i) flags_out[i] = 0; return MDB_OK; }
+    MDB_TRY(build_doc_map(ui));
+    bool dirty = false;
+    for (size_t i = 0; i < n; ++i) {
+        auto it = doc_maps[ui].find(U128Key{doc_ids[i].lo, doc_ids[i].hi});
+        if (it == doc_maps[ui].end()) { flags_out[i] = 0; continue; }
+        uint32_t pid = it->second;
+        size_t w = h_users[ui].tomb_base + (pid >> 5);
+        uint32_t bit = 1u << (pid & 31);
+        bool was = h_tomb[w] & bit;
+        if (test_only) { flags_out[i] = was; continue; }
+        flags_out[i] = !was;  // DashSet::insert returns true when newly inserted (index.rs:421-426)
+        if (!was) {
+            h_tomb[w] |= bit;
+            MDB_HIP(ctx, hipMemcpyAsync(d_tomb.p + w, &h_tomb[w], 4, hipMemcpyHostToDevice, ctx->stream));
+            dirty = true;
+        }
+    }
+    if (dirty) MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MDB_OK;
+}
+
+// ------------------------------------------------------------------------------------------ IvfSet: search
+// d_q: staged queries [b][qstride]; probes: device [b][probe_stride]; outputs: device keys [b][k] + counts
+mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
+                        const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts) {
+    if (b == 0) return MDB_OK;
+    if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
+    int nsplit = 1;
+    if (probe_stride > 1) {
+        size_t want = (1024 + b - 1) / b;  // aim for >= ~1024 blocks
+        nsplit = (int)std::min<size_t>(std::max<size_t>(want, 1), (size_t)probe_stride);
+        nsplit = std::min(nsplit, 64);
+    }
+    void* partial;
+    MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)nsplit * std::max<size_t>(k, 1) * 8, &partial));
+    ScanArgs a{d_users.p, d_q_user, d_list_tile_off.p, d_slot_ids.p, d_tomb.p, d_probes, d_probe_cnt, probe_stride,
+               (int)k, (uint64_t*)partial, ctx->d_flags};
+    dim3 grid((unsigned)nsplit, (unsigned)b);
+    size_t sel_lds = BlockSelect<MDB_BLOCK>::lds_bytes((int)k);
+    if (kind == MDB_QUANT_PQ) {
+        void* qcodes;
+        MDB_TRY(mdb_scratch(ctx, 7, b * (size_t)pq.m + 16, &qcodes));
+        MDB_TRY(pq_quantize_device(ctx, pq, d_q, b, (uint8_t*)qcodes, qstride));  // Q::QuantizedT::process_vector, index.rs:193
+        DistPlan sp = make_plan(pq.subdim, MDB_METRIC_L2);
+        size_t lut_bytes = (size_t)pq.m * pq.K * pq.subdim * 4;
+        size_t lds_lut = ((sel_lds + 15) & ~(size_t)15) + lut_bytes;
+        bool use_lut = lds_lut <= 150 * 1024;
+#define MDB_PQ_LAUNCH(METRIC, LUT, LDS)                                                                              \
+    do {                                                                                                             \
+        if ((LDS) > 48 * 1024)                                                                                       \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq_kernel<METRIC, LUT>,                           \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)));              \
+        ivf_scan_pq_kernel<METRIC, LUT><<<grid, MDB_BLOCK, (LDS), ctx->stream>>>(a, d_codes.p, pq.m, mw, pq.K, pq.subdim, \
+                                                                                  sp, pq.codebook.p, (uint8_t*)qcodes); \
+    } while (0)
+        if (metric == MDB_METRIC_L2) {
+            if (use_lut) MDB_PQ_LAUNCH(MDB_METRIC_L2, true, lds_lut); else MDB_PQ_LAUNCH(MDB_METRIC_L2, false, sel_lds);
+        } else {
+            if (use_lut) MDB_PQ_LAUNCH(MDB_METRIC_DOT, true, lds_lut); else MDB_PQ_LAUNCH(MDB_METRIC_DOT, false, sel_lds);
+        }
+#undef MDB_PQ_LAUNCH
+    } else {
+        DistPlan p = make_plan((int)num_features, metric);
+        if (metric == MDB_METRIC_L2)
+            ivf_scan_f32_kernel<MDB_METRIC_L2><<<grid, MDB_BLOCK, sel_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);
+        else
+            ivf_scan_f32_kernel<MDB_METRIC_DOT><<<grid, MDB_BLOCK, sel_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);
+    }
+    MDB_HIP(ctx, hipGetLastError());
+    MDB_TRY(merge_keys(ctx, (const uint64_t*)partial, (size_t)nsplit * k, b, k, d_keys, d_counts));
+    return MDB_OK;
+}
+
+mdb_status IvfSet::remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,
+                         mdb_u128* d_doc, float* d_score, uint32_t* d_counts_out) {
+    if (b == 0) return MDB_OK;
+    size_t lds = std::max<size_t>(k, 1) * 20 + 16;
+    remap_kernel<<<dim3((unsigned)b), 256, lds, ctx->stream>>>(d_keys, d_counts, (int)k, d_users.p, d_q_user, d_index.p, d_doc,
+                                                              d_score, d_counts_out);
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+// find_nearest_centroids (index.rs:147-163) for user `ui`: sqrt-L2 to every centroid, the
+// num_probes nearest ordered by (distance, index) [ties: the reference's select_nth_unstable +
+// stable sort leave equal distances implementation-defined; this path orders them by index]
+mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes) {
+    const IvfBlobInfo& bi = blobs[ui];
+    if (num_probes == 0 || num_probes > bi.num_clusters)
+        return mdb_fail(ctx, MDB_ERR_OUT_OF_RANGE, "num_probes=%zu out of range (num_clusters=%u): the reference panics in select_nth_unstable_by",
+                        num_probes, bi.num_clusters);
+    int d4 = ((int)num_features + 3) / 4;
+    TileView cv{d_cent_tiles.p + (size_t)h_users[ui].cent_tile_base * MDB_TILE * d4 * 4, bi.num_clusters,
+                (bi.num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
+    void* keys;
+    MDB_TRY(mdb_scratch(ctx, 5, b * num_probes * 8, &keys));
+    MDB_TRY(flat_topk_keys(ctx, cv, MDB_METRIC_L2, d_q, qstride, b, num_probes, (uint64_t*)keys, nullptr));  // always L2 (:155)
+    size_t total = b * num_probes;
+    keys_to_probes_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((uint64_t*)keys, total, d_probes);
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+// ============================================================================================
+// C ABI: single IVF
+// ============================================================================================
+struct mdb_ivf {
+    IvfSet set;
+};
+
+static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes,
+                                  size_t k, mdb_mem mem, bool remap, void* ids_out, float* scores_out, uint32_t* counts_out) {
+    IvfSet& s = ivf->set;
+    mdb_ctx* ctx = s.ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    if (b == 0) return MDB_OK;
+    if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
+    float* dq;
+    int qstride;
+    MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, (b + 3) / 4 * 4, &dq, &qstride));
+    void* dprobes;
+    MDB_TRY(mdb_scratch(ctx, 2, b * std::max<size_t>(num_probes, 1) * 4, &dprobes));
+    if (probes) {
+        if (num_probes == 0) { /* empty centroid list: empty results */ }
+        else MDB_HIP(ctx, hipMemcpyAsync(dprobes, probes, b * num_probes * 4,
+                                         mem == MDB_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        MDB_TRY(s.coarse(0, dq, qstride, b, num_probes, (uint32_t*)dprobes));
+    }
+    void *keys, *cnts;
+    MDB_TRY(mdb_scratch(ctx, 3, b * std::max<size_t>(k, 1) * 8, &keys));
+    MDB_TRY(mdb_scratch(ctx, 6, b * 4 + 16, &cnts));
+    MDB_TRY(s.scan(dq, qstride, b, nullptr, (uint32_t*)dprobes, nullptr, (int)num_probes, k, (uint64_t*)keys, (uint32_t*)cnts));
+    ctx->stats = mdb_stats{};
+    size_t total = b * k;
+    if (mem == MDB_MEM_DEVICE) {
+        if (remap) MDB_TRY(s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, (mdb_u128*)ids_out, scores_out, counts_out));
+        else {
+            if (total) unpack_keys(ctx, (uint64_t*)keys, total, (uint32_t*)ids_out, scores_out);
+            if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts, b * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        return MDB_OK;
+    }
+    void *dids, *dsc;
+    MDB_TRY(mdb_scratch(ctx, 5, total * 16 + 16, &dids));
+    MDB_TRY(mdb_scratch(ctx, 1, total * 4 + 16, &dsc));
+    if (remap) {
+        MDB_TRY(s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, (mdb_u128*)dids, (float*)dsc, nullptr));
+        if (total) MDB_HIP(ctx, hipMemcpyAsync(ids_out, dids, total * 16, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        if (total) unpack_keys(ctx, (uint64_t*)keys, total, (uint32_t*)dids, (float*)dsc);
+        if (total) MDB_HIP(ctx, hipMemcpyAsync(ids_out, dids, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (total) MDB_HIP(ctx, hipMemcpyAsync(scores_out, dsc, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts, b * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return mdb_check_flags(ctx);
+}
+
+extern "C" {
+
+mdb_status mdb_ivf_load(mdb_ctx* ctx, const void* index_bytes, size_t index_len, size_t index_offset,
+                        const void* vectors_bytes, size_t vectors_len, size_t vectors_offset, const mdb_quant_desc* quant,
+                        uint32_t shard_rank, uint32_t shard_world, mdb_ivf** out) {
+    if (!ctx || !index_bytes || !vectors_bytes || !out) return MDB_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    mdb_ivf* ivf = new mdb_ivf();
+    mdb_status st = ivf->set.load(ctx, (const uint8_t*)index_bytes, index_len, (const uint8_t*)vectors_bytes, vectors_len,
+                                  {{index_offset, vectors_offset}}, quant, shard_rank, shard_world);
+    if (st != MDB_OK) { delete ivf; return st; }
+    *out = ivf;
+    return MDB_OK;
+}
+
+void mdb_ivf_free(mdb_ivf* ivf) {
+    if (!ivf) return;
+    (void)hipSetDevice(ivf->set.ctx->device);
+    (void)hipStreamSynchronize(ivf->set.ctx->stream);
+    delete ivf;
+}
+
+size_t mdb_ivf_num_clusters(const mdb_ivf* ivf) { return ivf ? ivf->set.blobs[0].num_clusters : 0; }
+size_t mdb_ivf_num_vectors(const mdb_ivf* ivf) { return ivf ? (size_t)ivf->set.blobs[0].vec_num_vectors : 0; }
+size_t mdb_ivf_num_features(const mdb_ivf* ivf) { return ivf ? ivf->set.num_features : 0; }
+
+mdb_status mdb_ivf_find_nearest_centroids(mdb_ivf* ivf, const float* queries, size_t b, size_t num_probes, mdb_mem mem,
+                                          uint32_t* out) {
+    if (!ivf || (!queries && b) || !out) return MDB_ERR_INVALID_ARG;
+    IvfSet& s = ivf->set;
+    mdb_ctx* ctx = s.ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    if (num_probes == 0 || num_probes > s.blobs[0].num_clusters)
+        return mdb_fail(ctx, MDB_ERR_OUT_OF_RANGE, "num_probes=%zu out of range (num_clusters=%u)", num_probes, s.blobs[0].num_clusters);
+    if (b == 0) return MDB_OK;
+    float* dq;
+    int qstride;
+    MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, (b + 3) / 4 * 4, &dq, &qstride));
+    if (mem == MDB_MEM_DEVICE) return s.coarse(0, dq, qstride, b, num_probes, out);
+    void* dprobes;
+    MDB_TRY(mdb_scratch(ctx, 2, b * num_probes * 4, &dprobes));
+    MDB_TRY(s.coarse(0, dq, qstride, b, num_probes, (uint32_t*)dprobes));
+    MDB_HIP(ctx, hipMemcpyAsync(out, dprobes, b * num_probes * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return mdb_check_flags(ctx);
+}
+
+mdb_status mdb_ivf_search(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
+                          mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out) {
+    if (!ivf || (!queries && b) || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
+    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, true, doc_ids_out, scores_out, counts_out);
+}
+
+mdb_status mdb_ivf_search_points(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes,
+                                 size_t k, mdb_mem mem, uint32_t* point_ids_out, float* scores_out, uint32_t* counts_out) {
+    if (!ivf || (!queries && b) || !point_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
+    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, false, point_ids_out, scores_out, counts_out);
+}
+
+mdb_status mdb_ivf_invalidate(mdb_ivf* ivf, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out) {
+    if (!ivf || (!doc_ids && n) || !flags_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ivf->set.ctx->mu);
+    MDB_HIP(ivf->set.ctx, hipSetDevice(ivf->set.ctx->device));
+    return ivf->set.invalidate(0, doc_ids, n, flags_out, false);
+}
+
+mdb_status mdb_ivf_is_invalidated(mdb_ivf* ivf, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out) {
+    if (!ivf || (!doc_ids && n) || !flags_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ivf->set.ctx->mu);
+    MDB_HIP(ivf->set.ctx, hipSetDevice(ivf->set.ctx->device));
+    return ivf->set.invalidate(0, doc_ids, n, flags_out, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,455 @@
+"""Host-side mirror of the reference's search surface over the C ABI (include/muopdb_hip.h).
+
+Class and method names follow the reference (Rust, rs/index + rs/quantization) so that the
+parity tests read like the reference's own tests:
+
+    reference                                             here
+    ----------------------------------------------------  ---------------------------------------
+    L2DistanceCalculator / DotProductDistanceCalculator   L2DistanceCalculator / DotProduct...
+    NoQuantizer / ProductQuantizer                         NoQuantizer / ProductQuantizer
+    BlockBasedIvf::{find_nearest_centroids, search, ...}  BlockBasedIvf (batched: B queries)
+    BlockBasedHnsw::ann_search                             BlockBasedHnsw.ann_search
+    Spann::search, MultiSpannIndex::search_for_user       Spann.search, MultiSpannIndex.search_for_user
+    SearchParams, SearchResult{IdWithScore}                SearchParams, SearchResult
+
+Every search takes a BATCH of queries (the reference handles one query per call and loops,
+rs/index/src/collection/snapshot.rs:49-58); row i of a result is what the reference returns
+for query i.  All compute runs in libmuopdb_hip.so on the GPU; nothing here falls back to CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as L
+
+INF_ID = (1 << 128) - 1
+
+
+class SearchParams:
+    """rs/config/src/search_params.rs:1-34"""
+
+    def __init__(self, top_k, ef_construction, record_pages=False):
+        self.top_k = top_k
+        self.ef_construction = ef_construction
+        self.record_pages = record_pages
+        self.num_explored_centroids = None
+        self.centroid_distance_ratio = 0.1
+
+    def with_num_explored_centroids(self, n):
+        self.num_explored_centroids = n
+        return self
+
+    def with_centroid_distance_ratio(self, r):
+        self.centroid_distance_ratio = r
+        return self
+
+    def to_c(self):
+        p = L.SearchParamsC()
+        p.top_k, p.ef_construction, p.record_pages = self.top_k, self.ef_construction, int(self.record_pages)
+        p.num_explored_centroids = -1 if self.num_explored_centroids is None else int(self.num_explored_centroids)
+        p.centroid_distance_ratio = self.centroid_distance_ratio
+        return p
+
+
+class SearchResult:
+    """Batched SearchResult: row i = Vec<IdWithScore> of query i (rs/index/src/utils.rs:152-176)."""
+
+    def __init__(self, b, k, doc_lo, doc_hi, scores, counts, found=None):
+        self.b, self.k = b, k
+        self.doc_lo, self.doc_hi, self.scores, self.counts = doc_lo, doc_hi, scores, counts
+        self.found = found if found is not None else np.ones(b, np.uint8)
+
+    def doc_ids(self, qi):
+        n = int(self.counts[qi])
+        return [(int(self.doc_hi[qi, i]) << 64) | int(self.doc_lo[qi, i]) for i in range(n)]
+
+    def id_with_scores(self, qi):
+        n = int(self.counts[qi])
+        return list(zip(self.doc_ids(qi), self.scores[qi, :n].tolist()))
+
+
+class _OutBuf:
+    def __init__(self, b, k):
+        self.ids = np.empty((b, max(k, 1), 2), np.uint64)
+        self.scores = np.empty((b, max(k, 1)), np.float32)
+        self.counts = np.zeros(b, np.uint32)
+        self.found = np.ones(b, np.uint8)
+        self.b, self.k = b, k
+
+    def args(self):
+        return [self.ids.ctypes.data_as(C.POINTER(L.U128)), L.ptr(self.scores, C.c_float),
+                L.ptr(self.counts, C.c_uint32)]
+
+    def result(self):
+        return SearchResult(self.b, self.k, self.ids[:, :, 0], self.ids[:, :, 1], self.scores, self.counts, self.found)
+
+
+# ------------------------------------------------------------------------------------------ distances
+class L2DistanceCalculator:
+    """rs/utils/src/distance/l2.rs — batched pairs on the GPU."""
+
+    @staticmethod
+    def calculate(ctx, a, b):
+        return ctx.l2_distance(a, b, squared=False)
+
+    @staticmethod
+    def calculate_squared(ctx, a, b):
+        return ctx.l2_distance(a, b, squared=True)
+
+
+class DotProductDistanceCalculator:
+    """rs/utils/src/distance/dot_product.rs"""
+
+    @staticmethod
+    def calculate(ctx, a, b):
+        return ctx.dot_distance(a, b)
+
+
+class NoQuantizer:
+    """rs/quantization/src/noq/mod.rs"""
+
+    def __init__(self, dimension, metric=L.METRIC_L2):
+        self.dimension, self.metric = dimension, metric
+
+    def quantized_dimension(self):
+        return self.dimension
+
+    def desc(self):
+        return L.quant_desc(L.QUANT_NONE, self.metric, self.dimension)
+
+
+class ProductQuantizer:
+    """rs/quantization/src/pq/mod.rs (query-time functions)."""
+
+    def __init__(self, dimension, subvector_dimension, num_bits, codebook, metric=L.METRIC_L2):
+        if subvector_dimension == 0 or dimension % subvector_dimension != 0:
+            raise ValueError("Vector dimension needs to be divisible by the subvector dimension.")
+        self.dimension, self.subvector_dimension, self.num_bits, self.metric = (
+            dimension, subvector_dimension, num_bits, metric)
+        self.codebook = L.f32(codebook).reshape(-1)
+
+    def quantized_dimension(self):
+        return self.dimension // self.subvector_dimension
+
+    def desc(self):
+        return L.quant_desc(L.QUANT_PQ, self.metric, self.dimension, self.subvector_dimension, self.num_bits,
+                            self.codebook)
+
+    def quantize(self, ctx, vectors):
+        v = L.f32(vectors).reshape(-1, self.dimension)
+        out = np.empty((v.shape[0], self.quantized_dimension()), np.uint8)
+        q, keep = self.desc()
+        ctx.check(ctx.lib.mdb_pq_quantize(ctx.h, C.byref(q), L.ptr(v, C.c_float), C.c_size_t(v.shape[0]),
+                                          L.ptr(out, C.c_uint8)))
+        return out
+
+    def distance(self, ctx, a, b, implem=L.IMPL_STREAMING_SIMD):
+        m = self.quantized_dimension()
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, m)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, m)
+        out = np.empty(a.shape[0], np.float32)
+        q, keep = self.desc()
+        ctx.check(ctx.lib.mdb_pq_distance(ctx.h, C.byref(q), L.ptr(a, C.c_uint8), L.ptr(b, C.c_uint8),
+                                          C.c_size_t(a.shape[0]), C.c_int(implem), L.ptr(out, C.c_float)))
+        return out
+
+
+def _quant(q, dimension):
+    q = q or NoQuantizer(dimension)
+    return q.desc()
+
+
+# ------------------------------------------------------------------------------------------ flat
+class FlatIndex:
+    """Brute-force scan (the build's formulation of BASELINE config C1; ordering rules of
+    BlockBasedIvf::find_nearest_centroids, rs/index/src/ivf/block_based/index.rs:147-163)."""
+
+    def __init__(self, ctx, base, metric=L.METRIC_L2, device_ptr=None, n=None, d=None):
+        self.ctx = ctx
+        h = C.c_void_p()
+        if device_ptr is not None:
+            self.n, self.d = n, d
+            ctx.check(ctx.lib.mdb_flat_create(ctx.h, C.c_void_p(device_ptr), C.c_size_t(n), C.c_size_t(d),
+                                              C.c_int(metric), C.c_int(L.MEM_DEVICE), C.byref(h)))
+        else:
+            base = L.f32(base)
+            self.n, self.d = base.shape
+            ctx.check(ctx.lib.mdb_flat_create(ctx.h, L.ptr(base, C.c_float), C.c_size_t(self.n), C.c_size_t(self.d),
+                                              C.c_int(metric), C.c_int(L.MEM_HOST), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mdb_flat_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search(self, queries, k):
+        q = L.f32(queries).reshape(-1, self.d)
+        b = q.shape[0]
+        ids = np.empty((b, max(k, 1)), np.uint32)
+        dist = np.empty((b, max(k, 1)), np.float32)
+        counts = np.zeros(b, np.uint32)
+        self.ctx.check(self.ctx.lib.mdb_flat_search(self.h, L.ptr(q, C.c_float), C.c_size_t(b), C.c_size_t(k),
+                                                    C.c_int(L.MEM_HOST), L.ptr(ids, C.c_uint32),
+                                                    L.ptr(dist, C.c_float), L.ptr(counts, C.c_uint32)))
+        return ids[:, :k], dist[:, :k], counts
+
+    def search_device(self, q_ptr, b, k, ids_ptr, dist_ptr, counts_ptr=None):
+        """Device-resident queries / outputs (torch tensors' data_ptr()); enqueue only."""
+        self.ctx.check(self.ctx.lib.mdb_flat_search(self.h, C.c_void_p(q_ptr), C.c_size_t(b), C.c_size_t(k),
+                                                    C.c_int(L.MEM_DEVICE), C.c_void_p(ids_ptr), C.c_void_p(dist_ptr),
+                                                    C.c_void_p(counts_ptr) if counts_ptr else None))
+
+
+# ------------------------------------------------------------------------------------------ IVF
+class BlockBasedIvf:
+    """rs/index/src/ivf/block_based/index.rs"""
+
+    def __init__(self, ctx, index_bytes, vectors_bytes, quantizer=None, index_offset=0, vector_offset=0,
+                 shard_rank=0, shard_world=1):
+        self.ctx = ctx
+        ib, vb = L.u8buf(index_bytes), L.u8buf(vectors_bytes)
+        nf = int(np.frombuffer(ib[index_offset + 1:index_offset + 5].tobytes(), np.uint32)[0]) if ib.size >= index_offset + 5 else 0
+        q, keep = _quant(quantizer, nf)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mdb_ivf_load(ctx.h, L.ptr(ib, C.c_uint8), C.c_size_t(ib.size), C.c_size_t(index_offset),
+                                       L.ptr(vb, C.c_uint8), C.c_size_t(vb.size), C.c_size_t(vector_offset),
+                                       C.byref(q), C.c_uint32(shard_rank), C.c_uint32(shard_world), C.byref(h)))
+        self.h = h
+        self.num_features = int(ctx.lib.mdb_ivf_num_features(h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mdb_ivf_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_clusters(self):
+        return int(self.ctx.lib.mdb_ivf_num_clusters(self.h))
+
+    def num_vectors(self):
+        return int(self.ctx.lib.mdb_ivf_num_vectors(self.h))
+
+    def find_nearest_centroids(self, queries, num_probes):
+        q = L.f32(queries).reshape(-1, self.num_features)
+        out = np.empty((q.shape[0], max(num_probes, 1)), np.uint32)
+        self.ctx.check(self.ctx.lib.mdb_ivf_find_nearest_centroids(self.h, L.ptr(q, C.c_float), C.c_size_t(q.shape[0]),
+                                                                   C.c_size_t(num_probes), C.c_int(L.MEM_HOST),
+                                                                   L.ptr(out, C.c_uint32)))
+        return out[:, :num_probes]
+
+    def search(self, queries, k, num_probes):
+        """BlockBasedIvf::search (index.rs:396-413)."""
+        return self._search(queries, k, None, num_probes)
+
+    def search_with_centroids_and_remap(self, queries, nearest_centroid_ids, k):
+        """index.rs:298-332; nearest_centroid_ids: [B][P]."""
+        p = np.ascontiguousarray(nearest_centroid_ids, np.uint32)
+        p = p.reshape(-1, p.shape[-1])
+        return self._search(queries, k, p, p.shape[1])
+
+    def _search(self, queries, k, probes, num_probes):
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        out = _OutBuf(b, k)
+        self.ctx.check(self.ctx.lib.mdb_ivf_search(self.h, L.ptr(q, C.c_float), C.c_size_t(b),
+                                                   L.ptr(probes, C.c_uint32) if probes is not None else None,
+                                                   C.c_size_t(num_probes), C.c_size_t(k), C.c_int(L.MEM_HOST),
+                                                   *out.args()))
+        return out.result()
+
+    def search_points(self, queries, k, num_probes, probes=None):
+        """search_with_centroids (index.rs:250-286): top-k by (distance, point id), no remap."""
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        ids = np.empty((b, max(k, 1)), np.uint32)
+        sc = np.empty((b, max(k, 1)), np.float32)
+        cn = np.zeros(b, np.uint32)
+        if probes is not None:
+            probes = np.ascontiguousarray(probes, np.uint32).reshape(b, -1)
+            num_probes = probes.shape[1]
+        self.ctx.check(self.ctx.lib.mdb_ivf_search_points(self.h, L.ptr(q, C.c_float), C.c_size_t(b),
+                                                          L.ptr(probes, C.c_uint32) if probes is not None else None,
+                                                          C.c_size_t(num_probes), C.c_size_t(k), C.c_int(L.MEM_HOST),
+                                                          L.ptr(ids, C.c_uint32), L.ptr(sc, C.c_float),
+                                                          L.ptr(cn, C.c_uint32)))
+        return ids[:, :k], sc[:, :k], cn
+
+    def invalidate(self, doc_id):
+        return bool(self.invalidate_batch([doc_id])[0])
+
+    def invalidate_batch(self, doc_ids):
+        flags = np.zeros(max(len(doc_ids), 1), np.uint8)
+        arr = L.u128_array(doc_ids)
+        self.ctx.check(self.ctx.lib.mdb_ivf_invalidate(self.h, arr, C.c_size_t(len(doc_ids)), L.ptr(flags, C.c_uint8)))
+        return flags[:len(doc_ids)]
+
+    def is_invalidated(self, doc_id):
+        flags = np.zeros(1, np.uint8)
+        arr = L.u128_array([doc_id])
+        self.ctx.check(self.ctx.lib.mdb_ivf_is_invalidated(self.h, arr, C.c_size_t(1), L.ptr(flags, C.c_uint8)))
+        return bool(flags[0])
+
+
+# ------------------------------------------------------------------------------------------ HNSW
+class BlockBasedHnsw:
+    """rs/index/src/hnsw/block_based/index.rs"""
+
+    def __init__(self, ctx, index_bytes, vectors_bytes, dimension, quantizer=None, index_offset=0, vector_offset=0):
+        self.ctx, self.dimension = ctx, dimension
+        ib, vb = L.u8buf(index_bytes), L.u8buf(vectors_bytes)
+        q, keep = _quant(quantizer, dimension)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mdb_hnsw_load(ctx.h, L.ptr(ib, C.c_uint8), C.c_size_t(ib.size), C.c_size_t(index_offset),
+                                        L.ptr(vb, C.c_uint8), C.c_size_t(vb.size), C.c_size_t(vector_offset),
+                                        C.byref(q), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mdb_hnsw_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ann_search(self, queries, k, ef):
+        q = L.f32(queries).reshape(-1, self.dimension)
+        b = q.shape[0]
+        out = _OutBuf(b, k)
+        self.ctx.check(self.ctx.lib.mdb_hnsw_ann_search(self.h, L.ptr(q, C.c_float), C.c_size_t(b), C.c_size_t(k),
+                                                        C.c_uint32(ef), C.c_int(L.MEM_HOST), *out.args()))
+        return out.result()
+
+    def ann_search_device(self, q_ptr, b, k, ef, ids_ptr, scores_ptr, counts_ptr):
+        self.ctx.check(self.ctx.lib.mdb_hnsw_ann_search(self.h, C.c_void_p(q_ptr), C.c_size_t(b), C.c_size_t(k),
+                                                        C.c_uint32(ef), C.c_int(L.MEM_DEVICE), C.c_void_p(ids_ptr),
+                                                        C.c_void_p(scores_ptr), C.c_void_p(counts_ptr)))
+
+
+# ------------------------------------------------------------------------------------------ SPANN
+class Spann:
+    """rs/index/src/spann/index.rs"""
+
+    def __init__(self, ctx, hnsw_index, hnsw_vectors, ivf_index, ivf_vectors, quantizer=None, offsets=(0, 0, 0, 0)):
+        self.ctx = ctx
+        bufs = [L.u8buf(x) for x in (hnsw_index, hnsw_vectors, ivf_index, ivf_vectors)]
+        off = offsets[2]
+        self.num_features = int(np.frombuffer(bufs[2][off + 1:off + 5].tobytes(), np.uint32)[0])
+        q, keep = _quant(quantizer, self.num_features)
+        a = []
+        for buf, o in zip(bufs, offsets):
+            a += [L.ptr(buf, C.c_uint8), C.c_size_t(buf.size), C.c_size_t(o)]
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mdb_spann_load(ctx.h, *a, C.byref(q), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mdb_spann_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search(self, queries, params):
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        out = _OutBuf(b, params.top_k)
+        p = params.to_c()
+        self.ctx.check(self.ctx.lib.mdb_spann_search(self.h, L.ptr(q, C.c_float), C.c_size_t(b), C.byref(p),
+                                                     C.c_int(L.MEM_HOST), *out.args(), L.ptr(out.found, C.c_uint8)))
+        return out.result()
+
+    def invalidate(self, doc_id):
+        flags = np.zeros(1, np.uint8)
+        self.ctx.check(self.ctx.lib.mdb_spann_invalidate(self.h, L.u128_array([doc_id]), C.c_size_t(1),
+                                                         L.ptr(flags, C.c_uint8)))
+        return bool(flags[0])
+
+    def is_invalidated(self, doc_id):
+        flags = np.zeros(1, np.uint8)
+        self.ctx.check(self.ctx.lib.mdb_spann_is_invalidated(self.h, L.u128_array([doc_id]), C.c_size_t(1),
+                                                             L.ptr(flags, C.c_uint8)))
+        return bool(flags[0])
+
+
+class MultiSpannIndex:
+    """rs/index/src/multi_spann/index.rs — `user_table` = 112-byte UserIndexInfo records."""
+
+    def __init__(self, ctx, user_table, num_features, hnsw_index, hnsw_vectors, ivf_index, ivf_vectors,
+                 quantizer=None, shard_rank=0, shard_world=1):
+        self.ctx, self.num_features = ctx, num_features
+        ut = L.u8buf(user_table)
+        n_users = ut.size // 112
+        users = (L.UserIndexInfoC * max(n_users, 1))()
+        C.memmove(users, ut.ctypes.data, n_users * 112)
+        bufs = [L.u8buf(x) for x in (hnsw_index, hnsw_vectors, ivf_index, ivf_vectors)]
+        q, keep = _quant(quantizer, num_features)
+        a = []
+        for buf in bufs:
+            a += [L.ptr(buf, C.c_uint8), C.c_size_t(buf.size)]
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mdb_multi_spann_load(ctx.h, users, C.c_size_t(n_users), C.c_uint32(num_features), *a,
+                                               C.byref(q), C.c_uint32(shard_rank), C.c_uint32(shard_world),
+                                               C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mdb_multi_spann_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_users(self):
+        return int(self.ctx.lib.mdb_multi_spann_num_users(self.h))
+
+    def search_for_user(self, user_ids, queries, params):
+        """Batch of (user_id, query) pairs; found[i] == 0 mirrors `None`."""
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        out = _OutBuf(b, params.top_k)
+        p = params.to_c()
+        self.ctx.check(self.ctx.lib.mdb_multi_spann_search(self.h, L.u128_array(list(user_ids)), L.ptr(q, C.c_float),
+                                                           C.c_size_t(b), C.byref(p), C.c_int(L.MEM_HOST), *out.args(),
+                                                           L.ptr(out.found, C.c_uint8)))
+        return out.result()
+
+    def search_for_users(self, user_ids, query, params):
+        """Snapshot::search_for_users (collection/snapshot.rs:39-66): one query fanned to several
+        users, concatenated, sorted by (score, doc id), truncated to top_k."""
+        res = self.search_for_user(list(user_ids), np.repeat(L.f32(query).reshape(1, -1), len(user_ids), 0), params)
+        rows = []
+        for i in range(len(user_ids)):
+            if res.found[i]:
+                rows += res.id_with_scores(i)
+        rows.sort(key=lambda r: (np.isnan(r[1]), r[1], r[0]))
+        return rows[:params.top_k]
+
+    def invalidate(self, user_id, doc_id):
+        flags = np.zeros(1, np.uint8)
+        self.ctx.check(self.ctx.lib.mdb_multi_spann_invalidate(self.h, L.u128_array([user_id]), L.u128_array([doc_id]),
+                                                               C.c_size_t(1), L.ptr(flags, C.c_uint8)))
+        return bool(flags[0])

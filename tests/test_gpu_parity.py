@@ -1,0 +1,277 @@
+"""GPU parity tests (-m gpu): every call goes through the C ABI (libmuopdb_hip.so) and is
+compared with the CPU oracle on the same seeded inputs.  Bar: neighbour ids bit-exact; f32
+scores bit-exact too (the kernels keep the reference's lane association), asserted at the
+north-star tolerance 1e-4 relative AND, separately, exactly.
+"""
+import numpy as np
+import pytest
+
+from muopdb_amd import formats as F
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # BASELINE.json north_star: "distances within 1e-4 relative for f32"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from muopdb_amd import lib as L
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def assert_scores(gpu, cpu):
+    gpu, cpu = np.asarray(gpu, np.float32), np.asarray(cpu, np.float32)
+    fin = np.isfinite(cpu)
+    assert np.array_equal(np.isfinite(gpu), fin)
+    assert np.allclose(gpu[fin], cpu[fin], rtol=RTOL, atol=0)
+    assert np.array_equal(gpu[fin].view(np.uint32), cpu[fin].view(np.uint32)), "scores are not bit-identical"
+
+
+def assert_result_rows(res, ores, b):
+    for qi in range(b):
+        assert int(res.counts[qi]) == int(ores.counts[qi])
+        assert res.doc_ids(qi) == ores.doc_ids(qi), "query %d" % qi
+        n = int(res.counts[qi])
+        assert_scores(res.scores[qi, :n], ores.scores[qi, :n])
+
+
+# ----------------------------------------------------------------------------------- D1/D2 seams
+@pytest.mark.parametrize("d", [1, 3, 4, 5, 8, 9, 12, 15, 16, 17, 24, 30, 31, 32, 33, 100, 128, 768, 1000])
+def test_pair_distances(ctx, oracle, d):
+    rng = np.random.default_rng(d)
+    a = (rng.standard_normal((64, d)) * 10).astype(np.float32)
+    b = (rng.standard_normal((64, d)) * 10).astype(np.float32)
+    l2 = ctx.l2_distance(a, b)
+    l2sq = ctx.l2_distance(a, b, squared=True)
+    dot = ctx.dot_distance(a, b)
+    assert_scores(l2, [oracle.l2(x, y) for x, y in zip(a, b)])
+    assert_scores(l2sq, [oracle.l2_squared(x, y) for x, y in zip(a, b)])
+    assert_scores(dot, [oracle.dot(x, y) for x, y in zip(a, b)])
+
+
+def test_sqrt_is_correctly_rounded(ctx):
+    rng = np.random.default_rng(0)
+    x = np.abs(rng.standard_normal(4096).astype(np.float32)) * np.float32(10) ** rng.integers(-10, 10, 4096).astype(np.float32)
+    a = np.sqrt(x.astype(np.float32)).reshape(-1, 1)
+    got = ctx.l2_distance(x.reshape(-1, 1), np.zeros((4096, 1), np.float32), squared=False)
+    want = np.sqrt((x * x).astype(np.float32))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert a is not None
+
+
+# ----------------------------------------------------------------------------------- Q3 seams
+@pytest.mark.parametrize("d,sub,bits", [(128, 8, 8), (128, 4, 4), (256, 16, 8), (128, 32, 4), (64, 8, 1), (10, 2, 1),
+                                        (3, 1, 1), (30, 6, 3), (48, 12, 5), (40, 20, 2), (21, 7, 2)])
+def test_pq_quantize_and_distance(ctx, oracle, d, sub, bits):
+    from muopdb_amd.index import ProductQuantizer
+    from muopdb_amd import lib as L
+    rng = np.random.default_rng(d * 31 + sub)
+    m, K = d // sub, 1 << bits
+    cb = rng.random(m * K * sub, dtype=np.float32)
+    for metric in (L.METRIC_L2, L.METRIC_DOT):
+        pq = ProductQuantizer(d, sub, bits, cb, metric)
+        opq = oracle.ProductQuantizer(d, sub, bits, cb, metric)
+        v = rng.random((200, d), dtype=np.float32)
+        codes = pq.quantize(ctx, v)
+        assert np.array_equal(codes, opq.quantize(v))
+        a = rng.integers(0, K, (300, m)).astype(np.uint8)
+        b = rng.integers(0, K, (300, m)).astype(np.uint8)
+        for impl, oimpl in ((L.IMPL_STREAMING_SIMD, oracle.PQ_STREAMING), (L.IMPL_SIMD, oracle.PQ_SIMD),
+                            (L.IMPL_SCALAR, oracle.PQ_SCALAR)):
+            if metric == L.METRIC_DOT and impl == L.IMPL_SCALAR:
+                continue  # the Scalar arm is L2-only in the reference (pq/mod.rs:221-230)
+            assert_scores(pq.distance(ctx, a, b, impl), opq.distance(a, b, oimpl))
+
+
+def test_k5_k6_pq_quantize_kat(ctx):
+    # reference KATs straight through the GPU path (ivf/writer.rs:511-676, pq/mod.rs:321-371)
+    from muopdb_amd.index import ProductQuantizer
+    pq = ProductQuantizer(3, 1, 1, [1.5, 4.5, 2.3, 5.3, 3.1, 6.1])
+    assert pq.quantize(ctx, [[1, 2, 3], [4, 5, 6]]).tolist() == [[0, 0, 0], [1, 1, 1]]
+    cb = []
+    for s in range(5):
+        for i in range(2):
+            cb += [2 * s + i, 2 * s + i]
+    pq = ProductQuantizer(10, 2, 1, cb)
+    assert pq.quantize(ctx, [[1, 1, 3, 3, 5, 5, 7, 7, 9, 9]]).tolist() == [[1, 1, 1, 1, 1]]
+
+
+# ----------------------------------------------------------------------------------- E1
+@pytest.mark.parametrize("values,universe", [
+    ([5, 8, 8, 15, 32], 36), ([0, 1, 2, 3, 4], 5), ([10], 20), ([1000, 2000, 3000, 4000, 5000], 6000),
+    ([1, 5, 10, 15, 20, 25, 30], 100), (list(range(1, 201)), 500), ([42], 100)])
+def test_ef_decode_kat(ctx, values, universe):
+    assert ctx.ef_decode(F.ef_encode(values, universe)).tolist() == values
+
+
+def test_ef_decode_random(ctx, oracle):
+    rng = np.random.default_rng(4)
+    for n, bits in [(1, 3), (63, 10), (64, 20), (65, 31), (1000, 12), (5000, 32), (20000, 24), (300, 40), (7, 63)]:
+        v = np.sort(rng.integers(0, 1 << bits, n, dtype=np.uint64))
+        blob = F.ef_encode(v)
+        assert np.array_equal(ctx.ef_decode(blob), v)
+        assert np.array_equal(oracle.ef_decode(blob), v)
+    assert ctx.ef_decode(F.ef_encode([])).tolist() == []
+    dense = np.arange(100000, dtype=np.uint64)  # L = 0, all gaps 0/1
+    assert np.array_equal(ctx.ef_decode(F.ef_encode(dense)), dense)
+
+
+# ----------------------------------------------------------------------------------- flat (C1)
+@pytest.mark.parametrize("n,d,b,k,metric", [(1000, 128, 1, 10, 0), (1000, 128, 7, 10, 1), (10000, 128, 16, 10, 0),
+                                            (777, 30, 5, 3, 0), (300, 17, 4, 300, 1), (64, 4, 2, 100, 0),
+                                            (5000, 768, 3, 20, 0), (1, 8, 1, 1, 0), (4097, 16, 9, 1, 1)])
+def test_flat_topk(ctx, oracle, n, d, b, k, metric):
+    from muopdb_amd.index import FlatIndex
+    rng = np.random.default_rng(n + d)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((b, d)).astype(np.float32)
+    idx = FlatIndex(ctx, base, metric)
+    ids, dist, counts = idx.search(q, k)
+    oids, odist = oracle.flat_topk(metric, base, q, k)
+    kk = min(k, n)
+    assert counts.tolist() == [kk] * b
+    assert np.array_equal(ids[:, :kk], oids[:, :kk])
+    assert_scores(dist[:, :kk], odist[:, :kk])
+    assert np.all(ids[:, kk:] == 0xFFFFFFFF)
+
+
+def test_flat_c1_dataset_and_ties(ctx, oracle):
+    from muopdb_amd.index import FlatIndex
+    base = H.test_hdf5_like()  # BASELINE config C1: 10k x 128 (py/create_test_hdf5.py semantics)
+    q = H.test_hdf5_like(n_per=10, seed=43)[:32]
+    idx = FlatIndex(ctx, base)
+    ids, dist, _ = idx.search(q, 10)
+    oids, odist = oracle.flat_topk(0, base, q, 10)
+    assert np.array_equal(ids, oids)
+    assert_scores(dist, odist)
+    d64 = np.sqrt(((q[:, None, :].astype(np.float64) - base[None]) ** 2).sum(-1))
+    assert np.array_equal(np.sort(ids, 1), np.sort(np.argsort(d64, 1)[:, :10], 1))  # recall@10 = 1.0 vs f64
+    # exact ties: duplicated rows must come out ordered by row id
+    dup = np.repeat(base[:50], 4, axis=0)
+    idx2 = FlatIndex(ctx, dup)
+    ids2, dist2, _ = idx2.search(base[:5], 8)
+    oids2, odist2 = oracle.flat_topk(0, dup, base[:5], 8)
+    assert np.array_equal(ids2, oids2)
+    assert ids2[0, :4].tolist() == [0, 1, 2, 3]
+
+
+def test_flat_nan_is_an_error(ctx):
+    from muopdb_amd.index import FlatIndex
+    from muopdb_amd import lib as L
+    base = np.zeros((10, 4), np.float32)
+    base[3, 1] = np.nan
+    idx = FlatIndex(ctx, base)
+    with pytest.raises(L.MuopdbError) as e:
+        idx.search(np.zeros((1, 4), np.float32), 2)
+    assert e.value.status == 5  # MDB_ERR_NAN: the reference panics in NotNan::new(..).unwrap()
+    ids, _, _ = FlatIndex(ctx, np.ones((10, 4), np.float32)).search(np.zeros((1, 4), np.float32), 2)  # context still usable
+    assert ids.tolist() == [[0, 1]]
+
+
+# ----------------------------------------------------------------------------------- IVF (I1-I3)
+def _ivf_case(oracle, ctx, n, d, L, seed, quant=None, cpv=1, doc_base=100):
+    from muopdb_amd.index import BlockBasedIvf, ProductQuantizer
+    rng = np.random.default_rng(seed)
+    v = H.sift_like(n, d, n_clusters=max(L // 2, 1), seed=seed)
+    c = H.kmeans(v, L, iters=4, seed=seed)
+    doc_ids = [doc_base + 3 * i + ((i % 7) << 70) for i in range(n)]
+    if quant:
+        sub, bits = quant
+        cb = H.train_pq_codebook(v[: min(n, 2000)], sub, bits, iters=3)
+        opq = oracle.ProductQuantizer(d, sub, bits, cb)
+        index, vec, pls = H.build_ivf_files(v, doc_ids, c, quantize=opq.quantize, clusters_per_vector=cpv)
+        oq = oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, sub, bits, cb)
+        gq = ProductQuantizer(d, sub, bits, cb)
+    else:
+        index, vec, pls = H.build_ivf_files(v, doc_ids, c, clusters_per_vector=cpv)
+        oq, gq = None, None
+    o = oracle.BlockBasedIvf(index, vec, oq)
+    g = BlockBasedIvf(ctx, index, vec, gq)
+    q = v[rng.integers(0, n, 24)] + rng.normal(0, 2, (24, d)).astype(np.float32)
+    return o, g, q.astype(np.float32), v, doc_ids
+
+
+@pytest.mark.parametrize("n,d,L,P,k", [(3000, 32, 20, 5, 10), (3000, 128, 40, 40, 10), (500, 4, 10, 1, 3),
+                                       (2000, 100, 7, 3, 50), (4000, 768, 16, 4, 10)])
+def test_ivf_noq(ctx, oracle, n, d, L, P, k):
+    o, g, q, v, doc_ids = _ivf_case(oracle, ctx, n, d, L, seed=n + d)
+    assert g.num_clusters() == L and g.num_vectors() == n
+    assert np.array_equal(g.find_nearest_centroids(q, P), o.find_nearest_centroids(q, P))
+    assert_result_rows(g.search(q, k, P), o.search(q, k, num_probes=P), len(q))
+    probes = o.find_nearest_centroids(q, P)[:, ::-1].copy()  # explicit centroid ids, any order
+    assert_result_rows(g.search_with_centroids_and_remap(q, probes, k), o.search(q, k, probes=probes), len(q))
+
+
+@pytest.mark.parametrize("n,d,sub,bits,L,P,k", [(4000, 128, 8, 8, 32, 8, 10), (3000, 64, 4, 4, 10, 10, 25),
+                                                (2000, 30, 6, 3, 8, 3, 10), (2000, 48, 16, 6, 8, 8, 5),
+                                                (1500, 21, 7, 2, 6, 6, 7)])
+def test_ivf_pq(ctx, oracle, n, d, sub, bits, L, P, k):
+    o, g, q, v, doc_ids = _ivf_case(oracle, ctx, n, d, L, seed=n + d + sub, quant=(sub, bits))
+    assert_result_rows(g.search(q, k, P), o.search(q, k, num_probes=P), len(q))
+
+
+def test_ivf_duplicates_tombstones_and_errors(ctx, oracle):
+    from muopdb_amd import lib as L
+    o, g, q, v, doc_ids = _ivf_case(oracle, ctx, 1200, 16, 6, seed=5, cpv=2)
+    # a point in two probed lists is returned twice (index.rs:250-286 has no dedup)
+    r, ro = g.search(q, 10, 6), o.search(q, 10, num_probes=6)
+    assert_result_rows(r, ro, len(q))
+    assert any(len(set(r.doc_ids(i))) < len(r.doc_ids(i)) for i in range(len(q)))
+    # invalidate (index.rs:421-470)
+    victims = ro.doc_ids(0)[:3]
+    for d_ in victims:
+        assert g.invalidate(d_) == o.invalidate(d_)
+    assert not g.invalidate(victims[0]) and g.is_invalidated(victims[0]) and not g.invalidate(12345678901)
+    assert not g.is_invalidated(doc_ids[-1])
+    assert_result_rows(g.search(q, 10, 6), o.search(q, 10, num_probes=6), len(q))
+    assert not set(victims) & set(g.search(q, 10, 6).doc_ids(0))
+    # num_probes out of range: the reference panics (select_nth_unstable_by(num_probes - 1))
+    for bad in (0, 7):
+        with pytest.raises(L.MuopdbError) as e:
+            g.find_nearest_centroids(q, bad)
+        assert e.value.status == 8
+    # k larger than the candidates: short rows, padded
+    r = g.search(q[:2], 2000, 1)
+    ro = o.search(q[:2], 2000, num_probes=1)
+    assert_result_rows(r, ro, 2)
+    assert int(r.counts[0]) < 2000 and r.doc_lo[0, int(r.counts[0])] == 0xFFFFFFFFFFFFFFFF
+    # k = 0
+    assert g.search(q[:2], 0, 2).counts.tolist() == [0, 0]
+
+
+def test_ivf_kat_k7_container(ctx, oracle):
+    # hand-assembled container of combined_file.rs:172-300 searched through the GPU path
+    from muopdb_amd.index import BlockBasedIvf
+    centroids = np.array([[1, 2, 3, 4], [5, 6, 7, 8]], np.float32)
+    vecs = np.array([[1, 2, 3, 4], [1, 2, 3, 5], [5, 6, 7, 8], [5, 6, 7, 9]], np.float32)
+    index = F.write_ivf_index(centroids, [100, 200, 300, 400], [np.array([0, 1], np.uint64), np.array([2, 3], np.uint64)])
+    g = BlockBasedIvf(ctx, index, F.write_vector_file(vecs))
+    r = g.search([[5, 6, 7, 8.4]], 3, 1)
+    assert r.doc_ids(0) == [300, 400] and r.counts[0] == 2
+    assert g.find_nearest_centroids([[1, 2, 3, 4]], 2).tolist() == [[0, 1]]
+    # empty posting list + offset load (multi-user style): blob placed at a 16-aligned offset
+    index2 = F.write_ivf_index(centroids, [1, 2], [np.array([], np.uint64), np.array([0, 1], np.uint64)])
+    pad_i, pad_v = b"\xAA" * 32, b"\xBB" * 24
+    g2 = BlockBasedIvf(ctx, pad_i + index2, pad_v + F.write_vector_file(vecs[:2]), index_offset=32, vector_offset=24)
+    assert g2.search([[1, 2, 3, 4]], 5, 2).doc_ids(0) == [1, 2]
+    assert g2.search([[1, 2, 3, 4]], 5, 1).counts[0] == 0  # nearest list is the empty one
+
+
+def test_ivf_sharded_union_equals_unsharded(ctx, oracle):
+    # list sharding: the union of per-shard top-k == the single-GPU top-k
+    from muopdb_amd.index import BlockBasedIvf
+    o, g, q, v, doc_ids = _ivf_case(oracle, ctx, 3000, 32, 12, seed=77)
+    index, vec, _ = H.build_ivf_files(v, doc_ids, H.kmeans(v, 12, iters=4, seed=77))
+    full_ids, full_sc, full_cn = g.search_points(q, 10, 5)
+    shards = [BlockBasedIvf(ctx, index, vec, shard_rank=r, shard_world=3) for r in range(3)]
+    probes = g.find_nearest_centroids(q, 5)
+    for qi in range(len(q)):
+        rows = []
+        for s in shards:
+            ids, sc, cn = s.search_points(q[qi:qi + 1], 10, 5, probes=probes[qi:qi + 1])
+            rows += list(zip(sc[0, :cn[0]].tolist(), ids[0, :cn[0]].tolist()))
+        rows.sort()
+        assert [r[1] for r in rows[:10]] == full_ids[qi, :full_cn[qi]].tolist()
