@@ -27,6 +27,9 @@ struct mdb_ctx {
     mdb_stats stats{};
     uint32_t* d_flags = nullptr;   // device word: bit0 NaN seen, bit1 capacity overflow
     uint32_t* h_flags = nullptr;   // pinned host mirror
+    unsigned long long* d_counters = nullptr;  // [0] HNSW distance evals [1] expanded nodes [2] scored vectors [3] spare
+    unsigned long long* h_counters = nullptr;
+    uint64_t stat_bytes_per_eval = 0, stat_bytes_per_scored = 0, stat_fixed_bytes = 0;
     // growable device scratch (never shrinks; no allocation in steady state)
     void* scratch[8] = {nullptr};
     size_t scratch_cap[8] = {0};

@@ -57,7 +57,8 @@ mdb_status mdb_device_open(int gpu, mdb_ctx** out) {
     ctx->device = gpu;
     if (hipSetDevice(gpu) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_flags, 4) != hipSuccess || hipHostMalloc((void**)&ctx->h_flags, 4) != hipSuccess ||
-        hipMemset(ctx->d_flags, 0, 4) != hipSuccess) {
+        hipMemset(ctx->d_flags, 0, 4) != hipSuccess || hipMalloc((void**)&ctx->d_counters, 32) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_counters, 32) != hipSuccess || hipMemset(ctx->d_counters, 0, 32) != hipSuccess) {
         delete ctx;
         return MDB_ERR_HIP;
     }
@@ -74,6 +75,8 @@ void mdb_device_close(mdb_ctx* ctx) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -105,7 +108,16 @@ const char* mdb_last_error(mdb_ctx* ctx) { return ctx ? ctx->last_error.c_str() 
 
 mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out) {
     if (!ctx || !out) return MDB_ERR_INVALID_ARG;
-    *out = ctx->stats;
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    MDB_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 32, hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    mdb_stats st = ctx->stats;
+    st.distance_evals = ctx->h_counters[0];
+    st.expanded_nodes = ctx->h_counters[1];
+    if (ctx->h_counters[2]) st.scored_vectors = ctx->h_counters[2];
+    st.algorithmic_bytes = ctx->stat_fixed_bytes + st.distance_evals * ctx->stat_bytes_per_eval +
+                           st.expanded_nodes * 16 + st.scored_vectors * ctx->stat_bytes_per_scored;
+    *out = st;
     return MDB_OK;
 }
 
@@ -125,7 +137,7 @@ __global__ __launch_bounds__(256) void pair_distance_kernel(const float* __restr
     float raw[1];
     exact_sums<METRIC, 1>(lb, a + i * p.d, 0, p, raw);
     float r = raw[0];
-    if (METRIC == MDB_METRIC_L2) out[i] = mode ? r : __fsqrt_rn(r);
+    if (METRIC == MDB_METRIC_L2) out[i] = mode ? r : mdb_sqrtf(r);
     else out[i] = -r;
 }
 
@@ -239,11 +251,11 @@ __global__ __launch_bounds__(256) void pq_pair_distance_kernel(const uint8_t* __
                 float df = __fsub_rn(av[e], bv[e]);
                 t = __fadd_rn(t, __fmul_rn(df, df));
             }
-            dist = __fsqrt_rn(t);
+            dist = mdb_sqrtf(t);
         } else {  // SIMD: D::calculate
             RowLoader lb{bv, subdim};
             float raw[1];
-            if (metric == MDB_METRIC_L2) { exact_sums<MDB_METRIC_L2, 1>(lb, av, 0, spl2, raw); dist = __fsqrt_rn(raw[0]); }
+            if (metric == MDB_METRIC_L2) { exact_sums<MDB_METRIC_L2, 1>(lb, av, 0, spl2, raw); dist = mdb_sqrtf(raw[0]); }
             else { exact_sums<MDB_METRIC_DOT, 1>(lb, av, 0, sp, raw); dist = -raw[0]; }
         }
         sum = __fadd_rn(sum, __fmul_rn(dist, dist));

@@ -10,6 +10,13 @@
 #pragma once
 #include "mdb_common.h"
 
+// Rust never contracts a*b+c; keep every mul/add separately rounded in ALL device code of this
+// library (build.sh also passes -ffp-contract=off).  NOTE: hip's __fmul_rn/__fadd_rn are plain
+// operators and __fsqrt_rn is the NATIVE (1 ulp) sqrt — so sqrtf() (correctly rounded
+// __ocml_sqrt_f32) is used for DistanceCalculator::calculate.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float mdb_sqrtf(float x) { return sqrtf(x); }
+
 // ------------------------------------------------------------------------------------------ keys
 __device__ __forceinline__ uint32_t f32_orderable(float f) {
     uint32_t u = __float_as_uint(f);
@@ -149,7 +156,7 @@ __device__ __forceinline__ void exact_sums(const Loader& ld, const float* __rest
 // DistanceCalculator::calculate: sqrt for L2 (l2.rs:72-74), negation for dot (dot_product.rs:25-27)
 template <int METRIC>
 __device__ __forceinline__ float finish_distance(float raw) {
-    return METRIC == MDB_METRIC_L2 ? __fsqrt_rn(raw) : -raw;
+    return METRIC == MDB_METRIC_L2 ? mdb_sqrtf(raw) : -raw;
 }
 
 // ------------------------------------------------------------------------------------------ BlockSelect

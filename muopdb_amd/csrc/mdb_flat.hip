@@ -273,9 +273,12 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     MDB_TRY(mdb_scratch(ctx, 5, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4, &cnts));
     MDB_TRY(flat_topk_keys(ctx, view_of(flat->ts), flat->metric, dq, qstride, b, k, (uint64_t*)keys, (uint32_t*)cnts));
+    // one pass = N*d*4 B read once per batch + queries + outputs
     ctx->stats = mdb_stats{};
     ctx->stats.scored_vectors = (uint64_t)b * flat->ts.n;
-    ctx->stats.algorithmic_bytes = (uint64_t)flat->ts.n * flat->ts.d * 4 + (uint64_t)b * flat->ts.d * 4 + (uint64_t)b * k * 8;
+    MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    ctx->stat_bytes_per_eval = 0; ctx->stat_bytes_per_scored = 0;
+    ctx->stat_fixed_bytes = (uint64_t)flat->ts.n * flat->ts.d * 4 + (uint64_t)b * flat->ts.d * 4 + (uint64_t)b * k * 8;
     size_t total = b * k;
     if (mem == MDB_MEM_DEVICE) {
         if (total) unpack_keys_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((uint64_t*)keys, total, ids_out, dist_out);

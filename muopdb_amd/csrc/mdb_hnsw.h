@@ -1,0 +1,56 @@
+// mdb_hnsw.h — HnswSet: one or many (multi-user) HNSW graphs resident in HBM.
+#pragma once
+#include <utility>
+
+#include "mdb_common.h"
+
+// per-user (per-graph) descriptor read by the traversal kernel
+struct HnswUserDev {
+    uint32_t valid;
+    uint32_t n;            // number of vectors (point ids are < n)
+    uint32_t n0;           // number of layer-0 adjacency rows
+    uint32_t num_layers;
+    uint32_t entry_point;  // graph_storage.rs:527-558
+    uint32_t S0, SU;       // fixed row strides of the layer-0 / upper-layer adjacency
+    uint32_t pad;
+    uint64_t adj0_off;     // u32 index into the adjacency arena
+    uint64_t adjU_off;
+    uint64_t upper_off;    // index into upper_first[] / level[] (per point)
+    uint64_t vec_off;      // float index into the vector arena (row stride dpad)
+    uint64_t doc_ids_off;  // byte offset of doc id 0 inside the uploaded index bytes
+};
+
+struct HnswBlobInfo {
+    uint32_t quantized_dimension = 0, num_layers = 0;
+    uint64_t edges_len = 0, points_len = 0, edge_offsets_len = 0, level_offsets_len = 0, doc_id_mapping_len = 0;
+    size_t edges_offset = 0, points_offset = 0, edge_offsets_offset = 0, level_offsets_offset = 0, doc_id_mapping_offset = 0;
+    uint64_t num_vectors = 0;
+    size_t vec_data_offset = 0;
+};
+
+struct HnswSet {
+    mdb_ctx* ctx = nullptr;
+    int metric = MDB_METRIC_L2;
+    uint32_t dimension = 0;
+    int dpad = 0;
+    std::vector<HnswBlobInfo> blobs;
+    std::vector<HnswUserDev> h_users;
+    uint32_t max_n = 0, max_stride = 0;
+    uint64_t total_rows = 0;
+    DevBuf<uint8_t> d_index;       // uploaded graph file (doc ids are read from it)
+    DevBuf<HnswUserDev> d_users;
+    DevBuf<uint32_t> d_adj;        // layer-0 rows then upper rows, per user
+    DevBuf<uint32_t> d_upper_first;
+    DevBuf<uint8_t> d_level;
+    DevBuf<float> d_vecs;          // [total_rows][dpad], 16-byte aligned rows
+
+    mdb_status load(mdb_ctx* ctx, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
+                    const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant, uint32_t dimension);
+    // beam search of every query through its user's graph: device keys [b][k] (distance, point id)
+    // ascending + counts.  d_q_user == nullptr => user 0.
+    mdb_status search(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, size_t k, uint32_t ef,
+                      uint64_t* d_keys, uint32_t* d_counts);
+    // keys -> (u128 doc id, score) rows in key order (ann_search :192-208 does not re-sort)
+    mdb_status remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,
+                     mdb_u128* d_doc, float* d_score, uint32_t* d_counts_out);
+};

@@ -102,6 +102,7 @@ struct ScanArgs {
     int k;
     uint64_t* partial;             // [B][nsplit][k]
     uint32_t* flags;
+    unsigned long long* counters;  // [2] += scored vectors
 };
 
 __device__ __forceinline__ bool tomb_test(const uint32_t* tomb, uint32_t base_word, uint32_t pid) {
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
     const float* qb = q + (size_t)qi * qstride;
     const int np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
     bool nan_seen = false, bad = false;
+    unsigned scored = 0;
     if (u.valid) {
         for (int j = split; j < np; j += nsplit) {
             uint32_t c = a.probes[(size_t)qi * a.probe_stride + j];
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
                         float dist = finish_distance<METRIC>(raw[0]);
                         if (dist != dist) nan_seen = true;
                         key = make_key(dist, pid);
+                        ++scored;
                     }
                 }
                 sel.offer(key);
@@ -148,6 +151,12 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
     }
     if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
     if (bad) atomicOr(a.flags, MDB_FLAG_RANGE);
+    {
+        unsigned long long ws = scored;  // wave total -> one atomic per wave
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) ws += __shfl_xor((unsigned)ws, m);
+        if (lane == 0 && ws) atomicAdd(&a.counters[2], ws);
+    }
     sel.finish();
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_pq_kernel(ScanArgs a, cons
     const uint8_t* qc = qcodes + (size_t)qi * m;
     const int np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
     bool nan_seen = false, bad = false;
+    unsigned scored = 0;
     if (LUT_LDS) {
         const int rowlen = K * subdim, total = m * rowlen;
         for (int i = threadIdx.x; i < total; i += MDB_BLOCK) {
@@ -242,6 +252,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_pq_kernel(ScanArgs a, cons
                         float dist = METRIC == MDB_METRIC_L2 ? r : -r;
                         if (dist != dist) nan_seen = true;
                         key = make_key(dist, pid);
+                        ++scored;
                     }
                 }
                 sel.offer(key);
@@ -251,6 +262,12 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_pq_kernel(ScanArgs a, cons
     }
     if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
     if (bad) atomicOr(a.flags, MDB_FLAG_RANGE);
+    {
+        unsigned long long ws = scored;  // wave total -> one atomic per wave
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) ws += __shfl_xor((unsigned)ws, m);
+        if (lane == 0 && ws) atomicAdd(&a.counters[2], ws);
+    }
     sel.finish();
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
@@ -340,7 +357,7 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
     metric = quant ? quant->metric : MDB_METRIC_L2;
     const size_t U = offsets.size();
     blobs.resize(U);
-    h_users.assign(U, IvfUserDev{});
+    h_users.assign(U + 1, IvfUserDev{});  // [U] = sentinel (valid = 0): unknown user => None
     std::vector<uint64_t> list_byte_off;   // per global list (or ~0 when not owned / empty)
     std::vector<uint32_t> list_len;
     std::vector<uint32_t> h_list_tile_off(1, 0);
@@ -435,8 +452,8 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
     MDB_TRY(up32(d_ctfirst, cent_tile_first));
     MDB_TRY(up32(d_ctlim, cent_tile_limit));
     MDB_TRY(up32(d_list_tile_off, h_list_tile_off));
-    if (d_users.alloc(U + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
-    MDB_HIP(ctx, hipMemcpyAsync(d_users.p, h_users.data(), U * sizeof(IvfUserDev), hipMemcpyHostToDevice, ctx->stream));
+    if (d_users.alloc(U + 2) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
+    MDB_HIP(ctx, hipMemcpyAsync(d_users.p, h_users.data(), (U + 1) * sizeof(IvfUserDev), hipMemcpyHostToDevice, ctx->stream));
     h_tomb.assign(tomb_words + 1, 0);
     if (d_tomb.alloc(tomb_words + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
     MDB_HIP(ctx, hipMemsetAsync(d_tomb.p, 0, (tomb_words + 1) * 4, ctx->stream));
@@ -540,7 +557,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     void* partial;
     MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)nsplit * std::max<size_t>(k, 1) * 8, &partial));
     ScanArgs a{d_users.p, d_q_user, d_list_tile_off.p, d_slot_ids.p, d_tomb.p, d_probes, d_probe_cnt, probe_stride,
-               (int)k, (uint64_t*)partial, ctx->d_flags};
+               (int)k, (uint64_t*)partial, ctx->d_flags, ctx->d_counters};
     dim3 grid((unsigned)nsplit, (unsigned)b);
     size_t sel_lds = BlockSelect<MDB_BLOCK>::lds_bytes((int)k);
     if (kind == MDB_QUANT_PQ) {
@@ -637,8 +654,10 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
     void *keys, *cnts;
     MDB_TRY(mdb_scratch(ctx, 3, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4 + 16, &cnts));
-    MDB_TRY(s.scan(dq, qstride, b, nullptr, (uint32_t*)dprobes, nullptr, (int)num_probes, k, (uint64_t*)keys, (uint32_t*)cnts));
+    MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
     ctx->stats = mdb_stats{};
+    ctx->stat_bytes_per_eval = 0; ctx->stat_bytes_per_scored = s.bytes_per_scored(); ctx->stat_fixed_bytes = 0;
+    MDB_TRY(s.scan(dq, qstride, b, nullptr, (uint32_t*)dprobes, nullptr, (int)num_probes, k, (uint64_t*)keys, (uint32_t*)cnts));
     size_t total = b * k;
     if (mem == MDB_MEM_DEVICE) {
         if (remap) MDB_TRY(s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, (mdb_u128*)ids_out, scores_out, counts_out));

@@ -1,0 +1,334 @@
+// mdb_spann.hip — SPANN and multi-user SPANN search and the
+// per-shard result merge of the multi-GPU path (§8e).
+//
+// Spann::search (rs/index/src/spann/index.rs:211-266) for a BATCH of queries:
+//   1. centroid graph:  BlockBasedHnsw::ann_search(query, k = num_explored_centroids.unwrap_or(top_k),
+//                       ef = params.ef_construction)                      -> mdb_hnsw.hip
+//   2. ratio filter:    keep centroids with score - nearest <= nearest * centroid_distance_ratio
+//                       (:233-246; f32 sub and mul separately rounded)     -> spann_filter_kernel
+//   3. posting lists:   search_with_centroids_and_remap(query, kept ids, top_k)  -> mdb_ivf.hip
+// MultiSpannIndex::search_for_user (multi_spann/index.rs:282-293): every user's graph and
+// posting lists live in shared HBM arenas; a batch mixes users freely through a per-query user
+// index, so one launch per stage serves the whole batch (the reference opens one Spann per user
+// lazily and searches them one at a time).
+#include <unordered_map>
+
+#include "mdb_device.cuh"
+#include "mdb_hnsw.h"
+#include "mdb_ivf.h"
+#include "mdb_kernels.h"
+
+struct SpannSet {
+    mdb_ctx* ctx = nullptr;
+    HnswSet hnsw;
+    IvfSet ivf;
+    std::unordered_map<U128Key, uint32_t, U128Hash> user_index;
+    size_t num_users = 0;
+};
+
+// one thread per query (B is small); candidates come sorted by (distance, point id)
+__global__ void spann_filter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int nexp,
+                                    float ratio, const HnswUserDev* __restrict__ husers, const IvfUserDev* __restrict__ iusers,
+                                    const uint32_t* __restrict__ q_user, const uint8_t* __restrict__ hnsw_index_bytes,
+                                    uint32_t* __restrict__ probes, uint32_t* __restrict__ probe_cnt, uint8_t* __restrict__ found,
+                                    size_t b, uint32_t* __restrict__ flags) {
+    size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= b) return;
+    uint32_t ui = q_user ? q_user[qi] : 0;
+    const HnswUserDev hu = husers[ui];
+    const IvfUserDev iu = iusers[ui];
+    int c = (int)counts[qi];
+    if (!hu.valid || !iu.valid || c == 0) {  // unknown user / empty centroid result => None (:229-231)
+        probe_cnt[qi] = 0;
+        found[qi] = 0;
+        return;
+    }
+    found[qi] = 1;
+    float nearest = key_dist(keys[qi * (size_t)nexp]);  // min_by partial_cmp (:233-237): the list is ascending
+    for (int i = 1; i < c; ++i) {
+        float s = key_dist(keys[qi * (size_t)nexp + i]);
+        if (s < nearest) nearest = s;
+    }
+    float rhs = __fmul_rn(nearest, ratio);
+    uint32_t n = 0;
+    for (int i = 0; i < c; ++i) {
+        uint64_t key = keys[qi * (size_t)nexp + i];
+        float lhs = __fsub_rn(key_dist(key), nearest);
+        if (lhs <= rhs) {
+            // `x.doc_id as usize`: the centroid graph's doc id is the centroid (posting list) index
+            const uint64_t* dp = (const uint64_t*)(hnsw_index_bytes + hu.doc_ids_off + (size_t)key_id(key) * 16);
+            uint64_t cid = dp[0];
+            if (dp[1] != 0 || cid >= iu.num_lists) { atomicOr(flags, MDB_FLAG_RANGE); continue; }
+            probes[qi * (size_t)nexp + n++] = (uint32_t)cid;
+        }
+    }
+    probe_cnt[qi] = n;
+}
+
+static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b, const uint32_t* h_q_user,
+                                    const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out,
+                                    uint32_t* counts_out, uint8_t* found_out) {
+    mdb_ctx* ctx = s.ctx;
+    if (b == 0) return MDB_OK;
+    const size_t k = params->top_k;
+    const size_t nexp = params->num_explored_centroids < 0 ? k : (size_t)params->num_explored_centroids;
+    if (k > MDB_MAX_K || nexp > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "top_k / num_explored_centroids exceed MDB_MAX_K=%d", MDB_MAX_K);
+    float* dq;
+    int qstride;
+    MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.ivf.num_features, mem, (b + 3) / 4 * 4, &dq, &qstride));
+    uint32_t* d_q_user = nullptr;
+    DevBuf<uint32_t> qu;
+    if (h_q_user) {
+        if (qu.alloc(b) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
+        MDB_HIP(ctx, hipMemcpyAsync(qu.p, h_q_user, b * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_q_user = qu.p;
+    }
+    DevBuf<uint64_t> ckeys, keys;
+    DevBuf<uint32_t> ccnt, probes, pcnt, cnts;
+    DevBuf<uint8_t> dfound;
+    if (ckeys.alloc(b * std::max<size_t>(nexp, 1)) != hipSuccess || ccnt.alloc(b) != hipSuccess ||
+        probes.alloc(b * std::max<size_t>(nexp, 1)) != hipSuccess || pcnt.alloc(b) != hipSuccess ||
+        keys.alloc(b * std::max<size_t>(k, 1)) != hipSuccess || cnts.alloc(b) != hipSuccess || dfound.alloc(b) != hipSuccess)
+        return mdb_fail(ctx, MDB_ERR_OOM, "spann scratch alloc");
+    MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    ctx->stats = mdb_stats{};
+    ctx->stat_bytes_per_eval = (uint64_t)s.hnsw.dimension * 4 + 4;
+    ctx->stat_bytes_per_scored = s.ivf.bytes_per_scored();
+    ctx->stat_fixed_bytes = 0;
+    MDB_TRY(s.hnsw.search(dq, qstride, b, d_q_user, nexp, params->ef_construction, ckeys.p, ccnt.p));
+    spann_filter_kernel<<<dim3((unsigned)((b + 127) / 128)), 128, 0, ctx->stream>>>(
+        ckeys.p, ccnt.p, (int)nexp, params->centroid_distance_ratio, s.hnsw.d_users.p, s.ivf.d_users.p, d_q_user,
+        s.hnsw.d_index.p, probes.p, pcnt.p, dfound.p, b, ctx->d_flags);
+    MDB_HIP(ctx, hipGetLastError());
+    MDB_TRY(s.ivf.scan(dq, qstride, b, d_q_user, probes.p, pcnt.p, (int)std::max<size_t>(nexp, 1), k, keys.p, cnts.p));
+    size_t total = b * k;
+    if (mem == MDB_MEM_DEVICE) {
+        MDB_TRY(s.ivf.remap(keys.p, cnts.p, b, k, d_q_user, doc_ids_out, scores_out, counts_out));
+        if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound.p, b, hipMemcpyDeviceToDevice, ctx->stream));
+        MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the DevBufs above are released on return
+        return MDB_OK;
+    }
+    DevBuf<mdb_u128> ddoc;
+    DevBuf<float> dsc;
+    if (ddoc.alloc(std::max<size_t>(total, 1)) != hipSuccess || dsc.alloc(std::max<size_t>(total, 1)) != hipSuccess)
+        return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
+    MDB_TRY(s.ivf.remap(keys.p, cnts.p, b, k, d_q_user, ddoc.p, dsc.p, nullptr));
+    if (total) {
+        MDB_HIP(ctx, hipMemcpyAsync(doc_ids_out, ddoc.p, total * 16, hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP(ctx, hipMemcpyAsync(scores_out, dsc.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts.p, b * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound.p, b, hipMemcpyDeviceToHost, ctx->stream));
+    return mdb_check_flags(ctx);
+}
+
+struct mdb_spann {
+    SpannSet set;
+};
+struct mdb_multi_spann {
+    SpannSet set;
+};
+
+// ------------------------------------------------------------------------------------------ shard merge
+// one block per query: rank-sort the valid rows of the `world` shards by (score, doc id), keep k
+__global__ __launch_bounds__(256) void merge_shards_kernel(const mdb_u128* __restrict__ docs, const float* __restrict__ scores,
+                                                           const uint32_t* __restrict__ counts, int world, size_t b, int k,
+                                                           mdb_u128* __restrict__ doc_out, float* __restrict__ score_out,
+                                                           uint32_t* __restrict__ counts_out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int cap = world * k;
+    uint64_t* lo = (uint64_t*)lds;
+    uint64_t* hi = lo + cap;
+    float* sc = (float*)(hi + cap);
+    uint32_t* pos = (uint32_t*)(sc + cap);  // [world+1] prefix of counts
+    const size_t qi = blockIdx.x;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int w = 0; w < world; ++w) {
+            pos[w] = acc;
+            uint32_t c = counts[(size_t)w * b + qi];
+            acc += c < (uint32_t)k ? c : (uint32_t)k;
+        }
+        pos[world] = acc;
+    }
+    __syncthreads();
+    const int n = (int)pos[world];
+    for (int t = threadIdx.x; t < cap; t += blockDim.x) {
+        int w = t / k, jj = t % k;
+        uint32_t c = pos[w + 1] - pos[w];
+        if ((uint32_t)jj < c) {
+            size_t src = ((size_t)w * b + qi) * k + jj;
+            lo[pos[w] + jj] = docs[src].lo;
+            hi[pos[w] + jj] = docs[src].hi;
+            sc[pos[w] + jj] = scores[src];
+        }
+    }
+    __syncthreads();
+    const int outc = n < k ? n : k;
+    for (int j2 = threadIdx.x; j2 < k; j2 += blockDim.x)
+        if (j2 >= outc) { doc_out[qi * k + j2] = mdb_u128{~0ull, ~0ull}; score_out[qi * k + j2] = __uint_as_float(0x7F800000u); }
+    for (int j2 = threadIdx.x; j2 < n; j2 += blockDim.x) {
+        float s = sc[j2];
+        uint64_t l = lo[j2], h = hi[j2];
+        int rank = 0;
+        for (int i = 0; i < n; ++i) {
+            float si = sc[i];
+            bool less = si < s || (si == s && (hi[i] < h || (hi[i] == h && (lo[i] < l || (lo[i] == l && i < j2)))));
+            rank += less ? 1 : 0;
+        }
+        if (rank < k) { doc_out[qi * k + rank] = mdb_u128{l, h}; score_out[qi * k + rank] = s; }
+    }
+    if (threadIdx.x == 0 && counts_out) counts_out[qi] = (uint32_t)outc;
+}
+
+extern "C" {
+
+mdb_status mdb_merge_shards(mdb_ctx* ctx, const mdb_u128* doc_ids, const float* scores, const uint32_t* counts, size_t world,
+                            size_t b, size_t k, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out) {
+    if (!ctx || !doc_ids || !scores || !counts || !doc_ids_out || !scores_out || world == 0) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    if (b == 0) return MDB_OK;
+    if (k == 0) {
+        if (counts_out) MDB_HIP(ctx, hipMemsetAsync(counts_out, 0, b * 4, ctx->stream));
+        return MDB_OK;
+    }
+    size_t lds = world * k * 20 + (world + 1) * 4 + 16;
+    if (lds > 150 * 1024) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "world*k=%zu rows exceed the on-chip merge capacity", world * k);
+    if (lds > 48 * 1024)
+        MDB_HIP(ctx, hipFuncSetAttribute((const void*)merge_shards_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    merge_shards_kernel<<<dim3((unsigned)b), 256, lds, ctx->stream>>>(doc_ids, scores, counts, (int)world, b, (int)k, doc_ids_out,
+                                                                     scores_out, counts_out);
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+// ---------------------------------------------------------------- single-user SPANN
+mdb_status mdb_spann_load(mdb_ctx* ctx, const void* hnsw_index, size_t hnsw_index_len, size_t hnsw_index_offset,
+                          const void* hnsw_vectors, size_t hnsw_vectors_len, size_t hnsw_vectors_offset, const void* ivf_index,
+                          size_t ivf_index_len, size_t ivf_index_offset, const void* ivf_vectors, size_t ivf_vectors_len,
+                          size_t ivf_vectors_offset, const mdb_quant_desc* quant, mdb_spann** out) {
+    if (!ctx || !hnsw_index || !hnsw_vectors || !ivf_index || !ivf_vectors || !out) return MDB_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    mdb_spann* sp = new mdb_spann();
+    sp->set.ctx = ctx;
+    mdb_status st = sp->set.ivf.load(ctx, (const uint8_t*)ivf_index, ivf_index_len, (const uint8_t*)ivf_vectors, ivf_vectors_len,
+                                     {{ivf_index_offset, ivf_vectors_offset}}, quant, 0, 1);
+    if (st == MDB_OK) {
+        mdb_quant_desc noq{};  // the centroid index is always NoQuantizer<L2> (spann/index.rs:19)
+        noq.kind = MDB_QUANT_NONE;
+        noq.metric = MDB_METRIC_L2;
+        noq.dimension = sp->set.ivf.num_features;
+        st = sp->set.hnsw.load(ctx, (const uint8_t*)hnsw_index, hnsw_index_len, (const uint8_t*)hnsw_vectors, hnsw_vectors_len,
+                               {{hnsw_index_offset, hnsw_vectors_offset}}, &noq, sp->set.ivf.num_features);
+    }
+    if (st != MDB_OK) { delete sp; return st; }
+    sp->set.num_users = 1;
+    *out = sp;
+    return MDB_OK;
+}
+
+void mdb_spann_free(mdb_spann* sp) {
+    if (!sp) return;
+    (void)hipSetDevice(sp->set.ctx->device);
+    (void)hipStreamSynchronize(sp->set.ctx->stream);
+    delete sp;
+}
+
+mdb_status mdb_spann_search(mdb_spann* sp, const float* queries, size_t b, const mdb_search_params* params, mdb_mem mem,
+                            mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out, uint8_t* found_out) {
+    if (!sp || (!queries && b) || !params || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(sp->set.ctx->mu);
+    MDB_HIP(sp->set.ctx, hipSetDevice(sp->set.ctx->device));
+    return spann_search_impl(sp->set, queries, b, nullptr, params, mem, doc_ids_out, scores_out, counts_out, found_out);
+}
+
+mdb_status mdb_spann_invalidate(mdb_spann* sp, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out) {
+    if (!sp || (!doc_ids && n) || !flags_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(sp->set.ctx->mu);
+    MDB_HIP(sp->set.ctx, hipSetDevice(sp->set.ctx->device));
+    return sp->set.ivf.invalidate(0, doc_ids, n, flags_out, false);
+}
+
+mdb_status mdb_spann_is_invalidated(mdb_spann* sp, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out) {
+    if (!sp || (!doc_ids && n) || !flags_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(sp->set.ctx->mu);
+    MDB_HIP(sp->set.ctx, hipSetDevice(sp->set.ctx->device));
+    return sp->set.ivf.invalidate(0, doc_ids, n, flags_out, true);
+}
+
+// ---------------------------------------------------------------- multi-user SPANN
+mdb_status mdb_multi_spann_load(mdb_ctx* ctx, const mdb_user_index_info* users, size_t n_users, uint32_t num_features,
+                                const void* hnsw_index, size_t hnsw_index_len, const void* hnsw_vectors, size_t hnsw_vectors_len,
+                                const void* ivf_index, size_t ivf_index_len, const void* ivf_vectors, size_t ivf_vectors_len,
+                                const mdb_quant_desc* quant, uint32_t shard_rank, uint32_t shard_world, mdb_multi_spann** out) {
+    if (!ctx || (!users && n_users) || !hnsw_index || !hnsw_vectors || !ivf_index || !ivf_vectors || !out) return MDB_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_users == 0) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "no users");
+    mdb_multi_spann* ms = new mdb_multi_spann();
+    ms->set.ctx = ctx;
+    std::vector<std::pair<size_t, size_t>> hoff, ioff;
+    for (size_t i = 0; i < n_users; ++i) {
+        hoff.push_back({(size_t)users[i].centroid_index_offset, (size_t)users[i].centroid_vector_offset});
+        ioff.push_back({(size_t)users[i].ivf_index_offset, (size_t)users[i].ivf_vectors_offset});
+        ms->set.user_index[U128Key{users[i].user_id.lo, users[i].user_id.hi}] = (uint32_t)i;
+    }
+    mdb_status st = ms->set.ivf.load(ctx, (const uint8_t*)ivf_index, ivf_index_len, (const uint8_t*)ivf_vectors, ivf_vectors_len, ioff,
+                                     quant, shard_rank, shard_world);
+    if (st == MDB_OK && ms->set.ivf.num_features != num_features)
+        st = mdb_fail(ctx, MDB_ERR_FORMAT, "num_features %u != index header %u", num_features, ms->set.ivf.num_features);
+    if (st == MDB_OK) {
+        mdb_quant_desc noq{};
+        noq.kind = MDB_QUANT_NONE;
+        noq.metric = MDB_METRIC_L2;
+        noq.dimension = num_features;
+        st = ms->set.hnsw.load(ctx, (const uint8_t*)hnsw_index, hnsw_index_len, (const uint8_t*)hnsw_vectors, hnsw_vectors_len, hoff,
+                               &noq, num_features);
+    }
+    if (st != MDB_OK) { delete ms; return st; }
+    ms->set.num_users = n_users;
+    *out = ms;
+    return MDB_OK;
+}
+
+void mdb_multi_spann_free(mdb_multi_spann* ms) {
+    if (!ms) return;
+    (void)hipSetDevice(ms->set.ctx->device);
+    (void)hipStreamSynchronize(ms->set.ctx->stream);
+    delete ms;
+}
+
+size_t mdb_multi_spann_num_users(const mdb_multi_spann* ms) { return ms ? ms->set.num_users : 0; }
+
+mdb_status mdb_multi_spann_search(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                  const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out,
+                                  uint32_t* counts_out, uint8_t* found_out) {
+    if (!ms || (!queries && b) || (!user_ids && b) || !params || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ms->set.ctx->mu);
+    MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
+    std::vector<uint32_t> qu(b);
+    for (size_t i = 0; i < b; ++i) {
+        auto it = ms->set.user_index.find(U128Key{user_ids[i].lo, user_ids[i].hi});
+        qu[i] = it == ms->set.user_index.end() ? (uint32_t)ms->set.num_users : it->second;  // sentinel: valid = 0 => None
+    }
+    return spann_search_impl(ms->set, queries, b, qu.data(), params, mem, doc_ids_out, scores_out, counts_out, found_out);
+}
+
+mdb_status mdb_multi_spann_invalidate(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,
+                                      uint8_t* flags_out) {
+    if (!ms || !user_id || (!doc_ids && n) || !flags_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ms->set.ctx->mu);
+    MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
+    auto it = ms->set.user_index.find(U128Key{user_id->lo, user_id->hi});
+    if (it == ms->set.user_index.end()) {
+        for (size_t i = 0; i < n; ++i) flags_out[i] = 0;
+        return MDB_OK;
+    }
+    return ms->set.ivf.invalidate(it->second, doc_ids, n, flags_out, false);
+}
+
+}  // extern "C"

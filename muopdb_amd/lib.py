@@ -75,6 +75,15 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise OSError("libmuopdb_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as the
+        # system one this library links).  If torch is importable, load it FIRST so both share
+        # torch's runtime; the other order leaves torch with "No HIP GPUs are available".
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         _lib = C.CDLL(LIB_PATH)
         _lib.mdb_last_error.restype = C.c_char_p
         _lib.mdb_version.restype = C.c_char_p

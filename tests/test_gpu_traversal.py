@@ -1,0 +1,279 @@
+"""GPU parity tests (-m gpu) for the traversal rows: HNSW (H1/H2), SPANN (S1), multi-user SPANN
+(M1) and the shard merge (§8e) — through the C ABI, against the CPU oracle and the reference's
+end-to-end known answers (K8, K9, K10, K13)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from muopdb_amd import formats as F
+from tests import helpers as H
+from tests.test_gpu_parity import assert_result_rows, assert_scores
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from muopdb_amd import lib as L
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def _line_vectors(n=1000):
+    return np.repeat(np.arange(n, dtype=np.float32)[:, None], 4, 1)
+
+
+# ----------------------------------------------------------------------------------- HNSW
+def test_hnsw_k13_hand_graph(ctx, oracle):
+    # the 3-layer graph of rs/index/src/hnsw/writer.rs:269-430 with distinguishable vectors
+    from muopdb_amd.index import BlockBasedHnsw
+    l2 = {1: []}
+    l1 = {1: [4, 5], 4: [1, 5], 5: [1, 4]}
+    l0 = {1: [4, 5], 4: [1, 5], 5: [1, 4], 2: [1, 3], 3: [2, 4], 0: [1, 2]}
+    vec = np.arange(6 * 16, dtype=np.float32).reshape(6, 16) % 7
+    index = F.write_hnsw_index([l0, l1, l2], [1, 2, 3, 4, 5, 6], 16)
+    vf = F.write_vector_file(vec)
+    g = BlockBasedHnsw(ctx, index, vf, 16)
+    o = oracle.BlockBasedHnsw(index, vf, 16)
+    q = np.array([vec[3] + 0.25, vec[0] - 0.5, np.zeros(16)], np.float32)
+    for k, ef in [(3, 1), (6, 10), (2, 2), (10, 3)]:
+        assert_result_rows(g.ann_search(q, k, ef), o.ann_search(q, k, ef), len(q))
+
+
+@pytest.mark.parametrize("n,d,M,layers,efc,metric,seed", [
+    (1500, 8, 12, 4, 60, 0, 1), (2000, 128, 16, 3, 80, 0, 2), (1000, 4, 10, 2, 100, 0, 3), (800, 30, 8, 5, 40, 1, 4),
+    (3000, 16, 6, 6, 30, 0, 5), (500, 17, 24, 1, 50, 0, 6), (300, 768, 8, 2, 40, 0, 7)])
+def test_hnsw_ann_search(ctx, oracle, n, d, M, layers, efc, metric, seed):
+    from muopdb_amd.index import BlockBasedHnsw, NoQuantizer
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((n, d)).astype(np.float32)
+    doc = [7 * i + 3 + ((i % 3) << 90) for i in range(n)]
+    hidx, hvec = H.build_hnsw_files(oracle, v, doc, max_neighbors=M, max_layers=layers, ef_construction=efc, seed=seed,
+                                    metric=metric)
+    g = BlockBasedHnsw(ctx, hidx, hvec, d, NoQuantizer(d, metric))
+    o = oracle.BlockBasedHnsw(hidx, hvec, d, oracle.Quant(oracle.QUANT_NONE, metric))
+    q = rng.standard_normal((33, d)).astype(np.float32)
+    for k, ef in [(10, 200), (1, 1), (5, 7), (50, 64), (10, 0)]:
+        ores = o.ann_search(q, k, ef)
+        assert_result_rows(g.ann_search(q, k, ef), ores, len(q))
+    evals, expanded = o.stats()
+    o.ann_search(q, 10, 200)
+    evals, expanded = o.stats()
+    g.ann_search(q, 10, 200)
+    st = ctx.stats()
+    assert st["distance_evals"] == evals and st["expanded_nodes"] == expanded  # same traversal, step for step
+
+
+def test_hnsw_ties_and_duplicates(ctx, oracle):
+    # many exact distance ties: pop order (largest id first) and eviction order must match
+    from muopdb_amd.index import BlockBasedHnsw
+    base = np.repeat(np.random.default_rng(3).integers(0, 3, (40, 6)).astype(np.float32), 25, axis=0)
+    hidx, hvec = H.build_hnsw_files(oracle, base, list(range(1000)), max_neighbors=10, max_layers=3, ef_construction=40)
+    g = BlockBasedHnsw(ctx, hidx, hvec, 6)
+    o = oracle.BlockBasedHnsw(hidx, hvec, 6)
+    q = base[::97][:10] + 0.0
+    for k, ef in [(20, 30), (5, 5), (100, 128)]:
+        assert_result_rows(g.ann_search(q, k, ef), o.ann_search(q, k, ef), len(q))
+
+
+def test_hnsw_large_graph_uses_hbm_visited(ctx, oracle):
+    # > ~1.1M points: the visited bitmap no longer fits in LDS -> HBM bitmap path, same answers
+    from muopdb_amd.index import BlockBasedHnsw
+    n, d = 1_300_000, 4
+    rng = np.random.default_rng(8)
+    v = rng.random((n, d), dtype=np.float32)
+    # a cheap valid graph: ring + random long links (no need for quality, only for parity)
+    nb = np.stack([(np.arange(n) + 1) % n, (np.arange(n) - 1) % n, rng.integers(0, n, n), rng.integers(0, n, n)], 1)
+    indptr = np.arange(n + 1, dtype=np.uint64) * 4
+    index = F.write_hnsw_index([(None, indptr, nb.reshape(-1).astype(np.uint32))], np.arange(n, dtype=np.uint64), d)
+    vf = F.write_vector_file(v)
+    g = BlockBasedHnsw(ctx, index, vf, d)
+    o = oracle.BlockBasedHnsw(index, vf, d)
+    q = rng.random((4, d), dtype=np.float32)
+    assert_result_rows(g.ann_search(q, 10, 64), o.ann_search(q, 10, 64), 4)
+
+
+# ----------------------------------------------------------------------------------- SPANN (K8)
+def test_k8_spann_search(ctx, oracle):
+    # rs/index/src/spann/index.rs:293-445
+    from muopdb_amd.index import Spann, SearchParams
+    v = _line_vectors()
+    files, _, _ = H.build_spann_files(oracle, v, list(range(1000)), 10)
+    sp = Spann(ctx, files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"])
+    osp = oracle.Spann(files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"])
+    q = [[2.4, 3.4, 4.4, 5.4]]
+    res = sp.search(q, SearchParams(2, 2))
+    assert res.doc_ids(0) == [4, 3] and res.found[0] == 1
+    assert sp.invalidate(4) and sp.is_invalidated(4) and not sp.invalidate(4)
+    assert sp.search(q, SearchParams(2, 2)).doc_ids(0) == [3, 5]
+    osp.invalidate(4)
+    rng = np.random.default_rng(1)
+    qs = (rng.random((40, 4)) * 1000).astype(np.float32)
+    for params, op in [(SearchParams(2, 2), oracle.SearchParams(2, 2)),
+                       (SearchParams(10, 100), oracle.SearchParams(10, 100)),
+                       (SearchParams(5, 50).with_num_explored_centroids(4).with_centroid_distance_ratio(0.5),
+                        oracle.SearchParams(5, 50, num_explored_centroids=4, centroid_distance_ratio=0.5)),
+                       (SearchParams(3, 10).with_num_explored_centroids(0), oracle.SearchParams(3, 10, num_explored_centroids=0))]:
+        r, ro = sp.search(qs, params), osp.search(qs, op)
+        assert r.found.tolist() == ro.found.tolist()
+        assert_result_rows(r, ro, len(qs))
+
+
+def test_k8_spann_search_pq(ctx, oracle):
+    # spann/index.rs:448-527: subdim 2 / 2 bits => top-5 scores all 0.0
+    from muopdb_amd.index import Spann, SearchParams, ProductQuantizer
+    v = _line_vectors()
+    cb = H.train_pq_codebook(v, 2, 2)
+    opq = oracle.ProductQuantizer(4, 2, 2, cb)
+    files, _, _ = H.build_spann_files(oracle, v, list(range(1000)), 10, quantize=opq.quantize)
+    sp = Spann(ctx, files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"],
+               ProductQuantizer(4, 2, 2, cb))
+    osp = oracle.Spann(files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"],
+                       oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 2, 2, cb))
+    res = sp.search([[2.4, 3.4, 4.4, 5.4]], SearchParams(5, 2))
+    assert res.counts[0] == 5 and res.scores[0].tolist() == [0.0] * 5
+    assert_result_rows(res, osp.search([[2.4, 3.4, 4.4, 5.4]], oracle.SearchParams(5, 2)), 1)
+
+
+def test_spann_random_noq_and_pq(ctx, oracle):
+    from muopdb_amd.index import Spann, SearchParams, ProductQuantizer
+    rng = np.random.default_rng(21)
+    v = H.sift_like(4000, 32, n_clusters=30, seed=9)
+    doc = list(range(10, 4010))
+    files, _, _ = H.build_spann_files(oracle, v, doc, 40, max_neighbors=8, max_layers=3, ef_construction=50)
+    sp = Spann(ctx, files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"])
+    osp = oracle.Spann(files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"])
+    q = (v[rng.integers(0, 4000, 50)] + rng.normal(0, 3, (50, 32))).astype(np.float32)
+    p, op = SearchParams(10, 100).with_num_explored_centroids(8).with_centroid_distance_ratio(0.3), \
+        oracle.SearchParams(10, 100, num_explored_centroids=8, centroid_distance_ratio=0.3)
+    assert_result_rows(sp.search(q, p), osp.search(q, op), len(q))
+    cb = H.train_pq_codebook(v[:2000], 8, 6, iters=3)
+    opq = oracle.ProductQuantizer(32, 8, 6, cb)
+    files, _, _ = H.build_spann_files(oracle, v, doc, 40, quantize=opq.quantize, max_neighbors=8, max_layers=3,
+                                      ef_construction=50)
+    sp = Spann(ctx, files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"],
+               ProductQuantizer(32, 8, 6, cb))
+    osp = oracle.Spann(files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"],
+                       oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 6, cb))
+    assert_result_rows(sp.search(q, p), osp.search(q, op), len(q))
+
+
+# ----------------------------------------------------------------------------------- multi-user (K9, K10)
+def _multi(ctx, oracle, users, quant=None, oquant=None, **kw):
+    from muopdb_amd.index import MultiSpannIndex
+    cat = F.concat_multi_spann(users)
+    g = MultiSpannIndex(ctx, cat["user_table"], 4 if "nf" not in kw else kw["nf"], cat["hnsw_index"],
+                        cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], quant,
+                        kw.get("shard_rank", 0), kw.get("shard_world", 1))
+    o = oracle.MultiSpannIndex(cat["user_table"], 4 if "nf" not in kw else kw["nf"], cat["hnsw_index"],
+                               cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], oquant)
+    return g, o
+
+
+def test_k9_multi_user(ctx, oracle):
+    # rs/index/src/multi_spann/index.rs:358-412
+    from muopdb_amd.index import SearchParams
+    v = np.concatenate([_line_vectors(), np.array([[1.2, 2.2, 3.2, 4.2]], np.float32)])
+    f0, _, _ = H.build_spann_files(oracle, v, list(range(1001)), 10)
+    f1, _, _ = H.build_spann_files(oracle, _line_vectors(50) + 0.5, list(range(5000, 5050)), 3)
+    big = (1 << 70) + 1
+    g, o = _multi(ctx, oracle, {0: f0, big: f1})
+    assert g.num_users() == 2
+    res = g.search_for_user([0], [[1.4, 2.4, 3.4, 4.4]], SearchParams(3, 100))
+    assert res.found[0] == 1 and res.doc_ids(0) == [1000, 3, 2]
+    users = [big, 12345, 0, big]
+    qs = np.array([[1.4, 2.4, 3.4, 4.4]] * 4, np.float32)
+    r, ro = g.search_for_user(users, qs, SearchParams(2, 100)), o.search_for_user(users, qs, oracle.SearchParams(2, 100))
+    assert r.found.tolist() == [1, 0, 1, 1] == ro.found.tolist()
+    assert_result_rows(r, ro, 4)
+    assert g.invalidate(0, 1000) and not g.invalidate(0, 1000) and not g.invalidate(777, 3)
+    assert g.search_for_user([0], [[1.4, 2.4, 3.4, 4.4]], SearchParams(3, 100)).doc_ids(0) == [3, 2, 4]
+
+
+def test_k10_ratio_filter(ctx, oracle):
+    # rs/index/src/multi_spann/reader.rs:80-263
+    from muopdb_amd.index import SearchParams, ProductQuantizer
+    u0 = np.array([[1, 2, 3, 4], [5, 6, 7, 8]], np.float32)
+    u1 = np.array([[9, 10, 11, 12]], np.float32)
+    f0, _, _ = H.build_spann_files(oracle, u0, [1, 2], 2, centroids=u0.copy())
+    f1, _, _ = H.build_spann_files(oracle, u1, [3], 1, centroids=u1.copy())
+    g, o = _multi(ctx, oracle, {0: f0, 1: f1})
+    p = SearchParams(3, 100)
+    res = g.search_for_user([0, 1], [[1, 2, 3, 4]] * 2, p)
+    assert res.doc_ids(0) == [1] and res.doc_ids(1) == [3]
+    assert [d for d, _ in g.search_for_users([0, 1], [1, 2, 3, 4], p)] == [1, 3]  # snapshot.rs:39-66
+    cb = H.train_pq_codebook(np.concatenate([u0, u1]), 2, 1)
+    opq = oracle.ProductQuantizer(4, 2, 1, cb)
+    g0, _, _ = H.build_spann_files(oracle, u0, [1, 2], 2, centroids=u0.copy(), quantize=opq.quantize)
+    g1, _, _ = H.build_spann_files(oracle, u1, [3], 1, centroids=u1.copy(), quantize=opq.quantize)
+    g, o = _multi(ctx, oracle, {0: g0, 1: g1}, ProductQuantizer(4, 2, 1, cb),
+                  oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 2, 1, cb))
+    res = g.search_for_user([0, 1], [[1, 2, 3, 4]] * 2, p)
+    assert res.doc_ids(0) == [1] and res.doc_ids(1) == [3]
+
+
+def test_multi_user_many_users_and_shards(ctx, oracle):
+    from muopdb_amd.index import SearchParams
+    rng = np.random.default_rng(31)
+    users, allq, allu = {}, [], []
+    for ui in range(12):
+        n = int(rng.integers(150, 400))
+        v = (rng.standard_normal((n, 24)) + ui).astype(np.float32)
+        f, _, _ = H.build_spann_files(oracle, v, [1000 * ui + i for i in range(n)], int(rng.integers(3, 9)), seed=ui,
+                                      max_neighbors=6, max_layers=2, ef_construction=30)
+        users[(ui << 66) | ui] = f
+        for _ in range(4):
+            allq.append(v[rng.integers(0, n)] + rng.normal(0, 0.1, 24))
+            allu.append((ui << 66) | ui)
+    allq = np.asarray(allq, np.float32)
+    g, o = _multi(ctx, oracle, users, nf=24)
+    p, op = SearchParams(10, 50).with_num_explored_centroids(5).with_centroid_distance_ratio(1.0), \
+        oracle.SearchParams(10, 50, num_explored_centroids=5, centroid_distance_ratio=1.0)
+    full, ofull = g.search_for_user(allu, allq, p), o.search_for_user(allu, allq, op)
+    assert_result_rows(full, ofull, len(allq))
+    # posting-list sharding: merging the per-shard top-k by (score, doc id) == unsharded answer
+    shards = [_multi(ctx, oracle, users, nf=24, shard_rank=r, shard_world=3)[0] for r in range(3)]
+    parts = [s.search_for_user(allu, allq, p) for s in shards]
+    for qi in range(len(allq)):
+        rows = []
+        for pr in parts:
+            rows += pr.id_with_scores(qi)
+        rows.sort(key=lambda r: (r[1], r[0]))
+        assert [r[0] for r in rows[:10]] == full.doc_ids(qi)
+
+
+def test_merge_shards_device(ctx):
+    torch = pytest.importorskip("torch")
+    from muopdb_amd import lib as L
+    world, b, k = 4, 9, 6
+    rng = np.random.default_rng(2)
+    docs = rng.integers(0, 50, (world, b, k, 2)).astype(np.uint64)
+    docs[..., 1] = rng.integers(0, 2, (world, b, k))
+    scores = np.sort(rng.integers(0, 6, (world, b, k)).astype(np.float32), axis=2)
+    counts = rng.integers(0, k + 1, (world, b)).astype(np.uint32)
+    dev = torch.device("cuda:0")
+    t_docs = torch.from_numpy(docs.view(np.int64)).to(dev)
+    t_sc = torch.from_numpy(scores).to(dev)
+    t_cn = torch.from_numpy(counts.view(np.int32)).to(dev)
+    o_docs = torch.zeros((b, k, 2), dtype=torch.int64, device=dev)
+    o_sc = torch.zeros((b, k), dtype=torch.float32, device=dev)
+    o_cn = torch.zeros(b, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.mdb_merge_shards(ctx.h, C.c_void_p(t_docs.data_ptr()), C.c_void_p(t_sc.data_ptr()),
+                                       C.c_void_p(t_cn.data_ptr()), C.c_size_t(world), C.c_size_t(b), C.c_size_t(k),
+                                       C.c_void_p(o_docs.data_ptr()), C.c_void_p(o_sc.data_ptr()),
+                                       C.c_void_p(o_cn.data_ptr())))
+    ctx.sync()
+    od, osc, ocn = o_docs.cpu().numpy().view(np.uint64), o_sc.cpu().numpy(), o_cn.cpu().numpy()
+    for qi in range(b):
+        rows = []
+        for w in range(world):
+            for j in range(int(counts[w, qi])):
+                rows.append((float(scores[w, qi, j]), (int(docs[w, qi, j, 1]) << 64) | int(docs[w, qi, j, 0])))
+        rows.sort()
+        rows = rows[:k]
+        assert int(ocn[qi]) == len(rows)
+        got = [(float(osc[qi, j]), (int(od[qi, j, 1]) << 64) | int(od[qi, j, 0])) for j in range(len(rows))]
+        assert got == rows
