@@ -106,13 +106,20 @@ typedef struct mdb_multi_spann mdb_multi_spann;
 /* ---------------------------------------------------------------- context */
 mdb_status mdb_device_open(int gpu, mdb_ctx** out);
 void mdb_device_close(mdb_ctx* ctx);
-/* run on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+/* run on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = the legacy
+ * default (null) stream.  A context starts on its own non-blocking stream. */
 mdb_status mdb_set_stream(mdb_ctx* ctx, void* hip_stream);
 /* wait for the stream; returns the first deferred error of MDB_MEM_DEVICE calls (e.g. MDB_ERR_NAN) */
 mdb_status mdb_sync(mdb_ctx* ctx);
 const char* mdb_last_error(mdb_ctx* ctx);
 mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out);
 const char* mdb_version(void);
+/* Measurement aid (bench.py): when on, every search call brackets its DOMINANT
+ * kernel (flat scan / posting-list scan / HNSW traversal) with HIP events on the context's
+ * stream.  mdb_get_profile synchronises, returns the summed kernel time and the number of
+ * bracketed launches since the last call, and resets the accumulators. */
+mdb_status mdb_set_profiling(mdb_ctx* ctx, int on);
+mdb_status mdb_get_profile(mdb_ctx* ctx, double* kernel_ms_out, uint64_t* launches_out);
 
 /* ---------------------------------------------------------------- D1/D2/Q3 unit seams
  * L2DistanceCalculator::{calculate_squared,calculate} rs/utils/src/distance/l2.rs:32-74;

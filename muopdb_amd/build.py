@@ -1,0 +1,221 @@
+"""Index construction on the GPU (the callers / data producers either
+side of the hot path).  PyTorch is used here as device-memory plumbing for the bulk,
+GEMM-shaped build steps (k-NN graphs, k-means); the products are the reference's on-disk
+formats (muopdb_amd.formats), which the hot path (libmuopdb_hip.so) then loads.
+
+The reference builds are nondeterministic (thread_rng: rs/index/src/hnsw/builder.rs:332-337,
+rs/index/src/ivf/builder.rs:409,476), so build parity is QUALITY parity (recall), never bit
+parity; search parity is bit-exact given the same files.
+
+* bulk_hnsw       — HNSW-format graph from exact k-NN + the reference's neighbour-selection
+                    heuristic (builder.rs:339-375), level assignment as builder.rs:332-337.
+* kmeans / train_pq_codebook / assign_lists — IvfBuilder / ProductQuantizerBuilder roles.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import formats as F
+
+
+# ------------------------------------------------------------------------------------------ data
+def sift_like(n, d=128, n_clusters=4096, sigma=20.0, seed=1, device="cuda"):
+    """Gaussian clusters, clipped to [0,218], rounded, f32 (synthetic SIFT-1M)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    centers = torch.rand((n_clusters, d), generator=g) * 218.0
+    assign = torch.randint(0, n_clusters, (n,), generator=g)
+    out = torch.empty((n, d), dtype=torch.float32, device=device)
+    centers = centers.to(device)
+    chunk = 1 << 18
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        noise = torch.randn((e - s, d), generator=g) * sigma
+        out[s:e] = torch.clamp(torch.round(centers[assign[s:e].to(device)] + noise.to(device)), 0, 218)
+    return out
+
+
+def unit_gaussian(n, d, seed, device="cuda"):
+    """Gaussian rows normalised to unit length (nomic-embed-like)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    out = torch.empty((n, d), dtype=torch.float32, device=device)
+    chunk = 1 << 16
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        x = torch.randn((e - s, d), generator=g).to(device)
+        out[s:e] = x / x.norm(dim=1, keepdim=True)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ exact k-NN
+def exact_knn(x, k, queries=None, chunk=4096, f64=False, exclude_self=True):
+    """k nearest rows of x (squared L2) for every row of `queries` (default x itself).
+    Returns (idx int64 [nq,k], sqdist f32 [nq,k]) ascending.  f64=True gives the float64 ground
+    truth used for recall."""
+    self_q = queries is None
+    q = x if self_q else queries
+    dt = torch.float64 if f64 else torch.float32
+    xn = (x.to(dt) ** 2).sum(1)
+    xt = x.to(dt).t().contiguous() if f64 else x.t().contiguous()
+    nq = q.shape[0]
+    idx = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+    if f64:
+        chunk = max(64, chunk // 8)
+    for s in range(0, nq, chunk):
+        e = min(nq, s + chunk)
+        qc = q[s:e].to(dt)
+        dd = (qc ** 2).sum(1, keepdim=True) + xn[None, :] - 2.0 * (qc @ xt)
+        if self_q and exclude_self:
+            dd[torch.arange(e - s, device=x.device), torch.arange(s, e, device=x.device)] = float("inf")
+        v, i = torch.topk(dd, k, dim=1, largest=False, sorted=True)
+        idx[s:e] = i
+        dist[s:e] = v.clamp_min(0).to(torch.float32)
+    return idx, dist
+
+
+# ------------------------------------------------------------------------------------------ HNSW bulk build
+def _heuristic_prune(x, node_ids, cand_idx, cand_sq, max_neighbors, chunk=8192):
+    """select_neighbors_heuristic (rs/index/src/hnsw/builder.rs:339-375), batched: walk the
+    candidates nearest-first, keep e unless an already kept x is closer to e than the node is."""
+    n, K = cand_idx.shape
+    keep = torch.zeros((n, K), dtype=torch.bool, device=x.device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        ci = cand_idx[s:e]
+        cv = x[node_ids[ci]]                                   # [C,K,d]
+        sq = (cv ** 2).sum(-1)
+        pair = sq[:, :, None] + sq[:, None, :] - 2.0 * torch.bmm(cv, cv.transpose(1, 2))  # [C,K,K]
+        dq = cand_sq[s:e]
+        sel = torch.zeros((e - s, K), dtype=torch.bool, device=x.device)
+        cnt = torch.zeros(e - s, dtype=torch.int32, device=x.device)
+        valid = torch.isfinite(dq)
+        for i in range(K):
+            bad = ((pair[:, i, :] < dq[:, i:i + 1]) & sel).any(dim=1)
+            ok = (~bad) & (cnt < max_neighbors) & valid[:, i]
+            sel[:, i] = ok
+            cnt += ok.to(torch.int32)
+        keep[s:e] = sel
+    return keep
+
+
+def _layer_graph(x, node_ids, max_neighbors, kcand):
+    """Adjacency (CSR over local indices -> global ids) of one layer."""
+    n = node_ids.shape[0]
+    dev = x.device
+    if n <= 1:
+        return np.zeros(n + 1, np.uint64), np.zeros(0, np.uint32)
+    k = min(kcand, n - 1)
+    idx, sq = exact_knn(x[node_ids], k)
+    keep = _heuristic_prune(x, node_ids, idx, sq, max_neighbors)
+    src = torch.arange(n, device=dev)[:, None].expand(n, k)[keep]
+    dst = idx[keep]
+    dd = sq[keep]
+    # add reverse edges, dedup (src,dst), keep the max_neighbors nearest per node
+    s2 = torch.cat([src, dst])
+    d2 = torch.cat([dst, src])
+    w2 = torch.cat([dd, dd])
+    key = s2 * n + d2
+    key, order = torch.sort(key)
+    w2 = w2[order]
+    first = torch.ones_like(key, dtype=torch.bool)
+    first[1:] = key[1:] != key[:-1]
+    key, w2 = key[first], w2[first]
+    s2, d2 = key // n, key % n
+    o1 = torch.sort(w2, stable=True).indices
+    s2, d2 = s2[o1], d2[o1]
+    o2 = torch.sort(s2, stable=True).indices
+    s2, d2 = s2[o2], d2[o2]
+    counts = torch.bincount(s2, minlength=n)
+    starts = torch.cumsum(counts, 0) - counts
+    pos = torch.arange(s2.shape[0], device=dev) - starts[s2]
+    m = pos < max_neighbors
+    s2, d2 = s2[m], d2[m]
+    counts = torch.bincount(s2, minlength=n)
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(counts, 0)
+    edges = node_ids[d2]
+    return indptr.cpu().numpy().astype(np.uint64), edges.cpu().numpy().astype(np.uint32)
+
+
+def bulk_hnsw(x, max_neighbors=32, max_layers=8, kcand=64, seed=1):
+    """Returns (layers, levels): `layers` in muopdb_amd.formats.write_hnsw_index's CSR form
+    (layer 0 first; points None for layer 0), entry point = first point of the top layer."""
+    n = x.shape[0]
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    u = torch.rand(n, generator=g).clamp_min(1e-12)
+    # get_random_layer (builder.rs:332-337): floor(-ln(u)/ln(max_neighbors)), capped
+    lv = torch.floor(-torch.log(u) / math.log(max_neighbors)).to(torch.int64).clamp_max(max_layers)
+    top = int(lv.max().item())
+    lv = lv.to(x.device)
+    layers = []
+    for layer in range(top + 1):
+        ids = torch.nonzero(lv >= layer, as_tuple=False).reshape(-1)
+        indptr, edges = _layer_graph(x, ids, max_neighbors, kcand)
+        layers.append((None if layer == 0 else ids.cpu().numpy().astype(np.uint32), indptr, edges))
+    return layers, lv.cpu().numpy()
+
+
+def hnsw_files(x, doc_ids=None, **kw):
+    """(index_bytes, vector_bytes) in the reference's HNSW formats for device rows x."""
+    layers, _ = bulk_hnsw(x, **kw)
+    n, d = x.shape
+    if doc_ids is None:
+        doc_ids = np.arange(n, dtype=np.uint64)
+    return F.write_hnsw_index(layers, doc_ids, d), F.write_vector_file(x.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------ k-means / PQ / IVF
+def kmeans(x, k, iters=10, seed=0, sample=None):
+    """Lloyd on the GPU (KMeansBuilder role, rs/utils/src/kmeans_builder/kmeans_builder.rs:163-360,
+    without the size penalty); empty clusters keep their previous centre."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    n = x.shape[0]
+    if sample is not None and sample < n:
+        x = x[torch.randperm(n, generator=g)[:sample].to(x.device)]
+        n = sample
+    k = min(k, n)
+    c = x[torch.randperm(n, generator=g)[:k].to(x.device)].clone()
+    for _ in range(iters):
+        a = assign_nearest(x, c)
+        sums = torch.zeros_like(c).index_add_(0, a, x)
+        cnt = torch.bincount(a, minlength=k).to(x.dtype)
+        nz = cnt > 0
+        c[nz] = sums[nz] / cnt[nz, None]
+    return c
+
+
+def assign_nearest(x, c, chunk=1 << 16):
+    cn = (c ** 2).sum(1)
+    ct = c.t().contiguous()
+    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    for s in range(0, x.shape[0], chunk):
+        e = min(x.shape[0], s + chunk)
+        dd = cn[None, :] - 2.0 * (x[s:e] @ ct)
+        out[s:e] = dd.argmin(1)
+    return out
+
+
+def train_pq_codebook(x, subdim, num_bits, iters=8, seed=0, sample=100_000):
+    """[m][2^num_bits][subdim] f32 codebook (ProductQuantizerBuilder role, pq_builder.rs:43-102)."""
+    d = x.shape[1]
+    m, K = d // subdim, 1 << num_bits
+    cb = torch.empty((m, K, subdim), dtype=torch.float32, device=x.device)
+    for s in range(m):
+        c = kmeans(x[:, s * subdim:(s + 1) * subdim].contiguous(), K, iters, seed + s, sample)
+        if c.shape[0] < K:
+            c = torch.cat([c, c[-1:].expand(K - c.shape[0], subdim)])
+        cb[s] = c
+    return cb.reshape(-1).cpu().numpy()
+
+
+def posting_lists_from_assignment(assign, num_lists):
+    """list of sorted u64 point-id arrays (IvfBuilder::build_posting_lists role)."""
+    a = assign.cpu().numpy()
+    order = np.argsort(a, kind="stable")
+    bounds = np.searchsorted(a[order], np.arange(num_lists + 1))
+    return [order[bounds[i]:bounds[i + 1]].astype(np.uint64) for i in range(num_lists)]

@@ -33,7 +33,31 @@ struct mdb_ctx {
     // growable device scratch (never shrinks; no allocation in steady state)
     void* scratch[8] = {nullptr};
     size_t scratch_cap[8] = {0};
+    // optional HIP-event timing of the dominant kernel of each search call (mdb_set_profiling)
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
     std::mutex mu;
+};
+
+// records a start/stop event pair around the enclosed launches on the context's stream
+struct ProfScope {
+    mdb_ctx* c;
+    hipEvent_t stop = nullptr;
+    explicit ProfScope(mdb_ctx* ctx) : c(ctx) {
+        if (!c->prof_on) return;
+        if (c->prof_used == c->prof_events.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            c->prof_events.push_back({a, b});
+        }
+        auto& ev = c->prof_events[c->prof_used++];
+        (void)hipEventRecord(ev.first, c->stream);
+        stop = ev.second;
+    }
+    ~ProfScope() {
+        if (stop) (void)hipEventRecord(stop, c->stream);
+    }
 };
 
 #define MDB_FLAG_NAN 1u

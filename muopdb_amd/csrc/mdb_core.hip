@@ -77,21 +77,19 @@ void mdb_device_close(mdb_ctx* ctx) {
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    for (auto& ev : ctx->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 mdb_status mdb_set_stream(mdb_ctx* ctx, void* hip_stream) {
     if (!ctx) return MDB_ERR_INVALID_ARG;
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (hip_stream) {
-        ctx->stream = (hipStream_t)hip_stream;
-        ctx->own_stream = false;
-    } else {
-        MDB_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    // NULL is a valid HIP stream: the legacy default stream (what torch's default stream is)
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
     return MDB_OK;
 }
 
@@ -102,6 +100,27 @@ mdb_status mdb_sync(mdb_ctx* ctx) {
     if (st == MDB_OK && ctx->deferred != MDB_OK) st = ctx->deferred;
     ctx->deferred = MDB_OK;
     return st;
+}
+
+mdb_status mdb_set_profiling(mdb_ctx* ctx, int on) {
+    if (!ctx) return MDB_ERR_INVALID_ARG;
+    ctx->prof_on = on != 0;
+    return MDB_OK;
+}
+
+mdb_status mdb_get_profile(mdb_ctx* ctx, double* kernel_ms_out, uint64_t* launches_out) {
+    if (!ctx || !kernel_ms_out || !launches_out) return MDB_ERR_INVALID_ARG;
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0;
+    for (size_t i = 0; i < ctx->prof_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->prof_events[i].first, ctx->prof_events[i].second) == hipSuccess) total += ms;
+    }
+    *kernel_ms_out = total;
+    *launches_out = ctx->prof_used;
+    ctx->prof_used = 0;
+    return MDB_OK;
 }
 
 const char* mdb_last_error(mdb_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "no context"; }

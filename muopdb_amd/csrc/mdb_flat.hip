@@ -196,7 +196,7 @@ static int flat_choose_qt(size_t b, int k) {
 }
 
 mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const float* dq, int qstride, size_t b, size_t k,
-                          uint64_t* d_keys, uint32_t* d_counts) {
+                          uint64_t* d_keys, uint32_t* d_counts, bool profile) {
     if (b == 0) return MDB_OK;
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     int qt = flat_choose_qt(b, (int)k);
@@ -208,10 +208,16 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     void* partial;
     MDB_TRY(mdb_scratch(ctx, 4, (size_t)nblk * bpad * std::max<size_t>(k, 1) * 8, &partial));
     DistPlan p = make_plan(ts.d, metric);
+    bool saved = ctx->prof_on;
+    ctx->prof_on = saved && profile;
+    {
+    ProfScope prof(ctx);
+    ctx->prof_on = saved;
     if (metric == MDB_METRIC_L2)
         MDB_TRY(launch_flat_scan<MDB_METRIC_L2>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial));
     else
         MDB_TRY(launch_flat_scan<MDB_METRIC_DOT>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial));
+    }
     merge_keys_kernel<<<dim3((unsigned)b), MDB_BLOCK, BlockSelect<MDB_BLOCK>::lds_bytes((int)k), ctx->stream>>>(
         (const uint64_t*)partial, (size_t)nblk * k, (int)k, d_keys, d_counts);
     MDB_HIP(ctx, hipGetLastError());
@@ -272,7 +278,7 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     void *keys, *cnts;
     MDB_TRY(mdb_scratch(ctx, 5, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4, &cnts));
-    MDB_TRY(flat_topk_keys(ctx, view_of(flat->ts), flat->metric, dq, qstride, b, k, (uint64_t*)keys, (uint32_t*)cnts));
+    MDB_TRY(flat_topk_keys(ctx, view_of(flat->ts), flat->metric, dq, qstride, b, k, (uint64_t*)keys, (uint32_t*)cnts, true));
     // one pass = N*d*4 B read once per batch + queries + outputs
     ctx->stats = mdb_stats{};
     ctx->stats.scored_vectors = (uint64_t)b * flat->ts.n;

@@ -560,10 +560,14 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
                (int)k, (uint64_t*)partial, ctx->d_flags, ctx->d_counters};
     dim3 grid((unsigned)nsplit, (unsigned)b);
     size_t sel_lds = BlockSelect<MDB_BLOCK>::lds_bytes((int)k);
+    void* qcodes = nullptr;
     if (kind == MDB_QUANT_PQ) {
-        void* qcodes;
         MDB_TRY(mdb_scratch(ctx, 7, b * (size_t)pq.m + 16, &qcodes));
         MDB_TRY(pq_quantize_device(ctx, pq, d_q, b, (uint8_t*)qcodes, qstride));  // Q::QuantizedT::process_vector, index.rs:193
+    }
+    {
+    ProfScope prof(ctx);
+    if (kind == MDB_QUANT_PQ) {
         DistPlan sp = make_plan(pq.subdim, MDB_METRIC_L2);
         size_t lut_bytes = (size_t)pq.m * pq.K * pq.subdim * 4;
         size_t lds_lut = ((sel_lds + 15) & ~(size_t)15) + lut_bytes;
@@ -588,6 +592,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
             ivf_scan_f32_kernel<MDB_METRIC_L2><<<grid, MDB_BLOCK, sel_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);
         else
             ivf_scan_f32_kernel<MDB_METRIC_DOT><<<grid, MDB_BLOCK, sel_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);
+    }
     }
     MDB_HIP(ctx, hipGetLastError());
     MDB_TRY(merge_keys(ctx, (const uint64_t*)partial, (size_t)nsplit * k, b, k, d_keys, d_counts));

@@ -15,7 +15,7 @@ mdb_status stage_queries(mdb_ctx* ctx, int slot, const float* queries, size_t b,
                          float** d_out, int* qstride);
 // flat exact top-k of every query against a TileStore: keys (distance,row) ascending into d_keys [b][k]
 mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const float* d_queries_padded, int qstride,
-                          size_t b, size_t k, uint64_t* d_keys, uint32_t* d_counts);
+                          size_t b, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false);
 
 // k smallest of `per_query` candidate keys per query (one block per query), ascending
 mdb_status merge_keys(mdb_ctx* ctx, const uint64_t* d_partial, size_t per_query, size_t b, size_t k, uint64_t* d_out,
