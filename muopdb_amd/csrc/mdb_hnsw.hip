@@ -51,34 +51,35 @@ struct HnswArgs {
 __device__ __forceinline__ uint64_t cand_key(float d, uint32_t id) { return ((uint64_t)f32_orderable(d) << 32) | (uint32_t)~id; }
 __device__ __forceinline__ uint32_t cand_id(uint64_t k) { return ~(uint32_t)k; }
 
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
-    uint32_t lo = __shfl_xor((uint32_t)v, m), hi = __shfl_xor((uint32_t)(v >> 32), m);
-    return ((uint64_t)hi << 32) | lo;
-}
-// wave-wide arg-min / arg-max of (key, idx); all lanes receive the result
-__device__ __forceinline__ void wave_argmin(uint64_t& key, int& idx) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        uint64_t ok = shfl_xor_u64(key, m);
-        int oi = __shfl_xor(idx, m);
-        if (ok < key || (ok == key && oi < idx)) { key = ok; idx = oi; }
-    }
-}
-__device__ __forceinline__ void wave_argmax(uint64_t& key, int& idx) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        uint64_t ok = shfl_xor_u64(key, m);
-        int oi = __shfl_xor(idx, m);
-        if (ok > key || (ok == key && oi < idx)) { key = ok; idx = oi; }
-    }
-}
+// lane t of each 16-lane row broadcast to the whole row: one DPP instruction (row_newbcast),
+// no LDS crossbar round trip
+#define MDB_ROW_BCAST(x, t) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0x150 + (t), 0xF, 0xF, false))
 
 // ordered horizontal sum of the first L lanes of each 16-lane group (reduce_sum, lane 0..L-1)
 template <int L>
 __device__ __forceinline__ float group_reduce(float acc) {
     float s = 0.0f;
-#pragma unroll
-    for (int t = 0; t < L; ++t) s = __fadd_rn(s, __shfl(acc, t, 16));
+    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 0));
+    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 1));
+    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 2));
+    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 3));
+    if (L > 4) {
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 4));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 5));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 6));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 7));
+    }
+    if (L > 8) {
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 8));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 9));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 10));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 11));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 12));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 13));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 14));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 15));
+    }
     return s;
 }
 
@@ -108,15 +109,140 @@ __device__ __forceinline__ float group16_distance(const float* __restrict__ x, c
     return finish_distance<METRIC>(ret);
 }
 
-template <int METRIC, bool VIS_LDS>
+// ---- wave-0 helpers on the two sorted LDS arrays (all ballot based: no cross-lane reductions)
+// W: working set, ascending by (distance, id) key, size wsize <= ef.  Insert wk, dropping the
+// largest when full  ==  push + pop-max of BinaryHeap<PointAndDistance> (index.rs:265-282).
+__device__ __forceinline__ void work_insert(uint64_t* W, int& wsize, int ef, uint64_t wk, int lane) {
+    int moved = 0;
+    for (int r0 = 0; r0 < wsize; r0 += 64) {
+        int idx = wsize - 1 - r0 - lane;
+        uint64_t kk = idx >= 0 ? W[idx] : 0;
+        bool gt = idx >= 0 && kk > wk;
+        unsigned long long b = __ballot(gt);
+        if (gt && idx + 1 < ef) W[idx + 1] = kk;
+        moved += __popcll(b);
+        if (b != ~0ull) break;
+    }
+    int pos = wsize - moved;
+    if (pos < ef) {
+        if (lane == 0) W[pos] = wk;
+        if (wsize < ef) wsize += 1;
+    }
+}
+
+// C: candidate ring, logical index i in [0,cn) -> Cbuf[(cbase+i) & cmask], DESCENDING by candidate
+// key, so the next pop (smallest key) is the last element.
+__device__ __forceinline__ void cand_insert(uint64_t* C, int cbase, int cmask, int& cn, uint64_t ck, int lane) {
+    int less = 0;
+    for (int r0 = 0; r0 < cn; r0 += 64) {
+        int idx = cn - 1 - r0 - lane;
+        uint64_t kk = idx >= 0 ? C[(cbase + idx) & cmask] : ~0ull;
+        bool lt = idx >= 0 && kk < ck;
+        unsigned long long b = __ballot(lt);
+        if (lt) C[(cbase + idx + 1) & cmask] = kk;
+        less += __popcll(b);
+        if (b != ~0ull) break;
+    }
+    if (lane == 0) C[(cbase + cn - less) & cmask] = ck;
+    cn += 1;
+}
+
+// drop the candidates that can never be expanded: distance > furthest kept distance while the
+// working set is full (they sit at the FRONT of the descending ring)
+__device__ __forceinline__ void cand_drop_dead(const uint64_t* C, int& cbase, int cmask, int& cn, uint32_t fmax_o, int lane) {
+    int dead = 0;
+    for (int r0 = 0; r0 < cn; r0 += 64) {
+        int idx = r0 + lane;
+        bool dd = idx < cn && (uint32_t)(C[(cbase + idx) & cmask] >> 32) > fmax_o;
+        unsigned long long b = __ballot(dd);
+        dead += __popcll(b);
+        if (b != ~0ull) break;
+    }
+    cbase = (cbase + dead) & cmask;
+    cn -= dead;
+}
+
+
+// ---- register-resident state (ef <= 256): wave 0 keeps the working set (256 slots) and the
+// candidates (512 slots) UNSORTED in VGPRs, slot idx = lane + 64*r, split into an order-preserving
+// distance word and an id word.  Everything the traversal asks of the two BinaryHeaps becomes a few
+// single-issue instructions: counts are ballots of register compares, min / max are 6-step DPP
+// reductions, replace / append are exec-masked moves.  (A lone wave pays ~6-8 cycles per dependent
+// instruction, so instruction count — not LDS or HBM bandwidth — is what the per-step cost is made of.)
+#define WREGS 4
+#define CREGS 8
+#define SLOT_EMPTY 0xFFFFFFFFu
+
+#define MDB_DPP_U32(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rmask), 0xF, false))
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, MDB_DPP_U32(v, 0xB1, 0xF));   // quad_perm [1,0,3,2]
+    v = min(v, MDB_DPP_U32(v, 0x4E, 0xF));   // quad_perm [2,3,0,1]
+    v = min(v, MDB_DPP_U32(v, 0x141, 0xF));  // row_half_mirror
+    v = min(v, MDB_DPP_U32(v, 0x140, 0xF));  // row_mirror
+    v = min(v, MDB_DPP_U32(v, 0x142, 0xA));  // row_bcast:15
+    v = min(v, MDB_DPP_U32(v, 0x143, 0xC));  // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, MDB_DPP_U32(v, 0xB1, 0xF));
+    v = max(v, MDB_DPP_U32(v, 0x4E, 0xF));
+    v = max(v, MDB_DPP_U32(v, 0x141, 0xF));
+    v = max(v, MDB_DPP_U32(v, 0x140, 0xF));
+    v = max(v, MDB_DPP_U32(v, 0x142, 0xA));
+    v = max(v, MDB_DPP_U32(v, 0x143, 0xC));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// slot (uniform idx) <- (d, id)
+template <int R>
+__device__ __forceinline__ void slots_write(uint32_t (&sd)[R], uint32_t (&si)[R], int idx, uint32_t d, uint32_t id, int lane) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if ((idx >> 6) == r && lane == (idx & 63)) { sd[r] = d; si[r] = id; }
+}
+// the slot whose distance word is `m` and whose id is extreme among equal distances
+// (WANT_MAX_ID: largest id, else smallest); limit = number of usable slots.  Returns idx, sets id.
+template <int R, bool WANT_MAX_ID>
+__device__ __forceinline__ int slots_locate(const uint32_t (&sd)[R], const uint32_t (&si)[R], uint32_t m, int limit, int lane,
+                                            uint32_t& id_out) {
+    unsigned long long b[R];
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        b[r] = __ballot(lane + 64 * r < limit && sd[r] == m);
+        total += __popcll(b[r]);
+    }
+    if (total > 1) {  // distance tie: pick by id
+        uint32_t li = WANT_MAX_ID ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (lane + 64 * r < limit && sd[r] == m) li = WANT_MAX_ID ? max(li, si[r]) : min(li, si[r]);
+        uint32_t mid = WANT_MAX_ID ? wave_max_u32(li) : wave_min_u32(li);
+#pragma unroll
+        for (int r = 0; r < R; ++r) b[r] = __ballot(lane + 64 * r < limit && sd[r] == m && si[r] == mid);
+    }
+    int idx = 0;
+    uint32_t id = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (b[r]) {
+            int l = __ffsll((long long)b[r]) - 1;
+            idx = 64 * r + l;
+            id = (uint32_t)__builtin_amdgcn_readlane((int)si[r], l);
+        }
+    id_out = id;
+    return idx;
+}
+
+template <int METRIC, bool VIS_LDS, bool REGS>
 __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    uint64_t* work = (uint64_t*)lds;
-    uint64_t* cand = work + a.ef_cap;
-    uint32_t* nb_id = (uint32_t*)(cand + a.cand_cap);
+    uint64_t* W = (uint64_t*)lds;
+    uint64_t* C = W + a.ef_cap;
+    uint32_t* nb_id = (uint32_t*)(C + a.cand_cap);
     float* nb_dist = (float*)(nb_id + a.smax);
     float* qs = nb_dist + a.smax;
-    uint32_t* misc = (uint32_t*)(qs + a.dpad);  // [0] cur id, [1] state, [2] nnew, [4..7] wave counts
+    uint32_t* misc = (uint32_t*)(qs + a.dpad);  // [0] nnew (0xFFFFFFFF = stop), [1] next entry point, [2] wsize
     uint32_t* vis = VIS_LDS ? (misc + 16) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
 
     const int qi = blockIdx.x;
@@ -134,206 +260,246 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
     __syncthreads();
 
     const float* vecs = a.vecs + u.vec_off;
-    const int ef = a.ef;
+    const int ef = a.ef, cmask = a.cand_cap - 1;
     // wave-0 uniform state
-    int ncand = 0, wsize = 0, maxidx = 0;
-    uint64_t maxkey = 0;
+    int wsize = 0, cn = 0, cbase = 0;
+    uint32_t wd[WREGS], wi[WREGS], cd[CREGS], ci[CREGS];  // REGS mode slots
+    uint32_t fmax_o = 0, fmax_id = 0;                      // REGS: furthest element of the working set ...
+    int fmax_idx = 0;                                      // ... and its slot
     unsigned long long evals = 0, expanded = 0;
     bool nan_seen = false, overflow = false;
     uint32_t ep = u.entry_point;
 
     for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
         // ---- entry point: mark visited, distance, seed both sets (index.rs:219-231)
-        if (tid == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
-        if (grp == 0) {
-            float d0 = group16_distance<METRIC>(vecs + (size_t)ep * a.dpad, qs, a.p, j);
-            if (tid == 0) {
-                if (d0 != d0) nan_seen = true;
-                cand[0] = cand_key(d0, ep);
-                work[0] = make_key(d0, ep);
-            }
+        if (wave == 0) {
+            if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
+            float d0 = 0.0f;
+            if (lane < 16) d0 = group16_distance<METRIC>(vecs + (size_t)ep * a.dpad, qs, a.p, j);
+            d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), 0));
+            if (d0 != d0) nan_seen = true;
+            if (REGS) {
+#pragma unroll
+                for (int r = 0; r < WREGS; ++r) { wd[r] = SLOT_EMPTY; wi[r] = 0; }
+#pragma unroll
+                for (int r = 0; r < CREGS; ++r) { cd[r] = SLOT_EMPTY; ci[r] = 0; }
+                if (lane == 0) { wd[0] = f32_orderable(d0); wi[0] = ep; cd[0] = wd[0]; ci[0] = ep; }
+                fmax_o = f32_orderable(d0); fmax_id = ep; fmax_idx = 0;
+            } else if (lane == 0) { W[0] = make_key(d0, ep); C[0] = cand_key(d0, ep); }
+            wsize = 1; cn = 1; cbase = 0;
+            evals += 1;
         }
-        if (wave == 0) { ncand = 1; wsize = 1; maxidx = 0; }
-        evals += 1;
-        __syncthreads();
-        if (wave == 0) maxkey = work[0];
-
         for (;;) {
-            // ---- P1 (wave 0): pop the nearest candidate; stop when it is farther than the furthest kept
+            // ---- P1+P2 (wave 0): pop, adjacency row, visited test-and-set, ordered compaction
             if (wave == 0) {
-                uint32_t state = 0;  // 0 = stop, 1 = expand
-                if (ncand > 0 && !overflow) {
-                    uint64_t best = MDB_KEY_MAX;
-                    int bi = 0x7FFFFFFF;
-                    for (int i = lane; i < ncand; i += 64) {
-                        uint64_t kk = cand[i];
-                        if (kk < best) { best = kk; bi = i; }
-                    }
-                    wave_argmin(best, bi);
-                    // `distance > furthest.distance` on the order-preserving integer images of the two
-                    // floats (same result for non-NaN values; also sidesteps an ISel crash of this
-                    // toolchain on the float form of this compare)
-                    if (!((uint32_t)(best >> 32) > (uint32_t)(maxkey >> 32))) {
-                        state = 1;
-                        if (lane == 0) {
-                            cand[bi] = cand[ncand - 1];
-                            misc[0] = cand_id(best);
+                uint32_t nnew = 0xFFFFFFFFu;  // stop
+                bool go = false;
+                uint32_t cur = 0;
+                if (!overflow) {
+                    if (REGS) {
+                        // candidates.pop(): smallest distance, LARGEST id among equals (BinaryHeap<(-d,id)>)
+                        uint32_t lm = cd[0];
+#pragma unroll
+                        for (int r = 1; r < CREGS; ++r) lm = min(lm, cd[r]);
+                        const uint32_t m = wave_min_u32(lm);
+                        // `distance > furthest.distance` -> stop (index.rs:246-248), on the integer images
+                        if (m != SLOT_EMPTY && !(m > fmax_o)) {
+                            const int idx = slots_locate<CREGS, true>(cd, ci, m, 64 * CREGS, lane, cur);
+                            slots_write<CREGS>(cd, ci, idx, SLOT_EMPTY, 0, lane);
+                            go = true;
                         }
-                        ncand -= 1;
+                    } else if (cn > 0) {
+                        uint64_t ck = C[(cbase + cn - 1) & cmask];
+                        fmax_o = (uint32_t)(W[wsize - 1] >> 32);
+                        if (!((uint32_t)(ck >> 32) > fmax_o)) { cn -= 1; cur = cand_id(ck); go = true; }
                     }
                 }
-                if (lane == 0) misc[1] = state;
-            }
-            __syncthreads();
-            if (misc[1] == 0) break;
-            const uint32_t cur = misc[0];
-            // ---- P2 (all): adjacency row, visited test-and-set, ordered compaction of the new ones
-            uint32_t stride, nbr = 0xFFFFFFFFu;
-            const uint32_t* row = nullptr;
-            if (layer == 0) {
-                stride = u.S0;
-                if (cur < u.n0) row = a.adj + u.adj0_off + (size_t)cur * u.S0;
-            } else {
-                stride = u.SU;
-                if (a.level[u.upper_off + cur] >= layer)
-                    row = a.adj + u.adjU_off + ((size_t)a.upper_first[u.upper_off + cur] + (layer - 1)) * u.SU;
-            }
-            if (row && (uint32_t)tid < stride) nbr = row[tid];
-            bool isnew = false;
-            if (nbr != 0xFFFFFFFFu) {
-                if (nbr >= u.n) atomicOr(a.flags, MDB_FLAG_RANGE);
-                else {
-                    uint32_t bit = 1u << (nbr & 31);
-                    uint32_t old = atomicOr(&vis[nbr >> 5], bit);
-                    isnew = !(old & bit);
+                if (go) {
+                    uint32_t stride = 0;
+                    const uint32_t* row = nullptr;
+                    if (layer == 0) {
+                        stride = u.S0;
+                        if (cur < u.n0) row = a.adj + u.adj0_off + (size_t)cur * u.S0;
+                    } else {
+                        stride = u.SU;
+                        if (a.level[u.upper_off + cur] >= layer)
+                            row = a.adj + u.adjU_off + ((size_t)a.upper_first[u.upper_off + cur] + (layer - 1)) * u.SU;
+                    }
+                    nnew = 0;
+                    bool any = false;
+                    if (row) {
+                        for (uint32_t t0 = 0; t0 < stride; t0 += 64) {
+                            uint32_t t = t0 + lane;
+                            uint32_t nbr = t < stride ? row[t] : 0xFFFFFFFFu;
+                            bool isnew = false;
+                            if (nbr != 0xFFFFFFFFu) {
+                                if (nbr >= u.n) atomicOr(a.flags, MDB_FLAG_RANGE);
+                                else {
+                                    uint32_t bit = 1u << (nbr & 31);
+                                    uint32_t old = atomicOr(&vis[nbr >> 5], bit);
+                                    isnew = !(old & bit);
+                                }
+                            }
+                            any = any || __ballot(nbr != 0xFFFFFFFFu) != 0;
+                            unsigned long long bal = __ballot(isnew);
+                            if (isnew) nb_id[nnew + __popcll(bal & ((1ull << lane) - 1ull))] = nbr;
+                            nnew += __popcll(bal);
+                        }
+                    }
+                    expanded += any ? 1 : 0;
+                    evals += nnew;
                 }
+                if (lane == 0) misc[0] = nnew;
             }
-            unsigned long long bal = __ballot(isnew);
-            if (lane == 0) misc[4 + wave] = __popcll(bal);
-            unsigned long long has = __ballot(nbr != 0xFFFFFFFFu);
-            if (lane == 0) misc[8 + wave] = has != 0;
             __syncthreads();
-            uint32_t base = 0;
-            for (int w = 0; w < wave; ++w) base += misc[4 + w];
-            const uint32_t nnew = misc[4] + misc[5] + misc[6] + misc[7];
-            if (isnew) nb_id[base + __popcll(bal & ((1ull << lane) - 1ull))] = nbr;
-            if (tid == 0) { expanded += (misc[8] | misc[9] | misc[10] | misc[11]) ? 1 : 0; evals += nnew; }
-            __syncthreads();
+            const uint32_t nnew = misc[0];
+            if (nnew == 0xFFFFFFFFu) break;
             // ---- P3 (all): exact distances, one 16-lane group per neighbour
             for (uint32_t i = grp; i < nnew; i += HNSW_BLOCK / 16) {
                 float d = group16_distance<METRIC>(vecs + (size_t)nb_id[i] * a.dpad, qs, a.p, j);
                 if (j == 0) nb_dist[i] = d;
             }
             __syncthreads();
-            // ---- P4 (wave 0): accept in edge order (index.rs:258-283)
+            // ---- P4 (wave 0): accept (index.rs:258-283) and insert.
+            // e_i is accepted  <=>  d_i < furthest_i || len_i < ef, where furthest_i is the ef-th
+            // smallest distance of W u {e_1..e_{i-1}}  (rejected neighbours never change it)
+            //                  <=>  #{w in W : d_w <= d_i} + #{j < i : d_j <= d_i} < ef.
+            // The accepted set therefore does not depend on processing order, and the final W is the
+            // ef smallest keys of W u accepted: all tests are independent ballots.
             if (wave == 0) {
                 for (uint32_t c0 = 0; c0 < nnew; c0 += 64) {
-                    uint32_t i = c0 + lane;
-                    bool have = i < nnew;
-                    float d = have ? nb_dist[i] : 0.0f;
-                    uint32_t id = have ? nb_id[i] : 0;
-                    if (have && d != d) nan_seen = true;
-                    unsigned long long pending = __ballot(have);
-                    while (pending) {
-                        const uint32_t fdo = (uint32_t)(maxkey >> 32);  // orderable image of furthest.distance
-                        unsigned long long pass = __ballot(have && (f32_orderable(d) < fdo || wsize < ef)) & pending;
-                        if (!pass) break;
-                        int src = __ffsll((long long)pass) - 1;
-                        pending &= ~((2ull << src) - 1ull);  // everything up to src is decided
-                        float dd = __shfl(d, src);
-                        uint32_t did = __shfl(id, src);
-                        // candidates.push
-                        if (ncand >= a.cand_cap) {
-                            // drop candidates that can never be expanded (d > furthest while full)
-                            if (wsize >= ef) {
-                                int keep = 0;
-                                for (int b0 = 0; b0 < ncand; b0 += 64) {
-                                    int ii = b0 + lane;
-                                    uint64_t kk = ii < ncand ? cand[ii] : 0;
-                                    bool live = ii < ncand && !((uint32_t)(kk >> 32) > fdo);
-                                    unsigned long long lb = __ballot(live);
-                                    if (live) cand[keep + __popcll(lb & ((1ull << lane) - 1ull))] = kk;
-                                    keep += __popcll(lb);
-                                }
-                                ncand = keep;
-                            }
-                            if (ncand >= a.cand_cap) { overflow = true; pending = 0; break; }
-                        }
-                        if (lane == 0) cand[ncand] = cand_key(dd, did);
-                        ncand += 1;
-                        // working_list.push (+ pop of the maximum when over ef)
-                        uint64_t wk = make_key(dd, did);
-                        if (wsize < ef) {
-                            if (lane == 0) work[wsize] = wk;
-                            if (wk > maxkey) { maxkey = wk; maxidx = wsize; }
-                            wsize += 1;
+                    const uint32_t i = c0 + lane;
+                    const bool have0 = i < nnew;
+                    const float d = have0 ? nb_dist[i] : 0.0f;
+                    const uint32_t id = have0 ? nb_id[i] : 0;
+                    if (have0 && d != d) nan_seen = true;
+                    const bool have = have0 && d == d;
+                    const uint32_t od = f32_orderable(d);
+                    const bool full = wsize >= ef;
+                    if (!REGS) fmax_o = (uint32_t)(W[wsize - 1] >> 32);
+                    unsigned long long surv = __ballot(have && (!full || od < fmax_o));
+                    unsigned long long accepted = 0;
+                    const int wsize0 = wsize;
+                    while (surv) {
+                        const int sidx = __ffsll((long long)surv) - 1;
+                        surv &= surv - 1;
+                        const uint32_t ds = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                        int cnt = __popcll(__ballot(have && od <= ds) & ((1ull << sidx) - 1ull));
+                        if (REGS) {
+#pragma unroll
+                            for (int r = 0; r < WREGS; ++r) cnt += __popcll(__ballot(wd[r] <= ds));  // EMPTY never counts
                         } else {
-                            // len would be ef+1: pop removes the max of (set + new)
-                            if (wk < maxkey) {
-                                if (lane == 0) work[maxidx] = wk;
-                                uint64_t mk = 0;
-                                int mi = 0x7FFFFFFF;
-                                for (int ii = lane; ii < wsize; ii += 64) {
-                                    uint64_t kk = (ii == maxidx) ? wk : work[ii];
-                                    if (kk > mk || mi == 0x7FFFFFFF) { mk = kk; mi = ii; }
-                                }
-                                wave_argmax(mk, mi);
-                                maxkey = mk;
-                                maxidx = mi;
+                            for (int r0 = 0; r0 < wsize0 && cnt < ef; r0 += 64) {
+                                int idx = r0 + lane;
+                                bool le = idx < wsize0 && (uint32_t)(W[idx] >> 32) <= ds;
+                                unsigned long long b = __ballot(le);
+                                cnt += __popcll(b);
+                                if (b != ~0ull) break;  // W ascending: nothing further is <= ds
                             }
-                            // else: the new element itself is the maximum and is popped again
+                        }
+                        if (cnt < ef) accepted |= 1ull << sidx;
+                    }
+                    // NOTE: the tests above must see W as it was at the start of this chunk; the
+                    // insertions below only start after every test of the chunk is done.
+                    while (accepted) {
+                        const int sidx = __ffsll((long long)accepted) - 1;
+                        accepted &= accepted - 1;
+                        const uint32_t dod = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                        const uint32_t did = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
+                        if (REGS) {
+                            // candidates.push: first free slot
+                            bool placed = false;
+#pragma unroll
+                            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                                for (int r = 0; r < CREGS; ++r) {
+                                    if (!placed) {
+                                        unsigned long long fb = __ballot(cd[r] == SLOT_EMPTY);
+                                        if (fb) {
+                                            if (lane == __ffsll((long long)fb) - 1) { cd[r] = dod; ci[r] = did; }
+                                            placed = true;
+                                        }
+                                    }
+                                }
+                                if (!placed && pass == 0 && wsize >= ef) {
+                                    // no free slot: drop the candidates that can never be expanded
+                                    // (distance > furthest while the working set is full)
+#pragma unroll
+                                    for (int r = 0; r < CREGS; ++r)
+                                        if (cd[r] > fmax_o) cd[r] = SLOT_EMPTY;
+                                }
+                            }
+                            if (!placed) { overflow = true; break; }
+                            // working_list.push (+ pop of the maximum when over ef)
+                            if (wsize < ef) {
+                                slots_write<WREGS>(wd, wi, wsize, dod, did, lane);
+                                if (dod > fmax_o || (dod == fmax_o && did > fmax_id)) { fmax_o = dod; fmax_id = did; fmax_idx = wsize; }
+                                wsize += 1;
+                            } else if (dod < fmax_o || (dod == fmax_o && did < fmax_id)) {
+                                slots_write<WREGS>(wd, wi, fmax_idx, dod, did, lane);
+                                uint32_t lm = 0;
+#pragma unroll
+                                for (int r = 0; r < WREGS; ++r)
+                                    if (lane + 64 * r < ef) lm = max(lm, wd[r]);
+                                fmax_o = wave_max_u32(lm);
+                                fmax_idx = slots_locate<WREGS, true>(wd, wi, fmax_o, ef, lane, fmax_id);
+                            }
+                        } else {
+                            const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), sidx));
+                            if (cn >= a.cand_cap - 1) {
+                                if (wsize >= ef) cand_drop_dead(C, cbase, cmask, cn, (uint32_t)(W[wsize - 1] >> 32), lane);
+                                if (cn >= a.cand_cap - 1) { overflow = true; break; }
+                            }
+                            cand_insert(C, cbase, cmask, cn, cand_key(dd, did), lane);
+                            work_insert(W, wsize, ef, make_key(dd, did), lane);
                         }
                     }
                 }
             }
         }
-        __syncthreads();
+        // ---- layer done.  REGS: spill the working set and sort it (block-wide bitonic in the idle
+        // candidate region) so that W[0..wsize) is ascending by (distance, id) like the LDS variant.
+        if (REGS) {
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < WREGS; ++r)
+                    C[lane + 64 * r] = wd[r] == SLOT_EMPTY ? MDB_KEY_MAX : (((uint64_t)wd[r] << 32) | wi[r]);
+                if (lane == 0) misc[2] = (uint32_t)wsize;
+            }
+            __syncthreads();
+            const int n2 = 64 * WREGS;
+            for (int size = 2; size <= n2; size <<= 1) {
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int t = tid; t < (n2 >> 1); t += HNSW_BLOCK) {
+                        int lo = ((t / stride) * stride * 2) + (t % stride);
+                        int hi = lo + stride;
+                        bool up = ((lo & size) == 0);
+                        uint64_t x = C[lo], y = C[hi];
+                        if ((x > y) == up) { C[lo] = y; C[hi] = x; }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = tid; i < a.ef_cap; i += HNSW_BLOCK) W[i] = C[i];
+            __syncthreads();
+        } else {
+            if (wave == 0 && lane == 0) misc[2] = (uint32_t)wsize;
+            __syncthreads();
+        }
         if (layer > 0) {
             // ep = first minimum of the (distance,id)-sorted working set (index.rs:177-181)
-            if (wave == 0) {
-                uint64_t best = MDB_KEY_MAX;
-                int bi = 0x7FFFFFFF;
-                for (int i = lane; i < wsize; i += 64) {
-                    uint64_t kk = work[i];
-                    if (kk < best) { best = kk; bi = i; }
-                }
-                wave_argmin(best, bi);
-                if (lane == 0) misc[0] = key_id(best);
-            }
-            __syncthreads();
-            ep = misc[0];
+            ep = key_id(W[0]);
             __syncthreads();
         }
-        if (wave == 0 && lane == 0) misc[2] = (uint32_t)wsize;
-        __syncthreads();
     }
-    // ---- result: working set sorted by (distance, id), truncated to k
+    // ---- result: W is sorted by (distance, id); truncate to k
     const int ws = (int)misc[2];
-    int n2 = 2;
-    while (n2 < ws) n2 <<= 1;
-    uint64_t* sb = cand;  // reuse the candidate region (cand_cap >= pow2(ef_cap))
-    for (int i = tid; i < n2; i += HNSW_BLOCK) sb[i] = i < ws ? work[i] : MDB_KEY_MAX;
-    __syncthreads();
-    for (int size = 2; size <= n2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (n2 >> 1); t += HNSW_BLOCK) {
-                int lo = ((t / stride) * stride * 2) + (t % stride);
-                int hi = lo + stride;
-                bool up = ((lo & size) == 0);
-                uint64_t x = sb[lo], y = sb[hi];
-                if ((x > y) == up) { sb[lo] = y; sb[hi] = x; }
-            }
-            __syncthreads();
-        }
-    }
     const int outc = ws < a.k ? ws : a.k;
-    for (int i = tid; i < a.k; i += HNSW_BLOCK) a.out_keys[(size_t)qi * a.k + i] = i < outc ? sb[i] : MDB_KEY_MAX;
+    for (int i = tid; i < a.k; i += HNSW_BLOCK) a.out_keys[(size_t)qi * a.k + i] = i < outc ? W[i] : MDB_KEY_MAX;
     if (tid == 0) {
         a.out_counts[qi] = (uint32_t)outc;
         atomicAdd(&a.counters[0], evals);
         atomicAdd(&a.counters[1], expanded);
-    }
-    if (wave == 0 && lane == 0) {
         if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
         if (overflow) atomicOr(a.flags, MDB_FLAG_OVERFLOW);
     }
@@ -541,9 +707,9 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     a.vecs = d_vecs.p; a.q = d_q; a.qstride = qstride; a.dpad = dpad; a.p = make_plan((int)dimension, metric);
     a.ef = (int)ef;
     a.ef_cap = ((int)ef + 63) / 64 * 64;
-    int p2 = 2;
-    while (p2 < a.ef_cap) p2 <<= 1;
-    a.cand_cap = std::max(a.ef_cap + 1024, p2);
+    int p2 = 64 * CREGS;  // >= the register-resident candidate array (its dead-drop pass stages through C)
+    while (p2 < a.ef_cap + 192) p2 <<= 1;
+    a.cand_cap = p2;  // ring capacity (power of two): live candidates <= ef + ties
     a.smax = std::max<int>(64, ((int)max_stride + 63) / 64 * 64);
     a.k = (int)k;
     a.out_keys = d_keys; a.out_counts = d_counts; a.flags = ctx->d_flags; a.counters = ctx->d_counters;
@@ -559,15 +725,21 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         a.vis_global = (uint32_t*)vg;
     }
     ProfScope prof(ctx);
-#define MDB_HNSW_LAUNCH(METRIC, VL)                                                                                        \
+#define MDB_HNSW_LAUNCH(METRIC, VL, RG)                                                                                        \
     do {                                                                                                                   \
         if (lds > 48 * 1024)                                                                                               \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel<METRIC, VL>,                                  \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel<METRIC, VL, RG>,                                  \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
-        hnsw_search_kernel<METRIC, VL><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                            \
+        hnsw_search_kernel<METRIC, VL, RG><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                            \
     } while (0)
-    if (metric == MDB_METRIC_L2) { if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false); }
-    else { if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false); }
+    const bool regs = ef <= 64 * WREGS && !getenv("MDB_HNSW_NO_REGS");
+    if (metric == MDB_METRIC_L2) {
+        if (vis_lds) { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, true, false); }
+        else { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_L2, false, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false, false); }
+    } else {
+        if (vis_lds) { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true, false); }
+        else { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false, false); }
+    }
 #undef MDB_HNSW_LAUNCH
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
