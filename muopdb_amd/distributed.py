@@ -1,0 +1,69 @@
+"""Multi-GPU search: one process per GPU, `torch.distributed` (backend "nccl" is
+RCCL over xGMI on ROCm).
+
+Partitioning
+  * IVF / SPANN / multi-user SPANN: every rank loads the same files with (shard_rank, shard_world);
+    posting list l of every user is owned by rank l % world, centroids / graphs / doc-id tables are
+    replicated, so probe selection is identical on all ranks and the union of the per-rank top-k
+    equals the single-GPU result exactly.
+  * HNSW: the traversal does not partition (replicas only): ranks split the batch, no collective.
+  * flat: row-range shards, same gather + merge.
+
+Collective: ONE all-gather per batch of fixed-size per-rank blocks — doc ids [B][k] (2 x u64),
+scores [B][k] f32, counts [B] — (24*k + 4) bytes per query per rank: latency-bound, far below a
+single xGMI link's bandwidth, so a direct all-gather (not a ring pipeline) is the right shape.
+Merge: per query, the `world` sorted rows are merged by IdWithScore order (score, doc id) and
+truncated to k — Snapshot::search_for_users' rule (rs/index/src/collection/snapshot.rs:60-63), not
+the aggregator's descending sort (rs/aggregator/src/aggregator.rs:135).
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+
+def shard_of_list(list_index, world):
+    """Owner rank of posting list `list_index` (what mdb_*_load(shard_rank, shard_world) implements)."""
+    return list_index % world
+
+
+def split_batch(b, rank, world):
+    """Contiguous slice [lo, hi) of a batch of b queries for replica-parallel search."""
+    return rank * b // world, (rank + 1) * b // world
+
+
+def all_gather_topk(doc_ids, scores, counts, group=None):
+    """doc_ids int64 [B,k,2] (lo,hi), scores f32 [B,k], counts int32 [B] (this rank's shard result)
+    -> ([W,B,k,2], [W,B,k], [W,B]) on every rank."""
+    world = dist.get_world_size(group)
+    def gather(t):
+        t = t.contiguous()
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)  # rank-major concatenation along dim 0
+        return out.view((world,) + tuple(t.shape))
+
+    return gather(doc_ids), gather(scores), gather(counts)
+
+
+def merge_shards_device(ctx, gd, gs, gc, out_docs=None, out_scores=None, out_counts=None):
+    """mdb_merge_shards on HBM-resident gathered blocks; returns (docs [B,k,2], scores [B,k], counts [B])."""
+    world, b, k = gs.shape
+    dev = gs.device
+    out_docs = out_docs if out_docs is not None else torch.empty((b, k, 2), dtype=torch.int64, device=dev)
+    out_scores = out_scores if out_scores is not None else torch.empty((b, k), dtype=torch.float32, device=dev)
+    out_counts = out_counts if out_counts is not None else torch.empty(b, dtype=torch.int32, device=dev)
+    ctx.check(ctx.lib.mdb_merge_shards(ctx.h, C.c_void_p(gd.data_ptr()), C.c_void_p(gs.data_ptr()),
+                                       C.c_void_p(gc.data_ptr()), C.c_size_t(world), C.c_size_t(b), C.c_size_t(k),
+                                       C.c_void_p(out_docs.data_ptr()), C.c_void_p(out_scores.data_ptr()),
+                                       C.c_void_p(out_counts.data_ptr())))
+    return out_docs, out_scores, out_counts
+
+
+def sharded_search(local_search, merge, group=None):
+    """local_search() -> (docs, scores, counts) of this rank's shard; gathers and merges on every rank.
+    `merge(gd, gs, gc)` is merge_shards_device bound to a context on GPUs."""
+    docs, scores, counts = local_search()
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return docs, scores, counts
+    gd, gs, gc = all_gather_topk(docs, scores, counts, group)
+    return merge(gd, gs, gc)

@@ -23,6 +23,7 @@
 // an FMA, so contraction must stay off for the arithmetic to follow the reference).
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -637,10 +638,13 @@ struct Hnsw {
     HnswGraph g;
     VectorFile vec;
     Quantizer q;
-    mutable uint64_t stat_distance_evals = 0, stat_expanded = 0;
+    // per-query counters are accumulated locally and added once per query (no false sharing when
+    // queries run on many threads)
+    mutable std::atomic<uint64_t> stat_distance_evals{0}, stat_expanded{0};
+    struct Counters { uint64_t evals = 0, expanded = 0; };
 
-    float distance(const void* qq, uint32_t pid) const {  // :289-298
-        ++stat_distance_evals;
+    float distance(const void* qq, uint32_t pid, Counters& ct) const {  // :289-298
+        ++ct.evals;
         if (q.kind == 0) return metric_distance(q.metric, (const float*)qq, (const float*)vec.get(pid), q.dimension);
         return q.pq.distance_streaming((const uint8_t*)qq, vec.get(pid));
     }
@@ -648,11 +652,11 @@ struct Hnsw {
     // :212-287 (same algorithm as rs/index/src/hnsw/utils.rs:58-129).  `visited` persists
     // across layers (one SearchContext per ann_search, :172).
     bool search_layer(std::vector<bool>& visited, const void* qq, uint32_t entry, uint32_t ef,
-                      uint32_t layer, std::vector<PointAndDistance>& result) const {
+                      uint32_t layer, std::vector<PointAndDistance>& result, Counters& ct) const {
         visited[entry] = true;
         std::priority_queue<PointAndDistance> candidates;  // keyed (-d, id)
         std::priority_queue<PointAndDistance> working;     // keyed (d, id)
-        float ed = distance(qq, entry);
+        float ed = distance(qq, entry, ct);
         if (std::isnan(ed)) return false;
         candidates.push({-ed, entry});
         working.push({ed, entry});
@@ -664,14 +668,14 @@ struct Hnsw {
             if (working.empty()) continue;
             if (dist > working.top().distance) break;
             if (!g.get_edges_for_point(c.point_id, layer, edges)) continue;
-            ++stat_expanded;
+            ++ct.expanded;
             for (uint32_t e : edges) {
                 if (e >= visited.size()) return false;
                 if (visited[e]) continue;
                 visited[e] = true;
                 if (working.empty()) continue;
                 float furthest = working.top().distance;
-                float de = distance(qq, e);
+                float de = distance(qq, e, ct);
                 if (std::isnan(de)) return false;
                 if (de < furthest || working.size() < ef) {
                     candidates.push({-de, e});
@@ -698,15 +702,17 @@ struct Hnsw {
         uint32_t ep = g.entry_point_top_layer();
         if (ep >= vec.num_vectors) return false;
         std::vector<PointAndDistance> ws;
+        Counters ct;
+        struct Flush { const Hnsw* h; Counters* c; ~Flush() { h->stat_distance_evals.fetch_add(c->evals, std::memory_order_relaxed); h->stat_expanded.fetch_add(c->expanded, std::memory_order_relaxed); } } flush{this, &ct};
         while (layer > 0) {
-            if (!search_layer(visited, qq, ep, ef, (uint32_t)layer, ws)) return false;
+            if (!search_layer(visited, qq, ep, ef, (uint32_t)layer, ws, ct)) return false;
             // min_by distance only => FIRST minimum of the (distance,id)-sorted list
             size_t best = 0;
             for (size_t i = 1; i < ws.size(); ++i) if (ws[i].distance < ws[best].distance) best = i;
             ep = ws[best].point_id;
             --layer;
         }
-        if (!search_layer(visited, qq, ep, ef, 0, ws)) return false;
+        if (!search_layer(visited, qq, ep, ef, 0, ws, ct)) return false;
         std::stable_sort(ws.begin(), ws.end(), [](auto& a, auto& b) { return a.distance < b.distance; });
         if (ws.size() > k) ws.resize(k);
         for (auto& pd : ws) out.push_back({g.doc_id(pd.point_id), pd.distance});
@@ -1189,7 +1195,7 @@ int orc_hnsw_ann_search(void* p, const float* queries, size_t b, size_t k, uint3
 }
 void orc_hnsw_stats(void* p, uint64_t* evals, uint64_t* expanded, int reset) {
     Hnsw* h = (Hnsw*)p;
-    *evals = h->stat_distance_evals; *expanded = h->stat_expanded;
+    *evals = h->stat_distance_evals.load(); *expanded = h->stat_expanded.load();
     if (reset) { h->stat_distance_evals = 0; h->stat_expanded = 0; }
 }
 
@@ -1205,7 +1211,11 @@ void* orc_spann_open(const uint8_t* hidx, size_t hidx_len, size_t hidx_off, cons
                                    ivf->st.num_features, 0, 0, nullptr, 0);
     if (!h) { delete ivf; return nullptr; }
     Spann* s = new Spann();
-    s->centroids = std::move(*h);
+    s->centroids.index_bytes = std::move(h->index_bytes);
+    s->centroids.vector_bytes = std::move(h->vector_bytes);
+    s->centroids.g = std::move(h->g);
+    s->centroids.vec = h->vec;
+    s->centroids.q = std::move(h->q);
     s->centroids.g.bytes = s->centroids.index_bytes.data();
     s->centroids.vec.bytes = s->centroids.vector_bytes.data();
     s->posting_lists = std::move(*ivf);

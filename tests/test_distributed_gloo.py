@@ -1,0 +1,108 @@
+"""world_size-2 `gloo` tests (CPU) of the multi-GPU host path: list sharding,
+the per-batch all-gather of fixed-size top-k blocks and the (score, doc id) merge.  The per-shard
+results come from the CPU oracle here (the GPU kernels are covered by the -m gpu suite, including
+`test_merge_shards_device` and the shard-union tests); what is under test is the collective plumbing
+and that the union of per-rank top-k equals the unsharded answer."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from muopdb_amd import distributed as D
+from tests import helpers as H
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def merge_numpy(gd, gs, gc):
+    """Host restatement of mdb_merge_shards (IdWithScore order, truncate to k)."""
+    gd, gs, gc = gd.numpy().view(np.uint64), gs.numpy(), gc.numpy()
+    world, b, k = gs.shape
+    od = np.full((b, k, 2), np.iinfo(np.uint64).max, np.uint64)
+    osc = np.full((b, k), np.inf, np.float32)
+    ocn = np.zeros(b, np.int32)
+    for qi in range(b):
+        rows = []
+        for w in range(world):
+            for j in range(int(gc[w, qi])):
+                rows.append((float(gs[w, qi, j]), int(gd[w, qi, j, 1]), int(gd[w, qi, j, 0])))
+        rows.sort()
+        rows = rows[:k]
+        ocn[qi] = len(rows)
+        for j, (s, hi, lo) in enumerate(rows):
+            od[qi, j] = (lo, hi)
+            osc[qi, j] = s
+    return torch.from_numpy(od.view(np.int64)), torch.from_numpy(osc), torch.from_numpy(ocn)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    rng = np.random.default_rng(3)
+    v = H.sift_like(1500, 16, n_clusters=12, seed=4)
+    c = H.kmeans(v, 10, iters=3, seed=1)
+    doc_ids = [5 * i + 1 + ((i % 2) << 80) for i in range(1500)]
+    q = (v[rng.integers(0, 1500, 12)] + rng.normal(0, 1, (12, 16))).astype(np.float32)
+    k, P = 7, 4
+    full_index, full_vec, pls = H.build_ivf_files(v, doc_ids, c)
+    full = oracle.BlockBasedIvf(full_index, full_vec)
+    probes = full.find_nearest_centroids(q, P)  # replicated centroids => identical probes on every rank
+    # this rank's shard: only the posting lists it owns (list l -> rank l % world)
+    from muopdb_amd import formats as F
+    mine = [pl if D.shard_of_list(l, world) == rank else np.zeros(0, np.uint64) for l, pl in enumerate(pls)]
+    shard = oracle.BlockBasedIvf(F.write_ivf_index(c, doc_ids, mine), full_vec)
+    r = shard.search(q, k, probes=probes)
+
+    def local():
+        docs = np.stack([r.lo, r.hi], -1).astype(np.uint64).view(np.int64)
+        return torch.from_numpy(docs), torch.from_numpy(r.scores.copy()), torch.from_numpy(r.counts.astype(np.int32))
+
+    docs, scores, counts = D.sharded_search(local, merge_numpy)
+    ref = full.search(q, k, probes=probes)
+    got = docs.numpy().view(np.uint64)
+    ok = True
+    for qi in range(len(q)):
+        n = int(ref.counts[qi])
+        ok &= int(counts[qi]) == n
+        ok &= [(int(got[qi, j, 1]) << 64) | int(got[qi, j, 0]) for j in range(n)] == ref.doc_ids(qi)
+        ok &= np.array_equal(scores[qi, :n].numpy(), ref.scores[qi, :n])
+    lo, hi = D.split_batch(10, rank, world)
+    ok &= (lo, hi) == (rank * 5, rank * 5 + 5)
+    t = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(float(t.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ivf_gather_merge_world2():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) == 1.0
+
+
+def test_shard_assignment_covers_every_list_once():
+    for world in (1, 2, 3, 8):
+        owners = [D.shard_of_list(l, world) for l in range(100)]
+        assert set(owners) == set(range(min(world, 100)))
+        assert all(0 <= o < world for o in owners)
+        spans = [D.split_batch(64, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == 64 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
