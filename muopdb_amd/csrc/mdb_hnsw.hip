@@ -90,7 +90,7 @@ __device__ __forceinline__ float group16_distance(const float* __restrict__ x, c
     float ret = 0.0f;
     if (p.n16 > 0) {
         float acc = 0.0f;
-        for (int c = 0; c < p.n16; ++c) acc = acc_term<METRIC>(acc, qs[16 * c + j], x[16 * c + j]);
+        for (int c = 0; c < p.n16; ++c) acc = acc_term<METRIC>(acc, qs[16 * c + j], x[j * p.n16 + c]);
         ret = __fadd_rn(ret, group_reduce<16>(acc));
     }
     if (p.n8 > 0) {
@@ -107,6 +107,23 @@ __device__ __forceinline__ float group16_distance(const float* __restrict__ x, c
     }
     for (int t = 0; t < p.ntail; ++t) ret = acc_term<METRIC>(ret, qs[p.offt + t], x[p.offt + t]);
     return finish_distance<METRIC>(ret);
+}
+
+// d = 16*N16 exactly (128, 768, ...): lane j's query elements are already in registers and its N16
+// stored elements are contiguous (16-byte loads); fully unrolled, so all loads are in flight at once.
+template <int METRIC, int N16>
+__device__ __forceinline__ float group16_distance_fast(const float* __restrict__ x, const float (&qr)[N16], int j) {
+    float xv[N16];
+    const float4* x4 = (const float4*)(x + j * N16);
+#pragma unroll
+    for (int c = 0; c < N16 / 4; ++c) {
+        float4 v = x4[c];
+        xv[4 * c + 0] = v.x; xv[4 * c + 1] = v.y; xv[4 * c + 2] = v.z; xv[4 * c + 3] = v.w;
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < N16; ++c) acc = acc_term<METRIC>(acc, qr[c], xv[c]);
+    return finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce<16>(acc)));
 }
 
 // ---- wave-0 helpers on the two sorted LDS arrays (all ballot based: no cross-lane reductions)
@@ -234,7 +251,7 @@ __device__ __forceinline__ int slots_locate(const uint32_t (&sd)[R], const uint3
     return idx;
 }
 
-template <int METRIC, bool VIS_LDS, bool REGS>
+template <int METRIC, bool VIS_LDS, bool REGS, int N16T>
 __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint64_t* W = (uint64_t*)lds;
@@ -261,6 +278,13 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
 
     const float* vecs = a.vecs + u.vec_off;
     const int ef = a.ef, cmask = a.cand_cap - 1;
+    float qr[N16T > 0 ? N16T : 1];  // this lane's query elements (SIMD lane j of every 16-chunk)
+    if (N16T > 0) {
+#pragma unroll
+        for (int c = 0; c < N16T; ++c) qr[c] = qs[16 * c + j];
+    }
+#define MDB_GROUP_DIST(rowptr) (N16T > 0 ? group16_distance_fast<METRIC, (N16T > 0 ? N16T : 4)>((rowptr), reinterpret_cast<const float (&)[N16T > 0 ? N16T : 4]>(qr), j) \
+                                         : group16_distance<METRIC>((rowptr), qs, a.p, j))
     // wave-0 uniform state
     int wsize = 0, cn = 0, cbase = 0;
     uint32_t wd[WREGS], wi[WREGS], cd[CREGS], ci[CREGS];  // REGS mode slots
@@ -275,7 +299,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
         if (wave == 0) {
             if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
             float d0 = 0.0f;
-            if (lane < 16) d0 = group16_distance<METRIC>(vecs + (size_t)ep * a.dpad, qs, a.p, j);
+            if (lane < 16) d0 = MDB_GROUP_DIST(vecs + (size_t)ep * a.dpad);
             d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), 0));
             if (d0 != d0) nan_seen = true;
             if (REGS) {
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
             if (nnew == 0xFFFFFFFFu) break;
             // ---- P3 (all): exact distances, one 16-lane group per neighbour
             for (uint32_t i = grp; i < nnew; i += HNSW_BLOCK / 16) {
-                float d = group16_distance<METRIC>(vecs + (size_t)nb_id[i] * a.dpad, qs, a.p, j);
+                float d = MDB_GROUP_DIST(vecs + (size_t)nb_id[i] * a.dpad);
                 if (j == 0) nb_dist[i] = d;
             }
             __syncthreads();
@@ -527,13 +551,17 @@ __global__ void hnsw_remap_kernel(const uint64_t* __restrict__ keys, const uint3
     }
 }
 
+// Stored row layout: the part covered by the 16-lane pass (elements e < 16*n16) is transposed so
+// that SIMD lane j's n16 elements are contiguous — position (e%16)*n16 + e/16 — and a 16-lane group
+// reads a row with 16-byte loads; the remainder keeps its natural position.
 __global__ void copy_rows_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ row_src, int d, int dpad,
-                                 float* __restrict__ dst, size_t total) {
+                                 int n16, float* __restrict__ dst, size_t total) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     size_t r = t / dpad;
     int e = (int)(t % dpad);
-    dst[t] = e < d ? ((const float*)(src + row_src[r]))[e] : 0.0f;
+    int pos = e < 16 * n16 ? (e % 16) * n16 + e / 16 : e;
+    dst[r * dpad + pos] = e < d ? ((const float*)(src + row_src[r]))[e] : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------ load
@@ -690,7 +718,8 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
     if (!h_upper_first.empty()) MDB_HIP(ctx, hipMemcpyAsync(d_upper_first.p, h_upper_first.data(), h_upper_first.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!h_level.empty()) MDB_HIP(ctx, hipMemcpyAsync(d_level.p, h_level.data(), h_level.size(), hipMemcpyHostToDevice, ctx->stream));
     size_t total = row_src.size() * (size_t)dpad;
-    if (total) copy_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(d_vec.p, d_row_src.p, (int)dim, dpad, d_vecs.p, total);
+    if (total) copy_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(d_vec.p, d_row_src.p, (int)dim, dpad,
+                                                                                             make_plan((int)dim, metric).n16, d_vecs.p, total);
     MDB_HIP(ctx, hipGetLastError());
     MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MDB_OK;
@@ -725,14 +754,22 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         a.vis_global = (uint32_t*)vg;
     }
     ProfScope prof(ctx);
-#define MDB_HNSW_LAUNCH(METRIC, VL, RG)                                                                                        \
+#define MDB_HNSW_LAUNCH4(METRIC, VL, RG, NF)                                                                                        \
     do {                                                                                                                   \
         if (lds > 48 * 1024)                                                                                               \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel<METRIC, VL, RG>,                                  \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel<METRIC, VL, RG, NF>,                                  \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
-        hnsw_search_kernel<METRIC, VL, RG><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                            \
+        hnsw_search_kernel<METRIC, VL, RG, NF><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                            \
     } while (0)
     const bool regs = ef <= 64 * WREGS && !getenv("MDB_HNSW_NO_REGS");
+    // specialised distance when the whole vector is 16-lane chunks (d = 128 / 768: the configs' dims)
+    const int nf = (a.p.n8 == 0 && a.p.n4 == 0 && a.p.ntail == 0 && !getenv("MDB_HNSW_GENERIC_DIST")) ? a.p.n16 : 0;
+#define MDB_HNSW_LAUNCH(METRIC, VL, RG)                                   \
+    do {                                                                    \
+        if (nf == 8) MDB_HNSW_LAUNCH4(METRIC, VL, RG, 8);                   \
+        else if (nf == 48) MDB_HNSW_LAUNCH4(METRIC, VL, RG, 48);            \
+        else MDB_HNSW_LAUNCH4(METRIC, VL, RG, 0);                           \
+    } while (0)
     if (metric == MDB_METRIC_L2) {
         if (vis_lds) { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, true, false); }
         else { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_L2, false, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false, false); }
@@ -740,6 +777,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         if (vis_lds) { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true, false); }
         else { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false, false); }
     }
+#undef MDB_HNSW_LAUNCH4
 #undef MDB_HNSW_LAUNCH
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
