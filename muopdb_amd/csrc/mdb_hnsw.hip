@@ -263,7 +263,8 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
     uint32_t* vis = VIS_LDS ? (misc + 16) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
 
     const int qi = blockIdx.x;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
     const int grp = tid >> 4, j = tid & 15;
     const HnswUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
     if (!u.valid || u.n == 0 || u.num_layers == 0 || u.entry_point >= u.n) {
@@ -529,6 +530,313 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
     }
 }
 
+// ==========================================================================================
+// hnsw_beam_kernel — the ef <= 256 traversal kernel (bench configuration).
+//
+// One over-full array instead of two heaps, and COUNTS instead of a tracked maximum.
+//  * Every candidate the reference pushes enters the working list at the same moment
+//    (index.rs:269-277) and leaves it only by being the maximum when something nearer arrives; from
+//    then on it is a dead candidate (the `distance > furthest` break, :246-248) unless it ties with
+//    the furthest distance.  So wave 0 keeps ONE unsorted array B (320 slots in VGPRs, slot idx =
+//    lane + 64 r) holding the true working set W (= the ef smallest keys of B) plus whatever has been
+//    pushed out of W since the last compaction, and 5 uniform bitmasks of the unexpanded slots.
+//  * furthest.distance is never materialised.  With f = the ef-th smallest distance in B:
+//        d < f   <=>  #{b in B : d_b <= d} < ef        (accept test, together with the earlier
+//                                                       neighbours of the same node — see the lemma
+//                                                       in hnsw_search_kernel)
+//        d > f   <=>  #{b in B : d_b <  d} >= ef       (the stop test of a popped candidate)
+//    — elements of B outside W all have distance >= f, so they never disturb either count.
+//  * push = append to free slots (all accepted neighbours of a node at once, through a small LDS
+//    staging area); pop = masked DPP min-reduction over the unexpanded slots (largest id among equal
+//    distances, like BinaryHeap<(-d,id)>); when B is full, a 32-step ballot radix-select finds f and
+//    everything farther than f is dropped (ties stay: they are still legal candidates).
+// A lone wave pays ~10-15 cycles per dependent instruction (VALU<->SALU round trips), so the design
+// goal is instruction count on wave 0's path, not bandwidth.
+// ==========================================================================================
+#define BREGS 5
+#define BEAM_CAP (64 * BREGS)
+
+template <int METRIC, bool VIS_LDS, int N16T>
+__global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint64_t* W = (uint64_t*)lds;
+    uint64_t* C = W + a.ef_cap;              // [0..512): staging / sort buffer, [512..768) as u32 flags
+    uint32_t* nb_id = (uint32_t*)(C + a.cand_cap);
+    float* nb_dist = (float*)(nb_id + a.smax);
+    float* qs = nb_dist + a.smax;
+    uint32_t* misc = (uint32_t*)(qs + a.dpad);  // [0] nnew (0xFFFFFFFF = stop), [2] wsize
+    uint32_t* vis = VIS_LDS ? (misc + 16) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
+    uint32_t* stage_flag = (uint32_t*)(C + 512);
+
+    const int qi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+    const int grp = tid >> 4, j = tid & 15;
+    const HnswUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
+    if (!u.valid || u.n == 0 || u.num_layers == 0 || u.entry_point >= u.n) {
+        for (int i = tid; i < a.k; i += HNSW_BLOCK) a.out_keys[(size_t)qi * a.k + i] = MDB_KEY_MAX;
+        if (tid == 0) a.out_counts[qi] = 0;
+        return;
+    }
+    for (int i = tid; i < a.dpad; i += HNSW_BLOCK) qs[i] = a.q[(size_t)qi * a.qstride + i];
+    if (VIS_LDS)
+        for (unsigned long long i = tid; i < a.vis_words; i += HNSW_BLOCK) vis[i] = 0;
+    __syncthreads();
+
+    const float* vecs = a.vecs + u.vec_off;
+    const int ef = a.ef;
+    float qr[N16T > 0 ? N16T : 1];
+    if (N16T > 0) {
+#pragma unroll
+        for (int c = 0; c < N16T; ++c) qr[c] = qs[16 * c + j];
+    }
+#define MDB_BEAM_DIST(rowptr) (N16T > 0 ? group16_distance_fast<METRIC, (N16T > 0 ? N16T : 4)>((rowptr), reinterpret_cast<const float (&)[N16T > 0 ? N16T : 4]>(qr), j) \
+                                        : group16_distance<METRIC>((rowptr), qs, a.p, j))
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // ---- wave-0 state
+    uint32_t bd[BREGS], bi[BREGS];       // B: distance image / id per slot, SLOT_EMPTY beyond n
+    unsigned long long unexp[BREGS];     // unexpanded slots
+    int n = 0;                           // used slots
+    uint32_t fbound = SLOT_EMPTY;        // an upper bound of furthest.distance (prefilter only)
+    uint32_t rowv[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    bool stop = false;
+    unsigned long long evals = 0, expanded = 0;
+    bool nan_seen = false, overflow = false;
+    uint32_t ep = u.entry_point;
+
+    for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
+        const uint32_t stride = layer == 0 ? u.S0 : u.SU;
+        const uint32_t* const adj_base = a.adj + (layer == 0 ? u.adj0_off : u.adjU_off);
+        // adjacency row of `node` at this layer -> rowv (lane + 64 c); the loads stay in flight
+        auto load_row = [&](uint32_t node) {
+            const uint32_t* row = nullptr;
+            if (layer == 0) {
+                if (node < u.n0) row = adj_base + (size_t)node * stride;
+            } else if (a.level[u.upper_off + node] >= layer) {
+                row = adj_base + ((size_t)a.upper_first[u.upper_off + node] + (layer - 1)) * stride;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t t = lane + 64 * c;
+                rowv[c] = (row && t < stride) ? row[t] : 0xFFFFFFFFu;
+            }
+        };
+        // ---- entry point: mark visited, distance, seed B (index.rs:219-231) and pop it at once
+        if (wave == 0) {
+            if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
+            load_row(ep);
+            float d0 = 0.0f;
+            if (lane < 16) d0 = MDB_BEAM_DIST(vecs + (size_t)ep * a.dpad);
+            d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), 0));
+            if (d0 != d0) nan_seen = true;
+#pragma unroll
+            for (int r = 0; r < BREGS; ++r) { bd[r] = SLOT_EMPTY; bi[r] = 0; unexp[r] = 0; }
+            if (lane == 0) { bd[0] = f32_orderable(d0); bi[0] = ep; }
+            n = 1;
+            fbound = SLOT_EMPTY;
+            stop = false;
+            evals += 1;
+        }
+        for (;;) {
+            // ---- P2 (wave 0): visited test-and-set + ordered compaction of the popped node's row
+            if (wave == 0) {
+                uint32_t nnew = 0xFFFFFFFFu;
+                if (!stop && !overflow) {
+                    nnew = 0;
+                    bool any = false;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if ((uint32_t)(64 * c) < stride) {
+                            const uint32_t nbr = rowv[c];
+                            bool isnew = false;
+                            if (nbr != 0xFFFFFFFFu) {
+                                if (nbr >= u.n) atomicOr(a.flags, MDB_FLAG_RANGE);
+                                else {
+                                    uint32_t bit = 1u << (nbr & 31);
+                                    uint32_t old = atomicOr(&vis[nbr >> 5], bit);
+                                    isnew = !(old & bit);
+                                }
+                            }
+                            any = any || __ballot(nbr != 0xFFFFFFFFu) != 0;
+                            unsigned long long bal = __ballot(isnew);
+                            if (isnew) nb_id[nnew + __popcll(bal & lt_mask)] = nbr;
+                            nnew += __popcll(bal);
+                        }
+                    }
+                    expanded += any ? 1 : 0;
+                    evals += nnew;
+                }
+                if (lane == 0) misc[0] = nnew;
+            }
+            __syncthreads();
+            const uint32_t nnew = misc[0];
+            if (nnew == 0xFFFFFFFFu) break;
+            // ---- P3 (all): exact distances, one 16-lane group per neighbour
+            for (uint32_t i = grp; i < nnew; i += HNSW_BLOCK / 16) {
+                float d = MDB_BEAM_DIST(vecs + (size_t)nb_id[i] * a.dpad);
+                if (j == 0) nb_dist[i] = d;
+            }
+            __syncthreads();
+            // ---- P4 (wave 0): accept + push, then pop the next node and get its row moving
+            if (wave == 0) {
+                for (uint32_t c0 = 0; c0 < nnew; c0 += 64) {
+                    const uint32_t i = c0 + lane;
+                    const bool have0 = i < nnew;
+                    const float d = have0 ? nb_dist[i] : 0.0f;
+                    const uint32_t id = have0 ? nb_id[i] : 0;
+                    if (have0 && d != d) nan_seen = true;
+                    const bool have = have0 && d == d;
+                    const uint32_t od = f32_orderable(d);
+                    unsigned long long surv = __ballot(have && od < fbound);
+                    unsigned long long accepted = 0;
+                    while (surv) {
+                        const int sidx = __ffsll((long long)surv) - 1;
+                        surv &= surv - 1;
+                        const uint32_t ds = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                        int cnt = __popcll(__ballot(have && od <= ds) & ((1ull << sidx) - 1ull));
+#pragma unroll
+                        for (int r = 0; r < BREGS; ++r) cnt += __popcll(__ballot(bd[r] <= ds));
+                        if (cnt < ef) accepted |= 1ull << sidx;
+                        else fbound = min(fbound, ds);  // >= ef elements within ds: furthest <= ds from now on
+                    }
+                    const int na = __popcll(accepted);
+                    if (na) {
+                        if (n + na > BEAM_CAP) {
+                            // ---- compaction: f = ef-th smallest distance image in B (32-step radix select by
+                            // ballots; EMPTY = 0xFFFFFFFF sorts last), drop everything farther than f
+                            uint32_t prefix = 0;
+                            int need = ef;
+                            for (int bit = 31; bit >= 0; --bit) {
+                                const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+                                int cnt0 = 0;
+#pragma unroll
+                                for (int r = 0; r < BREGS; ++r)
+                                    cnt0 += __popcll(__ballot((((bd[r] ^ prefix) & hi_mask) == 0u) && !((bd[r] >> bit) & 1u)));
+                                if (cnt0 < need) { need -= cnt0; prefix |= 1u << bit; }
+                            }
+                            const uint32_t f = prefix;
+                            int kept = 0;
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r) {
+                                const bool keep = bd[r] <= f;  // EMPTY never kept (f is a real distance: n > ef here)
+                                const unsigned long long km = __ballot(keep);
+                                if (keep) {
+                                    const int pos = kept + __popcll(km & lt_mask);
+                                    C[pos] = ((uint64_t)bd[r] << 32) | bi[r];
+                                    stage_flag[pos] = (uint32_t)((unexp[r] >> lane) & 1ull);
+                                }
+                                kept += __popcll(km);
+                            }
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r) {
+                                const int idx = lane + 64 * r;
+                                const bool in = idx < kept;
+                                const uint64_t kk = in ? C[idx] : 0;
+                                bd[r] = in ? (uint32_t)(kk >> 32) : SLOT_EMPTY;
+                                bi[r] = in ? (uint32_t)kk : 0u;
+                                unexp[r] = __ballot(in && stage_flag[idx] != 0u);
+                            }
+                            n = kept;
+                            fbound = min(fbound, f);
+                            if (n + na > BEAM_CAP) { overflow = true; break; }  // > ~120 exact ties with furthest
+                        }
+                        // ---- push all accepted neighbours: slots n .. n+na-1, in edge order
+                        if ((accepted >> lane) & 1ull) C[__popcll(accepted & lt_mask)] = ((uint64_t)od << 32) | id;
+#pragma unroll
+                        for (int r = 0; r < BREGS; ++r) {
+                            const int idx = lane + 64 * r;
+                            const bool in = idx >= n && idx < n + na;
+                            if (in) {
+                                const uint64_t kk = C[idx - n];
+                                bd[r] = (uint32_t)(kk >> 32);
+                                bi[r] = (uint32_t)kk;
+                            }
+                            unexp[r] |= __ballot(in);
+                        }
+                        n += na;
+                    }
+                }
+                // ---- candidates.pop(): nearest unexpanded slot; stop when it is farther than furthest
+                if (!overflow) {
+                    uint32_t lm = SLOT_EMPTY;
+#pragma unroll
+                    for (int r = 0; r < BREGS; ++r) lm = min(lm, ((unexp[r] >> lane) & 1ull) ? bd[r] : SLOT_EMPTY);
+                    const uint32_t m = wave_min_u32(lm);
+                    int closer = 0;
+                    unsigned long long hit[BREGS];
+                    int total = 0;
+#pragma unroll
+                    for (int r = 0; r < BREGS; ++r) {
+                        closer += __popcll(__ballot(bd[r] < m));
+                        hit[r] = __ballot(((unexp[r] >> lane) & 1ull) && bd[r] == m);
+                        total += __popcll(hit[r]);
+                    }
+                    if (m == SLOT_EMPTY || closer >= ef) {
+                        stop = true;  // no candidate left / `distance > furthest.distance`
+                    } else {
+                        if (total > 1) {  // equal distances: the heap pops the LARGEST id first
+                            uint32_t li = 0;
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r)
+                                if ((hit[r] >> lane) & 1ull) li = max(li, bi[r]);
+                            const uint32_t mid = wave_max_u32(li);
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r) hit[r] = __ballot(((hit[r] >> lane) & 1ull) && bi[r] == mid);
+                        }
+                        uint32_t cur = 0;
+#pragma unroll
+                        for (int r = 0; r < BREGS; ++r)
+                            if (hit[r]) {
+                                const int l = __ffsll((long long)hit[r]) - 1;
+                                cur = (uint32_t)__builtin_amdgcn_readlane((int)bi[r], l);
+                                unexp[r] &= ~hit[r];
+                            }
+                        load_row(cur);
+                    }
+                }
+            }
+        }
+        // ---- layer done: spill B and sort it (block-wide bitonic); W = its ef smallest keys
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < BREGS; ++r)
+                C[lane + 64 * r] = bd[r] == SLOT_EMPTY ? MDB_KEY_MAX : (((uint64_t)bd[r] << 32) | bi[r]);
+            for (int i = BEAM_CAP + lane; i < 512; i += 64) C[i] = MDB_KEY_MAX;
+            if (lane == 0) misc[2] = (uint32_t)(n < ef ? n : ef);
+        }
+        __syncthreads();
+        const int n2 = 512;
+        for (int size = 2; size <= n2; size <<= 1) {
+            for (int st = size >> 1; st > 0; st >>= 1) {
+                for (int t = tid; t < (n2 >> 1); t += HNSW_BLOCK) {
+                    int lo = ((t / st) * st * 2) + (t % st);
+                    int hi = lo + st;
+                    bool up = ((lo & size) == 0);
+                    uint64_t x = C[lo], y = C[hi];
+                    if ((x > y) == up) { C[lo] = y; C[hi] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < a.ef_cap; i += HNSW_BLOCK) W[i] = C[i];
+        __syncthreads();
+        if (layer > 0) {
+            ep = key_id(W[0]);  // first minimum of the (distance,id)-sorted working set (index.rs:177-181)
+            __syncthreads();
+        }
+    }
+    const int ws = (int)misc[2];
+    const int outc = ws < a.k ? ws : a.k;
+    for (int i = tid; i < a.k; i += HNSW_BLOCK) a.out_keys[(size_t)qi * a.k + i] = i < outc ? W[i] : MDB_KEY_MAX;
+    if (tid == 0) {
+        a.out_counts[qi] = (uint32_t)outc;
+        atomicAdd(&a.counters[0], evals);
+        atomicAdd(&a.counters[1], expanded);
+        if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
+        if (overflow) atomicOr(a.flags, MDB_FLAG_OVERFLOW);
+    }
+}
+
 // keys (distance, point id) -> doc ids, order unchanged (ann_search :192-208)
 __global__ void hnsw_remap_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int k,
                                   const HnswUserDev* __restrict__ users, const uint32_t* __restrict__ q_user,
@@ -736,7 +1044,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     a.vecs = d_vecs.p; a.q = d_q; a.qstride = qstride; a.dpad = dpad; a.p = make_plan((int)dimension, metric);
     a.ef = (int)ef;
     a.ef_cap = ((int)ef + 63) / 64 * 64;
-    int p2 = 64 * CREGS;  // >= the register-resident candidate array (its dead-drop pass stages through C)
+    int p2 = 1024;  // sort / staging buffer of the beam kernel (512 keys + 512 flag words) fits as well
     while (p2 < a.ef_cap + 192) p2 <<= 1;
     a.cand_cap = p2;  // ring capacity (power of two): live candidates <= ef + ties
     a.smax = std::max<int>(64, ((int)max_stride + 63) / 64 * 64);
@@ -764,12 +1072,24 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     const bool regs = ef <= 64 * WREGS && !getenv("MDB_HNSW_NO_REGS");
     // specialised distance when the whole vector is 16-lane chunks (d = 128 / 768: the configs' dims)
     const int nf = (a.p.n8 == 0 && a.p.n4 == 0 && a.p.ntail == 0 && !getenv("MDB_HNSW_GENERIC_DIST")) ? a.p.n16 : 0;
-#define MDB_HNSW_LAUNCH(METRIC, VL, RG)                                   \
-    do {                                                                    \
-        if (nf == 8) MDB_HNSW_LAUNCH4(METRIC, VL, RG, 8);                   \
-        else if (nf == 48) MDB_HNSW_LAUNCH4(METRIC, VL, RG, 48);            \
-        else MDB_HNSW_LAUNCH4(METRIC, VL, RG, 0);                           \
+#define MDB_BEAM_LAUNCH(METRIC, VL, NF)                                                                                     \
+    do {                                                                                                                    \
+        if (lds > 48 * 1024)                                                                                                \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF>,                                 \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hnsw_beam_kernel<METRIC, VL, NF><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                           \
     } while (0)
+#define MDB_HNSW_LAUNCH(METRIC, VL, RG)                                                                          \
+    do {                                                                                                           \
+        if (beam) {                                                                                                \
+            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8);                                                           \
+            else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48);                                                    \
+            else MDB_BEAM_LAUNCH(METRIC, VL, 0);                                                                   \
+        } else if (nf == 8) MDB_HNSW_LAUNCH4(METRIC, VL, RG, 8);                                                   \
+        else if (nf == 48) MDB_HNSW_LAUNCH4(METRIC, VL, RG, 48);                                                   \
+        else MDB_HNSW_LAUNCH4(METRIC, VL, RG, 0);                                                                  \
+    } while (0)
+    const bool beam = regs && !getenv("MDB_HNSW_NO_BEAM");
     if (metric == MDB_METRIC_L2) {
         if (vis_lds) { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, true, false); }
         else { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_L2, false, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false, false); }
@@ -777,6 +1097,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         if (vis_lds) { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true, false); }
         else { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false, false); }
     }
+#undef MDB_BEAM_LAUNCH
 #undef MDB_HNSW_LAUNCH4
 #undef MDB_HNSW_LAUNCH
     MDB_HIP(ctx, hipGetLastError());
