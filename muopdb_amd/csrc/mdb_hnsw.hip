@@ -556,6 +556,36 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
 #define BREGS 5
 #define BEAM_CAP (64 * BREGS)
 
+// nearest unexpanded slot in pop order (smallest distance image, LARGEST id among equals); `cdv`
+// holds the distance image of unexpanded slots and SLOT_EMPTY elsewhere.  Returns false if none.
+// hit[r] = uniform one-hot masks of the winner's slot.
+__device__ __forceinline__ bool beam_best(const uint32_t (&cdv)[BREGS], const uint32_t (&bi)[BREGS], int lane, uint32_t& o_out,
+                                          uint32_t& id_out, unsigned long long (&hit)[BREGS]) {
+    uint32_t lm = cdv[0];
+#pragma unroll
+    for (int r = 1; r < BREGS; ++r) lm = min(lm, cdv[r]);
+    const uint32_t m = wave_min_u32(lm);
+    o_out = m;
+    if (m == SLOT_EMPTY) return false;
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < BREGS; ++r) { hit[r] = __ballot(cdv[r] == m); total += __popcll(hit[r]); }
+    if (total > 1) {
+        uint32_t li = 0;
+#pragma unroll
+        for (int r = 0; r < BREGS; ++r) li = max(li, cdv[r] == m ? bi[r] : 0u);
+        const uint32_t mid = wave_max_u32(li);
+#pragma unroll
+        for (int r = 0; r < BREGS; ++r) hit[r] = __ballot(cdv[r] == m && bi[r] == mid);
+    }
+    unsigned long long any = 0;
+    uint32_t sel = 0;
+#pragma unroll
+    for (int r = 0; r < BREGS; ++r) { any |= hit[r]; sel = ((hit[r] >> lane) & 1ull) ? bi[r] : sel; }
+    id_out = (uint32_t)__builtin_amdgcn_readlane((int)sel, __ffsll((long long)any) - 1);
+    return true;
+}
+
 template <int METRIC, bool VIS_LDS, int N16T>
 __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -594,12 +624,15 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                                         : group16_distance<METRIC>((rowptr), qs, a.p, j))
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // ---- wave-0 state
-    uint32_t bd[BREGS], bi[BREGS];       // B: distance image / id per slot, SLOT_EMPTY beyond n
-    unsigned long long unexp[BREGS];     // unexpanded slots
-    int n = 0;                           // used slots
-    uint32_t fbound = SLOT_EMPTY;        // an upper bound of furthest.distance (prefilter only)
-    uint32_t rowv[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    bool stop = false;
+    uint32_t bd[BREGS], bi[BREGS];  // B: distance image / id per slot (SLOT_EMPTY beyond n)
+    uint32_t cdv[BREGS];            // = bd for unexpanded slots, SLOT_EMPTY otherwise (the candidates)
+    int n = 0;                      // used slots
+    uint32_t fbound = SLOT_EMPTY;   // an upper bound of furthest.distance (prefilter only)
+    uint32_t rowv[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // row of the node being expanded
+    uint32_t rowr[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // row of the runner-up (speculative)
+    unsigned long long ru_hit[BREGS];
+    uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
+    bool ru_valid = false, stop = false;
     unsigned long long evals = 0, expanded = 0;
     bool nan_seen = false, overflow = false;
     uint32_t ep = u.entry_point;
@@ -607,8 +640,8 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
         const uint32_t stride = layer == 0 ? u.S0 : u.SU;
         const uint32_t* const adj_base = a.adj + (layer == 0 ? u.adj0_off : u.adjU_off);
-        // adjacency row of `node` at this layer -> rowv (lane + 64 c); the loads stay in flight
-        auto load_row = [&](uint32_t node) {
+        // adjacency row of `node` at this layer -> dst (lane + 64 c); the loads stay in flight
+        auto load_row = [&](uint32_t node, uint32_t (&dst)[4]) {
             const uint32_t* row = nullptr;
             if (layer == 0) {
                 if (node < u.n0) row = adj_base + (size_t)node * stride;
@@ -618,23 +651,24 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 uint32_t t = lane + 64 * c;
-                rowv[c] = (row && t < stride) ? row[t] : 0xFFFFFFFFu;
+                dst[c] = (row && t < stride) ? row[t] : 0xFFFFFFFFu;
             }
         };
         // ---- entry point: mark visited, distance, seed B (index.rs:219-231) and pop it at once
         if (wave == 0) {
             if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
-            load_row(ep);
+            load_row(ep, rowv);
             float d0 = 0.0f;
             if (lane < 16) d0 = MDB_BEAM_DIST(vecs + (size_t)ep * a.dpad);
             d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), 0));
             if (d0 != d0) nan_seen = true;
 #pragma unroll
-            for (int r = 0; r < BREGS; ++r) { bd[r] = SLOT_EMPTY; bi[r] = 0; unexp[r] = 0; }
+            for (int r = 0; r < BREGS; ++r) { bd[r] = SLOT_EMPTY; bi[r] = 0; cdv[r] = SLOT_EMPTY; }
             if (lane == 0) { bd[0] = f32_orderable(d0); bi[0] = ep; }
             n = 1;
             fbound = SLOT_EMPTY;
             stop = false;
+            ru_valid = false;
             evals += 1;
         }
         for (;;) {
@@ -671,14 +705,23 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
             __syncthreads();
             const uint32_t nnew = misc[0];
             if (nnew == 0xFFFFFFFFu) break;
-            // ---- P3 (all): exact distances, one 16-lane group per neighbour
-            for (uint32_t i = grp; i < nnew; i += HNSW_BLOCK / 16) {
-                float d = MDB_BEAM_DIST(vecs + (size_t)nb_id[i] * a.dpad);
-                if (j == 0) nb_dist[i] = d;
+            if (wave == 0) {
+                // ---- in the shadow of P3: the best candidate already in B (the next pop unless a neighbour
+                // accepted below beats it) and, speculatively, its adjacency row
+                ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_hit);
+                if (ru_valid) load_row(ru_id, rowr);
+            } else {
+                // ---- P3 (waves 1-3): exact distances, one 16-lane group per neighbour
+                for (uint32_t i = grp - 4; i < nnew; i += (HNSW_BLOCK - 64) / 16) {
+                    float d = MDB_BEAM_DIST(vecs + (size_t)nb_id[i] * a.dpad);
+                    if (j == 0) nb_dist[i] = d;
+                }
             }
             __syncthreads();
-            // ---- P4 (wave 0): accept + push, then pop the next node and get its row moving
+            // ---- P4 (wave 0): accept + push, then choose the next node
             if (wave == 0) {
+                uint32_t best_o = SLOT_EMPTY, best_id = 0;  // best accepted neighbour in pop order ...
+                int best_slot = -1;                          // ... and the slot it was pushed to
                 for (uint32_t c0 = 0; c0 < nnew; c0 += 64) {
                     const uint32_t i = c0 + lane;
                     const bool have0 = i < nnew;
@@ -723,7 +766,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                                 if (keep) {
                                     const int pos = kept + __popcll(km & lt_mask);
                                     C[pos] = ((uint64_t)bd[r] << 32) | bi[r];
-                                    stage_flag[pos] = (uint32_t)((unexp[r] >> lane) & 1ull);
+                                    stage_flag[pos] = cdv[r] != SLOT_EMPTY ? 1u : 0u;
                                 }
                                 kept += __popcll(km);
                             }
@@ -734,64 +777,73 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                                 const uint64_t kk = in ? C[idx] : 0;
                                 bd[r] = in ? (uint32_t)(kk >> 32) : SLOT_EMPTY;
                                 bi[r] = in ? (uint32_t)kk : 0u;
-                                unexp[r] = __ballot(in && stage_flag[idx] != 0u);
+                                cdv[r] = (in && stage_flag[idx] != 0u) ? bd[r] : SLOT_EMPTY;
                             }
                             n = kept;
                             fbound = min(fbound, f);
                             if (n + na > BEAM_CAP) { overflow = true; break; }  // > ~120 exact ties with furthest
+                            if (best_slot >= 0) {  // slots moved: re-find the best accepted so far (rare)
+                                best_slot = -1;
+#pragma unroll
+                                for (int r = 0; r < BREGS; ++r) {
+                                    unsigned long long hm = __ballot(cdv[r] == best_o && bi[r] == best_id);
+                                    if (hm) best_slot = 64 * r + __ffsll((long long)hm) - 1;
+                                }
+                            }
+                            ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_hit);  // slots moved
+                            if (ru_valid) load_row(ru_id, rowr);
                         }
                         // ---- push all accepted neighbours: slots n .. n+na-1, in edge order
                         if ((accepted >> lane) & 1ull) C[__popcll(accepted & lt_mask)] = ((uint64_t)od << 32) | id;
 #pragma unroll
                         for (int r = 0; r < BREGS; ++r) {
                             const int idx = lane + 64 * r;
-                            const bool in = idx >= n && idx < n + na;
-                            if (in) {
+                            if (idx >= n && idx < n + na) {
                                 const uint64_t kk = C[idx - n];
                                 bd[r] = (uint32_t)(kk >> 32);
                                 bi[r] = (uint32_t)kk;
+                                cdv[r] = bd[r];
                             }
-                            unexp[r] |= __ballot(in);
+                        }
+                        // best accepted neighbour of this chunk in pop order (smallest distance, largest id)
+                        unsigned long long am = accepted;
+                        int rank = 0;
+                        while (am) {
+                            const int sidx = __ffsll((long long)am) - 1;
+                            am &= am - 1;
+                            const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                            const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
+                            if (best_slot < 0 || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_slot = n + rank; }
+                            ++rank;
                         }
                         n += na;
                     }
                 }
-                // ---- candidates.pop(): nearest unexpanded slot; stop when it is farther than furthest
+                // ---- candidates.pop(): runner-up vs best accepted; stop when it is farther than furthest
                 if (!overflow) {
-                    uint32_t lm = SLOT_EMPTY;
-#pragma unroll
-                    for (int r = 0; r < BREGS; ++r) lm = min(lm, ((unexp[r] >> lane) & 1ull) ? bd[r] : SLOT_EMPTY);
-                    const uint32_t m = wave_min_u32(lm);
-                    int closer = 0;
-                    unsigned long long hit[BREGS];
-                    int total = 0;
-#pragma unroll
-                    for (int r = 0; r < BREGS; ++r) {
-                        closer += __popcll(__ballot(bd[r] < m));
-                        hit[r] = __ballot(((unexp[r] >> lane) & 1ull) && bd[r] == m);
-                        total += __popcll(hit[r]);
-                    }
-                    if (m == SLOT_EMPTY || closer >= ef) {
-                        stop = true;  // no candidate left / `distance > furthest.distance`
+                    const bool take_ru = ru_valid && (best_slot < 0 || ru_o < best_o || (ru_o == best_o && ru_id > best_id));
+                    if (!take_ru && best_slot < 0) {
+                        stop = true;  // no candidate left
                     } else {
-                        if (total > 1) {  // equal distances: the heap pops the LARGEST id first
-                            uint32_t li = 0;
+                        const uint32_t m = take_ru ? ru_o : best_o;
+                        int closer = 0;
+#pragma unroll
+                        for (int r = 0; r < BREGS; ++r) closer += __popcll(__ballot(bd[r] < m));
+                        if (closer >= ef) {
+                            stop = true;  // `distance > furthest.distance` (index.rs:246-248)
+                        } else if (take_ru) {
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r) {
+                                cdv[r] = ((ru_hit[r] >> lane) & 1ull) ? SLOT_EMPTY : cdv[r];
+                            }
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) rowv[c] = rowr[c];
+                        } else {
 #pragma unroll
                             for (int r = 0; r < BREGS; ++r)
-                                if ((hit[r] >> lane) & 1ull) li = max(li, bi[r]);
-                            const uint32_t mid = wave_max_u32(li);
-#pragma unroll
-                            for (int r = 0; r < BREGS; ++r) hit[r] = __ballot(((hit[r] >> lane) & 1ull) && bi[r] == mid);
+                                if (lane + 64 * r == best_slot) cdv[r] = SLOT_EMPTY;
+                            load_row(best_id, rowv);
                         }
-                        uint32_t cur = 0;
-#pragma unroll
-                        for (int r = 0; r < BREGS; ++r)
-                            if (hit[r]) {
-                                const int l = __ffsll((long long)hit[r]) - 1;
-                                cur = (uint32_t)__builtin_amdgcn_readlane((int)bi[r], l);
-                                unexp[r] &= ~hit[r];
-                            }
-                        load_row(cur);
                     }
                 }
             }
