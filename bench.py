@@ -34,6 +34,30 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 METRIC = "QPS @ recall@10, SIFT-1M d=128 top-10, batch=1/64; 1/2/4/8 GPUs"
 
 
+def measured_traffic(kind, cfg):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r*_traffic.json; rocprofv3 --pmc cannot run inside this process), only when the
+    workload matches the profiled one; else None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        with open(path) as f:
+            e = json.load(f).get(kind)
+        if e and all(cfg.get(k) == v for k, v in e["match"].items()):
+            return (e["fetch_kib"] * e["fetch_correction"] + e["write_kib"]) * 1024.0, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def dump(args, rank, **files):
+    """--dump-dir: the workload's files for examples/replay_search.cpp (torch-free PMC passes)."""
+    if not args.dump_dir or rank != 0:
+        return
+    os.makedirs(args.dump_dir, exist_ok=True)
+    for name, data in files.items():
+        with open(os.path.join(args.dump_dir, name), "wb") as f:
+            f.write(data if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data).tobytes())
+    log("dumped %s to %s" % (", ".join(files), args.dump_dir))
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -51,8 +75,10 @@ def parse():
     p.add_argument("--ef", type=int, default=200)
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--nprobe", type=int, default=16)
+    p.add_argument("--users", type=int, default=128, help="spann workload: number of users (1024 = full C4)")
     p.add_argument("--max-neighbors", type=int, default=32)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--dump-dir", default=None, help="write index files + queries for examples/replay_search.cpp")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
 
@@ -114,6 +140,7 @@ def run_hnsw(args, ctx, rank, world, timer):
     t0 = time.time()
     hnsw = BlockBasedHnsw(ctx, index_bytes, vec_bytes, d)
     log("load %.1fs" % (time.time() - t0))
+    dump(args, rank, index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy()})
     ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
     sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
     cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
@@ -153,13 +180,14 @@ def run_hnsw(args, ctx, rank, world, timer):
         config={"workload": "SIFT-1M-like synthetic %dx%d f32 (4096 Gaussian clusters, sigma 20, clipped [0,218]); HNSW "
                             "max_neighbors=%d ef=%d top-%d batch=%d per GPU; replicas" % (n, d, args.max_neighbors, ef, k, batch),
                 "n": n, "dim": d, "batch": batch, "ef": ef, "k": k, "index": "hnsw", "parallelism": "replica x%d" % world},
-        roofline=dict(bound="hbm", kernel="hnsw_search_kernel",
+        roofline=dict(bound="hbm", kernel="hnsw_beam_kernel" if ef <= 256 else "hnsw_search_kernel",
                       achieved=(abytes / steps) / (kernel_ms / launches * 1e-3) / 1e9 if launches else None,
                       peak=HBM_PEAK_GBS, unit="GB/s", traffic=None,
                       bytes_per_launch=abytes / steps, kernel_ms=kernel_ms / max(launches, 1),
                       evals_per_query=evals / (steps * batch), expanded_per_query=expanded / (steps * batch)),
     )
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS if out["roofline"]["achieved"] else None
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("hnsw", out["config"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         o = oracle.BlockBasedHnsw(index_bytes, vec_bytes, d)
@@ -197,6 +225,9 @@ def run_flat(args, ctx, rank, world, timer):
     # rows are sharded across ranks (SURVEY.md §8e flat: row-range shards); here every rank scans its shard
     lo, hi = rank * n // world, (rank + 1) * n // world
     idx = FlatIndex(ctx, None, device_ptr=x[lo:hi].data_ptr(), n=hi - lo, d=d)
+    if args.dump_dir:
+        from muopdb_amd import formats as F
+        dump(args, rank, vectors=F.write_vector_file(x.cpu().numpy()), **{"queries.f32": queries.cpu().numpy()})
     ids = torch.zeros((batch, k), dtype=torch.int32, device="cuda")
     ds = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
 
@@ -220,6 +251,7 @@ def run_flat(args, ctx, rank, world, timer):
                        "n": n, "dim": d, "batch": batch, "k": k, "index": "flat"},
                roofline=dict(bound="hbm", kernel="flat_scan_kernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                              frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes, kernel_ms=kernel_ms / launches))
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("flat", out["config"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         xb, qh = x.cpu().numpy(), queries[warm * batch:].cpu().numpy()
@@ -241,7 +273,7 @@ def run_ivfpq(args, ctx, rank, world, timer):
     steps, warm = args.steps, args.warmup
     nlist = max(1, min(4096, n // 244))
     nq = (steps + warm) * batch
-    x, queries = sift_base_and_queries(n, d, nq, rank)
+    x, queries = sift_base_and_queries(n, d, nq, 0)  # lists are sharded: every rank sees the SAME batch
     t0 = time.time()
     cent = B.kmeans(x, nlist, iters=6, seed=3, sample=min(n, 400_000))
     assign = B.assign_nearest(x, cent)
@@ -253,8 +285,10 @@ def run_ivfpq(args, ctx, rank, world, timer):
     vec_bytes = F.write_vector_file(codes)
     log("ivf-pq build %.1fs" % (time.time() - t0))
     ivf = BlockBasedIvf(ctx, index_bytes, vec_bytes, pq, shard_rank=rank, shard_world=world)
+    dump(args, rank, index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy(), "codebook.f32": cb})
     import ctypes as C
     from muopdb_amd import lib as L
+    from muopdb_amd import distributed as D
     ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
     sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
     cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
@@ -264,8 +298,12 @@ def run_ivfpq(args, ctx, rank, world, timer):
         ctx.check(ctx.lib.mdb_ivf_search(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch), None, C.c_size_t(P), C.c_size_t(k),
                                          C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()),
                                          C.c_void_p(cn.data_ptr())))
+        res = ids
+        if world > 1:  # one RCCL all-gather of the per-shard top-k + device merge
+            gd, gs, gc = D.all_gather_topk(ids, sc, cn)
+            res, _, _ = D.merge_shards_device(ctx, gd, gs, gc)
         if keep is not None:
-            keep.append(ids[:, :, 0].clone())
+            keep.append(res[:, :, 0].clone())
 
     for i in range(warm):
         step(i)
@@ -286,7 +324,7 @@ def run_ivfpq(args, ctx, rank, world, timer):
     gt, _ = B.exact_knn(x, k, queries=tq, f64=True)
     rec = recall_at_k(found, gt.cpu().numpy(), k)
     ach = (abytes / steps) / (kernel_ms / launches * 1e-3) / 1e9
-    out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec,
+    out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec, scaling="strong",
                config={"workload": "SIFT-1M-like synthetic %dx%d, IVF nlist=%d + PQ m=16 nbits=8 (symmetric distance), nprobe=%d, "
                                    "batch=%d, top-%d, lists sharded x%d" % (n, d, nlist, P, batch, k, world),
                        "n": n, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq"},
@@ -305,6 +343,116 @@ def run_ivfpq(args, ctx, rank, world, timer):
                                    ids_match_gpu=bool(ok))
     return out
 
+def run_spann(args, ctx, rank, world, timer):
+    """BASELINE.md C4 shape: multi-user SPANN over unit-norm f32 rows, one (user, query) pair per user
+    per batch, posting lists sharded l % world, one all-gather + merge per batch.  Defaults are a
+    1/8 slice (128 users x 9766 x 768 = 3.8 GB); --users 1024 is the full 10M x 768 (30.7 GB)."""
+    from muopdb_amd import build as B
+    from muopdb_amd import formats as F
+    from muopdb_amd import distributed as D
+    from muopdb_amd.index import MultiSpannIndex, SearchParams
+    import ctypes as C
+    from muopdb_amd import lib as L
+    U = args.users
+    per = (args.n // U) if args.n else 9766
+    d = args.dim or 768
+    batch = args.batch or U
+    k, P = args.k, args.nprobe
+    steps, warm = args.steps, args.warmup
+    nlist = max(1, per // 64)
+    t0 = time.time()
+    users, base = {}, []
+    for u in range(U):
+        x = B.unit_gaussian(per, d, seed=3_000_000 + u)
+        cent = B.kmeans(x, nlist, iters=4, seed=u)
+        pls = B.posting_lists_from_assignment(B.assign_nearest(x, cent), cent.shape[0])
+        hi, hv = B.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
+        docs = np.arange(u * per, (u + 1) * per, dtype=np.uint64)
+        users[u + 1] = dict(hnsw_index=hi, hnsw_vectors=hv, ivf_index=F.write_ivf_index(cent.cpu().numpy(), docs, pls),
+                            ivf_vectors=F.write_vector_file(x.cpu().numpy()))
+        base.append(x)
+    cat = F.concat_multi_spann(users)
+    del users
+    log("multi-user SPANN build: %d users x %d x %d, %.1fs, ivf_vectors %.2f GB" % (U, per, d, time.time() - t0,
+                                                                                    len(cat["ivf_vectors"]) / 1e9))
+    t0 = time.time()
+    ms = MultiSpannIndex(ctx, cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"],
+                         None, rank, world)
+    log("load %.1fs" % (time.time() - t0))
+    nq = (steps + warm) * batch
+    gq = torch.Generator(device="cpu"); gq.manual_seed(77)          # same pairs on every rank (lists are sharded)
+    quser = (torch.arange(nq) % U)
+    qrow = torch.randint(0, per, (nq,), generator=gq)
+    noise = torch.randn((nq, d), generator=gq) * (0.3 / d ** 0.5)
+    queries = torch.stack([base[int(u)][int(r)] for u, r in zip(quser.tolist(), qrow.tolist())]) + noise.cuda()
+    queries = (queries / queries.norm(dim=1, keepdim=True)).contiguous()
+    params = SearchParams(k, args.ef).with_num_explored_centroids(P).with_centroid_distance_ratio(0.1).to_c()
+    ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
+    sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
+    cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    fo = torch.zeros(batch, dtype=torch.uint8, device="cuda")
+    uid_arrays = [L.u128_array([int(u) + 1 for u in quser[i * batch:(i + 1) * batch].tolist()]) for i in range(steps + warm)]
+
+    def step(i, keep=None):
+        q = queries[i * batch:(i + 1) * batch]
+        ctx.check(ctx.lib.mdb_multi_spann_search(ms.h, uid_arrays[i], C.c_void_p(q.data_ptr()), C.c_size_t(batch), C.byref(params),
+                                                 C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()),
+                                                 C.c_void_p(cn.data_ptr()), C.c_void_p(fo.data_ptr())))
+        res = ids
+        if world > 1:
+            gd, gs, gc = D.all_gather_topk(ids, sc, cn)
+            res, _, _ = D.merge_shards_device(ctx, gd, gs, gc)
+        if keep is not None:
+            keep.append(res[:, :, 0].clone())
+
+    for i in range(warm):
+        step(i)
+    ctx.sync(); ctx.set_profiling(True); ctx.get_profile()
+    timer.barrier()
+    t0 = time.perf_counter()
+    for i in range(warm, warm + steps):
+        step(i)
+    timer.barrier()
+    elapsed = timer.max_over_ranks(time.perf_counter() - t0)
+    kernel_ms, launches = ctx.get_profile(); ctx.set_profiling(False)
+    found, scored, abytes = [], 0, 0
+    for i in range(warm, warm + steps):
+        step(i, found)
+        st = ctx.stats(); scored += st["scored_vectors"]; abytes += st["algorithmic_bytes"]
+    found = torch.cat(found).cpu().numpy()
+    # exact per-user ground truth (f64) for recall
+    hits = 0
+    for j in range(steps * batch):
+        qi = warm * batch + j
+        u = int(quser[qi])
+        xb = base[u].double()
+        dd = ((xb - queries[qi].double()[None, :]) ** 2).sum(1)
+        gt = (torch.topk(dd, k, largest=False).indices + u * per).cpu().numpy()
+        hits += len(set(found[j][:k].tolist()) & set(gt.tolist()))
+    rec = hits / (steps * batch * k)
+    ach = (abytes / steps) / (kernel_ms / launches * 1e-3) / 1e9
+    out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec, scaling="strong",
+               config={"workload": "multi-user SPANN, %d users x %d x %d f32 unit-norm (BASELINE.md C4 shape), batch=%d (user,query) "
+                                   "pairs, ef=%d, num_explored_centroids=%d, ratio=0.1, top-%d, posting lists sharded x%d"
+                                   % (U, per, d, batch, args.ef, P, k, world),
+                       "users": U, "n": U * per, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "multi-spann"},
+               roofline=dict(bound="hbm", kernel="ivf_scan_f32_kernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes / steps,
+                             kernel_ms=kernel_ms / launches, scored_per_query=scored / (steps * batch)))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        o = oracle.MultiSpannIndex(cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+        op = oracle.SearchParams(k, args.ef, num_explored_centroids=P, centroid_distance_ratio=0.1)
+        qh = queries[warm * batch:(warm + steps) * batch].cpu().numpy()
+        uh = [int(u) + 1 for u in quser[warm * batch:(warm + steps) * batch].tolist()]
+        t0 = time.perf_counter(); o.search_for_user(uh[:16], qh[:16], op); dt = time.perf_counter() - t0
+        ns = int(min(len(qh), max(16, args.cpu_seconds / (dt / 16))))
+        t0 = time.perf_counter(); r = o.search_for_user(uh[:ns], qh[:ns], op); dt1 = time.perf_counter() - t0
+        ok = all(r.doc_ids(i) == [int(v) for v in found[i][:int(r.counts[i])]] for i in range(min(ns, 256)))
+        out["cpu_baseline"] = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port", sample="%d (user,query) pairs, one thread" % ns,
+                                   ids_match_gpu=bool(ok))
+    return out
+
 
 def main():
     args = parse()
@@ -319,9 +467,9 @@ def main():
     ctx = L.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     timer = Timer(world)
-    res = {"hnsw": run_hnsw, "flat": run_flat, "ivfpq": run_ivfpq}[args.workload](args, ctx, rank, world, timer)
+    res = {"hnsw": run_hnsw, "flat": run_flat, "ivfpq": run_ivfpq, "spann": run_spann}[args.workload](args, ctx, rank, world, timer)
     line = {"metric": METRIC, "value": res.pop("value"), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": res.pop("scaling", "weak"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
     line.update(res)
     if rank == 0:

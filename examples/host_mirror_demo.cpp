@@ -1,0 +1,68 @@
+// host_mirror_demo — drives include/muopdb_host.hpp (the C++ mirror of the reference's Spann /
+// BlockBasedHnsw / BlockBasedIvf surface) end to end on reference-format files.
+//   host_mirror_demo <dir> <dim> <k> <ef> <nprobe> <ratio>
+// <dir> holds hnsw_index, hnsw_vectors, ivf_index, ivf_vectors (reference formats) and queries.f32.
+// Prints one line per (searcher, query): "<name> <q> <n> id:scorebits ..." — the GPU test compares
+// the lines with the ctypes binding's results (tests/test_gpu_traversal.py).
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+#include "muopdb_host.hpp"
+
+static std::vector<char> slurp(const std::string& p) {
+    std::ifstream f(p, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + p);
+    return std::vector<char>(std::istreambuf_iterator<char>(f), {});
+}
+
+static void print_row(const char* name, size_t q, const muopdb::SearchResult* r) {
+    if (!r) { std::printf("%s %zu none\n", name, q); return; }
+    std::printf("%s %zu %zu", name, q, r->id_with_scores.size());
+    for (auto& e : r->id_with_scores) {
+        uint32_t bits;
+        std::memcpy(&bits, &e.score, 4);
+        std::printf(" %llu:%08x", (unsigned long long)e.doc_id, bits);
+    }
+    std::printf("\n");
+}
+
+int main(int argc, char** argv) {
+    if (argc < 7) { std::fprintf(stderr, "usage: %s dir dim k ef nprobe ratio\n", argv[0]); return 2; }
+    try {
+        const std::string dir = argv[1];
+        const uint32_t dim = std::stoul(argv[2]);
+        const size_t k = std::stoul(argv[3]);
+        const uint32_t ef = std::stoul(argv[4]);
+        const size_t nprobe = std::stoul(argv[5]);
+        const float ratio = std::stof(argv[6]);
+        auto hi = slurp(dir + "/hnsw_index"), hv = slurp(dir + "/hnsw_vectors");
+        auto ii = slurp(dir + "/ivf_index"), iv = slurp(dir + "/ivf_vectors");
+        auto qb = slurp(dir + "/queries.f32");
+        const float* q = reinterpret_cast<const float*>(qb.data());
+        const size_t b = qb.size() / 4 / dim;
+
+        muopdb::Device dev(0);
+        muopdb::BlockBasedHnsw hnsw(dev, hi.data(), hi.size(), hv.data(), hv.size(), muopdb::Quantizer::none(dim));
+        auto hr = hnsw.ann_search(q, b, k, ef);
+        for (size_t i = 0; i < b; ++i) print_row("hnsw", i, &hr[i]);
+
+        muopdb::BlockBasedIvf ivf(dev, ii.data(), ii.size(), iv.data(), iv.size(), muopdb::Quantizer::none(dim));
+        auto ir = ivf.search(q, b, k, (uint32_t)nprobe);
+        for (size_t i = 0; i < b; ++i) print_row("ivf", i, ir[i] ? &*ir[i] : nullptr);
+
+        muopdb::Spann spann(dev, hi.data(), hi.size(), hv.data(), hv.size(), ii.data(), ii.size(), iv.data(), iv.size(),
+                            muopdb::Quantizer::none(dim));
+        muopdb::SearchParams p(k, ef);
+        p.with_num_explored_centroids(nprobe).with_centroid_distance_ratio(ratio);
+        auto sr = spann.search(q, b, p);
+        for (size_t i = 0; i < b; ++i) print_row("spann", i, sr[i] ? &*sr[i] : nullptr);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

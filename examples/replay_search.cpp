@@ -1,0 +1,98 @@
+// replay_search — torch-free replay of a bench.py workload through the C ABI, for rocprofv3 --pmc
+// passes (HBM traffic counters of the dominant kernel; rocprofv3's counter mode crashes inside
+// torch's own kernels on this image, so the counter passes run on this binary instead).
+//   replay_search <kind> <dir> <dim> <k> <ef|nprobe> <batch> <steps>
+// kind = hnsw | ivf | ivfpq | flat.  <dir> is what `bench.py --dump-dir` wrote:
+//   hnsw : index, vectors, queries.f32        ivf/ivfpq : index, vectors, queries.f32 [, codebook.f32]
+//   flat : vectors (reference vector-file format: u64 n + rows), queries.f32
+// Prints a checksum of the returned ids so a replay can be compared with bench.py's run.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+#include "muopdb_host.hpp"
+
+static std::vector<char> slurp(const std::string& p, bool required = true) {
+    std::ifstream f(p, std::ios::binary);
+    if (!f) {
+        if (required) throw std::runtime_error("cannot open " + p);
+        return {};
+    }
+    return std::vector<char>(std::istreambuf_iterator<char>(f), {});
+}
+
+int main(int argc, char** argv) {
+    if (argc < 8) {
+        std::fprintf(stderr, "usage: %s kind dir dim k ef|nprobe batch steps\n", argv[0]);
+        return 2;
+    }
+    try {
+        const std::string kind = argv[1], dir = argv[2];
+        const uint32_t dim = std::stoul(argv[3]);
+        const size_t k = std::stoul(argv[4]);
+        const uint32_t knob = std::stoul(argv[5]);
+        const size_t batch = std::stoul(argv[6]), steps = std::stoul(argv[7]);
+        auto qb = slurp(dir + "/queries.f32");
+        const float* q = reinterpret_cast<const float*>(qb.data());
+        const size_t nq = qb.size() / 4 / dim;
+        if (nq < batch) throw std::runtime_error("not enough queries for one batch");
+        auto vec = slurp(dir + "/vectors");
+        muopdb::Device dev(0);
+        uint64_t checksum = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        auto fold = [&](const std::vector<muopdb::IdWithScore>& row) {
+            for (auto& e : row) checksum = checksum * 1000003ull + (uint64_t)e.doc_id;
+        };
+        if (kind == "hnsw") {
+            auto idx = slurp(dir + "/index");
+            muopdb::BlockBasedHnsw h(dev, idx.data(), idx.size(), vec.data(), vec.size(), muopdb::Quantizer::none(dim));
+            t0 = std::chrono::steady_clock::now();
+            for (size_t s = 0; s < steps; ++s)
+                for (auto& r : h.ann_search(q + ((s * batch) % (nq - batch + 1)) * dim, batch, k, knob)) fold(r.id_with_scores);
+        } else if (kind == "ivf" || kind == "ivfpq") {
+            auto idx = slurp(dir + "/index");
+            muopdb::Quantizer qz = muopdb::Quantizer::none(dim);
+            if (kind == "ivfpq") {
+                auto cb = slurp(dir + "/codebook.f32");
+                std::vector<float> cbf(cb.size() / 4);
+                std::memcpy(cbf.data(), cb.data(), cbf.size() * 4);
+                qz = muopdb::Quantizer::product(dim, 8, 8, std::move(cbf));
+            }
+            muopdb::BlockBasedIvf ivf(dev, idx.data(), idx.size(), vec.data(), vec.size(), std::move(qz));
+            t0 = std::chrono::steady_clock::now();
+            for (size_t s = 0; s < steps; ++s)
+                for (auto& r : ivf.search(q + ((s * batch) % (nq - batch + 1)) * dim, batch, k, knob))
+                    if (r) fold(r->id_with_scores);
+        } else if (kind == "flat") {
+            uint64_t n;
+            std::memcpy(&n, vec.data(), 8);
+            mdb_flat* f = nullptr;
+            dev.check(mdb_flat_create(dev.ctx(), reinterpret_cast<const float*>(vec.data() + 8), n, dim, MDB_METRIC_L2, MDB_MEM_HOST, &f));
+            std::vector<uint32_t> ids(batch * k), cnt(batch);
+            std::vector<float> dist(batch * k);
+            t0 = std::chrono::steady_clock::now();
+            for (size_t s = 0; s < steps; ++s) {
+                dev.check(mdb_flat_search(f, q + ((s * batch) % (nq - batch + 1)) * dim, batch, k, MDB_MEM_HOST, ids.data(), dist.data(),
+                                          cnt.data()));
+                for (auto v : ids) checksum = checksum * 1000003ull + v;
+            }
+            mdb_flat_free(f);
+        } else {
+            throw std::runtime_error("unknown kind " + kind);
+        }
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        mdb_stats st{};
+        mdb_get_stats(dev.ctx(), &st);
+        std::printf("replay %s: %zu steps x %zu queries, %.3f ms/step (host buffers), ids checksum %016llx, "
+                    "last call algorithmic bytes %llu\n",
+                    kind.c_str(), steps, batch, ms / steps, (unsigned long long)checksum, (unsigned long long)st.algorithmic_bytes);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

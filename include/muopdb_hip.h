@@ -105,6 +105,8 @@ typedef struct mdb_multi_spann mdb_multi_spann;
 
 /* ---------------------------------------------------------------- context */
 mdb_status mdb_device_open(int gpu, mdb_ctx** out);
+/* drops the caller's reference; index handles created on the context keep it alive until they
+ * are freed, so the order of mdb_*_free and mdb_device_close does not matter */
 void mdb_device_close(mdb_ctx* ctx);
 /* run on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = the legacy
  * default (null) stream.  A context starts on its own non-blocking stream. */

@@ -1,0 +1,258 @@
+// muopdb_host.hpp — C++17 host-side mirror of the reference's search surface over the C ABI
+// (include/muopdb_hip.h).  The reference is Rust and no Rust toolchain exists in this image, so this
+// header plays the role of the Rust shim shown in INTEGRATION.md: same type and method names,
+// argument meaning and error behaviour as rs/index (errors -> exceptions where the reference returns
+// anyhow::Err / panics, std::optional where it returns Option).  Header-only, no torch types.
+//
+//   reference                                                  here
+//   BlockBasedIvf::{search, find_nearest_centroids, ...}       muopdb::BlockBasedIvf
+//     rs/index/src/ivf/block_based/index.rs:147-470
+//   BlockBasedHnsw::ann_search  hnsw/block_based/index.rs:159   muopdb::BlockBasedHnsw
+//   Spann::search  spann/index.rs:211-266                       muopdb::Spann
+//   MultiSpannIndex::search_for_user  multi_spann/index.rs:282  muopdb::MultiSpannIndex
+//   SearchParams  rs/config/src/search_params.rs                muopdb::SearchParams
+//   SearchResult / IdWithScore  rs/index/src/utils.rs:89-176    muopdb::SearchResult / IdWithScore
+// Every search takes a batch; row i is what the reference returns for query i.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "muopdb_hip.h"
+
+namespace muopdb {
+
+using u128 = unsigned __int128;
+
+struct Error : std::runtime_error {
+    mdb_status status;
+    Error(mdb_status s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+struct IdWithScore {
+    u128 doc_id;
+    float score;
+};
+struct SearchResult {
+    std::vector<IdWithScore> id_with_scores;
+};
+
+struct SearchParams {
+    size_t top_k;
+    uint32_t ef_construction;
+    bool record_pages = false;
+    std::optional<size_t> num_explored_centroids;
+    float centroid_distance_ratio = 0.1f;
+    SearchParams(size_t k, uint32_t ef, bool rp = false) : top_k(k), ef_construction(ef), record_pages(rp) {}
+    SearchParams& with_num_explored_centroids(std::optional<size_t> n) { num_explored_centroids = n; return *this; }
+    SearchParams& with_centroid_distance_ratio(float r) { centroid_distance_ratio = r; return *this; }
+    mdb_search_params c() const {
+        return mdb_search_params{top_k, ef_construction, record_pages ? 1 : 0,
+                                 num_explored_centroids ? (int64_t)*num_explored_centroids : -1, centroid_distance_ratio};
+    }
+};
+
+// Quantizer descriptors (rs/quantization): NoQuantizer / ProductQuantizer
+struct Quantizer {
+    mdb_quant_desc d{};
+    std::vector<float> codebook;
+    static Quantizer none(uint32_t dimension, mdb_metric metric = MDB_METRIC_L2) {
+        Quantizer q;
+        q.d.kind = MDB_QUANT_NONE; q.d.metric = metric; q.d.dimension = dimension;
+        return q;
+    }
+    static Quantizer product(uint32_t dimension, uint32_t subvector_dimension, uint32_t num_bits, std::vector<float> cb,
+                             mdb_metric metric = MDB_METRIC_L2) {
+        if (subvector_dimension == 0 || dimension % subvector_dimension != 0)
+            throw Error(MDB_ERR_INVALID_ARG, "Vector dimension needs to be divisible by the subvector dimension.");
+        Quantizer q;
+        q.codebook = std::move(cb);
+        q.d.kind = MDB_QUANT_PQ; q.d.metric = metric; q.d.dimension = dimension;
+        q.d.subvector_dimension = subvector_dimension; q.d.num_bits = num_bits;
+        return q;
+    }
+    const mdb_quant_desc* desc() {
+        d.codebook = codebook.empty() ? nullptr : codebook.data();
+        d.codebook_len = codebook.size();
+        return &d;
+    }
+};
+
+class Device {
+  public:
+    explicit Device(int gpu = 0) {
+        mdb_status st = mdb_device_open(gpu, &ctx_);
+        if (st != MDB_OK) throw Error(st, "mdb_device_open failed: no usable HIP device (there is no CPU fallback)");
+    }
+    ~Device() { mdb_device_close(ctx_); }
+    Device(const Device&) = delete;
+    Device& operator=(const Device&) = delete;
+    mdb_ctx* ctx() const { return ctx_; }
+    void check(mdb_status st) const {
+        if (st != MDB_OK) throw Error(st, mdb_last_error(ctx_));
+    }
+
+  private:
+    mdb_ctx* ctx_ = nullptr;
+};
+
+namespace detail {
+struct Rows {
+    std::vector<mdb_u128> ids;
+    std::vector<float> scores;
+    std::vector<uint32_t> counts;
+    std::vector<uint8_t> found;
+    Rows(size_t b, size_t k) : ids(b * (k ? k : 1)), scores(b * (k ? k : 1)), counts(b), found(b, 1) {}
+    std::vector<std::optional<SearchResult>> take(size_t b, size_t k) const {
+        std::vector<std::optional<SearchResult>> out(b);
+        for (size_t i = 0; i < b; ++i) {
+            if (!found[i]) continue;  // None
+            SearchResult r;
+            for (uint32_t j = 0; j < counts[i]; ++j)
+                r.id_with_scores.push_back({((u128)ids[i * k + j].hi << 64) | ids[i * k + j].lo, scores[i * k + j]});
+            out[i] = std::move(r);
+        }
+        return out;
+    }
+};
+inline mdb_u128 split(u128 v) { return mdb_u128{(uint64_t)v, (uint64_t)(v >> 64)}; }
+}  // namespace detail
+
+class BlockBasedIvf {
+  public:
+    // new_with_offset (index.rs:94-138): `index` / `vectors` are the mmapped files
+    BlockBasedIvf(Device& dev, const void* index, size_t index_len, const void* vectors, size_t vectors_len, Quantizer q,
+                  size_t index_offset = 0, size_t vector_offset = 0, uint32_t shard_rank = 0, uint32_t shard_world = 1)
+        : dev_(dev) {
+        dev_.check(mdb_ivf_load(dev.ctx(), index, index_len, index_offset, vectors, vectors_len, vector_offset, q.desc(),
+                                shard_rank, shard_world, &h_));
+    }
+    ~BlockBasedIvf() { mdb_ivf_free(h_); }
+    BlockBasedIvf(const BlockBasedIvf&) = delete;
+    size_t num_clusters() const { return mdb_ivf_num_clusters(h_); }
+    size_t num_vectors() const { return mdb_ivf_num_vectors(h_); }
+    size_t num_features() const { return mdb_ivf_num_features(h_); }
+    // find_nearest_centroids (:147-163); [b][num_probes]
+    std::vector<uint32_t> find_nearest_centroids(const float* queries, size_t b, size_t num_probes) {
+        std::vector<uint32_t> out(b * (num_probes ? num_probes : 1));
+        dev_.check(mdb_ivf_find_nearest_centroids(h_, queries, b, num_probes, MDB_MEM_HOST, out.data()));
+        return out;
+    }
+    // search (:396-413)
+    std::vector<std::optional<SearchResult>> search(const float* queries, size_t b, size_t k, uint32_t num_probes) {
+        detail::Rows r(b, k);
+        dev_.check(mdb_ivf_search(h_, queries, b, nullptr, num_probes, k, MDB_MEM_HOST, r.ids.data(), r.scores.data(), r.counts.data()));
+        return r.take(b, k);
+    }
+    // search_with_centroids_and_remap (:298-332); centroids [b][num_probes]
+    std::vector<std::optional<SearchResult>> search_with_centroids_and_remap(const float* queries, size_t b,
+                                                                             const uint32_t* centroids, size_t num_probes, size_t k) {
+        detail::Rows r(b, k);
+        dev_.check(mdb_ivf_search(h_, queries, b, centroids, num_probes, k, MDB_MEM_HOST, r.ids.data(), r.scores.data(), r.counts.data()));
+        return r.take(b, k);
+    }
+    bool invalidate(u128 doc_id) {
+        mdb_u128 d = detail::split(doc_id);
+        uint8_t f = 0;
+        dev_.check(mdb_ivf_invalidate(h_, &d, 1, &f));
+        return f != 0;
+    }
+    bool is_invalidated(u128 doc_id) {
+        mdb_u128 d = detail::split(doc_id);
+        uint8_t f = 0;
+        dev_.check(mdb_ivf_is_invalidated(h_, &d, 1, &f));
+        return f != 0;
+    }
+
+  private:
+    Device& dev_;
+    mdb_ivf* h_ = nullptr;
+};
+
+class BlockBasedHnsw {
+  public:
+    BlockBasedHnsw(Device& dev, const void* index, size_t index_len, const void* vectors, size_t vectors_len, Quantizer q,
+                   size_t index_offset = 0, size_t vector_offset = 0)
+        : dev_(dev) {
+        dev_.check(mdb_hnsw_load(dev.ctx(), index, index_len, index_offset, vectors, vectors_len, vector_offset, q.desc(), &h_));
+    }
+    ~BlockBasedHnsw() { mdb_hnsw_free(h_); }
+    BlockBasedHnsw(const BlockBasedHnsw&) = delete;
+    // ann_search (hnsw/block_based/index.rs:159-210)
+    std::vector<SearchResult> ann_search(const float* queries, size_t b, size_t k, uint32_t ef) {
+        detail::Rows r(b, k);
+        dev_.check(mdb_hnsw_ann_search(h_, queries, b, k, ef, MDB_MEM_HOST, r.ids.data(), r.scores.data(), r.counts.data()));
+        std::vector<SearchResult> out;
+        for (auto& o : r.take(b, k)) out.push_back(std::move(*o));
+        return out;
+    }
+
+  private:
+    Device& dev_;
+    mdb_hnsw* h_ = nullptr;
+};
+
+class Spann {
+  public:
+    // SpannReader::new_with_offsets (spann/reader.rs): offsets = {hnsw index, hnsw vectors, ivf index, ivf vectors}
+    Spann(Device& dev, const void* hnsw_index, size_t hil, const void* hnsw_vectors, size_t hvl, const void* ivf_index, size_t iil,
+          const void* ivf_vectors, size_t ivl, Quantizer q, const size_t (&offsets)[4] = {0, 0, 0, 0})
+        : dev_(dev) {
+        dev_.check(mdb_spann_load(dev.ctx(), hnsw_index, hil, offsets[0], hnsw_vectors, hvl, offsets[1], ivf_index, iil, offsets[2],
+                                  ivf_vectors, ivl, offsets[3], q.desc(), &h_));
+    }
+    ~Spann() { mdb_spann_free(h_); }
+    Spann(const Spann&) = delete;
+    // Spann::search (spann/index.rs:211-266): nullopt == None
+    std::vector<std::optional<SearchResult>> search(const float* queries, size_t b, const SearchParams& p) {
+        detail::Rows r(b, p.top_k);
+        mdb_search_params c = p.c();
+        dev_.check(mdb_spann_search(h_, queries, b, &c, MDB_MEM_HOST, r.ids.data(), r.scores.data(), r.counts.data(), r.found.data()));
+        return r.take(b, p.top_k);
+    }
+    bool invalidate(u128 doc_id) {
+        mdb_u128 d = detail::split(doc_id);
+        uint8_t f = 0;
+        dev_.check(mdb_spann_invalidate(h_, &d, 1, &f));
+        return f != 0;
+    }
+
+  private:
+    Device& dev_;
+    mdb_spann* h_ = nullptr;
+};
+
+class MultiSpannIndex {
+  public:
+    MultiSpannIndex(Device& dev, const std::vector<mdb_user_index_info>& users, uint32_t num_features, const void* hnsw_index,
+                    size_t hil, const void* hnsw_vectors, size_t hvl, const void* ivf_index, size_t iil, const void* ivf_vectors,
+                    size_t ivl, Quantizer q, uint32_t shard_rank = 0, uint32_t shard_world = 1)
+        : dev_(dev) {
+        dev_.check(mdb_multi_spann_load(dev.ctx(), users.data(), users.size(), num_features, hnsw_index, hil, hnsw_vectors, hvl,
+                                        ivf_index, iil, ivf_vectors, ivl, q.desc(), shard_rank, shard_world, &h_));
+    }
+    ~MultiSpannIndex() { mdb_multi_spann_free(h_); }
+    MultiSpannIndex(const MultiSpannIndex&) = delete;
+    size_t num_users() const { return mdb_multi_spann_num_users(h_); }
+    // search_for_user (multi_spann/index.rs:282-293) for a batch of (user, query) pairs
+    std::vector<std::optional<SearchResult>> search_for_user(const std::vector<u128>& user_ids, const float* queries,
+                                                             const SearchParams& p) {
+        const size_t b = user_ids.size();
+        std::vector<mdb_u128> ids(b);
+        for (size_t i = 0; i < b; ++i) ids[i] = detail::split(user_ids[i]);
+        detail::Rows r(b, p.top_k);
+        mdb_search_params c = p.c();
+        dev_.check(mdb_multi_spann_search(h_, ids.data(), queries, b, &c, MDB_MEM_HOST, r.ids.data(), r.scores.data(),
+                                          r.counts.data(), r.found.data()));
+        return r.take(b, p.top_k);
+    }
+
+  private:
+    Device& dev_;
+    mdb_multi_spann* h_ = nullptr;
+};
+
+}  // namespace muopdb

@@ -20,3 +20,9 @@ done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
 echo "built $OUT"
+# C++ host mirror demo (include/muopdb_host.hpp over the C ABI; plain g++, no HIP headers needed)
+g++ -std=c++17 -O2 -Wall -I../../include ../../examples/host_mirror_demo.cpp -o ../host_mirror_demo \
+  -L.. -lmuopdb_hip -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+g++ -std=c++17 -O2 -Wall -I../../include ../../examples/replay_search.cpp -o ../replay_search \
+  -L.. -lmuopdb_hip -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+echo "built ../host_mirror_demo ../replay_search"

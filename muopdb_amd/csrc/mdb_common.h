@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -38,7 +39,12 @@ struct mdb_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
     std::mutex mu;
+    // index handles keep their context alive: mdb_device_close drops the caller's reference and the
+    // context is destroyed with the last handle (so free order does not matter to the caller)
+    std::atomic<int> refs{1};
 };
+void mdb_ctx_retain(mdb_ctx* ctx);
+void mdb_ctx_release(mdb_ctx* ctx);
 
 // records a start/stop event pair around the enclosed launches on the context's stream
 struct ProfScope {

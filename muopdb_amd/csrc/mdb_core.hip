@@ -44,6 +44,23 @@ mdb_status mdb_check_flags(mdb_ctx* ctx) {
     return MDB_OK;
 }
 
+void mdb_ctx_retain(mdb_ctx* ctx) { ctx->refs.fetch_add(1); }
+
+void mdb_ctx_release(mdb_ctx* ctx) {
+    if (ctx->refs.fetch_sub(1) != 1) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 8; ++i)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    for (auto& ev : ctx->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
 extern "C" {
 
 const char* mdb_version(void) { return "muopdb-hip 0.1 (gfx950)"; }
@@ -68,19 +85,9 @@ mdb_status mdb_device_open(int gpu, mdb_ctx** out) {
 }
 
 void mdb_device_close(mdb_ctx* ctx) {
-    if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 8; ++i)
-        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
-    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
-    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
-    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
-    for (auto& ev : ctx->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
+    if (ctx) mdb_ctx_release(ctx);
 }
+
 
 mdb_status mdb_set_stream(mdb_ctx* ctx, void* hip_stream) {
     if (!ctx) return MDB_ERR_INVALID_ARG;

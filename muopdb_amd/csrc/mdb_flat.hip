@@ -253,6 +253,7 @@ mdb_status mdb_flat_create(mdb_ctx* ctx, const float* base, size_t n, size_t d, 
     mdb_status st = tiles_from_rows(ctx, d_rows, n, (int)d, f->ts);
     if (st == MDB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = mdb_fail(ctx, MDB_ERR_HIP, "sync failed");
     if (st != MDB_OK) { delete f; return st; }
+    mdb_ctx_retain(ctx);
     *out = f;
     return MDB_OK;
 }
@@ -261,7 +262,9 @@ void mdb_flat_free(mdb_flat* flat) {
     if (!flat) return;
     (void)hipSetDevice(flat->ctx->device);
     (void)hipStreamSynchronize(flat->ctx->stream);
+    mdb_ctx* ctx = flat->ctx;
     delete flat;
+    mdb_ctx_release(ctx);
 }
 
 mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_t k, mdb_mem mem, uint32_t* ids_out,

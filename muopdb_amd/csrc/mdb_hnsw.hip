@@ -1191,6 +1191,7 @@ mdb_status mdb_hnsw_load(mdb_ctx* ctx, const void* index_bytes, size_t index_len
     mdb_status st = h->set.load(ctx, (const uint8_t*)index_bytes, index_len, (const uint8_t*)vectors_bytes, vectors_len,
                                 {{index_offset, vectors_offset}}, quant, dim);
     if (st != MDB_OK) { delete h; return st; }
+    mdb_ctx_retain(ctx);
     *out = h;
     return MDB_OK;
 }
@@ -1199,7 +1200,9 @@ void mdb_hnsw_free(mdb_hnsw* h) {
     if (!h) return;
     (void)hipSetDevice(h->set.ctx->device);
     (void)hipStreamSynchronize(h->set.ctx->stream);
+    mdb_ctx* ctx = h->set.ctx;
     delete h;
+    mdb_ctx_release(ctx);
 }
 
 size_t mdb_hnsw_num_vectors(const mdb_hnsw* h) { return h ? (size_t)h->set.blobs[0].num_vectors : 0; }

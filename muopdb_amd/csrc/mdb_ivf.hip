@@ -700,6 +700,7 @@ mdb_status mdb_ivf_load(mdb_ctx* ctx, const void* index_bytes, size_t index_len,
     mdb_status st = ivf->set.load(ctx, (const uint8_t*)index_bytes, index_len, (const uint8_t*)vectors_bytes, vectors_len,
                                   {{index_offset, vectors_offset}}, quant, shard_rank, shard_world);
     if (st != MDB_OK) { delete ivf; return st; }
+    mdb_ctx_retain(ctx);
     *out = ivf;
     return MDB_OK;
 }
@@ -708,7 +709,9 @@ void mdb_ivf_free(mdb_ivf* ivf) {
     if (!ivf) return;
     (void)hipSetDevice(ivf->set.ctx->device);
     (void)hipStreamSynchronize(ivf->set.ctx->stream);
+    mdb_ctx* ctx = ivf->set.ctx;
     delete ivf;
+    mdb_ctx_release(ctx);
 }
 
 size_t mdb_ivf_num_clusters(const mdb_ivf* ivf) { return ivf ? ivf->set.blobs[0].num_clusters : 0; }

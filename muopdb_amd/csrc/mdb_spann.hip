@@ -226,6 +226,7 @@ mdb_status mdb_spann_load(mdb_ctx* ctx, const void* hnsw_index, size_t hnsw_inde
     }
     if (st != MDB_OK) { delete sp; return st; }
     sp->set.num_users = 1;
+    mdb_ctx_retain(ctx);
     *out = sp;
     return MDB_OK;
 }
@@ -234,7 +235,9 @@ void mdb_spann_free(mdb_spann* sp) {
     if (!sp) return;
     (void)hipSetDevice(sp->set.ctx->device);
     (void)hipStreamSynchronize(sp->set.ctx->stream);
+    mdb_ctx* ctx = sp->set.ctx;
     delete sp;
+    mdb_ctx_release(ctx);
 }
 
 mdb_status mdb_spann_search(mdb_spann* sp, const float* queries, size_t b, const mdb_search_params* params, mdb_mem mem,
@@ -291,6 +294,7 @@ mdb_status mdb_multi_spann_load(mdb_ctx* ctx, const mdb_user_index_info* users, 
     }
     if (st != MDB_OK) { delete ms; return st; }
     ms->set.num_users = n_users;
+    mdb_ctx_retain(ctx);
     *out = ms;
     return MDB_OK;
 }
@@ -299,7 +303,9 @@ void mdb_multi_spann_free(mdb_multi_spann* ms) {
     if (!ms) return;
     (void)hipSetDevice(ms->set.ctx->device);
     (void)hipStreamSynchronize(ms->set.ctx->stream);
+    mdb_ctx* ctx = ms->set.ctx;
     delete ms;
+    mdb_ctx_release(ctx);
 }
 
 size_t mdb_multi_spann_num_users(const mdb_multi_spann* ms) { return ms ? ms->set.num_users : 0; }

@@ -275,3 +275,22 @@ def test_ivf_sharded_union_equals_unsharded(ctx, oracle):
             rows += list(zip(sc[0, :cn[0]].tolist(), ids[0, :cn[0]].tolist()))
         rows.sort()
         assert [r[1] for r in rows[:10]] == full_ids[qi, :full_cn[qi]].tolist()
+
+
+def test_handles_outlive_context_close(oracle):
+    """mdb_device_close only drops the caller's reference: a handle freed (or even searched) after
+    the context was closed must not crash (Python GC frees in arbitrary order)."""
+    from muopdb_amd import lib
+    from muopdb_amd.index import FlatIndex
+    c = lib.Context(0)
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((500, 16)).astype(np.float32)
+    q = rng.standard_normal((3, 16)).astype(np.float32)
+    f = FlatIndex(c, base)
+    want = f.search(q, 5)[0]
+    h, c.h = c.h, None
+    c.lib.mdb_device_close(h)          # context "closed" while f is alive
+    c.h = h                            # still usable through the handle's reference
+    assert np.array_equal(f.search(q, 5)[0], want)
+    c.h = None
+    f.close()                          # last reference: destroys the context

@@ -160,6 +160,47 @@ def test_spann_random_noq_and_pq(ctx, oracle):
     assert_result_rows(sp.search(q, p), osp.search(q, op), len(q))
 
 
+def test_cpp_host_mirror_matches_ctypes_binding(ctx, oracle, tmp_path):
+    """include/muopdb_host.hpp (C++ mirror of the reference surface) through the same C ABI:
+    its rows must equal the ctypes binding's rows (which are oracle-checked above)."""
+    import os
+    import struct
+    import subprocess
+    from muopdb_amd.index import Spann, SearchParams, BlockBasedHnsw, BlockBasedIvf
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "muopdb_amd", "host_mirror_demo")
+    assert os.path.exists(exe), "host_mirror_demo not built (run __graft_entry__.build())"
+    rng = np.random.default_rng(5)
+    v = H.sift_like(3000, 24, n_clusters=20, seed=3)
+    doc = list(range(100, 3100))
+    files, _, _ = H.build_spann_files(oracle, v, doc, 30, max_neighbors=8, max_layers=3, ef_construction=50)
+    q = (v[rng.integers(0, 3000, 9)] + rng.normal(0, 3, (9, 24))).astype(np.float32)
+    for name in ("hnsw_index", "hnsw_vectors", "ivf_index", "ivf_vectors"):
+        (tmp_path / name).write_bytes(files[name])
+    (tmp_path / "queries.f32").write_bytes(q.tobytes())
+    out = subprocess.run([exe, str(tmp_path), "24", "7", "60", "5", "0.25"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = {}
+    for line in out.stdout.splitlines():
+        t = line.split()
+        if t[2] == "none":
+            got[(t[0], int(t[1]))] = None
+        else:
+            got[(t[0], int(t[1]))] = [(int(x.split(":")[0]), int(x.split(":")[1], 16)) for x in t[3:]]
+            assert len(got[(t[0], int(t[1]))]) == int(t[2])
+
+    def rows(res):
+        return [[(int(i), struct.unpack("<I", struct.pack("<f", float(s)))[0]) for i, s in res.id_with_scores(qi)]
+                if res.found[qi] else None for qi in range(res.b)]
+    sp = Spann(ctx, files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"])
+    p = SearchParams(7, 60).with_num_explored_centroids(5).with_centroid_distance_ratio(0.25)
+    want = {"spann": rows(sp.search(q, p)),
+            "hnsw": rows(BlockBasedHnsw(ctx, files["hnsw_index"], files["hnsw_vectors"], 24).ann_search(q, 7, 60)),
+            "ivf": rows(BlockBasedIvf(ctx, files["ivf_index"], files["ivf_vectors"]).search(q, 7, 5))}
+    for name, rr in want.items():
+        for i, r in enumerate(rr):
+            assert got[(name, i)] == r, (name, i)
+
+
 # ----------------------------------------------------------------------------------- multi-user (K9, K10)
 def _multi(ctx, oracle, users, quant=None, oquant=None, **kw):
     from muopdb_amd.index import MultiSpannIndex
