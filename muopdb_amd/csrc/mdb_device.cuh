@@ -187,6 +187,31 @@ struct BlockSelect {
         if (threadIdx.x == 0) { *cnt = 0; *thr = k_ > 0 ? MDB_KEY_MAX : 0ull; }
         __syncthreads();
     }
+    // Optional, once, before the first offer() and with the keys of the first round (uniform control
+    // flow, k <= 64): every wave sorts its 64 keys; the smallest "k-th of a wave" bounds the global
+    // k-th key from above, so it is a valid admission threshold from the very first round — without
+    // it the first rounds admit everything and force a full-queue sort.  Full keys (not just the
+    // distance) so that long runs of equal distances (PQ codes) stay out too.
+    __device__ void warm_start(uint64_t key) {
+        if (k <= 0 || k > 64) return;
+        const int lane = threadIdx.x & 63;
+        uint64_t d = key;
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(d >> 32), stride) << 32) |
+                             (uint32_t)__shfl_xor((int)(uint32_t)d, stride);
+                bool up = ((lane & size) == 0) == ((lane & stride) == 0);  // this lane keeps the smaller one
+                uint64_t mn = d < o ? d : o, mx = d < o ? o : d;
+                d = up ? mn : mx;
+            }
+        }
+        uint64_t kth = ((uint64_t)(uint32_t)__shfl((int)(d >> 32), k - 1) << 32) | (uint32_t)__shfl((int)(uint32_t)d, k - 1);
+        // k keys <= kth exist, so every member of the final top-k is <= kth: admit key < kth + 1
+        if (lane == 0 && kth < MDB_KEY_MAX - 1) atomicMin((unsigned long long*)thr, (unsigned long long)(kth + 1));
+        __syncthreads();
+    }
     __device__ __forceinline__ void offer(uint64_t key) {
         if (key < *thr) {
             uint32_t pos = atomicAdd(cnt, 1u);
@@ -203,7 +228,7 @@ struct BlockSelect {
         for (int size = 2; size <= n; size <<= 1) {
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
                 for (int t = threadIdx.x; t < (n >> 1); t += BLOCK) {
-                    int lo = ((t / stride) * stride * 2) + (t % stride);
+                    int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));  // stride is a power of two
                     int hi = lo + stride;
                     bool up = ((lo & size) == 0);
                     uint64_t a = buf[lo], b = buf[hi];

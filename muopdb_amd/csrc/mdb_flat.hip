@@ -109,6 +109,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_scan_kernel(const float4* __re
                 if (dist != dist) nan_seen = true;
                 key = make_key(dist, (uint32_t)v);
             }
+            if (g == blockIdx.x) sel[i].warm_start(key);  // first round: threshold from the waves' own k-th keys
             sel[i].offer(key);
         }
 #pragma unroll

@@ -15,6 +15,7 @@
 // splits; a final kernel maps point ids to u128 doc ids and orders by IdWithScore
 // (score, doc id) — rs/index/src/utils.rs:95-114.
 // Bound: HBM — (d*4+4) B per scored vector (NoQ) or (m+4) B (PQ), SURVEY.md §8d.
+#include <type_traits>
 #include <unordered_map>
 
 #include "mdb_device.cuh"
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
     const IvfUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
     const float* qb = q + (size_t)qi * qstride;
     const int np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
-    bool nan_seen = false, bad = false;
+    bool nan_seen = false, bad = false, first = true;
     unsigned scored = 0;
     if (u.valid) {
         for (int j = split; j < np; j += nsplit) {
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
                         ++scored;
                     }
                 }
+                if (first) { sel.warm_start(key); first = false; }
                 sel.offer(key);
                 sel.round_end();
             }
@@ -272,6 +274,236 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_pq_kernel(ScanArgs a, cons
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
     for (int j = threadIdx.x; j < a.k; j += MDB_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+}
+
+// ------------------------------------------------------------------------------------------
+// PQ posting-list scan, fast path: SUBDIM (compile time, multiple of 4, power of two) floats per
+// codebook row, per-element table in LDS (bit-exact association).
+//   * 1024 threads = 16 waves, one block per (query, split); the 128 KB table is built once per block
+//     with float4 traffic only;
+//   * all probed lists of the query are flattened into one tile sequence (LDS prefix array), so every
+//     wave has a tile in every round whatever the list lengths;
+//   * 2-deep software pipeline over rounds: slot ids + code words of round r+2 and the tombstone
+//     words of round r+1 are in flight while round r adds table rows (the only barrier per round is
+//     BlockSelect's).
+// LDS reads are the floor: d/4 ds_read_b128 per scored vector.
+#define PQ2_BLOCK 1024
+#define PQ2_NW (PQ2_BLOCK / MDB_WAVE)
+#define PQ2_PCH 512  // probes per chunk of the flattened tile sequence
+
+template <int SUBDIM>
+__device__ __forceinline__ void pq2_add_row(const float* __restrict__ row, float (&s16)[16], float (&s8)[8], float (&s4)[4]) {
+    constexpr int N16 = SUBDIM / 16, N8 = (SUBDIM % 16) / 8, N4 = (SUBDIM % 8) / 4;
+#pragma unroll
+    for (int c = 0; c < N16; ++c) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float4 t = *(const float4*)(row + 16 * c + 4 * v);
+            s16[4 * v + 0] = __fadd_rn(s16[4 * v + 0], t.x);
+            s16[4 * v + 1] = __fadd_rn(s16[4 * v + 1], t.y);
+            s16[4 * v + 2] = __fadd_rn(s16[4 * v + 2], t.z);
+            s16[4 * v + 3] = __fadd_rn(s16[4 * v + 3], t.w);
+        }
+    }
+    if (N8) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            float4 t = *(const float4*)(row + 16 * N16 + 4 * v);
+            s8[4 * v + 0] = __fadd_rn(s8[4 * v + 0], t.x);
+            s8[4 * v + 1] = __fadd_rn(s8[4 * v + 1], t.y);
+            s8[4 * v + 2] = __fadd_rn(s8[4 * v + 2], t.z);
+            s8[4 * v + 3] = __fadd_rn(s8[4 * v + 3], t.w);
+        }
+    }
+    if (N4) {
+        float4 t = *(const float4*)(row + 16 * N16 + 8 * N8);
+        s4[0] = __fadd_rn(s4[0], t.x);
+        s4[1] = __fadd_rn(s4[1], t.y);
+        s4[2] = __fadd_rn(s4[2], t.z);
+        s4[3] = __fadd_rn(s4[3], t.w);
+    }
+}
+
+template <int METRIC, int SUBDIM, int MW>
+__global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m,
+                                                                 int nbits, const float* __restrict__ cb,
+                                                                 const uint8_t* __restrict__ qcodes) {
+    static_assert(SUBDIM % 4 == 0 && (SUBDIM & (SUBDIM - 1)) == 0, "SUBDIM: power of two >= 4");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    BlockSelect<PQ2_BLOCK> sel;
+    sel.init(lds, a.k);
+    uint32_t* pstart = (uint32_t*)(lds + ((BlockSelect<PQ2_BLOCK>::lds_bytes(a.k) + 15) & ~(size_t)15));
+    uint32_t* ppref = pstart + PQ2_PCH;             // [PQ2_PCH + 1] exclusive prefix of tile counts
+    float* qv = (float*)(ppref + PQ2_PCH + 16);     // the query's own codebook rows [m][SUBDIM]
+    float* lut = qv + m * SUBDIM;
+    const int qi = blockIdx.y, split = blockIdx.x, nsplit = gridDim.x;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / MDB_WAVE), lane = tid % MDB_WAVE;
+    const IvfUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
+    const uint8_t* qc = qcodes + (size_t)qi * m;
+    const int np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
+    const int K = 1 << nbits;
+    constexpr int S4 = SUBDIM / 4;
+    bool nan_seen = false, bad = false;
+    unsigned scored = 0;
+
+    // ---- table: lut[s][c][e] = term(q_s[e], cb[s][c][e]), each individually rounded
+    for (int i = tid; i < m * SUBDIM; i += PQ2_BLOCK) {
+        int s = i / SUBDIM;
+        qv[i] = cb[((size_t)s * K + qc[s]) * SUBDIM + (i % SUBDIM)];
+    }
+    __syncthreads();
+    {
+        const int row4 = K * S4, total4 = m * row4;
+        const float4* cb4 = (const float4*)cb;
+        for (int i4 = tid; i4 < total4; i4 += PQ2_BLOCK) {
+            int s = i4 / row4;  // row4 is a power of two: a shift
+            float4 q = ((const float4*)qv)[s * S4 + (i4 & (S4 - 1))];
+            float4 c = cb4[i4], t;
+            t.x = acc_term<METRIC>(0.0f, q.x, c.x);  // 0 + term == term exactly
+            t.y = acc_term<METRIC>(0.0f, q.y, c.y);
+            t.z = acc_term<METRIC>(0.0f, q.z, c.z);
+            t.w = acc_term<METRIC>(0.0f, q.w, c.w);
+            ((float4*)lut)[i4] = t;
+        }
+    }
+    __syncthreads();
+
+    if (u.valid) {
+        for (int p0 = 0; p0 < np; p0 += PQ2_PCH) {
+            const int n = min(PQ2_PCH, np - p0);
+            // flatten this chunk's lists into one tile sequence
+            if (tid < PQ2_PCH) {
+                uint32_t t0 = 0, cnt = 0;
+                if (tid < n) {
+                    uint32_t c = a.probes[(size_t)qi * a.probe_stride + p0 + tid];
+                    if (c >= u.num_lists) bad = true;
+                    else {
+                        uint32_t g = u.list_base + c;
+                        t0 = a.list_tile_off[g];
+                        cnt = a.list_tile_off[g + 1] - t0;
+                    }
+                }
+                pstart[tid] = t0;
+                ppref[tid + 1] = cnt;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                constexpr int PER = PQ2_PCH / MDB_WAVE;
+                uint32_t loc[PER], sum = 0;
+#pragma unroll
+                for (int x = 0; x < PER; ++x) { loc[x] = ppref[1 + lane * PER + x]; sum += loc[x]; }
+                uint32_t incl = sum;
+#pragma unroll
+                for (int o = 1; o < MDB_WAVE; o <<= 1) {
+                    uint32_t v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                uint32_t run = incl - sum;
+#pragma unroll
+                for (int x = 0; x < PER; ++x) { run += loc[x]; ppref[1 + lane * PER + x] = run; }
+                if (lane == 0) ppref[0] = 0;
+            }
+            __syncthreads();
+            const int T = (int)ppref[PQ2_PCH];
+            const int per_round = PQ2_NW * nsplit;
+            const int rounds = (T + per_round - 1) / per_round;
+            // 3-stage software pipeline over rounds, unrolled by 3 so that no loaded register is ever
+            // moved (a move would force the wait right after the issue): stage set (r % 3) is fetched in
+            // iteration r (slot id + code words, unconditional loads from clamped addresses), gets its
+            // tombstone word in iteration r+1 and is consumed in iteration r+2.
+            uint32_t pid[3], tw[3], cw[3][MW];
+            bool live[3] = {false, false, false};  // wave-uniform: the set holds a real tile
+            int jsafe = 0;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                pid[x] = 0xFFFFFFFFu;
+                tw[x] = 0;
+#pragma unroll
+                for (int w = 0; w < MW; ++w) cw[x][w] = 0;
+            }
+            auto iteration = [&](int r, auto PH) {
+                constexpr int FA = decltype(PH)::value, TB = (FA + 2) % 3, CC = (FA + 1) % 3;
+                // ---- issue (branch-free, so that the compiler's vmcnt bookkeeping stays exact): fetch
+                // round r into set FA; a wave without a tile reads tile 0 of the sequence and is marked dead
+                {
+                    int t = (r * nsplit + split) * PQ2_NW + wave;
+                    int j = 0;  // number of lists that end at or before t
+#pragma unroll
+                    for (int x = 0; x < PQ2_PCH / MDB_WAVE; ++x)
+                        j += __popcll(__ballot(ppref[x * MDB_WAVE + lane + 1] <= (uint32_t)t));
+                    live[FA] = r < rounds && t < T;  // then j < n: unused entries have prefix == T > t
+                    j = live[FA] ? j : jsafe;
+                    uint32_t tile = pstart[j] + (live[FA] ? (uint32_t)t - ppref[j] : 0u);
+                    pid[FA] = a.slot_ids[(size_t)tile * MDB_TILE + lane];
+                    const uint32_t* cwp = codes + (size_t)tile * MW * MDB_TILE + lane;
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) cw[FA][w] = cwp[(size_t)w * MDB_TILE];
+                }
+                // ---- issue: tombstone word of round r-1 (set TB); padding slots read word 0
+                {
+                    uint32_t pz = pid[TB] == 0xFFFFFFFFu ? 0u : pid[TB];
+                    tw[TB] = a.tomb[u.tomb_base + (pz >> 5)];
+                }
+                // ---- compute round r-2 (set CC)
+                if (r >= 2) {
+                    uint64_t key = MDB_KEY_MAX;
+                    if (live[CC] && pid[CC] != 0xFFFFFFFFu && !((tw[CC] >> (pid[CC] & 31)) & 1u)) {
+                        float s16[16], s8[8], s4[4];
+#pragma unroll
+                        for (int x = 0; x < 16; ++x) s16[x] = 0.0f;
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) s8[x] = 0.0f;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) s4[x] = 0.0f;
+#pragma unroll
+                        for (int w = 0; w < MW; ++w) {
+#pragma unroll
+                            for (int bi = 0; bi < 4; ++bi) {
+                                int s = w * 4 + bi;
+                                if (s < m) {
+                                    uint32_t code = (cw[CC][w] >> (8 * bi)) & 0xFFu;
+                                    pq2_add_row<SUBDIM>(lut + ((size_t)(s << nbits) + code) * SUBDIM, s16, s8, s4);
+                                }
+                            }
+                        }
+                        float rs = __fadd_rn(__fadd_rn(__fadd_rn(reduce_ordered<16>(s16), reduce_ordered<8>(s8)),
+                                                       reduce_ordered<4>(s4)), 0.0f);
+                        float dist = METRIC == MDB_METRIC_L2 ? rs : -rs;
+                        if (dist != dist) nan_seen = true;
+                        key = make_key(dist, pid[CC]);
+                        ++scored;
+                    }
+                    if (p0 == 0 && r == 2) sel.warm_start(key);
+                    sel.offer(key);
+                    sel.round_end();
+                }
+            };
+            if (T > 0) {
+                int j0 = 0;  // first non-empty list of the chunk: a safe tile for idle waves
+#pragma unroll
+                for (int x = 0; x < PQ2_PCH / MDB_WAVE; ++x) j0 += __popcll(__ballot(ppref[x * MDB_WAVE + lane + 1] == 0u));
+                jsafe = j0;
+                for (int r = 0; r < rounds + 2; r += 3) {  // surplus iterations offer nothing (uniform)
+                    iteration(r, std::integral_constant<int, 0>{});
+                    iteration(r + 1, std::integral_constant<int, 1>{});
+                    iteration(r + 2, std::integral_constant<int, 2>{});
+                }
+            }
+            __syncthreads();  // pstart / ppref are rewritten by the next chunk
+        }
+    }
+    if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
+    if (bad) atomicOr(a.flags, MDB_FLAG_RANGE);
+    {
+        unsigned long long ws = scored;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ws += __shfl_xor((unsigned)ws, o);
+        if (lane == 0 && ws) atomicAdd(&a.counters[2], ws);
+    }
+    sel.finish();
+    uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
+    uint32_t c = sel.count();
+    for (int j = tid; j < a.k; j += PQ2_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
 }
 
 // keys (distance, point id) -> (u128 doc id, score) rows ordered by IdWithScore (score, doc id).
@@ -554,6 +786,21 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         nsplit = (int)std::min<size_t>(std::max<size_t>(want, 1), (size_t)probe_stride);
         nsplit = std::min(nsplit, 64);
     }
+    // PQ fast path (ivf_scan_pq2_kernel): compile-time subvector width, table + selector + tile map in LDS
+    size_t pq2_lds = 0;
+    bool pq2 = false;
+    if (kind == MDB_QUANT_PQ && !getenv("MDB_PQ_NO_FAST")) {
+        pq2_lds = ((BlockSelect<PQ2_BLOCK>::lds_bytes((int)k) + 15) & ~(size_t)15) + (2 * PQ2_PCH + 16) * 4 +
+                  (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * pq.K * pq.subdim * 4;
+        pq2 = (pq.subdim == 4 || pq.subdim == 8 || pq.subdim == 16 || pq.subdim == 32) && (mw == 1 || mw == 2 || mw == 4 || mw == 8) &&
+              pq.K == (1 << pq.num_bits) && pq.num_bits <= 8 && pq2_lds <= 160 * 1024 - 256;
+        if (pq2) {  // one block per CU (LDS).  More, shorter blocks do NOT balance skewed lists better here: the hardware
+            // dispatches 150 KB-LDS workgroups in order, so CUs idle between blocks (measured: 256 blocks 98 us,
+            // 512 blocks 140 us, 1024 blocks 247 us for the same work)
+            static const size_t target = getenv("MDB_PQ_BLOCKS") ? (size_t)atoi(getenv("MDB_PQ_BLOCKS")) : 256;
+            nsplit = (int)std::min<size_t>(std::max<size_t>((target + b - 1) / b, 1), 16);
+        }
+    }
     void* partial;
     MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)nsplit * std::max<size_t>(k, 1) * 8, &partial));
     ScanArgs a{d_users.p, d_q_user, d_list_tile_off.p, d_slot_ids.p, d_tomb.p, d_probes, d_probe_cnt, probe_stride,
@@ -580,11 +827,37 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         ivf_scan_pq_kernel<METRIC, LUT><<<grid, MDB_BLOCK, (LDS), ctx->stream>>>(a, d_codes.p, pq.m, mw, pq.K, pq.subdim, \
                                                                                   sp, pq.codebook.p, (uint8_t*)qcodes); \
     } while (0)
-        if (metric == MDB_METRIC_L2) {
+#define MDB_PQ2_LAUNCH(METRIC, SD, MWT)                                                                               \
+    do {                                                                                                             \
+        MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq2_kernel<METRIC, SD, MWT>,                          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq2_lds));                \
+        ivf_scan_pq2_kernel<METRIC, SD, MWT><<<grid, PQ2_BLOCK, pq2_lds, ctx->stream>>>(                              \
+            a, d_codes.p, pq.m, pq.num_bits, pq.codebook.p, (uint8_t*)qcodes);                                   \
+    } while (0)
+#define MDB_PQ2_SD(METRIC, MWT)                                                                                      \
+    do {                                                                                                             \
+        if (pq.subdim == 4) MDB_PQ2_LAUNCH(METRIC, 4, MWT);                                                          \
+        else if (pq.subdim == 8) MDB_PQ2_LAUNCH(METRIC, 8, MWT);                                                     \
+        else if (pq.subdim == 16) MDB_PQ2_LAUNCH(METRIC, 16, MWT);                                                   \
+        else MDB_PQ2_LAUNCH(METRIC, 32, MWT);                                                                        \
+    } while (0)
+        if (pq2) {
+#define MDB_PQ2_MW(METRIC)                                                                                           \
+    do {                                                                                                             \
+        if (mw == 1) MDB_PQ2_SD(METRIC, 1);                                                                          \
+        else if (mw == 2) MDB_PQ2_SD(METRIC, 2);                                                                     \
+        else if (mw == 4) MDB_PQ2_SD(METRIC, 4);                                                                     \
+        else MDB_PQ2_SD(METRIC, 8);                                                                                  \
+    } while (0)
+            if (metric == MDB_METRIC_L2) MDB_PQ2_MW(MDB_METRIC_L2); else MDB_PQ2_MW(MDB_METRIC_DOT);
+#undef MDB_PQ2_MW
+        } else if (metric == MDB_METRIC_L2) {
             if (use_lut) MDB_PQ_LAUNCH(MDB_METRIC_L2, true, lds_lut); else MDB_PQ_LAUNCH(MDB_METRIC_L2, false, sel_lds);
         } else {
             if (use_lut) MDB_PQ_LAUNCH(MDB_METRIC_DOT, true, lds_lut); else MDB_PQ_LAUNCH(MDB_METRIC_DOT, false, sel_lds);
         }
+#undef MDB_PQ2_SD
+#undef MDB_PQ2_LAUNCH
 #undef MDB_PQ_LAUNCH
     } else {
         DistPlan p = make_plan((int)num_features, metric);

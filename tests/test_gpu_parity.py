@@ -213,6 +213,22 @@ def test_ivf_pq(ctx, oracle, n, d, sub, bits, L, P, k):
     assert_result_rows(g.search(q, k, P), o.search(q, k, num_probes=P), len(q))
 
 
+@pytest.mark.parametrize("n,d,sub,bits,L,P,k", [(3000, 256, 32, 5, 12, 6, 10),      # code words per vector: 2
+                                                (3000, 256, 8, 4, 12, 12, 64),     # 8 code words, k = 64 (warm start limit)
+                                                (6000, 32, 8, 6, 700, 650, 10),    # > 512 probes: two chunks of the tile map
+                                                (3000, 64, 4, 8, 9, 9, 100)])      # k > 64: no warm start
+def test_ivf_pq_fast_scan_shapes(ctx, oracle, n, d, sub, bits, L, P, k):
+    """ivf_scan_pq2_kernel (compile-time subvector width, flattened tile sequence, 3-stage pipeline):
+    shapes around its template / chunk boundaries, with tombstones, against the oracle."""
+    o, g, q, v, doc_ids = _ivf_case(oracle, ctx, n, d, L, seed=n + d + sub + bits, quant=(sub, bits))
+    assert_result_rows(g.search(q, k, P), o.search(q, k, num_probes=P), len(q))
+    first = g.search(q, k, P)
+    dead = sorted({first.doc_ids(i)[0] for i in range(len(q)) if first.counts[i]})[:8]
+    for doc in dead:
+        assert g.invalidate(doc) and o.invalidate(doc)
+    assert_result_rows(g.search(q, k, P), o.search(q, k, num_probes=P), len(q))
+
+
 def test_ivf_duplicates_tombstones_and_errors(ctx, oracle):
     from muopdb_amd import lib as L
     o, g, q, v, doc_ids = _ivf_case(oracle, ctx, 1200, 16, 6, seed=5, cpv=2)
