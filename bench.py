@@ -215,13 +215,17 @@ def run_flat(args, ctx, rank, world, timer):
     batch = args.batch or 1
     k = args.k
     steps, warm = args.steps, args.warmup
-    g = torch.Generator(device="cpu"); g.manual_seed(42)
-    lab = torch.arange(n) % 10
-    x = (lab[:, None].float() * 100.0 + torch.randn((n, d), generator=g) * 5.0)
-    x = x[torch.randperm(n, generator=g)].cuda().contiguous()
     nq = (steps + warm) * batch
-    ql = torch.randint(0, 10, (nq,), generator=g)
-    queries = (ql[:, None].float() * 100.0 + torch.randn((nq, d), generator=g) * 5.0).cuda().contiguous()
+    if n >= 100_000:  # "flat SIFT-1M" of the north star: the C2/C3 synthetic SIFT-like base
+        x, queries = sift_base_and_queries(n, d, nq, rank)
+        x = x.contiguous()
+    else:             # C1: py/create_test_hdf5.py-shaped data
+        g = torch.Generator(device="cpu"); g.manual_seed(42)
+        lab = torch.arange(n) % 10
+        x = (lab[:, None].float() * 100.0 + torch.randn((n, d), generator=g) * 5.0)
+        x = x[torch.randperm(n, generator=g)].cuda().contiguous()
+        ql = torch.randint(0, 10, (nq,), generator=g)
+        queries = (ql[:, None].float() * 100.0 + torch.randn((nq, d), generator=g) * 5.0).cuda().contiguous()
     # rows are sharded across ranks (SURVEY.md §8e flat: row-range shards); here every rank scans its shard
     lo, hi = rank * n // world, (rank + 1) * n // world
     idx = FlatIndex(ctx, None, device_ptr=x[lo:hi].data_ptr(), n=hi - lo, d=d)
@@ -247,7 +251,8 @@ def run_flat(args, ctx, rank, world, timer):
     abytes = (hi - lo) * d * 4 + batch * d * 4 + batch * k * 8
     ach = abytes / (kernel_ms / launches * 1e-3) / 1e9
     out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=1.0,
-               config={"workload": "flat brute-force L2 %dx%d f32, batch=%d, top-%d (row-sharded x%d)" % (n, d, batch, k, world),
+               config={"workload": "flat brute-force L2 %dx%d f32 (%s), batch=%d, top-%d (row-sharded x%d)"
+                                   % (n, d, "SIFT-1M-like synthetic" if n >= 100_000 else "create_test_hdf5-like", batch, k, world),
                        "n": n, "dim": d, "batch": batch, "k": k, "index": "flat"},
                roofline=dict(bound="hbm", kernel="flat_scan_kernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                              frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes, kernel_ms=kernel_ms / launches))

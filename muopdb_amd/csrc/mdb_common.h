@@ -32,8 +32,8 @@ struct mdb_ctx {
     unsigned long long* h_counters = nullptr;
     uint64_t stat_bytes_per_eval = 0, stat_bytes_per_scored = 0, stat_fixed_bytes = 0;
     // growable device scratch (never shrinks; no allocation in steady state)
-    void* scratch[8] = {nullptr};
-    size_t scratch_cap[8] = {0};
+    void* scratch[12] = {nullptr};
+    size_t scratch_cap[12] = {0};
     // optional HIP-event timing of the dominant kernel of each search call (mdb_set_profiling)
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

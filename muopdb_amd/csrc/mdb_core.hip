@@ -50,7 +50,7 @@ void mdb_ctx_release(mdb_ctx* ctx) {
     if (ctx->refs.fetch_sub(1) != 1) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 12; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);

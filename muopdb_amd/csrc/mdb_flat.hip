@@ -81,8 +81,10 @@ mdb_status stage_queries(mdb_ctx* ctx, int slot, const float* queries, size_t b,
 template <int METRIC, int QT>
 __global__ __launch_bounds__(MDB_BLOCK) void flat_scan_kernel(const float4* __restrict__ tiles, size_t n, size_t ntiles,
                                                               DistPlan p, const float* __restrict__ q, int qstride, int k,
-                                                              uint64_t* __restrict__ partial, uint32_t* __restrict__ flags) {
+                                                              uint64_t* __restrict__ partial, uint32_t* __restrict__ flags,
+                                                              const uint32_t* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (gate && *gate == 0) return;  // fallback launch of the batched path: nothing overflowed
     BlockSelect<MDB_BLOCK> sel[QT];
     const size_t sel_bytes = BlockSelect<MDB_BLOCK>::lds_bytes(k);
 #pragma unroll
@@ -127,8 +129,10 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_scan_kernel(const float4* __re
 
 // one block per query: stream `per_query` candidate keys, keep the k smallest, ascending
 __global__ __launch_bounds__(MDB_BLOCK) void merge_keys_kernel(const uint64_t* __restrict__ partial, size_t per_query,
-                                                               int k, uint64_t* __restrict__ out, uint32_t* __restrict__ counts) {
+                                                               int k, uint64_t* __restrict__ out, uint32_t* __restrict__ counts,
+                                                               const uint32_t* __restrict__ gate = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (gate && *gate == 0) return;
     BlockSelect<MDB_BLOCK> sel;
     sel.init(lds, k);
     const uint64_t* src = partial + (size_t)blockIdx.x * per_query;
@@ -175,13 +179,14 @@ mdb_status unpack_keys(mdb_ctx* ctx, const uint64_t* d_keys, size_t total, uint3
 
 template <int METRIC>
 static mdb_status launch_flat_scan(mdb_ctx* ctx, const TileView& ts, const DistPlan& p, const float* dq, int qstride,
-                                   size_t b, size_t bpad, int qt, int k, unsigned nblk, uint64_t* partial) {
+                                   size_t b, size_t bpad, int qt, int k, unsigned nblk, uint64_t* partial,
+                                   const uint32_t* gate) {
     dim3 grid(nblk, (unsigned)(bpad / qt));
     size_t lds = BlockSelect<MDB_BLOCK>::lds_bytes(k) * qt;
     const float4* tiles = (const float4*)ts.data;
 #define MDB_LAUNCH(QT)                                                                                              \
     flat_scan_kernel<METRIC, QT><<<grid, MDB_BLOCK, lds, ctx->stream>>>(tiles, ts.n, ts.ntiles, p, dq, qstride, k, \
-                                                                          partial, ctx->d_flags)
+                                                                          partial, ctx->d_flags, gate)
     if (qt == 4) MDB_LAUNCH(4);
     else if (qt == 2) MDB_LAUNCH(2);
     else MDB_LAUNCH(1);
@@ -197,7 +202,7 @@ static int flat_choose_qt(size_t b, int k) {
 }
 
 mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const float* dq, int qstride, size_t b, size_t k,
-                          uint64_t* d_keys, uint32_t* d_counts, bool profile) {
+                          uint64_t* d_keys, uint32_t* d_counts, bool profile, const uint32_t* gate) {
     if (b == 0) return MDB_OK;
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     int qt = flat_choose_qt(b, (int)k);
@@ -215,12 +220,12 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     ProfScope prof(ctx);
     ctx->prof_on = saved;
     if (metric == MDB_METRIC_L2)
-        MDB_TRY(launch_flat_scan<MDB_METRIC_L2>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial));
+        MDB_TRY(launch_flat_scan<MDB_METRIC_L2>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial, gate));
     else
-        MDB_TRY(launch_flat_scan<MDB_METRIC_DOT>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial));
+        MDB_TRY(launch_flat_scan<MDB_METRIC_DOT>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial, gate));
     }
     merge_keys_kernel<<<dim3((unsigned)b), MDB_BLOCK, BlockSelect<MDB_BLOCK>::lds_bytes((int)k), ctx->stream>>>(
-        (const uint64_t*)partial, (size_t)nblk * k, (int)k, d_keys, d_counts);
+        (const uint64_t*)partial, (size_t)nblk * k, (int)k, d_keys, d_counts, gate);
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
 }
@@ -232,6 +237,7 @@ struct mdb_flat {
     mdb_ctx* ctx;
     TileStore ts;
     int metric;
+    FlatAux aux;  // sample + centred copy for the batched (MFMA filter) path; empty for small bases
 };
 
 extern "C" {
@@ -242,7 +248,9 @@ mdb_status mdb_flat_create(mdb_ctx* ctx, const float* base, size_t n, size_t d, 
     *out = nullptr;
     std::lock_guard<std::mutex> g(ctx->mu);
     MDB_HIP(ctx, hipSetDevice(ctx->device));
-    mdb_flat* f = new mdb_flat{ctx, {}, (int)metric};
+    mdb_flat* f = new mdb_flat;
+    f->ctx = ctx;
+    f->metric = (int)metric;
     const float* d_rows = base;
     DevBuf<float> staging;
     if (base_mem == MDB_MEM_HOST && n) {
@@ -252,6 +260,7 @@ mdb_status mdb_flat_create(mdb_ctx* ctx, const float* base, size_t n, size_t d, 
         d_rows = staging.p;
     }
     mdb_status st = tiles_from_rows(ctx, d_rows, n, (int)d, f->ts);
+    if (st == MDB_OK) st = flat_build_aux(ctx, view_of(f->ts), f->aux);
     if (st == MDB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = mdb_fail(ctx, MDB_ERR_HIP, "sync failed");
     if (st != MDB_OK) { delete f; return st; }
     mdb_ctx_retain(ctx);
@@ -278,11 +287,17 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     float* dq;
     int qstride;
-    MDB_TRY(stage_queries(ctx, 0, queries, b, flat->ts.d, mem, (b + 3) / 4 * 4, &dq, &qstride));
+    const bool batched = flat_mfma_applicable(view_of(flat->ts), flat->aux, b, k);
+    const size_t bpad = batched ? (b + 63) / 64 * 64 : (b + 3) / 4 * 4;
+    MDB_TRY(stage_queries(ctx, 0, queries, b, flat->ts.d, mem, bpad, &dq, &qstride));
     void *keys, *cnts;
     MDB_TRY(mdb_scratch(ctx, 5, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4, &cnts));
-    MDB_TRY(flat_topk_keys(ctx, view_of(flat->ts), flat->metric, dq, qstride, b, k, (uint64_t*)keys, (uint32_t*)cnts, true));
+    if (batched)
+        MDB_TRY(flat_topk_keys_mfma(ctx, view_of(flat->ts), flat->aux, flat->metric, dq, qstride, b, bpad, k, (uint64_t*)keys,
+                                    (uint32_t*)cnts, true));
+    else
+        MDB_TRY(flat_topk_keys(ctx, view_of(flat->ts), flat->metric, dq, qstride, b, k, (uint64_t*)keys, (uint32_t*)cnts, true));
     // one pass = N*d*4 B read once per batch + queries + outputs
     ctx->stats = mdb_stats{};
     ctx->stats.scored_vectors = (uint64_t)b * flat->ts.n;

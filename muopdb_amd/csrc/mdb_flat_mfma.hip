@@ -1,0 +1,467 @@
+// mdb_flat_mfma.hip — batched flat scan as MFMA filter + exact refine.
+//
+// The exact kernels (mdb_flat.hip) keep the reference's lane association and therefore cannot use
+// FMAs or matrix cores: at batch >= 8 they are VALU bound (64 queries x 1M x 128: 2.8 ms against a
+// 0.1 ms HBM pass).  For batches this path computes the SAME top-k with three launches:
+//   A. exact top-k of a strided SAMPLE of the base (flat_topk_keys on ~N/32 vectors): U_m = k-th
+//      exact distance of query m in the sample, an upper bound of its k-th distance in the base;
+//   B. flat_mfma_filter_kernel: approximate q.x for all (query, vector) pairs on the matrix cores
+//      (v_mfma_f32_32x32x2_f32; the GEMM form ||q'||^2 + ||x'||^2 - 2 q'.x' on a MEAN-CENTRED copy of
+//      the base, which keeps the cancellation error small), and every pair whose approximate
+//      distance could be <= U_m, given a rigorous bound on the f32 error of both sides, is appended
+//      to query m's candidate list (typically a few hundred of a million);
+//   C. flat_refine_kernel: the exact, reference-association distance of the candidates only and the
+//      usual BlockSelect top-k, so ids AND scores are bit-identical to the exact path.
+//   D. if any list overflowed (data whose neighbour distances are below the f32 resolution of the
+//      GEMM form: far-from-origin tight clusters, duplicates), the gated exact scan + merge run for
+//      the batch — the two launches return immediately otherwise — and the index stops using this
+//      path for a while.
+// Roofline: B reads N*d*4 bytes once per 64 queries and needs 2*64*d flop per 4*d bytes = 32 flop/B:
+// the ridge of 155 TF f32-MFMA vs ~5 TB/s HBM, i.e. both HBM- and MFMA-bound at batch 64.
+#include <algorithm>
+#include <cmath>
+
+#include "mdb_common.h"
+#include "mdb_device.cuh"
+#include "mdb_kernels.h"
+
+#define MF_CAP 4096  // candidates refined per query (more => the batch falls back to the exact scan)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------ aux store
+// every `stride`-th FULL tile of the source store, copied tile by tile (ids are irrelevant: only the
+// k-th distance of the sample is used)
+__global__ void sample_tiles_kernel(const float4* __restrict__ src, int d4, size_t stride, size_t total4,
+                                    float4* __restrict__ dst) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    size_t per_tile = (size_t)d4 * MDB_TILE;
+    size_t st = t / per_tile, r = t % per_tile;
+    dst[t] = src[st * stride * per_tile + r];
+}
+
+// per-dimension mean of the sample (any centre is valid; the sample's is close to the base's)
+__global__ __launch_bounds__(256) void column_mean_kernel(const float4* __restrict__ tiles, size_t ntiles, int d4,
+                                                         float* __restrict__ mean) {
+    __shared__ double red[256][4];
+    const int c4 = blockIdx.x;
+    double s[4] = {0, 0, 0, 0};
+    for (size_t i = threadIdx.x; i < ntiles * MDB_TILE; i += 256) {
+        float4 f = tiles[((i / MDB_TILE) * d4 + c4) * MDB_TILE + (i % MDB_TILE)];
+        s[0] += f.x; s[1] += f.y; s[2] += f.z; s[3] += f.w;
+    }
+    for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = s[j];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int j = 0; j < 4; ++j) red[threadIdx.x][j] += red[threadIdx.x + o][j];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        double m = red[0][threadIdx.x] / (double)(ntiles * MDB_TILE);
+        mean[c4 * 4 + threadIdx.x] = (m == m && fabs(m) < 1e30) ? (float)m : 0.0f;
+    }
+}
+
+__global__ void centre_tiles_kernel(const float4* __restrict__ src, size_t total4, int d4, const float4* __restrict__ mean4,
+                                    float4* __restrict__ dst) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    float4 f = src[t], m = mean4[(t / MDB_TILE) % d4];
+    dst[t] = make_float4(f.x - m.x, f.y - m.y, f.z - m.z, f.w - m.w);  // padding dims have mean 0 and stay 0
+}
+
+FlatAux::~FlatAux() {
+    if (h_ovf) (void)hipHostFree(h_ovf);
+}
+
+mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux) {
+    size_t full = v.n / MDB_TILE;
+    if (full < 1024) return MDB_OK;  // < 64K vectors: the exact path is used
+    size_t want = std::min<size_t>(std::max<size_t>(full / 32, 256), 1024);  // 16K .. 64K vectors
+    size_t stride = full / want;
+    size_t stiles = (full - 1) / stride + 1;
+    TileStore& out = aux.sample;
+    out.d = v.d;
+    out.d4 = v.d4;
+    out.ntiles = stiles;
+    out.n = stiles * MDB_TILE;
+    size_t total4 = stiles * MDB_TILE * (size_t)v.d4;
+    if (out.data.alloc(total4 * 4 + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "sample store alloc");
+    sample_tiles_kernel<<<dim3((unsigned)((total4 + 255) / 256)), 256, 0, ctx->stream>>>((const float4*)v.data, v.d4, stride, total4,
+                                                                                         (float4*)out.data.p);
+    MDB_HIP(ctx, hipGetLastError());
+    size_t all4 = v.ntiles * MDB_TILE * (size_t)v.d4;
+    if (aux.mean.alloc((size_t)v.d4 * 4) != hipSuccess || aux.ctiles.alloc(all4 * 4 + 4) != hipSuccess)
+        return mdb_fail(ctx, MDB_ERR_OOM, "centred store alloc (%zu floats)", all4 * 4);
+    column_mean_kernel<<<dim3((unsigned)v.d4), 256, 0, ctx->stream>>>((const float4*)out.data.p, stiles, v.d4, aux.mean.p);
+    centre_tiles_kernel<<<dim3((unsigned)((all4 + 255) / 256)), 256, 0, ctx->stream>>>((const float4*)v.data, all4, v.d4,
+                                                                                       (const float4*)aux.mean.p, (float4*)aux.ctiles.p);
+    MDB_HIP(ctx, hipGetLastError());
+    if (!aux.h_ovf) {
+        MDB_HIP(ctx, hipHostMalloc((void**)&aux.h_ovf, 4));
+        *aux.h_ovf = 0;
+    }
+    return MDB_OK;
+}
+
+// ------------------------------------------------------------------------------------------ prep
+// one block per (padded) query row: centred query q' = q - mean into dqc, and the admission constant
+// crow[m]: the filter admits (m, x) iff  acc(q'_m.x') >= xh(x') + crow[m]   
+//   L2 : ||q-x||^2 = qn + xn - 2 q'.x' <= T0 + kappa (qn + xn), T0 = (k-th sample distance)^2 rounded up
+//        <=> q'.x' >= xn (1 - kappa)/2 + (qn (1 - kappa) - T0)/2           [xh uses 0.5 - kappa: looser]
+//   dot: the centred form does not apply (a dot product is not translation invariant): mean == 0 is
+//        passed and  -q.x <= U + kappa (qn + xn)/2  <=>  q.x >= -kappa xn + (-U - kappa qn / 2)
+__global__ __launch_bounds__(128) void mfma_prep_kernel(const float* __restrict__ dq, int qstride, int d,
+                                                        const float* __restrict__ mean, const uint64_t* __restrict__ skeys,
+                                                        const uint32_t* __restrict__ scounts, int k, float kappa, int metric,
+                                                        size_t b, float* __restrict__ dqc, float* __restrict__ crow) {
+    __shared__ float red[128];
+    const size_t m = blockIdx.x;
+    const float* q = dq + m * qstride;
+    float* qc = dqc + m * qstride;
+    float part = 0.0f;
+    for (int e = threadIdx.x; e < qstride; e += 128) {
+        float v = (m < b && e < d) ? q[e] - (metric == MDB_METRIC_L2 ? mean[e] : 0.0f) : 0.0f;
+        qc[e] = v;
+        part = fmaf(v, v, part);
+    }
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x) return;
+    float qn = red[0];
+    float c = __uint_as_float(0x7F800000u);  // +inf: padded rows never admit anything
+    if (m < b) {
+        if (scounts[m] < (uint32_t)k || !(qn < __uint_as_float(0x7F800000u))) {
+            c = -__uint_as_float(0x7F800000u);  // no bound: everything is a candidate (-> overflow -> exact scan)
+        } else {
+            float u = key_dist(skeys[m * (size_t)k + (k - 1)]);
+            if (metric == MDB_METRIC_L2) {
+                float t0 = u * u * (1.0f + 2e-6f);
+                c = (qn * (1.0f - kappa) - t0) * 0.5f;
+            } else {
+                c = -u - kappa * qn * 0.5f;
+            }
+            c -= fabsf(c) * 4e-6f + 1e-30f;  // round the admission bound down
+        }
+    }
+    crow[m] = c;
+}
+
+// ------------------------------------------------------------------------------------------ filter
+// grid (nblk, query groups of BQ = 32*QB); 256 threads: every wave owns whole 64-vector tiles.
+// A operand = queries (row i = lane&31, k = lane>>5) from the LDS copy of the group's centred queries
+// (dimension-major); B operand = vectors (k = lane>>5, column j = lane&31): the tile store gives lane
+// v the float4 (x,y,z,w) of vector v, and v_permlane32_swap(x, y) turns the pair into
+//   lo lanes: vector l, dim 4c     | hi lanes: vector l-32, dim 4c+1     -> B for vectors  0..31
+//   lo lanes: vector l+32, dim 4c  | hi lanes: vector l,    dim 4c+1     -> B for vectors 32..63
+// D[i][j]: 16 accumulators per lane, column j = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Loads run one chunk of MF_CH float4s ahead of the matrix cores (register double buffer, also
+// across tile boundaries), so HBM latency hides behind 4*QB*MF_CH MFMAs of 64 cycles.
+#define MF_CH 8
+#define MF_LBUF 2048  // candidate pairs staged per block
+template <int METRIC, int QB>
+__global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* __restrict__ tiles, size_t n, size_t ntiles, int d4,
+                                                                  const float* __restrict__ dqc, int qstride,
+                                                                  const float* __restrict__ crow, float kappa,
+                                                                  uint64_t* __restrict__ pairs, uint32_t* __restrict__ npairs,
+                                                                  uint32_t pair_cap, size_t b, uint32_t* __restrict__ flags) {
+    constexpr int BQ = 32 * QB, BQP = BQ + 1;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* Qs = (float*)lds;                      // [nch*MF_CH*4][BQP], zero beyond d4*4
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const size_t q0 = (size_t)blockIdx.y * BQ;
+    const int nch = (d4 + MF_CH - 1) / MF_CH, dpad = d4 * 4, dlds = nch * MF_CH * 4;
+    float* Cr = Qs + (size_t)dlds * BQP;          // [BQ] admission constants of the group
+    // candidate (query, vector) pairs are staged in LDS and appended to the global list with ONE atomic
+    // per block: device-scope atomics on one line serialise (20k of them cost 1 ms here)
+    uint64_t* lbuf = (uint64_t*)(Cr + BQ + (BQ & 1));  // [MF_LBUF]
+    uint32_t* lcnt = (uint32_t*)(lbuf + MF_LBUF);
+    if (tid == 0) lcnt[0] = 0;
+    for (int i = tid; i < BQ * dlds; i += 256) {
+        int q = i / dlds, e = i % dlds;
+        Qs[e * BQP + q] = e < dpad ? dqc[(q0 + q) * qstride + e] : 0.0f;
+    }
+    if (tid < BQ) Cr[tid] = crow[q0 + tid];
+    __syncthreads();
+    bool nan_seen = false;
+    const size_t tstep = (size_t)gridDim.x * 4;
+    size_t tile = (size_t)blockIdx.x * 4 + wave;
+    f32x16 acc[2][QB];
+    float xn = 0.0f;
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][qb][r] = 0.0f;
+        xn = 0.0f;
+    };
+    // branch-free chunk load: float4s past d4 re-read the last one (their query rows in LDS are zero,
+    // and they are excluded from the norm by `live`)
+    auto load_chunk = [&](float4 (&dst)[MF_CH], size_t t, int ch) {
+        const float4* tp = tiles + t * (size_t)d4 * MDB_TILE + lane;
+#pragma unroll
+        for (int x = 0; x < MF_CH; ++x) dst[x] = tp[(size_t)min(ch * MF_CH + x, d4 - 1) * MDB_TILE];
+    };
+    auto compute_chunk = [&](const float4 (&cur)[MF_CH], int ch) {
+#pragma unroll
+        for (int x = 0; x < MF_CH; ++x) {
+            const int c = ch * MF_CH + x;
+            const float4 f = cur[x];
+            const float live = c < d4 ? 1.0f : 0.0f;
+            xn = fmaf(f.x * live, f.x, xn);
+            xn = fmaf(f.y * live, f.y, xn);
+            xn = fmaf(f.z * live, f.z, xn);
+            xn = fmaf(f.w * live, f.w, xn);
+            auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(f.x), __float_as_uint(f.y), false, false);
+            auto s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(f.z), __float_as_uint(f.w), false, false);
+            const float b0lo = __uint_as_float(s01[0]), b0hi = __uint_as_float(s01[1]);
+            const float b1lo = __uint_as_float(s23[0]), b1hi = __uint_as_float(s23[1]);
+            const float* qa = Qs + (4 * c + hi) * BQP + l31;  // dims (4c, 4c+1) by lane half
+            const float* qc = qa + 2 * BQP;                    // dims (4c+2, 4c+3)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float a0 = qa[qb * 32], a1 = qc[qb * 32];
+                acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0lo, acc[0][qb], 0, 0, 0);
+                acc[1][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0hi, acc[1][qb], 0, 0, 0);
+                acc[0][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1lo, acc[0][qb], 0, 0, 0);
+                acc[1][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1hi, acc[1][qb], 0, 0, 0);
+            }
+        }
+    };
+    auto epilogue = [&](size_t t) {
+        if (xn != xn) nan_seen = true;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float xnh = __shfl(xn, l31 + 32 * h);  // norm of this lane's column
+            const size_t v = t * MDB_TILE + 32 * h + l31;
+            // admission offset of the vector; an infinite norm admits the vector for every query
+            const float xh = METRIC == MDB_METRIC_L2 ? xnh * (0.5f - kappa) : -kappa * xnh;
+            const bool force = !(xnh < __uint_as_float(0x7F800000u));
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) any |= (acc[h][qb][r] >= xh + Cr[qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
+                any = (any || force) && v < n;
+                if (__ballot(any)) {  // rare
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (v < n && (force || acc[h][qb][r] >= xh + Cr[row])) {
+                            size_t m = q0 + row;
+                            if (m < b) {
+                                const uint64_t pr = ((uint64_t)m << 32) | (uint32_t)v;
+                                uint32_t pos = atomicAdd(lcnt, 1u);
+                                if (pos < MF_LBUF) lbuf[pos] = pr;
+                                else if (__builtin_nontemporal_load(npairs) <= pair_cap) {  // staging full: slow direct append
+                                    uint32_t g = atomicAdd(npairs, 1u);
+                                    if (g < pair_cap) pairs[g] = pr;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // one flat sequence of chunks over this wave's tiles, two per iteration (static buffer roles)
+    float4 buf0[MF_CH], buf1[MF_CH];
+    zero_acc();
+    if (tile < ntiles) load_chunk(buf0, tile, 0);
+    int ch = 0;
+    auto step = [&](float4 (&cur)[MF_CH], float4 (&nxt)[MF_CH]) {
+        // prefetch the chunk after (tile, ch) — possibly the next tile's first — then consume (tile, ch)
+        const bool last = ch + 1 == nch;
+        const size_t ntile = last ? tile + tstep : tile;
+        const int nchk = last ? 0 : ch + 1;
+        load_chunk(nxt, ntile < ntiles ? ntile : tile, nchk);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (the scheduler sinks it otherwise)
+        compute_chunk(cur, ch);
+        __builtin_amdgcn_sched_barrier(0);
+        if (last) {
+            epilogue(tile);
+            zero_acc();
+        }
+        tile = ntile;
+        ch = nchk;
+    };
+    while (tile < ntiles) {
+        step(buf0, buf1);
+        if (tile >= ntiles) break;
+        step(buf1, buf0);
+    }
+    if (nan_seen) atomicOr(flags, MDB_FLAG_NAN);
+    __syncthreads();
+    const uint32_t ln = min(lcnt[0], (uint32_t)MF_LBUF);
+    if (ln) {
+        if (tid == 0) lcnt[1] = atomicAdd(npairs, ln);
+        __syncthreads();
+        const uint32_t base = lcnt[1];
+        for (uint32_t i = tid; i < ln; i += 256)
+            if (base + i < pair_cap) pairs[base + i] = lbuf[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ refine
+// one block per query: collect the query's vectors from the pair list (LDS), then their exact distances.
+// A list longer than its capacity raises `ovf` instead (-> gated exact scan of the batch).
+template <int METRIC>
+__global__ __launch_bounds__(MDB_BLOCK) void flat_refine_kernel(const float4* __restrict__ tiles, DistPlan p,
+                                                                const float* __restrict__ dq, int qstride,
+                                                                const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ npairs,
+                                                                uint32_t pair_cap, int k, uint64_t* __restrict__ keys,
+                                                                uint32_t* __restrict__ counts, uint32_t* __restrict__ ovf,
+                                                                uint32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const size_t m = blockIdx.x;
+    const uint32_t np = *npairs;
+    if (np > pair_cap) {
+        if (threadIdx.x == 0 && m == 0) atomicAdd(ovf, 1u);
+        return;
+    }
+    BlockSelect<MDB_BLOCK> sel;
+    sel.init(lds, k);
+    uint32_t* mine = (uint32_t*)(lds + ((BlockSelect<MDB_BLOCK>::lds_bytes(k) + 15) & ~(size_t)15));  // [MF_CAP]
+    uint32_t* mcnt = mine + MF_CAP;
+    if (threadIdx.x == 0) *mcnt = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < np; i += MDB_BLOCK) {
+        uint64_t pr = pairs[i];
+        if ((uint32_t)(pr >> 32) == (uint32_t)m) {
+            uint32_t pos = atomicAdd(mcnt, 1u);
+            if (pos < MF_CAP) mine[pos] = (uint32_t)pr;
+        }
+    }
+    __syncthreads();
+    const uint32_t c = *mcnt;
+    if (c > MF_CAP) {
+        if (threadIdx.x == 0) atomicAdd(ovf, 1u);
+        return;
+    }
+    const float* qb = dq + m * qstride;
+    bool nan_seen = false, first = true;
+    for (uint32_t base = 0; base < c; base += MDB_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        uint64_t key = MDB_KEY_MAX;
+        if (i < c) {
+            uint32_t v = mine[i];
+            TileLoader ld{tiles + (size_t)(v / MDB_TILE) * p.d4 * MDB_TILE + (v % MDB_TILE)};
+            float raw[1];
+            exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
+            float dist = finish_distance<METRIC>(raw[0]);
+            if (dist != dist) nan_seen = true;
+            key = make_key(dist, v);
+        }
+        if (first) { sel.warm_start(key); first = false; }
+        sel.offer(key);
+        sel.round_end();
+    }
+    if (nan_seen) atomicOr(flags, MDB_FLAG_NAN);
+    sel.finish();
+    uint32_t cc = sel.count();
+    for (int j = threadIdx.x; j < k; j += MDB_BLOCK) keys[m * (size_t)k + j] = j < (int)cc ? sel.buf[j] : MDB_KEY_MAX;
+    if (threadIdx.x == 0 && counts) counts[m] = cc;
+}
+
+// ------------------------------------------------------------------------------------------ host
+bool flat_mfma_applicable(const TileView& ts, FlatAux& aux, size_t b, size_t k) {
+    if (getenv("MDB_FLAT_NO_MFMA")) return false;
+    if (aux.sample.n == 0 || b < 8 || k == 0) return false;
+    if (k * 4 > aux.sample.n) return false;
+    double expect = (double)k * (double)ts.n / (double)aux.sample.n;  // candidates per query
+    if (expect > MF_CAP / 4) return false;
+    // the group's queries live in LDS: d4*4 x 33 floats (QB = 1) must fit
+    if ((size_t)(ts.d4 + 8) * 4 * 33 * 4 > 150 * 1024) return false;
+    // the previous batches' overflow count arrives asynchronously: data below the filter's resolution
+    // sends the index back to the exact kernels for a while
+    if (aux.h_ovf && *aux.h_ovf) {
+        *aux.h_ovf = 0;
+        aux.cooldown = 256;
+    }
+    if (aux.cooldown > 0) {
+        --aux.cooldown;
+        return false;
+    }
+    return true;
+}
+
+mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, int metric, const float* dq, int qstride, size_t b,
+                               size_t bpad, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile) {
+    // queries are staged with bpad rows; the filter reads groups of BQ rows, so bpad must cover them
+    const int QB = ((size_t)(ts.d4 + MF_CH) * 4 * 65 * 4 <= 64 * 1024 && b > 32) ? 2 : 1;
+    const size_t BQ = 32 * QB, groups = (b + BQ - 1) / BQ, bpadq = groups * BQ;
+    if (bpadq > bpad) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "internal: queries staged with %zu rows, filter needs %zu", bpad, bpadq);
+    char* ax;
+    size_t off_sc = align_up(b * k * 8, 16), off_cr = off_sc + align_up(b * 4, 16), off_np = off_cr + align_up(bpadq * 4, 256),
+           off_ov = off_np + 256, off_qc = off_ov + 256;
+    MDB_TRY(mdb_scratch(ctx, 8, off_qc + bpadq * (size_t)qstride * 4, (void**)&ax));
+    uint64_t* skeys = (uint64_t*)ax;
+    uint32_t* scounts = (uint32_t*)(ax + off_sc);
+    float* crow = (float*)(ax + off_cr);
+    uint32_t* npairs = (uint32_t*)(ax + off_np);  // own 256-byte lines: these two words take device-scope atomics
+    uint32_t* ovf = (uint32_t*)(ax + off_ov);
+    float* dqc = (float*)(ax + off_qc);
+    const uint32_t pair_cap = (uint32_t)std::min<size_t>(b * 1024, 1u << 24);
+    uint64_t* pairs;
+    MDB_TRY(mdb_scratch(ctx, 9, (size_t)pair_cap * 8, (void**)&pairs));
+    // A. sample top-k (exact)
+    MDB_TRY(flat_topk_keys(ctx, view_of(aux.sample), metric, dq, qstride, b, k, skeys, scounts, false));
+    // error budget of the filter: |fl(q'.x') - q'.x'| <= d eps |q'||x'| <= d eps (qn + xn)/2, the same for each
+    // norm, the reference association's own d eps ||q-x||^2 <= 2 d eps (qn + xn), and the rounding of the
+    // centring itself (eps per component): below 4 d eps (qn + xn) in total.
+    const float kappa = 4.0f * (float)(ts.d4 * 4 + 4) * 5.9604645e-8f;
+    MDB_HIP(ctx, hipMemsetAsync(npairs, 0, 512, ctx->stream));  // npairs and ovf
+    mfma_prep_kernel<<<dim3((unsigned)bpadq), 128, 0, ctx->stream>>>(dq, qstride, ts.d, aux.mean.p, skeys, scounts, (int)k, kappa,
+                                                                    metric, b, dqc, crow);
+    // B. filter on the centred copy (L2) / the base itself (dot)
+    const float4* ftiles = (metric == MDB_METRIC_L2) ? (const float4*)aux.ctiles.p : (const float4*)ts.data;
+    {
+        bool saved = ctx->prof_on;
+        ctx->prof_on = saved && profile;
+        ProfScope prof(ctx);
+        ctx->prof_on = saved;
+        unsigned nblk = (unsigned)std::min<size_t>((ts.ntiles + 3) / 4, groups >= 4 ? 256 : 512);
+        dim3 grid(nblk, (unsigned)groups);
+        size_t lds = (size_t)((ts.d4 + MF_CH - 1) / MF_CH * MF_CH) * 4 * (BQ + 1) * 4 + (BQ + 2) * 4 + MF_LBUF * 8 + 16;
+#define MF_LAUNCH(METRIC, QBT)                                                                                       \
+    do {                                                                                                             \
+        if (lds > 48 * 1024)                                                                                         \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_mfma_filter_kernel<METRIC, QBT>,                      \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+        flat_mfma_filter_kernel<METRIC, QBT><<<grid, 256, lds, ctx->stream>>>(ftiles, ts.n, ts.ntiles, ts.d4, dqc, qstride, crow,    \
+                                                                              kappa, pairs, npairs, pair_cap, b, ctx->d_flags);                    \
+    } while (0)
+        if (metric == MDB_METRIC_L2) { if (QB == 2) MF_LAUNCH(MDB_METRIC_L2, 2); else MF_LAUNCH(MDB_METRIC_L2, 1); }
+        else { if (QB == 2) MF_LAUNCH(MDB_METRIC_DOT, 2); else MF_LAUNCH(MDB_METRIC_DOT, 1); }
+#undef MF_LAUNCH
+        MDB_HIP(ctx, hipGetLastError());
+    }
+    // C. refine
+    DistPlan p = make_plan(ts.d, metric);
+    size_t sel_lds = ((BlockSelect<MDB_BLOCK>::lds_bytes((int)k) + 15) & ~(size_t)15) + MF_CAP * 4 + 16;
+    if (metric == MDB_METRIC_L2)
+        flat_refine_kernel<MDB_METRIC_L2><<<dim3((unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(
+            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)k, d_keys, d_counts, ovf, ctx->d_flags);
+    else
+        flat_refine_kernel<MDB_METRIC_DOT><<<dim3((unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(
+            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)k, d_keys, d_counts, ovf, ctx->d_flags);
+    MDB_HIP(ctx, hipGetLastError());
+    if (getenv("MDB_MF_DBG")) {
+        uint32_t hn = 0, ho = 0;
+        MDB_HIP(ctx, hipMemcpyAsync(&hn, npairs, 4, hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP(ctx, hipMemcpyAsync(&ho, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[mf] b=%zu QB=%d candidate pairs %u (%.1f per query) overflowed %u\n", b, QB, hn, (double)hn / b, ho);
+    }
+    // D. gated exact scan of the batch: both launches return at once unless a list overflowed
+    MDB_TRY(flat_topk_keys(ctx, ts, metric, dq, qstride, b, k, d_keys, d_counts, false, ovf));
+    MDB_HIP(ctx, hipMemcpyAsync(aux.h_ovf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+    return MDB_OK;
+}

@@ -14,8 +14,29 @@ mdb_status tiles_from_rows(mdb_ctx* ctx, const float* d_rows, size_t n, int d, T
 mdb_status stage_queries(mdb_ctx* ctx, int slot, const float* queries, size_t b, int d, mdb_mem mem, size_t bpad,
                          float** d_out, int* qstride);
 // flat exact top-k of every query against a TileStore: keys (distance,row) ascending into d_keys [b][k]
+// gate (device word, optional): both launches return immediately while *gate == 0
 mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const float* d_queries_padded, int qstride,
-                          size_t b, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false);
+                          size_t b, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false,
+                          const uint32_t* gate = nullptr);
+
+// ---- mdb_flat_mfma.hip: batched flat scan = exact top-k of a strided sample + MFMA filter + exact refine
+// (same keys as flat_topk_keys, bit for bit).  FlatAux is built once per store by flat_build_aux (stays
+// empty for small stores); queries must be staged with bpad >= b rounded up to 64 rows.
+struct FlatAux {
+    TileStore sample;        // every stride-th tile: its exact k-th distance bounds the base's
+    DevBuf<float> ctiles;    // mean-centred copy of the base in the same tile layout (L2 filter operand)
+    DevBuf<float> mean;      // [d4*4]
+    uint32_t* h_ovf = nullptr;  // pinned: candidate-list overflows of the last batch (read one call late)
+    int cooldown = 0;        // batches left on the exact kernels after an overflow
+    FlatAux() = default;
+    FlatAux(const FlatAux&) = delete;
+    FlatAux& operator=(const FlatAux&) = delete;
+    ~FlatAux();
+};
+mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux);
+bool flat_mfma_applicable(const TileView& ts, FlatAux& aux, size_t b, size_t k);
+mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, int metric, const float* dq, int qstride, size_t b,
+                               size_t bpad, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false);
 
 // k smallest of `per_query` candidate keys per query (one block per query), ascending
 mdb_status merge_keys(mdb_ctx* ctx, const uint64_t* d_partial, size_t per_query, size_t b, size_t k, uint64_t* d_out,

@@ -158,6 +158,48 @@ def test_flat_c1_dataset_and_ties(ctx, oracle):
     assert ids2[0, :4].tolist() == [0, 1, 2, 3]
 
 
+@pytest.mark.parametrize("n,d,b,k,metric,kind", [
+    (100_000, 128, 40, 10, 0, "sift"), (100_000, 128, 100, 10, 1, "gauss"), (70_000, 30, 17, 5, 0, "gauss"),
+    (66_000, 768, 33, 10, 0, "unit"), (80_000, 4, 64, 3, 0, "ramp"), (70_000, 16, 9, 10, 0, "same"),
+    (130_000, 64, 8, 40, 1, "sift")])
+def test_flat_batched_mfma_filter_equals_exact(ctx, oracle, n, d, b, k, metric, kind):
+    """Batched flat path (sample top-k -> MFMA filter -> exact refine, mdb_flat_mfma.hip): ids and
+    scores must be bit-identical to the exact kernel's and to the oracle's, including on data that
+    defeats the sample bound (a ramp sorted by distance, all-identical rows -> overflow rescan)."""
+    import os
+    from muopdb_amd.index import FlatIndex
+    rng = np.random.default_rng(n + d + b)
+    if kind == "sift":
+        base = H.sift_like(n, d, n_clusters=50, seed=n)
+        q = (base[rng.integers(0, n, b)] + rng.normal(0, 10, (b, d))).astype(np.float32)
+    elif kind == "gauss":
+        base = rng.standard_normal((n, d)).astype(np.float32)
+        q = rng.standard_normal((b, d)).astype(np.float32)
+    elif kind == "unit":
+        base = rng.standard_normal((n, d)).astype(np.float32)
+        base /= np.linalg.norm(base, axis=1, keepdims=True)
+        q = base[rng.integers(0, n, b)] + rng.normal(0, 0.01, (b, d)).astype(np.float32)
+    elif kind == "ramp":  # spann/index.rs test data: row i = [i,i,i,i]
+        base = np.repeat(np.arange(n, dtype=np.float32)[:, None], d, 1)
+        q = np.repeat(rng.uniform(0, n, (b, 1)).astype(np.float32), d, 1) + np.float32(0.4)
+    else:
+        base = np.ones((n, d), np.float32)
+        q = rng.standard_normal((b, d)).astype(np.float32)
+    q = q.astype(np.float32)
+    idx = FlatIndex(ctx, base, metric)
+    ids, dist, counts = idx.search(q, k)
+    os.environ["MDB_FLAT_NO_MFMA"] = "1"
+    try:
+        eids, edist, ecounts = idx.search(q, k)
+    finally:
+        del os.environ["MDB_FLAT_NO_MFMA"]
+    assert np.array_equal(ids, eids) and np.array_equal(counts, ecounts)
+    assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    oids, odist = oracle.flat_topk(metric, base, q[:8], k)
+    assert np.array_equal(ids[:8], oids)
+    assert_scores(dist[:8], odist)
+
+
 def test_flat_nan_is_an_error(ctx):
     from muopdb_amd.index import FlatIndex
     from muopdb_amd import lib as L
