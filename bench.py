@@ -78,6 +78,7 @@ def parse():
     p.add_argument("--users", type=int, default=128, help="spann workload: number of users (1024 = full C4)")
     p.add_argument("--max-neighbors", type=int, default=32)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--streams", type=int, default=4, help="hnsw: extra measurement with this many batches in flight (0/1 = skip)")
     p.add_argument("--dump-dir", default=None, help="write index files + queries for examples/replay_search.cpp")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
@@ -188,6 +189,39 @@ def run_hnsw(args, ctx, rank, world, timer):
     )
     out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS if out["roofline"]["achieved"] else None
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("hnsw", out["config"])
+    if args.streams > 1:
+        # Extra, NOT the headline: the same K batches issued round-robin on several HIP streams (one context +
+        # index handle each), i.e. several batches of 64 in flight.  One batch occupies 64 of the 256 CUs for
+        # its whole latency-bound traversal, so a serving process overlaps batches to fill the chip.
+        from muopdb_amd import lib as L
+        lanes = []
+        for _ in range(args.streams):
+            st_ = torch.cuda.Stream()
+            c_ = L.Context(torch.cuda.current_device()); c_.set_stream(st_.cuda_stream)
+            lanes.append((st_, c_, BlockBasedHnsw(c_, index_bytes, vec_bytes, d), torch.zeros_like(ids), torch.zeros_like(sc),
+                          torch.zeros_like(cn)))
+        torch.cuda.synchronize()
+
+        def cstep(i):
+            _, _, h_, i_, s_, c_n = lanes[i % len(lanes)]
+            q = queries[i * batch:(i + 1) * batch]
+            h_.ann_search_device(q.data_ptr(), batch, k, ef, i_.data_ptr(), s_.data_ptr(), c_n.data_ptr())
+
+        for i in range(warm):
+            cstep(i)
+        timer.barrier()
+        t0 = time.perf_counter()
+        for i in range(warm, warm + steps):
+            cstep(i)
+        timer.barrier()
+        el = timer.max_over_ranks(time.perf_counter() - t0)
+        same = True
+        for j, i in enumerate(range(warm + steps - len(lanes), warm + steps)):  # last batch of every lane vs the serial run
+            same &= bool(torch.equal(lanes[i % len(lanes)][3][:, :, 0].cpu(), torch.from_numpy(found[(i - warm) * batch:(i - warm + 1) * batch])))
+        out["concurrent"] = dict(streams=args.streams, value=world * steps * batch / el, ms_per_step=1000 * el / steps,
+                                 ids_equal_serial=same, note="same batches, several in flight; not the headline value")
+        for lane_ in lanes:
+            lane_[2].close(); lane_[1].close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         o = oracle.BlockBasedHnsw(index_bytes, vec_bytes, d)
@@ -250,12 +284,27 @@ def run_flat(args, ctx, rank, world, timer):
     kernel_ms, launches = ctx.get_profile(); ctx.set_profiling(False)
     abytes = (hi - lo) * d * 4 + batch * d * 4 + batch * k * 8
     ach = abytes / (kernel_ms / launches * 1e-3) / 1e9
-    out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=1.0,
+    # recall@k of the last timed batch against the f64 brute force (untimed re-run of that batch)
+    from muopdb_amd import build as B
+    last = warm + steps - 1
+    step(last)
+    gt, _ = B.exact_knn(x[lo:hi], k, queries=queries[last * batch:(last + 1) * batch], f64=True)
+    rec = recall_at_k(ids.cpu().numpy().astype(np.int64), gt.cpu().numpy(), k)
+    batched = batch >= 8 and (hi - lo) >= 65536  # mdb_flat_mfma.hip: sample bound + MFMA filter + exact refine
+    out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec,
                config={"workload": "flat brute-force L2 %dx%d f32 (%s), batch=%d, top-%d (row-sharded x%d)"
                                    % (n, d, "SIFT-1M-like synthetic" if n >= 100_000 else "create_test_hdf5-like", batch, k, world),
                        "n": n, "dim": d, "batch": batch, "k": k, "index": "flat"},
-               roofline=dict(bound="hbm", kernel="flat_scan_kernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes, kernel_ms=kernel_ms / launches))
+               roofline=dict(bound="hbm", kernel="flat_mfma_filter_kernel" if batched else "flat_scan_kernel", achieved=ach,
+                             peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes,
+                             kernel_ms=kernel_ms / launches))
+    if batched:  # the filter is also on the f32-MFMA ridge: 2*B*N*d flop per launch against 157.3 TFLOP/s
+        groups = (batch + 63) // 64
+        out["roofline"]["bytes_per_launch"] = abytes * groups  # one pass over the base per 64 queries
+        out["roofline"]["achieved"] = ach * groups
+        out["roofline"]["frac"] = ach * groups / HBM_PEAK_GBS
+        out["roofline"]["mfma_tflops"] = 2.0 * batch * (hi - lo) * d / (kernel_ms / launches * 1e-3) / 1e12
+        out["roofline"]["mfma_frac_of_f32_peak"] = out["roofline"]["mfma_tflops"] / 157.3
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("flat", out["config"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
@@ -412,7 +461,7 @@ def run_spann(args, ctx, rank, world, timer):
 
     for i in range(warm):
         step(i)
-    ctx.sync(); ctx.set_profiling(True); ctx.get_profile()
+    ctx.sync(); ctx.set_profiling(1); ctx.get_profile()  # 1: posting-list scan only
     timer.barrier()
     t0 = time.perf_counter()
     for i in range(warm, warm + steps):
@@ -421,9 +470,11 @@ def run_spann(args, ctx, rank, world, timer):
     elapsed = timer.max_over_ranks(time.perf_counter() - t0)
     kernel_ms, launches = ctx.get_profile(); ctx.set_profiling(False)
     found, scored, abytes = [], 0, 0
+    ctx.set_profiling(2); ctx.get_profile()  # untimed re-run: centroid-graph traversal kernel time
     for i in range(warm, warm + steps):
         step(i, found)
         st = ctx.stats(); scored += st["scored_vectors"]; abytes += st["algorithmic_bytes"]
+    hnsw_ms, hnsw_launches = ctx.get_profile(); ctx.set_profiling(False)
     found = torch.cat(found).cpu().numpy()
     # exact per-user ground truth (f64) for recall
     hits = 0
@@ -443,7 +494,8 @@ def run_spann(args, ctx, rank, world, timer):
                        "users": U, "n": U * per, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "multi-spann"},
                roofline=dict(bound="hbm", kernel="ivf_scan_f32_kernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                              frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes / steps,
-                             kernel_ms=kernel_ms / launches, scored_per_query=scored / (steps * batch)))
+                             kernel_ms=kernel_ms / launches, scored_per_query=scored / (steps * batch),
+                             centroid_hnsw_kernel_ms=hnsw_ms / max(hnsw_launches, 1)))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         o = oracle.MultiSpannIndex(cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])

@@ -120,6 +120,7 @@ const char* mdb_version(void);
  * kernel (flat scan / posting-list scan / HNSW traversal) with HIP events on the context's
  * stream.  mdb_get_profile synchronises, returns the summed kernel time and the number of
  * bracketed launches since the last call, and resets the accumulators. */
+/* on: 0 = off, 1 = scan kernels only (flat / posting-list / MFMA filter), 2 = HNSW traversal only, 3 = both */
 mdb_status mdb_set_profiling(mdb_ctx* ctx, int on);
 mdb_status mdb_get_profile(mdb_ctx* ctx, double* kernel_ms_out, uint64_t* launches_out);
 

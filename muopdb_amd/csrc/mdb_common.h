@@ -36,6 +36,7 @@ struct mdb_ctx {
     size_t scratch_cap[12] = {0};
     // optional HIP-event timing of the dominant kernel of each search call (mdb_set_profiling)
     bool prof_on = false;
+    int prof_mask = 3;   // MDB_PROF_SCAN | MDB_PROF_HNSW: which kernel classes are bracketed
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
     std::mutex mu;
@@ -50,8 +51,8 @@ void mdb_ctx_release(mdb_ctx* ctx);
 struct ProfScope {
     mdb_ctx* c;
     hipEvent_t stop = nullptr;
-    explicit ProfScope(mdb_ctx* ctx) : c(ctx) {
-        if (!c->prof_on) return;
+    explicit ProfScope(mdb_ctx* ctx, int cls = 1) : c(ctx) {
+        if (!c->prof_on || !(c->prof_mask & cls)) return;
         if (c->prof_used == c->prof_events.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;

@@ -112,6 +112,7 @@ mdb_status mdb_sync(mdb_ctx* ctx) {
 mdb_status mdb_set_profiling(mdb_ctx* ctx, int on) {
     if (!ctx) return MDB_ERR_INVALID_ARG;
     ctx->prof_on = on != 0;
+    ctx->prof_mask = on ? (on & 3 ? on & 3 : 3) : 3;
     return MDB_OK;
 }
 

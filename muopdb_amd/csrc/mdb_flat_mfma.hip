@@ -413,10 +413,13 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     MDB_TRY(mdb_scratch(ctx, 9, (size_t)pair_cap * 8, (void**)&pairs));
     // A. sample top-k (exact)
     MDB_TRY(flat_topk_keys(ctx, view_of(aux.sample), metric, dq, qstride, b, k, skeys, scounts, false));
-    // error budget of the filter: |fl(q'.x') - q'.x'| <= d eps |q'||x'| <= d eps (qn + xn)/2, the same for each
-    // norm, the reference association's own d eps ||q-x||^2 <= 2 d eps (qn + xn), and the rounding of the
-    // centring itself (eps per component): below 4 d eps (qn + xn) in total.
-    const float kappa = 4.0f * (float)(ts.d4 * 4 + 4) * 5.9604645e-8f;
+    // error budget of the filter, eps = 2^-24, all norms of the centred operands:
+    //   centring (eps per component)            : |a' - ||q-x||^2| <= 4 eps (qn + xn)
+    //   reference association vs real arithmetic: s_ref >= s* (1 - (d+2) eps)  -> 2(d+3) eps (qn + xn)
+    //   fl(q'.x') on the matrix cores (fmaf chain): d eps |q'||x'| <= d eps (qn + xn) / 2
+    //   fl(qn), fl(xn) (fmaf chains)             : d eps each
+    // => a member of the true top-k passes the test when kappa >= (4d + 10) eps / (1 - d eps); 6 (d + 4) eps is used.
+    const float kappa = 6.0f * (float)(ts.d4 * 4 + 4) * 5.9604645e-8f;
     MDB_HIP(ctx, hipMemsetAsync(npairs, 0, 512, ctx->stream));  // npairs and ovf
     mfma_prep_kernel<<<dim3((unsigned)bpadq), 128, 0, ctx->stream>>>(dq, qstride, ts.d, aux.mean.p, skeys, scounts, (int)k, kappa,
                                                                     metric, b, dqc, crow);

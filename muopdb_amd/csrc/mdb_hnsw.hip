@@ -1113,7 +1113,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         MDB_HIP(ctx, hipMemsetAsync(vg, 0, b * words * 4, ctx->stream));
         a.vis_global = (uint32_t*)vg;
     }
-    ProfScope prof(ctx);
+    ProfScope prof(ctx, 2);
 #define MDB_HNSW_LAUNCH4(METRIC, VL, RG, NF)                                                                                        \
     do {                                                                                                                   \
         if (lds > 48 * 1024)                                                                                               \

@@ -110,6 +110,68 @@ __device__ __forceinline__ bool tomb_test(const uint32_t* tomb, uint32_t base_wo
     return (tomb[base_word + (pid >> 5)] >> (pid & 31)) & 1u;
 }
 
+// ------------------------------------------------------------------------------------------
+// Flattened tile sequence of one query's probed lists (shared by the f32 and the PQ scan): the lists of
+// up to MAP_PCH probes are laid end to end, so wave w of round r takes tile (r*nsplit + split)*NW + w
+// whatever the individual list lengths are (short lists would otherwise idle most waves).
+#define MAP_PCH 512
+struct TileMap {
+    uint32_t* pstart;  // [MAP_PCH]     first tile of probe j
+    uint32_t* ppref;   // [MAP_PCH + 1] exclusive prefix of tile counts (unused entries == total)
+    static __host__ __device__ size_t lds_bytes() { return (2 * MAP_PCH + 16) * 4; }
+    __device__ void init(void* lds) {
+        pstart = (uint32_t*)lds;
+        ppref = pstart + MAP_PCH;
+    }
+    // all threads of the block (>= MAP_PCH threads not required); returns the number of tiles; sets bad on
+    // an out-of-range list id ("Index out of bound", storage.rs:280-286 — the list is skipped)
+    __device__ int build(const ScanArgs& a, const IvfUserDev& u, int qi, int p0, int n, bool& bad) {
+        const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+        for (int j = tid; j < MAP_PCH; j += nthr) {
+            uint32_t t0 = 0, cnt = 0;
+            if (j < n) {
+                uint32_t c = a.probes[(size_t)qi * a.probe_stride + p0 + j];
+                if (c >= u.num_lists) bad = true;
+                else {
+                    uint32_t g = u.list_base + c;
+                    t0 = a.list_tile_off[g];
+                    cnt = a.list_tile_off[g + 1] - t0;
+                }
+            }
+            pstart[j] = t0;
+            ppref[j + 1] = cnt;
+        }
+        __syncthreads();
+        if (tid < MDB_WAVE) {
+            constexpr int PER = MAP_PCH / MDB_WAVE;
+            uint32_t loc[PER], sum = 0;
+#pragma unroll
+            for (int x = 0; x < PER; ++x) { loc[x] = ppref[1 + lane * PER + x]; sum += loc[x]; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int o = 1; o < MDB_WAVE; o <<= 1) {
+                uint32_t v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int x = 0; x < PER; ++x) { run += loc[x]; ppref[1 + lane * PER + x] = run; }
+            if (lane == 0) ppref[0] = 0;
+        }
+        __syncthreads();
+        return (int)ppref[MAP_PCH];
+    }
+    // wave-uniform t < total: index of the list holding tile t (all 64 lanes must call)
+    __device__ __forceinline__ int list_of(uint32_t t) const {
+        const int lane = threadIdx.x & 63;
+        int j = 0;
+#pragma unroll
+        for (int x = 0; x < MAP_PCH / MDB_WAVE; ++x) j += __popcll(__ballot(ppref[x * MDB_WAVE + lane + 1] <= t));
+        return j;
+    }
+    __device__ __forceinline__ uint32_t tile_of(uint32_t t, int j) const { return pstart[j] + (t - ppref[j]); }
+};
+
 // NoQuantizer<D>: distance = D::calculate(query, vector) (noq/mod.rs:44-51): sqrt L2 / neg dot
 template <int METRIC>
 __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, const float4* __restrict__ tiles, DistPlan p,
@@ -117,23 +179,26 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
     extern __shared__ __attribute__((aligned(16))) char lds[];
     BlockSelect<MDB_BLOCK> sel;
     sel.init(lds, a.k);
+    TileMap map;
+    map.init(lds + ((BlockSelect<MDB_BLOCK>::lds_bytes(a.k) + 15) & ~(size_t)15));
     const int qi = blockIdx.y, split = blockIdx.x, nsplit = gridDim.x;
-    const int wave = threadIdx.x / MDB_WAVE, lane = threadIdx.x % MDB_WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / MDB_WAVE), lane = threadIdx.x % MDB_WAVE;
+    constexpr int NW = MDB_BLOCK / MDB_WAVE;
     const IvfUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
     const float* qb = q + (size_t)qi * qstride;
     const int np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
     bool nan_seen = false, bad = false, first = true;
     unsigned scored = 0;
     if (u.valid) {
-        for (int j = split; j < np; j += nsplit) {
-            uint32_t c = a.probes[(size_t)qi * a.probe_stride + j];
-            if (c >= u.num_lists) { bad = true; continue; }  // "Index out of bound" (storage.rs:280-286)
-            uint32_t g = u.list_base + c;
-            uint32_t t0 = a.list_tile_off[g], t1 = a.list_tile_off[g + 1];
-            for (uint32_t tb = t0; tb < t1; tb += 4) {
-                uint32_t tile = tb + wave;
+        for (int p0 = 0; p0 < np; p0 += MAP_PCH) {
+            const int T = map.build(a, u, qi, p0, min(MAP_PCH, np - p0), bad);
+            const int per_round = NW * nsplit;
+            const int rounds = (T + per_round - 1) / per_round;
+            for (int r = 0; r < rounds; ++r) {
+                const int t = (r * nsplit + split) * NW + wave;
                 uint64_t key = MDB_KEY_MAX;
-                if (tile < t1) {
+                if (t < T) {
+                    const uint32_t tile = map.tile_of((uint32_t)t, map.list_of((uint32_t)t));
                     uint32_t pid = a.slot_ids[(size_t)tile * MDB_TILE + lane];
                     if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid)) {
                         TileLoader ld{tiles + (size_t)tile * p.d4 * MDB_TILE + lane};
@@ -149,6 +214,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
                 sel.offer(key);
                 sel.round_end();
             }
+            __syncthreads();  // the map is rebuilt by the next chunk
         }
     }
     if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
@@ -165,11 +231,6 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
     for (int j = threadIdx.x; j < a.k; j += MDB_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
 }
 
-// ProductQuantizer: symmetric distance between the QUANTIZED query and the stored codes
-// (pq/mod.rs:231-266).  The per-query table T[s][c][e] = term(cb[s][q_s][e], cb[s][c][e]) holds
-// the individually rounded per-element terms, so summing rows of T per lane in subspace order
-// reproduces the reference's shared sum_16/8/4 accumulators bit for bit.
-// LUT_LDS: table in LDS (d*K*4 bytes); otherwise terms are recomputed from the L2-resident codebook.
 template <int METRIC, bool LUT_LDS>
 __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_pq_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m,
                                                                 int mw, int K, int subdim, DistPlan sp,
@@ -861,10 +922,15 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
 #undef MDB_PQ_LAUNCH
     } else {
         DistPlan p = make_plan((int)num_features, metric);
+        const size_t f32_lds = ((sel_lds + 15) & ~(size_t)15) + TileMap::lds_bytes();
+        if (f32_lds > 48 * 1024) {
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_f32_kernel<MDB_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32_lds));
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_f32_kernel<MDB_METRIC_DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32_lds));
+        }
         if (metric == MDB_METRIC_L2)
-            ivf_scan_f32_kernel<MDB_METRIC_L2><<<grid, MDB_BLOCK, sel_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);
+            ivf_scan_f32_kernel<MDB_METRIC_L2><<<grid, MDB_BLOCK, f32_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);
         else
-            ivf_scan_f32_kernel<MDB_METRIC_DOT><<<grid, MDB_BLOCK, sel_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);
+            ivf_scan_f32_kernel<MDB_METRIC_DOT><<<grid, MDB_BLOCK, f32_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);
     }
     }
     MDB_HIP(ctx, hipGetLastError());

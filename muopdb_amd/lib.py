@@ -154,7 +154,8 @@ class Context:
         return {k: getattr(s, k) for k, _ in Stats._fields_}
 
     def set_profiling(self, on):
-        self.check(self.lib.mdb_set_profiling(self.h, C.c_int(int(on))))
+        # True -> 3 (every bracketed kernel); 1 = scan kernels only, 2 = HNSW traversal only
+        self.check(self.lib.mdb_set_profiling(self.h, C.c_int(3 if on is True else int(on))))
 
     def get_profile(self):
         """(summed dominant-kernel ms, launches) since the last call; synchronises."""
