@@ -208,7 +208,11 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     int qt = flat_choose_qt(b, (int)k);
     size_t bpad = (b + qt - 1) / qt * qt;
     size_t ngroups = (ts.ntiles + 3) / 4;
-    unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(ngroups, 1), 1024);
+    // blocks: enough to fill the chip (~4 per CU), but several rounds per block when there are many query
+    // groups — a block that scans one round pays its selectors' warm-up and final sort for nothing
+    static const size_t target = getenv("MDB_FLAT_BLOCKS") ? (size_t)atoi(getenv("MDB_FLAT_BLOCKS")) : 512;
+    const size_t qgroups = bpad / qt;
+    unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(ngroups, 1), std::max<size_t>((target + qgroups - 1) / qgroups, 1));
     // keep the partial buffer bounded (<= 256 MiB)
     while (nblk > 32 && (size_t)nblk * bpad * std::max<size_t>(k, 1) * 8 > (256u << 20)) nblk /= 2;
     void* partial;

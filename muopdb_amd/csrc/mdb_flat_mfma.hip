@@ -164,6 +164,7 @@ __global__ __launch_bounds__(128) void mfma_prep_kernel(const float* __restrict_
 // across tile boundaries), so HBM latency hides behind 4*QB*MF_CH MFMAs of 64 cycles.
 #define MF_CH 8
 #define MF_LBUF 2048  // candidate pairs staged per block
+#define MF_RS 8       // refine blocks (pair-list slices) per query
 template <int METRIC, int QB>
 __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* __restrict__ tiles, size_t n, size_t ntiles, int d4,
                                                                   const float* __restrict__ dqc, int qstride,
@@ -310,33 +311,42 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
 }
 
 // ------------------------------------------------------------------------------------------ refine
-// one block per query: collect the query's vectors from the pair list (LDS), then their exact distances.
-// A list longer than its capacity raises `ovf` instead (-> gated exact scan of the batch).
+// MF_RS blocks per query, each over its slice of the pair list: collect the query's vectors (LDS), then
+// their exact distances and a partial top-k (merged by merge_keys).  A list longer than its capacity
+// raises `ovf` instead (-> gated exact scan of the batch).
 template <int METRIC>
 __global__ __launch_bounds__(MDB_BLOCK) void flat_refine_kernel(const float4* __restrict__ tiles, DistPlan p,
                                                                 const float* __restrict__ dq, int qstride,
                                                                 const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ npairs,
                                                                 uint32_t pair_cap, int k, uint64_t* __restrict__ keys,
-                                                                uint32_t* __restrict__ counts, uint32_t* __restrict__ ovf,
-                                                                uint32_t* __restrict__ flags) {
+                                                                uint32_t* __restrict__ ovf, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const size_t m = blockIdx.x;
+    const size_t m = blockIdx.y;
     const uint32_t np = *npairs;
     if (np > pair_cap) {
-        if (threadIdx.x == 0 && m == 0) atomicAdd(ovf, 1u);
+        if (threadIdx.x == 0 && m == 0 && blockIdx.x == 0) atomicAdd(ovf, 1u);
         return;
     }
+    const uint32_t lo = (uint32_t)((uint64_t)np * blockIdx.x / gridDim.x), hi = (uint32_t)((uint64_t)np * (blockIdx.x + 1) / gridDim.x);
     BlockSelect<MDB_BLOCK> sel;
     sel.init(lds, k);
     uint32_t* mine = (uint32_t*)(lds + ((BlockSelect<MDB_BLOCK>::lds_bytes(k) + 15) & ~(size_t)15));  // [MF_CAP]
     uint32_t* mcnt = mine + MF_CAP;
     if (threadIdx.x == 0) *mcnt = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < np; i += MDB_BLOCK) {
-        uint64_t pr = pairs[i];
-        if ((uint32_t)(pr >> 32) == (uint32_t)m) {
-            uint32_t pos = atomicAdd(mcnt, 1u);
-            if (pos < MF_CAP) mine[pos] = (uint32_t)pr;
+    for (uint32_t i0 = lo; i0 < hi; i0 += MDB_BLOCK * 8) {  // 8 independent loads in flight per thread
+        uint64_t pr[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            uint32_t i = i0 + x * MDB_BLOCK + threadIdx.x;
+            pr[x] = i < hi ? pairs[i] : ~0ull;
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            if ((uint32_t)(pr[x] >> 32) == (uint32_t)m) {
+                uint32_t pos = atomicAdd(mcnt, 1u);
+                if (pos < MF_CAP) mine[pos] = (uint32_t)pr[x];
+            }
         }
     }
     __syncthreads();
@@ -366,8 +376,8 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_refine_kernel(const float4* __
     if (nan_seen) atomicOr(flags, MDB_FLAG_NAN);
     sel.finish();
     uint32_t cc = sel.count();
-    for (int j = threadIdx.x; j < k; j += MDB_BLOCK) keys[m * (size_t)k + j] = j < (int)cc ? sel.buf[j] : MDB_KEY_MAX;
-    if (threadIdx.x == 0 && counts) counts[m] = cc;
+    uint64_t* dst = keys + (m * gridDim.x + blockIdx.x) * (size_t)k;  // partial [query][slice][k]
+    for (int j = threadIdx.x; j < k; j += MDB_BLOCK) dst[j] = j < (int)cc ? sel.buf[j] : MDB_KEY_MAX;
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -449,13 +459,17 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     // C. refine
     DistPlan p = make_plan(ts.d, metric);
     size_t sel_lds = ((BlockSelect<MDB_BLOCK>::lds_bytes((int)k) + 15) & ~(size_t)15) + MF_CAP * 4 + 16;
+    uint64_t* rpart;
+    MDB_TRY(mdb_scratch(ctx, 10, b * (size_t)MF_RS * std::max<size_t>(k, 1) * 8, (void**)&rpart));
+    MDB_HIP(ctx, hipMemsetAsync(rpart, 0xFF, b * (size_t)MF_RS * k * 8, ctx->stream));  // a slice that bails out leaves KEY_MAX
     if (metric == MDB_METRIC_L2)
-        flat_refine_kernel<MDB_METRIC_L2><<<dim3((unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(
-            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)k, d_keys, d_counts, ovf, ctx->d_flags);
+        flat_refine_kernel<MDB_METRIC_L2><<<dim3(MF_RS, (unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(
+            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)k, rpart, ovf, ctx->d_flags);
     else
-        flat_refine_kernel<MDB_METRIC_DOT><<<dim3((unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(
-            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)k, d_keys, d_counts, ovf, ctx->d_flags);
+        flat_refine_kernel<MDB_METRIC_DOT><<<dim3(MF_RS, (unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(
+            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)k, rpart, ovf, ctx->d_flags);
     MDB_HIP(ctx, hipGetLastError());
+    MDB_TRY(merge_keys(ctx, rpart, (size_t)MF_RS * k, b, k, d_keys, d_counts));
     if (getenv("MDB_MF_DBG")) {
         uint32_t hn = 0, ho = 0;
         MDB_HIP(ctx, hipMemcpyAsync(&hn, npairs, 4, hipMemcpyDeviceToHost, ctx->stream));

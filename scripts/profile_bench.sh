@@ -10,7 +10,7 @@ TAG=$1; KIND=$2; DIM=$3; K=$4; KNOB=$5; BATCH=$6; shift 6
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 DUMP=/tmp/mdb_dump_$TAG
-PAT="hnsw_|flat_scan|ivf_scan"
+PAT="hnsw_|flat_scan|flat_mfma|flat_refine|ivf_scan"
 rm -rf $OUT $DUMP; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$TAG -o bench -- python $REPO/bench.py --no-cpu-baseline --dump-dir $DUMP "$@" > $OUT/bench_stats.log 2>&1
