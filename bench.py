@@ -382,9 +382,10 @@ def run_ivfpq(args, ctx, rank, world, timer):
                config={"workload": "SIFT-1M-like synthetic %dx%d, IVF nlist=%d + PQ m=16 nbits=8 (symmetric distance), nprobe=%d, "
                                    "batch=%d, top-%d, lists sharded x%d" % (n, d, nlist, P, batch, k, world),
                        "n": n, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq"},
-               roofline=dict(bound="hbm", kernel="ivf_scan_pq_kernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+               roofline=dict(bound="hbm", kernel="ivf_scan_pq2_kernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                              frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes / steps,
                              kernel_ms=kernel_ms / launches, scored_per_query=scored / (steps * batch)))
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ivfpq", out["config"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         o = oracle.BlockBasedIvf(index_bytes, vec_bytes, oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, cb))
