@@ -11,7 +11,9 @@ objs=""
 for s in $SRCS; do
   [ -f "$s" ] || continue
   o=build/${s%.hip}.o
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ mdb_device.cuh -nt "$o" ] || [ mdb_common.h -nt "$o" ] || [ mdb_kernels.h -nt "$o" ] || [ ../../include/muopdb_hip.h -nt "$o" ]; then
+  stale=0
+  for h in *.h *.cuh ../../include/muopdb_hip.h; do [ "$h" -nt "$o" ] && stale=1; done
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ $stale = 1 ]; then
     echo "hipcc $s"
     hipcc $FLAGS -c "$s" -o "$o" &
   fi

@@ -31,6 +31,8 @@ struct HnswBlobInfo {
 struct HnswSet {
     mdb_ctx* ctx = nullptr;
     int metric = MDB_METRIC_L2;
+    int kind = MDB_QUANT_NONE;     // MDB_QUANT_PQ: rows hold the points' codebook rows (decoded once at load)
+    PqDev pq;
     uint32_t dimension = 0;
     int dpad = 0;
     std::vector<HnswBlobInfo> blobs;

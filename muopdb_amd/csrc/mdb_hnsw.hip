@@ -38,6 +38,8 @@ struct HnswArgs {
     int qstride;
     int dpad;
     DistPlan p;
+    DistPlan sp;        // PQ: plan of one subvector (L2-style thresholds for every metric, pq/mod.rs:231-266)
+    int pq_m, pq_subdim;  // pq_m > 0: rows and query are sequences of codebook rows, ProductQuantizer::distance association
     int ef, ef_cap, cand_cap, smax, k;
     uint64_t* out_keys;
     uint32_t* out_counts;
@@ -107,6 +109,31 @@ __device__ __forceinline__ float group16_distance(const float* __restrict__ x, c
     }
     for (int t = 0; t < p.ntail; ++t) ret = acc_term<METRIC>(ret, qs[p.offt + t], x[p.offt + t]);
     return finish_distance<METRIC>(ret);
+}
+
+// ProductQuantizer::distance (StreamingSIMD arm, pq/mod.rs:231-266) of two code vectors whose codebook
+// rows were written out in full (stored row x / query row qs, natural order): the lane accumulators
+// sum_16/8/4 run ACROSS the m subvectors, sum_1 is overwritten by every subvector's sub-4 tail, no sqrt.
+template <int METRIC>
+__device__ __forceinline__ float group16_distance_pq(const float* __restrict__ x, const float* __restrict__ qs, const DistPlan& sp,
+                                                     int m, int subdim, int j) {
+    float a16 = 0.0f, a8 = 0.0f, a4 = 0.0f, tail = 0.0f;
+    for (int s = 0; s < m; ++s) {
+        const float* xs = x + s * subdim;
+        const float* q = qs + s * subdim;
+        for (int c = 0; c < sp.n16; ++c) a16 = acc_term<METRIC>(a16, q[16 * c + j], xs[16 * c + j]);
+        if (j < 8)
+            for (int c = 0; c < sp.n8; ++c) a8 = acc_term<METRIC>(a8, q[sp.off8 + 8 * c + j], xs[sp.off8 + 8 * c + j]);
+        if (j < 4)
+            for (int c = 0; c < sp.n4; ++c) a4 = acc_term<METRIC>(a4, q[sp.off4 + 4 * c + j], xs[sp.off4 + 4 * c + j]);
+        if (sp.ntail > 0) {
+            float t = 0.0f;
+            for (int i = 0; i < sp.ntail; ++i) t = acc_term<METRIC>(t, q[sp.offt + i], xs[sp.offt + i]);
+            tail = t;
+        }
+    }
+    float r = __fadd_rn(__fadd_rn(__fadd_rn(group_reduce<16>(a16), group_reduce<8>(a8)), group_reduce<4>(a4)), tail);
+    return METRIC == MDB_METRIC_L2 ? r : -r;
 }
 
 // d = 16*N16 exactly (128, 768, ...): lane j's query elements are already in registers and its N16
@@ -285,7 +312,8 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
         for (int c = 0; c < N16T; ++c) qr[c] = qs[16 * c + j];
     }
 #define MDB_GROUP_DIST(rowptr) (N16T > 0 ? group16_distance_fast<METRIC, (N16T > 0 ? N16T : 4)>((rowptr), reinterpret_cast<const float (&)[N16T > 0 ? N16T : 4]>(qr), j) \
-                                         : group16_distance<METRIC>((rowptr), qs, a.p, j))
+                                         : (a.pq_m > 0 ? group16_distance_pq<METRIC>((rowptr), qs, a.sp, a.pq_m, a.pq_subdim, j) \
+                                                       : group16_distance<METRIC>((rowptr), qs, a.p, j)))
     // wave-0 uniform state
     int wsize = 0, cn = 0, cbase = 0;
     uint32_t wd[WREGS], wi[WREGS], cd[CREGS], ci[CREGS];  // REGS mode slots
@@ -621,7 +649,8 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
         for (int c = 0; c < N16T; ++c) qr[c] = qs[16 * c + j];
     }
 #define MDB_BEAM_DIST(rowptr) (N16T > 0 ? group16_distance_fast<METRIC, (N16T > 0 ? N16T : 4)>((rowptr), reinterpret_cast<const float (&)[N16T > 0 ? N16T : 4]>(qr), j) \
-                                        : group16_distance<METRIC>((rowptr), qs, a.p, j))
+                                        : (a.pq_m > 0 ? group16_distance_pq<METRIC>((rowptr), qs, a.sp, a.pq_m, a.pq_subdim, j) \
+                                                      : group16_distance<METRIC>((rowptr), qs, a.p, j)))
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // ---- wave-0 state
     uint32_t bd[BREGS], bi[BREGS];  // B: distance image / id per slot (SLOT_EMPTY beyond n)
@@ -924,6 +953,23 @@ __global__ void copy_rows_kernel(const uint8_t* __restrict__ src, const uint64_t
     dst[r * dpad + pos] = e < d ? ((const float*)(src + row_src[r]))[e] : 0.0f;
 }
 
+// PQ graphs: every stored code vector (row r at src + row_src[r], or src + r*code_stride when row_src is
+// null) is written out as its m codebook rows, natural order, zero padded to dpad
+__global__ void pq_rows_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ row_src, size_t code_stride, int m,
+                               int subdim, int K, const float* __restrict__ cb, int dpad, float* __restrict__ dst, size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    size_t r = t / dpad;
+    int e = (int)(t % dpad);
+    float v = 0.0f;
+    if (e < m * subdim) {
+        const uint8_t* codes = row_src ? src + row_src[r] : src + r * code_stride;
+        int s = e / subdim;
+        v = cb[((size_t)s * K + codes[s]) * subdim + (e % subdim)];
+    }
+    dst[t] = v;
+}
+
 // ------------------------------------------------------------------------------------------ load
 static mdb_status parse_hnsw_blob(mdb_ctx* ctx, const uint8_t* b, size_t len, size_t data_offset, HnswBlobInfo& o) {
     if (data_offset + 49 > len) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW index: header out of bounds");
@@ -954,9 +1000,15 @@ static mdb_status parse_hnsw_blob(mdb_ctx* ctx, const uint8_t* b, size_t len, si
 mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
                          const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant, uint32_t dim) {
     ctx = ctx_;
-    if (quant && quant->kind != MDB_QUANT_NONE)
-        return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "HNSW traversal over PQ codes is not built yet (NoQuantizer graphs only)");
+    kind = quant ? (int)quant->kind : MDB_QUANT_NONE;
     metric = quant ? quant->metric : MDB_METRIC_L2;
+    if (kind == MDB_QUANT_PQ) {
+        MDB_TRY(pq_upload(ctx, quant, pq));
+        if ((uint32_t)pq.dimension != dim) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "PQ dimension %d != %u", pq.dimension, dim);
+    }
+    // bytes of one stored vector in the file: f32 row, or m u8 codes (BlockBasedHnsw<ProductQuantizer>)
+    const size_t file_row = kind == MDB_QUANT_PQ ? (size_t)pq.m : (size_t)dim * 4;
+    const uint32_t file_qdim = kind == MDB_QUANT_PQ ? (uint32_t)pq.m : dim;
     dimension = dim;
     dpad = ((int)dim + 3) / 4 * 4;
     const size_t U = offsets.size();
@@ -968,12 +1020,12 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
     for (size_t ui = 0; ui < U; ++ui) {
         HnswBlobInfo& bi = blobs[ui];
         MDB_TRY(parse_hnsw_blob(ctx, index, index_len, offsets[ui].first, bi));
-        if (bi.quantized_dimension != dim) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW quantized_dimension %u != %u", bi.quantized_dimension, dim);
+        if (bi.quantized_dimension != file_qdim) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW quantized_dimension %u != %u", bi.quantized_dimension, file_qdim);
         size_t voff = offsets[ui].second;
         if (voff + 8 > vectors_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file: header out of bounds");
         uint64_t nv = rd_u64(vectors + voff);
-        if (voff + 8 + nv * dim * 4 > vectors_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file truncated");
-        if ((voff + 8) % 4 != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "f32 vector file is not 4-byte aligned");
+        if (voff + 8 + nv * file_row > vectors_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file truncated");
+        if (kind != MDB_QUANT_PQ && (voff + 8) % 4 != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "f32 vector file is not 4-byte aligned");
         if (nv > 0xFFFFFFFEull) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "point ids are u32");
         bi.num_vectors = nv;
         bi.vec_data_offset = voff + 8;
@@ -983,7 +1035,7 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
         u.num_layers = bi.num_layers;
         u.doc_ids_off = bi.doc_id_mapping_offset;
         u.vec_off = (uint64_t)row_src.size() * dpad;
-        for (uint64_t r = 0; r < nv; ++r) row_src.push_back(bi.vec_data_offset + r * dim * 4);
+        for (uint64_t r = 0; r < nv; ++r) row_src.push_back(bi.vec_data_offset + r * file_row);
         u.upper_off = h_level.size();
         h_level.resize(h_level.size() + nv, 0);
         h_upper_first.resize(h_upper_first.size() + nv, 0xFFFFFFFFu);
@@ -1078,8 +1130,12 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
     if (!h_upper_first.empty()) MDB_HIP(ctx, hipMemcpyAsync(d_upper_first.p, h_upper_first.data(), h_upper_first.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!h_level.empty()) MDB_HIP(ctx, hipMemcpyAsync(d_level.p, h_level.data(), h_level.size(), hipMemcpyHostToDevice, ctx->stream));
     size_t total = row_src.size() * (size_t)dpad;
-    if (total) copy_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(d_vec.p, d_row_src.p, (int)dim, dpad,
-                                                                                             make_plan((int)dim, metric).n16, d_vecs.p, total);
+    if (total && kind == MDB_QUANT_PQ)
+        pq_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(d_vec.p, d_row_src.p, 0, pq.m, pq.subdim, pq.K,
+                                                                                      pq.codebook.p, dpad, d_vecs.p, total);
+    else if (total)
+        copy_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(d_vec.p, d_row_src.p, (int)dim, dpad,
+                                                                                        make_plan((int)dim, metric).n16, d_vecs.p, total);
     MDB_HIP(ctx, hipGetLastError());
     MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MDB_OK;
@@ -1094,6 +1150,21 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     HnswArgs a{};
     a.users = d_users.p; a.q_user = d_q_user; a.adj = d_adj.p; a.upper_first = d_upper_first.p; a.level = d_level.p;
     a.vecs = d_vecs.p; a.q = d_q; a.qstride = qstride; a.dpad = dpad; a.p = make_plan((int)dimension, metric);
+    if (kind == MDB_QUANT_PQ) {
+        // the query is quantized like a stored point (index.rs:168) and written out as its codebook rows
+        void *qcodes, *qrows;
+        MDB_TRY(mdb_scratch(ctx, 7, b * (size_t)pq.m + 16, &qcodes));
+        MDB_TRY(mdb_scratch(ctx, 2, b * (size_t)qstride * 4 + 16, &qrows));
+        MDB_TRY(pq_quantize_device(ctx, pq, d_q, b, (uint8_t*)qcodes, qstride));
+        size_t tq = b * (size_t)qstride;
+        pq_rows_kernel<<<dim3((unsigned)((tq + 255) / 256)), 256, 0, ctx->stream>>>((const uint8_t*)qcodes, nullptr, (size_t)pq.m, pq.m,
+                                                                                   pq.subdim, pq.K, pq.codebook.p, qstride, (float*)qrows, tq);
+        MDB_HIP(ctx, hipGetLastError());
+        a.q = (const float*)qrows;
+        a.pq_m = pq.m;
+        a.pq_subdim = pq.subdim;
+        a.sp = make_plan(pq.subdim, MDB_METRIC_L2);
+    }
     a.ef = (int)ef;
     a.ef_cap = ((int)ef + 63) / 64 * 64;
     int p2 = 1024;  // sort / staging buffer of the beam kernel (512 keys + 512 flag words) fits as well
@@ -1123,7 +1194,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     } while (0)
     const bool regs = ef <= 64 * WREGS && !getenv("MDB_HNSW_NO_REGS");
     // specialised distance when the whole vector is 16-lane chunks (d = 128 / 768: the configs' dims)
-    const int nf = (a.p.n8 == 0 && a.p.n4 == 0 && a.p.ntail == 0 && !getenv("MDB_HNSW_GENERIC_DIST")) ? a.p.n16 : 0;
+    const int nf = (kind != MDB_QUANT_PQ && a.p.n8 == 0 && a.p.n4 == 0 && a.p.ntail == 0 && !getenv("MDB_HNSW_GENERIC_DIST")) ? a.p.n16 : 0;
 #define MDB_BEAM_LAUNCH(METRIC, VL, NF)                                                                                     \
     do {                                                                                                                    \
         if (lds > 48 * 1024)                                                                                                \
@@ -1225,7 +1296,8 @@ mdb_status mdb_hnsw_ann_search(mdb_hnsw* h, const float* queries, size_t b, size
     MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
     ctx->stats = mdb_stats{};
     // d*4 B vector + 4 B edge id per distance evaluation, 16 B offsets per expanded node
-    ctx->stat_bytes_per_eval = (uint64_t)s.dimension * 4 + 4; ctx->stat_bytes_per_scored = 0; ctx->stat_fixed_bytes = 0;
+    ctx->stat_bytes_per_eval = (s.kind == MDB_QUANT_PQ ? (uint64_t)s.pq.m : (uint64_t)s.dimension * 4) + 4;
+    ctx->stat_bytes_per_scored = 0; ctx->stat_fixed_bytes = 0;
     MDB_TRY(s.search(dq, qstride, b, nullptr, k, ef, (uint64_t*)keys, (uint32_t*)cnts));
     size_t total = b * k;
     if (mem == MDB_MEM_DEVICE) return s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, doc_ids_out, scores_out, counts_out);

@@ -66,6 +66,40 @@ def test_hnsw_ann_search(ctx, oracle, n, d, M, layers, efc, metric, seed):
     assert st["distance_evals"] == evals and st["expanded_nodes"] == expanded  # same traversal, step for step
 
 
+@pytest.mark.parametrize("n,d,sub,bits,metric,ef", [(2000, 64, 8, 6, 0, 100), (1500, 32, 16, 5, 0, 300), (1200, 24, 6, 4, 0, 64),
+                                                   (1000, 21, 7, 3, 1, 50), (1500, 32, 2, 4, 0, 40)])
+def test_hnsw_over_pq_codes(ctx, oracle, n, d, sub, bits, metric, ef):
+    """BlockBasedHnsw<ProductQuantizer>: the graph file stores quantized_dimension = m, the vector file the
+    u8 codes; the query is quantized and every distance is ProductQuantizer::distance (symmetric, lane
+    accumulators across subvectors, no sqrt).  Heavy ties (few distinct codes) included."""
+    from muopdb_amd.index import BlockBasedHnsw, ProductQuantizer
+    rng = np.random.default_rng(n + d)
+    v = H.sift_like(n, d, n_clusters=25, seed=d)
+    cb = H.train_pq_codebook(v[:1000], sub, bits, iters=3)
+    opq = oracle.ProductQuantizer(d, sub, bits, cb, metric)
+    codes = opq.quantize(v)
+    m = d // sub
+    b = oracle.HnswBuilder(d, 10, 4, 60, metric, 3)
+    b.insert(v)
+    layers, eps = b.layers(), b.entry_points()
+    if len(layers) > 1:
+        top = layers[-1]
+        layers[-1] = {eps[0]: top[eps[0]], **{p: e for p, e in top.items() if p != eps[0]}}
+    doc = [11 * i + 5 for i in range(n)]
+    hidx, hvec = F.write_hnsw_index(layers, doc, m), F.write_vector_file(codes)
+    g = BlockBasedHnsw(ctx, hidx, hvec, d, ProductQuantizer(d, sub, bits, cb, metric))
+    o = oracle.BlockBasedHnsw(hidx, hvec, d, oracle.Quant(oracle.QUANT_PQ, metric, sub, bits, cb))
+    q = (v[rng.integers(0, n, 20)] + rng.normal(0, 5, (20, d))).astype(np.float32)
+    for k, e in [(10, ef), (3, 5)]:
+        assert_result_rows(g.ann_search(q, k, e), o.ann_search(q, k, e), len(q))
+    o.stats()  # reset the oracle's counters
+    o.ann_search(q, 10, ef)
+    evals, expanded = o.stats()
+    g.ann_search(q, 10, ef)
+    st = ctx.stats()
+    assert st["distance_evals"] == evals and st["expanded_nodes"] == expanded
+
+
 def test_hnsw_ties_and_duplicates(ctx, oracle):
     # many exact distance ties: pop order (largest id first) and eviction order must match
     from muopdb_amd.index import BlockBasedHnsw
