@@ -222,33 +222,42 @@ mdb_status pq_upload(mdb_ctx* ctx, const mdb_quant_desc* q, PqDev& pq) {
     return MDB_OK;
 }
 
-// ProductQuantizer::quantize pq/mod.rs:152-177: one thread per (vector, subspace); argmin over K
-// centroids of the EXACT squared-L2 cascade, first minimum wins (strict <), start f32::MAX.
+// ProductQuantizer::quantize pq/mod.rs:152-177: one WAVE per (vector, subspace); lane l scores centroids
+// l, l+64, ... with the EXACT squared-L2 cascade; "first minimum wins (strict <), start f32::MAX" is the
+// minimum of (distance, centroid index) keys; a NaN distance never wins (`NaN < best` is false).
 __global__ __launch_bounds__(256) void pq_quantize_kernel(const float* __restrict__ vecs, size_t n, int row_stride, int subdim,
                                                           int m, int K, const float* __restrict__ cb, DistPlan sp,
                                                           uint8_t* __restrict__ codes) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n * (size_t)m) return;
     size_t v = t / m;
     int s = (int)(t % m);
-    const float* sub = vecs + v * (size_t)row_stride + (size_t)s * subdim;
+    const float* sub = vecs + v * (size_t)row_stride + (size_t)s * subdim;  // wave-uniform: scalar loads
     const float* cbs = cb + (size_t)s * K * subdim;
-    float best = 3.402823466e+38f;
-    int bi = 0;
-    for (int c = 0; c < K; ++c) {
+    uint64_t best = ~0ull;  // no centroid strictly below f32::MAX yet (=> code 0)
+    for (int c = lane; c < K; c += 64) {
         RowLoader lc{cbs + (size_t)c * subdim, subdim};
         float raw[1];
         exact_sums<MDB_METRIC_L2, 1>(lc, sub, 0, sp, raw);
-        if (raw[0] < best) { best = raw[0]; bi = c; }
+        if (raw[0] < 3.402823466e+38f) {  // also false for NaN
+            uint64_t key = ((uint64_t)f32_orderable(raw[0]) << 32) | (uint32_t)c;
+            best = key < best ? key : best;
+        }
     }
-    codes[t] = (uint8_t)bi;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(best >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, o);
+        best = other < best ? other : best;
+    }
+    if (lane == 0) codes[t] = best == ~0ull ? (uint8_t)0 : (uint8_t)(best & 0xFFFFFFFFu);
 }
 
 mdb_status pq_quantize_device(mdb_ctx* ctx, const PqDev& pq, const float* d_vecs, size_t n, uint8_t* d_codes, int row_stride) {
     if (n == 0) return MDB_OK;
     DistPlan sp = make_plan(pq.subdim, MDB_METRIC_L2);  // quantize always uses squared L2 (pq/mod.rs:167)
     size_t total = n * (size_t)pq.m;
-    pq_quantize_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(d_vecs, n, row_stride ? row_stride : pq.dimension, pq.subdim, pq.m,
+    pq_quantize_kernel<<<dim3((unsigned)((total + 3) / 4)), 256, 0, ctx->stream>>>(d_vecs, n, row_stride ? row_stride : pq.dimension, pq.subdim, pq.m,
                                                                                    pq.K, pq.codebook.p, sp, d_codes);
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
