@@ -131,6 +131,10 @@ mdb_status mdb_get_profile(mdb_ctx* ctx, double* kernel_ms_out, uint64_t* launch
  * cascade, per-lane partial sums, ordered horizontal sum, no FMA). */
 mdb_status mdb_l2_distance(mdb_ctx* ctx, const float* a, const float* b, size_t n, size_t d, int squared, float* out);
 mdb_status mdb_dot_distance(mdb_ctx* ctx, const float* a, const float* b, size_t n, size_t d, float* out);
+/* LaneConformingDistanceCalculator<LANES, D>::calculate_squared lane_conforming.rs:22-26 (k-means only):
+ * one accumulator of lanes (4 | 8 | 16) over all whole chunks of d, no sqrt (L2) / negated (dot). */
+mdb_status mdb_lane_conforming_distance(mdb_ctx* ctx, const float* a, const float* b, size_t n, size_t d, int lanes,
+                                        mdb_metric metric, float* out);
 /* ProductQuantizer::quantize pq/mod.rs:152-177 — vectors [n][dimension] -> codes [n][m] */
 mdb_status mdb_pq_quantize(mdb_ctx* ctx, const mdb_quant_desc* pq, const float* vectors, size_t n, uint8_t* codes_out);
 /* ProductQuantizer::distance pq/mod.rs:202-278 — code pairs a[i], b[i] ([n][m]) */

@@ -202,6 +202,53 @@ extern "C" mdb_status mdb_dot_distance(mdb_ctx* ctx, const float* a, const float
     return pair_distance(ctx, MDB_METRIC_DOT, a, b, n, d, 0, out);
 }
 
+// D3: LaneConformingDistanceCalculator<LANES, D>::calculate_squared (lane_conforming.rs:22-26): one
+// LANES-wide accumulator over all whole chunks, ordered horizontal sum, outermost_op (identity / negate).
+template <int METRIC, int LANES>
+__global__ __launch_bounds__(256) void lane_conforming_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                              size_t d, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* x = a + i * d;
+    const float* y = b + i * d;
+    float acc[LANES];
+#pragma unroll
+    for (int j = 0; j < LANES; ++j) acc[j] = 0.0f;
+    for (size_t c = 0; c + LANES <= d; c += LANES)
+#pragma unroll
+        for (int j = 0; j < LANES; ++j) acc[j] = acc_term<METRIC>(acc[j], x[c + j], y[c + j]);
+    float r = reduce_ordered<LANES>(acc);
+    out[i] = METRIC == MDB_METRIC_L2 ? r : -r;
+}
+
+extern "C" mdb_status mdb_lane_conforming_distance(mdb_ctx* ctx, const float* a, const float* b, size_t n, size_t d, int lanes,
+                                                   mdb_metric metric, float* out) {
+    if (!ctx || !a || !b || !out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (lanes != 4 && lanes != 8 && lanes != 16) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "lanes must be 4, 8 or 16");
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return MDB_OK;
+    void *da, *db, *dout;
+    MDB_TRY(mdb_scratch(ctx, 0, (n * d + 4) * 4, &da));
+    MDB_TRY(mdb_scratch(ctx, 1, (n * d + 4) * 4, &db));
+    MDB_TRY(mdb_scratch(ctx, 2, n * 4, &dout));
+    MDB_HIP(ctx, hipMemcpyAsync(da, a, n * d * 4, hipMemcpyHostToDevice, ctx->stream));
+    MDB_HIP(ctx, hipMemcpyAsync(db, b, n * d * 4, hipMemcpyHostToDevice, ctx->stream));
+    dim3 grid((unsigned)((n + 255) / 256));
+#define MDB_LC(METRIC)                                                                                                        \
+    do {                                                                                                                      \
+        if (lanes == 4) lane_conforming_kernel<METRIC, 4><<<grid, 256, 0, ctx->stream>>>((float*)da, (float*)db, n, d, (float*)dout);        \
+        else if (lanes == 8) lane_conforming_kernel<METRIC, 8><<<grid, 256, 0, ctx->stream>>>((float*)da, (float*)db, n, d, (float*)dout);   \
+        else lane_conforming_kernel<METRIC, 16><<<grid, 256, 0, ctx->stream>>>((float*)da, (float*)db, n, d, (float*)dout);                  \
+    } while (0)
+    if (metric == MDB_METRIC_L2) MDB_LC(MDB_METRIC_L2); else MDB_LC(MDB_METRIC_DOT);
+#undef MDB_LC
+    MDB_HIP(ctx, hipGetLastError());
+    MDB_HIP(ctx, hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MDB_OK;
+}
+
 // ============================================================================================
 // Q3 seams: PQ quantize / distance
 // ============================================================================================

@@ -197,6 +197,7 @@ static mdb_status launch_flat_scan(mdb_ctx* ctx, const TileView& ts, const DistP
 
 static int flat_choose_qt(size_t b, int k) {
     int qt = b >= 4 ? 4 : (b >= 2 ? 2 : 1);
+    if (getenv("MDB_FLAT_QT")) qt = std::max(1, std::min(qt, atoi(getenv("MDB_FLAT_QT"))));
     while (qt > 1 && BlockSelect<MDB_BLOCK>::lds_bytes(k) * qt > 60 * 1024) qt >>= 1;
     return qt;
 }

@@ -962,6 +962,22 @@ float orc_l2(const float* a, const float* b, size_t n) { return l2_distance(a, b
 float orc_l2_scalar(const float* a, const float* b, size_t n) { return l2_scalar(a, b, n); }
 float orc_dot(const float* a, const float* b, size_t n) { return dot_distance(a, b, n); }
 float orc_dot_scalar(const float* a, const float* b, size_t n) { return dot_scalar(a, b, n); }
+// LaneConformingDistanceCalculator<LANES, D>::calculate_squared — rs/utils/src/distance/lane_conforming.rs:22-26:
+// ONE accumulator of `lanes` lanes over all chunks_exact(lanes) (a remainder is dropped, the caller
+// guarantees d % lanes == 0), ordered reduce_sum, then D::outermost_op (identity for L2 — the result stays
+// squared, l2.rs:97-99 — and neg_score for the dot product, dot_product.rs:96-98).  Used by k-means only.
+float orc_lane_conforming(int metric, int lanes, const float* a, const float* b, size_t n) {
+    float acc[16] = {0};
+    if (lanes != 4 && lanes != 8 && lanes != 16) return NAN;
+    for (size_t c = 0; c + lanes <= n; c += lanes)
+        for (int j = 0; j < lanes; ++j) {
+            if (metric == METRIC_L2) { float df = a[c + j] - b[c + j]; acc[j] = acc[j] + df * df; }
+            else acc[j] = acc[j] + a[c + j] * b[c + j];
+        }
+    float r = 0.0f;
+    for (int j = 0; j < lanes; ++j) r = r + acc[j];
+    return metric == METRIC_L2 ? r : -r;
+}
 
 // distances of one query against a row-major base (metric 0 = sqrt L2, 1 = neg dot, 2 = squared L2)
 void orc_distance_many(int metric, const float* q, const float* base, size_t n, size_t d, float* out) {

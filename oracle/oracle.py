@@ -57,6 +57,7 @@ def _u8buf(b):
 def _declare(L):
     f = C.c_float
     fp = C.POINTER(C.c_float)
+    L.orc_lane_conforming.restype = C.c_float
     for name in ("orc_l2_squared", "orc_l2", "orc_l2_scalar", "orc_dot", "orc_dot_scalar"):
         fn = getattr(L, name)
         fn.restype = f
@@ -99,6 +100,12 @@ def dot(a, b):
 def dot_scalar(a, b):
     a, b = _f32(a), _f32(b)
     return float(lib().orc_dot_scalar(_p(a, C.c_float), _p(b, C.c_float), a.size))
+
+
+def lane_conforming(metric, lanes, a, b):
+    """LaneConformingDistanceCalculator<LANES, D>::calculate_squared (lane_conforming.rs:22-26)."""
+    a, b = _f32(a), _f32(b)
+    return float(lib().orc_lane_conforming(C.c_int(metric), C.c_int(lanes), _p(a, C.c_float), _p(b, C.c_float), a.size))
 
 
 def distance_many(metric, q, base):

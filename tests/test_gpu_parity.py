@@ -213,6 +213,17 @@ def test_flat_nan_is_an_error(ctx):
     assert ids.tolist() == [[0, 1]]
 
 
+@pytest.mark.parametrize("lanes,d,metric", [(4, 16, 0), (8, 128, 0), (16, 768, 0), (16, 128, 1), (4, 100, 1), (8, 24, 0)])
+def test_lane_conforming_distance(ctx, oracle, lanes, d, metric):
+    # D3: LaneConformingDistanceCalculator (k-means' distance): bit-identical to the oracle
+    rng = np.random.default_rng(lanes * d)
+    a = (rng.standard_normal((50, d)) * 10).astype(np.float32)
+    b = (rng.standard_normal((50, d)) * 10).astype(np.float32)
+    got = ctx.lane_conforming_distance(a, b, lanes, metric)
+    want = np.array([oracle.lane_conforming(metric, lanes, a[i], b[i]) for i in range(50)], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 # ----------------------------------------------------------------------------------- IVF (I1-I3)
 def _ivf_case(oracle, ctx, n, d, L, seed, quant=None, cpv=1, doc_base=100):
     from muopdb_amd.index import BlockBasedIvf, ProductQuantizer

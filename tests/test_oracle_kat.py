@@ -134,6 +134,28 @@ def test_distance_simd_vs_scalar(oracle, d):
     assert abs(oracle.l2_squared(a, b) - ref * ref) < 1e-4 * max(1.0, ref * ref)
 
 
+@pytest.mark.parametrize("lanes", [4, 8, 16])
+def test_lane_conforming_matches_cascade(oracle, lanes):
+    # lane_conforming.rs:36-57: LaneConforming<4, D>::calculate_squared vs D::calculate_squared on d=16, eps 1e-5;
+    # also pinned structurally: with d == lanes the single pass IS the cascade's pass, so the bits agree
+    rng = np.random.default_rng(lanes)
+    a, b = rng.random(16, dtype=np.float32), rng.random(16, dtype=np.float32)
+    assert abs(oracle.lane_conforming(0, lanes, a, b) - oracle.l2_squared(a, b)) < 1e-5
+    assert abs(oracle.lane_conforming(1, lanes, a, b) - oracle.dot(a, b)) < 1e-5
+    a, b = a[:lanes], b[:lanes]
+    assert np.float32(oracle.lane_conforming(0, lanes, a, b)).tobytes() == np.float32(oracle.l2_squared(a, b)).tobytes()
+    # independent numpy float32 restatement of accumulate_lanes + ordered reduce_sum
+    a, b = rng.random(16 * 6, dtype=np.float32) * 50, rng.random(16 * 6, dtype=np.float32) * 50
+    acc = np.zeros(lanes, np.float32)
+    for c in range(0, a.size, lanes):
+        df = a[c:c + lanes] - b[c:c + lanes]
+        acc = acc + df * df
+    r = np.float32(0)
+    for v in acc:
+        r = np.float32(r + v)
+    assert np.float32(oracle.lane_conforming(0, lanes, a, b)).tobytes() == r.tobytes()
+
+
 def test_distance_association_is_lanewise(oracle):
     # The cascade is lane-wise partial sums then an ordered horizontal sum (l2.rs:37-67, 77-89):
     # restate it independently in numpy float32 and require bit equality.
