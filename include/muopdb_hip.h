@@ -157,6 +157,14 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
 mdb_status mdb_flat_topk(mdb_ctx* ctx, const float* base, size_t n, size_t d, const float* queries, size_t b,
                          mdb_metric metric, size_t k, uint32_t* ids_out, float* dist_out);
 
+/* IvfBuilder::build_posting_lists, assignment step (ivf/builder.rs:267-326): for every
+ * vector the max_clusters_per_vector nearest centroids by SQUARED L2 (ordered by (distance, centroid index)),
+ * of which those with |d - nearest| <= nearest * distance_threshold are kept.  centroid_ids_out
+ * [n][max_clusters_per_vector] (UINT32_MAX padded), counts_out [n]; `mem` applies to every pointer. */
+mdb_status mdb_ivf_assign(mdb_ctx* ctx, const float* centroids, size_t num_centroids, const float* vectors, size_t n, size_t d,
+                          size_t max_clusters_per_vector, float distance_threshold, mdb_mem mem, uint32_t* centroid_ids_out,
+                          uint32_t* counts_out);
+
 /* ---------------------------------------------------------------- IVF
  * BlockBasedIvf::new_with_offset ivf/block_based/index.rs:94-138: `index_bytes` is the IVF
  * `index` file (container: ivf/block_based/storage.rs:52-138), `vectors_bytes` the `vectors`

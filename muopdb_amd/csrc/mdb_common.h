@@ -18,6 +18,7 @@
 #define MDB_BLOCK 256        // threads per scan block (4 tiles per round)
 #define MDB_KEY_MAX 0xFFFFFFFFFFFFFFFFull
 #define MDB_MAX_K 2048       // largest top-k / ef served by the on-chip selectors
+#define MDB_METRIC_L2SQ 2     // internal: L2 cascade WITHOUT the final sqrt (L2DistanceCalculator::calculate_squared)
 
 struct mdb_ctx {
     int device = 0;
@@ -132,7 +133,7 @@ inline DistPlan make_plan(int d, int metric) {
     p.d = d;
     p.d4 = (d + 3) / 4;
     int rem = d, off = 0;
-    if (metric == MDB_METRIC_L2) {
+    if (metric != MDB_METRIC_DOT) {
         p.n16 = rem / 16; off += p.n16 * 16; rem -= p.n16 * 16;
         p.off8 = off; p.n8 = rem / 8; off += p.n8 * 8; rem -= p.n8 * 8;
         p.off4 = off; p.n4 = rem / 4; off += p.n4 * 4; rem -= p.n4 * 4;

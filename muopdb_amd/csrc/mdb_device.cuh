@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t key_id(uint64_t k) { return (uint32_t)k; }
 // ------------------------------------------------------------------------------------------ exact distances
 template <int METRIC>
 __device__ __forceinline__ float acc_term(float acc, float a, float b) {
-    if (METRIC == MDB_METRIC_L2) {
+    if (METRIC != MDB_METRIC_DOT) {
         float diff = __fsub_rn(a, b);
         return __fadd_rn(acc, __fmul_rn(diff, diff));
     } else {
@@ -156,7 +156,7 @@ __device__ __forceinline__ void exact_sums(const Loader& ld, const float* __rest
 // DistanceCalculator::calculate: sqrt for L2 (l2.rs:72-74), negation for dot (dot_product.rs:25-27)
 template <int METRIC>
 __device__ __forceinline__ float finish_distance(float raw) {
-    return METRIC == MDB_METRIC_L2 ? mdb_sqrtf(raw) : -raw;
+    return METRIC == MDB_METRIC_L2 ? mdb_sqrtf(raw) : (METRIC == MDB_METRIC_DOT ? -raw : raw);
 }
 
 // ------------------------------------------------------------------------------------------ BlockSelect

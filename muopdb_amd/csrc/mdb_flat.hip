@@ -226,6 +226,8 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     ctx->prof_on = saved;
     if (metric == MDB_METRIC_L2)
         MDB_TRY(launch_flat_scan<MDB_METRIC_L2>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial, gate));
+    else if (metric == MDB_METRIC_L2SQ)
+        MDB_TRY(launch_flat_scan<MDB_METRIC_L2SQ>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial, gate));
     else
         MDB_TRY(launch_flat_scan<MDB_METRIC_DOT>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial, gate));
     }
@@ -336,6 +338,79 @@ mdb_status mdb_flat_topk(mdb_ctx* ctx, const float* base, size_t n, size_t d, co
     mdb_status st = mdb_flat_search(f, queries, b, k, MDB_MEM_HOST, ids_out, dist_out, nullptr);
     mdb_flat_free(f);
     return st;
+}
+
+// ---------------------------------------------------------------- IvfBuilder::build_posting_lists, assignment step
+// keys [n][mc] ascending by (squared distance, centroid) -> accepted centroid ids: |d - nearest| <= nearest * thr
+// (ivf/builder.rs:305-321; f32 arithmetic), in key order, padded with UINT32_MAX
+__global__ void assign_filter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, size_t n, int mc,
+                                     float thr, uint32_t* __restrict__ ids_out, uint32_t* __restrict__ counts_out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)counts[i];
+    const float nearest = c > 0 ? key_dist(keys[i * mc]) : 0.0f;
+    int acc = 0;
+    for (int j = 0; j < mc; ++j) {
+        uint32_t id = 0xFFFFFFFFu;
+        if (j < c) {
+            const float dd = key_dist(keys[i * mc + j]);
+            if (fabsf(__fsub_rn(dd, nearest)) <= __fmul_rn(nearest, thr)) id = key_id(keys[i * mc + j]);
+        }
+        if (id != 0xFFFFFFFFu) ids_out[i * mc + acc++] = id;
+    }
+    for (int j = acc; j < mc; ++j) ids_out[i * mc + j] = 0xFFFFFFFFu;
+    counts_out[i] = (uint32_t)acc;
+}
+
+mdb_status mdb_ivf_assign(mdb_ctx* ctx, const float* centroids, size_t num_centroids, const float* vectors, size_t n, size_t d,
+                          size_t max_clusters_per_vector, float distance_threshold, mdb_mem mem, uint32_t* centroid_ids_out,
+                          uint32_t* counts_out) {
+    if (!ctx || (!centroids && num_centroids) || (!vectors && n) || !centroid_ids_out || !counts_out || d == 0) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t mc = max_clusters_per_vector;
+    if (mc == 0 || mc > num_centroids)
+        return mdb_fail(ctx, MDB_ERR_OUT_OF_RANGE, "max_clusters_per_vector=%zu out of range (num_centroids=%zu): the reference panics in select_nth_unstable_by", mc, num_centroids);
+    if (mc > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "max_clusters_per_vector=%zu exceeds %d", mc, MDB_MAX_K);
+    if (n == 0) return MDB_OK;
+    // centroids -> tile store
+    TileStore cs;
+    {
+        const float* d_rows = centroids;
+        DevBuf<float> staging;
+        if (mem == MDB_MEM_HOST) {
+            if (staging.alloc(num_centroids * d) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "centroid staging alloc");
+            MDB_HIP(ctx, hipMemcpyAsync(staging.p, centroids, num_centroids * d * 4, hipMemcpyHostToDevice, ctx->stream));
+            d_rows = staging.p;
+        }
+        MDB_TRY(tiles_from_rows(ctx, d_rows, num_centroids, (int)d, cs));
+        MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const size_t CH = 1 << 16;  // vectors per pass
+    void *keys, *cnts, *dids, *dcn;
+    MDB_TRY(mdb_scratch(ctx, 5, CH * mc * 8, &keys));
+    MDB_TRY(mdb_scratch(ctx, 6, CH * 4, &cnts));
+    MDB_TRY(mdb_scratch(ctx, 2, CH * mc * 4, &dids));
+    MDB_TRY(mdb_scratch(ctx, 3, CH * 4, &dcn));
+    for (size_t s0 = 0; s0 < n; s0 += CH) {
+        const size_t b = std::min(CH, n - s0);
+        float* dq;
+        int qstride;
+        MDB_TRY(stage_queries(ctx, 0, vectors + s0 * d, b, (int)d, mem, (b + 3) / 4 * 4, &dq, &qstride));
+        // L2DistanceCalculator::calculate_squared (:276) — no sqrt
+        MDB_TRY(flat_topk_keys(ctx, view_of(cs), MDB_METRIC_L2SQ, dq, qstride, b, mc, (uint64_t*)keys, (uint32_t*)cnts, false));
+        uint32_t* oi = mem == MDB_MEM_DEVICE ? centroid_ids_out + s0 * mc : (uint32_t*)dids;
+        uint32_t* oc = mem == MDB_MEM_DEVICE ? counts_out + s0 : (uint32_t*)dcn;
+        assign_filter_kernel<<<dim3((unsigned)((b + 255) / 256)), 256, 0, ctx->stream>>>((const uint64_t*)keys, (const uint32_t*)cnts, b,
+                                                                                         (int)mc, distance_threshold, oi, oc);
+        MDB_HIP(ctx, hipGetLastError());
+        if (mem == MDB_MEM_HOST) {
+            MDB_HIP(ctx, hipMemcpyAsync(centroid_ids_out + s0 * mc, dids, b * mc * 4, hipMemcpyDeviceToHost, ctx->stream));
+            MDB_HIP(ctx, hipMemcpyAsync(counts_out + s0, dcn, b * 4, hipMemcpyDeviceToHost, ctx->stream));
+            MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return mdb_check_flags(ctx);
 }
 
 }  // extern "C"

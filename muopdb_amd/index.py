@@ -341,6 +341,31 @@ class BlockBasedHnsw:
                                                         C.c_void_p(scores_ptr), C.c_void_p(counts_ptr)))
 
 
+def ivf_assign(ctx, centroids, vectors, max_clusters_per_vector=1, distance_threshold=0.1):
+    """IvfBuilder::build_posting_lists' assignment step (rs/index/src/ivf/builder.rs:267-326) on the GPU:
+    (centroid ids [n][mc] UINT32_MAX padded, counts [n])."""
+    c, v = L.f32(centroids), L.f32(vectors)
+    c = c.reshape(-1, c.shape[-1]); v = v.reshape(-1, v.shape[-1])
+    ids = np.empty((v.shape[0], max_clusters_per_vector), np.uint32)
+    cnt = np.empty(v.shape[0], np.uint32)
+    ctx.check(ctx.lib.mdb_ivf_assign(ctx.h, L.ptr(c, C.c_float), C.c_size_t(c.shape[0]), L.ptr(v, C.c_float), C.c_size_t(v.shape[0]),
+                                     C.c_size_t(v.shape[1]), C.c_size_t(max_clusters_per_vector), C.c_float(distance_threshold),
+                                     C.c_int(L.MEM_HOST), L.ptr(ids, C.c_uint32), L.ptr(cnt, C.c_uint32)))
+    return ids, cnt
+
+
+def posting_lists_from_assignment(ids, counts, num_lists):
+    """IvfBuilder::build_posting_lists :328-343: per centroid the sorted point ids (u64)."""
+    n, mc = ids.shape
+    mask = np.arange(mc)[None, :] < counts[:, None]
+    cent = ids[mask].astype(np.int64)
+    pts = np.repeat(np.arange(n, dtype=np.uint64), counts)
+    order = np.lexsort((pts, cent))
+    cent, pts = cent[order], pts[order]
+    bounds = np.searchsorted(cent, np.arange(num_lists + 1))
+    return [pts[bounds[i]:bounds[i + 1]] for i in range(num_lists)]
+
+
 # ------------------------------------------------------------------------------------------ SPANN
 class Spann:
     """rs/index/src/spann/index.rs"""

@@ -979,6 +979,35 @@ float orc_lane_conforming(int metric, int lanes, const float* a, const float* b,
     return metric == METRIC_L2 ? r : -r;
 }
 
+// IvfBuilder::build_posting_lists, assignment of one batch of vectors (rs/index/src/ivf/builder.rs:267-326):
+// find_nearest_centroids = the max_clusters nearest centroids by calculate_squared (select_nth_unstable_by +
+// truncate: the SET of the nearest; ties at the cut are implementation-defined there, (distance, index)
+// order here), nearest_distance = their minimum, a centroid is accepted when
+// |d - nearest| <= nearest * distance_threshold (f32).  ids_out [n][max_clusters] in (distance, index)
+// order, UINT32_MAX padded; returns 1 if a distance was NaN (NotNan::new(..).unwrap() panics).
+int orc_ivf_assign(const float* centroids, size_t num_centroids, const float* vectors, size_t n, size_t d, size_t max_clusters,
+                   float distance_threshold, uint32_t* ids_out, uint32_t* counts_out) {
+    if (max_clusters == 0 || max_clusters > num_centroids) return 2;
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (long long i = 0; i < (long long)n; ++i) {
+        std::vector<std::pair<float, uint32_t>> ds(num_centroids);
+        for (size_t c = 0; c < num_centroids; ++c) {
+            float v = l2_squared(vectors + (size_t)i * d, centroids + c * d, d);
+            if (v != v) bad = 1;
+            ds[c] = {v, (uint32_t)c};
+        }
+        std::partial_sort(ds.begin(), ds.begin() + max_clusters, ds.end());
+        float nearest = ds[0].first;
+        uint32_t acc = 0;
+        for (size_t j = 0; j < max_clusters; ++j)
+            if (std::fabs(ds[j].first - nearest) <= nearest * distance_threshold) ids_out[(size_t)i * max_clusters + acc++] = ds[j].second;
+        for (size_t j = acc; j < max_clusters; ++j) ids_out[(size_t)i * max_clusters + j] = 0xFFFFFFFFu;
+        counts_out[i] = acc;
+    }
+    return bad;
+}
+
 // distances of one query against a row-major base (metric 0 = sqrt L2, 1 = neg dot, 2 = squared L2)
 void orc_distance_many(int metric, const float* q, const float* base, size_t n, size_t d, float* out) {
     for (size_t i = 0; i < n; ++i) {

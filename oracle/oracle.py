@@ -108,6 +108,22 @@ def lane_conforming(metric, lanes, a, b):
     return float(lib().orc_lane_conforming(C.c_int(metric), C.c_int(lanes), _p(a, C.c_float), _p(b, C.c_float), a.size))
 
 
+def ivf_assign(centroids, vectors, max_clusters_per_vector, distance_threshold):
+    """IvfBuilder::build_posting_lists' assignment (ivf/builder.rs:267-326) -> (ids [n][mc] UINT32_MAX padded, counts [n])."""
+    c, v = _f32(centroids), _f32(vectors)
+    c = c.reshape(-1, c.shape[-1]); v = v.reshape(-1, v.shape[-1])
+    ids = np.empty((v.shape[0], max_clusters_per_vector), np.uint32)
+    cnt = np.empty(v.shape[0], np.uint32)
+    rc = lib().orc_ivf_assign(_p(c, C.c_float), C.c_size_t(c.shape[0]), _p(v, C.c_float), C.c_size_t(v.shape[0]),
+                              C.c_size_t(v.shape[1]), C.c_size_t(max_clusters_per_vector), C.c_float(distance_threshold),
+                              _p(ids, C.c_uint32), _p(cnt, C.c_uint32))
+    if rc == 2:
+        raise IndexError("max_clusters_per_vector out of range")
+    if rc:
+        raise ValueError("NaN distance")
+    return ids, cnt
+
+
 def distance_many(metric, q, base):
     """metric: 0 sqrt-L2, 1 neg-dot, 2 squared L2.  Returns f32[n]."""
     q, base = _f32(q), _f32(base)

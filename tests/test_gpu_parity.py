@@ -224,6 +224,22 @@ def test_lane_conforming_distance(ctx, oracle, lanes, d, metric):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("n,d,L,mc,thr", [(20000, 32, 64, 3, 0.1), (70000, 16, 10, 1, 0.1), (5000, 128, 300, 8, 0.5), (3000, 7, 5, 5, 0.0)])
+def test_ivf_assign_matches_builder_rule(ctx, oracle, n, d, L, mc, thr):
+    # IvfBuilder::build_posting_lists' assignment (squared L2, threshold rule)
+    from muopdb_amd.index import ivf_assign, posting_lists_from_assignment
+    from muopdb_amd import lib as Lb
+    v = H.sift_like(n, d, n_clusters=max(L // 2, 2), seed=n)
+    cent = H.kmeans(v[:4000], L, iters=3, seed=1)
+    ids, cnt = ivf_assign(ctx, cent, v, mc, thr)
+    oids, ocnt = oracle.ivf_assign(cent, v, mc, thr)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids)
+    pls = posting_lists_from_assignment(ids, cnt, cent.shape[0])
+    assert sum(len(p) for p in pls) == int(cnt.sum()) and all(np.all(np.diff(p.astype(np.int64)) > 0) for p in pls if len(p) > 1)
+    with pytest.raises(Lb.MuopdbError):
+        ivf_assign(ctx, cent, v[:10], cent.shape[0] + 1, thr)
+
+
 # ----------------------------------------------------------------------------------- IVF (I1-I3)
 def _ivf_case(oracle, ctx, n, d, L, seed, quant=None, cpv=1, doc_base=100):
     from muopdb_amd.index import BlockBasedIvf, ProductQuantizer

@@ -407,3 +407,16 @@ def test_hnsw_search_properties(oracle):
     assert hits >= 0.9 * 200
     evals, expanded = h.stats()
     assert evals > expanded > 0
+
+
+def test_ivf_assign_rule(oracle):
+    # ivf/builder.rs:305-321: |d - nearest| <= nearest * threshold on SQUARED distances, among the mc nearest
+    cent = np.array([[0, 0], [10, 0], [0, 11], [100, 100]], np.float32)
+    v = np.array([[5, 0], [1, 0], [5.2, 0], [0, 0]], np.float32)
+    ids, cnt = oracle.ivf_assign(cent, v, 2, 0.1)
+    assert cnt.tolist() == [2, 1, 1, 1]          # 25 vs 25 -> both; 1 vs 81 -> one; 23.04 vs 27.04: 4 > 2.304 -> one; 0 vs 100: 100 > 0 -> one
+    assert ids[0].tolist() == [0, 1] and ids[1, 0] == 0 and ids[2, 0] == 1
+    ids3, cnt3 = oracle.ivf_assign(cent, v, 3, 10.0)
+    assert cnt3.tolist() == [3, 1, 3, 1]          # 1 vs 81: 80 > 10; nearest == 0: only exact zeros pass (nearest * thr == 0)
+    with pytest.raises(IndexError):
+        oracle.ivf_assign(cent, v, 5, 0.1)
