@@ -84,7 +84,26 @@ __device__ __forceinline__ void exact_sums(const Loader& ld, const float* __rest
         for (int i = 0; i < QT; ++i)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
-        for (int c = 0; c < p.n16; ++c) {
+        int c = 0;
+        // two chunks per iteration: 8 independent 16-byte loads in flight per lane (the accumulation
+        // order per lane is unchanged: chunk c, then chunk c+1)
+        for (; c + 2 <= p.n16; c += 2) {
+            float4 x0 = ld.get4(4 * c + 0), x1 = ld.get4(4 * c + 1), x2 = ld.get4(4 * c + 2), x3 = ld.get4(4 * c + 3);
+            float4 y0 = ld.get4(4 * c + 4), y1 = ld.get4(4 * c + 5), y2 = ld.get4(4 * c + 6), y3 = ld.get4(4 * c + 7);
+            float xv[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
+                            x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+            float yv[16] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w,
+                            y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
+#pragma unroll
+            for (int i = 0; i < QT; ++i) {
+                const float* q = qbase + (size_t)i * qstride + 16 * c;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[i][j] = acc_term<METRIC>(acc[i][j], q[j], xv[j]);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[i][j] = acc_term<METRIC>(acc[i][j], q[16 + j], yv[j]);
+            }
+        }
+        for (; c < p.n16; ++c) {
             float4 x0 = ld.get4(4 * c + 0), x1 = ld.get4(4 * c + 1), x2 = ld.get4(4 * c + 2), x3 = ld.get4(4 * c + 3);
             float xv[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
                             x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};

@@ -127,24 +127,38 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_scan_kernel(const float4* __re
     }
 }
 
-// one block per query: stream `per_query` candidate keys, keep the k smallest, ascending
-__global__ __launch_bounds__(MDB_BLOCK) void merge_keys_kernel(const uint64_t* __restrict__ partial, size_t per_query,
-                                                               int k, uint64_t* __restrict__ out, uint32_t* __restrict__ counts,
-                                                               const uint32_t* __restrict__ gate = nullptr) {
+// one block per query: stream `per_query` candidate keys, keep the k smallest, ascending.  The partial
+// lists are sorted, so the first round already holds good keys and warm_start bounds the rest.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void merge_keys_kernel(const uint64_t* __restrict__ partial, size_t per_query, int k,
+                                                           uint64_t* __restrict__ out, uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ gate = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (gate && *gate == 0) return;
-    BlockSelect<MDB_BLOCK> sel;
+    BlockSelect<BLOCK> sel;
     sel.init(lds, k);
     const uint64_t* src = partial + (size_t)blockIdx.x * per_query;
-    for (size_t base = 0; base < per_query; base += MDB_BLOCK) {
+    for (size_t base = 0; base < per_query; base += BLOCK) {
         size_t i = base + threadIdx.x;
-        sel.offer(i < per_query ? src[i] : MDB_KEY_MAX);
+        uint64_t key = i < per_query ? src[i] : MDB_KEY_MAX;
+        if (base == 0) sel.warm_start(key);
+        sel.offer(key);
         sel.round_end();
     }
     sel.finish();
     uint32_t c = sel.count();
-    for (int j = threadIdx.x; j < k; j += MDB_BLOCK) out[(size_t)blockIdx.x * k + j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+    for (int j = threadIdx.x; j < k; j += BLOCK) out[(size_t)blockIdx.x * k + j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
     if (threadIdx.x == 0 && counts) counts[blockIdx.x] = c;
+}
+
+static void launch_merge_keys(mdb_ctx* ctx, const uint64_t* d_partial, size_t per_query, size_t b, size_t k, uint64_t* d_out,
+                              uint32_t* d_counts, const uint32_t* gate) {
+    if (per_query >= 2048)  // many partial lists (one query over a large base): 4x fewer rounds
+        merge_keys_kernel<1024><<<dim3((unsigned)b), 1024, BlockSelect<1024>::lds_bytes((int)k), ctx->stream>>>(d_partial, per_query, (int)k,
+                                                                                                               d_out, d_counts, gate);
+    else
+        merge_keys_kernel<MDB_BLOCK><<<dim3((unsigned)b), MDB_BLOCK, BlockSelect<MDB_BLOCK>::lds_bytes((int)k), ctx->stream>>>(
+            d_partial, per_query, (int)k, d_out, d_counts, gate);
 }
 
 __global__ void unpack_keys_kernel(const uint64_t* __restrict__ keys, size_t total, uint32_t* __restrict__ ids,
@@ -164,8 +178,7 @@ __global__ void unpack_keys_kernel(const uint64_t* __restrict__ keys, size_t tot
 mdb_status merge_keys(mdb_ctx* ctx, const uint64_t* d_partial, size_t per_query, size_t b, size_t k, uint64_t* d_out,
                       uint32_t* d_counts) {
     if (b == 0) return MDB_OK;
-    merge_keys_kernel<<<dim3((unsigned)b), MDB_BLOCK, BlockSelect<MDB_BLOCK>::lds_bytes((int)k), ctx->stream>>>(
-        d_partial, per_query, (int)k, d_out, d_counts);
+    launch_merge_keys(ctx, d_partial, per_query, b, k, d_out, d_counts, nullptr);
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
 }
@@ -231,8 +244,7 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     else
         MDB_TRY(launch_flat_scan<MDB_METRIC_DOT>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial, gate));
     }
-    merge_keys_kernel<<<dim3((unsigned)b), MDB_BLOCK, BlockSelect<MDB_BLOCK>::lds_bytes((int)k), ctx->stream>>>(
-        (const uint64_t*)partial, (size_t)nblk * k, (int)k, d_keys, d_counts, gate);
+    launch_merge_keys(ctx, (const uint64_t*)partial, (size_t)nblk * k, b, k, d_keys, d_counts, gate);
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
 }
