@@ -207,14 +207,7 @@ __device__ __forceinline__ void cand_drop_dead(const uint64_t* C, int& cbase, in
 }
 
 
-// ---- register-resident state (ef <= 256): wave 0 keeps the working set (256 slots) and the
-// candidates (512 slots) UNSORTED in VGPRs, slot idx = lane + 64*r, split into an order-preserving
-// distance word and an id word.  Everything the traversal asks of the two BinaryHeaps becomes a few
-// single-issue instructions: counts are ballots of register compares, min / max are 6-step DPP
-// reductions, replace / append are exec-masked moves.  (A lone wave pays ~6-8 cycles per dependent
-// instruction, so instruction count — not LDS or HBM bandwidth — is what the per-step cost is made of.)
-#define WREGS 4
-#define CREGS 8
+// ---- wave-wide reductions for the register-resident beam (hnsw_beam_kernel)
 #define SLOT_EMPTY 0xFFFFFFFFu
 
 #define MDB_DPP_U32(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rmask), 0xF, false))
@@ -237,48 +230,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// slot (uniform idx) <- (d, id)
-template <int R>
-__device__ __forceinline__ void slots_write(uint32_t (&sd)[R], uint32_t (&si)[R], int idx, uint32_t d, uint32_t id, int lane) {
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if ((idx >> 6) == r && lane == (idx & 63)) { sd[r] = d; si[r] = id; }
-}
-// the slot whose distance word is `m` and whose id is extreme among equal distances
-// (WANT_MAX_ID: largest id, else smallest); limit = number of usable slots.  Returns idx, sets id.
-template <int R, bool WANT_MAX_ID>
-__device__ __forceinline__ int slots_locate(const uint32_t (&sd)[R], const uint32_t (&si)[R], uint32_t m, int limit, int lane,
-                                            uint32_t& id_out) {
-    unsigned long long b[R];
-    int total = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        b[r] = __ballot(lane + 64 * r < limit && sd[r] == m);
-        total += __popcll(b[r]);
-    }
-    if (total > 1) {  // distance tie: pick by id
-        uint32_t li = WANT_MAX_ID ? 0u : 0xFFFFFFFFu;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (lane + 64 * r < limit && sd[r] == m) li = WANT_MAX_ID ? max(li, si[r]) : min(li, si[r]);
-        uint32_t mid = WANT_MAX_ID ? wave_max_u32(li) : wave_min_u32(li);
-#pragma unroll
-        for (int r = 0; r < R; ++r) b[r] = __ballot(lane + 64 * r < limit && sd[r] == m && si[r] == mid);
-    }
-    int idx = 0;
-    uint32_t id = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (b[r]) {
-            int l = __ffsll((long long)b[r]) - 1;
-            idx = 64 * r + l;
-            id = (uint32_t)__builtin_amdgcn_readlane((int)si[r], l);
-        }
-    id_out = id;
-    return idx;
-}
-
-template <int METRIC, bool VIS_LDS, bool REGS, int N16T>
+// hnsw_search_kernel — the general traversal kernel (any ef <= 2*MDB_MAX_K): the working set W and the
+// candidates C are SORTED arrays in LDS (insert = ballot-counted shift).  The bench configuration
+// (ef <= 256) runs hnsw_beam_kernel below instead.
+template <int METRIC, bool VIS_LDS, int N16T>
 __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint64_t* W = (uint64_t*)lds;
@@ -316,9 +271,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
                                                        : group16_distance<METRIC>((rowptr), qs, a.p, j)))
     // wave-0 uniform state
     int wsize = 0, cn = 0, cbase = 0;
-    uint32_t wd[WREGS], wi[WREGS], cd[CREGS], ci[CREGS];  // REGS mode slots
-    uint32_t fmax_o = 0, fmax_id = 0;                      // REGS: furthest element of the working set ...
-    int fmax_idx = 0;                                      // ... and its slot
+    uint32_t fmax_o = 0;  // distance image of furthest (the last element of W)
     unsigned long long evals = 0, expanded = 0;
     bool nan_seen = false, overflow = false;
     uint32_t ep = u.entry_point;
@@ -331,14 +284,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
             if (lane < 16) d0 = MDB_GROUP_DIST(vecs + (size_t)ep * a.dpad);
             d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), 0));
             if (d0 != d0) nan_seen = true;
-            if (REGS) {
-#pragma unroll
-                for (int r = 0; r < WREGS; ++r) { wd[r] = SLOT_EMPTY; wi[r] = 0; }
-#pragma unroll
-                for (int r = 0; r < CREGS; ++r) { cd[r] = SLOT_EMPTY; ci[r] = 0; }
-                if (lane == 0) { wd[0] = f32_orderable(d0); wi[0] = ep; cd[0] = wd[0]; ci[0] = ep; }
-                fmax_o = f32_orderable(d0); fmax_id = ep; fmax_idx = 0;
-            } else if (lane == 0) { W[0] = make_key(d0, ep); C[0] = cand_key(d0, ep); }
+            if (lane == 0) { W[0] = make_key(d0, ep); C[0] = cand_key(d0, ep); }
             wsize = 1; cn = 1; cbase = 0;
             evals += 1;
         }
@@ -349,19 +295,9 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
                 bool go = false;
                 uint32_t cur = 0;
                 if (!overflow) {
-                    if (REGS) {
-                        // candidates.pop(): smallest distance, LARGEST id among equals (BinaryHeap<(-d,id)>)
-                        uint32_t lm = cd[0];
-#pragma unroll
-                        for (int r = 1; r < CREGS; ++r) lm = min(lm, cd[r]);
-                        const uint32_t m = wave_min_u32(lm);
+                    if (cn > 0) {
+                        // candidates.pop(): smallest distance, LARGEST id among equals (BinaryHeap<(-d,id)>);
                         // `distance > furthest.distance` -> stop (index.rs:246-248), on the integer images
-                        if (m != SLOT_EMPTY && !(m > fmax_o)) {
-                            const int idx = slots_locate<CREGS, true>(cd, ci, m, 64 * CREGS, lane, cur);
-                            slots_write<CREGS>(cd, ci, idx, SLOT_EMPTY, 0, lane);
-                            go = true;
-                        }
-                    } else if (cn > 0) {
                         uint64_t ck = C[(cbase + cn - 1) & cmask];
                         fmax_o = (uint32_t)(W[wsize - 1] >> 32);
                         if (!((uint32_t)(ck >> 32) > fmax_o)) { cn -= 1; cur = cand_id(ck); go = true; }
@@ -429,7 +365,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
                     const bool have = have0 && d == d;
                     const uint32_t od = f32_orderable(d);
                     const bool full = wsize >= ef;
-                    if (!REGS) fmax_o = (uint32_t)(W[wsize - 1] >> 32);
+                    fmax_o = (uint32_t)(W[wsize - 1] >> 32);
                     unsigned long long surv = __ballot(have && (!full || od < fmax_o));
                     unsigned long long accepted = 0;
                     const int wsize0 = wsize;
@@ -438,17 +374,12 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
                         surv &= surv - 1;
                         const uint32_t ds = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
                         int cnt = __popcll(__ballot(have && od <= ds) & ((1ull << sidx) - 1ull));
-                        if (REGS) {
-#pragma unroll
-                            for (int r = 0; r < WREGS; ++r) cnt += __popcll(__ballot(wd[r] <= ds));  // EMPTY never counts
-                        } else {
-                            for (int r0 = 0; r0 < wsize0 && cnt < ef; r0 += 64) {
-                                int idx = r0 + lane;
-                                bool le = idx < wsize0 && (uint32_t)(W[idx] >> 32) <= ds;
-                                unsigned long long b = __ballot(le);
-                                cnt += __popcll(b);
-                                if (b != ~0ull) break;  // W ascending: nothing further is <= ds
-                            }
+                        for (int r0 = 0; r0 < wsize0 && cnt < ef; r0 += 64) {
+                            int idx = r0 + lane;
+                            bool le = idx < wsize0 && (uint32_t)(W[idx] >> 32) <= ds;
+                            unsigned long long b = __ballot(le);
+                            cnt += __popcll(b);
+                            if (b != ~0ull) break;  // W ascending: nothing further is <= ds
                         }
                         if (cnt < ef) accepted |= 1ull << sidx;
                     }
@@ -459,86 +390,20 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
                         accepted &= accepted - 1;
                         const uint32_t dod = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
                         const uint32_t did = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
-                        if (REGS) {
-                            // candidates.push: first free slot
-                            bool placed = false;
-#pragma unroll
-                            for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                                for (int r = 0; r < CREGS; ++r) {
-                                    if (!placed) {
-                                        unsigned long long fb = __ballot(cd[r] == SLOT_EMPTY);
-                                        if (fb) {
-                                            if (lane == __ffsll((long long)fb) - 1) { cd[r] = dod; ci[r] = did; }
-                                            placed = true;
-                                        }
-                                    }
-                                }
-                                if (!placed && pass == 0 && wsize >= ef) {
-                                    // no free slot: drop the candidates that can never be expanded
-                                    // (distance > furthest while the working set is full)
-#pragma unroll
-                                    for (int r = 0; r < CREGS; ++r)
-                                        if (cd[r] > fmax_o) cd[r] = SLOT_EMPTY;
-                                }
-                            }
-                            if (!placed) { overflow = true; break; }
-                            // working_list.push (+ pop of the maximum when over ef)
-                            if (wsize < ef) {
-                                slots_write<WREGS>(wd, wi, wsize, dod, did, lane);
-                                if (dod > fmax_o || (dod == fmax_o && did > fmax_id)) { fmax_o = dod; fmax_id = did; fmax_idx = wsize; }
-                                wsize += 1;
-                            } else if (dod < fmax_o || (dod == fmax_o && did < fmax_id)) {
-                                slots_write<WREGS>(wd, wi, fmax_idx, dod, did, lane);
-                                uint32_t lm = 0;
-#pragma unroll
-                                for (int r = 0; r < WREGS; ++r)
-                                    if (lane + 64 * r < ef) lm = max(lm, wd[r]);
-                                fmax_o = wave_max_u32(lm);
-                                fmax_idx = slots_locate<WREGS, true>(wd, wi, fmax_o, ef, lane, fmax_id);
-                            }
-                        } else {
-                            const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), sidx));
-                            if (cn >= a.cand_cap - 1) {
-                                if (wsize >= ef) cand_drop_dead(C, cbase, cmask, cn, (uint32_t)(W[wsize - 1] >> 32), lane);
-                                if (cn >= a.cand_cap - 1) { overflow = true; break; }
-                            }
-                            cand_insert(C, cbase, cmask, cn, cand_key(dd, did), lane);
-                            work_insert(W, wsize, ef, make_key(dd, did), lane);
+                        const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), sidx));
+                        if (cn >= a.cand_cap - 1) {
+                            if (wsize >= ef) cand_drop_dead(C, cbase, cmask, cn, (uint32_t)(W[wsize - 1] >> 32), lane);
+                            if (cn >= a.cand_cap - 1) { overflow = true; break; }
                         }
+                        cand_insert(C, cbase, cmask, cn, cand_key(dd, did), lane);
+                        work_insert(W, wsize, ef, make_key(dd, did), lane);
                     }
                 }
             }
         }
-        // ---- layer done.  REGS: spill the working set and sort it (block-wide bitonic in the idle
-        // candidate region) so that W[0..wsize) is ascending by (distance, id) like the LDS variant.
-        if (REGS) {
-            if (wave == 0) {
-#pragma unroll
-                for (int r = 0; r < WREGS; ++r)
-                    C[lane + 64 * r] = wd[r] == SLOT_EMPTY ? MDB_KEY_MAX : (((uint64_t)wd[r] << 32) | wi[r]);
-                if (lane == 0) misc[2] = (uint32_t)wsize;
-            }
-            __syncthreads();
-            const int n2 = 64 * WREGS;
-            for (int size = 2; size <= n2; size <<= 1) {
-                for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (int t = tid; t < (n2 >> 1); t += HNSW_BLOCK) {
-                        int lo = ((t / stride) * stride * 2) + (t % stride);
-                        int hi = lo + stride;
-                        bool up = ((lo & size) == 0);
-                        uint64_t x = C[lo], y = C[hi];
-                        if ((x > y) == up) { C[lo] = y; C[hi] = x; }
-                    }
-                    __syncthreads();
-                }
-            }
-            for (int i = tid; i < a.ef_cap; i += HNSW_BLOCK) W[i] = C[i];
-            __syncthreads();
-        } else {
-            if (wave == 0 && lane == 0) misc[2] = (uint32_t)wsize;
-            __syncthreads();
-        }
+        // ---- layer done: W is ascending by (distance, id)
+        if (wave == 0 && lane == 0) misc[2] = (uint32_t)wsize;
+        __syncthreads();
         if (layer > 0) {
             // ep = first minimum of the (distance,id)-sorted working set (index.rs:177-181)
             ep = key_id(W[0]);
@@ -1185,14 +1050,13 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         a.vis_global = (uint32_t*)vg;
     }
     ProfScope prof(ctx, 2);
-#define MDB_HNSW_LAUNCH4(METRIC, VL, RG, NF)                                                                                        \
+#define MDB_HNSW_LAUNCH4(METRIC, VL, NF)                                                                                    \
     do {                                                                                                                   \
         if (lds > 48 * 1024)                                                                                               \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel<METRIC, VL, RG, NF>,                                  \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_search_kernel<METRIC, VL, NF>,                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
-        hnsw_search_kernel<METRIC, VL, RG, NF><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                            \
+        hnsw_search_kernel<METRIC, VL, NF><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                        \
     } while (0)
-    const bool regs = ef <= 64 * WREGS && !getenv("MDB_HNSW_NO_REGS");
     // specialised distance when the whole vector is 16-lane chunks (d = 128 / 768: the configs' dims)
     const int nf = (kind != MDB_QUANT_PQ && a.p.n8 == 0 && a.p.n4 == 0 && a.p.ntail == 0 && !getenv("MDB_HNSW_GENERIC_DIST")) ? a.p.n16 : 0;
 #define MDB_BEAM_LAUNCH(METRIC, VL, NF)                                                                                     \
@@ -1202,23 +1066,22 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
         hnsw_beam_kernel<METRIC, VL, NF><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                           \
     } while (0)
-#define MDB_HNSW_LAUNCH(METRIC, VL, RG)                                                                          \
+#define MDB_HNSW_LAUNCH(METRIC, VL)                                                                              \
     do {                                                                                                           \
         if (beam) {                                                                                                \
             if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8);                                                           \
             else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48);                                                    \
             else MDB_BEAM_LAUNCH(METRIC, VL, 0);                                                                   \
-        } else if (nf == 8) MDB_HNSW_LAUNCH4(METRIC, VL, RG, 8);                                                   \
-        else if (nf == 48) MDB_HNSW_LAUNCH4(METRIC, VL, RG, 48);                                                   \
-        else MDB_HNSW_LAUNCH4(METRIC, VL, RG, 0);                                                                  \
+        } else if (nf == 8) MDB_HNSW_LAUNCH4(METRIC, VL, 8);                                                       \
+        else if (nf == 48) MDB_HNSW_LAUNCH4(METRIC, VL, 48);                                                       \
+        else MDB_HNSW_LAUNCH4(METRIC, VL, 0);                                                                      \
     } while (0)
-    const bool beam = regs && !getenv("MDB_HNSW_NO_BEAM");
+    // ef <= 256: register-resident beam; above: sorted LDS sets (MDB_HNSW_NO_BEAM forces the latter, for tests)
+    const bool beam = ef <= 256 && !getenv("MDB_HNSW_NO_BEAM");
     if (metric == MDB_METRIC_L2) {
-        if (vis_lds) { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, true, false); }
-        else { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_L2, false, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false, false); }
+        if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false);
     } else {
-        if (vis_lds) { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true, false); }
-        else { if (regs) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false, false); }
+        if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false);
     }
 #undef MDB_BEAM_LAUNCH
 #undef MDB_HNSW_LAUNCH4

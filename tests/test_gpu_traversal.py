@@ -100,6 +100,26 @@ def test_hnsw_over_pq_codes(ctx, oracle, n, d, sub, bits, metric, ef):
     assert st["distance_evals"] == evals and st["expanded_nodes"] == expanded
 
 
+def test_hnsw_general_kernel_equals_beam_kernel(ctx, oracle):
+    """hnsw_search_kernel (sorted LDS sets; serves ef > 256) must give the oracle's rows at small ef too:
+    MDB_HNSW_NO_BEAM routes ef <= 256 through it."""
+    import os
+    from muopdb_amd.index import BlockBasedHnsw
+    rng = np.random.default_rng(17)
+    v = H.sift_like(2500, 48, n_clusters=20, seed=4)
+    hidx, hvec = H.build_hnsw_files(oracle, v, list(range(2500)), max_neighbors=12, max_layers=4, ef_construction=60)
+    g = BlockBasedHnsw(ctx, hidx, hvec, 48)
+    o = oracle.BlockBasedHnsw(hidx, hvec, 48)
+    q = (v[rng.integers(0, 2500, 25)] + rng.normal(0, 4, (25, 48))).astype(np.float32)
+    os.environ["MDB_HNSW_NO_BEAM"] = "1"
+    try:
+        for k, ef in [(10, 100), (5, 8), (20, 256), (10, 600)]:
+            assert_result_rows(g.ann_search(q, k, ef), o.ann_search(q, k, ef), len(q))
+    finally:
+        del os.environ["MDB_HNSW_NO_BEAM"]
+    assert_result_rows(g.ann_search(q, 10, 600), o.ann_search(q, 10, 600), len(q))
+
+
 def test_hnsw_ties_and_duplicates(ctx, oracle):
     # many exact distance ties: pop order (largest id first) and eviction order must match
     from muopdb_amd.index import BlockBasedHnsw
