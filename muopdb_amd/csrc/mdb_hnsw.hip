@@ -234,17 +234,15 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // candidates C are SORTED arrays in LDS (insert = ballot-counted shift).  The bench configuration
 // (ef <= 256) runs hnsw_beam_kernel below instead.
 template <int METRIC, bool VIS_LDS, int N16T>
-__global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+__device__ void hnsw_general_traverse(const HnswArgs& a, const int qi, char* lds, const bool rezero_global_visited) {
     uint64_t* W = (uint64_t*)lds;
     uint64_t* C = W + a.ef_cap;
     uint32_t* nb_id = (uint32_t*)(C + a.cand_cap);
     float* nb_dist = (float*)(nb_id + a.smax);
     float* qs = nb_dist + a.smax;
     uint32_t* misc = (uint32_t*)(qs + a.dpad);  // [0] nnew (0xFFFFFFFF = stop), [1] next entry point, [2] wsize
-    uint32_t* vis = VIS_LDS ? (misc + 16) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
+    uint32_t* vis = VIS_LDS ? (misc + 16) : (a.vis_global + (size_t)qi * a.vis_words);
 
-    const int qi = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
     const int grp = tid >> 4, j = tid & 15;
@@ -255,7 +253,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
         return;
     }
     for (int i = tid; i < a.dpad; i += HNSW_BLOCK) qs[i] = a.q[(size_t)qi * a.qstride + i];
-    if (VIS_LDS)
+    if (VIS_LDS || rezero_global_visited)
         for (unsigned long long i = tid; i < a.vis_words; i += HNSW_BLOCK) vis[i] = 0;
     __syncthreads();
 
@@ -423,6 +421,13 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
     }
 }
 
+template <int METRIC, bool VIS_LDS, int N16T>
+__global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    hnsw_general_traverse<METRIC, VIS_LDS, N16T>(a, (int)blockIdx.x, lds, false);
+}
+
+
 // ==========================================================================================
 // hnsw_beam_kernel — the ef <= 256 traversal kernel (bench configuration).
 //
@@ -447,19 +452,26 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
 // goal is instruction count on wave 0's path, not bandwidth.
 // ==========================================================================================
 #define BREGS 5
+#define BEAM_LDS_C 2048
+#define BEAM_LDS_NBID (BEAM_LDS_C + 8192)
+#define BEAM_LDS_NBDIST (BEAM_LDS_NBID + 1024)
+#define BEAM_LDS_MISC (BEAM_LDS_NBDIST + 1024)
+#define BEAM_LDS_QS (BEAM_LDS_MISC + 64)
 #define BEAM_CAP (64 * BREGS)
 
 // nearest unexpanded slot in pop order (smallest distance image, LARGEST id among equals); `cdv`
 // holds the distance image of unexpanded slots and SLOT_EMPTY elsewhere.  Returns false if none.
-// hit[r] = uniform one-hot masks of the winner's slot.
+// slot_out = winner's slot (lane + 64 r) — one SGPR instead of BREGS one-hot masks: the kernel is
+// SGPR-bound and every spilled scalar costs a v_readlane on wave 0's critical path.
 __device__ __forceinline__ bool beam_best(const uint32_t (&cdv)[BREGS], const uint32_t (&bi)[BREGS], int lane, uint32_t& o_out,
-                                          uint32_t& id_out, unsigned long long (&hit)[BREGS]) {
+                                          uint32_t& id_out, int& slot_out) {
     uint32_t lm = cdv[0];
 #pragma unroll
     for (int r = 1; r < BREGS; ++r) lm = min(lm, cdv[r]);
     const uint32_t m = wave_min_u32(lm);
     o_out = m;
     if (m == SLOT_EMPTY) return false;
+    unsigned long long hit[BREGS];
     int total = 0;
 #pragma unroll
     for (int r = 0; r < BREGS; ++r) { hit[r] = __ballot(cdv[r] == m); total += __popcll(hit[r]); }
@@ -471,25 +483,33 @@ __device__ __forceinline__ bool beam_best(const uint32_t (&cdv)[BREGS], const ui
 #pragma unroll
         for (int r = 0; r < BREGS; ++r) hit[r] = __ballot(cdv[r] == m && bi[r] == mid);
     }
-    unsigned long long any = 0;
-    uint32_t sel = 0;
+    int slot = 0;
+    uint32_t id = 0;
 #pragma unroll
-    for (int r = 0; r < BREGS; ++r) { any |= hit[r]; sel = ((hit[r] >> lane) & 1ull) ? bi[r] : sel; }
-    id_out = (uint32_t)__builtin_amdgcn_readlane((int)sel, __ffsll((long long)any) - 1);
+    for (int r = 0; r < BREGS; ++r)
+        if (hit[r]) {
+            const int l = __ffsll((long long)hit[r]) - 1;
+            slot = 64 * r + l;
+            id = (uint32_t)__builtin_amdgcn_readlane((int)bi[r], l);
+        }
+    slot_out = slot;
+    id_out = id;
     return true;
 }
 
 template <int METRIC, bool VIS_LDS, int N16T>
 __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    uint64_t* W = (uint64_t*)lds;
-    uint64_t* C = W + a.ef_cap;              // [0..512): staging / sort buffer, [512..768) as u32 flags
-    uint32_t* nb_id = (uint32_t*)(C + a.cand_cap);
-    float* nb_dist = (float*)(nb_id + a.smax);
-    float* qs = nb_dist + a.smax;
-    uint32_t* misc = (uint32_t*)(qs + a.dpad);  // [0] nnew (0xFFFFFFFF = stop), [2] wsize
-    uint32_t* vis = VIS_LDS ? (misc + 16) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
-    uint32_t* stage_flag = (uint32_t*)(C + 512);
+    // FIXED LDS layout (compile-time offsets: the kernel is SGPR-bound, eight live LDS pointers are eight
+    // scalars it does not have): W 256 keys | C 1024 keys | nb_id 256 | nb_dist 256 | misc 16 | qs dpad | vis
+    uint64_t* const W = (uint64_t*)lds;
+    uint64_t* const C = (uint64_t*)(lds + BEAM_LDS_C);  // [0..512): staging / sort buffer, [512..768) as u32 flags
+    uint32_t* const nb_id = (uint32_t*)(lds + BEAM_LDS_NBID);
+    float* const nb_dist = (float*)(lds + BEAM_LDS_NBDIST);
+    uint32_t* const misc = (uint32_t*)(lds + BEAM_LDS_MISC);  // [0] nnew (0xFFFFFFFF = stop), [2] wsize, [3] overflow
+    float* const qs = (float*)(lds + BEAM_LDS_QS);
+    uint32_t* vis = VIS_LDS ? (uint32_t*)(lds + BEAM_LDS_QS + (size_t)a.dpad * 4) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
+    uint32_t* const stage_flag = (uint32_t*)(C + 512);
 
     const int qi = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -524,10 +544,10 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     uint32_t fbound = SLOT_EMPTY;   // an upper bound of furthest.distance (prefilter only)
     uint32_t rowv[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // row of the node being expanded
     uint32_t rowr[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // row of the runner-up (speculative)
-    unsigned long long ru_hit[BREGS];
+    int ru_slot = 0;
     uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
     bool ru_valid = false, stop = false;
-    unsigned long long evals = 0, expanded = 0;
+    uint32_t evals = 0, expanded = 0;  // per query: far below 2^32
     bool nan_seen = false, overflow = false;
     uint32_t ep = u.entry_point;
 
@@ -602,7 +622,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
             if (wave == 0) {
                 // ---- in the shadow of P3: the best candidate already in B (the next pop unless a neighbour
                 // accepted below beats it) and, speculatively, its adjacency row
-                ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_hit);
+                ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_slot);
                 if (ru_valid) load_row(ru_id, rowr);
             } else {
                 // ---- P3 (waves 1-3): exact distances, one 16-lane group per neighbour
@@ -684,7 +704,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                                     if (hm) best_slot = 64 * r + __ffsll((long long)hm) - 1;
                                 }
                             }
-                            ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_hit);  // slots moved
+                            ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_slot);  // slots moved
                             if (ru_valid) load_row(ru_id, rowr);
                         }
                         // ---- push all accepted neighbours: slots n .. n+na-1, in edge order
@@ -727,9 +747,8 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                             stop = true;  // `distance > furthest.distance` (index.rs:246-248)
                         } else if (take_ru) {
 #pragma unroll
-                            for (int r = 0; r < BREGS; ++r) {
-                                cdv[r] = ((ru_hit[r] >> lane) & 1ull) ? SLOT_EMPTY : cdv[r];
-                            }
+                            for (int r = 0; r < BREGS; ++r)
+                                if (lane + 64 * r == ru_slot) cdv[r] = SLOT_EMPTY;
 #pragma unroll
                             for (int c = 0; c < 4; ++c) rowv[c] = rowr[c];
                         } else {
@@ -776,11 +795,17 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     for (int i = tid; i < a.k; i += HNSW_BLOCK) a.out_keys[(size_t)qi * a.k + i] = i < outc ? W[i] : MDB_KEY_MAX;
     if (tid == 0) {
         a.out_counts[qi] = (uint32_t)outc;
-        atomicAdd(&a.counters[0], evals);
-        atomicAdd(&a.counters[1], expanded);
-        if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
-        if (overflow) atomicOr(a.flags, MDB_FLAG_OVERFLOW);
+        misc[3] = overflow ? 1u : 0u;
+        if (!overflow) {
+            atomicAdd(&a.counters[0], evals);
+            atomicAdd(&a.counters[1], expanded);
+            if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
+        }
     }
+    __syncthreads();
+    // > ~120 exact distance ties with furthest overflow the 320-slot beam: this block re-runs its query with
+    // the general algorithm (sorted LDS sets, room for ~800 ties); rows and counters come from that run
+    if (misc[3]) hnsw_general_traverse<METRIC, VIS_LDS, N16T>(a, qi, lds, true);
 }
 
 // keys (distance, point id) -> doc ids, order unchanged (ann_search :192-208)
@@ -1039,6 +1064,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     a.k = (int)k;
     a.out_keys = d_keys; a.out_counts = d_counts; a.flags = ctx->d_flags; a.counters = ctx->d_counters;
     size_t lds_base = (size_t)a.ef_cap * 8 + (size_t)a.cand_cap * 8 + (size_t)a.smax * 8 + (size_t)dpad * 4 + 64;
+    if (ef <= 256) lds_base = std::max<size_t>(lds_base, (size_t)BEAM_LDS_QS + (size_t)dpad * 4);  // the beam kernel's fixed layout
     size_t words = ((size_t)max_n + 31) / 32 + 1;
     bool vis_lds = lds_base + words * 4 <= 160 * 1024 - 256;
     size_t lds = lds_base + (vis_lds ? words * 4 : 0);

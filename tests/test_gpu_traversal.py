@@ -120,6 +120,26 @@ def test_hnsw_general_kernel_equals_beam_kernel(ctx, oracle):
     assert_result_rows(g.ann_search(q, 10, 600), o.ann_search(q, 10, 600), len(q))
 
 
+def test_hnsw_beam_overflow_falls_back_to_general_kernel(ctx, oracle):
+    """Hundreds of exact distance ties with `furthest` overflow the 320-slot register beam; those queries are
+    re-run by the general kernel inside the same call — rows and counters still equal the oracle's."""
+    from muopdb_amd.index import BlockBasedHnsw
+    rng = np.random.default_rng(23)
+    v = np.repeat(rng.integers(0, 3, (6, 8)).astype(np.float32), 150, axis=0)  # 6 distinct points x 150 copies
+    v = v[rng.permutation(len(v))]
+    hidx, hvec = H.build_hnsw_files(oracle, v, list(range(len(v))), max_neighbors=16, max_layers=3, ef_construction=60)
+    g = BlockBasedHnsw(ctx, hidx, hvec, 8)
+    o = oracle.BlockBasedHnsw(hidx, hvec, 8)
+    q = (v[:12] + 0.25).astype(np.float32)
+    for k, ef in [(10, 100), (50, 200), (5, 256)]:
+        o.stats()
+        ores = o.ann_search(q, k, ef)
+        evals, expanded = o.stats()
+        assert_result_rows(g.ann_search(q, k, ef), ores, len(q))
+        st = ctx.stats()
+        assert st["distance_evals"] == evals and st["expanded_nodes"] == expanded
+
+
 def test_hnsw_ties_and_duplicates(ctx, oracle):
     # many exact distance ties: pop order (largest id first) and eviction order must match
     from muopdb_amd.index import BlockBasedHnsw
