@@ -305,7 +305,7 @@ def run_flat(args, ctx, rank, world, timer):
         out["roofline"]["frac"] = ach * groups / HBM_PEAK_GBS
         out["roofline"]["mfma_tflops"] = 2.0 * batch * (hi - lo) * d / (kernel_ms / launches * 1e-3) / 1e12
         out["roofline"]["mfma_frac_of_f32_peak"] = out["roofline"]["mfma_tflops"] / 157.3
-    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("flat", out["config"])
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("flat_b64" if batched else "flat", out["config"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         xb, qh = x.cpu().numpy(), queries[warm * batch:].cpu().numpy()
