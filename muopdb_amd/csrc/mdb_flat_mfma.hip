@@ -78,7 +78,8 @@ FlatAux::~FlatAux() {
 mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux) {
     size_t full = v.n / MDB_TILE;
     if (full < 1024) return MDB_OK;  // < 64K vectors: the exact path is used
-    size_t want = std::min<size_t>(std::max<size_t>(full / 32, 256), 1024);  // 16K .. 64K vectors
+    static const size_t div = getenv("MDB_MF_SAMPLE_DIV") ? (size_t)atoi(getenv("MDB_MF_SAMPLE_DIV")) : 32;
+    size_t want = std::min<size_t>(std::max<size_t>(full / div, 256), 1024);  // 16K .. 64K vectors
     size_t stride = full / want;
     size_t stiles = (full - 1) / stride + 1;
     TileStore& out = aux.sample;

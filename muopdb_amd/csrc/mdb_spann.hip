@@ -76,49 +76,52 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     float* dq;
     int qstride;
     MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.ivf.num_features, mem, (b + 3) / 4 * 4, &dq, &qstride));
+    // all per-call device buffers come from ONE grow-only scratch slot: no hipMalloc / hipFree (which would
+    // synchronise the device) on the search path
+    const size_t ne = std::max<size_t>(nexp, 1), ke = std::max<size_t>(k, 1), total = b * k;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    const size_t o_qu = take(b * 4), o_ckeys = take(b * ne * 8), o_ccnt = take(b * 4), o_probes = take(b * ne * 4), o_pcnt = take(b * 4),
+                 o_keys = take(b * ke * 8), o_cnts = take(b * 4), o_found = take(b), o_doc = take(b * ke * 16), o_sc = take(b * ke * 4);
+    char* base;
+    MDB_TRY(mdb_scratch(ctx, 11, off, (void**)&base));
     uint32_t* d_q_user = nullptr;
-    DevBuf<uint32_t> qu;
     if (h_q_user) {
-        if (qu.alloc(b) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
-        MDB_HIP(ctx, hipMemcpyAsync(qu.p, h_q_user, b * 4, hipMemcpyHostToDevice, ctx->stream));
-        d_q_user = qu.p;
+        MDB_HIP(ctx, hipMemcpyAsync(base + o_qu, h_q_user, b * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_q_user = (uint32_t*)(base + o_qu);
     }
-    DevBuf<uint64_t> ckeys, keys;
-    DevBuf<uint32_t> ccnt, probes, pcnt, cnts;
-    DevBuf<uint8_t> dfound;
-    if (ckeys.alloc(b * std::max<size_t>(nexp, 1)) != hipSuccess || ccnt.alloc(b) != hipSuccess ||
-        probes.alloc(b * std::max<size_t>(nexp, 1)) != hipSuccess || pcnt.alloc(b) != hipSuccess ||
-        keys.alloc(b * std::max<size_t>(k, 1)) != hipSuccess || cnts.alloc(b) != hipSuccess || dfound.alloc(b) != hipSuccess)
-        return mdb_fail(ctx, MDB_ERR_OOM, "spann scratch alloc");
+    uint64_t* ckeys = (uint64_t*)(base + o_ckeys);
+    uint32_t* ccnt = (uint32_t*)(base + o_ccnt);
+    uint32_t* probes = (uint32_t*)(base + o_probes);
+    uint32_t* pcnt = (uint32_t*)(base + o_pcnt);
+    uint64_t* keys = (uint64_t*)(base + o_keys);
+    uint32_t* cnts = (uint32_t*)(base + o_cnts);
+    uint8_t* dfound = (uint8_t*)(base + o_found);
     MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
     ctx->stats = mdb_stats{};
     ctx->stat_bytes_per_eval = (uint64_t)s.hnsw.dimension * 4 + 4;
     ctx->stat_bytes_per_scored = s.ivf.bytes_per_scored();
     ctx->stat_fixed_bytes = 0;
-    MDB_TRY(s.hnsw.search(dq, qstride, b, d_q_user, nexp, params->ef_construction, ckeys.p, ccnt.p));
+    MDB_TRY(s.hnsw.search(dq, qstride, b, d_q_user, nexp, params->ef_construction, ckeys, ccnt));
     spann_filter_kernel<<<dim3((unsigned)((b + 127) / 128)), 128, 0, ctx->stream>>>(
-        ckeys.p, ccnt.p, (int)nexp, params->centroid_distance_ratio, s.hnsw.d_users.p, s.ivf.d_users.p, d_q_user,
-        s.hnsw.d_index.p, probes.p, pcnt.p, dfound.p, b, ctx->d_flags);
+        ckeys, ccnt, (int)nexp, params->centroid_distance_ratio, s.hnsw.d_users.p, s.ivf.d_users.p, d_q_user,
+        s.hnsw.d_index.p, probes, pcnt, dfound, b, ctx->d_flags);
     MDB_HIP(ctx, hipGetLastError());
-    MDB_TRY(s.ivf.scan(dq, qstride, b, d_q_user, probes.p, pcnt.p, (int)std::max<size_t>(nexp, 1), k, keys.p, cnts.p));
-    size_t total = b * k;
+    MDB_TRY(s.ivf.scan(dq, qstride, b, d_q_user, probes, pcnt, (int)ne, k, keys, cnts));
     if (mem == MDB_MEM_DEVICE) {
-        MDB_TRY(s.ivf.remap(keys.p, cnts.p, b, k, d_q_user, doc_ids_out, scores_out, counts_out));
-        if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound.p, b, hipMemcpyDeviceToDevice, ctx->stream));
-        MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the DevBufs above are released on return
-        return MDB_OK;
+        MDB_TRY(s.ivf.remap(keys, cnts, b, k, d_q_user, doc_ids_out, scores_out, counts_out));
+        if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound, b, hipMemcpyDeviceToDevice, ctx->stream));
+        return MDB_OK;  // asynchronous on the context's stream, like every MDB_MEM_DEVICE call
     }
-    DevBuf<mdb_u128> ddoc;
-    DevBuf<float> dsc;
-    if (ddoc.alloc(std::max<size_t>(total, 1)) != hipSuccess || dsc.alloc(std::max<size_t>(total, 1)) != hipSuccess)
-        return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
-    MDB_TRY(s.ivf.remap(keys.p, cnts.p, b, k, d_q_user, ddoc.p, dsc.p, nullptr));
+    mdb_u128* ddoc = (mdb_u128*)(base + o_doc);
+    float* dsc = (float*)(base + o_sc);
+    MDB_TRY(s.ivf.remap(keys, cnts, b, k, d_q_user, ddoc, dsc, nullptr));
     if (total) {
-        MDB_HIP(ctx, hipMemcpyAsync(doc_ids_out, ddoc.p, total * 16, hipMemcpyDeviceToHost, ctx->stream));
-        MDB_HIP(ctx, hipMemcpyAsync(scores_out, dsc.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP(ctx, hipMemcpyAsync(doc_ids_out, ddoc, total * 16, hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP(ctx, hipMemcpyAsync(scores_out, dsc, total * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts.p, b * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound.p, b, hipMemcpyDeviceToHost, ctx->stream));
+    if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts, b * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound, b, hipMemcpyDeviceToHost, ctx->stream));
     return mdb_check_flags(ctx);
 }
 
