@@ -194,6 +194,13 @@ mdb_status mdb_ivf_search_points(mdb_ivf* ivf, const float* queries, size_t b, c
                                  uint32_t* counts_out);
 /* BlockBasedIvf::invalidate / invalidate_batch / is_invalidated :421-470; flags_out[i] = 1 if
  * newly invalidated (resp. currently invalid) */
+/* Planner hook of scan_posting_list (ivf/block_based/index.rs:214-226): the planner keeps the subset of the
+ * scanned POINT ids that match the document filter.  Here that subset is an allow bitmap (bit p set = point p
+ * kept) applied by every following search on the handle until cleared with allow == NULL: n_bitmaps == 1 ->
+ * one bitmap shared by all queries, otherwise one per query of the batch ([n_bitmaps][words_per_bitmap] u32).
+ * Host bitmaps are copied; device bitmaps are borrowed until cleared.  Filtered points are skipped BEFORE the
+ * distance (the reference drops them after it). */
+mdb_status mdb_ivf_set_filter(mdb_ivf* ivf, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem);
 mdb_status mdb_ivf_invalidate(mdb_ivf* ivf, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
 mdb_status mdb_ivf_is_invalidated(mdb_ivf* ivf, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
 
@@ -222,6 +229,7 @@ void mdb_spann_free(mdb_spann* spann);
 mdb_status mdb_spann_search(mdb_spann* spann, const float* queries, size_t b, const mdb_search_params* params,
                             mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out,
                             uint8_t* found_out);
+mdb_status mdb_spann_set_filter(mdb_spann* spann, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem);
 mdb_status mdb_spann_invalidate(mdb_spann* spann, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
 mdb_status mdb_spann_is_invalidated(mdb_spann* spann, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
 
@@ -243,7 +251,9 @@ size_t mdb_multi_spann_num_users(const mdb_multi_spann* ms);
 mdb_status mdb_multi_spann_search(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
                                   const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out,
                                   float* scores_out, uint32_t* counts_out, uint8_t* found_out);
-/* per-shard variant for the multi-GPU merge: top-k by (score, doc id) of THIS rank's lists */
+/* planner hook: bitmaps are over the USER-LOCAL point ids of each query's user (see mdb_ivf_set_filter) */
+mdb_status mdb_multi_spann_set_filter(mdb_multi_spann* ms, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap,
+                                      mdb_mem mem);
 mdb_status mdb_multi_spann_invalidate(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,
                                       uint8_t* flags_out);
 

@@ -154,6 +154,12 @@ class BlockBasedIvf {
         dev_.check(mdb_ivf_search(h_, queries, b, centroids, num_probes, k, MDB_MEM_HOST, r.ids.data(), r.scores.data(), r.counts.data()));
         return r.take(b, k);
     }
+    // Planner hook (scan_posting_list :214-226): allow bitmaps over point ids for the following searches;
+    // n_bitmaps == 1 -> shared by every query; empty vector clears
+    void set_filter(const std::vector<uint32_t>& bitmaps, size_t n_bitmaps = 1) {
+        if (bitmaps.empty()) { dev_.check(mdb_ivf_set_filter(h_, nullptr, 0, 0, MDB_MEM_HOST)); return; }
+        dev_.check(mdb_ivf_set_filter(h_, bitmaps.data(), n_bitmaps, bitmaps.size() / n_bitmaps, MDB_MEM_HOST));
+    }
     bool invalidate(u128 doc_id) {
         mdb_u128 d = detail::split(doc_id);
         uint8_t f = 0;

@@ -52,6 +52,10 @@ struct IvfSet {
     DevBuf<float> d_cent_tiles;       // centroids, per user, SoA tiles
     PqDev pq;
     int mw = 0;
+    // Planner hook: per-query allow bitmaps over point ids applied by scan() until cleared
+    const uint32_t* flt = nullptr;
+    size_t flt_stride = 0, ones_word = 0;
+    DevBuf<uint32_t> flt_own;
     std::vector<std::unordered_map<U128Key, uint32_t, U128Hash>> doc_maps;
 
     mdb_status load(mdb_ctx* ctx, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
@@ -59,6 +63,7 @@ struct IvfSet {
                     uint32_t shard_rank, uint32_t shard_world);
     mdb_status build_doc_map(size_t ui);
     mdb_status invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out, bool test_only);
+    mdb_status set_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem);
     mdb_status coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes);
     mdb_status scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
                     const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts);

@@ -104,10 +104,18 @@ struct ScanArgs {
     uint64_t* partial;             // [B][nsplit][k]
     uint32_t* flags;
     unsigned long long* counters;  // [2] += scored vectors
+    // Planner hook (scan_posting_list, index.rs:214-226): query i keeps point p iff bit p of
+    // allow[i*allow_stride ...] is set.  Without a filter `allow` points at one all-ones word and
+    // allow_mask = 0 folds every index onto it (branch-free in the pipelined PQ kernel).
+    const uint32_t* allow;
+    uint32_t allow_stride, allow_mask;
 };
 
 __device__ __forceinline__ bool tomb_test(const uint32_t* tomb, uint32_t base_word, uint32_t pid) {
     return (tomb[base_word + (pid >> 5)] >> (pid & 31)) & 1u;
+}
+__device__ __forceinline__ bool allow_test(const ScanArgs& a, int qi, uint32_t pid) {
+    return (a.allow[(size_t)qi * a.allow_stride + ((pid >> 5) & a.allow_mask)] >> (pid & 31)) & 1u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
                 if (t < T) {
                     const uint32_t tile = map.tile_of((uint32_t)t, map.list_of((uint32_t)t));
                     uint32_t pid = a.slot_ids[(size_t)tile * MDB_TILE + lane];
-                    if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid)) {
+                    if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid) && allow_test(a, qi, pid)) {
                         TileLoader ld{tiles + (size_t)tile * p.d4 * MDB_TILE + lane};
                         float raw[1];
                         exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_pq_kernel(ScanArgs a, cons
                 uint64_t key = MDB_KEY_MAX;
                 if (tile < t1) {
                     uint32_t pid = a.slot_ids[(size_t)tile * MDB_TILE + lane];
-                    if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid)) {
+                    if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid) && allow_test(a, qi, pid)) {
                         const uint32_t* cw = codes + (size_t)tile * mw * MDB_TILE + lane;
                         float s16[16], s8[8], s4[4], s1 = 0.0f;
 #pragma unroll
@@ -472,13 +480,14 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
             // moved (a move would force the wait right after the issue): stage set (r % 3) is fetched in
             // iteration r (slot id + code words, unconditional loads from clamped addresses), gets its
             // tombstone word in iteration r+1 and is consumed in iteration r+2.
-            uint32_t pid[3], tw[3], cw[3][MW];
+            uint32_t pid[3], tw[3], aw[3], cw[3][MW];
             bool live[3] = {false, false, false};  // wave-uniform: the set holds a real tile
             int jsafe = 0;
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
                 pid[x] = 0xFFFFFFFFu;
                 tw[x] = 0;
+                aw[x] = 0;
 #pragma unroll
                 for (int w = 0; w < MW; ++w) cw[x][w] = 0;
             }
@@ -504,11 +513,12 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
                 {
                     uint32_t pz = pid[TB] == 0xFFFFFFFFu ? 0u : pid[TB];
                     tw[TB] = a.tomb[u.tomb_base + (pz >> 5)];
+                    aw[TB] = a.allow[(size_t)qi * a.allow_stride + ((pz >> 5) & a.allow_mask)];
                 }
                 // ---- compute round r-2 (set CC)
                 if (r >= 2) {
                     uint64_t key = MDB_KEY_MAX;
-                    if (live[CC] && pid[CC] != 0xFFFFFFFFu && !((tw[CC] >> (pid[CC] & 31)) & 1u)) {
+                    if (live[CC] && pid[CC] != 0xFFFFFFFFu && !((tw[CC] >> (pid[CC] & 31)) & 1u) && ((aw[CC] >> (pid[CC] & 31)) & 1u)) {
                         float s16[16], s8[8], s4[4];
 #pragma unroll
                         for (int x = 0; x < 16; ++x) s16[x] = 0.0f;
@@ -750,6 +760,8 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
     h_tomb.assign(tomb_words + 1, 0);
     if (d_tomb.alloc(tomb_words + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
     MDB_HIP(ctx, hipMemsetAsync(d_tomb.p, 0, (tomb_words + 1) * 4, ctx->stream));
+    ones_word = tomb_words;  // the spare last word: "no planner" allow bitmap
+    MDB_HIP(ctx, hipMemsetAsync(d_tomb.p + ones_word, 0xFF, 4, ctx->stream));
     // ---- decode posting lists into the slot id array
     const size_t nslots = ntiles * MDB_TILE;
     if (d_slot_ids.alloc(nslots + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "slot ids alloc");
@@ -835,6 +847,25 @@ mdb_status IvfSet::invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint
     return MDB_OK;
 }
 
+// allow bitmaps for the following searches (nullptr clears): n_bitmaps == 1 -> shared by every query, else one per
+// query of the batch; host bitmaps are copied
+mdb_status IvfSet::set_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem) {
+    flt = nullptr;
+    flt_stride = 0;
+    if (!allow) return MDB_OK;
+    if (n_bitmaps == 0 || words == 0) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "empty filter bitmap");
+    if (mem == MDB_MEM_DEVICE) {
+        flt = allow;
+    } else {
+        if (flt_own.alloc(n_bitmaps * words + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "filter bitmap alloc");
+        MDB_HIP(ctx, hipMemcpyAsync(flt_own.p, allow, n_bitmaps * words * 4, hipMemcpyHostToDevice, ctx->stream));
+        MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        flt = flt_own.p;
+    }
+    flt_stride = n_bitmaps == 1 ? 0 : words;
+    return MDB_OK;
+}
+
 // ------------------------------------------------------------------------------------------ IvfSet: search
 // d_q: staged queries [b][qstride]; probes: device [b][probe_stride]; outputs: device keys [b][k] + counts
 mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
@@ -865,7 +896,8 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     void* partial;
     MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)nsplit * std::max<size_t>(k, 1) * 8, &partial));
     ScanArgs a{d_users.p, d_q_user, d_list_tile_off.p, d_slot_ids.p, d_tomb.p, d_probes, d_probe_cnt, probe_stride,
-               (int)k, (uint64_t*)partial, ctx->d_flags, ctx->d_counters};
+               (int)k, (uint64_t*)partial, ctx->d_flags, ctx->d_counters,
+               flt ? flt : d_tomb.p + ones_word, flt ? (uint32_t)flt_stride : 0u, flt ? 0xFFFFFFFFu : 0u};
     dim3 grid((unsigned)nsplit, (unsigned)b);
     size_t sel_lds = BlockSelect<MDB_BLOCK>::lds_bytes((int)k);
     void* qcodes = nullptr;
@@ -1088,6 +1120,13 @@ mdb_status mdb_ivf_search_points(mdb_ivf* ivf, const float* queries, size_t b, c
                                  size_t k, mdb_mem mem, uint32_t* point_ids_out, float* scores_out, uint32_t* counts_out) {
     if (!ivf || (!queries && b) || !point_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
     return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, false, point_ids_out, scores_out, counts_out);
+}
+
+mdb_status mdb_ivf_set_filter(mdb_ivf* ivf, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem) {
+    if (!ivf) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ivf->set.ctx->mu);
+    MDB_HIP(ivf->set.ctx, hipSetDevice(ivf->set.ctx->device));
+    return ivf->set.set_filter(allow, n_bitmaps, words_per_bitmap, mem);
 }
 
 mdb_status mdb_ivf_invalidate(mdb_ivf* ivf, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out) {

@@ -251,6 +251,13 @@ mdb_status mdb_spann_search(mdb_spann* sp, const float* queries, size_t b, const
     return spann_search_impl(sp->set, queries, b, nullptr, params, mem, doc_ids_out, scores_out, counts_out, found_out);
 }
 
+mdb_status mdb_spann_set_filter(mdb_spann* sp, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem) {
+    if (!sp) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(sp->set.ctx->mu);
+    MDB_HIP(sp->set.ctx, hipSetDevice(sp->set.ctx->device));
+    return sp->set.ivf.set_filter(allow, n_bitmaps, words_per_bitmap, mem);
+}
+
 mdb_status mdb_spann_invalidate(mdb_spann* sp, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out) {
     if (!sp || (!doc_ids && n) || !flags_out) return MDB_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(sp->set.ctx->mu);
@@ -325,6 +332,14 @@ mdb_status mdb_multi_spann_search(mdb_multi_spann* ms, const mdb_u128* user_ids,
         qu[i] = it == ms->set.user_index.end() ? (uint32_t)ms->set.num_users : it->second;  // sentinel: valid = 0 => None
     }
     return spann_search_impl(ms->set, queries, b, qu.data(), params, mem, doc_ids_out, scores_out, counts_out, found_out);
+}
+
+mdb_status mdb_multi_spann_set_filter(mdb_multi_spann* ms, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap,
+                                      mdb_mem mem) {
+    if (!ms) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ms->set.ctx->mu);
+    MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
+    return ms->set.ivf.set_filter(allow, n_bitmaps, words_per_bitmap, mem);
 }
 
 mdb_status mdb_multi_spann_invalidate(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,

@@ -208,6 +208,25 @@ class FlatIndex:
 
 
 # ------------------------------------------------------------------------------------------ IVF
+
+def _set_filter(ctx, fn, handle, bitmaps):
+    """bitmaps: None (clear) | uint32 [words] (shared) | uint32 [b][words] (one per query)."""
+    if bitmaps is None:
+        ctx.check(fn(handle, None, C.c_size_t(0), C.c_size_t(0), C.c_int(L.MEM_HOST)))
+        return
+    bm = np.ascontiguousarray(bitmaps, dtype=np.uint32)
+    nb, words = (1, bm.shape[0]) if bm.ndim == 1 else bm.shape
+    ctx.check(fn(handle, L.ptr(bm, C.c_uint32), C.c_size_t(nb), C.c_size_t(words), C.c_int(L.MEM_HOST)))
+
+
+def allow_bitmap(point_ids, num_points):
+    """uint32 bitmap with the bits of `point_ids` set (the planner's kept ids)."""
+    bm = np.zeros((num_points + 31) // 32, np.uint32)
+    p = np.asarray(point_ids, np.int64)
+    np.bitwise_or.at(bm, p >> 5, (np.uint32(1) << (p & 31).astype(np.uint32)))
+    return bm
+
+
 class BlockBasedIvf:
     """rs/index/src/ivf/block_based/index.rs"""
 
@@ -285,6 +304,10 @@ class BlockBasedIvf:
                                                           L.ptr(ids, C.c_uint32), L.ptr(sc, C.c_float),
                                                           L.ptr(cn, C.c_uint32)))
         return ids[:, :k], sc[:, :k], cn
+
+    def set_filter(self, bitmaps):
+        """Planner hook (scan_posting_list :214-226): allow bitmaps over point ids for the following searches."""
+        _set_filter(self.ctx, self.ctx.lib.mdb_ivf_set_filter, self.h, bitmaps)
 
     def invalidate(self, doc_id):
         return bool(self.invalidate_batch([doc_id])[0])
@@ -403,6 +426,9 @@ class Spann:
                                                      C.c_int(L.MEM_HOST), *out.args(), L.ptr(out.found, C.c_uint8)))
         return out.result()
 
+    def set_filter(self, bitmaps):
+        _set_filter(self.ctx, self.ctx.lib.mdb_spann_set_filter, self.h, bitmaps)
+
     def invalidate(self, doc_id):
         flags = np.zeros(1, np.uint8)
         self.ctx.check(self.ctx.lib.mdb_spann_invalidate(self.h, L.u128_array([doc_id]), C.c_size_t(1),
@@ -472,6 +498,10 @@ class MultiSpannIndex:
                 rows += res.id_with_scores(i)
         rows.sort(key=lambda r: (np.isnan(r[1]), r[1], r[0]))
         return rows[:params.top_k]
+
+    def set_filter(self, bitmaps):
+        """bitmaps over the user-local point ids of each query's user"""
+        _set_filter(self.ctx, self.ctx.lib.mdb_multi_spann_set_filter, self.h, bitmaps)
 
     def invalidate(self, user_id, doc_id):
         flags = np.zeros(1, np.uint8)

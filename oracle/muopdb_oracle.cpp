@@ -457,6 +457,13 @@ struct IvfStorage {
 // ---------------------------------------------------------------------------------------
 // I2/I3: BlockBasedIvf — rs/index/src/ivf/block_based/index.rs
 // ---------------------------------------------------------------------------------------
+// Planner hook (ivf/block_based/index.rs:214-226): the planner returns the subset of the scanned point ids
+// that match the document filter; here that subset is a per-query allow bitmap over point ids.
+static const uint32_t* g_allow_base = nullptr;   // [b][g_allow_stride] words, set by orc_set_filter
+static size_t g_allow_stride = 0;
+static thread_local const uint32_t* tl_allow = nullptr;  // bitmap of the query being served by this thread
+static inline void select_filter(size_t qi) { tl_allow = g_allow_base ? g_allow_base + qi * g_allow_stride : nullptr; }
+
 struct Ivf {
     std::vector<uint8_t> index_bytes, vector_bytes;  // owned copies
     IvfStorage st;
@@ -508,6 +515,12 @@ struct Ivf {
         }
         std::stable_sort(out.begin(), out.end(),
                          [](auto& a, auto& b) { return a.point_id < b.point_id; });   // :212
+        if (tl_allow) {  // :214-226 retain the ids the planner returned (after the distances, like the reference)
+            const uint32_t* al = tl_allow;
+            out.erase(std::remove_if(out.begin(), out.end(),
+                                     [al](const PointAndDistance& pd) { return !((al[pd.point_id >> 5] >> (pd.point_id & 31)) & 1u); }),
+                      out.end());
+        }
         std::stable_sort(out.begin(), out.end(),
                          [](auto& a, auto& b) { return a.distance < b.distance; });   // :228
         return true;
@@ -1163,6 +1176,7 @@ int orc_ivf_search(void* p, const float* queries, size_t b, const uint32_t* prob
     for (long qi = 0; qi < (long)b; ++qi) {
         std::vector<IdWithScore> r;
         const float* q = queries + qi * ivf->st.num_features;
+        select_filter((size_t)qi);
         bool ok;
         if (probes) {
             std::vector<size_t> c(probes + qi * num_probes, probes + (qi + 1) * num_probes);
@@ -1285,6 +1299,7 @@ int orc_spann_search(void* p, const float* queries, size_t b, size_t top_k, uint
 #endif
     for (long qi = 0; qi < (long)b; ++qi) {
         std::vector<IdWithScore> r;
+        select_filter((size_t)qi);
         int rc = s->search(queries + qi * d, sp, r);
         if (rc < 0) { bad = 1; r.clear(); }
         found[qi] = rc == 1;
@@ -1340,6 +1355,7 @@ int orc_multi_spann_search(void* p, const uint64_t* user_lo, const uint64_t* use
         std::vector<IdWithScore> r;
         Spann* s = m->get_or_create(((u128)user_hi[qi] << 64) | user_lo[qi]);
         int rc = 0;
+        select_filter(qi);
         if (s) rc = s->search(queries + qi * m->num_features, sp, r);
         if (rc < 0) { bad = 1; r.clear(); }
         found[qi] = rc == 1;
@@ -1367,6 +1383,10 @@ int orc_multi_spann_search_for_users(void* p, const uint64_t* user_lo, const uin
     export_results(all, top_k, ids_lo, ids_hi, scores, count);
     return 0;
 }
+
+// per-query allow bitmaps for the next search calls (nullptr = no planner); stride in 32-bit words, 0 = one
+// bitmap shared by every query of the batch
+void orc_set_filter(const uint32_t* allow, size_t stride_words) { g_allow_base = allow; g_allow_stride = stride_words; }
 
 // ---- ordering helpers (K12) ----
 // sorts n (score, doc_lo, doc_hi) records by IdWithScore order; returns permutation

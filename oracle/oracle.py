@@ -465,6 +465,24 @@ class MultiSpannIndex:
 
 
 # ---------------------------------------------------------------- ordering (K12)
+class planner_filter:
+    """`with planner_filter(bitmaps): ...` — the searches inside see per-query allow bitmaps over point ids
+    (the Planner hook of scan_posting_list, ivf/block_based/index.rs:214-226).  bitmaps: uint32 [b][words] or
+    [words] (shared by every query)."""
+
+    def __init__(self, bitmaps):
+        self.b = np.ascontiguousarray(bitmaps, dtype=np.uint32)
+
+    def __enter__(self):
+        stride = self.b.shape[-1] if self.b.ndim == 2 else 0
+        lib().orc_set_filter(_p(self.b, C.c_uint32), C.c_size_t(stride))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_filter(None, C.c_size_t(0))
+        return False
+
+
 def sort_id_with_score(scores, doc_ids):
     s = _f32(scores)
     lo = np.array([d & 0xFFFFFFFFFFFFFFFF for d in doc_ids], np.uint64)

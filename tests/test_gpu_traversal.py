@@ -392,3 +392,56 @@ def test_merge_shards_device(ctx):
         assert int(ocn[qi]) == len(rows)
         got = [(float(osc[qi, j]), (int(od[qi, j, 1]) << 64) | int(od[qi, j, 0])) for j in range(len(rows))]
         assert got == rows
+
+
+# ----------------------------------------------------------------------------------- planner hook
+@pytest.mark.parametrize("pq", [False, True])
+def test_planner_filter_hook(ctx, oracle, pq):
+    """scan_posting_list's planner consumer (ivf/block_based/index.rs:214-226) as per-query allow bitmaps:
+    the reference's own test keeps the even doc ids (multi_spann/index.rs:850-880); here per-query random
+    subsets too, through IVF, SPANN and multi-user SPANN, NoQ and PQ, against the oracle."""
+    from muopdb_amd.index import BlockBasedIvf, MultiSpannIndex, ProductQuantizer, SearchParams, Spann, allow_bitmap
+    rng = np.random.default_rng(31 + pq)
+    n, d = 3000, 32
+    v = H.sift_like(n, d, n_clusters=25, seed=6)
+    doc = list(range(n))  # doc id == point id, so "even doc ids" == even point ids
+    quant = oquant = quantize = None
+    if pq:
+        cb = H.train_pq_codebook(v[:1500], 8, 6, iters=3)
+        opq = oracle.ProductQuantizer(d, 8, 6, cb)
+        quant, oquant, quantize = ProductQuantizer(d, 8, 6, cb), oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 6, cb), opq.quantize
+    files, cent, _ = H.build_spann_files(oracle, v, doc, 30, quantize=quantize, max_neighbors=8, max_layers=3, ef_construction=50)
+    q = (v[rng.integers(0, n, 16)] + rng.normal(0, 3, (16, d))).astype(np.float32)
+    even = allow_bitmap(np.arange(0, n, 2), n)
+    per_query = np.stack([allow_bitmap(rng.choice(n, size=int(rng.integers(1, n)), replace=False), n) for _ in range(16)])
+    # IVF
+    g = BlockBasedIvf(ctx, files["ivf_index"], files["ivf_vectors"], quant)
+    o = oracle.BlockBasedIvf(files["ivf_index"], files["ivf_vectors"], oquant)
+    for bm in (even, per_query):
+        g.set_filter(bm)
+        with oracle.planner_filter(bm):
+            want = o.search(q, 10, num_probes=12)
+        got = g.search(q, 10, 12)
+        assert_result_rows(got, want, len(q))
+        if bm is even:
+            assert all(x % 2 == 0 for i in range(len(q)) for x in got.doc_ids(i))
+    g.set_filter(None)
+    assert_result_rows(g.search(q, 10, 12), o.search(q, 10, num_probes=12), len(q))
+    # SPANN
+    sp = Spann(ctx, files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"], quant)
+    osp = oracle.Spann(files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"], oquant)
+    p, op = SearchParams(10, 50).with_num_explored_centroids(6), oracle.SearchParams(10, 50, num_explored_centroids=6)
+    sp.set_filter(per_query)
+    with oracle.planner_filter(per_query):
+        want = osp.search(q, op)
+    assert_result_rows(sp.search(q, p), want, len(q))
+    # multi-user (one user): bitmaps are over the user's local point ids
+    cat = F.concat_multi_spann({5: files})
+    ms = MultiSpannIndex(ctx, cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], quant)
+    oms = oracle.MultiSpannIndex(cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], oquant)
+    ms.set_filter(even)
+    with oracle.planner_filter(even):
+        want = oms.search_for_user([5] * len(q), q, op)
+    got = ms.search_for_user([5] * len(q), q, p)
+    assert_result_rows(got, want, len(q))
+    assert all(x % 2 == 0 for i in range(len(q)) for x in got.doc_ids(i))
