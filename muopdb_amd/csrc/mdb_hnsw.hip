@@ -597,13 +597,10 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                         if ((uint32_t)(64 * c) < stride) {
                             const uint32_t nbr = rowv[c];
                             bool isnew = false;
-                            if (nbr != 0xFFFFFFFFu) {
-                                if (nbr >= u.n) atomicOr(a.flags, MDB_FLAG_RANGE);
-                                else {
-                                    uint32_t bit = 1u << (nbr & 31);
-                                    uint32_t old = atomicOr(&vis[nbr >> 5], bit);
-                                    isnew = !(old & bit);
-                                }
+                            if (nbr != 0xFFFFFFFFu) {  // edges are < n: validated when the graph is loaded
+                                uint32_t bit = 1u << (nbr & 31);
+                                uint32_t old = atomicOr(&vis[nbr >> 5], bit);
+                                isnew = !(old & bit);
                             }
                             any = any || __ballot(nbr != 0xFFFFFFFFu) != 0;
                             unsigned long long bal = __ballot(isnew);
@@ -981,7 +978,11 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
         h_adj.resize(h_adj.size() + (size_t)u.n0 * S0, 0xFFFFFFFFu);
         for (size_t p = 0; p < u.n0; ++p) {
             uint64_t a0 = eo(s0 + p), a1 = eo(s0 + p + 1);
-            for (uint64_t x = a0; x < a1; ++x) h_adj[u.adj0_off + p * S0 + (x - a0)] = ed(x);
+            for (uint64_t x = a0; x < a1; ++x) {
+                const uint32_t e = ed(x);
+                if (e >= nv) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW edge %u of point %zu is outside the vector storage (%llu vectors)", e, p, (unsigned long long)nv);
+                h_adj[u.adj0_off + p * S0 + (x - a0)] = e;
+            }
         }
         // rows of the upper layers
         uint32_t rows = 0;
@@ -998,7 +999,11 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
                 if (filled[r]) continue;  // find_point_in_range returns the FIRST match
                 filled[r] = 1;
                 uint64_t a0 = eo(i), a1 = eo(i + 1);
-                for (uint64_t x = a0; x < a1; ++x) h_adj[u.adjU_off + r * SU + (x - a0)] = ed(x);
+                for (uint64_t x = a0; x < a1; ++x) {
+                    const uint32_t e = ed(x);
+                    if (e >= nv) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW upper-layer edge %u is outside the vector storage", e);
+                    h_adj[u.adjU_off + r * SU + (x - a0)] = e;
+                }
             }
         }
         max_n = std::max(max_n, u.n);

@@ -445,3 +445,15 @@ def test_planner_filter_hook(ctx, oracle, pq):
     got = ms.search_for_user([5] * len(q), q, p)
     assert_result_rows(got, want, len(q))
     assert all(x % 2 == 0 for i in range(len(q)) for x in got.doc_ids(i))
+
+
+def test_hnsw_edge_outside_vector_storage_is_rejected_at_load(ctx, oracle):
+    # the reference would fail reading the vector of such a neighbour; here the graph file is refused
+    from muopdb_amd.index import BlockBasedHnsw
+    from muopdb_amd import lib as L
+    v = np.random.default_rng(1).standard_normal((50, 8)).astype(np.float32)
+    layers = [{i: [(i + 1) % 50, 77 if i == 3 else (i + 2) % 50] for i in range(50)}]
+    hidx, hvec = F.write_hnsw_index(layers, list(range(50)), 8), F.write_vector_file(v)
+    with pytest.raises(L.MuopdbError) as e:
+        BlockBasedHnsw(ctx, hidx, hvec, 8)
+    assert e.value.status == 2  # MDB_ERR_FORMAT
