@@ -505,7 +505,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     uint64_t* const W = (uint64_t*)lds;
     uint64_t* const C = (uint64_t*)(lds + BEAM_LDS_C);  // [0..512): staging / sort buffer, [512..768) as u32 flags
     uint32_t* const nb_id = (uint32_t*)(lds + BEAM_LDS_NBID);
-    float* const nb_dist = (float*)(lds + BEAM_LDS_NBDIST);
+    uint32_t* const nb_od = (uint32_t*)(lds + BEAM_LDS_NBDIST);  // order-preserving images of the neighbours' distances
     uint32_t* const misc = (uint32_t*)(lds + BEAM_LDS_MISC);  // [0] nnew (0xFFFFFFFF = stop), [2] wsize, [3] overflow
     float* const qs = (float*)(lds + BEAM_LDS_QS);
     uint32_t* vis = VIS_LDS ? (uint32_t*)(lds + BEAM_LDS_QS + (size_t)a.dpad * 4) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
@@ -623,9 +623,13 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                 if (ru_valid) load_row(ru_id, rowr);
             } else {
                 // ---- P3 (waves 1-3): exact distances, one 16-lane group per neighbour
+                // (the groups also take the order-preserving integer image and the NaN check off wave 0's path)
                 for (uint32_t i = grp - 4; i < nnew; i += (HNSW_BLOCK - 64) / 16) {
                     float d = MDB_BEAM_DIST(vecs + (size_t)nb_id[i] * a.dpad);
-                    if (j == 0) nb_dist[i] = d;
+                    if (j == 0) {
+                        nb_od[i] = f32_orderable(d);
+                        if (d != d) atomicOr(a.flags, MDB_FLAG_NAN);  // the reference panics (NotNan::new(..).unwrap())
+                    }
                 }
             }
             __syncthreads();
@@ -635,12 +639,9 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                 int best_slot = -1;                          // ... and the slot it was pushed to
                 for (uint32_t c0 = 0; c0 < nnew; c0 += 64) {
                     const uint32_t i = c0 + lane;
-                    const bool have0 = i < nnew;
-                    const float d = have0 ? nb_dist[i] : 0.0f;
-                    const uint32_t id = have0 ? nb_id[i] : 0;
-                    if (have0 && d != d) nan_seen = true;
-                    const bool have = have0 && d == d;
-                    const uint32_t od = f32_orderable(d);
+                    const bool have = i < nnew;
+                    const uint32_t od = have ? nb_od[i] : SLOT_EMPTY;
+                    const uint32_t id = have ? nb_id[i] : 0;
                     unsigned long long surv = __ballot(have && od < fbound);
                     unsigned long long accepted = 0;
                     while (surv) {
