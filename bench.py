@@ -443,6 +443,10 @@ def run_spann(args, ctx, rank, world, timer):
     noise = torch.randn((nq, d), generator=gq) * (0.3 / d ** 0.5)
     queries = torch.stack([base[int(u)][int(r)] for u, r in zip(quser.tolist(), qrow.tolist())]) + noise.cuda()
     queries = (queries / queries.norm(dim=1, keepdim=True)).contiguous()
+    if args.dump_dir:
+        dump(args, rank, hnsw_index=cat["hnsw_index"], hnsw_vectors=cat["hnsw_vectors"], ivf_index=cat["ivf_index"],
+             vectors=cat["ivf_vectors"], user_table=cat["user_table"],
+             **{"queries.f32": queries.cpu().numpy(), "users.u64": (quser + 1).numpy().astype(np.uint64)})
     params = SearchParams(k, args.ef).with_num_explored_centroids(P).with_centroid_distance_ratio(0.1).to_c()
     ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
     sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
@@ -499,6 +503,7 @@ def run_spann(args, ctx, rank, world, timer):
                              frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes / steps,
                              kernel_ms=kernel_ms / launches, scored_per_query=scored / (steps * batch),
                              centroid_hnsw_kernel_ms=hnsw_ms / max(hnsw_launches, 1)))
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("spann", out["config"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         o = oracle.MultiSpannIndex(cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])

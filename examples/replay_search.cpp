@@ -1,8 +1,8 @@
 // replay_search — torch-free replay of a bench.py workload through the C ABI, for rocprofv3 --pmc
 // passes (HBM traffic counters of the dominant kernel; rocprofv3's counter mode crashes inside
 // torch's own kernels on this image, so the counter passes run on this binary instead).
-//   replay_search <kind> <dir> <dim> <k> <ef|nprobe> <batch> <steps>
-// kind = hnsw | ivf | ivfpq | flat.  <dir> is what `bench.py --dump-dir` wrote:
+//   replay_search <kind> <dir> <dim> <k> <ef|nprobe> <batch> <steps> [ef for mspann]
+// kind = hnsw | ivf | ivfpq | flat | mspann.  <dir> is what `bench.py --dump-dir` wrote:
 //   hnsw : index, vectors, queries.f32        ivf/ivfpq : index, vectors, queries.f32 [, codebook.f32]
 //   flat : vectors (reference vector-file format: u64 n + rows), queries.f32
 // Prints a checksum of the returned ids so a replay can be compared with bench.py's run.
@@ -67,6 +67,26 @@ int main(int argc, char** argv) {
             for (size_t s = 0; s < steps; ++s)
                 for (auto& r : ivf.search(q + ((s * batch) % (nq - batch + 1)) * dim, batch, k, knob))
                     if (r) fold(r->id_with_scores);
+        } else if (kind == "mspann") {
+            // multi-user SPANN: hnsw_index, hnsw_vectors, ivf_index, vectors (= ivf/vectors), user_table (112-byte
+            // UserIndexInfo records), users.u64 (user id of every query); knob = num_explored_centroids, ef = argv[8]
+            auto hi = slurp(dir + "/hnsw_index"), hv = slurp(dir + "/hnsw_vectors"), ii = slurp(dir + "/ivf_index");
+            auto ut = slurp(dir + "/user_table"), uq = slurp(dir + "/users.u64");
+            std::vector<mdb_user_index_info> users(ut.size() / sizeof(mdb_user_index_info));
+            std::memcpy(users.data(), ut.data(), users.size() * sizeof(mdb_user_index_info));
+            const uint64_t* quser = reinterpret_cast<const uint64_t*>(uq.data());
+            const uint32_t ef = argc > 8 ? std::stoul(argv[8]) : 200;
+            muopdb::MultiSpannIndex ms(dev, users, dim, hi.data(), hi.size(), hv.data(), hv.size(), ii.data(), ii.size(), vec.data(),
+                                       vec.size(), muopdb::Quantizer::none(dim));
+            muopdb::SearchParams p(k, ef);
+            p.with_num_explored_centroids(knob).with_centroid_distance_ratio(0.1f);
+            t0 = std::chrono::steady_clock::now();
+            for (size_t s = 0; s < steps; ++s) {
+                const size_t q0 = (s * batch) % (nq - batch + 1);
+                std::vector<muopdb::u128> ids(quser + q0, quser + q0 + batch);
+                for (auto& r : ms.search_for_user(ids, q + q0 * dim, p))
+                    if (r) fold(r->id_with_scores);
+            }
         } else if (kind == "flat") {
             uint64_t n;
             std::memcpy(&n, vec.data(), 8);

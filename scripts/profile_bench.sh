@@ -7,6 +7,7 @@
 #             files (examples/replay_search.cpp) — rocprofv3 counter mode crashes inside torch's own
 #             kernels on this image.  No sys/runtime trace flags are combined with --pmc.
 TAG=$1; KIND=$2; DIM=$3; K=$4; KNOB=$5; BATCH=$6; shift 6
+EXTRA=""; [ "$KIND" = "mspann" ] && EXTRA="200"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 DUMP=/tmp/mdb_dump_$TAG
@@ -17,9 +18,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$TAG -o 
 cp /tmp/prof_stats_$TAG/*kernel_stats.csv $OUT/ 2>/dev/null
 for f in /tmp/prof_stats_$TAG/*kernel_trace.csv; do [ -f "$f" ] && (head -1 $f; grep -E "$PAT" $f | head -300) > $OUT/kernel_trace_dominant.csv; done
 # uninstrumented replay first (checksum + host-buffer ms/step), then the counter passes
-$REPO/muopdb_amd/replay_search $KIND $DUMP $DIM $K $KNOB $BATCH 10 > $OUT/replay.log 2>&1
+$REPO/muopdb_amd/replay_search $KIND $DUMP $DIM $K $KNOB $BATCH 10 $EXTRA > $OUT/replay.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_${C}_$TAG -o replay -- $REPO/muopdb_amd/replay_search $KIND $DUMP $DIM $K $KNOB $BATCH 10 > $OUT/replay_$C.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_${C}_$TAG -o replay -- $REPO/muopdb_amd/replay_search $KIND $DUMP $DIM $K $KNOB $BATCH 10 $EXTRA > $OUT/replay_$C.log 2>&1
   echo "rc=$?" >> $OUT/replay_$C.log
   for f in /tmp/prof_${C}_$TAG/*counter_collection.csv; do [ -f "$f" ] && (head -1 $f; grep -E "$PAT" $f | head -200) > $OUT/pmc_$C.csv; done
 done
