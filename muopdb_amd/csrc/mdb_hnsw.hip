@@ -706,15 +706,22 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                             if (ru_valid) load_row(ru_id, rowr);
                         }
                         // ---- push all accepted neighbours: slots n .. n+na-1, in edge order
-                        if ((accepted >> lane) & 1ull) C[__popcll(accepted & lt_mask)] = ((uint64_t)od << 32) | id;
+                        // (forward lane permute: the accepted lane of rank r sends its pair to lane (n + r) & 63, everybody
+                        // else to an unused lane; no LDS staging round trip on wave 0's path)
+                        {
+                            const bool mine = (accepted >> lane) & 1ull;
+                            const int dest = mine ? (n + __popcll(accepted & lt_mask)) & 63 : (n + na) & 63;
+                            const uint32_t rod = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)od);
+                            const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)id);
+                            const int rel = (lane - n) & 63;
+                            const bool got = rel < na;
+                            const int reg = (n + rel) >> 6;
 #pragma unroll
-                        for (int r = 0; r < BREGS; ++r) {
-                            const int idx = lane + 64 * r;
-                            if (idx >= n && idx < n + na) {
-                                const uint64_t kk = C[idx - n];
-                                bd[r] = (uint32_t)(kk >> 32);
-                                bi[r] = (uint32_t)kk;
-                                cdv[r] = bd[r];
+                            for (int r = 0; r < BREGS; ++r) {
+                                const bool w = got && reg == r;
+                                bd[r] = w ? rod : bd[r];
+                                bi[r] = w ? rid : bi[r];
+                                cdv[r] = w ? rod : cdv[r];
                             }
                         }
                         // best accepted neighbour of this chunk in pop order (smallest distance, largest id)
