@@ -200,6 +200,17 @@ def test_flat_batched_mfma_filter_equals_exact(ctx, oracle, n, d, b, k, metric, 
     assert_scores(dist[:8], odist)
 
 
+def test_flat_c1_golden_fixture(ctx):
+    # the committed C1 fixture (tests/golden/c1_flat.npz) through the GPU path, one query per call (batch 1)
+    import os
+    from muopdb_amd.index import FlatIndex
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_flat.npz"))
+    idx = FlatIndex(ctx, H.test_hdf5_like())
+    for i, q in enumerate(g["queries"]):
+        ids, dist, _ = idx.search(q[None, :], 10)
+        assert np.array_equal(ids[0], g["ids"][i]) and np.array_equal(dist[0].view(np.uint32), g["dist"][i].view(np.uint32))
+
+
 def test_flat_nan_is_an_error(ctx):
     from muopdb_amd.index import FlatIndex
     from muopdb_amd import lib as L

@@ -420,3 +420,13 @@ def test_ivf_assign_rule(oracle):
     assert cnt3.tolist() == [3, 1, 3, 1]          # 1 vs 81: 80 > 10; nearest == 0: only exact zeros pass (nearest * thr == 0)
     with pytest.raises(IndexError):
         oracle.ivf_assign(cent, v, 5, 0.1)
+
+
+def test_c1_golden_fixture(oracle):
+    # tests/golden/c1_flat.npz (scripts/make_c1_fixture.py): BASELINE config C1 on the reference's own test dataset
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_flat.npz"))
+    base = H.test_hdf5_like()
+    assert np.array_equal(base[:256], g["base_head"])          # the regenerated base is the stored array
+    ids, dist = oracle.flat_topk(0, base, g["queries"], 10)
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(dist.view(np.uint32), g["dist"].view(np.uint32))
