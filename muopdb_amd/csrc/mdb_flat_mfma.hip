@@ -216,11 +216,12 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
         for (int x = 0; x < MF_CH; ++x) {
             const int c = ch * MF_CH + x;
             const float4 f = cur[x];
-            const float live = c < d4 ? 1.0f : 0.0f;
-            xn = fmaf(f.x * live, f.x, xn);
-            xn = fmaf(f.y * live, f.y, xn);
-            xn = fmaf(f.z * live, f.z, xn);
-            xn = fmaf(f.w * live, f.w, xn);
+            if (c < d4) {  // (a select, not a 0/1 factor: 0 * inf would be NaN; the branch is wave-uniform)
+                xn = fmaf(f.x, f.x, xn);
+                xn = fmaf(f.y, f.y, xn);
+                xn = fmaf(f.z, f.z, xn);
+                xn = fmaf(f.w, f.w, xn);
+            }
             auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(f.x), __float_as_uint(f.y), false, false);
             auto s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(f.z), __float_as_uint(f.w), false, false);
             const float b0lo = __uint_as_float(s01[0]), b0hi = __uint_as_float(s01[1]);
@@ -250,13 +251,13 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
             for (int qb = 0; qb < QB; ++qb) {
                 bool any = false;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) any |= (acc[h][qb][r] >= xh + Cr[qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
+                for (int r = 0; r < 16; ++r) any |= !(acc[h][qb][r] < xh + Cr[qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);  // NaN on either side admits
                 any = (any || force) && v < n;
                 if (__ballot(any)) {  // rare
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (v < n && (force || acc[h][qb][r] >= xh + Cr[row])) {
+                        if (v < n && (force || !(acc[h][qb][r] < xh + Cr[row]))) {
                             size_t m = q0 + row;
                             if (m < b) {
                                 const uint64_t pr = ((uint64_t)m << 32) | (uint32_t)v;

@@ -211,6 +211,40 @@ def test_flat_c1_golden_fixture(ctx):
         assert np.array_equal(ids[0], g["ids"][i]) and np.array_equal(dist[0].view(np.uint32), g["dist"][i].view(np.uint32))
 
 
+def test_flat_batched_path_nan_and_inf(ctx):
+    # the MFMA filter never evaluates the exact distance of most rows: a NaN row must still raise (the reference
+    # panics), an infinite row must behave as in the exact kernels
+    import os
+    from muopdb_amd.index import FlatIndex
+    from muopdb_amd import lib as L
+    rng = np.random.default_rng(9)
+    base = rng.standard_normal((70000, 16)).astype(np.float32)
+    q = rng.standard_normal((12, 16)).astype(np.float32)
+    binf = base.copy(); binf[1234, 3] = np.inf; binf[40000] = -np.inf
+    idx = FlatIndex(ctx, binf)
+    ids, dist, _ = idx.search(q, 10)
+    os.environ["MDB_FLAT_NO_MFMA"] = "1"
+    try:
+        eids, edist, _ = idx.search(q, 10)
+    finally:
+        del os.environ["MDB_FLAT_NO_MFMA"]
+    assert np.array_equal(ids, eids) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    qinf = q.copy(); qinf[3, 5] = np.inf   # an infinite query: every distance is inf, the top-k is the first k rows
+    idx2 = FlatIndex(ctx, base)
+    ids, dist, _ = idx2.search(qinf, 10)
+    os.environ["MDB_FLAT_NO_MFMA"] = "1"
+    try:
+        eids, edist, _ = idx2.search(qinf, 10)
+    finally:
+        del os.environ["MDB_FLAT_NO_MFMA"]
+    assert np.array_equal(ids, eids) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    assert ids[3].tolist() == list(range(10))
+    bnan = base.copy(); bnan[65000, 7] = np.nan
+    with pytest.raises(L.MuopdbError) as e:
+        FlatIndex(ctx, bnan).search(q, 10)
+    assert e.value.status == 5
+
+
 def test_flat_nan_is_an_error(ctx):
     from muopdb_amd.index import FlatIndex
     from muopdb_amd import lib as L
