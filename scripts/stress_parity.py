@@ -45,8 +45,15 @@ def data(rng, n, d, kind):
     if kind == 2:  # heavy duplicates / ties
         base = rng.integers(0, 4, (max(n // 8, 1), d)).astype(np.float32)
         return base[rng.integers(0, base.shape[0], n)]
-    v = rng.standard_normal((n, d)).astype(np.float32)
-    return (v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-6)).astype(np.float32)
+    if kind == 3:
+        v = rng.standard_normal((n, d)).astype(np.float32)
+        return (v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-6)).astype(np.float32)
+    # a few infinite components (legal: NotNan accepts inf; distances become inf, never NaN for L2 vs finite
+    # queries as long as no row mixes +inf and -inf against an infinite query)
+    v = rng.standard_normal((n, d)).astype(np.float32) * 10
+    rows = rng.integers(0, n, max(1, n // 50))
+    v[rows, rng.integers(0, d, len(rows))] = np.inf
+    return v
 
 
 def case_flat(ctx, rng):
@@ -55,10 +62,13 @@ def case_flat(ctx, rng):
     b = int(rng.choice([1, 2, 3, 5, 8, 33, 64, 100]))
     k = int(rng.choice([1, 3, 10, 50, 200]))
     metric = int(rng.integers(0, 2))
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
+    if kind == 4:
+        metric = 0  # dot with infinite components yields NaN (inf * 0, inf - inf): both sides error out
     cfg = dict(n=n, d=d, b=b, k=k, metric=metric, kind=kind)
     base = data(rng, n, d, kind)
     q = (base[rng.integers(0, n, b)] + rng.normal(0, 1, (b, d))).astype(np.float32)
+    q = np.where(np.isfinite(q), q, np.float32(0))  # finite queries: inf - inf would be a NaN distance on both sides
     ids, dist, cnt = FlatIndex(ctx, base, metric).search(q, k)
     oids, odist = oracle.flat_topk(metric, base, q, k)
     kk = min(k, n)
