@@ -220,11 +220,16 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     if (b == 0) return MDB_OK;
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     int qt = flat_choose_qt(b, (int)k);
+    // a base that stays in L2 (IVF centroids) gains nothing from sharing loads between 4 queries, and pays
+    // four selectors per block: 2 queries per block, twice the blocks (measured on the C3 coarse step)
+    const bool l2_resident = ts.ntiles * (size_t)ts.d4 * MDB_TILE * 16 <= (8u << 20);
+    if (l2_resident && qt > 2 && !getenv("MDB_FLAT_QT")) qt = 2;
     size_t bpad = (b + qt - 1) / qt * qt;
     size_t ngroups = (ts.ntiles + 3) / 4;
     // blocks: enough to fill the chip (~4 per CU), but several rounds per block when there are many query
     // groups — a block that scans one round pays its selectors' warm-up and final sort for nothing
-    static const size_t target = getenv("MDB_FLAT_BLOCKS") ? (size_t)atoi(getenv("MDB_FLAT_BLOCKS")) : 512;
+    static const size_t target_env = getenv("MDB_FLAT_BLOCKS") ? (size_t)atoi(getenv("MDB_FLAT_BLOCKS")) : 0;
+    const size_t target = target_env ? target_env : (l2_resident ? 1024 : 512);
     const size_t qgroups = bpad / qt;
     unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(ngroups, 1), std::max<size_t>((target + qgroups - 1) / qgroups, 1));
     // keep the partial buffer bounded (<= 256 MiB)
