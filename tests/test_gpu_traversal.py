@@ -457,3 +457,37 @@ def test_hnsw_edge_outside_vector_storage_is_rejected_at_load(ctx, oracle):
     with pytest.raises(L.MuopdbError) as e:
         BlockBasedHnsw(ctx, hidx, hvec, 8)
     assert e.value.status == 2  # MDB_ERR_FORMAT
+
+
+def test_concurrent_searches_from_host_threads(ctx, oracle):
+    """Quantizer: Send + Sync / one query per tokio task in the reference: handles must serve
+    concurrent callers.  Four host threads search one IVF and one HNSW handle at once (ctypes drops the GIL);
+    every row must still equal the serial result."""
+    import threading
+    from muopdb_amd.index import BlockBasedHnsw, BlockBasedIvf
+    rng = np.random.default_rng(41)
+    v = H.sift_like(4000, 32, n_clusters=30, seed=8)
+    files, _, _ = H.build_spann_files(oracle, v, list(range(4000)), 40, max_neighbors=8, max_layers=3, ef_construction=50)
+    ivf = BlockBasedIvf(ctx, files["ivf_index"], files["ivf_vectors"])
+    hidx, hvec = H.build_hnsw_files(oracle, v[:1500], list(range(1500)), max_neighbors=12, max_layers=3, ef_construction=60)
+    hn = BlockBasedHnsw(ctx, hidx, hvec, 32)
+    qs = [(v[rng.integers(0, 1500, 20)] + rng.normal(0, 2, (20, 32))).astype(np.float32) for _ in range(4)]
+    want = [(ivf.search(q, 10, 8), hn.ann_search(q, 10, 100)) for q in qs]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(15):
+                a, b = ivf.search(qs[i], 10, 8), hn.ann_search(qs[i], 10, 100)
+                for j in range(20):
+                    if a.doc_ids(j) != want[i][0].doc_ids(j) or b.doc_ids(j) != want[i][1].doc_ids(j):
+                        errors.append((i, j))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
