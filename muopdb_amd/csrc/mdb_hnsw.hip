@@ -795,22 +795,31 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
             __syncthreads();
         }
     }
+    // the output fields are re-read from the kernarg segment behind an opaque barrier: kept in `a` they would stay
+    // live (= spilled SGPRs, reloaded by v_readlane) through the whole main loop
+    const HnswArgs* ap = (const HnswArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
     const int ws = (int)misc[2];
-    const int outc = ws < a.k ? ws : a.k;
-    for (int i = tid; i < a.k; i += HNSW_BLOCK) a.out_keys[(size_t)qi * a.k + i] = i < outc ? W[i] : MDB_KEY_MAX;
+    const int kk = ap->k;
+    const int outc = ws < kk ? ws : kk;
+    uint64_t* const okeys = ap->out_keys;
+    for (int i = tid; i < kk; i += HNSW_BLOCK) okeys[(size_t)qi * kk + i] = i < outc ? W[i] : MDB_KEY_MAX;
     if (tid == 0) {
-        a.out_counts[qi] = (uint32_t)outc;
+        ap->out_counts[qi] = (uint32_t)outc;
         misc[3] = overflow ? 1u : 0u;
         if (!overflow) {
-            atomicAdd(&a.counters[0], evals);
-            atomicAdd(&a.counters[1], expanded);
-            if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
+            atomicAdd(&ap->counters[0], (unsigned long long)evals);
+            atomicAdd(&ap->counters[1], (unsigned long long)expanded);
+            if (nan_seen) atomicOr(ap->flags, MDB_FLAG_NAN);
         }
     }
     __syncthreads();
     // > ~120 exact distance ties with furthest overflow the 320-slot beam: this block re-runs its query with
     // the general algorithm (sorted LDS sets, room for ~800 ties); rows and counters come from that run
-    if (misc[3]) hnsw_general_traverse<METRIC, VIS_LDS, N16T>(a, qi, lds, true);
+    if (misc[3]) {
+        const HnswArgs a2 = *ap;
+        hnsw_general_traverse<METRIC, VIS_LDS, N16T>(a2, qi, lds, true);
+    }
 }
 
 // keys (distance, point id) -> doc ids, order unchanged (ann_search :192-208)
