@@ -203,7 +203,7 @@ struct BlockSelect {
         buf = (uint64_t*)lds;
         thr = (uint64_t*)((char*)lds + (size_t)cap * 8);
         cnt = (uint32_t*)((char*)lds + (size_t)cap * 8 + 8);
-        if (threadIdx.x == 0) { *cnt = 0; *thr = k_ > 0 ? MDB_KEY_MAX : 0ull; }
+        if (threadIdx.x == 0) { *cnt = 0; cnt[1] = 0; *thr = k_ > 0 ? MDB_KEY_MAX : 0ull; }  // cnt[1]: spare block-wide counter
         __syncthreads();
     }
     // Optional, once, before the first offer() and with the keys of the first round (uniform control
