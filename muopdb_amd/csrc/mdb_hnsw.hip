@@ -427,6 +427,158 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
     hnsw_general_traverse<METRIC, VIS_LDS, N16T>(a, (int)blockIdx.x, lds, false);
 }
 
+// hnsw_closure_kernel — graphs with no more points than ef (SPANN's per-user centroid graphs: ~150
+// centroids searched with ef >= 200).  Then search_layer (index.rs:212-287) degenerates:
+//   * |working_list| <= #visited <= n <= ef, so `working_list.len() < ef` holds at every push: every
+//     unvisited neighbour is accepted and nothing is ever popped from the working list;
+//   * every candidate is also in the working list, so `distance > furthest` (:246) never fires and
+//     every accepted point gets expanded.
+// A layer's result is therefore the CLOSURE of the entry point over that layer's edges through points
+// not visited before (the visited set is shared by all layers, :172) — independent of the pop order —
+// and the counters (one evaluation per newly visited point + one per entry point, one expansion per
+// point with a non-empty row) are order independent too.  So the block expands whole FRONTIERS at
+// once: all edges of all frontier points are test-and-set in parallel (LDS bitmap), all new points'
+// distances are evaluated by the sixteen 16-lane groups, ~diameter rounds per layer instead of one
+// sequential step per point; the layer's working list is sorted once at the end (block bitonic).
+template <int METRIC, int N16T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wcap) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int qi = (int)blockIdx.x;
+    uint64_t* W = (uint64_t*)lds;
+    uint32_t* cur = (uint32_t*)(W + wcap);
+    uint32_t* nxt = cur + wcap;
+    float* qs = (float*)(nxt + wcap);
+    unsigned long long* best = (unsigned long long*)(qs + a.dpad);  // min key of the layer (next entry point)
+    uint32_t* misc = (uint32_t*)(best + 1);  // [0..2] rotating frontier counters, [3] evals, [4] expanded, [5] NaN seen
+    uint32_t* vis = misc + 16;
+
+    const int tid = threadIdx.x;
+    const int grp = tid >> 4, j = tid & 15;
+    const HnswUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
+    if (!u.valid || u.n == 0 || u.num_layers == 0 || u.entry_point >= u.n || u.n > (uint32_t)wcap) {
+        for (int i = tid; i < a.k; i += BLOCK) a.out_keys[(size_t)qi * a.k + i] = MDB_KEY_MAX;
+        if (tid == 0) {
+            a.out_counts[qi] = 0;
+            if (u.valid && u.n > (uint32_t)wcap) atomicOr(a.flags, MDB_FLAG_OVERFLOW);  // host dispatch guarantees n <= wcap
+        }
+        return;
+    }
+    for (int i = tid; i < a.dpad; i += BLOCK) qs[i] = a.q[(size_t)qi * a.qstride + i];
+    for (uint32_t i = tid; i < (u.n + 31) / 32; i += BLOCK) vis[i] = 0;
+    if (tid < 16) misc[tid] = 0;
+    __syncthreads();
+
+    const float* vecs = a.vecs + u.vec_off;
+    float qr[N16T > 0 ? N16T : 1];
+    if (N16T > 0) {
+#pragma unroll
+        for (int c = 0; c < N16T; ++c) qr[c] = qs[16 * c + j];
+    }
+    uint32_t ep = u.entry_point;
+    int wn = 0;
+    for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
+        // the entry point is visited and becomes the first frontier (index.rs:219-231)
+        if (tid == 0) {
+            vis[ep >> 5] |= 1u << (ep & 31);
+            cur[0] = ep;
+            misc[0] = 0; misc[1] = 0; misc[2] = 0;
+            *best = MDB_KEY_MAX;
+        }
+        wn = 0;
+        int ncur = 1, par = 0;
+        const uint32_t stride = layer == 0 ? u.S0 : u.SU;
+        __syncthreads();
+        while (ncur > 0) {
+            // one 16-lane group per frontier point: its adjacency row and its vector are fetched together
+            // (the row does not depend on the distance), the point enters the working list, then its edges
+            // are test-and-set and the new points form the next frontier
+            for (int i = grp; i < ncur; i += BLOCK / 16) {
+                const uint32_t f = cur[i];
+                const uint32_t* row = nullptr;
+                if (layer == 0) {
+                    if (f < u.n0) row = a.adj + u.adj0_off + (size_t)f * u.S0;
+                } else if (a.level[u.upper_off + f] >= layer) {
+                    row = a.adj + u.adjU_off + ((size_t)a.upper_first[u.upper_off + f] + (layer - 1)) * u.SU;
+                }
+                uint32_t e[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t t = 16 * c + j;
+                    e[c] = (row && t < stride) ? row[t] : 0xFFFFFFFFu;
+                }
+                const float d = MDB_GROUP_DIST(vecs + (size_t)f * a.dpad);
+                if (j == 0) {
+                    W[wn + i] = make_key(d, f);
+                    if (d != d) misc[5] = 1;
+                    if (e[0] != 0xFFFFFFFFu) atomicAdd(&misc[4], 1u);   // rows are packed: slot 0 empty <=> no edges
+                }
+                for (uint32_t t0 = 0;;) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t nbr = e[c];
+                        if (nbr != 0xFFFFFFFFu) {
+                            const uint32_t bit = 1u << (nbr & 31);
+                            const uint32_t old = atomicOr(&vis[nbr >> 5], bit);
+                            if (!(old & bit)) nxt[atomicAdd(&misc[par], 1u)] = nbr;
+                        }
+                    }
+                    t0 += 64;
+                    if (!row || t0 >= stride) break;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t t = t0 + 16 * c + j;
+                        e[c] = t < stride ? row[t] : 0xFFFFFFFFu;
+                    }
+                }
+            }
+            __syncthreads();
+            // three rotating counters: the one zeroed here was last read before this barrier and is next
+            // added to after the following one, so a round costs a single barrier
+            const int nn = (int)misc[par];
+            const int par2 = par == 0 ? 2 : par - 1;
+            if (tid == 0) { misc[par2] = 0; misc[3] += (uint32_t)ncur; }
+            wn += ncur;
+            ncur = nn;
+            par = par == 2 ? 0 : par + 1;
+            uint32_t* tsw = cur; cur = nxt; nxt = tsw;
+        }
+        __syncthreads();
+        if (layer > 0) {
+            // ep = first minimum of the (distance,id)-sorted working list (index.rs:177-181)
+            unsigned long long m = MDB_KEY_MAX;
+            for (int i = tid; i < wn; i += BLOCK) m = W[i] < m ? W[i] : m;
+            if (m != MDB_KEY_MAX) atomicMin(best, m);
+            __syncthreads();
+            ep = key_id((uint64_t)*best);
+            __syncthreads();
+        }
+    }
+    // layer 0: sort the working list by (distance, id), truncate to k (index.rs:190-191)
+    int n2 = 64;
+    while (n2 < wn) n2 <<= 1;
+    for (int i = wn + tid; i < n2; i += BLOCK) W[i] = MDB_KEY_MAX;
+    __syncthreads();
+    for (int k2 = 2; k2 <= n2; k2 <<= 1)
+        for (int jj = k2 >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < n2; i += BLOCK) {
+                const int l = i ^ jj;
+                if (l > i) {
+                    const uint64_t x = W[i], y = W[l];
+                    if ((x > y) == ((i & k2) == 0)) { W[i] = y; W[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    const int outc = wn < a.k ? wn : a.k;
+    for (int i = tid; i < a.k; i += BLOCK) a.out_keys[(size_t)qi * a.k + i] = i < outc ? W[i] : MDB_KEY_MAX;
+    if (tid == 0) {
+        a.out_counts[qi] = (uint32_t)outc;
+        atomicAdd(&a.counters[0], (unsigned long long)misc[3]);
+        atomicAdd(&a.counters[1], (unsigned long long)misc[4]);
+        if (misc[5]) atomicOr(a.flags, MDB_FLAG_NAN);
+    }
+}
+
 
 // ==========================================================================================
 // hnsw_beam_kernel — the ef <= 256 traversal kernel (bench configuration).
@@ -1124,6 +1276,39 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         else if (nf == 48) MDB_HNSW_LAUNCH4(METRIC, VL, 48);                                                       \
         else MDB_HNSW_LAUNCH4(METRIC, VL, 0);                                                                      \
     } while (0)
+    // graphs no larger than ef (SPANN centroid graphs): frontier-parallel closure, see hnsw_closure_kernel
+    if (max_n <= ef && max_n <= 4096 && !getenv("MDB_HNSW_NO_CLOSURE")) {
+        int wcap = 64;
+        while ((uint32_t)wcap < max_n) wcap <<= 1;
+        // small batches: 64 groups per query (latency); large ones: 256-thread blocks, four resident per CU
+        const char* cbe = getenv("MDB_CLOSURE_BLOCK");
+        const bool big = cbe ? atoi(cbe) >= 1024 : b <= 256;
+        const size_t clds = (size_t)wcap * 16 + (size_t)dpad * 4 + 8 + 64 + (((size_t)max_n + 31) / 32 + 1) * 4;
+#define MDB_CLOSURE_LAUNCH(METRIC, NF, CB)                                                                                    \
+    do {                                                                                                                    \
+        if (clds > 48 * 1024)                                                                                               \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_closure_kernel<METRIC, NF, CB>,                              \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));                       \
+        hnsw_closure_kernel<METRIC, NF, CB><<<dim3((unsigned)b), CB, clds, ctx->stream>>>(a, wcap);                         \
+    } while (0)
+#define MDB_CLOSURE_LAUNCH_M(METRIC)                                 \
+    do {                                                             \
+        if (big) {                                                   \
+            if (nf == 8) MDB_CLOSURE_LAUNCH(METRIC, 8, 1024);        \
+            else if (nf == 48) MDB_CLOSURE_LAUNCH(METRIC, 48, 1024); \
+            else MDB_CLOSURE_LAUNCH(METRIC, 0, 1024);                \
+        } else {                                                     \
+            if (nf == 8) MDB_CLOSURE_LAUNCH(METRIC, 8, 256);         \
+            else if (nf == 48) MDB_CLOSURE_LAUNCH(METRIC, 48, 256);  \
+            else MDB_CLOSURE_LAUNCH(METRIC, 0, 256);                 \
+        }                                                            \
+    } while (0)
+        if (metric == MDB_METRIC_L2) MDB_CLOSURE_LAUNCH_M(MDB_METRIC_L2); else MDB_CLOSURE_LAUNCH_M(MDB_METRIC_DOT);
+#undef MDB_CLOSURE_LAUNCH_M
+#undef MDB_CLOSURE_LAUNCH
+        MDB_HIP(ctx, hipGetLastError());
+        return MDB_OK;
+    }
     // ef <= 256: register-resident beam; above: sorted LDS sets (MDB_HNSW_NO_BEAM forces the latter, for tests)
     const bool beam = ef <= 256 && !getenv("MDB_HNSW_NO_BEAM");
     if (metric == MDB_METRIC_L2) {

@@ -26,43 +26,49 @@ struct SpannSet {
     size_t num_users = 0;
 };
 
-// one thread per query (B is small); candidates come sorted by (distance, point id)
-__global__ void spann_filter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int nexp,
+// one wave per query, one lane per explored centroid: the doc-id lookups (dependent HBM reads) of a query are
+// all in flight at once; kept centroids are compacted in candidate order by ballot.  Candidates come sorted by
+// (distance, point id), so the `min_by partial_cmp` of :233-237 is the first one.
+__global__ __launch_bounds__(256) void spann_filter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int nexp,
                                     float ratio, const HnswUserDev* __restrict__ husers, const IvfUserDev* __restrict__ iusers,
                                     const uint32_t* __restrict__ q_user, const uint8_t* __restrict__ hnsw_index_bytes,
                                     uint32_t* __restrict__ probes, uint32_t* __restrict__ probe_cnt, uint8_t* __restrict__ found,
                                     size_t b, uint32_t* __restrict__ flags) {
-    size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t qi = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (qi >= b) return;
-    uint32_t ui = q_user ? q_user[qi] : 0;
-    const HnswUserDev hu = husers[ui];
-    const IvfUserDev iu = iusers[ui];
-    int c = (int)counts[qi];
-    if (!hu.valid || !iu.valid || c == 0) {  // unknown user / empty centroid result => None (:229-231)
-        probe_cnt[qi] = 0;
-        found[qi] = 0;
+    const uint32_t ui = q_user ? q_user[qi] : 0;
+    const uint32_t hvalid = husers[ui].valid, ivalid = iusers[ui].valid;
+    const int c = (int)counts[qi];
+    if (!hvalid || !ivalid || c == 0) {  // unknown user / empty centroid result => None (:229-231)
+        if (lane == 0) { probe_cnt[qi] = 0; found[qi] = 0; }
         return;
     }
-    found[qi] = 1;
-    float nearest = key_dist(keys[qi * (size_t)nexp]);  // min_by partial_cmp (:233-237): the list is ascending
-    for (int i = 1; i < c; ++i) {
-        float s = key_dist(keys[qi * (size_t)nexp + i]);
-        if (s < nearest) nearest = s;
-    }
-    float rhs = __fmul_rn(nearest, ratio);
+    const uint64_t doc_off = husers[ui].doc_ids_off;
+    const uint64_t num_lists = iusers[ui].num_lists;
+    const uint64_t* row = keys + qi * (size_t)nexp;
+    const float nearest = key_dist(row[0]);
+    const float rhs = __fmul_rn(nearest, ratio);
     uint32_t n = 0;
-    for (int i = 0; i < c; ++i) {
-        uint64_t key = keys[qi * (size_t)nexp + i];
-        float lhs = __fsub_rn(key_dist(key), nearest);
-        if (lhs <= rhs) {
-            // `x.doc_id as usize`: the centroid graph's doc id is the centroid (posting list) index
-            const uint64_t* dp = (const uint64_t*)(hnsw_index_bytes + hu.doc_ids_off + (size_t)key_id(key) * 16);
-            uint64_t cid = dp[0];
-            if (dp[1] != 0 || cid >= iu.num_lists) { atomicOr(flags, MDB_FLAG_RANGE); continue; }
-            probes[qi * (size_t)nexp + n++] = (uint32_t)cid;
+    for (int i0 = 0; i0 < c; i0 += 64) {
+        const int i = i0 + lane;
+        bool keep = false;
+        uint64_t cid = 0;
+        if (i < c) {
+            const uint64_t key = row[i];
+            if (__fsub_rn(key_dist(key), nearest) <= rhs) {
+                // `x.doc_id as usize`: the centroid graph's doc id is the centroid (posting list) index
+                const uint64_t* dp = (const uint64_t*)(hnsw_index_bytes + doc_off + (size_t)key_id(key) * 16);
+                cid = dp[0];
+                if (dp[1] != 0 || cid >= num_lists) atomicOr(flags, MDB_FLAG_RANGE);
+                else keep = true;
+            }
         }
+        const unsigned long long bal = __ballot(keep);
+        if (keep) probes[qi * (size_t)nexp + n + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)cid;
+        n += (uint32_t)__popcll(bal);
     }
-    probe_cnt[qi] = n;
+    if (lane == 0) { probe_cnt[qi] = n; found[qi] = 1; }
 }
 
 static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b, const uint32_t* h_q_user,
@@ -103,7 +109,7 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     ctx->stat_bytes_per_scored = s.ivf.bytes_per_scored();
     ctx->stat_fixed_bytes = 0;
     MDB_TRY(s.hnsw.search(dq, qstride, b, d_q_user, nexp, params->ef_construction, ckeys, ccnt));
-    spann_filter_kernel<<<dim3((unsigned)((b + 127) / 128)), 128, 0, ctx->stream>>>(
+    spann_filter_kernel<<<dim3((unsigned)((b + 3) / 4)), 256, 0, ctx->stream>>>(
         ckeys, ccnt, (int)nexp, params->centroid_distance_ratio, s.hnsw.d_users.p, s.ivf.d_users.p, d_q_user,
         s.hnsw.d_index.p, probes, pcnt, dfound, b, ctx->d_flags);
     MDB_HIP(ctx, hipGetLastError());

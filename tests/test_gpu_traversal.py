@@ -100,6 +100,49 @@ def test_hnsw_over_pq_codes(ctx, oracle, n, d, sub, bits, metric, ef):
     assert st["distance_evals"] == evals and st["expanded_nodes"] == expanded
 
 
+@pytest.mark.parametrize("n,d,M,layers,metric,seed", [
+    (1, 8, 4, 1, 0, 1), (2, 16, 4, 2, 0, 2), (17, 5, 4, 3, 0, 3), (152, 768, 16, 3, 0, 4), (300, 128, 8, 4, 1, 5),
+    (600, 30, 3, 5, 0, 6), (2000, 12, 6, 4, 0, 7)])
+def test_hnsw_small_graph_closure_kernel(ctx, oracle, n, d, M, layers, metric, seed):
+    """Graphs with no more points than ef (SPANN centroid graphs) run hnsw_closure_kernel (whole frontiers per
+    round); rows AND the evaluation / expansion counters must equal the sequential oracle's, and the
+    sequential kernels' (MDB_HNSW_NO_CLOSURE)."""
+    import os
+    from muopdb_amd.index import BlockBasedHnsw, NoQuantizer
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((n, d)).astype(np.float32)
+    if n > 20:
+        v[n // 2] = v[3]  # exact duplicates: distance ties broken by id
+        v[n // 3] = v[3]
+    doc = [11 * i + 5 + ((i % 2) << 77) for i in range(n)]
+    hidx, hvec = H.build_hnsw_files(oracle, v, doc, max_neighbors=M, max_layers=layers, ef_construction=30, seed=seed,
+                                    metric=metric)
+    g = BlockBasedHnsw(ctx, hidx, hvec, d, NoQuantizer(d, metric))
+    o = oracle.BlockBasedHnsw(hidx, hvec, d, oracle.Quant(oracle.QUANT_NONE, metric))
+    q = rng.standard_normal((40, d)).astype(np.float32)
+    q[0] = v[min(3, n - 1)]
+    for k, ef in [(10, n), (n + 5, n + 7), (1, 4096), (16, max(n, 200))]:
+        o.ann_search(q[:1], 1, 1)
+        o.stats()
+        ores = o.ann_search(q, k, ef)
+        evals, expanded = o.stats()
+        ctx.stats()
+        gres = g.ann_search(q, k, ef)
+        st = ctx.stats()
+        assert_result_rows(gres, ores, len(q))
+        assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)
+        os.environ["MDB_HNSW_NO_CLOSURE"] = "1"
+        try:
+            sres = g.ann_search(q, k, ef)
+        finally:
+            del os.environ["MDB_HNSW_NO_CLOSURE"]
+        st2 = ctx.stats()
+        assert_result_rows(sres, ores, len(q))
+        assert (st2["distance_evals"], st2["expanded_nodes"]) == (evals, expanded)
+    if n > 1:   # one below n: the sequential kernels again
+        assert_result_rows(g.ann_search(q, 5, n - 1), o.ann_search(q, 5, n - 1), len(q))
+
+
 def test_hnsw_general_kernel_equals_beam_kernel(ctx, oracle):
     """hnsw_search_kernel (sorted LDS sets; serves ef > 256) must give the oracle's rows at small ef too:
     MDB_HNSW_NO_BEAM routes ef <= 256 through it."""
