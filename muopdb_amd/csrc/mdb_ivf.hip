@@ -399,7 +399,7 @@ __device__ __forceinline__ void pq2_add_row(const float* __restrict__ row, float
     }
 }
 
-template <int METRIC, int SUBDIM, int MW>
+template <int METRIC, int SUBDIM, int MW, bool FILT>
 __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m,
                                                                  int nbits, const float* __restrict__ cb,
                                                                  const uint8_t* __restrict__ qcodes) {
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
     uint32_t* ppref = pstart + PQ2_PCH;             // [PQ2_PCH + 1] exclusive prefix of tile counts
     float* qv = (float*)(ppref + PQ2_PCH + 16);     // the query's own codebook rows [m][SUBDIM]
     float* lut = qv + m * SUBDIM;
+    uint16_t* atab = (uint16_t*)(lut + (size_t)(m << nbits) * SUBDIM);  // FILT: lower bounds of the row sums, bf16
     const int qi = blockIdx.y, split = blockIdx.x, nsplit = gridDim.x;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / MDB_WAVE), lane = tid % MDB_WAVE;
     const IvfUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
@@ -442,6 +443,53 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
         }
     }
     __syncthreads();
+    if (FILT) {
+        // L2 only (every term >= 0).  atab[s][c] <= the REAL sum of row (s, c): f32 sum, shrunk by more than its
+        // rounding error, truncated to bf16.  A vector whose bound already exceeds the selector's admission threshold
+        // cannot be admitted: its exact distance (sum of the same non-negative terms in the reference's order,
+        // <= 64 roundings) is >= (1 - 2^-17) x the real sum.  16 two-byte LDS reads replace 16 row reads for it.
+        for (int i = tid; i < (m << nbits); i += PQ2_BLOCK) {
+            const float* row = lut + (size_t)i * SUBDIM;
+            float sum = 0.0f;
+#pragma unroll
+            for (int e = 0; e < SUBDIM; ++e) sum = __fadd_rn(sum, row[e]);
+            const float low = __fmul_rn(sum, 0.99999f);
+            atab[i] = sum != sum ? (uint16_t)0x7FC0u : (uint16_t)(__float_as_uint(low) >> 16);
+        }
+        __syncthreads();
+    }
+
+    // exact symmetric distance of one stored code (this lane's) against the query's, as a selection key
+    auto exact_key = [&](uint32_t vid, const uint32_t (&cwv)[MW], bool active) -> uint64_t {
+        if (!active) return MDB_KEY_MAX;
+        float s16[16], s8[8], s4[4];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) s16[x] = 0.0f;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) s8[x] = 0.0f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) s4[x] = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) {
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) {
+                int s = w * 4 + bi;
+                if (s < m) {
+                    uint32_t code = (cwv[w] >> (8 * bi)) & 0xFFu;
+                    pq2_add_row<SUBDIM>(lut + ((size_t)(s << nbits) + code) * SUBDIM, s16, s8, s4);
+                }
+            }
+        }
+        float rs = __fadd_rn(__fadd_rn(__fadd_rn(reduce_ordered<16>(s16), reduce_ordered<8>(s8)), reduce_ordered<4>(s4)), 0.0f);
+        float dist = METRIC == MDB_METRIC_L2 ? rs : -rs;
+        if (dist != dist) nan_seen = true;
+        return make_key(dist, vid);
+    };
+    // FILT: survivors of the bound filter waiting for their exact evaluation (one per lane, lanes < pend_n)
+    uint32_t pend_pid = 0xFFFFFFFFu, pend_cw[MW];
+#pragma unroll
+    for (int w = 0; w < MW; ++w) pend_cw[w] = 0;
+    int pend_n = 0;
 
     if (u.valid) {
         for (int p0 = 0; p0 < np; p0 += PQ2_PCH) {
@@ -524,30 +572,56 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
                 // ---- compute round r-2 (set CC)
                 if (r >= 2) {
                     uint64_t key = MDB_KEY_MAX;
-                    if (live[CC] && pid[CC] != 0xFFFFFFFFu && !((tw[CC] >> (pid[CC] & 31)) & 1u) && ((aw[CC] >> (pid[CC] & 31)) & 1u)) {
-                        float s16[16], s8[8], s4[4];
+                    const bool take = live[CC] && pid[CC] != 0xFFFFFFFFu && !((tw[CC] >> (pid[CC] & 31)) & 1u) && ((aw[CC] >> (pid[CC] & 31)) & 1u);
+                    if (FILT) {
+                        // bound filter: only vectors whose lower bound does not exceed the admission threshold are
+                        // evaluated exactly — later, from a wave-wide pending set in registers (compacted by a
+                        // forward lane permute), so that the exact pass runs with (nearly) all lanes busy
+                        bool surv = false;
+                        if (take) {
+                            ++scored;
+                            float lb = 0.0f;
 #pragma unroll
-                        for (int x = 0; x < 16; ++x) s16[x] = 0.0f;
+                            for (int w = 0; w < MW; ++w) {
 #pragma unroll
-                        for (int x = 0; x < 8; ++x) s8[x] = 0.0f;
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) s4[x] = 0.0f;
-#pragma unroll
-                        for (int w = 0; w < MW; ++w) {
-#pragma unroll
-                            for (int bi = 0; bi < 4; ++bi) {
-                                int s = w * 4 + bi;
-                                if (s < m) {
-                                    uint32_t code = (cw[CC][w] >> (8 * bi)) & 0xFFu;
-                                    pq2_add_row<SUBDIM>(lut + ((size_t)(s << nbits) + code) * SUBDIM, s16, s8, s4);
+                                for (int bi = 0; bi < 4; ++bi) {
+                                    const int s = w * 4 + bi;
+                                    if (s < m) {
+                                        const uint32_t code = (cw[CC][w] >> (8 * bi)) & 0xFFu;
+                                        lb = __fadd_rn(lb, __uint_as_float((uint32_t)atab[(s << nbits) + code] << 16));
+                                    }
                                 }
                             }
+                            // a NaN bound (NaN term) always survives: the exact pass reports it
+                            const uint32_t thr_hi = (uint32_t)(*sel.thr >> 32);
+                            surv = !(lb == lb && f32_orderable(__fmul_rn(lb, 0.99998f)) > thr_hi);
                         }
-                        float rs = __fadd_rn(__fadd_rn(__fadd_rn(reduce_ordered<16>(s16), reduce_ordered<8>(s8)),
-                                                       reduce_ordered<4>(s4)), 0.0f);
-                        float dist = METRIC == MDB_METRIC_L2 ? rs : -rs;
-                        if (dist != dist) nan_seen = true;
-                        key = make_key(dist, pid[CC]);
+                        const unsigned long long sm = __ballot(surv);
+                        const int ns = __popcll(sm);
+                        if (ns) {
+                            bool flushed = false;
+                            if (pend_n + ns > MDB_WAVE) {
+                                key = exact_key(pend_pid, pend_cw, lane < pend_n);
+                                pend_n = 0;
+                                flushed = true;
+                            }
+                            const int dest = surv ? pend_n + __popcll(sm & ((1ull << lane) - 1ull)) : (pend_n + ns) & (MDB_WAVE - 1);
+                            const uint32_t rp = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)pid[CC]);
+                            const bool got = lane >= pend_n && lane < pend_n + ns;
+                            pend_pid = got ? rp : pend_pid;
+#pragma unroll
+                            for (int w = 0; w < MW; ++w) {
+                                const uint32_t rc = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)cw[CC][w]);
+                                pend_cw[w] = got ? rc : pend_cw[w];
+                            }
+                            pend_n += ns;
+                            if (!flushed && pend_n == MDB_WAVE) {
+                                key = exact_key(pend_pid, pend_cw, true);
+                                pend_n = 0;
+                            }
+                        }
+                    } else if (take) {
+                        key = exact_key(pid[CC], cw[CC], true);
                         ++scored;
                     }
                     if (p0 == 0 && r == 2) sel.warm_start(key);
@@ -567,6 +641,10 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
                 }
             }
             __syncthreads();  // pstart / ppref are rewritten by the next chunk
+        }
+        if (FILT) {  // the survivors still pending
+            sel.offer(exact_key(pend_pid, pend_cw, lane < pend_n));
+            sel.round_end();
         }
     }
     if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
@@ -888,13 +966,16 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         nsplit = std::min(nsplit, 64);
     }
     // PQ fast path (ivf_scan_pq2_kernel): compile-time subvector width, table + selector + tile map in LDS
-    size_t pq2_lds = 0;
-    bool pq2 = false;
+    size_t pq2_lds = 0, pq2_lds_f = 0;
+    bool pq2 = false, pq2_filt = false;
     if (kind == MDB_QUANT_PQ && !getenv("MDB_PQ_NO_FAST")) {
         pq2_lds = ((BlockSelect<PQ2_BLOCK>::lds_bytes((int)k) + 15) & ~(size_t)15) + (2 * PQ2_PCH + 16) * 4 +
                   (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * pq.K * pq.subdim * 4;
         pq2 = (pq.subdim == 4 || pq.subdim == 8 || pq.subdim == 16 || pq.subdim == 32) && (mw == 1 || mw == 2 || mw == 4 || mw == 8) &&
               pq.K == (1 << pq.num_bits) && pq.num_bits <= 8 && pq2_lds <= 160 * 1024 - 256;
+        // L2: bound filter in front of the exact row sums (ivf_scan_pq2_kernel<.., FILT>) when its table fits too
+        pq2_lds_f = pq2_lds + (size_t)pq.m * pq.K * 2;
+        pq2_filt = pq2 && metric == MDB_METRIC_L2 && pq2_lds_f <= 160 * 1024 - 256 && !getenv("MDB_PQ_NO_FILTER");
         if (pq2) {  // one block per CU (LDS).  More, shorter blocks do NOT balance skewed lists better here: the hardware
             // dispatches 150 KB-LDS workgroups in order, so CUs idle between blocks (measured: 256 blocks 98 us,
             // 512 blocks 140 us, 1024 blocks 247 us for the same work)
@@ -931,10 +1012,17 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     } while (0)
 #define MDB_PQ2_LAUNCH(METRIC, SD, MWT)                                                                               \
     do {                                                                                                             \
-        MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq2_kernel<METRIC, SD, MWT>,                          \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq2_lds));                \
-        ivf_scan_pq2_kernel<METRIC, SD, MWT><<<grid, PQ2_BLOCK, pq2_lds, ctx->stream>>>(                              \
-            a, d_codes.p, pq.m, pq.num_bits, pq.codebook.p, (uint8_t*)qcodes);                                   \
+        if (METRIC == MDB_METRIC_L2 && pq2_filt) {                                                                   \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq2_kernel<METRIC, SD, MWT, METRIC == MDB_METRIC_L2>,  \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq2_lds_f));          \
+            ivf_scan_pq2_kernel<METRIC, SD, MWT, METRIC == MDB_METRIC_L2><<<grid, PQ2_BLOCK, pq2_lds_f, ctx->stream>>>(   \
+                a, d_codes.p, pq.m, pq.num_bits, pq.codebook.p, (uint8_t*)qcodes);                               \
+        } else {                                                                                                     \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq2_kernel<METRIC, SD, MWT, false>,                   \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq2_lds));            \
+            ivf_scan_pq2_kernel<METRIC, SD, MWT, false><<<grid, PQ2_BLOCK, pq2_lds, ctx->stream>>>(                      \
+                a, d_codes.p, pq.m, pq.num_bits, pq.codebook.p, (uint8_t*)qcodes);                               \
+        }                                                                                                            \
     } while (0)
 #define MDB_PQ2_SD(METRIC, MWT)                                                                                      \
     do {                                                                                                             \
