@@ -343,6 +343,66 @@ def test_ivf_pq_fast_scan_shapes(ctx, oracle, n, d, sub, bits, L, P, k):
     assert_result_rows(g.search(q, k, P), o.search(q, k, num_probes=P), len(q))
 
 
+@pytest.mark.parametrize("case", ["wide_range", "ties", "overflow_to_inf", "zeros"])
+def test_ivf_pq_bound_filter_adversarial(ctx, oracle, case):
+    """The L2 bound filter of ivf_scan_pq2_kernel (bf16 lower bounds in front of the exact row sums) must never
+    drop a true neighbour: codebooks with 60 decades of dynamic range, few distinct rows (thousands of exact
+    ties with the admission threshold), squares that overflow to +inf, all-zero distances — rows, scores and the
+    scored-vector counter equal the oracle's and the unfiltered kernel's (MDB_PQ_NO_FILTER)."""
+    import os
+    from muopdb_amd.index import BlockBasedIvf, ProductQuantizer
+    rng = np.random.default_rng({"wide_range": 1, "ties": 2, "overflow_to_inf": 3, "zeros": 4}[case])
+    n, d, sub, bits, L, P, k = 6000, 64, 8, 8, 6, 6, 10
+    m, K = d // sub, 1 << bits
+    if case == "wide_range":
+        cb = rng.standard_normal((m, K, sub)).astype(np.float32)
+        cb *= (np.float32(10) ** rng.integers(-15, 15, (m, K, 1)).astype(np.float32))
+        cb[:, ::17, :] = 0
+        cb[1, 5, :] = np.float32(1e-42)  # denormal
+    elif case == "ties":
+        base = rng.integers(0, 3, (m, 4, sub)).astype(np.float32)
+        cb = base[:, rng.integers(0, 4, K), :]  # 4 distinct rows per subspace
+    elif case == "overflow_to_inf":
+        cb = rng.standard_normal((m, K, sub)).astype(np.float32)
+        cb[:, :8, :] = np.float32(3e38) * np.sign(cb[:, :8, :])  # (a - b)^2 -> +inf against ordinary rows
+    else:
+        cb = np.zeros((m, K, sub), np.float32)
+    cb = np.ascontiguousarray(cb.reshape(-1))
+    codes = rng.integers(0, K, (n, m)).astype(np.uint8)
+    if case == "overflow_to_inf":
+        codes[rng.random((n, m)) < 0.9] = 40  # most subvectors ordinary, some vectors fully finite
+    # vectors = their own reconstruction, so quantize() gives the codes back (nearest row; ties -> lowest index)
+    v = cb.reshape(m, K, sub)[np.arange(m)[None, :], codes].reshape(n, d)
+    if case == "overflow_to_inf":
+        v = np.where(np.abs(v) > 1e38, np.sign(v) * np.float32(3e38), v).astype(np.float32)
+    cent = v[rng.choice(n, L, replace=False)].astype(np.float32)
+    if case in ("overflow_to_inf", "wide_range"):
+        cent = rng.standard_normal((L, d)).astype(np.float32)
+    doc_ids = [5 + 2 * i for i in range(n)]
+    opq = oracle.ProductQuantizer(d, sub, bits, cb)
+    with np.errstate(all="ignore"):
+        stored = opq.quantize(v.astype(np.float32))
+    index, vec, pls = H.build_ivf_files(np.nan_to_num(v, posinf=3e38, neginf=-3e38).clip(-1e18, 1e18) if case != "zeros" else v,
+                                        doc_ids, cent, quantize=lambda x: stored)
+    o = oracle.BlockBasedIvf(index, vec, oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, sub, bits, cb))
+    g = BlockBasedIvf(ctx, index, vec, ProductQuantizer(d, sub, bits, cb))
+    q = v[rng.integers(0, n, 16)].astype(np.float32)
+    probes = np.tile(np.arange(L, dtype=np.uint32), (len(q), 1))
+    for kk in (k, 1, 64, 200):
+        ores = o.search(q, kk, probes=probes)
+        gres = g.search_with_centroids_and_remap(q, probes, kk)
+        st = ctx.stats()
+        assert_result_rows(gres, ores, len(q))
+        os.environ["MDB_PQ_NO_FILTER"] = "1"
+        try:
+            gres2 = g.search_with_centroids_and_remap(q, probes, kk)
+        finally:
+            del os.environ["MDB_PQ_NO_FILTER"]
+        st2 = ctx.stats()
+        assert_result_rows(gres2, ores, len(q))
+        assert st["scored_vectors"] == st2["scored_vectors"] == n * len(q)
+
+
 def test_ivf_duplicates_tombstones_and_errors(ctx, oracle):
     from muopdb_amd import lib as L
     o, g, q, v, doc_ids = _ivf_case(oracle, ctx, 1200, 16, 6, seed=5, cpv=2)
