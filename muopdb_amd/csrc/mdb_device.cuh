@@ -182,30 +182,40 @@ __device__ __forceinline__ float finish_distance(float raw) {
 // Streaming selection of the k smallest u64 keys seen by a block.  Usage per block:
 //   sel.init(...); loop { sel.offer(key) by every thread (MDB_KEY_MAX = nothing); sel.round_end(); }
 //   sel.finish();  -> buf[0 .. count()) ascending
-// LDS: cap u64 keys + 2 words.  Requires cap = pow2 >= k + BLOCK.
+// LDS: cap u64 keys + threshold + 4 words.  Requires cap = pow2 >= k + BLOCK.
+// One block barrier per round: a round's admissions are counted in one of THREE rotating LDS counters
+// (positions = uniform running total + atomicAdd on the round's counter).  After the barrier every thread
+// reads that counter — nobody adds to it during the next round — so the running total and the "queue nearly
+// full" decision are uniform without a second barrier; the counter zeroed after barrier r is the one of
+// round r-1 (all its readers are past barrier r) and is next used in round r+2.
 template <int BLOCK>
 struct BlockSelect {
     uint64_t* buf;
-    uint32_t* cnt;       // number of valid keys in buf
     uint64_t* thr;       // admission threshold: key must be < thr
+    uint32_t* ctr;       // [0..2] rotating admission counters, [3] spare block-wide counter for the caller
     int k, cap;
+    uint32_t total;      // keys in buf before the current round (uniform)
+    int slot;            // counter of the current round (uniform)
 
     static __host__ __device__ int cap_for(int k) {
         int c = 2;
         while (c < k + BLOCK) c <<= 1;
         return c;
     }
-    static __host__ __device__ size_t lds_bytes(int k) { return (size_t)cap_for(k) * 8 + 16; }
+    static __host__ __device__ size_t lds_bytes(int k) { return (size_t)cap_for(k) * 8 + 8 + 16; }
 
     __device__ void init(void* lds, int k_) {
         k = k_;
         cap = cap_for(k_);
         buf = (uint64_t*)lds;
         thr = (uint64_t*)((char*)lds + (size_t)cap * 8);
-        cnt = (uint32_t*)((char*)lds + (size_t)cap * 8 + 8);
-        if (threadIdx.x == 0) { *cnt = 0; cnt[1] = 0; *thr = k_ > 0 ? MDB_KEY_MAX : 0ull; }  // cnt[1]: spare block-wide counter
+        ctr = (uint32_t*)((char*)lds + (size_t)cap * 8 + 8);
+        total = 0;
+        slot = 0;
+        if (threadIdx.x == 0) { ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; *thr = k_ > 0 ? MDB_KEY_MAX : 0ull; }
         __syncthreads();
     }
+    __device__ __forceinline__ uint32_t* spare() const { return ctr + 3; }
     // Optional, once, before the first offer() and with the keys of the first round (uniform control
     // flow, k <= 64): every wave sorts its 64 keys; the smallest "k-th of a wave" bounds the global
     // k-th key from above, so it is a valid admission threshold from the very first round — without
@@ -233,13 +243,13 @@ struct BlockSelect {
     }
     __device__ __forceinline__ void offer(uint64_t key) {
         if (key < *thr) {
-            uint32_t pos = atomicAdd(cnt, 1u);
+            uint32_t pos = total + atomicAdd(&ctr[slot], 1u);
             buf[pos] = key;
         }
     }
     __device__ void sort_and_trim() {
-        // bitonic sort of the first n = pow2 >= *cnt entries (padded with KEY_MAX)
-        uint32_t c = *cnt;
+        // bitonic sort of the first n = pow2 >= total entries (padded with KEY_MAX)
+        const uint32_t c = total;
         int n = 2;
         while (n < (int)c) n <<= 1;
         for (int i = c + threadIdx.x; i < n; i += BLOCK) buf[i] = MDB_KEY_MAX;
@@ -256,9 +266,9 @@ struct BlockSelect {
                 __syncthreads();
             }
         }
+        const uint32_t nc = c < (uint32_t)k ? c : (uint32_t)k;
+        total = nc;
         if (threadIdx.x == 0) {
-            uint32_t nc = c < (uint32_t)k ? c : (uint32_t)k;
-            *cnt = nc;
             *thr = (nc == (uint32_t)k && k > 0) ? buf[k - 1] : MDB_KEY_MAX;
             if (k == 0) *thr = 0ull;  // nothing is ever admitted
         }
@@ -267,15 +277,18 @@ struct BlockSelect {
     // call after every offer() round (uniform control flow)
     __device__ __forceinline__ void round_end() {
         __syncthreads();
-        uint32_t c = *cnt;
-        __syncthreads();  // nobody may start the next round's atomicAdd before everyone has read cnt
-        if (c > (uint32_t)(cap - BLOCK)) sort_and_trim();
+        total += ctr[slot];
+        const int prev = slot == 0 ? 2 : slot - 1;
+        if (threadIdx.x == 0) ctr[prev] = 0;
+        slot = slot == 2 ? 0 : slot + 1;
+        if (total > (uint32_t)(cap - BLOCK)) sort_and_trim();
     }
     __device__ void finish() {
         __syncthreads();
+        total += ctr[slot];  // offers since the last round_end, if any
         sort_and_trim();
     }
-    __device__ __forceinline__ uint32_t count() const { return *cnt; }
+    __device__ __forceinline__ uint32_t count() const { return total; }
 };
 
 // ------------------------------------------------------------------------------------------ PQ (symmetric) distance

@@ -233,10 +233,10 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
         for (int m = 32; m >= 1; m >>= 1) ws += __shfl_xor((unsigned)ws, m);
         // one device-scope atomic per BLOCK (wave totals meet in LDS first): thousands of atomics on one cache
         // line serialise and were the largest fixed cost of a scan block
-        if (lane == 0 && ws) atomicAdd(sel.cnt + 1, (uint32_t)ws);
+        if (lane == 0 && ws) atomicAdd(sel.spare(), (uint32_t)ws);
     }
     sel.finish();
-    if (threadIdx.x == 0 && sel.cnt[1]) atomicAdd(&a.counters[2], (unsigned long long)sel.cnt[1]);
+    if (threadIdx.x == 0 && *sel.spare()) atomicAdd(&a.counters[2], (unsigned long long)*sel.spare());
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
     for (int j = threadIdx.x; j < a.k; j += MDB_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
@@ -342,10 +342,10 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_pq_kernel(ScanArgs a, cons
         for (int m = 32; m >= 1; m >>= 1) ws += __shfl_xor((unsigned)ws, m);
         // one device-scope atomic per BLOCK (wave totals meet in LDS first): thousands of atomics on one cache
         // line serialise and were the largest fixed cost of a scan block
-        if (lane == 0 && ws) atomicAdd(sel.cnt + 1, (uint32_t)ws);
+        if (lane == 0 && ws) atomicAdd(sel.spare(), (uint32_t)ws);
     }
     sel.finish();
-    if (threadIdx.x == 0 && sel.cnt[1]) atomicAdd(&a.counters[2], (unsigned long long)sel.cnt[1]);
+    if (threadIdx.x == 0 && *sel.spare()) atomicAdd(&a.counters[2], (unsigned long long)*sel.spare());
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
     for (int j = threadIdx.x; j < a.k; j += MDB_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
@@ -655,10 +655,10 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
         for (int o = 32; o >= 1; o >>= 1) ws += __shfl_xor((unsigned)ws, o);
         // one device-scope atomic per BLOCK (wave totals meet in LDS first): thousands of atomics on one cache
         // line serialise and were the largest fixed cost of a scan block
-        if (lane == 0 && ws) atomicAdd(sel.cnt + 1, (uint32_t)ws);
+        if (lane == 0 && ws) atomicAdd(sel.spare(), (uint32_t)ws);
     }
     sel.finish();
-    if (threadIdx.x == 0 && sel.cnt[1]) atomicAdd(&a.counters[2], (unsigned long long)sel.cnt[1]);
+    if (threadIdx.x == 0 && *sel.spare()) atomicAdd(&a.counters[2], (unsigned long long)*sel.spare());
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
     for (int j = tid; j < a.k; j += PQ2_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
