@@ -796,6 +796,9 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                     const uint32_t id = have ? nb_id[i] : 0;
                     unsigned long long surv = __ballot(have && od < fbound);
                     unsigned long long accepted = 0;
+                    // fill phase of a layer (every layer restarts from its entry point): with this chunk B still holds
+                    // at most ef elements, so every count below is < ef — all neighbours are accepted without counting
+                    if (n + (int)min(nnew - c0, 64u) <= ef) { accepted = surv; surv = 0; }
                     while (surv) {
                         const int sidx = __ffsll((long long)surv) - 1;
                         surv &= surv - 1;
