@@ -153,6 +153,33 @@ __device__ __forceinline__ float group16_distance_fast(const float* __restrict__
     return finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce<16>(acc)));
 }
 
+// two rows at once: all loads of both rows are in flight before the first accumulate (hnsw_beam_kernel, steps
+// with more unvisited neighbours than distance groups)
+template <int METRIC, int N16>
+__device__ __forceinline__ void group16_distance_fast2(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                       const float (&qr)[N16], int j, float& da, float& db) {
+    float va[N16], vb[N16];
+    const float4* a4 = (const float4*)(xa + j * N16);
+    const float4* b4 = (const float4*)(xb + j * N16);
+#pragma unroll
+    for (int c = 0; c < N16 / 4; ++c) {
+        float4 v = a4[c];
+        va[4 * c + 0] = v.x; va[4 * c + 1] = v.y; va[4 * c + 2] = v.z; va[4 * c + 3] = v.w;
+    }
+#pragma unroll
+    for (int c = 0; c < N16 / 4; ++c) {
+        float4 v = b4[c];
+        vb[4 * c + 0] = v.x; vb[4 * c + 1] = v.y; vb[4 * c + 2] = v.z; vb[4 * c + 3] = v.w;
+    }
+    float acc = 0.0f, bcc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < N16; ++c) acc = acc_term<METRIC>(acc, qr[c], va[c]);
+#pragma unroll
+    for (int c = 0; c < N16; ++c) bcc = acc_term<METRIC>(bcc, qr[c], vb[c]);
+    da = finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce<16>(acc)));
+    db = finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce<16>(bcc)));
+}
+
 // ---- wave-0 helpers on the two sorted LDS arrays (all ballot based: no cross-lane reductions)
 // W: working set, ascending by (distance, id) key, size wsize <= ef.  Insert wk, dropping the
 // largest when full  ==  push + pop-max of BinaryHeap<PointAndDistance> (index.rs:265-282).
@@ -776,11 +803,30 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
             } else {
                 // ---- P3 (waves 1-3): exact distances, one 16-lane group per neighbour
                 // (the groups also take the order-preserving integer image and the NaN check off wave 0's path)
-                for (uint32_t i = grp - 4; i < nnew; i += (HNSW_BLOCK - 64) / 16) {
-                    float d = MDB_BEAM_DIST(vecs + (size_t)nb_id[i] * a.dpad);
-                    if (j == 0) {
-                        nb_od[i] = f32_orderable(d);
-                        if (d != d) atomicOr(a.flags, MDB_FLAG_NAN);  // the reference panics (NotNan::new(..).unwrap())
+                constexpr int NG = (HNSW_BLOCK - 64) / 16;
+                if (N16T > 0 && N16T <= 16 && nnew > (uint32_t)NG) {
+                    // more neighbours than groups (the fill phase of a layer): every group takes two, so that up to
+                    // 2 NG evaluations share one gather latency
+                    for (uint32_t i = grp - 4; i < nnew; i += 2 * NG) {
+                        const bool two = i + NG < nnew;
+                        const uint32_t i2 = two ? i + NG : i;
+                        float da, db;
+                        group16_distance_fast2<METRIC, (N16T > 0 ? N16T : 4)>(
+                            vecs + (size_t)nb_id[i] * a.dpad, vecs + (size_t)nb_id[i2] * a.dpad,
+                            reinterpret_cast<const float (&)[N16T > 0 ? N16T : 4]>(qr), j, da, db);
+                        if (j == 0) {
+                            nb_od[i] = f32_orderable(da);
+                            if (two) nb_od[i2] = f32_orderable(db);
+                            if (da != da || db != db) atomicOr(a.flags, MDB_FLAG_NAN);
+                        }
+                    }
+                } else {
+                    for (uint32_t i = grp - 4; i < nnew; i += NG) {
+                        float d = MDB_BEAM_DIST(vecs + (size_t)nb_id[i] * a.dpad);
+                        if (j == 0) {
+                            nb_od[i] = f32_orderable(d);
+                            if (d != d) atomicOr(a.flags, MDB_FLAG_NAN);  // the reference panics (NotNan::new(..).unwrap())
+                        }
                     }
                 }
             }
