@@ -947,8 +947,10 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                     } else {
                         const uint32_t m = take_ru ? ru_o : best_o;
                         int closer = 0;
+                        if (n >= ef) {  // fewer than ef elements in B: the popped candidate cannot be beyond furthest
 #pragma unroll
-                        for (int r = 0; r < BREGS; ++r) closer += __popcll(__ballot(bd[r] < m));
+                            for (int r = 0; r < BREGS; ++r) closer += __popcll(__ballot(bd[r] < m));
+                        }
                         if (closer >= ef) {
                             stop = true;  // `distance > furthest.distance` (index.rs:246-248)
                         } else if (take_ru) {
@@ -967,7 +969,26 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                 }
             }
         }
-        // ---- layer done: spill B and sort it (block-wide bitonic); W = its ef smallest keys
+        if (layer > 0) {
+            // ---- an upper layer only hands its nearest point down (index.rs:177-181: first minimum of the
+            // (distance, id)-sorted working set = smallest distance, then smallest id): two wave reductions over B
+            // instead of sorting it
+            if (wave == 0) {
+                uint32_t m = bd[0];
+#pragma unroll
+                for (int r = 1; r < BREGS; ++r) m = min(m, bd[r]);
+                m = wave_min_u32(m);
+                uint32_t im = 0xFFFFFFFFu;
+#pragma unroll
+                for (int r = 0; r < BREGS; ++r) im = bd[r] == m ? min(im, bi[r]) : im;
+                im = wave_min_u32(im);
+                if (lane == 0) misc[1] = im;
+            }
+            __syncthreads();
+            ep = misc[1];
+            continue;
+        }
+        // ---- layer 0 done: spill B and sort it (block-wide bitonic); W = its ef smallest keys
         if (wave == 0) {
 #pragma unroll
             for (int r = 0; r < BREGS; ++r)
@@ -991,10 +1012,6 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
         }
         for (int i = tid; i < a.ef_cap; i += HNSW_BLOCK) W[i] = C[i];
         __syncthreads();
-        if (layer > 0) {
-            ep = key_id(W[0]);  // first minimum of the (distance,id)-sorted working set (index.rs:177-181)
-            __syncthreads();
-        }
     }
     // the output fields are re-read from the kernarg segment behind an opaque barrier: kept in `a` they would stay
     // live (= spilled SGPRs, reloaded by v_readlane) through the whole main loop
