@@ -928,6 +928,19 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                         // best accepted neighbour of this chunk in pop order (smallest distance, largest id)
                         unsigned long long am = accepted;
                         int rank = 0;
+                        if (na > 2) {
+                            // many accepted (fill phase): two wave reductions instead of a scalar loop over them
+                            const bool mine = (accepted >> lane) & 1ull;
+                            const uint32_t mo = wave_min_u32(mine ? od : SLOT_EMPTY);
+                            const uint32_t mi = wave_max_u32(mine && od == mo ? id : 0u);
+                            if (best_slot < 0 || mo < best_o || (mo == best_o && mi > best_id)) {
+                                const unsigned long long wm = __ballot(mine && od == mo && id == mi);
+                                best_o = mo;
+                                best_id = mi;
+                                best_slot = n + __popcll(accepted & ((1ull << (__ffsll((long long)wm) - 1)) - 1ull));
+                            }
+                            am = 0;
+                        }
                         while (am) {
                             const int sidx = __ffsll((long long)am) - 1;
                             am &= am - 1;
