@@ -12,7 +12,7 @@ struct HnswUserDev {
     uint32_t num_layers;
     uint32_t entry_point;  // graph_storage.rs:527-558
     uint32_t S0, SU;       // fixed row strides of the layer-0 / upper-layer adjacency
-    uint32_t pad;
+    uint32_t small_layer;  // every layer >= small_layer (> 0) holds <= 64 points and only edges among them; else num_layers
     uint64_t adj0_off;     // u32 index into the adjacency arena
     uint64_t adjU_off;
     uint64_t upper_off;    // index into upper_first[] / level[] (per point)

@@ -747,6 +747,53 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                 dst[c] = (row && t < stride) ? row[t] : 0xFFFFFFFFu;
             }
         };
+        if (layer > 0 && layer >= (int)u.small_layer && ef >= 64) {
+            // ---- a layer with no more points than ef: its result is the closure of the entry point (see
+            // hnsw_closure_kernel) — whole frontiers per round, one 16-lane group per point, instead of one pop per step
+            uint32_t* cur = nb_id;
+            uint32_t* nxt = nb_id + 64;
+            unsigned long long* const best = (unsigned long long*)(misc + 8);
+            if (tid == 0) {
+                atomicOr(&vis[ep >> 5], 1u << (ep & 31));
+                cur[0] = ep;
+                misc[4] = 0; misc[5] = 0; misc[6] = 0;
+                *best = MDB_KEY_MAX;
+            }
+            int ncur = 1;
+            __syncthreads();
+            while (ncur > 0) {
+                for (int i = grp; i < ncur; i += HNSW_BLOCK / 16) {
+                    const uint32_t f = cur[i];
+                    const uint32_t* row = nullptr;
+                    if (a.level[u.upper_off + f] >= layer)
+                        row = adj_base + ((size_t)a.upper_first[u.upper_off + f] + (layer - 1)) * stride;
+                    const float d = MDB_BEAM_DIST(vecs + (size_t)f * a.dpad);
+                    if (j == 0) {
+                        atomicMin(best, (unsigned long long)make_key(d, f));
+                        if (d != d) atomicOr(a.flags, MDB_FLAG_NAN);
+                        if (row && row[0] != 0xFFFFFFFFu) atomicAdd(&misc[5], 1u);
+                    }
+                    if (row)
+                        for (uint32_t t = j; t < stride; t += 16) {
+                            const uint32_t nbr = row[t];
+                            if (nbr == 0xFFFFFFFFu) break;  // rows are packed
+                            const uint32_t bit = 1u << (nbr & 31);
+                            if (!(atomicOr(&vis[nbr >> 5], bit) & bit)) nxt[atomicAdd(&misc[6], 1u)] = nbr;
+                        }
+                }
+                __syncthreads();
+                const int nn = (int)misc[6];
+                __syncthreads();
+                if (tid == 0) { misc[6] = 0; misc[4] += (uint32_t)ncur; }
+                ncur = nn;
+                uint32_t* tsw = cur; cur = nxt; nxt = tsw;
+            }
+            __syncthreads();
+            ep = key_id((uint64_t)*best);
+            if (wave == 0) { evals += misc[4]; expanded += misc[5]; }
+            __syncthreads();
+            continue;
+        }
         // ---- entry point: mark visited, distance, seed B (index.rs:219-231) and pop it at once
         if (wave == 0) {
             if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
@@ -1253,6 +1300,27 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
                     h_adj[u.adjU_off + r * SU + (x - a0)] = e;
                 }
             }
+        }
+        // tiny top layers (hnsw_beam_kernel expands them frontier-wise): <= 64 points, every edge inside the layer
+        {
+            std::vector<uint64_t> cnt(nl + 1, 0);
+            for (uint64_t p = 0; p < nv; ++p) cnt[std::min<uint32_t>(h_level[u.upper_off + p], nl)] += 1;
+            for (int l = (int)nl - 1; l >= 0; --l) cnt[l] += cnt[l + 1];  // cnt[l] = points with level >= l
+            uint32_t small = nl;
+            for (uint32_t layer = nl; layer-- > 1;) {
+                bool ok = cnt[layer] <= 64;
+                if (ok) {
+                    size_t s = lvl(nl - 1 - layer), e = lvl(nl - layer);
+                    for (size_t i = s; i < e && ok; ++i) {
+                        uint64_t a0 = eo(i), a1 = eo(i + 1);
+                        for (uint64_t x = a0; x < a1; ++x)
+                            if (h_level[u.upper_off + ed(x)] < layer) { ok = false; break; }
+                    }
+                }
+                if (!ok) break;
+                small = layer;
+            }
+            u.small_layer = small;
         }
         max_n = std::max(max_n, u.n);
     }
