@@ -248,8 +248,40 @@ struct BlockSelect {
         }
     }
     __device__ void sort_and_trim() {
-        // bitonic sort of the first n = pow2 >= total entries (padded with KEY_MAX)
         const uint32_t c = total;
+        if (c <= 128) {
+            // small queue (the usual case once the threshold is tight): ONE wave sorts it in registers, two keys per
+            // lane (elements lane and lane + 64), no block barrier per stage
+            if (threadIdx.x < 64) {
+                const int lane = threadIdx.x;
+                uint64_t a = lane < (int)c ? buf[lane] : MDB_KEY_MAX;
+                uint64_t b = lane + 64 < (int)c ? buf[lane + 64] : MDB_KEY_MAX;
+#pragma unroll
+                for (int size = 2; size <= 128; size <<= 1) {
+                    const bool up_a = size >= 64 ? true : (lane & size) == 0;
+                    const bool up_b = size == 64 ? false : up_a;
+#pragma unroll
+                    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                        if (stride == 64) {
+                            const uint64_t mn = a < b ? a : b, mx = a < b ? b : a;
+                            a = mn; b = mx;  // size == 128: ascending
+                        } else {
+                            const uint64_t oa = ((uint64_t)(uint32_t)__shfl_xor((int)(a >> 32), stride) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)a, stride);
+                            const uint64_t ob = ((uint64_t)(uint32_t)__shfl_xor((int)(b >> 32), stride) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)b, stride);
+                            const bool low = (lane & stride) == 0;
+                            a = (low == up_a) ? (a < oa ? a : oa) : (a < oa ? oa : a);
+                            b = (low == up_b) ? (b < ob ? b : ob) : (b < ob ? ob : b);
+                        }
+                    }
+                }
+                buf[lane] = a;
+                buf[lane + 64] = b;
+            }
+            __syncthreads();
+            finish_trim(c);
+            return;
+        }
+        // bitonic sort of the first n = pow2 >= total entries (padded with KEY_MAX)
         int n = 2;
         while (n < (int)c) n <<= 1;
         for (int i = c + threadIdx.x; i < n; i += BLOCK) buf[i] = MDB_KEY_MAX;
@@ -266,6 +298,9 @@ struct BlockSelect {
                 __syncthreads();
             }
         }
+        finish_trim(c);
+    }
+    __device__ __forceinline__ void finish_trim(uint32_t c) {
         const uint32_t nc = c < (uint32_t)k ? c : (uint32_t)k;
         total = nc;
         if (threadIdx.x == 0) {
