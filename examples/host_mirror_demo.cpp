@@ -46,6 +46,19 @@ int main(int argc, char** argv) {
         const size_t b = qb.size() / 4 / dim;
 
         muopdb::Device dev(0);
+        {   // the reference's own PQ known-answer test (pq/mod.rs:321-371) through the Quantizer seams
+            std::vector<float> cb;
+            for (int s = 0; s < 5; ++s)
+                for (int i = 0; i < 2; ++i) { cb.push_back(2.f * s + i); cb.push_back(2.f * s + i); }
+            auto pq = muopdb::Quantizer::product(10, 2, 1, cb);
+            const float v[10] = {1, 1, 3, 3, 5, 5, 7, 7, 9, 9};
+            auto codes = muopdb::quantize(dev, pq, v, 1);
+            auto back = muopdb::original_vector(dev, pq, codes.data(), 1);
+            auto dist = muopdb::distance(dev, pq, codes.data(), codes.data(), 1);
+            bool ok = codes == std::vector<uint8_t>{1, 1, 1, 1, 1} && back == std::vector<float>(v, v + 10) && dist[0] == 0.0f;
+            std::printf("pq_kat %s\n", ok ? "ok" : "MISMATCH");
+            if (!ok) return 3;
+        }
         muopdb::BlockBasedHnsw hnsw(dev, hi.data(), hi.size(), hv.data(), hv.size(), muopdb::Quantizer::none(dim));
         auto hr = hnsw.ann_search(q, b, k, ef);
         for (size_t i = 0; i < b; ++i) print_row("hnsw", i, &hr[i]);

@@ -99,6 +99,31 @@ class Device {
     mdb_ctx* ctx_ = nullptr;
 };
 
+// The `Quantizer` trait's operations (rs/quantization/src/quantization.rs:6-38) through the unit seams of the C ABI.
+// quantized_dimension(): pq/mod.rs:280-282, noq/mod.rs:53-55
+inline uint32_t quantized_dimension(const Quantizer& q) {
+    return q.d.kind == MDB_QUANT_PQ ? q.d.dimension / q.d.subvector_dimension : q.d.dimension;
+}
+// ProductQuantizer::quantize (pq/mod.rs:152-177): vectors [n][dimension] -> codes [n][m]
+inline std::vector<uint8_t> quantize(Device& dev, Quantizer& q, const float* vectors, size_t n) {
+    std::vector<uint8_t> codes(n * quantized_dimension(q));
+    dev.check(mdb_pq_quantize(dev.ctx(), q.desc(), vectors, n, codes.data()));
+    return codes;
+}
+// ProductQuantizer::original_vector (pq/mod.rs:184-200): codes [n][m] -> [n][dimension]
+inline std::vector<float> original_vector(Device& dev, Quantizer& q, const uint8_t* codes, size_t n) {
+    std::vector<float> out(n * q.d.dimension);
+    dev.check(mdb_pq_original_vector(dev.ctx(), q.desc(), codes, n, out.data()));
+    return out;
+}
+// ProductQuantizer::distance (pq/mod.rs:202-278): code pairs a[i], b[i]
+inline std::vector<float> distance(Device& dev, Quantizer& q, const uint8_t* a, const uint8_t* b, size_t n,
+                                   mdb_distance_impl impl = MDB_IMPL_STREAMING_SIMD) {
+    std::vector<float> out(n);
+    dev.check(mdb_pq_distance(dev.ctx(), q.desc(), a, b, n, impl, out.data()));
+    return out;
+}
+
 namespace detail {
 struct Rows {
     std::vector<mdb_u128> ids;

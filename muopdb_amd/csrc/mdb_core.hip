@@ -364,6 +364,37 @@ extern "C" mdb_status mdb_pq_quantize(mdb_ctx* ctx, const mdb_quant_desc* q, con
     return MDB_OK;
 }
 
+// ProductQuantizer::original_vector (pq/mod.rs:184-200): out[i][s*subdim + e] = codebook[s][codes[i][s]][e]
+__global__ void pq_original_vector_kernel(const uint8_t* __restrict__ codes, int m, int subdim, int K, const float* __restrict__ cb,
+                                          float* __restrict__ out, size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int d = m * subdim;
+    const size_t i = t / d;
+    const int c = (int)(t - i * d), s = c / subdim, e = c - s * subdim;
+    out[t] = cb[((size_t)s * K + codes[i * m + s]) * subdim + e];
+}
+
+extern "C" mdb_status mdb_pq_original_vector(mdb_ctx* ctx, const mdb_quant_desc* q, const uint8_t* codes, size_t n, float* vectors_out) {
+    if (!ctx || !q || !codes || !vectors_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    PqDev pq;
+    MDB_TRY(pq_upload(ctx, q, pq));
+    if (n == 0) return MDB_OK;
+    const size_t total = n * (size_t)pq.m * pq.subdim;
+    void *dc, *dv;
+    MDB_TRY(mdb_scratch(ctx, 1, n * pq.m, &dc));
+    MDB_TRY(mdb_scratch(ctx, 0, total * 4, &dv));
+    MDB_HIP(ctx, hipMemcpyAsync(dc, codes, n * pq.m, hipMemcpyHostToDevice, ctx->stream));
+    pq_original_vector_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((const uint8_t*)dc, pq.m, pq.subdim, pq.K,
+                                                                                            pq.codebook.p, (float*)dv, total);
+    MDB_HIP(ctx, hipGetLastError());
+    MDB_HIP(ctx, hipMemcpyAsync(vectors_out, dv, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MDB_OK;
+}
+
 extern "C" mdb_status mdb_pq_distance(mdb_ctx* ctx, const mdb_quant_desc* q, const uint8_t* a, const uint8_t* b, size_t n,
                                       mdb_distance_impl impl, float* out) {
     if (!ctx || !q || !a || !b || !out) return MDB_ERR_INVALID_ARG;

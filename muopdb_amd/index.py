@@ -143,6 +143,16 @@ class ProductQuantizer:
                                           L.ptr(out, C.c_uint8)))
         return out
 
+    def original_vector(self, ctx, codes):
+        """ProductQuantizer::original_vector (pq/mod.rs:184-200): codes [n][m] -> reconstructed vectors [n][dimension]."""
+        m = self.quantized_dimension()
+        c = np.ascontiguousarray(codes, np.uint8).reshape(-1, m)
+        out = np.empty((c.shape[0], self.dimension), np.float32)
+        q, keep = self.desc()
+        ctx.check(ctx.lib.mdb_pq_original_vector(ctx.h, C.byref(q), L.ptr(c, C.c_uint8), C.c_size_t(c.shape[0]),
+                                                 L.ptr(out, C.c_float)))
+        return out
+
     def distance(self, ctx, a, b, implem=L.IMPL_STREAMING_SIMD):
         m = self.quantized_dimension()
         a = np.ascontiguousarray(a, np.uint8).reshape(-1, m)

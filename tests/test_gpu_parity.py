@@ -77,6 +77,8 @@ def test_pq_quantize_and_distance(ctx, oracle, d, sub, bits):
         v = rng.random((200, d), dtype=np.float32)
         codes = pq.quantize(ctx, v)
         assert np.array_equal(codes, opq.quantize(v))
+        rec = pq.original_vector(ctx, codes[:50])   # pq/mod.rs:184-200
+        assert np.array_equal(rec.view(np.uint32), np.stack([opq.original_vector(c) for c in codes[:50]]).astype(np.float32).view(np.uint32))
         a = rng.integers(0, K, (300, m)).astype(np.uint8)
         b = rng.integers(0, K, (300, m)).astype(np.uint8)
         for impl, oimpl in ((L.IMPL_STREAMING_SIMD, oracle.PQ_STREAMING), (L.IMPL_SIMD, oracle.PQ_SIMD),
@@ -97,6 +99,7 @@ def test_k5_k6_pq_quantize_kat(ctx):
             cb += [2 * s + i, 2 * s + i]
     pq = ProductQuantizer(10, 2, 1, cb)
     assert pq.quantize(ctx, [[1, 1, 3, 3, 5, 5, 7, 7, 9, 9]]).tolist() == [[1, 1, 1, 1, 1]]
+    assert pq.original_vector(ctx, [[1, 1, 1, 1, 1]]).tolist() == [[1, 1, 3, 3, 5, 5, 7, 7, 9, 9]]  # pq/mod.rs:355-360
 
 
 # ----------------------------------------------------------------------------------- E1

@@ -297,8 +297,11 @@ def test_cpp_host_mirror_matches_ctypes_binding(ctx, oracle, tmp_path):
     out = subprocess.run([exe, str(tmp_path), "24", "7", "60", "5", "0.25"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     got = {}
+    assert "pq_kat ok" in out.stdout  # the reference's PQ known-answer test through the C++ Quantizer seams
     for line in out.stdout.splitlines():
         t = line.split()
+        if t[0] == "pq_kat":
+            continue
         if t[2] == "none":
             got[(t[0], int(t[1]))] = None
         else:
