@@ -192,15 +192,15 @@ def run_hnsw(args, ctx, rank, world, timer):
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("hnsw", out["config"])
     if args.streams > 1:
         # Extra, NOT the headline: the same K batches issued round-robin on several HIP streams (one context +
-        # index handle each), i.e. several batches of 64 in flight.  One batch occupies 64 of the 256 CUs for
+        # attached index handle each, all over the same resident graph), i.e. several batches of 64 in flight.  One batch occupies 64 of the 256 CUs for
         # its whole latency-bound traversal, so a serving process overlaps batches to fill the chip.
         from muopdb_amd import lib as L
         lanes = []
         for _ in range(args.streams):
             st_ = torch.cuda.Stream()
             c_ = L.Context(torch.cuda.current_device()); c_.set_stream(st_.cuda_stream)
-            lanes.append((st_, c_, BlockBasedHnsw(c_, index_bytes, vec_bytes, d), torch.zeros_like(ids), torch.zeros_like(sc),
-                          torch.zeros_like(cn)))
+            # one resident index, one handle per stream over it (mdb_hnsw_attach)
+            lanes.append((st_, c_, hnsw.attach(c_), torch.zeros_like(ids), torch.zeros_like(sc), torch.zeros_like(cn)))
         torch.cuda.synchronize()
 
         def cstep(i):

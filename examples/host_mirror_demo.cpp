@@ -62,6 +62,20 @@ int main(int argc, char** argv) {
         muopdb::BlockBasedHnsw hnsw(dev, hi.data(), hi.size(), hv.data(), hv.size(), muopdb::Quantizer::none(dim));
         auto hr = hnsw.ann_search(q, b, k, ef);
         for (size_t i = 0; i < b; ++i) print_row("hnsw", i, &hr[i]);
+        {   // a handle attached on a second context returns the same rows
+            muopdb::Device dev2(0);
+            muopdb::BlockBasedHnsw view(dev2, hnsw);
+            auto vr = view.ann_search(q, b, k, ef);
+            bool same = vr.size() == hr.size();
+            for (size_t i = 0; same && i < b; ++i) {
+                same = vr[i].id_with_scores.size() == hr[i].id_with_scores.size();
+                for (size_t j = 0; same && j < hr[i].id_with_scores.size(); ++j)
+                    same = vr[i].id_with_scores[j].doc_id == hr[i].id_with_scores[j].doc_id &&
+                           vr[i].id_with_scores[j].score == hr[i].id_with_scores[j].score;
+            }
+            std::printf("pq_kat attach_%s\n", same ? "ok" : "MISMATCH");
+            if (!same) return 4;
+        }
 
         muopdb::BlockBasedIvf ivf(dev, ii.data(), ii.size(), iv.data(), iv.size(), muopdb::Quantizer::none(dim));
         auto ir = ivf.search(q, b, k, (uint32_t)nprobe);

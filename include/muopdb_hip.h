@@ -213,6 +213,11 @@ mdb_status mdb_hnsw_load(mdb_ctx* ctx, const void* index_bytes, size_t index_len
                          const void* vectors_bytes, size_t vectors_len, size_t vectors_offset,
                          const mdb_quant_desc* quant, mdb_hnsw** out);
 void mdb_hnsw_free(mdb_hnsw* hnsw);
+/* A second handle over the SAME resident graph and vectors, bound to another context (its own stream and
+ * scratch): searches through different handles run concurrently on the device — the reference shares one
+ * immutable `BlockBasedHnsw` between tokio tasks (`Quantizer: Send + Sync`, one query per task).  The
+ * device memory is released when the last handle over it is freed, in any order. */
+mdb_status mdb_hnsw_attach(mdb_ctx* ctx, mdb_hnsw* src, mdb_hnsw** out);
 size_t mdb_hnsw_num_vectors(const mdb_hnsw* hnsw);
 /* ann_search :159-210 — results ordered by (distance, point id), truncated to k */
 mdb_status mdb_hnsw_ann_search(mdb_hnsw* hnsw, const float* queries, size_t b, size_t k, uint32_t ef, mdb_mem mem,

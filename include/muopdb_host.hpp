@@ -210,6 +210,11 @@ class BlockBasedHnsw {
         : dev_(dev) {
         dev_.check(mdb_hnsw_load(dev.ctx(), index, index_len, index_offset, vectors, vectors_len, vector_offset, q.desc(), &h_));
     }
+    // a second handle over the same resident graph on another Device context (own stream + scratch): searches through
+    // different handles overlap on the GPU, like the reference's tokio tasks over one immutable index
+    BlockBasedHnsw(Device& dev, const BlockBasedHnsw& resident) : dev_(dev) {
+        dev_.check(mdb_hnsw_attach(dev.ctx(), resident.h_, &h_));
+    }
     ~BlockBasedHnsw() { mdb_hnsw_free(h_); }
     BlockBasedHnsw(const BlockBasedHnsw&) = delete;
     // ann_search (hnsw/block_based/index.rs:159-210)

@@ -97,14 +97,22 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool borrowed = false;  // a view of another DevBuf's memory (attached handles): never freed here
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        borrowed = false;
+    }
+    void borrow(const DevBuf& o) {
+        release();
+        p = o.p;
+        n = o.n;
+        borrowed = o.p != nullptr;
     }
     hipError_t alloc(size_t count) {
         release();

@@ -46,6 +46,16 @@ struct HnswSet {
     DevBuf<uint8_t> d_level;
     DevBuf<float> d_vecs;          // [total_rows][dpad], 16-byte aligned rows
 
+    // a view of `src` (same device arrays, not owned) bound to another context
+    void view_of(const HnswSet& src, mdb_ctx* ctx2) {
+        ctx = ctx2;
+        metric = src.metric; kind = src.kind; dimension = src.dimension; dpad = src.dpad;
+        pq.metric = src.pq.metric; pq.dimension = src.pq.dimension; pq.subdim = src.pq.subdim; pq.num_bits = src.pq.num_bits;
+        pq.m = src.pq.m; pq.K = src.pq.K; pq.h_codebook = src.pq.h_codebook; pq.codebook.borrow(src.pq.codebook);
+        blobs = src.blobs; h_users = src.h_users; max_n = src.max_n; max_stride = src.max_stride; total_rows = src.total_rows;
+        d_index.borrow(src.d_index); d_users.borrow(src.d_users); d_adj.borrow(src.d_adj);
+        d_upper_first.borrow(src.d_upper_first); d_level.borrow(src.d_level); d_vecs.borrow(src.d_vecs);
+    }
     mdb_status load(mdb_ctx* ctx, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
                     const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant, uint32_t dimension);
     // beam search of every query through its user's graph: device keys [b][k] (distance, point id)

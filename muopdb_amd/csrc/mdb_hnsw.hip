@@ -20,6 +20,8 @@
 //   * accept loop in edge order by wave 0 (the `d < furthest || len < ef` test sees the heap as
 //     updated by earlier neighbours of the same node, index.rs:258-283).
 // Bound: HBM random-gather LATENCY (d*4 + 4 B per distance evaluation), not bandwidth.
+#include <atomic>
+
 #include "mdb_device.cuh"
 #include "mdb_hnsw.h"
 #include "mdb_kernels.h"
@@ -1488,7 +1490,19 @@ mdb_status HnswSet::remap(const uint64_t* d_keys, const uint32_t* d_counts, size
 // ============================================================================================
 struct mdb_hnsw {
     HnswSet set;
+    mdb_hnsw* parent = nullptr;   // attached handle: the owner of the device arrays
+    std::atomic<int> refs{1};     // this handle + the handles attached to it
 };
+
+static void hnsw_release(mdb_hnsw* h) {
+    if (h->refs.fetch_sub(1) != 1) return;
+    mdb_ctx* ctx = h->set.ctx;
+    mdb_hnsw* parent = h->parent;
+    (void)hipSetDevice(ctx->device);
+    delete h;
+    mdb_ctx_release(ctx);
+    if (parent) hnsw_release(parent);
+}
 
 extern "C" {
 
@@ -1514,9 +1528,21 @@ void mdb_hnsw_free(mdb_hnsw* h) {
     if (!h) return;
     (void)hipSetDevice(h->set.ctx->device);
     (void)hipStreamSynchronize(h->set.ctx->stream);
-    mdb_ctx* ctx = h->set.ctx;
-    delete h;
-    mdb_ctx_release(ctx);
+    hnsw_release(h);
+}
+
+mdb_status mdb_hnsw_attach(mdb_ctx* ctx, mdb_hnsw* src, mdb_hnsw** out) {
+    if (!ctx || !src || !out) return MDB_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (ctx->device != src->set.ctx->device) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "mdb_hnsw_attach: the index lives on device %d", src->set.ctx->device);
+    mdb_hnsw* owner = src->parent ? src->parent : src;
+    mdb_hnsw* h = new mdb_hnsw();
+    h->set.view_of(owner->set, ctx);
+    h->parent = owner;
+    owner->refs.fetch_add(1);
+    mdb_ctx_retain(ctx);
+    *out = h;
+    return MDB_OK;
 }
 
 size_t mdb_hnsw_num_vectors(const mdb_hnsw* h) { return h ? (size_t)h->set.blobs[0].num_vectors : 0; }

@@ -349,6 +349,16 @@ class BlockBasedHnsw:
                                         C.byref(q), C.byref(h)))
         self.h = h
 
+    def attach(self, ctx):
+        """A second handle over the same resident graph, bound to `ctx` (its own stream and scratch): searches
+        through different handles overlap on the device (mdb_hnsw_attach)."""
+        other = BlockBasedHnsw.__new__(BlockBasedHnsw)
+        other.ctx, other.dimension = ctx, self.dimension
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mdb_hnsw_attach(ctx.h, self.h, C.byref(h)))
+        other.h = h
+        return other
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.mdb_hnsw_free(self.h)

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "mdb_ivf_load", "mdb_ivf_free", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features",
     "mdb_ivf_find_nearest_centroids", "mdb_ivf_search", "mdb_ivf_search_points", "mdb_ivf_set_filter", "mdb_ivf_invalidate",
     "mdb_ivf_is_invalidated",
-    "mdb_hnsw_load", "mdb_hnsw_free", "mdb_hnsw_num_vectors", "mdb_hnsw_ann_search",
+    "mdb_hnsw_load", "mdb_hnsw_attach", "mdb_hnsw_free", "mdb_hnsw_num_vectors", "mdb_hnsw_ann_search",
     "mdb_spann_load", "mdb_spann_free", "mdb_spann_search", "mdb_spann_set_filter", "mdb_spann_invalidate", "mdb_spann_is_invalidated",
     "mdb_multi_spann_load", "mdb_multi_spann_free", "mdb_multi_spann_num_users", "mdb_multi_spann_search",
     "mdb_multi_spann_set_filter", "mdb_multi_spann_invalidate", "mdb_merge_shards",

@@ -298,6 +298,7 @@ def test_cpp_host_mirror_matches_ctypes_binding(ctx, oracle, tmp_path):
     assert out.returncode == 0, out.stderr
     got = {}
     assert "pq_kat ok" in out.stdout  # the reference's PQ known-answer test through the C++ Quantizer seams
+    assert "pq_kat attach_ok" in out.stdout  # an attached HNSW handle on a second context gives the same rows
     for line in out.stdout.splitlines():
         t = line.split()
         if t[0] == "pq_kat":
@@ -537,3 +538,42 @@ def test_concurrent_searches_from_host_threads(ctx, oracle):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_hnsw_attached_handles_share_one_resident_index(ctx, oracle):
+    """mdb_hnsw_attach: handles on other contexts (own stream + scratch) over the SAME device arrays.  Rows equal the
+    owner's and the oracle's from four host threads at once, and the memory outlives the owner handle when that is
+    freed first."""
+    import threading
+    from muopdb_amd import lib as L
+    from muopdb_amd.index import BlockBasedHnsw
+    rng = np.random.default_rng(43)
+    v = H.sift_like(3000, 48, n_clusters=25, seed=9)
+    hidx, hvec = H.build_hnsw_files(oracle, v, list(range(3000)), max_neighbors=12, max_layers=4, ef_construction=60)
+    owner = BlockBasedHnsw(ctx, hidx, hvec, 48)
+    o = oracle.BlockBasedHnsw(hidx, hvec, 48)
+    ctxs = [L.Context(0) for _ in range(4)]
+    views = [owner.attach(c) for c in ctxs]
+    views.append(views[0].attach(ctxs[1]))  # attaching to an attached handle attaches to its owner
+    qs = [(v[rng.integers(0, 3000, 16)] + rng.normal(0, 2, (16, 48))).astype(np.float32) for _ in range(5)]
+    want = [o.ann_search(q, 10, 120) for q in qs]
+    owner.close()  # the device arrays stay until the last view goes
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(10):
+                assert_result_rows(views[i].ann_search(qs[i], 10, 120), want[i], 16)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(5)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    for vw in views:
+        vw.close()
+    for c in ctxs:
+        c.close()
