@@ -109,6 +109,7 @@ struct ScanArgs {
     // allow_mask = 0 folds every index onto it (branch-free in the pipelined PQ kernel).
     const uint32_t* allow;
     uint32_t allow_stride, allow_mask;
+    uint32_t* counts_out;          // nsplit == 1: `partial` is the final [B][k] key array and the row lengths go here (no merge launch)
 };
 
 __device__ __forceinline__ bool tomb_test(const uint32_t* tomb, uint32_t base_word, uint32_t pid) {
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
     for (int j = threadIdx.x; j < a.k; j += MDB_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+    if (a.counts_out && threadIdx.x == 0) a.counts_out[qi] = c;
 }
 
 template <int METRIC, bool LUT_LDS>
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_pq_kernel(ScanArgs a, cons
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
     for (int j = threadIdx.x; j < a.k; j += MDB_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+    if (a.counts_out && threadIdx.x == 0) a.counts_out[qi] = c;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -662,6 +665,7 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
     for (int j = tid; j < a.k; j += PQ2_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+    if (a.counts_out && tid == 0) a.counts_out[qi] = c;
 }
 
 // keys (distance, point id) -> (u128 doc id, score) rows ordered by IdWithScore (score, doc id).
@@ -983,11 +987,14 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
             nsplit = (int)std::min<size_t>(std::max<size_t>((target + b - 1) / b, 1), 16);
         }
     }
-    void* partial;
-    MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)nsplit * std::max<size_t>(k, 1) * 8, &partial));
+    // one block per query: its sorted keys ARE the result — written in place, no merge launch
+    const bool direct = nsplit == 1 && k > 0;
+    void* partial = d_keys;
+    if (!direct) MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)nsplit * std::max<size_t>(k, 1) * 8, &partial));
     ScanArgs a{d_users.p, d_q_user, d_list_tile_off.p, d_slot_ids.p, d_tomb.p, d_probes, d_probe_cnt, probe_stride,
                (int)k, (uint64_t*)partial, ctx->d_flags, ctx->d_counters,
-               flt ? flt : d_tomb.p + ones_word, flt ? (uint32_t)flt_stride : 0u, flt ? 0xFFFFFFFFu : 0u};
+               flt ? flt : d_tomb.p + ones_word, flt ? (uint32_t)flt_stride : 0u, flt ? 0xFFFFFFFFu : 0u,
+               direct ? d_counts : nullptr};
     dim3 grid((unsigned)nsplit, (unsigned)b);
     size_t sel_lds = BlockSelect<MDB_BLOCK>::lds_bytes((int)k);
     void* qcodes = nullptr;
@@ -1063,7 +1070,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     }
     }
     MDB_HIP(ctx, hipGetLastError());
-    MDB_TRY(merge_keys(ctx, (const uint64_t*)partial, (size_t)nsplit * k, b, k, d_keys, d_counts));
+    if (!direct) MDB_TRY(merge_keys(ctx, (const uint64_t*)partial, (size_t)nsplit * k, b, k, d_keys, d_counts));
     return MDB_OK;
 }
 
