@@ -31,6 +31,7 @@ struct mdb_ctx {
     uint32_t* h_flags = nullptr;   // pinned host mirror
     unsigned long long* d_counters = nullptr;  // [0] HNSW distance evals [1] expanded nodes [2] scored vectors [3] spare
     unsigned long long* h_counters = nullptr;
+    bool dev_counters = true;      // false: the last call used no device counters (flat scans): mdb_get_stats reports zeros, no memset launch
     uint64_t stat_bytes_per_eval = 0, stat_bytes_per_scored = 0, stat_fixed_bytes = 0;
     // growable device scratch (never shrinks; no allocation in steady state)
     void* scratch[12] = {nullptr};

@@ -136,8 +136,9 @@ const char* mdb_last_error(mdb_ctx* ctx) { return ctx ? ctx->last_error.c_str() 
 mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out) {
     if (!ctx || !out) return MDB_ERR_INVALID_ARG;
     MDB_HIP(ctx, hipSetDevice(ctx->device));
-    MDB_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->dev_counters) MDB_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 32, hipMemcpyDeviceToHost, ctx->stream));
     MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->dev_counters) ctx->h_counters[0] = ctx->h_counters[1] = ctx->h_counters[2] = ctx->h_counters[3] = 0;
     mdb_stats st = ctx->stats;
     st.distance_evals = ctx->h_counters[0];
     st.expanded_nodes = ctx->h_counters[1];

@@ -357,7 +357,7 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     // one pass = N*d*4 B read once per batch + queries + outputs
     ctx->stats = mdb_stats{};
     ctx->stats.scored_vectors = (uint64_t)b * flat->ts.n;
-    MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    ctx->dev_counters = false;  // flat scans count on the host (scored = n x b): no counter memset launch on this path
     ctx->stat_bytes_per_eval = 0; ctx->stat_bytes_per_scored = 0;
     ctx->stat_fixed_bytes = (uint64_t)flat->ts.n * flat->ts.d * 4 + (uint64_t)b * flat->ts.d * 4 + (uint64_t)b * k * 8;
     size_t total = b * k;

@@ -1563,6 +1563,7 @@ mdb_status mdb_hnsw_ann_search(mdb_hnsw* h, const float* queries, size_t b, size
     MDB_TRY(mdb_scratch(ctx, 3, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4 + 16, &cnts));
     MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
     // d*4 B vector + 4 B edge id per distance evaluation, 16 B offsets per expanded node
     ctx->stat_bytes_per_eval = (s.kind == MDB_QUANT_PQ ? (uint64_t)s.pq.m : (uint64_t)s.dimension * 4) + 4;

@@ -104,6 +104,7 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     uint32_t* cnts = (uint32_t*)(base + o_cnts);
     uint8_t* dfound = (uint8_t*)(base + o_found);
     MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
     ctx->stat_bytes_per_eval = (uint64_t)s.hnsw.dimension * 4 + 4;
     ctx->stat_bytes_per_scored = s.ivf.bytes_per_scored();
