@@ -132,7 +132,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_scan_kernel(const float4* __re
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void merge_keys_kernel(const uint64_t* __restrict__ partial, size_t per_query, int k,
                                                            uint64_t* __restrict__ out, uint32_t* __restrict__ counts,
-                                                           const uint32_t* __restrict__ gate = nullptr) {
+                                                           const uint32_t* __restrict__ gate = nullptr, UnpackOut up = UnpackOut{}) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (gate && *gate == 0) return;
     BlockSelect<BLOCK> sel;
@@ -181,16 +181,25 @@ __global__ __launch_bounds__(BLOCK) void merge_keys_kernel(const uint64_t* __res
     uint32_t c = sel.count();
     for (int j = threadIdx.x; j < k; j += BLOCK) out[(size_t)blockIdx.x * k + j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
     if (threadIdx.x == 0 && counts) counts[blockIdx.x] = c;
+    if (up.ids) {  // the caller's final (row id, distance) rows straight from here: no unpack launch, no counts copy
+        for (int j = threadIdx.x; j < k; j += BLOCK) {
+            const bool have = j < (int)c;
+            up.ids[(size_t)blockIdx.x * k + j] = have ? key_id(sel.buf[j]) : 0xFFFFFFFFu;
+            up.dist[(size_t)blockIdx.x * k + j] = have ? key_dist(sel.buf[j]) : __uint_as_float(0x7F800000u);
+        }
+        if (threadIdx.x == 0 && up.counts) up.counts[blockIdx.x] = c;
+    }
 }
 
 static void launch_merge_keys(mdb_ctx* ctx, const uint64_t* d_partial, size_t per_query, size_t b, size_t k, uint64_t* d_out,
-                              uint32_t* d_counts, const uint32_t* gate) {
+                              uint32_t* d_counts, const uint32_t* gate, const UnpackOut* unpack = nullptr) {
+    const UnpackOut up = unpack ? *unpack : UnpackOut{};
     if (per_query >= 2048)  // many partial lists (one query over a large base): 4x fewer rounds
         merge_keys_kernel<1024><<<dim3((unsigned)b), 1024, BlockSelect<1024>::lds_bytes((int)k), ctx->stream>>>(d_partial, per_query, (int)k,
-                                                                                                               d_out, d_counts, gate);
+                                                                                                               d_out, d_counts, gate, up);
     else
         merge_keys_kernel<MDB_BLOCK><<<dim3((unsigned)b), MDB_BLOCK, BlockSelect<MDB_BLOCK>::lds_bytes((int)k), ctx->stream>>>(
-            d_partial, per_query, (int)k, d_out, d_counts, gate);
+            d_partial, per_query, (int)k, d_out, d_counts, gate, up);
 }
 
 __global__ void unpack_keys_kernel(const uint64_t* __restrict__ keys, size_t total, uint32_t* __restrict__ ids,
@@ -248,7 +257,7 @@ static int flat_choose_qt(size_t b, int k) {
 }
 
 mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const float* dq, int qstride, size_t b, size_t k,
-                          uint64_t* d_keys, uint32_t* d_counts, bool profile, const uint32_t* gate) {
+                          uint64_t* d_keys, uint32_t* d_counts, bool profile, const uint32_t* gate, const UnpackOut* unpack) {
     if (b == 0) return MDB_OK;
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     int qt = flat_choose_qt(b, (int)k);
@@ -281,7 +290,7 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     else
         MDB_TRY(launch_flat_scan<MDB_METRIC_DOT>(ctx, ts, p, dq, qstride, b, bpad, qt, (int)k, nblk, (uint64_t*)partial, gate));
     }
-    launch_merge_keys(ctx, (const uint64_t*)partial, (size_t)nblk * k, b, k, d_keys, d_counts, gate);
+    launch_merge_keys(ctx, (const uint64_t*)partial, (size_t)nblk * k, b, k, d_keys, d_counts, gate, unpack);
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
 }
@@ -347,13 +356,19 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     const size_t bpad = batched ? (b + 63) / 64 * 64 : (b + 3) / 4 * 4;
     MDB_TRY(stage_queries(ctx, 0, queries, b, flat->ts.d, mem, bpad, &dq, &qstride));
     void *keys, *cnts;
+    bool fused = false;
     MDB_TRY(mdb_scratch(ctx, 5, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4, &cnts));
     if (batched)
         MDB_TRY(flat_topk_keys_mfma(ctx, view_of(flat->ts), flat->aux, flat->metric, dq, qstride, b, bpad, k, (uint64_t*)keys,
                                     (uint32_t*)cnts, true));
-    else
-        MDB_TRY(flat_topk_keys(ctx, view_of(flat->ts), flat->metric, dq, qstride, b, k, (uint64_t*)keys, (uint32_t*)cnts, true));
+    else {
+        // device outputs: the merge kernel writes the caller's rows itself (scan + merge are the only two launches)
+        UnpackOut up{ids_out, dist_out, counts_out};
+        fused = mem == MDB_MEM_DEVICE && k > 0;
+        MDB_TRY(flat_topk_keys(ctx, view_of(flat->ts), flat->metric, dq, qstride, b, k, (uint64_t*)keys, (uint32_t*)cnts, true, nullptr,
+                               fused ? &up : nullptr));
+    }
     // one pass = N*d*4 B read once per batch + queries + outputs
     ctx->stats = mdb_stats{};
     ctx->stats.scored_vectors = (uint64_t)b * flat->ts.n;
@@ -362,6 +377,7 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     ctx->stat_fixed_bytes = (uint64_t)flat->ts.n * flat->ts.d * 4 + (uint64_t)b * flat->ts.d * 4 + (uint64_t)b * k * 8;
     size_t total = b * k;
     if (mem == MDB_MEM_DEVICE) {
+        if (fused) return MDB_OK;
         if (total) unpack_keys_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((uint64_t*)keys, total, ids_out, dist_out);
         if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts, b * 4, hipMemcpyDeviceToDevice, ctx->stream));
         MDB_HIP(ctx, hipGetLastError());

@@ -15,9 +15,15 @@ mdb_status stage_queries(mdb_ctx* ctx, int slot, const float* queries, size_t b,
                          float** d_out, int* qstride);
 // flat exact top-k of every query against a TileStore: keys (distance,row) ascending into d_keys [b][k]
 // gate (device word, optional): both launches return immediately while *gate == 0
+// optional final outputs written by the merge kernel itself (saves the unpack launch and the counts copy)
+struct UnpackOut {
+    uint32_t* ids = nullptr;      // [b][k] row ids, UINT32_MAX padded
+    float* dist = nullptr;        // [b][k] distances, +inf padded
+    uint32_t* counts = nullptr;   // [b] (may be null)
+};
 mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const float* d_queries_padded, int qstride,
                           size_t b, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false,
-                          const uint32_t* gate = nullptr);
+                          const uint32_t* gate = nullptr, const UnpackOut* unpack = nullptr);
 
 // ---- mdb_flat_mfma.hip: batched flat scan = exact top-k of a strided sample + MFMA filter + exact refine
 // (same keys as flat_topk_keys, bit for bit).  FlatAux is built once per store by flat_build_aux (stays
