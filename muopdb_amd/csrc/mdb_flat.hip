@@ -181,11 +181,12 @@ __global__ __launch_bounds__(BLOCK) void merge_keys_kernel(const uint64_t* __res
     uint32_t c = sel.count();
     for (int j = threadIdx.x; j < k; j += BLOCK) out[(size_t)blockIdx.x * k + j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
     if (threadIdx.x == 0 && counts) counts[blockIdx.x] = c;
+    if (up.zero4 && blockIdx.x == 0 && threadIdx.x < 4) up.zero4[threadIdx.x] = 0ull;
     if (up.ids) {  // the caller's final (row id, distance) rows straight from here: no unpack launch, no counts copy
         for (int j = threadIdx.x; j < k; j += BLOCK) {
             const bool have = j < (int)c;
             up.ids[(size_t)blockIdx.x * k + j] = have ? key_id(sel.buf[j]) : 0xFFFFFFFFu;
-            up.dist[(size_t)blockIdx.x * k + j] = have ? key_dist(sel.buf[j]) : __uint_as_float(0x7F800000u);
+            if (up.dist) up.dist[(size_t)blockIdx.x * k + j] = have ? key_dist(sel.buf[j]) : __uint_as_float(0x7F800000u);
         }
         if (threadIdx.x == 0 && up.counts) up.counts[blockIdx.x] = c;
     }

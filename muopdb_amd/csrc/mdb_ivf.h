@@ -64,7 +64,8 @@ struct IvfSet {
     mdb_status build_doc_map(size_t ui);
     mdb_status invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out, bool test_only);
     mdb_status set_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem);
-    mdb_status coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes);
+    mdb_status coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes,
+                      bool zero_counters = false);  // zero_counters: its merge kernel also clears the context's device counters
     mdb_status scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
                     const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts);
     mdb_status remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,

@@ -711,11 +711,6 @@ __global__ __launch_bounds__(256) void remap_kernel(const uint64_t* __restrict__
     if (threadIdx.x == 0 && counts_out) counts_out[qi] = (uint32_t)c;
 }
 
-__global__ void keys_to_probes_kernel(const uint64_t* __restrict__ keys, size_t total, uint32_t* __restrict__ probes) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < total) probes[t] = key_id(keys[t]);
-}
-
 // ------------------------------------------------------------------------------------------ IvfSet: load
 static mdb_status parse_ivf_blob(mdb_ctx* ctx, const uint8_t* b, size_t len, size_t offset, IvfBlobInfo& o) {
     if (offset + 45 > len) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: header out of bounds");
@@ -1087,7 +1082,7 @@ mdb_status IvfSet::remap(const uint64_t* d_keys, const uint32_t* d_counts, size_
 // find_nearest_centroids (index.rs:147-163) for user `ui`: sqrt-L2 to every centroid, the
 // num_probes nearest ordered by (distance, index) [ties: the reference's select_nth_unstable +
 // stable sort leave equal distances implementation-defined; this path orders them by index]
-mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes) {
+mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes, bool zero_counters) {
     const IvfBlobInfo& bi = blobs[ui];
     if (num_probes == 0 || num_probes > bi.num_clusters)
         return mdb_fail(ctx, MDB_ERR_OUT_OF_RANGE, "num_probes=%zu out of range (num_clusters=%u): the reference panics in select_nth_unstable_by",
@@ -1097,10 +1092,9 @@ mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, si
                 (bi.num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
     void* keys;
     MDB_TRY(mdb_scratch(ctx, 5, b * num_probes * 8, &keys));
-    MDB_TRY(flat_topk_keys(ctx, cv, MDB_METRIC_L2, d_q, qstride, b, num_probes, (uint64_t*)keys, nullptr));  // always L2 (:155)
-    size_t total = b * num_probes;
-    keys_to_probes_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((uint64_t*)keys, total, d_probes);
-    MDB_HIP(ctx, hipGetLastError());
+    // always L2 (:155); the merge kernel writes the probe (centroid) ids itself: num_probes <= num_clusters, so every row is full
+    const UnpackOut up{d_probes, nullptr, nullptr, zero_counters ? ctx->d_counters : nullptr};
+    MDB_TRY(flat_topk_keys(ctx, cv, MDB_METRIC_L2, d_q, qstride, b, num_probes, (uint64_t*)keys, nullptr, false, nullptr, &up));
     return MDB_OK;
 }
 
@@ -1129,12 +1123,12 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
         else MDB_HIP(ctx, hipMemcpyAsync(dprobes, probes, b * num_probes * 4,
                                          mem == MDB_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
     } else {
-        MDB_TRY(s.coarse(0, dq, qstride, b, num_probes, (uint32_t*)dprobes));
+        MDB_TRY(s.coarse(0, dq, qstride, b, num_probes, (uint32_t*)dprobes, true));  // also clears the device counters
     }
     void *keys, *cnts;
     MDB_TRY(mdb_scratch(ctx, 3, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4 + 16, &cnts));
-    MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    if (probes) MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
     ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
     ctx->stat_bytes_per_eval = 0; ctx->stat_bytes_per_scored = s.bytes_per_scored(); ctx->stat_fixed_bytes = 0;

@@ -20,6 +20,7 @@ struct UnpackOut {
     uint32_t* ids = nullptr;      // [b][k] row ids, UINT32_MAX padded
     float* dist = nullptr;        // [b][k] distances, +inf padded
     uint32_t* counts = nullptr;   // [b] (may be null)
+    unsigned long long* zero4 = nullptr;  // four words cleared by block 0 (the context's device counters, ahead of the kernels that add to them)
 };
 mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const float* d_queries_padded, int qstride,
                           size_t b, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false,
