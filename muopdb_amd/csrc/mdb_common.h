@@ -41,11 +41,19 @@ struct mdb_ctx {
     int prof_mask = 3;   // MDB_PROF_SCAN | MDB_PROF_HNSW: which kernel classes are bracketed
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
+    // pinned host staging for MDB_MEM_HOST calls: [0] inputs, [1] outputs.  Pageable hipMemcpyAsync costs ~0.2 ms a call
+    // on this stack; user buffer <-> pinned is a CPU memcpy, pinned <-> device a true async copy.
+    void* pinned[2] = {nullptr, nullptr};
+    size_t pinned_cap[2] = {0, 0};
     std::mutex mu;
     // index handles keep their context alive: mdb_device_close drops the caller's reference and the
     // context is destroyed with the last handle (so free order does not matter to the caller)
     std::atomic<int> refs{1};
 };
+mdb_status mdb_pinned(mdb_ctx* ctx, int slot, size_t bytes, void** out);  // grow-only pinned host buffer
+struct HostCopy { void* dst; const void* src; size_t bytes; };
+// device results -> caller's host buffers through ONE pinned block + the error flags, one stream sync; then mdb_check_flags' tests
+mdb_status mdb_return_to_host(mdb_ctx* ctx, const HostCopy* items, int n);
 void mdb_ctx_retain(mdb_ctx* ctx);
 void mdb_ctx_release(mdb_ctx* ctx);
 

@@ -44,6 +44,41 @@ mdb_status mdb_check_flags(mdb_ctx* ctx) {
     return MDB_OK;
 }
 
+mdb_status mdb_pinned(mdb_ctx* ctx, int slot, size_t bytes, void** out) {
+    if (bytes > ctx->pinned_cap[slot]) {
+        MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned[slot]) (void)hipHostFree(ctx->pinned[slot]);
+        ctx->pinned[slot] = nullptr;
+        ctx->pinned_cap[slot] = 0;
+        size_t cap = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+        if (hipHostMalloc(&ctx->pinned[slot], cap) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "pinned staging of %zu bytes", cap);
+        ctx->pinned_cap[slot] = cap;
+    }
+    *out = ctx->pinned[slot];
+    return MDB_OK;
+}
+
+mdb_status mdb_return_to_host(mdb_ctx* ctx, const HostCopy* items, int n) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += align_up(items[i].dst && items[i].bytes ? items[i].bytes : 0, 64);
+    char* stage = nullptr;
+    if (total) MDB_TRY(mdb_pinned(ctx, 1, total, (void**)&stage));
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!items[i].dst || !items[i].bytes) continue;
+        MDB_HIP(ctx, hipMemcpyAsync(stage + off, items[i].src, items[i].bytes, hipMemcpyDeviceToHost, ctx->stream));
+        off += align_up(items[i].bytes, 64);
+    }
+    mdb_status st = mdb_check_flags(ctx);  // flags copy + the stream sync
+    off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!items[i].dst || !items[i].bytes) continue;
+        memcpy(items[i].dst, stage + off, items[i].bytes);
+        off += align_up(items[i].bytes, 64);
+    }
+    return st;
+}
+
 void mdb_ctx_retain(mdb_ctx* ctx) { ctx->refs.fetch_add(1); }
 
 void mdb_ctx_release(mdb_ctx* ctx) {
@@ -56,6 +91,8 @@ void mdb_ctx_release(mdb_ctx* ctx) {
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
     for (auto& ev : ctx->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -65,7 +65,12 @@ mdb_status stage_queries(mdb_ctx* ctx, int slot, const float* queries, size_t b,
     if (mem == MDB_MEM_HOST) {
         void* raw;
         MDB_TRY(mdb_scratch(ctx, slot + 1, b * (size_t)d * 4 + 16, &raw));
-        MDB_HIP(ctx, hipMemcpyAsync(raw, queries, b * (size_t)d * 4, hipMemcpyHostToDevice, ctx->stream));
+        // caller's (pageable) rows -> pinned staging on the CPU, then a true async copy; every MDB_MEM_HOST call ends with a
+        // stream sync, so the staging block is free again when the next call starts
+        void* pin;
+        MDB_TRY(mdb_pinned(ctx, 0, b * (size_t)d * 4, &pin));
+        memcpy(pin, queries, b * (size_t)d * 4);
+        MDB_HIP(ctx, hipMemcpyAsync(raw, pin, b * (size_t)d * 4, hipMemcpyHostToDevice, ctx->stream));
         src = (const float*)raw;
     }
     size_t total = bpad * (size_t)qs;
@@ -389,12 +394,8 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     MDB_TRY(mdb_scratch(ctx, 3, total * 4, &ddist));
     if (total) unpack_keys_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((uint64_t*)keys, total, (uint32_t*)dids, (float*)ddist);
     MDB_HIP(ctx, hipGetLastError());
-    if (total) {
-        MDB_HIP(ctx, hipMemcpyAsync(ids_out, dids, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-        MDB_HIP(ctx, hipMemcpyAsync(dist_out, ddist, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts, b * 4, hipMemcpyDeviceToHost, ctx->stream));
-    return mdb_check_flags(ctx);
+    const HostCopy back[3] = {{ids_out, dids, total * 4}, {dist_out, ddist, total * 4}, {counts_out, cnts, b * 4}};
+    return mdb_return_to_host(ctx, back, 3);
 }
 
 mdb_status mdb_flat_topk(mdb_ctx* ctx, const float* base, size_t n, size_t d, const float* queries, size_t b,

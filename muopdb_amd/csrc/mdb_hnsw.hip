@@ -1575,12 +1575,8 @@ mdb_status mdb_hnsw_ann_search(mdb_hnsw* h, const float* queries, size_t b, size
     MDB_TRY(mdb_scratch(ctx, 5, total * 16 + 16, &dids));
     MDB_TRY(mdb_scratch(ctx, 1, total * 4 + 16, &dsc));
     MDB_TRY(s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, (mdb_u128*)dids, (float*)dsc, nullptr));
-    if (total) {
-        MDB_HIP(ctx, hipMemcpyAsync(doc_ids_out, dids, total * 16, hipMemcpyDeviceToHost, ctx->stream));
-        MDB_HIP(ctx, hipMemcpyAsync(scores_out, dsc, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts, b * 4, hipMemcpyDeviceToHost, ctx->stream));
-    return mdb_check_flags(ctx);
+    const HostCopy back[3] = {{doc_ids_out, dids, total * 16}, {scores_out, dsc, total * 4}, {counts_out, cnts, b * 4}};
+    return mdb_return_to_host(ctx, back, 3);
 }
 
 }  // extern "C"

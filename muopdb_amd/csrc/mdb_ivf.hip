@@ -1145,16 +1145,10 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
     void *dids, *dsc;
     MDB_TRY(mdb_scratch(ctx, 5, total * 16 + 16, &dids));
     MDB_TRY(mdb_scratch(ctx, 1, total * 4 + 16, &dsc));
-    if (remap) {
-        MDB_TRY(s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, (mdb_u128*)dids, (float*)dsc, nullptr));
-        if (total) MDB_HIP(ctx, hipMemcpyAsync(ids_out, dids, total * 16, hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        if (total) unpack_keys(ctx, (uint64_t*)keys, total, (uint32_t*)dids, (float*)dsc);
-        if (total) MDB_HIP(ctx, hipMemcpyAsync(ids_out, dids, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    if (total) MDB_HIP(ctx, hipMemcpyAsync(scores_out, dsc, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts, b * 4, hipMemcpyDeviceToHost, ctx->stream));
-    return mdb_check_flags(ctx);
+    if (remap) MDB_TRY(s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, (mdb_u128*)dids, (float*)dsc, nullptr));
+    else if (total) unpack_keys(ctx, (uint64_t*)keys, total, (uint32_t*)dids, (float*)dsc);
+    const HostCopy back[3] = {{ids_out, dids, total * (remap ? 16 : 4)}, {scores_out, dsc, total * 4}, {counts_out, cnts, b * 4}};
+    return mdb_return_to_host(ctx, back, 3);
 }
 
 extern "C" {

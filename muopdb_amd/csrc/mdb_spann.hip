@@ -123,13 +123,8 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     mdb_u128* ddoc = (mdb_u128*)(base + o_doc);
     float* dsc = (float*)(base + o_sc);
     MDB_TRY(s.ivf.remap(keys, cnts, b, k, d_q_user, ddoc, dsc, nullptr));
-    if (total) {
-        MDB_HIP(ctx, hipMemcpyAsync(doc_ids_out, ddoc, total * 16, hipMemcpyDeviceToHost, ctx->stream));
-        MDB_HIP(ctx, hipMemcpyAsync(scores_out, dsc, total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    if (counts_out) MDB_HIP(ctx, hipMemcpyAsync(counts_out, cnts, b * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound, b, hipMemcpyDeviceToHost, ctx->stream));
-    return mdb_check_flags(ctx);
+    const HostCopy back[4] = {{doc_ids_out, ddoc, total * 16}, {scores_out, dsc, total * 4}, {counts_out, cnts, b * 4}, {found_out, dfound, b}};
+    return mdb_return_to_host(ctx, back, 4);
 }
 
 struct mdb_spann {
