@@ -1,0 +1,175 @@
+"""BASELINE.json's FULL sizes on the GPU (C1 10k x 128 flat, C2 SIFT-1M HNSW ef=200, C3 SIFT-1M IVF-PQ), checked through
+properties that do not depend on the size — sortedness, idempotence, batch-split invariance, self-retrieval,
+tombstone monotonicity, recall against the exact scan — plus direct oracle parity on a handful of queries (the CPU
+oracle needs ~1 ms per HNSW query and ~12 ms per 1M-row exact scan, so a few rows at full size are affordable).
+The synthetic base is bench.py's (4096 Gaussian clusters, sigma 20, clipped to [0, 218], rounded).
+C4 / C5 do not fit a test's time budget; their shapes run at 1/8 size in test_gpu_traversal / bench.py."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+N, D, K = 1_000_000, 128, 10
+
+
+def rows_of(res, b):
+    return [(res.doc_ids(i), np.asarray(res.scores[i, :int(res.counts[i])], np.float32).view(np.uint32).tolist()) for i in range(b)]
+
+
+def assert_sorted(res, b):
+    """IdWithScore order (rs/index/src/utils.rs:89-128): score ascending, then doc id."""
+    for i in range(b):
+        n = int(res.counts[i])
+        sc = np.asarray(res.scores[i, :n], np.float32)
+        ids = res.doc_ids(i)
+        assert np.all(sc[:-1] <= sc[1:])
+        for j in range(n - 1):
+            if sc[j] == sc[j + 1]:
+                assert ids[j] < ids[j + 1]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from muopdb_amd import lib as L
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def base(ctx):
+    """(device rows, host rows, 96 host queries): the C2/C3 base of bench.py"""
+    import torch
+    from muopdb_amd import build as B
+    ncl = 4096
+    x = B.sift_like(N, D, n_clusters=ncl, seed=1)
+    g = torch.Generator(device="cpu"); g.manual_seed(1)
+    centers = (torch.rand((ncl, D), generator=g) * 218.0).cuda()
+    gq = torch.Generator(device="cpu"); gq.manual_seed(4242)
+    qa = torch.randint(0, ncl, (96,), generator=gq).cuda()
+    q = torch.clamp(torch.round(centers[qa] + (torch.randn((96, D), generator=gq) * 20.0).cuda()), 0, 218)
+    return x, x.cpu().numpy(), q.cpu().numpy().astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def flat_1m(ctx, base):
+    from muopdb_amd.index import FlatIndex
+    return FlatIndex(ctx, base[1])
+
+
+def test_c1_flat_10k_full_parity(ctx, oracle):
+    """C1 is small enough for the oracle in full: 10 clusters x 1000 x 128 (py/create_test_hdf5.py semantics), 200 queries."""
+    from muopdb_amd.index import FlatIndex
+    x = H.test_hdf5_like()
+    rng = np.random.default_rng(43)
+    q = (x[rng.integers(0, len(x), 200)] + rng.normal(0, 5, (200, D))).astype(np.float32)
+    g = FlatIndex(ctx, x)
+    ids, dist, cnt = g.search(q, K)
+    oids, odist = oracle.flat_topk(oracle.METRIC_L2, x, q, K)
+    assert np.array_equal(ids, oids) and np.array_equal(dist.view(np.uint32), odist.view(np.uint32)) and np.all(cnt == K)
+    one = [g.search(q[i:i + 1], K) for i in range(0, 200, 37)]  # batch 1 (the configuration's batch) == rows of the batch
+    for j, i in enumerate(range(0, 200, 37)):
+        assert np.array_equal(one[j][0][0], ids[i]) and np.array_equal(one[j][1][0].view(np.uint32), dist[i].view(np.uint32))
+
+
+def test_flat_1m_properties_and_oracle_rows(ctx, oracle, base, flat_1m):
+    _, xh, q = base
+    ids, dist, cnt = flat_1m.search(q[:64], K)             # batched path (sample bound + MFMA filter + exact refine)
+    assert np.all(cnt == K)
+    assert np.all(dist[:, :-1] <= dist[:, 1:])              # sorted by distance ...
+    tie = dist[:, :-1] == dist[:, 1:]
+    assert np.all(ids[:, :-1][tie] < ids[:, 1:][tie])       # ... then by row id
+    again = flat_1m.search(q[:64], K)                       # idempotent
+    assert np.array_equal(again[0], ids) and np.array_equal(again[1].view(np.uint32), dist.view(np.uint32))
+    for lo, hi in [(0, 1), (1, 4), (4, 32), (32, 64)]:      # batch-split invariance: exact kernels (B <= 4) and batched path agree
+        part = flat_1m.search(q[lo:hi], K)
+        assert np.array_equal(part[0], ids[lo:hi]) and np.array_equal(part[1].view(np.uint32), dist[lo:hi].view(np.uint32))
+    oids, odist = oracle.flat_topk(oracle.METRIC_L2, xh, q[:6], K)            # the oracle itself on the full base
+    assert np.array_equal(ids[:6], oids) and np.array_equal(dist[:6].view(np.uint32), odist.view(np.uint32))
+    rows = np.array([5, 77_777, 500_000, 999_999])          # self-retrieval: a stored row finds itself at distance 0
+    sids, sdist, _ = flat_1m.search(xh[rows], K)
+    assert np.all(sdist[:, 0] == 0.0)
+    for r, row in enumerate(rows):
+        zero = sids[r][sdist[r] == 0.0]
+        assert row in zero and np.all(np.diff(zero) > 0)    # duplicates of the clipped / rounded data: ascending ids
+
+
+@pytest.fixture(scope="module")
+def hnsw_1m(ctx, base):
+    from muopdb_amd import build as B
+    from muopdb_amd.index import BlockBasedHnsw
+    idx, vec = B.hnsw_files(base[0], max_neighbors=32, max_layers=8, kcand=64, seed=1)
+    return idx, vec, BlockBasedHnsw(ctx, idx, vec, D)
+
+
+def test_c2_hnsw_1m_ef200(ctx, oracle, base, flat_1m, hnsw_1m):
+    _, xh, q = base
+    idx, vec, g = hnsw_1m
+    res = g.ann_search(q[:64], K, 200)
+    assert all(int(c) == K for c in res.counts[:64])
+    assert_sorted(res, 64)
+    assert rows_of(g.ann_search(q[:64], K, 200), 64) == rows_of(res, 64)                 # idempotent
+    whole = rows_of(res, 64)
+    for lo, hi in [(0, 1), (1, 9), (9, 64)]:                                             # one block per query: any split, same rows
+        assert rows_of(g.ann_search(q[lo:hi], K, 200), hi - lo) == whole[lo:hi]
+    o = oracle.BlockBasedHnsw(idx, vec, D)                                               # the oracle on the same 768 MB of files
+    ores = o.ann_search(q[:24], K, 200)
+    evals, expanded = o.stats()
+    g.ann_search(q[:24], K, 200)
+    st = ctx.stats()
+    assert rows_of(ores, 24) == whole[:24]
+    assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)             # same traversal, step for step
+    exact_ids, _, _ = flat_1m.search(q[:64], K)                                          # recall@10 against the exact scan
+    hit = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(64))
+    assert hit / (64 * K) >= 0.99
+    # ef is monotone for the result quality: a larger ef never loses exact neighbours on this base
+    wide = g.ann_search(q[:16], K, 400)   # > 256: the general kernel
+    hit_w = sum(len(set(wide.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(16))
+    hit_n = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(16))
+    assert hit_w >= hit_n
+    assert rows_of(o.ann_search(q[:4], K, 400), 4) == rows_of(wide, 4)[:4]
+
+
+def test_c3_ivfpq_1m_nprobe16(ctx, oracle, base):
+    import torch
+    from muopdb_amd import build as B
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import BlockBasedIvf, ProductQuantizer
+    x, xh, q = base
+    nlist, P = 4096, 16
+    cent = B.kmeans(x, nlist, iters=4, seed=3, sample=300_000)
+    assign = B.assign_nearest(x, cent)
+    cb = B.train_pq_codebook(x, 8, 8, iters=4, seed=4, sample=100_000)
+    pq = ProductQuantizer(D, 8, 8, cb)
+    codes = pq.quantize(ctx, xh)
+    pls = B.posting_lists_from_assignment(assign, nlist)
+    index = F.write_ivf_index(cent.cpu().numpy(), np.arange(N, dtype=np.uint64), pls, quantized_dimension=D // 8)
+    vec = F.write_vector_file(codes)
+    del assign
+    torch.cuda.empty_cache()
+    g = BlockBasedIvf(ctx, index, vec, pq)
+    assert g.num_vectors() == N and g.num_clusters() == nlist
+    res = g.search(q[:96], K, P)
+    assert_sorted(res, 96)
+    whole = rows_of(res, 96)
+    assert rows_of(g.search(q[:96], K, P), 96) == whole                                   # idempotent
+    for lo, hi in [(0, 1), (1, 40), (40, 96)]:                                            # batch-split invariance
+        assert rows_of(g.search(q[lo:hi], K, P), hi - lo) == whole[lo:hi]
+    o = oracle.BlockBasedIvf(index, vec, oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, cb))
+    assert np.array_equal(g.find_nearest_centroids(q[:16], P), o.find_nearest_centroids(q[:16], P))
+    assert rows_of(o.search(q[:16], K, num_probes=P), 16) == whole[:16]                   # the oracle on the full index
+    # more probes scan a superset of lists: the k-th symmetric-PQ score can only improve
+    more = g.search(q[:32], K, 2 * P)
+    for i in range(32):
+        assert float(more.scores[i, K - 1]) <= float(res.scores[i, K - 1])
+    # tombstones are monotone: invalidating a query's best document removes it and never changes the rest's order
+    victims = sorted({res.doc_ids(i)[0] for i in range(8)})
+    for doc in victims:
+        assert g.invalidate(doc) and o.invalidate(doc)
+    after = g.search(q[:8], K, P)
+    assert rows_of(o.search(q[:8], K, num_probes=P), 8) == rows_of(after, 8)
+    for i in range(8):
+        kept = [dd for dd in res.doc_ids(i) if dd not in victims]
+        assert after.doc_ids(i)[:len(kept)] == kept
