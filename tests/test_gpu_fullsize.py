@@ -173,3 +173,48 @@ def test_c3_ivfpq_1m_nprobe16(ctx, oracle, base):
     for i in range(8):
         kept = [dd for dd in res.doc_ids(i) if dd not in victims]
         assert after.doc_ids(i)[:len(kept)] == kept
+
+
+def test_c4_shape_multi_user_spann_eighth(ctx, oracle):
+    """C4's shape at 1/8 of its users (the full 1024 x 9766 x 768 = 30.7 GB is bench.py's --users 1024): 128 users x 9766 x
+    768 unit-norm rows, one (user, query) pair per user, ef=200 >= the ~150 centroids of a user (closure kernel),
+    num_explored_centroids 16, ratio 0.1.  Properties + the oracle on 24 users + union of two list shards == unsharded."""
+    from muopdb_amd import build as B
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import MultiSpannIndex, SearchParams
+    U, per, d, P = 128, 9766, 768, 16
+    users, base = {}, []
+    for u in range(U):
+        x = B.unit_gaussian(per, d, seed=3_000_000 + u)
+        cent = B.kmeans(x, per // 64, iters=3, seed=u)
+        pls = B.posting_lists_from_assignment(B.assign_nearest(x, cent), cent.shape[0])
+        hi, hv = B.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
+        docs = np.arange(u * per, (u + 1) * per, dtype=np.uint64)
+        users[u + 1] = dict(hnsw_index=hi, hnsw_vectors=hv, ivf_index=F.write_ivf_index(cent.cpu().numpy(), docs, pls),
+                            ivf_vectors=F.write_vector_file(x.cpu().numpy()))
+        base.append(x[:4].cpu().numpy())
+    cat = F.concat_multi_spann(users)
+    del users
+    args = (cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+    g = MultiSpannIndex(ctx, *args)
+    rng = np.random.default_rng(5)
+    uids = [u + 1 for u in range(U)]
+    q = np.stack([base[u][1] + rng.normal(0, 0.3 / d ** 0.5, d) for u in range(U)]).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    p = SearchParams(K, 200).with_num_explored_centroids(P).with_centroid_distance_ratio(0.1)
+    res = g.search_for_user(uids, q, p)
+    assert all(res.found[i] for i in range(U))
+    assert_sorted(res, U)
+    whole = rows_of(res, U)
+    assert rows_of(g.search_for_user(uids, q, p), U) == whole                                     # idempotent
+    for lo, hi in [(0, 1), (1, 50), (50, U)]:                                                     # any batch composition
+        assert rows_of(g.search_for_user(uids[lo:hi], q[lo:hi], p), hi - lo) == whole[lo:hi]
+    for u in range(U):                                                                            # every hit belongs to the query's user
+        assert all(u * per <= dd < (u + 1) * per for dd in res.doc_ids(u))
+    o = oracle.MultiSpannIndex(*args)
+    op = oracle.SearchParams(K, 200, num_explored_centroids=P, centroid_distance_ratio=0.1)
+    assert rows_of(o.search_for_user(uids[:24], q[:24], op), 24) == whole[:24]
+    shards = [MultiSpannIndex(ctx, *args, None, r, 2).search_for_user(uids, q, p) for r in range(2)]  # lists l % 2 == r
+    for i in range(U):
+        merged = sorted([(float(s), dd) for sh in shards for dd, s in sh.id_with_scores(i)])[:K]
+        assert [dd for _, dd in merged] == res.doc_ids(i)
