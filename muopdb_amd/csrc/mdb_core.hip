@@ -321,10 +321,16 @@ __global__ __launch_bounds__(256) void pq_quantize_kernel(const float* __restric
     const float* sub = vecs + v * (size_t)row_stride + (size_t)s * subdim;  // wave-uniform: scalar loads
     const float* cbs = cb + (size_t)s * K * subdim;
     uint64_t best = ~0ull;  // no centroid strictly below f32::MAX yet (=> code 0)
+    const bool rows16 = (subdim & 3) == 0;  // codebook rows are then whole, 16-byte aligned float4s (the arena is)
     for (int c = lane; c < K; c += 64) {
-        RowLoader lc{cbs + (size_t)c * subdim, subdim};
         float raw[1];
-        exact_sums<MDB_METRIC_L2, 1>(lc, sub, 0, sp, raw);
+        if (rows16) {
+            Row4Loader lc{(const float4*)(cbs + (size_t)c * subdim)};
+            exact_sums<MDB_METRIC_L2, 1>(lc, sub, 0, sp, raw);
+        } else {
+            RowLoader lc{cbs + (size_t)c * subdim, subdim};
+            exact_sums<MDB_METRIC_L2, 1>(lc, sub, 0, sp, raw);
+        }
         if (raw[0] < 3.402823466e+38f) {  // also false for NaN
             uint64_t key = ((uint64_t)f32_orderable(raw[0]) << 32) | (uint32_t)c;
             best = key < best ? key : best;

@@ -70,6 +70,11 @@ struct RowLoader {  // plain row-major row, arbitrary alignment
     }
 };
 
+struct Row4Loader {  // row-major row whose start is 16-byte aligned and whose length is a multiple of 4
+    const float4* p;
+    __device__ __forceinline__ float4 get4(int c4) const { return p[c4]; }
+};
+
 // QT queries against ONE stored vector (this thread's).  q[i] = qbase + i*qstride must be
 // wave-uniform (scalar loads).  Returns the raw cascade sum (squared L2 / positive dot).
 template <int METRIC, int QT, class Loader>
