@@ -75,11 +75,12 @@ FlatAux::~FlatAux() {
     if (h_ovf) (void)hipHostFree(h_ovf);
 }
 
-mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux) {
+mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles) {
     size_t full = v.n / MDB_TILE;
     if (full < 1024) return MDB_OK;  // < 64K vectors: the exact path is used
     static const size_t div = getenv("MDB_MF_SAMPLE_DIV") ? (size_t)atoi(getenv("MDB_MF_SAMPLE_DIV")) : 32;
     size_t want = std::min<size_t>(std::max<size_t>(full / div, 256), 1024);  // 16K .. 64K vectors
+    if (want_tiles) want = std::min(std::max<size_t>(want_tiles, 16), full);
     size_t stride = full / want;
     size_t stiles = (full - 1) / stride + 1;
     TileStore& out = aux.sample;
@@ -170,8 +171,12 @@ template <int METRIC, int QB>
 __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* __restrict__ tiles, size_t n, size_t ntiles, int d4,
                                                                   const float* __restrict__ dqc, int qstride,
                                                                   const float* __restrict__ crow, float kappa,
-                                                                  uint64_t* __restrict__ pairs, uint32_t* __restrict__ npairs,
+                                                                  uint64_t* __restrict__ pairs_all, uint32_t* __restrict__ npairs_all,
                                                                   uint32_t pair_cap, size_t b, uint32_t* __restrict__ flags) {
+    // one candidate list per QUERY GROUP (blockIdx.y): the refine blocks of a query read their group's list only
+    // (with one global list a batch of 4096 queries made every refine block wade through all 2 M pairs)
+    uint64_t* __restrict__ pairs = pairs_all + (size_t)blockIdx.y * pair_cap;
+    uint32_t* __restrict__ npairs = npairs_all + (size_t)blockIdx.y * 64;  // own 256-byte line per group
     constexpr int BQ = 32 * QB, BQP = BQ + 1;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* Qs = (float*)lds;                      // [nch*MF_CH*4][BQP], zero beyond d4*4
@@ -319,12 +324,14 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
 template <int METRIC>
 __global__ __launch_bounds__(MDB_BLOCK) void flat_refine_kernel(const float4* __restrict__ tiles, DistPlan p,
                                                                 const float* __restrict__ dq, int qstride,
-                                                                const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ npairs,
-                                                                uint32_t pair_cap, int k, uint64_t* __restrict__ keys,
+                                                                const uint64_t* __restrict__ pairs_all, const uint32_t* __restrict__ npairs_all,
+                                                                uint32_t pair_cap, int group_queries, int k, uint64_t* __restrict__ keys,
                                                                 uint32_t* __restrict__ ovf, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const size_t m = blockIdx.y;
-    const uint32_t np = *npairs;
+    const size_t grp = m / (size_t)group_queries;  // the filter's query group of this query
+    const uint64_t* __restrict__ pairs = pairs_all + grp * pair_cap;
+    const uint32_t np = npairs_all[grp * 64];
     if (np > pair_cap) {
         if (threadIdx.x == 0 && m == 0 && blockIdx.x == 0) atomicAdd(ovf, 1u);
         return;
@@ -412,7 +419,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     if (bpadq > bpad) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "internal: queries staged with %zu rows, filter needs %zu", bpad, bpadq);
     char* ax;
     size_t off_sc = align_up(b * k * 8, 16), off_cr = off_sc + align_up(b * 4, 16), off_np = off_cr + align_up(bpadq * 4, 256),
-           off_ov = off_np + 256, off_qc = off_ov + 256;
+           off_ov = off_np + groups * 256, off_qc = off_ov + 256;
     MDB_TRY(mdb_scratch(ctx, 8, off_qc + bpadq * (size_t)qstride * 4, (void**)&ax));
     uint64_t* skeys = (uint64_t*)ax;
     uint32_t* scounts = (uint32_t*)(ax + off_sc);
@@ -420,9 +427,11 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     uint32_t* npairs = (uint32_t*)(ax + off_np);  // own 256-byte lines: these two words take device-scope atomics
     uint32_t* ovf = (uint32_t*)(ax + off_ov);
     float* dqc = (float*)(ax + off_qc);
-    const uint32_t pair_cap = (uint32_t)std::min<size_t>(b * 1024, 1u << 24);
+    // candidate lists: one per query group, ~1024 slots per query (bounded to 1 GiB in total)
+    uint32_t pair_cap = (uint32_t)(BQ * 1024);
+    while (pair_cap > 4096 && groups * (size_t)pair_cap * 8 > ((size_t)1 << 30)) pair_cap /= 2;
     uint64_t* pairs;
-    MDB_TRY(mdb_scratch(ctx, 9, (size_t)pair_cap * 8, (void**)&pairs));
+    MDB_TRY(mdb_scratch(ctx, 9, groups * (size_t)pair_cap * 8, (void**)&pairs));
     // A. sample top-k (exact)
     MDB_TRY(flat_topk_keys(ctx, view_of(aux.sample), metric, dq, qstride, b, k, skeys, scounts, false));
     // error budget of the filter, eps = 2^-24, all norms of the centred operands:
@@ -432,7 +441,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     //   fl(qn), fl(xn) (fmaf chains)             : d eps each
     // => a member of the true top-k passes the test when kappa >= (4d + 10) eps / (1 - d eps); 6 (d + 4) eps is used.
     const float kappa = 6.0f * (float)(ts.d4 * 4 + 4) * 5.9604645e-8f;
-    MDB_HIP(ctx, hipMemsetAsync(npairs, 0, 512, ctx->stream));  // npairs and ovf
+    MDB_HIP(ctx, hipMemsetAsync(npairs, 0, groups * 256 + 256, ctx->stream));  // the groups' counters and ovf
     mfma_prep_kernel<<<dim3((unsigned)bpadq), 128, 0, ctx->stream>>>(dq, qstride, ts.d, aux.mean.p, skeys, scounts, (int)k, kappa,
                                                                     metric, b, dqc, crow);
     // B. filter on the centred copy (L2) / the base itself (dot)
@@ -466,17 +475,19 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     MDB_HIP(ctx, hipMemsetAsync(rpart, 0xFF, b * (size_t)MF_RS * k * 8, ctx->stream));  // a slice that bails out leaves KEY_MAX
     if (metric == MDB_METRIC_L2)
         flat_refine_kernel<MDB_METRIC_L2><<<dim3(MF_RS, (unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(
-            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)k, rpart, ovf, ctx->d_flags);
+            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)BQ, (int)k, rpart, ovf, ctx->d_flags);
     else
         flat_refine_kernel<MDB_METRIC_DOT><<<dim3(MF_RS, (unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(
-            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)k, rpart, ovf, ctx->d_flags);
+            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)BQ, (int)k, rpart, ovf, ctx->d_flags);
     MDB_HIP(ctx, hipGetLastError());
     MDB_TRY(merge_keys(ctx, rpart, (size_t)MF_RS * k, b, k, d_keys, d_counts));
     if (getenv("MDB_MF_DBG")) {
         uint32_t hn = 0, ho = 0;
-        MDB_HIP(ctx, hipMemcpyAsync(&hn, npairs, 4, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<uint32_t> hcnt(groups * 64);
+        MDB_HIP(ctx, hipMemcpyAsync(hcnt.data(), npairs, groups * 256, hipMemcpyDeviceToHost, ctx->stream));
         MDB_HIP(ctx, hipMemcpyAsync(&ho, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
         MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t gi = 0; gi < groups; ++gi) hn += hcnt[gi * 64];
         fprintf(stderr, "[mf] b=%zu QB=%d candidate pairs %u (%.1f per query) overflowed %u\n", b, QB, hn, (double)hn / b, ho);
     }
     // D. gated exact scan of the batch: both launches return at once unless a list overflowed

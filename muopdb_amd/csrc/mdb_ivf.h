@@ -5,6 +5,7 @@
 #include <utility>
 
 #include "mdb_common.h"
+#include "mdb_kernels.h"
 
 // per-user (per-blob) descriptor read by the kernels
 struct IvfUserDev {
@@ -64,8 +65,12 @@ struct IvfSet {
     mdb_status build_doc_map(size_t ui);
     mdb_status invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out, bool test_only);
     mdb_status set_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem);
+    // single index with >= 64K centroids: sample / centred copy for the batched (MFMA-filtered) coarse search
+    FlatAux cent_aux;
+    // rows the queries must be staged with for coarse(): whole groups of 64 when the batched path may run
+    size_t coarse_bpad(size_t b) const { return cent_aux.sample.n ? (b + 63) / 64 * 64 : (b + 3) / 4 * 4; }
     mdb_status coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes,
-                      bool zero_counters = false);  // zero_counters: its merge kernel also clears the context's device counters
+                      bool zero_counters = false, size_t bpad = 0);  // zero_counters: its merge kernel also clears the context's device counters
     mdb_status scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
                     const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts);
     mdb_status remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,

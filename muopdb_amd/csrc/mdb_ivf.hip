@@ -890,6 +890,12 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
                 d_index.p, d_ctsrc.p, d_ctlim.p, nullptr, d_ctfirst.p, (int)num_features, d4, (float4*)d_cent_tiles.p, total4,
                 ctx->d_flags);
         MDB_HIP(ctx, hipGetLastError());
+        // one index with a large coarse quantizer (C5: 65 536 lists): large batches of queries go through the batched flat
+        // path (sample bound + matrix-core filter + exact refine) — the same probe ids, several times faster
+        if (U == 1 && blobs[0].num_clusters >= 65536) {
+            TileView cv{d_cent_tiles.p, blobs[0].num_clusters, (blobs[0].num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
+            MDB_TRY(flat_build_aux(ctx, cv, cent_aux, (cv.n / MDB_TILE) / 8));
+        }
     }
     mdb_status st = mdb_check_flags(ctx);  // synchronises: temporaries may now be released
     if (st != MDB_OK) return st;
@@ -1082,7 +1088,8 @@ mdb_status IvfSet::remap(const uint64_t* d_keys, const uint32_t* d_counts, size_
 // find_nearest_centroids (index.rs:147-163) for user `ui`: sqrt-L2 to every centroid, the
 // num_probes nearest ordered by (distance, index) [ties: the reference's select_nth_unstable +
 // stable sort leave equal distances implementation-defined; this path orders them by index]
-mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes, bool zero_counters) {
+mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes, bool zero_counters,
+                          size_t bpad) {
     const IvfBlobInfo& bi = blobs[ui];
     if (num_probes == 0 || num_probes > bi.num_clusters)
         return mdb_fail(ctx, MDB_ERR_OUT_OF_RANGE, "num_probes=%zu out of range (num_clusters=%u): the reference panics in select_nth_unstable_by",
@@ -1092,6 +1099,14 @@ mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, si
                 (bi.num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
     void* keys;
     MDB_TRY(mdb_scratch(ctx, 5, b * num_probes * 8, &keys));
+    if (ui == 0 && cent_aux.sample.n && bpad >= (b + 63) / 64 * 64 && flat_mfma_applicable(cv, cent_aux, b, num_probes)) {
+        MDB_TRY(flat_topk_keys_mfma(ctx, cv, cent_aux, MDB_METRIC_L2, d_q, qstride, b, bpad, num_probes, (uint64_t*)keys, nullptr));
+        void* dist;
+        MDB_TRY(mdb_scratch(ctx, 1, b * num_probes * 4 + 16, &dist));
+        MDB_TRY(unpack_keys(ctx, (const uint64_t*)keys, b * num_probes, d_probes, (float*)dist));
+        if (zero_counters) MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+        return MDB_OK;
+    }
     // always L2 (:155); the merge kernel writes the probe (centroid) ids itself: num_probes <= num_clusters, so every row is full
     const UnpackOut up{d_probes, nullptr, nullptr, zero_counters ? ctx->d_counters : nullptr};
     MDB_TRY(flat_topk_keys(ctx, cv, MDB_METRIC_L2, d_q, qstride, b, num_probes, (uint64_t*)keys, nullptr, false, nullptr, &up));
@@ -1115,7 +1130,8 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     float* dq;
     int qstride;
-    MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, (b + 3) / 4 * 4, &dq, &qstride));
+    const size_t bpad = probes ? (b + 3) / 4 * 4 : s.coarse_bpad(b);
+    MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, bpad, &dq, &qstride));
     void* dprobes;
     MDB_TRY(mdb_scratch(ctx, 2, b * std::max<size_t>(num_probes, 1) * 4, &dprobes));
     if (probes) {
@@ -1123,7 +1139,7 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
         else MDB_HIP(ctx, hipMemcpyAsync(dprobes, probes, b * num_probes * 4,
                                          mem == MDB_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
     } else {
-        MDB_TRY(s.coarse(0, dq, qstride, b, num_probes, (uint32_t*)dprobes, true));  // also clears the device counters
+        MDB_TRY(s.coarse(0, dq, qstride, b, num_probes, (uint32_t*)dprobes, true, bpad));  // also clears the device counters
     }
     void *keys, *cnts;
     MDB_TRY(mdb_scratch(ctx, 3, b * std::max<size_t>(k, 1) * 8, &keys));
@@ -1194,11 +1210,12 @@ mdb_status mdb_ivf_find_nearest_centroids(mdb_ivf* ivf, const float* queries, si
     if (b == 0) return MDB_OK;
     float* dq;
     int qstride;
-    MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, (b + 3) / 4 * 4, &dq, &qstride));
-    if (mem == MDB_MEM_DEVICE) return s.coarse(0, dq, qstride, b, num_probes, out);
+    const size_t bpad = s.coarse_bpad(b);
+    MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, bpad, &dq, &qstride));
+    if (mem == MDB_MEM_DEVICE) return s.coarse(0, dq, qstride, b, num_probes, out, false, bpad);
     void* dprobes;
     MDB_TRY(mdb_scratch(ctx, 2, b * num_probes * 4, &dprobes));
-    MDB_TRY(s.coarse(0, dq, qstride, b, num_probes, (uint32_t*)dprobes));
+    MDB_TRY(s.coarse(0, dq, qstride, b, num_probes, (uint32_t*)dprobes, false, bpad));
     MDB_HIP(ctx, hipMemcpyAsync(out, dprobes, b * num_probes * 4, hipMemcpyDeviceToHost, ctx->stream));
     return mdb_check_flags(ctx);
 }

@@ -40,7 +40,8 @@ struct FlatAux {
     FlatAux& operator=(const FlatAux&) = delete;
     ~FlatAux();
 };
-mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux);
+// want_tiles: size of the strided sample in tiles (0: N/32 clamped to 16K..64K vectors, the flat index default)
+mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles = 0);
 bool flat_mfma_applicable(const TileView& ts, FlatAux& aux, size_t b, size_t k);
 mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, int metric, const float* dq, int qstride, size_t b,
                                size_t bpad, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false);

@@ -406,6 +406,39 @@ def test_ivf_pq_bound_filter_adversarial(ctx, oracle, case):
         assert st["scored_vectors"] == st2["scored_vectors"] == n * len(q)
 
 
+def test_ivf_large_coarse_quantizer_batched_path(ctx, oracle):
+    """>= 64K centroids (C5 has 65 536 lists): batches of >= 8 queries find their probes through the batched flat path
+    (sample bound + matrix-core filter + exact refine) — probe ids and final rows must equal the oracle's, for a batch
+    that is not a multiple of 64, and equal the exact kernels' (small batch, MDB_FLAT_NO_MFMA)."""
+    import os
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import BlockBasedIvf
+    rng = np.random.default_rng(77)
+    L, d, extra, P = 65_600, 24, 3_000, 24
+    cent = (rng.standard_normal((L, d)) * 30).astype(np.float32)
+    cent[100] = cent[7]                                   # duplicate centroids: ties broken by index
+    own = np.concatenate([np.arange(L), rng.integers(0, L, extra)])
+    v = (cent[own] + rng.standard_normal((L + extra, d))).astype(np.float32)
+    order = np.argsort(own, kind="stable")
+    bounds = np.searchsorted(own[order], np.arange(L + 1))
+    pls = [order[bounds[i]:bounds[i + 1]].astype(np.uint64) for i in range(L)]
+    doc_ids = [3 * i + 1 for i in range(L + extra)]
+    index, vec = F.write_ivf_index(cent, doc_ids, pls), F.write_vector_file(v)
+    g, o = BlockBasedIvf(ctx, index, vec), oracle.BlockBasedIvf(index, vec)
+    q = (cent[rng.integers(0, L, 70)] + rng.standard_normal((70, d)) * 2).astype(np.float32)
+    q[3] = cent[7]
+    want = o.find_nearest_centroids(q, P)
+    assert np.array_equal(g.find_nearest_centroids(q, P), want)          # batched path (70 queries)
+    assert np.array_equal(g.find_nearest_centroids(q[:5], P), want[:5])  # exact kernels (batch < 8)
+    os.environ["MDB_FLAT_NO_MFMA"] = "1"
+    try:
+        assert np.array_equal(g.find_nearest_centroids(q, P), want)
+    finally:
+        del os.environ["MDB_FLAT_NO_MFMA"]
+    assert_result_rows(g.search(q, 10, P), o.search(q, 10, num_probes=P), len(q))
+    assert_result_rows(g.search(q[:9], 3, 1), o.search(q[:9], 3, num_probes=1), 9)
+
+
 def test_ivf_duplicates_tombstones_and_errors(ctx, oracle):
     from muopdb_amd import lib as L
     o, g, q, v, doc_ids = _ivf_case(oracle, ctx, 1200, 16, 6, seed=5, cpv=2)
