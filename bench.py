@@ -356,7 +356,11 @@ def run_ivfpq(args, ctx, rank, world, timer):
 
     def step(i, keep=None):
         q = queries[i * batch:(i + 1) * batch]
-        ctx.check(ctx.lib.mdb_ivf_search(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch), None, C.c_size_t(P), C.c_size_t(k),
+        probes = None
+        if world > 1:  # the coarse quantizer is sharded too: 1/world of the centroids per rank + one all-gather of (distance, id) rows
+            probes = D.sharded_probes(ctx, ivf, q.data_ptr(), batch, P, q.device)
+        ctx.check(ctx.lib.mdb_ivf_search(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch),
+                                         C.c_void_p(probes.data_ptr()) if probes is not None else None, C.c_size_t(P), C.c_size_t(k),
                                          C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()),
                                          C.c_void_p(cn.data_ptr())))
         res = ids

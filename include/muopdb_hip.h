@@ -185,6 +185,16 @@ size_t mdb_ivf_num_features(const mdb_ivf* ivf);
  * MDB_ERR_OUT_OF_RANGE when num_probes == 0 or > num_clusters (reference panics). */
 mdb_status mdb_ivf_find_nearest_centroids(mdb_ivf* ivf, const float* queries, size_t b, size_t num_probes, mdb_mem mem,
                                           uint32_t* out);
+/* Sharded coarse search for list-sharded multi-GPU IVF (find_nearest_centroids :147-163 split by
+ * centroid range): the num_probes nearest among centroids [first, first + count) ONLY, as (distance, centroid id) keys —
+ * u64 whose ascending order is (distance, id) — rows padded with UINT64_MAX.  `first` must be a multiple of 64.
+ * mdb_ivf_merge_coarse_keys turns `parts` such rows per query ([b][parts][num_probes], e.g. every rank's row after an
+ * all-gather) into the [b][num_probes] probe ids that mdb_ivf_search takes: the same ids find_nearest_centroids
+ * returns, with every rank scanning only its share of the centroids. */
+mdb_status mdb_ivf_coarse_keys(mdb_ivf* ivf, const float* queries, size_t b, size_t num_probes, size_t first, size_t count,
+                               mdb_mem mem, uint64_t* keys_out);
+mdb_status mdb_ivf_merge_coarse_keys(mdb_ivf* ivf, const uint64_t* keys, size_t b, size_t parts, size_t num_probes, mdb_mem mem,
+                                     uint32_t* probes_out);
 /* BlockBasedIvf::search :396-413 (probes == NULL) or search_with_centroids_and_remap :298-332
  * (probes = [B][num_probes] centroid ids).  Results ordered by IdWithScore (score, doc_id). */
 mdb_status mdb_ivf_search(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes,

@@ -1220,6 +1220,72 @@ mdb_status mdb_ivf_find_nearest_centroids(mdb_ivf* ivf, const float* queries, si
     return mdb_check_flags(ctx);
 }
 
+__global__ void keys_add_id_offset_kernel(uint64_t* __restrict__ keys, size_t total, uint32_t add) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total && keys[t] != MDB_KEY_MAX) keys[t] += add;  // id = low word; first + row < 2^32
+}
+
+mdb_status mdb_ivf_coarse_keys(mdb_ivf* ivf, const float* queries, size_t b, size_t num_probes, size_t first, size_t count,
+                               mdb_mem mem, uint64_t* keys_out) {
+    if (!ivf || (!queries && b) || !keys_out) return MDB_ERR_INVALID_ARG;
+    IvfSet& s = ivf->set;
+    mdb_ctx* ctx = s.ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t L = s.blobs[0].num_clusters;
+    if (num_probes == 0 || num_probes > MDB_MAX_K || (first % MDB_TILE) != 0 || first > L || count > L - first)
+        return mdb_fail(ctx, MDB_ERR_OUT_OF_RANGE, "coarse_keys: num_probes=%zu, centroid range [%zu, %zu) of %zu", num_probes, first, first + count, L);
+    if (b == 0) return MDB_OK;
+    const size_t total = b * num_probes;
+    void* dkeys = keys_out;
+    if (mem == MDB_MEM_HOST) MDB_TRY(mdb_scratch(ctx, 5, total * 8, &dkeys));
+    if (count == 0) {
+        MDB_HIP(ctx, hipMemsetAsync(dkeys, 0xFF, total * 8, ctx->stream));
+    } else {
+        float* dq;
+        int qstride;
+        MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, (b + 3) / 4 * 4, &dq, &qstride));
+        const int d4 = ((int)s.num_features + 3) / 4;
+        TileView cv{s.d_cent_tiles.p + ((size_t)s.h_users[0].cent_tile_base + first / MDB_TILE) * MDB_TILE * d4 * 4, count,
+                    (count + MDB_TILE - 1) / MDB_TILE, (int)s.num_features, d4};
+        MDB_TRY(flat_topk_keys(ctx, cv, MDB_METRIC_L2, dq, qstride, b, num_probes, (uint64_t*)dkeys, nullptr));
+        if (first) keys_add_id_offset_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((uint64_t*)dkeys, total, (uint32_t)first);
+        MDB_HIP(ctx, hipGetLastError());
+    }
+    if (mem == MDB_MEM_DEVICE) return MDB_OK;
+    const HostCopy back[1] = {{keys_out, dkeys, total * 8}};
+    return mdb_return_to_host(ctx, back, 1);
+}
+
+mdb_status mdb_ivf_merge_coarse_keys(mdb_ivf* ivf, const uint64_t* keys, size_t b, size_t parts, size_t num_probes, mdb_mem mem,
+                                     uint32_t* probes_out) {
+    if (!ivf || (!keys && b) || !probes_out || parts == 0 || num_probes == 0) return MDB_ERR_INVALID_ARG;
+    mdb_ctx* ctx = ivf->set.ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    if (num_probes > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "num_probes=%zu exceeds MDB_MAX_K=%d", num_probes, MDB_MAX_K);
+    if (b == 0) return MDB_OK;
+    const size_t per = parts * num_probes, total = b * num_probes;
+    const uint64_t* din = keys;
+    void *stage, *merged, *dist, *dids = probes_out;
+    if (mem == MDB_MEM_HOST) {
+        void* pin;
+        MDB_TRY(mdb_pinned(ctx, 0, b * per * 8, &pin));
+        memcpy(pin, keys, b * per * 8);
+        MDB_TRY(mdb_scratch(ctx, 4, b * per * 8, &stage));
+        MDB_HIP(ctx, hipMemcpyAsync(stage, pin, b * per * 8, hipMemcpyHostToDevice, ctx->stream));
+        din = (const uint64_t*)stage;
+        MDB_TRY(mdb_scratch(ctx, 2, total * 4, &dids));
+    }
+    MDB_TRY(mdb_scratch(ctx, 5, total * 8, &merged));
+    MDB_TRY(mdb_scratch(ctx, 1, total * 4 + 16, &dist));
+    MDB_TRY(merge_keys(ctx, din, per, b, num_probes, (uint64_t*)merged, nullptr));
+    MDB_TRY(unpack_keys(ctx, (const uint64_t*)merged, total, (uint32_t*)dids, (float*)dist));
+    if (mem == MDB_MEM_DEVICE) return MDB_OK;
+    const HostCopy back[1] = {{probes_out, dids, total * 4}};
+    return mdb_return_to_host(ctx, back, 1);
+}
+
 mdb_status mdb_ivf_search(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
                           mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out) {
     if (!ivf || (!queries && b) || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;

@@ -67,3 +67,42 @@ def sharded_search(local_search, merge, group=None):
         return docs, scores, counts
     gd, gs, gc = all_gather_topk(docs, scores, counts, group)
     return merge(gd, gs, gc)
+
+
+def coarse_range(num_clusters, rank, world):
+    """Centroid range [first, first + count) of `rank` for the sharded coarse search: whole tiles of 64 centroids
+    (`first` is always a multiple of 64; trailing ranks may get an empty range)."""
+    per = ((num_clusters + world - 1) // world + 63) // 64 * 64
+    first = rank * per
+    if first >= num_clusters:
+        return (num_clusters // 64) * 64, 0
+    return first, min(per, num_clusters - first)
+
+
+def gather_coarse_rows(keys, group=None):
+    """This rank's coarse rows [b][P] (int64 bit patterns of the u64 keys) -> every rank's, laid out [b][world][P] (what
+    mdb_ivf_merge_coarse_keys takes)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return keys.view(keys.shape[0], 1, keys.shape[1])
+    world = dist.get_world_size(group)
+    b, p = keys.shape
+    allk = torch.empty((world * b, p), dtype=keys.dtype, device=keys.device)
+    dist.all_gather_into_tensor(allk, keys.contiguous(), group=group)  # rank-major
+    return allk.view(world, b, p).permute(1, 0, 2).contiguous()
+
+
+def sharded_probes(ctx, ivf, q_ptr, b, num_probes, device, group=None):
+    """find_nearest_centroids with the coarse quantizer SHARDED over the ranks (every rank holds all centroids, but scans
+    only its 1/world of them): local (distance, id) keys -> one all-gather of [b][num_probes] u64 per rank -> merge on every
+    rank -> probe ids [b][num_probes] int32 on `device`, identical on all ranks and to the unsharded search."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    first, count = coarse_range(ivf.num_clusters(), rank, world)
+    keys = torch.empty((b, num_probes), dtype=torch.int64, device=device)
+    ctx.check(ctx.lib.mdb_ivf_coarse_keys(ivf.h, C.c_void_p(q_ptr), C.c_size_t(b), C.c_size_t(num_probes), C.c_size_t(first),
+                                          C.c_size_t(count), C.c_int(1), C.c_void_p(keys.data_ptr())))
+    keys = gather_coarse_rows(keys, group)  # [b][world][P]
+    probes = torch.empty((b, num_probes), dtype=torch.int32, device=device)
+    ctx.check(ctx.lib.mdb_ivf_merge_coarse_keys(ivf.h, C.c_void_p(keys.data_ptr()), C.c_size_t(b), C.c_size_t(world), C.c_size_t(num_probes),
+                                                C.c_int(1), C.c_void_p(probes.data_ptr())))
+    return probes

@@ -278,6 +278,23 @@ class BlockBasedIvf:
                                                                    L.ptr(out, C.c_uint32)))
         return out[:, :num_probes]
 
+    def coarse_keys(self, queries, num_probes, first, count):
+        """The num_probes nearest among centroids [first, first + count) as (distance, id) u64 keys (sharded coarse search)."""
+        q = L.f32(queries).reshape(-1, self.num_features)
+        out = np.empty((q.shape[0], num_probes), np.uint64)
+        self.ctx.check(self.ctx.lib.mdb_ivf_coarse_keys(self.h, L.ptr(q, C.c_float), C.c_size_t(q.shape[0]), C.c_size_t(num_probes),
+                                                        C.c_size_t(first), C.c_size_t(count), C.c_int(L.MEM_HOST), L.ptr(out, C.c_uint64)))
+        return out
+
+    def merge_coarse_keys(self, keys, num_probes):
+        """keys [b][parts][num_probes] (every shard's coarse_keys row) -> probe ids [b][num_probes]."""
+        k = np.ascontiguousarray(keys, np.uint64)
+        b, parts = k.shape[0], k.shape[1]
+        out = np.empty((b, num_probes), np.uint32)
+        self.ctx.check(self.ctx.lib.mdb_ivf_merge_coarse_keys(self.h, L.ptr(k, C.c_uint64), C.c_size_t(b), C.c_size_t(parts),
+                                                              C.c_size_t(num_probes), C.c_int(L.MEM_HOST), L.ptr(out, C.c_uint32)))
+        return out
+
     def search(self, queries, k, num_probes):
         """BlockBasedIvf::search (index.rs:396-413)."""
         return self._search(queries, k, None, num_probes)

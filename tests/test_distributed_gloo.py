@@ -76,6 +76,28 @@ def _worker(rank, world, port, out):
         ok &= int(counts[qi]) == n
         ok &= [(int(got[qi, j, 1]) << 64) | int(got[qi, j, 0]) for j in range(n)] == ref.doc_ids(qi)
         ok &= np.array_equal(scores[qi, :n].numpy(), ref.scores[qi, :n])
+    # sharded coarse search: every rank ranks its centroid range, rows are gathered [b][world][P] and merged by key
+    cent = rng.standard_normal((200, 16)).astype(np.float32) * 8
+    cent[150] = cent[3]                                      # a tie across two ranks' ranges: the lower index wins
+    qs = (cent[rng.integers(0, 200, 9)] + rng.normal(0, 1, (9, 16))).astype(np.float32)
+    qs[0] = cent[3]
+    Pc = 6
+
+    def key_rows(first, count):
+        rows = np.full((len(qs), Pc), -1, np.int64)          # all ones == UINT64_MAX padding
+        for i, qq in enumerate(qs):
+            ks = sorted(((int(np.float32(oracle.l2(qq, cent[c])).view(np.uint32)) | 0x80000000) << 32) | c for c in range(first, first + count))
+            for j, kk in enumerate(ks[:Pc]):
+                rows[i, j] = np.uint64(kk).astype(np.int64)
+        return rows
+
+    first, count = D.coarse_range(200, rank, world)
+    gathered = D.gather_coarse_rows(torch.from_numpy(key_rows(first, count))).numpy().view(np.uint64)   # [b][world][P]
+    ok &= gathered.shape == (len(qs), world, Pc)
+    merged = np.sort(gathered.reshape(len(qs), -1), axis=1)[:, :Pc]
+    want = key_rows(0, 200).view(np.uint64)
+    ok &= np.array_equal(merged, want)
+    ok &= int(want[0, 0] & np.uint64(0xFFFFFFFF)) == 3 and int(want[0, 1] & np.uint64(0xFFFFFFFF)) == 150
     lo, hi = D.split_batch(10, rank, world)
     ok &= (lo, hi) == (rank * 5, rank * 5 + 5)
     t = torch.tensor([1.0 if ok else 0.0])
@@ -101,6 +123,14 @@ def test_sharded_ivf_gather_merge_world2():
 
 def test_shard_assignment_covers_every_list_once():
     for world in (1, 2, 3, 8):
+        for L in (1, 40, 64, 65, 300, 4096, 65536, 65600):   # coarse ranges: whole tiles, contiguous, covering
+            rs = [D.coarse_range(L, r, world) for r in range(world)]
+            assert sum(c for _, c in rs) == L and all(f % 64 == 0 and f <= L and c <= L - f for f, c in rs)
+            pos = 0
+            for f, c in rs:
+                if c:
+                    assert f == pos
+                    pos += c
         owners = [D.shard_of_list(l, world) for l in range(100)]
         assert set(owners) == set(range(min(world, 100)))
         assert all(0 <= o < world for o in owners)

@@ -439,6 +439,38 @@ def test_ivf_large_coarse_quantizer_batched_path(ctx, oracle):
     assert_result_rows(g.search(q[:9], 3, 1), o.search(q[:9], 3, num_probes=1), 9)
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_ivf_sharded_coarse_search_equals_unsharded(ctx, oracle, world):
+    """Multi-GPU IVF shards the coarse quantizer too (muopdb_amd.distributed.sharded_probes): every rank scans its
+    centroid range (mdb_ivf_coarse_keys), the (distance, id) rows are all-gathered and merged
+    (mdb_ivf_merge_coarse_keys).  Simulated on one GPU: the merged probe ids equal find_nearest_centroids'."""
+    from muopdb_amd.distributed import coarse_range
+    o, g, q, v, doc_ids = _ivf_case(oracle, ctx, 6000, 20, 300, seed=91)
+    P = 12
+    want = o.find_nearest_centroids(q, P)
+    assert np.array_equal(g.find_nearest_centroids(q, P), want)
+    rows = []
+    for r in range(world):
+        first, count = coarse_range(300, r, world)
+        rows.append(g.coarse_keys(q, P, first, count))
+        ids = (rows[-1] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        valid = rows[-1] != np.uint64(0xFFFFFFFFFFFFFFFF)
+        assert np.all((ids[valid] >= first) & (ids[valid] < first + count)) and np.all(valid.sum(1) == min(P, count))
+        assert np.all(rows[-1][:, :-1] <= rows[-1][:, 1:])
+    keys = np.stack(rows, axis=1)                    # [b][world][P], what the all-gather + permute produces
+    assert np.array_equal(g.merge_coarse_keys(keys, P), want)
+    probes = g.merge_coarse_keys(keys, P)
+    assert_result_rows(g.search_with_centroids_and_remap(q, probes, 10), o.search(q, 10, num_probes=P), len(q))
+    if world == 1:  # the torch-side helper itself (no process group: one rank), device buffers
+        import torch
+        from muopdb_amd import distributed as D
+        qd = torch.from_numpy(q).cuda()
+        torch.cuda.synchronize()
+        pr = D.sharded_probes(ctx, g, qd.data_ptr(), len(q), P, qd.device)
+        ctx.stats()  # synchronises the context's stream
+        assert np.array_equal(pr.cpu().numpy().astype(np.uint32), want)
+
+
 def test_ivf_duplicates_tombstones_and_errors(ctx, oracle):
     from muopdb_amd import lib as L
     o, g, q, v, doc_ids = _ivf_case(oracle, ctx, 1200, 16, 6, seed=5, cpv=2)
