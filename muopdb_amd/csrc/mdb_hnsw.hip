@@ -396,6 +396,8 @@ __device__ void hnsw_general_traverse(const HnswArgs& a, const int qi, char* lds
                     unsigned long long surv = __ballot(have && (!full || od < fmax_o));
                     unsigned long long accepted = 0;
                     const int wsize0 = wsize;
+                    // fill phase of a layer: with this chunk W still holds at most ef elements — every count below is < ef
+                    if (wsize0 + (int)min(nnew - c0, 64u) <= ef) { accepted = surv; surv = 0; }
                     while (surv) {
                         const int sidx = __ffsll((long long)surv) - 1;
                         surv &= surv - 1;
