@@ -113,3 +113,16 @@ def test_hdf5_like(n_per=1000, n_clusters=10, d=128, seed=42):
     data = np.vstack(parts)
     np.random.shuffle(data)
     return data.astype(np.float32)
+
+
+def golden_rows(g, prefix=""):
+    """(doc ids per query, score bits per query) of a tests/golden/*.npz result block written by scripts/make_index_fixtures.py"""
+    lo, hi, sb, cnt = g[prefix + "lo"], g[prefix + "hi"], g[prefix + "score_bits"], g[prefix + "counts"]
+    docs = [[(int(hi[i, j]) << 64) | int(lo[i, j]) for j in range(int(cnt[i]))] for i in range(len(cnt))]
+    bits = [[int(x) for x in sb[i, :int(cnt[i])]] for i in range(len(cnt))]
+    return docs, bits
+
+
+def result_rows(res, b):
+    return ([res.doc_ids(i) for i in range(b)],
+            [[int(x) for x in np.asarray(res.scores[i, :int(res.counts[i])], np.float32).view(np.uint32)] for i in range(b)])

@@ -552,3 +552,37 @@ def test_handles_outlive_context_close(oracle):
     assert np.array_equal(f.search(q, 5)[0], want)
     c.h = None
     f.close()                          # last reference: destroys the context
+
+
+def test_golden_index_fixtures_through_the_hip_path(ctx):
+    """The committed fixtures (tests/golden/*.npz: index files + queries + expected doc ids / score bits / traversal
+    counters, scripts/make_index_fixtures.py) through the C ABI — no oracle in the loop."""
+    import os
+    from muopdb_amd.index import BlockBasedHnsw, BlockBasedIvf, MultiSpannIndex, ProductQuantizer, SearchParams
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(gold, "hnsw_small.npz"))
+    h = BlockBasedHnsw(ctx, g["index"].tobytes(), g["vectors"].tobytes(), int(g["dimension"]))
+    for ef in (40, 600):   # 40: beam kernel; 600 >= 500 points: closure kernel
+        r = h.ann_search(g["queries"], int(g["k"]), ef)
+        st = ctx.stats()
+        assert H.result_rows(r, len(g["queries"])) == H.golden_rows(g, "ef%d_" % ef)
+        assert [st["distance_evals"], st["expanded_nodes"]] == [int(x) for x in g["ef%d_counters" % ef]]
+    g = np.load(os.path.join(gold, "ivfpq_small.npz"))
+    ivf = BlockBasedIvf(ctx, g["index"].tobytes(), g["vectors"].tobytes(), ProductQuantizer(32, 8, 5, g["codebook"]))
+    q, k, P = g["queries"], int(g["k"]), int(g["nprobe"])
+    assert np.array_equal(ivf.find_nearest_centroids(q, P), g["probes"])
+    assert H.result_rows(ivf.search(q, k, P), len(q)) == H.golden_rows(g, "a_")
+    for lo, hi in zip(g["dead_lo"], g["dead_hi"]):
+        assert ivf.invalidate((int(hi) << 64) | int(lo))
+    assert H.result_rows(ivf.search(q, k, P), len(q)) == H.golden_rows(g, "b_")
+    g = np.load(os.path.join(gold, "mspann_small.npz"))
+    ms = MultiSpannIndex(ctx, g["user_table"].tobytes(), 8, g["hnsw_index"].tobytes(), g["hnsw_vectors"].tobytes(),
+                         g["ivf_index"].tobytes(), g["ivf_vectors"].tobytes())
+    p = SearchParams(5, 50).with_num_explored_centroids(4).with_centroid_distance_ratio(0.3)
+    r = ms.search_for_user([int(u) for u in g["user_ids"]], g["queries"], p)
+    assert [bool(f) for f in r.found] == [bool(f) for f in g["found"]]
+    docs, bits = H.golden_rows(g)
+    for i, f in enumerate(g["found"]):
+        if f:
+            assert r.doc_ids(i) == docs[i]
+            assert [int(x) for x in np.asarray(r.scores[i, :len(docs[i])], np.float32).view(np.uint32)] == bits[i]

@@ -430,3 +430,37 @@ def test_c1_golden_fixture(oracle):
     assert np.array_equal(base[:256], g["base_head"])          # the regenerated base is the stored array
     ids, dist = oracle.flat_topk(0, base, g["queries"], 10)
     assert np.array_equal(ids, g["ids"]) and np.array_equal(dist.view(np.uint32), g["dist"].view(np.uint32))
+
+
+def test_golden_index_fixtures(oracle):
+    """tests/golden/{hnsw_small,ivfpq_small,mspann_small}.npz (scripts/make_index_fixtures.py): index files in the reference's
+    formats + seeded queries + the answers the oracle gave when they were committed — a regression pin of the restatement
+    (doc ids, score BITS, HNSW traversal counters)."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(gold, "hnsw_small.npz"))
+    o = oracle.BlockBasedHnsw(g["index"].tobytes(), g["vectors"].tobytes(), int(g["dimension"]))
+    for ef in (40, 600):
+        o.stats()
+        r = o.ann_search(g["queries"], int(g["k"]), ef)
+        assert H.result_rows(r, len(g["queries"])) == H.golden_rows(g, "ef%d_" % ef)
+        assert list(o.stats()) == [int(x) for x in g["ef%d_counters" % ef]]
+    g = np.load(os.path.join(gold, "ivfpq_small.npz"))
+    o = oracle.BlockBasedIvf(g["index"].tobytes(), g["vectors"].tobytes(), oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 5, g["codebook"]))
+    q, k, P = g["queries"], int(g["k"]), int(g["nprobe"])
+    assert np.array_equal(o.find_nearest_centroids(q, P), g["probes"])
+    assert H.result_rows(o.search(q, k, num_probes=P), len(q)) == H.golden_rows(g, "a_")
+    for lo, hi in zip(g["dead_lo"], g["dead_hi"]):
+        assert o.invalidate((int(hi) << 64) | int(lo))
+    assert H.result_rows(o.search(q, k, num_probes=P), len(q)) == H.golden_rows(g, "b_")
+    g = np.load(os.path.join(gold, "mspann_small.npz"))
+    o = oracle.MultiSpannIndex(g["user_table"].tobytes(), 8, g["hnsw_index"].tobytes(), g["hnsw_vectors"].tobytes(),
+                               g["ivf_index"].tobytes(), g["ivf_vectors"].tobytes())
+    p = oracle.SearchParams(5, 50, num_explored_centroids=4, centroid_distance_ratio=0.3)
+    r = o.search_for_user([int(u) for u in g["user_ids"]], g["queries"], p)
+    assert [bool(f) for f in r.found] == [bool(f) for f in g["found"]]
+    docs, bits = H.golden_rows(g)
+    for i, f in enumerate(g["found"]):
+        if f:
+            assert r.doc_ids(i) == docs[i]
+            assert [int(x) for x in np.asarray(r.scores[i, :len(docs[i])], np.float32).view(np.uint32)] == bits[i]
