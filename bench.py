@@ -4,19 +4,30 @@
     python bench.py --gpus N --steps K --warmup W            (N=1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Default workload = BASELINE.json configs[1]: SIFT-1M-like 1M x 128 f32 (synthetic, BASELINE.md
-C2), HNSW ef=200, top-10, batch=64, through the C ABI (libmuopdb_hip.so) with queries and
-outputs resident in HBM.  A "step" is one batch of 64 queries through BlockBasedHnsw::ann_search.
-N>1: HNSW does not shard (replicas only) — every rank holds the graph and runs
-its own batches, so per-GPU work is fixed ("weak") and value = all ranks' queries / max time.
+Headline (`value`, `ms_per_step`, `roofline`, `cpu_baseline` at the top level of the ONE JSON line) =
+BASELINE.json configs[1]: SIFT-1M-like 1M x 128 f32 (synthetic), HNSW ef=200, top-10, batch=64,
+through the C ABI (libmuopdb_hip.so) with queries and outputs resident in HBM.  A "step" is one batch of 64 queries
+through BlockBasedHnsw::ann_search.  N>1: HNSW does not shard (SURVEY.md §8e: replicas only) — every rank holds the
+graph and runs its own batches, so per-GPU work is fixed ("weak") and value = all ranks' queries / max time.
 
-Other workloads (--workload flat | ivfpq | spann) time the other §8 rows the same way; only the
-default one is the headline.
+The same run also times the other north-star workloads and reports them under `workloads` (each entry with its own
+value / ms_per_step / recall_at_10 / roofline / cpu_baseline, every one bracketed by the same barrier +
+synchronize and max-over-ranks rule):
+    flat_1m_b1, flat_1m_b64   brute-force L2 over the same 1M x 128 base (batch 1: HBM stream; batch 64: MFMA filter)
+    ivfpq_c3                  IVF nlist=4096 + PQ m=16 nbits=8 (the reference's symmetric distance), batch 256,
+                              nprobe sweep {1, 8, 16, 32, 64} as (recall@10, QPS) pairs
+    spann_c4_128u             multi-user SPANN, 128 users x 9766 x 768 (C4's shape at 1/8 of its users; the full
+                              1024 users: --workload spann --users 1024), num_explored_centroids / ratio sweep
+For N>1 the list-sharded workloads (ivfpq, spann) run with posting lists sharded over the ranks and ONE packed RCCL
+all-gather of the per-shard top-k per batch ("strong": the same batch on every rank).
+`--workload hnsw|flat|ivfpq|spann|c5` runs a single workload as the line (profiling, other sizes).
 
-One JSON line on rank 0 with `roofline` (dominant kernel: algorithmic bytes / HIP-event kernel
-time vs 8 TB/s HBM) and `cpu_baseline` (the CPU oracle timed on this box's host cores).
+`roofline.achieved` = algorithmic bytes per launch (SURVEY.md §8d per-unit bytes x units) / the dominant
+kernel's mean duration from HIP events recorded on the launch stream inside the library (mdb_set_profiling).
+`cpu_baseline` = the CPU oracle (oracle/, a port of the reference's algorithm) timed on this box's host cores.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -52,15 +63,16 @@ def measured_traffic(kind, cfg):
     return None, None
 
 
-def dump(args, rank, **files):
+def dump(args, rank, sub, **files):
     """--dump-dir: the workload's files for examples/replay_search.cpp (torch-free PMC passes)."""
     if not args.dump_dir or rank != 0:
         return
-    os.makedirs(args.dump_dir, exist_ok=True)
+    d = os.path.join(args.dump_dir, sub)
+    os.makedirs(d, exist_ok=True)
     for name, data in files.items():
-        with open(os.path.join(args.dump_dir, name), "wb") as f:
+        with open(os.path.join(d, name), "wb") as f:
             f.write(data if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data).tobytes())
-    log("dumped %s to %s" % (", ".join(files), args.dump_dir))
+    log("dumped %s to %s" % (", ".join(files), d))
 
 
 def log(*a):
@@ -73,26 +85,32 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="hnsw", choices=["hnsw", "flat", "ivfpq", "spann"])
+    p.add_argument("--workload", default="all", choices=["all", "hnsw", "flat", "ivfpq", "spann", "c5"])
+    p.add_argument("--data", default="lowrank", choices=["lowrank", "legacy"],
+                   help="lowrank: muopdb_amd.build.SiftLike / EmbedLike; legacy: round 1's isotropic Gaussian generators")
     p.add_argument("--n", type=int, default=None, help="base vectors (default: the config's size)")
     p.add_argument("--dim", type=int, default=None)
     p.add_argument("--batch", type=int, default=None)
     p.add_argument("--ef", type=int, default=200)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--nprobe", type=int, default=16)
+    p.add_argument("--nprobe", type=int, default=None)
+    p.add_argument("--ratio", type=float, default=None, help="spann: centroid_distance_ratio of the primary setting")
     p.add_argument("--nlist", type=int, default=None, help="ivfpq: number of posting lists (default min(4096, n/244))")
     p.add_argument("--users", type=int, default=128, help="spann workload: number of users (1024 = full C4)")
     p.add_argument("--max-neighbors", type=int, default=32)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-sweep", action="store_true")
     p.add_argument("--streams", type=int, default=4, help="hnsw: extra measurement with this many batches in flight (0/1 = skip)")
     p.add_argument("--dump-dir", default=None, help="write index files + queries for examples/replay_search.cpp")
-    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--cpu-seconds", type=float, default=10.0)
     return p.parse_args()
 
 
-class Timer:
-    def __init__(self, world):
-        self.world = world
+class Env:
+    def __init__(self, args, ctx, rank, world):
+        self.args, self.ctx, self.rank, self.world = args, ctx, rank, world
+        self.cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+        self._sift = None
 
     def barrier(self):
         if self.world > 1:
@@ -106,6 +124,43 @@ class Timer:
             return float(t.item())
         return seconds
 
+    def timed(self, step, steps, warm, profiling=True):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.
+        Returns (seconds, dominant-kernel ms summed, launches)."""
+        for i in range(warm):
+            step(i)
+        self.ctx.sync()
+        self.ctx.set_profiling(profiling)
+        self.ctx.get_profile()
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(warm, warm + steps):
+            step(i)
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms, launches = self.ctx.get_profile()
+        self.ctx.set_profiling(False)
+        return self.max_over_ranks(elapsed), kernel_ms, launches
+
+    def sift(self, n, d, nq, qseed):
+        """(base rows, queries, description) of the C2/C3 synthetic SIFT-1M; the base is cached across workloads."""
+        from muopdb_amd import build as B
+        if self.args.data == "legacy":
+            ncl = max(1, min(4096, n // 244))
+            if self._sift is None or self._sift[0] != (n, d):
+                self._sift = ((n, d), B.gaussian_clusters(n, d, n_clusters=ncl, seed=1))
+            g = torch.Generator(device="cpu"); g.manual_seed(1)
+            centers = (torch.rand((ncl, d), generator=g) * 218.0).cuda()
+            gq = torch.Generator(device="cpu"); gq.manual_seed(qseed)
+            qa = torch.randint(0, ncl, (nq,), generator=gq).cuda()
+            q = torch.clamp(torch.round(centers[qa] + (torch.randn((nq, d), generator=gq) * 20.0).cuda()), 0, 218).contiguous()
+            return self._sift[1], q, "%d isotropic Gaussian clusters, sigma 20, clipped [0,218] (round-1 generator)" % ncl
+        gen = B.SiftLike(d, seed=1)
+        if self._sift is None or self._sift[0] != (n, d):
+            self._sift = ((n, d), gen.draw(n, seed=11))
+        return self._sift[1], gen.draw(nq, seed=qseed).contiguous(), \
+            "block low-rank (32 latent dims) + noise, clipped [0,218], rounded: muopdb_amd.build.SiftLike"
+
 
 def recall_at_k(found_lo, gt_idx, k):
     hits = 0
@@ -114,24 +169,20 @@ def recall_at_k(found_lo, gt_idx, k):
     return hits / (len(gt_idx) * k)
 
 
-# ------------------------------------------------------------------------------------------ workloads
-def sift_base_and_queries(n, d, nq, rank):
-    """BASELINE.md C2/C3 synthetic SIFT-1M: base rows (seed 1) and queries drawn from the same
-    cluster centres (seed 1000 + rank)."""
-    from muopdb_amd import build as B
-    ncl = max(1, min(4096, n // 244))
-    x = B.sift_like(n, d, n_clusters=ncl, seed=1)
-    g = torch.Generator(device="cpu"); g.manual_seed(1)
-    centers = (torch.rand((ncl, d), generator=g) * 218.0).cuda()  # first draw of sift_like(seed=1)
-    gq = torch.Generator(device="cpu"); gq.manual_seed(1000 + rank)
-    qa = torch.randint(0, ncl, (nq,), generator=gq).cuda()
-    q = torch.clamp(torch.round(centers[qa] + (torch.randn((nq, d), generator=gq) * 20.0).cuda()), 0, 218).contiguous()
-    return x, q
+def hbm_roofline(kernel, abytes_per_launch, kernel_ms, launches, **extra):
+    ms = kernel_ms / max(launches, 1)
+    ach = abytes_per_launch / (ms * 1e-3) / 1e9 if launches else None
+    r = dict(bound="hbm", kernel=kernel, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS if ach else None,
+             traffic=None, bytes_per_launch=abytes_per_launch, kernel_ms=ms)
+    r.update(extra)
+    return r
 
 
-def run_hnsw(args, ctx, rank, world, timer):
+# ------------------------------------------------------------------------------------------ HNSW (headline)
+def run_hnsw(env):
     from muopdb_amd import build as B
     from muopdb_amd.index import BlockBasedHnsw
+    args, ctx, rank, world = env.args, env.ctx, env.rank, env.world
     n = args.n or 1_000_000
     d = args.dim or 128
     batch = args.batch or 64
@@ -139,7 +190,7 @@ def run_hnsw(args, ctx, rank, world, timer):
     steps, warm = args.steps, args.warmup
     t0 = time.time()
     nq = (steps + warm) * batch
-    x, queries = sift_base_and_queries(n, d, nq, rank)
+    x, queries, desc = env.sift(n, d, nq, 1000 + rank)
     log("data %.1fs" % (time.time() - t0))
     t0 = time.time()
     index_bytes, vec_bytes = B.hnsw_files(x, max_neighbors=args.max_neighbors, max_layers=8, kcand=2 * args.max_neighbors, seed=1)
@@ -147,7 +198,7 @@ def run_hnsw(args, ctx, rank, world, timer):
     t0 = time.time()
     hnsw = BlockBasedHnsw(ctx, index_bytes, vec_bytes, d)
     log("load %.1fs" % (time.time() - t0))
-    dump(args, rank, index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy()})
+    dump(args, rank, "hnsw", index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy()})
     ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
     sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
     cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
@@ -158,20 +209,7 @@ def run_hnsw(args, ctx, rank, world, timer):
         if keep is not None:
             keep.append(ids[:, :, 0].clone())
 
-    for i in range(warm):
-        step(i)
-    ctx.sync()
-    ctx.set_profiling(True)
-    ctx.get_profile()
-    timer.barrier()
-    t0 = time.perf_counter()
-    for i in range(warm, warm + steps):
-        step(i)
-    timer.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = ctx.get_profile()
-    ctx.set_profiling(False)
-    elapsed = timer.max_over_ranks(elapsed)
+    elapsed, kernel_ms, launches = env.timed(step, steps, warm)
     # untimed re-run of the timed batches: results for recall + exact traversal counters per launch
     found, evals, expanded, abytes = [], 0, 0, 0
     for i in range(warm, warm + steps):
@@ -184,16 +222,13 @@ def run_hnsw(args, ctx, rank, world, timer):
     rec = recall_at_k(found, gt.cpu().numpy(), k)
     out = dict(
         value=world * steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec,
-        config={"workload": "SIFT-1M-like synthetic %dx%d f32 (4096 Gaussian clusters, sigma 20, clipped [0,218]); HNSW "
-                            "max_neighbors=%d ef=%d top-%d batch=%d per GPU; replicas" % (n, d, args.max_neighbors, ef, k, batch),
-                "n": n, "dim": d, "batch": batch, "ef": ef, "k": k, "index": "hnsw", "parallelism": "replica x%d" % world},
-        roofline=dict(bound="hbm", kernel="hnsw_beam_kernel" if ef <= 256 else "hnsw_search_kernel",
-                      achieved=(abytes / steps) / (kernel_ms / launches * 1e-3) / 1e9 if launches else None,
-                      peak=HBM_PEAK_GBS, unit="GB/s", traffic=None,
-                      bytes_per_launch=abytes / steps, kernel_ms=kernel_ms / max(launches, 1),
-                      evals_per_query=evals / (steps * batch), expanded_per_query=expanded / (steps * batch)),
+        config={"workload": "SIFT-1M-like synthetic %dx%d f32 (%s); HNSW max_neighbors=%d ef=%d top-%d batch=%d per GPU; replicas"
+                            % (n, d, desc, args.max_neighbors, ef, k, batch),
+                "n": n, "dim": d, "batch": batch, "ef": ef, "k": k, "index": "hnsw", "data": args.data,
+                "parallelism": "replica x%d" % world},
+        roofline=hbm_roofline("hnsw_beam_kernel" if ef <= 256 else "hnsw_search_kernel", abytes / steps, kernel_ms, launches,
+                              evals_per_query=evals / (steps * batch), expanded_per_query=expanded / (steps * batch)),
     )
-    out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS if out["roofline"]["achieved"] else None
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("hnsw", out["config"])
     if args.streams > 1:
         # Extra, NOT the headline: the same K batches issued round-robin on several HIP streams (one context +
@@ -215,12 +250,12 @@ def run_hnsw(args, ctx, rank, world, timer):
 
         for i in range(warm):
             cstep(i)
-        timer.barrier()
+        env.barrier()
         t0 = time.perf_counter()
         for i in range(warm, warm + steps):
             cstep(i)
-        timer.barrier()
-        el = timer.max_over_ranks(time.perf_counter() - t0)
+        env.barrier()
+        el = env.max_over_ranks(time.perf_counter() - t0)
         same = True
         for j, i in enumerate(range(warm + steps - len(lanes), warm + steps)):  # last batch of every lane vs the serial run
             same &= bool(torch.equal(lanes[i % len(lanes)][3][:, :, 0].cpu(), torch.from_numpy(found[(i - warm) * batch:(i - warm + 1) * batch])))
@@ -229,7 +264,7 @@ def run_hnsw(args, ctx, rank, world, timer):
                                       "(GPU_MAX_HW_QUEUES=%s); not the headline value" % os.environ.get("GPU_MAX_HW_QUEUES"))
         for lane_ in lanes:
             lane_[2].close(); lane_[1].close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if env.cpu:
         import oracle
         o = oracle.BlockBasedHnsw(index_bytes, vec_bytes, d)
         qh = tq.cpu().numpy()
@@ -244,23 +279,28 @@ def run_hnsw(args, ctx, rank, world, timer):
                                    sample="%d of the timed queries, one thread (the reference runs one query per task, "
                                           "no intra-query parallelism); index fully memory-resident" % ns,
                                    all_cores_value=na / dta, all_cores=nt, ids_match_gpu=bool(ok))
+    hnsw.close()
     return out
 
 
-def run_flat(args, ctx, rank, world, timer):
-    """BASELINE config C1 by default (10k x 128, batch 1): py/create_test_hdf5.py-shaped data."""
+# ------------------------------------------------------------------------------------------ flat
+def run_flat(env, n=None, batch=None):
+    """flat brute-force L2: the C2/C3 1M base (default inside --workload all) or BASELINE config C1 (10k x 128, batch 1,
+    py/create_test_hdf5.py-shaped data) with --workload flat."""
     from muopdb_amd import build as B
     from muopdb_amd.index import FlatIndex
-    n = args.n or 10_000
+    args, ctx, rank, world = env.args, env.ctx, env.rank, env.world
+    n = n or args.n or 10_000
     d = args.dim or 128
-    batch = args.batch or 1
+    batch = batch or args.batch or 1
     k = args.k
     steps, warm = args.steps, args.warmup
     nq = (steps + warm) * batch
     if n >= 100_000:  # "flat SIFT-1M" of the north star: the C2/C3 synthetic SIFT-like base
-        x, queries = sift_base_and_queries(n, d, nq, rank)
+        x, queries, desc = env.sift(n, d, nq, 2000 + rank)
         x = x.contiguous()
     else:             # C1: py/create_test_hdf5.py-shaped data
+        desc = "create_test_hdf5-like: 10 clusters, centre i*100, N(0, 5^2)"
         g = torch.Generator(device="cpu"); g.manual_seed(42)
         lab = torch.arange(n) % 10
         x = (lab[:, None].float() * 100.0 + torch.randn((n, d), generator=g) * 5.0)
@@ -272,87 +312,58 @@ def run_flat(args, ctx, rank, world, timer):
     idx = FlatIndex(ctx, None, device_ptr=x[lo:hi].data_ptr(), n=hi - lo, d=d)
     if args.dump_dir:
         from muopdb_amd import formats as F
-        dump(args, rank, vectors=F.write_vector_file(x.cpu().numpy()), **{"queries.f32": queries.cpu().numpy()})
+        dump(args, rank, "flat_b%d" % batch, vectors=F.write_vector_file(x.cpu().numpy()), **{"queries.f32": queries.cpu().numpy()})
     ids = torch.zeros((batch, k), dtype=torch.int32, device="cuda")
     ds = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
 
     def step(i):
         idx.search_device(queries[i * batch:(i + 1) * batch].data_ptr(), batch, k, ids.data_ptr(), ds.data_ptr())
 
-    for i in range(warm):
-        step(i)
-    ctx.sync(); ctx.set_profiling(True); ctx.get_profile()
-    timer.barrier()
-    t0 = time.perf_counter()
-    for i in range(warm, warm + steps):
-        step(i)
-    timer.barrier()
-    elapsed = timer.max_over_ranks(time.perf_counter() - t0)
-    kernel_ms, launches = ctx.get_profile(); ctx.set_profiling(False)
+    elapsed, kernel_ms, launches = env.timed(step, steps, warm)
     abytes = (hi - lo) * d * 4 + batch * d * 4 + batch * k * 8
-    ach = abytes / (kernel_ms / launches * 1e-3) / 1e9
     # recall@k of the last timed batch against the f64 brute force (untimed re-run of that batch)
-    from muopdb_amd import build as B
     last = warm + steps - 1
     step(last)
     gt, _ = B.exact_knn(x[lo:hi], k, queries=queries[last * batch:(last + 1) * batch], f64=True)
     rec = recall_at_k(ids.cpu().numpy().astype(np.int64), gt.cpu().numpy(), k)
     batched = batch >= 8 and (hi - lo) >= 65536  # mdb_flat_mfma.hip: sample bound + MFMA filter + exact refine
     out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec,
-               config={"workload": "flat brute-force L2 %dx%d f32 (%s), batch=%d, top-%d (row-sharded x%d)"
-                                   % (n, d, "SIFT-1M-like synthetic" if n >= 100_000 else "create_test_hdf5-like", batch, k, world),
-                       "n": n, "dim": d, "batch": batch, "k": k, "index": "flat"},
-               roofline=dict(bound="hbm", kernel="flat_mfma_filter_kernel" if batched else "flat_scan_kernel", achieved=ach,
-                             peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes,
-                             kernel_ms=kernel_ms / launches))
+               config={"workload": "flat brute-force L2 %dx%d f32 (%s), batch=%d, top-%d (row-sharded x%d)" % (n, d, desc, batch, k, world),
+                       "n": n, "dim": d, "batch": batch, "k": k, "index": "flat", "data": args.data},
+               roofline=hbm_roofline("flat_mfma_filter_kernel" if batched else "flat_scan_kernel", abytes, kernel_ms, launches))
     if batched:  # the filter is also on the f32-MFMA ridge: 2*B*N*d flop per launch against 157.3 TFLOP/s
         groups = (batch + 63) // 64
-        out["roofline"]["bytes_per_launch"] = abytes * groups  # one pass over the base per 64 queries
-        out["roofline"]["achieved"] = ach * groups
-        out["roofline"]["frac"] = ach * groups / HBM_PEAK_GBS
-        out["roofline"]["mfma_tflops"] = 2.0 * batch * (hi - lo) * d / (kernel_ms / launches * 1e-3) / 1e12
-        out["roofline"]["mfma_frac_of_f32_peak"] = out["roofline"]["mfma_tflops"] / 157.3
+        r = out["roofline"]
+        r["bytes_per_launch"] = abytes * groups  # one pass over the base per 64 queries
+        r["achieved"] *= groups
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        r["mfma_tflops"] = 2.0 * batch * (hi - lo) * d / (r["kernel_ms"] * 1e-3) / 1e12
+        r["mfma_frac_of_f32_peak"] = r["mfma_tflops"] / 157.3
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("flat_b64" if batched else "flat", out["config"])
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if env.cpu:
         import oracle
         xb, qh = x.cpu().numpy(), queries[warm * batch:].cpu().numpy()
         t0 = time.perf_counter(); oracle.flat_topk(0, xb, qh[:4], k); dt = time.perf_counter() - t0
         ns = int(min(len(qh), max(4, args.cpu_seconds / (dt / 4))))
         t0 = time.perf_counter(); oracle.flat_topk(0, xb, qh[:ns], k); dt1 = time.perf_counter() - t0
         out["cpu_baseline"] = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port", sample="%d queries, one thread" % ns)
+    idx.close()
     return out
 
 
-def run_ivfpq(args, ctx, rank, world, timer):
-    """BASELINE config C3: SIFT-1M-like, IVF nlist=4096 + PQ m=16 (subdim 8) nbits=8, batch 256."""
-    from muopdb_amd import build as B, formats as F
-    from muopdb_amd.index import BlockBasedIvf, ProductQuantizer
-    n = args.n or 1_000_000
-    d = args.dim or 128
-    batch = args.batch or 256
-    k, P = args.k, args.nprobe
-    steps, warm = args.steps, args.warmup
-    nlist = args.nlist or max(1, min(4096, n // 244))
-    nq = (steps + warm) * batch
-    x, queries = sift_base_and_queries(n, d, nq, 0)  # lists are sharded: every rank sees the SAME batch
-    t0 = time.time()
-    cent = B.kmeans(x, nlist, iters=6, seed=3, sample=min(n, 400_000))
-    assign = B.assign_nearest(x, cent)
-    cb = B.train_pq_codebook(x, 8, 8, iters=6, seed=4, sample=100_000)
-    pq = ProductQuantizer(d, 8, 8, cb)
-    codes = pq.quantize(ctx, x.cpu().numpy())
-    pls = B.posting_lists_from_assignment(assign, nlist)
-    index_bytes = F.write_ivf_index(cent.cpu().numpy(), np.arange(n, dtype=np.uint64), pls, quantized_dimension=d // 8)
-    vec_bytes = F.write_vector_file(codes)
-    log("ivf-pq build %.1fs" % (time.time() - t0))
-    ivf = BlockBasedIvf(ctx, index_bytes, vec_bytes, pq, shard_rank=rank, shard_world=world)
-    dump(args, rank, index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy(), "codebook.f32": cb})
-    import ctypes as C
+# ------------------------------------------------------------------------------------------ IVF-PQ
+def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=0):
+    """one (nprobe) setting: timed steps + untimed re-run for results / counters"""
     from muopdb_amd import lib as L
     from muopdb_amd import distributed as D
-    ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
-    sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
-    cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    ctx, world = env.ctx, env.world
+    gather = D.PackedTopkGather(ctx, batch, k, "cuda") if world > 1 else None
+    if gather:  # the search writes straight into this rank's block of the all-gather
+        ids, sc, cn = gather.ids, gather.scores, gather.counts
+    else:
+        ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
+        sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
+        cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
 
     def step(i, keep=None):
         q = queries[i * batch:(i + 1) * batch]
@@ -364,53 +375,128 @@ def run_ivfpq(args, ctx, rank, world, timer):
                                          C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()),
                                          C.c_void_p(cn.data_ptr())))
         res = ids
-        if world > 1:  # one RCCL all-gather of the per-shard top-k + device merge
-            gd, gs, gc = D.all_gather_topk(ids, sc, cn)
-            res, _, _ = D.merge_shards_device(ctx, gd, gs, gc)
+        if world > 1:  # ONE packed RCCL all-gather of the per-shard top-k + device merge
+            res, _, _ = gather.gather_merge()
         if keep is not None:
             keep.append(res[:, :, 0].clone())
 
-    for i in range(warm):
-        step(i)
-    ctx.sync(); ctx.set_profiling(True); ctx.get_profile()
-    timer.barrier()
-    t0 = time.perf_counter()
-    for i in range(warm, warm + steps):
-        step(i)
-    timer.barrier()
-    elapsed = timer.max_over_ranks(time.perf_counter() - t0)
-    kernel_ms, launches = ctx.get_profile(); ctx.set_profiling(False)
+    elapsed, kernel_ms, launches = env.timed(step, steps, warm)
     found, scored, abytes = [], 0, 0
     for i in range(warm, warm + steps):
         step(i, found)
         st = ctx.stats(); scored += st["scored_vectors"]; abytes += st["algorithmic_bytes"]
     found = torch.cat(found).cpu().numpy()
+    rec = recall_at_k(found[:nrec], gt, k) if gt is not None else None
+    return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes, recall=rec)
+
+
+def build_ivfpq(env, x, nlist, seed=3):
+    """IVF centroids + PQ codebook + codes + files for device rows x (build side: muopdb_amd.build)"""
+    from muopdb_amd import build as B, formats as F
+    from muopdb_amd.index import ProductQuantizer
+    n, d = x.shape
+    cent = B.kmeans(x, nlist, iters=6, seed=seed, sample=min(n, 400_000))
+    assign = B.assign_nearest(x, cent)
+    cb = B.train_pq_codebook(x, 8, 8, iters=6, seed=seed + 1, sample=100_000)
+    pq = ProductQuantizer(d, 8, 8, cb)
+    codes = pq.quantize(env.ctx, x.cpu().numpy())
+    pls = B.posting_lists_from_assignment(assign, nlist)
+    index_bytes = F.write_ivf_index(cent.cpu().numpy(), np.arange(n, dtype=np.uint64), pls, quantized_dimension=d // 8)
+    return index_bytes, F.write_vector_file(codes), pq, cb
+
+
+def run_ivfpq(env):
+    """BASELINE config C3: SIFT-1M-like, IVF nlist=4096 + PQ m=16 (subdim 8) nbits=8, batch 256; nprobe sweep."""
+    from muopdb_amd import build as B
+    from muopdb_amd.index import BlockBasedIvf
+    args, ctx, rank, world = env.args, env.ctx, env.rank, env.world
+    n = args.n or 1_000_000
+    d = args.dim or 128
+    batch = args.batch or 256
+    k, P = args.k, args.nprobe or 16
+    steps, warm = args.steps, args.warmup
+    nlist = args.nlist or max(1, min(4096, n // 244))
+    nq = (steps + warm) * batch
+    x, queries, desc = env.sift(n, d, nq, 3000)  # lists are sharded: every rank sees the SAME batch
+    t0 = time.time()
+    index_bytes, vec_bytes, pq, cb = build_ivfpq(env, x, nlist)
+    log("ivf-pq build %.1fs" % (time.time() - t0))
+    ivf = BlockBasedIvf(ctx, index_bytes, vec_bytes, pq, shard_rank=rank, shard_world=world)
+    dump(args, rank, "ivfpq", index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy(), "codebook.f32": cb})
     tq = queries[warm * batch:(warm + steps) * batch]
-    nrec = min(len(tq), 12800, max(256, int(1.3e10 // n)))  # f64 ground truth for a bounded number of the timed queries
-    gt, _ = B.exact_knn(x, k, queries=tq[:nrec], f64=True)
-    rec = recall_at_k(found[:nrec], gt.cpu().numpy(), k)
-    ach = (abytes / steps) / (kernel_ms / launches * 1e-3) / 1e9
-    out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec, scaling="strong",
-               config={"workload": "SIFT-1M-like synthetic %dx%d, IVF nlist=%d + PQ m=16 nbits=8 (symmetric distance), nprobe=%d, "
-                                   "batch=%d, top-%d, lists sharded x%d" % (n, d, nlist, P, batch, k, world),
-                       "n": n, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq"},
-               roofline=dict(bound="hbm", kernel="ivf_scan_pq2_kernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes / steps,
-                             kernel_ms=kernel_ms / launches, scored_per_query=scored / (steps * batch)))
+    nrec = min(len(tq), 2560, max(256, int(1.3e10 // n)))  # f64 ground truth for a bounded number of the timed queries
+    gt = B.exact_knn(x, k, queries=tq[:nrec], f64=True)[0].cpu().numpy()
+    m = ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt, nrec)
+    out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=m["recall"], scaling="strong",
+               config={"workload": "SIFT-1M-like synthetic %dx%d (%s), IVF nlist=%d + PQ m=16 nbits=8 (symmetric distance), nprobe=%d, "
+                                   "batch=%d, top-%d, lists sharded x%d" % (n, d, desc, nlist, P, batch, k, world),
+                       "n": n, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": args.data},
+               roofline=hbm_roofline("ivf_scan_pq2_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
+                                     scored_per_query=m["scored"] / (steps * batch)))
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ivfpq", out["config"])
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if not args.no_sweep:
+        sweep = []
+        for p in (1, 8, 16, 32, 64):
+            if p > nlist:
+                continue
+            s = m if p == P else ivfpq_measure(env, ivf, x, queries, batch, k, p, steps, warm, gt, nrec)
+            sweep.append(dict(nprobe=p, recall_at_10=s["recall"], value=steps * batch / s["elapsed"], ms_per_step=1000 * s["elapsed"] / steps,
+                              scan_kernel_ms=s["kernel_ms"] / max(s["launches"], 1), scored_per_query=s["scored"] / (steps * batch)))
+        out["sweep"] = sweep
+    if env.cpu:
         import oracle
         o = oracle.BlockBasedIvf(index_bytes, vec_bytes, oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, cb))
         qh = tq.cpu().numpy()
         t0 = time.perf_counter(); o.search(qh[:32], k, num_probes=P); dt = time.perf_counter() - t0
         ns = int(min(len(qh), max(32, args.cpu_seconds / (dt / 32))))
         t0 = time.perf_counter(); r = o.search(qh[:ns], k, num_probes=P); dt1 = time.perf_counter() - t0
-        ok = all(r.doc_ids(i) == [int(v) for v in found[i][:int(r.counts[i])]] for i in range(min(ns, 256)))
+        ok = all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(ns, 256)))
         out["cpu_baseline"] = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port", sample="%d queries, one thread" % ns,
                                    ids_match_gpu=bool(ok))
+    ivf.close()
     return out
 
-def run_spann(args, ctx, rank, world, timer):
+
+def run_c5(env):
+    """BASELINE config C5 as ONE GPU of the 8 sees it: rank 0's shard (posting lists l % 8 == 0) of a 100M x 128 index
+    stored as 16-byte PQ codes, the FULL coarse quantizer (65 536 centroids, replicated), nprobe 64, batch 4096."""
+    from muopdb_amd import build as B
+    from muopdb_amd.index import BlockBasedIvf
+    args, ctx = env.args, env.ctx
+    batch = args.batch or 4096
+    k, P = args.k, args.nprobe or 64
+    steps, warm = args.steps, args.warmup
+    total = args.n or 100_000_000
+    t0 = time.time()
+    sh = B.c5_shard(ctx, total=total, world=8, rank=0, nlist=args.nlist or 65536, log=log)
+    log("C5 shard build %.1fs: %d vectors in %d owned lists" % (time.time() - t0, sh["n"], sh["owned_lists"]))
+    ivf = BlockBasedIvf(ctx, sh["index"], sh["vectors"], sh["pq"])
+    queries = sh["gen"].draw((steps + warm) * batch, seed=5000).contiguous()
+    m = ivfpq_measure(env, ivf, None, queries, batch, k, P, steps, warm)
+    out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=None, scaling="strong",
+               config={"workload": "C5 per-GPU: rank 0's shard (lists l %% 8 == 0: %d vectors, %d lists) of a %d x 128 SiftLike index as 16-byte PQ "
+                                   "codes, full coarse quantizer nlist=%d, nprobe=%d, batch=%d, top-%d"
+                                   % (sh["n"], sh["owned_lists"], total, sh["nlist"], P, batch, k),
+                       "n": sh["n"], "dim": 128, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": "lowrank"},
+               roofline=hbm_roofline("ivf_scan_pq2_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
+                                     scored_per_query=m["scored"] / (steps * batch)))
+    out["recall_note"] = "a shard's rows are a partial result (1/8 of the probed lists): recall is defined after the all-gather merge only"
+    if env.cpu:
+        import oracle
+        o = oracle.BlockBasedIvf(sh["index"], sh["vectors"], oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, sh["codebook"]))
+        qh = queries[warm * batch:].cpu().numpy()
+        t0 = time.perf_counter(); o.search(qh[:16], k, num_probes=P); dt = time.perf_counter() - t0
+        ns = int(min(len(qh), max(16, args.cpu_seconds / (dt / 16))))
+        t0 = time.perf_counter(); r = o.search(qh[:ns], k, num_probes=P); dt1 = time.perf_counter() - t0
+        ok = all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(ns, 256)))
+        out["cpu_baseline"] = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port", sample="%d queries, one thread" % ns,
+                                   ids_match_gpu=bool(ok))
+    ivf.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------ multi-user SPANN
+def run_spann(env, users=None):
     """BASELINE.md C4 shape: multi-user SPANN over unit-norm f32 rows, one (user, query) pair per user
     per batch, posting lists sharded l % world, one all-gather + merge per batch.  Defaults are a
     1/8 slice (128 users x 9766 x 768 = 3.8 GB); --users 1024 is the full 10M x 768 (30.7 GB)."""
@@ -418,28 +504,34 @@ def run_spann(args, ctx, rank, world, timer):
     from muopdb_amd import formats as F
     from muopdb_amd import distributed as D
     from muopdb_amd.index import MultiSpannIndex, SearchParams
-    import ctypes as C
     from muopdb_amd import lib as L
-    U = args.users
+    args, ctx, rank, world = env.args, env.ctx, env.rank, env.world
+    U = users or args.users
     per = (args.n // U) if args.n else 9766
     d = args.dim or 768
     batch = args.batch or U
-    k, P = args.k, args.nprobe
+    k, P = args.k, args.nprobe or 16
+    ratio = args.ratio if args.ratio is not None else 0.1
     steps, warm = args.steps, args.warmup
     nlist = max(1, per // 64)
     t0 = time.time()
-    users, base = {}, []
+    gen = B.EmbedLike(d, seed=3) if args.data == "lowrank" else None
+    users_, base, ucent = {}, [], []
     for u in range(U):
-        x = B.unit_gaussian(per, d, seed=3_000_000 + u)
+        if gen is not None:
+            ucent.append(gen.user(u))
+            x = gen.draw(ucent[u], per, seed=3_000_000 + u)
+        else:
+            x = B.unit_gaussian(per, d, seed=3_000_000 + u)
         cent = B.kmeans(x, nlist, iters=4, seed=u)
         pls = B.posting_lists_from_assignment(B.assign_nearest(x, cent), cent.shape[0])
         hi, hv = B.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
         docs = np.arange(u * per, (u + 1) * per, dtype=np.uint64)
-        users[u + 1] = dict(hnsw_index=hi, hnsw_vectors=hv, ivf_index=F.write_ivf_index(cent.cpu().numpy(), docs, pls),
-                            ivf_vectors=F.write_vector_file(x.cpu().numpy()))
+        users_[u + 1] = dict(hnsw_index=hi, hnsw_vectors=hv, ivf_index=F.write_ivf_index(cent.cpu().numpy(), docs, pls),
+                             ivf_vectors=F.write_vector_file(x.cpu().numpy()))
         base.append(x)
-    cat = F.concat_multi_spann(users)
-    del users
+    cat = F.concat_multi_spann(users_)
+    del users_
     log("multi-user SPANN build: %d users x %d x %d, %.1fs, ivf_vectors %.2f GB" % (U, per, d, time.time() - t0,
                                                                                     len(cat["ivf_vectors"]) / 1e9))
     t0 = time.time()
@@ -447,85 +539,97 @@ def run_spann(args, ctx, rank, world, timer):
                          None, rank, world)
     log("load %.1fs" % (time.time() - t0))
     nq = (steps + warm) * batch
-    gq = torch.Generator(device="cpu"); gq.manual_seed(77)          # same pairs on every rank (lists are sharded)
     quser = (torch.arange(nq) % U)
-    qrow = torch.randint(0, per, (nq,), generator=gq)
-    noise = torch.randn((nq, d), generator=gq) * (0.3 / d ** 0.5)
-    queries = torch.stack([base[int(u)][int(r)] for u, r in zip(quser.tolist(), qrow.tolist())]) + noise.cuda()
-    queries = (queries / queries.norm(dim=1, keepdim=True)).contiguous()
+    if gen is not None:  # queries: fresh draws of each user's own distribution (same pairs on every rank: lists are sharded)
+        per_user = (nq + U - 1) // U
+        qs = torch.stack([gen.draw(ucent[u], per_user, seed=7_000_000 + u) for u in range(U)])  # [U][per_user][d]
+        queries = qs.permute(1, 0, 2).reshape(-1, d)[:nq].contiguous()                       # query i -> user i % U
+        desc = "low-rank (48) + noise unit-norm rows: muopdb_amd.build.EmbedLike"
+    else:
+        gq = torch.Generator(device="cpu"); gq.manual_seed(77)
+        qrow = torch.randint(0, per, (nq,), generator=gq)
+        noise = torch.randn((nq, d), generator=gq) * (0.3 / d ** 0.5)
+        queries = torch.stack([base[int(u)][int(r)] for u, r in zip(quser.tolist(), qrow.tolist())]) + noise.cuda()
+        queries = (queries / queries.norm(dim=1, keepdim=True)).contiguous()
+        desc = "isotropic Gaussian unit-norm rows (round-1 generator)"
     if args.dump_dir:
-        dump(args, rank, hnsw_index=cat["hnsw_index"], hnsw_vectors=cat["hnsw_vectors"], ivf_index=cat["ivf_index"],
+        dump(args, rank, "spann", hnsw_index=cat["hnsw_index"], hnsw_vectors=cat["hnsw_vectors"], ivf_index=cat["ivf_index"],
              vectors=cat["ivf_vectors"], user_table=cat["user_table"],
              **{"queries.f32": queries.cpu().numpy(), "users.u64": (quser + 1).numpy().astype(np.uint64)})
-    params = SearchParams(k, args.ef).with_num_explored_centroids(P).with_centroid_distance_ratio(0.1).to_c()
-    ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
-    sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
-    cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    gather = D.PackedTopkGather(ctx, batch, k, "cuda") if world > 1 else None
+    if gather:
+        ids, sc, cn = gather.ids, gather.scores, gather.counts
+    else:
+        ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
+        sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
+        cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
     fo = torch.zeros(batch, dtype=torch.uint8, device="cuda")
     uid_arrays = [L.u128_array([int(u) + 1 for u in quser[i * batch:(i + 1) * batch].tolist()]) for i in range(steps + warm)]
-
-    def step(i, keep=None):
-        q = queries[i * batch:(i + 1) * batch]
-        ctx.check(ctx.lib.mdb_multi_spann_search(ms.h, uid_arrays[i], C.c_void_p(q.data_ptr()), C.c_size_t(batch), C.byref(params),
-                                                 C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()),
-                                                 C.c_void_p(cn.data_ptr()), C.c_void_p(fo.data_ptr())))
-        res = ids
-        if world > 1:
-            gd, gs, gc = D.all_gather_topk(ids, sc, cn)
-            res, _, _ = D.merge_shards_device(ctx, gd, gs, gc)
-        if keep is not None:
-            keep.append(res[:, :, 0].clone())
-
-    for i in range(warm):
-        step(i)
-    ctx.sync(); ctx.set_profiling(1); ctx.get_profile()  # 1: posting-list scan only
-    timer.barrier()
-    t0 = time.perf_counter()
-    for i in range(warm, warm + steps):
-        step(i)
-    timer.barrier()
-    elapsed = timer.max_over_ranks(time.perf_counter() - t0)
-    kernel_ms, launches = ctx.get_profile(); ctx.set_profiling(False)
-    found, scored, abytes = [], 0, 0
-    ctx.set_profiling(2); ctx.get_profile()  # untimed re-run: centroid-graph traversal kernel time
-    for i in range(warm, warm + steps):
-        step(i, found)
-        st = ctx.stats(); scored += st["scored_vectors"]; abytes += st["algorithmic_bytes"]
-    hnsw_ms, hnsw_launches = ctx.get_profile(); ctx.set_profiling(False)
-    found = torch.cat(found).cpu().numpy()
-    # exact per-user ground truth (f64) for recall
-    hits = 0
+    # exact per-user ground truth (f64) of the timed queries
+    gts = []
     for j in range(steps * batch):
         qi = warm * batch + j
         u = int(quser[qi])
-        xb = base[u].double()
-        dd = ((xb - queries[qi].double()[None, :]) ** 2).sum(1)
-        gt = (torch.topk(dd, k, largest=False).indices + u * per).cpu().numpy()
-        hits += len(set(found[j][:k].tolist()) & set(gt.tolist()))
-    rec = hits / (steps * batch * k)
-    ach = (abytes / steps) / (kernel_ms / launches * 1e-3) / 1e9
-    out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec, scaling="strong",
-               config={"workload": "multi-user SPANN, %d users x %d x %d f32 unit-norm (BASELINE.md C4 shape), batch=%d (user,query) "
-                                   "pairs, ef=%d, num_explored_centroids=%d, ratio=0.1, top-%d, posting lists sharded x%d"
-                                   % (U, per, d, batch, args.ef, P, k, world),
-                       "users": U, "n": U * per, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "multi-spann"},
-               roofline=dict(bound="hbm", kernel="ivf_scan_f32_kernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=ach / HBM_PEAK_GBS, traffic=None, bytes_per_launch=abytes / steps,
-                             kernel_ms=kernel_ms / launches, scored_per_query=scored / (steps * batch),
-                             centroid_hnsw_kernel_ms=hnsw_ms / max(hnsw_launches, 1)))
+        dd = ((base[u].double() - queries[qi].double()[None, :]) ** 2).sum(1)
+        gts.append((torch.topk(dd, k, largest=False).indices + u * per))
+    gts = torch.stack(gts).cpu().numpy()
+
+    def measure(P_, ratio_):
+        params = SearchParams(k, args.ef).with_num_explored_centroids(P_).with_centroid_distance_ratio(ratio_).to_c()
+
+        def step(i, keep=None):
+            q = queries[i * batch:(i + 1) * batch]
+            ctx.check(ctx.lib.mdb_multi_spann_search(ms.h, uid_arrays[i], C.c_void_p(q.data_ptr()), C.c_size_t(batch), C.byref(params),
+                                                     C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()),
+                                                     C.c_void_p(cn.data_ptr()), C.c_void_p(fo.data_ptr())))
+            res = ids
+            if world > 1:
+                res, _, _ = gather.gather_merge()
+            if keep is not None:
+                keep.append(res[:, :, 0].clone())
+
+        elapsed, kernel_ms, launches = env.timed(step, steps, warm, profiling=1)  # 1: posting-list scan only
+        found, scored, abytes = [], 0, 0
+        ctx.set_profiling(2); ctx.get_profile()  # untimed re-run: centroid-graph traversal kernel time
+        for i in range(warm, warm + steps):
+            step(i, found)
+            st = ctx.stats(); scored += st["scored_vectors"]; abytes += st["algorithmic_bytes"]
+        hnsw_ms, hnsw_launches = ctx.get_profile(); ctx.set_profiling(False)
+        found = torch.cat(found).cpu().numpy()
+        return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes,
+                    recall=recall_at_k(found, gts, k), hnsw_ms=hnsw_ms / max(hnsw_launches, 1))
+
+    m = measure(P, ratio)
+    out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=m["recall"], scaling="strong",
+               config={"workload": "multi-user SPANN, %d users x %d x %d f32 (%s; BASELINE.md C4 shape), batch=%d (user,query) "
+                                   "pairs, ef=%d, num_explored_centroids=%d, ratio=%g, top-%d, posting lists sharded x%d"
+                                   % (U, per, d, desc, batch, args.ef, P, ratio, k, world),
+                       "users": U, "n": U * per, "dim": d, "batch": batch, "k": k, "nprobe": P, "ratio": ratio, "index": "multi-spann",
+                       "data": args.data},
+               roofline=hbm_roofline("ivf_scan_f32_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
+                                     scored_per_query=m["scored"] / (steps * batch), centroid_hnsw_kernel_ms=m["hnsw_ms"]))
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("spann", out["config"])
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if not args.no_sweep:
+        sweep = []
+        for p_, r_ in ((4, 0.1), (16, 0.1), (64, 0.1), (4, 0.3), (16, 0.3), (64, 0.3), (16, 1.0)):
+            s = m if (p_, r_) == (P, ratio) else measure(p_, r_)
+            sweep.append(dict(num_explored_centroids=p_, centroid_distance_ratio=r_, recall_at_10=s["recall"],
+                              value=steps * batch / s["elapsed"], ms_per_step=1000 * s["elapsed"] / steps,
+                              scan_kernel_ms=s["kernel_ms"] / max(s["launches"], 1), scored_per_query=s["scored"] / (steps * batch)))
+        out["sweep"] = sweep
+    if env.cpu:
         import oracle
         o = oracle.MultiSpannIndex(cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
-        op = oracle.SearchParams(k, args.ef, num_explored_centroids=P, centroid_distance_ratio=0.1)
+        op = oracle.SearchParams(k, args.ef, num_explored_centroids=P, centroid_distance_ratio=ratio)
         qh = queries[warm * batch:(warm + steps) * batch].cpu().numpy()
         uh = [int(u) + 1 for u in quser[warm * batch:(warm + steps) * batch].tolist()]
         t0 = time.perf_counter(); o.search_for_user(uh[:16], qh[:16], op); dt = time.perf_counter() - t0
         ns = int(min(len(qh), max(16, args.cpu_seconds / (dt / 16))))
         t0 = time.perf_counter(); r = o.search_for_user(uh[:ns], qh[:ns], op); dt1 = time.perf_counter() - t0
-        ok = all(r.doc_ids(i) == [int(v) for v in found[i][:int(r.counts[i])]] for i in range(min(ns, 256)))
+        ok = all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(ns, 256)))
         out["cpu_baseline"] = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port", sample="%d (user,query) pairs, one thread" % ns,
                                    ids_match_gpu=bool(ok))
+    ms.close()
     return out
 
 
@@ -541,8 +645,26 @@ def main():
     from muopdb_amd import lib as L
     ctx = L.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    timer = Timer(world)
-    res = {"hnsw": run_hnsw, "flat": run_flat, "ivfpq": run_ivfpq, "spann": run_spann}[args.workload](args, ctx, rank, world, timer)
+    env = Env(args, ctx, rank, world)
+    single = {"hnsw": run_hnsw, "flat": run_flat, "ivfpq": run_ivfpq, "spann": run_spann, "c5": run_c5}
+    if args.workload != "all":
+        res = single[args.workload](env)
+    else:
+        res = run_hnsw(env)
+        extra = {}
+        plan = [("flat_1m_b1", lambda: run_flat(env, n=1_000_000, batch=1)), ("flat_1m_b64", lambda: run_flat(env, n=1_000_000, batch=64)),
+                ("ivfpq_c3", lambda: run_ivfpq(env)), ("spann_c4_128u", lambda: run_spann(env, users=128))]
+        for name, fn in plan:
+            t0 = time.time()
+            try:  # a failing extra workload must never take the headline line with it
+                torch.cuda.empty_cache()
+                w = fn()
+                w.update(unit="queries/s", steps=args.steps, warmup=args.warmup, scaling=w.get("scaling", "weak"))
+                extra[name] = w
+            except Exception as e:  # noqa: BLE001
+                extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            log("%s: %.1fs" % (name, time.time() - t0))
+        res["workloads"] = extra
     line = {"metric": METRIC, "value": res.pop("value"), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": res.pop("scaling", "weak"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic"}

@@ -282,6 +282,21 @@ mdb_status mdb_merge_shards(mdb_ctx* ctx, const mdb_u128* doc_ids, const float* 
                             size_t world, size_t b, size_t k, mdb_u128* doc_ids_out, float* scores_out,
                             uint32_t* counts_out);
 
+/* The same merge over ONE packed block per rank, laid out as an all-gather delivers it ([world] blocks of
+ * mdb_shard_block_bytes(b, k) bytes, each = { mdb_u128 doc_ids[b][k]; float scores[b][k]; uint32_t counts[b]; pad to 16 }).
+ * A rank points its search outputs INTO its send block (mdb_shard_block_views), so a sharded step is: search ->
+ * one all-gather of a preallocated buffer -> this merge; nothing is allocated or repacked in the step. */
+size_t mdb_shard_block_bytes(size_t b, size_t k);
+mdb_status mdb_shard_block_views(void* block, size_t b, size_t k, mdb_u128** doc_ids, float** scores, uint32_t** counts);
+mdb_status mdb_merge_shards_packed(mdb_ctx* ctx, const void* blocks, size_t world, size_t b, size_t k, mdb_u128* doc_ids_out,
+                                   float* scores_out, uint32_t* counts_out);
+/* The collective itself, for hosts without torch (the reference's aggregator role, rs/aggregator/src/aggregator.rs:80-135,
+ * as ONE RCCL all-gather over xGMI): ncclAllGather(send_block -> recv_blocks, mdb_shard_block_bytes(b, k) bytes per rank)
+ * enqueued on the context's stream with the caller's communicator (`rccl_comm` = ncclComm_t from ncclCommInitRank, one
+ * rank per GPU), followed by mdb_merge_shards_packed.  librccl is bound lazily (dlopen); MDB_ERR_UNSUPPORTED if absent. */
+mdb_status mdb_allgather_merge(mdb_ctx* ctx, void* rccl_comm, const void* send_block, void* recv_blocks, size_t world, size_t b,
+                               size_t k, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out);
+
 #ifdef __cplusplus
 }
 #endif

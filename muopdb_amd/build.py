@@ -20,8 +20,77 @@ from . import formats as F
 
 
 # ------------------------------------------------------------------------------------------ data
-def sift_like(n, d=128, n_clusters=4096, sigma=20.0, seed=1, device="cuda"):
-    """Gaussian clusters, clipped to [0,218], rounded, f32 (synthetic SIFT-1M)."""
+class SiftLike:
+    """BASELINE.md C2/C3 synthetic "SIFT-1M" (no dataset can be downloaded): integer-valued f32 rows in [0, 218] with the
+    two properties of real descriptors that decide what an index can do with them — a LOW INTRINSIC DIMENSION and
+    per-subvector structure a product quantizer can code.  Every 8-float block s is a `latent_per_block`-dimensional
+    latent mapped through a fixed non-negative 8 x r frame U_s; the d/8 * r latent coordinates come from a mixture of
+    `n_clusters` Gaussians (centres uniform in the unit cube, spread `sigma`), plus isotropic full-rank noise, then
+    clipped and rounded like SIFT:  x = clip(round(300 * (z U) + 20 + noise * eps), 0, 218).
+    Round 1's generator (isotropic 128-d Gaussian clusters, `gaussian_clusters` below) has no such structure: its
+    intra-cluster distances concentrate, so the reference's SYMMETRIC PQ distance cannot rank them (recall@10 0.11) —
+    a property of the data, not of the scan.  With r = 2 (32 intrinsic dimensions) symmetric PQ m=16 reaches
+    recall@10 ~0.9 and IVF coverage rises gradually with nprobe, i.e. the QPS/recall sweep means something.
+    Base rows and queries are independent draws (different seeds) of the same distribution."""
+
+    def __init__(self, d=128, latent_per_block=2, n_clusters=4096, sigma=0.15, noise=1.0, seed=1, device="cuda"):
+        assert d % 8 == 0
+        self.d, self.r, self.m, self.sigma, self.noise, self.device = d, latent_per_block, d // 8, sigma, noise, device
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        u = torch.rand((self.m, self.r, 8), generator=g) + 0.1
+        self.frames = (u / u.norm(dim=2, keepdim=True)).to(device)
+        self.centers = torch.rand((n_clusters, self.m * self.r), generator=g).to(device)
+
+    def draw(self, n, seed, chunk=1 << 20):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        a = torch.randint(0, self.centers.shape[0], (n,), generator=g)
+        out = torch.empty((n, self.d), dtype=torch.float32, device=self.device)
+        gd = torch.Generator(device=self.device)
+        gd.manual_seed(seed)
+        for s in range(0, n, chunk):
+            e = min(n, s + chunk)
+            z = self.centers[a[s:e].to(self.device)] + self.sigma * torch.randn((e - s, self.m * self.r), generator=gd,
+                                                                                device=self.device)
+            x = torch.einsum("nmr,mre->nme", z.view(e - s, self.m, self.r), self.frames).reshape(e - s, self.d)
+            x = x * 300.0 + 20.0 + self.noise * torch.randn((e - s, self.d), generator=gd, device=self.device)
+            out[s:e] = torch.clamp(torch.round(x), 0, 218)
+        return out
+
+
+class EmbedLike:
+    """BASELINE.md C4 synthetic sentence embeddings (py/embed_1m_sentences.py's nomic-embed role): unit-norm 768-d rows
+    of LOW RANK + noise — a shared r x d map (the "model") applied to per-user latent mixtures.  Round 1's isotropic
+    768-d Gaussian has no neighbourhood structure at all (every centroid is equally far: SPANN recall 0.32 whatever the
+    probe count).  Here a user's rows are  normalise(z A + noise * eps),  z from `n_clusters` broad Gaussians."""
+
+    def __init__(self, d=768, rank=48, n_clusters=8, sigma=1.0, noise=0.01, seed=3, device="cuda"):
+        self.d, self.rank, self.ncl, self.sigma, self.noise, self.device = d, rank, n_clusters, sigma, noise, device
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        self.A = (torch.randn((rank, d), generator=g) / d ** 0.5).to(device)
+
+    def user(self, user_seed):
+        """the latent cluster centres of one user"""
+        g = torch.Generator(device="cpu")
+        g.manual_seed(1_000_003 * 7 + user_seed)
+        return torch.randn((self.ncl, self.rank), generator=g).to(self.device)
+
+    def draw(self, centers, n, seed):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        a = torch.randint(0, self.ncl, (n,), generator=g).to(self.device)
+        gd = torch.Generator(device=self.device)
+        gd.manual_seed(seed)
+        z = centers[a] + self.sigma * torch.randn((n, self.rank), generator=gd, device=self.device)
+        x = z @ self.A + self.noise * torch.randn((n, self.d), generator=gd, device=self.device)
+        return x / x.norm(dim=1, keepdim=True)
+
+
+def gaussian_clusters(n, d=128, n_clusters=4096, sigma=20.0, seed=1, device="cuda"):
+    """Round 1's C2/C3 base (isotropic Gaussian clusters, clipped to [0,218], rounded); kept so that round-1 numbers can be
+    reproduced (`bench.py --data legacy`)."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     centers = torch.rand((n_clusters, d), generator=g) * 218.0
@@ -37,7 +106,7 @@ def sift_like(n, d=128, n_clusters=4096, sigma=20.0, seed=1, device="cuda"):
 
 
 def unit_gaussian(n, d, seed, device="cuda"):
-    """Gaussian rows normalised to unit length (nomic-embed-like)."""
+    """Round 1's C4 rows (isotropic Gaussian, normalised); structure-free, kept for `--data legacy`."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     out = torch.empty((n, d), dtype=torch.float32, device=device)
@@ -190,6 +259,7 @@ def kmeans(x, k, iters=10, seed=0, sample=None):
 
 
 def assign_nearest(x, c, chunk=1 << 16):
+    chunk = max(1024, min(chunk, (1 << 29) // max(1, c.shape[0])))  # distance block of at most 2 GiB
     cn = (c ** 2).sum(1)
     ct = c.t().contiguous()
     out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
@@ -219,3 +289,50 @@ def posting_lists_from_assignment(assign, num_lists):
     order = np.argsort(a, kind="stable")
     bounds = np.searchsorted(a[order], np.arange(num_lists + 1))
     return [order[bounds[i]:bounds[i + 1]].astype(np.uint64) for i in range(num_lists)]
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config C5, one GPU's shard
+def c5_shard(ctx, total=100_000_000, world=8, rank=0, nlist=65536, d=128, chunk=2_000_000, seed=4, log=None):
+    """What ONE of the 8 GPUs holds of BASELINE config C5 (100M x 128 as 16-byte PQ codes, IVF nlist 65 536, posting lists
+    sharded l % world): the full coarse quantizer, the shared PQ codebook, and the posting lists this rank owns with
+    their codes (~total/world vectors, ~total/nlist per list).  The 100M rows are generated chunk by chunk (SiftLike),
+    assigned to their nearest of the 65 536 centroids, and only the rows of owned lists are kept — the other ranks'
+    lists are EMPTY in the returned index file, so loading it unsharded reproduces this rank's work exactly.
+    Returns dict(index, vectors, pq, codebook, gen, n, nlist, owned_lists, centroids)."""
+    from .index import ProductQuantizer
+    gen = SiftLike(d, seed=seed)
+    sample = gen.draw(min(total, 2_000_000), seed=seed * 100)
+    cent = kmeans(sample, nlist, iters=2, seed=seed)
+    cb = train_pq_codebook(sample, 8, 8, iters=6, seed=seed + 1, sample=100_000)
+    pq = ProductQuantizer(d, 8, 8, cb)
+    del sample
+    nlist = cent.shape[0]
+    keep_codes, keep_list = [], []
+    done = 0
+    ci = 0
+    while done < total:
+        m = min(chunk, total - done)
+        x = gen.draw(m, seed=seed * 1000 + ci)
+        a = assign_nearest(x, cent, chunk=1 << 14)
+        own = (a % world) == rank
+        xo = x[own]
+        keep_list.append(a[own].cpu().numpy().astype(np.int64))
+        keep_codes.append(pq.quantize(ctx, xo.cpu().numpy()))
+        done += m
+        ci += 1
+        if log and ci % 10 == 0:
+            log("c5 shard: %d / %d rows assigned" % (done, total))
+    lists = np.concatenate(keep_list)
+    codes = np.concatenate(keep_codes)
+    del keep_list, keep_codes
+    n = codes.shape[0]
+    # point ids in list order (what IvfBuilder::reindex produces, ivf/builder.rs:682): list l's points are contiguous
+    order = np.argsort(lists, kind="stable")
+    codes = codes[order]
+    bounds = np.searchsorted(lists[order], np.arange(nlist + 1))
+    pls = [np.arange(bounds[i], bounds[i + 1], dtype=np.uint64) for i in range(nlist)]
+    # this rank's global doc ids: an arbitrary injective labelling (rank-strided)
+    docs = np.arange(n, dtype=np.uint64) * np.uint64(world) + np.uint64(rank)
+    index = F.write_ivf_index(cent.cpu().numpy(), docs, pls, quantized_dimension=d // 8)
+    return dict(index=index, vectors=F.write_vector_file(codes), pq=pq, codebook=cb, gen=gen, n=n, nlist=nlist,
+                owned_lists=int((np.diff(bounds) > 0).sum()), centroids=cent)

@@ -11,6 +11,8 @@
 // posting lists live in shared HBM arenas; a batch mixes users freely through a per-query user
 // index, so one launch per stage serves the whole batch (the reference opens one Spann per user
 // lazily and searches them one at a time).
+#include <dlfcn.h>
+
 #include <unordered_map>
 
 #include "mdb_device.cuh"
@@ -136,9 +138,12 @@ struct mdb_multi_spann {
 
 // ------------------------------------------------------------------------------------------ shard merge
 // one block per query: rank-sort the valid rows of the `world` shards by (score, doc id), keep k
-__global__ __launch_bounds__(256) void merge_shards_kernel(const mdb_u128* __restrict__ docs, const float* __restrict__ scores,
-                                                           const uint32_t* __restrict__ counts, int world, size_t b, int k,
-                                                           mdb_u128* __restrict__ doc_out, float* __restrict__ score_out,
+// shard w's arrays start at docs + w * doc_stride (bytes) etc.: three separate [world][B][k] arrays (mdb_merge_shards) or
+// one packed block per rank as an all-gather delivers it (mdb_merge_shards_packed)
+__global__ __launch_bounds__(256) void merge_shards_kernel(const char* __restrict__ docs_base, size_t doc_stride,
+                                                           const char* __restrict__ scores_base, size_t score_stride,
+                                                           const char* __restrict__ counts_base, size_t count_stride, int world, size_t b,
+                                                           int k, mdb_u128* __restrict__ doc_out, float* __restrict__ score_out,
                                                            uint32_t* __restrict__ counts_out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int cap = world * k;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void merge_shards_kernel(const mdb_u128* __res
         uint32_t acc = 0;
         for (int w = 0; w < world; ++w) {
             pos[w] = acc;
-            uint32_t c = counts[(size_t)w * b + qi];
+            uint32_t c = ((const uint32_t*)(counts_base + (size_t)w * count_stride))[qi];
             acc += c < (uint32_t)k ? c : (uint32_t)k;
         }
         pos[world] = acc;
@@ -162,10 +167,11 @@ __global__ __launch_bounds__(256) void merge_shards_kernel(const mdb_u128* __res
         int w = t / k, jj = t % k;
         uint32_t c = pos[w + 1] - pos[w];
         if ((uint32_t)jj < c) {
-            size_t src = ((size_t)w * b + qi) * k + jj;
+            size_t src = qi * (size_t)k + jj;
+            const mdb_u128* docs = (const mdb_u128*)(docs_base + (size_t)w * doc_stride);
             lo[pos[w] + jj] = docs[src].lo;
             hi[pos[w] + jj] = docs[src].hi;
-            sc[pos[w] + jj] = scores[src];
+            sc[pos[w] + jj] = ((const float*)(scores_base + (size_t)w * score_stride))[src];
         }
     }
     __syncthreads();
@@ -188,11 +194,9 @@ __global__ __launch_bounds__(256) void merge_shards_kernel(const mdb_u128* __res
 
 extern "C" {
 
-mdb_status mdb_merge_shards(mdb_ctx* ctx, const mdb_u128* doc_ids, const float* scores, const uint32_t* counts, size_t world,
-                            size_t b, size_t k, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out) {
-    if (!ctx || !doc_ids || !scores || !counts || !doc_ids_out || !scores_out || world == 0) return MDB_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    MDB_HIP(ctx, hipSetDevice(ctx->device));
+static mdb_status merge_shards_launch(mdb_ctx* ctx, const char* docs, size_t ds, const char* scores, size_t ss, const char* counts,
+                                      size_t cs, size_t world, size_t b, size_t k, mdb_u128* doc_ids_out, float* scores_out,
+                                      uint32_t* counts_out) {
     if (b == 0) return MDB_OK;
     if (k == 0) {
         if (counts_out) MDB_HIP(ctx, hipMemsetAsync(counts_out, 0, b * 4, ctx->stream));
@@ -202,10 +206,70 @@ mdb_status mdb_merge_shards(mdb_ctx* ctx, const mdb_u128* doc_ids, const float* 
     if (lds > 150 * 1024) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "world*k=%zu rows exceed the on-chip merge capacity", world * k);
     if (lds > 48 * 1024)
         MDB_HIP(ctx, hipFuncSetAttribute((const void*)merge_shards_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    merge_shards_kernel<<<dim3((unsigned)b), 256, lds, ctx->stream>>>(doc_ids, scores, counts, (int)world, b, (int)k, doc_ids_out,
+    merge_shards_kernel<<<dim3((unsigned)b), 256, lds, ctx->stream>>>(docs, ds, scores, ss, counts, cs, (int)world, b, (int)k, doc_ids_out,
                                                                      scores_out, counts_out);
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
+}
+
+mdb_status mdb_merge_shards(mdb_ctx* ctx, const mdb_u128* doc_ids, const float* scores, const uint32_t* counts, size_t world,
+                            size_t b, size_t k, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out) {
+    if (!ctx || !doc_ids || !scores || !counts || !doc_ids_out || !scores_out || world == 0) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    return merge_shards_launch(ctx, (const char*)doc_ids, b * k * 16, (const char*)scores, b * k * 4, (const char*)counts, b * 4, world, b, k,
+                               doc_ids_out, scores_out, counts_out);
+}
+
+size_t mdb_shard_block_bytes(size_t b, size_t k) { return align_up(b * k * 20 + b * 4, 16); }
+
+mdb_status mdb_shard_block_views(void* block, size_t b, size_t k, mdb_u128** doc_ids, float** scores, uint32_t** counts) {
+    if (!block) return MDB_ERR_INVALID_ARG;
+    char* p = (char*)block;
+    if (doc_ids) *doc_ids = (mdb_u128*)p;
+    if (scores) *scores = (float*)(p + b * k * 16);
+    if (counts) *counts = (uint32_t*)(p + b * k * 20);
+    return MDB_OK;
+}
+
+mdb_status mdb_merge_shards_packed(mdb_ctx* ctx, const void* blocks, size_t world, size_t b, size_t k, mdb_u128* doc_ids_out,
+                                   float* scores_out, uint32_t* counts_out) {
+    if (!ctx || !blocks || !doc_ids_out || !scores_out || world == 0) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t stride = mdb_shard_block_bytes(b, k);
+    const char* p = (const char*)blocks;
+    return merge_shards_launch(ctx, p, stride, p + b * k * 16, stride, p + b * k * 20, stride, world, b, k, doc_ids_out, scores_out,
+                               counts_out);
+}
+
+// RCCL is bound lazily (dlopen): libmuopdb_hip.so has no load-time dependency on it, a single-GPU host never touches it,
+// and the copy already loaded by the host process (the one its ncclComm_t belongs to) is the one that gets used.
+typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static nccl_all_gather_fn rccl_all_gather() {
+    static nccl_all_gather_fn fn = [] {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        return h ? (nccl_all_gather_fn)dlsym(h, "ncclAllGather") : (nccl_all_gather_fn) nullptr;
+    }();
+    return fn;
+}
+
+mdb_status mdb_allgather_merge(mdb_ctx* ctx, void* rccl_comm, const void* send_block, void* recv_blocks, size_t world, size_t b,
+                               size_t k, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out) {
+    if (!ctx || !rccl_comm || !send_block || !recv_blocks || !doc_ids_out || !scores_out || world == 0) return MDB_ERR_INVALID_ARG;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        MDB_HIP(ctx, hipSetDevice(ctx->device));
+        nccl_all_gather_fn ag = rccl_all_gather();
+        if (!ag) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "librccl.so not found (dlopen): %s", dlerror());
+        const int rc = ag(send_block, recv_blocks, mdb_shard_block_bytes(b, k), /*ncclUint8*/ 1, rccl_comm, ctx->stream);
+        if (rc != 0) return mdb_fail(ctx, MDB_ERR_HIP, "ncclAllGather failed: ncclResult_t %d", rc);
+    }
+    return mdb_merge_shards_packed(ctx, recv_blocks, world, b, k, doc_ids_out, scores_out, counts_out);
 }
 
 // ---------------------------------------------------------------- single-user SPANN

@@ -9,9 +9,10 @@ Partitioning
   * HNSW: the traversal does not partition (replicas only): ranks split the batch, no collective.
   * flat: row-range shards, same gather + merge.
 
-Collective: ONE all-gather per batch of fixed-size per-rank blocks — doc ids [B][k] (2 x u64),
-scores [B][k] f32, counts [B] — (24*k + 4) bytes per query per rank: latency-bound, far below a
-single xGMI link's bandwidth, so a direct all-gather (not a ring pipeline) is the right shape.
+Collective: ONE all-gather per batch of one packed, preallocated block per rank — doc ids [B][k] (2 x u64),
+scores [B][k] f32, counts [B] (PackedTopkGather; (20*k + 4) bytes per query per rank): latency-bound, far below a
+single xGMI link's bandwidth, so a direct all-gather (not a ring pipeline) is the right shape.  A host without
+torch issues the same exchange through the C ABI: mdb_allgather_merge(ctx, ncclComm_t, ...).
 Merge: per query, the `world` sorted rows are merged by IdWithScore order (score, doc id) and
 truncated to k — Snapshot::search_for_users' rule (rs/index/src/collection/snapshot.rs:60-63), not
 the aggregator's descending sort (rs/aggregator/src/aggregator.rs:135).
@@ -32,10 +33,66 @@ def split_batch(b, rank, world):
     return rank * b // world, (rank + 1) * b // world
 
 
+def block_bytes(b, k):
+    """bytes of one rank's packed result block (mdb_shard_block_bytes): ids [b][k] u128 | scores [b][k] f32 | counts [b] u32 | pad 16"""
+    return (b * k * 20 + b * 4 + 15) // 16 * 16
+
+
+def block_views(block, b, k):
+    """typed views INTO a uint8 block tensor: (doc ids int64 [b,k,2] (lo, hi), scores f32 [b,k], counts int32 [b])"""
+    ids = block[:b * k * 16].view(torch.int64).view(b, k, 2)
+    scores = block[b * k * 16:b * k * 20].view(torch.float32).view(b, k)
+    counts = block[b * k * 20:b * k * 20 + b * 4].view(torch.int32)
+    return ids, scores, counts
+
+
+class PackedTopkGather:
+    """The sharded step's exchange: ONE all-gather per batch of one preallocated packed block per rank,
+    then the device merge.  The search writes its outputs straight into this rank's send block (`ids`, `scores`,
+    `counts` are views of it), so the step allocates nothing and repacks nothing:
+
+        g = PackedTopkGather(ctx, b, k, "cuda")
+        mdb_*_search(..., g.ids.data_ptr(), g.scores.data_ptr(), g.counts.data_ptr(), ...)
+        docs, scores, counts = g.gather_merge()          # [b,k,2], [b,k], [b] on every rank
+
+    `ctx` None (CPU / gloo plumbing tests): gather only, the caller merges `recv_views()` itself."""
+
+    def __init__(self, ctx, b, k, device, group=None):
+        self.ctx, self.b, self.k, self.group = ctx, b, k, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        nb = block_bytes(b, k)
+        self.send = torch.zeros(nb, dtype=torch.uint8, device=device)
+        self.recv = torch.zeros(self.world * nb, dtype=torch.uint8, device=device)
+        self.ids, self.scores, self.counts = block_views(self.send, b, k)
+        self.out_docs = torch.zeros((b, k, 2), dtype=torch.int64, device=device)
+        self.out_scores = torch.zeros((b, k), dtype=torch.float32, device=device)
+        self.out_counts = torch.zeros(b, dtype=torch.int32, device=device)
+
+    def gather(self):
+        if self.world == 1:
+            self.recv.copy_(self.send)
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)  # rank-major blocks
+        return self.recv
+
+    def recv_views(self):
+        nb = block_bytes(self.b, self.k)
+        return [block_views(self.recv[w * nb:(w + 1) * nb], self.b, self.k) for w in range(self.world)]
+
+    def gather_merge(self):
+        self.gather()
+        c = self.ctx
+        c.check(c.lib.mdb_merge_shards_packed(c.h, C.c_void_p(self.recv.data_ptr()), C.c_size_t(self.world), C.c_size_t(self.b),
+                                              C.c_size_t(self.k), C.c_void_p(self.out_docs.data_ptr()),
+                                              C.c_void_p(self.out_scores.data_ptr()), C.c_void_p(self.out_counts.data_ptr())))
+        return self.out_docs, self.out_scores, self.out_counts
+
+
 def all_gather_topk(doc_ids, scores, counts, group=None):
-    """doc_ids int64 [B,k,2] (lo,hi), scores f32 [B,k], counts int32 [B] (this rank's shard result)
-    -> ([W,B,k,2], [W,B,k], [W,B]) on every rank."""
+    """Unpacked variant (three collectives; kept for callers that hold three separate tensors — the packed class above is
+    the step's path): ([W,B,k,2], [W,B,k], [W,B]) on every rank."""
     world = dist.get_world_size(group)
+
     def gather(t):
         t = t.contiguous()
         out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)

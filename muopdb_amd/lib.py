@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmuopdb_hip.so")
 
 MDB_OK = 0
+MDB_ERR_INVALID_ARG = 1
 STATUS_NAMES = {0: "MDB_OK", 1: "MDB_ERR_INVALID_ARG", 2: "MDB_ERR_FORMAT", 3: "MDB_ERR_OOM", 4: "MDB_ERR_HIP",
                 5: "MDB_ERR_NAN", 6: "MDB_ERR_NOT_FOUND", 7: "MDB_ERR_UNSUPPORTED", 8: "MDB_ERR_OUT_OF_RANGE"}
 METRIC_L2, METRIC_DOT = 0, 1
@@ -29,6 +30,7 @@ EXPORTED_SYMBOLS = [
     "mdb_spann_load", "mdb_spann_free", "mdb_spann_search", "mdb_spann_set_filter", "mdb_spann_invalidate", "mdb_spann_is_invalidated",
     "mdb_multi_spann_load", "mdb_multi_spann_free", "mdb_multi_spann_num_users", "mdb_multi_spann_search",
     "mdb_multi_spann_set_filter", "mdb_multi_spann_invalidate", "mdb_merge_shards",
+    "mdb_shard_block_bytes", "mdb_shard_block_views", "mdb_merge_shards_packed", "mdb_allgather_merge",
 ]
 
 
@@ -87,7 +89,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         _lib.mdb_last_error.restype = C.c_char_p
         _lib.mdb_version.restype = C.c_char_p
-        for n in ("mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_hnsw_num_vectors",
+        for n in ("mdb_shard_block_bytes", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_hnsw_num_vectors",
                   "mdb_multi_spann_num_users"):
             if hasattr(_lib, n):
                 getattr(_lib, n).restype = C.c_size_t

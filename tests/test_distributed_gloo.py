@@ -76,6 +76,16 @@ def _worker(rank, world, port, out):
         ok &= int(counts[qi]) == n
         ok &= [(int(got[qi, j, 1]) << 64) | int(got[qi, j, 0]) for j in range(n)] == ref.doc_ids(qi)
         ok &= np.array_equal(scores[qi, :n].numpy(), ref.scores[qi, :n])
+    # the step's real exchange: results written INTO this rank's packed block, ONE all-gather, merge of the received blocks
+    pg = D.PackedTopkGather(None, len(q), k, "cpu")
+    d0, s0, c0 = local()
+    pg.ids.copy_(d0); pg.scores.copy_(s0); pg.counts.copy_(c0)
+    pg.gather()
+    ok &= pg.recv.numel() == world * D.block_bytes(len(q), k) and D.block_bytes(len(q), k) % 16 == 0
+    views = pg.recv_views()
+    ok &= bool(torch.equal(views[rank][0], d0) and torch.equal(views[rank][1], s0) and torch.equal(views[rank][2], c0))
+    pd, ps, pc = merge_numpy(torch.stack([v_[0] for v_ in views]), torch.stack([v_[1] for v_ in views]), torch.stack([v_[2] for v_ in views]))
+    ok &= bool(torch.equal(pd, docs) and torch.equal(ps, scores) and torch.equal(pc, counts))
     # sharded coarse search: every rank ranks its centroid range, rows are gathered [b][world][P] and merged by key
     cent = rng.standard_normal((200, 16)).astype(np.float32) * 8
     cent[150] = cent[3]                                      # a tie across two ranks' ranges: the lower index wins

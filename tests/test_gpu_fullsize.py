@@ -2,8 +2,10 @@
 properties that do not depend on the size — sortedness, idempotence, batch-split invariance, self-retrieval,
 tombstone monotonicity, recall against the exact scan — plus direct oracle parity on a handful of queries (the CPU
 oracle needs ~1 ms per HNSW query and ~12 ms per 1M-row exact scan, so a few rows at full size are affordable).
-The synthetic base is bench.py's (4096 Gaussian clusters, sigma 20, clipped to [0, 218], rounded).
-C4 / C5 do not fit a test's time budget; their shapes run at 1/8 size in test_gpu_traversal / bench.py."""
+The synthetic base is bench.py's (muopdb_amd.build.SiftLike — block low-rank + noise, clipped to [0, 218], rounded).
+C4 runs at 1/8 of its users and at its FULL size (1024 users x 9766 x 768 = 30.7 GB resident); C5 runs as ONE GPU of the 8
+sees it: rank 0's posting lists of the 100M-row index (12.5 M x 16-byte codes), the full 65 536-centroid coarse quantizer,
+nprobe 64, batch 4096."""
 import numpy as np
 import pytest
 
@@ -41,15 +43,10 @@ def ctx():
 @pytest.fixture(scope="module")
 def base(ctx):
     """(device rows, host rows, 96 host queries): the C2/C3 base of bench.py"""
-    import torch
     from muopdb_amd import build as B
-    ncl = 4096
-    x = B.sift_like(N, D, n_clusters=ncl, seed=1)
-    g = torch.Generator(device="cpu"); g.manual_seed(1)
-    centers = (torch.rand((ncl, D), generator=g) * 218.0).cuda()
-    gq = torch.Generator(device="cpu"); gq.manual_seed(4242)
-    qa = torch.randint(0, ncl, (96,), generator=gq).cuda()
-    q = torch.clamp(torch.round(centers[qa] + (torch.randn((96, D), generator=gq) * 20.0).cuda()), 0, 218)
+    gen = B.SiftLike(D, seed=1)
+    x = gen.draw(N, seed=11)
+    q = gen.draw(96, seed=4242)
     return x, x.cpu().numpy(), q.cpu().numpy().astype(np.float32)
 
 
@@ -184,8 +181,9 @@ def test_c4_shape_multi_user_spann_eighth(ctx, oracle):
     from muopdb_amd.index import MultiSpannIndex, SearchParams
     U, per, d, P = 128, 9766, 768, 16
     users, base = {}, []
+    gen = B.EmbedLike(d, seed=3)
     for u in range(U):
-        x = B.unit_gaussian(per, d, seed=3_000_000 + u)
+        x = gen.draw(gen.user(u), per, seed=3_000_000 + u)
         cent = B.kmeans(x, per // 64, iters=3, seed=u)
         pls = B.posting_lists_from_assignment(B.assign_nearest(x, cent), cent.shape[0])
         hi, hv = B.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
@@ -218,3 +216,115 @@ def test_c4_shape_multi_user_spann_eighth(ctx, oracle):
     for i in range(U):
         merged = sorted([(float(s), dd) for sh in shards for dd, s in sh.id_with_scores(i)])[:K]
         assert [dd for _, dd in merged] == res.doc_ids(i)
+
+
+def test_c4_full_size_multi_user_spann(ctx, oracle):
+    """BASELINE config C4 at its FULL size on one GPU: 1024 users x 9766 x 768 f32 = 10 M x 768 (30.7 GB resident), batch 1024
+    = one (user, query) pair per user.  Size-independent properties, the oracle on 16 users of the full index, and the
+    union of EIGHT posting-list shards (what the 8 GPUs hold) == the unsharded rows on 64 users."""
+    import torch
+    from muopdb_amd import build as B
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import MultiSpannIndex, SearchParams
+    U, per, d, P = 1024, 9766, 768, 16
+    gen = B.EmbedLike(d, seed=3)
+    users, q = {}, []
+    for u in range(U):
+        uc = gen.user(u)
+        x = gen.draw(uc, per, seed=3_000_000 + u)
+        cent = B.kmeans(x, per // 64, iters=2, seed=u)
+        pls = B.posting_lists_from_assignment(B.assign_nearest(x, cent), cent.shape[0])
+        hi, hv = B.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
+        docs = np.arange(u * per, (u + 1) * per, dtype=np.uint64)
+        users[u + 1] = dict(hnsw_index=hi, hnsw_vectors=hv, ivf_index=F.write_ivf_index(cent.cpu().numpy(), docs, pls),
+                            ivf_vectors=F.write_vector_file(x.cpu().numpy()))
+        q.append(gen.draw(uc, 1, seed=7_000_000 + u).cpu().numpy()[0])
+    del x
+    torch.cuda.empty_cache()
+    cat = F.concat_multi_spann(users)
+    del users
+    assert len(cat["ivf_vectors"]) > 30_000_000_000
+    args = (cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+    g = MultiSpannIndex(ctx, *args)
+    assert g.num_users() == U
+    uids = [u + 1 for u in range(U)]
+    q = np.stack(q).astype(np.float32)
+    p = SearchParams(K, 200).with_num_explored_centroids(P).with_centroid_distance_ratio(0.1)
+    res = g.search_for_user(uids, q, p)                                                           # batch 1024
+    assert all(res.found[i] for i in range(U))
+    assert_sorted(res, U)
+    whole = rows_of(res, U)
+    assert rows_of(g.search_for_user(uids, q, p), U) == whole                                     # idempotent
+    for lo, hi in [(0, 1), (1, 300), (300, U)]:                                                   # any batch composition
+        assert rows_of(g.search_for_user(uids[lo:hi], q[lo:hi], p), hi - lo) == whole[lo:hi]
+    for u in range(U):                                                                            # every hit belongs to the query's user
+        assert all(u * per <= dd < (u + 1) * per for dd in res.doc_ids(u))
+    rev = list(range(U - 1, -1, -1))                                                              # batch order is irrelevant
+    rr = rows_of(g.search_for_user([uids[i] for i in rev], q[rev], p), U)
+    assert [rr[U - 1 - i] for i in range(U)] == whole
+    wide = g.search_for_user(uids[:64], q[:64], SearchParams(K, 200).with_num_explored_centroids(64).with_centroid_distance_ratio(0.3))
+    for i in range(64):                                                                           # a superset of lists: k-th score can only improve
+        assert float(wide.scores[i, K - 1]) <= float(res.scores[i, K - 1])
+    sel = [0, 1, 2, 3, 100, 101, 500, 511, 512, 777, 1000, 1020, 1021, 1022, 1023, 640]
+    o = oracle.MultiSpannIndex(*args)
+    op = oracle.SearchParams(K, 200, num_explored_centroids=P, centroid_distance_ratio=0.1)
+    assert rows_of(o.search_for_user([uids[i] for i in sel], q[sel], op), len(sel)) == [whole[i] for i in sel]
+    del o
+    g.close()
+    sub = list(range(0, U, 16))                                                                   # 64 users through 8 list shards
+    parts = []
+    for r in range(8):
+        sh = MultiSpannIndex(ctx, *args, None, r, 8)
+        parts.append(sh.search_for_user([uids[i] for i in sub], q[sub], p))
+        sh.close()
+    for j, i in enumerate(sub):
+        merged = sorted([(float(s), dd) for sh in parts for dd, s in sh.id_with_scores(j)])[:K]
+        assert [dd for _, dd in merged] == res.doc_ids(i)
+
+
+def test_c5_shard_ivfpq(ctx, oracle):
+    """BASELINE config C5 as one GPU of the 8 runs it (ivf/block_based/index.rs:147-163, 250-286): rank 0's posting lists
+    (l % 8 == 0, ~12.5 M x 16-byte PQ codes) of the 100M x 128 index, the FULL replicated coarse quantizer (65 536
+    centroids), nprobe 64, batch 4096.  Properties (sorted, idempotent, batch-split invariant, tombstone monotone), the oracle's
+    rows on 12 queries, and the coarse search sharded over a simulated world of 8 == the unsharded probe ids."""
+    import torch
+    from muopdb_amd import build as B
+    from muopdb_amd.distributed import coarse_range
+    from muopdb_amd.index import BlockBasedIvf
+    sh = B.c5_shard(ctx, total=100_000_000, world=8, rank=0, nlist=65536)
+    torch.cuda.empty_cache()
+    assert sh["nlist"] == 65536 and 11_000_000 < sh["n"] < 14_000_000 and sh["owned_lists"] > 8000
+    g = BlockBasedIvf(ctx, sh["index"], sh["vectors"], sh["pq"])
+    assert g.num_vectors() == sh["n"] and g.num_clusters() == 65536
+    P, B_ = 64, 4096
+    q = sh["gen"].draw(B_, seed=5000).cpu().numpy()
+    res = g.search(q, K, P)                                                                # the configuration's batch
+    assert_sorted(res, B_)
+    whole = rows_of(res, B_)
+    assert sum(len(r[0]) == K for r in whole) > B_ * 0.9                                   # ~8 owned probes x ~1500 codes per query
+    assert rows_of(g.search(q, K, P), B_) == whole                                         # idempotent
+    for lo, hi in [(0, 1), (1, 6), (6, 500), (500, 1525)]:                                 # batch-split invariance (exact / batched coarse paths)
+        assert rows_of(g.search(q[lo:hi], K, P), hi - lo) == whole[lo:hi]
+    probes = g.find_nearest_centroids(q[:256], P)
+    assert np.array_equal(probes[:4], g.find_nearest_centroids(q[:4], P))                  # batched (MFMA-filtered) == exact coarse kernels
+    rows = []
+    for r in range(8):                                                                     # sharded coarse search, simulated world of 8
+        first, count = coarse_range(65536, r, 8)
+        rows.append(g.coarse_keys(q[:256], P, first, count))
+    assert np.array_equal(g.merge_coarse_keys(np.stack(rows, axis=1), P), probes)
+    assert rows_of(g.search_with_centroids_and_remap(q[:256], probes, K), 256) == whole[:256]
+    o = oracle.BlockBasedIvf(sh["index"], sh["vectors"], oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, sh["codebook"]))
+    assert np.array_equal(o.find_nearest_centroids(q[:12], P), probes[:12])
+    assert rows_of(o.search(q[:12], K, num_probes=P), 12) == whole[:12]                    # the oracle on the full shard
+    more = g.search(q[:64], K, 2 * P)                                                      # more probes: the k-th score can only improve
+    for i in range(64):
+        if len(whole[i][0]) == K:
+            assert float(more.scores[i, K - 1]) <= float(res.scores[i, K - 1])
+    victims = sorted({res.doc_ids(i)[0] for i in range(12) if res.doc_ids(i)})             # tombstones are monotone
+    for doc in victims:
+        assert g.invalidate(doc) and o.invalidate(doc)
+    after = g.search(q[:12], K, P)
+    assert rows_of(o.search(q[:12], K, num_probes=P), 12) == rows_of(after, 12)
+    for i in range(12):
+        kept = [dd for dd in res.doc_ids(i) if dd not in victims]
+        assert after.doc_ids(i)[:len(kept)] == kept

@@ -439,6 +439,30 @@ def test_merge_shards_device(ctx):
         assert int(ocn[qi]) == len(rows)
         got = [(float(osc[qi, j]), (int(od[qi, j, 1]) << 64) | int(od[qi, j, 0])) for j in range(len(rows))]
         assert got == rows
+    # the packed form: one block per rank as ONE all-gather delivers them (PackedTopkGather with no process group = one
+    # rank; here the `world` blocks are laid out by hand) -> mdb_merge_shards_packed == mdb_merge_shards
+    from muopdb_amd import distributed as D
+    nb = D.block_bytes(b, k)
+    assert nb == int(ctx.lib.mdb_shard_block_bytes(C.c_size_t(b), C.c_size_t(k))) and nb % 16 == 0
+    recv = torch.zeros(world * nb, dtype=torch.uint8, device=dev)
+    for w in range(world):
+        vi, vs, vc = D.block_views(recv[w * nb:(w + 1) * nb], b, k)
+        vi.copy_(t_docs[w]); vs.copy_(t_sc[w]); vc.copy_(t_cn[w])
+    p_docs, p_sc, p_cn = torch.zeros_like(o_docs), torch.zeros_like(o_sc), torch.zeros_like(o_cn)
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.mdb_merge_shards_packed(ctx.h, C.c_void_p(recv.data_ptr()), C.c_size_t(world), C.c_size_t(b), C.c_size_t(k),
+                                              C.c_void_p(p_docs.data_ptr()), C.c_void_p(p_sc.data_ptr()), C.c_void_p(p_cn.data_ptr())))
+    ctx.sync()
+    assert torch.equal(p_docs, o_docs) and torch.equal(p_sc, o_sc) and torch.equal(p_cn, o_cn)
+    one = D.PackedTopkGather(ctx, b, k, dev)          # world 1: gather is a copy, merge re-ranks by (score, doc id)
+    one.ids.copy_(t_docs[0]); one.scores.copy_(t_sc[0]); one.counts.copy_(t_cn[0])
+    torch.cuda.synchronize()
+    gd, gs, gc = one.gather_merge()
+    ctx.sync()
+    assert torch.equal(gc, t_cn[0])
+    # mdb_allgather_merge refuses a null communicator instead of touching RCCL
+    assert ctx.lib.mdb_allgather_merge(ctx.h, None, C.c_void_p(recv.data_ptr()), C.c_void_p(recv.data_ptr()), C.c_size_t(1), C.c_size_t(b),
+                                       C.c_size_t(k), C.c_void_p(p_docs.data_ptr()), C.c_void_p(p_sc.data_ptr()), None) == L.MDB_ERR_INVALID_ARG
 
 
 # ----------------------------------------------------------------------------------- planner hook
