@@ -58,7 +58,8 @@ def measured_traffic(kind, cfg):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         with open(path) as f:
             e = json.load(f).get(kind)
-        if e and all(cfg.get(k) == v for k, v in e["match"].items()):
+        # round 1's passes (no "data" key) were taken on the legacy generators
+        if e and e["match"].get("data", "legacy") == cfg.get("data") and all(cfg.get(k) == v for k, v in e["match"].items() if k != "data"):
             return (e["fetch_kib"] * e["fetch_correction"] + e["write_kib"]) * 1024.0, os.path.relpath(path, ROOT)
     return None, None
 
@@ -103,6 +104,9 @@ def parse():
     p.add_argument("--streams", type=int, default=4, help="hnsw: extra measurement with this many batches in flight (0/1 = skip)")
     p.add_argument("--dump-dir", default=None, help="write index files + queries for examples/replay_search.cpp")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
+    p.add_argument("--sift-clusters", type=int, default=None, help="SiftLike mixture components (generator exploration)")
+    p.add_argument("--sift-sigma", type=float, default=None)
+    p.add_argument("--sift-noise", type=float, default=None)
     return p.parse_args()
 
 
@@ -155,7 +159,9 @@ class Env:
             qa = torch.randint(0, ncl, (nq,), generator=gq).cuda()
             q = torch.clamp(torch.round(centers[qa] + (torch.randn((nq, d), generator=gq) * 20.0).cuda()), 0, 218).contiguous()
             return self._sift[1], q, "%d isotropic Gaussian clusters, sigma 20, clipped [0,218] (round-1 generator)" % ncl
-        gen = B.SiftLike(d, seed=1)
+        kw = {k: v for k, v in (("n_clusters", self.args.sift_clusters), ("sigma", self.args.sift_sigma), ("noise", self.args.sift_noise))
+              if v is not None}
+        gen = B.SiftLike(d, seed=1, **kw)
         if self._sift is None or self._sift[0] != (n, d):
             self._sift = ((n, d), gen.draw(n, seed=11))
         return self._sift[1], gen.draw(nq, seed=qseed).contiguous(), \

@@ -113,6 +113,10 @@ void mdb_device_close(mdb_ctx* ctx);
 mdb_status mdb_set_stream(mdb_ctx* ctx, void* hip_stream);
 /* wait for the stream; returns the first deferred error of MDB_MEM_DEVICE calls (e.g. MDB_ERR_NAN) */
 mdb_status mdb_sync(mdb_ctx* ctx);
+/* completes the context's pending mdb_*_search_submit call (no-op without one): waits for the stream, copies the results
+ * into the caller's buffers given at submit time and returns the call's status */
+mdb_status mdb_wait(mdb_ctx* ctx);
+int mdb_poll(mdb_ctx* ctx);
 const char* mdb_last_error(mdb_ctx* ctx);
 mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out);
 const char* mdb_version(void);
@@ -213,6 +217,27 @@ mdb_status mdb_ivf_search_points(mdb_ivf* ivf, const float* queries, size_t b, c
  * Host bitmaps are copied; device bitmaps are borrowed until cleared.  Filtered points are skipped BEFORE the
  * distance (the reference drops them after it). */
 mdb_status mdb_ivf_set_filter(mdb_ivf* ivf, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem);
+/* The planner as a PER-CALL argument, the way the reference passes it (scan_posting_list(.., planner), index.rs:175-237):
+ * mdb_ivf_search with allow bitmaps that apply to THIS call only (allow == NULL: no filter).  `allow` lives where `mem`
+ * says; n_bitmaps == 1 -> one bitmap for every query, otherwise at least b bitmaps (one per query), each of
+ * words_per_bitmap >= ceil(num_vectors / 32) u32 words — anything shorter is MDB_ERR_INVALID_ARG, never an
+ * out-of-bounds read.  Two host threads with different filters on handles over one index do not interact.
+ * mdb_ivf_set_filter above is the DEPRECATED stateful form (handle-global until cleared). */
+mdb_status mdb_ivf_search_filtered(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
+                                   mdb_mem mem, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap,
+                                   mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out);
+/* A second handle over the SAME resident posting lists / codes / centroids, bound to another context (own stream,
+ * scratch and staging): searches through different handles run concurrently over ONE copy of the index — the
+ * reference shares one immutable `BlockBasedIvf` between tokio tasks (segment/mod.rs:273-274, `Quantizer: Send + Sync`).
+ * Tombstones are shared (one `invalid_point_ids` set per index); memory is released with the last handle. */
+mdb_status mdb_ivf_attach(mdb_ctx* ctx, mdb_ivf* src, mdb_ivf** out);
+/* Asynchronous host-buffer call for hosts that overlap batches (a tokio task per batch): returns once the copies and
+ * kernels are ENQUEUED on the handle's context; queries / probes / bitmaps may be reused at once, the output buffers are
+ * filled by mdb_wait(ctx), which also reports the deferred status (MDB_ERR_NAN ...).  One pending call per context —
+ * keep several in flight with one context + attached handle each.  mdb_poll(ctx) != 0 when mdb_wait would not block. */
+mdb_status mdb_ivf_search_submit(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
+                                 const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_u128* doc_ids_out,
+                                 float* scores_out, uint32_t* counts_out);
 mdb_status mdb_ivf_invalidate(mdb_ivf* ivf, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
 mdb_status mdb_ivf_is_invalidated(mdb_ivf* ivf, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
 
@@ -229,6 +254,9 @@ void mdb_hnsw_free(mdb_hnsw* hnsw);
  * device memory is released when the last handle over it is freed, in any order. */
 mdb_status mdb_hnsw_attach(mdb_ctx* ctx, mdb_hnsw* src, mdb_hnsw** out);
 size_t mdb_hnsw_num_vectors(const mdb_hnsw* hnsw);
+/* asynchronous host-buffer form of mdb_hnsw_ann_search (see mdb_ivf_search_submit / mdb_wait) */
+mdb_status mdb_hnsw_ann_search_submit(mdb_hnsw* hnsw, const float* queries, size_t b, size_t k, uint32_t ef, mdb_u128* doc_ids_out,
+                                      float* scores_out, uint32_t* counts_out);
 /* ann_search :159-210 — results ordered by (distance, point id), truncated to k */
 mdb_status mdb_hnsw_ann_search(mdb_hnsw* hnsw, const float* queries, size_t b, size_t k, uint32_t ef, mdb_mem mem,
                                mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out);
@@ -246,6 +274,14 @@ void mdb_spann_free(mdb_spann* spann);
 mdb_status mdb_spann_search(mdb_spann* spann, const float* queries, size_t b, const mdb_search_params* params,
                             mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out,
                             uint8_t* found_out);
+/* per-call planner filter / shared-index handle / asynchronous submit: see the mdb_ivf_* forms */
+mdb_status mdb_spann_search_filtered(mdb_spann* spann, const float* queries, size_t b, const mdb_search_params* params, mdb_mem mem,
+                                     const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_u128* doc_ids_out,
+                                     float* scores_out, uint32_t* counts_out, uint8_t* found_out);
+mdb_status mdb_spann_attach(mdb_ctx* ctx, mdb_spann* src, mdb_spann** out);
+mdb_status mdb_spann_search_submit(mdb_spann* spann, const float* queries, size_t b, const mdb_search_params* params,
+                                   const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_u128* doc_ids_out,
+                                   float* scores_out, uint32_t* counts_out, uint8_t* found_out);
 mdb_status mdb_spann_set_filter(mdb_spann* spann, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem);
 mdb_status mdb_spann_invalidate(mdb_spann* spann, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
 mdb_status mdb_spann_is_invalidated(mdb_spann* spann, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
@@ -268,7 +304,18 @@ size_t mdb_multi_spann_num_users(const mdb_multi_spann* ms);
 mdb_status mdb_multi_spann_search(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
                                   const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out,
                                   float* scores_out, uint32_t* counts_out, uint8_t* found_out);
-/* planner hook: bitmaps are over the USER-LOCAL point ids of each query's user (see mdb_ivf_set_filter) */
+/* per-call planner filter (bitmaps over the USER-LOCAL point ids of each query's user, words_per_bitmap covering the
+ * largest user) / shared-index handle / asynchronous submit: see the mdb_ivf_* forms */
+mdb_status mdb_multi_spann_search_filtered(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                           const mdb_search_params* params, mdb_mem mem, const uint32_t* allow, size_t n_bitmaps,
+                                           size_t words_per_bitmap, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out,
+                                           uint8_t* found_out);
+mdb_status mdb_multi_spann_attach(mdb_ctx* ctx, mdb_multi_spann* src, mdb_multi_spann** out);
+mdb_status mdb_multi_spann_search_submit(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                         const mdb_search_params* params, const uint32_t* allow, size_t n_bitmaps,
+                                         size_t words_per_bitmap, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out,
+                                         uint8_t* found_out);
+/* DEPRECATED stateful planner hook: bitmaps are over the USER-LOCAL point ids of each query's user (see mdb_ivf_set_filter) */
 mdb_status mdb_multi_spann_set_filter(mdb_multi_spann* ms, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap,
                                       mdb_mem mem);
 mdb_status mdb_multi_spann_invalidate(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,

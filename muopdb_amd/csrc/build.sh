@@ -8,18 +8,21 @@ SRCS="mdb_core.hip mdb_flat.hip mdb_flat_mfma.hip mdb_ef.hip mdb_ivf.hip mdb_hns
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-variable $MDB_EXTRA_FLAGS"
 mkdir -p build
 objs=""
+pids=""
 for s in $SRCS; do
   [ -f "$s" ] || continue
   o=build/${s%.hip}.o
   stale=0
-  for h in *.h *.cuh ../../include/muopdb_hip.h; do [ "$h" -nt "$o" ] && stale=1; done
+  for h in *.h ../../include/muopdb_hip.h; do [ "$h" -nt "$o" ] && stale=1; done
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ $stale = 1 ]; then
     echo "hipcc $s"
+    rm -f "$o"   # a failed compile must never leave a stale object for the link step
     hipcc $FLAGS -c "$s" -o "$o" &
+    pids="$pids $!"
   fi
   objs="$objs $o"
 done
-wait
+for p in $pids; do wait "$p" || { echo "build.sh: a translation unit failed to compile" >&2; exit 1; }; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
 echo "built $OUT"
 # C++ host mirror demo (include/muopdb_host.hpp over the C ABI; plain g++, no HIP headers needed)

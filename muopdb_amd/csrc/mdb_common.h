@@ -43,8 +43,14 @@ struct mdb_ctx {
     size_t prof_used = 0;
     // pinned host staging for MDB_MEM_HOST calls: [0] inputs, [1] outputs.  Pageable hipMemcpyAsync costs ~0.2 ms a call
     // on this stack; user buffer <-> pinned is a CPU memcpy, pinned <-> device a true async copy.
-    void* pinned[2] = {nullptr, nullptr};
-    size_t pinned_cap[2] = {0, 0};
+    // [2] per-call filter bitmaps, [3] small auxiliary inputs (per-query user indices, probe lists)
+    void* pinned[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pinned_cap[4] = {0, 0, 0, 0};
+    // asynchronous host-buffer calls (mdb_*_search_submit / mdb_wait): the result copies of ONE pending call
+    bool submit_mode = false;
+    struct PendingCopy { void* dst; size_t off, bytes; };
+    std::vector<PendingCopy> pending;
+    bool has_pending = false;
     std::mutex mu;
     // index handles keep their context alive: mdb_device_close drops the caller's reference and the
     // context is destroyed with the last handle (so free order does not matter to the caller)
@@ -192,3 +198,19 @@ struct PqDev {
 static inline uint32_t rd_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static inline uint64_t rd_u64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) & ~(a - 1); }
+// overflow-checked a + b <= limit
+static inline bool fits(uint64_t a, uint64_t b, uint64_t limit) { return a <= limit && b <= limit - a; }
+// Host-side validation of one serialized Elias-Fano list (ef.rs:197-215 header: n, L, lower_words, upper_words) of `avail`
+// bytes BEFORE the device decoder trusts it: a corrupt header would otherwise make ef_low_bits read lower[w + 1] past the
+// blob, or shift by >= 64.  The encoder writes lower_words == ceil(n * L / 64) and at least n upper bits.
+static inline const char* ef_header_error(const uint8_t* p, uint64_t avail, uint64_t max_n) {
+    if (avail < 32) return "Not enough metadata for EliasFano encoded data";
+    const uint64_t n = rd_u64(p), L = rd_u64(p + 8), lw = rd_u64(p + 16), uw = rd_u64(p + 24);
+    const uint64_t words = (avail - 32) / 8;
+    if (lw > words || uw > words - lw) return "EliasFano list truncated (word counts exceed the blob)";
+    if (L >= 64) return "EliasFano lower_bit_length >= 64";
+    if (n > max_n) return "EliasFano num_elem exceeds the number of vectors";
+    if (n && L && (n > (~0ull) / L || lw < (n * L + 63) / 64)) return "EliasFano lower_words < ceil(num_elem * lower_bit_length / 64)";
+    if (uw > (~0ull) / 64 || uw * 64 < n) return "EliasFano upper stream shorter than num_elem bits";
+    return nullptr;
+}

@@ -2,7 +2,7 @@
 // (distance pairs, PQ quantize / distance, Elias-Fano decode).
 #include <cstdarg>
 
-#include "mdb_device.cuh"
+#include "mdb_device.hip.h"
 #include "mdb_kernels.h"
 
 mdb_status mdb_fail(mdb_ctx* ctx, mdb_status st, const char* fmt, ...) {
@@ -69,6 +69,19 @@ mdb_status mdb_return_to_host(mdb_ctx* ctx, const HostCopy* items, int n) {
         MDB_HIP(ctx, hipMemcpyAsync(stage + off, items[i].src, items[i].bytes, hipMemcpyDeviceToHost, ctx->stream));
         off += align_up(items[i].bytes, 64);
     }
+    if (ctx->submit_mode) {  // mdb_*_search_submit: everything is enqueued; mdb_wait finishes the call
+        ctx->pending.clear();
+        off = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!items[i].dst || !items[i].bytes) continue;
+            ctx->pending.push_back({items[i].dst, off, items[i].bytes});
+            off += align_up(items[i].bytes, 64);
+        }
+        MDB_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4, ctx->stream));
+        ctx->has_pending = true;
+        return MDB_OK;
+    }
     mdb_status st = mdb_check_flags(ctx);  // flags copy + the stream sync
     off = 0;
     for (int i = 0; i < n; ++i) {
@@ -77,6 +90,32 @@ mdb_status mdb_return_to_host(mdb_ctx* ctx, const HostCopy* items, int n) {
         off += align_up(items[i].bytes, 64);
     }
     return st;
+}
+
+static mdb_status flags_to_status(mdb_ctx* ctx, uint32_t f) {
+    if (f & MDB_FLAG_NAN) return mdb_fail(ctx, MDB_ERR_NAN, "a distance evaluated to NaN (reference: NotNan::new(..).unwrap() panics)");
+    if (f & MDB_FLAG_OVERFLOW) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "traversal state exceeded the on-chip capacity");
+    if (f & MDB_FLAG_RANGE) return mdb_fail(ctx, MDB_ERR_FORMAT, "index refers to a point id outside the vector storage");
+    return MDB_OK;
+}
+
+extern "C" mdb_status mdb_wait(mdb_ctx* ctx) {
+    if (!ctx) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->has_pending) return MDB_OK;
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_pending = false;
+    const char* stage = (const char*)ctx->pinned[1];
+    for (auto& c : ctx->pending) memcpy(c.dst, stage + c.off, c.bytes);
+    ctx->pending.clear();
+    return flags_to_status(ctx, *ctx->h_flags);
+}
+
+extern "C" int mdb_poll(mdb_ctx* ctx) {
+    if (!ctx || !ctx->has_pending) return 1;
+    (void)hipSetDevice(ctx->device);
+    return hipStreamQuery(ctx->stream) == hipSuccess ? 1 : 0;
 }
 
 void mdb_ctx_retain(mdb_ctx* ctx) { ctx->refs.fetch_add(1); }
@@ -91,7 +130,7 @@ void mdb_ctx_release(mdb_ctx* ctx) {
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
         if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
     for (auto& ev : ctx->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

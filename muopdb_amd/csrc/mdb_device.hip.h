@@ -1,4 +1,4 @@
-// mdb_device.cuh — device-side building blocks (gfx950, wave64):
+// mdb_device.hip.h — device-side building blocks (gfx950, wave64):
 //   * exact-association distances: the reference's 16/8/4/scalar lane cascade
 //     (rs/utils/src/distance/l2.rs:32-89, dot_product.rs:38-89) with per-lane partial sums,
 //     separately rounded mul/add (__fmul_rn/__fadd_rn: never contracted to FMA) and an

@@ -8,7 +8,7 @@
 // owns a contiguous run of upper words, a block scan of popcounts gives every 1 bit its element
 // index, so all elements decode in parallel.  Integer, HBM-bound: (2+L)/8 B read + 4 B written
 // per id.
-#include "mdb_device.cuh"
+#include "mdb_device.hip.h"
 #include "mdb_kernels.h"
 
 __device__ __forceinline__ uint64_t ef_low_bits(const uint64_t* __restrict__ lower, uint64_t idx, uint32_t L) {
@@ -79,9 +79,8 @@ extern "C" mdb_status mdb_ef_decode(mdb_ctx* ctx, const uint8_t* blob, size_t bl
     if (!ctx || !blob || !n_out) return MDB_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(ctx->mu);
     MDB_HIP(ctx, hipSetDevice(ctx->device));
-    if (blob_len < 32) return mdb_fail(ctx, MDB_ERR_FORMAT, "Not enough metadata for EliasFano encoded data");
-    uint64_t n = rd_u64(blob), lw = rd_u64(blob + 16), uw = rd_u64(blob + 24);
-    if (32 + (lw + uw) * 8 > blob_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "EliasFano blob truncated");
+    if (const char* why = ef_header_error(blob, blob_len, (blob_len / 8) * 64)) return mdb_fail(ctx, MDB_ERR_FORMAT, "%s", why);
+    uint64_t n = rd_u64(blob);
     *n_out = n;
     if (n == 0) return MDB_OK;
     void *db, *dmeta, *dout;

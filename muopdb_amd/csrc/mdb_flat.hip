@@ -8,7 +8,7 @@
 // 16 B loads while keeping the reference's 16 partial sums in registers (one thread = one
 // vector = bit-exact lane association, no cross-lane reduction).  Queries are wave-uniform
 // (scalar loads).  Bound: HBM (N*d*4 bytes per pass); VALU = 3 ops per element per query.
-#include "mdb_device.cuh"
+#include "mdb_device.hip.h"
 #include "mdb_kernels.h"
 
 // ------------------------------------------------------------------------------------------ relayout
@@ -63,6 +63,7 @@ mdb_status stage_queries(mdb_ctx* ctx, int slot, const float* queries, size_t b,
     MDB_TRY(mdb_scratch(ctx, slot, bpad * (size_t)qs * 4 + 64, &dq));
     const float* src = queries;
     if (mem == MDB_MEM_HOST) {
+        if (ctx->has_pending) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "a submitted call is pending on this context: call mdb_wait first");
         void* raw;
         MDB_TRY(mdb_scratch(ctx, slot + 1, b * (size_t)d * 4 + 16, &raw));
         // caller's (pageable) rows -> pinned staging on the CPU, then a true async copy; every MDB_MEM_HOST call ends with a

@@ -22,7 +22,7 @@
 #include <cmath>
 
 #include "mdb_common.h"
-#include "mdb_device.cuh"
+#include "mdb_device.hip.h"
 #include "mdb_kernels.h"
 
 #define MF_CAP 4096  // candidates refined per query (more => the batch falls back to the exact scan)
@@ -73,6 +73,15 @@ __global__ void centre_tiles_kernel(const float4* __restrict__ src, size_t total
 
 FlatAux::~FlatAux() {
     if (h_ovf) (void)hipHostFree(h_ovf);
+}
+
+void flat_aux_view(const FlatAux& src, FlatAux& dst) {
+    dst.sample.data.borrow(src.sample.data);
+    dst.sample.n = src.sample.n; dst.sample.ntiles = src.sample.ntiles; dst.sample.d = src.sample.d; dst.sample.d4 = src.sample.d4;
+    dst.ctiles.borrow(src.ctiles);
+    dst.mean.borrow(src.mean);
+    dst.cooldown = 0;
+    if (src.sample.n && !dst.h_ovf && hipHostMalloc((void**)&dst.h_ovf, 4) == hipSuccess) *dst.h_ovf = 0;
 }
 
 mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles) {

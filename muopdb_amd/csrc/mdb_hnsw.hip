@@ -22,7 +22,7 @@
 // Bound: HBM random-gather LATENCY (d*4 + 4 B per distance evaluation), not bandwidth.
 #include <atomic>
 
-#include "mdb_device.cuh"
+#include "mdb_device.hip.h"
 #include "mdb_hnsw.h"
 #include "mdb_kernels.h"
 
@@ -1158,7 +1158,7 @@ __global__ void pq_rows_kernel(const uint8_t* __restrict__ src, const uint64_t* 
 
 // ------------------------------------------------------------------------------------------ load
 static mdb_status parse_hnsw_blob(mdb_ctx* ctx, const uint8_t* b, size_t len, size_t data_offset, HnswBlobInfo& o) {
-    if (data_offset + 49 > len) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW index: header out of bounds");
+    if (!fits(data_offset, 49, len)) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW index: header out of bounds");
     const uint8_t* h = b + data_offset;
     if (h[0] != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "Unknown version: %d", (int)h[0]);
     o.quantized_dimension = rd_u32(h + 1);
@@ -1168,6 +1168,9 @@ static mdb_status parse_hnsw_blob(mdb_ctx* ctx, const uint8_t* b, size_t len, si
     o.edge_offsets_len = rd_u64(h + 25);
     o.level_offsets_len = rd_u64(h + 33);
     o.doc_id_mapping_len = rd_u64(h + 41);
+    // section lengths come from the file: reject any that cannot fit before forming offsets (overflow-safe)
+    if (o.edges_len > len || o.points_len > len || o.edge_offsets_len > len || o.level_offsets_len > len || o.doc_id_mapping_len > len)
+        return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW index: sections out of bounds");
     size_t off = data_offset + 49;  // calculate_offsets, graph_storage.rs:170-196
     o.edges_offset = off + (4 - (off % 4)) % 4;
     o.points_offset = o.edges_offset + o.edges_len;
@@ -1208,9 +1211,9 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
         MDB_TRY(parse_hnsw_blob(ctx, index, index_len, offsets[ui].first, bi));
         if (bi.quantized_dimension != file_qdim) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW quantized_dimension %u != %u", bi.quantized_dimension, file_qdim);
         size_t voff = offsets[ui].second;
-        if (voff + 8 > vectors_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file: header out of bounds");
+        if (!fits(voff, 8, vectors_len)) return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file: header out of bounds");
         uint64_t nv = rd_u64(vectors + voff);
-        if (voff + 8 + nv * file_row > vectors_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file truncated");
+        if (file_row == 0 || nv > (vectors_len - voff - 8) / file_row) return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file truncated");
         if (kind != MDB_QUANT_PQ && (voff + 8) % 4 != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "f32 vector file is not 4-byte aligned");
         if (nv > 0xFFFFFFFEull) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "point ids are u32");
         bi.num_vectors = nv;
@@ -1549,14 +1552,32 @@ mdb_status mdb_hnsw_attach(mdb_ctx* ctx, mdb_hnsw* src, mdb_hnsw** out) {
 
 size_t mdb_hnsw_num_vectors(const mdb_hnsw* h) { return h ? (size_t)h->set.blobs[0].num_vectors : 0; }
 
+static mdb_status hnsw_ann_search_impl(mdb_hnsw* h, const float* queries, size_t b, size_t k, uint32_t ef, mdb_mem mem,
+                                       mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out, bool submit);
+
 mdb_status mdb_hnsw_ann_search(mdb_hnsw* h, const float* queries, size_t b, size_t k, uint32_t ef, mdb_mem mem,
                                mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out) {
+    return hnsw_ann_search_impl(h, queries, b, k, ef, mem, doc_ids_out, scores_out, counts_out, false);
+}
+
+mdb_status mdb_hnsw_ann_search_submit(mdb_hnsw* h, const float* queries, size_t b, size_t k, uint32_t ef, mdb_u128* doc_ids_out,
+                                      float* scores_out, uint32_t* counts_out) {
+    return hnsw_ann_search_impl(h, queries, b, k, ef, MDB_MEM_HOST, doc_ids_out, scores_out, counts_out, true);
+}
+
+static mdb_status hnsw_ann_search_impl(mdb_hnsw* h, const float* queries, size_t b, size_t k, uint32_t ef, mdb_mem mem,
+                                       mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out, bool submit) {
     if (!h || (!queries && b) || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
     HnswSet& s = h->set;
     mdb_ctx* ctx = s.ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     MDB_HIP(ctx, hipSetDevice(ctx->device));
     if (b == 0) return MDB_OK;
+    struct SubmitScope {  // mdb_hnsw_ann_search_submit: mdb_return_to_host enqueues instead of synchronising
+        mdb_ctx* c; bool on;
+        SubmitScope(mdb_ctx* c_, bool on_) : c(c_), on(on_) { if (on) c->submit_mode = true; }
+        ~SubmitScope() { if (on) c->submit_mode = false; }
+    } submit_scope(ctx, submit && mem == MDB_MEM_HOST);
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     float* dq;
     int qstride;

@@ -1,6 +1,7 @@
 // mdb_ivf.h — IvfSet: one or many (multi-user) IVF blobs resident in HBM, shared by the
 // single-index, SPANN and multi-user SPANN handles.
 #pragma once
+#include <mutex>
 #include <unordered_map>
 #include <utility>
 
@@ -53,11 +54,24 @@ struct IvfSet {
     DevBuf<float> d_cent_tiles;       // centroids, per user, SoA tiles
     PqDev pq;
     int mw = 0;
-    // Planner hook: per-query allow bitmaps over point ids applied by scan() until cleared
-    const uint32_t* flt = nullptr;
-    size_t flt_stride = 0, ones_word = 0;
+    // Planner hook (scan_posting_list, index.rs:214-226): allow bitmaps over point ids.  The reference passes the planner
+    // PER CALL; so does scan() (ScanFilter argument).  The stateful form (set_filter, deprecated) stores one here.
+    struct ScanFilter {
+        const uint32_t* allow = nullptr;  // device; nullptr = no filter
+        size_t n_bitmaps = 0, words = 0;  // n_bitmaps == 1: shared by every query, else >= batch
+    };
+    ScanFilter flt;
+    size_t ones_word = 0;
+    uint64_t max_user_vectors = 0;        // bitmaps must cover every point id of every user
     DevBuf<uint32_t> flt_own;
     std::vector<std::unordered_map<U128Key, uint32_t, U128Hash>> doc_maps;
+    // attached view (mdb_*_attach): device arrays borrowed from `root`, own context / scratch; the mutable host state
+    // (tombstone mirror, doc-id maps) lives in the root and is guarded by its tomb_mu
+    IvfSet* root = nullptr;
+    std::mutex tomb_mu;
+    void view_of(IvfSet& src, mdb_ctx* ctx2);
+    // validates a per-call filter against the batch size and the largest point id; host bitmaps are staged (async, pinned)
+    mdb_status stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem, size_t b, ScanFilter* out);
 
     mdb_status load(mdb_ctx* ctx, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
                     const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant,
@@ -72,7 +86,8 @@ struct IvfSet {
     mdb_status coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes,
                       bool zero_counters = false, size_t bpad = 0);  // zero_counters: its merge kernel also clears the context's device counters
     mdb_status scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
-                    const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts);
+                    const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts,
+                    const ScanFilter* filter = nullptr);
     mdb_status remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,
                      mdb_u128* d_doc, float* d_score, uint32_t* d_counts_out);
     // algorithmic bytes per scored vector

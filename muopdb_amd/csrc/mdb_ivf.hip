@@ -18,7 +18,7 @@
 #include <type_traits>
 #include <unordered_map>
 
-#include "mdb_device.cuh"
+#include "mdb_device.hip.h"
 #include "mdb_ivf.h"
 #include "mdb_kernels.h"
 
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void remap_kernel(const uint64_t* __restrict__
 
 // ------------------------------------------------------------------------------------------ IvfSet: load
 static mdb_status parse_ivf_blob(mdb_ctx* ctx, const uint8_t* b, size_t len, size_t offset, IvfBlobInfo& o) {
-    if (offset + 45 > len) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: header out of bounds");
+    if (!fits(offset, 45, len)) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: header out of bounds");
     const uint8_t* h = b + offset;
     if (h[0] != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "Unknown version: %d", (int)h[0]);
     o.num_features = rd_u32(h + 1);
@@ -722,17 +722,20 @@ static mdb_status parse_ivf_blob(mdb_ctx* ctx, const uint8_t* b, size_t len, siz
     o.num_vectors = rd_u64(h + 13);
     uint64_t doc_len = rd_u64(h + 21), cent_len = rd_u64(h + 29);
     o.doc_id_mapping_offset = offset + align_up(45, 16);                 // storage.rs:66-67
+    // every section length comes from the file: all sums below are overflow-checked against the blob length
+    if (!fits(o.doc_id_mapping_offset, doc_len, len - 8)) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: doc-id section out of bounds");
     o.centroid_offset = align_up(o.doc_id_mapping_offset + doc_len, 8);  // :69-72
+    if (!fits(o.centroid_offset, cent_len, len - 8)) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: centroid section out of bounds");
     size_t meta = align_up(o.centroid_offset + cent_len, 8);             // :74-75
-    if (meta + 8 > len) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: metadata out of bounds");
+    if (!fits(meta, 8, len)) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: metadata out of bounds");
     o.num_posting_lists = rd_u64(b + meta);
     o.pl_metadata_offset = meta + 8;
+    if (o.num_posting_lists > (len - o.pl_metadata_offset) / 16) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: posting lists out of bounds");
     o.pl_start_offset = o.pl_metadata_offset + o.num_posting_lists * 16;  // :80-82
-    if (o.pl_start_offset > len) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: posting lists out of bounds");
-    if (o.doc_id_mapping_offset + 16 + o.num_vectors * 16 > len ||
-        o.centroid_offset + 8 + (uint64_t)o.num_clusters * o.num_features * 4 > len)
-        return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: sections out of bounds");
     if (o.num_vectors > 0xFFFFFFFEull) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "point ids are u32");
+    if (!fits(o.doc_id_mapping_offset + 16, o.num_vectors * 16, len) ||
+        (uint64_t)o.num_clusters * o.num_features > (len / 4) || !fits(o.centroid_offset + 8, (uint64_t)o.num_clusters * o.num_features * 4, len))
+        return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: sections out of bounds");
     return MDB_OK;
 }
 
@@ -766,9 +769,10 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
                             bi.num_clusters, (size_t)bi.num_posting_lists);
         const size_t esz = kind == MDB_QUANT_PQ ? 1 : 4;
         size_t voff = offsets[ui].second;
-        if (voff + 8 > vectors_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file: header out of bounds");
+        if (!fits(voff, 8, vectors_len)) return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file: header out of bounds");
         uint64_t nv = rd_u64(vectors + voff);  // async_storage.rs:83-87
-        if (voff + 8 + nv * quantized_dimension * esz > vectors_len)
+        const uint64_t row_bytes = (uint64_t)quantized_dimension * esz;
+        if (row_bytes == 0 || nv > (vectors_len - voff - 8) / row_bytes)
             return mdb_fail(ctx, MDB_ERR_FORMAT, "vector file: %zu vectors of %u x %zu B exceed the file", (size_t)nv,
                             quantized_dimension, esz);
         bi.vec_num_vectors = nv;
@@ -781,6 +785,7 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
         u.doc_ids_off = bi.doc_id_mapping_offset + 16;
         u.tomb_base = (uint32_t)tomb_words;
         tomb_words += (std::max<uint64_t>(bi.num_vectors, nv) + 31) / 32 + 1;
+        max_user_vectors = std::max<uint64_t>(max_user_vectors, std::max<uint64_t>(bi.num_vectors, nv));
         u.cent_tile_base = (uint32_t)cent_tile_src.size();
         for (uint32_t c0 = 0; c0 < bi.num_clusters; c0 += MDB_TILE) {
             cent_tile_src.push_back(bi.centroid_offset + 8);
@@ -789,10 +794,13 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
         }
         for (uint32_t l = 0; l < bi.num_clusters; ++l) {
             const uint8_t* md = index + bi.pl_metadata_offset + (size_t)l * 16;
-            size_t pl_off = rd_u64(md + 8) + bi.pl_start_offset;  // storage.rs:293-294
-            if (pl_off + 32 > index_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list %u out of bounds", l);
-            uint64_t ne = rd_u64(index + pl_off), lw = rd_u64(index + pl_off + 16), uw = rd_u64(index + pl_off + 24);
-            if (pl_off + 32 + (lw + uw) * 8 > index_len) return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list %u truncated", l);
+            const uint64_t rel = rd_u64(md + 8);
+            if (!fits(bi.pl_start_offset, rel, index_len) || !fits(bi.pl_start_offset + rel, 32, index_len))
+                return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list %u out of bounds", l);
+            size_t pl_off = rel + bi.pl_start_offset;  // storage.rs:293-294
+            if (const char* why = ef_header_error(index + pl_off, index_len - pl_off, std::max<uint64_t>(bi.num_vectors, nv)))
+                return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list %u: %s", l, why);
+            uint64_t ne = rd_u64(index + pl_off);
             if (pl_off % 8 != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list %u is not 8-byte aligned", l);
             bool owned = (l % shard_world) == shard_rank;
             if (!owned) ne = 0;
@@ -916,22 +924,33 @@ mdb_status IvfSet::build_doc_map(size_t ui) {
     return MDB_OK;
 }
 
+// The tombstone set is ONE per resident index (`invalid_point_ids: DashSet<u32>`, index.rs:30), whatever handle it is
+// reached through: the host mirror and the doc-id maps live in the root set; the device word is written on the calling
+// handle's stream.
 mdb_status IvfSet::invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out, bool test_only) {
+    IvfSet& r = root ? *root : *this;
     if (ui >= blobs.size()) { for (size_t i = 0; i < n; ++i) flags_out[i] = 0; return MDB_OK; }
-    MDB_TRY(build_doc_map(ui));
+    std::lock_guard<std::mutex> tg(r.tomb_mu);
+    if (r.doc_maps[ui].empty() && r.blobs[ui].num_vectors) {
+        mdb_ctx* saved = r.ctx;
+        r.ctx = ctx;  // errors are reported on the calling handle's context
+        mdb_status st = r.build_doc_map(ui);
+        r.ctx = saved;
+        MDB_TRY(st);
+    }
     bool dirty = false;
     for (size_t i = 0; i < n; ++i) {
-        auto it = doc_maps[ui].find(U128Key{doc_ids[i].lo, doc_ids[i].hi});
-        if (it == doc_maps[ui].end()) { flags_out[i] = 0; continue; }
+        auto it = r.doc_maps[ui].find(U128Key{doc_ids[i].lo, doc_ids[i].hi});
+        if (it == r.doc_maps[ui].end()) { flags_out[i] = 0; continue; }
         uint32_t pid = it->second;
         size_t w = h_users[ui].tomb_base + (pid >> 5);
         uint32_t bit = 1u << (pid & 31);
-        bool was = h_tomb[w] & bit;
+        bool was = r.h_tomb[w] & bit;
         if (test_only) { flags_out[i] = was; continue; }
         flags_out[i] = !was;  // DashSet::insert returns true when newly inserted (index.rs:421-426)
         if (!was) {
-            h_tomb[w] |= bit;
-            MDB_HIP(ctx, hipMemcpyAsync(d_tomb.p + w, &h_tomb[w], 4, hipMemcpyHostToDevice, ctx->stream));
+            r.h_tomb[w] |= bit;
+            MDB_HIP(ctx, hipMemcpyAsync(d_tomb.p + w, &r.h_tomb[w], 4, hipMemcpyHostToDevice, ctx->stream));
             dirty = true;
         }
     }
@@ -939,31 +958,75 @@ mdb_status IvfSet::invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint
     return MDB_OK;
 }
 
-// allow bitmaps for the following searches (nullptr clears): n_bitmaps == 1 -> shared by every query, else one per
-// query of the batch; host bitmaps are copied
-mdb_status IvfSet::set_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem) {
-    flt = nullptr;
-    flt_stride = 0;
+void IvfSet::view_of(IvfSet& src, mdb_ctx* ctx2) {
+    ctx = ctx2;
+    root = src.root ? src.root : &src;
+    kind = src.kind; metric = src.metric; num_features = src.num_features; quantized_dimension = src.quantized_dimension;
+    blobs = src.blobs; h_users = src.h_users; G = src.G; total_tiles = src.total_tiles; total_slots_valid = src.total_slots_valid;
+    d_index.borrow(src.d_index); d_list_tile_off.borrow(src.d_list_tile_off); d_users.borrow(src.d_users); d_tomb.borrow(src.d_tomb);
+    d_slot_ids.borrow(src.d_slot_ids); d_codes.borrow(src.d_codes); d_tiles.borrow(src.d_tiles); d_cent_tiles.borrow(src.d_cent_tiles);
+    pq.metric = src.pq.metric; pq.dimension = src.pq.dimension; pq.subdim = src.pq.subdim; pq.num_bits = src.pq.num_bits;
+    pq.m = src.pq.m; pq.K = src.pq.K; pq.h_codebook = src.pq.h_codebook; pq.codebook.borrow(src.pq.codebook);
+    mw = src.mw; ones_word = src.ones_word; max_user_vectors = src.max_user_vectors;
+    flat_aux_view(src.cent_aux, cent_aux);
+}
+
+// allow bitmaps: bit p of bitmap i keeps point p for query i (n_bitmaps == 1: one bitmap for every query).  A bitmap
+// must cover every point id a scan can meet, a per-query set every query of the batch: anything shorter would be read
+// out of bounds by allow_test.
+mdb_status IvfSet::stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem, size_t b, ScanFilter* out) {
+    *out = ScanFilter{};
     if (!allow) return MDB_OK;
     if (n_bitmaps == 0 || words == 0) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "empty filter bitmap");
+    if (words < (max_user_vectors + 31) / 32)
+        return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "filter bitmaps of %zu words do not cover %zu point ids", words, (size_t)max_user_vectors);
+    if (n_bitmaps != 1 && n_bitmaps < b)
+        return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "%zu filter bitmaps for a batch of %zu queries", n_bitmaps, b);
+    if (n_bitmaps != 1) n_bitmaps = b;
+    out->n_bitmaps = n_bitmaps;
+    out->words = words;
+    if (mem == MDB_MEM_DEVICE) { out->allow = allow; return MDB_OK; }
+    const size_t bytes = n_bitmaps * words * 4;
+    void *pin, *dev;
+    MDB_TRY(mdb_pinned(ctx, 2, bytes, &pin));
+    memcpy(pin, allow, bytes);
+    MDB_TRY(mdb_scratch(ctx, 8, bytes, &dev));
+    MDB_HIP(ctx, hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, ctx->stream));
+    out->allow = (const uint32_t*)dev;
+    return MDB_OK;
+}
+
+// DEPRECATED stateful form (kept for callers of round 1's ABI): the filter applies to every following search on THIS
+// handle until cleared; two host threads with different filters must use the per-call *_search_filtered entries.
+mdb_status IvfSet::set_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem) {
+    flt = ScanFilter{};
+    if (!allow) return MDB_OK;
+    if (n_bitmaps == 0 || words == 0) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "empty filter bitmap");
+    if (words < (max_user_vectors + 31) / 32)
+        return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "filter bitmaps of %zu words do not cover %zu point ids", words, (size_t)max_user_vectors);
     if (mem == MDB_MEM_DEVICE) {
-        flt = allow;
+        flt.allow = allow;
     } else {
         if (flt_own.alloc(n_bitmaps * words + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "filter bitmap alloc");
         MDB_HIP(ctx, hipMemcpyAsync(flt_own.p, allow, n_bitmaps * words * 4, hipMemcpyHostToDevice, ctx->stream));
         MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        flt = flt_own.p;
+        flt.allow = flt_own.p;
     }
-    flt_stride = n_bitmaps == 1 ? 0 : words;
+    flt.n_bitmaps = n_bitmaps;
+    flt.words = words;
     return MDB_OK;
 }
 
 // ------------------------------------------------------------------------------------------ IvfSet: search
 // d_q: staged queries [b][qstride]; probes: device [b][probe_stride]; outputs: device keys [b][k] + counts
 mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
-                        const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts) {
+                        const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts,
+                        const ScanFilter* filter) {
     if (b == 0) return MDB_OK;
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
+    const ScanFilter& f = filter && filter->allow ? *filter : flt;
+    if (f.allow && f.n_bitmaps != 1 && f.n_bitmaps < b)
+        return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "%zu filter bitmaps for a batch of %zu queries", f.n_bitmaps, b);
     int nsplit = 1;
     if (probe_stride > 1) {
         size_t want = (1024 + b - 1) / b;  // aim for >= ~1024 blocks
@@ -994,7 +1057,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     if (!direct) MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)nsplit * std::max<size_t>(k, 1) * 8, &partial));
     ScanArgs a{d_users.p, d_q_user, d_list_tile_off.p, d_slot_ids.p, d_tomb.p, d_probes, d_probe_cnt, probe_stride,
                (int)k, (uint64_t*)partial, ctx->d_flags, ctx->d_counters,
-               flt ? flt : d_tomb.p + ones_word, flt ? (uint32_t)flt_stride : 0u, flt ? 0xFFFFFFFFu : 0u,
+               f.allow ? f.allow : d_tomb.p + ones_word, f.allow && f.n_bitmaps != 1 ? (uint32_t)f.words : 0u, f.allow ? 0xFFFFFFFFu : 0u,
                direct ? d_counts : nullptr};
     dim3 grid((unsigned)nsplit, (unsigned)b);
     size_t sel_lds = BlockSelect<MDB_BLOCK>::lds_bytes((int)k);
@@ -1118,16 +1181,38 @@ mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, si
 // ============================================================================================
 struct mdb_ivf {
     IvfSet set;
+    mdb_ivf* parent = nullptr;   // attached handle: the owner of the device arrays
+    std::atomic<int> refs{1};    // this handle + the handles attached to it
 };
 
+static void ivf_release(mdb_ivf* h) {
+    if (h->refs.fetch_sub(1) != 1) return;
+    mdb_ctx* ctx = h->set.ctx;
+    mdb_ivf* parent = h->parent;
+    (void)hipSetDevice(ctx->device);
+    delete h;
+    mdb_ctx_release(ctx);
+    if (parent) ivf_release(parent);
+}
+
+struct FilterArg { const uint32_t* allow; size_t n_bitmaps, words; };
+
 static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes,
-                                  size_t k, mdb_mem mem, bool remap, void* ids_out, float* scores_out, uint32_t* counts_out) {
+                                  size_t k, mdb_mem mem, bool remap, void* ids_out, float* scores_out, uint32_t* counts_out,
+                                  const FilterArg* fa = nullptr, bool submit = false) {
     IvfSet& s = ivf->set;
     mdb_ctx* ctx = s.ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     MDB_HIP(ctx, hipSetDevice(ctx->device));
     if (b == 0) return MDB_OK;
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
+    struct SubmitScope {  // mdb_*_search_submit: mdb_return_to_host enqueues instead of synchronising
+        mdb_ctx* c; bool on;
+        SubmitScope(mdb_ctx* c_, bool on_) : c(c_), on(on_) { if (on) c->submit_mode = true; }
+        ~SubmitScope() { if (on) c->submit_mode = false; }
+    } submit_scope(ctx, submit && mem == MDB_MEM_HOST);
+    IvfSet::ScanFilter filt;
+    if (fa) MDB_TRY(s.stage_filter(fa->allow, fa->n_bitmaps, fa->words, mem, b, &filt));
     float* dq;
     int qstride;
     const size_t bpad = probes ? (b + 3) / 4 * 4 : s.coarse_bpad(b);
@@ -1136,8 +1221,12 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
     MDB_TRY(mdb_scratch(ctx, 2, b * std::max<size_t>(num_probes, 1) * 4, &dprobes));
     if (probes) {
         if (num_probes == 0) { /* empty centroid list: empty results */ }
-        else MDB_HIP(ctx, hipMemcpyAsync(dprobes, probes, b * num_probes * 4,
-                                         mem == MDB_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+        else if (mem == MDB_MEM_HOST) {  // through pinned staging: the caller's buffer is free when the call returns
+            void* pin;
+            MDB_TRY(mdb_pinned(ctx, 3, b * num_probes * 4, &pin));
+            memcpy(pin, probes, b * num_probes * 4);
+            MDB_HIP(ctx, hipMemcpyAsync(dprobes, pin, b * num_probes * 4, hipMemcpyHostToDevice, ctx->stream));
+        } else MDB_HIP(ctx, hipMemcpyAsync(dprobes, probes, b * num_probes * 4, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
         MDB_TRY(s.coarse(0, dq, qstride, b, num_probes, (uint32_t*)dprobes, true, bpad));  // also clears the device counters
     }
@@ -1148,7 +1237,7 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
     ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
     ctx->stat_bytes_per_eval = 0; ctx->stat_bytes_per_scored = s.bytes_per_scored(); ctx->stat_fixed_bytes = 0;
-    MDB_TRY(s.scan(dq, qstride, b, nullptr, (uint32_t*)dprobes, nullptr, (int)num_probes, k, (uint64_t*)keys, (uint32_t*)cnts));
+    MDB_TRY(s.scan(dq, qstride, b, nullptr, (uint32_t*)dprobes, nullptr, (int)num_probes, k, (uint64_t*)keys, (uint32_t*)cnts, &filt));
     size_t total = b * k;
     if (mem == MDB_MEM_DEVICE) {
         if (remap) MDB_TRY(s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, (mdb_u128*)ids_out, scores_out, counts_out));
@@ -1189,9 +1278,21 @@ void mdb_ivf_free(mdb_ivf* ivf) {
     if (!ivf) return;
     (void)hipSetDevice(ivf->set.ctx->device);
     (void)hipStreamSynchronize(ivf->set.ctx->stream);
-    mdb_ctx* ctx = ivf->set.ctx;
-    delete ivf;
-    mdb_ctx_release(ctx);
+    ivf_release(ivf);
+}
+
+mdb_status mdb_ivf_attach(mdb_ctx* ctx, mdb_ivf* src, mdb_ivf** out) {
+    if (!ctx || !src || !out) return MDB_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (ctx->device != src->set.ctx->device) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "mdb_ivf_attach: the index lives on device %d", src->set.ctx->device);
+    mdb_ivf* owner = src->parent ? src->parent : src;
+    mdb_ivf* h = new mdb_ivf();
+    h->set.view_of(owner->set, ctx);
+    h->parent = owner;
+    owner->refs.fetch_add(1);
+    mdb_ctx_retain(ctx);
+    *out = h;
+    return MDB_OK;
 }
 
 size_t mdb_ivf_num_clusters(const mdb_ivf* ivf) { return ivf ? ivf->set.blobs[0].num_clusters : 0; }
@@ -1296,6 +1397,22 @@ mdb_status mdb_ivf_search_points(mdb_ivf* ivf, const float* queries, size_t b, c
                                  size_t k, mdb_mem mem, uint32_t* point_ids_out, float* scores_out, uint32_t* counts_out) {
     if (!ivf || (!queries && b) || !point_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
     return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, false, point_ids_out, scores_out, counts_out);
+}
+
+mdb_status mdb_ivf_search_filtered(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
+                                   mdb_mem mem, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap,
+                                   mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out) {
+    if (!ivf || (!queries && b) || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
+    const FilterArg fa{allow, n_bitmaps, words_per_bitmap};
+    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, true, doc_ids_out, scores_out, counts_out, &fa);
+}
+
+mdb_status mdb_ivf_search_submit(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
+                                 const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_u128* doc_ids_out,
+                                 float* scores_out, uint32_t* counts_out) {
+    if (!ivf || (!queries && b) || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
+    const FilterArg fa{allow, n_bitmaps, words_per_bitmap};
+    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, MDB_MEM_HOST, true, doc_ids_out, scores_out, counts_out, &fa, true);
 }
 
 mdb_status mdb_ivf_set_filter(mdb_ivf* ivf, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem) {

@@ -40,6 +40,8 @@ struct FlatAux {
     FlatAux& operator=(const FlatAux&) = delete;
     ~FlatAux();
 };
+// dst = a view of src's device arrays (attached handles) with its own overflow word / cooldown
+void flat_aux_view(const FlatAux& src, FlatAux& dst);
 // want_tiles: size of the strided sample in tiles (0: N/32 clamped to 16K..64K vectors, the flat index default)
 mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles = 0);
 bool flat_mfma_applicable(const TileView& ts, FlatAux& aux, size_t b, size_t k);

@@ -15,7 +15,7 @@
 
 #include <unordered_map>
 
-#include "mdb_device.cuh"
+#include "mdb_device.hip.h"
 #include "mdb_hnsw.h"
 #include "mdb_ivf.h"
 #include "mdb_kernels.h"
@@ -73,11 +73,18 @@ __global__ __launch_bounds__(256) void spann_filter_kernel(const uint64_t* __res
     if (lane == 0) { probe_cnt[qi] = n; found[qi] = 1; }
 }
 
+struct SpannFilterArg { const uint32_t* allow; size_t n_bitmaps, words; };
+
 static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b, const uint32_t* h_q_user,
                                     const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out,
-                                    uint32_t* counts_out, uint8_t* found_out) {
+                                    uint32_t* counts_out, uint8_t* found_out, const SpannFilterArg* fa = nullptr, bool submit = false) {
     mdb_ctx* ctx = s.ctx;
     if (b == 0) return MDB_OK;
+    struct SubmitScope {  // mdb_*_search_submit: mdb_return_to_host enqueues instead of synchronising
+        mdb_ctx* c; bool on;
+        SubmitScope(mdb_ctx* c_, bool on_) : c(c_), on(on_) { if (on) c->submit_mode = true; }
+        ~SubmitScope() { if (on) c->submit_mode = false; }
+    } submit_scope(ctx, submit && mem == MDB_MEM_HOST);
     const size_t k = params->top_k;
     const size_t nexp = params->num_explored_centroids < 0 ? k : (size_t)params->num_explored_centroids;
     if (k > MDB_MAX_K || nexp > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "top_k / num_explored_centroids exceed MDB_MAX_K=%d", MDB_MAX_K);
@@ -94,10 +101,15 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     char* base;
     MDB_TRY(mdb_scratch(ctx, 11, off, (void**)&base));
     uint32_t* d_q_user = nullptr;
-    if (h_q_user) {
-        MDB_HIP(ctx, hipMemcpyAsync(base + o_qu, h_q_user, b * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (h_q_user) {  // through pinned staging: the caller's (stack) array may die before the copy runs
+        void* pin;
+        MDB_TRY(mdb_pinned(ctx, 3, b * 4, &pin));
+        memcpy(pin, h_q_user, b * 4);
+        MDB_HIP(ctx, hipMemcpyAsync(base + o_qu, pin, b * 4, hipMemcpyHostToDevice, ctx->stream));
         d_q_user = (uint32_t*)(base + o_qu);
     }
+    IvfSet::ScanFilter filt;
+    if (fa) MDB_TRY(s.ivf.stage_filter(fa->allow, fa->n_bitmaps, fa->words, mem, b, &filt));
     uint64_t* ckeys = (uint64_t*)(base + o_ckeys);
     uint32_t* ccnt = (uint32_t*)(base + o_ccnt);
     uint32_t* probes = (uint32_t*)(base + o_probes);
@@ -116,7 +128,7 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
         ckeys, ccnt, (int)nexp, params->centroid_distance_ratio, s.hnsw.d_users.p, s.ivf.d_users.p, d_q_user,
         s.hnsw.d_index.p, probes, pcnt, dfound, b, ctx->d_flags);
     MDB_HIP(ctx, hipGetLastError());
-    MDB_TRY(s.ivf.scan(dq, qstride, b, d_q_user, probes, pcnt, (int)ne, k, keys, cnts));
+    MDB_TRY(s.ivf.scan(dq, qstride, b, d_q_user, probes, pcnt, (int)ne, k, keys, cnts, &filt));
     if (mem == MDB_MEM_DEVICE) {
         MDB_TRY(s.ivf.remap(keys, cnts, b, k, d_q_user, doc_ids_out, scores_out, counts_out));
         if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound, b, hipMemcpyDeviceToDevice, ctx->stream));
@@ -131,10 +143,45 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
 
 struct mdb_spann {
     SpannSet set;
+    mdb_spann* parent = nullptr;  // attached handle: the owner of the device arrays
+    std::atomic<int> refs{1};
 };
 struct mdb_multi_spann {
     SpannSet set;
+    mdb_multi_spann* parent = nullptr;
+    std::atomic<int> refs{1};
 };
+
+template <class H>
+static void spann_release(H* h) {
+    if (h->refs.fetch_sub(1) != 1) return;
+    mdb_ctx* ctx = h->set.ctx;
+    H* parent = h->parent;
+    (void)hipSetDevice(ctx->device);
+    delete h;
+    mdb_ctx_release(ctx);
+    if (parent) spann_release(parent);
+}
+
+// a second handle over the same resident centroid graphs + posting lists, bound to another context
+template <class H>
+static mdb_status spann_attach(mdb_ctx* ctx, H* src, H** out) {
+    if (!ctx || !src || !out) return MDB_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (ctx->device != src->set.ctx->device) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "attach: the index lives on device %d", src->set.ctx->device);
+    H* owner = src->parent ? src->parent : src;
+    H* h = new H();
+    h->set.ctx = ctx;
+    h->set.hnsw.view_of(owner->set.hnsw, ctx);
+    h->set.ivf.view_of(owner->set.ivf, ctx);
+    h->set.user_index = owner->set.user_index;
+    h->set.num_users = owner->set.num_users;
+    h->parent = owner;
+    owner->refs.fetch_add(1);
+    mdb_ctx_retain(ctx);
+    *out = h;
+    return MDB_OK;
+}
 
 // ------------------------------------------------------------------------------------------ shard merge
 // one block per query: rank-sort the valid rows of the `world` shards by (score, doc id), keep k
@@ -304,10 +351,10 @@ void mdb_spann_free(mdb_spann* sp) {
     if (!sp) return;
     (void)hipSetDevice(sp->set.ctx->device);
     (void)hipStreamSynchronize(sp->set.ctx->stream);
-    mdb_ctx* ctx = sp->set.ctx;
-    delete sp;
-    mdb_ctx_release(ctx);
+    spann_release(sp);
 }
+
+mdb_status mdb_spann_attach(mdb_ctx* ctx, mdb_spann* src, mdb_spann** out) { return spann_attach(ctx, src, out); }
 
 mdb_status mdb_spann_search(mdb_spann* sp, const float* queries, size_t b, const mdb_search_params* params, mdb_mem mem,
                             mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out, uint8_t* found_out) {
@@ -315,6 +362,26 @@ mdb_status mdb_spann_search(mdb_spann* sp, const float* queries, size_t b, const
     std::lock_guard<std::mutex> g(sp->set.ctx->mu);
     MDB_HIP(sp->set.ctx, hipSetDevice(sp->set.ctx->device));
     return spann_search_impl(sp->set, queries, b, nullptr, params, mem, doc_ids_out, scores_out, counts_out, found_out);
+}
+
+mdb_status mdb_spann_search_filtered(mdb_spann* sp, const float* queries, size_t b, const mdb_search_params* params, mdb_mem mem,
+                                     const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_u128* doc_ids_out,
+                                     float* scores_out, uint32_t* counts_out, uint8_t* found_out) {
+    if (!sp || (!queries && b) || !params || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(sp->set.ctx->mu);
+    MDB_HIP(sp->set.ctx, hipSetDevice(sp->set.ctx->device));
+    const SpannFilterArg fa{allow, n_bitmaps, words_per_bitmap};
+    return spann_search_impl(sp->set, queries, b, nullptr, params, mem, doc_ids_out, scores_out, counts_out, found_out, &fa);
+}
+
+mdb_status mdb_spann_search_submit(mdb_spann* sp, const float* queries, size_t b, const mdb_search_params* params,
+                                   const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_u128* doc_ids_out,
+                                   float* scores_out, uint32_t* counts_out, uint8_t* found_out) {
+    if (!sp || (!queries && b) || !params || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(sp->set.ctx->mu);
+    MDB_HIP(sp->set.ctx, hipSetDevice(sp->set.ctx->device));
+    const SpannFilterArg fa{allow, n_bitmaps, words_per_bitmap};
+    return spann_search_impl(sp->set, queries, b, nullptr, params, MDB_MEM_HOST, doc_ids_out, scores_out, counts_out, found_out, &fa, true);
 }
 
 mdb_status mdb_spann_set_filter(mdb_spann* sp, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem) {
@@ -379,16 +446,16 @@ void mdb_multi_spann_free(mdb_multi_spann* ms) {
     if (!ms) return;
     (void)hipSetDevice(ms->set.ctx->device);
     (void)hipStreamSynchronize(ms->set.ctx->stream);
-    mdb_ctx* ctx = ms->set.ctx;
-    delete ms;
-    mdb_ctx_release(ctx);
+    spann_release(ms);
 }
+
+mdb_status mdb_multi_spann_attach(mdb_ctx* ctx, mdb_multi_spann* src, mdb_multi_spann** out) { return spann_attach(ctx, src, out); }
 
 size_t mdb_multi_spann_num_users(const mdb_multi_spann* ms) { return ms ? ms->set.num_users : 0; }
 
-mdb_status mdb_multi_spann_search(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
-                                  const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out,
-                                  uint32_t* counts_out, uint8_t* found_out) {
+static mdb_status multi_spann_search_impl(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                          const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out,
+                                          uint32_t* counts_out, uint8_t* found_out, const SpannFilterArg* fa, bool submit) {
     if (!ms || (!queries && b) || (!user_ids && b) || !params || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(ms->set.ctx->mu);
     MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
@@ -397,7 +464,29 @@ mdb_status mdb_multi_spann_search(mdb_multi_spann* ms, const mdb_u128* user_ids,
         auto it = ms->set.user_index.find(U128Key{user_ids[i].lo, user_ids[i].hi});
         qu[i] = it == ms->set.user_index.end() ? (uint32_t)ms->set.num_users : it->second;  // sentinel: valid = 0 => None
     }
-    return spann_search_impl(ms->set, queries, b, qu.data(), params, mem, doc_ids_out, scores_out, counts_out, found_out);
+    return spann_search_impl(ms->set, queries, b, qu.data(), params, mem, doc_ids_out, scores_out, counts_out, found_out, fa, submit);
+}
+
+mdb_status mdb_multi_spann_search(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                  const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out,
+                                  uint32_t* counts_out, uint8_t* found_out) {
+    return multi_spann_search_impl(ms, user_ids, queries, b, params, mem, doc_ids_out, scores_out, counts_out, found_out, nullptr, false);
+}
+
+mdb_status mdb_multi_spann_search_filtered(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                           const mdb_search_params* params, mdb_mem mem, const uint32_t* allow, size_t n_bitmaps,
+                                           size_t words_per_bitmap, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out,
+                                           uint8_t* found_out) {
+    const SpannFilterArg fa{allow, n_bitmaps, words_per_bitmap};
+    return multi_spann_search_impl(ms, user_ids, queries, b, params, mem, doc_ids_out, scores_out, counts_out, found_out, &fa, false);
+}
+
+mdb_status mdb_multi_spann_search_submit(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                         const mdb_search_params* params, const uint32_t* allow, size_t n_bitmaps,
+                                         size_t words_per_bitmap, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out,
+                                         uint8_t* found_out) {
+    const SpannFilterArg fa{allow, n_bitmaps, words_per_bitmap};
+    return multi_spann_search_impl(ms, user_ids, queries, b, params, MDB_MEM_HOST, doc_ids_out, scores_out, counts_out, found_out, &fa, true);
 }
 
 mdb_status mdb_multi_spann_set_filter(mdb_multi_spann* ms, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap,
