@@ -5,7 +5,13 @@ Partitioning
   * IVF / SPANN / multi-user SPANN: every rank loads the same files with (shard_rank, shard_world);
     posting list l of every user is owned by rank l % world, centroids / graphs / doc-id tables are
     replicated, so probe selection is identical on all ranks and the union of the per-rank top-k
-    equals the single-GPU result exactly.
+    equals the single-GPU result exactly — with ONE caveat at exact score ties on the k-th boundary: a rank
+    (like the unsharded path) selects its top-k by (distance, POINT id) and only then re-ranks by
+    (score, DOC id), while the cross-rank merge sees doc ids only.  When several candidates tie exactly at
+    rank k and doc ids are not monotone in point ids (a reindexed segment), the merged row may keep a
+    different one of the tied documents than the unsharded search does (same scores, same count).  The
+    reference's own cross-segment merge (Snapshot::search_for_user, collection/snapshot.rs:69-110) has the
+    same property: it too merges per-segment rows by (score, doc id).
   * HNSW: the traversal does not partition (replicas only): ranks split the batch, no collective.
   * flat: row-range shards, same gather + merge.
 

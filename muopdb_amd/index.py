@@ -229,6 +229,30 @@ def _set_filter(ctx, fn, handle, bitmaps):
     ctx.check(fn(handle, L.ptr(bm, C.c_uint32), C.c_size_t(nb), C.c_size_t(words), C.c_int(L.MEM_HOST)))
 
 
+def _planner_args(planner):
+    """per-call planner filter -> (allow pointer, n_bitmaps, words_per_bitmap, keepalive)"""
+    if planner is None:
+        return None, C.c_size_t(0), C.c_size_t(0), None
+    bm = np.ascontiguousarray(planner, dtype=np.uint32)
+    nb, words = (1, bm.shape[0]) if bm.ndim == 1 else bm.shape
+    return L.ptr(bm, C.c_uint32), C.c_size_t(nb), C.c_size_t(words), bm
+
+
+class Pending:
+    """Result of a *_submit call: `wait()` completes it (mdb_wait) and returns the SearchResult."""
+
+    def __init__(self, ctx, out, keep):
+        self.ctx, self.out, self.keep = ctx, out, keep
+
+    def done(self):
+        return bool(self.ctx.lib.mdb_poll(self.ctx.h))
+
+    def wait(self):
+        self.ctx.check(self.ctx.lib.mdb_wait(self.ctx.h))
+        self.keep = None
+        return self.out.result()
+
+
 def allow_bitmap(point_ids, num_points):
     """uint32 bitmap with the bits of `point_ids` set (the planner's kept ids)."""
     bm = np.zeros((num_points + 31) // 32, np.uint32)
@@ -295,25 +319,52 @@ class BlockBasedIvf:
                                                               C.c_size_t(num_probes), C.c_int(L.MEM_HOST), L.ptr(out, C.c_uint32)))
         return out
 
-    def search(self, queries, k, num_probes):
-        """BlockBasedIvf::search (index.rs:396-413)."""
-        return self._search(queries, k, None, num_probes)
+    def attach(self, ctx):
+        """A second handle over the same resident index, bound to `ctx` (own stream / scratch): mdb_ivf_attach."""
+        other = BlockBasedIvf.__new__(BlockBasedIvf)
+        other.ctx, other.num_features = ctx, self.num_features
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mdb_ivf_attach(ctx.h, self.h, C.byref(h)))
+        other.h = h
+        return other
 
-    def search_with_centroids_and_remap(self, queries, nearest_centroid_ids, k):
+    def search(self, queries, k, num_probes, planner=None):
+        """BlockBasedIvf::search (index.rs:396-413).  planner: per-call allow bitmaps (uint32 [words] shared or
+        [b][words] one per query) — the `planner` argument of scan_posting_list (index.rs:175)."""
+        return self._search(queries, k, None, num_probes, planner)
+
+    def search_with_centroids_and_remap(self, queries, nearest_centroid_ids, k, planner=None):
         """index.rs:298-332; nearest_centroid_ids: [B][P]."""
         p = np.ascontiguousarray(nearest_centroid_ids, np.uint32)
         p = p.reshape(-1, p.shape[-1])
-        return self._search(queries, k, p, p.shape[1])
+        return self._search(queries, k, p, p.shape[1], planner)
 
-    def _search(self, queries, k, probes, num_probes):
+    def _search(self, queries, k, probes, num_probes, planner=None):
         q = L.f32(queries).reshape(-1, self.num_features)
         b = q.shape[0]
         out = _OutBuf(b, k)
-        self.ctx.check(self.ctx.lib.mdb_ivf_search(self.h, L.ptr(q, C.c_float), C.c_size_t(b),
-                                                   L.ptr(probes, C.c_uint32) if probes is not None else None,
-                                                   C.c_size_t(num_probes), C.c_size_t(k), C.c_int(L.MEM_HOST),
-                                                   *out.args()))
+        if planner is None:
+            self.ctx.check(self.ctx.lib.mdb_ivf_search(self.h, L.ptr(q, C.c_float), C.c_size_t(b),
+                                                       L.ptr(probes, C.c_uint32) if probes is not None else None,
+                                                       C.c_size_t(num_probes), C.c_size_t(k), C.c_int(L.MEM_HOST),
+                                                       *out.args()))
+        else:
+            ap, nb, words, keep = _planner_args(planner)
+            self.ctx.check(self.ctx.lib.mdb_ivf_search_filtered(self.h, L.ptr(q, C.c_float), C.c_size_t(b),
+                                                                L.ptr(probes, C.c_uint32) if probes is not None else None,
+                                                                C.c_size_t(num_probes), C.c_size_t(k), C.c_int(L.MEM_HOST),
+                                                                ap, nb, words, *out.args()))
         return out.result()
+
+    def search_submit(self, queries, k, num_probes, planner=None):
+        """mdb_ivf_search_submit: enqueue and return; Pending.wait() gives the SearchResult."""
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        out = _OutBuf(b, k)
+        ap, nb, words, keep = _planner_args(planner)
+        self.ctx.check(self.ctx.lib.mdb_ivf_search_submit(self.h, L.ptr(q, C.c_float), C.c_size_t(b), None, C.c_size_t(num_probes),
+                                                          C.c_size_t(k), ap, nb, words, *out.args()))
+        return Pending(self.ctx, out, None)
 
     def search_points(self, queries, k, num_probes, probes=None):
         """search_with_centroids (index.rs:250-286): top-k by (distance, point id), no remap."""
@@ -395,6 +446,15 @@ class BlockBasedHnsw:
                                                         C.c_uint32(ef), C.c_int(L.MEM_HOST), *out.args()))
         return out.result()
 
+    def ann_search_submit(self, queries, k, ef):
+        """mdb_hnsw_ann_search_submit: enqueue and return; Pending.wait() gives the SearchResult."""
+        q = L.f32(queries).reshape(-1, self.dimension)
+        b = q.shape[0]
+        out = _OutBuf(b, k)
+        self.ctx.check(self.ctx.lib.mdb_hnsw_ann_search_submit(self.h, L.ptr(q, C.c_float), C.c_size_t(b), C.c_size_t(k),
+                                                               C.c_uint32(ef), *out.args()))
+        return Pending(self.ctx, out, None)
+
     def ann_search_device(self, q_ptr, b, k, ef, ids_ptr, scores_ptr, counts_ptr):
         self.ctx.check(self.ctx.lib.mdb_hnsw_ann_search(self.h, C.c_void_p(q_ptr), C.c_size_t(b), C.c_size_t(k),
                                                         C.c_uint32(ef), C.c_int(L.MEM_DEVICE), C.c_void_p(ids_ptr),
@@ -454,14 +514,39 @@ class Spann:
         except Exception:
             pass
 
-    def search(self, queries, params):
+    def attach(self, ctx):
+        """A second handle over the same resident centroid graph + posting lists, bound to `ctx` (mdb_spann_attach)."""
+        other = Spann.__new__(Spann)
+        other.ctx, other.num_features = ctx, self.num_features
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mdb_spann_attach(ctx.h, self.h, C.byref(h)))
+        other.h = h
+        return other
+
+    def search(self, queries, params, planner=None):
         q = L.f32(queries).reshape(-1, self.num_features)
         b = q.shape[0]
         out = _OutBuf(b, params.top_k)
         p = params.to_c()
-        self.ctx.check(self.ctx.lib.mdb_spann_search(self.h, L.ptr(q, C.c_float), C.c_size_t(b), C.byref(p),
-                                                     C.c_int(L.MEM_HOST), *out.args(), L.ptr(out.found, C.c_uint8)))
+        if planner is None:
+            self.ctx.check(self.ctx.lib.mdb_spann_search(self.h, L.ptr(q, C.c_float), C.c_size_t(b), C.byref(p),
+                                                         C.c_int(L.MEM_HOST), *out.args(), L.ptr(out.found, C.c_uint8)))
+        else:
+            ap, nb, words, keep = _planner_args(planner)
+            self.ctx.check(self.ctx.lib.mdb_spann_search_filtered(self.h, L.ptr(q, C.c_float), C.c_size_t(b), C.byref(p),
+                                                                  C.c_int(L.MEM_HOST), ap, nb, words, *out.args(),
+                                                                  L.ptr(out.found, C.c_uint8)))
         return out.result()
+
+    def search_submit(self, queries, params, planner=None):
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        out = _OutBuf(b, params.top_k)
+        p = params.to_c()
+        ap, nb, words, keep = _planner_args(planner)
+        self.ctx.check(self.ctx.lib.mdb_spann_search_submit(self.h, L.ptr(q, C.c_float), C.c_size_t(b), C.byref(p), ap, nb, words,
+                                                            *out.args(), L.ptr(out.found, C.c_uint8)))
+        return Pending(self.ctx, out, None)
 
     def set_filter(self, bitmaps):
         _set_filter(self.ctx, self.ctx.lib.mdb_spann_set_filter, self.h, bitmaps)
@@ -514,16 +599,43 @@ class MultiSpannIndex:
     def num_users(self):
         return int(self.ctx.lib.mdb_multi_spann_num_users(self.h))
 
-    def search_for_user(self, user_ids, queries, params):
-        """Batch of (user_id, query) pairs; found[i] == 0 mirrors `None`."""
+    def attach(self, ctx):
+        """A second handle over the same resident users, bound to `ctx` (mdb_multi_spann_attach)."""
+        other = MultiSpannIndex.__new__(MultiSpannIndex)
+        other.ctx, other.num_features = ctx, self.num_features
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mdb_multi_spann_attach(ctx.h, self.h, C.byref(h)))
+        other.h = h
+        return other
+
+    def search_for_user(self, user_ids, queries, params, planner=None):
+        """Batch of (user_id, query) pairs; found[i] == 0 mirrors `None`.  planner: per-call allow bitmaps over each
+        query's user-local point ids."""
         q = L.f32(queries).reshape(-1, self.num_features)
         b = q.shape[0]
         out = _OutBuf(b, params.top_k)
         p = params.to_c()
-        self.ctx.check(self.ctx.lib.mdb_multi_spann_search(self.h, L.u128_array(list(user_ids)), L.ptr(q, C.c_float),
-                                                           C.c_size_t(b), C.byref(p), C.c_int(L.MEM_HOST), *out.args(),
-                                                           L.ptr(out.found, C.c_uint8)))
+        if planner is None:
+            self.ctx.check(self.ctx.lib.mdb_multi_spann_search(self.h, L.u128_array(list(user_ids)), L.ptr(q, C.c_float),
+                                                               C.c_size_t(b), C.byref(p), C.c_int(L.MEM_HOST), *out.args(),
+                                                               L.ptr(out.found, C.c_uint8)))
+        else:
+            ap, nb, words, keep = _planner_args(planner)
+            self.ctx.check(self.ctx.lib.mdb_multi_spann_search_filtered(self.h, L.u128_array(list(user_ids)), L.ptr(q, C.c_float),
+                                                                        C.c_size_t(b), C.byref(p), C.c_int(L.MEM_HOST), ap, nb, words,
+                                                                        *out.args(), L.ptr(out.found, C.c_uint8)))
         return out.result()
+
+    def search_for_user_submit(self, user_ids, queries, params, planner=None):
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        out = _OutBuf(b, params.top_k)
+        p = params.to_c()
+        ap, nb, words, keep = _planner_args(planner)
+        self.ctx.check(self.ctx.lib.mdb_multi_spann_search_submit(self.h, L.u128_array(list(user_ids)), L.ptr(q, C.c_float),
+                                                                  C.c_size_t(b), C.byref(p), ap, nb, words, *out.args(),
+                                                                  L.ptr(out.found, C.c_uint8)))
+        return Pending(self.ctx, out, None)
 
     def search_for_users(self, user_ids, query, params):
         """Snapshot::search_for_users (collection/snapshot.rs:39-66): one query fanned to several

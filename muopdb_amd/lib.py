@@ -197,7 +197,7 @@ class Context:
     def ef_decode(self, blob):
         b = u8buf(blob)
         n = C.c_size_t()
-        cap = int(np.frombuffer(b[:8].tobytes(), np.uint64)[0]) if b.size >= 8 else 0
+        cap = min(int(np.frombuffer(b[:8].tobytes(), np.uint64)[0]), b.size * 8) if b.size >= 8 else 0  # a list cannot hold more ids than bits
         out = np.empty(max(cap, 1), np.uint64)
         self.check(self.lib.mdb_ef_decode(self.h, ptr(b, C.c_uint8), C.c_size_t(b.size), ptr(out, C.c_uint64),
                                           C.c_size_t(cap), C.byref(n)))

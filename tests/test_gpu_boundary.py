@@ -1,0 +1,273 @@
+"""GPU tests (-m gpu) of the boundary semantics the reference's callers rely on: the planner filter as
+a PER-CALL argument (ivf/block_based/index.rs:175-237 takes `planner` per call), ONE resident index shared by concurrent
+callers (segment/mod.rs:273-274: immutable index, `Quantizer: Send + Sync`, one query per tokio task), tombstones shared
+by every handle over an index (`invalid_point_ids: DashSet`, index.rs:30), asynchronous submit / wait for host-buffer
+callers, and malformed inputs refused before a kernel can read out of bounds."""
+import struct
+import threading
+
+import numpy as np
+import pytest
+
+from muopdb_amd import formats as F
+from tests import helpers as H
+from tests.test_gpu_parity import assert_result_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from muopdb_amd import lib as L
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def case(oracle):
+    """one SPANN-shaped index (PQ posting lists) + its multi-user concatenation, the oracle twins, queries, two filters"""
+    from muopdb_amd.index import ProductQuantizer, allow_bitmap
+    rng = np.random.default_rng(77)
+    n, d = 4000, 32
+    v = H.sift_like(n, d, n_clusters=30, seed=16)
+    cb = H.train_pq_codebook(v[:1500], 8, 6, iters=3)
+    opq = oracle.ProductQuantizer(d, 8, 6, cb)
+    files, cent, _ = H.build_spann_files(oracle, v, list(range(n)), 40, quantize=opq.quantize, max_neighbors=8, max_layers=3,
+                                         ef_construction=50)
+    q = (v[rng.integers(0, n, 24)] + rng.normal(0, 3, (24, d))).astype(np.float32)
+    even = allow_bitmap(np.arange(0, n, 2), n)
+    per_query = np.stack([allow_bitmap(rng.choice(n, size=int(rng.integers(1, n)), replace=False), n) for _ in range(24)])
+    return dict(n=n, d=d, files=files, q=q, even=even, per_query=per_query, quant=ProductQuantizer(d, 8, 6, cb),
+                oquant=oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 6, cb))
+
+
+def test_per_call_filter_equals_oracle_and_leaves_no_state(ctx, oracle, case):
+    from muopdb_amd.index import BlockBasedIvf, MultiSpannIndex, SearchParams, Spann
+    f, q = case["files"], case["q"]
+    g = BlockBasedIvf(ctx, f["ivf_index"], f["ivf_vectors"], case["quant"])
+    o = oracle.BlockBasedIvf(f["ivf_index"], f["ivf_vectors"], case["oquant"])
+    plain = o.search(q, 10, num_probes=12)
+    for bm in (case["even"], case["per_query"]):
+        with oracle.planner_filter(bm):
+            want = o.search(q, 10, num_probes=12)
+        assert_result_rows(g.search(q, 10, 12, planner=bm), want, len(q))
+        assert_result_rows(g.search(q, 10, 12), plain, len(q))          # the filter was an argument, not state
+    probes = g.find_nearest_centroids(q, 12)
+    with oracle.planner_filter(case["even"]):
+        want = o.search(q, 10, num_probes=12)
+    assert_result_rows(g.search_with_centroids_and_remap(q, probes, 10, planner=case["even"]), want, len(q))
+    sp = Spann(ctx, f["hnsw_index"], f["hnsw_vectors"], f["ivf_index"], f["ivf_vectors"], case["quant"])
+    osp = oracle.Spann(f["hnsw_index"], f["hnsw_vectors"], f["ivf_index"], f["ivf_vectors"], case["oquant"])
+    p, op = SearchParams(10, 50).with_num_explored_centroids(6), oracle.SearchParams(10, 50, num_explored_centroids=6)
+    with oracle.planner_filter(case["per_query"]):
+        want = osp.search(q, op)
+    assert_result_rows(sp.search(q, p, planner=case["per_query"]), want, len(q))
+    assert_result_rows(sp.search(q, p), osp.search(q, op), len(q))
+    cat = F.concat_multi_spann({5: f})
+    margs = (cat["user_table"], case["d"], cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+    ms = MultiSpannIndex(ctx, *margs, case["quant"])
+    oms = oracle.MultiSpannIndex(*margs, case["oquant"])
+    with oracle.planner_filter(case["even"]):
+        want = oms.search_for_user([5] * len(q), q, op)
+    got = ms.search_for_user([5] * len(q), q, p, planner=case["even"])
+    assert_result_rows(got, want, len(q))
+    assert all(x % 2 == 0 for i in range(len(q)) for x in got.doc_ids(i))
+
+
+def test_filter_bitmaps_are_validated(ctx, case):
+    """a bitmap shorter than ceil(num_vectors / 32) words, or fewer per-query bitmaps than queries, used to be
+    read out of bounds by the scan; now both are MDB_ERR_INVALID_ARG — per call and in the deprecated stateful form."""
+    from muopdb_amd import lib as L
+    from muopdb_amd.index import BlockBasedIvf
+    f, q = case["files"], case["q"]
+    g = BlockBasedIvf(ctx, f["ivf_index"], f["ivf_vectors"], case["quant"])
+    short = case["even"][:-1]
+    for bad in (short, case["per_query"][:5], np.zeros((0,), np.uint32)):
+        with pytest.raises(L.MuopdbError) as e:
+            g.search(q, 10, 12, planner=bad)
+        assert e.value.status == L.MDB_ERR_INVALID_ARG
+    with pytest.raises(L.MuopdbError) as e:
+        g.set_filter(short)
+    assert e.value.status == L.MDB_ERR_INVALID_ARG
+    g.set_filter(case["per_query"][:5])         # stateful: the batch size is only known at search time
+    with pytest.raises(L.MuopdbError) as e:
+        g.search(q, 10, 12)
+    assert e.value.status == L.MDB_ERR_INVALID_ARG
+    g.search(q[:5], 10, 12)                     # ... and a batch the bitmaps cover is served
+    g.set_filter(None)
+    g.search(q, 10, 12, planner=case["per_query"])
+
+
+def test_two_threads_with_different_filters_on_one_resident_index(ctx, oracle, case):
+    """two host threads, DIFFERENT planner filters, ONE resident index (attached handles, each
+    on its own context / stream): no handle-global state to race on, every row equals the oracle's for that thread's filter."""
+    from muopdb_amd import lib as L
+    from muopdb_amd.index import BlockBasedIvf
+    f, q = case["files"], case["q"]
+    g = BlockBasedIvf(ctx, f["ivf_index"], f["ivf_vectors"], case["quant"])
+    o = oracle.BlockBasedIvf(f["ivf_index"], f["ivf_vectors"], case["oquant"])
+    filters = [case["even"], case["per_query"], None]
+    wants = []
+    for bm in filters:
+        if bm is None:
+            wants.append(o.search(q, 10, num_probes=12))
+        else:
+            with oracle.planner_filter(bm):
+                wants.append(o.search(q, 10, num_probes=12))
+    ctxs = [L.Context(0) for _ in filters]
+    handles = [g.attach(c) for c in ctxs]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(25):
+                assert_result_rows(handles[i].search(q, 10, 12, planner=filters[i]), wants[i], len(q))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(filters))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    # the SAME handle from two threads with different filters: calls serialise on the context, filters still do not mix
+    errors.clear()
+    handles[2] = handles[0]
+    ts = [threading.Thread(target=worker, args=(i,)) for i in (0, 2)]
+    filters[2], wants[2] = filters[1], wants[1]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for h in handles[:2]:
+        h.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_attached_handles_share_index_and_tombstones(ctx, oracle, case):
+    """mdb_{ivf,spann,multi_spann}_attach: same rows through every handle; a tombstone set through one handle is seen by all
+    (one `invalid_point_ids` per index); the memory outlives the first handle (freed in any order)."""
+    from muopdb_amd import lib as L
+    from muopdb_amd.index import BlockBasedIvf, MultiSpannIndex, SearchParams, Spann
+    f, q = case["files"], case["q"]
+    c2, c3 = L.Context(0), L.Context(0)
+    g = BlockBasedIvf(ctx, f["ivf_index"], f["ivf_vectors"], case["quant"])
+    o = oracle.BlockBasedIvf(f["ivf_index"], f["ivf_vectors"], case["oquant"])
+    a, b = g.attach(c2), g.attach(c3)
+    want = o.search(q, 10, num_probes=12)
+    for h in (g, a, b):
+        assert_result_rows(h.search(q, 10, 12), want, len(q))
+    victim = want.doc_ids(0)[0]
+    assert a.invalidate(victim) and o.invalidate(victim)       # through an ATTACHED handle
+    assert g.is_invalidated(victim) and b.is_invalidated(victim) and not b.invalidate(victim)
+    want = o.search(q, 10, num_probes=12)
+    g.close()                                                   # the owner first: the arrays live on with the views
+    for h in (a, b):
+        assert_result_rows(h.search(q, 10, 12), want, len(q))
+    a.close(); b.close()
+    sp = Spann(ctx, f["hnsw_index"], f["hnsw_vectors"], f["ivf_index"], f["ivf_vectors"], case["quant"])
+    osp = oracle.Spann(f["hnsw_index"], f["hnsw_vectors"], f["ivf_index"], f["ivf_vectors"], case["oquant"])
+    p, op = SearchParams(10, 50).with_num_explored_centroids(6), oracle.SearchParams(10, 50, num_explored_centroids=6)
+    sa = sp.attach(c2)
+    assert_result_rows(sa.search(q, p), osp.search(q, op), len(q))
+    assert sa.invalidate(osp.search(q, op).doc_ids(1)[0]) and osp.invalidate(osp.search(q, op).doc_ids(1)[0])
+    assert_result_rows(sp.search(q, p), osp.search(q, op), len(q))
+    cat = F.concat_multi_spann({5: f, 9: f})
+    margs = (cat["user_table"], case["d"], cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+    ms = MultiSpannIndex(ctx, *margs, case["quant"])
+    oms = oracle.MultiSpannIndex(*margs, case["oquant"])
+    ma = ms.attach(c3)
+    users = [5 if i % 2 else 9 for i in range(len(q))]
+    assert_result_rows(ma.search_for_user(users, q, p), oms.search_for_user(users, q, op), len(q))
+    ms.close()
+    assert_result_rows(ma.search_for_user(users, q, p), oms.search_for_user(users, q, op), len(q))
+    ma.close(); sa.close(); sp.close()
+    c2.close(); c3.close()
+
+
+def test_submit_wait_equals_synchronous_calls(ctx, oracle, case):
+    """mdb_*_search_submit / mdb_wait: the call returns after enqueueing (inputs are reusable at once), the outputs are
+    filled by mdb_wait; several batches in flight = one context + attached handle each."""
+    from muopdb_amd import lib as L
+    from muopdb_amd.index import BlockBasedHnsw, BlockBasedIvf, MultiSpannIndex, SearchParams
+    f, q = case["files"], case["q"]
+    g = BlockBasedIvf(ctx, f["ivf_index"], f["ivf_vectors"], case["quant"])
+    want = g.search(q, 10, 12, planner=case["even"])
+    ctxs = [L.Context(0) for _ in range(3)]
+    hs = [g.attach(c) for c in ctxs]
+    qs = [q.copy() for _ in hs]
+    pend = [h.search_submit(qq, 10, 12, planner=case["even"]) for h, qq in zip(hs, qs)]
+    for qq in qs:
+        qq[:] = 0                                   # the inputs were staged at submit time
+    for p_ in pend:
+        assert_result_rows(p_.wait(), want, len(q))
+    assert pend[0].done()
+    with pytest.raises(L.MuopdbError):              # one pending call per context
+        pd = hs[0].search_submit(q, 10, 12)
+        try:
+            hs[0].search(q, 10, 12)
+        finally:
+            pd.wait()
+    v = np.random.default_rng(3).standard_normal((1200, 24)).astype(np.float32)
+    hidx, hvec = H.build_hnsw_files(oracle, v, list(range(1200)), max_neighbors=10, max_layers=3, ef_construction=60)
+    hn = BlockBasedHnsw(ctx, hidx, hvec, 24)
+    hq = v[:17] + 0.01
+    assert_result_rows(hn.ann_search_submit(hq, 5, 40).wait(), hn.ann_search(hq, 5, 40), len(hq))
+    bad = hq.copy(); bad[3, 2] = np.nan             # a deferred error surfaces at wait()
+    pd = hn.ann_search_submit(bad, 5, 40)
+    with pytest.raises(L.MuopdbError) as e:
+        pd.wait()
+    assert e.value.status == 5  # MDB_ERR_NAN
+    assert_result_rows(hn.ann_search(hq, 5, 40), hn.ann_search_submit(hq, 5, 40).wait(), len(hq))
+    cat = F.concat_multi_spann({5: f})
+    ms = MultiSpannIndex(ctx, cat["user_table"], case["d"], cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"],
+                         case["quant"])
+    p = SearchParams(10, 50).with_num_explored_centroids(6)
+    assert_result_rows(ms.search_for_user_submit([5] * len(q), q, p, planner=case["per_query"]).wait(),
+                       ms.search_for_user([5] * len(q), q, p, planner=case["per_query"]), len(q))
+    for h in hs:
+        h.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_corrupt_posting_list_headers_are_refused(ctx, case):
+    """the Elias-Fano decoder trusted the on-disk list header (lower_bit_length, word counts); a corrupt or
+    truncated index made the device read past the blob.  Now validated on the host before upload: MDB_ERR_FORMAT."""
+    from muopdb_amd import lib as L
+    from muopdb_amd.index import BlockBasedIvf
+    good = F.ef_encode(np.array([5, 8, 8, 15, 32, 1000, 5000], np.uint64))
+    assert list(ctx.ef_decode(good)) == [5, 8, 8, 15, 32, 1000, 5000]
+    n, Lb, lw, uw = struct.unpack("<QQQQ", good[:32])
+
+    def hdr(n_=n, L_=Lb, lw_=lw, uw_=uw):
+        return struct.pack("<QQQQ", n_, L_, lw_, uw_) + good[32:]
+
+    for blob in (hdr(L_=64), hdr(L_=200), hdr(lw_=0) if Lb else hdr(uw_=0), hdr(uw_=0), hdr(lw_=(1 << 61)), hdr(uw_=(1 << 62)),
+                 hdr(n_=1 << 40), good[:40], good[:16]):
+        with pytest.raises(L.MuopdbError) as e:
+            ctx.ef_decode(blob)
+        assert e.value.status == 2, blob[:32]
+    # the same inside an IVF index file: corrupt one list's header in place
+    f = case["files"]
+    idx = bytearray(f["ivf_index"])
+    nf, qd, ncl = struct.unpack_from("<III", idx, 1)
+    nv, doc_len, cent_len = struct.unpack_from("<QQQ", idx, 13)
+    meta = (((48 + doc_len + 7) // 8 * 8) + cent_len + 7) // 8 * 8
+    npl = struct.unpack_from("<Q", idx, meta)[0]
+    pl0 = meta + 8 + npl * 16 + struct.unpack_from("<Q", idx, meta + 8 + 8)[0]
+    for field, value in ((8, 77), (16, 1 << 60), (24, 0), (0, 1 << 33)):
+        bad = bytearray(idx)
+        struct.pack_into("<Q", bad, pl0 + field, value)
+        with pytest.raises(L.MuopdbError) as e:
+            BlockBasedIvf(ctx, bytes(bad), f["ivf_vectors"], case["quant"])
+        assert e.value.status == 2
+    bad = bytearray(idx)
+    struct.pack_into("<Q", bad, 21, (1 << 63))          # doc_id_mapping_len that wraps the section offsets
+    with pytest.raises(L.MuopdbError) as e:
+        BlockBasedIvf(ctx, bytes(bad), f["ivf_vectors"], case["quant"])
+    assert e.value.status == 2

@@ -311,6 +311,32 @@ def test_k8_spann_search_pq(oracle):
     assert res.doc_ids(0) == sorted(res.doc_ids(0))
 
 
+# ----------------------------------------------------------------------------- K11: HNSW builder reindex
+def test_k11_hnsw_builder_reindex():
+    # rs/index/src/hnsw/builder.rs:460-575 test_hnsw_builder_reindex: 3 points, one layer, entry points [0, 1]
+    from muopdb_amd import hnsw_build as HB
+    layer = {0: [(2, 1.0)], 1: [(2, 2.0)], 2: [(1, 2.0), (0, 1.0)]}
+    codes = np.array([[0] * 5, [1] * 5, [2] * 5], np.uint8)
+    layers, entry, docs, vec, assigned = HB.reindex([layer], [0, 1], [100, 101, 102], codes)
+    assert assigned.tolist() == [0, 2, 1]                       # expected_mapping
+    assert entry == [0, 2]
+    assert all(100 <= docs[m] <= 102 for m in (0, 2, 1)) and docs == [100, 102, 101]
+    assert layers[0][0] == [(1, 1.0)]
+    assert layers[0][1] == [(0, 1.0), (2, 2.0)]                 # the nearest-first sort happens in place during the BFS
+    assert layers[0][2] == [(1, 2.0)]
+    assert vec.tolist() == [[0] * 5, [2] * 5, [1] * 5]          # vectors follow their points
+
+
+def test_k11_layer_reindex():
+    # builder.rs:577-620 test_layer_reindex: identity mapping changes nothing; the reversed mapping mirrors every id
+    from muopdb_amd import hnsw_build as HB
+    og = {i: [((i + 1) % 10, 1.0), ((i + 5) % 10, 2.0)] for i in range(10)}
+    assert HB.layer_reindex(og, list(range(10))) == og
+    rev = HB.layer_reindex(og, list(range(9, -1, -1)))
+    for i in range(10):
+        assert rev[i] == [((i - 1 + 10) % 10, 1.0), ((i - 5 + 10) % 10, 2.0)]
+
+
 # ----------------------------------------------------------------------------- K9/K10: multi-user
 def test_k9_multi_user(oracle):
     # rs/index/src/multi_spann/index.rs:358-412: user 0 = 1000 x [i,i,i,i] + doc 1000 = [1.2,2.2,3.2,4.2]
@@ -321,8 +347,10 @@ def test_k9_multi_user(oracle):
     cat = F.concat_multi_spann({0: f0, (1 << 70) + 1: f1})
     ms = oracle.MultiSpannIndex(cat["user_table"], 4, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"],
                                 cat["ivf_vectors"])
-    res = ms.search_for_user([0], [[1.4, 2.4, 3.4, 4.4]], oracle.SearchParams(3, 100))
+    # SearchParams::new(k = 3, num_probes = 2, false): ef_construction 2, as the reference's test (index.rs:398-400)
+    res = ms.search_for_user([0], [[1.4, 2.4, 3.4, 4.4]], oracle.SearchParams(3, 2))
     assert res.found[0] == 1 and res.doc_ids(0) == [1000, 3, 2]
+    assert ms.search_for_user([0], [[1.4, 2.4, 3.4, 4.4]], oracle.SearchParams(3, 100)).doc_ids(0) == [1000, 3, 2]
     res = ms.search_for_user([(1 << 70) + 1, 12345], [[1.4, 2.4, 3.4, 4.4]] * 2, oracle.SearchParams(2, 100))
     assert res.doc_ids(0) == [5002, 5003] and res.found[1] == 0 and res.counts[1] == 0
     # the concatenation pads index blobs to 16 and vector blobs to 8 (multi_spann/writer.rs:171-229)
