@@ -30,10 +30,11 @@ class SiftLike:
     Round 1's generator (isotropic 128-d Gaussian clusters, `gaussian_clusters` below) has no such structure: its
     intra-cluster distances concentrate, so the reference's SYMMETRIC PQ distance cannot rank them (recall@10 0.11) —
     a property of the data, not of the scan.  With r = 2 (32 intrinsic dimensions) symmetric PQ m=16 reaches
-    recall@10 ~0.9 and IVF coverage rises gradually with nprobe, i.e. the QPS/recall sweep means something.
+    recall@10 ~0.82 and IVF coverage rises gradually with nprobe (512 broad components cut by 4096 lists: measured
+    0.42 / 0.81 / 0.82 / 0.82 / 0.82 at nprobe 1 / 8 / 16 / 32 / 64), i.e. the QPS/recall sweep means something.
     Base rows and queries are independent draws (different seeds) of the same distribution."""
 
-    def __init__(self, d=128, latent_per_block=2, n_clusters=4096, sigma=0.15, noise=1.0, seed=1, device="cuda"):
+    def __init__(self, d=128, latent_per_block=2, n_clusters=512, sigma=0.2, noise=1.0, seed=1, device="cuda"):
         assert d % 8 == 0
         self.d, self.r, self.m, self.sigma, self.noise, self.device = d, latent_per_block, d // 8, sigma, noise, device
         g = torch.Generator(device="cpu")
