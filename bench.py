@@ -148,11 +148,11 @@ class Env:
 
     def sift(self, n, d, nq, qseed):
         """(base rows, queries, description) of the C2/C3 synthetic SIFT-1M; the base is cached across workloads."""
-        from muopdb_amd import build as B
+        from muopdb_amd import build as B, synth as S
         if self.args.data == "legacy":
             ncl = max(1, min(4096, n // 244))
             if self._sift is None or self._sift[0] != (n, d):
-                self._sift = ((n, d), B.gaussian_clusters(n, d, n_clusters=ncl, seed=1))
+                self._sift = ((n, d), S.gaussian_clusters(n, d, n_clusters=ncl, seed=1))
             g = torch.Generator(device="cpu"); g.manual_seed(1)
             centers = (torch.rand((ncl, d), generator=g) * 218.0).cuda()
             gq = torch.Generator(device="cpu"); gq.manual_seed(qseed)
@@ -161,7 +161,7 @@ class Env:
             return self._sift[1], q, "%d isotropic Gaussian clusters, sigma 20, clipped [0,218] (round-1 generator)" % ncl
         kw = {k: v for k, v in (("n_clusters", self.args.sift_clusters), ("sigma", self.args.sift_sigma), ("noise", self.args.sift_noise))
               if v is not None}
-        gen = B.SiftLike(d, seed=1, **kw)
+        gen = S.SiftLike(d, seed=1, **kw)
         if self._sift is None or self._sift[0] != (n, d):
             self._sift = ((n, d), gen.draw(n, seed=11))
         return self._sift[1], gen.draw(nq, seed=qseed).contiguous(), \
@@ -186,7 +186,7 @@ def hbm_roofline(kernel, abytes_per_launch, kernel_ms, launches, **extra):
 
 # ------------------------------------------------------------------------------------------ HNSW (headline)
 def run_hnsw(env):
-    from muopdb_amd import build as B
+    from muopdb_amd import build as B, synth as S
     from muopdb_amd.index import BlockBasedHnsw
     args, ctx, rank, world = env.args, env.ctx, env.rank, env.world
     n = args.n or 1_000_000
@@ -199,7 +199,7 @@ def run_hnsw(env):
     x, queries, desc = env.sift(n, d, nq, 1000 + rank)
     log("data %.1fs" % (time.time() - t0))
     t0 = time.time()
-    index_bytes, vec_bytes = B.hnsw_files(x, max_neighbors=args.max_neighbors, max_layers=8, kcand=2 * args.max_neighbors, seed=1)
+    index_bytes, vec_bytes = S.hnsw_files(x, max_neighbors=args.max_neighbors, max_layers=8, kcand=2 * args.max_neighbors, seed=1)
     log("graph build %.1fs (%d MiB index)" % (time.time() - t0, len(index_bytes) >> 20))
     t0 = time.time()
     hnsw = BlockBasedHnsw(ctx, index_bytes, vec_bytes, d)
@@ -224,7 +224,7 @@ def run_hnsw(env):
         evals += st["distance_evals"]; expanded += st["expanded_nodes"]; abytes += st["algorithmic_bytes"]
     found = torch.cat(found).cpu().numpy()
     tq = queries[warm * batch:(warm + steps) * batch]
-    gt, _ = B.exact_knn(x, k, queries=tq, f64=True)
+    gt, _ = S.exact_knn(x, k, queries=tq, f64=True)
     rec = recall_at_k(found, gt.cpu().numpy(), k)
     out = dict(
         value=world * steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec,
@@ -293,7 +293,7 @@ def run_hnsw(env):
 def run_flat(env, n=None, batch=None):
     """flat brute-force L2: the C2/C3 1M base (default inside --workload all) or BASELINE config C1 (10k x 128, batch 1,
     py/create_test_hdf5.py-shaped data) with --workload flat."""
-    from muopdb_amd import build as B
+    from muopdb_amd import build as B, synth as S
     from muopdb_amd.index import FlatIndex
     args, ctx, rank, world = env.args, env.ctx, env.rank, env.world
     n = n or args.n or 10_000
@@ -330,7 +330,7 @@ def run_flat(env, n=None, batch=None):
     # recall@k of the last timed batch against the f64 brute force (untimed re-run of that batch)
     last = warm + steps - 1
     step(last)
-    gt, _ = B.exact_knn(x[lo:hi], k, queries=queries[last * batch:(last + 1) * batch], f64=True)
+    gt, _ = S.exact_knn(x[lo:hi], k, queries=queries[last * batch:(last + 1) * batch], f64=True)
     rec = recall_at_k(ids.cpu().numpy().astype(np.int64), gt.cpu().numpy(), k)
     batched = batch >= 8 and (hi - lo) >= 65536  # mdb_flat_mfma.hip: sample bound + MFMA filter + exact refine
     out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec,
@@ -398,12 +398,13 @@ def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=
 
 def build_ivfpq(env, x, nlist, seed=3):
     """IVF centroids + PQ codebook + codes + files for device rows x (build side: muopdb_amd.build)"""
-    from muopdb_amd import build as B, formats as F
+    from muopdb_amd import build as B, formats as F, synth as S
     from muopdb_amd.index import ProductQuantizer
     n, d = x.shape
-    cent = B.kmeans(x, nlist, iters=6, seed=seed, sample=min(n, 400_000))
-    assign = B.assign_nearest(x, cent)
-    cb = B.train_pq_codebook(x, 8, 8, iters=6, seed=seed + 1, sample=100_000)
+    ctx = env.ctx
+    cent = B.kmeans(ctx, x, nlist, iters=6, seed=seed, sample=min(n, 400_000))
+    assign = B.assign_nearest(ctx, x, cent)
+    cb = B.train_pq_codebook(ctx, x, 8, 8, iters=6, seed=seed + 1, sample=100_000)
     pq = ProductQuantizer(d, 8, 8, cb)
     codes = pq.quantize(env.ctx, x.cpu().numpy())
     pls = B.posting_lists_from_assignment(assign, nlist)
@@ -413,7 +414,7 @@ def build_ivfpq(env, x, nlist, seed=3):
 
 def run_ivfpq(env):
     """BASELINE config C3: SIFT-1M-like, IVF nlist=4096 + PQ m=16 (subdim 8) nbits=8, batch 256; nprobe sweep."""
-    from muopdb_amd import build as B
+    from muopdb_amd import build as B, synth as S
     from muopdb_amd.index import BlockBasedIvf
     args, ctx, rank, world = env.args, env.ctx, env.rank, env.world
     n = args.n or 1_000_000
@@ -431,7 +432,7 @@ def run_ivfpq(env):
     dump(args, rank, "ivfpq", index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy(), "codebook.f32": cb})
     tq = queries[warm * batch:(warm + steps) * batch]
     nrec = min(len(tq), 2560, max(256, int(1.3e10 // n)))  # f64 ground truth for a bounded number of the timed queries
-    gt = B.exact_knn(x, k, queries=tq[:nrec], f64=True)[0].cpu().numpy()
+    gt = S.exact_knn(x, k, queries=tq[:nrec], f64=True)[0].cpu().numpy()
     m = ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt, nrec)
     out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=m["recall"], scaling="strong",
                config={"workload": "SIFT-1M-like synthetic %dx%d (%s), IVF nlist=%d + PQ m=16 nbits=8 (symmetric distance), nprobe=%d, "
@@ -466,7 +467,7 @@ def run_ivfpq(env):
 def run_c5(env):
     """BASELINE config C5 as ONE GPU of the 8 sees it: rank 0's shard (posting lists l % 8 == 0) of a 100M x 128 index
     stored as 16-byte PQ codes, the FULL coarse quantizer (65 536 centroids, replicated), nprobe 64, batch 4096."""
-    from muopdb_amd import build as B
+    from muopdb_amd import build as B, synth as S
     from muopdb_amd.index import BlockBasedIvf
     args, ctx = env.args, env.ctx
     batch = args.batch or 4096
@@ -474,7 +475,7 @@ def run_c5(env):
     steps, warm = args.steps, args.warmup
     total = args.n or 100_000_000
     t0 = time.time()
-    sh = B.c5_shard(ctx, total=total, world=8, rank=0, nlist=args.nlist or 65536, log=log)
+    sh = S.c5_shard(ctx, total=total, world=8, rank=0, nlist=args.nlist or 65536, log=log)
     log("C5 shard build %.1fs: %d vectors in %d owned lists" % (time.time() - t0, sh["n"], sh["owned_lists"]))
     ivf = BlockBasedIvf(ctx, sh["index"], sh["vectors"], sh["pq"])
     queries = sh["gen"].draw((steps + warm) * batch, seed=5000).contiguous()
@@ -506,7 +507,7 @@ def run_spann(env, users=None):
     """BASELINE.md C4 shape: multi-user SPANN over unit-norm f32 rows, one (user, query) pair per user
     per batch, posting lists sharded l % world, one all-gather + merge per batch.  Defaults are a
     1/8 slice (128 users x 9766 x 768 = 3.8 GB); --users 1024 is the full 10M x 768 (30.7 GB)."""
-    from muopdb_amd import build as B
+    from muopdb_amd import build as B, synth as S
     from muopdb_amd import formats as F
     from muopdb_amd import distributed as D
     from muopdb_amd.index import MultiSpannIndex, SearchParams
@@ -521,17 +522,17 @@ def run_spann(env, users=None):
     steps, warm = args.steps, args.warmup
     nlist = max(1, per // 64)
     t0 = time.time()
-    gen = B.EmbedLike(d, seed=3) if args.data == "lowrank" else None
+    gen = S.EmbedLike(d, seed=3) if args.data == "lowrank" else None
     users_, base, ucent = {}, [], []
     for u in range(U):
         if gen is not None:
             ucent.append(gen.user(u))
             x = gen.draw(ucent[u], per, seed=3_000_000 + u)
         else:
-            x = B.unit_gaussian(per, d, seed=3_000_000 + u)
-        cent = B.kmeans(x, nlist, iters=4, seed=u)
-        pls = B.posting_lists_from_assignment(B.assign_nearest(x, cent), cent.shape[0])
-        hi, hv = B.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
+            x = S.unit_gaussian(per, d, seed=3_000_000 + u)
+        cent = B.kmeans(ctx, x, nlist, iters=4, seed=u)
+        pls = B.posting_lists_from_assignment(B.assign_nearest(ctx, x, cent), cent.shape[0])
+        hi, hv = S.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
         docs = np.arange(u * per, (u + 1) * per, dtype=np.uint64)
         users_[u + 1] = dict(hnsw_index=hi, hnsw_vectors=hv, ivf_index=F.write_ivf_index(cent.cpu().numpy(), docs, pls),
                              ivf_vectors=F.write_vector_file(x.cpu().numpy()))

@@ -171,6 +171,17 @@ mdb_status mdb_ivf_assign(mdb_ctx* ctx, const float* centroids, size_t num_centr
                           size_t max_clusters_per_vector, float distance_threshold, mdb_mem mem, uint32_t* centroid_ids_out,
                           uint32_t* counts_out);
 
+/* KMeansBuilder::fit / run_lloyd (rs/utils/src/kmeans_builder/kmeans_builder.rs:116-360), L2: Lloyd
+ * iterations with the reference's size penalty (cost = squared distance + tolerance * cluster size), LaneConforming /
+ * cascade distance by the dimension's divisibility, sequential-order centroid sums and empty-cluster repair — bit-identical
+ * to the reference's run from the same initial points.  `init_point_ids` [n_init] = `cluster_init_values` (the reference
+ * draws them with thread_rng when absent; the host draws them here), n_init must equal min(num_clusters, n).
+ * data [n][d]; centroids_out [min(num_clusters, n)][d]; assignments_out [n] (may be NULL); `mem` applies to data and outputs
+ * (init_point_ids, error_out, iterations_out are host).  error_out = the reference's `last_dist`. */
+mdb_status mdb_kmeans_fit(mdb_ctx* ctx, const float* data, size_t n, size_t d, size_t num_clusters, size_t max_iter, float tolerance,
+                          const uint64_t* init_point_ids, size_t n_init, mdb_mem mem, float* centroids_out,
+                          uint32_t* assignments_out, float* error_out, uint32_t* iterations_out);
+
 /* ---------------------------------------------------------------- IVF
  * BlockBasedIvf::new_with_offset ivf/block_based/index.rs:94-138: `index_bytes` is the IVF
  * `index` file (container: ivf/block_based/storage.rs:52-138), `vectors_bytes` the `vectors`

@@ -1,339 +1,177 @@
-"""Index construction on the GPU (the callers / data producers either
-side of the hot path).  PyTorch is used here as device-memory plumbing for the bulk,
-GEMM-shaped build steps (k-NN graphs, k-means); the products are the reference's on-disk
-formats (muopdb_amd.formats), which the hot path (libmuopdb_hip.so) then loads.
+"""Index construction through the native library (the callers / data producers either side of the
+hot path).  Every distance-shaped step runs in libmuopdb_hip.so:
 
-The reference builds are nondeterministic (thread_rng: rs/index/src/hnsw/builder.rs:332-337,
-rs/index/src/ivf/builder.rs:409,476), so build parity is QUALITY parity (recall), never bit
-parity; search parity is bit-exact given the same files.
+* kmeans_fit / kmeans      — KMeansBuilder::fit (rs/utils/src/kmeans_builder/kmeans_builder.rs:116-360) = mdb_kmeans_fit:
+                             Lloyd with the size penalty and the empty-cluster repair, bit-identical to the reference's
+                             run from the same initial points (the reference draws them with thread_rng, here a seeded
+                             numpy generator does);
+* train_pq_codebook        — ProductQuantizerBuilder's role (rs/quantization/src/pq/pq_builder.rs:43-102: one k-means
+                             per subvector; the reference uses the third-party `kmeans` crate's minibatch variant, so this
+                             is QUALITY parity by construction) on mdb_kmeans_fit;
+* assign_nearest           — IvfBuilder::build_posting_lists' per-vector step (ivf/builder.rs:267-326) = mdb_ivf_assign;
+* ivf_build_centroids      — IvfBuilder::build_centroids (ivf/builder.rs:460-541): sample -> k-means -> assign -> split the
+                             longest posting list until none exceeds max_posting_list_size;
+* insert_hnsw              — HnswBuilder::insert (hnsw/builder.rs:221-305) batched over the library's traversal kernels.
 
-* bulk_hnsw       — HNSW-format graph from exact k-NN + the reference's neighbour-selection
-                    heuristic (builder.rs:339-375), level assignment as builder.rs:332-337.
-* kmeans / train_pq_codebook / assign_lists — IvfBuilder / ProductQuantizerBuilder roles.
+Inputs are numpy arrays (host) or torch CUDA tensors (device; torch is plumbing here: data_ptr() and slicing only).
+The products are the reference's on-disk formats (muopdb_amd.formats), which the hot path then loads.
 """
-import math
+import ctypes as C
 
 import numpy as np
-import torch
 
 from . import formats as F
+from . import lib as L
 
 
-# ------------------------------------------------------------------------------------------ data
-class SiftLike:
-    """BASELINE.md C2/C3 synthetic "SIFT-1M" (no dataset can be downloaded): integer-valued f32 rows in [0, 218] with the
-    two properties of real descriptors that decide what an index can do with them — a LOW INTRINSIC DIMENSION and
-    per-subvector structure a product quantizer can code.  Every 8-float block s is a `latent_per_block`-dimensional
-    latent mapped through a fixed non-negative 8 x r frame U_s; the d/8 * r latent coordinates come from a mixture of
-    `n_clusters` Gaussians (centres uniform in the unit cube, spread `sigma`), plus isotropic full-rank noise, then
-    clipped and rounded like SIFT:  x = clip(round(300 * (z U) + 20 + noise * eps), 0, 218).
-    Round 1's generator (isotropic 128-d Gaussian clusters, `gaussian_clusters` below) has no such structure: its
-    intra-cluster distances concentrate, so the reference's SYMMETRIC PQ distance cannot rank them (recall@10 0.11) —
-    a property of the data, not of the scan.  With r = 2 (32 intrinsic dimensions) symmetric PQ m=16 reaches
-    recall@10 ~0.82 and IVF coverage rises gradually with nprobe (512 broad components cut by 4096 lists: measured
-    0.42 / 0.81 / 0.82 / 0.82 / 0.82 at nprobe 1 / 8 / 16 / 32 / 64), i.e. the QPS/recall sweep means something.
-    Base rows and queries are independent draws (different seeds) of the same distribution."""
-
-    def __init__(self, d=128, latent_per_block=2, n_clusters=512, sigma=0.2, noise=1.0, seed=1, device="cuda"):
-        assert d % 8 == 0
-        self.d, self.r, self.m, self.sigma, self.noise, self.device = d, latent_per_block, d // 8, sigma, noise, device
-        g = torch.Generator(device="cpu")
-        g.manual_seed(seed)
-        u = torch.rand((self.m, self.r, 8), generator=g) + 0.1
-        self.frames = (u / u.norm(dim=2, keepdim=True)).to(device)
-        self.centers = torch.rand((n_clusters, self.m * self.r), generator=g).to(device)
-
-    def draw(self, n, seed, chunk=1 << 20):
-        g = torch.Generator(device="cpu")
-        g.manual_seed(seed)
-        a = torch.randint(0, self.centers.shape[0], (n,), generator=g)
-        out = torch.empty((n, self.d), dtype=torch.float32, device=self.device)
-        gd = torch.Generator(device=self.device)
-        gd.manual_seed(seed)
-        for s in range(0, n, chunk):
-            e = min(n, s + chunk)
-            z = self.centers[a[s:e].to(self.device)] + self.sigma * torch.randn((e - s, self.m * self.r), generator=gd,
-                                                                                device=self.device)
-            x = torch.einsum("nmr,mre->nme", z.view(e - s, self.m, self.r), self.frames).reshape(e - s, self.d)
-            x = x * 300.0 + 20.0 + self.noise * torch.randn((e - s, self.d), generator=gd, device=self.device)
-            out[s:e] = torch.clamp(torch.round(x), 0, 218)
-        return out
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
 
 
-class EmbedLike:
-    """BASELINE.md C4 synthetic sentence embeddings (py/embed_1m_sentences.py's nomic-embed role): unit-norm 768-d rows
-    of LOW RANK + noise — a shared r x d map (the "model") applied to per-user latent mixtures.  Round 1's isotropic
-    768-d Gaussian has no neighbourhood structure at all (every centroid is equally far: SPANN recall 0.32 whatever the
-    probe count).  Here a user's rows are  normalise(z A + noise * eps),  z from `n_clusters` broad Gaussians."""
-
-    def __init__(self, d=768, rank=48, n_clusters=8, sigma=1.0, noise=0.01, seed=3, device="cuda"):
-        self.d, self.rank, self.ncl, self.sigma, self.noise, self.device = d, rank, n_clusters, sigma, noise, device
-        g = torch.Generator(device="cpu")
-        g.manual_seed(seed)
-        self.A = (torch.randn((rank, d), generator=g) / d ** 0.5).to(device)
-
-    def user(self, user_seed):
-        """the latent cluster centres of one user"""
-        g = torch.Generator(device="cpu")
-        g.manual_seed(1_000_003 * 7 + user_seed)
-        return torch.randn((self.ncl, self.rank), generator=g).to(self.device)
-
-    def draw(self, centers, n, seed):
-        g = torch.Generator(device="cpu")
-        g.manual_seed(seed)
-        a = torch.randint(0, self.ncl, (n,), generator=g).to(self.device)
-        gd = torch.Generator(device=self.device)
-        gd.manual_seed(seed)
-        z = centers[a] + self.sigma * torch.randn((n, self.rank), generator=gd, device=self.device)
-        x = z @ self.A + self.noise * torch.randn((n, self.d), generator=gd, device=self.device)
-        return x / x.norm(dim=1, keepdim=True)
+def _rows(x):
+    """(pointer, n, d, mem, keepalive) of a [n][d] f32 matrix: numpy -> host, torch CUDA tensor -> device"""
+    if _is_torch(x):
+        import torch
+        t = x.contiguous()
+        if t.dtype != torch.float32:
+            t = t.float()
+        if t.is_cuda:
+            return C.c_void_p(t.data_ptr()), t.shape[0], t.shape[1], L.MEM_DEVICE, t
+        x = t.numpy()
+    a = L.f32(x)
+    a = a.reshape(-1, a.shape[-1])
+    return L.ptr(a, C.c_float), a.shape[0], a.shape[1], L.MEM_HOST, a
 
 
-def gaussian_clusters(n, d=128, n_clusters=4096, sigma=20.0, seed=1, device="cuda"):
-    """Round 1's C2/C3 base (isotropic Gaussian clusters, clipped to [0,218], rounded); kept so that round-1 numbers can be
-    reproduced (`bench.py --data legacy`)."""
-    g = torch.Generator(device="cpu")
-    g.manual_seed(seed)
-    centers = torch.rand((n_clusters, d), generator=g) * 218.0
-    assign = torch.randint(0, n_clusters, (n,), generator=g)
-    out = torch.empty((n, d), dtype=torch.float32, device=device)
-    centers = centers.to(device)
-    chunk = 1 << 18
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        noise = torch.randn((e - s, d), generator=g) * sigma
-        out[s:e] = torch.clamp(torch.round(centers[assign[s:e].to(device)] + noise.to(device)), 0, 218)
-    return out
+def _take(x, idx):
+    if _is_torch(x):
+        import torch
+        return x[torch.as_tensor(idx, device=x.device)]
+    return np.asarray(x)[idx]
 
 
-def unit_gaussian(n, d, seed, device="cuda"):
-    """Round 1's C4 rows (isotropic Gaussian, normalised); structure-free, kept for `--data legacy`."""
-    g = torch.Generator(device="cpu")
-    g.manual_seed(seed)
-    out = torch.empty((n, d), dtype=torch.float32, device=device)
-    chunk = 1 << 16
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        x = torch.randn((e - s, d), generator=g).to(device)
-        out[s:e] = x / x.norm(dim=1, keepdim=True)
-    return out
+# ------------------------------------------------------------------------------------------ k-means
+def kmeans_fit(ctx, x, num_clusters, max_iter=10, tolerance=0.0, init_ids=None, seed=0):
+    """KMeansBuilder::fit: (centroids [k][d], assignments [n], error, iterations); k = min(num_clusters, n).
+    Outputs live where x lives (numpy / torch CUDA).  init_ids = `cluster_init_values` (default: k distinct random points,
+    like init_random_points' choose_multiple, from a seeded generator)."""
+    p, n, d, mem, keep = _rows(x)
+    k = min(int(num_clusters), n)
+    if init_ids is None:
+        init_ids = np.random.default_rng(seed).choice(n, size=k, replace=False)
+    init = np.ascontiguousarray(init_ids, np.uint64)
+    err, it = C.c_float(), C.c_uint32()
+    if mem == L.MEM_DEVICE:
+        import torch
+        cent = torch.empty((k, d), dtype=torch.float32, device=keep.device)
+        lab = torch.empty(n, dtype=torch.int32, device=keep.device)
+        cp, lp = C.c_void_p(cent.data_ptr()), C.c_void_p(lab.data_ptr())
+        torch.cuda.synchronize()  # x may still be in flight on torch's stream (the context runs on its own)
+    else:
+        cent = np.empty((k, d), np.float32)
+        lab = np.empty(n, np.uint32)
+        cp, lp = L.ptr(cent, C.c_float), L.ptr(lab, C.c_uint32)
+    ctx.check(ctx.lib.mdb_kmeans_fit(ctx.h, p, C.c_size_t(n), C.c_size_t(d), C.c_size_t(num_clusters), C.c_size_t(max_iter),
+                                     C.c_float(tolerance), L.ptr(init, C.c_uint64), C.c_size_t(init.size), C.c_int(mem), cp, lp,
+                                     C.byref(err), C.byref(it)))
+    return cent, lab, float(err.value), int(it.value)
 
 
-# ------------------------------------------------------------------------------------------ exact k-NN
-def exact_knn(x, k, queries=None, chunk=4096, f64=False, exclude_self=True):
-    """k nearest rows of x (squared L2) for every row of `queries` (default x itself).
-    Returns (idx int64 [nq,k], sqdist f32 [nq,k]) ascending.  f64=True gives the float64 ground
-    truth used for recall."""
-    self_q = queries is None
-    q = x if self_q else queries
-    dt = torch.float64 if f64 else torch.float32
-    xn = (x.to(dt) ** 2).sum(1)
-    xt = x.to(dt).t().contiguous() if f64 else x.t().contiguous()
-    nq = q.shape[0]
-    idx = torch.empty((nq, k), dtype=torch.int64, device=x.device)
-    dist = torch.empty((nq, k), dtype=torch.float32, device=x.device)
-    if f64:
-        chunk = max(64, chunk // 8)
-    for s in range(0, nq, chunk):
-        e = min(nq, s + chunk)
-        qc = q[s:e].to(dt)
-        dd = (qc ** 2).sum(1, keepdim=True) + xn[None, :] - 2.0 * (qc @ xt)
-        if self_q and exclude_self:
-            dd[torch.arange(e - s, device=x.device), torch.arange(s, e, device=x.device)] = float("inf")
-        v, i = torch.topk(dd, k, dim=1, largest=False, sorted=True)
-        idx[s:e] = i
-        dist[s:e] = v.clamp_min(0).to(torch.float32)
-    return idx, dist
-
-
-# ------------------------------------------------------------------------------------------ HNSW bulk build
-def _heuristic_prune(x, node_ids, cand_idx, cand_sq, max_neighbors, chunk=8192):
-    """select_neighbors_heuristic (rs/index/src/hnsw/builder.rs:339-375), batched: walk the
-    candidates nearest-first, keep e unless an already kept x is closer to e than the node is."""
-    n, K = cand_idx.shape
-    keep = torch.zeros((n, K), dtype=torch.bool, device=x.device)
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        ci = cand_idx[s:e]
-        cv = x[node_ids[ci]]                                   # [C,K,d]
-        sq = (cv ** 2).sum(-1)
-        pair = sq[:, :, None] + sq[:, None, :] - 2.0 * torch.bmm(cv, cv.transpose(1, 2))  # [C,K,K]
-        dq = cand_sq[s:e]
-        sel = torch.zeros((e - s, K), dtype=torch.bool, device=x.device)
-        cnt = torch.zeros(e - s, dtype=torch.int32, device=x.device)
-        valid = torch.isfinite(dq)
-        for i in range(K):
-            bad = ((pair[:, i, :] < dq[:, i:i + 1]) & sel).any(dim=1)
-            ok = (~bad) & (cnt < max_neighbors) & valid[:, i]
-            sel[:, i] = ok
-            cnt += ok.to(torch.int32)
-        keep[s:e] = sel
-    return keep
-
-
-def _layer_graph(x, node_ids, max_neighbors, kcand):
-    """Adjacency (CSR over local indices -> global ids) of one layer."""
-    n = node_ids.shape[0]
-    dev = x.device
-    if n <= 1:
-        return np.zeros(n + 1, np.uint64), np.zeros(0, np.uint32)
-    k = min(kcand, n - 1)
-    idx, sq = exact_knn(x[node_ids], k)
-    keep = _heuristic_prune(x, node_ids, idx, sq, max_neighbors)
-    src = torch.arange(n, device=dev)[:, None].expand(n, k)[keep]
-    dst = idx[keep]
-    dd = sq[keep]
-    # add reverse edges, dedup (src,dst), keep the max_neighbors nearest per node
-    s2 = torch.cat([src, dst])
-    d2 = torch.cat([dst, src])
-    w2 = torch.cat([dd, dd])
-    key = s2 * n + d2
-    key, order = torch.sort(key)
-    w2 = w2[order]
-    first = torch.ones_like(key, dtype=torch.bool)
-    first[1:] = key[1:] != key[:-1]
-    key, w2 = key[first], w2[first]
-    s2, d2 = key // n, key % n
-    o1 = torch.sort(w2, stable=True).indices
-    s2, d2 = s2[o1], d2[o1]
-    o2 = torch.sort(s2, stable=True).indices
-    s2, d2 = s2[o2], d2[o2]
-    counts = torch.bincount(s2, minlength=n)
-    starts = torch.cumsum(counts, 0) - counts
-    pos = torch.arange(s2.shape[0], device=dev) - starts[s2]
-    m = pos < max_neighbors
-    s2, d2 = s2[m], d2[m]
-    counts = torch.bincount(s2, minlength=n)
-    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-    indptr[1:] = torch.cumsum(counts, 0)
-    edges = node_ids[d2]
-    return indptr.cpu().numpy().astype(np.uint64), edges.cpu().numpy().astype(np.uint32)
-
-
-def bulk_hnsw(x, max_neighbors=32, max_layers=8, kcand=64, seed=1):
-    """Returns (layers, levels): `layers` in muopdb_amd.formats.write_hnsw_index's CSR form
-    (layer 0 first; points None for layer 0), entry point = first point of the top layer."""
-    n = x.shape[0]
-    g = torch.Generator(device="cpu")
-    g.manual_seed(seed)
-    u = torch.rand(n, generator=g).clamp_min(1e-12)
-    # get_random_layer (builder.rs:332-337): floor(-ln(u)/ln(max_neighbors)), capped
-    lv = torch.floor(-torch.log(u) / math.log(max_neighbors)).to(torch.int64).clamp_max(max_layers)
-    top = int(lv.max().item())
-    lv = lv.to(x.device)
-    layers = []
-    for layer in range(top + 1):
-        ids = torch.nonzero(lv >= layer, as_tuple=False).reshape(-1)
-        indptr, edges = _layer_graph(x, ids, max_neighbors, kcand)
-        layers.append((None if layer == 0 else ids.cpu().numpy().astype(np.uint32), indptr, edges))
-    return layers, lv.cpu().numpy()
-
-
-def hnsw_files(x, doc_ids=None, **kw):
-    """(index_bytes, vector_bytes) in the reference's HNSW formats for device rows x."""
-    layers, _ = bulk_hnsw(x, **kw)
-    n, d = x.shape
-    if doc_ids is None:
-        doc_ids = np.arange(n, dtype=np.uint64)
-    return F.write_hnsw_index(layers, doc_ids, d), F.write_vector_file(x.cpu().numpy())
-
-
-# ------------------------------------------------------------------------------------------ k-means / PQ / IVF
-def kmeans(x, k, iters=10, seed=0, sample=None):
-    """Lloyd on the GPU (KMeansBuilder role, rs/utils/src/kmeans_builder/kmeans_builder.rs:163-360,
-    without the size penalty); empty clusters keep their previous centre."""
-    g = torch.Generator(device="cpu")
-    g.manual_seed(seed)
+def kmeans(ctx, x, k, iters=10, seed=0, sample=None, tolerance=0.0):
+    """centroids [k][d] of a (sampled) Lloyd run — IvfBuilder's use of KMeansBuilder (ivf/builder.rs:470-500)."""
     n = x.shape[0]
     if sample is not None and sample < n:
-        x = x[torch.randperm(n, generator=g)[:sample].to(x.device)]
-        n = sample
-    k = min(k, n)
-    c = x[torch.randperm(n, generator=g)[:k].to(x.device)].clone()
-    for _ in range(iters):
-        a = assign_nearest(x, c)
-        sums = torch.zeros_like(c).index_add_(0, a, x)
-        cnt = torch.bincount(a, minlength=k).to(x.dtype)
-        nz = cnt > 0
-        c[nz] = sums[nz] / cnt[nz, None]
-    return c
+        x = _take(x, np.sort(np.random.default_rng(seed + 7919).choice(n, size=sample, replace=False)))
+    return kmeans_fit(ctx, x, k, max_iter=iters, tolerance=tolerance, seed=seed)[0]
 
 
-def assign_nearest(x, c, chunk=1 << 16):
-    chunk = max(1024, min(chunk, (1 << 29) // max(1, c.shape[0])))  # distance block of at most 2 GiB
-    cn = (c ** 2).sum(1)
-    ct = c.t().contiguous()
-    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
-    for s in range(0, x.shape[0], chunk):
-        e = min(x.shape[0], s + chunk)
-        dd = cn[None, :] - 2.0 * (x[s:e] @ ct)
-        out[s:e] = dd.argmin(1)
-    return out
-
-
-def train_pq_codebook(x, subdim, num_bits, iters=8, seed=0, sample=100_000):
-    """[m][2^num_bits][subdim] f32 codebook (ProductQuantizerBuilder role, pq_builder.rs:43-102)."""
-    d = x.shape[1]
+def train_pq_codebook(ctx, x, subdim, num_bits, iters=8, seed=0, sample=100_000):
+    """[m][2^num_bits][subdim] f32 codebook, flattened (the `codebook` file of pq/mod.rs:101-126): one k-means per subvector."""
+    n, d = x.shape
     m, K = d // subdim, 1 << num_bits
-    cb = torch.empty((m, K, subdim), dtype=torch.float32, device=x.device)
+    if sample is not None and sample < n:
+        x = _take(x, np.sort(np.random.default_rng(seed + 104729).choice(n, size=sample, replace=False)))
+    cb = np.empty((m, K, subdim), np.float32)
     for s in range(m):
-        c = kmeans(x[:, s * subdim:(s + 1) * subdim].contiguous(), K, iters, seed + s, sample)
-        if c.shape[0] < K:
-            c = torch.cat([c, c[-1:].expand(K - c.shape[0], subdim)])
+        sub = x[:, s * subdim:(s + 1) * subdim]
+        c = kmeans_fit(ctx, sub.contiguous() if _is_torch(sub) else np.ascontiguousarray(sub), K, max_iter=iters, seed=seed + s)[0]
+        c = c.cpu().numpy() if _is_torch(c) else c
+        if c.shape[0] < K:  # fewer points than codes: pad by repeating the last row
+            c = np.concatenate([c, np.repeat(c[-1:], K - c.shape[0], 0)])
         cb[s] = c
-    return cb.reshape(-1).cpu().numpy()
+    return cb.reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------ IVF
+def assign_nearest(ctx, x, centroids, max_clusters_per_vector=1, distance_threshold=0.1):
+    """nearest centroid(s) of every row by the reference's squared-L2 cascade (mdb_ivf_assign).  max_clusters_per_vector == 1:
+    labels [n]; otherwise (ids [n][mc] UINT32_MAX padded, counts [n]).  Output lives where x lives."""
+    p, n, d, mem, keep = _rows(x)
+    if mem == L.MEM_DEVICE:
+        import torch
+        c = centroids if _is_torch(centroids) else torch.from_numpy(L.f32(centroids)).to(keep.device)
+        c = c.contiguous().float()
+        ids = torch.empty((n, max_clusters_per_vector), dtype=torch.int32, device=keep.device)
+        cnt = torch.empty(n, dtype=torch.int32, device=keep.device)
+        torch.cuda.synchronize()
+        ctx.check(ctx.lib.mdb_ivf_assign(ctx.h, C.c_void_p(c.data_ptr()), C.c_size_t(c.shape[0]), p, C.c_size_t(n), C.c_size_t(d),
+                                         C.c_size_t(max_clusters_per_vector), C.c_float(distance_threshold), C.c_int(mem),
+                                         C.c_void_p(ids.data_ptr()), C.c_void_p(cnt.data_ptr())))
+        ctx.sync()
+        return ids[:, 0].to(torch.int64) if max_clusters_per_vector == 1 else (ids, cnt)
+    c = L.f32(centroids.cpu().numpy() if _is_torch(centroids) else centroids)
+    ids = np.empty((n, max_clusters_per_vector), np.uint32)
+    cnt = np.empty(n, np.uint32)
+    ctx.check(ctx.lib.mdb_ivf_assign(ctx.h, L.ptr(c, C.c_float), C.c_size_t(c.shape[0]), p, C.c_size_t(n), C.c_size_t(d),
+                                     C.c_size_t(max_clusters_per_vector), C.c_float(distance_threshold), C.c_int(mem),
+                                     L.ptr(ids, C.c_uint32), L.ptr(cnt, C.c_uint32)))
+    return ids[:, 0].astype(np.int64) if max_clusters_per_vector == 1 else (ids, cnt)
 
 
 def posting_lists_from_assignment(assign, num_lists):
     """list of sorted u64 point-id arrays (IvfBuilder::build_posting_lists role)."""
-    a = assign.cpu().numpy()
+    a = assign.cpu().numpy() if _is_torch(assign) else np.asarray(assign)
     order = np.argsort(a, kind="stable")
     bounds = np.searchsorted(a[order], np.arange(num_lists + 1))
     return [order[bounds[i]:bounds[i + 1]].astype(np.uint64) for i in range(num_lists)]
 
 
-# ------------------------------------------------------------------------------------------ BASELINE config C5, one GPU's shard
-def c5_shard(ctx, total=100_000_000, world=8, rank=0, nlist=65536, d=128, chunk=2_000_000, seed=4, log=None):
-    """What ONE of the 8 GPUs holds of BASELINE config C5 (100M x 128 as 16-byte PQ codes, IVF nlist 65 536, posting lists
-    sharded l % world): the full coarse quantizer, the shared PQ codebook, and the posting lists this rank owns with
-    their codes (~total/world vectors, ~total/nlist per list).  The 100M rows are generated chunk by chunk (SiftLike),
-    assigned to their nearest of the 65 536 centroids, and only the rows of owned lists are kept — the other ranks'
-    lists are EMPTY in the returned index file, so loading it unsharded reproduces this rank's work exactly.
-    Returns dict(index, vectors, pq, codebook, gen, n, nlist, owned_lists, centroids)."""
-    from .index import ProductQuantizer
-    gen = SiftLike(d, seed=seed)
-    sample = gen.draw(min(total, 2_000_000), seed=seed * 100)
-    cent = kmeans(sample, nlist, iters=2, seed=seed)
-    cb = train_pq_codebook(sample, 8, 8, iters=6, seed=seed + 1, sample=100_000)
-    pq = ProductQuantizer(d, 8, 8, cb)
-    del sample
-    nlist = cent.shape[0]
-    keep_codes, keep_list = [], []
-    done = 0
-    ci = 0
-    while done < total:
-        m = min(chunk, total - done)
-        x = gen.draw(m, seed=seed * 1000 + ci)
-        a = assign_nearest(x, cent, chunk=1 << 14)
-        own = (a % world) == rank
-        xo = x[own]
-        keep_list.append(a[own].cpu().numpy().astype(np.int64))
-        keep_codes.append(pq.quantize(ctx, xo.cpu().numpy()))
-        done += m
-        ci += 1
-        if log and ci % 10 == 0:
-            log("c5 shard: %d / %d rows assigned" % (done, total))
-    lists = np.concatenate(keep_list)
-    codes = np.concatenate(keep_codes)
-    del keep_list, keep_codes
-    n = codes.shape[0]
-    # point ids in list order (what IvfBuilder::reindex produces, ivf/builder.rs:682): list l's points are contiguous
-    order = np.argsort(lists, kind="stable")
-    codes = codes[order]
-    bounds = np.searchsorted(lists[order], np.arange(nlist + 1))
-    pls = [np.arange(bounds[i], bounds[i + 1], dtype=np.uint64) for i in range(nlist)]
-    # this rank's global doc ids: an arbitrary injective labelling (rank-strided)
-    docs = np.arange(n, dtype=np.uint64) * np.uint64(world) + np.uint64(rank)
-    index = F.write_ivf_index(cent.cpu().numpy(), docs, pls, quantized_dimension=d // 8)
-    return dict(index=index, vectors=F.write_vector_file(codes), pq=pq, codebook=cb, gen=gen, n=n, nlist=nlist,
-                owned_lists=int((np.diff(bounds) > 0).sum()), centroids=cent)
+
+
+def ivf_build_centroids(ctx, x, num_clusters, max_posting_list_size, num_data_points_for_clustering=20_000, max_iteration=10,
+                        tolerance=0.0, seed=0):
+    """IvfBuilder::build_centroids (rs/index/src/ivf/builder.rs:460-541): first pass = k-means over a sample with
+    compute_actual_num_clusters clusters and an assignment of every point; then the LONGEST posting list is re-clustered
+    (cluster_docs :419-444: ceil(len / max) clusters from a sample of max(10 * clusters, num_data_points_for_clustering) of
+    its points) until no list exceeds max_posting_list_size.  Returns (centroids [L][d] numpy, posting lists as sorted u64
+    arrays); empty lists are dropped like the reference does (:529-534).  The reference's sampling is thread_rng, so the
+    outcome is quality-parity; each k-means run inside is the bit-exact mdb_kmeans_fit."""
+    import heapq
+    n, d = x.shape
+    rng = np.random.default_rng(seed)
+
+    def ceil_div(a, b):
+        return (a + b - 1) // b
+
+    def cluster(point_ids, k, n_sample, s):
+        pick = point_ids if len(point_ids) <= n_sample else np.sort(rng.choice(point_ids, size=n_sample, replace=False))
+        cent = kmeans_fit(ctx, _take(x, pick), k, max_iter=max_iteration, tolerance=tolerance, seed=s)[0]
+        lab = assign_nearest(ctx, _take(x, point_ids), cent)
+        lab = lab.cpu().numpy() if _is_torch(lab) else lab
+        cent = cent.cpu().numpy() if _is_torch(cent) else cent
+        order = np.argsort(lab, kind="stable")
+        bounds = np.searchsorted(lab[order], np.arange(cent.shape[0] + 1))
+        return [(cent[i], point_ids[order[bounds[i]:bounds[i + 1]]]) for i in range(cent.shape[0])]
+
+    per = ceil_div(n, num_clusters)
+    k0 = ceil_div(n, min(per, max_posting_list_size))  # compute_actual_num_clusters :446-458
+    heap, tick = [], 0
+    for cen, pl in cluster(np.arange(n), k0, max(k0, num_data_points_for_clustering), seed):
+        heapq.heappush(heap, (-len(pl), tick, cen, pl)); tick += 1
+    while heap and -heap[0][0] > max_posting_list_size:
+        _, _, _, pl = heapq.heappop(heap)
+        k = ceil_div(len(pl), max_posting_list_size)
+        for cen, sub in cluster(pl, k, max(k * 10, num_data_points_for_clustering), seed + tick):
+            heapq.heappush(heap, (-len(sub), tick, cen, sub)); tick += 1
+    kept = [(cen, pl) for _, _, cen, pl in sorted(heap, key=lambda t: t[1]) if len(pl)]
+    return np.stack([c for c, _ in kept]).astype(np.float32), [np.sort(pl).astype(np.uint64) for _, pl in kept]

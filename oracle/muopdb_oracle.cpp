@@ -1021,6 +1021,114 @@ int orc_ivf_assign(const float* centroids, size_t num_centroids, const float* ve
     return bad;
 }
 
+// KMeansBuilder::fit / run_lloyd — rs/utils/src/kmeans_builder/kmeans_builder.rs:116-360, L2 only (the server's
+// quantizers are hard-wired to L2, collection/snapshot.rs:160-163).  Deterministic given the initial points
+// (`cluster_init_values`, :141-150; the reference draws them with thread_rng otherwise): the distance is
+// LaneConformingDistanceCalculator<16|8|4> by the divisibility of the dimension (:127-137) or the full cascade,
+// plus the size penalty tolerance * cluster_size (:173-180, 333-338); first minimum wins (strict <, :205-211);
+// centroids are summed sequentially in point order (:227-247) and divided by the cluster size (:257-265); an
+// empty cluster takes the point of a cluster with > 1 points that is farthest from the EMPTY cluster's centroid —
+// which is the zero vector at that moment (:268-314); the loop stops when the labels repeat or after max_iter
+// iterations (:346-356).  error = the total of the second-to-last evaluation (`last_dist`, :358).
+// centroids_out [k][d], assignments_out [n]; *k_out = min(num_clusters, n); *iters_out = iterations run.
+static float kmeans_distance(const float* a, const float* b, size_t d) {
+    if (d % 16 == 0) return orc_lane_conforming(METRIC_L2, 16, a, b, d);
+    if (d % 8 == 0) return orc_lane_conforming(METRIC_L2, 8, a, b, d);
+    if (d % 4 == 0) return orc_lane_conforming(METRIC_L2, 4, a, b, d);
+    return l2_squared(a, b, d);
+}
+
+int orc_kmeans_fit(const float* data, size_t n, size_t d, size_t num_clusters, size_t max_iter, float tolerance,
+                   const uint64_t* init_ids, float* centroids_out, uint32_t* assignments_out, float* error_out,
+                   uint32_t* iters_out, size_t* k_out) {
+    const size_t k = std::min(num_clusters, n);
+    *k_out = k;
+    if (k == 0) return 1;
+    std::vector<float> cent(k * d);
+    for (size_t c = 0; c < k; ++c) {
+        if (init_ids[c] >= n) return 2;
+        std::copy(data + init_ids[c] * d, data + (init_ids[c] + 1) * d, cent.begin() + c * d);
+    }
+    std::vector<size_t> sizes(k, 0);
+    std::vector<float> penalties(k, 0.0f);
+    if (tolerance > 0.0f) for (size_t c = 0; c < k; ++c) penalties[c] = tolerance * (float)sizes[c];
+    std::vector<uint32_t> labels(n, 0), last(n);
+    std::vector<float> cost(n);
+    float last_dist = std::numeric_limits<float>::max();
+    size_t iteration = 0;
+    for (;;) {
+        last = labels;
+        std::vector<uint32_t> cur(n);
+#pragma omp parallel for schedule(static)
+        for (long long i = 0; i < (long long)n; ++i) {
+            uint32_t ml = 0;
+            float mc = std::numeric_limits<float>::max();
+            for (size_t c = 0; c < k; ++c) {
+                float dist = kmeans_distance(data + (size_t)i * d, cent.data() + c * d, d) + penalties[c];
+                if (dist < mc) { ml = (uint32_t)c; mc = dist; }
+            }
+            cur[i] = ml;
+            cost[i] = mc;
+        }
+        float total = 0.0f;
+        for (size_t i = 0; i < n; ++i) total = total + std::sqrt(cost[i]);
+        std::fill(cent.begin(), cent.end(), 0.0f);
+        for (size_t i = 0; i < n; ++i) {  // sequential, point order: c += s (f32)
+            float* c = cent.data() + (size_t)cur[i] * d;
+            const float* p = data + i * d;
+            for (size_t j = 0; j < d; ++j) c[j] = c[j] + p[j];  // chunks_exact(SIMD_WIDTH) covers every element (width 1 for other d)
+        }
+        std::fill(sizes.begin(), sizes.end(), 0);
+        for (size_t i = 0; i < n; ++i) sizes[cur[i]]++;
+        bool empty = false;
+        for (size_t c = 0; c < k; ++c) {
+            if (sizes[c] > 0) for (size_t j = 0; j < d; ++j) cent[c * d + j] /= (float)sizes[c];
+            else empty = true;
+        }
+        if (empty) {
+            for (size_t cid = 0; cid < k; ++cid) {
+                if (sizes[cid] != 0) continue;
+                float maxd = 0.0f;
+                size_t chosen_p = 0, chosen_c = 0;
+                for (size_t i = 0; i < n; ++i) {
+                    const size_t cc = cur[i];
+                    if (sizes[cc] > 1) {
+                        float dist = kmeans_distance(data + i * d, cent.data() + cid * d, d);
+                        if (dist > maxd) { maxd = dist; chosen_p = i; chosen_c = cc; }
+                    }
+                }
+                const float old_size = (float)sizes[chosen_c];
+                sizes[chosen_c] -= 1;
+                const float* cp = data + chosen_p * d;
+                for (size_t j = 0; j < d; ++j) {
+                    float x = cent[chosen_c * d + j];
+                    cent[chosen_c * d + j] = (x * old_size - cp[j]) / (old_size - 1.0f);
+                }
+                cur[chosen_p] = (uint32_t)cid;
+                sizes[cid] = 1;
+                for (size_t j = 0; j < d; ++j) cent[cid * d + j] = cp[j];
+            }
+        }
+        if (tolerance > 0.0f) {
+            float pen_total = 0.0f;
+            for (size_t c = 0; c < k; ++c) {
+                penalties[c] = tolerance * (float)sizes[c];
+                pen_total = pen_total + penalties[c] * (float)sizes[c];
+            }
+            total += pen_total;
+        }
+        labels = cur;
+        if (labels == last || iteration >= max_iter) break;
+        last_dist = total;
+        iteration += 1;
+    }
+    std::copy(cent.begin(), cent.end(), centroids_out);
+    std::copy(labels.begin(), labels.end(), assignments_out);
+    *error_out = last_dist;
+    *iters_out = (uint32_t)iteration;
+    return 0;
+}
+
 // distances of one query against a row-major base (metric 0 = sqrt L2, 1 = neg dot, 2 = squared L2)
 void orc_distance_many(int metric, const float* q, const float* base, size_t n, size_t d, float* out) {
     for (size_t i = 0; i < n; ++i) {

@@ -108,6 +108,26 @@ def lane_conforming(metric, lanes, a, b):
     return float(lib().orc_lane_conforming(C.c_int(metric), C.c_int(lanes), _p(a, C.c_float), _p(b, C.c_float), a.size))
 
 
+def kmeans_fit(data, num_clusters, max_iter, tolerance, init_ids):
+    """KMeansBuilder::fit with cluster_init_values (kmeans_builder.rs:116-360): (centroids [k][d], assignments [n], error, iterations)."""
+    x = _f32(data)
+    x = x.reshape(-1, x.shape[-1])
+    n, d = x.shape
+    k = min(num_clusters, n)
+    init = np.ascontiguousarray(init_ids, np.uint64)
+    if init.size != k:
+        raise ValueError("init_ids must hold min(num_clusters, n) point ids")
+    cent = np.empty((k, d), np.float32)
+    lab = np.empty(n, np.uint32)
+    err, it, kk = C.c_float(), C.c_uint32(), C.c_size_t()
+    rc = lib().orc_kmeans_fit(_p(x, C.c_float), C.c_size_t(n), C.c_size_t(d), C.c_size_t(num_clusters), C.c_size_t(max_iter),
+                              C.c_float(tolerance), _p(init, C.c_uint64), _p(cent, C.c_float), _p(lab, C.c_uint32), C.byref(err),
+                              C.byref(it), C.byref(kk))
+    if rc:
+        raise ValueError("orc_kmeans_fit failed: %d" % rc)
+    return cent, lab, float(err.value), int(it.value)
+
+
 def ivf_assign(centroids, vectors, max_clusters_per_vector, distance_threshold):
     """IvfBuilder::build_posting_lists' assignment (ivf/builder.rs:267-326) -> (ids [n][mc] UINT32_MAX padded, counts [n])."""
     c, v = _f32(centroids), _f32(vectors)

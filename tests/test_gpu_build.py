@@ -1,0 +1,113 @@
+"""GPU tests (-m gpu) of the build side: native Lloyd k-means (mdb_kmeans_fit) against the CPU
+restatement of KMeansBuilder::run_lloyd (rs/utils/src/kmeans_builder/kmeans_builder.rs:163-360) — BIT parity from the same
+initial points, incl. the size penalty, the lane-conforming distance variants and the empty-cluster repair — the
+reference's own k-means tests through the GPU, PQ codebook training (quality parity: the reference trains with a third-party
+crate) and IvfBuilder::build_centroids' list splitting."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from muopdb_amd import lib as L
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def _same(got, want):
+    gc, ga, ge, gi = got
+    wc, wa, we, wi = want
+    assert gi == wi, "iterations %d != %d" % (gi, wi)
+    assert np.array_equal(np.asarray(ga, np.int64), np.asarray(wa, np.int64))
+    assert np.array_equal(np.asarray(gc, np.float32).view(np.uint32), np.asarray(wc, np.float32).view(np.uint32))
+    assert np.float32(ge).view(np.uint32) == np.float32(we).view(np.uint32)
+
+
+@pytest.mark.parametrize("n,d,k,tol,iters,seed", [
+    (3000, 16, 20, 0.0, 10, 1),      # LaneConforming<16>
+    (3000, 128, 37, 1e-4, 6, 2),     # C3 coarse shape, size penalty
+    (2500, 24, 16, 1e-3, 8, 3),      # LaneConforming<8>
+    (2000, 12, 9, 0.0, 8, 4),        # LaneConforming<4>
+    (1500, 10, 7, 1e-4, 8, 5),       # full cascade (d % 4 != 0)
+    (1200, 3, 5, 0.0, 20, 6),
+    (4000, 8, 256, 0.0, 5, 7),       # PQ subvector shape
+    (700, 768, 11, 0.0, 3, 8),       # C4 dimension
+    (65, 5, 64, 0.0, 4, 9),          # nearly one point per cluster
+    (300, 32, 1, 0.0, 5, 10),        # a single cluster: the labels repeat at once
+])
+def test_kmeans_bit_parity(ctx, oracle, n, d, k, tol, iters, seed):
+    from muopdb_amd import build as B
+    rng = np.random.default_rng(seed)
+    x = H.sift_like(n, d, n_clusters=max(2, k // 2), seed=seed) if d >= 8 else rng.standard_normal((n, d)).astype(np.float32) * 10
+    init = rng.choice(n, size=min(k, n), replace=False)
+    _same(B.kmeans_fit(ctx, x, k, max_iter=iters, tolerance=tol, init_ids=init), oracle.kmeans_fit(x, k, iters, tol, init))
+
+
+def test_kmeans_empty_cluster_repair_and_device_buffers(ctx, oracle):
+    """duplicated rows and repeated init points force empty clusters (kmeans_builder.rs:268-314): same moves as the oracle;
+    the same run with device-resident data (torch tensors) returns the same bits"""
+    import torch
+    from muopdb_amd import build as B
+    rng = np.random.default_rng(12)
+    base = rng.standard_normal((40, 16)).astype(np.float32) * 5
+    x = np.concatenate([base, base, base[:10], rng.standard_normal((300, 16)).astype(np.float32)])
+    init = np.array([0, 40, 80, 1, 41, 3, 3, 3, 100, 200, 201, 5], np.uint64)   # identical points -> empty clusters
+    want = oracle.kmeans_fit(x, 12, 10, 0.0, init)
+    _same(B.kmeans_fit(ctx, x, 12, max_iter=10, tolerance=0.0, init_ids=init), want)
+    assert len(set(np.asarray(want[1]).tolist())) == 12
+    xt = torch.from_numpy(x).cuda()
+    c, a, e, it = B.kmeans_fit(ctx, xt, 12, max_iter=10, tolerance=0.0, init_ids=init)
+    _same((c.cpu().numpy(), a.cpu().numpy(), e, it), want)
+    want = oracle.kmeans_fit(x, 12, 10, 1e-3, init)                            # the penalty changes the assignment
+    _same(B.kmeans_fit(ctx, x, 12, max_iter=10, tolerance=1e-3, init_ids=init), want)
+
+
+def test_k14_reference_kmeans_tests_on_the_gpu(ctx):
+    # rs/utils/src/kmeans_builder/kmeans_builder.rs:373-486 (see tests/test_oracle_kat.py::test_k14_*)
+    from muopdb_amd import build as B
+    from muopdb_amd import lib as L
+    km = np.array([[0, 0], [40, 40], [90, 90], [1, 1], [41, 41], [91, 91], [2, 2], [42, 42], [92, 92]], np.float32)
+    cent, a, err, it = B.kmeans_fit(ctx, km, 3, max_iter=100, tolerance=1e-4, init_ids=[0, 1, 2])
+    assert a[0] == a[3] == a[6] and a[1] == a[4] == a[7] and a[2] == a[5] == a[8]
+    assert cent.tolist() == [[1.0, 1.0], [41.0, 41.0], [91.0, 91.0]]
+    km[7] = [5, 5]
+    cent, a, err, it = B.kmeans_fit(ctx, km, 3, max_iter=100, tolerance=0.0, init_ids=[0, 1, 2])
+    assert a[0] == a[3] == a[6] == a[7] and a[1] == a[4] and a[2] == a[5] == a[8]
+    cent, a, err, it = B.kmeans_fit(ctx, km, 10, max_iter=100, tolerance=0.0, seed=3)     # 10 clusters of 9 points -> 9
+    assert cent.shape == (9, 2) and set(a.tolist()) == set(range(9))
+    with pytest.raises(L.MuopdbError):
+        B.kmeans_fit(ctx, km, 3, init_ids=[0, 1])        # cluster_init_values of the wrong length
+    with pytest.raises(L.MuopdbError):
+        B.kmeans_fit(ctx, km, 3, init_ids=[0, 1, 99])    # not a point
+
+
+def test_pq_training_quality_and_ivf_list_splitting(ctx, oracle):
+    from muopdb_amd import build as B
+    from muopdb_amd.index import ProductQuantizer
+    x = H.sift_like(20000, 32, n_clusters=40, seed=21)
+    cb = B.train_pq_codebook(ctx, x, 8, 6, iters=8, seed=1, sample=8000)
+    ref = H.train_pq_codebook(x[:8000], 8, 6, iters=8)               # plain numpy Lloyd from another init
+    pq, rq = ProductQuantizer(32, 8, 6, cb), ProductQuantizer(32, 8, 6, ref)
+
+    def distortion(q):
+        rec = q.original_vector(ctx, q.quantize(ctx, x))
+        return float(((rec - x) ** 2).sum(1).mean())
+
+    assert distortion(pq) <= 1.05 * distortion(rq)
+    # IvfBuilder::build_centroids: no list longer than max_posting_list_size, every point in exactly one list
+    cent, pls = B.ivf_build_centroids(ctx, x, num_clusters=16, max_posting_list_size=900, num_data_points_for_clustering=4000,
+                                      max_iteration=6, tolerance=1e-5, seed=2)
+    assert len(pls) == cent.shape[0] >= 23 and max(len(p) for p in pls) <= 900 and min(len(p) for p in pls) > 0
+    allp = np.concatenate(pls)
+    assert allp.size == len(x) and np.array_equal(np.sort(allp), np.arange(len(x), dtype=np.uint64))
+    lab = B.assign_nearest(ctx, x, cent)
+    sizes = np.bincount(lab, minlength=cent.shape[0])
+    assert sizes.max() <= 4 * 900                                    # a final re-assignment stays balanced
+    ids, cnt = B.assign_nearest(ctx, x[:500], cent, max_clusters_per_vector=2, distance_threshold=0.1)
+    oids, ocnt = oracle.ivf_assign(cent, x[:500], 2, 0.1)
+    assert np.array_equal(ids, oids) and np.array_equal(cnt, ocnt)

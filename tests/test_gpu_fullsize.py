@@ -43,8 +43,8 @@ def ctx():
 @pytest.fixture(scope="module")
 def base(ctx):
     """(device rows, host rows, 96 host queries): the C2/C3 base of bench.py"""
-    from muopdb_amd import build as B
-    gen = B.SiftLike(D, seed=1)
+    from muopdb_amd import build as B, synth as S
+    gen = S.SiftLike(D, seed=1)
     x = gen.draw(N, seed=11)
     q = gen.draw(96, seed=4242)
     return x, x.cpu().numpy(), q.cpu().numpy().astype(np.float32)
@@ -95,9 +95,9 @@ def test_flat_1m_properties_and_oracle_rows(ctx, oracle, base, flat_1m):
 
 @pytest.fixture(scope="module")
 def hnsw_1m(ctx, base):
-    from muopdb_amd import build as B
+    from muopdb_amd import build as B, synth as S
     from muopdb_amd.index import BlockBasedHnsw
-    idx, vec = B.hnsw_files(base[0], max_neighbors=32, max_layers=8, kcand=64, seed=1)
+    idx, vec = S.hnsw_files(base[0], max_neighbors=32, max_layers=8, kcand=64, seed=1)
     return idx, vec, BlockBasedHnsw(ctx, idx, vec, D)
 
 
@@ -131,14 +131,14 @@ def test_c2_hnsw_1m_ef200(ctx, oracle, base, flat_1m, hnsw_1m):
 
 def test_c3_ivfpq_1m_nprobe16(ctx, oracle, base):
     import torch
-    from muopdb_amd import build as B
+    from muopdb_amd import build as B, synth as S
     from muopdb_amd import formats as F
     from muopdb_amd.index import BlockBasedIvf, ProductQuantizer
     x, xh, q = base
     nlist, P = 4096, 16
-    cent = B.kmeans(x, nlist, iters=4, seed=3, sample=300_000)
-    assign = B.assign_nearest(x, cent)
-    cb = B.train_pq_codebook(x, 8, 8, iters=4, seed=4, sample=100_000)
+    cent = B.kmeans(ctx, x, nlist, iters=4, seed=3, sample=300_000)
+    assign = B.assign_nearest(ctx, x, cent)
+    cb = B.train_pq_codebook(ctx, x, 8, 8, iters=4, seed=4, sample=100_000)
     pq = ProductQuantizer(D, 8, 8, cb)
     codes = pq.quantize(ctx, xh)
     pls = B.posting_lists_from_assignment(assign, nlist)
@@ -176,17 +176,17 @@ def test_c4_shape_multi_user_spann_eighth(ctx, oracle):
     """C4's shape at 1/8 of its users (the full 1024 x 9766 x 768 = 30.7 GB is bench.py's --users 1024): 128 users x 9766 x
     768 unit-norm rows, one (user, query) pair per user, ef=200 >= the ~150 centroids of a user (closure kernel),
     num_explored_centroids 16, ratio 0.1.  Properties + the oracle on 24 users + union of two list shards == unsharded."""
-    from muopdb_amd import build as B
+    from muopdb_amd import build as B, synth as S
     from muopdb_amd import formats as F
     from muopdb_amd.index import MultiSpannIndex, SearchParams
     U, per, d, P = 128, 9766, 768, 16
     users, base = {}, []
-    gen = B.EmbedLike(d, seed=3)
+    gen = S.EmbedLike(d, seed=3)
     for u in range(U):
         x = gen.draw(gen.user(u), per, seed=3_000_000 + u)
-        cent = B.kmeans(x, per // 64, iters=3, seed=u)
-        pls = B.posting_lists_from_assignment(B.assign_nearest(x, cent), cent.shape[0])
-        hi, hv = B.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
+        cent = B.kmeans(ctx, x, per // 64, iters=3, seed=u)
+        pls = B.posting_lists_from_assignment(B.assign_nearest(ctx, x, cent), cent.shape[0])
+        hi, hv = S.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
         docs = np.arange(u * per, (u + 1) * per, dtype=np.uint64)
         users[u + 1] = dict(hnsw_index=hi, hnsw_vectors=hv, ivf_index=F.write_ivf_index(cent.cpu().numpy(), docs, pls),
                             ivf_vectors=F.write_vector_file(x.cpu().numpy()))
@@ -223,18 +223,18 @@ def test_c4_full_size_multi_user_spann(ctx, oracle):
     = one (user, query) pair per user.  Size-independent properties, the oracle on 16 users of the full index, and the
     union of EIGHT posting-list shards (what the 8 GPUs hold) == the unsharded rows on 64 users."""
     import torch
-    from muopdb_amd import build as B
+    from muopdb_amd import build as B, synth as S
     from muopdb_amd import formats as F
     from muopdb_amd.index import MultiSpannIndex, SearchParams
     U, per, d, P = 1024, 9766, 768, 16
-    gen = B.EmbedLike(d, seed=3)
+    gen = S.EmbedLike(d, seed=3)
     users, q = {}, []
     for u in range(U):
         uc = gen.user(u)
         x = gen.draw(uc, per, seed=3_000_000 + u)
-        cent = B.kmeans(x, per // 64, iters=2, seed=u)
-        pls = B.posting_lists_from_assignment(B.assign_nearest(x, cent), cent.shape[0])
-        hi, hv = B.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
+        cent = B.kmeans(ctx, x, per // 64, iters=2, seed=u)
+        pls = B.posting_lists_from_assignment(B.assign_nearest(ctx, x, cent), cent.shape[0])
+        hi, hv = S.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
         docs = np.arange(u * per, (u + 1) * per, dtype=np.uint64)
         users[u + 1] = dict(hnsw_index=hi, hnsw_vectors=hv, ivf_index=F.write_ivf_index(cent.cpu().numpy(), docs, pls),
                             ivf_vectors=F.write_vector_file(x.cpu().numpy()))
@@ -288,10 +288,10 @@ def test_c5_shard_ivfpq(ctx, oracle):
     centroids), nprobe 64, batch 4096.  Properties (sorted, idempotent, batch-split invariant, tombstone monotone), the oracle's
     rows on 12 queries, and the coarse search sharded over a simulated world of 8 == the unsharded probe ids."""
     import torch
-    from muopdb_amd import build as B
+    from muopdb_amd import build as B, synth as S
     from muopdb_amd.distributed import coarse_range
     from muopdb_amd.index import BlockBasedIvf
-    sh = B.c5_shard(ctx, total=100_000_000, world=8, rank=0, nlist=65536)
+    sh = S.c5_shard(ctx, total=100_000_000, world=8, rank=0, nlist=65536)
     torch.cuda.empty_cache()
     assert sh["nlist"] == 65536 and 11_000_000 < sh["n"] < 14_000_000 and sh["owned_lists"] > 8000
     g = BlockBasedIvf(ctx, sh["index"], sh["vectors"], sh["pq"])

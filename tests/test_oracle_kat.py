@@ -311,6 +311,36 @@ def test_k8_spann_search_pq(oracle):
     assert res.doc_ids(0) == sorted(res.doc_ids(0))
 
 
+# ----------------------------------------------------------------------------- K14: k-means (the reference's own tests)
+_KM = [[0, 0], [40, 40], [90, 90], [1, 1], [41, 41], [91, 91], [2, 2], [42, 42], [92, 92]]
+
+
+def test_k14_kmeans_lloyd(oracle):
+    # rs/utils/src/kmeans_builder/kmeans_builder.rs:373-412 test_kmeans_lloyd: init points 0,1,2, tolerance 1e-4
+    cent, a, err, it = oracle.kmeans_fit(np.array(_KM, np.float32), 3, 100, 1e-4, [0, 1, 2])
+    assert cent.shape == (3, 2)
+    assert a[0] == a[3] == a[6] and a[1] == a[4] == a[7] and a[2] == a[5] == a[8]
+    assert cent.tolist() == [[1.0, 1.0], [41.0, 41.0], [91.0, 91.0]]
+
+
+def test_k14_kmeans_no_distance_penalty(oracle):
+    # :414-449 test_kmeans_no_distance_penalty: point 7 = (5, 5) joins the cluster of points 0, 3, 6 when tolerance = 0
+    data = [r[:] for r in _KM]
+    data[7] = [5, 5]
+    cent, a, err, it = oracle.kmeans_fit(np.array(data, np.float32), 3, 100, 0.0, [0, 1, 2])
+    assert a[0] == a[3] == a[6] == a[7] and a[1] == a[4] and a[2] == a[5] == a[8]
+
+
+def test_k14_kmeans_with_empty_cluster(oracle):
+    # :451-486 test_kmeans_with_empty_cluster: 10 clusters asked of 9 points -> 9 centroids, every cluster non-empty
+    # (the reference's init is random there because 3 init values != 9 clusters; any init must give the same property)
+    data = [r[:] for r in _KM]
+    data[7] = [5, 5]
+    for init in ([0, 1, 2, 3, 4, 5, 6, 7, 8], [8, 7, 6, 5, 4, 3, 2, 1, 0], [0, 0, 0, 0, 0, 0, 0, 0, 0]):
+        cent, a, err, it = oracle.kmeans_fit(np.array(data, np.float32), 10, 100, 0.0, init)
+        assert cent.shape == (9, 2) and set(a.tolist()) == set(range(9))
+
+
 # ----------------------------------------------------------------------------- K11: HNSW builder reindex
 def test_k11_hnsw_builder_reindex():
     # rs/index/src/hnsw/builder.rs:460-575 test_hnsw_builder_reindex: 3 points, one layer, entry points [0, 1]
