@@ -188,7 +188,9 @@ mdb_status mdb_kmeans_fit(mdb_ctx* ctx, const float* data, size_t n, size_t d, s
  * file (vector/async_storage.rs:67-136); both host pointers, borrowed.  Posting lists are
  * Elias-Fano-decoded on the GPU and the vectors re-laid list-contiguous in HBM.
  * shard_rank/shard_world: keep only the posting lists this rank owns (list sharding for the
- * multi-GPU path; 0/1 = everything). */
+ * multi-GPU path; 0/1 = everything).  Ownership is SIZE-BALANCED for a single index: lists longest first
+ * (ties: lower index), each to the least loaded rank (ties: lower rank) — every rank derives the same map from
+ * the same file.  (Multi-user collections: list l of every user -> rank l % world.) */
 mdb_status mdb_ivf_load(mdb_ctx* ctx, const void* index_bytes, size_t index_len, size_t index_offset,
                         const void* vectors_bytes, size_t vectors_len, size_t vectors_offset,
                         const mdb_quant_desc* quant, uint32_t shard_rank, uint32_t shard_world, mdb_ivf** out);
@@ -196,6 +198,8 @@ void mdb_ivf_free(mdb_ivf* ivf);
 size_t mdb_ivf_num_clusters(const mdb_ivf* ivf);
 size_t mdb_ivf_num_vectors(const mdb_ivf* ivf);
 size_t mdb_ivf_num_features(const mdb_ivf* ivf);
+/* posting-list entries resident on this handle (= a shard's share of the scan work) */
+size_t mdb_ivf_num_resident_vectors(const mdb_ivf* ivf);
 /* find_nearest_centroids :147-163 — out [B][num_probes] centroid indices (nearest first).
  * MDB_ERR_OUT_OF_RANGE when num_probes == 0 or > num_clusters (reference panics). */
 mdb_status mdb_ivf_find_nearest_centroids(mdb_ivf* ivf, const float* queries, size_t b, size_t num_probes, mdb_mem mem,

@@ -758,6 +758,32 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
     std::vector<uint64_t> cent_tile_src;
     std::vector<uint32_t> cent_tile_first, cent_tile_limit;
     size_t tomb_words = 0;
+    // list ownership for the multi-GPU path.  Multi-user collections: list l of every user -> rank l % world
+    // (a user's ~150 lists spread evenly whatever their sizes).  ONE index (C5: 65 536 lists of very different lengths):
+    // size-balanced — lists taken longest first (ties: lower index), each to the least loaded rank (ties: lower rank);
+    // every rank parses the same file, so every rank computes the same map.
+    std::vector<uint32_t> balanced_owner;
+    if (U == 1 && shard_world > 1) {
+        IvfBlobInfo b0;
+        MDB_TRY(parse_ivf_blob(ctx, index, index_len, offsets[0].first, b0));
+        std::vector<std::pair<uint64_t, uint32_t>> order;  // (num_elem, list)
+        for (uint32_t l = 0; l < b0.num_clusters && l < b0.num_posting_lists; ++l) {
+            const uint8_t* md = index + b0.pl_metadata_offset + (size_t)l * 16;
+            const uint64_t rel = rd_u64(md + 8);
+            uint64_t ne = 0;
+            if (fits(b0.pl_start_offset, rel, index_len) && fits(b0.pl_start_offset + rel, 32, index_len)) ne = rd_u64(index + b0.pl_start_offset + rel);
+            order.push_back({ne, l});
+        }
+        std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        std::vector<uint64_t> load(shard_world, 0);
+        balanced_owner.assign(order.size(), 0);
+        for (auto& e : order) {
+            uint32_t r = 0;
+            for (uint32_t i = 1; i < shard_world; ++i) if (load[i] < load[r]) r = i;
+            balanced_owner[e.second] = r;
+            load[r] += e.first;
+        }
+    }
     for (size_t ui = 0; ui < U; ++ui) {
         IvfBlobInfo& bi = blobs[ui];
         MDB_TRY(parse_ivf_blob(ctx, index, index_len, offsets[ui].first, bi));
@@ -802,7 +828,7 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
                 return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list %u: %s", l, why);
             uint64_t ne = rd_u64(index + pl_off);
             if (pl_off % 8 != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list %u is not 8-byte aligned", l);
-            bool owned = (l % shard_world) == shard_rank;
+            bool owned = balanced_owner.empty() ? (l % shard_world) == shard_rank : balanced_owner[l] == shard_rank;
             if (!owned) ne = 0;
             if (ne > 0xFFFFFFFFull) return mdb_fail(ctx, MDB_ERR_FORMAT, "posting list too long");
             list_byte_off.push_back(ne ? pl_off : ~0ull);
@@ -1298,6 +1324,7 @@ mdb_status mdb_ivf_attach(mdb_ctx* ctx, mdb_ivf* src, mdb_ivf** out) {
 size_t mdb_ivf_num_clusters(const mdb_ivf* ivf) { return ivf ? ivf->set.blobs[0].num_clusters : 0; }
 size_t mdb_ivf_num_vectors(const mdb_ivf* ivf) { return ivf ? (size_t)ivf->set.blobs[0].vec_num_vectors : 0; }
 size_t mdb_ivf_num_features(const mdb_ivf* ivf) { return ivf ? ivf->set.num_features : 0; }
+size_t mdb_ivf_num_resident_vectors(const mdb_ivf* ivf) { return ivf ? ivf->set.total_slots_valid : 0; }
 
 mdb_status mdb_ivf_find_nearest_centroids(mdb_ivf* ivf, const float* queries, size_t b, size_t num_probes, mdb_mem mem,
                                           uint32_t* out) {

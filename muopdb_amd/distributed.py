@@ -3,7 +3,8 @@ RCCL over xGMI on ROCm).
 
 Partitioning
   * IVF / SPANN / multi-user SPANN: every rank loads the same files with (shard_rank, shard_world);
-    posting list l of every user is owned by rank l % world, centroids / graphs / doc-id tables are
+    posting list l of every user of a multi-user collection is owned by rank l % world, the lists of a single IVF
+    index (C5) are dealt size-balanced (`balanced_owners`: longest first to the least loaded rank), centroids / graphs / doc-id tables are
     replicated, so probe selection is identical on all ranks and the union of the per-rank top-k
     equals the single-GPU result exactly — with ONE caveat at exact score ties on the k-th boundary: a rank
     (like the unsharded path) selects its top-k by (distance, POINT id) and only then re-ranks by
@@ -30,8 +31,22 @@ import torch.distributed as dist
 
 
 def shard_of_list(list_index, world):
-    """Owner rank of posting list `list_index` (what mdb_*_load(shard_rank, shard_world) implements)."""
+    """Owner rank of posting list `list_index` of every user of a MULTI-USER collection (mdb_multi_spann_load)."""
     return list_index % world
+
+
+def balanced_owners(list_sizes, world):
+    """Owner rank of every posting list of ONE index (mdb_ivf_load with shard_world > 1): size-balanced greedy — lists
+    longest first (ties: lower index), each to the least loaded rank (ties: lower rank).  Same rule as the library, so a
+    host can tell which rank holds a list without asking."""
+    order = sorted(range(len(list_sizes)), key=lambda l: (-int(list_sizes[l]), l))
+    load = [0] * world
+    owner = [0] * len(list_sizes)
+    for l in order:
+        r = min(range(world), key=lambda i: (load[i], i))
+        owner[l] = r
+        load[r] += int(list_sizes[l])
+    return owner
 
 
 def split_batch(b, rank, world):

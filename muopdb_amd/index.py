@@ -294,6 +294,10 @@ class BlockBasedIvf:
     def num_vectors(self):
         return int(self.ctx.lib.mdb_ivf_num_vectors(self.h))
 
+    def num_resident_vectors(self):
+        """posting-list entries held by this handle (a shard's share)"""
+        return int(self.ctx.lib.mdb_ivf_num_resident_vectors(self.h))
+
     def find_nearest_centroids(self, queries, num_probes):
         q = L.f32(queries).reshape(-1, self.num_features)
         out = np.empty((q.shape[0], max(num_probes, 1)), np.uint32)

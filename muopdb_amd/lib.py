@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "mdb_device_open", "mdb_device_close", "mdb_set_stream", "mdb_sync", "mdb_last_error", "mdb_get_stats",
     "mdb_version", "mdb_set_profiling", "mdb_get_profile", "mdb_l2_distance", "mdb_dot_distance", "mdb_lane_conforming_distance", "mdb_pq_quantize", "mdb_pq_original_vector", "mdb_pq_distance", "mdb_ef_decode",
     "mdb_ivf_assign", "mdb_kmeans_fit", "mdb_flat_create", "mdb_flat_free", "mdb_flat_search", "mdb_flat_topk",
-    "mdb_ivf_load", "mdb_ivf_free", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features",
+    "mdb_ivf_load", "mdb_ivf_free", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_ivf_num_resident_vectors",
     "mdb_ivf_find_nearest_centroids", "mdb_ivf_coarse_keys", "mdb_ivf_merge_coarse_keys", "mdb_ivf_search", "mdb_ivf_search_points", "mdb_ivf_set_filter", "mdb_ivf_invalidate",
     "mdb_ivf_is_invalidated",
     "mdb_hnsw_load", "mdb_hnsw_attach", "mdb_hnsw_free", "mdb_hnsw_num_vectors", "mdb_hnsw_ann_search",
@@ -92,7 +92,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         _lib.mdb_last_error.restype = C.c_char_p
         _lib.mdb_version.restype = C.c_char_p
-        for n in ("mdb_shard_block_bytes", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_hnsw_num_vectors",
+        for n in ("mdb_shard_block_bytes", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_ivf_num_resident_vectors", "mdb_hnsw_num_vectors",
                   "mdb_multi_spann_num_users"):
             if hasattr(_lib, n):
                 getattr(_lib, n).restype = C.c_size_t

@@ -57,9 +57,10 @@ def _worker(rank, world, port, out):
     full_index, full_vec, pls = H.build_ivf_files(v, doc_ids, c)
     full = oracle.BlockBasedIvf(full_index, full_vec)
     probes = full.find_nearest_centroids(q, P)  # replicated centroids => identical probes on every rank
-    # this rank's shard: only the posting lists it owns (list l -> rank l % world)
+    # this rank's shard: only the posting lists it owns (single index: the library's size-balanced map)
     from muopdb_amd import formats as F
-    mine = [pl if D.shard_of_list(l, world) == rank else np.zeros(0, np.uint64) for l, pl in enumerate(pls)]
+    owner = D.balanced_owners([len(pl) for pl in pls], world)
+    mine = [pl if owner[l] == rank else np.zeros(0, np.uint64) for l, pl in enumerate(pls)]
     shard = oracle.BlockBasedIvf(F.write_ivf_index(c, doc_ids, mine), full_vec)
     r = shard.search(q, k, probes=probes)
 
@@ -141,6 +142,11 @@ def test_shard_assignment_covers_every_list_once():
                 if c:
                     assert f == pos
                     pos += c
+        sizes = [((7 * l) % 23) * 10 + (l % 3) for l in range(100)]          # skewed list lengths
+        bal = D.balanced_owners(sizes, world)
+        loads = [sum(sz for sz, o in zip(sizes, bal) if o == r) for r in range(world)]
+        assert set(bal) == set(range(world)) and max(loads) - min(loads) <= max(sizes)   # greedy longest-first bound
+        assert D.balanced_owners(sizes, world) == bal                                     # deterministic: every rank derives the same map
         owners = [D.shard_of_list(l, world) for l in range(100)]
         assert set(owners) == set(range(min(world, 100)))
         assert all(0 <= o < world for o in owners)

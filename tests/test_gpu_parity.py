@@ -533,6 +533,14 @@ def test_ivf_sharded_union_equals_unsharded(ctx, oracle):
             rows += list(zip(sc[0, :cn[0]].tolist(), ids[0, :cn[0]].tolist()))
         rows.sort()
         assert [r[1] for r in rows[:10]] == full_ids[qi, :full_cn[qi]].tolist()
+    # ownership of a single index is size-balanced (longest list first to the least loaded rank): the shards hold what
+    # muopdb_amd.distributed.balanced_owners says, every vector exactly once, loads within one list of each other
+    from muopdb_amd.distributed import balanced_owners
+    sizes = [len(pl) for pl in H.build_ivf_files(v, doc_ids, H.kmeans(v, 12, iters=4, seed=77))[2]]
+    owner = balanced_owners(sizes, 3)
+    loads = [s.num_resident_vectors() for s in shards]
+    assert loads == [sum(sz for sz, o in zip(sizes, owner) if o == r) for r in range(3)]
+    assert sum(loads) == g.num_resident_vectors() == len(v) and max(loads) - min(loads) <= max(sizes)
 
 
 def test_handles_outlive_context_close(oracle):
