@@ -313,6 +313,10 @@ mdb_status mdb_multi_spann_load(mdb_ctx* ctx, const mdb_user_index_info* users, 
                                 const void* ivf_vectors, size_t ivf_vectors_len, const mdb_quant_desc* quant,
                                 uint32_t shard_rank, uint32_t shard_world, mdb_multi_spann** out);
 void mdb_multi_spann_free(mdb_multi_spann* ms);
+/* The segment's `user_index_info` file (an odht 0.3.1 table: multi_spann/writer.rs:253-259, user_index_info.rs:84-140) ->
+ * the UserIndexInfo records mdb_multi_spann_load takes, ascending by user id.  Host-only, no device needed.  *n_out = number of
+ * users (call with users_out == NULL to size the array).  MDB_ERR_FORMAT if the bytes are not such a table. */
+mdb_status mdb_odht_user_table(const void* odht_bytes, size_t len, mdb_user_index_info* users_out, size_t cap, size_t* n_out);
 size_t mdb_multi_spann_num_users(const mdb_multi_spann* ms);
 /* search_for_user :282-293 for a batch of (user_ids[i], queries[i]) pairs; unknown user =>
  * found_out[i] = 0 (`Err(_) => None`) */

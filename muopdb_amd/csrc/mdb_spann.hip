@@ -405,6 +405,42 @@ mdb_status mdb_spann_is_invalidated(mdb_spann* sp, const mdb_u128* doc_ids, size
     return sp->set.ivf.invalidate(0, doc_ids, n, flags_out, true);
 }
 
+// ---------------------------------------------------------------- user_index_info (odht 0.3.1 table)
+// The reference keeps the 112-byte UserIndexInfo records in an `odht` on-disk hash table (multi_spann/writer.rs:253-259,
+// read by HashTable::from_raw_bytes at multi_spann/index.rs:50).  Layout (the crate is not under /root/reference: restated
+// from its published format, see muopdb_amd/formats.py): 32-byte header "ODHT" | meta 1 | key 16 | value 112 | header 32 |
+// item_count u64 | slot_count u64 | version [0,0,0,2] | load factor u16 | pad; slot_count entries {key[16], value[112]};
+// slot_count + 16 control bytes (0xFF = empty).  Host-only: every occupied slot's value IS a UserIndexInfo record.
+mdb_status mdb_odht_user_table(const void* odht_bytes, size_t len, mdb_user_index_info* users_out, size_t cap, size_t* n_out) {
+    if (!odht_bytes || !n_out) return MDB_ERR_INVALID_ARG;
+    const uint8_t* p = (const uint8_t*)odht_bytes;
+    static const uint8_t version[4] = {0, 0, 0, 2};
+    if (len < 32 || memcmp(p, "ODHT", 4) != 0 || p[4] != 1 || p[5] != 16 || p[6] != 112 || p[7] != 32 || memcmp(p + 24, version, 4) != 0)
+        return MDB_ERR_FORMAT;
+    const uint64_t count = rd_u64(p + 8), slots = rd_u64(p + 16);
+    if (slots == 0 || (slots & (slots - 1)) || slots > (len - 32) / 129 || len != 32 + slots * 128 + slots + 16 || count > slots)
+        return MDB_ERR_FORMAT;
+    const uint8_t* entries = p + 32;
+    const uint8_t* meta = entries + slots * 128;
+    size_t n = 0;
+    for (uint64_t i = 0; i < slots; ++i) {
+        if (meta[i] == 0xFF) continue;
+        if (users_out && n < cap) {
+            static_assert(sizeof(mdb_user_index_info) == 112, "UserIndexInfo is a 112-byte record");
+            memcpy(&users_out[n], entries + i * 128 + 16, 112);
+            if (memcmp(entries + i * 128, entries + i * 128 + 16, 16) != 0) return MDB_ERR_FORMAT;  // key == the record's user_id
+        }
+        ++n;
+    }
+    *n_out = n;
+    if (n != count) return MDB_ERR_FORMAT;
+    if (users_out && cap >= n)  // deterministic order for the caller: ascending user id
+        std::sort(users_out, users_out + n, [](const mdb_user_index_info& a, const mdb_user_index_info& b) {
+            return a.user_id.hi != b.user_id.hi ? a.user_id.hi < b.user_id.hi : a.user_id.lo < b.user_id.lo;
+        });
+    return MDB_OK;
+}
+
 // ---------------------------------------------------------------- multi-user SPANN
 mdb_status mdb_multi_spann_load(mdb_ctx* ctx, const mdb_user_index_info* users, size_t n_users, uint32_t num_features,
                                 const void* hnsw_index, size_t hnsw_index_len, const void* hnsw_vectors, size_t hnsw_vectors_len,

@@ -307,3 +307,192 @@ def parse_simple_yaml(text):
         k, v = line.split(":", 1)
         out[k.strip()] = int(v.strip())
     return out
+
+
+# --------------------------------------------------------------------------- odht 0.3.1 table (`user_index_info`)
+# The reference keeps the UserIndexInfo records in an `odht` on-disk hash table (multi_spann/writer.rs:253-259:
+# HashTableOwned::<HashConfig>::with_capacity(n_users, 90), insert per user, raw_bytes(); read back by
+# HashTable::from_raw_bytes, multi_spann/index.rs:50).  The crate (Cargo.lock: odht 0.3.1) is NOT under /root/reference, so
+# this is a restatement of its PUBLISHED layout — a SwissTable-style open-addressing table — and is PARITY-UNPINNED
+# against the crate itself (no crate, no golden file here); tests pin it with a hand-computed table and by round trip:
+#   header, 32 bytes:  tag "ODHT" | size_of_metadata u8 = 1 | size_of_key u8 = 16 | size_of_value u8 = 112 |
+#                      size_of_header u8 = 32 | item_count u64 LE | slot_count u64 LE | file_format_version [0,0,0,2] |
+#                      max_load_factor u16 LE (percent * 65535 / 100) | 2 bytes padding
+#   entries:           slot_count x { key [16] | value [112] }   (empty slots are all zero)
+#   metadata:          slot_count + 16 control bytes: 0xFF = empty, else h2 = top 7 bits of the key's hash; the first 16
+#                      bytes are mirrored after the end so that an unaligned 16-byte group read never wraps
+#   hash:              FxHashFn over the encoded key (HashConfig::H, user_index_info.rs:84-90): for every LE u32 word w:
+#                      h = (rotl(h, 5) ^ w) * 0x9e3779b9 (mod 2^32)
+#   probing:           groups of 16 control bytes starting at h & (slot_count - 1), then triangular steps of 16
+#                      (index += stride, stride += 16); a key goes into the first empty slot of the first group that has one
+#   slot_count:        max(16, next_power_of_two(ceil(n * 65535 / factor)))
+ODHT_GROUP = 16
+ODHT_EMPTY = 0xFF
+
+
+def fx_hash32(data):
+    """odht::FxHashFn::hash — u32 words, then a u16, then a u8 tail."""
+    h = 0
+    i, n = 0, len(data)
+
+    def add(hv, v):
+        return ((((hv << 5) | (hv >> 27)) & 0xFFFFFFFF) ^ v) * 0x9E3779B9 & 0xFFFFFFFF
+
+    while n - i >= 4:
+        h = add(h, int.from_bytes(data[i:i + 4], "little"))
+        i += 4
+    if n - i >= 2:
+        h = add(h, int.from_bytes(data[i:i + 2], "little"))
+        i += 2
+    if n - i >= 1:
+        h = add(h, data[i])
+    return h
+
+
+def odht_slots_needed(item_count, max_load_factor_percent=90):
+    factor = (0xFFFF * max_load_factor_percent) // 100
+    need = (item_count * 0xFFFF + factor - 1) // factor
+    p = 1
+    while p < need:
+        p <<= 1
+    return max(p, ODHT_GROUP), factor
+
+
+def _odht_probe(h, mask):
+    index, stride = h & mask, 0
+    while True:
+        yield index
+        stride += ODHT_GROUP
+        index = (index + stride) & mask
+
+
+def odht_table(entries, key_size=16, value_size=112, max_load_factor_percent=90):
+    """raw_bytes() of an odht table holding `entries` = [(key bytes, value bytes)] inserted in that order."""
+    slots, factor = odht_slots_needed(len(entries), max_load_factor_percent)
+    mask = slots - 1
+    esz = key_size + value_size
+    data = bytearray(slots * esz)
+    meta = bytearray([ODHT_EMPTY]) * (slots + ODHT_GROUP)
+    count = 0
+    for key, value in entries:
+        assert len(key) == key_size and len(value) == value_size
+        h = fx_hash32(key)
+        h2 = h >> 25
+        done = False
+        for start in _odht_probe(h, mask):
+            group = [(start + j) & mask for j in range(ODHT_GROUP)]
+            for idx in group:                       # an equal key already present: the value is replaced
+                if meta[idx] == h2 and bytes(data[idx * esz:idx * esz + key_size]) == key:
+                    data[idx * esz + key_size:(idx + 1) * esz] = value
+                    done = True
+                    break
+            if done:
+                break
+            empty = next((idx for idx in group if meta[idx] == ODHT_EMPTY), None)
+            if empty is not None:
+                data[empty * esz:(empty + 1) * esz] = key + value
+                meta[empty] = h2
+                if empty < ODHT_GROUP:
+                    meta[slots + empty] = h2
+                count += 1
+                break
+    header = b"ODHT" + bytes([1, key_size, value_size, 32]) + struct.pack("<QQ", count, slots) + bytes([0, 0, 0, 2]) + \
+        struct.pack("<H", factor) + b"\0\0"
+    return header + bytes(data) + bytes(meta)
+
+
+def odht_entries(raw, key_size=16, value_size=112):
+    """[(key, value)] of every occupied slot of an odht table, in slot order (what HashTable::iter yields)."""
+    if len(raw) < 32 or raw[:4] != b"ODHT":
+        raise ValueError("not an odht table")
+    if raw[4] != 1 or raw[5] != key_size or raw[6] != value_size or raw[7] != 32 or bytes(raw[24:28]) != bytes([0, 0, 0, 2]):
+        raise ValueError("odht header does not describe a %d/%d-byte table of format version 2" % (key_size, value_size))
+    count, slots = struct.unpack_from("<QQ", raw, 8)
+    esz = key_size + value_size
+    if slots & (slots - 1) or len(raw) != 32 + slots * esz + slots + ODHT_GROUP:
+        raise ValueError("odht table size does not match its slot count")
+    meta = raw[32 + slots * esz:]
+    out = []
+    for i in range(slots):
+        if meta[i] != ODHT_EMPTY:
+            e = raw[32 + i * esz:32 + (i + 1) * esz]
+            out.append((bytes(e[:key_size]), bytes(e[key_size:])))
+    if len(out) != count:
+        raise ValueError("odht item_count %d != %d occupied slots" % (count, len(out)))
+    return out
+
+
+def odht_get(raw, key, key_size=16, value_size=112):
+    """HashTable::get: the value stored under `key`, or None."""
+    slots = struct.unpack_from("<Q", raw, 16)[0]
+    mask, esz = slots - 1, key_size + value_size
+    meta = raw[32 + slots * esz:]
+    h = fx_hash32(key)
+    h2 = h >> 25
+    for start in _odht_probe(h, mask):
+        group = [(start + j) & mask for j in range(ODHT_GROUP)]
+        for idx in group:
+            if meta[idx] == h2 and bytes(raw[32 + idx * esz:32 + idx * esz + key_size]) == key:
+                return bytes(raw[32 + idx * esz + key_size:32 + (idx + 1) * esz])
+        if any(meta[idx] == ODHT_EMPTY for idx in group):
+            return None
+
+
+def user_index_info_table(user_table):
+    """flat 112-byte records -> the `user_index_info` file (odht: key = user id u128 LE, value = the 112-byte record)."""
+    recs = [bytes(user_table[i:i + 112]) for i in range(0, len(user_table), 112)]
+    return odht_table([(r[:16], r) for r in recs])
+
+
+def user_table_from_odht(raw):
+    """`user_index_info` file -> flat 112-byte records sorted by user id (mdb_multi_spann_load's `users`)."""
+    vals = [v for _, v in odht_entries(raw)]
+    vals.sort(key=lambda r: int.from_bytes(r[:16], "little"))
+    return b"".join(vals)
+
+
+# --------------------------------------------------------------------------- segment directory (SURVEY.md Appendix A)
+def write_segment(directory, cat, num_features, pq=None):
+    """One (multi-user) SPANN segment as the reference lays it out on disk (multi_spann/writer.rs:82-298; SURVEY.md
+    Appendix A) from concat_multi_spann's result: the reference's readers (MultiSpannReader::read, multi_spann/reader.rs:35)
+    open this tree.  pq = (dimension, subvector_dimension, num_bits) when the posting lists hold PQ codes (cat["codebook"]).
+    bloom_filter/ and invalidated_ids_storage/ (delete path) are created empty."""
+    import os
+    def put(rel, data):
+        path = os.path.join(directory, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "wb") as f:
+            f.write(data if isinstance(data, (bytes, bytearray)) else data.encode())
+    put("user_index_info", user_index_info_table(cat["user_table"]))
+    put("centroids/quantizer/no_op_quantizer_config.yaml", no_op_quantizer_config_yaml(num_features))
+    put("centroids/hnsw/index", cat["hnsw_index"])
+    put("centroids/hnsw/vector_storage", cat["hnsw_vectors"])
+    if pq is None:
+        put("ivf/quantizer/no_op_quantizer_config.yaml", no_op_quantizer_config_yaml(num_features))
+    else:
+        put("ivf/quantizer/product_quantizer_config.yaml", product_quantizer_config_yaml(*pq))
+        put("ivf/quantizer/codebook", cat.get("codebook", b""))
+    put("ivf/index", cat["ivf_index"])
+    put("ivf/vectors", cat["ivf_vectors"])
+    put("ivf/raw_vectors", cat.get("ivf_raw_vectors", b""))
+    for sub in ("bloom_filter", "invalidated_ids_storage"):
+        os.makedirs(os.path.join(directory, sub), exist_ok=True)
+
+
+def read_segment(directory):
+    """The files of a segment directory as write_segment / the reference's MultiSpannWriter leave them:
+    dict(user_table (flat records), hnsw_index, hnsw_vectors, ivf_index, ivf_vectors, num_features, pq, codebook)."""
+    import os
+    def get(rel):
+        with open(os.path.join(directory, rel), "rb") as f:
+            return f.read()
+    out = dict(user_table=user_table_from_odht(get("user_index_info")), hnsw_index=get("centroids/hnsw/index"),
+               hnsw_vectors=get("centroids/hnsw/vector_storage"), ivf_index=get("ivf/index"), ivf_vectors=get("ivf/vectors"))
+    out["num_features"] = parse_simple_yaml(get("centroids/quantizer/no_op_quantizer_config.yaml").decode())["dimension"]
+    pq_path = os.path.join(directory, "ivf/quantizer/product_quantizer_config.yaml")
+    out["pq"], out["codebook"] = None, None
+    if os.path.exists(pq_path):
+        y = parse_simple_yaml(get("ivf/quantizer/product_quantizer_config.yaml").decode())
+        out["pq"] = (y["dimension"], y["subvector_dimension"], y["num_bits"])
+        out["codebook"] = np.frombuffer(get("ivf/quantizer/codebook"), np.float32)
+    return out

@@ -589,6 +589,38 @@ class MultiSpannIndex:
                                                C.byref(h)))
         self.h = h
 
+    @classmethod
+    def open_segment(cls, ctx, directory, shard_rank=0, shard_world=1):
+        """MultiSpannReader::read (rs/index/src/multi_spann/reader.rs:35): open a segment DIRECTORY as the reference
+        writes it — `user_index_info` is the odht table, parsed by the library
+        (mdb_odht_user_table); the five data files are mapped and handed to mdb_multi_spann_load."""
+        import mmap
+        import os
+        from . import formats as F
+
+        def mapped(rel):
+            with open(os.path.join(directory, rel), "rb") as f:
+                size = os.fstat(f.fileno()).st_size
+                return np.frombuffer(mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ), np.uint8) if size else np.zeros(0, np.uint8)
+
+        raw = mapped("user_index_info")
+        n = C.c_size_t()
+        ctx.check(ctx.lib.mdb_odht_user_table(L.ptr(raw, C.c_uint8), C.c_size_t(raw.size), None, C.c_size_t(0), C.byref(n)))
+        users = (L.UserIndexInfoC * max(n.value, 1))()
+        ctx.check(ctx.lib.mdb_odht_user_table(L.ptr(raw, C.c_uint8), C.c_size_t(raw.size), users, C.c_size_t(n.value), C.byref(n)))
+        table = C.string_at(users, n.value * 112)
+        with open(os.path.join(directory, "centroids/quantizer/no_op_quantizer_config.yaml")) as f:
+            d = F.parse_simple_yaml(f.read())["dimension"]
+        quant = None
+        pq_cfg = os.path.join(directory, "ivf/quantizer/product_quantizer_config.yaml")
+        if os.path.exists(pq_cfg):
+            with open(pq_cfg) as f:
+                y = F.parse_simple_yaml(f.read())
+            quant = ProductQuantizer(y["dimension"], y["subvector_dimension"], y["num_bits"],
+                                     np.frombuffer(mapped("ivf/quantizer/codebook").tobytes(), np.float32))
+        return cls(ctx, table, d, mapped("centroids/hnsw/index"), mapped("centroids/hnsw/vector_storage"), mapped("ivf/index"),
+                   mapped("ivf/vectors"), quant, shard_rank, shard_world)
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.mdb_multi_spann_free(self.h)

@@ -111,3 +111,41 @@ def test_pq_training_quality_and_ivf_list_splitting(ctx, oracle):
     ids, cnt = B.assign_nearest(ctx, x[:500], cent, max_clusters_per_vector=2, distance_threshold=0.1)
     oids, ocnt = oracle.ivf_assign(cent, x[:500], 2, 0.1)
     assert np.array_equal(ids, oids) and np.array_equal(cnt, ocnt)
+
+
+@pytest.mark.parametrize("pq", [False, True])
+def test_open_segment_directory(ctx, oracle, tmp_path, pq):
+    """a segment written as the reference lays it out on disk (odht `user_index_info`,
+    centroids/..., ivf/..., quantizer YAML + codebook) and opened through MultiSpannReader::read's mirror
+    (MultiSpannIndex.open_segment -> mdb_odht_user_table + mdb_multi_spann_load) gives the rows of the K9 data set."""
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import MultiSpannIndex, ProductQuantizer, SearchParams
+    v = np.concatenate([np.repeat(np.arange(1000, dtype=np.float32)[:, None], 4, 1), np.array([[1.2, 2.2, 3.2, 4.2]], np.float32)])
+    quant = oquant = quantize = None
+    pqcfg = None
+    if pq:
+        cb = H.train_pq_codebook(v, 2, 4)
+        opq = oracle.ProductQuantizer(4, 2, 4, cb)
+        quant, oquant, quantize, pqcfg = ProductQuantizer(4, 2, 4, cb), oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 2, 4, cb), opq.quantize, (4, 2, 4)
+    f0, _, _ = H.build_spann_files(oracle, v, list(range(1001)), 10, quantize=quantize)
+    f1, _, _ = H.build_spann_files(oracle, v[:50] + 0.5, list(range(5000, 5050)), 3, quantize=quantize)
+    big = (1 << 70) + 1
+    if pq:
+        f0["codebook"] = f1["codebook"] = np.asarray(cb, np.float32).tobytes()
+    cat = F.concat_multi_spann({0: f0, big: f1})
+    seg = str(tmp_path / "segment")
+    F.write_segment(seg, cat, 4, pq=pqcfg)
+    g = MultiSpannIndex.open_segment(ctx, seg)
+    assert g.num_users() == 2
+    direct = MultiSpannIndex(ctx, cat["user_table"], 4, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], quant)
+    o = oracle.MultiSpannIndex(cat["user_table"], 4, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], oquant)
+    users = [0, big, 12345, 0]
+    q = np.array([[1.4, 2.4, 3.4, 4.4], [3.1, 3.1, 3.1, 3.1], [0, 0, 0, 0], [500.2, 500.2, 500.2, 500.2]], np.float32)
+    p, op = SearchParams(3, 2), oracle.SearchParams(3, 2)
+    r, rd, ro = g.search_for_user(users, q, p), direct.search_for_user(users, q, p), o.search_for_user(users, q, op)
+    assert r.found.tolist() == rd.found.tolist() == ro.found.tolist() == [1, 1, 0, 1]
+    for i in range(4):
+        assert r.doc_ids(i) == rd.doc_ids(i) == ro.doc_ids(i)
+        assert np.array_equal(r.scores[i, :int(r.counts[i])].view(np.uint32), ro.scores[i, :int(ro.counts[i])].view(np.uint32))
+    if not pq:
+        assert r.doc_ids(0) == [1000, 3, 2]        # K9 (multi_spann/index.rs:358-412) through the on-disk tree

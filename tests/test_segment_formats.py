@@ -1,0 +1,125 @@
+"""CPU tests of the segment-level producers: the odht `user_index_info` table and the on-disk
+segment tree of Appendix A.
+
+odht 0.3.1 is a third-party crate ABSENT from /root/reference (Cargo.lock pins it; multi_spann/writer.rs:253-259 and
+user_index_info.rs:84-140 are its only call sites, and the reference's tests at that boundary are end to end: K9 / K10).
+muopdb_amd.formats restates its published layout; these tests pin the restatement against a HAND-computed table and against
+the library's own reader (mdb_odht_user_table) — they cannot pin it against the crate itself: **parity unpinned** there."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from muopdb_amd import formats as F
+from muopdb_amd import lib as L
+
+K = 0x9E3779B9
+M32 = 0xFFFFFFFF
+
+
+def test_fx_hash_by_hand():
+    # FxHashFn over a u128 key = four LE u32 words; h <- (rotl(h, 5) ^ w) * 0x9e3779b9 mod 2^32
+    assert F.fx_hash32((0).to_bytes(16, "little")) == 0                       # (0 ^ 0) * K four times
+    h = (0 ^ 1) * K & M32                                                     # word 0 = 1
+    assert h == 0x9E3779B9
+    for _ in range(3):                                                        # words 1..3 = 0
+        h = ((((h << 5) | (h >> 27)) & M32) ^ 0) * K & M32
+    assert h == 0x4D286184 == F.fx_hash32((1).to_bytes(16, "little"))
+    # a 7-byte key: one u32 word (1), then a u16 (2), then a u8 (3)
+    rot = lambda v: ((v << 5) | (v >> 27)) & M32
+    h = (rot(0) ^ 1) * K & M32
+    h = (rot(h) ^ 2) * K & M32
+    h = (rot(h) ^ 3) * K & M32
+    assert F.fx_hash32(b"\x01\x00\x00\x00\x02\x00\x03") == h
+
+
+def test_odht_two_entry_table_by_hand():
+    """users 0 and 1, with_capacity(2, 90): factor = 65535 * 90 / 100 = 58981, ceil(2 * 65535 / 58981) = 3 -> 4 -> max(.., 16)
+    = 16 slots.  key 0: hash 0 -> control byte 0, slot 0 (mirrored at 16).  key 1: hash 0x4d286184 -> control byte
+    0x4d286184 >> 25 = 38, slot 0x4d286184 & 15 = 4 (mirrored at 20)."""
+    r0 = F.pack_user_index_info(0, centroid_vector_offset=7, ivf_index_len=99)
+    r1 = F.pack_user_index_info(1, centroid_vector_offset=8, ivf_pq_codebook_len=5)
+    t = F.user_index_info_table(r0 + r1)
+    assert len(t) == 32 + 16 * 128 + 16 + 16
+    assert t[:32] == b"ODHT" + bytes([1, 16, 112, 32]) + struct.pack("<QQ", 2, 16) + bytes([0, 0, 0, 2]) + struct.pack("<H", 58981) + b"\0\0"
+    entries, meta = t[32:32 + 16 * 128], t[32 + 16 * 128:]
+    assert entries[0:16] == (0).to_bytes(16, "little") and entries[16:128] == r0
+    assert entries[4 * 128:4 * 128 + 16] == (1).to_bytes(16, "little") and entries[4 * 128 + 16:5 * 128] == r1
+    assert all(b == 0 for i in range(16) if i not in (0, 4) for b in entries[i * 128:(i + 1) * 128])
+    want = [0xFF] * 32
+    want[0] = want[16] = 0
+    want[4] = want[20] = 38
+    assert list(meta) == want
+    assert F.user_table_from_odht(t) == r0 + r1 and F.odht_get(t, (1).to_bytes(16, "little")) == r1
+    assert F.odht_get(t, (2).to_bytes(16, "little")) is None
+
+
+def test_odht_probing_wrap_and_round_trip_and_native_reader():
+    rng = np.random.default_rng(4)
+    for n in (1, 3, 14, 15, 33, 200, 1024):
+        ids = sorted({int(x) for x in rng.integers(0, 1 << 62, n)} | ({(1 << 100) + 5} if n > 2 else set()))
+        recs = b"".join(F.pack_user_index_info(u, centroid_index_offset=i * 16, ivf_vectors_len=i) for i, u in enumerate(ids))
+        t = F.user_index_info_table(recs)
+        slots, _ = F.odht_slots_needed(len(ids))
+        assert len(t) == 32 + slots * 129 + 16 and slots >= 16 and slots & (slots - 1) == 0 and len(ids) * 100 <= slots * 90 + 99
+        assert t[32 + slots * 128:32 + slots * 128 + 16] == t[32 + slots * 129:]           # the mirrored first group
+        assert F.user_table_from_odht(t) == recs
+        for i, u in enumerate(ids):
+            assert F.odht_get(t, u.to_bytes(16, "little")) == recs[i * 112:(i + 1) * 112]
+        # the library's reader (host-only entry point of the C ABI)
+        lib = L.load()
+        buf = np.frombuffer(t, np.uint8)
+        cnt = C.c_size_t()
+        assert lib.mdb_odht_user_table(L.ptr(buf, C.c_uint8), C.c_size_t(buf.size), None, C.c_size_t(0), C.byref(cnt)) == 0
+        assert cnt.value == len(ids)
+        users = (L.UserIndexInfoC * len(ids))()
+        assert lib.mdb_odht_user_table(L.ptr(buf, C.c_uint8), C.c_size_t(buf.size), users, C.c_size_t(len(ids)), C.byref(cnt)) == 0
+        assert C.string_at(users, len(ids) * 112) == recs
+    # a full group forces the triangular probe: 17 keys whose hashes share the low 4 bits land in two groups
+    same = []
+    x = 0
+    while len(same) < 17:
+        x += 1
+        if F.fx_hash32(x.to_bytes(16, "little")) & 31 == 7:
+            same.append(x)
+    recs = b"".join(F.pack_user_index_info(u, ivf_index_len=u) for u in same)
+    t = F.user_index_info_table(recs)
+    assert F.odht_slots_needed(17)[0] == 32
+    assert F.user_table_from_odht(t) == b"".join(sorted((recs[i:i + 112] for i in range(0, len(recs), 112)), key=lambda r: int.from_bytes(r[:16], "little")))
+    for u in same:
+        assert F.odht_get(t, u.to_bytes(16, "little"))[:16] == u.to_bytes(16, "little")
+    for bad in (t[:31], b"XDHT" + t[4:], t[:-1], t[:5] + bytes([8]) + t[6:], t[:8] + struct.pack("<Q", 3) + t[16:]):
+        buf = np.frombuffer(bad, np.uint8)
+        assert lib.mdb_odht_user_table(L.ptr(buf, C.c_uint8), C.c_size_t(buf.size), None, C.c_size_t(0), C.byref(cnt)) == 2  # MDB_ERR_FORMAT
+
+
+def test_write_segment_tree_and_read_back(tmp_path):
+    """the files a MultiSpannReader opens, at the paths MultiSpannWriter writes them."""
+    users = {}
+    for u in (3, 9, (1 << 90) + 2):
+        v = np.arange(20 * 4, dtype=np.float32).reshape(20, 4) + (u & 0xFF)
+        cent = v[:2].copy()
+        ivf = F.write_ivf_index(cent, list(range(20)), [np.arange(0, 10, dtype=np.uint64), np.arange(10, 20, dtype=np.uint64)])
+        hn = F.write_hnsw_index([{0: [1], 1: [0]}], [0, 1], 4)
+        users[u] = dict(hnsw_index=hn, hnsw_vectors=F.write_vector_file(cent), ivf_index=ivf, ivf_vectors=F.write_vector_file(v),
+                        ivf_raw_vectors=F.write_vector_file(v))
+    cat = F.concat_multi_spann(users)
+    seg = str(tmp_path / "segment")
+    F.write_segment(seg, cat, 4)
+    for rel in ("user_index_info", "centroids/quantizer/no_op_quantizer_config.yaml", "centroids/hnsw/index", "centroids/hnsw/vector_storage",
+                "ivf/quantizer/no_op_quantizer_config.yaml", "ivf/index", "ivf/vectors", "ivf/raw_vectors"):
+        assert os.path.isfile(os.path.join(seg, rel)), rel
+    assert open(os.path.join(seg, "centroids/quantizer/no_op_quantizer_config.yaml")).read() == "dimension: 4\n"
+    back = F.read_segment(seg)
+    assert back["user_table"] == cat["user_table"] and back["num_features"] == 4 and back["pq"] is None
+    for kf in ("hnsw_index", "hnsw_vectors", "ivf_index", "ivf_vectors"):
+        assert back[kf] == cat[kf]
+    # PQ variant: product_quantizer_config.yaml + codebook instead of the no-op config
+    cat["codebook"] = np.arange(2 * 4 * 2, dtype=np.float32).tobytes()
+    seg2 = str(tmp_path / "segment_pq")
+    F.write_segment(seg2, cat, 4, pq=(4, 2, 2))
+    back = F.read_segment(seg2)
+    assert back["pq"] == (4, 2, 2) and back["codebook"].tobytes() == cat["codebook"]
+    assert not os.path.exists(os.path.join(seg2, "ivf/quantizer/no_op_quantizer_config.yaml"))
