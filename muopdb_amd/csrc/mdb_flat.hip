@@ -332,7 +332,7 @@ mdb_status mdb_flat_create(mdb_ctx* ctx, const float* base, size_t n, size_t d, 
         d_rows = staging.p;
     }
     mdb_status st = tiles_from_rows(ctx, d_rows, n, (int)d, f->ts);
-    if (st == MDB_OK) st = flat_build_aux(ctx, view_of(f->ts), f->aux);
+    if (st == MDB_OK) st = flat_build_aux(ctx, view_of(f->ts), f->aux, 0, f->metric);
     if (st == MDB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = mdb_fail(ctx, MDB_ERR_HIP, "sync failed");
     if (st != MDB_OK) { delete f; return st; }
     mdb_ctx_retain(ctx);

@@ -80,11 +80,92 @@ void flat_aux_view(const FlatAux& src, FlatAux& dst) {
     dst.sample.n = src.sample.n; dst.sample.ntiles = src.sample.ntiles; dst.sample.d = src.sample.d; dst.sample.d4 = src.sample.d4;
     dst.ctiles.borrow(src.ctiles);
     dst.mean.borrow(src.mean);
+    dst.bhi.borrow(src.bhi); dst.blo.borrow(src.blo); dst.xnorm.borrow(src.xnorm);
+    dst.nk = src.nk; dst.nt32 = src.nt32; dst.split_metric = src.split_metric;
     dst.cooldown = 0;
     if (src.sample.n && !dst.h_ovf && hipHostMalloc((void**)&dst.h_ovf, 4) == hipSuccess) *dst.h_ovf = 0;
 }
 
-mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles) {
+// ------------------------------------------------------------------------------------------ bf16 x 3 split
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// round-to-nearest-even f32 -> bf16 bits (|v - hi| <= 2^-9 |v| for normal values; NaN stays NaN, inf stays inf)
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+    const uint32_t u = __float_as_uint(f);
+    if (f != f) return 0x7FC0u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+// (hi, lo) halves of 8 consecutive values packed as two uint4 MFMA fragments
+__device__ __forceinline__ void bf16_split8(const float (&x)[8], uint4& hi, uint4& lo) {
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = bf16_rne(x[i]);
+        l[i] = bf16_rne(x[i] - bf16_to_f32(h[i]));   // exact subtraction (hi shares x's leading bits), then rounded: |x - hi - lo| <= 2^-18 |x|
+    }
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+// one thread per output fragment ((tile32 * nk + kc) * 64 + lane)
+__global__ void bf16_split_kernel(const float4* __restrict__ tiles, size_t n, int d, int d4, const float* __restrict__ mean, int nk,
+                                  size_t total, uint4* __restrict__ bhi, uint4* __restrict__ blo) {
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const int lane = (int)(o & 63);
+    const size_t tk = o >> 6;
+    const int kc = (int)(tk % nk);
+    const size_t t32 = tk / nk;
+    const size_t v = t32 * 32 + (lane & 31);
+    const int e0 = kc * 16 + 8 * (lane >> 5);
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.0f;
+    if (v < n) {
+        const float4* tp = tiles + ((v >> 6) * (size_t)d4) * MDB_TILE + (v & 63);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c4 = e0 / 4 + h;
+            if (c4 < d4) {
+                const float4 f = tp[(size_t)c4 * MDB_TILE];
+                const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = c4 * 4 + i;
+                    x[4 * h + i] = e < d ? fv[i] - (mean ? mean[e] : 0.0f) : 0.0f;
+                }
+            }
+        }
+    }
+    uint4 hi, lo;
+    bf16_split8(x, hi, lo);
+    bhi[o] = hi;
+    blo[o] = lo;
+}
+
+// squared norm of every (centred) vector, fmaf chain over its d coordinates (d eps relative, as in the error budget)
+__global__ void bf16_norm_kernel(const float4* __restrict__ tiles, size_t n, size_t npad, int d, int d4, const float* __restrict__ mean,
+                                 float* __restrict__ xnorm) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= npad) return;
+    float s = 0.0f;
+    if (v < n) {
+        const float4* tp = tiles + ((v >> 6) * (size_t)d4) * MDB_TILE + (v & 63);
+        for (int c4 = 0; c4 < d4; ++c4) {
+            const float4 f = tp[(size_t)c4 * MDB_TILE];
+            const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = c4 * 4 + i;
+                if (e < d) { const float x = fv[i] - (mean ? mean[e] : 0.0f); s = fmaf(x, x, s); }
+            }
+        }
+    }
+    xnorm[v] = s;
+}
+
+mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles, int metric) {
     size_t full = v.n / MDB_TILE;
     if (full < 1024) return MDB_OK;  // < 64K vectors: the exact path is used
     static const size_t div = getenv("MDB_MF_SAMPLE_DIV") ? (size_t)atoi(getenv("MDB_MF_SAMPLE_DIV")) : 32;
@@ -103,11 +184,28 @@ mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t 
                                                                                          (float4*)out.data.p);
     MDB_HIP(ctx, hipGetLastError());
     size_t all4 = v.ntiles * MDB_TILE * (size_t)v.d4;
-    if (aux.mean.alloc((size_t)v.d4 * 4) != hipSuccess || aux.ctiles.alloc(all4 * 4 + 4) != hipSuccess)
-        return mdb_fail(ctx, MDB_ERR_OOM, "centred store alloc (%zu floats)", all4 * 4);
+    if (aux.mean.alloc((size_t)v.d4 * 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "mean alloc");
     column_mean_kernel<<<dim3((unsigned)v.d4), 256, 0, ctx->stream>>>((const float4*)out.data.p, stiles, v.d4, aux.mean.p);
-    centre_tiles_kernel<<<dim3((unsigned)((all4 + 255) / 256)), 256, 0, ctx->stream>>>((const float4*)v.data, all4, v.d4,
-                                                                                       (const float4*)aux.mean.p, (float4*)aux.ctiles.p);
+    // bf16 x 3 operands when a group's query fragments fit LDS (d <= 512); the f32-MFMA filter's centred copy otherwise
+    const int nk = (v.d + 15) / 16;
+    static const bool no_bf16 = getenv("MDB_MF_F32") != nullptr;
+    if (!no_bf16 && nk <= 32) {
+        aux.nk = nk;
+        aux.nt32 = v.ntiles * 2;
+        aux.split_metric = metric;
+        const size_t total = aux.nt32 * (size_t)nk * 64;
+        if (aux.bhi.alloc(total + 1) != hipSuccess || aux.blo.alloc(total + 1) != hipSuccess || aux.xnorm.alloc(aux.nt32 * 32 + 4) != hipSuccess)
+            return mdb_fail(ctx, MDB_ERR_OOM, "bf16 split alloc (%zu fragments)", total);
+        const float* mean = metric == MDB_METRIC_L2 ? aux.mean.p : nullptr;
+        bf16_split_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((const float4*)v.data, v.n, v.d, v.d4, mean, nk, total,
+                                                                                         aux.bhi.p, aux.blo.p);
+        bf16_norm_kernel<<<dim3((unsigned)((aux.nt32 * 32 + 255) / 256)), 256, 0, ctx->stream>>>((const float4*)v.data, v.n, aux.nt32 * 32, v.d,
+                                                                                               v.d4, mean, aux.xnorm.p);
+    } else {
+        if (aux.ctiles.alloc(all4 * 4 + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "centred store alloc (%zu floats)", all4 * 4);
+        centre_tiles_kernel<<<dim3((unsigned)((all4 + 255) / 256)), 256, 0, ctx->stream>>>((const float4*)v.data, all4, v.d4,
+                                                                                           (const float4*)aux.mean.p, (float4*)aux.ctiles.p);
+    }
     MDB_HIP(ctx, hipGetLastError());
     if (!aux.h_ovf) {
         MDB_HIP(ctx, hipHostMalloc((void**)&aux.h_ovf, 4));
@@ -326,6 +424,135 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
     }
 }
 
+// ------------------------------------------------------------------------------------------ bf16 x 3 filter
+// Same admission test as flat_mfma_filter_kernel, the dot products on the bf16 matrix cores (16x the f32-MFMA rate):
+//   q'.x' ~ qh.xh + qh.xl + ql.xh   with  v = vh + vl + r,  vh = bf16(v), vl = bf16(v - vh), |r| <= 2^-18 |v| per coordinate,
+// every bf16 x bf16 product is exact in f32 and the sums run in f32 accumulators.  What is dropped or rounded:
+//   ql.xl + qr.x + q.xr  <= 3 * 2^-18 |q'||x'| (1 + 2^-8)   (Cauchy-Schwarz on the per-coordinate bounds)
+//   f32 accumulation of 3d products: <= 3 d eps (|qh||xh| + |qh||xl| + |ql||xh|) <= 3.03 d eps |q'||x'|
+// and |q'||x'| <= (qn + xn) / 2, so the host widens kappa by 4 d eps + 2^-16 (> 1.01 (3 d eps + 3 * 2^-18)) and the test
+// stays a NECESSARY condition for membership in the top-k: a true neighbour is never dropped (NaN / inf still admit).
+// A fragments (queries, 32 rows x 16 dims per MFMA) live in LDS, converted once per block; B fragments stream from the
+// precomputed split (coalesced 16-byte loads, one k-chunk ahead of the matrix cores).  grid (nblk, query groups of 32 * QB).
+#define BF_LBUF 1024   // candidate pairs staged per block (8 KB: two QB = 4 blocks fit one CU's LDS)
+template <int METRIC, int QB, int NKT>   // NKT: compile-time number of 16-dim chunks (8 = d <= 128: LDS offsets become immediates), 0 = run time
+__global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kernel(
+    const uint4* __restrict__ bhi, const uint4* __restrict__ blo, const float* __restrict__ xnorm, size_t n, size_t nt32, int nk_rt,
+    const float* __restrict__ dqc, int qstride, const float* __restrict__ crow, float kappa, uint64_t* __restrict__ pairs_all,
+    uint32_t* __restrict__ npairs_all, uint32_t pair_cap, size_t b, uint32_t* __restrict__ flags) {
+    uint64_t* __restrict__ pairs = pairs_all + (size_t)blockIdx.y * pair_cap;
+    uint32_t* __restrict__ npairs = npairs_all + (size_t)blockIdx.y * 64;
+    constexpr int BQ = 32 * QB;
+    const int nk = NKT ? NKT : nk_rt;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint4* Ahi = (uint4*)lds;                         // [QB][nk][64]
+    uint4* Alo = Ahi + (size_t)QB * nk * 64;
+    float* Cr = (float*)(Alo + (size_t)QB * nk * 64); // [BQ]
+    uint64_t* lbuf = (uint64_t*)(Cr + BQ);            // [BF_LBUF]
+    uint32_t* lcnt = (uint32_t*)(lbuf + BF_LBUF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const size_t q0 = (size_t)blockIdx.y * BQ;
+    if (tid == 0) lcnt[0] = 0;
+    for (int i = tid; i < QB * nk * 64; i += 256) {
+        const int l = i & 63, kc = (i >> 6) % nk, qb = (i >> 6) / nk;
+        const float* src = dqc + (q0 + qb * 32 + (l & 31)) * (size_t)qstride + kc * 16 + 8 * (l >> 5);
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = src[e];   // rows are zero beyond d (mfma_prep_kernel) and padded rows are all zero
+        uint4 h, lo;
+        bf16_split8(x, h, lo);
+        Ahi[i] = h;
+        Alo[i] = lo;
+    }
+    if (tid < BQ) Cr[tid] = crow[q0 + tid];
+    __syncthreads();
+    const size_t tstep = (size_t)gridDim.x * 4;
+    f32x16 acc[QB];
+    uint4 ch, cl, nh, nl;   // current / next B fragments
+    size_t t = (size_t)blockIdx.x * 4 + wave;
+    if (t < nt32) { ch = bhi[(t * nk) * 64 + lane]; cl = blo[(t * nk) * 64 + lane]; }
+    while (t < nt32) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qb][r] = 0.0f;
+        const size_t tn = t + tstep;
+        for (int kc = 0; kc < nk; ++kc) {
+            // prefetch the next fragment pair (the next tile's first when this is the last chunk)
+            const bool last = kc + 1 == nk;
+            const size_t pt = last ? (tn < nt32 ? tn : t) : t;
+            const size_t po = (pt * nk + (last ? 0 : kc + 1)) * 64 + lane;
+            nh = bhi[po];
+            nl = blo[po];
+            // the A fragments are loop invariant: without this the compiler hoists all QB * nk * 2 LDS loads out of the tile
+            // loop and spills (512 registers at QB = 8); they are re-read per chunk instead (2 QB ds_read_b128 per 3 QB MFMAs)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 vbh = __builtin_bit_cast(bf16x8, ch), vbl = __builtin_bit_cast(bf16x8, cl);
+            // three passes over the query blocks: consecutive MFMAs hit different accumulators (no dependent issue stalls)
+            bf16x8 vah[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                vah[qb] = __builtin_bit_cast(bf16x8, Ahi[((size_t)qb * nk + kc) * 64 + lane]);
+                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah[qb], vbh, acc[qb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah[qb], vbl, acc[qb], 0, 0, 0);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const bf16x8 val = __builtin_bit_cast(bf16x8, Alo[((size_t)qb * nk + kc) * 64 + lane]);
+                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, vbh, acc[qb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ch = nh;
+            cl = nl;
+        }
+        // epilogue: D[i][j], column j = lane & 31 (vector), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query)
+        const size_t v = t * 32 + l31;
+        const float xnh = xnorm[v];
+        const float xh = METRIC == MDB_METRIC_L2 ? xnh * (0.5f - kappa) : -kappa * xnh;
+        const bool force = !(xnh < __uint_as_float(0x7F800000u));   // infinite / NaN norm: admitted for every query
+        // the admission constants are re-read from LDS for every tile (volatile): hoisted out of the tile loop they would
+        // pin 16 * QB registers next to the accumulators
+        const volatile float* Crv = Cr;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            uint32_t hits = 0;   // bit r: row r of this lane's column is a candidate
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hits |= (acc[qb][r] < xh + Crv[qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]) ? 0u : (1u << r);  // NaN on either side admits
+            if (force) hits = 0xFFFFu;
+            if (v >= n) hits = 0;
+            if (__ballot(hits != 0)) {  // rare: a plain loop over the set bits (unrolled, its 16 * QB row constants get hoisted and spilled)
+                while (hits) {
+                    const int r = __ffs((int)hits) - 1;
+                    hits &= hits - 1;
+                    const size_t m = q0 + (size_t)(qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                    if (m < b) {
+                        const uint64_t pr = ((uint64_t)m << 32) | (uint32_t)v;
+                        const uint32_t pos = atomicAdd(lcnt, 1u);
+                        if (pos < BF_LBUF) lbuf[pos] = pr;
+                        else if (__builtin_nontemporal_load(npairs) <= pair_cap) {  // staging full: slow direct append
+                            const uint32_t g = atomicAdd(npairs, 1u);
+                            if (g < pair_cap) pairs[g] = pr;
+                        }
+                    }
+                }
+            }
+        }
+        t = tn;
+    }
+    __syncthreads();
+    const uint32_t ln = min(lcnt[0], (uint32_t)BF_LBUF);
+    if (ln) {
+        if (tid == 0) lcnt[1] = atomicAdd(npairs, ln);
+        __syncthreads();
+        const uint32_t base = lcnt[1];
+        for (uint32_t i = tid; i < ln; i += 256)
+            if (base + i < pair_cap) pairs[base + i] = lbuf[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ refine
 // MF_RS blocks per query, each over its slice of the pair list: collect the query's vectors (LDS), then
 // their exact distances and a partial top-k (merged by merge_keys).  A list longer than its capacity
@@ -423,7 +650,12 @@ bool flat_mfma_applicable(const TileView& ts, FlatAux& aux, size_t b, size_t k) 
 mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, int metric, const float* dq, int qstride, size_t b,
                                size_t bpad, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile) {
     // queries are staged with bpad rows; the filter reads groups of BQ rows, so bpad must cover them
-    const int QB = ((size_t)(ts.d4 + MF_CH) * 4 * 65 * 4 <= 64 * 1024 && b > 32) ? 2 : 1;
+    const bool use_bf16 = aux.bhi.p && aux.split_metric == metric;
+    int QB = ((size_t)(ts.d4 + MF_CH) * 4 * 65 * 4 <= 64 * 1024 && b > 32) ? 2 : 1;
+    if (use_bf16) {  // query blocks of 32 per thread block: as many as the batch fills and LDS holds (A fragments: QB * nk * 2 KiB)
+        QB = b > 128 ? 8 : b > 64 ? 4 : b > 32 ? 2 : 1;
+        while (QB > 1 && ((size_t)QB * aux.nk * 2048 + 32 * QB * 4 + BF_LBUF * 8 + 64 > 150 * 1024 || (size_t)32 * QB > bpad)) QB /= 2;
+    }
     const size_t BQ = 32 * QB, groups = (b + BQ - 1) / BQ, bpadq = groups * BQ;
     if (bpadq > bpad) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "internal: queries staged with %zu rows, filter needs %zu", bpad, bpadq);
     char* ax;
@@ -449,17 +681,46 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     //   fl(q'.x') on the matrix cores (fmaf chain): d eps |q'||x'| <= d eps (qn + xn) / 2
     //   fl(qn), fl(xn) (fmaf chains)             : d eps each
     // => a member of the true top-k passes the test when kappa >= (4d + 10) eps / (1 - d eps); 6 (d + 4) eps is used.
-    const float kappa = 6.0f * (float)(ts.d4 * 4 + 4) * 5.9604645e-8f;
+    //   bf16 x 3 split (flat_bf16_filter_kernel): dropped cross terms 3 * 2^-18 and 3d f32 accumulations -> + 4 d eps + 2^-16
+    const float kappa = 6.0f * (float)(ts.d4 * 4 + 4) * 5.9604645e-8f +
+                        (use_bf16 ? 4.0f * (float)(aux.nk * 16) * 5.9604645e-8f + 1.52587890625e-5f : 0.0f);
     MDB_HIP(ctx, hipMemsetAsync(npairs, 0, groups * 256 + 256, ctx->stream));  // the groups' counters and ovf
     mfma_prep_kernel<<<dim3((unsigned)bpadq), 128, 0, ctx->stream>>>(dq, qstride, ts.d, aux.mean.p, skeys, scounts, (int)k, kappa,
                                                                     metric, b, dqc, crow);
     // B. filter on the centred copy (L2) / the base itself (dot)
     const float4* ftiles = (metric == MDB_METRIC_L2) ? (const float4*)aux.ctiles.p : (const float4*)ts.data;
+    if (!use_bf16 && metric == MDB_METRIC_L2 && !aux.ctiles.p) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "internal: no filter operand for this metric");
     {
         bool saved = ctx->prof_on;
         ctx->prof_on = saved && profile;
         ProfScope prof(ctx);
         ctx->prof_on = saved;
+        if (use_bf16) {
+            const unsigned nblk_b = (unsigned)std::max<size_t>(1, std::min<size_t>((aux.nt32 + 3) / 4, std::max<size_t>(1, 512 / groups)));
+            dim3 gridb(nblk_b, (unsigned)groups);
+            const size_t ldsb = (size_t)QB * aux.nk * 2048 + BQ * 4 + BF_LBUF * 8 + 64;
+#define BF_LAUNCH(METRIC, QBT, NKT)                                                                                  \
+    do {                                                                                                             \
+        if (ldsb > 48 * 1024)                                                                                        \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_bf16_filter_kernel<METRIC, QBT, NKT>,                 \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));               \
+        flat_bf16_filter_kernel<METRIC, QBT, NKT><<<gridb, 256, ldsb, ctx->stream>>>(aux.bhi.p, aux.blo.p, aux.xnorm.p, ts.n, aux.nt32,    \
+                                                                                     aux.nk, dqc, qstride, crow, kappa, pairs, npairs,    \
+                                                                                     pair_cap, b, ctx->d_flags);                          \
+    } while (0)
+#define BF_QB(METRIC, NKT)                                             \
+    do {                                                               \
+        if (QB == 8) BF_LAUNCH(METRIC, 8, NKT);                        \
+        else if (QB == 4) BF_LAUNCH(METRIC, 4, NKT);                   \
+        else if (QB == 2) BF_LAUNCH(METRIC, 2, NKT);                   \
+        else BF_LAUNCH(METRIC, 1, NKT);                                \
+    } while (0)
+            if (metric == MDB_METRIC_L2) { if (aux.nk == 8) BF_QB(MDB_METRIC_L2, 8); else BF_QB(MDB_METRIC_L2, 0); }
+            else { if (aux.nk == 8) BF_QB(MDB_METRIC_DOT, 8); else BF_QB(MDB_METRIC_DOT, 0); }
+#undef BF_QB
+#undef BF_LAUNCH
+            MDB_HIP(ctx, hipGetLastError());
+        } else {
         unsigned nblk = (unsigned)std::min<size_t>((ts.ntiles + 3) / 4, groups >= 4 ? 256 : 512);
         dim3 grid(nblk, (unsigned)groups);
         size_t lds = (size_t)((ts.d4 + MF_CH - 1) / MF_CH * MF_CH) * 4 * (BQ + 1) * 4 + (BQ + 2) * 4 + MF_LBUF * 8 + 16;
@@ -475,6 +736,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
         else { if (QB == 2) MF_LAUNCH(MDB_METRIC_DOT, 2); else MF_LAUNCH(MDB_METRIC_DOT, 1); }
 #undef MF_LAUNCH
         MDB_HIP(ctx, hipGetLastError());
+        }
     }
     // C. refine
     DistPlan p = make_plan(ts.d, metric);

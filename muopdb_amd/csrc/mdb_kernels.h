@@ -31,8 +31,16 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
 // empty for small stores); queries must be staged with bpad >= b rounded up to 64 rows.
 struct FlatAux {
     TileStore sample;        // every stride-th tile: its exact k-th distance bounds the base's
-    DevBuf<float> ctiles;    // mean-centred copy of the base in the same tile layout (L2 filter operand)
+    DevBuf<float> ctiles;    // mean-centred copy of the base in the same tile layout (f32 filter operand; only when the bf16 split is not used)
     DevBuf<float> mean;      // [d4*4]
+    // bf16 x 3 filter operands: the (centred) base split into hi = bf16(x'), lo = bf16(x' - hi), laid out as
+    // v_mfma_f32_32x32x16_bf16 B fragments — uint4 (8 bf16) index ((tile32 * nk + kc) * 64 + lane): vector tile32*32 + (lane & 31),
+    // dims kc*16 + 8*(lane >> 5) .. +7 — plus the f32 squared norms of the centred vectors.  Same bytes as the f32 copy.
+    DevBuf<uint4> bhi, blo;
+    DevBuf<float> xnorm;
+    int nk = 0;              // 16-dim chunks per vector
+    size_t nt32 = 0;         // 32-vector tiles
+    int split_metric = -1;   // metric the split was built for (L2: centred; dot: as is)
     uint32_t* h_ovf = nullptr;  // pinned: candidate-list overflows of the last batch (read one call late)
     int cooldown = 0;        // batches left on the exact kernels after an overflow
     FlatAux() = default;
@@ -43,7 +51,7 @@ struct FlatAux {
 // dst = a view of src's device arrays (attached handles) with its own overflow word / cooldown
 void flat_aux_view(const FlatAux& src, FlatAux& dst);
 // want_tiles: size of the strided sample in tiles (0: N/32 clamped to 16K..64K vectors, the flat index default)
-mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles = 0);
+mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles = 0, int metric = MDB_METRIC_L2);
 bool flat_mfma_applicable(const TileView& ts, FlatAux& aux, size_t b, size_t k);
 mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, int metric, const float* dq, int qstride, size_t b,
                                size_t bpad, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false);
