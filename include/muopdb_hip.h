@@ -276,6 +276,17 @@ mdb_status mdb_hnsw_ann_search_submit(mdb_hnsw* hnsw, const float* queries, size
 mdb_status mdb_hnsw_ann_search(mdb_hnsw* hnsw, const float* queries, size_t b, size_t k, uint32_t ef, mdb_mem mem,
                                mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out);
 
+/* HnswBuilder::select_neighbors_heuristic (rs/index/src/hnsw/builder.rs:339-375) for `rows` candidate lists at once (the
+ * distance-heavy step of construction): list r = cand_ids[r][0..width) (UINT32_MAX padded) with the
+ * candidates' distances to the list's own point, in the heap's pop order (distance ascending, larger id first among
+ * equals); a candidate is kept unless an already kept point is closer to it than it is to the list's point
+ * (distance_two_points :318-326 = the quantizer's distance, here NoQuantizer: sqrt L2 / negated dot, exact cascade).
+ * ids_out / dist_out [rows][max_neighbors] in selection order (UINT32_MAX / +inf padded), counts_out [rows];
+ * max_neighbors <= 64.  `vectors` [n][d] row-major lives where vectors_mem says; the other pointers are host. */
+mdb_status mdb_hnsw_select_neighbors(mdb_ctx* ctx, const float* vectors, size_t n, size_t d, mdb_metric metric, mdb_mem vectors_mem,
+                                     const uint32_t* cand_ids, const float* cand_dist, size_t rows, size_t width,
+                                     size_t max_neighbors, uint32_t* ids_out, float* dist_out, uint32_t* counts_out);
+
 /* ---------------------------------------------------------------- SPANN
  * SpannReader::new_with_offsets + Spann::search (spann/reader.rs, spann/index.rs:211-266):
  * centroid HNSW (always NoQuantizer<L2>) + IVF posting lists (quant). */

@@ -175,3 +175,208 @@ def ivf_build_centroids(ctx, x, num_clusters, max_posting_list_size, num_data_po
             heapq.heappush(heap, (-len(sub), tick, cen, sub)); tick += 1
     kept = [(cen, pl) for _, _, cen, pl in sorted(heap, key=lambda t: t[1]) if len(pl)]
     return np.stack([c for c, _ in kept]).astype(np.float32), [np.sort(pl).astype(np.uint64) for _, pl in kept]
+
+
+# ------------------------------------------------------------------------------------------ HNSW construction
+def select_neighbors(ctx, x, cand_ids, cand_dist, max_neighbors, metric=L.METRIC_L2):
+    """HnswBuilder::select_neighbors_heuristic (hnsw/builder.rs:339-375) for many candidate lists at once
+    (mdb_hnsw_select_neighbors).  cand_ids / cand_dist [rows][width] in pop order (distance ascending, larger id first among
+    equals), UINT32_MAX padded.  Returns (ids [rows][M], dist [rows][M], counts [rows]) as numpy arrays."""
+    p, n, d, mem, keep = _rows(x)
+    ci = np.ascontiguousarray(cand_ids, np.uint32)
+    cd = np.ascontiguousarray(cand_dist, np.float32)
+    rows, width = ci.shape
+    ids = np.empty((rows, max_neighbors), np.uint32)
+    dist = np.empty((rows, max_neighbors), np.float32)
+    cnt = np.zeros(rows, np.uint32)
+    if mem == L.MEM_DEVICE:
+        import torch
+        torch.cuda.synchronize()
+    ctx.check(ctx.lib.mdb_hnsw_select_neighbors(ctx.h, p, C.c_size_t(n), C.c_size_t(d), C.c_int(metric), C.c_int(mem), L.ptr(ci, C.c_uint32),
+                                                L.ptr(cd, C.c_float), C.c_size_t(rows), C.c_size_t(width), C.c_size_t(max_neighbors),
+                                                L.ptr(ids, C.c_uint32), L.ptr(dist, C.c_float), L.ptr(cnt, C.c_uint32)))
+    return ids, dist, cnt
+
+
+def _pop_order(ids, dist):
+    """rows re-ordered into the heap's pop order: distance ascending, LARGER id first among equal distances; padding last"""
+    pad = ids == 0xFFFFFFFF
+    key_id = np.where(pad, -1, ids.astype(np.int64))
+    o1 = np.argsort(-key_id, axis=1, kind="stable")
+    ids, dist, pad = np.take_along_axis(ids, o1, 1), np.take_along_axis(dist, o1, 1), np.take_along_axis(pad, o1, 1)
+    o2 = np.argsort(np.where(pad, np.inf, dist), axis=1, kind="stable")
+    return np.take_along_axis(ids, o2, 1), np.take_along_axis(dist, o2, 1)
+
+
+def insert_hnsw(ctx, x, max_neighbors=32, max_layers=8, ef_construction=100, seed=1, batch_frac=0.125, exact_below=2048, log=None):
+    """HNSW construction with the reference's algorithm, batched for the GPU (HnswBuilder::insert, hnsw/builder.rs:221-305).
+
+    Per new point the reference (i) draws a level (get_random_layer :332-337), (ii) finds ef_construction candidates on
+    every layer <= its level with search_layer, (iii) keeps <= max_neighbors of them with select_neighbors_heuristic, links
+    both ways and (iv) re-runs the heuristic on every neighbour whose edge list overflowed (:256-300).  Here a BATCH of
+    points (batch_frac of the points already inserted) goes through (ii)-(iv) together: the layer-0 searches run through the
+    library's traversal kernel on the graph built so far (written in the reference's on-disk format and loaded like any
+    index), the selections and the trims through mdb_hnsw_select_neighbors.  Points of one batch do not see each other —
+    the usual relaxation of parallel HNSW builds — so the graph is quality-parity with the sequential reference build
+    (tests compare recall against the oracle's restatement of `insert`), not edge-identical.  Upper layers (1/M of the points)
+    and the first `exact_below` points take their candidates from an exact scan (FlatIndex) instead of a graph search.
+    The reference stores the heuristic's NEGATED distance on a kept edge (builder.rs:366-369, a sign slip that its later
+    trims inherit); edges here carry the true distance.
+
+    x: [n][d] numpy or torch CUDA tensor.  Returns (layers, levels): layers in formats.write_hnsw_index's CSR form
+    (layer 0 first; points None for layer 0), point ids = row numbers."""
+    from .index import BlockBasedHnsw, FlatIndex
+    n, d = x.shape
+    M, efc = int(max_neighbors), int(ef_construction)
+    rng = np.random.default_rng(seed)
+    u = 1.0 - rng.random(n)
+    levels = np.minimum(np.floor(-np.log(u) / np.log(M)), max_layers).astype(np.int64)
+    xh = x.cpu().numpy() if _is_torch(x) else L.f32(x)
+    adj = np.full((n, M), 0xFFFFFFFF, np.uint32)       # layer 0 edge lists
+    adjd = np.full((n, M), np.inf, np.float32)
+    cnt = np.zeros(n, np.int64)
+    upper = {}                                          # layer -> {point: [(id, dist), ...]}
+    top = int(levels[0])
+    for l in range(1, top + 1):
+        upper.setdefault(l, {})[0] = []
+    first_top = 0
+
+    def csr_layers(cur):
+        m = np.arange(M)[None, :] < cnt[:cur, None]
+        indptr = np.zeros(cur + 1, np.uint64)
+        indptr[1:] = np.cumsum(cnt[:cur])
+        out = [(None, indptr, adj[:cur][m])]
+        for l in range(1, top + 1):
+            pts = sorted(upper.get(l, {}).keys())
+            if l == top and first_top in pts:           # the reader's entry point = FIRST point of the top layer
+                pts.remove(first_top)
+                pts.insert(0, first_top)
+            ip = np.zeros(len(pts) + 1, np.uint64)
+            ed = []
+            for i, pnt in enumerate(pts):
+                ed += [e for e, _ in upper[l][pnt]]
+                ip[i + 1] = len(ed)
+            out.append((np.asarray(pts, np.uint32), ip, np.asarray(ed, np.uint32)))
+        return out
+
+    def link(layer_get, layer_put, p, sel_ids, sel_d):
+        """forward + reverse edges of point p on one UPPER layer, trims through the heuristic (python: few points)"""
+        layer_put(p, list(zip(sel_ids, sel_d)))
+        over = []
+        for e, de in zip(sel_ids, sel_d):
+            lst = layer_get(e)
+            lst.append((p, de))
+            if len(lst) > M:
+                over.append(e)
+        return over
+
+    cur = 1
+    while cur < n:
+        B = int(min(n - cur, max(1, cur * batch_frac)))
+        new = np.arange(cur, cur + B)
+        q = xh[cur:cur + B]
+        # ---- (ii) layer-0 candidates of the whole batch
+        k0 = min(efc, cur)
+        if cur <= exact_below:
+            fi = FlatIndex(ctx, xh[:cur])
+            ids0, d0, _ = fi.search(q, k0)
+            fi.close()
+            ids0 = ids0.astype(np.uint32)
+        else:
+            idx = F.write_hnsw_index(csr_layers(cur), np.arange(cur, dtype=np.uint64), d)
+            g = BlockBasedHnsw(ctx, idx, F.write_vector_file(xh[:cur]), d)
+            res = g.ann_search(q, k0, efc)
+            g.close()
+            ids0 = np.where(np.arange(k0)[None, :] < res.counts[:, None], res.doc_lo[:, :k0], 0xFFFFFFFF).astype(np.uint32)
+            d0 = np.where(ids0 == 0xFFFFFFFF, np.inf, res.scores[:, :k0]).astype(np.float32)
+        ci, cd = _pop_order(ids0, d0.astype(np.float32))
+        sel, seld, selc = select_neighbors(ctx, x if _is_torch(x) else xh, ci, cd, M)
+        # ---- (iii) layer 0: forward edges, then reverse edges grouped by target
+        adj[new, :] = sel
+        adjd[new, :] = seld
+        cnt[new] = selc
+        valid = np.arange(M)[None, :] < selc[:, None]
+        tgt = sel[valid].astype(np.int64)
+        src = np.repeat(new, selc.astype(np.int64))
+        rd = seld[valid]
+        order = np.lexsort((rd, tgt))                   # per target: nearest new neighbours first
+        tgt, src, rd = tgt[order], src[order], rd[order]
+        ue, start, ncount = np.unique(tgt, return_index=True, return_counts=True)
+        rank = np.arange(tgt.size) - np.repeat(start, ncount)
+        fits = cnt[ue] + ncount <= M
+        # targets with room: append in place
+        fm = np.repeat(fits, ncount)
+        adj[tgt[fm], cnt[tgt[fm]] + rank[fm]] = src[fm].astype(np.uint32)
+        adjd[tgt[fm], cnt[tgt[fm]] + rank[fm]] = rd[fm]
+        cnt[ue[fits]] += ncount[fits]
+        # ---- (iv) overflowing targets: old edges + new ones through the heuristic again
+        oe = ue[~fits]
+        if oe.size:
+            R = int(min(ncount[~fits].max(), 2 * M))    # the nearest <= 2M newcomers of a target compete with its M old edges
+            W = M + R
+            li = np.full((oe.size, W), 0xFFFFFFFF, np.uint32)
+            ld = np.full((oe.size, W), np.inf, np.float32)
+            li[:, :M] = adj[oe]
+            ld[:, :M] = adjd[oe]
+            om = (~fm) & (rank < R)
+            rowof = np.searchsorted(oe, tgt[om])
+            li[rowof, M + rank[om]] = src[om].astype(np.uint32)
+            ld[rowof, M + rank[om]] = rd[om]
+            li, ld = _pop_order(li, ld)
+            t_ids, t_d, t_c = select_neighbors(ctx, x if _is_torch(x) else xh, li, ld, M)
+            adj[oe] = t_ids
+            adjd[oe] = t_d
+            cnt[oe] = t_c
+        # ---- upper layers of the batch (1/M of the points): exact candidates among the layer's members, python bookkeeping
+        for l in range(1, int(levels[new].max()) + 1):
+            pts_new = new[levels[new] >= l]
+            members = np.array(sorted(upper.get(l, {}).keys()), np.int64)
+            lay = upper.setdefault(l, {})
+            if members.size and pts_new.size:
+                fi = FlatIndex(ctx, xh[members])
+                kk = min(efc, members.size)
+                ui, ud, _ = fi.search(xh[pts_new], kk)
+                fi.close()
+                ci, cd = _pop_order(members[ui.astype(np.int64)].astype(np.uint32), ud.astype(np.float32))
+                s_i, s_d, s_c = select_neighbors(ctx, x if _is_torch(x) else xh, ci, cd, M)
+            over = []
+            for r, pnt in enumerate(pts_new.tolist()):
+                if members.size:
+                    c_ = int(s_c[r])
+                    over += link(lambda e: lay[e], lambda p_, v: lay.__setitem__(p_, v), pnt, s_i[r, :c_].tolist(), s_d[r, :c_].tolist())
+                else:
+                    lay[pnt] = []
+            over = sorted(set(over))
+            if over:
+                W = max(len(lay[e]) for e in over)
+                li = np.full((len(over), W), 0xFFFFFFFF, np.uint32)
+                ld = np.full((len(over), W), np.inf, np.float32)
+                for r, e in enumerate(over):
+                    li[r, :len(lay[e])] = [a for a, _ in lay[e]]
+                    ld[r, :len(lay[e])] = [b for _, b in lay[e]]
+                li, ld = _pop_order(li, ld)
+                t_i, t_d, t_c = select_neighbors(ctx, x if _is_torch(x) else xh, li, ld, M)
+                for r, e in enumerate(over):
+                    lay[e] = list(zip(t_i[r, :int(t_c[r])].tolist(), t_d[r, :int(t_c[r])].tolist()))
+        hi = int(levels[new].max())
+        if hi > top:                                    # a new top layer: its first point becomes the entry point (:301-303)
+            first_top = int(new[levels[new] == hi][0])
+            for l in range(top + 1, hi + 1):
+                upper.setdefault(l, {})
+                for pnt in new[levels[new] >= l].tolist():
+                    upper[l].setdefault(pnt, [])
+            top = hi
+        cur += B
+        if log:
+            log("insert_hnsw: %d / %d points" % (cur, n))
+    return csr_layers(n), levels
+
+
+def hnsw_files_by_insertion(ctx, x, doc_ids=None, **kw):
+    """(index_bytes, vector_bytes) in the reference's HNSW formats, graph built by insert_hnsw."""
+    layers, _ = insert_hnsw(ctx, x, **kw)
+    n, d = x.shape
+    if doc_ids is None:
+        doc_ids = np.arange(n, dtype=np.uint64)
+    xh = x.cpu().numpy() if _is_torch(x) else L.f32(x)
+    return F.write_hnsw_index(layers, doc_ids, d), F.write_vector_file(xh)

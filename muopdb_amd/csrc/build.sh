@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libmuopdb_hip.so
-SRCS="mdb_core.hip mdb_flat.hip mdb_flat_mfma.hip mdb_ef.hip mdb_ivf.hip mdb_hnsw.hip mdb_spann.hip mdb_kmeans.hip"
+SRCS="mdb_core.hip mdb_flat.hip mdb_flat_mfma.hip mdb_ef.hip mdb_ivf.hip mdb_hnsw.hip mdb_spann.hip mdb_kmeans.hip mdb_hnsw_build.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-variable $MDB_EXTRA_FLAGS"
 mkdir -p build
 objs=""

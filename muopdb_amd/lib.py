@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "mdb_multi_spann_load", "mdb_multi_spann_free", "mdb_multi_spann_num_users", "mdb_multi_spann_search",
     "mdb_multi_spann_set_filter", "mdb_multi_spann_invalidate", "mdb_merge_shards",
     "mdb_shard_block_bytes", "mdb_shard_block_views", "mdb_merge_shards_packed", "mdb_allgather_merge",
-    "mdb_odht_user_table", "mdb_wait", "mdb_poll", "mdb_ivf_search_filtered", "mdb_ivf_attach", "mdb_ivf_search_submit", "mdb_hnsw_ann_search_submit",
+    "mdb_odht_user_table", "mdb_hnsw_select_neighbors", "mdb_wait", "mdb_poll", "mdb_ivf_search_filtered", "mdb_ivf_attach", "mdb_ivf_search_submit", "mdb_hnsw_ann_search_submit",
     "mdb_spann_search_filtered", "mdb_spann_attach", "mdb_spann_search_submit",
     "mdb_multi_spann_search_filtered", "mdb_multi_spann_attach", "mdb_multi_spann_search_submit",
 ]

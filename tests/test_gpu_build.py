@@ -149,3 +149,75 @@ def test_open_segment_directory(ctx, oracle, tmp_path, pq):
         assert np.array_equal(r.scores[i, :int(r.counts[i])].view(np.uint32), ro.scores[i, :int(ro.counts[i])].view(np.uint32))
     if not pq:
         assert r.doc_ids(0) == [1000, 3, 2]        # K9 (multi_spann/index.rs:358-412) through the on-disk tree
+
+
+def test_select_neighbors_heuristic(ctx, oracle):
+    """mdb_hnsw_select_neighbors == select_neighbors_heuristic (hnsw/builder.rs:339-375) restated with the oracle's exact
+    distance: pop order (distance asc, larger id first), keep e unless a kept x has distance(x, e) < distance(e, q)."""
+    from muopdb_amd import build as B
+    rng = np.random.default_rng(8)
+    n, d, M, W = 600, 24, 8, 40
+    x = H.sift_like(n, d, n_clusters=6, seed=5)
+    x[100] = x[7]; x[200] = x[7]                                      # duplicates: exact ties
+    cand = np.full((50, W), 0xFFFFFFFF, np.uint32)
+    dist = np.full((50, W), np.inf, np.float32)
+    for r in range(50):
+        c = rng.choice(n, size=int(rng.integers(1, W + 1)), replace=False)
+        if r % 5 == 0:
+            c = np.unique(np.concatenate([c[:W - 3], [7, 100, 200]]))[:W]
+        dd = np.array([oracle.l2(x[r], x[j]) for j in c], np.float32)
+        order = np.lexsort((-c.astype(np.int64), dd))
+        cand[r, :len(c)], dist[r, :len(c)] = c[order], dd[order]
+    ids, ds, cnt = B.select_neighbors(ctx, x, cand, dist, M)
+    for r in range(50):
+        kept = []
+        for j in range(W):
+            e = int(cand[r, j])
+            if e == 0xFFFFFFFF or len(kept) == M:
+                break
+            if all(not (np.float32(oracle.l2(x[e], x[k_])) < dist[r, j]) for k_, _ in kept):
+                kept.append((e, dist[r, j]))
+        assert int(cnt[r]) == len(kept) and ids[r, :len(kept)].tolist() == [e for e, _ in kept]
+        assert np.array_equal(ds[r, :len(kept)].view(np.uint32), np.array([v for _, v in kept], np.float32).view(np.uint32))
+
+
+def test_insert_hnsw_quality_parity_with_the_reference_algorithm(ctx, oracle):
+    """SURVEY.md §8f rank 3: the batched GPU construction (muopdb_amd.build.insert_hnsw: HnswBuilder::insert's steps over the
+    library's traversal + selection kernels) against the oracle's sequential restatement of HnswBuilder::insert on the same
+    points and parameters: recall@10 of the two graphs under the same search, degree bound, every point reachable."""
+    from muopdb_amd import build as B
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import BlockBasedHnsw, FlatIndex
+    n, d, M, efc = 9000, 32, 16, 64
+    x = H.sift_like(n, d, n_clusters=60, seed=33)
+    rng = np.random.default_rng(2)
+    q = (x[rng.integers(0, n, 200)] + rng.normal(0, 4, (200, d))).astype(np.float32)
+    layers, levels = B.insert_hnsw(ctx, x, max_neighbors=M, max_layers=4, ef_construction=efc, seed=3)
+    _, indptr, edges = layers[0]
+    deg = np.diff(indptr.astype(np.int64))
+    assert deg.max() <= M and deg.min() >= 1 and len(layers) == int(levels.max()) + 1
+    assert edges.max() < n and len(indptr) == n + 1
+    idx = F.write_hnsw_index(layers, np.arange(n, dtype=np.uint64), d)
+    vec = F.write_vector_file(x)
+    g = BlockBasedHnsw(ctx, idx, vec, d)
+    o = oracle.BlockBasedHnsw(idx, vec, d)                                # the oracle's traversal reads the GPU-built file too
+    res = g.ann_search(q, 10, 50)
+    ores = o.ann_search(q[:40], 10, 50)
+    assert [res.doc_ids(i) for i in range(40)] == [ores.doc_ids(i) for i in range(40)]
+    exact, _, _ = FlatIndex(ctx, x).search(q, 10)
+    rec_gpu = np.mean([len(set(res.doc_ids(i)) & set(int(v) for v in exact[i])) / 10 for i in range(200)])
+    ridx, rvec = H.build_hnsw_files(oracle, x, list(range(n)), max_neighbors=M, max_layers=4, ef_construction=efc, seed=3)
+    rres = BlockBasedHnsw(ctx, ridx, rvec, d).ann_search(q, 10, 50)
+    rec_ref = np.mean([len(set(rres.doc_ids(i)) & set(int(v) for v in exact[i])) / 10 for i in range(200)])
+    assert rec_gpu >= 0.9 and rec_gpu >= rec_ref - 0.03, (rec_gpu, rec_ref)
+    # every point is reachable on layer 0 from the entry point (a build that dropped reverse edges would strand points)
+    seen = np.zeros(n, bool)
+    ep = int(layers[-1][0][0]) if len(layers) > 1 else int(np.argmax(deg > 0))
+    stack, seen[ep] = [ep], True
+    while stack:
+        p_ = stack.pop()
+        for e in edges[int(indptr[p_]):int(indptr[p_ + 1])].tolist():
+            if not seen[e]:
+                seen[e] = True
+                stack.append(e)
+    assert seen.mean() > 0.999
