@@ -693,3 +693,68 @@ class MultiSpannIndex:
         self.ctx.check(self.ctx.lib.mdb_multi_spann_invalidate(self.h, L.u128_array([user_id]), L.u128_array([doc_id]),
                                                                C.c_size_t(1), L.ptr(flags, C.c_uint8)))
         return bool(flags[0])
+
+
+# ------------------------------------------------------------------------------------------ segment fan-out (callers of the path)
+def _id_with_score_key(row):
+    """IdWithScore order (rs/index/src/utils.rs:95-114): score ascending, NaN last, then doc id"""
+    return (np.isnan(row[1]), row[1], row[0])
+
+
+class PendingSegment:
+    """PendingSegment::search_with_id while the merged index is not built yet (rs/index/src/segment/pending_segment.rs:285-335):
+    the inner segments are searched with an OVER-FETCH of top_k + len(invalidated ids of the user), the temporarily
+    invalidated documents are dropped from every inner result, the rows are concatenated, sorted (IdWithScore) and truncated
+    to top_k.  `inner_segments`: MultiSpannIndex handles (resident on the GPU); `temp_invalidated_ids`: user id -> doc ids."""
+
+    def __init__(self, inner_segments, temp_invalidated_ids=None):
+        self.inner_segments = list(inner_segments)
+        self.temp_invalidated_ids = {u: set(v) for u, v in (temp_invalidated_ids or {}).items()}
+
+    def invalidate(self, user_id, doc_id):
+        self.temp_invalidated_ids.setdefault(user_id, set()).add(doc_id)
+
+    def search_with_id(self, user_id, query, params, planner=None):
+        dead = self.temp_invalidated_ids.get(user_id) or set()
+        adjusted = SearchParams(params.top_k + len(dead), params.ef_construction, params.record_pages)
+        adjusted.num_explored_centroids = params.num_explored_centroids
+        adjusted.centroid_distance_ratio = params.centroid_distance_ratio
+        rows, any_found = [], False
+        for seg in self.inner_segments:
+            res = seg.search_for_user([user_id], np.asarray(query, np.float32).reshape(1, -1), adjusted, planner=planner)
+            if res.found[0]:
+                any_found = True
+                rows += [r for r in res.id_with_scores(0) if r[0] not in dead]
+        if not any_found:
+            return None
+        rows.sort(key=_id_with_score_key)
+        return rows[:params.top_k]
+
+
+class Snapshot:
+    """Snapshot::search_for_user / search_for_users (rs/index/src/collection/snapshot.rs:39-110): every segment of the
+    snapshot is searched (immutable segments = MultiSpannIndex handles, pending ones = PendingSegment), the rows are
+    concatenated, sorted by IdWithScore and truncated to top_k; search_for_users does the same over several users."""
+
+    def __init__(self, segments):
+        self.segments = list(segments)
+
+    def search_for_user(self, user_id, query, params, planner=None):
+        rows = []
+        for seg in self.segments:
+            if isinstance(seg, PendingSegment):
+                r = seg.search_with_id(user_id, query, params, planner=planner)
+                rows += r or []
+            else:
+                res = seg.search_for_user([user_id], np.asarray(query, np.float32).reshape(1, -1), params, planner=planner)
+                if res.found[0]:
+                    rows += res.id_with_scores(0)
+        rows.sort(key=_id_with_score_key)
+        return rows[:params.top_k]
+
+    def search_for_users(self, user_ids, query, params, planner=None):
+        rows = []
+        for u in user_ids:
+            rows += self.search_for_user(u, query, params, planner=planner)
+        rows.sort(key=_id_with_score_key)
+        return rows[:params.top_k]

@@ -271,3 +271,42 @@ def test_corrupt_posting_list_headers_are_refused(ctx, case):
     with pytest.raises(L.MuopdbError) as e:
         BlockBasedIvf(ctx, bytes(bad), f["ivf_vectors"], case["quant"])
     assert e.value.status == 2
+
+
+def test_pending_segment_over_fetch_and_snapshot_merge(ctx, oracle, case):
+    """PendingSegment::search_with_id's over-fetch (segment/pending_segment.rs:300-318: top_k + len(invalidated)) and
+    Snapshot::search_for_user's cross-segment merge (collection/snapshot.rs:69-110) over GPU-resident segments, against
+    the same procedure over the oracle's segments."""
+    from muopdb_amd.index import MultiSpannIndex, PendingSegment, SearchParams, Snapshot
+    f, q = case["files"], case["q"]
+    n = case["n"]
+    v2 = H.sift_like(1500, case["d"], n_clusters=12, seed=77)
+    opq = oracle.ProductQuantizer(case["d"], 8, 6, case["quant"].codebook)
+    f2, _, _ = H.build_spann_files(oracle, v2, list(range(100_000, 101_500)), 15, quantize=opq.quantize, max_neighbors=8, max_layers=3,
+                                   ef_construction=50)
+    cats = [F.concat_multi_spann({7: f}), F.concat_multi_spann({7: f2, 8: f2})]
+    segs, osegs = [], []
+    for cat in cats:
+        a = (cat["user_table"], case["d"], cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+        segs.append(MultiSpannIndex(ctx, *a, case["quant"]))
+        osegs.append(oracle.MultiSpannIndex(*a, case["oquant"]))
+    p = SearchParams(5, 50).with_num_explored_centroids(6)
+    first = PendingSegment(segs[:1]).search_with_id(7, q[0], p)
+    dead = {7: [first[0][0], first[2][0]]}                       # two of the top documents are temporarily invalidated
+    pend = PendingSegment(segs[:1], dead)
+    got = pend.search_with_id(7, q[0], p)
+    op = oracle.SearchParams(5 + 2, 50, num_explored_centroids=6)
+    ores = osegs[0].search_for_user([7], q[:1], op)
+    want = sorted([r for r in ores.id_with_scores(0) if r[0] not in dead[7]], key=lambda r: (r[1], r[0]))[:5]
+    assert got == want and len(got) == 5 and all(r[0] not in dead[7] for r in got)
+    assert got[:3] == [r for r in first if r[0] not in dead[7]][:3]     # the over-fetch refills the row instead of shortening it
+    assert PendingSegment(segs[:1]).search_with_id(12345, q[0], p) is None
+    snap = Snapshot([pend, segs[1]])
+    rows = snap.search_for_user(7, q[1], p)
+    o1 = osegs[0].search_for_user([7], q[1:2], oracle.SearchParams(7, 50, num_explored_centroids=6))
+    o2 = osegs[1].search_for_user([7], q[1:2], oracle.SearchParams(5, 50, num_explored_centroids=6))
+    merged = sorted([r for r in o1.id_with_scores(0) if r[0] not in dead[7]][:5] + o2.id_with_scores(0), key=lambda r: (r[1], r[0]))[:5]
+    assert rows == merged
+    many = snap.search_for_users([7, 8, 999], q[1], p)
+    o3 = osegs[1].search_for_user([8], q[1:2], oracle.SearchParams(5, 50, num_explored_centroids=6))
+    assert many == sorted(merged + o3.id_with_scores(0), key=lambda r: (r[1], r[0]))[:5]
