@@ -360,7 +360,7 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     float* dq;
     int qstride;
     const bool batched = flat_mfma_applicable(view_of(flat->ts), flat->aux, b, k);
-    const size_t bpad = batched ? (b + 63) / 64 * 64 : (b + 3) / 4 * 4;
+    const size_t bpad = batched ? (b + 255) / 256 * 256 : (b + 3) / 4 * 4;  // whole query groups of the matrix-core filter (up to 8 x 32 rows)
     MDB_TRY(stage_queries(ctx, 0, queries, b, flat->ts.d, mem, bpad, &dq, &qstride));
     void *keys, *cnts;
     bool fused = false;

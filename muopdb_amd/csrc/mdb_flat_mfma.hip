@@ -654,7 +654,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     int QB = ((size_t)(ts.d4 + MF_CH) * 4 * 65 * 4 <= 64 * 1024 && b > 32) ? 2 : 1;
     if (use_bf16) {  // query blocks of 32 per thread block: as many as the batch fills and LDS holds (A fragments: QB * nk * 2 KiB)
         QB = b > 128 ? 8 : b > 64 ? 4 : b > 32 ? 2 : 1;
-        while (QB > 1 && ((size_t)QB * aux.nk * 2048 + 32 * QB * 4 + BF_LBUF * 8 + 64 > 150 * 1024 || (size_t)32 * QB > bpad)) QB /= 2;
+        while (QB > 1 && ((size_t)QB * aux.nk * 2048 + 32 * QB * 4 + BF_LBUF * 8 + 64 > 150 * 1024 || (b + 32 * QB - 1) / (32 * QB) * (32 * QB) > bpad)) QB /= 2;
     }
     const size_t BQ = 32 * QB, groups = (b + BQ - 1) / BQ, bpadq = groups * BQ;
     if (bpadq > bpad) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "internal: queries staged with %zu rows, filter needs %zu", bpad, bpadq);

@@ -82,7 +82,7 @@ struct IvfSet {
     // single index with >= 64K centroids: sample / centred copy for the batched (MFMA-filtered) coarse search
     FlatAux cent_aux;
     // rows the queries must be staged with for coarse(): whole groups of 64 when the batched path may run
-    size_t coarse_bpad(size_t b) const { return cent_aux.sample.n ? (b + 63) / 64 * 64 : (b + 3) / 4 * 4; }
+    size_t coarse_bpad(size_t b) const { return cent_aux.sample.n ? (b + 255) / 256 * 256 : (b + 3) / 4 * 4; }
     mdb_status coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes,
                       bool zero_counters = false, size_t bpad = 0);  // zero_counters: its merge kernel also clears the context's device counters
     mdb_status scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
