@@ -479,6 +479,7 @@ def run_c5(env):
     log("C5 shard build %.1fs: %d vectors in %d owned lists" % (time.time() - t0, sh["n"], sh["owned_lists"]))
     ivf = BlockBasedIvf(ctx, sh["index"], sh["vectors"], sh["pq"])
     queries = sh["gen"].draw((steps + warm) * batch, seed=5000).contiguous()
+    dump(args, env.rank, "c5", index=sh["index"], vectors=sh["vectors"], **{"queries.f32": queries.cpu().numpy(), "codebook.f32": sh["codebook"]})
     m = ivfpq_measure(env, ivf, None, queries, batch, k, P, steps, warm)
     out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=None, scaling="strong",
                config={"workload": "C5 per-GPU: rank 0's shard (lists l %% 8 == 0: %d vectors, %d lists) of a %d x 128 SiftLike index as 16-byte PQ "
