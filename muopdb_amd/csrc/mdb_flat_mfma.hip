@@ -512,15 +512,19 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
         const float xnh = xnorm[v];
         const float xh = METRIC == MDB_METRIC_L2 ? xnh * (0.5f - kappa) : -kappa * xnh;
         const bool force = !(xnh < __uint_as_float(0x7F800000u));   // infinite / NaN norm: admitted for every query
-        // the admission constants are re-read from LDS for every tile (volatile): hoisted out of the tile loop they would
-        // pin 16 * QB registers next to the accumulators
-        const volatile float* Crv = Cr;
+        // the admission constants are re-read from LDS for every tile, behind a compiler barrier: hoisted out of the tile
+        // loop they would pin 16 * QB registers next to the accumulators.  Rows (r & 3) + 8 (r >> 2) + 4 hi are four runs
+        // of four consecutive floats: four 16-byte LDS reads per query block.
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
+            const float4* c4 = (const float4*)(Cr + qb * 32 + 4 * hi);
+            const float4 t0 = c4[0], t1 = c4[2], t2 = c4[4], t3 = c4[6];   // rows +0..3, +8..11, +16..19, +24..27
+            const float thr[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
             uint32_t hits = 0;   // bit r: row r of this lane's column is a candidate
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                hits |= (acc[qb][r] < xh + Crv[qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]) ? 0u : (1u << r);  // NaN on either side admits
+                hits |= (acc[qb][r] < xh + thr[r]) ? 0u : (1u << r);  // NaN on either side admits
             if (force) hits = 0xFFFFu;
             if (v >= n) hits = 0;
             if (__ballot(hits != 0)) {  // rare: a plain loop over the set bits (unrolled, its 16 * QB row constants get hoisted and spilled)
@@ -653,7 +657,9 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     const bool use_bf16 = aux.bhi.p && aux.split_metric == metric;
     int QB = ((size_t)(ts.d4 + MF_CH) * 4 * 65 * 4 <= 64 * 1024 && b > 32) ? 2 : 1;
     if (use_bf16) {  // query blocks of 32 per thread block: as many as the batch fills and LDS holds (A fragments: QB * nk * 2 KiB)
+        static const int qb_max = getenv("MDB_BF_QB") ? atoi(getenv("MDB_BF_QB")) : 8;
         QB = b > 128 ? 8 : b > 64 ? 4 : b > 32 ? 2 : 1;
+        while (QB > qb_max && QB > 1) QB /= 2;
         while (QB > 1 && ((size_t)QB * aux.nk * 2048 + 32 * QB * 4 + BF_LBUF * 8 + 64 > 150 * 1024 || (b + 32 * QB - 1) / (32 * QB) * (32 * QB) > bpad)) QB /= 2;
     }
     const size_t BQ = 32 * QB, groups = (b + BQ - 1) / BQ, bpadq = groups * BQ;

@@ -1104,6 +1104,578 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     }
 }
 
+// ==========================================================================================
+// hnsw_pipe_kernel — hnsw_beam_kernel's traversal, SOFTWARE-PIPELINED across the block's four waves.
+//
+// In hnsw_beam_kernel a step is a serial chain on wave 0 — visited test (P2) -> barrier -> neighbour gather + distances
+// (P3, ~0.8 us of HBM latency; wave 0 selects the runner-up meanwhile) -> barrier -> accept / push / choose (P4) — and the
+// three other waves idle through P2 and P4.  The reference's algorithm fixes the ORDER of the expansions, not when the
+// distances are computed, and the next node is predictable: it is the beam's runner-up unless a neighbour accepted in this
+// very step beats it (8 % of the steps).  So the waves get roles and talk through LDS mailboxes instead of barriers:
+//   wave 0  COMMIT   the beam (registers, as before): visited test-and-set, acceptance by counting, pushes, the choice of
+//                    the next node.  Every decision of the traversal is taken here, in the reference's order, from exact
+//                    distances — counters and results are those of hnsw_beam_kernel step for step.
+//   wave 1  SELECT   after every step reads the candidate mirror wave 0 keeps in LDS and publishes the two best candidates
+//                    (c1 = the runner-up of the NEXT choice, c2 = the likely node after it) and touches their adjacency
+//                    rows into L2.  This is the 0.7 us selection that used to sit in wave 0's instruction stream.
+//   waves 2,3 SPECULATE  for the node predicted to be expanded after the next one (c2, or the loser of this step's choice):
+//                    read its row, test (never set) the visited bits, gather the unvisited neighbours and store their
+//                    exact distances by ROW POSITION.  The visited set only grows, so when wave 0 reaches that node a
+//                    step or two later every neighbour it finds unvisited has its distance waiting in LDS: the gather has
+//                    left the critical path.  A misprediction (or a spec that is not ready) costs nothing but the old
+//                    latency: wave 0 evaluates the distances itself.
+// Speculative distances that are never consumed are never counted (evals) and never raise MDB_ERR_NAN.
+// Requirements (else hnsw_beam_kernel runs): ef <= 256, d a multiple of 16 (N16T > 0), no PQ rows, row strides <= 64.
+// ==========================================================================================
+#define PIPE_LDS_NB (BEAM_LDS_C + 8192)      // nb_id[64] | nb_od[64]
+#define PIPE_LDS_MIR (PIPE_LDS_NB + 512)     // candidate mirror: {cd, id}[320] (cd = distance image of an unexpanded slot, else EMPTY)
+#define PIPE_LDS_SPEC (PIPE_LDS_MIR + 2560)  // spec_od[2][64]: distance images by row position
+#define PIPE_LDS_MBOX (PIPE_LDS_SPEC + 512)  // 64 mailbox words
+#define PIPE_LDS_QS (PIPE_LDS_MBOX + 256)
+#define PIPE_LDS_DTMP (BEAM_LDS_C + 6144)    // per speculating wave: ids[32] | pos[32] (inside C: unused while the roles run)
+enum {
+    MB_GEN = 0, MB_STOP, MB_ACK, MB_RU_GEN, MB_RU_O, MB_RU_ID, MB_RU_SLOT, MB_RU_VALID, MB_C2_GEN, MB_C2_O, MB_C2_ID, MB_C2_VALID,
+    MB_SREQ, MB_SNODE0, MB_SNODE1, MB_SDONE_A0, MB_SDONE_A1, MB_SDONE_B0, MB_SDONE_B1,
+    MB_SMASK = 20  // [wave 2|3][buf 0|1][lo|hi]: 8 words
+};
+
+__device__ __forceinline__ uint32_t mb_load(const uint32_t* mb, int i) {
+    const uint32_t v = *(const volatile uint32_t*)(mb + i);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void mb_store(uint32_t* mb, int i, uint32_t v) { *(volatile uint32_t*)(mb + i) = v; }
+#define PIPE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#define PIPE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+
+template <int METRIC, bool VIS_LDS, int N16T>
+__global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint64_t* const W = (uint64_t*)lds;
+    uint64_t* const C = (uint64_t*)(lds + BEAM_LDS_C);
+    uint32_t* const nb_id = (uint32_t*)(lds + PIPE_LDS_NB);
+    uint32_t* const nb_od = nb_id + 64;
+    uint64_t* const mir = (uint64_t*)(lds + PIPE_LDS_MIR);      // (id << 32) | cd
+    uint32_t* const spec_od = (uint32_t*)(lds + PIPE_LDS_SPEC);
+    uint32_t* const mb = (uint32_t*)(lds + PIPE_LDS_MBOX);
+    uint32_t* const misc = mb + 40;                              // [1] ep handoff, [2] wsize, [3] overflow, [4..9] closure scratch
+    float* const qs = (float*)(lds + PIPE_LDS_QS);
+    uint32_t* vis = VIS_LDS ? (uint32_t*)(lds + PIPE_LDS_QS + (size_t)a.dpad * 4) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
+    uint32_t* const stage_flag = (uint32_t*)(C + 512);
+
+    const int qi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = tid >> 4, j = tid & 15;
+    const HnswUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
+    if (!u.valid || u.n == 0 || u.num_layers == 0 || u.entry_point >= u.n) {
+        for (int i = tid; i < a.k; i += HNSW_BLOCK) a.out_keys[(size_t)qi * a.k + i] = MDB_KEY_MAX;
+        if (tid == 0) a.out_counts[qi] = 0;
+        return;
+    }
+    for (int i = tid; i < a.dpad; i += HNSW_BLOCK) qs[i] = a.q[(size_t)qi * a.qstride + i];
+    if (VIS_LDS)
+        for (unsigned long long i = tid; i < a.vis_words; i += HNSW_BLOCK) vis[i] = 0;
+    __syncthreads();
+
+    const float* vecs = a.vecs + u.vec_off;
+    const int ef = a.ef;
+    float qr[N16T];
+#pragma unroll
+    for (int c = 0; c < N16T; ++c) qr[c] = qs[16 * c + j];
+#define PIPE_DIST(rowptr) group16_distance_fast<METRIC, N16T>((rowptr), qr, j)
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // ---- wave-0 state (as in hnsw_beam_kernel)
+    uint32_t bd[BREGS], bi[BREGS], cdv[BREGS];
+    int n = 0;
+    uint32_t fbound = SLOT_EMPTY;
+    uint32_t rowv = 0xFFFFFFFFu, rowr = 0xFFFFFFFFu;   // row of the node being expanded / of the runner-up (lane = row position)
+    int ru_slot = 0;
+    uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
+    bool ru_valid = false, ru_have = false, stop = false;
+    uint32_t evals = 0, expanded = 0;
+    bool nan_seen = false, overflow = false;
+    uint32_t ep = u.entry_point;
+    uint32_t spec_hits = 0;
+
+    for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
+        const uint32_t stride = layer == 0 ? u.S0 : u.SU;
+        const uint32_t* const adj_base = a.adj + (layer == 0 ? u.adj0_off : u.adjU_off);
+        // adjacency row of `node` at this layer, lane = row position (stride <= 64); the load stays in flight
+        auto load_row = [&](uint32_t node) -> uint32_t {
+            const uint32_t* row = nullptr;
+            if (layer == 0) {
+                if (node < u.n0) row = adj_base + (size_t)node * stride;
+            } else if (a.level[u.upper_off + node] >= layer) {
+                row = adj_base + ((size_t)a.upper_first[u.upper_off + node] + (layer - 1)) * stride;
+            }
+            return (row && (uint32_t)lane < stride) ? row[lane] : 0xFFFFFFFFu;
+        };
+        if (layer > 0 && layer >= (int)u.small_layer && ef >= 64) {
+            // ---- a layer with no more points than ef: closure of the entry point, whole frontiers per round (all waves)
+            uint32_t* cur = nb_id;
+            uint32_t* nxt = nb_id + 64;
+            unsigned long long* const best = (unsigned long long*)(misc + 8);
+            if (tid == 0) {
+                atomicOr(&vis[ep >> 5], 1u << (ep & 31));
+                cur[0] = ep;
+                misc[4] = 0; misc[5] = 0; misc[6] = 0;
+                *best = MDB_KEY_MAX;
+            }
+            int ncur = 1;
+            __syncthreads();
+            while (ncur > 0) {
+                for (int i = grp; i < ncur; i += HNSW_BLOCK / 16) {
+                    const uint32_t f = cur[i];
+                    const uint32_t* row = nullptr;
+                    if (a.level[u.upper_off + f] >= layer)
+                        row = adj_base + ((size_t)a.upper_first[u.upper_off + f] + (layer - 1)) * stride;
+                    const float d = PIPE_DIST(vecs + (size_t)f * a.dpad);
+                    if (j == 0) {
+                        atomicMin(best, (unsigned long long)make_key(d, f));
+                        if (d != d) atomicOr(a.flags, MDB_FLAG_NAN);
+                        if (row && row[0] != 0xFFFFFFFFu) atomicAdd(&misc[5], 1u);
+                    }
+                    if (row)
+                        for (uint32_t t = j; t < stride; t += 16) {
+                            const uint32_t nbr = row[t];
+                            if (nbr == 0xFFFFFFFFu) break;  // rows are packed
+                            const uint32_t bit = 1u << (nbr & 31);
+                            if (!(atomicOr(&vis[nbr >> 5], bit) & bit)) nxt[atomicAdd(&misc[6], 1u)] = nbr;
+                        }
+                }
+                __syncthreads();
+                const int nn = (int)misc[6];
+                __syncthreads();
+                if (tid == 0) { misc[6] = 0; misc[4] += (uint32_t)ncur; }
+                ncur = nn;
+                uint32_t* tsw = cur; cur = nxt; nxt = tsw;
+            }
+            __syncthreads();
+            ep = key_id((uint64_t)*best);
+            if (wave == 0) { evals += misc[4]; expanded += misc[5]; }
+            __syncthreads();
+            continue;
+        }
+        // ---- layer start: mailboxes, mirror, entry point (index.rs:219-231: visited, distance, seed B, popped at once)
+        if (wave == 0) {
+            if (lane < 40) mb[lane] = lane == MB_SNODE0 || lane == MB_SNODE1 ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int r = 0; r < BREGS; ++r) mir[lane + 64 * r] = (uint64_t)SLOT_EMPTY;
+            if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
+            rowv = load_row(ep);
+            float d0 = 0.0f;
+            if (lane < 16) d0 = PIPE_DIST(vecs + (size_t)ep * a.dpad);
+            d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), 0));
+            if (d0 != d0) nan_seen = true;
+#pragma unroll
+            for (int r = 0; r < BREGS; ++r) { bd[r] = SLOT_EMPTY; bi[r] = 0; cdv[r] = SLOT_EMPTY; }
+            if (lane == 0) { bd[0] = f32_orderable(d0); bi[0] = ep; }
+            n = 1;
+            fbound = SLOT_EMPTY;
+            stop = false;
+            evals += 1;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // =============================================================== COMMIT
+            uint32_t gen = 1, sreq = 0;
+            uint32_t rb0 = 0, rb1 = 0;          // request ids last issued into spec buffers 0 / 1
+            PIPE_RELEASE();
+            if (lane == 0) mb_store(mb, MB_GEN, gen);   // S_1: B = {ep}, no candidates
+            uint32_t xnode = ep;
+            for (;;) {
+                // ---- speculated distances of xnode, if a finished (or nearly finished) spec exists
+                int sb = -1;
+                if (mb_load(mb, MB_SNODE0) == xnode && rb0) sb = 0;
+                else if (mb_load(mb, MB_SNODE1) == xnode && rb1) sb = 1;
+                unsigned long long smask = 0;
+                if (sb >= 0) {
+                    const uint32_t want = sb ? rb1 : rb0;
+                    while (mb_load(mb, sb ? MB_SDONE_A1 : MB_SDONE_A0) != want || mb_load(mb, sb ? MB_SDONE_B1 : MB_SDONE_B0) != want)
+                        __builtin_amdgcn_s_sleep(1);
+                    PIPE_ACQUIRE();
+                    const uint32_t* mw = mb + MB_SMASK + sb * 2;
+                    smask = ((unsigned long long)(mb_load(mw, 1) | mb_load(mw, 5)) << 32) | (mb_load(mw, 0) | mb_load(mw, 4));
+                }
+                // ---- P2: visited test-and-set + ordered compaction of xnode's row (lane = row position)
+                uint32_t nnew = 0;
+                {
+                    const uint32_t nbr = rowv;
+                    const uint32_t sv = sb >= 0 ? spec_od[sb * 64 + lane] : 0u;
+                    bool isnew = false;
+                    if (nbr != 0xFFFFFFFFu) {
+                        const uint32_t bit = 1u << (nbr & 31);
+                        isnew = !(atomicOr(&vis[nbr >> 5], bit) & bit);
+                    }
+                    const unsigned long long bal = __ballot(isnew);
+                    expanded += __ballot(nbr != 0xFFFFFFFFu) != 0 ? 1 : 0;
+                    nnew = (uint32_t)__popcll(bal);
+                    evals += nnew;
+                    if (sb >= 0 && (bal & ~smask)) sb = -1;   // a neighbour the spec did not cover (cannot happen: visited only grows): evaluate here
+                    if (isnew) {
+                        const int kpos = __popcll(bal & lt_mask);
+                        nb_id[kpos] = nbr;
+                        if (sb >= 0) nb_od[kpos] = sv;
+                    }
+                    if (sb >= 0) ++spec_hits;
+                }
+                if (sb < 0 && nnew) {
+                    // ---- miss: this wave's four 16-lane groups evaluate the neighbours themselves (two rows per group and gather)
+                    const int g0 = lane >> 4;
+                    for (uint32_t i = g0; i < nnew; i += 8) {
+                        const bool two = i + 4 < nnew;
+                        const uint32_t i2 = two ? i + 4 : i;
+                        float da, db;
+                        group16_distance_fast2<METRIC, N16T>(vecs + (size_t)nb_id[i] * a.dpad, vecs + (size_t)nb_id[i2] * a.dpad, qr, j, da, db);
+                        if (j == 0) {
+                            nb_od[i] = f32_orderable(da);
+                            if (two) nb_od[i2] = f32_orderable(db);
+                        }
+                    }
+                }
+                // ---- the runner-up of this step's choice (wave 1, from S_gen): start its row load as early as it is known
+                ru_have = false;
+                if (mb_load(mb, MB_RU_GEN) == gen) {
+                    PIPE_ACQUIRE();
+                    ru_valid = mb_load(mb, MB_RU_VALID) != 0;
+                    ru_o = mb_load(mb, MB_RU_O); ru_id = mb_load(mb, MB_RU_ID); ru_slot = (int)mb_load(mb, MB_RU_SLOT);
+                    if (ru_valid) rowr = load_row(ru_id);
+                    ru_have = true;
+                }
+                // ---- P4: accept + push (hnsw_beam_kernel's, with the mirror kept in step), then the choice
+                uint32_t best_o = SLOT_EMPTY, best_id = 0;
+                int best_slot = -1;
+                bool mirror_free = false;   // wave 1 has finished reading S_gen: the mirror may change
+                {
+                    const uint32_t i = lane;
+                    const bool have = i < nnew;
+                    const uint32_t od = have ? nb_od[i] : SLOT_EMPTY;
+                    const uint32_t id = have ? nb_id[i] : 0;
+                    if (__ballot(have && od > 0xFF800000u)) nan_seen = true;   // the image of a NaN distance (the reference panics)
+                    unsigned long long surv = __ballot(have && od < fbound);
+                    unsigned long long accepted = 0;
+                    if (n + (int)nnew <= ef) { accepted = surv; surv = 0; }
+                    while (surv) {
+                        const int sidx = __ffsll((long long)surv) - 1;
+                        surv &= surv - 1;
+                        const uint32_t ds = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                        int cnt = __popcll(__ballot(have && od <= ds) & ((1ull << sidx) - 1ull));
+#pragma unroll
+                        for (int r = 0; r < BREGS; ++r) cnt += __popcll(__ballot(bd[r] <= ds));
+                        if (cnt < ef) accepted |= 1ull << sidx;
+                        else fbound = min(fbound, ds);
+                    }
+                    const int na = __popcll(accepted);
+                    if (na) {
+                        while (mb_load(mb, MB_ACK) != gen) __builtin_amdgcn_s_sleep(1);
+                        mirror_free = true;
+                        if (n + na > BEAM_CAP) {
+                            // ---- compaction (radix select of the ef-th smallest image, drop everything farther)
+                            uint32_t prefix = 0;
+                            int need = ef;
+                            for (int bit = 31; bit >= 0; --bit) {
+                                const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+                                int cnt0 = 0;
+#pragma unroll
+                                for (int r = 0; r < BREGS; ++r)
+                                    cnt0 += __popcll(__ballot((((bd[r] ^ prefix) & hi_mask) == 0u) && !((bd[r] >> bit) & 1u)));
+                                if (cnt0 < need) { need -= cnt0; prefix |= 1u << bit; }
+                            }
+                            const uint32_t f = prefix;
+                            int kept = 0;
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r) {
+                                const bool keep = bd[r] <= f;
+                                const unsigned long long km = __ballot(keep);
+                                if (keep) {
+                                    const int pos = kept + __popcll(km & lt_mask);
+                                    C[pos] = ((uint64_t)bd[r] << 32) | bi[r];
+                                    stage_flag[pos] = cdv[r] != SLOT_EMPTY ? 1u : 0u;
+                                }
+                                kept += __popcll(km);
+                            }
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r) {
+                                const int idx = lane + 64 * r;
+                                const bool in = idx < kept;
+                                const uint64_t kk = in ? C[idx] : 0;
+                                bd[r] = in ? (uint32_t)(kk >> 32) : SLOT_EMPTY;
+                                bi[r] = in ? (uint32_t)kk : 0u;
+                                cdv[r] = (in && stage_flag[idx] != 0u) ? bd[r] : SLOT_EMPTY;
+                                mir[idx] = ((uint64_t)bi[r] << 32) | cdv[r];
+                            }
+                            n = kept;
+                            fbound = min(fbound, f);
+                            if (n + na > BEAM_CAP) overflow = true;
+                            // slots moved: wave 1's runner-up names an old slot; select here (rare)
+                            ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_slot);
+                            if (ru_valid) rowr = load_row(ru_id);
+                            ru_have = true;
+                        }
+                        if (!overflow) {
+                            // ---- push the accepted neighbours into slots n .. n+na-1 (forward lane permute), mirror included
+                            const bool mine = (accepted >> lane) & 1ull;
+                            const int dest = mine ? (n + __popcll(accepted & lt_mask)) & 63 : (n + na) & 63;
+                            const uint32_t rod = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)od);
+                            const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)id);
+                            const int rel = (lane - n) & 63;
+                            const bool got = rel < na;
+                            const int reg = (n + rel) >> 6;
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r) {
+                                const bool w = got && reg == r;
+                                bd[r] = w ? rod : bd[r];
+                                bi[r] = w ? rid : bi[r];
+                                cdv[r] = w ? rod : cdv[r];
+                            }
+                            if (got) mir[n + rel] = ((uint64_t)rid << 32) | rod;
+                            // best accepted neighbour in pop order (smallest distance, largest id)
+                            const uint32_t mo = wave_min_u32(mine ? od : SLOT_EMPTY);
+                            const uint32_t mi = wave_max_u32(mine && od == mo ? id : 0u);
+                            const unsigned long long wm = __ballot(mine && od == mo && id == mi);
+                            best_o = mo;
+                            best_id = mi;
+                            best_slot = n + __popcll(accepted & ((1ull << (__ffsll((long long)wm) - 1)) - 1ull));
+                            n += na;
+                        }
+                    }
+                }
+                if (overflow) { stop = true; }
+                uint32_t pred = 0xFFFFFFFFu;   // node predicted to be expanded after the next one
+                if (!stop) {
+                    if (!ru_have) {
+                        while (mb_load(mb, MB_RU_GEN) != gen) __builtin_amdgcn_s_sleep(1);
+                        PIPE_ACQUIRE();
+                        ru_valid = mb_load(mb, MB_RU_VALID) != 0;
+                        ru_o = mb_load(mb, MB_RU_O); ru_id = mb_load(mb, MB_RU_ID); ru_slot = (int)mb_load(mb, MB_RU_SLOT);
+                        if (ru_valid) rowr = load_row(ru_id);
+                    }
+                    // ---- candidates.pop(): runner-up vs best accepted; stop when it is farther than furthest
+                    const bool take_ru = ru_valid && (best_slot < 0 || ru_o < best_o || (ru_o == best_o && ru_id > best_id));
+                    if (!take_ru && best_slot < 0) {
+                        stop = true;
+                    } else {
+                        const uint32_t m = take_ru ? ru_o : best_o;
+                        int closer = 0;
+                        if (n >= ef) {
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r) closer += __popcll(__ballot(bd[r] < m));
+                        }
+                        if (closer >= ef) {
+                            stop = true;
+                        } else {
+                            if (!mirror_free)
+                                while (mb_load(mb, MB_ACK) != gen) __builtin_amdgcn_s_sleep(1);
+                            const int pslot = take_ru ? ru_slot : best_slot;
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r)
+                                if (lane + 64 * r == pslot) { cdv[r] = SLOT_EMPTY; mir[pslot] = ((uint64_t)bi[r] << 32) | SLOT_EMPTY; }
+                            if (take_ru) {
+                                xnode = ru_id;
+                                rowv = rowr;
+                                if (best_slot >= 0) pred = best_id;                 // the loser of this choice ...
+                            } else {
+                                xnode = best_id;
+                                rowv = load_row(best_id);
+                                if (ru_valid) pred = ru_id;
+                            }
+                            // ... unless wave 1's second candidate of S_gen is nearer (no waiting: a late c2 is simply not used)
+                            if (mb_load(mb, MB_C2_GEN) == gen && mb_load(mb, MB_C2_VALID)) {
+                                const uint32_t c2o = mb_load(mb, MB_C2_O), c2i = mb_load(mb, MB_C2_ID);
+                                const uint32_t lo = take_ru ? best_o : ru_o, li = take_ru ? best_id : ru_id;
+                                if (pred == 0xFFFFFFFFu || c2o < lo || (c2o == lo && c2i > li)) pred = c2i;
+                            }
+                        }
+                    }
+                }
+                if (stop) {
+                    PIPE_RELEASE();
+                    if (lane == 0) mb_store(mb, MB_STOP, 1u);
+                    break;
+                }
+                // ---- publish S_{gen+1}; ask for the speculation of `pred`
+                ++gen;
+                PIPE_RELEASE();
+                if (lane == 0) mb_store(mb, MB_GEN, gen);
+                if (pred != 0xFFFFFFFFu && pred != xnode && mb_load(mb, MB_SNODE0) != pred && mb_load(mb, MB_SNODE1) != pred) {
+                    const int b = (int)((sreq + 1) & 1u);
+                    const uint32_t prev = b ? rb1 : rb0;   // the buffer's previous request must have been served (and consumed or stale)
+                    if (mb_load(mb, b ? MB_SDONE_A1 : MB_SDONE_A0) == prev && mb_load(mb, b ? MB_SDONE_B1 : MB_SDONE_B0) == prev &&
+                        mb_load(mb, b ? MB_SNODE1 : MB_SNODE0) != xnode) {
+                        ++sreq;
+                        if (b) rb1 = sreq; else rb0 = sreq;
+                        if (lane == 0) { mb_store(mb, b ? MB_SNODE1 : MB_SNODE0, pred); }
+                        PIPE_RELEASE();
+                        if (lane == 0) mb_store(mb, MB_SREQ, sreq);
+                    }
+                }
+            }
+        } else if (wave == 1) {
+            // =============================================================== SELECT
+            uint32_t seen = 0;
+            uint32_t cd[BREGS], ci[BREGS];
+            for (;;) {
+                uint32_t g;
+                bool quit = false;
+                for (;;) {
+                    g = mb_load(mb, MB_GEN);
+                    if (g != seen) break;
+                    if (mb_load(mb, MB_STOP)) { quit = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (quit) break;
+                seen = g;
+                PIPE_ACQUIRE();
+#pragma unroll
+                for (int r = 0; r < BREGS; ++r) {
+                    const uint64_t e = *(const volatile uint64_t*)(mir + lane + 64 * r);
+                    cd[r] = (uint32_t)e;
+                    ci[r] = (uint32_t)(e >> 32);
+                }
+                PIPE_RELEASE();
+                if (lane == 0) mb_store(mb, MB_ACK, g);
+                uint32_t o1 = SLOT_EMPTY, id1 = 0;
+                int s1 = 0;
+                const bool v1 = beam_best(cd, ci, lane, o1, id1, s1);
+                if (lane == 0) { mb_store(mb, MB_RU_O, o1); mb_store(mb, MB_RU_ID, id1); mb_store(mb, MB_RU_SLOT, (uint32_t)s1); mb_store(mb, MB_RU_VALID, v1 ? 1u : 0u); }
+                PIPE_RELEASE();
+                if (lane == 0) mb_store(mb, MB_RU_GEN, g);
+                uint32_t touch = 0;
+                if (v1) {
+                    touch ^= load_row(id1);   // into L2 for wave 0 (and the speculating waves)
+#pragma unroll
+                    for (int r = 0; r < BREGS; ++r)
+                        if (lane + 64 * r == s1) cd[r] = SLOT_EMPTY;
+                    uint32_t o2 = SLOT_EMPTY, id2 = 0;
+                    int s2 = 0;
+                    const bool v2 = beam_best(cd, ci, lane, o2, id2, s2);
+                    if (lane == 0) { mb_store(mb, MB_C2_O, o2); mb_store(mb, MB_C2_ID, id2); mb_store(mb, MB_C2_VALID, v2 ? 1u : 0u); }
+                    PIPE_RELEASE();
+                    if (lane == 0) mb_store(mb, MB_C2_GEN, g);
+                    if (v2) touch ^= load_row(id2);
+                } else {
+                    if (lane == 0) mb_store(mb, MB_C2_VALID, 0u);
+                    PIPE_RELEASE();
+                    if (lane == 0) mb_store(mb, MB_C2_GEN, g);
+                }
+                asm volatile("" ::"v"(touch));
+            }
+        } else {
+            // =============================================================== SPECULATE (waves 2, 3)
+            const int half = wave - 2;                       // this wave's row positions: ((pos >> 4) & 1) == half
+            uint32_t* const tid_ = (uint32_t*)(lds + PIPE_LDS_DTMP) + half * 64;   // ids[32] | pos[32]
+            uint32_t next = 1;
+            for (;;) {
+                bool quit = false;
+                for (;;) {
+                    if (mb_load(mb, MB_SREQ) >= next) break;
+                    if (mb_load(mb, MB_STOP)) { quit = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (quit) break;
+                PIPE_ACQUIRE();
+                const int b = (int)(next & 1u);
+                const uint32_t p = mb_load(mb, b ? MB_SNODE1 : MB_SNODE0);
+                const uint32_t nbr = load_row(p);
+                bool isnew = false;
+                if (nbr != 0xFFFFFFFFu && ((lane >> 4) & 1) == half) {
+                    const uint32_t word = *(const volatile uint32_t*)(vis + (nbr >> 5));
+                    isnew = !((word >> (nbr & 31)) & 1u);
+                }
+                const unsigned long long bal = __ballot(isnew);
+                const int cnt = __popcll(bal);
+                if (isnew) {
+                    const int kpos = __popcll(bal & lt_mask);
+                    tid_[kpos] = nbr;
+                    tid_[32 + kpos] = (uint32_t)lane;
+                }
+                const int g0 = lane >> 4;
+                for (int i = g0; i < cnt; i += 8) {
+                    const bool two = i + 4 < cnt;
+                    const int i2 = two ? i + 4 : i;
+                    float da, db;
+                    group16_distance_fast2<METRIC, N16T>(vecs + (size_t)tid_[i] * a.dpad, vecs + (size_t)tid_[i2] * a.dpad, qr, j, da, db);
+                    if (j == 0) {
+                        spec_od[b * 64 + tid_[32 + i]] = f32_orderable(da);
+                        if (two) spec_od[b * 64 + tid_[32 + i2]] = f32_orderable(db);
+                    }
+                }
+                if (lane == 0) {
+                    mb_store(mb, MB_SMASK + half * 4 + b * 2, (uint32_t)bal);
+                    mb_store(mb, MB_SMASK + half * 4 + b * 2 + 1, (uint32_t)(bal >> 32));
+                }
+                PIPE_RELEASE();
+                if (lane == 0) mb_store(mb, half ? (b ? MB_SDONE_B1 : MB_SDONE_B0) : (b ? MB_SDONE_A1 : MB_SDONE_A0), next);
+                ++next;
+            }
+        }
+        __syncthreads();
+        if (layer > 0) {
+            if (wave == 0) {
+                uint32_t m = bd[0];
+#pragma unroll
+                for (int r = 1; r < BREGS; ++r) m = min(m, bd[r]);
+                m = wave_min_u32(m);
+                uint32_t im = 0xFFFFFFFFu;
+#pragma unroll
+                for (int r = 0; r < BREGS; ++r) im = bd[r] == m ? min(im, bi[r]) : im;
+                im = wave_min_u32(im);
+                if (lane == 0) misc[1] = im;
+            }
+            __syncthreads();
+            ep = misc[1];
+            continue;
+        }
+        // ---- layer 0 done: spill B and sort it (block-wide bitonic); W = its ef smallest keys
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < BREGS; ++r)
+                C[lane + 64 * r] = bd[r] == SLOT_EMPTY ? MDB_KEY_MAX : (((uint64_t)bd[r] << 32) | bi[r]);
+            for (int i = BEAM_CAP + lane; i < 512; i += 64) C[i] = MDB_KEY_MAX;
+            if (lane == 0) misc[2] = (uint32_t)(n < ef ? n : ef);
+        }
+        __syncthreads();
+        const int n2 = 512;
+        for (int size = 2; size <= n2; size <<= 1) {
+            for (int st = size >> 1; st > 0; st >>= 1) {
+                for (int t = tid; t < (n2 >> 1); t += HNSW_BLOCK) {
+                    int lo = ((t / st) * st * 2) + (t % st);
+                    int hi = lo + st;
+                    bool up = ((lo & size) == 0);
+                    uint64_t x = C[lo], y = C[hi];
+                    if ((x > y) == up) { C[lo] = y; C[hi] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < a.ef_cap; i += HNSW_BLOCK) W[i] = C[i];
+        __syncthreads();
+    }
+    const HnswArgs* ap = (const HnswArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    const int ws = (int)misc[2];
+    const int kk = ap->k;
+    const int outc = ws < kk ? ws : kk;
+    uint64_t* const okeys = ap->out_keys;
+    for (int i = tid; i < kk; i += HNSW_BLOCK) okeys[(size_t)qi * kk + i] = i < outc ? W[i] : MDB_KEY_MAX;
+    if (tid == 0) {
+        ap->out_counts[qi] = (uint32_t)outc;
+        misc[3] = overflow ? 1u : 0u;
+        if (!overflow) {
+            atomicAdd(&ap->counters[0], (unsigned long long)evals);
+            atomicAdd(&ap->counters[1], (unsigned long long)expanded);
+            atomicAdd(&ap->counters[3], (unsigned long long)spec_hits);   // spare word: steps served by speculated distances
+            if (nan_seen) atomicOr(ap->flags, MDB_FLAG_NAN);
+        }
+    }
+    __syncthreads();
+    if (misc[3]) {
+        const HnswArgs a2 = *ap;
+        hnsw_general_traverse<METRIC, VIS_LDS, N16T>(a2, qi, lds, true);
+    }
+}
+#undef PIPE_DIST
+
 // keys (distance, point id) -> doc ids, order unchanged (ann_search :192-208)
 __global__ void hnsw_remap_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int k,
                                   const HnswUserDev* __restrict__ users, const uint32_t* __restrict__ q_user,
@@ -1392,7 +1964,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     a.k = (int)k;
     a.out_keys = d_keys; a.out_counts = d_counts; a.flags = ctx->d_flags; a.counters = ctx->d_counters;
     size_t lds_base = (size_t)a.ef_cap * 8 + (size_t)a.cand_cap * 8 + (size_t)a.smax * 8 + (size_t)dpad * 4 + 64;
-    if (ef <= 256) lds_base = std::max<size_t>(lds_base, (size_t)BEAM_LDS_QS + (size_t)dpad * 4);  // the beam kernel's fixed layout
+    if (ef <= 256) lds_base = std::max<size_t>(lds_base, (size_t)PIPE_LDS_QS + (size_t)dpad * 4);  // the beam / pipe kernels' fixed layouts
     size_t words = ((size_t)max_n + 31) / 32 + 1;
     bool vis_lds = lds_base + words * 4 <= 160 * 1024 - 256;
     size_t lds = lds_base + (vis_lds ? words * 4 : 0);
@@ -1420,9 +1992,19 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
         hnsw_beam_kernel<METRIC, VL, NF><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                           \
     } while (0)
+#define MDB_PIPE_LAUNCH(METRIC, VL, NF)                                                                                     \
+    do {                                                                                                                    \
+        if (lds > 48 * 1024)                                                                                                \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_pipe_kernel<METRIC, VL, NF>,                                 \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hnsw_pipe_kernel<METRIC, VL, NF><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                           \
+    } while (0)
 #define MDB_HNSW_LAUNCH(METRIC, VL)                                                                              \
     do {                                                                                                           \
-        if (beam) {                                                                                                \
+        if (beam && pipe) {                                                                                        \
+            if (nf == 8) MDB_PIPE_LAUNCH(METRIC, VL, 8);                                                           \
+            else MDB_PIPE_LAUNCH(METRIC, VL, 48);                                                                  \
+        } else if (beam) {                                                                                         \
             if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8);                                                           \
             else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48);                                                    \
             else MDB_BEAM_LAUNCH(METRIC, VL, 0);                                                                   \
@@ -1465,12 +2047,15 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     }
     // ef <= 256: register-resident beam; above: sorted LDS sets (MDB_HNSW_NO_BEAM forces the latter, for tests)
     const bool beam = ef <= 256 && !getenv("MDB_HNSW_NO_BEAM");
+    // software-pipelined traversal (hnsw_pipe_kernel): whole-vector 16-lane chunks, rows of at most 64 edges
+    const bool pipe = beam && (nf == 8 || nf == 48) && max_stride <= 64 && !getenv("MDB_HNSW_NO_PIPE");
     if (metric == MDB_METRIC_L2) {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false);
     } else {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false);
     }
 #undef MDB_BEAM_LAUNCH
+#undef MDB_PIPE_LAUNCH
 #undef MDB_HNSW_LAUNCH4
 #undef MDB_HNSW_LAUNCH
     MDB_HIP(ctx, hipGetLastError());
