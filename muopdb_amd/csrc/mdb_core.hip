@@ -150,8 +150,8 @@ mdb_status mdb_device_open(int gpu, mdb_ctx** out) {
     ctx->device = gpu;
     if (hipSetDevice(gpu) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_flags, 4) != hipSuccess || hipHostMalloc((void**)&ctx->h_flags, 4) != hipSuccess ||
-        hipMemset(ctx->d_flags, 0, 4) != hipSuccess || hipMalloc((void**)&ctx->d_counters, 32) != hipSuccess ||
-        hipHostMalloc((void**)&ctx->h_counters, 32) != hipSuccess || hipMemset(ctx->d_counters, 0, 32) != hipSuccess) {
+        hipMemset(ctx->d_flags, 0, 4) != hipSuccess || hipMalloc((void**)&ctx->d_counters, 128) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_counters, 128) != hipSuccess || hipMemset(ctx->d_counters, 0, 128) != hipSuccess) {
         delete ctx;
         return MDB_ERR_HIP;
     }
@@ -212,8 +212,13 @@ const char* mdb_last_error(mdb_ctx* ctx) { return ctx ? ctx->last_error.c_str() 
 mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out) {
     if (!ctx || !out) return MDB_ERR_INVALID_ARG;
     MDB_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->dev_counters) MDB_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->dev_counters) MDB_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 128, hipMemcpyDeviceToHost, ctx->stream));
     MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->dev_counters && getenv("MDB_HNSW_DBG")) {  // debug words [4..15] of an MDB_PIPE_DBG build (cycles / counts of the pipelined traversal)
+        fprintf(stderr, "[hnsw dbg]");
+        for (int i = 3; i < 16; ++i) fprintf(stderr, " %llu", ctx->h_counters[i]);
+        fprintf(stderr, "\n");
+    }
     if (!ctx->dev_counters) ctx->h_counters[0] = ctx->h_counters[1] = ctx->h_counters[2] = ctx->h_counters[3] = 0;
     mdb_stats st = ctx->stats;
     st.distance_evals = ctx->h_counters[0];

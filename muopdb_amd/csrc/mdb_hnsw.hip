@@ -1135,17 +1135,30 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
 #define PIPE_LDS_DTMP (BEAM_LDS_C + 6144)    // per speculating wave: ids[32] | pos[32] (inside C: unused while the roles run)
 enum {
     MB_GEN = 0, MB_STOP, MB_ACK, MB_RU_GEN, MB_RU_O, MB_RU_ID, MB_RU_SLOT, MB_RU_VALID, MB_C2_GEN, MB_C2_O, MB_C2_ID, MB_C2_VALID,
-    MB_SREQ, MB_SNODE0, MB_SNODE1, MB_SDONE_A0, MB_SDONE_A1, MB_SDONE_B0, MB_SDONE_B1,
-    MB_SMASK = 20  // [wave 2|3][buf 0|1][lo|hi]: 8 words
+    MB_SREQ, MB_SNODE0, MB_SNODE1, MB_SDONE_A0, MB_SDONE_A1, MB_SDONE_B0, MB_SDONE_B1, MB_SRID0, MB_SRID1, MB_XNODE,
+    MB_SMASK = 23  // [wave 2|3][buf 0|1][lo|hi]: 8 words
 };
 
-__device__ __forceinline__ uint32_t mb_load(const uint32_t* mb, int i) {
-    const uint32_t v = *(const volatile uint32_t*)(mb + i);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
+// ONE LDS read returns the whole mailbox (lane i = word i; every word lives in the first 32 lanes' pass, so the snapshot is
+// a single point in time); fields are then picked out of the register with v_readlane — a poll costs one LDS round trip
+// however many words it looks at.
+__device__ __forceinline__ uint32_t mb_snap(const uint32_t* mb, int lane) { return *(const volatile uint32_t*)(mb + (lane & 31)); }
+#define MBW(snap, i) ((uint32_t)__builtin_amdgcn_readlane((int)(snap), (i)))
 __device__ __forceinline__ void mb_store(uint32_t* mb, int i, uint32_t v) { *(volatile uint32_t*)(mb + i) = v; }
-#define PIPE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
-#define PIPE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+#ifdef MDB_PIPE_DBG
+#define PIPE_T0() const unsigned long long _t0 = __builtin_readcyclecounter()
+#define PIPE_ADD(slot) dbg_acc[slot] += __builtin_readcyclecounter() - _t0
+#define PIPE_CNT(slot, v) dbg_acc[slot] += (v)
+#else
+#define PIPE_T0() do {} while (0)
+#define PIPE_ADD(slot) do {} while (0)
+#define PIPE_CNT(slot, v) do {} while (0)
+#endif
+// The LDS operations of one wave are issued and completed in order, so publishing data before a flag (and reading a flag before
+// the data) only needs the COMPILER kept from reordering them; a real fence would also wait for the outstanding global loads —
+// the prefetched adjacency rows.
+#define PIPE_RELEASE() asm volatile("" ::: "memory")
+#define PIPE_ACQUIRE() asm volatile("" ::: "memory")
 
 template <int METRIC, bool VIS_LDS, int N16T>
 __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
@@ -1196,6 +1209,9 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
     bool nan_seen = false, overflow = false;
     uint32_t ep = u.entry_point;
     uint32_t spec_hits = 0;
+#ifdef MDB_PIPE_DBG
+    unsigned long long dbg_acc[12] = {0};   // wave 0: [0] steps [1] misses [2] spec wait [3] ack wait [4] ru wait [5] miss compute [6] loop total [7] spec requests [8] spec skipped (busy)
+#endif
 
     for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
         const uint32_t stride = layer == 0 ? u.S0 : u.SU;
@@ -1278,24 +1294,43 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
         __syncthreads();
         if (wave == 0) {
             // =============================================================== COMMIT
-            uint32_t gen = 1, sreq = 0;
-            uint32_t rb0 = 0, rb1 = 0;          // request ids last issued into spec buffers 0 / 1
+            uint32_t gen = 1;
+            uint32_t xnode = ep;
+            if (lane == 0) mb_store(mb, MB_XNODE, xnode);
             PIPE_RELEASE();
             if (lane == 0) mb_store(mb, MB_GEN, gen);   // S_1: B = {ep}, no candidates
-            uint32_t xnode = ep;
+#ifdef MDB_PIPE_DBG
+            const unsigned long long _tl = __builtin_readcyclecounter();
+#endif
             for (;;) {
+#ifdef MDB_PIPE_DBG
+                unsigned long long _ts = __builtin_readcyclecounter(), _tn;
+#define PIPE_SEG(slot) do { _tn = __builtin_readcyclecounter(); dbg_acc[slot] += _tn - _ts; _ts = _tn; } while (0)
+#else
+#define PIPE_SEG(slot) do {} while (0)
+#endif
                 // ---- speculated distances of xnode, if a finished (or nearly finished) spec exists
                 int sb = -1;
-                if (mb_load(mb, MB_SNODE0) == xnode && rb0) sb = 0;
-                else if (mb_load(mb, MB_SNODE1) == xnode && rb1) sb = 1;
+                uint32_t snap = mb_snap(mb, lane);
+                // (a request id names its buffer by parity; wave 1 issues them: MB_SRID0 / 1 = the id last put into buffer 0 / 1)
+                const uint32_t rb0 = MBW(snap, MB_SRID0), rb1 = MBW(snap, MB_SRID1);
+                if (MBW(snap, MB_SNODE0) == xnode && rb0) sb = 0;
+                else if (MBW(snap, MB_SNODE1) == xnode && rb1) sb = 1;
                 unsigned long long smask = 0;
+                PIPE_CNT(0, 1);
                 if (sb >= 0) {
                     const uint32_t want = sb ? rb1 : rb0;
-                    while (mb_load(mb, sb ? MB_SDONE_A1 : MB_SDONE_A0) != want || mb_load(mb, sb ? MB_SDONE_B1 : MB_SDONE_B0) != want)
+                    PIPE_T0();
+                    while ((sb ? MBW(snap, MB_SDONE_A1) : MBW(snap, MB_SDONE_A0)) != want || (sb ? MBW(snap, MB_SDONE_B1) : MBW(snap, MB_SDONE_B0)) != want) {
                         __builtin_amdgcn_s_sleep(1);
+                        snap = mb_snap(mb, lane);
+                    }
+                    PIPE_ADD(2);
                     PIPE_ACQUIRE();
-                    const uint32_t* mw = mb + MB_SMASK + sb * 2;
-                    smask = ((unsigned long long)(mb_load(mw, 1) | mb_load(mw, 5)) << 32) | (mb_load(mw, 0) | mb_load(mw, 4));
+                    const int mo = MB_SMASK + sb * 2;
+                    smask = sb ? ((unsigned long long)(MBW(snap, MB_SMASK + 3) | MBW(snap, MB_SMASK + 7)) << 32) | (MBW(snap, MB_SMASK + 2) | MBW(snap, MB_SMASK + 6))
+                               : ((unsigned long long)(MBW(snap, MB_SMASK + 1) | MBW(snap, MB_SMASK + 5)) << 32) | (MBW(snap, MB_SMASK + 0) | MBW(snap, MB_SMASK + 4));
+                    (void)mo;
                 }
                 // ---- P2: visited test-and-set + ordered compaction of xnode's row (lane = row position)
                 uint32_t nnew = 0;
@@ -1321,6 +1356,8 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 }
                 if (sb < 0 && nnew) {
                     // ---- miss: this wave's four 16-lane groups evaluate the neighbours themselves (two rows per group and gather)
+                    PIPE_CNT(1, 1);
+                    PIPE_T0();
                     const int g0 = lane >> 4;
                     for (uint32_t i = g0; i < nnew; i += 8) {
                         const bool two = i + 4 < nnew;
@@ -1332,16 +1369,19 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                             if (two) nb_od[i2] = f32_orderable(db);
                         }
                     }
+                    PIPE_ADD(5);
                 }
+                PIPE_SEG(8);
                 // ---- the runner-up of this step's choice (wave 1, from S_gen): start its row load as early as it is known
                 ru_have = false;
-                if (mb_load(mb, MB_RU_GEN) == gen) {
-                    PIPE_ACQUIRE();
-                    ru_valid = mb_load(mb, MB_RU_VALID) != 0;
-                    ru_o = mb_load(mb, MB_RU_O); ru_id = mb_load(mb, MB_RU_ID); ru_slot = (int)mb_load(mb, MB_RU_SLOT);
+                snap = mb_snap(mb, lane);
+                if (MBW(snap, MB_RU_GEN) == gen) {
+                    ru_valid = MBW(snap, MB_RU_VALID) != 0;
+                    ru_o = MBW(snap, MB_RU_O); ru_id = MBW(snap, MB_RU_ID); ru_slot = (int)MBW(snap, MB_RU_SLOT);
                     if (ru_valid) rowr = load_row(ru_id);
                     ru_have = true;
                 }
+                PIPE_SEG(9);
                 // ---- P4: accept + push (hnsw_beam_kernel's, with the mirror kept in step), then the choice
                 uint32_t best_o = SLOT_EMPTY, best_id = 0;
                 int best_slot = -1;
@@ -1367,7 +1407,11 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     }
                     const int na = __popcll(accepted);
                     if (na) {
-                        while (mb_load(mb, MB_ACK) != gen) __builtin_amdgcn_s_sleep(1);
+                        {
+                            PIPE_T0();
+                            while (MBW(snap, MB_ACK) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
+                            PIPE_ADD(3);
+                        }
                         mirror_free = true;
                         if (n + na > BEAM_CAP) {
                             // ---- compaction (radix select of the ef-th smallest image, drop everything farther)
@@ -1441,13 +1485,15 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     }
                 }
                 if (overflow) { stop = true; }
-                uint32_t pred = 0xFFFFFFFFu;   // node predicted to be expanded after the next one
+                PIPE_SEG(10);
                 if (!stop) {
+                    snap = mb_snap(mb, lane);   // the snapshot the choice works from: runner-up, c2, ack, the spec buffers' state
                     if (!ru_have) {
-                        while (mb_load(mb, MB_RU_GEN) != gen) __builtin_amdgcn_s_sleep(1);
-                        PIPE_ACQUIRE();
-                        ru_valid = mb_load(mb, MB_RU_VALID) != 0;
-                        ru_o = mb_load(mb, MB_RU_O); ru_id = mb_load(mb, MB_RU_ID); ru_slot = (int)mb_load(mb, MB_RU_SLOT);
+                        PIPE_T0();
+                        while (MBW(snap, MB_RU_GEN) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
+                        PIPE_ADD(4);
+                        ru_valid = MBW(snap, MB_RU_VALID) != 0;
+                        ru_o = MBW(snap, MB_RU_O); ru_id = MBW(snap, MB_RU_ID); ru_slot = (int)MBW(snap, MB_RU_SLOT);
                         if (ru_valid) rowr = load_row(ru_id);
                     }
                     // ---- candidates.pop(): runner-up vs best accepted; stop when it is farther than furthest
@@ -1465,7 +1511,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                             stop = true;
                         } else {
                             if (!mirror_free)
-                                while (mb_load(mb, MB_ACK) != gen) __builtin_amdgcn_s_sleep(1);
+                                while (MBW(snap, MB_ACK) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
                             const int pslot = take_ru ? ru_slot : best_slot;
 #pragma unroll
                             for (int r = 0; r < BREGS; ++r)
@@ -1473,17 +1519,9 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                             if (take_ru) {
                                 xnode = ru_id;
                                 rowv = rowr;
-                                if (best_slot >= 0) pred = best_id;                 // the loser of this choice ...
                             } else {
                                 xnode = best_id;
                                 rowv = load_row(best_id);
-                                if (ru_valid) pred = ru_id;
-                            }
-                            // ... unless wave 1's second candidate of S_gen is nearer (no waiting: a late c2 is simply not used)
-                            if (mb_load(mb, MB_C2_GEN) == gen && mb_load(mb, MB_C2_VALID)) {
-                                const uint32_t c2o = mb_load(mb, MB_C2_O), c2i = mb_load(mb, MB_C2_ID);
-                                const uint32_t lo = take_ru ? best_o : ru_o, li = take_ru ? best_id : ru_id;
-                                if (pred == 0xFFFFFFFFu || c2o < lo || (c2o == lo && c2i > li)) pred = c2i;
                             }
                         }
                     }
@@ -1491,36 +1529,30 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 if (stop) {
                     PIPE_RELEASE();
                     if (lane == 0) mb_store(mb, MB_STOP, 1u);
+#ifdef MDB_PIPE_DBG
+                    dbg_acc[6] += __builtin_readcyclecounter() - _tl;
+#endif
                     break;
                 }
+                PIPE_SEG(11);
                 // ---- publish S_{gen+1}; ask for the speculation of `pred`
                 ++gen;
+                if (lane == 0) mb_store(mb, MB_XNODE, xnode);
                 PIPE_RELEASE();
                 if (lane == 0) mb_store(mb, MB_GEN, gen);
-                if (pred != 0xFFFFFFFFu && pred != xnode && mb_load(mb, MB_SNODE0) != pred && mb_load(mb, MB_SNODE1) != pred) {
-                    const int b = (int)((sreq + 1) & 1u);
-                    const uint32_t prev = b ? rb1 : rb0;   // the buffer's previous request must have been served (and consumed or stale)
-                    if (mb_load(mb, b ? MB_SDONE_A1 : MB_SDONE_A0) == prev && mb_load(mb, b ? MB_SDONE_B1 : MB_SDONE_B0) == prev &&
-                        mb_load(mb, b ? MB_SNODE1 : MB_SNODE0) != xnode) {
-                        ++sreq;
-                        if (b) rb1 = sreq; else rb0 = sreq;
-                        if (lane == 0) { mb_store(mb, b ? MB_SNODE1 : MB_SNODE0, pred); }
-                        PIPE_RELEASE();
-                        if (lane == 0) mb_store(mb, MB_SREQ, sreq);
-                    }
-                }
             }
         } else if (wave == 1) {
             // =============================================================== SELECT
-            uint32_t seen = 0;
+            uint32_t seen = 0, sreq = 0, rid0 = 0, rid1 = 0;
             uint32_t cd[BREGS], ci[BREGS];
             for (;;) {
                 uint32_t g;
                 bool quit = false;
                 for (;;) {
-                    g = mb_load(mb, MB_GEN);
+                    const uint32_t sn = mb_snap(mb, lane);
+                    g = MBW(sn, MB_GEN);
                     if (g != seen) break;
-                    if (mb_load(mb, MB_STOP)) { quit = true; break; }
+                    if (MBW(sn, MB_STOP)) { quit = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (quit) break;
@@ -1540,25 +1572,21 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 if (lane == 0) { mb_store(mb, MB_RU_O, o1); mb_store(mb, MB_RU_ID, id1); mb_store(mb, MB_RU_SLOT, (uint32_t)s1); mb_store(mb, MB_RU_VALID, v1 ? 1u : 0u); }
                 PIPE_RELEASE();
                 if (lane == 0) mb_store(mb, MB_RU_GEN, g);
-                uint32_t touch = 0;
+                // ---- c1 is also the node most likely expanded after the next one (92 %): have its neighbours' distances
+                // evaluated ahead of time — unless a buffer already holds it, or the buffer whose turn it is is still busy
                 if (v1) {
-                    touch ^= load_row(id1);   // into L2 for wave 0 (and the speculating waves)
-#pragma unroll
-                    for (int r = 0; r < BREGS; ++r)
-                        if (lane + 64 * r == s1) cd[r] = SLOT_EMPTY;
-                    uint32_t o2 = SLOT_EMPTY, id2 = 0;
-                    int s2 = 0;
-                    const bool v2 = beam_best(cd, ci, lane, o2, id2, s2);
-                    if (lane == 0) { mb_store(mb, MB_C2_O, o2); mb_store(mb, MB_C2_ID, id2); mb_store(mb, MB_C2_VALID, v2 ? 1u : 0u); }
-                    PIPE_RELEASE();
-                    if (lane == 0) mb_store(mb, MB_C2_GEN, g);
-                    if (v2) touch ^= load_row(id2);
-                } else {
-                    if (lane == 0) mb_store(mb, MB_C2_VALID, 0u);
-                    PIPE_RELEASE();
-                    if (lane == 0) mb_store(mb, MB_C2_GEN, g);
+                    const uint32_t sn2 = mb_snap(mb, lane);
+                    const int b = (int)((sreq + 1) & 1u);
+                    const uint32_t prev = b ? rid1 : rid0;
+                    if (MBW(sn2, MB_SNODE0) != id1 && MBW(sn2, MB_SNODE1) != id1 && (b ? MBW(sn2, MB_SNODE1) : MBW(sn2, MB_SNODE0)) != MBW(sn2, MB_XNODE) &&
+                        (b ? MBW(sn2, MB_SDONE_A1) : MBW(sn2, MB_SDONE_A0)) == prev && (b ? MBW(sn2, MB_SDONE_B1) : MBW(sn2, MB_SDONE_B0)) == prev) {
+                        ++sreq;
+                        if (b) rid1 = sreq; else rid0 = sreq;
+                        if (lane == 0) { mb_store(mb, b ? MB_SNODE1 : MB_SNODE0, id1); mb_store(mb, b ? MB_SRID1 : MB_SRID0, sreq); }
+                        PIPE_RELEASE();
+                        if (lane == 0) mb_store(mb, MB_SREQ, sreq);
+                    }
                 }
-                asm volatile("" ::"v"(touch));
             }
         } else {
             // =============================================================== SPECULATE (waves 2, 3)
@@ -1567,15 +1595,17 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
             uint32_t next = 1;
             for (;;) {
                 bool quit = false;
+                uint32_t sn;
                 for (;;) {
-                    if (mb_load(mb, MB_SREQ) >= next) break;
-                    if (mb_load(mb, MB_STOP)) { quit = true; break; }
+                    sn = mb_snap(mb, lane);
+                    if (MBW(sn, MB_SREQ) >= next) break;
+                    if (MBW(sn, MB_STOP)) { quit = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (quit) break;
                 PIPE_ACQUIRE();
                 const int b = (int)(next & 1u);
-                const uint32_t p = mb_load(mb, b ? MB_SNODE1 : MB_SNODE0);
+                const uint32_t p = b ? MBW(sn, MB_SNODE1) : MBW(sn, MB_SNODE0);
                 const uint32_t nbr = load_row(p);
                 bool isnew = false;
                 if (nbr != 0xFFFFFFFFu && ((lane >> 4) & 1) == half) {
@@ -1665,6 +1695,9 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
             atomicAdd(&ap->counters[0], (unsigned long long)evals);
             atomicAdd(&ap->counters[1], (unsigned long long)expanded);
             atomicAdd(&ap->counters[3], (unsigned long long)spec_hits);   // spare word: steps served by speculated distances
+#ifdef MDB_PIPE_DBG
+            for (int i = 0; i < 12; ++i) atomicAdd(&ap->counters[4 + i], dbg_acc[i]);
+#endif
             if (nan_seen) atomicOr(ap->flags, MDB_FLAG_NAN);
         }
     }
@@ -2170,7 +2203,7 @@ static mdb_status hnsw_ann_search_impl(mdb_hnsw* h, const float* queries, size_t
     void *keys, *cnts;
     MDB_TRY(mdb_scratch(ctx, 3, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4 + 16, &cnts));
-    MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, ctx->stream));
     ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
     // d*4 B vector + 4 B edge id per distance evaluation, 16 B offsets per expanded node
