@@ -80,7 +80,7 @@ void flat_aux_view(const FlatAux& src, FlatAux& dst) {
     dst.sample.n = src.sample.n; dst.sample.ntiles = src.sample.ntiles; dst.sample.d = src.sample.d; dst.sample.d4 = src.sample.d4;
     dst.ctiles.borrow(src.ctiles);
     dst.mean.borrow(src.mean);
-    dst.bhi.borrow(src.bhi); dst.blo.borrow(src.blo); dst.xnorm.borrow(src.xnorm);
+    dst.bhi.borrow(src.bhi); dst.blo.borrow(src.blo); dst.xnorm.borrow(src.xnorm); dst.rows.borrow(src.rows);
     dst.nk = src.nk; dst.nt32 = src.nt32; dst.split_metric = src.split_metric;
     dst.cooldown = 0;
     if (src.sample.n && !dst.h_ovf && hipHostMalloc((void**)&dst.h_ovf, 4) == hipSuccess) *dst.h_ovf = 0;
@@ -165,7 +165,15 @@ __global__ void bf16_norm_kernel(const float4* __restrict__ tiles, size_t n, siz
     xnorm[v] = s;
 }
 
-mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles, int metric) {
+// tile layout -> row-major rows of d4 float4s
+__global__ void untile_rows_kernel(const float4* __restrict__ tiles, size_t n, int d4, float4* __restrict__ rows) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index in the tile layout: consecutive threads, consecutive vectors
+    const size_t tile = i / ((size_t)d4 * MDB_TILE), r = i % ((size_t)d4 * MDB_TILE);
+    const size_t v = tile * MDB_TILE + (r % MDB_TILE);
+    if (v < n) rows[v * d4 + r / MDB_TILE] = tiles[i];
+}
+
+mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles, int metric, bool want_rows) {
     size_t full = v.n / MDB_TILE;
     if (full < 1024) return MDB_OK;  // < 64K vectors: the exact path is used
     static const size_t div = getenv("MDB_MF_SAMPLE_DIV") ? (size_t)atoi(getenv("MDB_MF_SAMPLE_DIV")) : 32;
@@ -207,6 +215,11 @@ mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t 
                                                                                            (const float4*)aux.mean.p, (float4*)aux.ctiles.p);
     }
     MDB_HIP(ctx, hipGetLastError());
+    if (want_rows) {
+        if (aux.rows.alloc(v.n * (size_t)v.d4 * 4 + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "row-major copy alloc");
+        untile_rows_kernel<<<dim3((unsigned)((all4 + 255) / 256)), 256, 0, ctx->stream>>>((const float4*)v.data, v.n, v.d4, (float4*)aux.rows.p);
+        MDB_HIP(ctx, hipGetLastError());
+    }
     if (!aux.h_ovf) {
         MDB_HIP(ctx, hipHostMalloc((void**)&aux.h_ovf, 4));
         *aux.h_ovf = 0;
@@ -261,6 +274,43 @@ __global__ __launch_bounds__(128) void mfma_prep_kernel(const float* __restrict_
     crow[m] = c;
 }
 
+// ------------------------------------------------------------------------------------------ candidate lists
+// One list of vector ids PER QUERY: qids[m][0 .. qcnt[m]) (qcap slots; qcnt keeps counting past it: a count above qcap is how
+// the refine kernel sees the overflow).  A wave stages its (query, vector) pairs in a private LDS buffer — appended with a
+// ballot prefix, no atomics — and flushes WS_CAP of them at a time: one device-scope atomic per pair, but spread over the
+// batch's counters and issued 4 per lane back to back.  (One list per query GROUP with a block-level staging buffer, the
+// previous layout, serialised on the group's counter once a batch produced millions of pairs — C5's coarse search: 4096
+// queries x 512 candidates — and made every refine block read its whole group's list to find its own query's entries.)
+// Every counter sits on its own 128-byte line: device-scope atomics on one line are served one after the other by its L2
+// channel (~2 ns each — 64 queries' counters packed into one line cost the 1M x 64 workload 40 us for 20k candidates).
+#define WS_CAP 256   // pairs staged per wave (2 KB)
+#define QCNT_STRIDE 32
+__device__ __forceinline__ void ws_flush(uint64_t* __restrict__ wbuf, uint32_t& wcnt, uint32_t* __restrict__ qcnt, uint32_t* __restrict__ qids,
+                                         uint32_t qcap, int lane) {
+    // four pairs per lane, their atomics in flight together
+    uint64_t pr[WS_CAP / 64];
+    uint32_t pos[WS_CAP / 64];
+#pragma unroll
+    for (int x = 0; x < WS_CAP / 64; ++x) {
+        const uint32_t i = lane + 64 * x;
+        pr[x] = i < wcnt ? wbuf[i] : 0;
+        if (i < wcnt) pos[x] = atomicAdd(&qcnt[(size_t)(uint32_t)(pr[x] >> 32) * QCNT_STRIDE], 1u);
+    }
+#pragma unroll
+    for (int x = 0; x < WS_CAP / 64; ++x) {
+        const uint32_t i = lane + 64 * x;
+        if (i < wcnt && pos[x] < qcap) qids[(size_t)(uint32_t)(pr[x] >> 32) * qcap + pos[x]] = (uint32_t)pr[x];
+    }
+    wcnt = 0;
+}
+__device__ __forceinline__ void ws_push(bool has, uint64_t pr, uint64_t* __restrict__ wbuf, uint32_t& wcnt, uint32_t* __restrict__ qcnt,
+                                        uint32_t* __restrict__ qids, uint32_t qcap, int lane) {
+    if (wcnt + 64 > WS_CAP) ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane);
+    const unsigned long long bal = __ballot(has);
+    if (has) wbuf[wcnt + __popcll(bal & ((1ull << lane) - 1ull))] = pr;
+    wcnt += (uint32_t)__popcll(bal);
+}
+
 // ------------------------------------------------------------------------------------------ filter
 // grid (nblk, query groups of BQ = 32*QB); 256 threads: every wave owns whole 64-vector tiles.
 // A operand = queries (row i = lane&31, k = lane>>5) from the LDS copy of the group's centred queries
@@ -272,18 +322,14 @@ __global__ __launch_bounds__(128) void mfma_prep_kernel(const float* __restrict_
 // Loads run one chunk of MF_CH float4s ahead of the matrix cores (register double buffer, also
 // across tile boundaries), so HBM latency hides behind 4*QB*MF_CH MFMAs of 64 cycles.
 #define MF_CH 8
-#define MF_LBUF 2048  // candidate pairs staged per block
-#define MF_RS 8       // refine blocks (pair-list slices) per query
+#define MF_LBUF (4 * WS_CAP)  // candidate pairs staged per block: one WS_CAP buffer per wave
+#define MF_RS 8       // refine blocks (candidate-list slices) per query of a small batch; large batches fill the chip with fewer
 template <int METRIC, int QB>
 __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* __restrict__ tiles, size_t n, size_t ntiles, int d4,
                                                                   const float* __restrict__ dqc, int qstride,
                                                                   const float* __restrict__ crow, float kappa,
-                                                                  uint64_t* __restrict__ pairs_all, uint32_t* __restrict__ npairs_all,
-                                                                  uint32_t pair_cap, size_t b, uint32_t* __restrict__ flags) {
-    // one candidate list per QUERY GROUP (blockIdx.y): the refine blocks of a query read their group's list only
-    // (with one global list a batch of 4096 queries made every refine block wade through all 2 M pairs)
-    uint64_t* __restrict__ pairs = pairs_all + (size_t)blockIdx.y * pair_cap;
-    uint32_t* __restrict__ npairs = npairs_all + (size_t)blockIdx.y * 64;  // own 256-byte line per group
+                                                                  uint32_t* __restrict__ qcnt, uint32_t* __restrict__ qids,
+                                                                  uint32_t qcap, size_t b, uint32_t* __restrict__ flags) {
     constexpr int BQ = 32 * QB, BQP = BQ + 1;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* Qs = (float*)lds;                      // [nch*MF_CH*4][BQP], zero beyond d4*4
@@ -291,11 +337,8 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
     const size_t q0 = (size_t)blockIdx.y * BQ;
     const int nch = (d4 + MF_CH - 1) / MF_CH, dpad = d4 * 4, dlds = nch * MF_CH * 4;
     float* Cr = Qs + (size_t)dlds * BQP;          // [BQ] admission constants of the group
-    // candidate (query, vector) pairs are staged in LDS and appended to the global list with ONE atomic
-    // per block: device-scope atomics on one line serialise (20k of them cost 1 ms here)
-    uint64_t* lbuf = (uint64_t*)(Cr + BQ + (BQ & 1));  // [MF_LBUF]
-    uint32_t* lcnt = (uint32_t*)(lbuf + MF_LBUF);
-    if (tid == 0) lcnt[0] = 0;
+    uint64_t* const wbuf = (uint64_t*)(Cr + BQ + (BQ & 1)) + wave * WS_CAP;  // this wave's staged pairs
+    uint32_t wcnt = 0;
     for (int i = tid; i < BQ * dlds; i += 256) {
         int q = i / dlds, e = i % dlds;
         Qs[e * BQP + q] = e < dpad ? dqc[(q0 + q) * qstride + e] : 0.0f;
@@ -369,18 +412,9 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (v < n && (force || !(acc[h][qb][r] < xh + Cr[row]))) {
-                            size_t m = q0 + row;
-                            if (m < b) {
-                                const uint64_t pr = ((uint64_t)m << 32) | (uint32_t)v;
-                                uint32_t pos = atomicAdd(lcnt, 1u);
-                                if (pos < MF_LBUF) lbuf[pos] = pr;
-                                else if (__builtin_nontemporal_load(npairs) <= pair_cap) {  // staging full: slow direct append
-                                    uint32_t g = atomicAdd(npairs, 1u);
-                                    if (g < pair_cap) pairs[g] = pr;
-                                }
-                            }
-                        }
+                        const size_t m = q0 + row;
+                        const bool has = v < n && m < b && (force || !(acc[h][qb][r] < xh + Cr[row]));
+                        ws_push(has, ((uint64_t)m << 32) | (uint32_t)v, wbuf, wcnt, qcnt, qids, qcap, lane);
                     }
                 }
             }
@@ -413,15 +447,7 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
         step(buf1, buf0);
     }
     if (nan_seen) atomicOr(flags, MDB_FLAG_NAN);
-    __syncthreads();
-    const uint32_t ln = min(lcnt[0], (uint32_t)MF_LBUF);
-    if (ln) {
-        if (tid == 0) lcnt[1] = atomicAdd(npairs, ln);
-        __syncthreads();
-        const uint32_t base = lcnt[1];
-        for (uint32_t i = tid; i < ln; i += 256)
-            if (base + i < pair_cap) pairs[base + i] = lbuf[i];
-    }
+    ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane);
 }
 
 // ------------------------------------------------------------------------------------------ bf16 x 3 filter
@@ -434,25 +460,22 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
 // stays a NECESSARY condition for membership in the top-k: a true neighbour is never dropped (NaN / inf still admit).
 // A fragments (queries, 32 rows x 16 dims per MFMA) live in LDS, converted once per block; B fragments stream from the
 // precomputed split (coalesced 16-byte loads, one k-chunk ahead of the matrix cores).  grid (nblk, query groups of 32 * QB).
-#define BF_LBUF 1024   // candidate pairs staged per block (8 KB: two QB = 4 blocks fit one CU's LDS)
+#define BF_LBUF (4 * WS_CAP)   // candidate pairs staged per block (8 KB: two QB = 4 blocks fit one CU's LDS)
 template <int METRIC, int QB, int NKT>   // NKT: compile-time number of 16-dim chunks (8 = d <= 128: LDS offsets become immediates), 0 = run time
 __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kernel(
     const uint4* __restrict__ bhi, const uint4* __restrict__ blo, const float* __restrict__ xnorm, size_t n, size_t nt32, int nk_rt,
-    const float* __restrict__ dqc, int qstride, const float* __restrict__ crow, float kappa, uint64_t* __restrict__ pairs_all,
-    uint32_t* __restrict__ npairs_all, uint32_t pair_cap, size_t b, uint32_t* __restrict__ flags) {
-    uint64_t* __restrict__ pairs = pairs_all + (size_t)blockIdx.y * pair_cap;
-    uint32_t* __restrict__ npairs = npairs_all + (size_t)blockIdx.y * 64;
+    const float* __restrict__ dqc, int qstride, const float* __restrict__ crow, float kappa, uint32_t* __restrict__ qcnt,
+    uint32_t* __restrict__ qids, uint32_t qcap, size_t b, uint32_t* __restrict__ flags) {
     constexpr int BQ = 32 * QB;
     const int nk = NKT ? NKT : nk_rt;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint4* Ahi = (uint4*)lds;                         // [QB][nk][64]
     uint4* Alo = Ahi + (size_t)QB * nk * 64;
     float* Cr = (float*)(Alo + (size_t)QB * nk * 64); // [BQ]
-    uint64_t* lbuf = (uint64_t*)(Cr + BQ);            // [BF_LBUF]
-    uint32_t* lcnt = (uint32_t*)(lbuf + BF_LBUF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    uint64_t* const wbuf = (uint64_t*)(Cr + BQ) + wave * WS_CAP;   // this wave's staged pairs
+    uint32_t wcnt = 0;
     const size_t q0 = (size_t)blockIdx.y * BQ;
-    if (tid == 0) lcnt[0] = 0;
     for (int i = tid; i < QB * nk * 64; i += 256) {
         const int l = i & 63, kc = (i >> 6) % nk, qb = (i >> 6) / nk;
         const float* src = dqc + (q0 + qb * 32 + (l & 31)) * (size_t)qstride + kc * 16 + 8 * (l >> 5);
@@ -468,48 +491,43 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
     __syncthreads();
     const size_t tstep = (size_t)gridDim.x * 4;
     f32x16 acc[QB];
-    uint4 ch, cl, nh, nl;   // current / next B fragments
     size_t t = (size_t)blockIdx.x * 4 + wave;
-    if (t < nt32) { ch = bhi[(t * nk) * 64 + lane]; cl = blo[(t * nk) * 64 + lane]; }
-    while (t < nt32) {
+    // B fragments stream one k-chunk ahead of the matrix cores (a whole tile ahead was measured: no faster on an L2-resident
+    // base, slower on an HBM-resident one — 128 more registers halve the occupancy)
+    uint4 ch, cl, nh, nl;   // current / next fragment pair
+    if (t < nt32) {
+        ch = bhi[(t * nk) * 64 + lane];
+        cl = blo[(t * nk) * 64 + lane];
+    }
+    auto mma_chunk = [&](const uint4& xh_, const uint4& xl_, int kc) {
+        // the A fragments are loop invariant: without the barrier the compiler hoists all QB * nk * 2 LDS loads out of the tile
+        // loop and spills (512 registers at QB = 8); they are re-read per chunk instead (2 QB ds_read_b128 per 3 QB MFMAs)
+        asm volatile("" ::: "memory");
+        const bf16x8 vbh = __builtin_bit_cast(bf16x8, xh_), vbl = __builtin_bit_cast(bf16x8, xl_);
+        // three passes over the query blocks: consecutive MFMAs hit different accumulators (no dependent issue stalls)
+        bf16x8 vah[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            vah[qb] = __builtin_bit_cast(bf16x8, Ahi[((size_t)qb * nk + kc) * 64 + lane]);
+            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah[qb], vbh, acc[qb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah[qb], vbl, acc[qb], 0, 0, 0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const bf16x8 val = __builtin_bit_cast(bf16x8, Alo[((size_t)qb * nk + kc) * 64 + lane]);
+            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, vbh, acc[qb], 0, 0, 0);
+        }
+    };
+    auto zero_acc = [&]() {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[qb][r] = 0.0f;
-        const size_t tn = t + tstep;
-        for (int kc = 0; kc < nk; ++kc) {
-            // prefetch the next fragment pair (the next tile's first when this is the last chunk)
-            const bool last = kc + 1 == nk;
-            const size_t pt = last ? (tn < nt32 ? tn : t) : t;
-            const size_t po = (pt * nk + (last ? 0 : kc + 1)) * 64 + lane;
-            nh = bhi[po];
-            nl = blo[po];
-            // the A fragments are loop invariant: without this the compiler hoists all QB * nk * 2 LDS loads out of the tile
-            // loop and spills (512 registers at QB = 8); they are re-read per chunk instead (2 QB ds_read_b128 per 3 QB MFMAs)
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 vbh = __builtin_bit_cast(bf16x8, ch), vbl = __builtin_bit_cast(bf16x8, cl);
-            // three passes over the query blocks: consecutive MFMAs hit different accumulators (no dependent issue stalls)
-            bf16x8 vah[QB];
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                vah[qb] = __builtin_bit_cast(bf16x8, Ahi[((size_t)qb * nk + kc) * 64 + lane]);
-                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah[qb], vbh, acc[qb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah[qb], vbl, acc[qb], 0, 0, 0);
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const bf16x8 val = __builtin_bit_cast(bf16x8, Alo[((size_t)qb * nk + kc) * 64 + lane]);
-                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, vbh, acc[qb], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            ch = nh;
-            cl = nl;
-        }
+    };
+    auto epilogue = [&](size_t t, float xnh) {
         // epilogue: D[i][j], column j = lane & 31 (vector), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query)
         const size_t v = t * 32 + l31;
-        const float xnh = xnorm[v];
         const float xh = METRIC == MDB_METRIC_L2 ? xnh * (0.5f - kappa) : -kappa * xnh;
         const bool force = !(xnh < __uint_as_float(0x7F800000u));   // infinite / NaN norm: admitted for every query
         // the admission constants are re-read from LDS for every tile, behind a compiler barrier: hoisted out of the tile
@@ -527,83 +545,62 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
                 hits |= (acc[qb][r] < xh + thr[r]) ? 0u : (1u << r);  // NaN on either side admits
             if (force) hits = 0xFFFFu;
             if (v >= n) hits = 0;
-            if (__ballot(hits != 0)) {  // rare: a plain loop over the set bits (unrolled, its 16 * QB row constants get hoisted and spilled)
-                while (hits) {
-                    const int r = __ffs((int)hits) - 1;
-                    hits &= hits - 1;
-                    const size_t m = q0 + (size_t)(qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
-                    if (m < b) {
-                        const uint64_t pr = ((uint64_t)m << 32) | (uint32_t)v;
-                        const uint32_t pos = atomicAdd(lcnt, 1u);
-                        if (pos < BF_LBUF) lbuf[pos] = pr;
-                        else if (__builtin_nontemporal_load(npairs) <= pair_cap) {  // staging full: slow direct append
-                            const uint32_t g = atomicAdd(npairs, 1u);
-                            if (g < pair_cap) pairs[g] = pr;
-                        }
-                    }
-                }
+            // rare: a wave-uniform loop, every lane's lowest set bit per round (unrolled over r, the 16 * QB row constants get
+            // hoisted and spilled)
+            if (__builtin_expect(__ballot(hits != 0) != 0, 0))
+            while (__ballot(hits != 0)) {
+                const bool has = hits != 0;
+                const int r = has ? __ffs((int)hits) - 1 : 0;
+                hits &= hits - 1;
+                const size_t m = q0 + (size_t)(qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                ws_push(has && m < b, ((uint64_t)m << 32) | (uint32_t)v, wbuf, wcnt, qcnt, qids, qcap, lane);
             }
         }
+    };
+    while (t < nt32) {
+        zero_acc();
+        const size_t tn = t + tstep;
+        const float xnt = xnorm[t * 32 + l31];   // issued ahead of the tile's prefetches: vmcnt counts in order
+        for (int kc = 0; kc < nk; ++kc) {
+            // prefetch the next fragment pair (the next tile's first when this is the last chunk)
+            const bool last = kc + 1 == nk;
+            const size_t pt = last ? (tn < nt32 ? tn : t) : t;
+            const size_t po = (pt * nk + (last ? 0 : kc + 1)) * 64 + lane;
+            nh = bhi[po];
+            nl = blo[po];
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk(ch, cl, kc);
+            __builtin_amdgcn_sched_barrier(0);
+            ch = nh;
+            cl = nl;
+        }
+        epilogue(t, xnt);
         t = tn;
     }
-    __syncthreads();
-    const uint32_t ln = min(lcnt[0], (uint32_t)BF_LBUF);
-    if (ln) {
-        if (tid == 0) lcnt[1] = atomicAdd(npairs, ln);
-        __syncthreads();
-        const uint32_t base = lcnt[1];
-        for (uint32_t i = tid; i < ln; i += 256)
-            if (base + i < pair_cap) pairs[base + i] = lbuf[i];
-    }
+    ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane);
 }
 
 // ------------------------------------------------------------------------------------------ refine
-// MF_RS blocks per query, each over its slice of the pair list: collect the query's vectors (LDS), then
-// their exact distances and a partial top-k (merged by merge_keys).  A list longer than its capacity
-// raises `ovf` instead (-> gated exact scan of the batch).
-template <int METRIC>
+// MF_RS blocks per query, each over its slice of the query's candidate list: exact distances and a partial top-k (merged
+// by merge_keys).  A list longer than its capacity raises `ovf` instead (-> gated exact scan of the batch).
+template <int METRIC, bool ROWS>   // ROWS: `tiles` is the row-major copy (FlatAux::rows)
 __global__ __launch_bounds__(MDB_BLOCK) void flat_refine_kernel(const float4* __restrict__ tiles, DistPlan p,
                                                                 const float* __restrict__ dq, int qstride,
-                                                                const uint64_t* __restrict__ pairs_all, const uint32_t* __restrict__ npairs_all,
-                                                                uint32_t pair_cap, int group_queries, int k, uint64_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ qcnt, const uint32_t* __restrict__ qids,
+                                                                uint32_t qcap, int k, uint64_t* __restrict__ keys,
                                                                 uint32_t* __restrict__ ovf, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const size_t m = blockIdx.y;
-    const size_t grp = m / (size_t)group_queries;  // the filter's query group of this query
-    const uint64_t* __restrict__ pairs = pairs_all + grp * pair_cap;
-    const uint32_t np = npairs_all[grp * 64];
-    if (np > pair_cap) {
-        if (threadIdx.x == 0 && m == 0 && blockIdx.x == 0) atomicAdd(ovf, 1u);
+    const uint32_t np = qcnt[m * QCNT_STRIDE];
+    if (np > qcap) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(ovf, 1u);
         return;
     }
-    const uint32_t lo = (uint32_t)((uint64_t)np * blockIdx.x / gridDim.x), hi = (uint32_t)((uint64_t)np * (blockIdx.x + 1) / gridDim.x);
+    const uint32_t lo = (uint32_t)((uint64_t)np * blockIdx.x / gridDim.x), c = (uint32_t)((uint64_t)np * (blockIdx.x + 1) / gridDim.x) - lo;
+    const uint32_t* __restrict__ mine = qids + m * (size_t)qcap + lo;
     BlockSelect<MDB_BLOCK> sel;
     sel.init(lds, k);
-    uint32_t* mine = (uint32_t*)(lds + ((BlockSelect<MDB_BLOCK>::lds_bytes(k) + 15) & ~(size_t)15));  // [MF_CAP]
-    uint32_t* mcnt = mine + MF_CAP;
-    if (threadIdx.x == 0) *mcnt = 0;
     __syncthreads();
-    for (uint32_t i0 = lo; i0 < hi; i0 += MDB_BLOCK * 8) {  // 8 independent loads in flight per thread
-        uint64_t pr[8];
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            uint32_t i = i0 + x * MDB_BLOCK + threadIdx.x;
-            pr[x] = i < hi ? pairs[i] : ~0ull;
-        }
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            if ((uint32_t)(pr[x] >> 32) == (uint32_t)m) {
-                uint32_t pos = atomicAdd(mcnt, 1u);
-                if (pos < MF_CAP) mine[pos] = (uint32_t)pr[x];
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t c = *mcnt;
-    if (c > MF_CAP) {
-        if (threadIdx.x == 0) atomicAdd(ovf, 1u);
-        return;
-    }
     const float* qb = dq + m * qstride;
     bool nan_seen = false, first = true;
     for (uint32_t base = 0; base < c; base += MDB_BLOCK) {
@@ -611,9 +608,14 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_refine_kernel(const float4* __
         uint64_t key = MDB_KEY_MAX;
         if (i < c) {
             uint32_t v = mine[i];
-            TileLoader ld{tiles + (size_t)(v / MDB_TILE) * p.d4 * MDB_TILE + (v % MDB_TILE)};
             float raw[1];
-            exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
+            if (ROWS) {
+                Row4Loader ld{tiles + (size_t)v * p.d4};
+                exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
+            } else {
+                TileLoader ld{tiles + (size_t)(v / MDB_TILE) * p.d4 * MDB_TILE + (v % MDB_TILE)};
+                exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
+            }
             float dist = finish_distance<METRIC>(raw[0]);
             if (dist != dist) nan_seen = true;
             key = make_key(dist, v);
@@ -657,7 +659,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     const bool use_bf16 = aux.bhi.p && aux.split_metric == metric;
     int QB = ((size_t)(ts.d4 + MF_CH) * 4 * 65 * 4 <= 64 * 1024 && b > 32) ? 2 : 1;
     if (use_bf16) {  // query blocks of 32 per thread block: as many as the batch fills and LDS holds (A fragments: QB * nk * 2 KiB)
-        static const int qb_max = getenv("MDB_BF_QB") ? atoi(getenv("MDB_BF_QB")) : 8;
+        static const int qb_max = getenv("MDB_BF_QB") ? atoi(getenv("MDB_BF_QB")) : 4;   // 8 (one block per CU) measured slower than 4
         QB = b > 128 ? 8 : b > 64 ? 4 : b > 32 ? 2 : 1;
         while (QB > qb_max && QB > 1) QB /= 2;
         while (QB > 1 && ((size_t)QB * aux.nk * 2048 + 32 * QB * 4 + BF_LBUF * 8 + 64 > 150 * 1024 || (b + 32 * QB - 1) / (32 * QB) * (32 * QB) > bpad)) QB /= 2;
@@ -666,19 +668,19 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     if (bpadq > bpad) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "internal: queries staged with %zu rows, filter needs %zu", bpad, bpadq);
     char* ax;
     size_t off_sc = align_up(b * k * 8, 16), off_cr = off_sc + align_up(b * 4, 16), off_np = off_cr + align_up(bpadq * 4, 256),
-           off_ov = off_np + groups * 256, off_qc = off_ov + 256;
+           off_ov = off_np + bpadq * (size_t)QCNT_STRIDE * 4, off_qc = off_ov + 256;
     MDB_TRY(mdb_scratch(ctx, 8, off_qc + bpadq * (size_t)qstride * 4, (void**)&ax));
     uint64_t* skeys = (uint64_t*)ax;
     uint32_t* scounts = (uint32_t*)(ax + off_sc);
     float* crow = (float*)(ax + off_cr);
-    uint32_t* npairs = (uint32_t*)(ax + off_np);  // own 256-byte lines: these two words take device-scope atomics
-    uint32_t* ovf = (uint32_t*)(ax + off_ov);
+    uint32_t* qcnt = (uint32_t*)(ax + off_np);    // per-query candidate counts (device-scope atomics)
+    uint32_t* ovf = (uint32_t*)(ax + off_ov);     // own 256-byte line
     float* dqc = (float*)(ax + off_qc);
-    // candidate lists: one per query group, ~1024 slots per query (bounded to 1 GiB in total)
-    uint32_t pair_cap = (uint32_t)(BQ * 1024);
-    while (pair_cap > 4096 && groups * (size_t)pair_cap * 8 > ((size_t)1 << 30)) pair_cap /= 2;
-    uint64_t* pairs;
-    MDB_TRY(mdb_scratch(ctx, 9, groups * (size_t)pair_cap * 8, (void**)&pairs));
+    // candidate lists: one per query, MF_CAP ids (fewer when the batch is so large that they would pass 1 GiB in total)
+    uint32_t qcap = MF_CAP;
+    while (qcap > 512 && bpadq * (size_t)qcap * 4 > ((size_t)1 << 30)) qcap /= 2;
+    uint32_t* qids;
+    MDB_TRY(mdb_scratch(ctx, 9, bpadq * (size_t)qcap * 4, (void**)&qids));
     // A. sample top-k (exact)
     MDB_TRY(flat_topk_keys(ctx, view_of(aux.sample), metric, dq, qstride, b, k, skeys, scounts, false));
     // error budget of the filter, eps = 2^-24, all norms of the centred operands:
@@ -690,7 +692,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     //   bf16 x 3 split (flat_bf16_filter_kernel): dropped cross terms 3 * 2^-18 and 3d f32 accumulations -> + 4 d eps + 2^-16
     const float kappa = 6.0f * (float)(ts.d4 * 4 + 4) * 5.9604645e-8f +
                         (use_bf16 ? 4.0f * (float)(aux.nk * 16) * 5.9604645e-8f + 1.52587890625e-5f : 0.0f);
-    MDB_HIP(ctx, hipMemsetAsync(npairs, 0, groups * 256 + 256, ctx->stream));  // the groups' counters and ovf
+    MDB_HIP(ctx, hipMemsetAsync(qcnt, 0, bpadq * (size_t)QCNT_STRIDE * 4 + 256, ctx->stream));  // the queries' counters and ovf
     mfma_prep_kernel<<<dim3((unsigned)bpadq), 128, 0, ctx->stream>>>(dq, qstride, ts.d, aux.mean.p, skeys, scounts, (int)k, kappa,
                                                                     metric, b, dqc, crow);
     // B. filter on the centred copy (L2) / the base itself (dot)
@@ -711,8 +713,8 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_bf16_filter_kernel<METRIC, QBT, NKT>,                 \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));               \
         flat_bf16_filter_kernel<METRIC, QBT, NKT><<<gridb, 256, ldsb, ctx->stream>>>(aux.bhi.p, aux.blo.p, aux.xnorm.p, ts.n, aux.nt32,    \
-                                                                                     aux.nk, dqc, qstride, crow, kappa, pairs, npairs,    \
-                                                                                     pair_cap, b, ctx->d_flags);                          \
+                                                                                     aux.nk, dqc, qstride, crow, kappa, qcnt, qids,       \
+                                                                                     qcap, b, ctx->d_flags);                              \
     } while (0)
 #define BF_QB(METRIC, NKT)                                             \
     do {                                                               \
@@ -736,7 +738,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_mfma_filter_kernel<METRIC, QBT>,                      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
         flat_mfma_filter_kernel<METRIC, QBT><<<grid, 256, lds, ctx->stream>>>(ftiles, ts.n, ts.ntiles, ts.d4, dqc, qstride, crow,    \
-                                                                              kappa, pairs, npairs, pair_cap, b, ctx->d_flags);                    \
+                                                                              kappa, qcnt, qids, qcap, b, ctx->d_flags);                           \
     } while (0)
         if (metric == MDB_METRIC_L2) { if (QB == 2) MF_LAUNCH(MDB_METRIC_L2, 2); else MF_LAUNCH(MDB_METRIC_L2, 1); }
         else { if (QB == 2) MF_LAUNCH(MDB_METRIC_DOT, 2); else MF_LAUNCH(MDB_METRIC_DOT, 1); }
@@ -746,25 +748,28 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     }
     // C. refine
     DistPlan p = make_plan(ts.d, metric);
-    size_t sel_lds = ((BlockSelect<MDB_BLOCK>::lds_bytes((int)k) + 15) & ~(size_t)15) + MF_CAP * 4 + 16;
+    size_t sel_lds = ((BlockSelect<MDB_BLOCK>::lds_bytes((int)k) + 15) & ~(size_t)15) + 16;
     uint64_t* rpart;
-    MDB_TRY(mdb_scratch(ctx, 10, b * (size_t)MF_RS * std::max<size_t>(k, 1) * 8, (void**)&rpart));
-    MDB_HIP(ctx, hipMemsetAsync(rpart, 0xFF, b * (size_t)MF_RS * k * 8, ctx->stream));  // a slice that bails out leaves KEY_MAX
-    if (metric == MDB_METRIC_L2)
-        flat_refine_kernel<MDB_METRIC_L2><<<dim3(MF_RS, (unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(
-            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)BQ, (int)k, rpart, ovf, ctx->d_flags);
-    else
-        flat_refine_kernel<MDB_METRIC_DOT><<<dim3(MF_RS, (unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(
-            (const float4*)ts.data, p, dq, qstride, pairs, npairs, pair_cap, (int)BQ, (int)k, rpart, ovf, ctx->d_flags);
+    const unsigned rs = MF_RS;   // (fewer, larger slices for large batches were measured: 2.5x slower — a block's rounds are latency bound)
+    MDB_TRY(mdb_scratch(ctx, 10, b * (size_t)rs * std::max<size_t>(k, 1) * 8, (void**)&rpart));
+    MDB_HIP(ctx, hipMemsetAsync(rpart, 0xFF, b * (size_t)rs * k * 8, ctx->stream));  // a slice that bails out leaves KEY_MAX
+    const bool rows = aux.rows.p != nullptr;
+    const float4* rsrc = rows ? (const float4*)aux.rows.p : (const float4*)ts.data;
+#define RF_LAUNCH(METRIC, ROWS)                                                                                                \
+    flat_refine_kernel<METRIC, ROWS><<<dim3(rs, (unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(rsrc, p, dq, qstride, qcnt, qids, qcap, \
+                                                                                                  (int)k, rpart, ovf, ctx->d_flags)
+    if (metric == MDB_METRIC_L2) { if (rows) RF_LAUNCH(MDB_METRIC_L2, true); else RF_LAUNCH(MDB_METRIC_L2, false); }
+    else { if (rows) RF_LAUNCH(MDB_METRIC_DOT, true); else RF_LAUNCH(MDB_METRIC_DOT, false); }
+#undef RF_LAUNCH
     MDB_HIP(ctx, hipGetLastError());
-    MDB_TRY(merge_keys(ctx, rpart, (size_t)MF_RS * k, b, k, d_keys, d_counts));
+    MDB_TRY(merge_keys(ctx, rpart, (size_t)rs * k, b, k, d_keys, d_counts));
     if (getenv("MDB_MF_DBG")) {
         uint32_t hn = 0, ho = 0;
-        std::vector<uint32_t> hcnt(groups * 64);
-        MDB_HIP(ctx, hipMemcpyAsync(hcnt.data(), npairs, groups * 256, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<uint32_t> hcnt(b * QCNT_STRIDE);
+        MDB_HIP(ctx, hipMemcpyAsync(hcnt.data(), qcnt, b * (size_t)QCNT_STRIDE * 4, hipMemcpyDeviceToHost, ctx->stream));
         MDB_HIP(ctx, hipMemcpyAsync(&ho, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
         MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t gi = 0; gi < groups; ++gi) hn += hcnt[gi * 64];
+        for (size_t gi = 0; gi < b; ++gi) hn += hcnt[gi * QCNT_STRIDE];
         fprintf(stderr, "[mf] b=%zu QB=%d candidate pairs %u (%.1f per query) overflowed %u\n", b, QB, hn, (double)hn / b, ho);
     }
     // D. gated exact scan of the batch: both launches return at once unless a list overflowed

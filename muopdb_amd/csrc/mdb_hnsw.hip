@@ -1105,38 +1105,42 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
 }
 
 // ==========================================================================================
-// hnsw_pipe_kernel — hnsw_beam_kernel's traversal, SOFTWARE-PIPELINED across the block's four waves.
+// hnsw_pipe_kernel — hnsw_beam_kernel's traversal, SOFTWARE-PIPELINED across six waves with roles.
 //
 // In hnsw_beam_kernel a step is a serial chain on wave 0 — visited test (P2) -> barrier -> neighbour gather + distances
-// (P3, ~0.8 us of HBM latency; wave 0 selects the runner-up meanwhile) -> barrier -> accept / push / choose (P4) — and the
-// three other waves idle through P2 and P4.  The reference's algorithm fixes the ORDER of the expansions, not when the
-// distances are computed, and the next node is predictable: it is the beam's runner-up unless a neighbour accepted in this
-// very step beats it (8 % of the steps).  So the waves get roles and talk through LDS mailboxes instead of barriers:
-//   wave 0  COMMIT   the beam (registers, as before): visited test-and-set, acceptance by counting, pushes, the choice of
-//                    the next node.  Every decision of the traversal is taken here, in the reference's order, from exact
-//                    distances — counters and results are those of hnsw_beam_kernel step for step.
-//   wave 1  SELECT   after every step reads the candidate mirror wave 0 keeps in LDS and publishes the two best candidates
-//                    (c1 = the runner-up of the NEXT choice, c2 = the likely node after it) and touches their adjacency
-//                    rows into L2.  This is the 0.7 us selection that used to sit in wave 0's instruction stream.
-//   waves 2,3 SPECULATE  for the node predicted to be expanded after the next one (c2, or the loser of this step's choice):
-//                    read its row, test (never set) the visited bits, gather the unvisited neighbours and store their
-//                    exact distances by ROW POSITION.  The visited set only grows, so when wave 0 reaches that node a
-//                    step or two later every neighbour it finds unvisited has its distance waiting in LDS: the gather has
-//                    left the critical path.  A misprediction (or a spec that is not ready) costs nothing but the old
-//                    latency: wave 0 evaluates the distances itself.
-// Speculative distances that are never consumed are never counted (evals) and never raise MDB_ERR_NAN.
+// (P3, ~0.8 us of HBM latency; wave 0 selects the runner-up meanwhile) -> barrier -> accept / push / choose (P4) — and a lone
+// wave pays 10-15 cycles per dependent instruction, so the ~450 instructions of a step ARE its 1.8 us.  The reference's
+// algorithm fixes the ORDER of the expansions and what every test sees, not which wave evaluates what or when, and the next
+// node is predictable: it is the beam's runner-up unless a neighbour accepted in this very step beats it (8 % of the steps).
+// So the waves get roles and talk through an LDS mailbox (one snapshot read = the whole mailbox) instead of barriers:
+//   wave 0  COMMIT   owns the beam (registers, as before): acceptance by counting, pushes, the stop test, the choice of the
+//                    next node — every decision of the traversal, in the reference's order, from exact distances.
+//   wave 1  PREPARE  owns the visited set.  After every step it reads the candidate mirror wave 0 keeps in LDS, selects the
+//                    runner-up c1 (wave 0's next choice needs it), and — c1 being the next node 92 % of the time — runs c1's
+//                    visited test-and-set TENTATIVELY: the list of its new neighbours with their distances is ready in LDS
+//                    when wave 0 gets there.  A wrong guess is undone bit for bit (nobody else writes the set) and redone
+//                    for the node wave 0 really chose; a traversal that stops leaves no tentative bit behind.
+//   wave 2  PREDICT  selects the candidate after c1 (the node likely expanded two steps ahead) and asks the distance waves
+//                    for its neighbours' distances; touches its adjacency row into L2.
+//   waves 3-5 DISTANCES  per request: the node's row, a read-only visited test, the gather of the unvisited neighbours and
+//                    their exact distances stored by ROW POSITION.  The visited set only grows (tentative bits apart), so
+//                    when wave 1 runs that node's test-and-set a step later the distances are waiting in LDS: the gather
+//                    has left the critical path.  What a speculation did not cover, wave 1 evaluates itself.
+// Counters and results are hnsw_beam_kernel's step for step: speculative work is never counted and never raises MDB_ERR_NAN.
 // Requirements (else hnsw_beam_kernel runs): ef <= 256, d a multiple of 16 (N16T > 0), no PQ rows, row strides <= 64.
 // ==========================================================================================
-#define PIPE_LDS_NB (BEAM_LDS_C + 8192)      // nb_id[64] | nb_od[64]
-#define PIPE_LDS_MIR (PIPE_LDS_NB + 512)     // candidate mirror: {cd, id}[320] (cd = distance image of an unexpanded slot, else EMPTY)
+#define PIPE_BLOCK 384
+#define PIPE_LDS_NB (BEAM_LDS_C + 8192)      // nb_id[2][64] | nb_od[2][64]: the new-neighbour lists of even / odd steps
+#define PIPE_LDS_MIR (PIPE_LDS_NB + 1024)    // candidate mirror: {cd, id}[320] (cd = distance image of an unexpanded slot, else EMPTY)
 #define PIPE_LDS_SPEC (PIPE_LDS_MIR + 2560)  // spec_od[2][64]: distance images by row position
-#define PIPE_LDS_MBOX (PIPE_LDS_SPEC + 512)  // 64 mailbox words
+#define PIPE_LDS_MBOX (PIPE_LDS_SPEC + 512)  // 64 mailbox words (the first 32 are the snapshot)
 #define PIPE_LDS_QS (PIPE_LDS_MBOX + 256)
-#define PIPE_LDS_DTMP (BEAM_LDS_C + 6144)    // per speculating wave: ids[32] | pos[32] (inside C: unused while the roles run)
+#define PIPE_LDS_DTMP (BEAM_LDS_C + 5632)    // per distance wave: ids[32] | pos[32]; wave 1: ids[64] (inside C: unused while the roles run)
 enum {
-    MB_GEN = 0, MB_STOP, MB_ACK, MB_RU_GEN, MB_RU_O, MB_RU_ID, MB_RU_SLOT, MB_RU_VALID, MB_C2_GEN, MB_C2_O, MB_C2_ID, MB_C2_VALID,
-    MB_SREQ, MB_SNODE0, MB_SNODE1, MB_SDONE_A0, MB_SDONE_A1, MB_SDONE_B0, MB_SDONE_B1, MB_SRID0, MB_SRID1, MB_XNODE,
-    MB_SMASK = 23  // [wave 2|3][buf 0|1][lo|hi]: 8 words
+    MB_GEN = 0, MB_STOP, MB_XNODE, MB_ACK1, MB_ACK2, MB_RU_GEN, MB_RU_O, MB_RU_ID, MB_RU_SLOT, MB_RU_VALID,
+    MB_LIST_GEN, MB_LIST_GEN_ODD, MB_LIST_NODE, MB_LIST_NODE_ODD, MB_LIST_N, MB_LIST_N_ODD,   // by the parity of the step
+    MB_SREQ, MB_SNODE0, MB_SNODE1, MB_SRID0, MB_SRID1, MB_SDONE0, MB_SDONE1, MB_SDONE0B, MB_SDONE1B, MB_SDONE0C, MB_SDONE1C,
+    MB_SMASK = 27   // [buf 0|1][lo|hi] x 2 words, OR-ed into by the three distance waves: 4 words (27..30)
 };
 
 // ONE LDS read returns the whole mailbox (lane i = word i; every word lives in the first 32 lanes' pass, so the snapshot is
@@ -1145,28 +1149,28 @@ enum {
 __device__ __forceinline__ uint32_t mb_snap(const uint32_t* mb, int lane) { return *(const volatile uint32_t*)(mb + (lane & 31)); }
 #define MBW(snap, i) ((uint32_t)__builtin_amdgcn_readlane((int)(snap), (i)))
 __device__ __forceinline__ void mb_store(uint32_t* mb, int i, uint32_t v) { *(volatile uint32_t*)(mb + i) = v; }
-#ifdef MDB_PIPE_DBG
-#define PIPE_T0() const unsigned long long _t0 = __builtin_readcyclecounter()
-#define PIPE_ADD(slot) dbg_acc[slot] += __builtin_readcyclecounter() - _t0
-#define PIPE_CNT(slot, v) dbg_acc[slot] += (v)
-#else
-#define PIPE_T0() do {} while (0)
-#define PIPE_ADD(slot) do {} while (0)
-#define PIPE_CNT(slot, v) do {} while (0)
-#endif
 // The LDS operations of one wave are issued and completed in order, so publishing data before a flag (and reading a flag before
 // the data) only needs the COMPILER kept from reordering them; a real fence would also wait for the outstanding global loads —
 // the prefetched adjacency rows.
 #define PIPE_RELEASE() asm volatile("" ::: "memory")
 #define PIPE_ACQUIRE() asm volatile("" ::: "memory")
+#ifdef MDB_PIPE_DBG   // cycle / event accounting of the roles into counters[4..15] (MDB_HNSW_DBG=1 prints them)
+#define PIPE_TB(t) const unsigned long long t = __builtin_readcyclecounter()
+#define PIPE_TE(slot, t) dbg_acc[slot] += __builtin_readcyclecounter() - (t)
+#define PIPE_CNT(slot, v) dbg_acc[slot] += (v)
+#else
+#define PIPE_TB(t) do {} while (0)
+#define PIPE_TE(slot, t) do {} while (0)
+#define PIPE_CNT(slot, v) do {} while (0)
+#endif
 
 template <int METRIC, bool VIS_LDS, int N16T>
-__global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
+__global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint64_t* const W = (uint64_t*)lds;
     uint64_t* const C = (uint64_t*)(lds + BEAM_LDS_C);
-    uint32_t* const nb_id = (uint32_t*)(lds + PIPE_LDS_NB);
-    uint32_t* const nb_od = nb_id + 64;
+    uint32_t* const nb_id = (uint32_t*)(lds + PIPE_LDS_NB);      // [parity][64]
+    uint32_t* const nb_od = nb_id + 128;                         // [parity][64]
     uint64_t* const mir = (uint64_t*)(lds + PIPE_LDS_MIR);      // (id << 32) | cd
     uint32_t* const spec_od = (uint32_t*)(lds + PIPE_LDS_SPEC);
     uint32_t* const mb = (uint32_t*)(lds + PIPE_LDS_MBOX);
@@ -1181,13 +1185,13 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
     const int grp = tid >> 4, j = tid & 15;
     const HnswUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
     if (!u.valid || u.n == 0 || u.num_layers == 0 || u.entry_point >= u.n) {
-        for (int i = tid; i < a.k; i += HNSW_BLOCK) a.out_keys[(size_t)qi * a.k + i] = MDB_KEY_MAX;
+        for (int i = tid; i < a.k; i += PIPE_BLOCK) a.out_keys[(size_t)qi * a.k + i] = MDB_KEY_MAX;
         if (tid == 0) a.out_counts[qi] = 0;
         return;
     }
-    for (int i = tid; i < a.dpad; i += HNSW_BLOCK) qs[i] = a.q[(size_t)qi * a.qstride + i];
+    for (int i = tid; i < a.dpad; i += PIPE_BLOCK) qs[i] = a.q[(size_t)qi * a.qstride + i];
     if (VIS_LDS)
-        for (unsigned long long i = tid; i < a.vis_words; i += HNSW_BLOCK) vis[i] = 0;
+        for (unsigned long long i = tid; i < a.vis_words; i += PIPE_BLOCK) vis[i] = 0;
     __syncthreads();
 
     const float* vecs = a.vecs + u.vec_off;
@@ -1201,16 +1205,14 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
     uint32_t bd[BREGS], bi[BREGS], cdv[BREGS];
     int n = 0;
     uint32_t fbound = SLOT_EMPTY;
-    uint32_t rowv = 0xFFFFFFFFu, rowr = 0xFFFFFFFFu;   // row of the node being expanded / of the runner-up (lane = row position)
     int ru_slot = 0;
     uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
-    bool ru_valid = false, ru_have = false, stop = false;
+    bool ru_valid = false, stop = false;
     uint32_t evals = 0, expanded = 0;
     bool nan_seen = false, overflow = false;
     uint32_t ep = u.entry_point;
-    uint32_t spec_hits = 0;
 #ifdef MDB_PIPE_DBG
-    unsigned long long dbg_acc[12] = {0};   // wave 0: [0] steps [1] misses [2] spec wait [3] ack wait [4] ru wait [5] miss compute [6] loop total [7] spec requests [8] spec skipped (busy)
+    unsigned long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
@@ -1240,7 +1242,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
             int ncur = 1;
             __syncthreads();
             while (ncur > 0) {
-                for (int i = grp; i < ncur; i += HNSW_BLOCK / 16) {
+                for (int i = grp; i < ncur; i += PIPE_BLOCK / 16) {
                     const uint32_t f = cur[i];
                     const uint32_t* row = nullptr;
                     if (a.level[u.upper_off + f] >= layer)
@@ -1272,13 +1274,12 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
             __syncthreads();
             continue;
         }
-        // ---- layer start: mailboxes, mirror, entry point (index.rs:219-231: visited, distance, seed B, popped at once)
+        // ---- layer start: mailbox, mirror, entry point (index.rs:219-231: visited, distance, seed B, popped at once)
         if (wave == 0) {
             if (lane < 40) mb[lane] = lane == MB_SNODE0 || lane == MB_SNODE1 ? 0xFFFFFFFFu : 0u;
 #pragma unroll
             for (int r = 0; r < BREGS; ++r) mir[lane + 64 * r] = (uint64_t)SLOT_EMPTY;
             if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
-            rowv = load_row(ep);
             float d0 = 0.0f;
             if (lane < 16) d0 = PIPE_DIST(vecs + (size_t)ep * a.dpad);
             d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), 0));
@@ -1298,99 +1299,30 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
             uint32_t xnode = ep;
             if (lane == 0) mb_store(mb, MB_XNODE, xnode);
             PIPE_RELEASE();
-            if (lane == 0) mb_store(mb, MB_GEN, gen);   // S_1: B = {ep}, no candidates
-#ifdef MDB_PIPE_DBG
-            const unsigned long long _tl = __builtin_readcyclecounter();
-#endif
+            if (lane == 0) mb_store(mb, MB_GEN, gen);   // S_1: B = {ep}, no candidates; x_1 = ep
+            PIPE_TB(t_w0);
             for (;;) {
-#ifdef MDB_PIPE_DBG
-                unsigned long long _ts = __builtin_readcyclecounter(), _tn;
-#define PIPE_SEG(slot) do { _tn = __builtin_readcyclecounter(); dbg_acc[slot] += _tn - _ts; _ts = _tn; } while (0)
-#else
-#define PIPE_SEG(slot) do {} while (0)
-#endif
-                // ---- speculated distances of xnode, if a finished (or nearly finished) spec exists
-                int sb = -1;
+                PIPE_CNT(4, 1);
+                PIPE_TB(t_l);
+                // ---- the new neighbours of xnode with their distances (wave 1's list, prepared ahead when it guessed right)
                 uint32_t snap = mb_snap(mb, lane);
-                // (a request id names its buffer by parity; wave 1 issues them: MB_SRID0 / 1 = the id last put into buffer 0 / 1)
-                const uint32_t rb0 = MBW(snap, MB_SRID0), rb1 = MBW(snap, MB_SRID1);
-                if (MBW(snap, MB_SNODE0) == xnode && rb0) sb = 0;
-                else if (MBW(snap, MB_SNODE1) == xnode && rb1) sb = 1;
-                unsigned long long smask = 0;
-                PIPE_CNT(0, 1);
-                if (sb >= 0) {
-                    const uint32_t want = sb ? rb1 : rb0;
-                    PIPE_T0();
-                    while ((sb ? MBW(snap, MB_SDONE_A1) : MBW(snap, MB_SDONE_A0)) != want || (sb ? MBW(snap, MB_SDONE_B1) : MBW(snap, MB_SDONE_B0)) != want) {
-                        __builtin_amdgcn_s_sleep(1);
-                        snap = mb_snap(mb, lane);
-                    }
-                    PIPE_ADD(2);
-                    PIPE_ACQUIRE();
-                    const int mo = MB_SMASK + sb * 2;
-                    smask = sb ? ((unsigned long long)(MBW(snap, MB_SMASK + 3) | MBW(snap, MB_SMASK + 7)) << 32) | (MBW(snap, MB_SMASK + 2) | MBW(snap, MB_SMASK + 6))
-                               : ((unsigned long long)(MBW(snap, MB_SMASK + 1) | MBW(snap, MB_SMASK + 5)) << 32) | (MBW(snap, MB_SMASK + 0) | MBW(snap, MB_SMASK + 4));
-                    (void)mo;
-                }
-                // ---- P2: visited test-and-set + ordered compaction of xnode's row (lane = row position)
-                uint32_t nnew = 0;
-                {
-                    const uint32_t nbr = rowv;
-                    const uint32_t sv = sb >= 0 ? spec_od[sb * 64 + lane] : 0u;
-                    bool isnew = false;
-                    if (nbr != 0xFFFFFFFFu) {
-                        const uint32_t bit = 1u << (nbr & 31);
-                        isnew = !(atomicOr(&vis[nbr >> 5], bit) & bit);
-                    }
-                    const unsigned long long bal = __ballot(isnew);
-                    expanded += __ballot(nbr != 0xFFFFFFFFu) != 0 ? 1 : 0;
-                    nnew = (uint32_t)__popcll(bal);
-                    evals += nnew;
-                    if (sb >= 0 && (bal & ~smask)) sb = -1;   // a neighbour the spec did not cover (cannot happen: visited only grows): evaluate here
-                    if (isnew) {
-                        const int kpos = __popcll(bal & lt_mask);
-                        nb_id[kpos] = nbr;
-                        if (sb >= 0) nb_od[kpos] = sv;
-                    }
-                    if (sb >= 0) ++spec_hits;
-                }
-                if (sb < 0 && nnew) {
-                    // ---- miss: this wave's four 16-lane groups evaluate the neighbours themselves (two rows per group and gather)
-                    PIPE_CNT(1, 1);
-                    PIPE_T0();
-                    const int g0 = lane >> 4;
-                    for (uint32_t i = g0; i < nnew; i += 8) {
-                        const bool two = i + 4 < nnew;
-                        const uint32_t i2 = two ? i + 4 : i;
-                        float da, db;
-                        group16_distance_fast2<METRIC, N16T>(vecs + (size_t)nb_id[i] * a.dpad, vecs + (size_t)nb_id[i2] * a.dpad, qr, j, da, db);
-                        if (j == 0) {
-                            nb_od[i] = f32_orderable(da);
-                            if (two) nb_od[i2] = f32_orderable(db);
-                        }
-                    }
-                    PIPE_ADD(5);
-                }
-                PIPE_SEG(8);
-                // ---- the runner-up of this step's choice (wave 1, from S_gen): start its row load as early as it is known
-                ru_have = false;
-                snap = mb_snap(mb, lane);
-                if (MBW(snap, MB_RU_GEN) == gen) {
-                    ru_valid = MBW(snap, MB_RU_VALID) != 0;
-                    ru_o = MBW(snap, MB_RU_O); ru_id = MBW(snap, MB_RU_ID); ru_slot = (int)MBW(snap, MB_RU_SLOT);
-                    if (ru_valid) rowr = load_row(ru_id);
-                    ru_have = true;
-                }
-                PIPE_SEG(9);
-                // ---- P4: accept + push (hnsw_beam_kernel's, with the mirror kept in step), then the choice
+                const int lpar = (int)(gen & 1u);
+                while (MBW(snap, MB_LIST_GEN + lpar) != gen || MBW(snap, MB_LIST_NODE + lpar) != xnode) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
+                PIPE_ACQUIRE();
+                PIPE_TE(1, t_l);
+                const uint32_t ln = MBW(snap, MB_LIST_N + lpar);
+                const uint32_t nnew = ln & 0xFFFFu;
+                expanded += ln >> 16;
+                evals += nnew;
+                const int par = (int)(gen & 1u) * 64;
+                const bool have = (uint32_t)lane < nnew;
+                const uint32_t od = have ? nb_od[par + lane] : SLOT_EMPTY;
+                const uint32_t id = have ? nb_id[par + lane] : 0;
+                // ---- accept + push (hnsw_beam_kernel's P4, with the mirror kept in step)
                 uint32_t best_o = SLOT_EMPTY, best_id = 0;
                 int best_slot = -1;
-                bool mirror_free = false;   // wave 1 has finished reading S_gen: the mirror may change
+                bool ru_local = false;      // the runner-up was selected here (slots moved in a compaction)
                 {
-                    const uint32_t i = lane;
-                    const bool have = i < nnew;
-                    const uint32_t od = have ? nb_od[i] : SLOT_EMPTY;
-                    const uint32_t id = have ? nb_id[i] : 0;
                     if (__ballot(have && od > 0xFF800000u)) nan_seen = true;   // the image of a NaN distance (the reference panics)
                     unsigned long long surv = __ballot(have && od < fbound);
                     unsigned long long accepted = 0;
@@ -1407,12 +1339,9 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     }
                     const int na = __popcll(accepted);
                     if (na) {
-                        {
-                            PIPE_T0();
-                            while (MBW(snap, MB_ACK) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
-                            PIPE_ADD(3);
-                        }
-                        mirror_free = true;
+                        PIPE_TB(t_a);
+                        while (MBW(snap, MB_ACK1) != gen || MBW(snap, MB_ACK2) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
+                        PIPE_TE(2, t_a);
                         if (n + na > BEAM_CAP) {
                             // ---- compaction (radix select of the ef-th smallest image, drop everything farther)
                             uint32_t prefix = 0;
@@ -1453,8 +1382,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                             if (n + na > BEAM_CAP) overflow = true;
                             // slots moved: wave 1's runner-up names an old slot; select here (rare)
                             ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_slot);
-                            if (ru_valid) rowr = load_row(ru_id);
-                            ru_have = true;
+                            ru_local = true;
                         }
                         if (!overflow) {
                             // ---- push the accepted neighbours into slots n .. n+na-1 (forward lane permute), mirror included
@@ -1474,29 +1402,40 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                             }
                             if (got) mir[n + rel] = ((uint64_t)rid << 32) | rod;
                             // best accepted neighbour in pop order (smallest distance, largest id)
-                            const uint32_t mo = wave_min_u32(mine ? od : SLOT_EMPTY);
-                            const uint32_t mi = wave_max_u32(mine && od == mo ? id : 0u);
-                            const unsigned long long wm = __ballot(mine && od == mo && id == mi);
-                            best_o = mo;
-                            best_id = mi;
-                            best_slot = n + __popcll(accepted & ((1ull << (__ffsll((long long)wm) - 1)) - 1ull));
+                            if (na > 2) {
+                                const uint32_t mo = wave_min_u32(mine ? od : SLOT_EMPTY);
+                                const uint32_t mi = wave_max_u32(mine && od == mo ? id : 0u);
+                                const unsigned long long wm = __ballot(mine && od == mo && id == mi);
+                                best_o = mo;
+                                best_id = mi;
+                                best_slot = n + __popcll(accepted & ((1ull << (__ffsll((long long)wm) - 1)) - 1ull));
+                            } else {
+                                unsigned long long am = accepted;
+                                int rank = 0;
+                                while (am) {
+                                    const int sidx = __ffsll((long long)am) - 1;
+                                    am &= am - 1;
+                                    const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                                    const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
+                                    if (best_slot < 0 || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_slot = n + rank; }
+                                    ++rank;
+                                }
+                            }
                             n += na;
                         }
                     }
                 }
-                if (overflow) { stop = true; }
-                PIPE_SEG(10);
+                if (overflow) stop = true;
                 if (!stop) {
-                    snap = mb_snap(mb, lane);   // the snapshot the choice works from: runner-up, c2, ack, the spec buffers' state
-                    if (!ru_have) {
-                        PIPE_T0();
+                    // ---- candidates.pop(): the runner-up (wave 1, from S_gen) vs the best accepted; stop when it is farther than furthest
+                    snap = mb_snap(mb, lane);
+                    if (!ru_local) {
+                        PIPE_TB(t_r);
                         while (MBW(snap, MB_RU_GEN) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
-                        PIPE_ADD(4);
+                        PIPE_TE(3, t_r);
                         ru_valid = MBW(snap, MB_RU_VALID) != 0;
                         ru_o = MBW(snap, MB_RU_O); ru_id = MBW(snap, MB_RU_ID); ru_slot = (int)MBW(snap, MB_RU_SLOT);
-                        if (ru_valid) rowr = load_row(ru_id);
                     }
-                    // ---- candidates.pop(): runner-up vs best accepted; stop when it is farther than furthest
                     const bool take_ru = ru_valid && (best_slot < 0 || ru_o < best_o || (ru_o == best_o && ru_id > best_id));
                     if (!take_ru && best_slot < 0) {
                         stop = true;
@@ -1510,46 +1449,193 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                         if (closer >= ef) {
                             stop = true;
                         } else {
-                            if (!mirror_free)
-                                while (MBW(snap, MB_ACK) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
+                            while (MBW(snap, MB_ACK1) != gen || MBW(snap, MB_ACK2) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
                             const int pslot = take_ru ? ru_slot : best_slot;
 #pragma unroll
                             for (int r = 0; r < BREGS; ++r)
                                 if (lane + 64 * r == pslot) { cdv[r] = SLOT_EMPTY; mir[pslot] = ((uint64_t)bi[r] << 32) | SLOT_EMPTY; }
-                            if (take_ru) {
-                                xnode = ru_id;
-                                rowv = rowr;
-                            } else {
-                                xnode = best_id;
-                                rowv = load_row(best_id);
-                            }
+                            xnode = take_ru ? ru_id : best_id;
                         }
                     }
                 }
                 if (stop) {
                     PIPE_RELEASE();
                     if (lane == 0) mb_store(mb, MB_STOP, 1u);
-#ifdef MDB_PIPE_DBG
-                    dbg_acc[6] += __builtin_readcyclecounter() - _tl;
-#endif
                     break;
                 }
-                PIPE_SEG(11);
-                // ---- publish S_{gen+1}; ask for the speculation of `pred`
+                // ---- publish S_{gen+1} and x_{gen+1}
                 ++gen;
                 if (lane == 0) mb_store(mb, MB_XNODE, xnode);
                 PIPE_RELEASE();
                 if (lane == 0) mb_store(mb, MB_GEN, gen);
             }
+            PIPE_TE(0, t_w0);
         } else if (wave == 1) {
-            // =============================================================== SELECT
+            // =============================================================== PREPARE: the visited set + the runner-up
+            uint32_t* const tids = (uint32_t*)(lds + PIPE_LDS_DTMP) + 192;   // ids this wave has to evaluate itself
+            uint32_t cd[BREGS], ci[BREGS];
+            // P2 of `node` for the step of generation lg (list into nb[lg & 1]): visited test-and-set + ordered compaction,
+            // distances from a finished speculation where it has them, evaluated here otherwise.  Returns nnew | any_edge << 16.
+            auto make_list = [&](uint32_t node, uint32_t lg, unsigned long long& set_mask, uint32_t& row_keep) -> uint32_t {
+                const uint32_t nbr = load_row(node);
+                uint32_t snap = mb_snap(mb, lane);
+                int sb = -1;
+                if (MBW(snap, MB_SNODE0) == node && MBW(snap, MB_SRID0)) sb = 0;
+                else if (MBW(snap, MB_SNODE1) == node && MBW(snap, MB_SRID1)) sb = 1;
+                unsigned long long smask = 0;
+                if (sb >= 0) {
+                    const uint32_t want = sb ? MBW(snap, MB_SRID1) : MBW(snap, MB_SRID0);
+                    PIPE_TB(t_s);
+                    for (;;) {   // a speculation under way is worth waiting for: it started its gather long ago
+                        const bool done = sb ? (MBW(snap, MB_SDONE1) == want && MBW(snap, MB_SDONE1B) == want && MBW(snap, MB_SDONE1C) == want)
+                                             : (MBW(snap, MB_SDONE0) == want && MBW(snap, MB_SDONE0B) == want && MBW(snap, MB_SDONE0C) == want);
+                        if (done) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        snap = mb_snap(mb, lane);
+                    }
+                    PIPE_TE(6, t_s);
+                    PIPE_ACQUIRE();
+                    smask = sb ? ((unsigned long long)MBW(snap, MB_SMASK + 3) << 32) | MBW(snap, MB_SMASK + 2)
+                               : ((unsigned long long)MBW(snap, MB_SMASK + 1) << 32) | MBW(snap, MB_SMASK + 0);
+                }
+                uint32_t sv = 0u;
+                if (sb >= 0) {
+                    // wave 2 may hand the buffer to another node at any time: read, THEN check that the buffer still names this
+                    // request (the distance waves overwrite it only after the new request is published; LDS runs in order)
+                    sv = *(const volatile uint32_t*)(spec_od + sb * 64 + lane);
+                    PIPE_ACQUIRE();
+                    const uint32_t s2 = mb_snap(mb, lane);
+                    const uint32_t want = sb ? MBW(snap, MB_SRID1) : MBW(snap, MB_SRID0);
+                    if ((sb ? MBW(s2, MB_SNODE1) : MBW(s2, MB_SNODE0)) != node || (sb ? MBW(s2, MB_SRID1) : MBW(s2, MB_SRID0)) != want) smask = 0;
+                }
+                bool isnew = false;
+                if (nbr != 0xFFFFFFFFu) {
+                    const uint32_t bit = 1u << (nbr & 31);
+                    isnew = !(atomicOr(&vis[nbr >> 5], bit) & bit);
+                }
+                const unsigned long long bal = __ballot(isnew);
+                const uint32_t anyedge = __ballot(nbr != 0xFFFFFFFFu) != 0 ? 1u : 0u;
+                const uint32_t nnew = (uint32_t)__popcll(bal);
+                const int par = (int)(lg & 1u) * 64;
+                const int kpos = __popcll(bal & lt_mask);
+                const bool covered = (smask >> lane) & 1ull;
+                if (isnew) {
+                    nb_id[par + kpos] = nbr;
+                    if (covered) nb_od[par + kpos] = sv;
+                }
+                // what no speculation covered: this wave's four 16-lane groups (two rows per group and gather)
+                const unsigned long long todo = bal & ~smask;
+                PIPE_CNT(8, __popcll(todo));
+                PIPE_CNT(9, nnew);
+                if (todo) {
+                    const int nt = __popcll(todo);
+                    if (isnew && !covered) {
+                        const int tp = __popcll(todo & lt_mask);
+                        tids[tp] = nbr;
+                        tids[64 + tp] = (uint32_t)kpos;
+                    }
+                    const int g0 = lane >> 4;
+                    for (int i = g0; i < nt; i += 8) {
+                        const bool two = i + 4 < nt;
+                        const int i2 = two ? i + 4 : i;
+                        float da, db;
+                        group16_distance_fast2<METRIC, N16T>(vecs + (size_t)tids[i] * a.dpad, vecs + (size_t)tids[i2] * a.dpad, qr, j, da, db);
+                        if (j == 0) {
+                            nb_od[par + tids[64 + i]] = f32_orderable(da);
+                            if (two) nb_od[par + tids[64 + i2]] = f32_orderable(db);
+                        }
+                    }
+                }
+                set_mask = bal;
+                row_keep = nbr;
+                return nnew | (anyedge << 16);
+            };
+            // the list first, then its size and node, then the generation: wave 0 matches generation AND node in one snapshot,
+            // so a list republished for the same generation (a wrong guess redone) is never seen half-written
+            auto publish_list = [&](uint32_t lg, uint32_t node, uint32_t nn) {
+                const int lp = (int)(lg & 1u);
+                PIPE_RELEASE();
+                if (lane == 0) { mb_store(mb, MB_LIST_N + lp, nn); mb_store(mb, MB_LIST_NODE + lp, node); }
+                PIPE_RELEASE();
+                if (lane == 0) mb_store(mb, MB_LIST_GEN + lp, lg);
+            };
+            auto undo_list = [&](unsigned long long set_mask, uint32_t row_keep) {
+                if ((set_mask >> lane) & 1ull) atomicAnd(&vis[row_keep >> 5], ~(1u << (row_keep & 31)));
+            };
+            uint32_t seen = 0;
+            unsigned long long t_mask = 0;      // tentative list: the bits it set (by row position) ...
+            uint32_t t_row = 0xFFFFFFFFu, t_node = 0xFFFFFFFFu, t_n = 0;   // ... its row, node and nnew | any_edge << 16
+            bool t_live = false;
+            // the entry point's list (real): generation 1
+            {
+                unsigned long long m0; uint32_t r0;
+                const uint32_t n0 = make_list(ep, 1, m0, r0);
+                publish_list(1u, ep, n0);
+            }
+            for (;;) {
+                uint32_t g, sn;
+                bool quit = false;
+                PIPE_TB(t_i);
+                for (;;) {
+                    sn = mb_snap(mb, lane);
+                    g = MBW(sn, MB_GEN);
+                    if (g != seen) break;
+                    if (MBW(sn, MB_STOP)) { quit = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                PIPE_TE(5, t_i);
+                if (quit) break;
+                seen = g;
+                PIPE_ACQUIRE();
+                PIPE_TB(t_body);
+                // ---- the list of x_g: the tentative one if the guess was right (wave 0 is already consuming it), else undo + redo
+                if (g > 1) {
+                    const uint32_t xg = MBW(sn, MB_XNODE);
+                    if (!(t_live && t_node == xg)) {
+                        if (t_live) undo_list(t_mask, t_row);
+                        PIPE_CNT(7, 1);
+                        unsigned long long m0; uint32_t r0;
+                        const uint32_t n0 = make_list(xg, g, m0, r0);
+                        publish_list(g, xg, n0);
+                    }
+                    t_live = false;
+                }
+                // ---- the runner-up of S_g
+#pragma unroll
+                for (int r = 0; r < BREGS; ++r) {
+                    const uint64_t e = *(const volatile uint64_t*)(mir + lane + 64 * r);
+                    cd[r] = (uint32_t)e;
+                    ci[r] = (uint32_t)(e >> 32);
+                }
+                PIPE_RELEASE();
+                if (lane == 0) mb_store(mb, MB_ACK1, g);
+                uint32_t o1 = SLOT_EMPTY, id1 = 0;
+                int s1 = 0;
+                const bool v1 = beam_best(cd, ci, lane, o1, id1, s1);
+                if (lane == 0) { mb_store(mb, MB_RU_O, o1); mb_store(mb, MB_RU_ID, id1); mb_store(mb, MB_RU_SLOT, (uint32_t)s1); mb_store(mb, MB_RU_VALID, v1 ? 1u : 0u); }
+                PIPE_RELEASE();
+                if (lane == 0) mb_store(mb, MB_RU_GEN, g);
+                PIPE_TE(11, t_body);
+                // ---- tentatively: c1 is the next node
+                PIPE_TB(t_t);
+                if (v1) {
+                    t_n = make_list(id1, g + 1, t_mask, t_row);
+                    t_node = id1;
+                    t_live = true;
+                    publish_list(g + 1, id1, t_n);
+                }
+                PIPE_TE(10, t_t);
+            }
+            if (t_live) undo_list(t_mask, t_row);   // the traversal stopped: a tentative list nobody consumed leaves no mark
+        } else if (wave == 2) {
+            // =============================================================== PREDICT: the candidate after the runner-up
             uint32_t seen = 0, sreq = 0, rid0 = 0, rid1 = 0;
             uint32_t cd[BREGS], ci[BREGS];
             for (;;) {
-                uint32_t g;
+                uint32_t g, sn;
                 bool quit = false;
                 for (;;) {
-                    const uint32_t sn = mb_snap(mb, lane);
+                    sn = mb_snap(mb, lane);
                     g = MBW(sn, MB_GEN);
                     if (g != seen) break;
                     if (MBW(sn, MB_STOP)) { quit = true; break; }
@@ -1565,33 +1651,41 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     ci[r] = (uint32_t)(e >> 32);
                 }
                 PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, MB_ACK, g);
-                uint32_t o1 = SLOT_EMPTY, id1 = 0;
-                int s1 = 0;
-                const bool v1 = beam_best(cd, ci, lane, o1, id1, s1);
-                if (lane == 0) { mb_store(mb, MB_RU_O, o1); mb_store(mb, MB_RU_ID, id1); mb_store(mb, MB_RU_SLOT, (uint32_t)s1); mb_store(mb, MB_RU_VALID, v1 ? 1u : 0u); }
-                PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, MB_RU_GEN, g);
-                // ---- c1 is also the node most likely expanded after the next one (92 %): have its neighbours' distances
-                // evaluated ahead of time — unless a buffer already holds it, or the buffer whose turn it is is still busy
-                if (v1) {
-                    const uint32_t sn2 = mb_snap(mb, lane);
-                    const int b = (int)((sreq + 1) & 1u);
-                    const uint32_t prev = b ? rid1 : rid0;
-                    if (MBW(sn2, MB_SNODE0) != id1 && MBW(sn2, MB_SNODE1) != id1 && (b ? MBW(sn2, MB_SNODE1) : MBW(sn2, MB_SNODE0)) != MBW(sn2, MB_XNODE) &&
-                        (b ? MBW(sn2, MB_SDONE_A1) : MBW(sn2, MB_SDONE_A0)) == prev && (b ? MBW(sn2, MB_SDONE_B1) : MBW(sn2, MB_SDONE_B0)) == prev) {
-                        ++sreq;
-                        if (b) rid1 = sreq; else rid0 = sreq;
-                        if (lane == 0) { mb_store(mb, b ? MB_SNODE1 : MB_SNODE0, id1); mb_store(mb, b ? MB_SRID1 : MB_SRID0, sreq); }
-                        PIPE_RELEASE();
-                        if (lane == 0) mb_store(mb, MB_SREQ, sreq);
+                if (lane == 0) mb_store(mb, MB_ACK2, g);
+                uint32_t o1 = SLOT_EMPTY, id1 = 0, o2 = SLOT_EMPTY, id2 = 0;
+                int s1 = 0, s2 = 0;
+                if (!beam_best(cd, ci, lane, o1, id1, s1)) continue;
+#pragma unroll
+                for (int r = 0; r < BREGS; ++r)
+                    if (lane + 64 * r == s1) cd[r] = SLOT_EMPTY;
+                uint32_t target = 0xFFFFFFFFu;
+                const uint32_t sn2 = mb_snap(mb, lane);
+                if (beam_best(cd, ci, lane, o2, id2, s2) && MBW(sn2, MB_SNODE0) != id2 && MBW(sn2, MB_SNODE1) != id2) target = id2;
+                if (target == 0xFFFFFFFFu) continue;
+                const int b = (int)((sreq + 1) & 1u);
+                const uint32_t prev = b ? rid1 : rid0;
+                const bool free_ = b ? (MBW(sn2, MB_SDONE1) == prev && MBW(sn2, MB_SDONE1B) == prev && MBW(sn2, MB_SDONE1C) == prev)
+                                     : (MBW(sn2, MB_SDONE0) == prev && MBW(sn2, MB_SDONE0B) == prev && MBW(sn2, MB_SDONE0C) == prev);
+                // not the buffer holding the distances of wave 1's guess c1 (it is consuming them now; it checks, so this is
+                // about not wasting them)
+                const uint32_t held = b ? MBW(sn2, MB_SNODE1) : MBW(sn2, MB_SNODE0);
+                if (free_ && held != id1) {
+                    ++sreq;
+                    if (b) rid1 = sreq; else rid0 = sreq;
+                    if (lane == 0) {
+                        mb_store(mb, b ? MB_SNODE1 : MB_SNODE0, target);
+                        mb_store(mb, b ? MB_SRID1 : MB_SRID0, sreq);
+                        mb_store(mb, MB_SMASK + 2 * b, 0u);
+                        mb_store(mb, MB_SMASK + 2 * b + 1, 0u);
                     }
+                    PIPE_RELEASE();
+                    if (lane == 0) mb_store(mb, MB_SREQ, sreq);
                 }
             }
         } else {
-            // =============================================================== SPECULATE (waves 2, 3)
-            const int half = wave - 2;                       // this wave's row positions: ((pos >> 4) & 1) == half
-            uint32_t* const tid_ = (uint32_t*)(lds + PIPE_LDS_DTMP) + half * 64;   // ids[32] | pos[32]
+            // =============================================================== DISTANCES (waves 3, 4, 5)
+            const int third = wave - 3;                      // this wave's row positions: pos % 3 == third
+            uint32_t* const tid_ = (uint32_t*)(lds + PIPE_LDS_DTMP) + third * 64;   // ids[32] | pos[32]
             uint32_t next = 1;
             for (;;) {
                 bool quit = false;
@@ -1608,7 +1702,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 const uint32_t p = b ? MBW(sn, MB_SNODE1) : MBW(sn, MB_SNODE0);
                 const uint32_t nbr = load_row(p);
                 bool isnew = false;
-                if (nbr != 0xFFFFFFFFu && ((lane >> 4) & 1) == half) {
+                if (nbr != 0xFFFFFFFFu && (lane % 3) == third) {
                     const uint32_t word = *(const volatile uint32_t*)(vis + (nbr >> 5));
                     isnew = !((word >> (nbr & 31)) & 1u);
                 }
@@ -1631,11 +1725,11 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     }
                 }
                 if (lane == 0) {
-                    mb_store(mb, MB_SMASK + half * 4 + b * 2, (uint32_t)bal);
-                    mb_store(mb, MB_SMASK + half * 4 + b * 2 + 1, (uint32_t)(bal >> 32));
+                    atomicOr(mb + MB_SMASK + 2 * b, (uint32_t)bal);
+                    atomicOr(mb + MB_SMASK + 2 * b + 1, (uint32_t)(bal >> 32));
                 }
                 PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, half ? (b ? MB_SDONE_B1 : MB_SDONE_B0) : (b ? MB_SDONE_A1 : MB_SDONE_A0), next);
+                if (lane == 0) mb_store(mb, third == 0 ? (b ? MB_SDONE1 : MB_SDONE0) : third == 1 ? (b ? MB_SDONE1B : MB_SDONE0B) : (b ? MB_SDONE1C : MB_SDONE0C), next);
                 ++next;
             }
         }
@@ -1668,7 +1762,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
         const int n2 = 512;
         for (int size = 2; size <= n2; size <<= 1) {
             for (int st = size >> 1; st > 0; st >>= 1) {
-                for (int t = tid; t < (n2 >> 1); t += HNSW_BLOCK) {
+                for (int t = tid; t < (n2 >> 1); t += PIPE_BLOCK) {
                     int lo = ((t / st) * st * 2) + (t % st);
                     int hi = lo + st;
                     bool up = ((lo & size) == 0);
@@ -1678,7 +1772,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 __syncthreads();
             }
         }
-        for (int i = tid; i < a.ef_cap; i += HNSW_BLOCK) W[i] = C[i];
+        for (int i = tid; i < a.ef_cap; i += PIPE_BLOCK) W[i] = C[i];
         __syncthreads();
     }
     const HnswArgs* ap = (const HnswArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1687,22 +1781,25 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
     const int kk = ap->k;
     const int outc = ws < kk ? ws : kk;
     uint64_t* const okeys = ap->out_keys;
-    for (int i = tid; i < kk; i += HNSW_BLOCK) okeys[(size_t)qi * kk + i] = i < outc ? W[i] : MDB_KEY_MAX;
+    for (int i = tid; i < kk; i += PIPE_BLOCK) okeys[(size_t)qi * kk + i] = i < outc ? W[i] : MDB_KEY_MAX;
+#ifdef MDB_PIPE_DBG
+    if (lane == 0 && wave < 2)
+        for (int i = 0; i < 12; ++i)
+            if (dbg_acc[i]) atomicAdd(&ap->counters[4 + i], dbg_acc[i]);
+#endif
     if (tid == 0) {
         ap->out_counts[qi] = (uint32_t)outc;
         misc[3] = overflow ? 1u : 0u;
         if (!overflow) {
             atomicAdd(&ap->counters[0], (unsigned long long)evals);
             atomicAdd(&ap->counters[1], (unsigned long long)expanded);
-            atomicAdd(&ap->counters[3], (unsigned long long)spec_hits);   // spare word: steps served by speculated distances
-#ifdef MDB_PIPE_DBG
-            for (int i = 0; i < 12; ++i) atomicAdd(&ap->counters[4 + i], dbg_acc[i]);
-#endif
             if (nan_seen) atomicOr(ap->flags, MDB_FLAG_NAN);
         }
     }
     __syncthreads();
-    if (misc[3]) {
+    // > ~120 exact distance ties with furthest overflow the 320-slot beam: the first four waves re-run the query with the
+    // general algorithm (sorted LDS sets); rows and counters come from that run
+    if (misc[3] && tid < HNSW_BLOCK) {
         const HnswArgs a2 = *ap;
         hnsw_general_traverse<METRIC, VIS_LDS, N16T>(a2, qi, lds, true);
     }
@@ -2030,7 +2127,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         if (lds > 48 * 1024)                                                                                                \
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_pipe_kernel<METRIC, VL, NF>,                                 \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hnsw_pipe_kernel<METRIC, VL, NF><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                           \
+        hnsw_pipe_kernel<METRIC, VL, NF><<<dim3((unsigned)b), PIPE_BLOCK, lds, ctx->stream>>>(a);                           \
     } while (0)
 #define MDB_HNSW_LAUNCH(METRIC, VL)                                                                              \
     do {                                                                                                           \
@@ -2080,8 +2177,9 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     }
     // ef <= 256: register-resident beam; above: sorted LDS sets (MDB_HNSW_NO_BEAM forces the latter, for tests)
     const bool beam = ef <= 256 && !getenv("MDB_HNSW_NO_BEAM");
-    // software-pipelined traversal (hnsw_pipe_kernel): whole-vector 16-lane chunks, rows of at most 64 edges
-    const bool pipe = beam && (nf == 8 || nf == 48) && max_stride <= 64 && !getenv("MDB_HNSW_NO_PIPE");
+    // software-pipelined traversal (hnsw_pipe_kernel): whole-vector 16-lane chunks, rows of at most 64 edges.  Same rows and
+    // counters as hnsw_beam_kernel (tests run both); OPT-IN (MDB_HNSW_PIPE=1) while it is the slower of the two on the C2 workload.
+    const bool pipe = beam && (nf == 8 || nf == 48) && max_stride <= 64 && getenv("MDB_HNSW_PIPE");
     if (metric == MDB_METRIC_L2) {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false);
     } else {

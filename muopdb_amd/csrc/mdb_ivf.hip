@@ -928,7 +928,8 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
         // path (sample bound + matrix-core filter + exact refine) — the same probe ids, several times faster
         if (U == 1 && blobs[0].num_clusters >= 65536) {
             TileView cv{d_cent_tiles.p, blobs[0].num_clusters, (blobs[0].num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
-            MDB_TRY(flat_build_aux(ctx, cv, cent_aux, (cv.n / MDB_TILE) / 8));
+            static const size_t sdiv = getenv("MDB_IVF_COARSE_SAMPLE_DIV") ? (size_t)std::max(1, atoi(getenv("MDB_IVF_COARSE_SAMPLE_DIV"))) : 8;
+            MDB_TRY(flat_build_aux(ctx, cv, cent_aux, (cv.n / MDB_TILE) / sdiv, MDB_METRIC_L2, true));
         }
     }
     mdb_status st = mdb_check_flags(ctx);  // synchronises: temporaries may now be released

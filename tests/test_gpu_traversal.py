@@ -163,6 +163,35 @@ def test_hnsw_general_kernel_equals_beam_kernel(ctx, oracle):
     assert_result_rows(g.ann_search(q, 10, 600), o.ann_search(q, 10, 600), len(q))
 
 
+@pytest.mark.parametrize("d,metric", [(128, 0), (768, 1), (128, 1)])
+def test_hnsw_pipelined_kernel_equals_oracle(ctx, oracle, d, metric):
+    """hnsw_pipe_kernel (MDB_HNSW_PIPE=1: the traversal software-pipelined over six waves, tentative visited updates undone on
+    a wrong guess) must give the oracle's rows AND counters — no speculative evaluation may be counted, no tentative
+    visited bit may survive."""
+    import os
+    from muopdb_amd.index import BlockBasedHnsw, NoQuantizer
+    rng = np.random.default_rng(31)
+    n = 3000
+    v = H.sift_like(n, d, n_clusters=24, seed=6)
+    if metric == 1:
+        v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    hidx, hvec = H.build_hnsw_files(oracle, v, list(range(n)), max_neighbors=12, max_layers=4, ef_construction=60, metric=metric)
+    g = BlockBasedHnsw(ctx, hidx, hvec, d, NoQuantizer(d, metric))
+    o = oracle.BlockBasedHnsw(hidx, hvec, d, oracle.Quant(oracle.QUANT_NONE, metric))
+    q = (v[rng.integers(0, n, 40)] + rng.normal(0, 0.05 if metric == 1 else 4, (40, d))).astype(np.float32)
+    os.environ["MDB_HNSW_PIPE"] = "1"
+    try:
+        for k, ef in [(10, 100), (5, 8), (20, 256), (10, 1), (10, 40)]:
+            want = o.ann_search(q, k, ef)
+            evals, expanded = o.stats()
+            got = g.ann_search(q, k, ef)
+            st = ctx.stats()
+            assert_result_rows(got, want, len(q))
+            assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded), (k, ef)
+    finally:
+        del os.environ["MDB_HNSW_PIPE"]
+
+
 def test_hnsw_beam_overflow_falls_back_to_general_kernel(ctx, oracle):
     """Hundreds of exact distance ties with `furthest` overflow the 320-slot register beam; those queries are
     re-run by the general kernel inside the same call — rows and counters still equal the oracle's."""
