@@ -34,8 +34,8 @@ struct mdb_ctx {
     bool dev_counters = true;      // false: the last call used no device counters (flat scans): mdb_get_stats reports zeros, no memset launch
     uint64_t stat_bytes_per_eval = 0, stat_bytes_per_scored = 0, stat_fixed_bytes = 0;
     // growable device scratch (never shrinks; no allocation in steady state)
-    void* scratch[12] = {nullptr};
-    size_t scratch_cap[12] = {0};
+    void* scratch[16] = {nullptr};
+    size_t scratch_cap[16] = {0};
     // optional HIP-event timing of the dominant kernel of each search call (mdb_set_profiling)
     bool prof_on = false;
     int prof_mask = 3;   // MDB_PROF_SCAN | MDB_PROF_HNSW: which kernel classes are bracketed

@@ -124,7 +124,7 @@ void mdb_ctx_release(mdb_ctx* ctx) {
     if (ctx->refs.fetch_sub(1) != 1) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 12; ++i)
+    for (size_t i = 0; i < sizeof(ctx->scratch) / sizeof(ctx->scratch[0]); ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);

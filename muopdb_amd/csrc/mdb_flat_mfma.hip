@@ -77,6 +77,7 @@ FlatAux::~FlatAux() {
 
 void flat_aux_view(const FlatAux& src, FlatAux& dst) {
     dst.sample.data.borrow(src.sample.data);
+    dst.sample_stride = src.sample_stride;
     dst.sample.n = src.sample.n; dst.sample.ntiles = src.sample.ntiles; dst.sample.d = src.sample.d; dst.sample.d4 = src.sample.d4;
     dst.ctiles.borrow(src.ctiles);
     dst.mean.borrow(src.mean);
@@ -182,6 +183,7 @@ mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t 
     size_t stride = full / want;
     size_t stiles = (full - 1) / stride + 1;
     TileStore& out = aux.sample;
+    aux.sample_stride = stride;
     out.d = v.d;
     out.d4 = v.d4;
     out.ntiles = stiles;
@@ -257,7 +259,9 @@ __global__ __launch_bounds__(128) void mfma_prep_kernel(const float* __restrict_
     if (threadIdx.x) return;
     float qn = red[0];
     float c = __uint_as_float(0x7F800000u);  // +inf: padded rows never admit anything
-    if (m < b) {
+    if (m < b && !skeys) {
+        c = qn;  // bf16 route: the bound comes from flat_bf16 sample kernels, which need the norm first (sample_bound_kernel finishes crow)
+    } else if (m < b) {
         if (scounts[m] < (uint32_t)k || !(qn < __uint_as_float(0x7F800000u))) {
             c = -__uint_as_float(0x7F800000u);  // no bound: everything is a candidate (-> overflow -> exact scan)
         } else {
@@ -270,6 +274,91 @@ __global__ __launch_bounds__(128) void mfma_prep_kernel(const float* __restrict_
             }
             c -= fabsf(c) * 4e-6f + 1e-30f;  // round the admission bound down
         }
+    }
+    crow[m] = c;
+}
+
+// ------------------------------------------------------------------------------------------ sample bound (bf16 route)
+// U[m][i] >= the reference distance (squared L2 / negated dot) of query m to sample row i (flat_bf16_filter_kernel<.., SMP>:
+// the matrix-core approximation plus its error budget).  Any value with at least k entries of U[m][.] at or below it therefore
+// bounds the k-th smallest exact distance of the sample, hence of the base: it replaces the exact top-k scan of the sample
+// (the largest kernel of a 4096-query coarse search).  One block per query: the row is cut into SB_SUB strided subsets, each
+// thread keeps the minima of its four subsets in registers (one coalesced pass over the row), and the k-th smallest MINIMUM
+// — k distinct entries at or below it — is found by a radix select on the order-preserving integer images (k <= SB_SUB / 4:
+// at most ~15 % of the top-k share a subset, so the bound sits within a few ranks of the exact k-th).  Then the admission
+// constant exactly as mfma_prep_kernel derives it from an exact bound.
+#define SB_SUB 1024
+__global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restrict__ U, uint32_t ns, int k, float kappa, int metric,
+                                                           float* __restrict__ crow) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh_prefix, sh_need;
+    const size_t m = blockIdx.x;
+    const float* __restrict__ row = U + m * (size_t)ns;
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t mn[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // an empty subset never counts
+    for (uint32_t i0 = 0; i0 < ns; i0 += 4 * SB_SUB) {   // 16 independent loads in flight per thread
+        float v[4][4];
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const uint32_t i = i0 + SB_SUB * y + 256 * x + tid;
+                v[y][x] = i < ns ? row[i] : __uint_as_float(0x7FFFFFFFu);   // image 0xFFFFFFFF: counts as empty
+            }
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) mn[x] = min(mn[x], f32_orderable(v[y][x]));
+    }
+    uint32_t prefix = 0, need = (uint32_t)k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            if (mn[x] != 0xFFFFFFFFu && (pass == 0 || (mn[x] >> (shift + 8)) == prefix)) atomicAdd(&hist[(mn[x] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < 64) {  // first digit whose cumulative count reaches `need`
+            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const uint32_t sum = h0 + h1 + h2 + h3;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const unsigned long long reach = __ballot(incl >= need);
+            if (reach == 0) {   // fewer than k subsets hold a value (ns < k or NaN-only rows): no bound
+                if (lane == 0) { sh_prefix = 0xFFFFFFFFu; sh_need = 0; }
+            } else {
+                const int first = __ffsll((long long)reach) - 1;
+                if (lane == first) {
+                    uint32_t before = incl - sum, d = 0;
+                    if (before + h0 >= need) d = 0;
+                    else if (before + h0 + h1 >= need) { d = 1; before += h0; }
+                    else if (before + h0 + h1 + h2 >= need) { d = 2; before += h0 + h1; }
+                    else { d = 3; before += h0 + h1 + h2; }
+                    sh_prefix = (prefix << 8) | (4u * lane + d);
+                    sh_need = need - before;
+                }
+            }
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        need = sh_need;
+        if (need == 0) break;   // (uniform) no bound
+    }
+    if (tid) return;
+    const float qn = crow[m];                        // mfma_prep_kernel left the norm here
+    const float t = f32_from_orderable(prefix);      // the k-th smallest bound
+    float c;
+    if (!(qn < __uint_as_float(0x7F800000u)) || !(t < __uint_as_float(0x7F800000u))) {
+        c = -__uint_as_float(0x7F800000u);           // no bound: everything is a candidate (-> overflow -> exact scan)
+    } else {
+        if (metric == MDB_METRIC_L2) c = (qn * (1.0f - kappa) - t * (1.0f + 2e-6f)) * 0.5f;
+        else c = -t - kappa * qn * 0.5f;
+        c -= fabsf(c) * 4e-6f + 1e-30f;              // round the admission bound down
     }
     crow[m] = c;
 }
@@ -461,13 +550,19 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
 // A fragments (queries, 32 rows x 16 dims per MFMA) live in LDS, converted once per block; B fragments stream from the
 // precomputed split (coalesced 16-byte loads, one k-chunk ahead of the matrix cores).  grid (nblk, query groups of 32 * QB).
 #define BF_LBUF (4 * WS_CAP)   // candidate pairs staged per block (8 KB: two QB = 4 blocks fit one CU's LDS)
-template <int METRIC, int QB, int NKT>   // NKT: compile-time number of 16-dim chunks (8 = d <= 128: LDS offsets become immediates), 0 = run time
+// SMP: the same products over the SAMPLE's tiles (every smp_stride-th 64-vector tile of the base: 32-vector tile t' of the
+// sample is tile (t' / 2) * 2 smp_stride + (t' & 1) of the split), and instead of the admission test the epilogue stores
+// U[m][t' * 32 + column] = approximate distance + its error budget (crow[m] holds the query's norm at that point):
+//   L2 : qn + xn - 2 acc + kappa (qn + xn)        dot: -acc + kappa (qn + xn) / 2
+// `qids` is U (as floats), `qcap` the sample size, `nt32` the sample's tile count.
+template <int METRIC, int QB, int NKT, bool SMP = false>   // NKT: compile-time number of 16-dim chunks (8 = d <= 128: LDS offsets become immediates), 0 = run time
 __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kernel(
     const uint4* __restrict__ bhi, const uint4* __restrict__ blo, const float* __restrict__ xnorm, size_t n, size_t nt32, int nk_rt,
     const float* __restrict__ dqc, int qstride, const float* __restrict__ crow, float kappa, uint32_t* __restrict__ qcnt,
-    uint32_t* __restrict__ qids, uint32_t qcap, size_t b, uint32_t* __restrict__ flags) {
+    uint32_t* __restrict__ qids, uint32_t qcap, size_t b, uint32_t* __restrict__ flags, size_t smp_stride) {
     constexpr int BQ = 32 * QB;
     const int nk = NKT ? NKT : nk_rt;
+    auto base_tile = [&](size_t t) -> size_t { return SMP ? (t >> 1) * 2 * smp_stride + (t & 1) : t; };
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint4* Ahi = (uint4*)lds;                         // [QB][nk][64]
     uint4* Alo = Ahi + (size_t)QB * nk * 64;
@@ -496,8 +591,8 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
     // base, slower on an HBM-resident one — 128 more registers halve the occupancy)
     uint4 ch, cl, nh, nl;   // current / next fragment pair
     if (t < nt32) {
-        ch = bhi[(t * nk) * 64 + lane];
-        cl = blo[(t * nk) * 64 + lane];
+        ch = bhi[(base_tile(t) * nk) * 64 + lane];
+        cl = blo[(base_tile(t) * nk) * 64 + lane];
     }
     auto mma_chunk = [&](const uint4& xh_, const uint4& xl_, int kc) {
         // the A fragments are loop invariant: without the barrier the compiler hoists all QB * nk * 2 LDS loads out of the tile
@@ -528,6 +623,24 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
     auto epilogue = [&](size_t t, float xnh) {
         // epilogue: D[i][j], column j = lane & 31 (vector), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query)
         const size_t v = t * 32 + l31;
+        if (SMP) {
+            float* __restrict__ U = (float*)qids;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float4* c4 = (const float4*)(Cr + qb * 32 + 4 * hi);
+                const float4 t0 = c4[0], t1 = c4[2], t2 = c4[4], t3 = c4[6];
+                const float qnr[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const size_t m = q0 + (size_t)(qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                    const float nn = qnr[r] + xnh;
+                    const float u = METRIC == MDB_METRIC_L2 ? (nn - 2.0f * acc[qb][r]) + kappa * nn : kappa * 0.5f * nn - acc[qb][r];
+                    if (m < b) U[m * (size_t)qcap + v] = u;
+                }
+            }
+            return;
+        }
         const float xh = METRIC == MDB_METRIC_L2 ? xnh * (0.5f - kappa) : -kappa * xnh;
         const bool force = !(xnh < __uint_as_float(0x7F800000u));   // infinite / NaN norm: admitted for every query
         // the admission constants are re-read from LDS for every tile, behind a compiler barrier: hoisted out of the tile
@@ -560,11 +673,11 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
     while (t < nt32) {
         zero_acc();
         const size_t tn = t + tstep;
-        const float xnt = xnorm[t * 32 + l31];   // issued ahead of the tile's prefetches: vmcnt counts in order
+        const float xnt = xnorm[base_tile(t) * 32 + l31];   // issued ahead of the tile's prefetches: vmcnt counts in order
         for (int kc = 0; kc < nk; ++kc) {
             // prefetch the next fragment pair (the next tile's first when this is the last chunk)
             const bool last = kc + 1 == nk;
-            const size_t pt = last ? (tn < nt32 ? tn : t) : t;
+            const size_t pt = base_tile(last ? (tn < nt32 ? tn : t) : t);
             const size_t po = (pt * nk + (last ? 0 : kc + 1)) * 64 + lane;
             nh = bhi[po];
             nl = blo[po];
@@ -577,7 +690,7 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
         epilogue(t, xnt);
         t = tn;
     }
-    ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane);
+    if (!SMP) ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane);
 }
 
 // ------------------------------------------------------------------------------------------ refine
@@ -681,8 +794,13 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     while (qcap > 512 && bpadq * (size_t)qcap * 4 > ((size_t)1 << 30)) qcap /= 2;
     uint32_t* qids;
     MDB_TRY(mdb_scratch(ctx, 9, bpadq * (size_t)qcap * 4, (void**)&qids));
-    // A. sample top-k (exact)
-    MDB_TRY(flat_topk_keys(ctx, view_of(aux.sample), metric, dq, qstride, b, k, skeys, scounts, false));
+    // A. bound of the k-th distance from the sample: its exact top-k (f32 route), or the k-th smallest of matrix-core upper
+    //    bounds (bf16 route: no exact pass over the sample at all — the U matrix must fit 1 GiB, else the exact sample scan)
+    const size_t ns = aux.sample.n;
+    const bool smp_bf16 = use_bf16 && aux.sample_stride && k <= SB_SUB / 4 && b * ns * 4 <= ((size_t)1 << 30) && !getenv("MDB_BF_EXACT_SAMPLE");
+    float* umat = nullptr;
+    if (smp_bf16) MDB_TRY(mdb_scratch(ctx, 12, b * ns * 4, (void**)&umat));
+    else MDB_TRY(flat_topk_keys(ctx, view_of(aux.sample), metric, dq, qstride, b, k, skeys, scounts, false));
     // error budget of the filter, eps = 2^-24, all norms of the centred operands:
     //   centring (eps per component)            : |a' - ||q-x||^2| <= 4 eps (qn + xn)
     //   reference association vs real arithmetic: s_ref >= s* (1 - (d+2) eps)  -> 2(d+3) eps (qn + xn)
@@ -693,8 +811,40 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     const float kappa = 6.0f * (float)(ts.d4 * 4 + 4) * 5.9604645e-8f +
                         (use_bf16 ? 4.0f * (float)(aux.nk * 16) * 5.9604645e-8f + 1.52587890625e-5f : 0.0f);
     MDB_HIP(ctx, hipMemsetAsync(qcnt, 0, bpadq * (size_t)QCNT_STRIDE * 4 + 256, ctx->stream));  // the queries' counters and ovf
-    mfma_prep_kernel<<<dim3((unsigned)bpadq), 128, 0, ctx->stream>>>(dq, qstride, ts.d, aux.mean.p, skeys, scounts, (int)k, kappa,
-                                                                    metric, b, dqc, crow);
+    mfma_prep_kernel<<<dim3((unsigned)bpadq), 128, 0, ctx->stream>>>(dq, qstride, ts.d, aux.mean.p, smp_bf16 ? nullptr : skeys, scounts, (int)k,
+                                                                    kappa, metric, b, dqc, crow);
+    if (smp_bf16) {
+        // the sample's products on the matrix cores -> U, then the k-th smallest bound per query -> crow (+ 8 eps: the roundings of
+        // the bound's own arithmetic)
+        const size_t snt32 = aux.sample.ntiles * 2;
+        const unsigned nblk_s = (unsigned)std::max<size_t>(1, std::min<size_t>((snt32 + 3) / 4, std::max<size_t>(1, 512 / groups)));
+        dim3 grids(nblk_s, (unsigned)groups);
+        const size_t ldss = (size_t)QB * aux.nk * 2048 + BQ * 4 + BF_LBUF * 8 + 64;
+        const float kappa_s = kappa + 8.0f * 5.9604645e-8f;
+#define BS_LAUNCH(METRIC, QBT, NKT)                                                                                          \
+    do {                                                                                                                     \
+        if (ldss > 48 * 1024)                                                                                                \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_bf16_filter_kernel<METRIC, QBT, NKT, true>,                   \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss));                       \
+        flat_bf16_filter_kernel<METRIC, QBT, NKT, true><<<grids, 256, ldss, ctx->stream>>>(                                   \
+            aux.bhi.p, aux.blo.p, aux.xnorm.p, ts.n, snt32, aux.nk, dqc, qstride, crow, kappa_s, nullptr, (uint32_t*)umat, (uint32_t)ns, b, \
+            ctx->d_flags, aux.sample_stride);                                                                                \
+    } while (0)
+#define BS_QB(METRIC, NKT)                                             \
+    do {                                                               \
+        if (QB == 8) BS_LAUNCH(METRIC, 8, NKT);                        \
+        else if (QB == 4) BS_LAUNCH(METRIC, 4, NKT);                   \
+        else if (QB == 2) BS_LAUNCH(METRIC, 2, NKT);                   \
+        else BS_LAUNCH(METRIC, 1, NKT);                                \
+    } while (0)
+        if (metric == MDB_METRIC_L2) { if (aux.nk == 8) BS_QB(MDB_METRIC_L2, 8); else BS_QB(MDB_METRIC_L2, 0); }
+        else { if (aux.nk == 8) BS_QB(MDB_METRIC_DOT, 8); else BS_QB(MDB_METRIC_DOT, 0); }
+#undef BS_QB
+#undef BS_LAUNCH
+        MDB_HIP(ctx, hipGetLastError());
+        sample_bound_kernel<<<dim3((unsigned)b), 256, 0, ctx->stream>>>(umat, (uint32_t)ns, (int)k, kappa, metric, crow);
+        MDB_HIP(ctx, hipGetLastError());
+    }
     // B. filter on the centred copy (L2) / the base itself (dot)
     const float4* ftiles = (metric == MDB_METRIC_L2) ? (const float4*)aux.ctiles.p : (const float4*)ts.data;
     if (!use_bf16 && metric == MDB_METRIC_L2 && !aux.ctiles.p) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "internal: no filter operand for this metric");
@@ -714,7 +864,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));               \
         flat_bf16_filter_kernel<METRIC, QBT, NKT><<<gridb, 256, ldsb, ctx->stream>>>(aux.bhi.p, aux.blo.p, aux.xnorm.p, ts.n, aux.nt32,    \
                                                                                      aux.nk, dqc, qstride, crow, kappa, qcnt, qids,       \
-                                                                                     qcap, b, ctx->d_flags);                              \
+                                                                                     qcap, b, ctx->d_flags, 0);                           \
     } while (0)
 #define BF_QB(METRIC, NKT)                                             \
     do {                                                               \

@@ -31,6 +31,7 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
 // empty for small stores); queries must be staged with bpad >= b rounded up to 64 rows.
 struct FlatAux {
     TileStore sample;        // every stride-th tile: its exact k-th distance bounds the base's
+    size_t sample_stride = 0;  // sample tile i is base tile i * sample_stride
     DevBuf<float> ctiles;    // mean-centred copy of the base in the same tile layout (f32 filter operand; only when the bf16 split is not used)
     DevBuf<float> mean;      // [d4*4]
     // bf16 x 3 filter operands: the (centred) base split into hi = bf16(x'), lo = bf16(x' - hi), laid out as
