@@ -336,15 +336,18 @@ def run_flat(env, n=None, batch=None):
     out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec,
                config={"workload": "flat brute-force L2 %dx%d f32 (%s), batch=%d, top-%d (row-sharded x%d)" % (n, d, desc, batch, k, world),
                        "n": n, "dim": d, "batch": batch, "k": k, "index": "flat", "data": args.data},
-               roofline=hbm_roofline("flat_mfma_filter_kernel" if batched else "flat_scan_kernel", abytes, kernel_ms, launches))
-    if batched:  # the filter is also on the f32-MFMA ridge: 2*B*N*d flop per launch against 157.3 TFLOP/s
-        groups = (batch + 63) // 64
+               roofline=hbm_roofline("flat_bf16_filter_kernel" if batched else "flat_scan_kernel", abytes, kernel_ms, launches))
+    if batched:
+        # the filter streams the bf16 hi/lo split of the base (2 + 2 bytes per element: the base's own size) once per group of
+        # 32 QB queries (QB = 1 / 2 / 4 for batches up to 32 / 64 / more) and issues three bf16 MFMA products per element pair
+        qb = 4 if batch > 64 else 2 if batch > 32 else 1
+        groups = (batch + 32 * qb - 1) // (32 * qb)
         r = out["roofline"]
-        r["bytes_per_launch"] = abytes * groups  # one pass over the base per 64 queries
+        r["bytes_per_launch"] = abytes * groups
         r["achieved"] *= groups
         r["frac"] = r["achieved"] / HBM_PEAK_GBS
-        r["mfma_tflops"] = 2.0 * batch * (hi - lo) * d / (r["kernel_ms"] * 1e-3) / 1e12
-        r["mfma_frac_of_f32_peak"] = r["mfma_tflops"] / 157.3
+        r["mfma_tflops"] = 3 * 2.0 * batch * (hi - lo) * d / (r["kernel_ms"] * 1e-3) / 1e12
+        r["mfma_frac_of_bf16_peak"] = r["mfma_tflops"] / 2500.0
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("flat_b64" if batched else "flat", out["config"])
     if env.cpu:
         import oracle
