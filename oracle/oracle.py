@@ -261,6 +261,10 @@ class _Res:
         n = int(self.counts[qi])
         return [(int(self.hi[qi, i]) << 64) | int(self.lo[qi, i]) for i in range(n)]
 
+    def id_with_scores(self, qi):
+        """[(doc_id, score)] of row qi in IdWithScore order — the same accessor as muopdb_amd.index.SearchResult."""
+        return [(d, float(self.scores[qi, i])) for i, d in enumerate(self.doc_ids(qi))]
+
 
 def _split(doc_id):
     return C.c_uint64(doc_id & 0xFFFFFFFFFFFFFFFF), C.c_uint64(doc_id >> 64)

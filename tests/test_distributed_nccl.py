@@ -96,15 +96,20 @@ def _worker(rank, world, port, out):
         if rccl is not None:
             class UniqueId(C.Structure):
                 _fields_ = [("internal", C.c_char * 128)]
+            rccl.ncclGetLastError.restype = C.c_char_p
+            rccl.ncclGetLastError.argtypes = [C.c_void_p]
             uid = UniqueId()
             if rank == 0:
-                check(rccl.ncclGetUniqueId(C.byref(uid)) == 0, "ncclGetUniqueId")
-            box = [bytes(uid.internal)] if rank == 0 else [None]
+                rc = rccl.ncclGetUniqueId(C.byref(uid))
+                check(rc == 0, "ncclGetUniqueId rc=%d %r" % (rc, rccl.ncclGetLastError(None)))
+            box = [C.string_at(C.byref(uid), 128)] if rank == 0 else [None]     # (bytes(uid.internal) would stop at the first NUL)
             dist.broadcast_object_list(box, src=0)
             C.memmove(C.byref(uid), box[0], 128)
             comm = C.c_void_p()
             rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-            check(rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0, "ncclCommInitRank")
+            rccl.ncclCommInitRank.restype = C.c_int
+            rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+            check(rc == 0, "ncclCommInitRank rc=%d %r" % (rc, rccl.ncclGetLastError(None)))
             recv = torch.zeros(world * D.block_bytes(b, k), dtype=torch.uint8, device=dev)
             o_docs, o_sc, o_cn = torch.zeros_like(docs), torch.zeros_like(scores), torch.zeros_like(counts)
             torch.cuda.synchronize()
