@@ -101,6 +101,7 @@ def parse():
     p.add_argument("--max-neighbors", type=int, default=32)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-sweep", action="store_true")
+    p.add_argument("--no-c5", action="store_true", help="all: skip the C5 per-GPU shard workload (~50 s of build)")
     p.add_argument("--streams", type=int, default=4, help="hnsw: extra measurement with this many batches in flight (0/1 = skip)")
     p.add_argument("--dump-dir", default=None, help="write index files + queries for examples/replay_search.cpp")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -444,6 +445,39 @@ def run_ivfpq(env):
                roofline=hbm_roofline("ivf_scan_pq2_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ivfpq", out["config"])
+    if args.streams > 1 and world == 1:
+        # Extra: the same batches round-robin on several HIP streams, each through its own handle ATTACHED to the one resident
+        # index (mdb_ivf_attach: shared posting lists / tombstones, own scratch + stream) — several batches in flight.
+        from muopdb_amd import lib as L
+        lanes = []
+        for _ in range(args.streams):
+            st_ = torch.cuda.Stream()
+            c_ = L.Context(torch.cuda.current_device()); c_.set_stream(st_.cuda_stream)
+            lanes.append((st_, c_, ivf.attach(c_), torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda"),
+                          torch.zeros((batch, k), dtype=torch.float32, device="cuda"), torch.zeros(batch, dtype=torch.int32, device="cuda")))
+        torch.cuda.synchronize()
+
+        def cstep(i):
+            _, c_, h_, i_, s_, n_ = lanes[i % len(lanes)]
+            q = queries[i * batch:(i + 1) * batch]
+            c_.check(c_.lib.mdb_ivf_search(h_.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch), None, C.c_size_t(P), C.c_size_t(k),
+                                           C.c_int(L.MEM_DEVICE), C.c_void_p(i_.data_ptr()), C.c_void_p(s_.data_ptr()), C.c_void_p(n_.data_ptr())))
+
+        for i in range(warm):
+            cstep(i)
+        env.barrier()
+        t0 = time.perf_counter()
+        for i in range(warm, warm + steps):
+            cstep(i)
+        env.barrier()
+        el = time.perf_counter() - t0
+        same = True
+        for i in range(max(warm, warm + steps - len(lanes)), warm + steps):  # last batch of every lane vs the serial run
+            same &= bool(np.array_equal(lanes[i % len(lanes)][3][:, :, 0].cpu().numpy(), m["found"][(i - warm) * batch:(i - warm + 1) * batch]))
+        out["concurrent"] = dict(streams=args.streams, value=steps * batch / el, ms_per_step=1000 * el / steps, ids_equal_serial=same,
+                                 note="same batches, several in flight on handles attached to ONE resident index; not the workload's value")
+        for lane_ in lanes:
+            lane_[2].close(); lane_[1].close()
     if not args.no_sweep:
         sweep = []
         for p in (1, 8, 16, 32, 64):
@@ -467,7 +501,7 @@ def run_ivfpq(env):
     return out
 
 
-def run_c5(env):
+def run_c5(env, steps=None, warm=None):
     """BASELINE config C5 as ONE GPU of the 8 sees it: rank 0's shard (posting lists l % 8 == 0) of a 100M x 128 index
     stored as 16-byte PQ codes, the FULL coarse quantizer (65 536 centroids, replicated), nprobe 64, batch 4096."""
     from muopdb_amd import build as B, synth as S
@@ -475,7 +509,7 @@ def run_c5(env):
     args, ctx = env.args, env.ctx
     batch = args.batch or 4096
     k, P = args.k, args.nprobe or 64
-    steps, warm = args.steps, args.warmup
+    steps, warm = steps or args.steps, args.warmup if warm is None else warm
     total = args.n or 100_000_000
     t0 = time.time()
     sh = S.c5_shard(ctx, total=total, world=8, rank=0, nlist=args.nlist or 65536, log=log)
@@ -491,6 +525,7 @@ def run_c5(env):
                        "n": sh["n"], "dim": 128, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": "lowrank"},
                roofline=hbm_roofline("ivf_scan_pq2_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
+    out["steps"], out["warmup"] = steps, warm
     out["recall_note"] = "a shard's rows are a partial result (1/8 of the probed lists): recall is defined after the all-gather merge only"
     if env.cpu:
         import oracle
@@ -665,12 +700,16 @@ def main():
         extra = {}
         plan = [("flat_1m_b1", lambda: run_flat(env, n=1_000_000, batch=1)), ("flat_1m_b64", lambda: run_flat(env, n=1_000_000, batch=64)),
                 ("ivfpq_c3", lambda: run_ivfpq(env)), ("spann_c4_128u", lambda: run_spann(env, users=128))]
+        if world == 1 and not args.no_c5:  # one GPU's share of C5 (a 1/8 shard of 100M x 16-byte codes: ~50 s of build)
+            plan.append(("c5_shard_per_gpu", lambda: run_c5(env, steps=min(args.steps, 8), warm=min(args.warmup, 2))))
         for name, fn in plan:
             t0 = time.time()
             try:  # a failing extra workload must never take the headline line with it
                 torch.cuda.empty_cache()
                 w = fn()
-                w.update(unit="queries/s", steps=args.steps, warmup=args.warmup, scaling=w.get("scaling", "weak"))
+                w.update(unit="queries/s", scaling=w.get("scaling", "weak"))
+                w.setdefault("steps", args.steps)
+                w.setdefault("warmup", args.warmup)
                 extra[name] = w
             except Exception as e:  # noqa: BLE001
                 extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}

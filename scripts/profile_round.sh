@@ -1,0 +1,50 @@
+#!/bin/bash
+# Round profile set (run on the GPU box through gpurun): for every bench workload
+#   pass 1  rocprofv3 --kernel-trace --stats over bench.py itself (per-kernel average duration; C5: over the torch-free replay —
+#           tracing the 100M-row shard build under rocprofv3 takes longer than the box allows)
+#   pass 2/3 rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, each in its own run, over the torch-free replay of the dumped files
+#           (examples/replay_search.cpp): counter mode crashes inside torch's own kernels on this image.  --pmc is never combined
+#           with sys / runtime trace flags.
+# Output: gpurun_out/<tag>/<workload>_{kernel_stats.csv,pmc_FETCH_SIZE.csv,pmc_WRITE_SIZE.csv,replay.log} + bench_all.json;
+# the ones to be judged are copied to profiles/ by hand.
+# usage: scripts/profile_round.sh <tag> [workloads...]   (default: hnsw flat_b1 flat_b64 ivfpq spann c5)
+TAG=$1; shift
+WL="$@"; [ -z "$WL" ] && WL="hnsw flat_b1 flat_b64 ivfpq spann c5"
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/$TAG
+DUMP=/tmp/mdb_dump_round
+PAT="hnsw_|flat_scan|flat_mfma|flat_bf16|flat_refine|sample_bound|ivf_scan|merge_keys"
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# every workload's files + the un-instrumented bench line
+(time timeout 900 python $REPO/bench.py --steps 20 --warmup 5 --dump-dir $DUMP) > $OUT/bench_all.json 2> $OUT/bench_all.err
+for W in $WL; do
+  case $W in
+    hnsw)     SUB=hnsw;     REPLAY="hnsw $DUMP/hnsw 128 10 200 64 20";        BARGS="--workload hnsw --streams 0";;
+    flat_b1)  SUB=flat_b1;  REPLAY="flat $DUMP/flat_b1 128 10 0 1 20";        BARGS="--workload flat --n 1000000 --batch 1";;
+    flat_b64) SUB=flat_b64; REPLAY="flat $DUMP/flat_b64 128 10 0 64 20";      BARGS="--workload flat --n 1000000 --batch 64";;
+    ivfpq)    SUB=ivfpq;    REPLAY="ivfpq $DUMP/ivfpq 128 10 16 256 20";      BARGS="--workload ivfpq --no-sweep --streams 0";;
+    spann)    SUB=spann;    REPLAY="mspann $DUMP/spann 768 10 16 128 20 200"; BARGS="--workload spann --users 128 --no-sweep";;
+    c5)       SUB=c5;       REPLAY="ivfpq $DUMP/c5 128 10 64 4096 6";         BARGS="";;
+  esac
+  if [ -n "$BARGS" ]; then
+    rm -rf /tmp/prof_stats_$W
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$W -o bench -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline $BARGS > $OUT/${W}_bench_stats.log 2>&1
+    cp /tmp/prof_stats_$W/*kernel_stats.csv $OUT/${W}_kernel_stats.csv 2>/dev/null
+  fi
+  $REPO/muopdb_amd/replay_search $REPLAY > $OUT/${W}_replay.log 2>&1
+  if [ -z "$BARGS" ]; then
+    rm -rf /tmp/prof_stats_$W
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$W -o replay -- $REPO/muopdb_amd/replay_search $REPLAY > $OUT/${W}_replay_stats.log 2>&1
+    cp /tmp/prof_stats_$W/*kernel_stats.csv $OUT/${W}_kernel_stats.csv 2>/dev/null
+  fi
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/prof_${C}_$W
+    timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_${C}_$W -o replay -- $REPO/muopdb_amd/replay_search $REPLAY > $OUT/${W}_replay_$C.log 2>&1
+    echo "rc=$?" >> $OUT/${W}_replay_$C.log
+    for f in /tmp/prof_${C}_$W/*counter_collection.csv; do [ -f "$f" ] && (head -1 $f; grep -E "$PAT" $f | head -400) > $OUT/${W}_pmc_$C.csv; done
+  done
+  echo "== $W: $(tail -1 $OUT/${W}_replay.log)"
+done
+rm -rf $DUMP
+du -sh $OUT; ls $OUT | head -60
