@@ -526,6 +526,7 @@ def run_c5(env, steps=None, warm=None):
                roofline=hbm_roofline("ivf_scan_pq2_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
     out["steps"], out["warmup"] = steps, warm
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("c5", out["config"])
     out["recall_note"] = "a shard's rows are a partial result (1/8 of the probed lists): recall is defined after the all-gather merge only"
     if env.cpu:
         import oracle

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""gpurun_out/<tag>/ (scripts/profile_round.sh) -> profiles/r<NN>_*: per-workload kernel_stats (our kernels + the top rows), the
+PMC passes as collected, r<NN>_traffic.json (per-launch FETCH_SIZE / WRITE_SIZE averages of the dominant kernel, KiB) and the
+un-instrumented bench line.  usage: summarize_profiles.py <tag> <round, e.g. r02>"""
+import csv, json, os, shutil, sys
+
+tag, rnd = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+OURS = ("hnsw_", "flat_", "sample_bound", "ivf_", "merge_", "remap_", "spann_", "pq_quantize", "mfma_prep", "unpack_", "kmeans_")
+WL = {  # workload -> (dominant kernel prefix, bench.py traffic key, config match)
+    "hnsw": ("hnsw_beam_kernel", "hnsw", {"n": 1000000, "dim": 128, "batch": 64, "ef": 200, "k": 10}),
+    "flat_b1": ("flat_scan_kernel", "flat", {"n": 1000000, "dim": 128, "batch": 1, "k": 10}),
+    "flat_b64": ("flat_bf16_filter_kernel<0, 2, 8, false>", "flat_b64", {"n": 1000000, "dim": 128, "batch": 64, "k": 10}),
+    "ivfpq": ("ivf_scan_pq2_kernel", "ivfpq", {"n": 1000000, "dim": 128, "batch": 256, "k": 10, "nprobe": 16}),
+    "spann": ("ivf_scan_f32_kernel", "spann", {"n": 1250048, "dim": 768, "batch": 128, "k": 10}),
+    "c5": ("ivf_scan_pq2_kernel", "c5", {"dim": 128, "batch": 4096, "k": 10, "nprobe": 64}),
+}
+bench = json.loads(open(os.path.join(src, "bench_all.json")).read().strip().splitlines()[-1])
+shutil.copy(os.path.join(src, "bench_all.json"), os.path.join(dst, "%s_bench_all.json" % rnd))
+lines = {"hnsw": bench}
+for k, v in bench.get("workloads", {}).items():
+    lines[{"flat_1m_b1": "flat_b1", "flat_1m_b64": "flat_b64", "ivfpq_c3": "ivfpq", "spann_c4_128u": "spann", "c5_shard_per_gpu": "c5"}.get(k, k)] = v
+traffic = {"_note": "HBM traffic per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the torch-free "
+                    "replay of the same files (examples/replay_search.cpp, scripts/profile_round.sh); counters in KiB; gfx950 correction per "
+                    "MI355X_MICROARCH.md: FETCH_SIZE x2 (calibrated on the flat scan: 512.0 MB algorithmic).  bench.py reports `traffic` from this "
+                    "file only when its config matches `match`."}
+summary = {}
+for w, (kern, key, match) in WL.items():
+    ks = os.path.join(src, "%s_kernel_stats.csv" % w)
+    if not os.path.exists(ks):
+        continue
+    rows = list(csv.DictReader(open(ks)))
+    keep = [r for i, r in enumerate(rows) if i < 12 or r["Name"].replace("void ", "").startswith(OURS)]
+    with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, w)), "w", newline="") as f:
+        wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        wr.writeheader()
+        wr.writerows(keep)
+    dom = [r for r in rows if kern in r["Name"]]
+    avg_ms = float(dom[0]["AverageNs"]) / 1e6 if dom else None
+    vals = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        pf = os.path.join(src, "%s_pmc_%s.csv" % (w, c))
+        if not os.path.exists(pf):
+            continue
+        shutil.copy(pf, os.path.join(dst, "%s_%s_pmc_%s.csv" % (rnd, w, c)))
+        per = {}
+        for r in csv.DictReader(open(pf)):
+            if kern in r["Kernel_Name"] and r["Counter_Name"] == c:
+                per.setdefault(r["Dispatch_Id"], 0.0)
+                per[r["Dispatch_Id"]] += float(r["Counter_Value"])   # one row per XCD / dimension instance: sum per dispatch
+        disp = sorted(per.items(), key=lambda kv: int(kv[0]))[1:]     # skip the warm-up call
+        vals[c] = sum(v for _, v in disp) / max(len(disp), 1)
+    rp = os.path.join(src, "%s_replay.log" % w)
+    if os.path.exists(rp):
+        shutil.copy(rp, os.path.join(dst, "%s_%s_replay.log" % (rnd, w)))
+    cfg = lines.get(w, {}).get("config", {})
+    m = dict(match, data=cfg.get("data", "lowrank"))
+    if w in ("spann", "c5") and "n" in cfg:
+        m["n"] = cfg["n"]
+    if "FETCH_SIZE" in vals:
+        traffic[key] = {"match": m, "kernel": kern.split("<")[0], "fetch_kib": round(vals["FETCH_SIZE"], 1), "write_kib": round(vals.get("WRITE_SIZE", 0.0), 1),
+                        "fetch_correction": 2.0, "source": ["profiles/%s_%s_pmc_FETCH_SIZE.csv" % (rnd, w), "profiles/%s_%s_pmc_WRITE_SIZE.csv" % (rnd, w)]}
+    r = lines.get(w, {}).get("roofline", {})
+    summary[w] = dict(rocprof_avg_ms=avg_ms, bench_kernel_ms=r.get("kernel_ms"), bench_ms_per_step=lines.get(w, {}).get("ms_per_step"),
+                      algorithmic_bytes=r.get("bytes_per_launch"),
+                      measured_traffic_bytes=(vals.get("FETCH_SIZE", 0) * 2 + vals.get("WRITE_SIZE", 0)) * 1024 if vals else None)
+json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % rnd), "w"), indent=1)
+json.dump(summary, open(os.path.join(dst, "%s_summary.json" % rnd), "w"), indent=1)
+for w, s in summary.items():
+    print(w, {k: (round(v, 4) if isinstance(v, float) and v < 1e4 else v) for k, v in s.items()})
