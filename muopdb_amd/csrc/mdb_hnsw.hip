@@ -1134,13 +1134,16 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
 #define PIPE_LDS_MIR (PIPE_LDS_NB + 1024)    // candidate mirror: {cd, id}[320] (cd = distance image of an unexpanded slot, else EMPTY)
 #define PIPE_LDS_SPEC (PIPE_LDS_MIR + 2560)  // spec_od[2][64]: distance images by row position
 #define PIPE_LDS_MBOX (PIPE_LDS_SPEC + 512)  // 64 mailbox words (the first 32 are the snapshot)
-#define PIPE_LDS_QS (PIPE_LDS_MBOX + 256)
+#define PIPE_LDS_X (PIPE_LDS_MBOX + 256)     // cand[2][4] (uint4) | srow[2][64]
+#define PIPE_LDS_QS (PIPE_LDS_X + 640)
 #define PIPE_LDS_DTMP (BEAM_LDS_C + 5632)    // per distance wave: ids[32] | pos[32]; wave 1: ids[64] (inside C: unused while the roles run)
 enum {
     MB_GEN = 0, MB_STOP, MB_XNODE, MB_ACK1, MB_ACK2, MB_RU_GEN, MB_RU_O, MB_RU_ID, MB_RU_SLOT, MB_RU_VALID,
     MB_LIST_GEN, MB_LIST_GEN_ODD, MB_LIST_NODE, MB_LIST_NODE_ODD, MB_LIST_N, MB_LIST_N_ODD,   // by the parity of the step
-    MB_SREQ, MB_SNODE0, MB_SNODE1, MB_SRID0, MB_SRID1, MB_SDONE0, MB_SDONE1, MB_SDONE0B, MB_SDONE1B, MB_SDONE0C, MB_SDONE1C,
-    MB_SMASK = 27   // [buf 0|1][lo|hi] x 2 words, OR-ed into by the three distance waves: 4 words (27..30)
+    MB_PRED_GEN, MB_PRED_GEN_ODD,            // wave 2's two best candidates of S_g are in cand[g & 1][0..1]
+    MB_SREQ, MB_SNODE0, MB_SNODE1, MB_SRID0, MB_SRID1,
+    MB_SDONE0, MB_SDONE1,                    // distance waves that finished, ever, per buffer: request rid is done at 3 * spec_done_count(rid)
+    MB_SMASK = 25   // [buf 0|1][lo|hi] x 2 words, OR-ed into by the three distance waves: 4 words (25..28)
 };
 
 // ONE LDS read returns the whole mailbox (lane i = word i; every word lives in the first 32 lanes' pass, so the snapshot is
@@ -1148,6 +1151,9 @@ enum {
 // however many words it looks at.
 __device__ __forceinline__ uint32_t mb_snap(const uint32_t* mb, int lane) { return *(const volatile uint32_t*)(mb + (lane & 31)); }
 #define MBW(snap, i) ((uint32_t)__builtin_amdgcn_readlane((int)(snap), (i)))
+// requests alternate between the two speculation buffers (rid & 1), so request rid is the ((rid + (rid & 1)) / 2)-th of its buffer
+__device__ __forceinline__ uint32_t spec_done_count(uint32_t rid) { return 3u * ((rid + (rid & 1u)) >> 1); }
+enum { CF_VALID = 1, AF_MORE = 4, AF_MOVED = 8 };   // candidate record flags: entry holds a candidate; more than two accepted; slots moved
 __device__ __forceinline__ void mb_store(uint32_t* mb, int i, uint32_t v) { *(volatile uint32_t*)(mb + i) = v; }
 // The LDS operations of one wave are issued and completed in order, so publishing data before a flag (and reading a flag before
 // the data) only needs the COMPILER kept from reordering them; a real fence would also wait for the outstanding global loads —
@@ -1175,6 +1181,10 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
     uint32_t* const spec_od = (uint32_t*)(lds + PIPE_LDS_SPEC);
     uint32_t* const mb = (uint32_t*)(lds + PIPE_LDS_MBOX);
     uint32_t* const misc = mb + 40;                              // [1] ep handoff, [2] wsize, [3] overflow, [4..9] closure scratch
+    // cand[h & 1][0..3] = {o, id, slot, flags}: [0], [1] the two best candidates of S_h (wave 2), [2], [3] the two best neighbours
+    // accepted in step h (wave 0, published with GEN = h + 1); flags: CF_VALID, and on [2] AF_MORE / AF_MOVED
+    uint4* const cand = (uint4*)(lds + PIPE_LDS_X);              // 2 x 4 x 16 bytes
+    uint32_t* const srow = (uint32_t*)(lds + PIPE_LDS_X) + 32;   // [buffer][64]: the adjacency row of a speculation's node
     float* const qs = (float*)(lds + PIPE_LDS_QS);
     uint32_t* vis = VIS_LDS ? (uint32_t*)(lds + PIPE_LDS_QS + (size_t)a.dpad * 4) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
     uint32_t* const stage_flag = (uint32_t*)(C + 512);
@@ -1321,6 +1331,9 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 // ---- accept + push (hnsw_beam_kernel's P4, with the mirror kept in step)
                 uint32_t best_o = SLOT_EMPTY, best_id = 0;
                 int best_slot = -1;
+                uint32_t sec_o = SLOT_EMPTY, sec_id = 0;   // the second best accepted (known when at most two were accepted)
+                int sec_slot = -1;
+                uint32_t aflags = 0;
                 bool ru_local = false;      // the runner-up was selected here (slots moved in a compaction)
                 {
                     if (__ballot(have && od > 0xFF800000u)) nan_seen = true;   // the image of a NaN distance (the reference panics)
@@ -1339,9 +1352,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     }
                     const int na = __popcll(accepted);
                     if (na) {
-                        PIPE_TB(t_a);
                         while (MBW(snap, MB_ACK1) != gen || MBW(snap, MB_ACK2) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
-                        PIPE_TE(2, t_a);
                         if (n + na > BEAM_CAP) {
                             // ---- compaction (radix select of the ef-th smallest image, drop everything farther)
                             uint32_t prefix = 0;
@@ -1383,6 +1394,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                             // slots moved: wave 1's runner-up names an old slot; select here (rare)
                             ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_slot);
                             ru_local = true;
+                            aflags |= AF_MOVED;
                         }
                         if (!overflow) {
                             // ---- push the accepted neighbours into slots n .. n+na-1 (forward lane permute), mirror included
@@ -1409,6 +1421,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                                 best_o = mo;
                                 best_id = mi;
                                 best_slot = n + __popcll(accepted & ((1ull << (__ffsll((long long)wm) - 1)) - 1ull));
+                                aflags |= AF_MORE;
                             } else {
                                 unsigned long long am = accepted;
                                 int rank = 0;
@@ -1417,7 +1430,12 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                                     am &= am - 1;
                                     const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
                                     const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
-                                    if (best_slot < 0 || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_slot = n + rank; }
+                                    if (best_slot < 0 || ao < best_o || (ao == best_o && ai > best_id)) {
+                                        sec_o = best_o; sec_id = best_id; sec_slot = best_slot;
+                                        best_o = ao; best_id = ai; best_slot = n + rank;
+                                    } else {
+                                        sec_o = ao; sec_id = ai; sec_slot = n + rank;
+                                    }
                                     ++rank;
                                 }
                             }
@@ -1463,8 +1481,14 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     if (lane == 0) mb_store(mb, MB_STOP, 1u);
                     break;
                 }
-                // ---- publish S_{gen+1} and x_{gen+1}
+                // ---- publish S_{gen+1} and x_{gen+1} (and what this step accepted: wave 1 derives the next runner-up from it)
                 ++gen;
+                if (lane < 2) {   // lane 0: the best accepted (+ the step's flags), lane 1: the second
+                    const bool second = lane == 1;
+                    const int sl = second ? sec_slot : best_slot;
+                    cand[4 * ((gen - 1) & 1u) + 2 + lane] = make_uint4(second ? sec_o : best_o, second ? sec_id : best_id, (uint32_t)sl,
+                                                                      (sl >= 0 ? CF_VALID : 0u) | (second ? 0u : aflags));
+                }
                 if (lane == 0) mb_store(mb, MB_XNODE, xnode);
                 PIPE_RELEASE();
                 if (lane == 0) mb_store(mb, MB_GEN, gen);
@@ -1477,19 +1501,19 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
             // P2 of `node` for the step of generation lg (list into nb[lg & 1]): visited test-and-set + ordered compaction,
             // distances from a finished speculation where it has them, evaluated here otherwise.  Returns nnew | any_edge << 16.
             auto make_list = [&](uint32_t node, uint32_t lg, unsigned long long& set_mask, uint32_t& row_keep) -> uint32_t {
-                const uint32_t nbr = load_row(node);
                 uint32_t snap = mb_snap(mb, lane);
-                int sb = -1;
-                if (MBW(snap, MB_SNODE0) == node && MBW(snap, MB_SRID0)) sb = 0;
-                else if (MBW(snap, MB_SNODE1) == node && MBW(snap, MB_SRID1)) sb = 1;
+                // which buffer names the node (word i of the mailbox sits in lane i of the snapshot: one compare finds it; node ids
+                // never equal 0xFFFFFFFF, the buffers' idle value)
+                const unsigned long long named = __ballot(snap == node) & ((1ull << MB_SNODE0) | (1ull << MB_SNODE1));
+                const int sb = named == 0 ? -1 : (named & (1ull << MB_SNODE0)) ? 0 : 1;
+                uint32_t nbr = 0xFFFFFFFFu;
+                if (sb < 0) nbr = load_row(node);   // (a speculation keeps the node's row in LDS: no global round trip on this path)
                 unsigned long long smask = 0;
                 if (sb >= 0) {
                     const uint32_t want = sb ? MBW(snap, MB_SRID1) : MBW(snap, MB_SRID0);
                     PIPE_TB(t_s);
                     for (;;) {   // a speculation under way is worth waiting for: it started its gather long ago
-                        const bool done = sb ? (MBW(snap, MB_SDONE1) == want && MBW(snap, MB_SDONE1B) == want && MBW(snap, MB_SDONE1C) == want)
-                                             : (MBW(snap, MB_SDONE0) == want && MBW(snap, MB_SDONE0B) == want && MBW(snap, MB_SDONE0C) == want);
-                        if (done) break;
+                        if ((sb ? MBW(snap, MB_SDONE1) : MBW(snap, MB_SDONE0)) >= spec_done_count(want)) break;
                         __builtin_amdgcn_s_sleep(1);
                         snap = mb_snap(mb, lane);
                     }
@@ -1503,10 +1527,13 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     // wave 2 may hand the buffer to another node at any time: read, THEN check that the buffer still names this
                     // request (the distance waves overwrite it only after the new request is published; LDS runs in order)
                     sv = *(const volatile uint32_t*)(spec_od + sb * 64 + lane);
+                    nbr = *(const volatile uint32_t*)(srow + sb * 64 + lane);
                     PIPE_ACQUIRE();
                     const uint32_t s2 = mb_snap(mb, lane);
-                    const uint32_t want = sb ? MBW(snap, MB_SRID1) : MBW(snap, MB_SRID0);
-                    if ((sb ? MBW(s2, MB_SNODE1) : MBW(s2, MB_SNODE0)) != node || (sb ? MBW(s2, MB_SRID1) : MBW(s2, MB_SRID0)) != want) smask = 0;
+                    if (__ballot(s2 != snap) & (sb ? (1ull << MB_SNODE1) | (1ull << MB_SRID1) : (1ull << MB_SNODE0) | (1ull << MB_SRID0))) {
+                        smask = 0;               // the buffer was handed to another node meanwhile: nothing read from it counts
+                        nbr = load_row(node);
+                    }
                 }
                 bool isnew = false;
                 if (nbr != 0xFFFFFFFFu) {
@@ -1525,8 +1552,6 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 }
                 // what no speculation covered: this wave's four 16-lane groups (two rows per group and gather)
                 const unsigned long long todo = bal & ~smask;
-                PIPE_CNT(8, __popcll(todo));
-                PIPE_CNT(9, nnew);
                 if (todo) {
                     const int nt = __popcll(todo);
                     if (isnew && !covered) {
@@ -1588,9 +1613,64 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 seen = g;
                 PIPE_ACQUIRE();
                 PIPE_TB(t_body);
+                const uint32_t xg = MBW(sn, MB_XNODE);
+                // ---- the runner-up of S_g.  S_g = S_{g-1} + (accepted in step g-1) - x_g, so with wave 2's two best of S_{g-1} and wave 0's
+                // two best accepted it is a handful of compares: min(first of {p1, p2} that is not x_g, first of {a1, a2} that is not x_g)
+                // in pop order.  Exact whenever the pieces are known; else (more than two accepted AND the best of them was taken, or a
+                // compaction moved the slots) the full selection over the mirror, as wave 2 does it.
+                uint32_t o1 = SLOT_EMPTY, id1 = 0;
+                int s1 = 0;
+                bool v1 = false, full = g > 1;
+                if (g > 1) {
+                    const uint32_t pp = (g - 1) & 1u;
+                    PIPE_TB(t_p);
+                    while (MBW(sn, MB_PRED_GEN + pp) != g - 1) { __builtin_amdgcn_s_sleep(1); sn = mb_snap(mb, lane); }
+                    PIPE_TE(2, t_p);
+                    PIPE_ACQUIRE();
+                    // lanes 0..3 take one record each: in pop order p1 <= p2 and a1 <= a2, so "the first of each pair that is not x_g"
+                    // is simply the best record that is valid and not x_g
+                    const uint4 cr = *(const uint4*)(cand + 4 * pp + (lane & 3));
+                    const uint32_t af = (uint32_t)__builtin_amdgcn_readlane((int)cr.w, 2);
+                    const bool a1_taken = (uint32_t)__builtin_amdgcn_readlane((int)cr.y, 2) == xg && (af & CF_VALID);
+                    if (!(af & AF_MOVED) && !((af & AF_MORE) && a1_taken)) {
+                        full = false;
+                        const bool ok = lane < 4 && (cr.w & CF_VALID) && cr.y != xg;
+                        // quad reductions (lanes 0..3 are one DPP quad): smallest image, then the largest id among its holders
+                        uint32_t mo = ok ? cr.x : SLOT_EMPTY;
+                        mo = min(mo, MDB_DPP_U32(mo, 0xB1, 0xF));
+                        mo = min(mo, MDB_DPP_U32(mo, 0x4E, 0xF));
+                        uint32_t mi = (ok && cr.x == mo) ? cr.y : 0u;
+                        mi = max(mi, MDB_DPP_U32(mi, 0xB1, 0xF));
+                        mi = max(mi, MDB_DPP_U32(mi, 0x4E, 0xF));
+                        const unsigned long long win = __ballot(ok && cr.x == mo && cr.y == mi) & 0xFull;
+                        v1 = win != 0;
+                        if (v1) {
+                            const int wl = __ffsll((long long)win) - 1;
+                            o1 = (uint32_t)__builtin_amdgcn_readlane((int)cr.x, wl);
+                            id1 = (uint32_t)__builtin_amdgcn_readlane((int)cr.y, wl);
+                            s1 = __builtin_amdgcn_readlane((int)cr.z, wl);
+                        }
+                    }
+                }
+                if (full) {
+                    PIPE_CNT(9, 1);
+#pragma unroll
+                    for (int r = 0; r < BREGS; ++r) {
+                        const uint64_t e = *(const volatile uint64_t*)(mir + lane + 64 * r);
+                        cd[r] = (uint32_t)e;
+                        ci[r] = (uint32_t)(e >> 32);
+                    }
+                    PIPE_RELEASE();
+                    if (lane == 0) mb_store(mb, MB_ACK1, g);
+                    v1 = beam_best(cd, ci, lane, o1, id1, s1);
+                } else {
+                    if (lane == 0) mb_store(mb, MB_ACK1, g);
+                }
+                if (lane == 0) { mb_store(mb, MB_RU_O, o1); mb_store(mb, MB_RU_ID, id1); mb_store(mb, MB_RU_SLOT, (uint32_t)s1); mb_store(mb, MB_RU_VALID, v1 ? 1u : 0u); }
+                PIPE_RELEASE();
+                if (lane == 0) mb_store(mb, MB_RU_GEN, g);
                 // ---- the list of x_g: the tentative one if the guess was right (wave 0 is already consuming it), else undo + redo
                 if (g > 1) {
-                    const uint32_t xg = MBW(sn, MB_XNODE);
                     if (!(t_live && t_node == xg)) {
                         if (t_live) undo_list(t_mask, t_row);
                         PIPE_CNT(7, 1);
@@ -1600,21 +1680,6 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     }
                     t_live = false;
                 }
-                // ---- the runner-up of S_g
-#pragma unroll
-                for (int r = 0; r < BREGS; ++r) {
-                    const uint64_t e = *(const volatile uint64_t*)(mir + lane + 64 * r);
-                    cd[r] = (uint32_t)e;
-                    ci[r] = (uint32_t)(e >> 32);
-                }
-                PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, MB_ACK1, g);
-                uint32_t o1 = SLOT_EMPTY, id1 = 0;
-                int s1 = 0;
-                const bool v1 = beam_best(cd, ci, lane, o1, id1, s1);
-                if (lane == 0) { mb_store(mb, MB_RU_O, o1); mb_store(mb, MB_RU_ID, id1); mb_store(mb, MB_RU_SLOT, (uint32_t)s1); mb_store(mb, MB_RU_VALID, v1 ? 1u : 0u); }
-                PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, MB_RU_GEN, g);
                 PIPE_TE(11, t_body);
                 // ---- tentatively: c1 is the next node
                 PIPE_TB(t_t);
@@ -1644,6 +1709,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 if (quit) break;
                 seen = g;
                 PIPE_ACQUIRE();
+                PIPE_TB(t_w2);
 #pragma unroll
                 for (int r = 0; r < BREGS; ++r) {
                     const uint64_t e = *(const volatile uint64_t*)(mir + lane + 64 * r);
@@ -1654,18 +1720,30 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 if (lane == 0) mb_store(mb, MB_ACK2, g);
                 uint32_t o1 = SLOT_EMPTY, id1 = 0, o2 = SLOT_EMPTY, id2 = 0;
                 int s1 = 0, s2 = 0;
-                if (!beam_best(cd, ci, lane, o1, id1, s1)) continue;
+                const bool v1 = beam_best(cd, ci, lane, o1, id1, s1);
+                bool v2 = false;
+                if (v1) {
 #pragma unroll
-                for (int r = 0; r < BREGS; ++r)
-                    if (lane + 64 * r == s1) cd[r] = SLOT_EMPTY;
+                    for (int r = 0; r < BREGS; ++r)
+                        if (lane + 64 * r == s1) cd[r] = SLOT_EMPTY;
+                    v2 = beam_best(cd, ci, lane, o2, id2, s2);
+                }
+                // the two best candidates of S_g: wave 1 derives the runner-up of S_{g+1} from them one step later
+                if (lane < 2) {
+                    const bool second = lane == 1;
+                    cand[4 * (g & 1u) + lane] = make_uint4(second ? o2 : o1, second ? id2 : id1, (uint32_t)(second ? s2 : s1),
+                                                          (second ? v2 : v1) ? CF_VALID : 0u);
+                }
+                PIPE_RELEASE();
+                if (lane == 0) mb_store(mb, MB_PRED_GEN + (int)(g & 1u), g);
+                PIPE_TE(8, t_w2);
                 uint32_t target = 0xFFFFFFFFu;
                 const uint32_t sn2 = mb_snap(mb, lane);
-                if (beam_best(cd, ci, lane, o2, id2, s2) && MBW(sn2, MB_SNODE0) != id2 && MBW(sn2, MB_SNODE1) != id2) target = id2;
+                if (v2 && MBW(sn2, MB_SNODE0) != id2 && MBW(sn2, MB_SNODE1) != id2) target = id2;
                 if (target == 0xFFFFFFFFu) continue;
                 const int b = (int)((sreq + 1) & 1u);
                 const uint32_t prev = b ? rid1 : rid0;
-                const bool free_ = b ? (MBW(sn2, MB_SDONE1) == prev && MBW(sn2, MB_SDONE1B) == prev && MBW(sn2, MB_SDONE1C) == prev)
-                                     : (MBW(sn2, MB_SDONE0) == prev && MBW(sn2, MB_SDONE0B) == prev && MBW(sn2, MB_SDONE0C) == prev);
+                const bool free_ = (b ? MBW(sn2, MB_SDONE1) : MBW(sn2, MB_SDONE0)) >= spec_done_count(prev);
                 // not the buffer holding the distances of wave 1's guess c1 (it is consuming them now; it checks, so this is
                 // about not wasting them)
                 const uint32_t held = b ? MBW(sn2, MB_SNODE1) : MBW(sn2, MB_SNODE0);
@@ -1701,6 +1779,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 const int b = (int)(next & 1u);
                 const uint32_t p = b ? MBW(sn, MB_SNODE1) : MBW(sn, MB_SNODE0);
                 const uint32_t nbr = load_row(p);
+                if (third == 0) srow[b * 64 + lane] = nbr;   // wave 1 takes the row from here
                 bool isnew = false;
                 if (nbr != 0xFFFFFFFFu && (lane % 3) == third) {
                     const uint32_t word = *(const volatile uint32_t*)(vis + (nbr >> 5));
@@ -1729,7 +1808,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     atomicOr(mb + MB_SMASK + 2 * b + 1, (uint32_t)(bal >> 32));
                 }
                 PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, third == 0 ? (b ? MB_SDONE1 : MB_SDONE0) : third == 1 ? (b ? MB_SDONE1B : MB_SDONE0B) : (b ? MB_SDONE1C : MB_SDONE0C), next);
+                if (lane == 0) atomicAdd(mb + (b ? MB_SDONE1 : MB_SDONE0), 1u);
                 ++next;
             }
         }
@@ -1783,7 +1862,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
     uint64_t* const okeys = ap->out_keys;
     for (int i = tid; i < kk; i += PIPE_BLOCK) okeys[(size_t)qi * kk + i] = i < outc ? W[i] : MDB_KEY_MAX;
 #ifdef MDB_PIPE_DBG
-    if (lane == 0 && wave < 2)
+    if (lane == 0 && wave < 3)
         for (int i = 0; i < 12; ++i)
             if (dbg_acc[i]) atomicAdd(&ap->counters[4 + i], dbg_acc[i]);
 #endif
