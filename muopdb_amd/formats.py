@@ -12,7 +12,7 @@ these layouts out of the mmapped files:
 * multi-user concat      rs/index/src/multi_spann/writer.rs:171-250, user_index_info.rs:26-42
 
 The byte layouts are pinned by the reference's own writer tests (SURVEY.md §8c K1-K3, K5,
-K7, K13), re-encoded in tests/test_formats_kat.py.
+K7, K13), re-encoded in tests/test_oracle_kat.py and tests/test_segment_formats.py.
 """
 import struct
 
