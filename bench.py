@@ -685,10 +685,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # Validation hooks for boxes with ONE GPU (the multi-rank logic of every workload — sharding, gathers, merges, max over ranks —
+    # without RCCL, which needs one device per rank): MDB_BENCH_DEVICE pins every rank to that device, MDB_BENCH_BACKEND=gloo
+    # moves the collectives to gloo.  Never set by the driver; numbers from such a run are not bench results.
+    if os.environ.get("MDB_BENCH_DEVICE"):
+        local = int(os.environ["MDB_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("MDB_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from muopdb_amd import lib as L
     ctx = L.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
