@@ -2,7 +2,7 @@
 // passes (HBM traffic counters of the dominant kernel; rocprofv3's counter mode crashes inside
 // torch's own kernels on this image, so the counter passes run on this binary instead).
 //   replay_search <kind> <dir> <dim> <k> <ef|nprobe> <batch> <steps> [ef for mspann]
-// kind = hnsw | ivf | ivfpq | flat | mspann.  <dir> is what `bench.py --dump-dir` wrote:
+// kind = hnsw | hnsw-async (argv[8] = batches in flight, submit / wait on attached handles) | ivf | ivfpq | flat | mspann.  <dir> is what `bench.py --dump-dir` wrote:
 //   hnsw : index, vectors, queries.f32        ivf/ivfpq : index, vectors, queries.f32 [, codebook.f32]
 //   flat : vectors (reference vector-file format: u64 n + rows), queries.f32
 // Prints a checksum of the returned ids so a replay can be compared with bench.py's run.
@@ -54,6 +54,47 @@ int main(int argc, char** argv) {
             t0 = std::chrono::steady_clock::now();
             for (size_t s = 0; s < steps; ++s)
                 for (auto& r : h.ann_search(q + ((s * batch) % (nq - batch + 1)) * dim, batch, k, knob)) fold(r.id_with_scores);
+        } else if (kind == "hnsw-async") {
+            // the host path a serving process would use: HOST buffers, `lanes` batches in flight — one context + one handle ATTACHED
+            // to the single resident index per lane, mdb_hnsw_ann_search_submit returns after enqueueing, mdb_wait hands the rows
+            // over.  argv[8] = lanes (default 4).
+            auto idx = slurp(dir + "/index");
+            const size_t lanes = argc > 8 ? std::stoul(argv[8]) : 4;
+            muopdb::BlockBasedHnsw h(dev, idx.data(), idx.size(), vec.data(), vec.size(), muopdb::Quantizer::none(dim));
+            struct Lane { mdb_ctx* ctx = nullptr; mdb_hnsw* h = nullptr; std::vector<mdb_u128> ids; std::vector<float> sc; std::vector<uint32_t> cn; bool busy = false; };
+            std::vector<Lane> ln(lanes);
+            for (auto& l : ln) {
+                if (mdb_device_open(0, &l.ctx) != MDB_OK) throw std::runtime_error("mdb_device_open");
+                if (mdb_hnsw_attach(l.ctx, h.raw(), &l.h) != MDB_OK) throw std::runtime_error(mdb_last_error(l.ctx));
+                l.ids.resize(batch * k); l.sc.resize(batch * k); l.cn.resize(batch);
+            }
+            auto drain = [&](Lane& l) {
+                if (!l.busy) return;
+                if (mdb_wait(l.ctx) != MDB_OK) throw std::runtime_error(mdb_last_error(l.ctx));
+                for (size_t i = 0; i < batch; ++i)
+                    for (uint32_t j = 0; j < l.cn[i]; ++j) checksum = checksum * 1000003ull + (uint64_t)l.ids[i * k + j].lo;
+                l.busy = false;
+            };
+            auto submit = [&](Lane& l, size_t s) {
+                if (mdb_hnsw_ann_search_submit(l.h, q + ((s * batch) % (nq - batch + 1)) * dim, batch, k, knob, l.ids.data(), l.sc.data(), l.cn.data()) != MDB_OK)
+                    throw std::runtime_error(mdb_last_error(l.ctx));
+                l.busy = true;
+            };
+            for (size_t i = 0; i < lanes; ++i) { submit(ln[i], i); }
+            for (auto& l : ln) drain(l);
+            checksum = 0;
+            t0 = std::chrono::steady_clock::now();
+            for (size_t s = 0; s < steps; ++s) {
+                Lane& l = ln[s % lanes];
+                drain(l);        // results are folded in submission order: the checksum equals the synchronous replay's
+                submit(l, s);
+            }
+            for (size_t s = steps; s < steps + lanes; ++s) drain(ln[s % lanes]);
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("replay hnsw-async: %zu steps x %zu queries, %zu lanes, %.3f ms/step (host buffers, submit / wait), ids checksum %016llx\n",
+                        steps, batch, lanes, ms / steps, (unsigned long long)checksum);
+            for (auto& l : ln) { mdb_hnsw_free(l.h); mdb_device_close(l.ctx); }
+            return 0;
         } else if (kind == "ivf" || kind == "ivfpq") {
             auto idx = slurp(dir + "/index");
             muopdb::Quantizer qz = muopdb::Quantizer::none(dim);

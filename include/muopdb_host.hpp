@@ -225,6 +225,7 @@ class BlockBasedHnsw {
         for (auto& o : r.take(b, k)) out.push_back(std::move(*o));
         return out;
     }
+    mdb_hnsw* raw() const { return h_; }   // for the C-ABI entries this mirror does not wrap (submit / attach on a raw context)
 
   private:
     Device& dev_;
