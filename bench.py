@@ -102,6 +102,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-sweep", action="store_true")
     p.add_argument("--no-c5", action="store_true", help="all: skip the C5 per-GPU shard workload (~50 s of build)")
+    p.add_argument("--no-c4-full", action="store_true", help="all: skip the full-size C4 workload (1024 users, 30.7 GB, ~60 s)")
     p.add_argument("--streams", type=int, default=4, help="hnsw: extra measurement with this many batches in flight (0/1 = skip)")
     p.add_argument("--dump-dir", default=None, help="write index files + queries for examples/replay_search.cpp")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -543,7 +544,7 @@ def run_c5(env, steps=None, warm=None):
 
 
 # ------------------------------------------------------------------------------------------ multi-user SPANN
-def run_spann(env, users=None):
+def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
     """BASELINE.md C4 shape: multi-user SPANN over unit-norm f32 rows, one (user, query) pair per user
     per batch, posting lists sharded l % world, one all-gather + merge per batch.  Defaults are a
     1/8 slice (128 users x 9766 x 768 = 3.8 GB); --users 1024 is the full 10M x 768 (30.7 GB)."""
@@ -559,7 +560,7 @@ def run_spann(env, users=None):
     batch = args.batch or U
     k, P = args.k, args.nprobe or 16
     ratio = args.ratio if args.ratio is not None else 0.1
-    steps, warm = args.steps, args.warmup
+    steps, warm = steps or args.steps, args.warmup if warm is None else warm
     nlist = max(1, per // 64)
     t0 = time.time()
     gen = S.EmbedLike(d, seed=3) if args.data == "lowrank" else None
@@ -599,7 +600,7 @@ def run_spann(env, users=None):
         queries = torch.stack([base[int(u)][int(r)] for u, r in zip(quser.tolist(), qrow.tolist())]) + noise.cuda()
         queries = (queries / queries.norm(dim=1, keepdim=True)).contiguous()
         desc = "isotropic Gaussian unit-norm rows (round-1 generator)"
-    if args.dump_dir:
+    if args.dump_dir and U * per * d * 4 < (8 << 30):   # (the full C4 would write 30 GB)
         dump(args, rank, "spann", hnsw_index=cat["hnsw_index"], hnsw_vectors=cat["hnsw_vectors"], ivf_index=cat["ivf_index"],
              vectors=cat["ivf_vectors"], user_table=cat["user_table"],
              **{"queries.f32": queries.cpu().numpy(), "users.u64": (quser + 1).numpy().astype(np.uint64)})
@@ -656,7 +657,8 @@ def run_spann(env, users=None):
                roofline=hbm_roofline("ivf_scan_f32_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch), centroid_hnsw_kernel_ms=m["hnsw_ms"]))
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("spann", out["config"])
-    if not args.no_sweep:
+    out["steps"], out["warmup"] = steps, warm
+    if not (args.no_sweep or no_sweep):
         sweep = []
         for p_, r_ in ((4, 0.1), (16, 0.1), (64, 0.1), (4, 0.3), (16, 0.3), (64, 0.3), (16, 1.0)):
             s = m if (p_, r_) == (P, ratio) else measure(p_, r_)
@@ -712,6 +714,8 @@ def main():
                 ("ivfpq_c3", lambda: run_ivfpq(env)), ("spann_c4_128u", lambda: run_spann(env, users=128))]
         if world == 1 and not args.no_c5:  # one GPU's share of C5 (a 1/8 shard of 100M x 16-byte codes: ~50 s of build)
             plan.append(("c5_shard_per_gpu", lambda: run_c5(env, steps=min(args.steps, 8), warm=min(args.warmup, 2))))
+        if world == 1 and not args.no_c4_full:  # the whole of C4 on one GPU: 1024 users x 9766 x 768 = 30.7 GB resident (~60 s of build + load)
+            plan.append(("spann_c4_full_1024u", lambda: run_spann(env, users=1024, no_sweep=True, steps=min(args.steps, 10), warm=min(args.warmup, 3))))
         for name, fn in plan:
             t0 = time.time()
             try:  # a failing extra workload must never take the headline line with it
