@@ -1129,7 +1129,14 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
 // Counters and results are hnsw_beam_kernel's step for step: speculative work is never counted and never raises MDB_ERR_NAN.
 // Requirements (else hnsw_beam_kernel runs): ef <= 256, d a multiple of 16 (N16T > 0), no PQ rows, row strides <= 64.
 // ==========================================================================================
-#define PIPE_BLOCK 384
+#define PIPE_BLOCK 512   // eight waves, two per SIMD (wave w runs on SIMD w % 4): COMMIT and PREPARE get a SIMD each — waves 4 and 5, their
+                         // SIMD mates, sit at the layer's closing barrier (no issue slots) — PREDICT shares with a distance wave (6), the
+                         // other two distance waves (3, 7) share SIMD 3.  With six waves the two critical waves shared their SIMDs with
+                         // polling distance waves.
+#ifndef PIPE_POLL_SLEEP
+#define PIPE_POLL_SLEEP 0   // critical waves poll without sleeping (nobody else wants their SIMD)
+#endif
+#define PIPE_CRIT_WAIT() do { if (PIPE_POLL_SLEEP) __builtin_amdgcn_s_sleep(PIPE_POLL_SLEEP); } while (0)
 #define PIPE_LDS_NB (BEAM_LDS_C + 8192)      // nb_id[2][64] | nb_od[2][64]: the new-neighbour lists of even / odd steps
 #define PIPE_LDS_MIR (PIPE_LDS_NB + 1024)    // candidate mirror: {cd, id}[320] (cd = distance image of an unexpanded slot, else EMPTY)
 #define PIPE_LDS_SPEC (PIPE_LDS_MIR + 2560)  // spec_od[2][64]: distance images by row position
@@ -1317,7 +1324,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 // ---- the new neighbours of xnode with their distances (wave 1's list, prepared ahead when it guessed right)
                 uint32_t snap = mb_snap(mb, lane);
                 const int lpar = (int)(gen & 1u);
-                while (MBW(snap, MB_LIST_GEN + lpar) != gen || MBW(snap, MB_LIST_NODE + lpar) != xnode) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
+                while (MBW(snap, MB_LIST_GEN + lpar) != gen || MBW(snap, MB_LIST_NODE + lpar) != xnode) { PIPE_CRIT_WAIT(); snap = mb_snap(mb, lane); }
                 PIPE_ACQUIRE();
                 PIPE_TE(1, t_l);
                 const uint32_t ln = MBW(snap, MB_LIST_N + lpar);
@@ -1352,7 +1359,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     }
                     const int na = __popcll(accepted);
                     if (na) {
-                        while (MBW(snap, MB_ACK1) != gen || MBW(snap, MB_ACK2) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
+                        while (MBW(snap, MB_ACK1) != gen || MBW(snap, MB_ACK2) != gen) { PIPE_CRIT_WAIT(); snap = mb_snap(mb, lane); }
                         if (n + na > BEAM_CAP) {
                             // ---- compaction (radix select of the ef-th smallest image, drop everything farther)
                             uint32_t prefix = 0;
@@ -1449,7 +1456,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     snap = mb_snap(mb, lane);
                     if (!ru_local) {
                         PIPE_TB(t_r);
-                        while (MBW(snap, MB_RU_GEN) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
+                        while (MBW(snap, MB_RU_GEN) != gen) { PIPE_CRIT_WAIT(); snap = mb_snap(mb, lane); }
                         PIPE_TE(3, t_r);
                         ru_valid = MBW(snap, MB_RU_VALID) != 0;
                         ru_o = MBW(snap, MB_RU_O); ru_id = MBW(snap, MB_RU_ID); ru_slot = (int)MBW(snap, MB_RU_SLOT);
@@ -1467,7 +1474,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                         if (closer >= ef) {
                             stop = true;
                         } else {
-                            while (MBW(snap, MB_ACK1) != gen || MBW(snap, MB_ACK2) != gen) { __builtin_amdgcn_s_sleep(1); snap = mb_snap(mb, lane); }
+                            while (MBW(snap, MB_ACK1) != gen || MBW(snap, MB_ACK2) != gen) { PIPE_CRIT_WAIT(); snap = mb_snap(mb, lane); }
                             const int pslot = take_ru ? ru_slot : best_slot;
 #pragma unroll
                             for (int r = 0; r < BREGS; ++r)
@@ -1514,7 +1521,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     PIPE_TB(t_s);
                     for (;;) {   // a speculation under way is worth waiting for: it started its gather long ago
                         if ((sb ? MBW(snap, MB_SDONE1) : MBW(snap, MB_SDONE0)) >= spec_done_count(want)) break;
-                        __builtin_amdgcn_s_sleep(1);
+                        PIPE_CRIT_WAIT();
                         snap = mb_snap(mb, lane);
                     }
                     PIPE_TE(6, t_s);
@@ -1606,7 +1613,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     g = MBW(sn, MB_GEN);
                     if (g != seen) break;
                     if (MBW(sn, MB_STOP)) { quit = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    PIPE_CRIT_WAIT();
                 }
                 PIPE_TE(5, t_i);
                 if (quit) break;
@@ -1624,7 +1631,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 if (g > 1) {
                     const uint32_t pp = (g - 1) & 1u;
                     PIPE_TB(t_p);
-                    while (MBW(sn, MB_PRED_GEN + pp) != g - 1) { __builtin_amdgcn_s_sleep(1); sn = mb_snap(mb, lane); }
+                    while (MBW(sn, MB_PRED_GEN + pp) != g - 1) { PIPE_CRIT_WAIT(); sn = mb_snap(mb, lane); }
                     PIPE_TE(2, t_p);
                     PIPE_ACQUIRE();
                     // lanes 0..3 take one record each: in pop order p1 <= p2 and a1 <= a2, so "the first of each pair that is not x_g"
@@ -1653,7 +1660,6 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     }
                 }
                 if (full) {
-                    PIPE_CNT(9, 1);
 #pragma unroll
                     for (int r = 0; r < BREGS; ++r) {
                         const uint64_t e = *(const volatile uint64_t*)(mir + lane + 64 * r);
@@ -1669,18 +1675,20 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 if (lane == 0) { mb_store(mb, MB_RU_O, o1); mb_store(mb, MB_RU_ID, id1); mb_store(mb, MB_RU_SLOT, (uint32_t)s1); mb_store(mb, MB_RU_VALID, v1 ? 1u : 0u); }
                 PIPE_RELEASE();
                 if (lane == 0) mb_store(mb, MB_RU_GEN, g);
+                PIPE_TE(11, t_body);
                 // ---- the list of x_g: the tentative one if the guess was right (wave 0 is already consuming it), else undo + redo
                 if (g > 1) {
                     if (!(t_live && t_node == xg)) {
+                        PIPE_TB(t_redo);
                         if (t_live) undo_list(t_mask, t_row);
                         PIPE_CNT(7, 1);
                         unsigned long long m0; uint32_t r0;
                         const uint32_t n0 = make_list(xg, g, m0, r0);
                         publish_list(g, xg, n0);
+                        PIPE_TE(9, t_redo);
                     }
                     t_live = false;
                 }
-                PIPE_TE(11, t_body);
                 // ---- tentatively: c1 is the next node
                 PIPE_TB(t_t);
                 if (v1) {
@@ -1760,9 +1768,9 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     if (lane == 0) mb_store(mb, MB_SREQ, sreq);
                 }
             }
-        } else {
-            // =============================================================== DISTANCES (waves 3, 4, 5)
-            const int third = wave - 3;                      // this wave's row positions: pos % 3 == third
+        } else if (wave == 3 || wave >= 6) {
+            // =============================================================== DISTANCES (waves 3, 6, 7)
+            const int third = wave == 3 ? 0 : wave - 5;      // this wave's row positions: pos % 3 == third
             uint32_t* const tid_ = (uint32_t*)(lds + PIPE_LDS_DTMP) + third * 64;   // ids[32] | pos[32]
             uint32_t next = 1;
             for (;;) {
