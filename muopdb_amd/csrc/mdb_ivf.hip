@@ -555,9 +555,13 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
                 {
                     int t = (r * nsplit + split) * PQ2_NW + wave;
                     int j = 0;  // number of lists that end at or before t
+                    if (n <= MDB_WAVE) {  // (the usual probe counts: one ballot instead of eight — entries past n hold T > t)
+                        j = __popcll(__ballot(ppref[lane + 1] <= (uint32_t)t));
+                    } else {
 #pragma unroll
-                    for (int x = 0; x < PQ2_PCH / MDB_WAVE; ++x)
-                        j += __popcll(__ballot(ppref[x * MDB_WAVE + lane + 1] <= (uint32_t)t));
+                        for (int x = 0; x < PQ2_PCH / MDB_WAVE; ++x)
+                            j += __popcll(__ballot(ppref[x * MDB_WAVE + lane + 1] <= (uint32_t)t));
+                    }
                     live[FA] = r < rounds && t < T;  // then j < n: unused entries have prefix == T > t
                     j = live[FA] ? j : jsafe;
                     uint32_t tile = pstart[j] + (live[FA] ? (uint32_t)t - ppref[j] : 0u);
