@@ -90,22 +90,49 @@ __device__ __forceinline__ void exact_sums(const Loader& ld, const float* __rest
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
         int c = 0;
-        // two chunks per iteration: 8 independent 16-byte loads in flight per lane (the accumulation
-        // order per lane is unchanged: chunk c, then chunk c+1)
-        for (; c + 2 <= p.n16; c += 2) {
-            float4 x0 = ld.get4(4 * c + 0), x1 = ld.get4(4 * c + 1), x2 = ld.get4(4 * c + 2), x3 = ld.get4(4 * c + 3);
-            float4 y0 = ld.get4(4 * c + 4), y1 = ld.get4(4 * c + 5), y2 = ld.get4(4 * c + 6), y3 = ld.get4(4 * c + 7);
-            float xv[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
-                            x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
-            float yv[16] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w,
-                            y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
+        // two 16-float chunks (8 independent 16-byte loads per lane) per step; the accumulation order per lane is unchanged:
+        // chunk c, then chunk c+1
+        auto load8 = [&](float4 (&v)[8], int c0) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) v[x] = ld.get4(4 * c0 + x);
+        };
+        auto add8 = [&](const float4 (&v)[8], int c0) {
+            const float xv[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+                                  v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+            const float yv[16] = {v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w,
+                                  v[6].x, v[6].y, v[6].z, v[6].w, v[7].x, v[7].y, v[7].z, v[7].w};
 #pragma unroll
             for (int i = 0; i < QT; ++i) {
-                const float* q = qbase + (size_t)i * qstride + 16 * c;
+                const float* q = qbase + (size_t)i * qstride + 16 * c0;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[i][j] = acc_term<METRIC>(acc[i][j], q[j], xv[j]);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[i][j] = acc_term<METRIC>(acc[i][j], q[16 + j], yv[j]);
+            }
+        };
+        if (QT == 1) {
+            // register double buffer: the next step's 8 loads are issued BEFORE this step's 32 QT accumulates, so a lane keeps
+            // 16 loads (256 B) in flight instead of 8 — a streaming scan at one query per vector is a latency x
+            // bytes-in-flight problem (the loop is unrolled by two steps so that the buffer roles are static)
+            const int pairs = p.n16 >> 1;
+            if (pairs > 0) {
+                float4 va[8], vb[8];
+                load8(va, 0);
+                int i = 0;
+                for (; i + 2 <= pairs; i += 2) {
+                    load8(vb, 2 * (i + 1));
+                    add8(va, 2 * i);
+                    if (i + 2 < pairs) load8(va, 2 * (i + 2));
+                    add8(vb, 2 * (i + 1));
+                }
+                if (i < pairs) add8(va, 2 * i);
+            }
+            c = 2 * pairs;
+        } else {
+            for (; c + 2 <= p.n16; c += 2) {
+                float4 v[8];
+                load8(v, c);
+                add8(v, c);
             }
         }
         for (; c < p.n16; ++c) {

@@ -277,7 +277,7 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     // blocks: enough to fill the chip (~4 per CU), but several rounds per block when there are many query
     // groups — a block that scans one round pays its selectors' warm-up and final sort for nothing
     static const size_t target_env = getenv("MDB_FLAT_BLOCKS") ? (size_t)atoi(getenv("MDB_FLAT_BLOCKS")) : 0;
-    const size_t target = target_env ? target_env : (l2_resident ? 1024 : 512);
+    const size_t target = target_env ? target_env : 1024;   // (HBM-resident base, batch 1: 512 blocks 0.0996 ms + merge, 1024: 0.0959, 2048: 0.0934 but a slower merge)
     const size_t qgroups = bpad / qt;
     unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(ngroups, 1), std::max<size_t>((target + qgroups - 1) / qgroups, 1));
     // keep the partial buffer bounded (<= 256 MiB)
