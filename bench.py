@@ -363,6 +363,11 @@ def run_flat(env, n=None, batch=None):
 
 
 # ------------------------------------------------------------------------------------------ IVF-PQ
+def pq_scan_kernel_name(batch):
+    """the library's choice (mdb_ivf.hip): two-phase scan (bounds, then exact distances of the candidates) from 512 queries per batch"""
+    return "ivf_scan_pq3_kernel+ivf_pq3_refine_kernel" if batch >= 512 else "ivf_scan_pq2_kernel"
+
+
 def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=0):
     """one (nprobe) setting: timed steps + untimed re-run for results / counters"""
     from muopdb_amd import lib as L
@@ -443,7 +448,7 @@ def run_ivfpq(env):
                config={"workload": "SIFT-1M-like synthetic %dx%d (%s), IVF nlist=%d + PQ m=16 nbits=8 (symmetric distance), nprobe=%d, "
                                    "batch=%d, top-%d, lists sharded x%d" % (n, d, desc, nlist, P, batch, k, world),
                        "n": n, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": args.data},
-               roofline=hbm_roofline("ivf_scan_pq2_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
+               roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ivfpq", out["config"])
     if args.streams > 1 and world == 1:
@@ -524,7 +529,7 @@ def run_c5(env, steps=None, warm=None):
                                    "codes, full coarse quantizer nlist=%d, nprobe=%d, batch=%d, top-%d"
                                    % (sh["n"], sh["owned_lists"], total, sh["nlist"], P, batch, k),
                        "n": sh["n"], "dim": 128, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": "lowrank"},
-               roofline=hbm_roofline("ivf_scan_pq2_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
+               roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
     out["steps"], out["warmup"] = steps, warm
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("c5", out["config"])

@@ -77,7 +77,8 @@ struct Row4Loader {  // row-major row whose start is 16-byte aligned and whose l
 
 // QT queries against ONE stored vector (this thread's).  q[i] = qbase + i*qstride must be
 // wave-uniform (scalar loads).  Returns the raw cascade sum (squared L2 / positive dot).
-template <int METRIC, int QT, class Loader>
+// DB (streaming scans only): register double buffer of the 16-lane passes, see below.
+template <int METRIC, int QT, class Loader, bool DB = false>
 __device__ __forceinline__ void exact_sums(const Loader& ld, const float* __restrict__ qbase, int qstride,
                                            const DistPlan& p, float (&out)[QT]) {
     float ret[QT];
@@ -110,10 +111,11 @@ __device__ __forceinline__ void exact_sums(const Loader& ld, const float* __rest
                 for (int j = 0; j < 16; ++j) acc[i][j] = acc_term<METRIC>(acc[i][j], q[16 + j], yv[j]);
             }
         };
-        if (QT == 1) {
+        if (DB && QT == 1) {
             // register double buffer: the next step's 8 loads are issued BEFORE this step's 32 QT accumulates, so a lane keeps
             // 16 loads (256 B) in flight instead of 8 — a streaming scan at one query per vector is a latency x
-            // bytes-in-flight problem (the loop is unrolled by two steps so that the buffer roles are static)
+            // bytes-in-flight problem (the loop is unrolled by two steps so that the buffer roles are static).  NOT for gathers of single
+            // rows (refine, quantize): the 64 extra registers cost them occupancy — 229 -> 300 us and 55 -> 105 us on C5's coarse refine / quantize
             const int pairs = p.n16 >> 1;
             if (pairs > 0) {
                 float4 va[8], vb[8];
@@ -341,14 +343,15 @@ struct BlockSelect {
         }
         __syncthreads();
     }
-    // call after every offer() round (uniform control flow)
-    __device__ __forceinline__ void round_end() {
+    // call after every offer() round (uniform control flow).  trim_above < cap - BLOCK: sort and tighten the threshold as soon as
+    // that many keys are queued (callers whose per-key work is cheap but whose FOLLOW-UP work grows with a slack threshold)
+    __device__ __forceinline__ void round_end(uint32_t trim_above = 0xFFFFFFFFu) {
         __syncthreads();
         total += ctr[slot];
         const int prev = slot == 0 ? 2 : slot - 1;
         if (threadIdx.x == 0) ctr[prev] = 0;
         slot = slot == 2 ? 0 : slot + 1;
-        if (total > (uint32_t)(cap - BLOCK)) sort_and_trim();
+        if (total > min((uint32_t)(cap - BLOCK), trim_above)) sort_and_trim();
     }
     __device__ void finish() {
         __syncthreads();

@@ -110,6 +110,7 @@ struct ScanArgs {
     const uint32_t* allow;
     uint32_t allow_stride, allow_mask;
     uint32_t* counts_out;          // nsplit == 1: `partial` is the final [B][k] key array and the row lengths go here (no merge launch)
+    const uint32_t* gate;          // non-null: the launch is a fallback and returns at once unless *gate != 0 (its scored count is not added)
 };
 
 __device__ __forceinline__ bool tomb_test(const uint32_t* tomb, uint32_t base_word, uint32_t pid) {
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
                     if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid) && allow_test(a, qi, pid)) {
                         TileLoader ld{tiles + (size_t)tile * p.d4 * MDB_TILE + lane};
                         float raw[1];
-                        exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
+                        exact_sums<METRIC, 1, TileLoader, true>(ld, qb, 0, p, raw);
                         float dist = finish_distance<METRIC>(raw[0]);
                         if (dist != dist) nan_seen = true;
                         key = make_key(dist, pid);
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
                                                                  int nbits, const float* __restrict__ cb,
                                                                  const uint8_t* __restrict__ qcodes) {
     static_assert(SUBDIM % 4 == 0 && (SUBDIM & (SUBDIM - 1)) == 0, "SUBDIM: power of two >= 4");
+    if (a.gate && __builtin_nontemporal_load(a.gate) == 0u) return;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     BlockSelect<PQ2_BLOCK> sel;
     sel.init(lds, a.k);
@@ -665,10 +667,288 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
         if (lane == 0 && ws) atomicAdd(sel.spare(), (uint32_t)ws);
     }
     sel.finish();
-    if (threadIdx.x == 0 && *sel.spare()) atomicAdd(&a.counters[2], (unsigned long long)*sel.spare());
+    if (threadIdx.x == 0 && *sel.spare() && !a.gate) atomicAdd(&a.counters[2], (unsigned long long)*sel.spare());
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
     for (int j = tid; j < a.k; j += PQ2_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+    if (a.counts_out && tid == 0) a.counts_out[qi] = c;
+}
+
+// ------------------------------------------------------------------------------------------
+// PQ posting-list scan in TWO PHASES (L2, k <= 64): bounds first, exact distances for the few vectors that can matter.
+// The one-phase kernel above is pinned to one block per CU by its 128 KB per-element table, and its waves spend 62 % of
+// their time waiting (PMC).  Only ROW SUMS are needed to decide which vectors can enter the top-k:
+//   phase 1 (ivf_scan_pq3_kernel): per (subspace, code) the block keeps ONE word — a bf16 lower bound and a bf16 upper bound of
+//     the row's sum (16 KB in all: two 1024-thread blocks per CU, no table build).  For every scanned vector it adds up both;
+//     the upper bounds feed a BlockSelect, whose k-th smallest U bounds the k-th exact distance from above (k vectors have
+//     exact <= upper <= U); a vector whose LOWER bound exceeds U can never be in the top-k, every other one is a CANDIDATE:
+//     its slot index goes to the (query, split) list.  With 8-bit mantissas the two bounds are 0.8 % apart, so little more
+//     than the top-k itself survives once U has settled (warm start: the first round sets U).
+//   phase 2 (ivf_pq3_refine_kernel): one block per query evaluates the candidates EXACTLY — the same per-element terms in the
+//     same association as the table kernel, rows taken from the codebook in L2 — and selects the top-k: identical keys.
+// A list that outgrows its capacity raises `ovf`; the one-phase kernel, launched behind it and gated on that word, then redoes
+// the batch (both launches return at once otherwise).
+struct Pq3Args {
+    uint32_t* cand;       // [B][nsplit][cap] slot indices (tile * 64 + lane)
+    uint32_t* cand_cnt;   // [B][nsplit]
+    uint32_t cap;
+    uint32_t* ovf;
+};
+
+template <int MW, int BLK>
+__global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m, int nbits, int subdim,
+                                                                 const float* __restrict__ cb, const uint8_t* __restrict__ qcodes, Pq3Args c3) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    BlockSelect<BLK> sel;
+    sel.init(lds, a.k);
+    uint32_t* pstart = (uint32_t*)(lds + ((BlockSelect<BLK>::lds_bytes(a.k) + 15) & ~(size_t)15));
+    uint32_t* ppref = pstart + PQ2_PCH;
+    uint32_t* ccnt = ppref + PQ2_PCH + 8;            // candidates of this block
+    float* qv = (float*)(ppref + PQ2_PCH + 16);      // the query's own codebook rows [m][subdim]
+    uint32_t* btab = (uint32_t*)(qv + m * subdim);   // [m << nbits]: upper bound (bf16) << 16 | lower bound (bf16) of the row's sum
+    const int qi = blockIdx.y, split = blockIdx.x, nsplit = gridDim.x;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / MDB_WAVE), lane = tid % MDB_WAVE;
+    const IvfUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
+    const uint8_t* qc = qcodes + (size_t)qi * m;
+    const int np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
+    const int K = 1 << nbits;
+    bool bad = false;
+    unsigned scored = 0;
+    uint32_t* const my_cand = c3.cand + ((size_t)qi * nsplit + split) * c3.cap;
+    if (tid == 0) *ccnt = 0;
+    for (int i = tid; i < m * subdim; i += BLK) {
+        int s = i / subdim;
+        qv[i] = cb[((size_t)s * K + qc[s]) * subdim + (i % subdim)];
+    }
+    __syncthreads();
+    for (int i = tid; i < (m << nbits); i += BLK) {
+        const float* row = cb + (size_t)i * subdim;
+        const float* q = qv + (i >> nbits) * subdim;
+        float sum = 0.0f;
+        for (int e = 0; e < subdim; ++e) sum = __fadd_rn(sum, acc_term<MDB_METRIC_L2>(0.0f, q[e], row[e]));   // every term >= 0
+        // real row sum within (1 +- 8 eps) of `sum`; the exact distance (the same terms in the reference's association) within
+        // (1 +- 2^-17) of the real total: shrink / stretch by 1e-5 / 2e-5, then round the bf16 mantissa outwards
+        const uint32_t lo = __float_as_uint(__fmul_rn(sum, 0.99999f)) >> 16;
+        const uint32_t hi = (__float_as_uint(__fmul_rn(sum, 1.00002f)) + 0xFFFFu) >> 16;
+        btab[i] = sum != sum ? 0x7FC07FC0u : ((hi << 16) | lo);
+    }
+    __syncthreads();
+
+    if (u.valid) {
+        for (int p0 = 0; p0 < np; p0 += PQ2_PCH) {
+            const int n = min(PQ2_PCH, np - p0);
+            for (int e = tid; e < PQ2_PCH; e += BLK) {
+                uint32_t t0 = 0, cnt = 0;
+                if (e < n) {
+                    uint32_t c = a.probes[(size_t)qi * a.probe_stride + p0 + e];
+                    if (c >= u.num_lists) bad = true;
+                    else {
+                        uint32_t g = u.list_base + c;
+                        t0 = a.list_tile_off[g];
+                        cnt = a.list_tile_off[g + 1] - t0;
+                    }
+                }
+                pstart[e] = t0;
+                ppref[e + 1] = cnt;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                constexpr int PER = PQ2_PCH / MDB_WAVE;
+                uint32_t loc[PER], sum = 0;
+#pragma unroll
+                for (int x = 0; x < PER; ++x) { loc[x] = ppref[1 + lane * PER + x]; sum += loc[x]; }
+                uint32_t incl = sum;
+#pragma unroll
+                for (int o = 1; o < MDB_WAVE; o <<= 1) {
+                    uint32_t v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                uint32_t run = incl - sum;
+#pragma unroll
+                for (int x = 0; x < PER; ++x) { run += loc[x]; ppref[1 + lane * PER + x] = run; }
+                if (lane == 0) ppref[0] = 0;
+            }
+            __syncthreads();
+            const int T = (int)ppref[PQ2_PCH];
+            constexpr int NW = BLK / MDB_WAVE;
+            const int per_round = NW * nsplit;
+            const int rounds = (T + per_round - 1) / per_round;
+            // the same 3-stage pipeline as the one-phase kernel (fetch / tombstone word / consume)
+            uint32_t pid[3], tw[3], aw[3], cw[3][MW], slot0[3];
+            bool live[3] = {false, false, false};
+            int jsafe = 0;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                pid[x] = 0xFFFFFFFFu; tw[x] = 0; aw[x] = 0; slot0[x] = 0;
+#pragma unroll
+                for (int w = 0; w < MW; ++w) cw[x][w] = 0;
+            }
+            auto iteration = [&](int r, auto PH) {
+                constexpr int FA = decltype(PH)::value, TB = (FA + 2) % 3, CC = (FA + 1) % 3;
+                {
+                    int t = (r * nsplit + split) * NW + wave;
+                    int j = 0;
+                    if (n <= MDB_WAVE) {
+                        j = __popcll(__ballot(ppref[lane + 1] <= (uint32_t)t));
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < PQ2_PCH / MDB_WAVE; ++x)
+                            j += __popcll(__ballot(ppref[x * MDB_WAVE + lane + 1] <= (uint32_t)t));
+                    }
+                    live[FA] = r < rounds && t < T;
+                    j = live[FA] ? j : jsafe;
+                    uint32_t tile = pstart[j] + (live[FA] ? (uint32_t)t - ppref[j] : 0u);
+                    slot0[FA] = tile * MDB_TILE;
+                    pid[FA] = a.slot_ids[(size_t)tile * MDB_TILE + lane];
+                    const uint32_t* cwp = codes + (size_t)tile * MW * MDB_TILE + lane;
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) cw[FA][w] = cwp[(size_t)w * MDB_TILE];
+                }
+                {
+                    uint32_t pz = pid[TB] == 0xFFFFFFFFu ? 0u : pid[TB];
+                    tw[TB] = a.tomb[u.tomb_base + (pz >> 5)];
+                    aw[TB] = a.allow[(size_t)qi * a.allow_stride + ((pz >> 5) & a.allow_mask)];
+                }
+                if (r >= 2) {
+                    uint64_t key = MDB_KEY_MAX;
+                    const bool take = live[CC] && pid[CC] != 0xFFFFFFFFu && !((tw[CC] >> (pid[CC] & 31)) & 1u) && ((aw[CC] >> (pid[CC] & 31)) & 1u);
+                    float lb = 0.0f, ub = 0.0f;
+                    if (take) {
+                        ++scored;
+#pragma unroll
+                        for (int w = 0; w < MW; ++w) {
+#pragma unroll
+                            for (int bi = 0; bi < 4; ++bi) {
+                                const int s = w * 4 + bi;
+                                if (s < m) {
+                                    const uint32_t code = (cw[CC][w] >> (8 * bi)) & 0xFFu;
+                                    const uint32_t e = btab[(s << nbits) + code];
+                                    lb = __fadd_rn(lb, __uint_as_float(e << 16));
+                                    ub = __fadd_rn(ub, __uint_as_float(e & 0xFFFF0000u));
+                                }
+                            }
+                        }
+                        key = make_key(ub, pid[CC]);   // NaN sorts last: it never lowers the threshold
+                    }
+                    if (p0 == 0 && r == 2) sel.warm_start(key);
+                    // candidates against the threshold as it stands (it only tightens: a vector admitted early is merely superfluous)
+                    const uint32_t thr_hi = (uint32_t)(*sel.thr >> 32);
+                    const bool surv = take && !(lb == lb && f32_orderable(__fmul_rn(lb, 0.99998f)) > thr_hi);
+                    const unsigned long long sm = __ballot(surv);
+                    if (sm) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(ccnt, (uint32_t)__popcll(sm));
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        const uint32_t pos = base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+                        if (surv && pos < c3.cap) my_cand[pos] = slot0[CC] + (uint32_t)lane;
+                    }
+                    sel.offer(key);
+                    sel.round_end((uint32_t)a.k + 64u);   // eager: a slack threshold costs phase 2 exact evaluations
+                }
+            };
+            if (T > 0) {
+                int j0 = 0;
+#pragma unroll
+                for (int x = 0; x < PQ2_PCH / MDB_WAVE; ++x) j0 += __popcll(__ballot(ppref[x * MDB_WAVE + lane + 1] == 0u));
+                jsafe = j0;
+                for (int r = 0; r < rounds + 2; r += 3) {
+                    iteration(r, std::integral_constant<int, 0>{});
+                    iteration(r + 1, std::integral_constant<int, 1>{});
+                    iteration(r + 2, std::integral_constant<int, 2>{});
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (bad) atomicOr(a.flags, MDB_FLAG_RANGE);
+    {
+        unsigned long long ws = scored;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ws += __shfl_xor((unsigned)ws, o);
+        if (lane == 0 && ws) atomicAdd(sel.spare(), (uint32_t)ws);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (*sel.spare()) atomicAdd(&a.counters[2], (unsigned long long)*sel.spare());
+        const uint32_t c = *ccnt;
+        c3.cand_cnt[(size_t)qi * nsplit + split] = min(c, c3.cap);
+        if (c > c3.cap) atomicAdd(c3.ovf, 1u);
+    }
+}
+
+// phase 2: exact symmetric distances of a query's candidates (all splits), top-k -> the final key rows
+template <int SUBDIM, int MW>
+__global__ __launch_bounds__(256) void ivf_pq3_refine_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m, int nbits,
+                                                             const float* __restrict__ cb, const uint8_t* __restrict__ qcodes, Pq3Args c3,
+                                                             int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    BlockSelect<256> sel;
+    sel.init(lds, a.k);
+    float* qv = (float*)(lds + ((BlockSelect<256>::lds_bytes(a.k) + 15) & ~(size_t)15));
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* qc = qcodes + (size_t)qi * m;
+    const int K = 1 << nbits;
+    constexpr int S4 = SUBDIM / 4;
+    for (int i = tid; i < m * SUBDIM; i += 256) {
+        int s = i / SUBDIM;
+        qv[i] = cb[((size_t)s * K + qc[s]) * SUBDIM + (i % SUBDIM)];
+    }
+    __syncthreads();
+    bool nan_seen = false, first = true;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const uint32_t c = c3.cand_cnt[(size_t)qi * nsplit + sp];
+        const uint32_t* __restrict__ list = c3.cand + ((size_t)qi * nsplit + sp) * c3.cap;
+        for (uint32_t base = 0; base < c; base += 256) {
+            const uint32_t i = base + tid;
+            uint64_t key = MDB_KEY_MAX;
+            if (i < c) {
+                const uint32_t slot = list[i];
+                const uint32_t vid = a.slot_ids[slot];
+                const uint32_t* cwp = codes + (size_t)(slot / MDB_TILE) * MW * MDB_TILE + (slot % MDB_TILE);
+                float s16[16], s8[8], s4[4];
+#pragma unroll
+                for (int x = 0; x < 16; ++x) s16[x] = 0.0f;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) s8[x] = 0.0f;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) s4[x] = 0.0f;
+#pragma unroll
+                for (int w = 0; w < MW; ++w) {
+                    const uint32_t word = cwp[(size_t)w * MDB_TILE];
+#pragma unroll
+                    for (int bi = 0; bi < 4; ++bi) {
+                        const int s = w * 4 + bi;
+                        if (s < m) {
+                            const uint32_t code = (word >> (8 * bi)) & 0xFFu;
+                            const float4* c4 = (const float4*)cb + ((size_t)(s << nbits) + code) * S4;
+                            const float4* q4 = (const float4*)qv + s * S4;
+                            float trow[SUBDIM];
+#pragma unroll
+                            for (int x = 0; x < S4; ++x) {
+                                const float4 q = q4[x], cc = c4[x];
+                                trow[4 * x + 0] = acc_term<MDB_METRIC_L2>(0.0f, q.x, cc.x);
+                                trow[4 * x + 1] = acc_term<MDB_METRIC_L2>(0.0f, q.y, cc.y);
+                                trow[4 * x + 2] = acc_term<MDB_METRIC_L2>(0.0f, q.z, cc.z);
+                                trow[4 * x + 3] = acc_term<MDB_METRIC_L2>(0.0f, q.w, cc.w);
+                            }
+                            pq2_add_row<SUBDIM>(trow, s16, s8, s4);
+                        }
+                    }
+                }
+                const float rs = __fadd_rn(__fadd_rn(__fadd_rn(reduce_ordered<16>(s16), reduce_ordered<8>(s8)), reduce_ordered<4>(s4)), 0.0f);
+                if (rs != rs) nan_seen = true;
+                key = make_key(rs, vid);
+            }
+            if (first) { sel.warm_start(key); first = false; }
+            sel.offer(key);
+            sel.round_end();
+        }
+    }
+    if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
+    sel.finish();
+    uint64_t* dst = a.partial + (size_t)qi * a.k;
+    const uint32_t c = sel.count();
+    for (int j = tid; j < a.k; j += 256) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
     if (a.counts_out && tid == 0) a.counts_out[qi] = c;
 }
 
@@ -1089,7 +1369,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     ScanArgs a{d_users.p, d_q_user, d_list_tile_off.p, d_slot_ids.p, d_tomb.p, d_probes, d_probe_cnt, probe_stride,
                (int)k, (uint64_t*)partial, ctx->d_flags, ctx->d_counters,
                f.allow ? f.allow : d_tomb.p + ones_word, f.allow && f.n_bitmaps != 1 ? (uint32_t)f.words : 0u, f.allow ? 0xFFFFFFFFu : 0u,
-               direct ? d_counts : nullptr};
+               direct ? d_counts : nullptr, nullptr};
     dim3 grid((unsigned)nsplit, (unsigned)b);
     size_t sel_lds = BlockSelect<MDB_BLOCK>::lds_bytes((int)k);
     void* qcodes = nullptr;
@@ -1133,6 +1413,56 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         else if (pq.subdim == 16) MDB_PQ2_LAUNCH(METRIC, 16, MWT);                                                   \
         else MDB_PQ2_LAUNCH(METRIC, 32, MWT);                                                                        \
     } while (0)
+        // two-phase scan (ivf_scan_pq3_kernel + ivf_pq3_refine_kernel) for batches of several one-phase blocks per CU: bounds at
+        // four 512-thread blocks per CU, exact distances for the candidates only; the one-phase launch behind it is gated on the
+        // candidate lists' overflow word.  (At batch 256 — one one-phase block per CU, C3 — the two extra launches and the second
+        // pass over the candidates cost more than the table build they save: 0.113 vs 0.105 ms per step.)
+        static const size_t pq3_min_b = getenv("MDB_PQ_TWO_PHASE_MIN_B") ? (size_t)atoi(getenv("MDB_PQ_TWO_PHASE_MIN_B")) : 512;
+        const bool pq3 = pq2 && metric == MDB_METRIC_L2 && direct && k <= 64 && b >= pq3_min_b && !getenv("MDB_PQ_NO_TWO_PHASE");
+        if (pq3) {
+            static const size_t tgt3 = getenv("MDB_PQ3_BLOCKS") ? (size_t)atoi(getenv("MDB_PQ3_BLOCKS")) : 512;
+            const int ns3 = (int)std::min<size_t>(std::max<size_t>((tgt3 + b - 1) / b, 1), std::min<size_t>(16, (size_t)std::max(probe_stride, 1)));
+            const uint32_t cap3 = 2048;
+            uint32_t *cand, *ccnt;
+            MDB_TRY(mdb_scratch(ctx, 13, b * (size_t)ns3 * cap3 * 4, (void**)&cand));
+            MDB_TRY(mdb_scratch(ctx, 14, b * (size_t)ns3 * 4 + 512, (void**)&ccnt));
+            uint32_t* ovf3 = ccnt + ((b * (size_t)ns3 + 63) / 64) * 64;   // own 256-byte line
+            MDB_HIP(ctx, hipMemsetAsync(ovf3, 0, 4, ctx->stream));
+            const Pq3Args c3{cand, ccnt, cap3, ovf3};
+            static const int blk3 = getenv("MDB_PQ3_BLOCK") ? atoi(getenv("MDB_PQ3_BLOCK")) : 512;   // C5 shard: 1024 -> 0.76 ms, 512 -> 0.48, 256 -> 0.49
+            const size_t sel3 = blk3 == 256 ? BlockSelect<256>::lds_bytes((int)k) : blk3 == 512 ? BlockSelect<512>::lds_bytes((int)k) : BlockSelect<1024>::lds_bytes((int)k);
+            const size_t lds3 = ((sel3 + 15) & ~(size_t)15) + (2 * PQ2_PCH + 16) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * pq.K * 4;
+            const size_t ldsr = ((BlockSelect<256>::lds_bytes((int)k) + 15) & ~(size_t)15) + (size_t)pq.m * pq.subdim * 4;
+            ScanArgs a3 = a;
+            a3.counts_out = nullptr;
+#define MDB_PQ3_SCAN_B(MWT, BLKT)                                                                                                  \
+    do {                                                                                                                           \
+        if (lds3 > 48 * 1024)                                                                                                      \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq3_kernel<MWT, BLKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+        ivf_scan_pq3_kernel<MWT, BLKT><<<dim3((unsigned)ns3, (unsigned)b), BLKT, lds3, ctx->stream>>>(a3, d_codes.p, pq.m, pq.num_bits, pq.subdim, \
+                                                                                                    pq.codebook.p, (uint8_t*)qcodes, c3);      \
+    } while (0)
+#define MDB_PQ3_SCAN(MWT) do { if (blk3 == 256) MDB_PQ3_SCAN_B(MWT, 256); else if (blk3 == 512) MDB_PQ3_SCAN_B(MWT, 512); else MDB_PQ3_SCAN_B(MWT, 1024); } while (0)
+            if (mw == 1) MDB_PQ3_SCAN(1); else if (mw == 2) MDB_PQ3_SCAN(2); else if (mw == 4) MDB_PQ3_SCAN(4); else MDB_PQ3_SCAN(8);
+#undef MDB_PQ3_SCAN
+#undef MDB_PQ3_SCAN_B
+            MDB_HIP(ctx, hipGetLastError());
+#define MDB_PQ3_REF(SD, MWT)                                                                                                      \
+    ivf_pq3_refine_kernel<SD, MWT><<<dim3((unsigned)b), 256, ldsr, ctx->stream>>>(a, d_codes.p, pq.m, pq.num_bits, pq.codebook.p,  \
+                                                                                    (uint8_t*)qcodes, c3, ns3)
+#define MDB_PQ3_REF_SD(MWT)                                                      \
+    do {                                                                         \
+        if (pq.subdim == 4) MDB_PQ3_REF(4, MWT);                                 \
+        else if (pq.subdim == 8) MDB_PQ3_REF(8, MWT);                            \
+        else if (pq.subdim == 16) MDB_PQ3_REF(16, MWT);                          \
+        else MDB_PQ3_REF(32, MWT);                                               \
+    } while (0)
+            if (mw == 1) MDB_PQ3_REF_SD(1); else if (mw == 2) MDB_PQ3_REF_SD(2); else if (mw == 4) MDB_PQ3_REF_SD(4); else MDB_PQ3_REF_SD(8);
+#undef MDB_PQ3_REF_SD
+#undef MDB_PQ3_REF
+            MDB_HIP(ctx, hipGetLastError());
+            a.gate = ovf3;
+        }
         if (pq2) {
 #define MDB_PQ2_MW(METRIC)                                                                                           \
     do {                                                                                                             \
