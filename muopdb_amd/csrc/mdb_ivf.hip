@@ -111,6 +111,7 @@ struct ScanArgs {
     uint32_t allow_stride, allow_mask;
     uint32_t* counts_out;          // nsplit == 1: `partial` is the final [B][k] key array and the row lengths go here (no merge launch)
     const uint32_t* gate;          // non-null: the launch is a fallback and returns at once unless *gate != 0 (its scored count is not added)
+    int eager_trim;                // PQ bound-filter scan: tighten the selector's threshold as soon as k + 64 keys are queued
 };
 
 __device__ __forceinline__ bool tomb_test(const uint32_t* tomb, uint32_t base_word, uint32_t pid) {
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
     constexpr int S4 = SUBDIM / 4;
     bool nan_seen = false, bad = false;
     unsigned scored = 0;
+    const bool eager_trim = a.eager_trim != 0;
 
     // ---- table: lut[s][c][e] = term(q_s[e], cb[s][c][e]), each individually rounded
     for (int i = tid; i < m * SUBDIM; i += PQ2_BLOCK) {
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
                     }
                     if (p0 == 0 && r == 2) sel.warm_start(key);
                     sel.offer(key);
-                    sel.round_end();
+                    sel.round_end(FILT && eager_trim ? (uint32_t)a.k + 64u : 0xFFFFFFFFu);
                 }
             };
             if (T > 0) {
@@ -1369,7 +1371,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     ScanArgs a{d_users.p, d_q_user, d_list_tile_off.p, d_slot_ids.p, d_tomb.p, d_probes, d_probe_cnt, probe_stride,
                (int)k, (uint64_t*)partial, ctx->d_flags, ctx->d_counters,
                f.allow ? f.allow : d_tomb.p + ones_word, f.allow && f.n_bitmaps != 1 ? (uint32_t)f.words : 0u, f.allow ? 0xFFFFFFFFu : 0u,
-               direct ? d_counts : nullptr, nullptr};
+               direct ? d_counts : nullptr, nullptr, getenv("MDB_PQ_EAGER_TRIM") ? atoi(getenv("MDB_PQ_EAGER_TRIM")) : 1};
     dim3 grid((unsigned)nsplit, (unsigned)b);
     size_t sel_lds = BlockSelect<MDB_BLOCK>::lds_bytes((int)k);
     void* qcodes = nullptr;
