@@ -696,8 +696,9 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
 // ------------------------------------------------------------------------------------------ refine
 // MF_RS blocks per query, each over its slice of the query's candidate list: exact distances and a partial top-k (merged
 // by merge_keys).  A list longer than its capacity raises `ovf` instead (-> gated exact scan of the batch).
-template <int METRIC, bool ROWS>   // ROWS: `tiles` is the row-major copy (FlatAux::rows)
-__global__ __launch_bounds__(MDB_BLOCK) void flat_refine_kernel(const float4* __restrict__ tiles, DistPlan p,
+template <int METRIC, bool ROWS, int BLK>   // ROWS: `tiles` is the row-major copy (FlatAux::rows); BLK: threads per slice (64: one wave, for
+                                            // large batches — a slice then holds ~64 candidates and three of a 256-thread block's waves idle)
+__global__ __launch_bounds__(BLK) void flat_refine_kernel(const float4* __restrict__ tiles, DistPlan p,
                                                                 const float* __restrict__ dq, int qstride,
                                                                 const uint32_t* __restrict__ qcnt, const uint32_t* __restrict__ qids,
                                                                 uint32_t qcap, int k, uint64_t* __restrict__ keys,
@@ -711,12 +712,12 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_refine_kernel(const float4* __
     }
     const uint32_t lo = (uint32_t)((uint64_t)np * blockIdx.x / gridDim.x), c = (uint32_t)((uint64_t)np * (blockIdx.x + 1) / gridDim.x) - lo;
     const uint32_t* __restrict__ mine = qids + m * (size_t)qcap + lo;
-    BlockSelect<MDB_BLOCK> sel;
+    BlockSelect<BLK> sel;
     sel.init(lds, k);
     __syncthreads();
     const float* qb = dq + m * qstride;
     bool nan_seen = false, first = true;
-    for (uint32_t base = 0; base < c; base += MDB_BLOCK) {
+    for (uint32_t base = 0; base < c; base += BLK) {
         uint32_t i = base + threadIdx.x;
         uint64_t key = MDB_KEY_MAX;
         if (i < c) {
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_refine_kernel(const float4* __
     sel.finish();
     uint32_t cc = sel.count();
     uint64_t* dst = keys + (m * gridDim.x + blockIdx.x) * (size_t)k;  // partial [query][slice][k]
-    for (int j = threadIdx.x; j < k; j += MDB_BLOCK) dst[j] = j < (int)cc ? sel.buf[j] : MDB_KEY_MAX;
+    for (int j = threadIdx.x; j < k; j += BLK) dst[j] = j < (int)cc ? sel.buf[j] : MDB_KEY_MAX;
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -898,7 +899,9 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     }
     // C. refine
     DistPlan p = make_plan(ts.d, metric);
-    size_t sel_lds = ((BlockSelect<MDB_BLOCK>::lds_bytes((int)k) + 15) & ~(size_t)15) + 16;
+    static const size_t wave_min_b = getenv("MDB_REFINE_WAVE_MIN_B") ? (size_t)atoi(getenv("MDB_REFINE_WAVE_MIN_B")) : 512;
+    const bool wave_slices = b >= wave_min_b && k <= 64;   // one wave per slice
+    size_t sel_lds = ((std::max(BlockSelect<MDB_BLOCK>::lds_bytes((int)k), BlockSelect<64>::lds_bytes((int)k)) + 15) & ~(size_t)15) + 16;
     uint64_t* rpart;
     const unsigned rs = MF_RS;   // (fewer, larger slices for large batches were measured: 2.5x slower — a block's rounds are latency bound)
     MDB_TRY(mdb_scratch(ctx, 10, b * (size_t)rs * std::max<size_t>(k, 1) * 8, (void**)&rpart));
@@ -906,8 +909,14 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     const bool rows = aux.rows.p != nullptr;
     const float4* rsrc = rows ? (const float4*)aux.rows.p : (const float4*)ts.data;
 #define RF_LAUNCH(METRIC, ROWS)                                                                                                \
-    flat_refine_kernel<METRIC, ROWS><<<dim3(rs, (unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(rsrc, p, dq, qstride, qcnt, qids, qcap, \
-                                                                                                  (int)k, rpart, ovf, ctx->d_flags)
+    do {                                                                                                                       \
+        if (wave_slices)                                                                                                       \
+            flat_refine_kernel<METRIC, ROWS, 64><<<dim3(rs, (unsigned)b), 64, sel_lds, ctx->stream>>>(rsrc, p, dq, qstride, qcnt, qids, qcap, \
+                                                                                                   (int)k, rpart, ovf, ctx->d_flags);        \
+        else                                                                                                                   \
+            flat_refine_kernel<METRIC, ROWS, MDB_BLOCK><<<dim3(rs, (unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(                          \
+                rsrc, p, dq, qstride, qcnt, qids, qcap, (int)k, rpart, ovf, ctx->d_flags);                                                    \
+    } while (0)
     if (metric == MDB_METRIC_L2) { if (rows) RF_LAUNCH(MDB_METRIC_L2, true); else RF_LAUNCH(MDB_METRIC_L2, false); }
     else { if (rows) RF_LAUNCH(MDB_METRIC_DOT, true); else RF_LAUNCH(MDB_METRIC_DOT, false); }
 #undef RF_LAUNCH

@@ -13,7 +13,7 @@ WL="$@"; [ -z "$WL" ] && WL="hnsw flat_b1 flat_b64 ivfpq spann c5"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 DUMP=/tmp/mdb_dump_round
-PAT="hnsw_|flat_scan|flat_mfma|flat_bf16|flat_refine|sample_bound|ivf_scan|merge_keys"
+PAT="hnsw_|flat_scan|flat_mfma|flat_bf16|flat_refine|sample_bound|ivf_scan|ivf_pq3|merge_keys"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # every workload's files + the un-instrumented bench line

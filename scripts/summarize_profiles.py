@@ -14,7 +14,7 @@ WL = {  # workload -> (dominant kernel prefix, bench.py traffic key, config matc
     "flat_b64": ("flat_bf16_filter_kernel<0, 2, 8, false>", "flat_b64", {"n": 1000000, "dim": 128, "batch": 64, "k": 10}),
     "ivfpq": ("ivf_scan_pq2_kernel", "ivfpq", {"n": 1000000, "dim": 128, "batch": 256, "k": 10, "nprobe": 16}),
     "spann": ("ivf_scan_f32_kernel", "spann", {"n": 1250048, "dim": 768, "batch": 128, "k": 10}),
-    "c5": ("ivf_scan_pq2_kernel", "c5", {"dim": 128, "batch": 4096, "k": 10, "nprobe": 64}),
+    "c5": ("ivf_scan_pq3_kernel", "c5", {"dim": 128, "batch": 4096, "k": 10, "nprobe": 64}),   # two-phase scan: phase 1 dominates
 }
 bench = json.loads(open(os.path.join(src, "bench_all.json")).read().strip().splitlines()[-1])
 shutil.copy(os.path.join(src, "bench_all.json"), os.path.join(dst, "%s_bench_all.json" % rnd))
