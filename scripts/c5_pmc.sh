@@ -16,7 +16,7 @@ for G in "$@"; do
   i=$((i+1)); rm -rf /tmp/pmc_c5_$i
   timeout 300 rocprofv3 --pmc $G --kernel-trace --output-format csv -d /tmp/pmc_c5_$i -o r -- $REPO/muopdb_amd/replay_search ivfpq $DUMP/c5 128 10 64 4096 3 > $OUT/pmc_$i.log 2>&1
   echo "rc=$? group: $G" | tee -a $OUT/pmc_$i.log
-  for f in /tmp/pmc_c5_$i/*counter_collection.csv; do [ -f "$f" ] && (head -1 $f; grep -E "ivf_scan_pq2|flat_bf16_filter" $f) > $OUT/pmc_$i.csv; done
+  for f in /tmp/pmc_c5_$i/*counter_collection.csv; do [ -f "$f" ] && (head -1 $f; grep -E "ivf_scan_pq|ivf_pq3|flat_refine" $f) > $OUT/pmc_$i.csv; done
   python3 - $OUT/pmc_$i.csv <<'PY'
 import csv,sys,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(set)
