@@ -903,7 +903,10 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     const bool wave_slices = b >= wave_min_b && k <= 64;   // one wave per slice
     size_t sel_lds = ((std::max(BlockSelect<MDB_BLOCK>::lds_bytes((int)k), BlockSelect<64>::lds_bytes((int)k)) + 15) & ~(size_t)15) + 16;
     uint64_t* rpart;
-    const unsigned rs = MF_RS;   // (fewer, larger slices for large batches were measured: 2.5x slower — a block's rounds are latency bound)
+    static const unsigned rs_env = getenv("MDB_REFINE_SLICES") ? (unsigned)atoi(getenv("MDB_REFINE_SLICES")) : 0;
+    // 256-thread slices: fewer, larger ones measured 2.5x slower (a block's rounds are latency bound); one-wave slices: 4 beat 8 and 16
+    // (C5 coarse: refine 157 / 167 / 175 us, merge 23 / 34 / 38 us)
+    const unsigned rs = rs_env ? rs_env : (wave_slices ? 4 : MF_RS);
     MDB_TRY(mdb_scratch(ctx, 10, b * (size_t)rs * std::max<size_t>(k, 1) * 8, (void**)&rpart));
     MDB_HIP(ctx, hipMemsetAsync(rpart, 0xFF, b * (size_t)rs * k * 8, ctx->stream));  // a slice that bails out leaves KEY_MAX
     const bool rows = aux.rows.p != nullptr;
