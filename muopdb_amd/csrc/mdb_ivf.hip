@@ -404,11 +404,16 @@ __device__ __forceinline__ void pq2_add_row(const float* __restrict__ row, float
     }
 }
 
-template <int METRIC, int SUBDIM, int MW, bool FILT>
-__global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m,
-                                                                 int nbits, const float* __restrict__ cb,
+// FULL: m == 4 MW and nbits == 8 (the usual codebooks) as COMPILE-TIME facts.  With run-time m / nbits every one of the m lookups
+// of a vector sat behind its own uniform branch (`s < m`, the condition masks and per-subspace table bases were 48 spilled scalars,
+// re-read with v_readlane per lookup) and its LDS read was waited for at once: m dependent LDS round trips per tile.  Constant-folded,
+// the reads become m independent ds_reads with immediate offsets.
+template <int METRIC, int SUBDIM, int MW, bool FILT, bool FULL>
+__global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m_rt,
+                                                                 int nbits_rt, const float* __restrict__ cb,
                                                                  const uint8_t* __restrict__ qcodes) {
     static_assert(SUBDIM % 4 == 0 && (SUBDIM & (SUBDIM - 1)) == 0, "SUBDIM: power of two >= 4");
+    const int m = FULL ? 4 * MW : m_rt, nbits = FULL ? 8 : nbits_rt;
     if (a.gate && __builtin_nontemporal_load(a.gate) == 0u) return;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     BlockSelect<PQ2_BLOCK> sel;
@@ -697,9 +702,10 @@ struct Pq3Args {
     uint32_t* ovf;
 };
 
-template <int MW, int BLK>
-__global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m, int nbits, int subdim,
+template <int MW, int BLK, bool FULL>   // FULL: as in ivf_scan_pq2_kernel
+__global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m_rt, int nbits_rt, int subdim,
                                                                  const float* __restrict__ cb, const uint8_t* __restrict__ qcodes, Pq3Args c3) {
+    const int m = FULL ? 4 * MW : m_rt, nbits = FULL ? 8 : nbits_rt;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     BlockSelect<BLK> sel;
     sel.init(lds, a.k);
@@ -879,10 +885,11 @@ __global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uin
 }
 
 // phase 2: exact symmetric distances of a query's candidates (all splits), top-k -> the final key rows
-template <int SUBDIM, int MW>
-__global__ __launch_bounds__(256) void ivf_pq3_refine_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m, int nbits,
+template <int SUBDIM, int MW, bool FULL>
+__global__ __launch_bounds__(256) void ivf_pq3_refine_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m_rt, int nbits_rt,
                                                              const float* __restrict__ cb, const uint8_t* __restrict__ qcodes, Pq3Args c3,
                                                              int nsplit) {
+    const int m = FULL ? 4 * MW : m_rt, nbits = FULL ? 8 : nbits_rt;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     BlockSelect<256> sel;
     sel.init(lds, a.k);
@@ -1348,7 +1355,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     }
     // PQ fast path (ivf_scan_pq2_kernel): compile-time subvector width, table + selector + tile map in LDS
     size_t pq2_lds = 0, pq2_lds_f = 0;
-    bool pq2 = false, pq2_filt = false;
+    bool pq2 = false, pq2_filt = false, pq_full = false;
     if (kind == MDB_QUANT_PQ && !getenv("MDB_PQ_NO_FAST")) {
         pq2_lds = ((BlockSelect<PQ2_BLOCK>::lds_bytes((int)k) + 15) & ~(size_t)15) + (2 * PQ2_PCH + 16) * 4 +
                   (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * pq.K * pq.subdim * 4;
@@ -1357,6 +1364,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         // L2: bound filter in front of the exact row sums (ivf_scan_pq2_kernel<.., FILT>) when its table fits too
         pq2_lds_f = pq2_lds + (size_t)pq.m * pq.K * 2;
         pq2_filt = pq2 && metric == MDB_METRIC_L2 && pq2_lds_f <= 160 * 1024 - 256 && !getenv("MDB_PQ_NO_FILTER");
+        pq_full = pq.m == 4 * mw && pq.num_bits == 8 && !getenv("MDB_PQ_NO_FULL");
         if (pq2) {  // one block per CU (LDS).  More, shorter blocks do NOT balance skewed lists better here: the hardware
             // dispatches 150 KB-LDS workgroups in order, so CUs idle between blocks (measured: 256 blocks 98 us,
             // 512 blocks 140 us, 1024 blocks 247 us for the same work)
@@ -1394,20 +1402,21 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         ivf_scan_pq_kernel<METRIC, LUT><<<grid, MDB_BLOCK, (LDS), ctx->stream>>>(a, d_codes.p, pq.m, mw, pq.K, pq.subdim, \
                                                                                   sp, pq.codebook.p, (uint8_t*)qcodes); \
     } while (0)
-#define MDB_PQ2_LAUNCH(METRIC, SD, MWT)                                                                               \
+#define MDB_PQ2_LAUNCH_F(METRIC, SD, MWT, FULLT)                                                                      \
     do {                                                                                                             \
         if (METRIC == MDB_METRIC_L2 && pq2_filt) {                                                                   \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq2_kernel<METRIC, SD, MWT, METRIC == MDB_METRIC_L2>,  \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq2_kernel<METRIC, SD, MWT, METRIC == MDB_METRIC_L2, FULLT>,  \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq2_lds_f));          \
-            ivf_scan_pq2_kernel<METRIC, SD, MWT, METRIC == MDB_METRIC_L2><<<grid, PQ2_BLOCK, pq2_lds_f, ctx->stream>>>(   \
+            ivf_scan_pq2_kernel<METRIC, SD, MWT, METRIC == MDB_METRIC_L2, FULLT><<<grid, PQ2_BLOCK, pq2_lds_f, ctx->stream>>>(   \
                 a, d_codes.p, pq.m, pq.num_bits, pq.codebook.p, (uint8_t*)qcodes);                               \
         } else {                                                                                                     \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq2_kernel<METRIC, SD, MWT, false>,                   \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq2_kernel<METRIC, SD, MWT, false, FULLT>,            \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pq2_lds));            \
-            ivf_scan_pq2_kernel<METRIC, SD, MWT, false><<<grid, PQ2_BLOCK, pq2_lds, ctx->stream>>>(                      \
+            ivf_scan_pq2_kernel<METRIC, SD, MWT, false, FULLT><<<grid, PQ2_BLOCK, pq2_lds, ctx->stream>>>(               \
                 a, d_codes.p, pq.m, pq.num_bits, pq.codebook.p, (uint8_t*)qcodes);                               \
         }                                                                                                            \
     } while (0)
+#define MDB_PQ2_LAUNCH(METRIC, SD, MWT) do { if (pq_full) MDB_PQ2_LAUNCH_F(METRIC, SD, MWT, true); else MDB_PQ2_LAUNCH_F(METRIC, SD, MWT, false); } while (0)
 #define MDB_PQ2_SD(METRIC, MWT)                                                                                      \
     do {                                                                                                             \
         if (pq.subdim == 4) MDB_PQ2_LAUNCH(METRIC, 4, MWT);                                                          \
@@ -1432,26 +1441,34 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
             MDB_HIP(ctx, hipMemsetAsync(ovf3, 0, 4, ctx->stream));
             const Pq3Args c3{cand, ccnt, cap3, ovf3};
             static const int blk3 = getenv("MDB_PQ3_BLOCK") ? atoi(getenv("MDB_PQ3_BLOCK")) : 512;   // C5 shard: 1024 -> 0.76 ms, 512 -> 0.48, 256 -> 0.49
-            const size_t sel3 = blk3 == 256 ? BlockSelect<256>::lds_bytes((int)k) : blk3 == 512 ? BlockSelect<512>::lds_bytes((int)k) : BlockSelect<1024>::lds_bytes((int)k);
+            const size_t sel3 = blk3 == 1024 ? BlockSelect<1024>::lds_bytes((int)k) : BlockSelect<512>::lds_bytes((int)k);
             const size_t lds3 = ((sel3 + 15) & ~(size_t)15) + (2 * PQ2_PCH + 16) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * pq.K * 4;
             const size_t ldsr = ((BlockSelect<256>::lds_bytes((int)k) + 15) & ~(size_t)15) + (size_t)pq.m * pq.subdim * 4;
             ScanArgs a3 = a;
             a3.counts_out = nullptr;
-#define MDB_PQ3_SCAN_B(MWT, BLKT)                                                                                                  \
+#define MDB_PQ3_SCAN_F(MWT, BLKT, FULLT)                                                                                          \
     do {                                                                                                                           \
         if (lds3 > 48 * 1024)                                                                                                      \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq3_kernel<MWT, BLKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
-        ivf_scan_pq3_kernel<MWT, BLKT><<<dim3((unsigned)ns3, (unsigned)b), BLKT, lds3, ctx->stream>>>(a3, d_codes.p, pq.m, pq.num_bits, pq.subdim, \
-                                                                                                    pq.codebook.p, (uint8_t*)qcodes, c3);      \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq3_kernel<MWT, BLKT, FULLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+        ivf_scan_pq3_kernel<MWT, BLKT, FULLT><<<dim3((unsigned)ns3, (unsigned)b), BLKT, lds3, ctx->stream>>>(a3, d_codes.p, pq.m, pq.num_bits, pq.subdim, \
+                                                                                                           pq.codebook.p, (uint8_t*)qcodes, c3);  \
     } while (0)
-#define MDB_PQ3_SCAN(MWT) do { if (blk3 == 256) MDB_PQ3_SCAN_B(MWT, 256); else if (blk3 == 512) MDB_PQ3_SCAN_B(MWT, 512); else MDB_PQ3_SCAN_B(MWT, 1024); } while (0)
+#define MDB_PQ3_SCAN_B(MWT, BLKT) do { if (pq_full) MDB_PQ3_SCAN_F(MWT, BLKT, true); else MDB_PQ3_SCAN_F(MWT, BLKT, false); } while (0)
+#define MDB_PQ3_SCAN(MWT) do { if (blk3 == 1024) MDB_PQ3_SCAN_B(MWT, 1024); else MDB_PQ3_SCAN_B(MWT, 512); } while (0)
             if (mw == 1) MDB_PQ3_SCAN(1); else if (mw == 2) MDB_PQ3_SCAN(2); else if (mw == 4) MDB_PQ3_SCAN(4); else MDB_PQ3_SCAN(8);
 #undef MDB_PQ3_SCAN
 #undef MDB_PQ3_SCAN_B
+#undef MDB_PQ3_SCAN_F
             MDB_HIP(ctx, hipGetLastError());
 #define MDB_PQ3_REF(SD, MWT)                                                                                                      \
-    ivf_pq3_refine_kernel<SD, MWT><<<dim3((unsigned)b), 256, ldsr, ctx->stream>>>(a, d_codes.p, pq.m, pq.num_bits, pq.codebook.p,  \
-                                                                                    (uint8_t*)qcodes, c3, ns3)
+    do {                                                                                                                          \
+        if (pq_full)                                                                                                              \
+            ivf_pq3_refine_kernel<SD, MWT, true><<<dim3((unsigned)b), 256, ldsr, ctx->stream>>>(a, d_codes.p, pq.m, pq.num_bits, pq.codebook.p, \
+                                                                                                  (uint8_t*)qcodes, c3, ns3);              \
+        else                                                                                                                      \
+            ivf_pq3_refine_kernel<SD, MWT, false><<<dim3((unsigned)b), 256, ldsr, ctx->stream>>>(a, d_codes.p, pq.m, pq.num_bits, pq.codebook.p, \
+                                                                                                   (uint8_t*)qcodes, c3, ns3);             \
+    } while (0)
 #define MDB_PQ3_REF_SD(MWT)                                                      \
     do {                                                                         \
         if (pq.subdim == 4) MDB_PQ3_REF(4, MWT);                                 \
@@ -1482,6 +1499,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         }
 #undef MDB_PQ2_SD
 #undef MDB_PQ2_LAUNCH
+#undef MDB_PQ2_LAUNCH_F
 #undef MDB_PQ_LAUNCH
     } else {
         DistPlan p = make_plan((int)num_features, metric);
