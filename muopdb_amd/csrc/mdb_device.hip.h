@@ -78,7 +78,7 @@ struct Row4Loader {  // row-major row whose start is 16-byte aligned and whose l
 // QT queries against ONE stored vector (this thread's).  q[i] = qbase + i*qstride must be
 // wave-uniform (scalar loads).  Returns the raw cascade sum (squared L2 / positive dot).
 // DB (streaming scans only): register double buffer of the 16-lane passes, see below.
-template <int METRIC, int QT, class Loader, bool DB = false>
+template <int METRIC, int QT, class Loader, int DB = 0>   // DB: 0 / 2 / 3 register buffers of 8 loads
 __device__ __forceinline__ void exact_sums(const Loader& ld, const float* __restrict__ qbase, int qstride,
                                            const DistPlan& p, float (&out)[QT]) {
     float ret[QT];
@@ -117,7 +117,24 @@ __device__ __forceinline__ void exact_sums(const Loader& ld, const float* __rest
             // bytes-in-flight problem (the loop is unrolled by two steps so that the buffer roles are static).  NOT for gathers of single
             // rows (refine, quantize): the 64 extra registers cost them occupancy — 229 -> 300 us and 55 -> 105 us on C5's coarse refine / quantize
             const int pairs = p.n16 >> 1;
-            if (pairs > 0) {
+            if (DB >= 3 && pairs > 0) {
+                // three buffers: 24 loads (384 B) per lane in flight — long vectors (d = 768: 24 steps) on short posting lists, where few
+                // waves stream at a time
+                float4 va[8], vb[8], vc[8];
+                load8(va, 0);
+                if (pairs > 1) load8(vb, 2);
+                int i = 0;
+                for (; i + 3 <= pairs; i += 3) {
+                    load8(vc, 2 * (i + 2));
+                    add8(va, 2 * i);
+                    if (i + 3 < pairs) load8(va, 2 * (i + 3));
+                    add8(vb, 2 * (i + 1));
+                    if (i + 4 < pairs) load8(vb, 2 * (i + 4));
+                    add8(vc, 2 * (i + 2));
+                }
+                if (i < pairs) add8(va, 2 * i);
+                if (i + 1 < pairs) add8(vb, 2 * (i + 1));
+            } else if (pairs > 0) {
                 float4 va[8], vb[8];
                 load8(va, 0);
                 int i = 0;

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_scan_kernel(const float4* __re
         float raw[QT];
         if (valid) {
             TileLoader ld{tiles + tile * (size_t)p.d4 * MDB_TILE + lane};
-            exact_sums<METRIC, QT, TileLoader, true>(ld, qb, qstride, p, raw);
+            exact_sums<METRIC, QT, TileLoader, 2>(ld, qb, qstride, p, raw);
         }
 #pragma unroll
         for (int i = 0; i < QT; ++i) {

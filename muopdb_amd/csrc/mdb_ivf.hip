@@ -214,7 +214,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
                     if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid) && allow_test(a, qi, pid)) {
                         TileLoader ld{tiles + (size_t)tile * p.d4 * MDB_TILE + lane};
                         float raw[1];
-                        exact_sums<METRIC, 1, TileLoader, true>(ld, qb, 0, p, raw);
+                        exact_sums<METRIC, 1, TileLoader, 3>(ld, qb, 0, p, raw);
                         float dist = finish_distance<METRIC>(raw[0]);
                         if (dist != dist) nan_seen = true;
                         key = make_key(dist, pid);
