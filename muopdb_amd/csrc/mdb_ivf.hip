@@ -1428,12 +1428,12 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         // four 512-thread blocks per CU, exact distances for the candidates only; the one-phase launch behind it is gated on the
         // candidate lists' overflow word.  (At batch 256 — one one-phase block per CU, C3 — the two extra launches and the second
         // pass over the candidates cost more than the table build they save: 0.113 vs 0.105 ms per step.)
-        static const size_t pq3_min_b = getenv("MDB_PQ_TWO_PHASE_MIN_B") ? (size_t)atoi(getenv("MDB_PQ_TWO_PHASE_MIN_B")) : 512;
+        const size_t pq3_min_b = getenv("MDB_PQ_TWO_PHASE_MIN_B") ? (size_t)atoi(getenv("MDB_PQ_TWO_PHASE_MIN_B")) : 512;   // (read per call: tests toggle it)
         const bool pq3 = pq2 && metric == MDB_METRIC_L2 && direct && k <= 64 && b >= pq3_min_b && !getenv("MDB_PQ_NO_TWO_PHASE");
         if (pq3) {
             static const size_t tgt3 = getenv("MDB_PQ3_BLOCKS") ? (size_t)atoi(getenv("MDB_PQ3_BLOCKS")) : 512;
             const int ns3 = (int)std::min<size_t>(std::max<size_t>((tgt3 + b - 1) / b, 1), std::min<size_t>(16, (size_t)std::max(probe_stride, 1)));
-            const uint32_t cap3 = 2048;
+            const uint32_t cap3 = getenv("MDB_PQ3_CAP") ? (uint32_t)std::max(1, atoi(getenv("MDB_PQ3_CAP"))) : 2048;   // (tests force the overflow path)
             uint32_t *cand, *ccnt;
             MDB_TRY(mdb_scratch(ctx, 13, b * (size_t)ns3 * cap3 * 4, (void**)&cand));
             MDB_TRY(mdb_scratch(ctx, 14, b * (size_t)ns3 * 4 + 512, (void**)&ccnt));

@@ -112,7 +112,9 @@ def case_ivf(ctx, rng):
     else:
         index, vec, _ = H.build_ivf_files(v, doc, cent, clusters_per_vector=cpv)
         g, o = BlockBasedIvf(ctx, index, vec), oracle.BlockBasedIvf(index, vec)
-    b = int(rng.choice([1, 4, 19, 64]))
+    b = int(rng.choice([1, 4, 19, 64, 300, 530]))   # 300 / 530: one one-phase block per query / the two-phase PQ scan's range
+    if b > 64 and n > 3000:
+        b = 64
     q = (v[rng.integers(0, n, b)] + rng.normal(0, 1, (b, d))).astype(np.float32)
     for step in range(2):
         err = rows_equal(g.search(q, k, P), o.search(q, k, num_probes=P), b)

@@ -404,6 +404,28 @@ def test_ivf_pq_bound_filter_adversarial(ctx, oracle, case):
         st2 = ctx.stats()
         assert_result_rows(gres2, ores, len(q))
         assert st["scored_vectors"] == st2["scored_vectors"] == n * len(q)
+        if kk <= 64:
+            # the two-phase scan (bf16 lower / upper bounds, then exact distances of the candidates: batches >= 512);
+            # then with candidate lists of 8 slots: every list overflows and the gated one-phase launch behind redoes the batch
+            # (its scored count must not be added a second time)
+            qb = np.concatenate([q, v[rng.integers(0, n, 560 - len(q))].astype(np.float32)])     # 560 queries: the path's own batch range
+            pb = np.tile(np.arange(L, dtype=np.uint32), (len(qb), 1))
+            oresb = o.search(qb, kk, probes=pb)
+            for cap in (None, "8"):
+                if cap:
+                    os.environ["MDB_PQ3_CAP"] = cap
+                try:
+                    gres3 = g.search_with_centroids_and_remap(qb, pb, kk)
+                finally:
+                    os.environ.pop("MDB_PQ3_CAP", None)
+                st3 = ctx.stats()
+                assert_result_rows(gres3, oresb, len(qb))
+                assert st3["scored_vectors"] == n * len(qb), (cap, st3["scored_vectors"])
+            os.environ["MDB_PQ_NO_TWO_PHASE"] = "1"                                                 # and the one-phase kernel on the same batch
+            try:
+                assert_result_rows(g.search_with_centroids_and_remap(qb, pb, kk), oresb, len(qb))
+            finally:
+                del os.environ["MDB_PQ_NO_TWO_PHASE"]
 
 
 def test_ivf_large_coarse_quantizer_batched_path(ctx, oracle):
