@@ -380,12 +380,10 @@ __global__ __launch_bounds__(256) void pq_quantize_kernel(const float* __restric
             best = key < best ? key : best;
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(best >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, o);
-        best = other < best ? other : best;
-    }
-    if (lane == 0) codes[t] = best == ~0ull ? (uint8_t)0 : (uint8_t)(best & 0xFFFFFFFFu);
+    // minimum of the (distance image, centroid) keys over the wave: smallest image first, then the smallest index among its holders
+    const uint32_t mo = mdb_wave_min_u32((uint32_t)(best >> 32));
+    const uint32_t mi = mdb_wave_min_u32((uint32_t)(best >> 32) == mo ? (uint32_t)best : 0xFFFFFFFFu);
+    if (lane == 0) codes[t] = mo == 0xFFFFFFFFu ? (uint8_t)0 : (uint8_t)mi;
 }
 
 mdb_status pq_quantize_device(mdb_ctx* ctx, const PqDev& pq, const float* d_vecs, size_t n, uint8_t* d_codes, int row_stride) {

@@ -16,6 +16,18 @@
 // __ocml_sqrt_f32) is used for DistanceCalculator::calculate.
 #pragma clang fp contract(off)
 __device__ __forceinline__ float mdb_sqrtf(float x) { return sqrtf(x); }
+// wave-wide unsigned min by DPP (six v_min with a DPP source: ~100 cycles; the __shfl_xor butterfly goes through the LDS crossbar,
+// ~1.2 k cycles for a 64-bit key)
+#define MDB_DPP_MIN_STEP(v, ctrl, rmask) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rmask), 0xF, false))
+__device__ __forceinline__ uint32_t mdb_wave_min_u32(uint32_t v) {
+    MDB_DPP_MIN_STEP(v, 0xB1, 0xF);   // quad_perm [1,0,3,2]
+    MDB_DPP_MIN_STEP(v, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+    MDB_DPP_MIN_STEP(v, 0x141, 0xF);  // row_half_mirror
+    MDB_DPP_MIN_STEP(v, 0x140, 0xF);  // row_mirror
+    MDB_DPP_MIN_STEP(v, 0x142, 0xA);  // row_bcast:15
+    MDB_DPP_MIN_STEP(v, 0x143, 0xC);  // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 // ------------------------------------------------------------------------------------------ keys
 __device__ __forceinline__ uint32_t f32_orderable(float f) {
