@@ -1136,6 +1136,9 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
 #ifndef PIPE_POLL_SLEEP
 #define PIPE_POLL_SLEEP 0   // critical waves poll without sleeping (nobody else wants their SIMD)
 #endif
+#ifndef PIPE_DIST_SLEEP
+#define PIPE_DIST_SLEEP 1
+#endif
 #define PIPE_CRIT_WAIT() do { if (PIPE_POLL_SLEEP) __builtin_amdgcn_s_sleep(PIPE_POLL_SLEEP); } while (0)
 #define PIPE_LDS_NB (BEAM_LDS_C + 8192)      // nb_id[2][64] | nb_od[2][64]: the new-neighbour lists of even / odd steps
 #define PIPE_LDS_MIR (PIPE_LDS_NB + 1024)    // candidate mirror: {cd, id}[320] (cd = distance image of an unexpanded slot, else EMPTY)
@@ -1156,12 +1159,21 @@ enum {
 // ONE LDS read returns the whole mailbox (lane i = word i; every word lives in the first 32 lanes' pass, so the snapshot is
 // a single point in time); fields are then picked out of the register with v_readlane — a poll costs one LDS round trip
 // however many words it looks at.
-__device__ __forceinline__ uint32_t mb_snap(const uint32_t* mb, int lane) { return *(const volatile uint32_t*)(mb + (lane & 31)); }
+// Volatile accesses through a GENERIC pointer are never rewritten to the LDS address space (InferAddressSpaces leaves volatile
+// memory operations alone): they compile to flat_load / flat_store with system scope and an s_waitcnt vmcnt(0) each — a poll of
+// the mailbox then costs a flat round trip AND waits for every outstanding global load of the wave.  These accessors name the
+// address space, so the accesses are plain ds_read / ds_write.
+typedef __attribute__((address_space(3))) uint32_t mdb_lds_u32;
+typedef __attribute__((address_space(3))) uint64_t mdb_lds_u64;
+__device__ __forceinline__ uint32_t lds_vload(const uint32_t* p) { return *(const volatile mdb_lds_u32*)p; }
+__device__ __forceinline__ uint64_t lds_vload(const uint64_t* p) { return *(const volatile mdb_lds_u64*)p; }
+__device__ __forceinline__ void lds_vstore(uint32_t* p, uint32_t v) { *(volatile mdb_lds_u32*)p = v; }
+__device__ __forceinline__ uint32_t mb_snap(const uint32_t* mb, int lane) { return lds_vload(mb + (lane & 31)); }
 #define MBW(snap, i) ((uint32_t)__builtin_amdgcn_readlane((int)(snap), (i)))
 // requests alternate between the two speculation buffers (rid & 1), so request rid is the ((rid + (rid & 1)) / 2)-th of its buffer
 __device__ __forceinline__ uint32_t spec_done_count(uint32_t rid) { return 3u * ((rid + (rid & 1u)) >> 1); }
 enum { CF_VALID = 1, AF_MORE = 4, AF_MOVED = 8 };   // candidate record flags: entry holds a candidate; more than two accepted; slots moved
-__device__ __forceinline__ void mb_store(uint32_t* mb, int i, uint32_t v) { *(volatile uint32_t*)(mb + i) = v; }
+__device__ __forceinline__ void mb_store(uint32_t* mb, int i, uint32_t v) { lds_vstore(mb + i, v); }
 // The LDS operations of one wave are issued and completed in order, so publishing data before a flag (and reading a flag before
 // the data) only needs the COMPILER kept from reordering them; a real fence would also wait for the outstanding global loads —
 // the prefetched adjacency rows.
@@ -1533,8 +1545,8 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 if (sb >= 0) {
                     // wave 2 may hand the buffer to another node at any time: read, THEN check that the buffer still names this
                     // request (the distance waves overwrite it only after the new request is published; LDS runs in order)
-                    sv = *(const volatile uint32_t*)(spec_od + sb * 64 + lane);
-                    nbr = *(const volatile uint32_t*)(srow + sb * 64 + lane);
+                    sv = lds_vload(spec_od + sb * 64 + lane);
+                    nbr = lds_vload(srow + sb * 64 + lane);
                     PIPE_ACQUIRE();
                     const uint32_t s2 = mb_snap(mb, lane);
                     if (__ballot(s2 != snap) & (sb ? (1ull << MB_SNODE1) | (1ull << MB_SRID1) : (1ull << MB_SNODE0) | (1ull << MB_SRID0))) {
@@ -1662,7 +1674,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 if (full) {
 #pragma unroll
                     for (int r = 0; r < BREGS; ++r) {
-                        const uint64_t e = *(const volatile uint64_t*)(mir + lane + 64 * r);
+                        const uint64_t e = lds_vload(mir + lane + 64 * r);
                         cd[r] = (uint32_t)e;
                         ci[r] = (uint32_t)(e >> 32);
                     }
@@ -1720,7 +1732,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 PIPE_TB(t_w2);
 #pragma unroll
                 for (int r = 0; r < BREGS; ++r) {
-                    const uint64_t e = *(const volatile uint64_t*)(mir + lane + 64 * r);
+                    const uint64_t e = lds_vload(mir + lane + 64 * r);
                     cd[r] = (uint32_t)e;
                     ci[r] = (uint32_t)(e >> 32);
                 }
@@ -1780,7 +1792,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                     sn = mb_snap(mb, lane);
                     if (MBW(sn, MB_SREQ) >= next) break;
                     if (MBW(sn, MB_STOP)) { quit = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    if (PIPE_DIST_SLEEP) __builtin_amdgcn_s_sleep(PIPE_DIST_SLEEP);
                 }
                 if (quit) break;
                 PIPE_ACQUIRE();
@@ -1790,7 +1802,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 if (third == 0) srow[b * 64 + lane] = nbr;   // wave 1 takes the row from here
                 bool isnew = false;
                 if (nbr != 0xFFFFFFFFu && (lane % 3) == third) {
-                    const uint32_t word = *(const volatile uint32_t*)(vis + (nbr >> 5));
+                    const uint32_t word = VIS_LDS ? lds_vload(vis + (nbr >> 5)) : *(const volatile uint32_t*)(vis + (nbr >> 5));
                     isnew = !((word >> (nbr & 31)) & 1u);
                 }
                 const unsigned long long bal = __ballot(isnew);
