@@ -472,7 +472,8 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
     }
 
     // exact symmetric distance of one stored code (this lane's) against the query's, as a selection key
-    auto exact_key = [&](uint32_t vid, const uint32_t (&cwv)[MW], bool active) -> uint64_t {
+    // (always_inline: left as a call for the widest shapes — SUBDIM 16 / 32 with 8 code words — its table reads became flat loads)
+    auto exact_key = [&](uint32_t vid, const uint32_t (&cwv)[MW], bool active) __attribute__((always_inline)) -> uint64_t {
         if (!active) return MDB_KEY_MAX;
         float s16[16], s8[8], s4[4];
 #pragma unroll
