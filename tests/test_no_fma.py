@@ -22,9 +22,16 @@ from muopdb_amd import lib as L
 LLVM = "/opt/rocm/lib/llvm/bin"
 FUSED = re.compile(r"\b(v_fma_f|v_fmac_f|v_mad_f|v_mac_f|v_pk_fma|v_pk_mad|v_fmaak|v_fmamk|v_madak|v_madmk|v_dot\d|v_mfma)")
 # kernels whose results carry the reference's lane association (every distance that is RETURNED or RANKED exactly)
-EXACT = re.compile(r"(flat_scan_kernel|flat_refine_kernel|ivf_scan_f32_kernel|ivf_scan_pq2?_kernel|hnsw_(beam|search|closure)_kernel|"
+EXACT = re.compile(r"(flat_scan_kernel|flat_refine_kernel|ivf_scan_f32_kernel|ivf_scan_pq2?_kernel|ivf_pq3_refine_kernel|"
+                   r"hnsw_(beam|search|closure|pipe|select)_kernel|"
                    r"pair_distance_kernel|lane_conforming_kernel|pq_quantize_kernel|pq_distance_kernel|pq_rows_kernel|spann_filter_kernel|"
                    r"kmeans_assign_kernel)")
+# kernels whose hot loops must address LDS as LDS: a `volatile` access through a generic pointer is never rewritten to the LDS
+# address space and compiles to flat_load / flat_store + s_waitcnt vmcnt(0) (round 2: the pipelined HNSW kernel's mailbox polls;
+# a non-inlined lambda did the same to the PQ table reads).  The HNSW kernels keep the flat accesses of their shared fallback
+# (hnsw_general_traverse: the visited set may live in HBM there), so for those the bound is the beam kernel's own count.
+NO_FLAT = re.compile(r"(ivf_scan_pq3_kernel|ivf_pq3_refine_kernel|ivf_scan_pq2_kernel|ivf_scan_f32_kernel|flat_scan_kernel|flat_bf16_filter_kernel|"
+                     r"flat_refine_kernel|sample_bound_kernel)")
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="llvm-objdump not installed")
@@ -66,3 +73,29 @@ def test_exact_kernels_contain_no_fused_multiply_add(tmp_path):
     assert kernels >= 20, "expected the exact-path kernels in the code objects, found %d" % kernels
     assert not offenders, "fused multiply-add inside an exact-association kernel: %r" % offenders[:5]
     assert explained > 0   # the sqrt residuals are there: the scan did look inside the right functions
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="llvm-objdump not installed")
+def test_streaming_kernels_address_lds_as_lds(tmp_path):
+    so = tmp_path / "libmuopdb_hip.so"
+    shutil.copy(L.LIB_PATH, so)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", so.name], cwd=tmp_path, check=True, capture_output=True)
+    flat, seen = {}, set()
+    for f in [f for f in os.listdir(tmp_path) if f.endswith("gfx950")]:
+        asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        cur = None
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+            if m:
+                cur = m.group(1)
+                seen.add(cur)
+                continue
+            if cur and line.split("//")[0].strip().startswith("flat_"):
+                flat[cur] = flat.get(cur, 0) + 1
+    checked = [k for k in seen if NO_FLAT.search(k)]
+    assert len(checked) >= 20, "expected the streaming kernels in the code objects, found %d" % len(checked)
+    bad = {k[:90]: v for k, v in flat.items() if NO_FLAT.search(k)}
+    assert not bad, "flat (generic address space) memory instructions inside a streaming kernel: %r" % sorted(bad.items())[:5]
+    beam = max((v for k, v in flat.items() if "hnsw_beam_kernel" in k), default=0)
+    pipe = max((v for k, v in flat.items() if "hnsw_pipe_kernel" in k), default=0)
+    assert pipe <= beam, "hnsw_pipe_kernel has %d flat instructions, the shared fallback accounts for %d" % (pipe, beam)
