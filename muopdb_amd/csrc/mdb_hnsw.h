@@ -15,6 +15,7 @@ struct HnswUserDev {
     uint32_t small_layer;  // every layer >= small_layer (> 0) holds <= 64 points and only edges among them; else num_layers
     uint64_t adj0_off;     // u32 index into the adjacency arena
     uint64_t adjU_off;
+    uint64_t adjD_off;     // DENSE upper layers: row of (layer, point) at adjD_off + ((layer-1) * n + point) * SU — ~0 when not built
     uint64_t upper_off;    // index into upper_first[] / level[] (per point)
     uint64_t vec_off;      // float index into the vector arena (row stride dpad)
     uint64_t doc_ids_off;  // byte offset of doc id 0 inside the uploaded index bytes

@@ -240,6 +240,17 @@ __device__ __forceinline__ void cand_drop_dead(const uint64_t* C, int& cbase, in
 #define SLOT_EMPTY 0xFFFFFFFFu
 
 #define MDB_DPP_U32(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rmask), 0xF, false))
+// Adjacency row of `node` on an UPPER layer.  Compact form (the file's own economy): level[node] and upper_first[node], then the
+// row — two dependent round trips.  Dense form (built at load when (layers-1) * n * SU * 4 bytes is affordable): the row's address
+// is a function of (layer, node) alone, ONE round trip like layer 0; a point that is not on the layer has an all-empty row, which
+// is what the compact form's null row means to every caller.  60 % of a query's expansions happen on upper layers (the reference
+// runs them with the full ef), and the runner-up's row fetch no longer outlasts the distance phase it hides in.
+__device__ __forceinline__ const uint32_t* hnsw_upper_row(const HnswArgs& a, const HnswUserDev& u, int layer, uint32_t node) {
+    if (u.adjD_off != ~0ull) return a.adj + u.adjD_off + ((size_t)(layer - 1) * u.n + node) * u.SU;
+    if (a.level[u.upper_off + node] >= layer) return a.adj + u.adjU_off + ((size_t)a.upper_first[u.upper_off + node] + (layer - 1)) * u.SU;
+    return nullptr;
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     v = min(v, MDB_DPP_U32(v, 0xB1, 0xF));   // quad_perm [1,0,3,2]
     v = min(v, MDB_DPP_U32(v, 0x4E, 0xF));   // quad_perm [2,3,0,1]
@@ -338,8 +349,7 @@ __device__ void hnsw_general_traverse(const HnswArgs& a, const int qi, char* lds
                         if (cur < u.n0) row = a.adj + u.adj0_off + (size_t)cur * u.S0;
                     } else {
                         stride = u.SU;
-                        if (a.level[u.upper_off + cur] >= layer)
-                            row = a.adj + u.adjU_off + ((size_t)a.upper_first[u.upper_off + cur] + (layer - 1)) * u.SU;
+                        row = hnsw_upper_row(a, u, layer, cur);
                     }
                     nnew = 0;
                     bool any = false;
@@ -528,8 +538,8 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
                 const uint32_t* row = nullptr;
                 if (layer == 0) {
                     if (f < u.n0) row = a.adj + u.adj0_off + (size_t)f * u.S0;
-                } else if (a.level[u.upper_off + f] >= layer) {
-                    row = a.adj + u.adjU_off + ((size_t)a.upper_first[u.upper_off + f] + (layer - 1)) * u.SU;
+                } else {
+                    row = hnsw_upper_row(a, u, layer, f);
                 }
                 uint32_t e[4];
 #pragma unroll
@@ -742,8 +752,8 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
             const uint32_t* row = nullptr;
             if (layer == 0) {
                 if (node < u.n0) row = adj_base + (size_t)node * stride;
-            } else if (a.level[u.upper_off + node] >= layer) {
-                row = adj_base + ((size_t)a.upper_first[u.upper_off + node] + (layer - 1)) * stride;
+            } else {
+                row = hnsw_upper_row(a, u, layer, node);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -769,8 +779,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                 for (int i = grp; i < ncur; i += HNSW_BLOCK / 16) {
                     const uint32_t f = cur[i];
                     const uint32_t* row = nullptr;
-                    if (a.level[u.upper_off + f] >= layer)
-                        row = adj_base + ((size_t)a.upper_first[u.upper_off + f] + (layer - 1)) * stride;
+                    row = hnsw_upper_row(a, u, layer, f);
                     const float d = MDB_BEAM_DIST(vecs + (size_t)f * a.dpad);
                     if (j == 0) {
                         atomicMin(best, (unsigned long long)make_key(d, f));
@@ -1252,8 +1261,8 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
             const uint32_t* row = nullptr;
             if (layer == 0) {
                 if (node < u.n0) row = adj_base + (size_t)node * stride;
-            } else if (a.level[u.upper_off + node] >= layer) {
-                row = adj_base + ((size_t)a.upper_first[u.upper_off + node] + (layer - 1)) * stride;
+            } else {
+                row = hnsw_upper_row(a, u, layer, node);
             }
             return (row && (uint32_t)lane < stride) ? row[lane] : 0xFFFFFFFFu;
         };
@@ -1274,8 +1283,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
                 for (int i = grp; i < ncur; i += PIPE_BLOCK / 16) {
                     const uint32_t f = cur[i];
                     const uint32_t* row = nullptr;
-                    if (a.level[u.upper_off + f] >= layer)
-                        row = adj_base + ((size_t)a.upper_first[u.upper_off + f] + (layer - 1)) * stride;
+                    row = hnsw_upper_row(a, u, layer, f);
                     const float d = PIPE_DIST(vecs + (size_t)f * a.dpad);
                     if (j == 0) {
                         atomicMin(best, (unsigned long long)make_key(d, f));
@@ -2106,6 +2114,20 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
                     const uint32_t e = ed(x);
                     if (e >= nv) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW upper-layer edge %u is outside the vector storage", e);
                     h_adj[u.adjU_off + r * SU + (x - a0)] = e;
+                }
+            }
+        }
+        // dense upper layers (hnsw_upper_row): every (layer, point) gets a row slot — affordable up to 1 GiB per graph
+        u.adjD_off = ~0ull;
+        if (nl > 1 && !getenv("MDB_HNSW_NO_DENSE") && (uint64_t)(nl - 1) * nv * SU * 4 <= ((uint64_t)1 << 30)) {
+            u.adjD_off = h_adj.size();
+            h_adj.resize(h_adj.size() + (size_t)(nl - 1) * nv * SU, 0xFFFFFFFFu);
+            for (uint64_t p = 0; p < nv; ++p) {
+                const uint32_t lv = h_level[u.upper_off + p];
+                for (uint32_t layer = 1; layer <= lv && layer < nl; ++layer) {
+                    const size_t r = (size_t)h_upper_first[u.upper_off + p] + (layer - 1);
+                    std::copy(h_adj.begin() + u.adjU_off + r * SU, h_adj.begin() + u.adjU_off + (r + 1) * SU,
+                              h_adj.begin() + u.adjD_off + ((size_t)(layer - 1) * nv + p) * SU);
                 }
             }
         }
