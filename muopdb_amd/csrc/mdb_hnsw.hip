@@ -87,6 +87,32 @@ __device__ __forceinline__ float group_reduce(float acc) {
     return s;
 }
 
+// group_reduce<16> with the broadcast folded into the add (v_add_f32_dpp): 17 issue slots instead of 33 on the distance groups'
+// chain; the same sixteen additions in the same order (0 + lane 0, + lane 1, ...; a + b == b + a bit for bit).
+__device__ __forceinline__ float group_reduce16_dpp(float acc) {
+    float s = 0.0f;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(s)
+        : "v"(acc));
+    return s;
+}
+
 // exact cascade distance of one stored row against the query (LDS), computed by a 16-lane group
 template <int METRIC>
 __device__ __forceinline__ float group16_distance(const float* __restrict__ x, const float* __restrict__ qs, const DistPlan& p,
@@ -152,7 +178,7 @@ __device__ __forceinline__ float group16_distance_fast(const float* __restrict__
     float acc = 0.0f;
 #pragma unroll
     for (int c = 0; c < N16; ++c) acc = acc_term<METRIC>(acc, qr[c], xv[c]);
-    return finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce<16>(acc)));
+    return finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce16_dpp(acc)));
 }
 
 // two rows at once: all loads of both rows are in flight before the first accumulate (hnsw_beam_kernel, steps
@@ -178,8 +204,8 @@ __device__ __forceinline__ void group16_distance_fast2(const float* __restrict__
     for (int c = 0; c < N16; ++c) acc = acc_term<METRIC>(acc, qr[c], va[c]);
 #pragma unroll
     for (int c = 0; c < N16; ++c) bcc = acc_term<METRIC>(bcc, qr[c], vb[c]);
-    da = finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce<16>(acc)));
-    db = finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce<16>(bcc)));
+    da = finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce16_dpp(acc)));
+    db = finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce16_dpp(bcc)));
 }
 
 // ---- wave-0 helpers on the two sorted LDS arrays (all ballot based: no cross-lane reductions)
@@ -240,6 +266,15 @@ __device__ __forceinline__ void cand_drop_dead(const uint64_t* C, int& cbase, in
 #define SLOT_EMPTY 0xFFFFFFFFu
 
 #define MDB_DPP_U32(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rmask), 0xF, false))
+// Volatile accesses through a GENERIC pointer are never rewritten to the LDS address space (InferAddressSpaces leaves volatile
+// memory operations alone): they compile to flat_load / flat_store with system scope and an s_waitcnt vmcnt(0) each — a poll of
+// the mailbox then costs a flat round trip AND waits for every outstanding global load of the wave.  These accessors name the
+// address space, so the accesses are plain ds_read / ds_write.
+typedef __attribute__((address_space(3))) uint32_t mdb_lds_u32;
+typedef __attribute__((address_space(3))) uint64_t mdb_lds_u64;
+__device__ __forceinline__ uint32_t lds_vload(const uint32_t* p) { return *(const volatile mdb_lds_u32*)p; }
+__device__ __forceinline__ uint64_t lds_vload(const uint64_t* p) { return *(const volatile mdb_lds_u64*)p; }
+__device__ __forceinline__ void lds_vstore(uint32_t* p, uint32_t v) { *(volatile mdb_lds_u32*)p = v; }
 // Adjacency row of `node` on an UPPER layer.  Compact form (the file's own economy): level[node] and upper_first[node], then the
 // row — two dependent round trips.  Dense form (built at load when (layers-1) * n * SU * 4 bytes is affordable): the row's address
 // is a function of (layer, node) alone, ONE round trip like layer 0; a point that is not on the layer has an all-empty row, which
@@ -251,22 +286,24 @@ __device__ __forceinline__ const uint32_t* hnsw_upper_row(const HnswArgs& a, con
     return nullptr;
 }
 
+// Wave-wide min / max in six DPP steps, the DPP operand folded into the min / max itself (v_min_u32_dpp): 12 issue slots
+// instead of the 24 of "copy, nop, dpp-move, min" — these reductions sit on wave 0's serial chain, where a slot is ~10 cycles.
+// (s_nop 1 = the two wait states a DPP read of a just-written VGPR needs; nobody adds them inside asm.)
+#define MDB_WAVE_REDUCE_ASM(op)                                                        \
+    asm volatile("s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
+                 "s_nop 1"                                                             \
+                 : "+v"(v))
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    v = min(v, MDB_DPP_U32(v, 0xB1, 0xF));   // quad_perm [1,0,3,2]
-    v = min(v, MDB_DPP_U32(v, 0x4E, 0xF));   // quad_perm [2,3,0,1]
-    v = min(v, MDB_DPP_U32(v, 0x141, 0xF));  // row_half_mirror
-    v = min(v, MDB_DPP_U32(v, 0x140, 0xF));  // row_mirror
-    v = min(v, MDB_DPP_U32(v, 0x142, 0xA));  // row_bcast:15
-    v = min(v, MDB_DPP_U32(v, 0x143, 0xC));  // row_bcast:31
+    MDB_WAVE_REDUCE_ASM("v_min_u32_dpp");
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    v = max(v, MDB_DPP_U32(v, 0xB1, 0xF));
-    v = max(v, MDB_DPP_U32(v, 0x4E, 0xF));
-    v = max(v, MDB_DPP_U32(v, 0x141, 0xF));
-    v = max(v, MDB_DPP_U32(v, 0x140, 0xF));
-    v = max(v, MDB_DPP_U32(v, 0x142, 0xA));
-    v = max(v, MDB_DPP_U32(v, 0x143, 0xC));
+    MDB_WAVE_REDUCE_ASM("v_max_u32_dpp");
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
@@ -690,8 +727,54 @@ __device__ __forceinline__ bool beam_best(const uint32_t (&cdv)[BREGS], const ui
     return true;
 }
 
-template <int METRIC, bool VIS_LDS, int N16T>
-__global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
+// beam_best without the slot: ids are unique in B, so the kernel below marks the popped slot by id and needs no slot index.
+// One min reduction; the winner's id is the per-lane maximum over the lane's matching slots (in-lane ties resolved for free),
+// read from the single matching lane — only distance ties ACROSS lanes pay a second reduction.
+__device__ __forceinline__ bool beam_best_id(const uint32_t (&cdv)[BREGS], const uint32_t (&bi)[BREGS], uint32_t& o_out, uint32_t& id_out) {
+    uint32_t lm = cdv[0];
+#pragma unroll
+    for (int r = 1; r < BREGS; ++r) lm = min(lm, cdv[r]);
+    const uint32_t m = wave_min_u32(lm);
+    o_out = m;
+    if (m == SLOT_EMPTY) return false;
+    uint32_t li = 0;
+#pragma unroll
+    for (int r = 0; r < BREGS; ++r) li = max(li, cdv[r] == m ? bi[r] : 0u);
+    const unsigned long long hm = __ballot(lm == m);
+    uint32_t id;
+    if (__builtin_expect((hm & (hm - 1)) == 0, 1)) {
+        id = (uint32_t)__builtin_amdgcn_readlane((int)li, __ffsll((long long)hm) - 1);
+    } else {
+        id = wave_max_u32(lm == m ? li : 0u);
+    }
+    id_out = id;
+    return true;
+}
+
+#ifdef MDB_PIPE_DBG   // cycle / event accounting of the roles into counters[4..15] (MDB_HNSW_DBG=1 prints them)
+#define PIPE_TB(t) const unsigned long long t = __builtin_readcyclecounter()
+#define PIPE_TE(slot, t) dbg_acc[slot] += __builtin_readcyclecounter() - (t)
+#define PIPE_CNT(slot, v) dbg_acc[slot] += (v)
+#else
+#define PIPE_TB(t) do {} while (0)
+#define PIPE_TE(slot, t) do {} while (0)
+#define PIPE_CNT(slot, v) do {} while (0)
+#endif
+
+// PF (f32 rows that are whole 16-lane chunks): one more wave that takes no decision and computes nothing — it warms the cache.
+// The next node is the beam's runner-up 92 % of the time and wave 0 knows the runner-up ~0.15 us into a step, two phases before
+// it needs that node's neighbours; the gather of those neighbours' vectors from HBM is the longest single wait of a step (P3).
+// So wave 0 publishes the runner-up's id, and the prefetch wave fetches its row, drops the neighbours already visited (a plain
+// read of the set: stale answers only cost or save a touch) and touches every 128-byte line of the others' vectors while wave 0
+// is still accepting / choosing / testing: when P3 of the next step asks for them they are in L2 or on their way.  A touch is
+// a load whose value is only "used" a step later, so nothing ever waits for it.  Results and counters cannot change: the
+// wave writes nothing but its own scratch list.
+#define BEAM_PF_ROUNDS 8   // touches per lane and step (64 x 8 lines = 128 vectors of d 128, 21 of d 768)
+template <int METRIC, bool VIS_LDS, int N16T, bool PF>
+__global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
+    // the prefetch wave is wave 5: SIMD 1, which it shares with a distance wave that mostly waits for memory; wave 4 (it would share
+    // SIMD 0 with wave 0, whose issue slots ARE the step time) only attends the barriers
+    constexpr int BLK = PF ? HNSW_BLOCK + 128 : HNSW_BLOCK;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // FIXED LDS layout (compile-time offsets: the kernel is SGPR-bound, eight live LDS pointers are eight
     // scalars it does not have): W 256 keys | C 1024 keys | nb_id 256 | nb_dist 256 | misc 16 | qs dpad | vis
@@ -699,7 +782,9 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     uint64_t* const C = (uint64_t*)(lds + BEAM_LDS_C);  // [0..512): staging / sort buffer, [512..768) as u32 flags
     uint32_t* const nb_id = (uint32_t*)(lds + BEAM_LDS_NBID);
     uint32_t* const nb_od = (uint32_t*)(lds + BEAM_LDS_NBDIST);  // order-preserving images of the neighbours' distances
-    uint32_t* const misc = (uint32_t*)(lds + BEAM_LDS_MISC);  // [0] nnew (0xFFFFFFFF = stop), [2] wsize, [3] overflow
+    uint32_t* const misc = (uint32_t*)(lds + BEAM_LDS_MISC);  // [0] nnew (0xFFFFFFFF = stop), [2] wsize, [3] overflow,
+                                                              // PF: [10] runner-up id (0xFFFFFFFF = none), [11] step tag of [10]
+    uint32_t* const pf_list = (uint32_t*)(C + 768);           // PF: the prefetch wave's compacted neighbour list (512 ids; C[768..) is free)
     float* const qs = (float*)(lds + BEAM_LDS_QS);
     uint32_t* vis = VIS_LDS ? (uint32_t*)(lds + BEAM_LDS_QS + (size_t)a.dpad * 4) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
     uint32_t* const stage_flag = (uint32_t*)(C + 512);
@@ -710,13 +795,13 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     const int grp = tid >> 4, j = tid & 15;
     const HnswUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
     if (!u.valid || u.n == 0 || u.num_layers == 0 || u.entry_point >= u.n) {
-        for (int i = tid; i < a.k; i += HNSW_BLOCK) a.out_keys[(size_t)qi * a.k + i] = MDB_KEY_MAX;
+        for (int i = tid; i < a.k; i += BLK) a.out_keys[(size_t)qi * a.k + i] = MDB_KEY_MAX;
         if (tid == 0) a.out_counts[qi] = 0;
         return;
     }
-    for (int i = tid; i < a.dpad; i += HNSW_BLOCK) qs[i] = a.q[(size_t)qi * a.qstride + i];
+    for (int i = tid; i < a.dpad; i += BLK) qs[i] = a.q[(size_t)qi * a.qstride + i];
     if (VIS_LDS)
-        for (unsigned long long i = tid; i < a.vis_words; i += HNSW_BLOCK) vis[i] = 0;
+        for (unsigned long long i = tid; i < a.vis_words; i += BLK) vis[i] = 0;
     __syncthreads();
 
     const float* vecs = a.vecs + u.vec_off;
@@ -737,12 +822,19 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     uint32_t fbound = SLOT_EMPTY;   // an upper bound of furthest.distance (prefilter only)
     uint32_t rowv[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // row of the node being expanded
     uint32_t rowr[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // row of the runner-up (speculative)
-    int ru_slot = 0;
     uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
     bool ru_valid = false, stop = false;
+    int ru_closer = 0;                 // #{b in B : d_b < d_runner-up}, counted in the shadow of P3 (the stop test of P4)
     uint32_t evals = 0, expanded = 0;  // per query: far below 2^32
     bool nan_seen = false, overflow = false;
     uint32_t ep = u.entry_point;
+    uint32_t sg = 0;                   // PF: step tag (every wave counts alike)
+#ifdef MDB_PIPE_DBG
+    unsigned long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    float pf_hold[BEAM_PF_ROUNDS];     // PF: the touched words, "used" one step later
+#pragma unroll
+    for (int r = 0; r < BEAM_PF_ROUNDS; ++r) pf_hold[r] = 0.0f;
 
     for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
         const uint32_t stride = layer == 0 ? u.S0 : u.SU;
@@ -776,7 +868,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
             int ncur = 1;
             __syncthreads();
             while (ncur > 0) {
-                for (int i = grp; i < ncur; i += HNSW_BLOCK / 16) {
+                for (int i = grp; i < ncur; i += BLK / 16) {
                     const uint32_t f = cur[i];
                     const uint32_t* row = nullptr;
                     row = hnsw_upper_row(a, u, layer, f);
@@ -823,9 +915,12 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
             stop = false;
             ru_valid = false;
             evals += 1;
+            if (PF && lane == 0) misc[11] = 0;
         }
+        sg = 0;
         for (;;) {
             // ---- P2 (wave 0): visited test-and-set + ordered compaction of the popped node's row
+            PIPE_TB(t_p2);
             if (wave == 0) {
                 uint32_t nnew = 0xFFFFFFFFu;
                 if (!stop && !overflow) {
@@ -852,15 +947,41 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                 }
                 if (lane == 0) misc[0] = nnew;
             }
+            if (wave == 0) PIPE_TE(0, t_p2);
+            PIPE_TB(t_b1);
             __syncthreads();
+            if (wave == 0) PIPE_TE(1, t_b1);
+            PIPE_TB(t_sh);
             const uint32_t nnew = misc[0];
             if (nnew == 0xFFFFFFFFu) break;
+            ++sg;
+            if (wave == 0) PIPE_CNT(5, 1);
+            uint32_t pf_row[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             if (wave == 0) {
                 // ---- in the shadow of P3: the best candidate already in B (the next pop unless a neighbour
                 // accepted below beats it) and, speculatively, its adjacency row
-                ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_slot);
-                if (ru_valid) load_row(ru_id, rowr);
-            } else {
+                ru_valid = beam_best_id(cdv, bi, ru_o, ru_id);
+                if (PF) {
+                    if (lane == 0) misc[10] = ru_valid ? ru_id : 0xFFFFFFFFu;
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) lds_vstore(misc + 11, sg);
+                }
+                if (ru_valid) {
+                    load_row(ru_id, rowr);
+                    // the stop test of the runner-up (92 % of the pops), minus the neighbours this step will add: wave 0 would only
+                    // wait for the distance waves here
+                    ru_closer = 0;
+#pragma unroll
+                    for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
+                }
+            } else if (PF && wave == 5) {
+                // ---- prefetch wave: the runner-up's row, requested as soon as wave 0 names it (it arrives around the barrier)
+                while (lds_vload(misc + 11) != sg) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[10]);
+                PIPE_TE(6, t_sh);
+                if (rid != 0xFFFFFFFFu) load_row(rid, pf_row);
+            } else if (!PF || wave <= 3) {
                 // ---- P3 (waves 1-3): exact distances, one 16-lane group per neighbour
                 // (the groups also take the order-preserving integer image and the NaN check off wave 0's path)
                 constexpr int NG = (HNSW_BLOCK - 64) / 16;
@@ -890,11 +1011,50 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                     }
                 }
             }
+            if (wave == 0) PIPE_TE(2, t_sh);
+            if (wave == 1) PIPE_TE(9, t_sh);
+            PIPE_TB(t_b2);
             __syncthreads();
+            if (wave == 0) PIPE_TE(3, t_b2);
+            PIPE_TB(t_p4);
+            if (PF && wave == 5) {
+#ifdef MDB_PIPE_DBG
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                PIPE_TE(7, t_p4);
+                // ---- prefetch wave, while wave 0 runs P4 and the next P2: touch the unvisited neighbours' vectors
+                constexpr int LPV = N16T > 0 ? N16T / 2 : 1;   // 128-byte lines per vector
+#pragma unroll
+                for (int r = 0; r < BEAM_PF_ROUNDS; ++r) asm volatile("" ::"v"(pf_hold[r]));   // last step's touches end here
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if ((uint32_t)(64 * c) < stride) {
+                        const uint32_t nbr = pf_row[c];
+                        bool want = nbr != 0xFFFFFFFFu;
+                        if (VIS_LDS && want) want = !((vis[nbr >> 5] >> (nbr & 31)) & 1u);
+                        const unsigned long long bal = __ballot(want);
+                        if (want) pf_list[cnt + __popcll(bal & lt_mask)] = nbr;
+                        cnt += __popcll(bal);
+                    }
+                }
+                const uint32_t touches = cnt * LPV;
+                if (touches) {
+                    // branch-free: a lane without a touch of its own repeats touch 0 (same address as lane 0's: one request)
+#pragma unroll
+                    for (int r = 0; r < BEAM_PF_ROUNDS; ++r) {
+                        uint32_t t = lane + 64 * r;
+                        t = t < touches ? t : 0u;
+                        pf_hold[r] = vecs[(size_t)pf_list[t / LPV] * a.dpad + (t % LPV) * 32];
+                    }
+                }
+                PIPE_TE(8, t_p4);
+                PIPE_CNT(10, touches);
+            }
             // ---- P4 (wave 0): accept + push, then choose the next node
             if (wave == 0) {
-                uint32_t best_o = SLOT_EMPTY, best_id = 0;  // best accepted neighbour in pop order ...
-                int best_slot = -1;                          // ... and the slot it was pushed to
+                uint32_t best_o = SLOT_EMPTY, best_id = 0;  // best accepted neighbour in pop order
+                bool best_have = false;
                 for (uint32_t c0 = 0; c0 < nnew; c0 += 64) {
                     const uint32_t i = c0 + lane;
                     const bool have = i < nnew;
@@ -955,17 +1115,19 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                             n = kept;
                             fbound = min(fbound, f);
                             if (n + na > BEAM_CAP) { overflow = true; break; }  // > ~120 exact ties with furthest
-                            if (best_slot >= 0) {  // slots moved: re-find the best accepted so far (rare)
-                                best_slot = -1;
+                            if (best_have) {  // the best accepted so far may have been dropped (rare)
+                                bool still = false;
 #pragma unroll
-                                for (int r = 0; r < BREGS; ++r) {
-                                    unsigned long long hm = __ballot(cdv[r] == best_o && bi[r] == best_id);
-                                    if (hm) best_slot = 64 * r + __ffsll((long long)hm) - 1;
-                                }
+                                for (int r = 0; r < BREGS; ++r) still = still || __ballot(cdv[r] == best_o && bi[r] == best_id) != 0;
+                                best_have = still;
                             }
-                            ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_slot);  // slots moved
+                            ru_valid = beam_best_id(cdv, bi, ru_o, ru_id);  // may have been dropped too
                             if (ru_valid) load_row(ru_id, rowr);
+                            ru_closer = 0;   // recount over the compacted B (it holds the earlier chunks' pushes)
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
                         }
+                        ru_closer += __popcll(accepted & __ballot(od < ru_o));   // this chunk's pushes
                         // ---- push all accepted neighbours: slots n .. n+na-1, in edge order
                         // (forward lane permute: the accepted lane of rank r sends its pair to lane (n + r) & 63, everybody
                         // else to an unused lane; no LDS staging round trip on wave 0's path)
@@ -987,17 +1149,15 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                         }
                         // best accepted neighbour of this chunk in pop order (smallest distance, largest id)
                         unsigned long long am = accepted;
-                        int rank = 0;
                         if (na > 2) {
                             // many accepted (fill phase): two wave reductions instead of a scalar loop over them
                             const bool mine = (accepted >> lane) & 1ull;
                             const uint32_t mo = wave_min_u32(mine ? od : SLOT_EMPTY);
                             const uint32_t mi = wave_max_u32(mine && od == mo ? id : 0u);
-                            if (best_slot < 0 || mo < best_o || (mo == best_o && mi > best_id)) {
-                                const unsigned long long wm = __ballot(mine && od == mo && id == mi);
+                            if (!best_have || mo < best_o || (mo == best_o && mi > best_id)) {
                                 best_o = mo;
                                 best_id = mi;
-                                best_slot = n + __popcll(accepted & ((1ull << (__ffsll((long long)wm) - 1)) - 1ull));
+                                best_have = true;
                             }
                             am = 0;
                         }
@@ -1006,40 +1166,42 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                             am &= am - 1;
                             const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
                             const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
-                            if (best_slot < 0 || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_slot = n + rank; }
-                            ++rank;
+                            if (!best_have || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_have = true; }
                         }
                         n += na;
                     }
                 }
                 // ---- candidates.pop(): runner-up vs best accepted; stop when it is farther than furthest
                 if (!overflow) {
-                    const bool take_ru = ru_valid && (best_slot < 0 || ru_o < best_o || (ru_o == best_o && ru_id > best_id));
-                    if (!take_ru && best_slot < 0) {
+                    const bool take_ru = ru_valid && (!best_have || ru_o < best_o || (ru_o == best_o && ru_id > best_id));
+                    if (!take_ru && !best_have) {
                         stop = true;  // no candidate left
                     } else {
-                        const uint32_t m = take_ru ? ru_o : best_o;
-                        int closer = 0;
-                        if (n >= ef) {  // fewer than ef elements in B: the popped candidate cannot be beyond furthest
+                        int closer = ru_closer;   // the runner-up's count is ready (shadow of P3 + this step's pushes)
+                        if (!take_ru) {
+                            closer = 0;
+                            if (n >= ef) {  // fewer than ef elements in B: the popped candidate cannot be beyond furthest
 #pragma unroll
-                            for (int r = 0; r < BREGS; ++r) closer += __popcll(__ballot(bd[r] < m));
+                                for (int r = 0; r < BREGS; ++r) closer += __popcll(__ballot(bd[r] < best_o));
+                            }
                         }
                         if (closer >= ef) {
                             stop = true;  // `distance > furthest.distance` (index.rs:246-248)
                         } else if (take_ru) {
 #pragma unroll
                             for (int r = 0; r < BREGS; ++r)
-                                if (lane + 64 * r == ru_slot) cdv[r] = SLOT_EMPTY;
+                                if (bi[r] == ru_id) cdv[r] = SLOT_EMPTY;   // ids are unique in B (unused slots: already EMPTY)
 #pragma unroll
                             for (int c = 0; c < 4; ++c) rowv[c] = rowr[c];
                         } else {
 #pragma unroll
                             for (int r = 0; r < BREGS; ++r)
-                                if (lane + 64 * r == best_slot) cdv[r] = SLOT_EMPTY;
+                                if (bi[r] == best_id) cdv[r] = SLOT_EMPTY;
                             load_row(best_id, rowv);
                         }
                     }
                 }
+                PIPE_TE(4, t_p4);
             }
         }
         if (layer > 0) {
@@ -1073,7 +1235,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
         const int n2 = 512;
         for (int size = 2; size <= n2; size <<= 1) {
             for (int st = size >> 1; st > 0; st >>= 1) {
-                for (int t = tid; t < (n2 >> 1); t += HNSW_BLOCK) {
+                for (int t = tid; t < (n2 >> 1); t += BLK) {
                     int lo = ((t / st) * st * 2) + (t % st);
                     int hi = lo + st;
                     bool up = ((lo & size) == 0);
@@ -1083,7 +1245,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                 __syncthreads();
             }
         }
-        for (int i = tid; i < a.ef_cap; i += HNSW_BLOCK) W[i] = C[i];
+        for (int i = tid; i < a.ef_cap; i += BLK) W[i] = C[i];
         __syncthreads();
     }
     // the output fields are re-read from the kernarg segment behind an opaque barrier: kept in `a` they would stay
@@ -1094,7 +1256,12 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     const int kk = ap->k;
     const int outc = ws < kk ? ws : kk;
     uint64_t* const okeys = ap->out_keys;
-    for (int i = tid; i < kk; i += HNSW_BLOCK) okeys[(size_t)qi * kk + i] = i < outc ? W[i] : MDB_KEY_MAX;
+    for (int i = tid; i < kk; i += BLK) okeys[(size_t)qi * kk + i] = i < outc ? W[i] : MDB_KEY_MAX;
+#ifdef MDB_PIPE_DBG
+    if (lane == 0 && (wave == 0 || wave == 1 || wave == 5))
+        for (int i = 0; i < 12; ++i)
+            if (dbg_acc[i]) atomicAdd(&ap->counters[4 + i], dbg_acc[i]);
+#endif
     if (tid == 0) {
         ap->out_counts[qi] = (uint32_t)outc;
         misc[3] = overflow ? 1u : 0u;
@@ -1105,6 +1272,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
         }
     }
     __syncthreads();
+    if (PF && wave >= 4) return;   // the fall-back below is written for HNSW_BLOCK threads
     // > ~120 exact distance ties with furthest overflow the 320-slot beam: this block re-runs its query with
     // the general algorithm (sorted LDS sets, room for ~800 ties); rows and counters come from that run
     if (misc[3]) {
@@ -1168,15 +1336,6 @@ enum {
 // ONE LDS read returns the whole mailbox (lane i = word i; every word lives in the first 32 lanes' pass, so the snapshot is
 // a single point in time); fields are then picked out of the register with v_readlane — a poll costs one LDS round trip
 // however many words it looks at.
-// Volatile accesses through a GENERIC pointer are never rewritten to the LDS address space (InferAddressSpaces leaves volatile
-// memory operations alone): they compile to flat_load / flat_store with system scope and an s_waitcnt vmcnt(0) each — a poll of
-// the mailbox then costs a flat round trip AND waits for every outstanding global load of the wave.  These accessors name the
-// address space, so the accesses are plain ds_read / ds_write.
-typedef __attribute__((address_space(3))) uint32_t mdb_lds_u32;
-typedef __attribute__((address_space(3))) uint64_t mdb_lds_u64;
-__device__ __forceinline__ uint32_t lds_vload(const uint32_t* p) { return *(const volatile mdb_lds_u32*)p; }
-__device__ __forceinline__ uint64_t lds_vload(const uint64_t* p) { return *(const volatile mdb_lds_u64*)p; }
-__device__ __forceinline__ void lds_vstore(uint32_t* p, uint32_t v) { *(volatile mdb_lds_u32*)p = v; }
 __device__ __forceinline__ uint32_t mb_snap(const uint32_t* mb, int lane) { return lds_vload(mb + (lane & 31)); }
 #define MBW(snap, i) ((uint32_t)__builtin_amdgcn_readlane((int)(snap), (i)))
 // requests alternate between the two speculation buffers (rid & 1), so request rid is the ((rid + (rid & 1)) / 2)-th of its buffer
@@ -1188,15 +1347,6 @@ __device__ __forceinline__ void mb_store(uint32_t* mb, int i, uint32_t v) { lds_
 // the prefetched adjacency rows.
 #define PIPE_RELEASE() asm volatile("" ::: "memory")
 #define PIPE_ACQUIRE() asm volatile("" ::: "memory")
-#ifdef MDB_PIPE_DBG   // cycle / event accounting of the roles into counters[4..15] (MDB_HNSW_DBG=1 prints them)
-#define PIPE_TB(t) const unsigned long long t = __builtin_readcyclecounter()
-#define PIPE_TE(slot, t) dbg_acc[slot] += __builtin_readcyclecounter() - (t)
-#define PIPE_CNT(slot, v) dbg_acc[slot] += (v)
-#else
-#define PIPE_TB(t) do {} while (0)
-#define PIPE_TE(slot, t) do {} while (0)
-#define PIPE_CNT(slot, v) do {} while (0)
-#endif
 
 template <int METRIC, bool VIS_LDS, int N16T>
 __global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
@@ -2236,12 +2386,12 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     } while (0)
     // specialised distance when the whole vector is 16-lane chunks (d = 128 / 768: the configs' dims)
     const int nf = (kind != MDB_QUANT_PQ && a.p.n8 == 0 && a.p.n4 == 0 && a.p.ntail == 0 && !getenv("MDB_HNSW_GENERIC_DIST")) ? a.p.n16 : 0;
-#define MDB_BEAM_LAUNCH(METRIC, VL, NF)                                                                                     \
+#define MDB_BEAM_LAUNCH(METRIC, VL, NF, PF)                                                                                   \
     do {                                                                                                                    \
         if (lds > 48 * 1024)                                                                                                \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF>,                                 \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF, PF>,                             \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hnsw_beam_kernel<METRIC, VL, NF><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                           \
+        hnsw_beam_kernel<METRIC, VL, NF, PF><<<dim3((unsigned)b), (PF) ? HNSW_BLOCK + 128 : HNSW_BLOCK, lds, ctx->stream>>>(a); \
     } while (0)
 #define MDB_PIPE_LAUNCH(METRIC, VL, NF)                                                                                     \
     do {                                                                                                                    \
@@ -2255,10 +2405,13 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         if (beam && pipe) {                                                                                        \
             if (nf == 8) MDB_PIPE_LAUNCH(METRIC, VL, 8);                                                           \
             else MDB_PIPE_LAUNCH(METRIC, VL, 48);                                                                  \
+        } else if (beam && prefetch) {                                                                             \
+            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, true);                                                     \
+            else MDB_BEAM_LAUNCH(METRIC, VL, 48, true);                                                            \
         } else if (beam) {                                                                                         \
-            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8);                                                           \
-            else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48);                                                    \
-            else MDB_BEAM_LAUNCH(METRIC, VL, 0);                                                                   \
+            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, false);                                                    \
+            else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48, false);                                             \
+            else MDB_BEAM_LAUNCH(METRIC, VL, 0, false);                                                            \
         } else if (nf == 8) MDB_HNSW_LAUNCH4(METRIC, VL, 8);                                                       \
         else if (nf == 48) MDB_HNSW_LAUNCH4(METRIC, VL, 48);                                                       \
         else MDB_HNSW_LAUNCH4(METRIC, VL, 0);                                                                      \
@@ -2301,6 +2454,8 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     // software-pipelined traversal (hnsw_pipe_kernel): whole-vector 16-lane chunks, rows of at most 64 edges.  Same rows and
     // counters as hnsw_beam_kernel (tests run both); OPT-IN (MDB_HNSW_PIPE=1) while it is the slower of the two on the C2 workload.
     const bool pipe = beam && (nf == 8 || nf == 48) && max_stride <= 64 && getenv("MDB_HNSW_PIPE");
+    // hnsw_beam_kernel with its prefetch wave (see the kernel): f32 rows of whole 16-lane chunks
+    const bool prefetch = beam && (nf == 8 || nf == 48) && getenv("MDB_HNSW_PREFETCH");   // OPT-IN: measured slower
     if (metric == MDB_METRIC_L2) {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false);
     } else {

@@ -119,15 +119,16 @@ def test_c2_hnsw_1m_ef200(ctx, oracle, base, flat_1m, hnsw_1m):
     assert rows_of(ores, 24) == whole[:24]
     assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)             # same traversal, step for step
     import os
-    os.environ["MDB_HNSW_PIPE"] = "1"                                                    # the software-pipelined kernel (opt-in)
-    try:
-        pres = g.ann_search(q[:64], K, 200)
-        assert rows_of(pres, 64) == whole
-        g.ann_search(q[:24], K, 200)
-        st = ctx.stats()
-        assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)
-    finally:
-        del os.environ["MDB_HNSW_PIPE"]
+    for variant in ("MDB_HNSW_PIPE", "MDB_HNSW_PREFETCH"):                            # the pipelined kernel (opt-in); the beam kernel without its prefetch wave
+        os.environ[variant] = "1"
+        try:
+            pres = g.ann_search(q[:64], K, 200)
+            assert rows_of(pres, 64) == whole
+            g.ann_search(q[:24], K, 200)
+            st = ctx.stats()
+            assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)
+        finally:
+            del os.environ[variant]
     exact_ids, _, _ = flat_1m.search(q[:64], K)                                          # recall@10 against the exact scan
     hit = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(64))
     assert hit / (64 * K) >= 0.99

@@ -163,11 +163,13 @@ def test_hnsw_general_kernel_equals_beam_kernel(ctx, oracle):
     assert_result_rows(g.ann_search(q, 10, 600), o.ann_search(q, 10, 600), len(q))
 
 
+@pytest.mark.parametrize("variant", ["MDB_HNSW_PIPE", "MDB_HNSW_PREFETCH"])
 @pytest.mark.parametrize("d,metric", [(128, 0), (768, 1), (128, 1)])
-def test_hnsw_pipelined_kernel_equals_oracle(ctx, oracle, d, metric):
-    """hnsw_pipe_kernel (MDB_HNSW_PIPE=1: the traversal software-pipelined over six waves, tentative visited updates undone on
-    a wrong guess) must give the oracle's rows AND counters — no speculative evaluation may be counted, no tentative
-    visited bit may survive."""
+def test_hnsw_pipelined_kernel_equals_oracle(ctx, oracle, d, metric, variant):
+    """hnsw_pipe_kernel (MDB_HNSW_PIPE=1: the traversal software-pipelined over six waves) and hnsw_beam_kernel's SPEC variant
+    (MDB_HNSW_SPEC=1: wave 1 runs the runner-up's visited test-and-set during wave 0's accept phase) both update the visited set
+    tentatively and undo a wrong guess: they must give the oracle's rows AND counters — no speculative evaluation may be
+    counted, no tentative visited bit may survive."""
     import os
     from muopdb_amd.index import BlockBasedHnsw, NoQuantizer
     rng = np.random.default_rng(31)
@@ -179,7 +181,7 @@ def test_hnsw_pipelined_kernel_equals_oracle(ctx, oracle, d, metric):
     g = BlockBasedHnsw(ctx, hidx, hvec, d, NoQuantizer(d, metric))
     o = oracle.BlockBasedHnsw(hidx, hvec, d, oracle.Quant(oracle.QUANT_NONE, metric))
     q = (v[rng.integers(0, n, 40)] + rng.normal(0, 0.05 if metric == 1 else 4, (40, d))).astype(np.float32)
-    os.environ["MDB_HNSW_PIPE"] = "1"
+    os.environ[variant] = "1"
     try:
         for k, ef in [(10, 100), (5, 8), (20, 256), (10, 1), (10, 40)]:
             want = o.ann_search(q, k, ef)
@@ -189,7 +191,7 @@ def test_hnsw_pipelined_kernel_equals_oracle(ctx, oracle, d, metric):
             assert_result_rows(got, want, len(q))
             assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded), (k, ef)
     finally:
-        del os.environ["MDB_HNSW_PIPE"]
+        del os.environ[variant]
 
 
 def test_hnsw_beam_overflow_falls_back_to_general_kernel(ctx, oracle):
