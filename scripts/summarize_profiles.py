@@ -65,7 +65,11 @@ for w, (kern, key, match) in WL.items():
     summary[w] = dict(rocprof_avg_ms=avg_ms, bench_kernel_ms=r.get("kernel_ms"), bench_ms_per_step=lines.get(w, {}).get("ms_per_step"),
                       algorithmic_bytes=r.get("bytes_per_launch"),
                       measured_traffic_bytes=(vals.get("FETCH_SIZE", 0) * 2 + vals.get("WRITE_SIZE", 0)) * 1024 if vals else None)
-json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % rnd), "w"), indent=1)
-json.dump(summary, open(os.path.join(dst, "%s_summary.json" % rnd), "w"), indent=1)
+# a partial re-profile (profile_round.sh <tag> hnsw spann) keeps the other workloads' entries of the round
+for name, new in (("traffic", traffic), ("summary", summary)):
+    path = os.path.join(dst, "%s_%s.json" % (rnd, name))
+    merged = json.load(open(path)) if os.path.exists(path) else {}
+    merged.update(new)
+    json.dump(merged, open(path, "w"), indent=1)
 for w, s in summary.items():
     print(w, {k: (round(v, 4) if isinstance(v, float) and v < 1e4 else v) for k, v in s.items()})
