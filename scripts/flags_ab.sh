@@ -1,0 +1,8 @@
+for v in hnswonly all; do
+  cp muopdb_amd/variants/lib_$v.so muopdb_amd/libmuopdb_hip.so
+  for args in "--workload flat --n 1000000 --batch 1" "--workload flat --n 1000000 --batch 64" "--workload ivfpq --no-sweep --streams 0" "--workload spann --users 128 --no-sweep" "--workload c5"; do
+    timeout 400 python bench.py $args --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$v] $args'.ljust(60), round(d['value']), round(d['ms_per_step'],4), round(d['roofline']['kernel_ms'],4), d.get('recall_at_10'))"
+  done
+done
