@@ -770,8 +770,12 @@ __device__ __forceinline__ bool beam_best_id(const uint32_t (&cdv)[BREGS], const
 // a load whose value is only "used" a step later, so nothing ever waits for it.  Results and counters cannot change: the
 // wave writes nothing but its own scratch list.
 #define BEAM_PF_ROUNDS 8   // touches per lane and step (64 x 8 lines = 128 vectors of d 128, 21 of d 768)
-template <int METRIC, bool VIS_LDS, int N16T, bool PF>
+// ROW64: every adjacency row of the index has at most 64 edges (max_neighbors <= 32: the configurations' graphs) — a row is ONE
+// register per lane, a step has ONE chunk: the per-chunk loops, their scalar branches and three of four register copies leave
+// wave 0's chain.
+template <int METRIC, bool VIS_LDS, int N16T, bool PF, bool ROW64>
 __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
+    constexpr int NCH = ROW64 ? 1 : 4;   // 64-edge chunks of a row
     // the prefetch wave is wave 5: SIMD 1, which it shares with a distance wave that mostly waits for memory; wave 4 (it would share
     // SIMD 0 with wave 0, whose issue slots ARE the step time) only attends the barriers
     constexpr int BLK = PF ? HNSW_BLOCK + 128 : HNSW_BLOCK;
@@ -820,8 +824,9 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
     uint32_t cdv[BREGS];            // = bd for unexpanded slots, SLOT_EMPTY otherwise (the candidates)
     int n = 0;                      // used slots
     uint32_t fbound = SLOT_EMPTY;   // an upper bound of furthest.distance (prefilter only)
-    uint32_t rowv[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // row of the node being expanded
-    uint32_t rowr[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // row of the runner-up (speculative)
+    uint32_t rowv[NCH], rowr[NCH];   // row of the node being expanded / of the runner-up (speculative)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) rowv[c] = rowr[c] = 0xFFFFFFFFu;
     uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
     bool ru_valid = false, stop = false;
     int ru_closer = 0;                 // #{b in B : d_b < d_runner-up}, counted in the shadow of P3 (the stop test of P4)
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
         const uint32_t stride = layer == 0 ? u.S0 : u.SU;
         const uint32_t* const adj_base = a.adj + (layer == 0 ? u.adj0_off : u.adjU_off);
         // adjacency row of `node` at this layer -> dst (lane + 64 c); the loads stay in flight
-        auto load_row = [&](uint32_t node, uint32_t (&dst)[4]) {
+        auto load_row = [&](uint32_t node, uint32_t (&dst)[NCH]) {
             const uint32_t* row = nullptr;
             if (layer == 0) {
                 if (node < u.n0) row = adj_base + (size_t)node * stride;
@@ -848,7 +853,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                 row = hnsw_upper_row(a, u, layer, node);
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NCH; ++c) {
                 uint32_t t = lane + 64 * c;
                 dst[c] = (row && t < stride) ? row[t] : 0xFFFFFFFFu;
             }
@@ -927,8 +932,8 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                     nnew = 0;
                     bool any = false;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if ((uint32_t)(64 * c) < stride) {
+                    for (int c = 0; c < NCH; ++c) {
+                        if (ROW64 || (uint32_t)(64 * c) < stride) {
                             const uint32_t nbr = rowv[c];
                             bool isnew = false;
                             if (nbr != 0xFFFFFFFFu) {  // edges are < n: validated when the graph is loaded
@@ -956,7 +961,9 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
             if (nnew == 0xFFFFFFFFu) break;
             ++sg;
             if (wave == 0) PIPE_CNT(5, 1);
-            uint32_t pf_row[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            uint32_t pf_row[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) pf_row[c] = 0xFFFFFFFFu;
             if (wave == 0) {
                 // ---- in the shadow of P3: the best candidate already in B (the next pop unless a neighbour
                 // accepted below beats it) and, speculatively, its adjacency row
@@ -1028,8 +1035,8 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                 for (int r = 0; r < BEAM_PF_ROUNDS; ++r) asm volatile("" ::"v"(pf_hold[r]));   // last step's touches end here
                 uint32_t cnt = 0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if ((uint32_t)(64 * c) < stride) {
+                for (int c = 0; c < NCH; ++c) {
+                    if (ROW64 || (uint32_t)(64 * c) < stride) {
                         const uint32_t nbr = pf_row[c];
                         bool want = nbr != 0xFFFFFFFFu;
                         if (VIS_LDS && want) want = !((vis[nbr >> 5] >> (nbr & 31)) & 1u);
@@ -1170,6 +1177,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                         }
                         n += na;
                     }
+                    if (ROW64) break;   // at most 64 new neighbours: one chunk
                 }
                 // ---- candidates.pop(): runner-up vs best accepted; stop when it is farther than furthest
                 if (!overflow) {
@@ -1192,7 +1200,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                             for (int r = 0; r < BREGS; ++r)
                                 if (bi[r] == ru_id) cdv[r] = SLOT_EMPTY;   // ids are unique in B (unused slots: already EMPTY)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) rowv[c] = rowr[c];
+                            for (int c = 0; c < NCH; ++c) rowv[c] = rowr[c];
                         } else {
 #pragma unroll
                             for (int r = 0; r < BREGS; ++r)
@@ -2386,12 +2394,12 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     } while (0)
     // specialised distance when the whole vector is 16-lane chunks (d = 128 / 768: the configs' dims)
     const int nf = (kind != MDB_QUANT_PQ && a.p.n8 == 0 && a.p.n4 == 0 && a.p.ntail == 0 && !getenv("MDB_HNSW_GENERIC_DIST")) ? a.p.n16 : 0;
-#define MDB_BEAM_LAUNCH(METRIC, VL, NF, PF)                                                                                   \
+#define MDB_BEAM_LAUNCH(METRIC, VL, NF, PF, R64)                                                                                   \
     do {                                                                                                                    \
         if (lds > 48 * 1024)                                                                                                \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF, PF>,                             \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF, PF, R64>,                             \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hnsw_beam_kernel<METRIC, VL, NF, PF><<<dim3((unsigned)b), (PF) ? HNSW_BLOCK + 128 : HNSW_BLOCK, lds, ctx->stream>>>(a); \
+        hnsw_beam_kernel<METRIC, VL, NF, PF, R64><<<dim3((unsigned)b), (PF) ? HNSW_BLOCK + 128 : HNSW_BLOCK, lds, ctx->stream>>>(a); \
     } while (0)
 #define MDB_PIPE_LAUNCH(METRIC, VL, NF)                                                                                     \
     do {                                                                                                                    \
@@ -2406,12 +2414,16 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
             if (nf == 8) MDB_PIPE_LAUNCH(METRIC, VL, 8);                                                           \
             else MDB_PIPE_LAUNCH(METRIC, VL, 48);                                                                  \
         } else if (beam && prefetch) {                                                                             \
-            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, true);                                                     \
-            else MDB_BEAM_LAUNCH(METRIC, VL, 48, true);                                                            \
+            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, true, true);                                               \
+            else MDB_BEAM_LAUNCH(METRIC, VL, 48, true, true);                                                      \
+        } else if (beam && row64) {                                                                                \
+            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, false, true);                                              \
+            else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48, false, true);                                       \
+            else MDB_BEAM_LAUNCH(METRIC, VL, 0, false, true);                                                      \
         } else if (beam) {                                                                                         \
-            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, false);                                                    \
-            else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48, false);                                             \
-            else MDB_BEAM_LAUNCH(METRIC, VL, 0, false);                                                            \
+            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, false, false);                                             \
+            else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48, false, false);                                      \
+            else MDB_BEAM_LAUNCH(METRIC, VL, 0, false, false);                                                     \
         } else if (nf == 8) MDB_HNSW_LAUNCH4(METRIC, VL, 8);                                                       \
         else if (nf == 48) MDB_HNSW_LAUNCH4(METRIC, VL, 48);                                                       \
         else MDB_HNSW_LAUNCH4(METRIC, VL, 0);                                                                      \
@@ -2455,7 +2467,8 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     // counters as hnsw_beam_kernel (tests run both); OPT-IN (MDB_HNSW_PIPE=1) while it is the slower of the two on the C2 workload.
     const bool pipe = beam && (nf == 8 || nf == 48) && max_stride <= 64 && getenv("MDB_HNSW_PIPE");
     // hnsw_beam_kernel with its prefetch wave (see the kernel): f32 rows of whole 16-lane chunks
-    const bool prefetch = beam && (nf == 8 || nf == 48) && getenv("MDB_HNSW_PREFETCH");   // OPT-IN: measured slower
+    const bool row64 = max_stride <= 64 && !getenv("MDB_HNSW_NO_ROW64");   // hnsw_beam_kernel's one-chunk specialisation
+    const bool prefetch = beam && row64 && (nf == 8 || nf == 48) && getenv("MDB_HNSW_PREFETCH");   // OPT-IN: measured slower
     if (metric == MDB_METRIC_L2) {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false);
     } else {

@@ -129,7 +129,7 @@ def case_ivf(ctx, rng):
 def case_hnsw(ctx, rng):
     n = int(rng.choice([1, 2, 40, 600, 2500]))
     d = int(rng.choice([3, 4, 16, 30, 48, 128]))
-    M = int(rng.choice([4, 8, 16, 32]))
+    M = int(rng.choice([4, 8, 16, 32, 40]))   # 40: rows longer than 64 edges (the multi-chunk beam kernel)
     layers = int(rng.integers(1, 6))
     metric = int(rng.integers(0, 2))
     kind = int(rng.integers(0, 3))

@@ -119,7 +119,7 @@ def test_c2_hnsw_1m_ef200(ctx, oracle, base, flat_1m, hnsw_1m):
     assert rows_of(ores, 24) == whole[:24]
     assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)             # same traversal, step for step
     import os
-    for variant in ("MDB_HNSW_PIPE", "MDB_HNSW_PREFETCH"):                            # the pipelined kernel (opt-in); the beam kernel without its prefetch wave
+    for variant in ("MDB_HNSW_PIPE", "MDB_HNSW_PREFETCH", "MDB_HNSW_NO_ROW64"):        # the pipelined kernel, the prefetch wave (opt-in); the beam kernel for rows of any length
         os.environ[variant] = "1"
         try:
             pres = g.ann_search(q[:64], K, 200)

@@ -44,7 +44,8 @@ def test_hnsw_k13_hand_graph(ctx, oracle):
 
 @pytest.mark.parametrize("n,d,M,layers,efc,metric,seed", [
     (1500, 8, 12, 4, 60, 0, 1), (2000, 128, 16, 3, 80, 0, 2), (1000, 4, 10, 2, 100, 0, 3), (800, 30, 8, 5, 40, 1, 4),
-    (3000, 16, 6, 6, 30, 0, 5), (500, 17, 24, 1, 50, 0, 6), (300, 768, 8, 2, 40, 0, 7)])
+    (3000, 16, 6, 6, 30, 0, 5), (500, 17, 24, 1, 50, 0, 6), (300, 768, 8, 2, 40, 0, 7),
+    (900, 16, 40, 3, 60, 0, 8)])   # the last: layer-0 rows of 80 edges — two 64-edge chunks per row (not the ROW64 kernel)
 def test_hnsw_ann_search(ctx, oracle, n, d, M, layers, efc, metric, seed):
     from muopdb_amd.index import BlockBasedHnsw, NoQuantizer
     rng = np.random.default_rng(seed)
@@ -163,7 +164,7 @@ def test_hnsw_general_kernel_equals_beam_kernel(ctx, oracle):
     assert_result_rows(g.ann_search(q, 10, 600), o.ann_search(q, 10, 600), len(q))
 
 
-@pytest.mark.parametrize("variant", ["MDB_HNSW_PIPE", "MDB_HNSW_PREFETCH"])
+@pytest.mark.parametrize("variant", ["MDB_HNSW_PIPE", "MDB_HNSW_PREFETCH", "MDB_HNSW_NO_ROW64"])
 @pytest.mark.parametrize("d,metric", [(128, 0), (768, 1), (128, 1)])
 def test_hnsw_pipelined_kernel_equals_oracle(ctx, oracle, d, metric, variant):
     """hnsw_pipe_kernel (MDB_HNSW_PIPE=1: the traversal software-pipelined over six waves) and hnsw_beam_kernel's SPEC variant
