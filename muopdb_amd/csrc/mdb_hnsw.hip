@@ -667,17 +667,18 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 //    then on it is a dead candidate (the `distance > furthest` break, :246-248) unless it ties with
 //    the furthest distance.  So wave 0 keeps ONE unsorted array B (320 slots in VGPRs, slot idx =
 //    lane + 64 r) holding the true working set W (= the ef smallest keys of B) plus whatever has been
-//    pushed out of W since the last compaction, and 5 uniform bitmasks of the unexpanded slots.
+//    pushed out of W since the last compaction, and per slot its distance image once more while the slot is an
+//    unexpanded candidate (`cdv`, SLOT_EMPTY otherwise).
 //  * furthest.distance is never materialised.  With f = the ef-th smallest distance in B:
 //        d < f   <=>  #{b in B : d_b <= d} < ef        (accept test, together with the earlier
 //                                                       neighbours of the same node — see the lemma
 //                                                       in hnsw_search_kernel)
 //        d > f   <=>  #{b in B : d_b <  d} >= ef       (the stop test of a popped candidate)
 //    — elements of B outside W all have distance >= f, so they never disturb either count.
-//  * push = append to free slots (all accepted neighbours of a node at once, through a small LDS
-//    staging area); pop = masked DPP min-reduction over the unexpanded slots (largest id among equal
-//    distances, like BinaryHeap<(-d,id)>); when B is full, a 32-step ballot radix-select finds f and
-//    everything farther than f is dropped (ties stay: they are still legal candidates).
+//  * push = append to free slots (all accepted neighbours of a node at once, by a forward lane permute);
+//    pop = DPP min-reduction over `cdv` (largest id among equal distances, like BinaryHeap<(-d,id)>), the
+//    popped slot marked by its id — ids are unique in B; when B is full, a 32-step ballot radix-select finds f
+//    and everything farther than f is dropped (ties stay: they are still legal candidates).
 // A lone wave pays ~10-15 cycles per dependent instruction (VALU<->SALU round trips), so the design
 // goal is instruction count on wave 0's path, not bandwidth.
 // ==========================================================================================
@@ -693,6 +694,7 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 // holds the distance image of unexpanded slots and SLOT_EMPTY elsewhere.  Returns false if none.
 // slot_out = winner's slot (lane + 64 r) — one SGPR instead of BREGS one-hot masks: the kernel is
 // SGPR-bound and every spilled scalar costs a v_readlane on wave 0's critical path.
+// (hnsw_pipe_kernel's form — its candidate mirror is addressed by slot; hnsw_beam_kernel uses beam_best_id.)
 __device__ __forceinline__ bool beam_best(const uint32_t (&cdv)[BREGS], const uint32_t (&bi)[BREGS], int lane, uint32_t& o_out,
                                           uint32_t& id_out, int& slot_out) {
     uint32_t lm = cdv[0];
