@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """bench.py — measures BASELINE.json's metric on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(a plain `python bench.py --gpus N` with N > 1 starts its N ranks itself through torch.distributed.run — one process per GPU over
+RCCL — and fails loudly when fewer than N devices are visible; `n_gpus` in the line is always the number of ranks that ran)
 
 Headline (`value`, `ms_per_step`, `roofline`, `cpu_baseline` at the top level of the ONE JSON line) =
 BASELINE.json configs[1]: SIFT-1M-like 1M x 128 f32 (synthetic), HNSW ef=200, top-10, batch=64,
@@ -106,10 +108,49 @@ def parse():
     p.add_argument("--streams", type=int, default=4, help="hnsw: extra measurement with this many batches in flight (0/1 = skip)")
     p.add_argument("--dump-dir", default=None, help="write index files + queries for examples/replay_search.cpp")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
+    p.add_argument("--sift-dir", default=None, help="directory holding sift_base.fvecs / sift_query.fvecs / sift_groundtruth.ivecs: "
+                                                    "the C2/C3 workloads then run on the real SIFT-1M (data: sift1m) instead of synthetic rows")
+    p.add_argument("--graph", default="knn", choices=["knn", "insert"],
+                   help="hnsw: how the base graph is built — knn: exact k-NN + the reference's selection heuristic (fast bulk build); "
+                        "insert: HnswBuilder::insert's algorithm, wave-batched on the GPU (muopdb_amd.build.insert_hnsw)")
+    p.add_argument("--no-insert-graph", action="store_true", help="all: skip the second HNSW line on an insert-built graph")
+    p.add_argument("--insert-n", type=int, default=None, help="all: base size of the insert-built HNSW workload (default: --n)")
     p.add_argument("--sift-clusters", type=int, default=None, help="SiftLike mixture components (generator exploration)")
     p.add_argument("--sift-sigma", type=float, default=None)
     p.add_argument("--sift-noise", type=float, default=None)
     return p.parse_args()
+
+
+def cpu_stamp(threads_all):
+    """CPU model, core count and the thread counts used, recorded with every cpu_baseline"""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(cpu_model=model, host_cores=os.cpu_count(), threads_single=1, threads_all=int(threads_all),
+                omp_places=os.environ.get("OMP_PLACES"), omp_proc_bind=os.environ.get("OMP_PROC_BIND"))
+
+
+def cpu_baseline(single_fn, multi_fn, nq, seconds, probe, match_fn, sample_fmt):
+    """Times the oracle on a bounded sample of the timed queries: `single_fn(n)` runs the first n on ONE thread and returns its
+    result, `multi_fn(n, threads)` the same on all cores; match_fn(result, n) compares the one-thread rows with the GPU's."""
+    import oracle
+    t0 = time.perf_counter(); single_fn(probe); dt = time.perf_counter() - t0
+    ns = int(min(nq, max(probe, seconds / (dt / probe))))
+    t0 = time.perf_counter(); r = single_fn(ns); dt1 = time.perf_counter() - t0
+    nt = oracle.num_threads()
+    na = int(min(nq, max(ns, 8 * nt)))
+    multi_fn(min(na, nt), nt)   # warm the thread pool
+    t0 = time.perf_counter(); multi_fn(na, nt); dta = time.perf_counter() - t0
+    out = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port", sample=sample_fmt % ns, all_cores_value=na / dta, all_cores=nt,
+               all_cores_sample="%d queries, one query per thread" % na, ids_match_gpu=bool(match_fn(r, ns)))
+    out.update(cpu_stamp(nt))
+    return out
 
 
 class Env:
@@ -117,6 +158,8 @@ class Env:
         self.args, self.ctx, self.rank, self.world = args, ctx, rank, world
         self.cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
         self._sift = None
+        self._real = None
+        self.hnsw_cache = {}
 
     def barrier(self):
         if self.world > 1:
@@ -151,6 +194,19 @@ class Env:
     def sift(self, n, d, nq, qseed):
         """(base rows, queries, description) of the C2/C3 synthetic SIFT-1M; the base is cached across workloads."""
         from muopdb_amd import build as B, synth as S
+        if self.args.sift_dir:   # the real dataset, when the box has it
+            if self._real is None:
+                from muopdb_amd import datasets as DS
+                r = DS.load_sift(self.args.sift_dir)
+                if r is None:
+                    raise SystemExit("--sift-dir %s: sift_base.fvecs / sift_query.fvecs not found" % self.args.sift_dir)
+                self._real = (torch.from_numpy(r[0]).cuda(), torch.from_numpy(r[1]).cuda())
+            xb, xq = self._real
+            if xb.shape[1] != d:
+                raise SystemExit("--sift-dir holds %d-d rows, the workload wants %d" % (xb.shape[1], d))
+            g = torch.Generator(device="cpu"); g.manual_seed(qseed)
+            pick = torch.randint(0, xq.shape[0], (nq,), generator=g).cuda()   # the 10 k queries, drawn with replacement to fill the batches
+            return xb[:n].contiguous(), xq[pick].contiguous(), "SIFT-1M (sift_base.fvecs[:%d], sift_query.fvecs)" % min(n, xb.shape[0])
         if self.args.data == "legacy":
             ncl = max(1, min(4096, n // 244))
             if self._sift is None or self._sift[0] != (n, d):
@@ -187,26 +243,39 @@ def hbm_roofline(kernel, abytes_per_launch, kernel_ms, launches, **extra):
 
 
 # ------------------------------------------------------------------------------------------ HNSW (headline)
-def run_hnsw(env):
+def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=None):
+    """BASELINE config C2.  batch 64 = the headline; batch 1 = the metric's other batch size (same resident graph);
+    graph "insert" = the same workload on a graph built by HnswBuilder::insert's algorithm (what MuopDB itself would write)."""
     from muopdb_amd import build as B, synth as S
     from muopdb_amd.index import BlockBasedHnsw
     args, ctx, rank, world = env.args, env.ctx, env.rank, env.world
-    n = args.n or 1_000_000
+    n = n or args.n or 1_000_000
     d = args.dim or 128
-    batch = args.batch or 64
+    batch = batch or args.batch or 64
+    graph = graph or args.graph
     k, ef = args.k, args.ef
-    steps, warm = args.steps, args.warmup
+    steps, warm = steps or args.steps, warm if warm is not None else args.warmup
     t0 = time.time()
     nq = (steps + warm) * batch
     x, queries, desc = env.sift(n, d, nq, 1000 + rank)
+    n = x.shape[0]
     log("data %.1fs" % (time.time() - t0))
-    t0 = time.time()
-    index_bytes, vec_bytes = S.hnsw_files(x, max_neighbors=args.max_neighbors, max_layers=8, kcand=2 * args.max_neighbors, seed=1)
-    log("graph build %.1fs (%d MiB index)" % (time.time() - t0, len(index_bytes) >> 20))
-    t0 = time.time()
-    hnsw = BlockBasedHnsw(ctx, index_bytes, vec_bytes, d)
-    log("load %.1fs" % (time.time() - t0))
-    dump(args, rank, "hnsw", index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy()})
+    key = (n, d, graph, args.max_neighbors)
+    if key not in env.hnsw_cache:
+        t0 = time.time()
+        if graph == "insert":
+            index_bytes, vec_bytes = B.hnsw_files_by_insertion(ctx, x, max_neighbors=args.max_neighbors, max_layers=8, ef_construction=100, seed=1)
+        else:
+            index_bytes, vec_bytes = S.hnsw_files(x, max_neighbors=args.max_neighbors, max_layers=8, kcand=2 * args.max_neighbors, seed=1)
+        build_s = time.time() - t0
+        log("graph build (%s) %.1fs (%d MiB index)" % (graph, build_s, len(index_bytes) >> 20))
+        t0 = time.time()
+        env.hnsw_cache.clear()   # one resident graph at a time
+        env.hnsw_cache[key] = (BlockBasedHnsw(ctx, index_bytes, vec_bytes, d), index_bytes, vec_bytes, build_s)
+        log("load %.1fs" % (time.time() - t0))
+    hnsw, index_bytes, vec_bytes, build_s = env.hnsw_cache[key]
+    if batch == 64 and graph == "knn":
+        dump(args, rank, "hnsw", index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy()})
     ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
     sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
     cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
@@ -228,17 +297,21 @@ def run_hnsw(env):
     tq = queries[warm * batch:(warm + steps) * batch]
     gt, _ = S.exact_knn(x, k, queries=tq, f64=True)
     rec = recall_at_k(found, gt.cpu().numpy(), k)
+    how = ("exact k-NN + select_neighbors_heuristic (bulk build)" if graph == "knn"
+           else "HnswBuilder::insert's algorithm, wave-batched (muopdb_amd.build.insert_hnsw, ef_construction=100)")
     out = dict(
         value=world * steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec,
-        config={"workload": "SIFT-1M-like synthetic %dx%d f32 (%s); HNSW max_neighbors=%d ef=%d top-%d batch=%d per GPU; replicas"
-                            % (n, d, desc, args.max_neighbors, ef, k, batch),
-                "n": n, "dim": d, "batch": batch, "ef": ef, "k": k, "index": "hnsw", "data": args.data,
-                "parallelism": "replica x%d" % world},
+        config={"workload": "%s %dx%d f32 (%s); HNSW max_neighbors=%d ef=%d top-%d batch=%d per GPU; graph: %s; replicas"
+                            % ("SIFT-1M" if args.sift_dir else "SIFT-1M-like synthetic", n, d, desc, args.max_neighbors, ef, k, batch, how),
+                "n": n, "dim": d, "batch": batch, "ef": ef, "k": k, "index": "hnsw", "graph": graph,
+                "data": "sift1m" if args.sift_dir else args.data, "parallelism": "replica x%d" % world, "graph_build_s": build_s},
         roofline=hbm_roofline("hnsw_beam_kernel" if ef <= 256 else "hnsw_search_kernel", abytes / steps, kernel_ms, launches,
                               evals_per_query=evals / (steps * batch), expanded_per_query=expanded / (steps * batch)),
     )
-    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("hnsw", out["config"])
-    if args.streams > 1:
+    out["steps"], out["warmup"] = steps, warm
+    if batch == 64 and graph == "knn":
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("hnsw", out["config"])
+    if extras and args.streams > 1:
         # Extra, NOT the headline: the same K batches issued round-robin on several HIP streams (one context +
         # attached index handle each, all over the same resident graph), i.e. several batches of 64 in flight.  One batch occupies 64 of the 256 CUs for
         # its whole latency-bound traversal, so a serving process overlaps batches to fill the chip.
@@ -276,18 +349,11 @@ def run_hnsw(env):
         import oracle
         o = oracle.BlockBasedHnsw(index_bytes, vec_bytes, d)
         qh = tq.cpu().numpy()
-        t0 = time.perf_counter(); o.ann_search(qh[:64], k, ef, threads=1); dt = time.perf_counter() - t0
-        ns = int(min(len(qh), max(64, args.cpu_seconds / (dt / 64))))
-        t0 = time.perf_counter(); r = o.ann_search(qh[:ns], k, ef, threads=1); dt1 = time.perf_counter() - t0
-        ok = all(r.doc_ids(i) == [int(v) for v in found[i][:int(r.counts[i])]] for i in range(min(ns, 256)))
-        nt = oracle.num_threads()
-        na = min(len(qh), max(ns, 8 * nt))
-        t0 = time.perf_counter(); o.ann_search(qh[:na], k, ef, threads=nt); dta = time.perf_counter() - t0
-        out["cpu_baseline"] = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port",
-                                   sample="%d of the timed queries, one thread (the reference runs one query per task, "
-                                          "no intra-query parallelism); index fully memory-resident" % ns,
-                                   all_cores_value=na / dta, all_cores=nt, ids_match_gpu=bool(ok))
-    hnsw.close()
+        out["cpu_baseline"] = cpu_baseline(
+            lambda m: o.ann_search(qh[:m], k, ef, threads=1), lambda m, t: o.ann_search(qh[:m], k, ef, threads=t), len(qh),
+            args.cpu_seconds if extras else min(args.cpu_seconds, 4.0), min(64, len(qh)),
+            lambda r, m: all(r.doc_ids(i) == [int(v) for v in found[i][:int(r.counts[i])]] for i in range(min(m, 256))),
+            "%d of the timed queries, one thread (the reference runs one query per task, no intra-query parallelism); index fully memory-resident")
     return out
 
 
@@ -353,11 +419,17 @@ def run_flat(env, n=None, batch=None):
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("flat_b64" if batched else "flat", out["config"])
     if env.cpu:
         import oracle
-        xb, qh = x.cpu().numpy(), queries[warm * batch:].cpu().numpy()
-        t0 = time.perf_counter(); oracle.flat_topk(0, xb, qh[:4], k); dt = time.perf_counter() - t0
-        ns = int(min(len(qh), max(4, args.cpu_seconds / (dt / 4))))
-        t0 = time.perf_counter(); oracle.flat_topk(0, xb, qh[:ns], k); dt1 = time.perf_counter() - t0
-        out["cpu_baseline"] = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port", sample="%d queries, one thread" % ns)
+        xb, qh = x[lo:hi].cpu().numpy(), queries[warm * batch:].cpu().numpy()
+        got = []                                    # the GPU's rows for the first timed queries (untimed re-run)
+        for i in range(warm, warm + min(steps, max(1, 32 // batch))):
+            step(i)
+            got.append(ids.cpu().numpy().astype(np.int64))
+        got = np.concatenate(got)
+        out["cpu_baseline"] = cpu_baseline(
+            lambda m: oracle.flat_topk(0, xb, qh[:m], k, threads=1), lambda m, t: oracle.flat_topk(0, xb, qh[:m], k, threads=t), len(qh),
+            args.cpu_seconds, min(4, len(qh)),
+            lambda r, m: bool(np.array_equal(np.asarray(r[0])[:min(m, len(got))].astype(np.int64), got[:min(m, len(got))])),
+            "%d queries, one thread")
     idx.close()
     return out
 
@@ -373,26 +445,27 @@ def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=
     from muopdb_amd import lib as L
     from muopdb_amd import distributed as D
     ctx, world = env.ctx, env.world
-    gather = D.PackedTopkGather(ctx, batch, k, "cuda") if world > 1 else None
-    if gather:  # the search writes straight into this rank's block of the all-gather
-        ids, sc, cn = gather.ids, gather.scores, gather.counts
-    else:
-        ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
-        sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
-        cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    # world > 1: the EXACT sharded step — the search writes this rank's (distance, point id) rows straight into its points block
+    gather = D.PointsGather(ctx, batch, k, "cuda") if world > 1 else None
+    ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
+    sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
+    cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
 
     def step(i, keep=None):
         q = queries[i * batch:(i + 1) * batch]
-        probes = None
-        if world > 1:  # the coarse quantizer is sharded too: 1/world of the centroids per rank + one all-gather of (distance, id) rows
+        if world > 1:
+            # the coarse quantizer is sharded too: 1/world of the centroids per rank + one all-gather of (distance, id) rows
             probes = D.sharded_probes(ctx, ivf, q.data_ptr(), batch, P, q.device)
-        ctx.check(ctx.lib.mdb_ivf_search(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch),
-                                         C.c_void_p(probes.data_ptr()) if probes is not None else None, C.c_size_t(P), C.c_size_t(k),
-                                         C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()),
-                                         C.c_void_p(cn.data_ptr())))
-        res = ids
-        if world > 1:  # ONE packed RCCL all-gather of the per-shard top-k + device merge
-            res, _, _ = gather.gather_merge()
+            ctx.check(ctx.lib.mdb_ivf_search_shard(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch), C.c_void_p(probes.data_ptr()),
+                                                   C.c_size_t(P), C.c_size_t(k), C.c_int(L.MEM_DEVICE), None, C.c_size_t(0), C.c_size_t(0),
+                                                   C.c_void_p(gather.send.data_ptr())))
+            # ONE RCCL all-gather of the points blocks + merge by (distance, point id), then remap
+            res, _, _ = gather.gather_merge_ivf(ivf)
+        else:
+            ctx.check(ctx.lib.mdb_ivf_search(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch), None, C.c_size_t(P), C.c_size_t(k),
+                                             C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()),
+                                             C.c_void_p(cn.data_ptr())))
+            res = ids
         if keep is not None:
             keep.append(res[:, :, 0].clone())
 
@@ -497,12 +570,11 @@ def run_ivfpq(env):
         import oracle
         o = oracle.BlockBasedIvf(index_bytes, vec_bytes, oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, cb))
         qh = tq.cpu().numpy()
-        t0 = time.perf_counter(); o.search(qh[:32], k, num_probes=P); dt = time.perf_counter() - t0
-        ns = int(min(len(qh), max(32, args.cpu_seconds / (dt / 32))))
-        t0 = time.perf_counter(); r = o.search(qh[:ns], k, num_probes=P); dt1 = time.perf_counter() - t0
-        ok = all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(ns, 256)))
-        out["cpu_baseline"] = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port", sample="%d queries, one thread" % ns,
-                                   ids_match_gpu=bool(ok))
+        out["cpu_baseline"] = cpu_baseline(
+            lambda m_: o.search(qh[:m_], k, num_probes=P, threads=1), lambda m_, t: o.search(qh[:m_], k, num_probes=P, threads=t), len(qh),
+            args.cpu_seconds, min(32, len(qh)),
+            lambda r, m_: all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(m_, 256))),
+            "%d queries, one thread")
     ivf.close()
     return out
 
@@ -538,12 +610,11 @@ def run_c5(env, steps=None, warm=None):
         import oracle
         o = oracle.BlockBasedIvf(sh["index"], sh["vectors"], oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, sh["codebook"]))
         qh = queries[warm * batch:].cpu().numpy()
-        t0 = time.perf_counter(); o.search(qh[:16], k, num_probes=P); dt = time.perf_counter() - t0
-        ns = int(min(len(qh), max(16, args.cpu_seconds / (dt / 16))))
-        t0 = time.perf_counter(); r = o.search(qh[:ns], k, num_probes=P); dt1 = time.perf_counter() - t0
-        ok = all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(ns, 256)))
-        out["cpu_baseline"] = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port", sample="%d queries, one thread" % ns,
-                                   ids_match_gpu=bool(ok))
+        out["cpu_baseline"] = cpu_baseline(
+            lambda m_: o.search(qh[:m_], k, num_probes=P, threads=1), lambda m_, t: o.search(qh[:m_], k, num_probes=P, threads=t), len(qh),
+            args.cpu_seconds, min(16, len(qh)),
+            lambda r, m_: all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(m_, 256))),
+            "%d queries, one thread")
     ivf.close()
     return out
 
@@ -609,13 +680,10 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
         dump(args, rank, "spann", hnsw_index=cat["hnsw_index"], hnsw_vectors=cat["hnsw_vectors"], ivf_index=cat["ivf_index"],
              vectors=cat["ivf_vectors"], user_table=cat["user_table"],
              **{"queries.f32": queries.cpu().numpy(), "users.u64": (quser + 1).numpy().astype(np.uint64)})
-    gather = D.PackedTopkGather(ctx, batch, k, "cuda") if world > 1 else None
-    if gather:
-        ids, sc, cn = gather.ids, gather.scores, gather.counts
-    else:
-        ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
-        sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
-        cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    gather = D.PointsGather(ctx, batch, k, "cuda") if world > 1 else None   # the EXACT sharded step (points blocks)
+    ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
+    sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
+    cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
     fo = torch.zeros(batch, dtype=torch.uint8, device="cuda")
     uid_arrays = [L.u128_array([int(u) + 1 for u in quser[i * batch:(i + 1) * batch].tolist()]) for i in range(steps + warm)]
     # exact per-user ground truth (f64) of the timed queries
@@ -632,12 +700,16 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
 
         def step(i, keep=None):
             q = queries[i * batch:(i + 1) * batch]
-            ctx.check(ctx.lib.mdb_multi_spann_search(ms.h, uid_arrays[i], C.c_void_p(q.data_ptr()), C.c_size_t(batch), C.byref(params),
-                                                     C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()),
-                                                     C.c_void_p(cn.data_ptr()), C.c_void_p(fo.data_ptr())))
-            res = ids
             if world > 1:
-                res, _, _ = gather.gather_merge()
+                ctx.check(ctx.lib.mdb_multi_spann_search_shard(ms.h, uid_arrays[i], C.c_void_p(q.data_ptr()), C.c_size_t(batch),
+                                                               C.byref(params), C.c_int(L.MEM_DEVICE), None, C.c_size_t(0), C.c_size_t(0),
+                                                               C.c_void_p(gather.send.data_ptr())))
+                res, _, _ = gather.gather_merge_multi(ms, uid_arrays[i])
+            else:
+                ctx.check(ctx.lib.mdb_multi_spann_search(ms.h, uid_arrays[i], C.c_void_p(q.data_ptr()), C.c_size_t(batch), C.byref(params),
+                                                         C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()),
+                                                         C.c_void_p(cn.data_ptr()), C.c_void_p(fo.data_ptr())))
+                res = ids
             if keep is not None:
                 keep.append(res[:, :, 0].clone())
 
@@ -677,27 +749,52 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
         op = oracle.SearchParams(k, args.ef, num_explored_centroids=P, centroid_distance_ratio=ratio)
         qh = queries[warm * batch:(warm + steps) * batch].cpu().numpy()
         uh = [int(u) + 1 for u in quser[warm * batch:(warm + steps) * batch].tolist()]
-        t0 = time.perf_counter(); o.search_for_user(uh[:16], qh[:16], op); dt = time.perf_counter() - t0
-        ns = int(min(len(qh), max(16, args.cpu_seconds / (dt / 16))))
-        t0 = time.perf_counter(); r = o.search_for_user(uh[:ns], qh[:ns], op); dt1 = time.perf_counter() - t0
-        ok = all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(ns, 256)))
-        out["cpu_baseline"] = dict(value=ns / dt1, unit="queries/s", cores=1, kind="port", sample="%d (user,query) pairs, one thread" % ns,
-                                   ids_match_gpu=bool(ok))
+        out["cpu_baseline"] = cpu_baseline(
+            lambda m_: o.search_for_user(uh[:m_], qh[:m_], op, threads=1), lambda m_, t: o.search_for_user(uh[:m_], qh[:m_], op, threads=t),
+            len(qh), args.cpu_seconds, min(16, len(qh)),
+            lambda r, m_: all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(m_, 256))),
+            "%d (user,query) pairs, one thread")
     ms.close()
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks through torch.distributed.run — one process per
+    GPU, RCCL over xGMI — exactly the command the driver uses.  Fewer than N visible devices is an ERROR (never a silent
+    1-rank run), unless the one-GPU validation hook below is set."""
+    import socket
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not os.environ.get("MDB_BENCH_DEVICE"):
+        sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible; refusing to measure fewer ranks than asked "
+                         "(one-GPU plumbing check: MDB_BENCH_BACKEND=gloo MDB_BENCH_DEVICE=0)\n" % (args.gpus, ndev))
+        sys.exit(2)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)   # does not return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher and the flag disagree\n" % (args.gpus, world))
+        sys.exit(2)
     # Validation hooks for boxes with ONE GPU (the multi-rank logic of every workload — sharding, gathers, merges, max over ranks —
     # without RCCL, which needs one device per rank): MDB_BENCH_DEVICE pins every rank to that device, MDB_BENCH_BACKEND=gloo
     # moves the collectives to gloo.  Never set by the driver; numbers from such a run are not bench results.
     if os.environ.get("MDB_BENCH_DEVICE"):
         local = int(os.environ["MDB_BENCH_DEVICE"])
+    if local >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d wants device %d, %d visible\n" % (rank, local, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("MDB_BENCH_BACKEND", "nccl")
@@ -713,14 +810,18 @@ def main():
     if args.workload != "all":
         res = single[args.workload](env)
     else:
-        res = run_hnsw(env)
+        res = run_hnsw(env, batch=64, graph="knn")
         extra = {}
-        plan = [("flat_1m_b1", lambda: run_flat(env, n=1_000_000, batch=1)), ("flat_1m_b64", lambda: run_flat(env, n=1_000_000, batch=64)),
+        # the metric's other batch size over the same resident graph (one sequential chain on one CU: latency, not throughput)
+        plan = [("hnsw_c2_b1", lambda: run_hnsw(env, batch=1, graph="knn", extras=False, steps=max(args.steps, 200), warm=max(args.warmup, 20))),
+                ("flat_1m_b1", lambda: run_flat(env, n=1_000_000, batch=1)), ("flat_1m_b64", lambda: run_flat(env, n=1_000_000, batch=64)),
                 ("ivfpq_c3", lambda: run_ivfpq(env)), ("spann_c4_128u", lambda: run_spann(env, users=128))]
         if world == 1 and not args.no_c5:  # one GPU's share of C5 (a 1/8 shard of 100M x 16-byte codes: ~50 s of build)
             plan.append(("c5_shard_per_gpu", lambda: run_c5(env, steps=min(args.steps, 8), warm=min(args.warmup, 2))))
         if world == 1 and not args.no_c4_full:  # the whole of C4 on one GPU: 1024 users x 9766 x 768 = 30.7 GB resident (~60 s of build + load)
             plan.append(("spann_c4_full_1024u", lambda: run_spann(env, users=1024, no_sweep=True, steps=min(args.steps, 10), warm=min(args.warmup, 3))))
+        if world == 1 and not args.no_insert_graph:  # C2 again on a graph built the way MuopDB builds it (HnswBuilder::insert)
+            plan.append(("hnsw_c2_insert_graph", lambda: run_hnsw(env, batch=64, graph="insert", n=args.insert_n, extras=False)))
         for name, fn in plan:
             t0 = time.time()
             try:  # a failing extra workload must never take the headline line with it
@@ -734,9 +835,14 @@ def main():
                 extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             log("%s: %.1fs" % (name, time.time() - t0))
         res["workloads"] = extra
+    for h in env.hnsw_cache.values():
+        h[0].close()
+    res.pop("steps", None); res.pop("warmup", None)
     line = {"metric": METRIC, "value": res.pop("value"), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": res.pop("scaling", "weak"),
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+            "vs_baseline": None, "dtype": "f32", "data": "sift1m" if args.sift_dir else "synthetic",
+            # ranks that took part in the collectives (RCCL when the backend is nccl; 0 for a single process)
+            "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else 0, "collective_backend": backend}
     line.update(res)
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -119,6 +119,12 @@ mdb_status mdb_wait(mdb_ctx* ctx);
 int mdb_poll(mdb_ctx* ctx);
 const char* mdb_last_error(mdb_ctx* ctx);
 mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out);
+/* Tuning / test switches of ONE context (kernel variants, grid targets: the list is MDB_OPTIONS in csrc/mdb_common.h, e.g.
+ * "MDB_FLAT_NO_MFMA", "MDB_PQ_NO_FILTER", "MDB_HNSW_NO_BEAM").  Defaults come from same-named environment variables read
+ * ONCE in mdb_device_open; no search call reads the environment.  Serialised with the context's searches; load-time switches
+ * apply to indexes loaded afterwards.  MDB_ERR_NOT_FOUND for an unknown name. */
+mdb_status mdb_set_option(mdb_ctx* ctx, const char* name, long long value);
+mdb_status mdb_get_option(mdb_ctx* ctx, const char* name, long long* value_out);
 const char* mdb_version(void);
 /* Measurement aid (bench.py): when on, every search call brackets its DOMINANT
  * kernel (flat scan / posting-list scan / HNSW traversal) with HIP events on the context's
@@ -218,8 +224,8 @@ mdb_status mdb_ivf_merge_coarse_keys(mdb_ivf* ivf, const uint64_t* keys, size_t 
  * (probes = [B][num_probes] centroid ids).  Results ordered by IdWithScore (score, doc_id). */
 mdb_status mdb_ivf_search(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes,
                           size_t k, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out);
-/* same, stopping before the doc-id remap: the per-shard top-k by (distance, point id) —
- * BlockBasedIvf::search_with_centroids :250-286 — used by the sharded multi-GPU merge */
+/* same, stopping before the doc-id remap: the top-k by (distance, point id) —
+ * BlockBasedIvf::search_with_centroids :250-286 (the sharded multi-GPU path uses the block form, mdb_ivf_search_shard) */
 mdb_status mdb_ivf_search_points(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes,
                                  size_t num_probes, size_t k, mdb_mem mem, uint32_t* point_ids_out, float* scores_out,
                                  uint32_t* counts_out);
@@ -351,26 +357,58 @@ mdb_status mdb_multi_spann_set_filter(mdb_multi_spann* ms, const uint32_t* allow
 mdb_status mdb_multi_spann_invalidate(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,
                                       uint8_t* flags_out);
 
-/* ---------------------------------------------------------------- shard merge
- * Merge `world` per-shard result blocks ([world][B][k] records gathered by RCCL all-gather)
- * into the global top-k per query, ordered by IdWithScore (score, doc_id) like
- * Snapshot::search_for_users (collection/snapshot.rs:60-63).  Device buffers. */
+/* ---------------------------------------------------------------- list-sharded search, EXACT
+ * One index (or multi-user collection) whose posting lists are dealt over `world` GPUs (shard_rank / shard_world at load);
+ * centroids, centroid graphs and doc-id tables are replicated, so every rank selects the same probes.  The reference picks
+ * its top-k by (distance, POINT id) over all probed lists and only then maps to doc ids and sorts by (score, doc id)
+ * (search_with_centroids ivf/block_based/index.rs:250-286, then .._and_remap :298-332).  The sharded path does exactly that
+ * across ranks:
+ *   1. mdb_*_search_shard: this rank's search_with_centroids rows — its k smallest (distance, point id) over the lists it owns,
+ *      NOT remapped — written as one POINTS BLOCK of mdb_points_block_bytes(b, k) bytes:
+ *        { uint32_t point_ids[b][k]; float scores[b][k]; uint32_t counts[b]; uint8_t found[b]; pad to 16 }
+ *      (`block_out` lives where `mem` says; allow == NULL: no planner filter; multi-user point ids are user-local);
+ *   2. ONE all-gather of the blocks (RCCL over xGMI: torch.distributed, or mdb_allgather_blocks with a raw ncclComm_t);
+ *   3. mdb_*_merge_shards on every rank (device buffers): the k smallest of the union by (distance, point id), then doc ids
+ *      from the handle's replicated table, ordered by IdWithScore (score, doc_id).
+ * The result equals the unsharded mdb_*_search row for row, including ties at rank k under non-monotone doc ids
+ * (reindexed segments) and duplicate PQ codes.  The role replaced: rs/aggregator/src/aggregator.rs:80-135. */
+size_t mdb_points_block_bytes(size_t b, size_t k);
+mdb_status mdb_points_block_views(void* block, size_t b, size_t k, uint32_t** point_ids, float** scores, uint32_t** counts,
+                                  uint8_t** found);
+mdb_status mdb_ivf_search_shard(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
+                                mdb_mem mem, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, void* block_out);
+mdb_status mdb_ivf_merge_shards(mdb_ivf* ivf, const void* blocks, size_t world, size_t b, size_t k, mdb_u128* doc_ids_out,
+                                float* scores_out, uint32_t* counts_out);
+mdb_status mdb_spann_search_shard(mdb_spann* spann, const float* queries, size_t b, const mdb_search_params* params, mdb_mem mem,
+                                  const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, void* block_out);
+mdb_status mdb_spann_merge_shards(mdb_spann* spann, const void* blocks, size_t world, size_t b, size_t k, mdb_u128* doc_ids_out,
+                                  float* scores_out, uint32_t* counts_out, uint8_t* found_out);
+mdb_status mdb_multi_spann_search_shard(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                        const mdb_search_params* params, mdb_mem mem, const uint32_t* allow, size_t n_bitmaps,
+                                        size_t words_per_bitmap, void* block_out);
+mdb_status mdb_multi_spann_merge_shards(mdb_multi_spann* ms, const mdb_u128* user_ids, const void* blocks, size_t world, size_t b,
+                                        size_t k, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out, uint8_t* found_out);
+/* The collective alone, for hosts without torch: ncclAllGather(send_block -> recv_blocks, bytes_per_rank per rank, ncclUint8)
+ * enqueued on the context's stream with the caller's communicator (`rccl_comm` = ncclComm_t from ncclCommInitRank, one rank
+ * per GPU).  librccl is bound lazily (dlopen); MDB_ERR_UNSUPPORTED if absent. */
+mdb_status mdb_allgather_blocks(mdb_ctx* ctx, void* rccl_comm, const void* send_block, void* recv_blocks, size_t bytes_per_rank);
+
+/* ---------------------------------------------------------------- merge of rows from DIFFERENT indexes
+ * IdWithScore (score, doc_id) merge of `world` result blocks ([world][B][k]), truncated to k: the cross-SEGMENT rule of
+ * Snapshot::search_for_user(s) (collection/snapshot.rs:60-63, 69-110), and exact for row-sharded flat bases (ids = global
+ * rows).  NOT the merge of list shards of one index — use mdb_*_merge_shards above for those.  Device buffers. */
 mdb_status mdb_merge_shards(mdb_ctx* ctx, const mdb_u128* doc_ids, const float* scores, const uint32_t* counts,
                             size_t world, size_t b, size_t k, mdb_u128* doc_ids_out, float* scores_out,
                             uint32_t* counts_out);
 
 /* The same merge over ONE packed block per rank, laid out as an all-gather delivers it ([world] blocks of
  * mdb_shard_block_bytes(b, k) bytes, each = { mdb_u128 doc_ids[b][k]; float scores[b][k]; uint32_t counts[b]; pad to 16 }).
- * A rank points its search outputs INTO its send block (mdb_shard_block_views), so a sharded step is: search ->
- * one all-gather of a preallocated buffer -> this merge; nothing is allocated or repacked in the step. */
+ * A rank points its search outputs INTO its send block (mdb_shard_block_views); nothing is allocated or repacked in the step. */
 size_t mdb_shard_block_bytes(size_t b, size_t k);
 mdb_status mdb_shard_block_views(void* block, size_t b, size_t k, mdb_u128** doc_ids, float** scores, uint32_t** counts);
 mdb_status mdb_merge_shards_packed(mdb_ctx* ctx, const void* blocks, size_t world, size_t b, size_t k, mdb_u128* doc_ids_out,
                                    float* scores_out, uint32_t* counts_out);
-/* The collective itself, for hosts without torch (the reference's aggregator role, rs/aggregator/src/aggregator.rs:80-135,
- * as ONE RCCL all-gather over xGMI): ncclAllGather(send_block -> recv_blocks, mdb_shard_block_bytes(b, k) bytes per rank)
- * enqueued on the context's stream with the caller's communicator (`rccl_comm` = ncclComm_t from ncclCommInitRank, one
- * rank per GPU), followed by mdb_merge_shards_packed.  librccl is bound lazily (dlopen); MDB_ERR_UNSUPPORTED if absent. */
+/* mdb_allgather_blocks(mdb_shard_block_bytes(b, k)) followed by mdb_merge_shards_packed */
 mdb_status mdb_allgather_merge(mdb_ctx* ctx, void* rccl_comm, const void* send_block, void* recv_blocks, size_t world, size_t b,
                                size_t k, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out);
 

@@ -20,8 +20,50 @@
 #define MDB_MAX_K 2048       // largest top-k / ef served by the on-chip selectors
 #define MDB_METRIC_L2SQ 2     // internal: L2 cascade WITHOUT the final sqrt (L2DistanceCalculator::calculate_squared)
 
+
+// Tuning and test switches.  Defaults below; mdb_device_open overrides them ONCE from same-named environment variables
+// (the only place the library reads the environment), mdb_set_option(ctx, name, value) changes one on a context.  Search
+// entries read ctx->opt under ctx->mu — no call path consults the environment, so host threads may toggle freely.
+// Load-time switches (marked L) take effect for indexes loaded afterwards on that context.
+#define MDB_OPTIONS(X)                                                                                              \
+    X(flat_qt, "MDB_FLAT_QT", 0)                       /* queries per flat-scan block (0 = choose) */               \
+    X(flat_blocks, "MDB_FLAT_BLOCKS", 0)               /* flat-scan grid target (0 = 1024) */                       \
+    X(flat_no_mfma, "MDB_FLAT_NO_MFMA", 0)             /* exact flat kernels only */                                \
+    X(mf_sample_div, "MDB_MF_SAMPLE_DIV", 32)          /* L: sample = 1/div of the base tiles */                    \
+    X(mf_f32, "MDB_MF_F32", 0)                         /* L: f32-MFMA filter instead of bf16 x 3 */                 \
+    X(mf_dbg, "MDB_MF_DBG", 0)                                                                                      \
+    X(bf_qb, "MDB_BF_QB", 4)                           /* max query blocks of 32 per filter block */                \
+    X(bf_exact_sample, "MDB_BF_EXACT_SAMPLE", 0)                                                                    \
+    X(refine_wave_min_b, "MDB_REFINE_WAVE_MIN_B", 512)                                                              \
+    X(refine_slices, "MDB_REFINE_SLICES", 0)                                                                        \
+    X(hnsw_no_dense, "MDB_HNSW_NO_DENSE", 0)           /* L */                                                      \
+    X(hnsw_generic_dist, "MDB_HNSW_GENERIC_DIST", 0)                                                                \
+    X(hnsw_no_closure, "MDB_HNSW_NO_CLOSURE", 0)                                                                    \
+    X(closure_block, "MDB_CLOSURE_BLOCK", 0)                                                                        \
+    X(hnsw_no_beam, "MDB_HNSW_NO_BEAM", 0)                                                                          \
+    X(hnsw_no_row64, "MDB_HNSW_NO_ROW64", 0)                                                                        \
+    X(hnsw_prefetch, "MDB_HNSW_PREFETCH", 0)                                                                        \
+    X(hnsw_dbg, "MDB_HNSW_DBG", 0)                                                                                  \
+    X(ivf_coarse_sample_div, "MDB_IVF_COARSE_SAMPLE_DIV", 8) /* L */                                                \
+    X(pq_no_fast, "MDB_PQ_NO_FAST", 0)                                                                              \
+    X(pq_no_filter, "MDB_PQ_NO_FILTER", 0)                                                                          \
+    X(pq_no_full, "MDB_PQ_NO_FULL", 0)                                                                              \
+    X(pq_blocks, "MDB_PQ_BLOCKS", 256)                                                                              \
+    X(pq_eager_trim, "MDB_PQ_EAGER_TRIM", 1)                                                                        \
+    X(pq_two_phase_min_b, "MDB_PQ_TWO_PHASE_MIN_B", 512)                                                            \
+    X(pq_no_two_phase, "MDB_PQ_NO_TWO_PHASE", 0)                                                                    \
+    X(pq3_blocks, "MDB_PQ3_BLOCKS", 512)                                                                            \
+    X(pq3_cap, "MDB_PQ3_CAP", 2048)                                                                                 \
+    X(pq3_block, "MDB_PQ3_BLOCK", 512)
+struct mdb_options {
+#define X(field, name, dflt) long long field = dflt;
+    MDB_OPTIONS(X)
+#undef X
+};
+
 struct mdb_ctx {
     int device = 0;
+    mdb_options opt;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string last_error;
@@ -46,6 +88,12 @@ struct mdb_ctx {
     // [2] per-call filter bitmaps, [3] small auxiliary inputs (per-query user indices, probe lists)
     void* pinned[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t pinned_cap[4] = {0, 0, 0, 0};
+    // small host arrays that accompany MDB_MEM_DEVICE calls (per-query user slots): those calls return without a sync, so
+    // each staging buffer is guarded by an event and reused only four calls later (mdb_stage_small)
+    void* small_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t small_cap[4] = {0, 0, 0, 0};
+    hipEvent_t small_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int small_next = 0;
     // asynchronous host-buffer calls (mdb_*_search_submit / mdb_wait): the result copies of ONE pending call
     bool submit_mode = false;
     struct PendingCopy { void* dst; size_t off, bytes; };
@@ -57,6 +105,8 @@ struct mdb_ctx {
     std::atomic<int> refs{1};
 };
 mdb_status mdb_pinned(mdb_ctx* ctx, int slot, size_t bytes, void** out);  // grow-only pinned host buffer
+// host -> device copy of a small array, enqueued on the stream; `src` may be reused at once, and so may the call
+mdb_status mdb_stage_small(mdb_ctx* ctx, const void* src, size_t bytes, void* d_dst);
 struct HostCopy { void* dst; const void* src; size_t bytes; };
 // device results -> caller's host buffers through ONE pinned block + the error flags, one stream sync; then mdb_check_flags' tests
 mdb_status mdb_return_to_host(mdb_ctx* ctx, const HostCopy* items, int n);
@@ -103,6 +153,13 @@ mdb_status mdb_fail(mdb_ctx* ctx, mdb_status st, const char* fmt, ...);
         if (_s != MDB_OK) return _s;     \
     } while (0)
 
+// MDB_MEM_HOST entries stage through the context's pinned buffers and scratch, which a submitted call still owns until
+// mdb_wait: refuse BEFORE anything is staged (called with ctx->mu held)
+static inline mdb_status mdb_require_idle(mdb_ctx* ctx, mdb_mem mem) {
+    if (mem == MDB_MEM_HOST && ctx->has_pending)
+        return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "a submitted call is pending on this context: call mdb_wait first");
+    return MDB_OK;
+}
 // grow-only scratch slot
 mdb_status mdb_scratch(mdb_ctx* ctx, int slot, size_t bytes, void** out);
 // check the device flag word after a synchronising call

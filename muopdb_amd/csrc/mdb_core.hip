@@ -58,6 +58,26 @@ mdb_status mdb_pinned(mdb_ctx* ctx, int slot, size_t bytes, void** out) {
     return MDB_OK;
 }
 
+mdb_status mdb_stage_small(mdb_ctx* ctx, const void* src, size_t bytes, void* d_dst) {
+    if (bytes == 0) return MDB_OK;
+    const int i = ctx->small_next;
+    ctx->small_next = (i + 1) & 3;
+    if (!ctx->small_ev[i]) MDB_HIP(ctx, hipEventCreateWithFlags(&ctx->small_ev[i], hipEventDisableTiming));
+    else MDB_HIP(ctx, hipEventSynchronize(ctx->small_ev[i]));   // the copy issued four calls ago: long done
+    if (ctx->small_cap[i] < bytes) {
+        if (ctx->small_buf[i]) (void)hipHostFree(ctx->small_buf[i]);
+        ctx->small_buf[i] = nullptr;
+        ctx->small_cap[i] = 0;
+        const size_t cap = std::max<size_t>(bytes + bytes / 2, 1 << 14);
+        if (hipHostMalloc(&ctx->small_buf[i], cap) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "pinned staging of %zu bytes", cap);
+        ctx->small_cap[i] = cap;
+    }
+    memcpy(ctx->small_buf[i], src, bytes);
+    MDB_HIP(ctx, hipMemcpyAsync(d_dst, ctx->small_buf[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+    MDB_HIP(ctx, hipEventRecord(ctx->small_ev[i], ctx->stream));
+    return MDB_OK;
+}
+
 mdb_status mdb_return_to_host(mdb_ctx* ctx, const HostCopy* items, int n) {
     size_t total = 0;
     for (int i = 0; i < n; ++i) total += align_up(items[i].dst && items[i].bytes ? items[i].bytes : 0, 64);
@@ -113,7 +133,9 @@ extern "C" mdb_status mdb_wait(mdb_ctx* ctx) {
 }
 
 extern "C" int mdb_poll(mdb_ctx* ctx) {
-    if (!ctx || !ctx->has_pending) return 1;
+    if (!ctx) return 1;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->has_pending) return 1;
     (void)hipSetDevice(ctx->device);
     return hipStreamQuery(ctx->stream) == hipSuccess ? 1 : 0;
 }
@@ -130,8 +152,11 @@ void mdb_ctx_release(mdb_ctx* ctx) {
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
         if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
+        if (ctx->small_buf[i]) (void)hipHostFree(ctx->small_buf[i]);
+        if (ctx->small_ev[i]) (void)hipEventDestroy(ctx->small_ev[i]);
+    }
     for (auto& ev : ctx->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -156,8 +181,30 @@ mdb_status mdb_device_open(int gpu, mdb_ctx** out) {
         return MDB_ERR_HIP;
     }
     ctx->own_stream = true;
+    // the ONE place the library reads the environment: option defaults of this context (mdb_set_option changes them later)
+#define X(field, name, dflt) if (const char* v = getenv(name)) ctx->opt.field = atoll(v);
+    MDB_OPTIONS(X)
+#undef X
     *out = ctx;
     return MDB_OK;
+}
+
+mdb_status mdb_set_option(mdb_ctx* ctx, const char* name, long long value) {
+    if (!ctx || !name) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+#define X(field, oname, dflt) if (strcmp(name, oname) == 0) { ctx->opt.field = value; return MDB_OK; }
+    MDB_OPTIONS(X)
+#undef X
+    return mdb_fail(ctx, MDB_ERR_NOT_FOUND, "unknown option %s", name);
+}
+
+mdb_status mdb_get_option(mdb_ctx* ctx, const char* name, long long* value_out) {
+    if (!ctx || !name || !value_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+#define X(field, oname, dflt) if (strcmp(name, oname) == 0) { *value_out = ctx->opt.field; return MDB_OK; }
+    MDB_OPTIONS(X)
+#undef X
+    return mdb_fail(ctx, MDB_ERR_NOT_FOUND, "unknown option %s", name);
 }
 
 void mdb_device_close(mdb_ctx* ctx) {
@@ -214,7 +261,7 @@ mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out) {
     MDB_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->dev_counters) MDB_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 128, hipMemcpyDeviceToHost, ctx->stream));
     MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->dev_counters && getenv("MDB_HNSW_DBG")) {  // debug words [4..15] of an MDB_PIPE_DBG build (cycles / counts of the pipelined traversal)
+    if (ctx->dev_counters && ctx->opt.hnsw_dbg) {  // debug words [4..15] of an MDB_PIPE_DBG build (cycles / counts of the pipelined traversal)
         fprintf(stderr, "[hnsw dbg]");
         for (int i = 3; i < 16; ++i) fprintf(stderr, " %llu", ctx->h_counters[i]);
         fprintf(stderr, "\n");

@@ -256,9 +256,9 @@ static mdb_status launch_flat_scan(mdb_ctx* ctx, const TileView& ts, const DistP
     return MDB_OK;
 }
 
-static int flat_choose_qt(size_t b, int k) {
+static int flat_choose_qt(const mdb_ctx* ctx, size_t b, int k) {
     int qt = b >= 4 ? 4 : (b >= 2 ? 2 : 1);
-    if (getenv("MDB_FLAT_QT")) qt = std::max(1, std::min(qt, atoi(getenv("MDB_FLAT_QT"))));
+    if (ctx->opt.flat_qt > 0) qt = std::max(1, std::min(qt, (int)ctx->opt.flat_qt));
     while (qt > 1 && BlockSelect<MDB_BLOCK>::lds_bytes(k) * qt > 60 * 1024) qt >>= 1;
     return qt;
 }
@@ -267,17 +267,16 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
                           uint64_t* d_keys, uint32_t* d_counts, bool profile, const uint32_t* gate, const UnpackOut* unpack) {
     if (b == 0) return MDB_OK;
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
-    int qt = flat_choose_qt(b, (int)k);
+    int qt = flat_choose_qt(ctx, b, (int)k);
     // a base that stays in L2 (IVF centroids) gains nothing from sharing loads between 4 queries, and pays
     // four selectors per block: 2 queries per block, twice the blocks (measured on the C3 coarse step)
     const bool l2_resident = ts.ntiles * (size_t)ts.d4 * MDB_TILE * 16 <= (8u << 20);
-    if (l2_resident && qt > 2 && !getenv("MDB_FLAT_QT")) qt = 2;
+    if (l2_resident && qt > 2 && ctx->opt.flat_qt <= 0) qt = 2;
     size_t bpad = (b + qt - 1) / qt * qt;
     size_t ngroups = (ts.ntiles + 3) / 4;
     // blocks: enough to fill the chip (~4 per CU), but several rounds per block when there are many query
     // groups — a block that scans one round pays its selectors' warm-up and final sort for nothing
-    static const size_t target_env = getenv("MDB_FLAT_BLOCKS") ? (size_t)atoi(getenv("MDB_FLAT_BLOCKS")) : 0;
-    const size_t target = target_env ? target_env : 1024;   // (HBM-resident base, batch 1: 512 blocks 0.0996 ms + merge, 1024: 0.0959, 2048: 0.0934 but a slower merge)
+    const size_t target = ctx->opt.flat_blocks > 0 ? (size_t)ctx->opt.flat_blocks : 1024;   // (HBM-resident base, batch 1: 512 blocks 0.0996 ms + merge, 1024: 0.0959, 2048: 0.0934 but a slower merge)
     const size_t qgroups = bpad / qt;
     unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(ngroups, 1), std::max<size_t>((target + qgroups - 1) / qgroups, 1));
     // keep the partial buffer bounded (<= 256 MiB)
@@ -359,7 +358,7 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     float* dq;
     int qstride;
-    const bool batched = flat_mfma_applicable(view_of(flat->ts), flat->aux, b, k);
+    const bool batched = flat_mfma_applicable(ctx, view_of(flat->ts), flat->aux, b, k);
     const size_t bpad = batched ? (b + 255) / 256 * 256 : (b + 3) / 4 * 4;  // whole query groups of the matrix-core filter (up to 8 x 32 rows)
     MDB_TRY(stage_queries(ctx, 0, queries, b, flat->ts.d, mem, bpad, &dq, &qstride));
     void *keys, *cnts;

@@ -177,7 +177,7 @@ __global__ void untile_rows_kernel(const float4* __restrict__ tiles, size_t n, i
 mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles, int metric, bool want_rows) {
     size_t full = v.n / MDB_TILE;
     if (full < 1024) return MDB_OK;  // < 64K vectors: the exact path is used
-    static const size_t div = getenv("MDB_MF_SAMPLE_DIV") ? (size_t)atoi(getenv("MDB_MF_SAMPLE_DIV")) : 32;
+    const size_t div = (size_t)std::max<long long>(1, ctx->opt.mf_sample_div);
     size_t want = std::min<size_t>(std::max<size_t>(full / div, 256), 1024);  // 16K .. 64K vectors
     if (want_tiles) want = std::min(std::max<size_t>(want_tiles, 16), full);
     size_t stride = full / want;
@@ -198,7 +198,7 @@ mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t 
     column_mean_kernel<<<dim3((unsigned)v.d4), 256, 0, ctx->stream>>>((const float4*)out.data.p, stiles, v.d4, aux.mean.p);
     // bf16 x 3 operands when a group's query fragments fit LDS (d <= 512); the f32-MFMA filter's centred copy otherwise
     const int nk = (v.d + 15) / 16;
-    static const bool no_bf16 = getenv("MDB_MF_F32") != nullptr;
+    const bool no_bf16 = ctx->opt.mf_f32 != 0;
     if (!no_bf16 && nk <= 32) {
         aux.nk = nk;
         aux.nt32 = v.ntiles * 2;
@@ -746,8 +746,8 @@ __global__ __launch_bounds__(BLK) void flat_refine_kernel(const float4* __restri
 }
 
 // ------------------------------------------------------------------------------------------ host
-bool flat_mfma_applicable(const TileView& ts, FlatAux& aux, size_t b, size_t k) {
-    if (getenv("MDB_FLAT_NO_MFMA")) return false;
+bool flat_mfma_applicable(const mdb_ctx* ctx, const TileView& ts, FlatAux& aux, size_t b, size_t k) {
+    if (ctx->opt.flat_no_mfma) return false;
     if (aux.sample.n == 0 || b < 8 || k == 0) return false;
     if (k * 4 > aux.sample.n) return false;
     double expect = (double)k * (double)ts.n / (double)aux.sample.n;  // candidates per query
@@ -773,7 +773,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     const bool use_bf16 = aux.bhi.p && aux.split_metric == metric;
     int QB = ((size_t)(ts.d4 + MF_CH) * 4 * 65 * 4 <= 64 * 1024 && b > 32) ? 2 : 1;
     if (use_bf16) {  // query blocks of 32 per thread block: as many as the batch fills and LDS holds (A fragments: QB * nk * 2 KiB)
-        static const int qb_max = getenv("MDB_BF_QB") ? atoi(getenv("MDB_BF_QB")) : 4;   // 8 (one block per CU) measured slower than 4
+        const int qb_max = (int)std::max<long long>(1, ctx->opt.bf_qb);   // 8 (one block per CU) measured slower than 4
         QB = b > 128 ? 8 : b > 64 ? 4 : b > 32 ? 2 : 1;
         while (QB > qb_max && QB > 1) QB /= 2;
         while (QB > 1 && ((size_t)QB * aux.nk * 2048 + 32 * QB * 4 + BF_LBUF * 8 + 64 > 150 * 1024 || (b + 32 * QB - 1) / (32 * QB) * (32 * QB) > bpad)) QB /= 2;
@@ -798,7 +798,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     // A. bound of the k-th distance from the sample: its exact top-k (f32 route), or the k-th smallest of matrix-core upper
     //    bounds (bf16 route: no exact pass over the sample at all — the U matrix must fit 1 GiB, else the exact sample scan)
     const size_t ns = aux.sample.n;
-    const bool smp_bf16 = use_bf16 && aux.sample_stride && k <= SB_SUB / 4 && b * ns * 4 <= ((size_t)1 << 30) && !getenv("MDB_BF_EXACT_SAMPLE");
+    const bool smp_bf16 = use_bf16 && aux.sample_stride && k <= SB_SUB / 4 && b * ns * 4 <= ((size_t)1 << 30) && !ctx->opt.bf_exact_sample;
     float* umat = nullptr;
     if (smp_bf16) MDB_TRY(mdb_scratch(ctx, 12, b * ns * 4, (void**)&umat));
     else MDB_TRY(flat_topk_keys(ctx, view_of(aux.sample), metric, dq, qstride, b, k, skeys, scounts, false));
@@ -899,11 +899,11 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     }
     // C. refine
     DistPlan p = make_plan(ts.d, metric);
-    static const size_t wave_min_b = getenv("MDB_REFINE_WAVE_MIN_B") ? (size_t)atoi(getenv("MDB_REFINE_WAVE_MIN_B")) : 512;
+    const size_t wave_min_b = (size_t)std::max<long long>(0, ctx->opt.refine_wave_min_b);
     const bool wave_slices = b >= wave_min_b && k <= 64;   // one wave per slice
     size_t sel_lds = ((std::max(BlockSelect<MDB_BLOCK>::lds_bytes((int)k), BlockSelect<64>::lds_bytes((int)k)) + 15) & ~(size_t)15) + 16;
     uint64_t* rpart;
-    static const unsigned rs_env = getenv("MDB_REFINE_SLICES") ? (unsigned)atoi(getenv("MDB_REFINE_SLICES")) : 0;
+    const unsigned rs_env = (unsigned)std::max<long long>(0, ctx->opt.refine_slices);
     // 256-thread slices: fewer, larger ones measured 2.5x slower (a block's rounds are latency bound); one-wave slices: 4 beat 8 and 16
     // (C5 coarse: refine 157 / 167 / 175 us, merge 23 / 34 / 38 us)
     const unsigned rs = rs_env ? rs_env : (wave_slices ? 4 : MF_RS);
@@ -925,7 +925,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
 #undef RF_LAUNCH
     MDB_HIP(ctx, hipGetLastError());
     MDB_TRY(merge_keys(ctx, rpart, (size_t)rs * k, b, k, d_keys, d_counts));
-    if (getenv("MDB_MF_DBG")) {
+    if (ctx->opt.mf_dbg) {
         uint32_t hn = 0, ho = 0;
         std::vector<uint32_t> hcnt(b * QCNT_STRIDE);
         MDB_HIP(ctx, hipMemcpyAsync(hcnt.data(), qcnt, b * (size_t)QCNT_STRIDE * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -690,46 +690,10 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 #define BEAM_LDS_QS (BEAM_LDS_MISC + 64)
 #define BEAM_CAP (64 * BREGS)
 
-// nearest unexpanded slot in pop order (smallest distance image, LARGEST id among equals); `cdv`
-// holds the distance image of unexpanded slots and SLOT_EMPTY elsewhere.  Returns false if none.
-// slot_out = winner's slot (lane + 64 r) — one SGPR instead of BREGS one-hot masks: the kernel is
-// SGPR-bound and every spilled scalar costs a v_readlane on wave 0's critical path.
-// (hnsw_pipe_kernel's form — its candidate mirror is addressed by slot; hnsw_beam_kernel uses beam_best_id.)
-__device__ __forceinline__ bool beam_best(const uint32_t (&cdv)[BREGS], const uint32_t (&bi)[BREGS], int lane, uint32_t& o_out,
-                                          uint32_t& id_out, int& slot_out) {
-    uint32_t lm = cdv[0];
-#pragma unroll
-    for (int r = 1; r < BREGS; ++r) lm = min(lm, cdv[r]);
-    const uint32_t m = wave_min_u32(lm);
-    o_out = m;
-    if (m == SLOT_EMPTY) return false;
-    unsigned long long hit[BREGS];
-    int total = 0;
-#pragma unroll
-    for (int r = 0; r < BREGS; ++r) { hit[r] = __ballot(cdv[r] == m); total += __popcll(hit[r]); }
-    if (total > 1) {
-        uint32_t li = 0;
-#pragma unroll
-        for (int r = 0; r < BREGS; ++r) li = max(li, cdv[r] == m ? bi[r] : 0u);
-        const uint32_t mid = wave_max_u32(li);
-#pragma unroll
-        for (int r = 0; r < BREGS; ++r) hit[r] = __ballot(cdv[r] == m && bi[r] == mid);
-    }
-    int slot = 0;
-    uint32_t id = 0;
-#pragma unroll
-    for (int r = 0; r < BREGS; ++r)
-        if (hit[r]) {
-            const int l = __ffsll((long long)hit[r]) - 1;
-            slot = 64 * r + l;
-            id = (uint32_t)__builtin_amdgcn_readlane((int)bi[r], l);
-        }
-    slot_out = slot;
-    id_out = id;
-    return true;
-}
-
-// beam_best without the slot: ids are unique in B, so the kernel below marks the popped slot by id and needs no slot index.
+// nearest unexpanded candidate in pop order (smallest distance image, LARGEST id among equals); `cdv` holds the distance
+// image of unexpanded slots and SLOT_EMPTY elsewhere.  Returns false if none.  Ids are unique in B, so the kernel marks
+// the popped slot by id and needs no slot index (the kernel is SGPR-bound: every spilled scalar costs a v_readlane on wave
+// 0's critical path).
 // One min reduction; the winner's id is the per-lane maximum over the lane's matching slots (in-lane ties resolved for free),
 // read from the single matching lane — only distance ties ACROSS lanes pay a second reduction.
 __device__ __forceinline__ bool beam_best_id(const uint32_t (&cdv)[BREGS], const uint32_t (&bi)[BREGS], uint32_t& o_out, uint32_t& id_out) {
@@ -1291,787 +1255,6 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
     }
 }
 
-// ==========================================================================================
-// hnsw_pipe_kernel — hnsw_beam_kernel's traversal, SOFTWARE-PIPELINED across six waves with roles.
-//
-// In hnsw_beam_kernel a step is a serial chain on wave 0 — visited test (P2) -> barrier -> neighbour gather + distances
-// (P3, ~0.8 us of HBM latency; wave 0 selects the runner-up meanwhile) -> barrier -> accept / push / choose (P4) — and a lone
-// wave pays 10-15 cycles per dependent instruction, so the ~450 instructions of a step ARE its 1.8 us.  The reference's
-// algorithm fixes the ORDER of the expansions and what every test sees, not which wave evaluates what or when, and the next
-// node is predictable: it is the beam's runner-up unless a neighbour accepted in this very step beats it (8 % of the steps).
-// So the waves get roles and talk through an LDS mailbox (one snapshot read = the whole mailbox) instead of barriers:
-//   wave 0  COMMIT   owns the beam (registers, as before): acceptance by counting, pushes, the stop test, the choice of the
-//                    next node — every decision of the traversal, in the reference's order, from exact distances.
-//   wave 1  PREPARE  owns the visited set.  After every step it reads the candidate mirror wave 0 keeps in LDS, selects the
-//                    runner-up c1 (wave 0's next choice needs it), and — c1 being the next node 92 % of the time — runs c1's
-//                    visited test-and-set TENTATIVELY: the list of its new neighbours with their distances is ready in LDS
-//                    when wave 0 gets there.  A wrong guess is undone bit for bit (nobody else writes the set) and redone
-//                    for the node wave 0 really chose; a traversal that stops leaves no tentative bit behind.
-//   wave 2  PREDICT  selects the candidate after c1 (the node likely expanded two steps ahead) and asks the distance waves
-//                    for its neighbours' distances; touches its adjacency row into L2.
-//   waves 3-5 DISTANCES  per request: the node's row, a read-only visited test, the gather of the unvisited neighbours and
-//                    their exact distances stored by ROW POSITION.  The visited set only grows (tentative bits apart), so
-//                    when wave 1 runs that node's test-and-set a step later the distances are waiting in LDS: the gather
-//                    has left the critical path.  What a speculation did not cover, wave 1 evaluates itself.
-// Counters and results are hnsw_beam_kernel's step for step: speculative work is never counted and never raises MDB_ERR_NAN.
-// Requirements (else hnsw_beam_kernel runs): ef <= 256, d a multiple of 16 (N16T > 0), no PQ rows, row strides <= 64.
-// ==========================================================================================
-#define PIPE_BLOCK 512   // eight waves, two per SIMD (wave w runs on SIMD w % 4): COMMIT and PREPARE get a SIMD each — waves 4 and 5, their
-                         // SIMD mates, sit at the layer's closing barrier (no issue slots) — PREDICT shares with a distance wave (6), the
-                         // other two distance waves (3, 7) share SIMD 3.  With six waves the two critical waves shared their SIMDs with
-                         // polling distance waves.
-#ifndef PIPE_POLL_SLEEP
-#define PIPE_POLL_SLEEP 0   // critical waves poll without sleeping (nobody else wants their SIMD)
-#endif
-#ifndef PIPE_DIST_SLEEP
-#define PIPE_DIST_SLEEP 1
-#endif
-#define PIPE_CRIT_WAIT() do { if (PIPE_POLL_SLEEP) __builtin_amdgcn_s_sleep(PIPE_POLL_SLEEP); } while (0)
-#define PIPE_LDS_NB (BEAM_LDS_C + 8192)      // nb_id[2][64] | nb_od[2][64]: the new-neighbour lists of even / odd steps
-#define PIPE_LDS_MIR (PIPE_LDS_NB + 1024)    // candidate mirror: {cd, id}[320] (cd = distance image of an unexpanded slot, else EMPTY)
-#define PIPE_LDS_SPEC (PIPE_LDS_MIR + 2560)  // spec_od[2][64]: distance images by row position
-#define PIPE_LDS_MBOX (PIPE_LDS_SPEC + 512)  // 64 mailbox words (the first 32 are the snapshot)
-#define PIPE_LDS_X (PIPE_LDS_MBOX + 256)     // cand[2][4] (uint4) | srow[2][64]
-#define PIPE_LDS_QS (PIPE_LDS_X + 640)
-#define PIPE_LDS_DTMP (BEAM_LDS_C + 5632)    // per distance wave: ids[32] | pos[32]; wave 1: ids[64] (inside C: unused while the roles run)
-enum {
-    MB_GEN = 0, MB_STOP, MB_XNODE, MB_ACK1, MB_ACK2, MB_RU_GEN, MB_RU_O, MB_RU_ID, MB_RU_SLOT, MB_RU_VALID,
-    MB_LIST_GEN, MB_LIST_GEN_ODD, MB_LIST_NODE, MB_LIST_NODE_ODD, MB_LIST_N, MB_LIST_N_ODD,   // by the parity of the step
-    MB_PRED_GEN, MB_PRED_GEN_ODD,            // wave 2's two best candidates of S_g are in cand[g & 1][0..1]
-    MB_SREQ, MB_SNODE0, MB_SNODE1, MB_SRID0, MB_SRID1,
-    MB_SDONE0, MB_SDONE1,                    // distance waves that finished, ever, per buffer: request rid is done at 3 * spec_done_count(rid)
-    MB_SMASK = 25   // [buf 0|1][lo|hi] x 2 words, OR-ed into by the three distance waves: 4 words (25..28)
-};
-
-// ONE LDS read returns the whole mailbox (lane i = word i; every word lives in the first 32 lanes' pass, so the snapshot is
-// a single point in time); fields are then picked out of the register with v_readlane — a poll costs one LDS round trip
-// however many words it looks at.
-__device__ __forceinline__ uint32_t mb_snap(const uint32_t* mb, int lane) { return lds_vload(mb + (lane & 31)); }
-#define MBW(snap, i) ((uint32_t)__builtin_amdgcn_readlane((int)(snap), (i)))
-// requests alternate between the two speculation buffers (rid & 1), so request rid is the ((rid + (rid & 1)) / 2)-th of its buffer
-__device__ __forceinline__ uint32_t spec_done_count(uint32_t rid) { return 3u * ((rid + (rid & 1u)) >> 1); }
-enum { CF_VALID = 1, AF_MORE = 4, AF_MOVED = 8 };   // candidate record flags: entry holds a candidate; more than two accepted; slots moved
-__device__ __forceinline__ void mb_store(uint32_t* mb, int i, uint32_t v) { lds_vstore(mb + i, v); }
-// The LDS operations of one wave are issued and completed in order, so publishing data before a flag (and reading a flag before
-// the data) only needs the COMPILER kept from reordering them; a real fence would also wait for the outstanding global loads —
-// the prefetched adjacency rows.
-#define PIPE_RELEASE() asm volatile("" ::: "memory")
-#define PIPE_ACQUIRE() asm volatile("" ::: "memory")
-
-template <int METRIC, bool VIS_LDS, int N16T>
-__global__ __launch_bounds__(PIPE_BLOCK) void hnsw_pipe_kernel(HnswArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    uint64_t* const W = (uint64_t*)lds;
-    uint64_t* const C = (uint64_t*)(lds + BEAM_LDS_C);
-    uint32_t* const nb_id = (uint32_t*)(lds + PIPE_LDS_NB);      // [parity][64]
-    uint32_t* const nb_od = nb_id + 128;                         // [parity][64]
-    uint64_t* const mir = (uint64_t*)(lds + PIPE_LDS_MIR);      // (id << 32) | cd
-    uint32_t* const spec_od = (uint32_t*)(lds + PIPE_LDS_SPEC);
-    uint32_t* const mb = (uint32_t*)(lds + PIPE_LDS_MBOX);
-    uint32_t* const misc = mb + 40;                              // [1] ep handoff, [2] wsize, [3] overflow, [4..9] closure scratch
-    // cand[h & 1][0..3] = {o, id, slot, flags}: [0], [1] the two best candidates of S_h (wave 2), [2], [3] the two best neighbours
-    // accepted in step h (wave 0, published with GEN = h + 1); flags: CF_VALID, and on [2] AF_MORE / AF_MOVED
-    uint4* const cand = (uint4*)(lds + PIPE_LDS_X);              // 2 x 4 x 16 bytes
-    uint32_t* const srow = (uint32_t*)(lds + PIPE_LDS_X) + 32;   // [buffer][64]: the adjacency row of a speculation's node
-    float* const qs = (float*)(lds + PIPE_LDS_QS);
-    uint32_t* vis = VIS_LDS ? (uint32_t*)(lds + PIPE_LDS_QS + (size_t)a.dpad * 4) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
-    uint32_t* const stage_flag = (uint32_t*)(C + 512);
-
-    const int qi = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = tid >> 4, j = tid & 15;
-    const HnswUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
-    if (!u.valid || u.n == 0 || u.num_layers == 0 || u.entry_point >= u.n) {
-        for (int i = tid; i < a.k; i += PIPE_BLOCK) a.out_keys[(size_t)qi * a.k + i] = MDB_KEY_MAX;
-        if (tid == 0) a.out_counts[qi] = 0;
-        return;
-    }
-    for (int i = tid; i < a.dpad; i += PIPE_BLOCK) qs[i] = a.q[(size_t)qi * a.qstride + i];
-    if (VIS_LDS)
-        for (unsigned long long i = tid; i < a.vis_words; i += PIPE_BLOCK) vis[i] = 0;
-    __syncthreads();
-
-    const float* vecs = a.vecs + u.vec_off;
-    const int ef = a.ef;
-    float qr[N16T];
-#pragma unroll
-    for (int c = 0; c < N16T; ++c) qr[c] = qs[16 * c + j];
-#define PIPE_DIST(rowptr) group16_distance_fast<METRIC, N16T>((rowptr), qr, j)
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    // ---- wave-0 state (as in hnsw_beam_kernel)
-    uint32_t bd[BREGS], bi[BREGS], cdv[BREGS];
-    int n = 0;
-    uint32_t fbound = SLOT_EMPTY;
-    int ru_slot = 0;
-    uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
-    bool ru_valid = false, stop = false;
-    uint32_t evals = 0, expanded = 0;
-    bool nan_seen = false, overflow = false;
-    uint32_t ep = u.entry_point;
-#ifdef MDB_PIPE_DBG
-    unsigned long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-
-    for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
-        const uint32_t stride = layer == 0 ? u.S0 : u.SU;
-        const uint32_t* const adj_base = a.adj + (layer == 0 ? u.adj0_off : u.adjU_off);
-        // adjacency row of `node` at this layer, lane = row position (stride <= 64); the load stays in flight
-        auto load_row = [&](uint32_t node) -> uint32_t {
-            const uint32_t* row = nullptr;
-            if (layer == 0) {
-                if (node < u.n0) row = adj_base + (size_t)node * stride;
-            } else {
-                row = hnsw_upper_row(a, u, layer, node);
-            }
-            return (row && (uint32_t)lane < stride) ? row[lane] : 0xFFFFFFFFu;
-        };
-        if (layer > 0 && layer >= (int)u.small_layer && ef >= 64) {
-            // ---- a layer with no more points than ef: closure of the entry point, whole frontiers per round (all waves)
-            uint32_t* cur = nb_id;
-            uint32_t* nxt = nb_id + 64;
-            unsigned long long* const best = (unsigned long long*)(misc + 8);
-            if (tid == 0) {
-                atomicOr(&vis[ep >> 5], 1u << (ep & 31));
-                cur[0] = ep;
-                misc[4] = 0; misc[5] = 0; misc[6] = 0;
-                *best = MDB_KEY_MAX;
-            }
-            int ncur = 1;
-            __syncthreads();
-            while (ncur > 0) {
-                for (int i = grp; i < ncur; i += PIPE_BLOCK / 16) {
-                    const uint32_t f = cur[i];
-                    const uint32_t* row = nullptr;
-                    row = hnsw_upper_row(a, u, layer, f);
-                    const float d = PIPE_DIST(vecs + (size_t)f * a.dpad);
-                    if (j == 0) {
-                        atomicMin(best, (unsigned long long)make_key(d, f));
-                        if (d != d) atomicOr(a.flags, MDB_FLAG_NAN);
-                        if (row && row[0] != 0xFFFFFFFFu) atomicAdd(&misc[5], 1u);
-                    }
-                    if (row)
-                        for (uint32_t t = j; t < stride; t += 16) {
-                            const uint32_t nbr = row[t];
-                            if (nbr == 0xFFFFFFFFu) break;  // rows are packed
-                            const uint32_t bit = 1u << (nbr & 31);
-                            if (!(atomicOr(&vis[nbr >> 5], bit) & bit)) nxt[atomicAdd(&misc[6], 1u)] = nbr;
-                        }
-                }
-                __syncthreads();
-                const int nn = (int)misc[6];
-                __syncthreads();
-                if (tid == 0) { misc[6] = 0; misc[4] += (uint32_t)ncur; }
-                ncur = nn;
-                uint32_t* tsw = cur; cur = nxt; nxt = tsw;
-            }
-            __syncthreads();
-            ep = key_id((uint64_t)*best);
-            if (wave == 0) { evals += misc[4]; expanded += misc[5]; }
-            __syncthreads();
-            continue;
-        }
-        // ---- layer start: mailbox, mirror, entry point (index.rs:219-231: visited, distance, seed B, popped at once)
-        if (wave == 0) {
-            if (lane < 40) mb[lane] = lane == MB_SNODE0 || lane == MB_SNODE1 ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-            for (int r = 0; r < BREGS; ++r) mir[lane + 64 * r] = (uint64_t)SLOT_EMPTY;
-            if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
-            float d0 = 0.0f;
-            if (lane < 16) d0 = PIPE_DIST(vecs + (size_t)ep * a.dpad);
-            d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), 0));
-            if (d0 != d0) nan_seen = true;
-#pragma unroll
-            for (int r = 0; r < BREGS; ++r) { bd[r] = SLOT_EMPTY; bi[r] = 0; cdv[r] = SLOT_EMPTY; }
-            if (lane == 0) { bd[0] = f32_orderable(d0); bi[0] = ep; }
-            n = 1;
-            fbound = SLOT_EMPTY;
-            stop = false;
-            evals += 1;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            // =============================================================== COMMIT
-            uint32_t gen = 1;
-            uint32_t xnode = ep;
-            if (lane == 0) mb_store(mb, MB_XNODE, xnode);
-            PIPE_RELEASE();
-            if (lane == 0) mb_store(mb, MB_GEN, gen);   // S_1: B = {ep}, no candidates; x_1 = ep
-            PIPE_TB(t_w0);
-            for (;;) {
-                PIPE_CNT(4, 1);
-                PIPE_TB(t_l);
-                // ---- the new neighbours of xnode with their distances (wave 1's list, prepared ahead when it guessed right)
-                uint32_t snap = mb_snap(mb, lane);
-                const int lpar = (int)(gen & 1u);
-                while (MBW(snap, MB_LIST_GEN + lpar) != gen || MBW(snap, MB_LIST_NODE + lpar) != xnode) { PIPE_CRIT_WAIT(); snap = mb_snap(mb, lane); }
-                PIPE_ACQUIRE();
-                PIPE_TE(1, t_l);
-                const uint32_t ln = MBW(snap, MB_LIST_N + lpar);
-                const uint32_t nnew = ln & 0xFFFFu;
-                expanded += ln >> 16;
-                evals += nnew;
-                const int par = (int)(gen & 1u) * 64;
-                const bool have = (uint32_t)lane < nnew;
-                const uint32_t od = have ? nb_od[par + lane] : SLOT_EMPTY;
-                const uint32_t id = have ? nb_id[par + lane] : 0;
-                // ---- accept + push (hnsw_beam_kernel's P4, with the mirror kept in step)
-                uint32_t best_o = SLOT_EMPTY, best_id = 0;
-                int best_slot = -1;
-                uint32_t sec_o = SLOT_EMPTY, sec_id = 0;   // the second best accepted (known when at most two were accepted)
-                int sec_slot = -1;
-                uint32_t aflags = 0;
-                bool ru_local = false;      // the runner-up was selected here (slots moved in a compaction)
-                {
-                    if (__ballot(have && od > 0xFF800000u)) nan_seen = true;   // the image of a NaN distance (the reference panics)
-                    unsigned long long surv = __ballot(have && od < fbound);
-                    unsigned long long accepted = 0;
-                    if (n + (int)nnew <= ef) { accepted = surv; surv = 0; }
-                    while (surv) {
-                        const int sidx = __ffsll((long long)surv) - 1;
-                        surv &= surv - 1;
-                        const uint32_t ds = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
-                        int cnt = __popcll(__ballot(have && od <= ds) & ((1ull << sidx) - 1ull));
-#pragma unroll
-                        for (int r = 0; r < BREGS; ++r) cnt += __popcll(__ballot(bd[r] <= ds));
-                        if (cnt < ef) accepted |= 1ull << sidx;
-                        else fbound = min(fbound, ds);
-                    }
-                    const int na = __popcll(accepted);
-                    if (na) {
-                        while (MBW(snap, MB_ACK1) != gen || MBW(snap, MB_ACK2) != gen) { PIPE_CRIT_WAIT(); snap = mb_snap(mb, lane); }
-                        if (n + na > BEAM_CAP) {
-                            // ---- compaction (radix select of the ef-th smallest image, drop everything farther)
-                            uint32_t prefix = 0;
-                            int need = ef;
-                            for (int bit = 31; bit >= 0; --bit) {
-                                const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
-                                int cnt0 = 0;
-#pragma unroll
-                                for (int r = 0; r < BREGS; ++r)
-                                    cnt0 += __popcll(__ballot((((bd[r] ^ prefix) & hi_mask) == 0u) && !((bd[r] >> bit) & 1u)));
-                                if (cnt0 < need) { need -= cnt0; prefix |= 1u << bit; }
-                            }
-                            const uint32_t f = prefix;
-                            int kept = 0;
-#pragma unroll
-                            for (int r = 0; r < BREGS; ++r) {
-                                const bool keep = bd[r] <= f;
-                                const unsigned long long km = __ballot(keep);
-                                if (keep) {
-                                    const int pos = kept + __popcll(km & lt_mask);
-                                    C[pos] = ((uint64_t)bd[r] << 32) | bi[r];
-                                    stage_flag[pos] = cdv[r] != SLOT_EMPTY ? 1u : 0u;
-                                }
-                                kept += __popcll(km);
-                            }
-#pragma unroll
-                            for (int r = 0; r < BREGS; ++r) {
-                                const int idx = lane + 64 * r;
-                                const bool in = idx < kept;
-                                const uint64_t kk = in ? C[idx] : 0;
-                                bd[r] = in ? (uint32_t)(kk >> 32) : SLOT_EMPTY;
-                                bi[r] = in ? (uint32_t)kk : 0u;
-                                cdv[r] = (in && stage_flag[idx] != 0u) ? bd[r] : SLOT_EMPTY;
-                                mir[idx] = ((uint64_t)bi[r] << 32) | cdv[r];
-                            }
-                            n = kept;
-                            fbound = min(fbound, f);
-                            if (n + na > BEAM_CAP) overflow = true;
-                            // slots moved: wave 1's runner-up names an old slot; select here (rare)
-                            ru_valid = beam_best(cdv, bi, lane, ru_o, ru_id, ru_slot);
-                            ru_local = true;
-                            aflags |= AF_MOVED;
-                        }
-                        if (!overflow) {
-                            // ---- push the accepted neighbours into slots n .. n+na-1 (forward lane permute), mirror included
-                            const bool mine = (accepted >> lane) & 1ull;
-                            const int dest = mine ? (n + __popcll(accepted & lt_mask)) & 63 : (n + na) & 63;
-                            const uint32_t rod = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)od);
-                            const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)id);
-                            const int rel = (lane - n) & 63;
-                            const bool got = rel < na;
-                            const int reg = (n + rel) >> 6;
-#pragma unroll
-                            for (int r = 0; r < BREGS; ++r) {
-                                const bool w = got && reg == r;
-                                bd[r] = w ? rod : bd[r];
-                                bi[r] = w ? rid : bi[r];
-                                cdv[r] = w ? rod : cdv[r];
-                            }
-                            if (got) mir[n + rel] = ((uint64_t)rid << 32) | rod;
-                            // best accepted neighbour in pop order (smallest distance, largest id)
-                            if (na > 2) {
-                                const uint32_t mo = wave_min_u32(mine ? od : SLOT_EMPTY);
-                                const uint32_t mi = wave_max_u32(mine && od == mo ? id : 0u);
-                                const unsigned long long wm = __ballot(mine && od == mo && id == mi);
-                                best_o = mo;
-                                best_id = mi;
-                                best_slot = n + __popcll(accepted & ((1ull << (__ffsll((long long)wm) - 1)) - 1ull));
-                                aflags |= AF_MORE;
-                            } else {
-                                unsigned long long am = accepted;
-                                int rank = 0;
-                                while (am) {
-                                    const int sidx = __ffsll((long long)am) - 1;
-                                    am &= am - 1;
-                                    const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
-                                    const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
-                                    if (best_slot < 0 || ao < best_o || (ao == best_o && ai > best_id)) {
-                                        sec_o = best_o; sec_id = best_id; sec_slot = best_slot;
-                                        best_o = ao; best_id = ai; best_slot = n + rank;
-                                    } else {
-                                        sec_o = ao; sec_id = ai; sec_slot = n + rank;
-                                    }
-                                    ++rank;
-                                }
-                            }
-                            n += na;
-                        }
-                    }
-                }
-                if (overflow) stop = true;
-                if (!stop) {
-                    // ---- candidates.pop(): the runner-up (wave 1, from S_gen) vs the best accepted; stop when it is farther than furthest
-                    snap = mb_snap(mb, lane);
-                    if (!ru_local) {
-                        PIPE_TB(t_r);
-                        while (MBW(snap, MB_RU_GEN) != gen) { PIPE_CRIT_WAIT(); snap = mb_snap(mb, lane); }
-                        PIPE_TE(3, t_r);
-                        ru_valid = MBW(snap, MB_RU_VALID) != 0;
-                        ru_o = MBW(snap, MB_RU_O); ru_id = MBW(snap, MB_RU_ID); ru_slot = (int)MBW(snap, MB_RU_SLOT);
-                    }
-                    const bool take_ru = ru_valid && (best_slot < 0 || ru_o < best_o || (ru_o == best_o && ru_id > best_id));
-                    if (!take_ru && best_slot < 0) {
-                        stop = true;
-                    } else {
-                        const uint32_t m = take_ru ? ru_o : best_o;
-                        int closer = 0;
-                        if (n >= ef) {
-#pragma unroll
-                            for (int r = 0; r < BREGS; ++r) closer += __popcll(__ballot(bd[r] < m));
-                        }
-                        if (closer >= ef) {
-                            stop = true;
-                        } else {
-                            while (MBW(snap, MB_ACK1) != gen || MBW(snap, MB_ACK2) != gen) { PIPE_CRIT_WAIT(); snap = mb_snap(mb, lane); }
-                            const int pslot = take_ru ? ru_slot : best_slot;
-#pragma unroll
-                            for (int r = 0; r < BREGS; ++r)
-                                if (lane + 64 * r == pslot) { cdv[r] = SLOT_EMPTY; mir[pslot] = ((uint64_t)bi[r] << 32) | SLOT_EMPTY; }
-                            xnode = take_ru ? ru_id : best_id;
-                        }
-                    }
-                }
-                if (stop) {
-                    PIPE_RELEASE();
-                    if (lane == 0) mb_store(mb, MB_STOP, 1u);
-                    break;
-                }
-                // ---- publish S_{gen+1} and x_{gen+1} (and what this step accepted: wave 1 derives the next runner-up from it)
-                ++gen;
-                if (lane < 2) {   // lane 0: the best accepted (+ the step's flags), lane 1: the second
-                    const bool second = lane == 1;
-                    const int sl = second ? sec_slot : best_slot;
-                    cand[4 * ((gen - 1) & 1u) + 2 + lane] = make_uint4(second ? sec_o : best_o, second ? sec_id : best_id, (uint32_t)sl,
-                                                                      (sl >= 0 ? CF_VALID : 0u) | (second ? 0u : aflags));
-                }
-                if (lane == 0) mb_store(mb, MB_XNODE, xnode);
-                PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, MB_GEN, gen);
-            }
-            PIPE_TE(0, t_w0);
-        } else if (wave == 1) {
-            // =============================================================== PREPARE: the visited set + the runner-up
-            uint32_t* const tids = (uint32_t*)(lds + PIPE_LDS_DTMP) + 192;   // ids this wave has to evaluate itself
-            uint32_t cd[BREGS], ci[BREGS];
-            // P2 of `node` for the step of generation lg (list into nb[lg & 1]): visited test-and-set + ordered compaction,
-            // distances from a finished speculation where it has them, evaluated here otherwise.  Returns nnew | any_edge << 16.
-            auto make_list = [&](uint32_t node, uint32_t lg, unsigned long long& set_mask, uint32_t& row_keep) -> uint32_t {
-                uint32_t snap = mb_snap(mb, lane);
-                // which buffer names the node (word i of the mailbox sits in lane i of the snapshot: one compare finds it; node ids
-                // never equal 0xFFFFFFFF, the buffers' idle value)
-                const unsigned long long named = __ballot(snap == node) & ((1ull << MB_SNODE0) | (1ull << MB_SNODE1));
-                const int sb = named == 0 ? -1 : (named & (1ull << MB_SNODE0)) ? 0 : 1;
-                uint32_t nbr = 0xFFFFFFFFu;
-                if (sb < 0) nbr = load_row(node);   // (a speculation keeps the node's row in LDS: no global round trip on this path)
-                unsigned long long smask = 0;
-                if (sb >= 0) {
-                    const uint32_t want = sb ? MBW(snap, MB_SRID1) : MBW(snap, MB_SRID0);
-                    PIPE_TB(t_s);
-                    for (;;) {   // a speculation under way is worth waiting for: it started its gather long ago
-                        if ((sb ? MBW(snap, MB_SDONE1) : MBW(snap, MB_SDONE0)) >= spec_done_count(want)) break;
-                        PIPE_CRIT_WAIT();
-                        snap = mb_snap(mb, lane);
-                    }
-                    PIPE_TE(6, t_s);
-                    PIPE_ACQUIRE();
-                    smask = sb ? ((unsigned long long)MBW(snap, MB_SMASK + 3) << 32) | MBW(snap, MB_SMASK + 2)
-                               : ((unsigned long long)MBW(snap, MB_SMASK + 1) << 32) | MBW(snap, MB_SMASK + 0);
-                }
-                uint32_t sv = 0u;
-                if (sb >= 0) {
-                    // wave 2 may hand the buffer to another node at any time: read, THEN check that the buffer still names this
-                    // request (the distance waves overwrite it only after the new request is published; LDS runs in order)
-                    sv = lds_vload(spec_od + sb * 64 + lane);
-                    nbr = lds_vload(srow + sb * 64 + lane);
-                    PIPE_ACQUIRE();
-                    const uint32_t s2 = mb_snap(mb, lane);
-                    if (__ballot(s2 != snap) & (sb ? (1ull << MB_SNODE1) | (1ull << MB_SRID1) : (1ull << MB_SNODE0) | (1ull << MB_SRID0))) {
-                        smask = 0;               // the buffer was handed to another node meanwhile: nothing read from it counts
-                        nbr = load_row(node);
-                    }
-                }
-                bool isnew = false;
-                if (nbr != 0xFFFFFFFFu) {
-                    const uint32_t bit = 1u << (nbr & 31);
-                    isnew = !(atomicOr(&vis[nbr >> 5], bit) & bit);
-                }
-                const unsigned long long bal = __ballot(isnew);
-                const uint32_t anyedge = __ballot(nbr != 0xFFFFFFFFu) != 0 ? 1u : 0u;
-                const uint32_t nnew = (uint32_t)__popcll(bal);
-                const int par = (int)(lg & 1u) * 64;
-                const int kpos = __popcll(bal & lt_mask);
-                const bool covered = (smask >> lane) & 1ull;
-                if (isnew) {
-                    nb_id[par + kpos] = nbr;
-                    if (covered) nb_od[par + kpos] = sv;
-                }
-                // what no speculation covered: this wave's four 16-lane groups (two rows per group and gather)
-                const unsigned long long todo = bal & ~smask;
-                if (todo) {
-                    const int nt = __popcll(todo);
-                    if (isnew && !covered) {
-                        const int tp = __popcll(todo & lt_mask);
-                        tids[tp] = nbr;
-                        tids[64 + tp] = (uint32_t)kpos;
-                    }
-                    const int g0 = lane >> 4;
-                    for (int i = g0; i < nt; i += 8) {
-                        const bool two = i + 4 < nt;
-                        const int i2 = two ? i + 4 : i;
-                        float da, db;
-                        group16_distance_fast2<METRIC, N16T>(vecs + (size_t)tids[i] * a.dpad, vecs + (size_t)tids[i2] * a.dpad, qr, j, da, db);
-                        if (j == 0) {
-                            nb_od[par + tids[64 + i]] = f32_orderable(da);
-                            if (two) nb_od[par + tids[64 + i2]] = f32_orderable(db);
-                        }
-                    }
-                }
-                set_mask = bal;
-                row_keep = nbr;
-                return nnew | (anyedge << 16);
-            };
-            // the list first, then its size and node, then the generation: wave 0 matches generation AND node in one snapshot,
-            // so a list republished for the same generation (a wrong guess redone) is never seen half-written
-            auto publish_list = [&](uint32_t lg, uint32_t node, uint32_t nn) {
-                const int lp = (int)(lg & 1u);
-                PIPE_RELEASE();
-                if (lane == 0) { mb_store(mb, MB_LIST_N + lp, nn); mb_store(mb, MB_LIST_NODE + lp, node); }
-                PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, MB_LIST_GEN + lp, lg);
-            };
-            auto undo_list = [&](unsigned long long set_mask, uint32_t row_keep) {
-                if ((set_mask >> lane) & 1ull) atomicAnd(&vis[row_keep >> 5], ~(1u << (row_keep & 31)));
-            };
-            uint32_t seen = 0;
-            unsigned long long t_mask = 0;      // tentative list: the bits it set (by row position) ...
-            uint32_t t_row = 0xFFFFFFFFu, t_node = 0xFFFFFFFFu, t_n = 0;   // ... its row, node and nnew | any_edge << 16
-            bool t_live = false;
-            // the entry point's list (real): generation 1
-            {
-                unsigned long long m0; uint32_t r0;
-                const uint32_t n0 = make_list(ep, 1, m0, r0);
-                publish_list(1u, ep, n0);
-            }
-            for (;;) {
-                uint32_t g, sn;
-                bool quit = false;
-                PIPE_TB(t_i);
-                for (;;) {
-                    sn = mb_snap(mb, lane);
-                    g = MBW(sn, MB_GEN);
-                    if (g != seen) break;
-                    if (MBW(sn, MB_STOP)) { quit = true; break; }
-                    PIPE_CRIT_WAIT();
-                }
-                PIPE_TE(5, t_i);
-                if (quit) break;
-                seen = g;
-                PIPE_ACQUIRE();
-                PIPE_TB(t_body);
-                const uint32_t xg = MBW(sn, MB_XNODE);
-                // ---- the runner-up of S_g.  S_g = S_{g-1} + (accepted in step g-1) - x_g, so with wave 2's two best of S_{g-1} and wave 0's
-                // two best accepted it is a handful of compares: min(first of {p1, p2} that is not x_g, first of {a1, a2} that is not x_g)
-                // in pop order.  Exact whenever the pieces are known; else (more than two accepted AND the best of them was taken, or a
-                // compaction moved the slots) the full selection over the mirror, as wave 2 does it.
-                uint32_t o1 = SLOT_EMPTY, id1 = 0;
-                int s1 = 0;
-                bool v1 = false, full = g > 1;
-                if (g > 1) {
-                    const uint32_t pp = (g - 1) & 1u;
-                    PIPE_TB(t_p);
-                    while (MBW(sn, MB_PRED_GEN + pp) != g - 1) { PIPE_CRIT_WAIT(); sn = mb_snap(mb, lane); }
-                    PIPE_TE(2, t_p);
-                    PIPE_ACQUIRE();
-                    // lanes 0..3 take one record each: in pop order p1 <= p2 and a1 <= a2, so "the first of each pair that is not x_g"
-                    // is simply the best record that is valid and not x_g
-                    const uint4 cr = *(const uint4*)(cand + 4 * pp + (lane & 3));
-                    const uint32_t af = (uint32_t)__builtin_amdgcn_readlane((int)cr.w, 2);
-                    const bool a1_taken = (uint32_t)__builtin_amdgcn_readlane((int)cr.y, 2) == xg && (af & CF_VALID);
-                    if (!(af & AF_MOVED) && !((af & AF_MORE) && a1_taken)) {
-                        full = false;
-                        const bool ok = lane < 4 && (cr.w & CF_VALID) && cr.y != xg;
-                        // quad reductions (lanes 0..3 are one DPP quad): smallest image, then the largest id among its holders
-                        uint32_t mo = ok ? cr.x : SLOT_EMPTY;
-                        mo = min(mo, MDB_DPP_U32(mo, 0xB1, 0xF));
-                        mo = min(mo, MDB_DPP_U32(mo, 0x4E, 0xF));
-                        uint32_t mi = (ok && cr.x == mo) ? cr.y : 0u;
-                        mi = max(mi, MDB_DPP_U32(mi, 0xB1, 0xF));
-                        mi = max(mi, MDB_DPP_U32(mi, 0x4E, 0xF));
-                        const unsigned long long win = __ballot(ok && cr.x == mo && cr.y == mi) & 0xFull;
-                        v1 = win != 0;
-                        if (v1) {
-                            const int wl = __ffsll((long long)win) - 1;
-                            o1 = (uint32_t)__builtin_amdgcn_readlane((int)cr.x, wl);
-                            id1 = (uint32_t)__builtin_amdgcn_readlane((int)cr.y, wl);
-                            s1 = __builtin_amdgcn_readlane((int)cr.z, wl);
-                        }
-                    }
-                }
-                if (full) {
-#pragma unroll
-                    for (int r = 0; r < BREGS; ++r) {
-                        const uint64_t e = lds_vload(mir + lane + 64 * r);
-                        cd[r] = (uint32_t)e;
-                        ci[r] = (uint32_t)(e >> 32);
-                    }
-                    PIPE_RELEASE();
-                    if (lane == 0) mb_store(mb, MB_ACK1, g);
-                    v1 = beam_best(cd, ci, lane, o1, id1, s1);
-                } else {
-                    if (lane == 0) mb_store(mb, MB_ACK1, g);
-                }
-                if (lane == 0) { mb_store(mb, MB_RU_O, o1); mb_store(mb, MB_RU_ID, id1); mb_store(mb, MB_RU_SLOT, (uint32_t)s1); mb_store(mb, MB_RU_VALID, v1 ? 1u : 0u); }
-                PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, MB_RU_GEN, g);
-                PIPE_TE(11, t_body);
-                // ---- the list of x_g: the tentative one if the guess was right (wave 0 is already consuming it), else undo + redo
-                if (g > 1) {
-                    if (!(t_live && t_node == xg)) {
-                        PIPE_TB(t_redo);
-                        if (t_live) undo_list(t_mask, t_row);
-                        PIPE_CNT(7, 1);
-                        unsigned long long m0; uint32_t r0;
-                        const uint32_t n0 = make_list(xg, g, m0, r0);
-                        publish_list(g, xg, n0);
-                        PIPE_TE(9, t_redo);
-                    }
-                    t_live = false;
-                }
-                // ---- tentatively: c1 is the next node
-                PIPE_TB(t_t);
-                if (v1) {
-                    t_n = make_list(id1, g + 1, t_mask, t_row);
-                    t_node = id1;
-                    t_live = true;
-                    publish_list(g + 1, id1, t_n);
-                }
-                PIPE_TE(10, t_t);
-            }
-            if (t_live) undo_list(t_mask, t_row);   // the traversal stopped: a tentative list nobody consumed leaves no mark
-        } else if (wave == 2) {
-            // =============================================================== PREDICT: the candidate after the runner-up
-            uint32_t seen = 0, sreq = 0, rid0 = 0, rid1 = 0;
-            uint32_t cd[BREGS], ci[BREGS];
-            for (;;) {
-                uint32_t g, sn;
-                bool quit = false;
-                for (;;) {
-                    sn = mb_snap(mb, lane);
-                    g = MBW(sn, MB_GEN);
-                    if (g != seen) break;
-                    if (MBW(sn, MB_STOP)) { quit = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (quit) break;
-                seen = g;
-                PIPE_ACQUIRE();
-                PIPE_TB(t_w2);
-#pragma unroll
-                for (int r = 0; r < BREGS; ++r) {
-                    const uint64_t e = lds_vload(mir + lane + 64 * r);
-                    cd[r] = (uint32_t)e;
-                    ci[r] = (uint32_t)(e >> 32);
-                }
-                PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, MB_ACK2, g);
-                uint32_t o1 = SLOT_EMPTY, id1 = 0, o2 = SLOT_EMPTY, id2 = 0;
-                int s1 = 0, s2 = 0;
-                const bool v1 = beam_best(cd, ci, lane, o1, id1, s1);
-                bool v2 = false;
-                if (v1) {
-#pragma unroll
-                    for (int r = 0; r < BREGS; ++r)
-                        if (lane + 64 * r == s1) cd[r] = SLOT_EMPTY;
-                    v2 = beam_best(cd, ci, lane, o2, id2, s2);
-                }
-                // the two best candidates of S_g: wave 1 derives the runner-up of S_{g+1} from them one step later
-                if (lane < 2) {
-                    const bool second = lane == 1;
-                    cand[4 * (g & 1u) + lane] = make_uint4(second ? o2 : o1, second ? id2 : id1, (uint32_t)(second ? s2 : s1),
-                                                          (second ? v2 : v1) ? CF_VALID : 0u);
-                }
-                PIPE_RELEASE();
-                if (lane == 0) mb_store(mb, MB_PRED_GEN + (int)(g & 1u), g);
-                PIPE_TE(8, t_w2);
-                uint32_t target = 0xFFFFFFFFu;
-                const uint32_t sn2 = mb_snap(mb, lane);
-                if (v2 && MBW(sn2, MB_SNODE0) != id2 && MBW(sn2, MB_SNODE1) != id2) target = id2;
-                if (target == 0xFFFFFFFFu) continue;
-                const int b = (int)((sreq + 1) & 1u);
-                const uint32_t prev = b ? rid1 : rid0;
-                const bool free_ = (b ? MBW(sn2, MB_SDONE1) : MBW(sn2, MB_SDONE0)) >= spec_done_count(prev);
-                // not the buffer holding the distances of wave 1's guess c1 (it is consuming them now; it checks, so this is
-                // about not wasting them)
-                const uint32_t held = b ? MBW(sn2, MB_SNODE1) : MBW(sn2, MB_SNODE0);
-                if (free_ && held != id1) {
-                    ++sreq;
-                    if (b) rid1 = sreq; else rid0 = sreq;
-                    if (lane == 0) {
-                        mb_store(mb, b ? MB_SNODE1 : MB_SNODE0, target);
-                        mb_store(mb, b ? MB_SRID1 : MB_SRID0, sreq);
-                        mb_store(mb, MB_SMASK + 2 * b, 0u);
-                        mb_store(mb, MB_SMASK + 2 * b + 1, 0u);
-                    }
-                    PIPE_RELEASE();
-                    if (lane == 0) mb_store(mb, MB_SREQ, sreq);
-                }
-            }
-        } else if (wave == 3 || wave >= 6) {
-            // =============================================================== DISTANCES (waves 3, 6, 7)
-            const int third = wave == 3 ? 0 : wave - 5;      // this wave's row positions: pos % 3 == third
-            uint32_t* const tid_ = (uint32_t*)(lds + PIPE_LDS_DTMP) + third * 64;   // ids[32] | pos[32]
-            uint32_t next = 1;
-            for (;;) {
-                bool quit = false;
-                uint32_t sn;
-                for (;;) {
-                    sn = mb_snap(mb, lane);
-                    if (MBW(sn, MB_SREQ) >= next) break;
-                    if (MBW(sn, MB_STOP)) { quit = true; break; }
-                    if (PIPE_DIST_SLEEP) __builtin_amdgcn_s_sleep(PIPE_DIST_SLEEP);
-                }
-                if (quit) break;
-                PIPE_ACQUIRE();
-                const int b = (int)(next & 1u);
-                const uint32_t p = b ? MBW(sn, MB_SNODE1) : MBW(sn, MB_SNODE0);
-                const uint32_t nbr = load_row(p);
-                if (third == 0) srow[b * 64 + lane] = nbr;   // wave 1 takes the row from here
-                bool isnew = false;
-                if (nbr != 0xFFFFFFFFu && (lane % 3) == third) {
-                    const uint32_t word = VIS_LDS ? lds_vload(vis + (nbr >> 5)) : *(const volatile uint32_t*)(vis + (nbr >> 5));
-                    isnew = !((word >> (nbr & 31)) & 1u);
-                }
-                const unsigned long long bal = __ballot(isnew);
-                const int cnt = __popcll(bal);
-                if (isnew) {
-                    const int kpos = __popcll(bal & lt_mask);
-                    tid_[kpos] = nbr;
-                    tid_[32 + kpos] = (uint32_t)lane;
-                }
-                const int g0 = lane >> 4;
-                for (int i = g0; i < cnt; i += 8) {
-                    const bool two = i + 4 < cnt;
-                    const int i2 = two ? i + 4 : i;
-                    float da, db;
-                    group16_distance_fast2<METRIC, N16T>(vecs + (size_t)tid_[i] * a.dpad, vecs + (size_t)tid_[i2] * a.dpad, qr, j, da, db);
-                    if (j == 0) {
-                        spec_od[b * 64 + tid_[32 + i]] = f32_orderable(da);
-                        if (two) spec_od[b * 64 + tid_[32 + i2]] = f32_orderable(db);
-                    }
-                }
-                if (lane == 0) {
-                    atomicOr(mb + MB_SMASK + 2 * b, (uint32_t)bal);
-                    atomicOr(mb + MB_SMASK + 2 * b + 1, (uint32_t)(bal >> 32));
-                }
-                PIPE_RELEASE();
-                if (lane == 0) atomicAdd(mb + (b ? MB_SDONE1 : MB_SDONE0), 1u);
-                ++next;
-            }
-        }
-        __syncthreads();
-        if (layer > 0) {
-            if (wave == 0) {
-                uint32_t m = bd[0];
-#pragma unroll
-                for (int r = 1; r < BREGS; ++r) m = min(m, bd[r]);
-                m = wave_min_u32(m);
-                uint32_t im = 0xFFFFFFFFu;
-#pragma unroll
-                for (int r = 0; r < BREGS; ++r) im = bd[r] == m ? min(im, bi[r]) : im;
-                im = wave_min_u32(im);
-                if (lane == 0) misc[1] = im;
-            }
-            __syncthreads();
-            ep = misc[1];
-            continue;
-        }
-        // ---- layer 0 done: spill B and sort it (block-wide bitonic); W = its ef smallest keys
-        if (wave == 0) {
-#pragma unroll
-            for (int r = 0; r < BREGS; ++r)
-                C[lane + 64 * r] = bd[r] == SLOT_EMPTY ? MDB_KEY_MAX : (((uint64_t)bd[r] << 32) | bi[r]);
-            for (int i = BEAM_CAP + lane; i < 512; i += 64) C[i] = MDB_KEY_MAX;
-            if (lane == 0) misc[2] = (uint32_t)(n < ef ? n : ef);
-        }
-        __syncthreads();
-        const int n2 = 512;
-        for (int size = 2; size <= n2; size <<= 1) {
-            for (int st = size >> 1; st > 0; st >>= 1) {
-                for (int t = tid; t < (n2 >> 1); t += PIPE_BLOCK) {
-                    int lo = ((t / st) * st * 2) + (t % st);
-                    int hi = lo + st;
-                    bool up = ((lo & size) == 0);
-                    uint64_t x = C[lo], y = C[hi];
-                    if ((x > y) == up) { C[lo] = y; C[hi] = x; }
-                }
-                __syncthreads();
-            }
-        }
-        for (int i = tid; i < a.ef_cap; i += PIPE_BLOCK) W[i] = C[i];
-        __syncthreads();
-    }
-    const HnswArgs* ap = (const HnswArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ap));
-    const int ws = (int)misc[2];
-    const int kk = ap->k;
-    const int outc = ws < kk ? ws : kk;
-    uint64_t* const okeys = ap->out_keys;
-    for (int i = tid; i < kk; i += PIPE_BLOCK) okeys[(size_t)qi * kk + i] = i < outc ? W[i] : MDB_KEY_MAX;
-#ifdef MDB_PIPE_DBG
-    if (lane == 0 && wave < 3)
-        for (int i = 0; i < 12; ++i)
-            if (dbg_acc[i]) atomicAdd(&ap->counters[4 + i], dbg_acc[i]);
-#endif
-    if (tid == 0) {
-        ap->out_counts[qi] = (uint32_t)outc;
-        misc[3] = overflow ? 1u : 0u;
-        if (!overflow) {
-            atomicAdd(&ap->counters[0], (unsigned long long)evals);
-            atomicAdd(&ap->counters[1], (unsigned long long)expanded);
-            if (nan_seen) atomicOr(ap->flags, MDB_FLAG_NAN);
-        }
-    }
-    __syncthreads();
-    // > ~120 exact distance ties with furthest overflow the 320-slot beam: the first four waves re-run the query with the
-    // general algorithm (sorted LDS sets); rows and counters come from that run
-    if (misc[3] && tid < HNSW_BLOCK) {
-        const HnswArgs a2 = *ap;
-        hnsw_general_traverse<METRIC, VIS_LDS, N16T>(a2, qi, lds, true);
-    }
-}
-#undef PIPE_DIST
 
 // keys (distance, point id) -> doc ids, order unchanged (ann_search :192-208)
 __global__ void hnsw_remap_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, int k,
@@ -2279,7 +1462,7 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
         }
         // dense upper layers (hnsw_upper_row): every (layer, point) gets a row slot — affordable up to 1 GiB per graph
         u.adjD_off = ~0ull;
-        if (nl > 1 && !getenv("MDB_HNSW_NO_DENSE") && (uint64_t)(nl - 1) * nv * SU * 4 <= ((uint64_t)1 << 30)) {
+        if (nl > 1 && !ctx->opt.hnsw_no_dense && (uint64_t)(nl - 1) * nv * SU * 4 <= ((uint64_t)1 << 30)) {
             u.adjD_off = h_adj.size();
             h_adj.resize(h_adj.size() + (size_t)(nl - 1) * nv * SU, 0xFFFFFFFFu);
             for (uint64_t p = 0; p < nv; ++p) {
@@ -2375,7 +1558,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     a.k = (int)k;
     a.out_keys = d_keys; a.out_counts = d_counts; a.flags = ctx->d_flags; a.counters = ctx->d_counters;
     size_t lds_base = (size_t)a.ef_cap * 8 + (size_t)a.cand_cap * 8 + (size_t)a.smax * 8 + (size_t)dpad * 4 + 64;
-    if (ef <= 256) lds_base = std::max<size_t>(lds_base, (size_t)PIPE_LDS_QS + (size_t)dpad * 4);  // the beam / pipe kernels' fixed layouts
+    if (ef <= 256) lds_base = std::max<size_t>(lds_base, (size_t)BEAM_LDS_QS + (size_t)dpad * 4);  // the beam kernel's fixed layout
     size_t words = ((size_t)max_n + 31) / 32 + 1;
     bool vis_lds = lds_base + words * 4 <= 160 * 1024 - 256;
     size_t lds = lds_base + (vis_lds ? words * 4 : 0);
@@ -2395,7 +1578,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         hnsw_search_kernel<METRIC, VL, NF><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);                        \
     } while (0)
     // specialised distance when the whole vector is 16-lane chunks (d = 128 / 768: the configs' dims)
-    const int nf = (kind != MDB_QUANT_PQ && a.p.n8 == 0 && a.p.n4 == 0 && a.p.ntail == 0 && !getenv("MDB_HNSW_GENERIC_DIST")) ? a.p.n16 : 0;
+    const int nf = (kind != MDB_QUANT_PQ && a.p.n8 == 0 && a.p.n4 == 0 && a.p.ntail == 0 && !ctx->opt.hnsw_generic_dist) ? a.p.n16 : 0;
 #define MDB_BEAM_LAUNCH(METRIC, VL, NF, PF, R64)                                                                                   \
     do {                                                                                                                    \
         if (lds > 48 * 1024)                                                                                                \
@@ -2403,19 +1586,9 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
         hnsw_beam_kernel<METRIC, VL, NF, PF, R64><<<dim3((unsigned)b), (PF) ? HNSW_BLOCK + 128 : HNSW_BLOCK, lds, ctx->stream>>>(a); \
     } while (0)
-#define MDB_PIPE_LAUNCH(METRIC, VL, NF)                                                                                     \
-    do {                                                                                                                    \
-        if (lds > 48 * 1024)                                                                                                \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_pipe_kernel<METRIC, VL, NF>,                                 \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hnsw_pipe_kernel<METRIC, VL, NF><<<dim3((unsigned)b), PIPE_BLOCK, lds, ctx->stream>>>(a);                           \
-    } while (0)
 #define MDB_HNSW_LAUNCH(METRIC, VL)                                                                              \
     do {                                                                                                           \
-        if (beam && pipe) {                                                                                        \
-            if (nf == 8) MDB_PIPE_LAUNCH(METRIC, VL, 8);                                                           \
-            else MDB_PIPE_LAUNCH(METRIC, VL, 48);                                                                  \
-        } else if (beam && prefetch) {                                                                             \
+        if (beam && prefetch) {                                                                             \
             if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, true, true);                                               \
             else MDB_BEAM_LAUNCH(METRIC, VL, 48, true, true);                                                      \
         } else if (beam && row64) {                                                                                \
@@ -2431,12 +1604,11 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         else MDB_HNSW_LAUNCH4(METRIC, VL, 0);                                                                      \
     } while (0)
     // graphs no larger than ef (SPANN centroid graphs): frontier-parallel closure, see hnsw_closure_kernel
-    if (max_n <= ef && max_n <= 4096 && !getenv("MDB_HNSW_NO_CLOSURE")) {
+    if (max_n <= ef && max_n <= 4096 && !ctx->opt.hnsw_no_closure) {
         int wcap = 64;
         while ((uint32_t)wcap < max_n) wcap <<= 1;
         // small batches: 64 groups per query (latency); large ones: 256-thread blocks, four resident per CU
-        const char* cbe = getenv("MDB_CLOSURE_BLOCK");
-        const bool big = cbe ? atoi(cbe) >= 1024 : b <= 256;
+        const bool big = ctx->opt.closure_block > 0 ? ctx->opt.closure_block >= 1024 : b <= 256;
         const size_t clds = (size_t)wcap * 16 + (size_t)dpad * 4 + 8 + 64 + (((size_t)max_n + 31) / 32 + 1) * 4;
 #define MDB_CLOSURE_LAUNCH(METRIC, NF, CB)                                                                                    \
     do {                                                                                                                    \
@@ -2464,20 +1636,16 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         return MDB_OK;
     }
     // ef <= 256: register-resident beam; above: sorted LDS sets (MDB_HNSW_NO_BEAM forces the latter, for tests)
-    const bool beam = ef <= 256 && !getenv("MDB_HNSW_NO_BEAM");
-    // software-pipelined traversal (hnsw_pipe_kernel): whole-vector 16-lane chunks, rows of at most 64 edges.  Same rows and
-    // counters as hnsw_beam_kernel (tests run both); OPT-IN (MDB_HNSW_PIPE=1) while it is the slower of the two on the C2 workload.
-    const bool pipe = beam && (nf == 8 || nf == 48) && max_stride <= 64 && getenv("MDB_HNSW_PIPE");
+    const bool beam = ef <= 256 && !ctx->opt.hnsw_no_beam;
     // hnsw_beam_kernel with its prefetch wave (see the kernel): f32 rows of whole 16-lane chunks
-    const bool row64 = max_stride <= 64 && !getenv("MDB_HNSW_NO_ROW64");   // hnsw_beam_kernel's one-chunk specialisation
-    const bool prefetch = beam && row64 && (nf == 8 || nf == 48) && getenv("MDB_HNSW_PREFETCH");   // OPT-IN: measured slower
+    const bool row64 = max_stride <= 64 && !ctx->opt.hnsw_no_row64;   // hnsw_beam_kernel's one-chunk specialisation
+    const bool prefetch = beam && row64 && (nf == 8 || nf == 48) && ctx->opt.hnsw_prefetch;   // OPT-IN: measured slower
     if (metric == MDB_METRIC_L2) {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false);
     } else {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false);
     }
 #undef MDB_BEAM_LAUNCH
-#undef MDB_PIPE_LAUNCH
 #undef MDB_HNSW_LAUNCH4
 #undef MDB_HNSW_LAUNCH
     MDB_HIP(ctx, hipGetLastError());

@@ -36,6 +36,8 @@ struct U128Hash {
     size_t operator()(const U128Key& k) const { return (size_t)(k.lo * 0x9E3779B97F4A7C15ull ^ (k.hi + 0x7F4A7C15ull + (k.lo << 6))); }
 };
 
+size_t mdb_points_block_bytes_impl(size_t b, size_t k);
+
 struct IvfSet {
     mdb_ctx* ctx = nullptr;
     int kind = MDB_QUANT_NONE, metric = MDB_METRIC_L2;
@@ -76,7 +78,7 @@ struct IvfSet {
     mdb_status load(mdb_ctx* ctx, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
                     const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant,
                     uint32_t shard_rank, uint32_t shard_world);
-    mdb_status build_doc_map(size_t ui);
+    mdb_status build_doc_map(size_t ui, mdb_ctx* ectx);
     mdb_status invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out, bool test_only);
     mdb_status set_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem);
     // single index with >= 64K centroids: sample / centred copy for the batched (MFMA-filtered) coarse search
@@ -90,6 +92,10 @@ struct IvfSet {
                     const ScanFilter* filter = nullptr);
     mdb_status remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,
                      mdb_u128* d_doc, float* d_score, uint32_t* d_counts_out);
+    // exact list-sharded search: keys -> one rank's points block; `world` blocks -> merged rows
+    mdb_status pack_points(const uint64_t* d_keys, const uint32_t* d_counts, const uint8_t* d_found, size_t b, size_t k, void* d_block);
+    mdb_status merge_points(const void* d_blocks, size_t world, size_t b, size_t k, const uint32_t* d_q_user, mdb_u128* d_doc,
+                            float* d_score, uint32_t* d_counts_out, uint8_t* d_found_out);
     // algorithmic bytes per scored vector
     size_t bytes_per_scored() const { return (kind == MDB_QUANT_PQ ? (size_t)pq.m : (size_t)num_features * 4) + 4; }
 };

@@ -1005,6 +1005,114 @@ __global__ __launch_bounds__(256) void remap_kernel(const uint64_t* __restrict__
     if (threadIdx.x == 0 && counts_out) counts_out[qi] = (uint32_t)c;
 }
 
+
+// ------------------------------------------------------------------------------------------ exact list-sharded search (§8e)
+// One rank's POINTS block: { uint32 point_ids[b][k]; float scores[b][k]; uint32 counts[b]; uint8 found[b]; pad to 16 } — its
+// search_with_centroids rows (index.rs:250-286: ascending by (distance, point id)) BEFORE the doc-id remap.
+__global__ __launch_bounds__(256) void pack_points_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts,
+                                                          const uint8_t* __restrict__ found, int k, size_t b, uint32_t* __restrict__ pid_out,
+                                                          float* __restrict__ score_out, uint32_t* __restrict__ counts_out,
+                                                          uint8_t* __restrict__ found_out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b * (size_t)(k > 0 ? k : 1)) return;
+    const size_t qi = k > 0 ? t / k : t;
+    const int j = k > 0 ? (int)(t % k) : 0;
+    const uint32_t c = counts[qi];
+    if (j == 0) { counts_out[qi] = c; found_out[qi] = found ? found[qi] : (uint8_t)1; }
+    if (k == 0) return;
+    if ((uint32_t)j < c) { const uint64_t key = keys[t]; pid_out[t] = key_id(key); score_out[t] = key_dist(key); }
+    else { pid_out[t] = 0xFFFFFFFFu; score_out[t] = __uint_as_float(0x7F800000u); }
+}
+
+// The merge of `world` points blocks, per query: the k smallest of the union by (distance, point id) — exactly the heap of
+// search_with_centroids (index.rs:250-286) run over ALL probed lists, since every list is on one rank and each rank kept its
+// own k smallest — and only then the doc ids and the IdWithScore order of search_with_centroids_and_remap (:298-332).  (A merge
+// of already remapped rows by (score, doc id) would keep a different document when scores tie at rank k and doc ids are not
+// monotone in point ids.)  Rows are ascending, so an element's rank is its own index plus one binary search per other row;
+// equal keys (a point assigned to lists on two ranks) are ordered by rank.  One block per query.
+__global__ __launch_bounds__(256) void merge_points_kernel(const char* __restrict__ blocks, size_t stride, int world, size_t b, int k,
+                                                           const IvfUserDev* __restrict__ users, const uint32_t* __restrict__ q_user,
+                                                           const uint8_t* __restrict__ index_bytes, mdb_u128* __restrict__ doc_out,
+                                                           float* __restrict__ score_out, uint32_t* __restrict__ counts_out,
+                                                           uint8_t* __restrict__ found_out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int cap = world * k;
+    uint64_t* keys = (uint64_t*)lds;          // [world * k]
+    uint64_t* lo = keys + cap;                // winners [k]
+    uint64_t* hi = lo + k;
+    float* sc = (float*)(hi + k);
+    uint32_t* pos = (uint32_t*)(sc + k);      // [world + 1] prefix of the rows' lengths
+    const size_t qi = blockIdx.x;
+    const size_t o_sc = b * (size_t)k * 4, o_cnt = b * (size_t)k * 8, o_found = o_cnt + b * 4;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int w = 0; w < world; ++w) {
+            pos[w] = acc;
+            const uint32_t c = ((const uint32_t*)(blocks + (size_t)w * stride + o_cnt))[qi];
+            acc += c < (uint32_t)k ? c : (uint32_t)k;
+        }
+        pos[world] = acc;
+    }
+    __syncthreads();
+    const int n = (int)pos[world];
+    for (int t = threadIdx.x; t < cap; t += blockDim.x) {
+        const int w = t / k, j = t % k;
+        if ((uint32_t)j < pos[w + 1] - pos[w]) {
+            const char* blk = blocks + (size_t)w * stride;
+            const size_t src = qi * (size_t)k + j;
+            keys[pos[w] + j] = make_key(((const float*)(blk + o_sc))[src], ((const uint32_t*)blk)[src]);
+        }
+    }
+    __syncthreads();
+    const IvfUserDev u = users[q_user ? q_user[qi] : 0];
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        int w = 0;
+        while ((int)pos[w + 1] <= t) ++w;
+        const uint64_t key = keys[t];
+        int rank = t - (int)pos[w];
+        for (int w2 = 0; w2 < world && rank < k; ++w2) {
+            if (w2 == w) continue;
+            int a0 = (int)pos[w2], a1 = (int)pos[w2 + 1];  // first index with key > `key` (w2 < w) / >= `key` (w2 > w)
+            const int base = a0;
+            while (a0 < a1) {
+                const int mid = (a0 + a1) >> 1;
+                const uint64_t km = keys[mid];
+                if (w2 < w ? km <= key : km < key) a0 = mid + 1; else a1 = mid;
+            }
+            rank += a0 - base;
+        }
+        if (rank < k) {
+            const uint64_t* dp = (const uint64_t*)(index_bytes + u.doc_ids_off + (size_t)key_id(key) * 16);
+            lo[rank] = dp[0];
+            hi[rank] = dp[1];
+            sc[rank] = key_dist(key);
+        }
+    }
+    __syncthreads();
+    const int c = n < k ? n : k;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        if (j < c) {
+            int rank = 0;
+            const float s = sc[j];
+            const uint64_t l = lo[j], h = hi[j];
+            for (int i = 0; i < c; ++i) {
+                const float si = sc[i];
+                const bool less = si < s || (si == s && (hi[i] < h || (hi[i] == h && (lo[i] < l || (lo[i] == l && i < j)))));
+                rank += less ? 1 : 0;
+            }
+            doc_out[qi * (size_t)k + rank] = mdb_u128{l, h};
+            score_out[qi * (size_t)k + rank] = s;
+        } else {
+            doc_out[qi * (size_t)k + j] = mdb_u128{~0ull, ~0ull};
+            score_out[qi * (size_t)k + j] = __uint_as_float(0x7F800000u);
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (counts_out) counts_out[qi] = (uint32_t)c;
+        if (found_out) found_out[qi] = ((const uint8_t*)(blocks + o_found))[qi];   // replicated centroid graphs: the same on every rank
+    }
+}
+
 // ------------------------------------------------------------------------------------------ IvfSet: load
 static mdb_status parse_ivf_blob(mdb_ctx* ctx, const uint8_t* b, size_t len, size_t offset, IvfBlobInfo& o) {
     if (!fits(offset, 45, len)) return mdb_fail(ctx, MDB_ERR_FORMAT, "IVF index: header out of bounds");
@@ -1222,7 +1330,7 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
         // path (sample bound + matrix-core filter + exact refine) — the same probe ids, several times faster
         if (U == 1 && blobs[0].num_clusters >= 65536) {
             TileView cv{d_cent_tiles.p, blobs[0].num_clusters, (blobs[0].num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
-            static const size_t sdiv = getenv("MDB_IVF_COARSE_SAMPLE_DIV") ? (size_t)std::max(1, atoi(getenv("MDB_IVF_COARSE_SAMPLE_DIV"))) : 8;
+            const size_t sdiv = (size_t)std::max<long long>(1, ctx->opt.ivf_coarse_sample_div);
             MDB_TRY(flat_build_aux(ctx, cv, cent_aux, (cv.n / MDB_TILE) / sdiv, MDB_METRIC_L2, true));
         }
     }
@@ -1234,7 +1342,8 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
 
 // doc id -> point id map of one user, built on first use (BlockBasedIvf::new builds it eagerly,
 // index.rs:67-73; here it is only needed by invalidate / is_invalidated)
-mdb_status IvfSet::build_doc_map(size_t ui) {
+mdb_status IvfSet::build_doc_map(size_t ui, mdb_ctx* ectx) {   // ectx: the CALLING handle's context (errors are reported there)
+    mdb_ctx* const ctx = ectx;
     if (!doc_maps[ui].empty() || blobs[ui].num_vectors == 0) return MDB_OK;
     const IvfBlobInfo& bi = blobs[ui];
     std::vector<uint64_t> ids(bi.num_vectors * 2);
@@ -1252,13 +1361,7 @@ mdb_status IvfSet::invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint
     IvfSet& r = root ? *root : *this;
     if (ui >= blobs.size()) { for (size_t i = 0; i < n; ++i) flags_out[i] = 0; return MDB_OK; }
     std::lock_guard<std::mutex> tg(r.tomb_mu);
-    if (r.doc_maps[ui].empty() && r.blobs[ui].num_vectors) {
-        mdb_ctx* saved = r.ctx;
-        r.ctx = ctx;  // errors are reported on the calling handle's context
-        mdb_status st = r.build_doc_map(ui);
-        r.ctx = saved;
-        MDB_TRY(st);
-    }
+    if (r.doc_maps[ui].empty() && r.blobs[ui].num_vectors) MDB_TRY(r.build_doc_map(ui, ctx));   // the root's ctx is never touched: its searches run meanwhile
     bool dirty = false;
     for (size_t i = 0; i < n; ++i) {
         auto it = r.doc_maps[ui].find(U128Key{doc_ids[i].lo, doc_ids[i].hi});
@@ -1311,7 +1414,7 @@ mdb_status IvfSet::stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t 
     void *pin, *dev;
     MDB_TRY(mdb_pinned(ctx, 2, bytes, &pin));
     memcpy(pin, allow, bytes);
-    MDB_TRY(mdb_scratch(ctx, 8, bytes, &dev));
+    MDB_TRY(mdb_scratch(ctx, 15, bytes, &dev));   // a slot of its own: the coarse search of a large index uses 8-10, 12 (flat_topk_keys_mfma)
     MDB_HIP(ctx, hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, ctx->stream));
     out->allow = (const uint32_t*)dev;
     return MDB_OK;
@@ -1357,19 +1460,19 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     // PQ fast path (ivf_scan_pq2_kernel): compile-time subvector width, table + selector + tile map in LDS
     size_t pq2_lds = 0, pq2_lds_f = 0;
     bool pq2 = false, pq2_filt = false, pq_full = false;
-    if (kind == MDB_QUANT_PQ && !getenv("MDB_PQ_NO_FAST")) {
+    if (kind == MDB_QUANT_PQ && !ctx->opt.pq_no_fast) {
         pq2_lds = ((BlockSelect<PQ2_BLOCK>::lds_bytes((int)k) + 15) & ~(size_t)15) + (2 * PQ2_PCH + 16) * 4 +
                   (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * pq.K * pq.subdim * 4;
         pq2 = (pq.subdim == 4 || pq.subdim == 8 || pq.subdim == 16 || pq.subdim == 32) && (mw == 1 || mw == 2 || mw == 4 || mw == 8) &&
               pq.K == (1 << pq.num_bits) && pq.num_bits <= 8 && pq2_lds <= 160 * 1024 - 256;
         // L2: bound filter in front of the exact row sums (ivf_scan_pq2_kernel<.., FILT>) when its table fits too
         pq2_lds_f = pq2_lds + (size_t)pq.m * pq.K * 2;
-        pq2_filt = pq2 && metric == MDB_METRIC_L2 && pq2_lds_f <= 160 * 1024 - 256 && !getenv("MDB_PQ_NO_FILTER");
-        pq_full = pq.m == 4 * mw && pq.num_bits == 8 && !getenv("MDB_PQ_NO_FULL");
+        pq2_filt = pq2 && metric == MDB_METRIC_L2 && pq2_lds_f <= 160 * 1024 - 256 && !ctx->opt.pq_no_filter;
+        pq_full = pq.m == 4 * mw && pq.num_bits == 8 && !ctx->opt.pq_no_full;
         if (pq2) {  // one block per CU (LDS).  More, shorter blocks do NOT balance skewed lists better here: the hardware
             // dispatches 150 KB-LDS workgroups in order, so CUs idle between blocks (measured: 256 blocks 98 us,
             // 512 blocks 140 us, 1024 blocks 247 us for the same work)
-            static const size_t target = getenv("MDB_PQ_BLOCKS") ? (size_t)atoi(getenv("MDB_PQ_BLOCKS")) : 256;
+            const size_t target = (size_t)std::max<long long>(1, ctx->opt.pq_blocks);
             nsplit = (int)std::min<size_t>(std::max<size_t>((target + b - 1) / b, 1), 16);
         }
     }
@@ -1380,7 +1483,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     ScanArgs a{d_users.p, d_q_user, d_list_tile_off.p, d_slot_ids.p, d_tomb.p, d_probes, d_probe_cnt, probe_stride,
                (int)k, (uint64_t*)partial, ctx->d_flags, ctx->d_counters,
                f.allow ? f.allow : d_tomb.p + ones_word, f.allow && f.n_bitmaps != 1 ? (uint32_t)f.words : 0u, f.allow ? 0xFFFFFFFFu : 0u,
-               direct ? d_counts : nullptr, nullptr, getenv("MDB_PQ_EAGER_TRIM") ? atoi(getenv("MDB_PQ_EAGER_TRIM")) : 1};
+               direct ? d_counts : nullptr, nullptr, (int)ctx->opt.pq_eager_trim};
     dim3 grid((unsigned)nsplit, (unsigned)b);
     size_t sel_lds = BlockSelect<MDB_BLOCK>::lds_bytes((int)k);
     void* qcodes = nullptr;
@@ -1429,19 +1532,19 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         // four 512-thread blocks per CU, exact distances for the candidates only; the one-phase launch behind it is gated on the
         // candidate lists' overflow word.  (At batch 256 — one one-phase block per CU, C3 — the two extra launches and the second
         // pass over the candidates cost more than the table build they save: 0.113 vs 0.105 ms per step.)
-        const size_t pq3_min_b = getenv("MDB_PQ_TWO_PHASE_MIN_B") ? (size_t)atoi(getenv("MDB_PQ_TWO_PHASE_MIN_B")) : 512;   // (read per call: tests toggle it)
-        const bool pq3 = pq2 && metric == MDB_METRIC_L2 && direct && k <= 64 && b >= pq3_min_b && !getenv("MDB_PQ_NO_TWO_PHASE");
+        const size_t pq3_min_b = (size_t)std::max<long long>(0, ctx->opt.pq_two_phase_min_b);
+        const bool pq3 = pq2 && metric == MDB_METRIC_L2 && direct && k <= 64 && b >= pq3_min_b && !ctx->opt.pq_no_two_phase;
         if (pq3) {
-            static const size_t tgt3 = getenv("MDB_PQ3_BLOCKS") ? (size_t)atoi(getenv("MDB_PQ3_BLOCKS")) : 512;
+            const size_t tgt3 = (size_t)std::max<long long>(1, ctx->opt.pq3_blocks);
             const int ns3 = (int)std::min<size_t>(std::max<size_t>((tgt3 + b - 1) / b, 1), std::min<size_t>(16, (size_t)std::max(probe_stride, 1)));
-            const uint32_t cap3 = getenv("MDB_PQ3_CAP") ? (uint32_t)std::max(1, atoi(getenv("MDB_PQ3_CAP"))) : 2048;   // (tests force the overflow path)
+            const uint32_t cap3 = (uint32_t)std::max<long long>(1, ctx->opt.pq3_cap);   // (tests force the overflow path)
             uint32_t *cand, *ccnt;
             MDB_TRY(mdb_scratch(ctx, 13, b * (size_t)ns3 * cap3 * 4, (void**)&cand));
             MDB_TRY(mdb_scratch(ctx, 14, b * (size_t)ns3 * 4 + 512, (void**)&ccnt));
             uint32_t* ovf3 = ccnt + ((b * (size_t)ns3 + 63) / 64) * 64;   // own 256-byte line
             MDB_HIP(ctx, hipMemsetAsync(ovf3, 0, 4, ctx->stream));
             const Pq3Args c3{cand, ccnt, cap3, ovf3};
-            static const int blk3 = getenv("MDB_PQ3_BLOCK") ? atoi(getenv("MDB_PQ3_BLOCK")) : 512;   // C5 shard: 1024 -> 0.76 ms, 512 -> 0.48, 256 -> 0.49
+            const int blk3 = (int)ctx->opt.pq3_block;   // C5 shard: 1024 -> 0.76 ms, 512 -> 0.48, 256 -> 0.49
             const size_t sel3 = blk3 == 1024 ? BlockSelect<1024>::lds_bytes((int)k) : BlockSelect<512>::lds_bytes((int)k);
             const size_t lds3 = ((sel3 + 15) & ~(size_t)15) + (2 * PQ2_PCH + 16) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * pq.K * 4;
             const size_t ldsr = ((BlockSelect<256>::lds_bytes((int)k) + 15) & ~(size_t)15) + (size_t)pq.m * pq.subdim * 4;
@@ -1530,6 +1633,37 @@ mdb_status IvfSet::remap(const uint64_t* d_keys, const uint32_t* d_counts, size_
     return MDB_OK;
 }
 
+size_t mdb_points_block_bytes_impl(size_t b, size_t k) { return align_up(b * k * 8 + b * 4 + b, 16); }
+
+mdb_status IvfSet::pack_points(const uint64_t* d_keys, const uint32_t* d_counts, const uint8_t* d_found, size_t b, size_t k, void* d_block) {
+    if (b == 0) return MDB_OK;
+    char* p = (char*)d_block;
+    const size_t total = b * std::max<size_t>(k, 1);
+    pack_points_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(
+        d_keys, d_counts, d_found, (int)k, b, (uint32_t*)p, (float*)(p + b * k * 4), (uint32_t*)(p + b * k * 8), (uint8_t*)(p + b * k * 8 + b * 4));
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+mdb_status IvfSet::merge_points(const void* d_blocks, size_t world, size_t b, size_t k, const uint32_t* d_q_user, mdb_u128* d_doc,
+                                float* d_score, uint32_t* d_counts_out, uint8_t* d_found_out) {
+    if (b == 0) return MDB_OK;
+    const size_t stride = mdb_points_block_bytes_impl(b, k);
+    if (k == 0) {
+        if (d_counts_out) MDB_HIP(ctx, hipMemsetAsync(d_counts_out, 0, b * 4, ctx->stream));
+        if (d_found_out) MDB_HIP(ctx, hipMemcpyAsync(d_found_out, (const char*)d_blocks + b * 4, b, hipMemcpyDeviceToDevice, ctx->stream));
+        return MDB_OK;
+    }
+    const size_t lds = world * k * 8 + k * 20 + (world + 1) * 4 + 16;
+    if (lds > 150 * 1024) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "world*k=%zu rows exceed the on-chip merge capacity", world * k);
+    if (lds > 48 * 1024)
+        MDB_HIP(ctx, hipFuncSetAttribute((const void*)merge_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    merge_points_kernel<<<dim3((unsigned)b), 256, lds, ctx->stream>>>((const char*)d_blocks, stride, (int)world, b, (int)k, d_users.p, d_q_user,
+                                                                     d_index.p, d_doc, d_score, d_counts_out, d_found_out);
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
 // find_nearest_centroids (index.rs:147-163) for user `ui`: sqrt-L2 to every centroid, the
 // num_probes nearest ordered by (distance, index) [ties: the reference's select_nth_unstable +
 // stable sort leave equal distances implementation-defined; this path orders them by index]
@@ -1544,7 +1678,7 @@ mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, si
                 (bi.num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
     void* keys;
     MDB_TRY(mdb_scratch(ctx, 5, b * num_probes * 8, &keys));
-    if (ui == 0 && cent_aux.sample.n && bpad >= (b + 63) / 64 * 64 && flat_mfma_applicable(cv, cent_aux, b, num_probes)) {
+    if (ui == 0 && cent_aux.sample.n && bpad >= (b + 63) / 64 * 64 && flat_mfma_applicable(ctx, cv, cent_aux, b, num_probes)) {
         MDB_TRY(flat_topk_keys_mfma(ctx, cv, cent_aux, MDB_METRIC_L2, d_q, qstride, b, bpad, num_probes, (uint64_t*)keys, nullptr));
         void* dist;
         MDB_TRY(mdb_scratch(ctx, 1, b * num_probes * 4 + 16, &dist));
@@ -1579,13 +1713,18 @@ static void ivf_release(mdb_ivf* h) {
 
 struct FilterArg { const uint32_t* allow; size_t n_bitmaps, words; };
 
+// mode: OUT_POINTS = point ids + distances (search_with_centroids), OUT_DOCS = doc ids + scores (.._and_remap),
+// OUT_BLOCK = this rank's points block for the exact sharded merge (ids_out = the block, scores_out / counts_out unused)
+enum { OUT_POINTS = 0, OUT_DOCS = 1, OUT_BLOCK = 2 };
 static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes,
-                                  size_t k, mdb_mem mem, bool remap, void* ids_out, float* scores_out, uint32_t* counts_out,
+                                  size_t k, mdb_mem mem, int mode, void* ids_out, float* scores_out, uint32_t* counts_out,
                                   const FilterArg* fa = nullptr, bool submit = false) {
     IvfSet& s = ivf->set;
     mdb_ctx* ctx = s.ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     MDB_HIP(ctx, hipSetDevice(ctx->device));
+    MDB_TRY(mdb_require_idle(ctx, mem));
+    const bool remap = mode == OUT_DOCS;
     if (b == 0) return MDB_OK;
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     struct SubmitScope {  // mdb_*_search_submit: mdb_return_to_host enqueues instead of synchronising
@@ -1621,6 +1760,15 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
     ctx->stat_bytes_per_eval = 0; ctx->stat_bytes_per_scored = s.bytes_per_scored(); ctx->stat_fixed_bytes = 0;
     MDB_TRY(s.scan(dq, qstride, b, nullptr, (uint32_t*)dprobes, nullptr, (int)num_probes, k, (uint64_t*)keys, (uint32_t*)cnts, &filt));
     size_t total = b * k;
+    if (mode == OUT_BLOCK) {
+        if (mem == MDB_MEM_DEVICE) return s.pack_points((uint64_t*)keys, (uint32_t*)cnts, nullptr, b, k, ids_out);
+        void* dblk;
+        const size_t nb = mdb_points_block_bytes_impl(b, k);
+        MDB_TRY(mdb_scratch(ctx, 5, nb, &dblk));
+        MDB_TRY(s.pack_points((uint64_t*)keys, (uint32_t*)cnts, nullptr, b, k, dblk));
+        const HostCopy back[1] = {{ids_out, dblk, nb}};
+        return mdb_return_to_host(ctx, back, 1);
+    }
     if (mem == MDB_MEM_DEVICE) {
         if (remap) MDB_TRY(s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, (mdb_u128*)ids_out, scores_out, counts_out));
         else {
@@ -1773,13 +1921,13 @@ mdb_status mdb_ivf_merge_coarse_keys(mdb_ivf* ivf, const uint64_t* keys, size_t 
 mdb_status mdb_ivf_search(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
                           mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out) {
     if (!ivf || (!queries && b) || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
-    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, true, doc_ids_out, scores_out, counts_out);
+    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, OUT_DOCS, doc_ids_out, scores_out, counts_out);
 }
 
 mdb_status mdb_ivf_search_points(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes,
                                  size_t k, mdb_mem mem, uint32_t* point_ids_out, float* scores_out, uint32_t* counts_out) {
     if (!ivf || (!queries && b) || !point_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
-    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, false, point_ids_out, scores_out, counts_out);
+    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, OUT_POINTS, point_ids_out, scores_out, counts_out);
 }
 
 mdb_status mdb_ivf_search_filtered(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
@@ -1787,7 +1935,7 @@ mdb_status mdb_ivf_search_filtered(mdb_ivf* ivf, const float* queries, size_t b,
                                    mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out) {
     if (!ivf || (!queries && b) || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
     const FilterArg fa{allow, n_bitmaps, words_per_bitmap};
-    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, true, doc_ids_out, scores_out, counts_out, &fa);
+    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, OUT_DOCS, doc_ids_out, scores_out, counts_out, &fa);
 }
 
 mdb_status mdb_ivf_search_submit(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
@@ -1795,7 +1943,37 @@ mdb_status mdb_ivf_search_submit(mdb_ivf* ivf, const float* queries, size_t b, c
                                  float* scores_out, uint32_t* counts_out) {
     if (!ivf || (!queries && b) || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
     const FilterArg fa{allow, n_bitmaps, words_per_bitmap};
-    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, MDB_MEM_HOST, true, doc_ids_out, scores_out, counts_out, &fa, true);
+    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, MDB_MEM_HOST, OUT_DOCS, doc_ids_out, scores_out, counts_out, &fa, true);
+}
+
+// ---- exact list-sharded search
+size_t mdb_points_block_bytes(size_t b, size_t k) { return mdb_points_block_bytes_impl(b, k); }
+
+mdb_status mdb_points_block_views(void* block, size_t b, size_t k, uint32_t** point_ids, float** scores, uint32_t** counts, uint8_t** found) {
+    if (!block) return MDB_ERR_INVALID_ARG;
+    char* p = (char*)block;
+    if (point_ids) *point_ids = (uint32_t*)p;
+    if (scores) *scores = (float*)(p + b * k * 4);
+    if (counts) *counts = (uint32_t*)(p + b * k * 8);
+    if (found) *found = (uint8_t*)(p + b * k * 8 + b * 4);
+    return MDB_OK;
+}
+
+mdb_status mdb_ivf_search_shard(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
+                                mdb_mem mem, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, void* block_out) {
+    if (!ivf || (!queries && b) || !block_out) return MDB_ERR_INVALID_ARG;
+    const FilterArg fa{allow, n_bitmaps, words_per_bitmap};
+    return ivf_search_impl(ivf, queries, b, probes, num_probes, k, mem, OUT_BLOCK, block_out, nullptr, nullptr, &fa);
+}
+
+mdb_status mdb_ivf_merge_shards(mdb_ivf* ivf, const void* blocks, size_t world, size_t b, size_t k, mdb_u128* doc_ids_out,
+                                float* scores_out, uint32_t* counts_out) {
+    if (!ivf || !blocks || !doc_ids_out || !scores_out || world == 0) return MDB_ERR_INVALID_ARG;
+    IvfSet& s = ivf->set;
+    std::lock_guard<std::mutex> g(s.ctx->mu);
+    MDB_HIP(s.ctx, hipSetDevice(s.ctx->device));
+    if (k > MDB_MAX_K) return mdb_fail(s.ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
+    return s.merge_points(blocks, world, b, k, nullptr, doc_ids_out, scores_out, counts_out, nullptr);
 }
 
 mdb_status mdb_ivf_set_filter(mdb_ivf* ivf, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem) {

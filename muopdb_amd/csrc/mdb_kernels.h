@@ -56,7 +56,7 @@ struct FlatAux {
 void flat_aux_view(const FlatAux& src, FlatAux& dst);
 // want_tiles: size of the strided sample in tiles (0: N/32 clamped to 16K..64K vectors, the flat index default)
 mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles = 0, int metric = MDB_METRIC_L2, bool want_rows = false);
-bool flat_mfma_applicable(const TileView& ts, FlatAux& aux, size_t b, size_t k);
+bool flat_mfma_applicable(const mdb_ctx* ctx, const TileView& ts, FlatAux& aux, size_t b, size_t k);
 mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, int metric, const float* dq, int qstride, size_t b,
                                size_t bpad, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false);
 

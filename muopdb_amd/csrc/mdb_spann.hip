@@ -77,8 +77,10 @@ struct SpannFilterArg { const uint32_t* allow; size_t n_bitmaps, words; };
 
 static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b, const uint32_t* h_q_user,
                                     const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out,
-                                    uint32_t* counts_out, uint8_t* found_out, const SpannFilterArg* fa = nullptr, bool submit = false) {
+                                    uint32_t* counts_out, uint8_t* found_out, const SpannFilterArg* fa = nullptr, bool submit = false,
+                                    void* block_out = nullptr) {   // block_out: this rank's POINTS block (exact sharded merge) instead of the remapped rows
     mdb_ctx* ctx = s.ctx;
+    MDB_TRY(mdb_require_idle(ctx, mem));
     if (b == 0) return MDB_OK;
     struct SubmitScope {  // mdb_*_search_submit: mdb_return_to_host enqueues instead of synchronising
         mdb_ctx* c; bool on;
@@ -97,15 +99,14 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     const size_t o_qu = take(b * 4), o_ckeys = take(b * ne * 8), o_ccnt = take(b * 4), o_probes = take(b * ne * 4), o_pcnt = take(b * 4),
-                 o_keys = take(b * ke * 8), o_cnts = take(b * 4), o_found = take(b), o_doc = take(b * ke * 16), o_sc = take(b * ke * 4);
+                 o_keys = take(b * ke * 8), o_cnts = take(b * 4), o_found = take(b), o_doc = take(b * ke * 16), o_sc = take(b * ke * 4),
+                 o_blk = take(block_out ? mdb_points_block_bytes_impl(b, k) : 0);
     char* base;
     MDB_TRY(mdb_scratch(ctx, 11, off, (void**)&base));
     uint32_t* d_q_user = nullptr;
-    if (h_q_user) {  // through pinned staging: the caller's (stack) array may die before the copy runs
-        void* pin;
-        MDB_TRY(mdb_pinned(ctx, 3, b * 4, &pin));
-        memcpy(pin, h_q_user, b * 4);
-        MDB_HIP(ctx, hipMemcpyAsync(base + o_qu, pin, b * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (h_q_user) {  // through event-guarded pinned staging: the caller's (stack) array may die before the copy runs, and a
+                     // MDB_MEM_DEVICE call returns without a sync, so the next call must not overwrite a buffer still being read
+        MDB_TRY(mdb_stage_small(ctx, h_q_user, b * 4, base + o_qu));
         d_q_user = (uint32_t*)(base + o_qu);
     }
     IvfSet::ScanFilter filt;
@@ -129,6 +130,12 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
         s.hnsw.d_index.p, probes, pcnt, dfound, b, ctx->d_flags);
     MDB_HIP(ctx, hipGetLastError());
     MDB_TRY(s.ivf.scan(dq, qstride, b, d_q_user, probes, pcnt, (int)ne, k, keys, cnts, &filt));
+    if (block_out) {
+        if (mem == MDB_MEM_DEVICE) return s.ivf.pack_points(keys, cnts, dfound, b, k, block_out);
+        MDB_TRY(s.ivf.pack_points(keys, cnts, dfound, b, k, base + o_blk));
+        const HostCopy back[1] = {{block_out, base + o_blk, mdb_points_block_bytes_impl(b, k)}};
+        return mdb_return_to_host(ctx, back, 1);
+    }
     if (mem == MDB_MEM_DEVICE) {
         MDB_TRY(s.ivf.remap(keys, cnts, b, k, d_q_user, doc_ids_out, scores_out, counts_out));
         if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound, b, hipMemcpyDeviceToDevice, ctx->stream));
@@ -319,6 +326,34 @@ mdb_status mdb_allgather_merge(mdb_ctx* ctx, void* rccl_comm, const void* send_b
     return mdb_merge_shards_packed(ctx, recv_blocks, world, b, k, doc_ids_out, scores_out, counts_out);
 }
 
+// the collective alone (hosts without torch): ncclAllGather(send -> recv, bytes_per_rank per rank) on the context's stream
+mdb_status mdb_allgather_blocks(mdb_ctx* ctx, void* rccl_comm, const void* send_block, void* recv_blocks, size_t bytes_per_rank) {
+    if (!ctx || !rccl_comm || !send_block || !recv_blocks) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    nccl_all_gather_fn ag = rccl_all_gather();
+    if (!ag) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "librccl.so not found (dlopen): %s", dlerror());
+    const int rc = ag(send_block, recv_blocks, bytes_per_rank, /*ncclUint8*/ 1, rccl_comm, ctx->stream);
+    if (rc != 0) return mdb_fail(ctx, MDB_ERR_HIP, "ncclAllGather failed: ncclResult_t %d", rc);
+    return MDB_OK;
+}
+
+// exact merge of the ranks' points blocks of a SPANN / multi-user SPANN batch (device buffers)
+static mdb_status spann_merge_impl(SpannSet& s, const uint32_t* h_q_user, const void* blocks, size_t world, size_t b, size_t k,
+                                   mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out, uint8_t* found_out) {
+    mdb_ctx* ctx = s.ctx;
+    if (b == 0) return MDB_OK;
+    if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
+    uint32_t* d_q_user = nullptr;
+    if (h_q_user) {
+        void* dev;
+        MDB_TRY(mdb_scratch(ctx, 14, b * 4, &dev));
+        MDB_TRY(mdb_stage_small(ctx, h_q_user, b * 4, dev));
+        d_q_user = (uint32_t*)dev;
+    }
+    return s.ivf.merge_points(blocks, world, b, k, d_q_user, doc_ids_out, scores_out, counts_out, found_out);
+}
+
 // ---------------------------------------------------------------- single-user SPANN
 mdb_status mdb_spann_load(mdb_ctx* ctx, const void* hnsw_index, size_t hnsw_index_len, size_t hnsw_index_offset,
                           const void* hnsw_vectors, size_t hnsw_vectors_len, size_t hnsw_vectors_offset, const void* ivf_index,
@@ -384,6 +419,23 @@ mdb_status mdb_spann_search_submit(mdb_spann* sp, const float* queries, size_t b
     return spann_search_impl(sp->set, queries, b, nullptr, params, MDB_MEM_HOST, doc_ids_out, scores_out, counts_out, found_out, &fa, true);
 }
 
+mdb_status mdb_spann_search_shard(mdb_spann* sp, const float* queries, size_t b, const mdb_search_params* params, mdb_mem mem,
+                                  const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, void* block_out) {
+    if (!sp || (!queries && b) || !params || !block_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(sp->set.ctx->mu);
+    MDB_HIP(sp->set.ctx, hipSetDevice(sp->set.ctx->device));
+    const SpannFilterArg fa{allow, n_bitmaps, words_per_bitmap};
+    return spann_search_impl(sp->set, queries, b, nullptr, params, mem, nullptr, nullptr, nullptr, nullptr, &fa, false, block_out);
+}
+
+mdb_status mdb_spann_merge_shards(mdb_spann* sp, const void* blocks, size_t world, size_t b, size_t k, mdb_u128* doc_ids_out,
+                                  float* scores_out, uint32_t* counts_out, uint8_t* found_out) {
+    if (!sp || !blocks || !doc_ids_out || !scores_out || world == 0) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(sp->set.ctx->mu);
+    MDB_HIP(sp->set.ctx, hipSetDevice(sp->set.ctx->device));
+    return spann_merge_impl(sp->set, nullptr, blocks, world, b, k, doc_ids_out, scores_out, counts_out, found_out);
+}
+
 mdb_status mdb_spann_set_filter(mdb_spann* sp, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem) {
     if (!sp) return MDB_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(sp->set.ctx->mu);
@@ -410,7 +462,7 @@ mdb_status mdb_spann_is_invalidated(mdb_spann* sp, const mdb_u128* doc_ids, size
 // read by HashTable::from_raw_bytes at multi_spann/index.rs:50).  Layout (the crate is not under /root/reference: restated
 // from its published format, see muopdb_amd/formats.py): 32-byte header "ODHT" | meta 1 | key 16 | value 112 | header 32 |
 // item_count u64 | slot_count u64 | version [0,0,0,2] | load factor u16 | pad; slot_count entries {key[16], value[112]};
-// slot_count + 16 control bytes (0xFF = empty).  Host-only: every occupied slot's value IS a UserIndexInfo record.
+// slot_count + 16 control bytes (bit 7 set = empty; occupied = the 7-bit h2).  Host-only: every occupied slot's value IS a UserIndexInfo record.
 mdb_status mdb_odht_user_table(const void* odht_bytes, size_t len, mdb_user_index_info* users_out, size_t cap, size_t* n_out) {
     if (!odht_bytes || !n_out) return MDB_ERR_INVALID_ARG;
     const uint8_t* p = (const uint8_t*)odht_bytes;
@@ -424,7 +476,7 @@ mdb_status mdb_odht_user_table(const void* odht_bytes, size_t len, mdb_user_inde
     const uint8_t* meta = entries + slots * 128;
     size_t n = 0;
     for (uint64_t i = 0; i < slots; ++i) {
-        if (meta[i] == 0xFF) continue;
+        if (meta[i] & 0x80) continue;   // empty: bit 7 (h2 is 7 bits; odht's group query takes the movemask of the control bytes)
         if (users_out && n < cap) {
             static_assert(sizeof(mdb_user_index_info) == 112, "UserIndexInfo is a 112-byte record");
             memcpy(&users_out[n], entries + i * 128 + 16, 112);
@@ -489,18 +541,23 @@ mdb_status mdb_multi_spann_attach(mdb_ctx* ctx, mdb_multi_spann* src, mdb_multi_
 
 size_t mdb_multi_spann_num_users(const mdb_multi_spann* ms) { return ms ? ms->set.num_users : 0; }
 
+static void multi_spann_user_slots(mdb_multi_spann* ms, const mdb_u128* user_ids, size_t b, uint32_t* out) {
+    for (size_t i = 0; i < b; ++i) {
+        auto it = ms->set.user_index.find(U128Key{user_ids[i].lo, user_ids[i].hi});
+        out[i] = it == ms->set.user_index.end() ? (uint32_t)ms->set.num_users : it->second;  // sentinel: valid = 0 => None
+    }
+}
+
 static mdb_status multi_spann_search_impl(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
                                           const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out,
-                                          uint32_t* counts_out, uint8_t* found_out, const SpannFilterArg* fa, bool submit) {
-    if (!ms || (!queries && b) || (!user_ids && b) || !params || !doc_ids_out || !scores_out) return MDB_ERR_INVALID_ARG;
+                                          uint32_t* counts_out, uint8_t* found_out, const SpannFilterArg* fa, bool submit,
+                                          void* block_out = nullptr) {
+    if (!ms || (!queries && b) || (!user_ids && b) || !params || (!block_out && (!doc_ids_out || !scores_out))) return MDB_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(ms->set.ctx->mu);
     MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
     std::vector<uint32_t> qu(b);
-    for (size_t i = 0; i < b; ++i) {
-        auto it = ms->set.user_index.find(U128Key{user_ids[i].lo, user_ids[i].hi});
-        qu[i] = it == ms->set.user_index.end() ? (uint32_t)ms->set.num_users : it->second;  // sentinel: valid = 0 => None
-    }
-    return spann_search_impl(ms->set, queries, b, qu.data(), params, mem, doc_ids_out, scores_out, counts_out, found_out, fa, submit);
+    multi_spann_user_slots(ms, user_ids, b, qu.data());
+    return spann_search_impl(ms->set, queries, b, qu.data(), params, mem, doc_ids_out, scores_out, counts_out, found_out, fa, submit, block_out);
 }
 
 mdb_status mdb_multi_spann_search(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
@@ -523,6 +580,24 @@ mdb_status mdb_multi_spann_search_submit(mdb_multi_spann* ms, const mdb_u128* us
                                          uint8_t* found_out) {
     const SpannFilterArg fa{allow, n_bitmaps, words_per_bitmap};
     return multi_spann_search_impl(ms, user_ids, queries, b, params, MDB_MEM_HOST, doc_ids_out, scores_out, counts_out, found_out, &fa, true);
+}
+
+mdb_status mdb_multi_spann_search_shard(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                        const mdb_search_params* params, mdb_mem mem, const uint32_t* allow, size_t n_bitmaps,
+                                        size_t words_per_bitmap, void* block_out) {
+    if (!block_out) return MDB_ERR_INVALID_ARG;
+    const SpannFilterArg fa{allow, n_bitmaps, words_per_bitmap};
+    return multi_spann_search_impl(ms, user_ids, queries, b, params, mem, nullptr, nullptr, nullptr, nullptr, &fa, false, block_out);
+}
+
+mdb_status mdb_multi_spann_merge_shards(mdb_multi_spann* ms, const mdb_u128* user_ids, const void* blocks, size_t world, size_t b,
+                                        size_t k, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out, uint8_t* found_out) {
+    if (!ms || (!user_ids && b) || !blocks || !doc_ids_out || !scores_out || world == 0) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ms->set.ctx->mu);
+    MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
+    std::vector<uint32_t> qu(b);
+    multi_spann_user_slots(ms, user_ids, b, qu.data());
+    return spann_merge_impl(ms->set, qu.data(), blocks, world, b, k, doc_ids_out, scores_out, counts_out, found_out);
 }
 
 mdb_status mdb_multi_spann_set_filter(mdb_multi_spann* ms, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap,

@@ -5,24 +5,27 @@ Partitioning
   * IVF / SPANN / multi-user SPANN: every rank loads the same files with (shard_rank, shard_world);
     posting list l of every user of a multi-user collection is owned by rank l % world, the lists of a single IVF
     index (C5) are dealt size-balanced (`balanced_owners`: longest first to the least loaded rank), centroids / graphs / doc-id tables are
-    replicated, so probe selection is identical on all ranks and the union of the per-rank top-k
-    equals the single-GPU result exactly — with ONE caveat at exact score ties on the k-th boundary: a rank
-    (like the unsharded path) selects its top-k by (distance, POINT id) and only then re-ranks by
-    (score, DOC id), while the cross-rank merge sees doc ids only.  When several candidates tie exactly at
-    rank k and doc ids are not monotone in point ids (a reindexed segment), the merged row may keep a
-    different one of the tied documents than the unsharded search does (same scores, same count).  The
-    reference's own cross-segment merge (Snapshot::search_for_user, collection/snapshot.rs:69-110) has the
-    same property: it too merges per-segment rows by (score, doc id).
+    replicated, so probe selection is identical on all ranks.
   * HNSW: the traversal does not partition (replicas only): ranks split the batch, no collective.
-  * flat: row-range shards, same gather + merge.
+  * flat: row-range shards; ids are global rows, so the (distance, row) merge of the per-shard rows is exact.
 
-Collective: ONE all-gather per batch of one packed, preallocated block per rank — doc ids [B][k] (2 x u64),
-scores [B][k] f32, counts [B] (PackedTopkGather; (20*k + 4) bytes per query per rank): latency-bound, far below a
-single xGMI link's bandwidth, so a direct all-gather (not a ring pipeline) is the right shape.  A host without
-torch issues the same exchange through the C ABI: mdb_allgather_merge(ctx, ncclComm_t, ...).
-Merge: per query, the `world` sorted rows are merged by IdWithScore order (score, doc id) and
-truncated to k — Snapshot::search_for_users' rule (rs/index/src/collection/snapshot.rs:60-63), not
-the aggregator's descending sort (rs/aggregator/src/aggregator.rs:135).
+The step of a list-sharded index is EXACT (PointsGather):
+  1. every rank runs search_with_centroids (rs/index/src/ivf/block_based/index.rs:250-286) over the lists it owns and writes its
+     k smallest (distance, POINT id) rows — not remapped — straight into its POINTS block (mdb_*_search_shard;
+     { u32 point_ids[b][k]; f32 scores[b][k]; u32 counts[b]; u8 found[b] }: (8 k + 5) bytes per query per rank);
+  2. ONE all-gather of the preallocated blocks: latency-bound, far below a single xGMI link's bandwidth, so a direct
+     all-gather (not a ring pipeline) is the right shape;
+  3. every rank merges on the device (mdb_*_merge_shards): the k smallest of the union by (distance, point id) — which is the
+     reference's heap over all probed lists, since each list lives on one rank — and only THEN doc ids and the IdWithScore
+     (score, doc id) order (search_with_centroids_and_remap :298-332).
+  Row for row the unsharded result, including score ties at rank k under doc ids that are not monotone in point ids
+  (reindexed segments) and duplicate PQ codes (tests/test_gpu_traversal.py::test_sharded_merge_is_exact_under_ties).
+  A host without torch issues step 2 through the C ABI: mdb_allgather_blocks(ctx, ncclComm_t, ...).
+  The role replaced is the aggregator's fan-out (rs/aggregator/src/aggregator.rs:80-135).
+
+PackedTopkGather / mdb_merge_shards (IdWithScore merge of already remapped rows) remain for rows of DIFFERENT indexes —
+flat row shards and the segments of a snapshot (Snapshot::search_for_users, rs/index/src/collection/snapshot.rs:60-63) — where
+(score, doc id) IS the reference's merge rule.
 """
 import ctypes as C
 
@@ -68,8 +71,8 @@ def block_views(block, b, k):
 
 
 class PackedTopkGather:
-    """The sharded step's exchange: ONE all-gather per batch of one preallocated packed block per rank,
-    then the device merge.  The search writes its outputs straight into this rank's send block (`ids`, `scores`,
+    """Exchange + IdWithScore merge of already remapped rows (flat row shards, segments of a snapshot — NOT list shards of one
+    index: PointsGather): ONE all-gather per batch of one preallocated packed block per rank, then the device merge.  The search writes its outputs straight into this rank's send block (`ids`, `scores`,
     `counts` are views of it), so the step allocates nothing and repacks nothing:
 
         g = PackedTopkGather(ctx, b, k, "cuda")
@@ -108,6 +111,75 @@ class PackedTopkGather:
                                               C.c_void_p(self.out_scores.data_ptr()), C.c_void_p(self.out_counts.data_ptr())))
         return self.out_docs, self.out_scores, self.out_counts
 
+
+
+def points_block_bytes(b, k):
+    """bytes of one rank's POINTS block (mdb_points_block_bytes): point ids [b][k] u32 | scores [b][k] f32 | counts [b] u32 | found [b] u8 | pad 16"""
+    return (b * k * 8 + b * 4 + b + 15) // 16 * 16
+
+
+def points_block_views(block, b, k):
+    """typed views INTO a uint8 points block: (point ids int32 [b,k], scores f32 [b,k], counts int32 [b], found uint8 [b])"""
+    pids = block[:b * k * 4].view(torch.int32).view(b, k)
+    scores = block[b * k * 4:b * k * 8].view(torch.float32).view(b, k)
+    counts = block[b * k * 8:b * k * 8 + b * 4].view(torch.int32)
+    found = block[b * k * 8 + b * 4:b * k * 8 + b * 5]
+    return pids, scores, counts, found
+
+
+class PointsGather:
+    """The EXACT sharded step (module docstring): search_shard into `send`, ONE all-gather, merge on the device.
+
+        g = PointsGather(ctx, b, k, "cuda")
+        mdb_ivf_search_shard(ivf, ..., MDB_MEM_DEVICE, ..., g.send.data_ptr())
+        docs, scores, counts = g.gather_merge_ivf(ivf)                   # [b,k,2], [b,k], [b] on every rank
+      (SPANN: mdb_spann_search_shard / g.gather_merge_spann(spann); multi-user: g.gather_merge_multi(ms, user_ids))
+
+    `ctx` None (CPU / gloo plumbing tests): gather only, the caller merges `recv_views()` itself."""
+
+    def __init__(self, ctx, b, k, device, group=None):
+        self.ctx, self.b, self.k, self.group = ctx, b, k, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.nb = points_block_bytes(b, k)
+        self.send = torch.zeros(self.nb, dtype=torch.uint8, device=device)
+        self.recv = torch.zeros(self.world * self.nb, dtype=torch.uint8, device=device)
+        self.out_docs = torch.zeros((b, max(k, 1), 2), dtype=torch.int64, device=device)
+        self.out_scores = torch.zeros((b, max(k, 1)), dtype=torch.float32, device=device)
+        self.out_counts = torch.zeros(b, dtype=torch.int32, device=device)
+        self.out_found = torch.ones(b, dtype=torch.uint8, device=device)
+
+    def gather(self):
+        if self.world == 1:
+            self.recv.copy_(self.send)
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)  # rank-major blocks
+        return self.recv
+
+    def recv_views(self):
+        return [points_block_views(self.recv[w * self.nb:(w + 1) * self.nb], self.b, self.k) for w in range(self.world)]
+
+    def _tail(self, with_found):
+        a = [C.c_void_p(self.recv.data_ptr()), C.c_size_t(self.world), C.c_size_t(self.b), C.c_size_t(self.k),
+             C.c_void_p(self.out_docs.data_ptr()), C.c_void_p(self.out_scores.data_ptr()), C.c_void_p(self.out_counts.data_ptr())]
+        if with_found:
+            a.append(C.c_void_p(self.out_found.data_ptr()))
+        return a
+
+    def gather_merge_ivf(self, ivf):
+        self.gather()
+        self.ctx.check(self.ctx.lib.mdb_ivf_merge_shards(ivf.h, *self._tail(False)))
+        return self.out_docs, self.out_scores, self.out_counts
+
+    def gather_merge_spann(self, spann):
+        self.gather()
+        self.ctx.check(self.ctx.lib.mdb_spann_merge_shards(spann.h, *self._tail(True)))
+        return self.out_docs, self.out_scores, self.out_counts
+
+    def gather_merge_multi(self, ms, user_ids_c):
+        """user_ids_c: the same ctypes U128 array the search was called with"""
+        self.gather()
+        self.ctx.check(self.ctx.lib.mdb_multi_spann_merge_shards(ms.h, user_ids_c, *self._tail(True)))
+        return self.out_docs, self.out_scores, self.out_counts
 
 def all_gather_topk(doc_ids, scores, counts, group=None):
     """Unpacked variant (three collectives; kept for callers that hold three separate tensors — the packed class above is

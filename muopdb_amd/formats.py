@@ -327,7 +327,12 @@ def parse_simple_yaml(text):
 #                      (index += stride, stride += 16); a key goes into the first empty slot of the first group that has one
 #   slot_count:        max(16, next_power_of_two(ceil(n * 65535 / factor)))
 ODHT_GROUP = 16
-ODHT_EMPTY = 0xFF
+ODHT_EMPTY = 0xFF   # what the writer fills empty control bytes with; READERS test bit 7 (h2 is 7 bits: odht's group query takes
+                    # the movemask of the control bytes), so a table whose writer used 0x80 reads the same
+
+
+def _odht_is_empty(ctrl):
+    return (ctrl & 0x80) != 0
 
 
 def fx_hash32(data):
@@ -388,7 +393,7 @@ def odht_table(entries, key_size=16, value_size=112, max_load_factor_percent=90)
                     break
             if done:
                 break
-            empty = next((idx for idx in group if meta[idx] == ODHT_EMPTY), None)
+            empty = next((idx for idx in group if _odht_is_empty(meta[idx])), None)
             if empty is not None:
                 data[empty * esz:(empty + 1) * esz] = key + value
                 meta[empty] = h2
@@ -414,7 +419,7 @@ def odht_entries(raw, key_size=16, value_size=112):
     meta = raw[32 + slots * esz:]
     out = []
     for i in range(slots):
-        if meta[i] != ODHT_EMPTY:
+        if not _odht_is_empty(meta[i]):
             e = raw[32 + i * esz:32 + (i + 1) * esz]
             out.append((bytes(e[:key_size]), bytes(e[key_size:])))
     if len(out) != count:
@@ -434,7 +439,7 @@ def odht_get(raw, key, key_size=16, value_size=112):
         for idx in group:
             if meta[idx] == h2 and bytes(raw[32 + idx * esz:32 + idx * esz + key_size]) == key:
                 return bytes(raw[32 + idx * esz + key_size:32 + (idx + 1) * esz])
-        if any(meta[idx] == ODHT_EMPTY for idx in group):
+        if any(_odht_is_empty(meta[idx]) for idx in group):
             return None
 
 

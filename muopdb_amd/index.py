@@ -261,6 +261,28 @@ def allow_bitmap(point_ids, num_points):
     return bm
 
 
+def _merge_shards(ctx, call, blocks, b, k, with_found):
+    """Host-side convenience over mdb_*_merge_shards (device buffers): uploads the gathered blocks with torch, merges on
+    the GPU, returns a SearchResult.  Production ranks keep everything on the device (muopdb_amd.distributed.PointsGather)."""
+    import torch
+    world = len(blocks)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    recv = torch.from_numpy(np.concatenate([np.ascontiguousarray(x, np.uint8) for x in blocks])).to(dev)
+    ke = max(k, 1)
+    docs = torch.zeros((b, ke, 2), dtype=torch.int64, device=dev)
+    sc = torch.zeros((b, ke), dtype=torch.float32, device=dev)
+    cn = torch.zeros(b, dtype=torch.int32, device=dev)
+    fd = torch.ones(b, dtype=torch.uint8, device=dev)
+    args = [C.c_void_p(recv.data_ptr()), C.c_size_t(world), C.c_size_t(b), C.c_size_t(k), C.c_void_p(docs.data_ptr()),
+            C.c_void_p(sc.data_ptr()), C.c_void_p(cn.data_ptr())]
+    if with_found:
+        args.append(C.c_void_p(fd.data_ptr()))
+    ctx.check(call(*args))
+    ctx.sync()
+    ids = docs.cpu().numpy().view(np.uint64)
+    return SearchResult(b, k, ids[:, :, 0], ids[:, :, 1], sc.cpu().numpy(), cn.cpu().numpy().view(np.uint32), fd.cpu().numpy())
+
+
 class BlockBasedIvf:
     """rs/index/src/ivf/block_based/index.rs"""
 
@@ -386,6 +408,26 @@ class BlockBasedIvf:
                                                           L.ptr(ids, C.c_uint32), L.ptr(sc, C.c_float),
                                                           L.ptr(cn, C.c_uint32)))
         return ids[:, :k], sc[:, :k], cn
+
+    # ---- exact list-sharded search (include/muopdb_hip.h, "list-sharded search, EXACT")
+    def search_shard(self, queries, k, num_probes=0, probes=None, planner=None):
+        """This rank's search_with_centroids rows as a POINTS block (uint8 array of mdb_points_block_bytes(b, k))."""
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        if probes is not None:
+            probes = np.ascontiguousarray(probes, np.uint32).reshape(b, -1)
+            num_probes = probes.shape[1]
+        blk = np.zeros(int(self.ctx.lib.mdb_points_block_bytes(C.c_size_t(b), C.c_size_t(k))), np.uint8)
+        ap, nb, words, keep = _planner_args(planner)
+        self.ctx.check(self.ctx.lib.mdb_ivf_search_shard(self.h, L.ptr(q, C.c_float), C.c_size_t(b),
+                                                         L.ptr(probes, C.c_uint32) if probes is not None else None,
+                                                         C.c_size_t(num_probes), C.c_size_t(k), C.c_int(L.MEM_HOST), ap, nb, words,
+                                                         L.ptr(blk, C.c_uint8)))
+        return blk
+
+    def merge_shards(self, blocks, b, k):
+        """`blocks`: the ranks' points blocks (list of uint8 arrays, rank order) -> SearchResult equal to the unsharded search."""
+        return _merge_shards(self.ctx, lambda *a: self.ctx.lib.mdb_ivf_merge_shards(self.h, *a), blocks, b, k, False)
 
     def set_filter(self, bitmaps):
         """Planner hook (scan_posting_list :214-226): allow bitmaps over point ids for the following searches."""
@@ -552,6 +594,20 @@ class Spann:
                                                             *out.args(), L.ptr(out.found, C.c_uint8)))
         return Pending(self.ctx, out, None)
 
+    def search_shard(self, queries, params, planner=None):
+        """This rank's rows of Spann::search before the remap, as a POINTS block (mdb_spann_search_shard)."""
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        blk = np.zeros(int(self.ctx.lib.mdb_points_block_bytes(C.c_size_t(b), C.c_size_t(params.top_k))), np.uint8)
+        p = params.to_c()
+        ap, nb, words, keep = _planner_args(planner)
+        self.ctx.check(self.ctx.lib.mdb_spann_search_shard(self.h, L.ptr(q, C.c_float), C.c_size_t(b), C.byref(p), C.c_int(L.MEM_HOST),
+                                                           ap, nb, words, L.ptr(blk, C.c_uint8)))
+        return blk
+
+    def merge_shards(self, blocks, b, k):
+        return _merge_shards(self.ctx, lambda *a: self.ctx.lib.mdb_spann_merge_shards(self.h, *a), blocks, b, k, True)
+
     def set_filter(self, bitmaps):
         _set_filter(self.ctx, self.ctx.lib.mdb_spann_set_filter, self.h, bitmaps)
 
@@ -673,6 +729,21 @@ class MultiSpannIndex:
                                                                   L.ptr(out.found, C.c_uint8)))
         return Pending(self.ctx, out, None)
 
+    def search_shard(self, user_ids, queries, params, planner=None):
+        """This rank's rows of search_for_user before the remap, as a POINTS block (mdb_multi_spann_search_shard)."""
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        blk = np.zeros(int(self.ctx.lib.mdb_points_block_bytes(C.c_size_t(b), C.c_size_t(params.top_k))), np.uint8)
+        p = params.to_c()
+        ap, nb, words, keep = _planner_args(planner)
+        self.ctx.check(self.ctx.lib.mdb_multi_spann_search_shard(self.h, L.u128_array(list(user_ids)), L.ptr(q, C.c_float), C.c_size_t(b),
+                                                                 C.byref(p), C.c_int(L.MEM_HOST), ap, nb, words, L.ptr(blk, C.c_uint8)))
+        return blk
+
+    def merge_shards(self, user_ids, blocks, b, k):
+        uids = L.u128_array(list(user_ids))
+        return _merge_shards(self.ctx, lambda *a: self.ctx.lib.mdb_multi_spann_merge_shards(self.h, uids, *a), blocks, b, k, True)
+
     def search_for_users(self, user_ids, query, params):
         """Snapshot::search_for_users (collection/snapshot.rs:39-66): one query fanned to several
         users, concatenated, sorted by (score, doc id), truncated to top_k."""
@@ -703,9 +774,12 @@ def _id_with_score_key(row):
 
 class PendingSegment:
     """PendingSegment::search_with_id while the merged index is not built yet (rs/index/src/segment/pending_segment.rs:285-335):
-    the inner segments are searched with an OVER-FETCH of top_k + len(invalidated ids of the user), the temporarily
-    invalidated documents are dropped from every inner result, the rows are concatenated, sorted (IdWithScore) and truncated
-    to top_k.  `inner_segments`: MultiSpannIndex handles (resident on the GPU); `temp_invalidated_ids`: user id -> doc ids."""
+    the inner segments are searched with an OVER-FETCH of top_k + len(invalidated ids of the user) and NO planner
+    (`search_with_id(s, id, query, &adjusted_params, None)`, :316-323), the temporarily invalidated documents are dropped from
+    every inner result and the rows are CONCATENATED — neither sorted nor truncated here: the caller
+    (Snapshot::search_for_user, collection/snapshot.rs:69-110) sorts and truncates.  The result is Some(..) even when no inner
+    segment knows the user (an empty list, :333).  `inner_segments`: MultiSpannIndex handles (resident on the GPU);
+    `temp_invalidated_ids`: user id -> doc ids."""
 
     def __init__(self, inner_segments, temp_invalidated_ids=None):
         self.inner_segments = list(inner_segments)
@@ -714,21 +788,17 @@ class PendingSegment:
     def invalidate(self, user_id, doc_id):
         self.temp_invalidated_ids.setdefault(user_id, set()).add(doc_id)
 
-    def search_with_id(self, user_id, query, params, planner=None):
+    def search_with_id(self, user_id, query, params):
         dead = self.temp_invalidated_ids.get(user_id) or set()
         adjusted = SearchParams(params.top_k + len(dead), params.ef_construction, params.record_pages)
         adjusted.num_explored_centroids = params.num_explored_centroids
         adjusted.centroid_distance_ratio = params.centroid_distance_ratio
-        rows, any_found = [], False
+        rows = []
         for seg in self.inner_segments:
-            res = seg.search_for_user([user_id], np.asarray(query, np.float32).reshape(1, -1), adjusted, planner=planner)
+            res = seg.search_for_user([user_id], np.asarray(query, np.float32).reshape(1, -1), adjusted)
             if res.found[0]:
-                any_found = True
                 rows += [r for r in res.id_with_scores(0) if r[0] not in dead]
-        if not any_found:
-            return None
-        rows.sort(key=_id_with_score_key)
-        return rows[:params.top_k]
+        return rows
 
 
 class Snapshot:
@@ -742,9 +812,8 @@ class Snapshot:
     def search_for_user(self, user_id, query, params, planner=None):
         rows = []
         for seg in self.segments:
-            if isinstance(seg, PendingSegment):
-                r = seg.search_with_id(user_id, query, params, planner=planner)
-                rows += r or []
+            if isinstance(seg, PendingSegment):   # BoxedImmutableSegment::PendingSegment passes no planner (segment/mod.rs)
+                rows += seg.search_with_id(user_id, query, params)
             else:
                 res = seg.search_for_user([user_id], np.asarray(query, np.float32).reshape(1, -1), params, planner=planner)
                 if res.found[0]:

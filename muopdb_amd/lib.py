@@ -34,6 +34,9 @@ EXPORTED_SYMBOLS = [
     "mdb_odht_user_table", "mdb_hnsw_select_neighbors", "mdb_wait", "mdb_poll", "mdb_ivf_search_filtered", "mdb_ivf_attach", "mdb_ivf_search_submit", "mdb_hnsw_ann_search_submit",
     "mdb_spann_search_filtered", "mdb_spann_attach", "mdb_spann_search_submit",
     "mdb_multi_spann_search_filtered", "mdb_multi_spann_attach", "mdb_multi_spann_search_submit",
+    "mdb_set_option", "mdb_get_option", "mdb_points_block_bytes", "mdb_points_block_views", "mdb_ivf_search_shard", "mdb_ivf_merge_shards",
+    "mdb_spann_search_shard", "mdb_spann_merge_shards", "mdb_multi_spann_search_shard", "mdb_multi_spann_merge_shards",
+    "mdb_allgather_blocks",
 ]
 
 
@@ -92,7 +95,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         _lib.mdb_last_error.restype = C.c_char_p
         _lib.mdb_version.restype = C.c_char_p
-        for n in ("mdb_shard_block_bytes", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_ivf_num_resident_vectors", "mdb_hnsw_num_vectors",
+        for n in ("mdb_shard_block_bytes", "mdb_points_block_bytes", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_ivf_num_resident_vectors", "mdb_hnsw_num_vectors",
                   "mdb_multi_spann_num_users"):
             if hasattr(_lib, n):
                 getattr(_lib, n).restype = C.c_size_t
@@ -146,6 +149,28 @@ class Context:
     def check(self, st):
         if st != MDB_OK:
             raise MuopdbError(st, (self.lib.mdb_last_error(self.h) or b"").decode())
+
+    def set_option(self, name, value):
+        """mdb_set_option: a tuning / test switch of THIS context (names: MDB_OPTIONS in csrc/mdb_common.h)."""
+        self.check(self.lib.mdb_set_option(self.h, name.encode(), C.c_longlong(int(value))))
+
+    def get_option(self, name):
+        v = C.c_longlong()
+        self.check(self.lib.mdb_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def option(self, name, value):
+        """with ctx.option("MDB_FLAT_NO_MFMA", 1): ...  — set for the block, restored afterwards."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.old = ctx.get_option(name)
+                ctx.set_option(name, value)
+
+            def __exit__(self_, *exc):
+                ctx.set_option(name, self_.old)
+        return _Scope()
 
     def set_stream(self, stream_ptr):
         self.check(self.lib.mdb_set_stream(self.h, C.c_void_p(stream_ptr)))

@@ -1452,18 +1452,25 @@ int orc_multi_spann_invalidate(void* p, uint64_t ulo, uint64_t uhi, uint64_t lo,
     if (!s) return 0;
     return orc_ivf_invalidate(&s->posting_lists, lo, hi);
 }
-// search_for_user for a batch of (user, query) pairs (sequential: the cache is not thread safe)
+// search_for_user for a batch of (user, query) pairs.  The per-user cache is not thread safe: every pair's Spann is
+// resolved first (sequentially: get_or_create, multi_spann/index.rs:100-131), then the searches run one query per thread
+// (threads > 1; the reference runs one query per tokio task).
 int orc_multi_spann_search(void* p, const uint64_t* user_lo, const uint64_t* user_hi, const float* queries, size_t b,
                            size_t top_k, uint32_t ef, int64_t num_explored, float ratio, uint64_t* ids_lo,
-                           uint64_t* ids_hi, float* scores, uint32_t* counts, uint8_t* found) {
+                           uint64_t* ids_hi, float* scores, uint32_t* counts, uint8_t* found, int threads) {
     MultiSpann* m = (MultiSpann*)p;
     SearchParams sp{top_k, ef, num_explored, ratio};
     int bad = 0;
-    for (size_t qi = 0; qi < b; ++qi) {
+    std::vector<Spann*> who(b);
+    for (size_t qi = 0; qi < b; ++qi) who[qi] = m->get_or_create(((u128)user_hi[qi] << 64) | user_lo[qi]);
+#if defined(_OPENMP)
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1)
+#endif
+    for (long qi = 0; qi < (long)b; ++qi) {
         std::vector<IdWithScore> r;
-        Spann* s = m->get_or_create(((u128)user_hi[qi] << 64) | user_lo[qi]);
+        Spann* s = who[qi];
         int rc = 0;
-        select_filter(qi);
+        select_filter((size_t)qi);
         if (s) rc = s->search(queries + qi * m->num_features, sp, r);
         if (rc < 0) { bad = 1; r.clear(); }
         found[qi] = rc == 1;

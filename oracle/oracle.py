@@ -458,7 +458,7 @@ class MultiSpannIndex:
             lib().orc_multi_spann_free(C.c_void_p(self.h))
             self.h = None
 
-    def search_for_user(self, user_ids, queries, params):
+    def search_for_user(self, user_ids, queries, params, threads=1):
         """Batch of (user_id, query) pairs -> _Res (found[qi]=0 means None)."""
         q = _f32(queries).reshape(-1, self.num_features)
         b = q.shape[0]
@@ -467,7 +467,7 @@ class MultiSpannIndex:
         res = _Res(b, params.top_k)
         rc = lib().orc_multi_spann_search(C.c_void_p(self.h), _p(ulo, C.c_uint64), _p(uhi, C.c_uint64),
                                           _p(q, C.c_float), C.c_size_t(b), *params.args(), *res.args(),
-                                          _p(res.found, C.c_uint8))
+                                          _p(res.found, C.c_uint8), C.c_int(threads))
         if rc:
             raise ValueError("multi-spann search error")
         return res

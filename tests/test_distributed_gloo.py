@@ -1,5 +1,6 @@
 """world_size-2 `gloo` tests (CPU) of the multi-GPU host path: list sharding,
-the per-batch all-gather of fixed-size top-k blocks and the (score, doc id) merge.  The per-shard
+the per-batch all-gather of fixed-size blocks, the EXACT merge of points blocks ((distance, point id), then remap) and the
+(score, doc id) merge of rows from different indexes.  The per-shard
 results come from the CPU oracle here (the GPU kernels are covered by the -m gpu suite, including
 `test_merge_shards_device` and the shard-union tests); what is under test is the collective plumbing
 and that the union of per-rank top-k equals the unsharded answer."""
@@ -124,6 +125,91 @@ def test_sharded_ivf_gather_merge_world2():
     out = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) == 1.0
+
+
+def merge_points_numpy(views, doc_table, k):
+    """Host restatement of mdb_ivf_merge_shards: the k smallest of the union by (distance, point id), THEN doc ids and the
+    IdWithScore order (search_with_centroids :250-286 across ranks, then search_with_centroids_and_remap :298-332 once)."""
+    b = views[0][1].shape[0]
+    out = []
+    for qi in range(b):
+        rows = []
+        for w, (pids, scores, counts, _found) in enumerate(views):
+            for j in range(int(counts[qi])):
+                rows.append((float(scores[qi, j]), int(pids[qi, j]) & 0xFFFFFFFF, w))
+        rows.sort()
+        rows = rows[:k]
+        out.append(sorted((s, doc_table[p]) for s, p, _ in rows))
+    return out
+
+
+def _exact_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from muopdb_amd import formats as F
+    rng = np.random.default_rng(11)
+    n, d, Lc, P = 1200, 16, 10, 5
+    v = rng.integers(0, 3, (n, d)).astype(np.float32)                  # low entropy + 2-bit PQ: a handful of distinct distances
+    c = H.kmeans(v + rng.normal(0, 0.01, v.shape).astype(np.float32), Lc, iters=3, seed=2)
+    cb = H.train_pq_codebook(v[:600], 4, 2, iters=3)
+    opq = oracle.ProductQuantizer(d, 4, 2, cb)
+    oq = oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 4, 2, cb)
+    doc_ids = [int(x) for x in rng.permutation(n) + 7000]              # NOT monotone in point ids (a reindexed segment)
+    q = (v[rng.integers(0, n, 16)] + rng.normal(0, 0.3, (16, d))).astype(np.float32)
+    index, vec, pls = H.build_ivf_files(v, doc_ids, c, quantize=opq.quantize)
+    full = oracle.BlockBasedIvf(index, vec, oq)
+    probes = full.find_nearest_centroids(q, P)
+    owner = D.balanced_owners([len(pl) for pl in pls], world)
+    mine = [pl if owner[l] == rank else np.zeros(0, np.uint64) for l, pl in enumerate(pls)]
+    # this rank's search_with_centroids rows: the oracle over its lists with doc id == point id, so (score, "doc") IS (distance, point id)
+    shard = oracle.BlockBasedIvf(F.write_ivf_index(c, list(range(n)), mine, quantized_dimension=4), vec, oq)
+    ok, stale = True, 0
+    for k in (1, 6):
+        r = shard.search(q, k, probes=probes)
+        g = D.PointsGather(None, len(q), k, "cpu")
+        pids, scores, counts, found = D.points_block_views(g.send, len(q), k)
+        pids.copy_(torch.from_numpy(r.lo[:, :k].astype(np.uint32).view(np.int32)))
+        scores.copy_(torch.from_numpy(r.scores[:, :k].copy()))
+        counts.copy_(torch.from_numpy(r.counts.astype(np.int32)))
+        found.fill_(1)
+        g.gather()                                                     # ONE all-gather of the points blocks
+        ok &= g.recv.numel() == world * D.points_block_bytes(len(q), k) and D.points_block_bytes(len(q), k) % 16 == 0
+        views = [tuple(t.numpy() for t in vw) for vw in g.recv_views()]
+        got = merge_points_numpy(views, doc_ids, k)
+        ref = full.search(q, k, probes=probes)
+        for qi in range(len(q)):
+            nq = int(ref.counts[qi])
+            ok &= [dd for _, dd in got[qi]] == ref.doc_ids(qi)
+            ok &= [np.float32(s_) for s_, _ in got[qi]] == [np.float32(x) for x in ref.scores[qi, :nq]]
+            # the old rule — per-rank remap, then (score, doc id) re-selection — picks other documents at rank-k ties
+            rows = []
+            for pv, sv, cv, _ in views:
+                rows += [(float(sv[qi, j]), doc_ids[int(pv[qi, j])]) for j in range(int(cv[qi]))]
+            rows.sort()
+            stale += [dd for _, dd in rows[:k]] != ref.doc_ids(qi)
+    ok &= stale > 0
+    t = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(float(t.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exact_sharded_merge_points_blocks_world2():
+    """permuted doc ids + duplicate PQ codes over two gloo ranks: all-gather of POINTS blocks + merge by (distance, point id),
+    then remap == the unsharded oracle row for row (and the old (score, doc id) merge is shown to differ on this case)"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exact_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -5,11 +5,13 @@ with simulated ranks on one GPU (test_gpu_parity / test_gpu_traversal / test_gpu
 
 What each rank checks, on its own GPU, against the UNSHARDED index it also loads:
   * sharded coarse search (mdb_ivf_coarse_keys -> all-gather -> mdb_ivf_merge_coarse_keys) == find_nearest_centroids;
-  * list-sharded IVF-PQ search written straight into the packed block -> ONE all-gather -> mdb_merge_shards_packed
-    == the unsharded rows (ids and score bits);
-  * the torch-free form of the same step: mdb_allgather_merge(ctx, ncclComm_t, ...) with a communicator created through
-    librccl's C API (what a Rust host would do, INTEGRATION.md §5) == the torch.distributed result;
-  * multi-user SPANN sharded l % world the same way."""
+  * list-sharded IVF-PQ search (PERMUTED doc ids, coarse PQ: score ties at rank k) written straight into this rank's POINTS
+    block -> ONE all-gather -> mdb_ivf_merge_shards (merge by (distance, point id), then remap) == the unsharded rows
+    (ids and score bits);
+  * the torch-free form of the same step: mdb_allgather_blocks(ctx, ncclComm_t, ...) with a communicator created through
+    librccl's C API (what a Rust host would do, INTEGRATION.md §5) + mdb_ivf_merge_shards == the torch.distributed result;
+    mdb_allgather_merge (the IdWithScore merge of remapped rows, flat shards / segments) on the same communicator;
+  * multi-user SPANN sharded l % world the same way (mdb_multi_spann_search_shard / _merge_shards)."""
 import ctypes as C
 import os
 import socket
@@ -59,7 +61,8 @@ def _worker(rank, world, port, out):
         cent = H.kmeans(v, nl, iters=3, seed=1)
         cb = H.train_pq_codebook(v[:2000], 8, 6, iters=3)
         opq = oracle.ProductQuantizer(d, 8, 6, cb)
-        index, vec, pls = H.build_ivf_files(v, [3 * i + 1 for i in range(n)], cent, quantize=opq.quantize)
+        doc_ids = [int(x) for x in np.random.default_rng(9).permutation(n) * 3 + 1]     # not monotone in point ids
+        index, vec, pls = H.build_ivf_files(v, doc_ids, cent, quantize=opq.quantize)
         pq = ProductQuantizer(d, 8, 6, cb)
         full = BlockBasedIvf(ctx, index, vec, pq)
         shard = BlockBasedIvf(ctx, index, vec, pq, shard_rank=rank, shard_world=world)
@@ -72,11 +75,11 @@ def _worker(rank, world, port, out):
         probes = D.sharded_probes(ctx, shard, q.data_ptr(), b, P, dev)
         ctx.sync()
         check(np.array_equal(probes.cpu().numpy().astype(np.uint32), full.find_nearest_centroids(qh, P)), "sharded probes")
-        g = D.PackedTopkGather(ctx, b, k, dev)
-        ctx.check(ctx.lib.mdb_ivf_search(shard.h, C.c_void_p(q.data_ptr()), C.c_size_t(b), C.c_void_p(probes.data_ptr()), C.c_size_t(P),
-                                         C.c_size_t(k), C.c_int(L.MEM_DEVICE), C.c_void_p(g.ids.data_ptr()),
-                                         C.c_void_p(g.scores.data_ptr()), C.c_void_p(g.counts.data_ptr())))
-        docs, scores, counts = g.gather_merge()
+        g = D.PointsGather(ctx, b, k, dev)
+        ctx.check(ctx.lib.mdb_ivf_search_shard(shard.h, C.c_void_p(q.data_ptr()), C.c_size_t(b), C.c_void_p(probes.data_ptr()), C.c_size_t(P),
+                                               C.c_size_t(k), C.c_int(L.MEM_DEVICE), None, C.c_size_t(0), C.c_size_t(0),
+                                               C.c_void_p(g.send.data_ptr())))
+        docs, scores, counts = g.gather_merge_ivf(shard)
         ctx.sync()
         hd, hs, hc = docs.cpu().numpy().view(np.uint64), scores.cpu().numpy(), counts.cpu().numpy()
         for i in range(b):
@@ -110,14 +113,28 @@ def _worker(rank, world, port, out):
             rccl.ncclCommInitRank.restype = C.c_int
             rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
             check(rc == 0, "ncclCommInitRank rc=%d %r" % (rc, rccl.ncclGetLastError(None)))
-            recv = torch.zeros(world * D.block_bytes(b, k), dtype=torch.uint8, device=dev)
+            recv = torch.zeros(world * D.points_block_bytes(b, k), dtype=torch.uint8, device=dev)
             o_docs, o_sc, o_cn = torch.zeros_like(docs), torch.zeros_like(scores), torch.zeros_like(counts)
             torch.cuda.synchronize()
-            ctx.check(ctx.lib.mdb_allgather_merge(ctx.h, comm, C.c_void_p(g.send.data_ptr()), C.c_void_p(recv.data_ptr()), C.c_size_t(world),
+            ctx.check(ctx.lib.mdb_allgather_blocks(ctx.h, comm, C.c_void_p(g.send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                                   C.c_size_t(D.points_block_bytes(b, k))))
+            ctx.check(ctx.lib.mdb_ivf_merge_shards(shard.h, C.c_void_p(recv.data_ptr()), C.c_size_t(world), C.c_size_t(b), C.c_size_t(k),
+                                                   C.c_void_p(o_docs.data_ptr()), C.c_void_p(o_sc.data_ptr()), C.c_void_p(o_cn.data_ptr())))
+            ctx.sync()
+            check(bool(torch.equal(o_docs, docs) and torch.equal(o_sc, scores) and torch.equal(o_cn, counts)), "mdb_allgather_blocks + merge != torch path")
+            # the doc-id form (rows of different indexes): every rank contributes the SAME full rows, the merge keeps them
+            pg = D.PackedTopkGather(ctx, b, k, dev)
+            pg.ids.copy_(docs); pg.scores.copy_(scores); pg.counts.copy_(counts)
+            recv2 = torch.zeros(world * D.block_bytes(b, k), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            ctx.check(ctx.lib.mdb_allgather_merge(ctx.h, comm, C.c_void_p(pg.send.data_ptr()), C.c_void_p(recv2.data_ptr()), C.c_size_t(world),
                                                   C.c_size_t(b), C.c_size_t(k), C.c_void_p(o_docs.data_ptr()), C.c_void_p(o_sc.data_ptr()),
                                                   C.c_void_p(o_cn.data_ptr())))
             ctx.sync()
-            check(bool(torch.equal(o_docs, docs) and torch.equal(o_sc, scores) and torch.equal(o_cn, counts)), "mdb_allgather_merge != torch path")
+            if world == 1:
+                check(bool(torch.equal(o_docs, docs) and torch.equal(o_sc, scores)), "mdb_allgather_merge of one rank")
+            else:   # duplicates of every row: the first k of the doubled, sorted rows
+                check(bool(torch.equal(o_sc[:, 0], scores[:, 0]) and torch.equal(o_docs[:, 0], docs[:, 0])), "mdb_allgather_merge head row")
             rccl.ncclCommDestroy(comm)
         # ---- multi-user SPANN, posting lists l % world
         users = {}
@@ -133,16 +150,17 @@ def _worker(rank, world, port, out):
         mq = np.stack([H.sift_like(24, 16, n_clusters=8, seed=30 + (i % 6))[i] for i in range(24)]).astype(np.float32)
         sp = SearchParams(5, 40).with_num_explored_centroids(6).with_centroid_distance_ratio(0.5)
         mwant = mfull.search_for_user(uq, mq, sp)
-        g2 = D.PackedTopkGather(ctx, 24, 5, dev)
+        g2 = D.PointsGather(ctx, 24, 5, dev)
         mqd = torch.from_numpy(mq).to(dev)
-        fo = torch.zeros(24, dtype=torch.uint8, device=dev)
         pc = sp.to_c()
+        uarr = L.u128_array(uq)
         torch.cuda.synchronize()
-        ctx.check(ctx.lib.mdb_multi_spann_search(mshard.h, L.u128_array(uq), C.c_void_p(mqd.data_ptr()), C.c_size_t(24), C.byref(pc),
-                                                 C.c_int(L.MEM_DEVICE), C.c_void_p(g2.ids.data_ptr()), C.c_void_p(g2.scores.data_ptr()),
-                                                 C.c_void_p(g2.counts.data_ptr()), C.c_void_p(fo.data_ptr())))
-        d2, s2, c2 = g2.gather_merge()
+        ctx.check(ctx.lib.mdb_multi_spann_search_shard(mshard.h, uarr, C.c_void_p(mqd.data_ptr()), C.c_size_t(24), C.byref(pc),
+                                                       C.c_int(L.MEM_DEVICE), None, C.c_size_t(0), C.c_size_t(0),
+                                                       C.c_void_p(g2.send.data_ptr())))
+        d2, s2, c2 = g2.gather_merge_multi(mshard, uarr)
         ctx.sync()
+        check(bool(g2.out_found.cpu().numpy().tolist() == mwant.found.tolist()), "multi-user found flags")
         h2 = d2.cpu().numpy().view(np.uint64)
         for i in range(24):
             c = int(mwant.counts[i])
@@ -178,7 +196,7 @@ def test_sharded_search_over_rccl_world2():
 
 def test_rccl_path_single_rank_dry_run():
     """The same worker with world_size 1 on ONE GPU: the nccl process group, a real ncclComm_t from librccl's C API and
-    mdb_allgather_merge's ncclAllGather all run (a one-rank all-gather is a copy) — everything but the second GPU."""
+    mdb_allgather_blocks' / mdb_allgather_merge's ncclAllGather all run (a one-rank all-gather is a copy) — everything but the second GPU."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()

@@ -297,15 +297,15 @@ def test_pending_segment_over_fetch_and_snapshot_merge(ctx, oracle, case):
     got = pend.search_with_id(7, q[0], p)
     op = oracle.SearchParams(5 + 2, 50, num_explored_centroids=6)
     ores = osegs[0].search_for_user([7], q[:1], op)
-    want = sorted([r for r in ores.id_with_scores(0) if r[0] not in dead[7]], key=lambda r: (r[1], r[0]))[:5]
+    want = [r for r in ores.id_with_scores(0) if r[0] not in dead[7]]   # concatenated, neither re-sorted nor truncated (:324-333)
     assert got == want and len(got) == 5 and all(r[0] not in dead[7] for r in got)
     assert got[:3] == [r for r in first if r[0] not in dead[7]][:3]     # the over-fetch refills the row instead of shortening it
-    assert PendingSegment(segs[:1]).search_with_id(12345, q[0], p) is None
+    assert PendingSegment(segs[:1]).search_with_id(12345, q[0], p) == []   # Some(empty): no inner segment knows the user (:333)
     snap = Snapshot([pend, segs[1]])
     rows = snap.search_for_user(7, q[1], p)
     o1 = osegs[0].search_for_user([7], q[1:2], oracle.SearchParams(7, 50, num_explored_centroids=6))
     o2 = osegs[1].search_for_user([7], q[1:2], oracle.SearchParams(5, 50, num_explored_centroids=6))
-    merged = sorted([r for r in o1.id_with_scores(0) if r[0] not in dead[7]][:5] + o2.id_with_scores(0), key=lambda r: (r[1], r[0]))[:5]
+    merged = sorted([r for r in o1.id_with_scores(0) if r[0] not in dead[7]] + o2.id_with_scores(0), key=lambda r: (r[1], r[0]))[:5]
     assert rows == merged
     many = snap.search_for_users([7, 8, 999], q[1], p)
     o3 = osegs[1].search_for_user([8], q[1:2], oracle.SearchParams(5, 50, num_explored_centroids=6))

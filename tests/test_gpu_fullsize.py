@@ -118,17 +118,13 @@ def test_c2_hnsw_1m_ef200(ctx, oracle, base, flat_1m, hnsw_1m):
     st = ctx.stats()
     assert rows_of(ores, 24) == whole[:24]
     assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)             # same traversal, step for step
-    import os
-    for variant in ("MDB_HNSW_PIPE", "MDB_HNSW_PREFETCH", "MDB_HNSW_NO_ROW64"):        # the pipelined kernel, the prefetch wave (opt-in); the beam kernel for rows of any length
-        os.environ[variant] = "1"
-        try:
+    for variant in ("MDB_HNSW_PREFETCH", "MDB_HNSW_NO_ROW64"):        # the prefetch wave (opt-in); the beam kernel for rows of any length
+        with ctx.option(variant, 1):
             pres = g.ann_search(q[:64], K, 200)
             assert rows_of(pres, 64) == whole
             g.ann_search(q[:24], K, 200)
             st = ctx.stats()
             assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)
-        finally:
-            del os.environ[variant]
     exact_ids, _, _ = flat_1m.search(q[:64], K)                                          # recall@10 against the exact scan
     hit = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(64))
     assert hit / (64 * K) >= 0.99
@@ -165,9 +161,20 @@ def test_c3_ivfpq_1m_nprobe16(ctx, oracle, base):
     assert rows_of(g.search(q[:96], K, P), 96) == whole                                   # idempotent
     for lo, hi in [(0, 1), (1, 40), (40, 96)]:                                            # batch-split invariance
         assert rows_of(g.search(q[lo:hi], K, P), hi - lo) == whole[lo:hi]
+    # the configuration's own batch: 256 queries in ONE call (its launch geometry: one block per CU), row for row the rows of
+    # the smaller calls, and the oracle's on a sample of them
+    q256 = np.concatenate([q, S.SiftLike(D, seed=1).draw(160, seed=4343).cpu().numpy().astype(np.float32)])
+    big = g.search(q256, K, P)
+    assert_sorted(big, 256)
+    rows256 = rows_of(big, 256)
+    assert rows256[:96] == whole
+    for lo, hi in [(96, 160), (160, 256)]:
+        assert rows_of(g.search(q256[lo:hi], K, P), hi - lo) == rows256[lo:hi]
     o = oracle.BlockBasedIvf(index, vec, oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, cb))
     assert np.array_equal(g.find_nearest_centroids(q[:16], P), o.find_nearest_centroids(q[:16], P))
     assert rows_of(o.search(q[:16], K, num_probes=P), 16) == whole[:16]                   # the oracle on the full index
+    pick = [100, 129, 200, 255]
+    assert rows_of(o.search(q256[pick], K, num_probes=P), 4) == [rows256[i] for i in pick]
     # more probes scan a superset of lists: the k-th symmetric-PQ score can only improve
     more = g.search(q[:32], K, 2 * P)
     for i in range(32):
@@ -223,10 +230,9 @@ def test_c4_shape_multi_user_spann_eighth(ctx, oracle):
     o = oracle.MultiSpannIndex(*args)
     op = oracle.SearchParams(K, 200, num_explored_centroids=P, centroid_distance_ratio=0.1)
     assert rows_of(o.search_for_user(uids[:24], q[:24], op), 24) == whole[:24]
-    shards = [MultiSpannIndex(ctx, *args, None, r, 2).search_for_user(uids, q, p) for r in range(2)]  # lists l % 2 == r
-    for i in range(U):
-        merged = sorted([(float(s), dd) for sh in shards for dd, s in sh.id_with_scores(i)])[:K]
-        assert [dd for _, dd in merged] == res.doc_ids(i)
+    shards = [MultiSpannIndex(ctx, *args, None, r, 2) for r in range(2)]                          # lists l % 2 == r
+    merged = shards[0].merge_shards(uids, [sh.search_shard(uids, q, p) for sh in shards], U, K)   # the exact merge of the points blocks
+    assert rows_of(merged, U) == whole
 
 
 def test_c4_full_size_multi_user_spann(ctx, oracle):
@@ -283,14 +289,15 @@ def test_c4_full_size_multi_user_spann(ctx, oracle):
     del o
     g.close()
     sub = list(range(0, U, 16))                                                                   # 64 users through 8 list shards
-    parts = []
+    blocks, sh = [], None
     for r in range(8):
+        if sh is not None:
+            sh.close()
         sh = MultiSpannIndex(ctx, *args, None, r, 8)
-        parts.append(sh.search_for_user([uids[i] for i in sub], q[sub], p))
-        sh.close()
-    for j, i in enumerate(sub):
-        merged = sorted([(float(s), dd) for sh in parts for dd, s in sh.id_with_scores(j)])[:K]
-        assert [dd for _, dd in merged] == res.doc_ids(i)
+        blocks.append(sh.search_shard([uids[i] for i in sub], q[sub], p))
+    merged = sh.merge_shards([uids[i] for i in sub], blocks, len(sub), K)                         # any rank merges: doc-id tables are replicated
+    sh.close()
+    assert rows_of(merged, len(sub)) == [whole[i] for i in sub]
 
 
 def test_c5_shard_ivfpq(ctx, oracle):

@@ -191,11 +191,8 @@ def test_flat_batched_mfma_filter_equals_exact(ctx, oracle, n, d, b, k, metric, 
     q = q.astype(np.float32)
     idx = FlatIndex(ctx, base, metric)
     ids, dist, counts = idx.search(q, k)
-    os.environ["MDB_FLAT_NO_MFMA"] = "1"
-    try:
+    with ctx.option("MDB_FLAT_NO_MFMA", 1):
         eids, edist, ecounts = idx.search(q, k)
-    finally:
-        del os.environ["MDB_FLAT_NO_MFMA"]
     assert np.array_equal(ids, eids) and np.array_equal(counts, ecounts)
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     oids, odist = oracle.flat_topk(metric, base, q[:8], k)
@@ -226,20 +223,14 @@ def test_flat_batched_path_nan_and_inf(ctx):
     binf = base.copy(); binf[1234, 3] = np.inf; binf[40000] = -np.inf
     idx = FlatIndex(ctx, binf)
     ids, dist, _ = idx.search(q, 10)
-    os.environ["MDB_FLAT_NO_MFMA"] = "1"
-    try:
+    with ctx.option("MDB_FLAT_NO_MFMA", 1):
         eids, edist, _ = idx.search(q, 10)
-    finally:
-        del os.environ["MDB_FLAT_NO_MFMA"]
     assert np.array_equal(ids, eids) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     qinf = q.copy(); qinf[3, 5] = np.inf   # an infinite query: every distance is inf, the top-k is the first k rows
     idx2 = FlatIndex(ctx, base)
     ids, dist, _ = idx2.search(qinf, 10)
-    os.environ["MDB_FLAT_NO_MFMA"] = "1"
-    try:
+    with ctx.option("MDB_FLAT_NO_MFMA", 1):
         eids, edist, _ = idx2.search(qinf, 10)
-    finally:
-        del os.environ["MDB_FLAT_NO_MFMA"]
     assert np.array_equal(ids, eids) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     assert ids[3].tolist() == list(range(10))
     bnan = base.copy(); bnan[65000, 7] = np.nan
@@ -396,11 +387,8 @@ def test_ivf_pq_bound_filter_adversarial(ctx, oracle, case):
         gres = g.search_with_centroids_and_remap(q, probes, kk)
         st = ctx.stats()
         assert_result_rows(gres, ores, len(q))
-        os.environ["MDB_PQ_NO_FILTER"] = "1"
-        try:
+        with ctx.option("MDB_PQ_NO_FILTER", 1):
             gres2 = g.search_with_centroids_and_remap(q, probes, kk)
-        finally:
-            del os.environ["MDB_PQ_NO_FILTER"]
         st2 = ctx.stats()
         assert_result_rows(gres2, ores, len(q))
         assert st["scored_vectors"] == st2["scored_vectors"] == n * len(q)
@@ -411,21 +399,14 @@ def test_ivf_pq_bound_filter_adversarial(ctx, oracle, case):
             qb = np.concatenate([q, v[rng.integers(0, n, 560 - len(q))].astype(np.float32)])     # 560 queries: the path's own batch range
             pb = np.tile(np.arange(L, dtype=np.uint32), (len(qb), 1))
             oresb = o.search(qb, kk, probes=pb)
-            for cap in (None, "8"):
-                if cap:
-                    os.environ["MDB_PQ3_CAP"] = cap
-                try:
+            for cap in (2048, 8):
+                with ctx.option("MDB_PQ3_CAP", cap):
                     gres3 = g.search_with_centroids_and_remap(qb, pb, kk)
-                finally:
-                    os.environ.pop("MDB_PQ3_CAP", None)
                 st3 = ctx.stats()
                 assert_result_rows(gres3, oresb, len(qb))
                 assert st3["scored_vectors"] == n * len(qb), (cap, st3["scored_vectors"])
-            os.environ["MDB_PQ_NO_TWO_PHASE"] = "1"                                                 # and the one-phase kernel on the same batch
-            try:
+            with ctx.option("MDB_PQ_NO_TWO_PHASE", 1):                                                 # and the one-phase kernel on the same batch
                 assert_result_rows(g.search_with_centroids_and_remap(qb, pb, kk), oresb, len(qb))
-            finally:
-                del os.environ["MDB_PQ_NO_TWO_PHASE"]
 
 
 def test_ivf_large_coarse_quantizer_batched_path(ctx, oracle):
@@ -452,13 +433,31 @@ def test_ivf_large_coarse_quantizer_batched_path(ctx, oracle):
     want = o.find_nearest_centroids(q, P)
     assert np.array_equal(g.find_nearest_centroids(q, P), want)          # batched path (70 queries)
     assert np.array_equal(g.find_nearest_centroids(q[:5], P), want[:5])  # exact kernels (batch < 8)
-    os.environ["MDB_FLAT_NO_MFMA"] = "1"
-    try:
+    with ctx.option("MDB_FLAT_NO_MFMA", 1):
         assert np.array_equal(g.find_nearest_centroids(q, P), want)
-    finally:
-        del os.environ["MDB_FLAT_NO_MFMA"]
     assert_result_rows(g.search(q, 10, P), o.search(q, 10, num_probes=P), len(q))
     assert_result_rows(g.search(q[:9], 3, 1), o.search(q[:9], 3, num_probes=1), 9)
+    # a per-call planner filter WITH the library's own (batched, matrix-core) coarse search: the staged host bitmaps must
+    # survive the coarse search's scratch use (they once shared a slot).  Expected rows: the oracle under the same filter,
+    # and the unfiltered rows with the dropped points removed wherever k of them remain.
+    from muopdb_amd.index import allow_bitmap
+    nv = L + extra
+    keep = np.sort(rng.choice(nv, nv // 2, replace=False))
+    shared = allow_bitmap(keep, nv)
+    per_q = np.stack([allow_bitmap(np.sort(rng.choice(nv, nv // 3, replace=False)), nv) for _ in range(len(q))])
+    for bm in (shared, per_q):
+        with oracle.planner_filter(bm):
+            want_f = o.search(q, 10, num_probes=P)
+        assert_result_rows(g.search(q, 10, P, planner=bm), want_f, len(q))               # host bitmaps, internal coarse search
+        pend = g.search_submit(q, 10, P, planner=bm)                                      # and through submit / wait
+        assert_result_rows(pend.wait(), want_f, len(q))
+    kept = set(int(3 * i + 1) for i in keep)
+    wide = g.search(q, 40, P)
+    filt = g.search(q, 10, P, planner=shared)
+    for qi in range(len(q)):
+        expect = [dd for dd in wide.doc_ids(qi) if dd in kept][:10]
+        if len(expect) == 10:
+            assert filt.doc_ids(qi) == expect
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])

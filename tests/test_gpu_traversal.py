@@ -132,11 +132,8 @@ def test_hnsw_small_graph_closure_kernel(ctx, oracle, n, d, M, layers, metric, s
         st = ctx.stats()
         assert_result_rows(gres, ores, len(q))
         assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)
-        os.environ["MDB_HNSW_NO_CLOSURE"] = "1"
-        try:
+        with ctx.option("MDB_HNSW_NO_CLOSURE", 1):
             sres = g.ann_search(q, k, ef)
-        finally:
-            del os.environ["MDB_HNSW_NO_CLOSURE"]
         st2 = ctx.stats()
         assert_result_rows(sres, ores, len(q))
         assert (st2["distance_evals"], st2["expanded_nodes"]) == (evals, expanded)
@@ -155,23 +152,18 @@ def test_hnsw_general_kernel_equals_beam_kernel(ctx, oracle):
     g = BlockBasedHnsw(ctx, hidx, hvec, 48)
     o = oracle.BlockBasedHnsw(hidx, hvec, 48)
     q = (v[rng.integers(0, 2500, 25)] + rng.normal(0, 4, (25, 48))).astype(np.float32)
-    os.environ["MDB_HNSW_NO_BEAM"] = "1"
-    try:
+    with ctx.option("MDB_HNSW_NO_BEAM", 1):
         for k, ef in [(10, 100), (5, 8), (20, 256), (10, 600)]:
             assert_result_rows(g.ann_search(q, k, ef), o.ann_search(q, k, ef), len(q))
-    finally:
-        del os.environ["MDB_HNSW_NO_BEAM"]
     assert_result_rows(g.ann_search(q, 10, 600), o.ann_search(q, 10, 600), len(q))
 
 
-@pytest.mark.parametrize("variant", ["MDB_HNSW_PIPE", "MDB_HNSW_PREFETCH", "MDB_HNSW_NO_ROW64"])
+@pytest.mark.parametrize("variant", ["MDB_HNSW_PREFETCH", "MDB_HNSW_NO_ROW64", "MDB_HNSW_GENERIC_DIST"])
 @pytest.mark.parametrize("d,metric", [(128, 0), (768, 1), (128, 1)])
-def test_hnsw_pipelined_kernel_equals_oracle(ctx, oracle, d, metric, variant):
-    """hnsw_pipe_kernel (MDB_HNSW_PIPE=1: the traversal software-pipelined over six waves) and hnsw_beam_kernel's SPEC variant
-    (MDB_HNSW_SPEC=1: wave 1 runs the runner-up's visited test-and-set during wave 0's accept phase) both update the visited set
-    tentatively and undo a wrong guess: they must give the oracle's rows AND counters — no speculative evaluation may be
-    counted, no tentative visited bit may survive."""
-    import os
+def test_hnsw_beam_kernel_variants_equal_oracle(ctx, oracle, d, metric, variant):
+    """hnsw_beam_kernel's variants — the prefetch wave (touches the runner-up's neighbours ahead of the step that needs them),
+    rows of any length (NO_ROW64) and the generic distance cascade — must give the oracle's rows AND counters: no speculative
+    touch may be counted."""
     from muopdb_amd.index import BlockBasedHnsw, NoQuantizer
     rng = np.random.default_rng(31)
     n = 3000
@@ -182,8 +174,7 @@ def test_hnsw_pipelined_kernel_equals_oracle(ctx, oracle, d, metric, variant):
     g = BlockBasedHnsw(ctx, hidx, hvec, d, NoQuantizer(d, metric))
     o = oracle.BlockBasedHnsw(hidx, hvec, d, oracle.Quant(oracle.QUANT_NONE, metric))
     q = (v[rng.integers(0, n, 40)] + rng.normal(0, 0.05 if metric == 1 else 4, (40, d))).astype(np.float32)
-    os.environ[variant] = "1"
-    try:
+    with ctx.option(variant, 1):
         for k, ef in [(10, 100), (5, 8), (20, 256), (10, 1), (10, 40)]:
             want = o.ann_search(q, k, ef)
             evals, expanded = o.stats()
@@ -191,8 +182,6 @@ def test_hnsw_pipelined_kernel_equals_oracle(ctx, oracle, d, metric, variant):
             st = ctx.stats()
             assert_result_rows(got, want, len(q))
             assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded), (k, ef)
-    finally:
-        del os.environ[variant]
 
 
 def test_hnsw_beam_overflow_falls_back_to_general_kernel(ctx, oracle):
@@ -427,15 +416,105 @@ def test_multi_user_many_users_and_shards(ctx, oracle):
         oracle.SearchParams(10, 50, num_explored_centroids=5, centroid_distance_ratio=1.0)
     full, ofull = g.search_for_user(allu, allq, p), o.search_for_user(allu, allq, op)
     assert_result_rows(full, ofull, len(allq))
-    # posting-list sharding: merging the per-shard top-k by (score, doc id) == unsharded answer
+    # posting-list sharding: the exact merge of the per-shard points blocks == unsharded answer
     shards = [_multi(ctx, oracle, users, nf=24, shard_rank=r, shard_world=3)[0] for r in range(3)]
-    parts = [s.search_for_user(allu, allq, p) for s in shards]
-    for qi in range(len(allq)):
-        rows = []
-        for pr in parts:
-            rows += pr.id_with_scores(qi)
-        rows.sort(key=lambda r: (r[1], r[0]))
-        assert [r[0] for r in rows[:10]] == full.doc_ids(qi)
+    merged = shards[1].merge_shards(allu, [s.search_shard(allu, allq, p) for s in shards], len(allq), 10)
+    assert_result_rows(merged, ofull, len(allq))
+
+
+def _old_style_rows(parts, qi, k):
+    """the inexact merge this suite used to accept: already remapped per-shard rows re-selected by (score, doc id)"""
+    rows = []
+    for pr in parts:
+        rows += pr.id_with_scores(qi)
+    rows.sort(key=lambda r: (r[1], r[0]))
+    return [r[0] for r in rows[:k]]
+
+
+@pytest.mark.parametrize("cpv", [1, 2])
+@pytest.mark.parametrize("world", [8, 3])
+def test_sharded_merge_is_exact_under_ties_ivfpq(ctx, oracle, world, cpv):
+    """The reference selects its top-k by (distance, POINT id) over all probed lists and only then remaps and sorts by
+    (score, doc id) (ivf/block_based/index.rs:250-286, then :298-332).  With PQ codes exact score ties are the norm, and a
+    reindexed segment's doc ids are not monotone in point ids: the sharded result must still be the unsharded one row for
+    row.  Low-entropy vectors + a 2-bit codebook (a handful of distinct distances), PERMUTED doc ids, posting lists dealt
+    over `world` simulated ranks; cpv = 2 also puts one point into lists of different ranks (the reference keeps both)."""
+    from muopdb_amd.index import BlockBasedIvf, ProductQuantizer
+    rng = np.random.default_rng(100 + world + cpv)
+    n, d, L, P = 4000, 16, 24, 9
+    v = rng.integers(0, 3, (n, d)).astype(np.float32)
+    cent = H.kmeans(v + rng.normal(0, 0.01, v.shape).astype(np.float32), L, iters=3, seed=5)
+    cb = H.train_pq_codebook(v[:1500], 4, 2, iters=3)
+    doc_ids = [int(x) for x in rng.permutation(n) + 50_000]           # not monotone in point ids
+    doc_ids[7] += 1 << 90                                              # and a 128-bit one
+    opq = oracle.ProductQuantizer(d, 4, 2, cb)
+    index, vec, _ = H.build_ivf_files(v, doc_ids, cent, quantize=opq.quantize, clusters_per_vector=cpv)
+    gq = ProductQuantizer(d, 4, 2, cb)
+    o = oracle.BlockBasedIvf(index, vec, oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 4, 2, cb))
+    g = BlockBasedIvf(ctx, index, vec, gq)
+    shards = [BlockBasedIvf(ctx, index, vec, gq, shard_rank=r, shard_world=world) for r in range(world)]
+    q = (v[rng.integers(0, n, 40)] + rng.normal(0, 0.3, (40, d))).astype(np.float32)
+    probes = g.find_nearest_centroids(q, P)
+    stale = 0
+    for k in (1, 10, 17):
+        want = o.search(q, k, probes=probes)
+        full = g.search_with_centroids_and_remap(q, probes, k)
+        assert_result_rows(full, want, len(q))
+        blocks = [s.search_shard(q, k, probes=probes) for s in shards]
+        merged = shards[world - 1].merge_shards(blocks, len(q), k)     # any rank: the doc-id table is replicated
+        assert_result_rows(merged, want, len(q))
+        assert H.result_rows(merged, len(q)) == H.result_rows(full, len(q))
+        parts = [s.search_with_centroids_and_remap(q, probes, k) for s in shards]
+        stale += sum(_old_style_rows(parts, qi, k) != full.doc_ids(qi) for qi in range(len(q)))
+    assert stale > 0, "the case must contain rank-k ties that a (score, doc id) merge resolves differently"
+    # a per-call planner filter is applied by every rank alike
+    from muopdb_amd.index import allow_bitmap
+    bm = allow_bitmap(rng.choice(n, n // 2, replace=False), n)
+    fblocks = [s.search_shard(q, 10, probes=probes, planner=bm) for s in shards]
+    assert H.result_rows(shards[0].merge_shards(fblocks, len(q), 10), len(q)) == \
+        H.result_rows(g.search_with_centroids_and_remap(q, probes, 10, planner=bm), len(q))
+
+
+def test_sharded_merge_is_exact_under_ties_multi_user_spann(ctx, oracle):
+    """The same for MultiSpannIndex::search_for_user with PQ posting lists: lists l % 8 per user, permuted doc ids, mixed
+    users (one unknown) in one batch — merged == unsharded == oracle, and `found` survives the merge."""
+    from muopdb_amd.index import MultiSpannIndex, ProductQuantizer, SearchParams
+    rng = np.random.default_rng(77)
+    d, world = 16, 8
+    cb = H.train_pq_codebook(rng.integers(0, 3, (1500, d)).astype(np.float32), 4, 2, iters=3)
+    opq = oracle.ProductQuantizer(d, 4, 2, cb)
+    users, allq, allu = {}, [], []
+    for ui in range(3):
+        n = 900 + 200 * ui
+        v = rng.integers(0, 3, (n, d)).astype(np.float32)
+        docs = [int(x) for x in rng.permutation(n) + 10_000 * (ui + 1)]
+        f, _, _ = H.build_spann_files(oracle, v, docs, 10 + ui, quantize=opq.quantize, seed=ui, max_neighbors=6, max_layers=2,
+                                      ef_construction=30)
+        uid = (ui << 66) | (ui + 1)
+        users[uid] = f
+        for _ in range(10):
+            allq.append(v[rng.integers(0, n)] + rng.normal(0, 0.3, d))
+            allu.append(uid)
+    allq.append(allq[0]); allu.append(424242)                          # an unknown user: None
+    allq = np.asarray(allq, np.float32)
+    cat = F.concat_multi_spann(users)
+    a = (cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+    gq, oq = ProductQuantizer(d, 4, 2, cb), oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 4, 2, cb)
+    g, o = MultiSpannIndex(ctx, *a, gq), oracle.MultiSpannIndex(*a, oq)
+    shards = [MultiSpannIndex(ctx, *a, gq, shard_rank=r, shard_world=world) for r in range(world)]
+    stale = 0
+    for k in (1, 10):
+        p = SearchParams(k, 40).with_num_explored_centroids(6).with_centroid_distance_ratio(2.0)
+        op = oracle.SearchParams(k, 40, num_explored_centroids=6, centroid_distance_ratio=2.0)
+        want, full = o.search_for_user(allu, allq, op), g.search_for_user(allu, allq, p)
+        assert_result_rows(full, want, len(allq))
+        blocks = [s.search_shard(allu, allq, p) for s in shards]
+        merged = shards[3].merge_shards(allu, blocks, len(allq), k)
+        assert_result_rows(merged, want, len(allq))
+        assert merged.found.tolist() == full.found.tolist() and merged.found[-1] == 0
+        parts = [s.search_for_user(allu, allq, p) for s in shards]
+        stale += sum(_old_style_rows(parts, qi, k) != full.doc_ids(qi) for qi in range(len(allq)))
+    assert stale > 0
 
 
 def test_merge_shards_device(ctx):

@@ -77,6 +77,17 @@ def test_odht_probing_wrap_and_round_trip_and_native_reader():
         users = (L.UserIndexInfoC * len(ids))()
         assert lib.mdb_odht_user_table(L.ptr(buf, C.c_uint8), C.c_size_t(buf.size), users, C.c_size_t(len(ids)), C.byref(cnt)) == 0
         assert C.string_at(users, len(ids) * 112) == recs
+        # empty control bytes are recognised by bit 7 (odht's group query = movemask of the control bytes): the same table with
+        # its empties written as 0x80 instead of 0xFF reads identically through both readers
+        alt = bytearray(t)
+        for i in range(32 + slots * 128, len(alt)):
+            if alt[i] == 0xFF:
+                alt[i] = 0x80
+        alt = bytes(alt)
+        assert F.user_table_from_odht(alt) == recs and F.odht_get(alt, ids[0].to_bytes(16, "little")) == recs[:112]
+        buf2 = np.frombuffer(alt, np.uint8)
+        assert lib.mdb_odht_user_table(L.ptr(buf2, C.c_uint8), C.c_size_t(buf2.size), users, C.c_size_t(len(ids)), C.byref(cnt)) == 0
+        assert C.string_at(users, len(ids) * 112) == recs
     # a full group forces the triangular probe: 17 keys whose hashes share the low 4 bits land in two groups
     same = []
     x = 0
