@@ -45,6 +45,8 @@
     X(hnsw_prefetch, "MDB_HNSW_PREFETCH", 0)                                                                        \
     X(hnsw_dbg, "MDB_HNSW_DBG", 0)                                                                                  \
     X(ivf_coarse_sample_div, "MDB_IVF_COARSE_SAMPLE_DIV", 8) /* L */                                                \
+    X(pq_no_fused, "MDB_PQ_NO_FUSED", 0)               /* small batches: the six-launch step instead of ivf_pq_fused_kernel */ \
+    X(pqf_cap, "MDB_PQF_CAP", 2048)                    /* fused step: candidate slots (tests force the overflow pass) */      \
     X(pq_no_fast, "MDB_PQ_NO_FAST", 0)                                                                              \
     X(pq_no_filter, "MDB_PQ_NO_FILTER", 0)                                                                          \
     X(pq_no_full, "MDB_PQ_NO_FULL", 0)                                                                              \
@@ -71,7 +73,11 @@ struct mdb_ctx {
     mdb_stats stats{};
     uint32_t* d_flags = nullptr;   // device word: bit0 NaN seen, bit1 capacity overflow
     uint32_t* h_flags = nullptr;   // pinned host mirror
-    unsigned long long* d_counters = nullptr;  // [0] HNSW distance evals [1] expanded nodes [2] scored vectors [3] spare
+    unsigned long long* d_counters = nullptr;  // 32 words; [0] HNSW distance evals [1] expanded nodes [2] scored vectors [3] spare (words 4..15: debug
+                                               // builds); words 16..19 / 20..23: the fused IVF-PQ step alternates between them — each call's kernel clears the
+                                               // OTHER set for the next call, so the step needs no memset launch
+    int counter_base = 0;          // word offset of the last call's [0..3] (mdb_get_stats)
+    int fused_parity = 0;
     unsigned long long* h_counters = nullptr;
     bool dev_counters = true;      // false: the last call used no device counters (flat scans): mdb_get_stats reports zeros, no memset launch
     uint64_t stat_bytes_per_eval = 0, stat_bytes_per_scored = 0, stat_fixed_bytes = 0;

@@ -175,8 +175,8 @@ mdb_status mdb_device_open(int gpu, mdb_ctx** out) {
     ctx->device = gpu;
     if (hipSetDevice(gpu) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_flags, 4) != hipSuccess || hipHostMalloc((void**)&ctx->h_flags, 4) != hipSuccess ||
-        hipMemset(ctx->d_flags, 0, 4) != hipSuccess || hipMalloc((void**)&ctx->d_counters, 128) != hipSuccess ||
-        hipHostMalloc((void**)&ctx->h_counters, 128) != hipSuccess || hipMemset(ctx->d_counters, 0, 128) != hipSuccess) {
+        hipMemset(ctx->d_flags, 0, 4) != hipSuccess || hipMalloc((void**)&ctx->d_counters, 256) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_counters, 256) != hipSuccess || hipMemset(ctx->d_counters, 0, 256) != hipSuccess) {
         delete ctx;
         return MDB_ERR_HIP;
     }
@@ -259,18 +259,19 @@ const char* mdb_last_error(mdb_ctx* ctx) { return ctx ? ctx->last_error.c_str() 
 mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out) {
     if (!ctx || !out) return MDB_ERR_INVALID_ARG;
     MDB_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->dev_counters) MDB_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 128, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->dev_counters) MDB_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 256, hipMemcpyDeviceToHost, ctx->stream));
     MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->dev_counters && ctx->opt.hnsw_dbg) {  // debug words [4..15] of an MDB_PIPE_DBG build (cycles / counts of the pipelined traversal)
         fprintf(stderr, "[hnsw dbg]");
         for (int i = 3; i < 16; ++i) fprintf(stderr, " %llu", ctx->h_counters[i]);
         fprintf(stderr, "\n");
     }
+    const unsigned long long* hc = ctx->h_counters + ctx->counter_base;   // the last call's counter words
     if (!ctx->dev_counters) ctx->h_counters[0] = ctx->h_counters[1] = ctx->h_counters[2] = ctx->h_counters[3] = 0;
     mdb_stats st = ctx->stats;
-    st.distance_evals = ctx->h_counters[0];
-    st.expanded_nodes = ctx->h_counters[1];
-    if (ctx->h_counters[2]) st.scored_vectors = ctx->h_counters[2];
+    st.distance_evals = hc[0];
+    st.expanded_nodes = hc[1];
+    if (hc[2]) st.scored_vectors = hc[2];
     st.algorithmic_bytes = ctx->stat_fixed_bytes + st.distance_evals * ctx->stat_bytes_per_eval +
                            st.expanded_nodes * 16 + st.scored_vectors * ctx->stat_bytes_per_scored;
     *out = st;
@@ -398,9 +399,7 @@ mdb_status pq_upload(mdb_ctx* ctx, const mdb_quant_desc* q, PqDev& pq) {
     return MDB_OK;
 }
 
-// ProductQuantizer::quantize pq/mod.rs:152-177: one WAVE per (vector, subspace); lane l scores centroids
-// l, l+64, ... with the EXACT squared-L2 cascade; "first minimum wins (strict <), start f32::MAX" is the
-// minimum of (distance, centroid index) keys; a NaN distance never wins (`NaN < best` is false).
+// ProductQuantizer::quantize pq/mod.rs:152-177: one WAVE per (vector, subspace) — pq_quantize_wave (mdb_device.hip.h)
 __global__ __launch_bounds__(256) void pq_quantize_kernel(const float* __restrict__ vecs, size_t n, int row_stride, int subdim,
                                                           int m, int K, const float* __restrict__ cb, DistPlan sp,
                                                           uint8_t* __restrict__ codes) {
@@ -410,27 +409,8 @@ __global__ __launch_bounds__(256) void pq_quantize_kernel(const float* __restric
     size_t v = t / m;
     int s = (int)(t % m);
     const float* sub = vecs + v * (size_t)row_stride + (size_t)s * subdim;  // wave-uniform: scalar loads
-    const float* cbs = cb + (size_t)s * K * subdim;
-    uint64_t best = ~0ull;  // no centroid strictly below f32::MAX yet (=> code 0)
-    const bool rows16 = (subdim & 3) == 0;  // codebook rows are then whole, 16-byte aligned float4s (the arena is)
-    for (int c = lane; c < K; c += 64) {
-        float raw[1];
-        if (rows16) {
-            Row4Loader lc{(const float4*)(cbs + (size_t)c * subdim)};
-            exact_sums<MDB_METRIC_L2, 1>(lc, sub, 0, sp, raw);
-        } else {
-            RowLoader lc{cbs + (size_t)c * subdim, subdim};
-            exact_sums<MDB_METRIC_L2, 1>(lc, sub, 0, sp, raw);
-        }
-        if (raw[0] < 3.402823466e+38f) {  // also false for NaN
-            uint64_t key = ((uint64_t)f32_orderable(raw[0]) << 32) | (uint32_t)c;
-            best = key < best ? key : best;
-        }
-    }
-    // minimum of the (distance image, centroid) keys over the wave: smallest image first, then the smallest index among its holders
-    const uint32_t mo = mdb_wave_min_u32((uint32_t)(best >> 32));
-    const uint32_t mi = mdb_wave_min_u32((uint32_t)(best >> 32) == mo ? (uint32_t)best : 0xFFFFFFFFu);
-    if (lane == 0) codes[t] = mo == 0xFFFFFFFFu ? (uint8_t)0 : (uint8_t)mi;
+    const uint32_t code = pq_quantize_wave(sub, cb + (size_t)s * K * subdim, K, subdim, sp, lane);
+    if (lane == 0) codes[t] = (uint8_t)code;
 }
 
 mdb_status pq_quantize_device(mdb_ctx* ctx, const PqDev& pq, const float* d_vecs, size_t n, uint8_t* d_codes, int row_stride) {

@@ -390,6 +390,34 @@ struct BlockSelect {
     __device__ __forceinline__ uint32_t count() const { return total; }
 };
 
+// ------------------------------------------------------------------------------------------ PQ quantize, one wave per subspace
+// ProductQuantizer::quantize pq/mod.rs:152-177 for ONE (vector, subspace): lane l scores centroids l, l+64, ... with the EXACT
+// squared-L2 cascade; "first minimum wins (strict <), start f32::MAX" is the minimum of (distance, centroid index) keys; a NaN
+// distance never wins (`NaN < best` is false).  `sub` (the query's subvector) must be wave-uniform; all 64 lanes call.
+__device__ __forceinline__ uint32_t pq_quantize_wave(const float* __restrict__ sub, const float* __restrict__ cbs, int K, int subdim,
+                                                     const DistPlan& sp, int lane) {
+    uint64_t best = ~0ull;  // no centroid strictly below f32::MAX yet (=> code 0)
+    const bool rows16 = (subdim & 3) == 0;  // codebook rows are then whole, 16-byte aligned float4s (the arena is)
+    for (int c = lane; c < K; c += 64) {
+        float raw[1];
+        if (rows16) {
+            Row4Loader lc{(const float4*)(cbs + (size_t)c * subdim)};
+            exact_sums<MDB_METRIC_L2, 1>(lc, sub, 0, sp, raw);
+        } else {
+            RowLoader lc{cbs + (size_t)c * subdim, subdim};
+            exact_sums<MDB_METRIC_L2, 1>(lc, sub, 0, sp, raw);
+        }
+        if (raw[0] < 3.402823466e+38f) {  // also false for NaN
+            uint64_t key = ((uint64_t)f32_orderable(raw[0]) << 32) | (uint32_t)c;
+            best = key < best ? key : best;
+        }
+    }
+    // minimum of the (distance image, centroid) keys over the wave: smallest image first, then the smallest index among its holders
+    const uint32_t mo = mdb_wave_min_u32((uint32_t)(best >> 32));
+    const uint32_t mi = mdb_wave_min_u32((uint32_t)(best >> 32) == mo ? (uint32_t)best : 0xFFFFFFFFu);
+    return mo == 0xFFFFFFFFu ? 0u : mi;
+}
+
 // ------------------------------------------------------------------------------------------ PQ (symmetric) distance
 // ProductQuantizer::distance, StreamingSIMD arm — rs/quantization/src/pq/mod.rs:231-266.
 // The accumulators sum_16/sum_8/sum_4 are SHARED across subspaces (per-lane sums over s), the

@@ -377,6 +377,7 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     }
     // one pass = N*d*4 B read once per batch + queries + outputs
     ctx->stats = mdb_stats{};
+    ctx->counter_base = 0;
     ctx->stats.scored_vectors = (uint64_t)b * flat->ts.n;
     ctx->dev_counters = false;  // flat scans count on the host (scored = n x b): no counter memset launch on this path
     ctx->stat_bytes_per_eval = 0; ctx->stat_bytes_per_scored = 0;

@@ -1763,6 +1763,7 @@ static mdb_status hnsw_ann_search_impl(mdb_hnsw* h, const float* queries, size_t
     MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, ctx->stream));
     ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
+    ctx->counter_base = 0;
     // d*4 B vector + 4 B edge id per distance evaluation, 16 B offsets per expanded node
     ctx->stat_bytes_per_eval = (s.kind == MDB_QUANT_PQ ? (uint64_t)s.pq.m : (uint64_t)s.dimension * 4) + 4;
     ctx->stat_bytes_per_scored = 0; ctx->stat_fixed_bytes = 0;

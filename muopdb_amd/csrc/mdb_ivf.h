@@ -92,6 +92,12 @@ struct IvfSet {
                     const ScanFilter* filter = nullptr);
     mdb_status remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,
                      mdb_u128* d_doc, float* d_score, uint32_t* d_counts_out);
+    // small batches of one L2 PQ index: the whole search in ONE launch (ivf_pq_fused_kernel).  d_probes == nullptr: the coarse
+    // search runs in the kernel; d_doc != nullptr: remapped rows (else keys + counts)
+    bool fused_ok(size_t b, size_t k, size_t num_probes, bool have_probes) const;
+    mdb_status search_fused(const float* d_q, int qstride, size_t b, const uint32_t* d_probes, size_t num_probes, size_t k,
+                            const ScanFilter* filter, uint64_t* d_keys, uint32_t* d_counts, mdb_u128* d_doc, float* d_score,
+                            uint32_t* d_doc_counts);
     // exact list-sharded search: keys -> one rank's points block; `world` blocks -> merged rows
     mdb_status pack_points(const uint64_t* d_keys, const uint32_t* d_counts, const uint8_t* d_found, size_t b, size_t k, void* d_block);
     mdb_status merge_points(const void* d_blocks, size_t world, size_t b, size_t k, const uint32_t* d_q_user, mdb_u128* d_doc,

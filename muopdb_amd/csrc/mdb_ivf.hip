@@ -962,6 +962,358 @@ __global__ __launch_bounds__(256) void ivf_pq3_refine_kernel(ScanArgs a, const u
     if (a.counts_out && tid == 0) a.counts_out[qi] = c;
 }
 
+// ------------------------------------------------------------------------------------------
+// ivf_pq_fused_kernel — BlockBasedIvf::search (index.rs:396-413) of ONE query per block in ONE launch, for the small-batch
+// shape of BASELINE config C3 (a few thousand scanned vectors per query): find_nearest_centroids (:147-163), the query's
+// quantization (pq/mod.rs:152-177), the posting-list scan with symmetric PQ distances (:175-237, pq/mod.rs:202-278),
+// the top-k by (distance, point id) (:250-286) and the doc-id remap + IdWithScore order (:298-332).
+//
+// The unfused step was six launches — pad, flat scan, merge, quantize, scan, remap: 96 us for 84 us of kernels — and its scan
+// built a 128 KB table of every (subspace, code, element) term per query to evaluate some 4 000 vectors, of which a few
+// dozen can reach the top-k.  Here the block keeps ONE word per (subspace, code): a bf16 lower and upper bound of the row's
+// sum (ivf_scan_pq3_kernel's table); upper bounds feed a selector whose k-th smallest bounds the k-th exact distance from
+// above, a vector whose lower bound exceeds it is out, every other one is a CANDIDATE kept in LDS and evaluated exactly
+// afterwards from the codebook rows in L2 — the same per-element terms in the same association as ivf_scan_pq2_kernel, so
+// the keys are identical.  A candidate list that overflows (thousands of tied vectors) makes the block re-scan its tiles and
+// evaluate what passes the FINAL bound as it goes: slower, still exact, no second launch.
+// Requires: one index (no per-query user), L2, m == 4 MW, nbits == 8, k <= 64, probes <= 64 (COARSE: <= centroids <= 16 K).
+#define PQF_BLOCK 1024
+#define PQF_NW (PQF_BLOCK / MDB_WAVE)
+#define PQF_CAP 2048   // candidate slots kept in LDS
+struct FusedArgs {
+    const float* q;             // query rows [B][qstride], read with scalar loads (wave-uniform addresses)
+    int qstride;
+    const float4* cent_tiles;   // COARSE: the centroid tiles, their count and the exact-distance plan of `num_features`
+    uint32_t num_clusters, cent_ntiles;
+    DistPlan cp, sp;            // sp = plan of one subvector (quantization)
+    int num_probes;
+    const uint8_t* index_bytes; // remap (doc_out != nullptr): doc ids are read from the uploaded index file
+    mdb_u128* doc_out;
+    float* score_out;
+    uint32_t* doc_counts_out;
+    unsigned long long* zero4;  // four words cleared by block 0: the NEXT fused call's counters (no memset launch per call)
+    uint32_t cap;               // candidate slots in use (<= PQF_CAP; tests shrink it to force the overflow pass)
+};
+
+template <int SUBDIM, int MW, bool COARSE>
+__global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, FusedArgs f, const uint32_t* __restrict__ codes,
+                                                                 const float* __restrict__ cb, size_t sel_bytes) {
+    constexpr int m = 4 * MW, nbits = 8, K = 256, S4 = SUBDIM / 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    BlockSelect<PQF_BLOCK> sel;
+    uint32_t* pstart = (uint32_t*)(lds + sel_bytes);     // [64]  first tile of probe j
+    uint32_t* ppref = pstart + 64;                         // [65]  exclusive prefix of the probes' tile counts (+ pad to 80)
+    uint32_t* ccnt = ppref + 72;                           // candidates of this block
+    uint32_t* scnt = ppref + 73;                           // scored vectors of this block
+    uint32_t* probes_l = ppref + 80;                       // [64]
+    uint32_t* qcode = probes_l + 64;                       // [m <= 32]
+    float* qv = (float*)(qcode + 32);                      // the query's own codebook rows [m][SUBDIM]
+    uint32_t* btab = (uint32_t*)(qv + m * SUBDIM);         // [m * 256]: upper bound (bf16) << 16 | lower bound (bf16) of the row's sum
+    uint32_t* cand = btab + m * K;                         // [PQF_CAP] slot indices (tile * 64 + lane)
+    uint64_t* rlo = (uint64_t*)(cand + PQF_CAP);           // remap: [64] doc id halves, scores
+    uint64_t* rhi = rlo + 64;
+    float* rsc = (float*)(rhi + 64);
+    const int qi = blockIdx.x;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / MDB_WAVE), lane = tid % MDB_WAVE;
+    const IvfUserDev u = a.users[0];
+    const float* qrow = f.q + (size_t)qi * f.qstride;
+    bool nan_seen = false, bad = false;
+    unsigned scored = 0;
+    if (f.zero4 && qi == 0 && tid < 4) f.zero4[tid] = 0ull;
+    if (tid == 0) { *ccnt = 0; *scnt = 0; }
+
+    // ---- 1. find_nearest_centroids: sqrt-L2 to every centroid, the num_probes nearest by (distance, index)
+    int np = f.num_probes;
+    if (COARSE) {
+        sel.init(lds, np);
+        bool first = true;
+        for (uint32_t t0 = 0; t0 < f.cent_ntiles; t0 += PQF_NW) {
+            const uint32_t t = t0 + (uint32_t)wave, v = t * MDB_TILE + (uint32_t)lane;
+            uint64_t key = MDB_KEY_MAX;
+            if (t < f.cent_ntiles && v < f.num_clusters) {
+                TileLoader ld{f.cent_tiles + (size_t)t * f.cp.d4 * MDB_TILE + lane};
+                float raw[1];
+                exact_sums<MDB_METRIC_L2, 1, TileLoader, 0>(ld, qrow, 0, f.cp, raw);
+                const float dist = finish_distance<MDB_METRIC_L2>(raw[0]);
+                if (dist != dist) nan_seen = true;
+                key = make_key(dist, v);
+            }
+            if (first) { sel.warm_start(key); first = false; }
+            sel.offer(key);
+            sel.round_end();
+        }
+        sel.finish();
+        np = min(np, (int)sel.count());
+        if (tid < 64) probes_l[tid] = tid < np ? key_id(sel.buf[tid]) : 0xFFFFFFFFu;
+    } else {
+        np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
+        if (tid < 64) probes_l[tid] = tid < np ? a.probes[(size_t)qi * a.probe_stride + tid] : 0xFFFFFFFFu;
+    }
+    // ---- 2. the query's codes (Q::QuantizedT::process_vector, index.rs:193): one wave per subspace
+    for (int s = wave; s < m; s += PQF_NW) {
+        const uint32_t code = pq_quantize_wave(qrow + (size_t)s * SUBDIM, cb + (size_t)s * K * SUBDIM, K, SUBDIM, f.sp, lane);
+        if (lane == 0) qcode[s] = code;
+    }
+    __syncthreads();
+    // ---- 3. the query's own codebook rows, then the bound table (ivf_scan_pq3_kernel's arithmetic)
+    for (int i = tid; i < m * SUBDIM; i += PQF_BLOCK) {
+        const int s = i / SUBDIM;
+        qv[i] = cb[((size_t)s * K + qcode[s]) * SUBDIM + (i % SUBDIM)];
+    }
+    // ... and the flattened tile sequence of the probed lists (wave 0; independent of the table)
+    if (tid < 64) {
+        uint32_t t0 = 0, cnt = 0;
+        if (tid < np) {
+            const uint32_t c = probes_l[tid];
+            if (c >= u.num_lists) bad = true;
+            else {
+                const uint32_t g = u.list_base + c;
+                t0 = a.list_tile_off[g];
+                cnt = a.list_tile_off[g + 1] - t0;
+            }
+        }
+        pstart[tid] = t0;
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < MDB_WAVE; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        ppref[tid + 1] = incl;   // entries past np repeat the total
+        if (tid == 0) ppref[0] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < m * K; i += PQF_BLOCK) {
+        const float4* row = (const float4*)cb + (size_t)i * S4;
+        const float4* q4 = (const float4*)qv + (i >> nbits) * S4;
+        float sum = 0.0f;
+#pragma unroll
+        for (int x = 0; x < S4; ++x) {
+            const float4 c = row[x], q = q4[x];
+            sum = __fadd_rn(sum, acc_term<MDB_METRIC_L2>(0.0f, q.x, c.x));   // every term >= 0
+            sum = __fadd_rn(sum, acc_term<MDB_METRIC_L2>(0.0f, q.y, c.y));
+            sum = __fadd_rn(sum, acc_term<MDB_METRIC_L2>(0.0f, q.z, c.z));
+            sum = __fadd_rn(sum, acc_term<MDB_METRIC_L2>(0.0f, q.w, c.w));
+        }
+        // real row sum within (1 +- 8 eps) of `sum` (SUBDIM <= 32: (1 +- 32 eps)); the exact distance (the same terms in the
+        // reference's association) within (1 +- 2^-17) of the real total: shrink / stretch by 1e-5 / 2e-5, then round the bf16
+        // mantissa outwards
+        const uint32_t lo = __float_as_uint(__fmul_rn(sum, 0.99999f)) >> 16;
+        const uint32_t hi = (__float_as_uint(__fmul_rn(sum, 1.00002f)) + 0xFFFFu) >> 16;
+        btab[i] = sum != sum ? 0x7FC07FC0u : ((hi << 16) | lo);
+    }
+    sel.init(lds, a.k);   // (ends with a barrier: btab, pstart, ppref are visible)
+    const int T = (int)ppref[64];
+
+    // lower / upper bound of one stored code against the query's
+    auto bounds = [&](const uint32_t (&cwv)[MW], float& lb, float& ub) {
+        lb = 0.0f; ub = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) {
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) {
+                const uint32_t code = (cwv[w] >> (8 * bi)) & 0xFFu;
+                const uint32_t e = btab[((w * 4 + bi) << nbits) + code];
+                lb = __fadd_rn(lb, __uint_as_float(e << 16));
+                ub = __fadd_rn(ub, __uint_as_float(e & 0xFFFF0000u));
+            }
+        }
+    };
+    // exact symmetric distance of one stored code (ivf_scan_pq2_kernel::exact_key's terms and association; rows from L2)
+    auto exact_key = [&](uint32_t vid, const uint32_t (&cwv)[MW]) -> uint64_t {
+        float s16[16], s8[8], s4[4];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) s16[x] = 0.0f;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) s8[x] = 0.0f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) s4[x] = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) {
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) {
+                const int s = w * 4 + bi;
+                const uint32_t code = (cwv[w] >> (8 * bi)) & 0xFFu;
+                const float4* c4 = (const float4*)cb + ((size_t)(s << nbits) + code) * S4;
+                const float4* q4 = (const float4*)qv + s * S4;
+                float trow[SUBDIM];
+#pragma unroll
+                for (int x = 0; x < S4; ++x) {
+                    const float4 q = q4[x], cc = c4[x];
+                    trow[4 * x + 0] = acc_term<MDB_METRIC_L2>(0.0f, q.x, cc.x);
+                    trow[4 * x + 1] = acc_term<MDB_METRIC_L2>(0.0f, q.y, cc.y);
+                    trow[4 * x + 2] = acc_term<MDB_METRIC_L2>(0.0f, q.z, cc.z);
+                    trow[4 * x + 3] = acc_term<MDB_METRIC_L2>(0.0f, q.w, cc.w);
+                }
+                pq2_add_row<SUBDIM>(trow, s16, s8, s4);
+            }
+        }
+        const float rs = __fadd_rn(__fadd_rn(__fadd_rn(reduce_ordered<16>(s16), reduce_ordered<8>(s8)), reduce_ordered<4>(s4)), 0.0f);
+        if (rs != rs) nan_seen = true;
+        return make_key(rs, vid);
+    };
+
+    // ---- 4. bounds pass over the probed lists' tiles: 3-stage pipeline (fetch / tombstone + filter words / consume), as in
+    //         ivf_scan_pq3_kernel; wave w of round r takes tile r * NW + w of the flattened sequence
+    const int rounds = (T + PQF_NW - 1) / PQF_NW;
+    if (T > 0) {
+        uint32_t pid[3], tw[3], aw[3], cw[3][MW], slot0[3];
+        bool live[3] = {false, false, false};
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            pid[x] = 0xFFFFFFFFu; tw[x] = 0; aw[x] = 0; slot0[x] = 0;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) cw[x][w] = 0;
+        }
+        const int jsafe = __popcll(__ballot(ppref[lane + 1] == 0u));   // first non-empty list: a safe tile for idle waves
+        auto iteration = [&](int r, auto PH) {
+            constexpr int FA = decltype(PH)::value, TB = (FA + 2) % 3, CC = (FA + 1) % 3;
+            {
+                const int t = r * PQF_NW + wave;
+                int j = __popcll(__ballot(ppref[lane + 1] <= (uint32_t)t));   // lists that end at or before t
+                live[FA] = r < rounds && t < T;
+                j = live[FA] ? j : jsafe;
+                const uint32_t tile = pstart[j] + (live[FA] ? (uint32_t)t - ppref[j] : 0u);
+                slot0[FA] = tile * MDB_TILE;
+                pid[FA] = a.slot_ids[(size_t)tile * MDB_TILE + lane];
+                const uint32_t* cwp = codes + (size_t)tile * MW * MDB_TILE + lane;
+#pragma unroll
+                for (int w = 0; w < MW; ++w) cw[FA][w] = cwp[(size_t)w * MDB_TILE];
+            }
+            {
+                const uint32_t pz = pid[TB] == 0xFFFFFFFFu ? 0u : pid[TB];
+                tw[TB] = a.tomb[u.tomb_base + (pz >> 5)];
+                aw[TB] = a.allow[(size_t)qi * a.allow_stride + ((pz >> 5) & a.allow_mask)];
+            }
+            if (r >= 2) {
+                uint64_t key = MDB_KEY_MAX;
+                const bool take = live[CC] && pid[CC] != 0xFFFFFFFFu && !((tw[CC] >> (pid[CC] & 31)) & 1u) && ((aw[CC] >> (pid[CC] & 31)) & 1u);
+                float lb = 0.0f, ub = 0.0f;
+                if (take) {
+                    ++scored;
+                    bounds(cw[CC], lb, ub);
+                    key = make_key(ub, pid[CC]);   // NaN sorts last: it never lowers the threshold
+                }
+                if (r == 2) sel.warm_start(key);
+                // candidates against the threshold as it stands (it only tightens: a vector admitted early is merely superfluous)
+                const uint32_t thr_hi = (uint32_t)(*sel.thr >> 32);
+                const bool surv = take && !(lb == lb && f32_orderable(__fmul_rn(lb, 0.99998f)) > thr_hi);
+                const unsigned long long sm = __ballot(surv);
+                if (sm) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(ccnt, (uint32_t)__popcll(sm));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const uint32_t pos = base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+                    if (surv && pos < f.cap) cand[pos] = slot0[CC] + (uint32_t)lane;
+                }
+                sel.offer(key);
+                sel.round_end((uint32_t)a.k + 64u);   // eager: a slack threshold costs exact evaluations
+            }
+        };
+        for (int r = 0; r < rounds + 2; r += 3) {  // surplus iterations offer nothing (uniform)
+            iteration(r, std::integral_constant<int, 0>{});
+            iteration(r + 1, std::integral_constant<int, 1>{});
+            iteration(r + 2, std::integral_constant<int, 2>{});
+        }
+    }
+    sel.finish();
+    const uint32_t thr_fin = (uint32_t)(*sel.thr >> 32);   // k-th smallest upper bound (all ones: fewer than k vectors)
+    const uint32_t nc = *ccnt;
+    {
+        unsigned long long ws = scored;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ws += __shfl_xor((unsigned)ws, o);
+        if (lane == 0 && ws) atomicAdd(scnt, (uint32_t)ws);
+    }
+    __syncthreads();   // everybody has read the threshold and the count: the selector's memory is reused
+    // one device-scope atomic per BLOCK: thousands of atomics on one cache line serialise
+    if (tid == 0 && *scnt) atomicAdd(&a.counters[2], (unsigned long long)*scnt);
+    // ---- 5. exact distances of the candidates, top-k by (distance, point id)
+    sel.init(lds, a.k);
+    if (nc <= f.cap) {
+        bool first = true;
+        for (uint32_t base = 0; base < nc; base += PQF_BLOCK) {
+            const uint32_t i = base + (uint32_t)tid;
+            uint64_t key = MDB_KEY_MAX;
+            if (i < nc) {
+                const uint32_t slot = cand[i];
+                const uint32_t* cwp = codes + (size_t)(slot / MDB_TILE) * MW * MDB_TILE + (slot % MDB_TILE);
+                uint32_t cwv[MW];
+#pragma unroll
+                for (int w = 0; w < MW; ++w) cwv[w] = cwp[(size_t)w * MDB_TILE];
+                key = exact_key(a.slot_ids[slot], cwv);
+            }
+            if (first) { sel.warm_start(key); first = false; }
+            sel.offer(key);
+            sel.round_end();
+        }
+    } else {
+        // the list overflowed (thousands of vectors within the bound: heavy ties): second pass over the tiles, exact evaluation
+        // of everything the FINAL bound lets through
+        for (int r = 0; r < rounds; ++r) {
+            const int t = r * PQF_NW + wave;
+            uint64_t key = MDB_KEY_MAX;
+            if (t < T) {
+                const int j = __popcll(__ballot(ppref[lane + 1] <= (uint32_t)t));
+                const uint32_t tile = pstart[j] + ((uint32_t)t - ppref[j]);
+                const uint32_t pidv = a.slot_ids[(size_t)tile * MDB_TILE + lane];
+                const uint32_t* cwp = codes + (size_t)tile * MW * MDB_TILE + lane;
+                uint32_t cwv[MW];
+#pragma unroll
+                for (int w = 0; w < MW; ++w) cwv[w] = cwp[(size_t)w * MDB_TILE];
+                const uint32_t pz = pidv == 0xFFFFFFFFu ? 0u : pidv;
+                const uint32_t twv = a.tomb[u.tomb_base + (pz >> 5)];
+                const uint32_t awv = a.allow[(size_t)qi * a.allow_stride + ((pz >> 5) & a.allow_mask)];
+                const bool take = pidv != 0xFFFFFFFFu && !((twv >> (pidv & 31)) & 1u) && ((awv >> (pidv & 31)) & 1u);
+                if (take) {
+                    float lb, ub;
+                    bounds(cwv, lb, ub);
+                    if (!(lb == lb && f32_orderable(__fmul_rn(lb, 0.99998f)) > thr_fin)) key = exact_key(pidv, cwv);
+                }
+            }
+            sel.offer(key);
+            sel.round_end();
+        }
+    }
+    if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
+    if (bad) atomicOr(a.flags, MDB_FLAG_RANGE);
+    sel.finish();
+    const int c = (int)sel.count();
+    if (!f.doc_out) {  // (distance, point id) rows: search_with_centroids
+        uint64_t* dst = a.partial + (size_t)qi * a.k;
+        for (int j = tid; j < a.k; j += PQF_BLOCK) dst[j] = j < c ? sel.buf[j] : MDB_KEY_MAX;
+        if (a.counts_out && tid == 0) a.counts_out[qi] = (uint32_t)c;
+        return;
+    }
+    // ---- 6. search_with_centroids_and_remap: doc ids, IdWithScore order (remap_kernel's rank sort; k <= 64)
+    if (tid < c) {
+        const uint64_t key = sel.buf[tid];
+        const uint64_t* dp = (const uint64_t*)(f.index_bytes + u.doc_ids_off + (size_t)key_id(key) * 16);
+        rlo[tid] = dp[0];
+        rhi[tid] = dp[1];
+        rsc[tid] = key_dist(key);
+    }
+    __syncthreads();
+    if (tid < a.k) {
+        if (tid < c) {
+            int rank = 0;
+            const float sv = rsc[tid];
+            const uint64_t l = rlo[tid], h = rhi[tid];
+            for (int i = 0; i < c; ++i) {
+                const float si = rsc[i];
+                const bool less = si < sv || (si == sv && (rhi[i] < h || (rhi[i] == h && (rlo[i] < l || (rlo[i] == l && i < tid)))));
+                rank += less ? 1 : 0;
+            }
+            f.doc_out[(size_t)qi * a.k + rank] = mdb_u128{l, h};
+            f.score_out[(size_t)qi * a.k + rank] = sv;
+        } else {
+            f.doc_out[(size_t)qi * a.k + tid] = mdb_u128{~0ull, ~0ull};
+            f.score_out[(size_t)qi * a.k + tid] = __uint_as_float(0x7F800000u);
+        }
+    }
+    if (tid == 0 && f.doc_counts_out) f.doc_counts_out[qi] = (uint32_t)c;
+}
+
 // keys (distance, point id) -> (u128 doc id, score) rows ordered by IdWithScore (score, doc id).
 // One block per query; rank sort (k <= MDB_MAX_K).
 __global__ __launch_bounds__(256) void remap_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts,
@@ -1623,6 +1975,73 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     return MDB_OK;
 }
 
+// The fused small-batch step (ivf_pq_fused_kernel): one index, L2 PQ with 8-bit codes in whole 4-byte words, k and probes
+// within one wave, batches below the two-phase scan's range (from there on several blocks per CU pay off).
+bool IvfSet::fused_ok(size_t b, size_t k, size_t num_probes, bool have_probes) const {
+    if (ctx->opt.pq_no_fused || kind != MDB_QUANT_PQ || metric != MDB_METRIC_L2 || blobs.size() != 1) return false;
+    if (pq.num_bits != 8 || pq.K != 256 || pq.m != 4 * mw || !(mw == 1 || mw == 2 || mw == 4 || mw == 8)) return false;
+    if (!(pq.subdim == 4 || pq.subdim == 8 || pq.subdim == 16 || pq.subdim == 32)) return false;
+    if (k < 1 || k > 64 || num_probes < 1 || num_probes > 64 || b == 0) return false;
+    if (b >= (size_t)std::max<long long>(1, ctx->opt.pq_two_phase_min_b) && !ctx->opt.pq_no_two_phase) return false;
+    if (!have_probes && (num_probes > blobs[0].num_clusters || blobs[0].num_clusters > 16384)) return false;
+    return true;
+}
+
+mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const uint32_t* d_probes, size_t num_probes, size_t k,
+                                const ScanFilter* filter, uint64_t* d_keys, uint32_t* d_counts, mdb_u128* d_doc, float* d_score,
+                                uint32_t* d_doc_counts) {
+    const ScanFilter& f = filter && filter->allow ? *filter : flt;
+    if (f.allow && f.n_bitmaps != 1 && f.n_bitmaps < b)
+        return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "%zu filter bitmaps for a batch of %zu queries", f.n_bitmaps, b);
+    const int par = ctx->fused_parity;
+    ctx->fused_parity ^= 1;
+    ctx->counter_base = 16 + 4 * par;
+    ScanArgs a{d_users.p, nullptr, d_list_tile_off.p, d_slot_ids.p, d_tomb.p, d_probes, nullptr, (int)num_probes,
+               (int)k, d_keys, ctx->d_flags, ctx->d_counters + ctx->counter_base,
+               f.allow ? f.allow : d_tomb.p + ones_word, f.allow && f.n_bitmaps != 1 ? (uint32_t)f.words : 0u, f.allow ? 0xFFFFFFFFu : 0u,
+               d_counts, nullptr, 1};
+    const IvfBlobInfo& bi = blobs[0];
+    const int d4 = ((int)num_features + 3) / 4;
+    FusedArgs fa{};
+    fa.q = d_q;
+    fa.qstride = qstride;
+    fa.cent_tiles = (const float4*)(d_cent_tiles.p + (size_t)h_users[0].cent_tile_base * MDB_TILE * d4 * 4);
+    fa.num_clusters = bi.num_clusters;
+    fa.cent_ntiles = (bi.num_clusters + MDB_TILE - 1) / MDB_TILE;
+    fa.cp = make_plan((int)num_features, MDB_METRIC_L2);
+    fa.sp = make_plan(pq.subdim, MDB_METRIC_L2);
+    fa.num_probes = (int)num_probes;
+    fa.index_bytes = d_index.p;
+    fa.doc_out = d_doc;
+    fa.score_out = d_score;
+    fa.doc_counts_out = d_doc_counts;
+    fa.zero4 = ctx->d_counters + 16 + 4 * (par ^ 1);
+    fa.cap = (uint32_t)std::min<long long>(PQF_CAP, std::max<long long>(1, ctx->opt.pqf_cap));
+    const size_t sel_bytes = (BlockSelect<PQF_BLOCK>::lds_bytes((int)std::max(k, num_probes)) + 15) & ~(size_t)15;
+    const size_t lds = sel_bytes + (64 + 80 + 64 + 32) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * 256 * 4 + PQF_CAP * 4 + 64 * 20;
+    ProfScope prof(ctx);
+#define MDB_PQF_LAUNCH(SD, MWT, CO)                                                                                                       \
+    do {                                                                                                                                  \
+        if (lds > 48 * 1024)                                                                                                              \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_pq_fused_kernel<SD, MWT, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        ivf_pq_fused_kernel<SD, MWT, CO><<<dim3((unsigned)b), PQF_BLOCK, lds, ctx->stream>>>(a, fa, d_codes.p, pq.codebook.p, sel_bytes);    \
+    } while (0)
+#define MDB_PQF_CO(SD, MWT) do { if (d_probes) MDB_PQF_LAUNCH(SD, MWT, false); else MDB_PQF_LAUNCH(SD, MWT, true); } while (0)
+#define MDB_PQF_SD(MWT)                                       \
+    do {                                                      \
+        if (pq.subdim == 4) MDB_PQF_CO(4, MWT);               \
+        else if (pq.subdim == 8) MDB_PQF_CO(8, MWT);          \
+        else if (pq.subdim == 16) MDB_PQF_CO(16, MWT);        \
+        else MDB_PQF_CO(32, MWT);                             \
+    } while (0)
+    if (mw == 1) MDB_PQF_SD(1); else if (mw == 2) MDB_PQF_SD(2); else if (mw == 4) MDB_PQF_SD(4); else MDB_PQF_SD(8);
+#undef MDB_PQF_SD
+#undef MDB_PQF_CO
+#undef MDB_PQF_LAUNCH
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
 mdb_status IvfSet::remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,
                          mdb_u128* d_doc, float* d_score, uint32_t* d_counts_out) {
     if (b == 0) return MDB_OK;
@@ -1737,7 +2156,10 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
     float* dq;
     int qstride;
     const size_t bpad = probes ? (b + 3) / 4 * 4 : s.coarse_bpad(b);
-    MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, bpad, &dq, &qstride));
+    // small batches of an L2 PQ index: the whole step is ONE kernel (ivf_pq_fused_kernel), device-resident queries are read in place
+    const bool fused = s.fused_ok(b, k, num_probes, probes != nullptr);
+    if (fused && mem == MDB_MEM_DEVICE) { dq = const_cast<float*>(queries); qstride = (int)s.num_features; }
+    else MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, bpad, &dq, &qstride));
     void* dprobes;
     MDB_TRY(mdb_scratch(ctx, 2, b * std::max<size_t>(num_probes, 1) * 4, &dprobes));
     if (probes) {
@@ -1748,18 +2170,34 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
             memcpy(pin, probes, b * num_probes * 4);
             MDB_HIP(ctx, hipMemcpyAsync(dprobes, pin, b * num_probes * 4, hipMemcpyHostToDevice, ctx->stream));
         } else MDB_HIP(ctx, hipMemcpyAsync(dprobes, probes, b * num_probes * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    } else {
+    } else if (!fused) {
         MDB_TRY(s.coarse(0, dq, qstride, b, num_probes, (uint32_t*)dprobes, true, bpad));  // also clears the device counters
     }
     void *keys, *cnts;
     MDB_TRY(mdb_scratch(ctx, 3, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4 + 16, &cnts));
-    if (probes) MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    if (probes && !fused) MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
     ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
+    ctx->counter_base = 0;
     ctx->stat_bytes_per_eval = 0; ctx->stat_bytes_per_scored = s.bytes_per_scored(); ctx->stat_fixed_bytes = 0;
-    MDB_TRY(s.scan(dq, qstride, b, nullptr, (uint32_t*)dprobes, nullptr, (int)num_probes, k, (uint64_t*)keys, (uint32_t*)cnts, &filt));
     size_t total = b * k;
+    if (fused) {
+        const uint32_t* fp = probes ? (const uint32_t*)dprobes : nullptr;
+        if (mode != OUT_DOCS) {
+            MDB_TRY(s.search_fused(dq, qstride, b, fp, num_probes, k, &filt, (uint64_t*)keys, (uint32_t*)cnts, nullptr, nullptr, nullptr));
+        } else if (mem == MDB_MEM_DEVICE) {   // doc ids, scores and counts straight into the caller's buffers
+            return s.search_fused(dq, qstride, b, fp, num_probes, k, &filt, nullptr, nullptr, (mdb_u128*)ids_out, scores_out, counts_out);
+        } else {
+            void *dids, *dsc;
+            MDB_TRY(mdb_scratch(ctx, 5, total * 16 + 16, &dids));
+            MDB_TRY(mdb_scratch(ctx, 1, total * 4 + 16, &dsc));
+            MDB_TRY(s.search_fused(dq, qstride, b, fp, num_probes, k, &filt, nullptr, nullptr, (mdb_u128*)dids, (float*)dsc, (uint32_t*)cnts));
+            const HostCopy back[3] = {{ids_out, dids, total * 16}, {scores_out, dsc, total * 4}, {counts_out, cnts, b * 4}};
+            return mdb_return_to_host(ctx, back, 3);
+        }
+    } else
+    MDB_TRY(s.scan(dq, qstride, b, nullptr, (uint32_t*)dprobes, nullptr, (int)num_probes, k, (uint64_t*)keys, (uint32_t*)cnts, &filt));
     if (mode == OUT_BLOCK) {
         if (mem == MDB_MEM_DEVICE) return s.pack_points((uint64_t*)keys, (uint32_t*)cnts, nullptr, b, k, ids_out);
         void* dblk;

@@ -121,6 +121,7 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
     ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
+    ctx->counter_base = 0;
     ctx->stat_bytes_per_eval = (uint64_t)s.hnsw.dimension * 4 + 4;
     ctx->stat_bytes_per_scored = s.ivf.bytes_per_scored();
     ctx->stat_fixed_bytes = 0;

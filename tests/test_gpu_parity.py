@@ -337,6 +337,78 @@ def test_ivf_pq_fast_scan_shapes(ctx, oracle, n, d, sub, bits, L, P, k):
     assert_result_rows(g.search(q, k, P), o.search(q, k, num_probes=P), len(q))
 
 
+@pytest.mark.parametrize("n,d,sub,L,P,k", [(5000, 128, 8, 48, 16, 10),      # C3's shape in small: m = 16 (4 code words)
+                                           (3000, 64, 4, 20, 1, 1),        # one probe, k = 1, m = 16
+                                           (4000, 32, 8, 70, 64, 64),      # probes and k at the step's limits (one wave), m = 4 (1 code word)
+                                           (3000, 128, 16, 12, 5, 25),     # m = 8 (2 code words)
+                                           (2500, 256, 32, 9, 9, 7),       # widest subvectors, m = 8
+                                           (3000, 128, 4, 33, 7, 10)])     # m = 32 (8 code words)
+def test_ivf_pq_fused_step(ctx, oracle, n, d, sub, L, P, k):
+    """ivf_pq_fused_kernel: coarse search + query quantization + bound table + scan + exact evaluation of the candidates + remap in
+    ONE launch for small batches of an 8-bit L2 PQ index.  Rows, score bits and the scored-vector counter equal the oracle's
+    and the unfused step's (MDB_PQ_NO_FUSED), with the library's own coarse search and with caller-given probes, through
+    host and device buffers, as doc rows / point rows / a points block, with tombstones and per-call filters, and with a
+    candidate list of 8 slots (every block overflows into its second, exact pass)."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from muopdb_amd import lib as L_
+    from muopdb_amd.index import allow_bitmap
+    o, g, q, v, doc_ids = _ivf_case(oracle, ctx, n, d, L, seed=n + d + sub + P, quant=(sub, 8))
+    b = len(q)
+    want = o.search(q, k, num_probes=P)
+    probes = o.find_nearest_centroids(q, P)
+    for cap in (2048, 8):
+        with ctx.option("MDB_PQF_CAP", cap):
+            got = g.search(q, k, P)                                              # coarse search inside the kernel
+            st = ctx.stats()
+            assert_result_rows(got, want, b)
+            assert_result_rows(g.search_with_centroids_and_remap(q, probes, k), want, b)   # caller's probes
+    with ctx.option("MDB_PQ_NO_FUSED", 1):
+        ref = g.search(q, k, P)
+        st_ref = ctx.stats()
+    assert H.result_rows(ref, b) == H.result_rows(got, b)
+    assert st["scored_vectors"] == st_ref["scored_vectors"] > 0
+    assert np.array_equal(g.find_nearest_centroids(q, P), probes)
+    # point rows and the points block of the sharded path come from the same kernel
+    pi, ps, pc = g.search_points(q, k, P)
+    with ctx.option("MDB_PQ_NO_FUSED", 1):
+        ri, rs_, rc = g.search_points(q, k, P)
+        blk_ref = g.search_shard(q, k, P)
+    assert np.array_equal(pc, rc) and all(np.array_equal(pi[i, :pc[i]], ri[i, :rc[i]]) and
+                                          np.array_equal(ps[i, :pc[i]].view(np.uint32), rs_[i, :rc[i]].view(np.uint32)) for i in range(b))
+    assert np.array_equal(g.search_shard(q, k, P), blk_ref)
+    # device-resident queries are read IN PLACE (row stride d, no staging copy): same rows
+    dev = torch.device("cuda", torch.cuda.current_device())
+    qd = torch.from_numpy(q).to(dev)
+    ids = torch.zeros((b, k, 2), dtype=torch.int64, device=dev)
+    sc = torch.zeros((b, k), dtype=torch.float32, device=dev)
+    cn = torch.zeros(b, dtype=torch.int32, device=dev)
+    ctx.check(ctx.lib.mdb_ivf_search(g.h, C.c_void_p(qd.data_ptr()), C.c_size_t(b), None, C.c_size_t(P), C.c_size_t(k), C.c_int(L_.MEM_DEVICE),
+                                     C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(cn.data_ptr())))
+    ctx.sync()
+    hi = ids.cpu().numpy().view(np.uint64)
+    for i in range(b):
+        c = int(want.counts[i])
+        assert int(cn[i]) == c and [(int(hi[i, j, 1]) << 64) | int(hi[i, j, 0]) for j in range(c)] == want.doc_ids(i)
+    # tombstones + per-call filters (shared and per query)
+    dead = sorted({want.doc_ids(i)[0] for i in range(b) if want.counts[i]})[:6]
+    for doc in dead:
+        assert g.invalidate(doc) and o.invalidate(doc)
+    assert_result_rows(g.search(q, k, P), o.search(q, k, num_probes=P), b)
+    rng = np.random.default_rng(5)
+    shared = allow_bitmap(np.sort(rng.choice(n, n // 2, replace=False)), n)
+    per_q = np.stack([allow_bitmap(np.sort(rng.choice(n, n // 3, replace=False)), n) for _ in range(b)])
+    for bm in (shared, per_q):
+        with oracle.planner_filter(bm):
+            fw = o.search(q, k, num_probes=P)
+        assert_result_rows(g.search(q, k, P, planner=bm), fw, b)
+        with ctx.option("MDB_PQF_CAP", 8):
+            assert_result_rows(g.search(q, k, P, planner=bm), fw, b)
+    # batch 1 and an odd batch
+    assert_result_rows(g.search(q[:1], k, P), o.search(q[:1], k, num_probes=P), 1)
+    assert_result_rows(g.search(q[3:10], k, P), o.search(q[3:10], k, num_probes=P), 7)
+
+
 @pytest.mark.parametrize("case", ["wide_range", "ties", "overflow_to_inf", "zeros"])
 def test_ivf_pq_bound_filter_adversarial(ctx, oracle, case):
     """The L2 bound filter of ivf_scan_pq2_kernel (bf16 lower bounds in front of the exact row sums) must never
@@ -387,11 +459,15 @@ def test_ivf_pq_bound_filter_adversarial(ctx, oracle, case):
         gres = g.search_with_centroids_and_remap(q, probes, kk)
         st = ctx.stats()
         assert_result_rows(gres, ores, len(q))
-        with ctx.option("MDB_PQ_NO_FILTER", 1):
-            gres2 = g.search_with_centroids_and_remap(q, probes, kk)
-        st2 = ctx.stats()
+        with ctx.option("MDB_PQ_NO_FUSED", 1):                                    # the unfused step: table kernel with / without its bound filter
+            gres1 = g.search_with_centroids_and_remap(q, probes, kk)
+            st1 = ctx.stats()
+            with ctx.option("MDB_PQ_NO_FILTER", 1):
+                gres2 = g.search_with_centroids_and_remap(q, probes, kk)
+            st2 = ctx.stats()
+        assert_result_rows(gres1, ores, len(q))
         assert_result_rows(gres2, ores, len(q))
-        assert st["scored_vectors"] == st2["scored_vectors"] == n * len(q)
+        assert st["scored_vectors"] == st1["scored_vectors"] == st2["scored_vectors"] == n * len(q)
         if kk <= 64:
             # the two-phase scan (bf16 lower / upper bounds, then exact distances of the candidates: batches >= 512);
             # then with candidate lists of 8 slots: every list overflows and the gated one-phase launch behind redoes the batch
