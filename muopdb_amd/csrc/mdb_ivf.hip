@@ -963,103 +963,249 @@ __global__ __launch_bounds__(256) void ivf_pq3_refine_kernel(ScanArgs a, const u
 }
 
 // ------------------------------------------------------------------------------------------
-// ivf_pq_fused_kernel — BlockBasedIvf::search (index.rs:396-413) of ONE query per block in ONE launch, for the small-batch
-// shape of BASELINE config C3 (a few thousand scanned vectors per query): find_nearest_centroids (:147-163), the query's
-// quantization (pq/mod.rs:152-177), the posting-list scan with symmetric PQ distances (:175-237, pq/mod.rs:202-278),
-// the top-k by (distance, point id) (:250-286) and the doc-id remap + IdWithScore order (:298-332).
+// The small-batch step of BASELINE config C3 — BlockBasedIvf::search (index.rs:396-413) over an L2 PQ index, a few thousand
+// scanned vectors per query — in TWO launches instead of six (pad, flat scan, merge, quantize, table scan, remap):
 //
-// The unfused step was six launches — pad, flat scan, merge, quantize, scan, remap: 96 us for 84 us of kernels — and its scan
-// built a 128 KB table of every (subspace, code, element) term per query to evaluate some 4 000 vectors, of which a few
-// dozen can reach the top-k.  Here the block keeps ONE word per (subspace, code): a bf16 lower and upper bound of the row's
-// sum (ivf_scan_pq3_kernel's table); upper bounds feed a selector whose k-th smallest bounds the k-th exact distance from
-// above, a vector whose lower bound exceeds it is out, every other one is a CANDIDATE kept in LDS and evaluated exactly
-// afterwards from the codebook rows in L2 — the same per-element terms in the same association as ivf_scan_pq2_kernel, so
-// the keys are identical.  A candidate list that overflows (thousands of tied vectors) makes the block re-scan its tiles and
-// evaluate what passes the FINAL bound as it goes: slower, still exact, no second launch.
-// Requires: one index (no per-query user), L2, m == 4 MW, nbits == 8, k <= 64, probes <= 64 (COARSE: <= centroids <= 16 K).
+//   ivf_prep_kernel       every (query, centroid) distance of find_nearest_centroids (:147-163) — 8 queries share each centroid
+//                         load, nothing is selected here — and the queries' PQ codes (pq/mod.rs:152-177).
+//   ivf_pq_fused_kernel   ONE 1024-thread block per query: the num_probes nearest centroids, the bound table, the scan, the exact
+//                         distances of the candidates, the top-k by (distance, point id) (:250-286), doc ids + IdWithScore order
+//                         (:298-332).
+//
+// The old step was latency, not work: its scan built a 128 KB table of every (subspace, code, element) term per query to
+// evaluate ~4 000 vectors of which a few dozen can reach the top-k, and every selection went through a streaming selector
+// with a block barrier (16 waves) and often a sort per round.  Here
+//   * the block keeps ONE word per (subspace, code): a bf16 lower and upper bound of the row's sum (ivf_scan_pq3_kernel's
+//     table).  The k-th smallest UPPER bound bounds the k-th exact distance from above; a vector whose LOWER bound exceeds it
+//     is out, every other one is a CANDIDATE, evaluated exactly from the codebook rows in L2 with ivf_scan_pq2_kernel's
+//     terms and association: identical keys.
+//   * "k-th smallest of n" is never computed exactly: block_kth_bound() buckets the order-preserving images of the values
+//     (a monotone map: min .. max onto 1024 bins, one LDS histogram, one scan) and returns the upper edge of the bin that
+//     holds the k-th — a few barriers whatever n and k.  What passes is a small superset of the k smallest, ranked by
+//     COUNTING (every element counts the smaller ones: no sort, one barrier).
+//   * a wave fetches four tiles of the flattened list sequence at once (one load latency per 4 096 vectors).
+// Thousands of exact ties (candidate lists beyond their capacity) take the streaming selector instead: slower, still exact.
+// Requires: one index (no per-query user), L2, m == 4 MW, nbits == 8, k <= 64, probes <= 64 (<= 8 192 centroids when the
+// coarse search runs here).
 #define PQF_BLOCK 1024
 #define PQF_NW (PQF_BLOCK / MDB_WAVE)
+#define PQF_TPW 4      // tiles per wave and chunk: a chunk of the tile sequence = 64 tiles
 #define PQF_CAP 2048   // candidate slots kept in LDS
+#define PQF_NB 1024    // histogram bins of block_kth_bound
+#define PQF_QT 8       // queries per block of the coarse part of ivf_prep_kernel
 struct FusedArgs {
     const float* q;             // query rows [B][qstride], read with scalar loads (wave-uniform addresses)
     int qstride;
-    const float4* cent_tiles;   // COARSE: the centroid tiles, their count and the exact-distance plan of `num_features`
+    const float4* cent_tiles;   // the centroid tiles, their count and the exact-distance plan of `num_features`
     uint32_t num_clusters, cent_ntiles;
     DistPlan cp, sp;            // sp = plan of one subvector (quantization)
     int num_probes;
+    float* cdist;               // [B][cent_ntiles * 64] centroid distances (prep -> fused)
+    uint8_t* qcodes;            // [B][m] (prep -> fused)
     const uint8_t* index_bytes; // remap (doc_out != nullptr): doc ids are read from the uploaded index file
     mdb_u128* doc_out;
     float* score_out;
     uint32_t* doc_counts_out;
     unsigned long long* zero4;  // four words cleared by block 0: the NEXT fused call's counters (no memset launch per call)
+    unsigned long long* dbg;    // MDB_PQF_DBG: block 0 / thread 0 stores a cycle stamp after every phase
     uint32_t cap;               // candidate slots in use (<= PQF_CAP; tests shrink it to force the overflow pass)
+    uint32_t b, m, coarse_blocks, tile_groups;
 };
+
+__global__ __launch_bounds__(256) void ivf_prep_kernel(FusedArgs f, const float* __restrict__ cb, uint32_t* __restrict__ flags) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (blockIdx.x < f.coarse_blocks) {
+        // ---- distances to 4 tiles of centroids (one per wave) for PQF_QT queries: sqrt-L2 with the reference's lane cascade
+        const uint32_t g = blockIdx.x % f.tile_groups, qg = blockIdx.x / f.tile_groups;
+        const uint32_t t = g * 4 + (uint32_t)wave;
+        if (t >= f.cent_ntiles) return;
+        const uint32_t q0 = qg * PQF_QT;
+        const uint32_t qn = min((uint32_t)PQF_QT, f.b - q0);
+        // the last group may be short: its missing queries alias the last one (their results are not stored)
+        const uint32_t qlast = f.b - 1;
+        const float* qbase = f.q + (size_t)min(q0, qlast) * f.qstride;
+        TileLoader ld{f.cent_tiles + (size_t)t * f.cp.d4 * MDB_TILE + lane};
+        float raw[PQF_QT];
+        if (qn == PQF_QT) {
+            exact_sums<MDB_METRIC_L2, PQF_QT, TileLoader, 0>(ld, qbase, f.qstride, f.cp, raw);
+        } else {
+            for (uint32_t i = 0; i < qn; ++i) {
+                float r1[1];
+                exact_sums<MDB_METRIC_L2, 1, TileLoader, 0>(ld, qbase + (size_t)i * f.qstride, 0, f.cp, r1);
+                raw[i] = r1[0];
+            }
+        }
+        const size_t lpad = (size_t)f.cent_ntiles * MDB_TILE;
+        bool nan_seen = false;
+        const bool valid = t * MDB_TILE + (uint32_t)lane < f.num_clusters;
+#pragma unroll
+        for (int i = 0; i < PQF_QT; ++i) {
+            if ((uint32_t)i < qn) {
+                const float dist = finish_distance<MDB_METRIC_L2>(raw[i]);
+                if (valid && dist != dist) nan_seen = true;
+                f.cdist[(size_t)(q0 + i) * lpad + (size_t)t * MDB_TILE + lane] = dist;
+            }
+        }
+        if (nan_seen) atomicOr(flags, MDB_FLAG_NAN);
+        return;
+    }
+    // ---- the queries' codes (Q::QuantizedT::process_vector, index.rs:193): one wave per (query, subspace)
+    const size_t task = (size_t)(blockIdx.x - f.coarse_blocks) * 4 + wave;
+    if (task >= (size_t)f.b * f.m) return;
+    const size_t qi = task / f.m;
+    const int s = (int)(task % f.m);
+    const int subdim = f.sp.d;
+    const uint32_t code = pq_quantize_wave(f.q + qi * f.qstride + (size_t)s * subdim, cb + (size_t)s * 256 * subdim, 256, subdim, f.sp, lane);
+    if (lane == 0) f.qcodes[task] = (uint8_t)code;
+}
+
+// Block-wide (PQF_BLOCK threads, uniform control flow): a threshold T with #{v <= T} >= kth over the block's values
+// v[0..R) per thread (order-preserving u32 images; 0xFFFFFFFF = no value), close to the kth smallest: the images are mapped
+// monotonically onto PQF_NB bins between the block's minimum and maximum, T is the upper edge of the bin holding the kth
+// smallest.  All ones when fewer than kth values exist.  hist: PQF_NB + 1 words, red: 64 words of LDS.
+template <int R>
+__device__ __forceinline__ uint32_t block_kth_bound(const uint32_t (&v)[R], uint32_t kth, uint32_t* hist, uint32_t* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t lmin = 0xFFFFFFFFu, lmax = 0u, lcnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool have = v[r] != 0xFFFFFFFFu;
+        lmin = min(lmin, v[r]);
+        lmax = have ? max(lmax, v[r]) : lmax;
+        lcnt += have ? 1u : 0u;
+    }
+    const uint32_t wmin = mdb_wave_min_u32(lmin);
+    const uint32_t wmax = ~mdb_wave_min_u32(~lmax);
+    uint32_t wc = lcnt;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wc += __shfl_xor(wc, o);
+    hist[tid] = 0;
+    if (lane == 0) { red[wave] = wmin; red[16 + wave] = wmax; red[32 + wave] = wc; }
+    if (tid == 0) hist[PQF_NB] = 0;
+    __syncthreads();
+    uint32_t gmin = 0xFFFFFFFFu, gmax = 0u, total = 0;
+#pragma unroll
+    for (int w = 0; w < PQF_NW; ++w) { gmin = min(gmin, red[w]); gmax = max(gmax, red[16 + w]); total += red[32 + w]; }
+    if (total < kth || kth == 0) { __syncthreads(); return 0xFFFFFFFFu; }   // (uniform)
+    const uint32_t range = gmax - gmin;
+    const int sh = max(0, 32 - (int)__clz(range | 1u) - 10);   // (v - gmin) >> sh < 1024
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (v[r] != 0xFFFFFFFFu) atomicAdd(&hist[(v[r] - gmin) >> sh], 1u);
+    __syncthreads();
+    // inclusive scan of the 1024 bins: one bin per thread
+    const uint32_t mine = hist[tid];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < MDB_WAVE; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) red[48 + wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < PQF_NW; ++w) before += w < wave ? red[48 + w] : 0u;
+    incl += before;
+    if (incl >= kth && incl - mine < kth) hist[PQF_NB] = (uint32_t)tid;   // exactly one bin
+    __syncthreads();
+    const uint32_t B = hist[PQF_NB];
+    const unsigned long long edge = (unsigned long long)gmin + (((unsigned long long)B + 1ull) << sh) - 1ull;
+    __syncthreads();   // hist / red may be reused at once
+    return edge >= 0xFFFFFFFFull ? 0xFFFFFFFEu : (uint32_t)edge;   // never the "no value" image
+}
 
 template <int SUBDIM, int MW, bool COARSE>
 __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, FusedArgs f, const uint32_t* __restrict__ codes,
-                                                                 const float* __restrict__ cb, size_t sel_bytes) {
+                                                                 const float* __restrict__ cb) {
     constexpr int m = 4 * MW, nbits = 8, K = 256, S4 = SUBDIM / 4;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    BlockSelect<PQF_BLOCK> sel;
-    uint32_t* pstart = (uint32_t*)(lds + sel_bytes);     // [64]  first tile of probe j
+    uint32_t* red = (uint32_t*)lds;                        // [64]
+    uint32_t* hist = red + 64;                             // [PQF_NB + 1] (+ pad)
+    uint32_t* misc = hist + PQF_NB + 16;                   // [0] candidates [1] scored [2] coarse candidates
+    uint32_t* pstart = misc + 16;                          // [64]  first tile of probe j
     uint32_t* ppref = pstart + 64;                         // [65]  exclusive prefix of the probes' tile counts (+ pad to 80)
-    uint32_t* ccnt = ppref + 72;                           // candidates of this block
-    uint32_t* scnt = ppref + 73;                           // scored vectors of this block
     uint32_t* probes_l = ppref + 80;                       // [64]
-    uint32_t* qcode = probes_l + 64;                       // [m <= 32]
-    float* qv = (float*)(qcode + 32);                      // the query's own codebook rows [m][SUBDIM]
+    float* qv = (float*)(probes_l + 64);                   // the query's own codebook rows [m][SUBDIM]
     uint32_t* btab = (uint32_t*)(qv + m * SUBDIM);         // [m * 256]: upper bound (bf16) << 16 | lower bound (bf16) of the row's sum
     uint32_t* cand = btab + m * K;                         // [PQF_CAP] slot indices (tile * 64 + lane)
-    uint64_t* rlo = (uint64_t*)(cand + PQF_CAP);           // remap: [64] doc id halves, scores
+    uint64_t* ck = (uint64_t*)(cand + PQF_CAP);            // [PQF_CAP] keys: coarse candidates, then the candidates' exact keys
+    uint64_t* wkey = ck + PQF_CAP;                         // [64] the winners, ascending
+    uint64_t* rlo = wkey + 64;                             // remap: [64] doc id halves, scores
     uint64_t* rhi = rlo + 64;
     float* rsc = (float*)(rhi + 64);
+    char* sel_lds = (char*)(rsc + 64);                     // the streaming selector of the overflow paths
     const int qi = blockIdx.x;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / MDB_WAVE), lane = tid % MDB_WAVE;
     const IvfUserDev u = a.users[0];
-    const float* qrow = f.q + (size_t)qi * f.qstride;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     bool nan_seen = false, bad = false;
     unsigned scored = 0;
     if (f.zero4 && qi == 0 && tid < 4) f.zero4[tid] = 0ull;
-    if (tid == 0) { *ccnt = 0; *scnt = 0; }
+    if (tid < 16) misc[tid] = 0;
+#define PQF_STAMP(i) do { if (f.dbg && qi == 0 && tid == 0) f.dbg[i] = __builtin_readcyclecounter(); } while (0)
+    PQF_STAMP(0);
 
-    // ---- 1. find_nearest_centroids: sqrt-L2 to every centroid, the num_probes nearest by (distance, index)
+    // ---- 1. find_nearest_centroids: the num_probes nearest by (distance, index) among the distances of ivf_prep_kernel
     int np = f.num_probes;
     if (COARSE) {
-        sel.init(lds, np);
-        bool first = true;
-        for (uint32_t t0 = 0; t0 < f.cent_ntiles; t0 += PQF_NW) {
-            const uint32_t t = t0 + (uint32_t)wave, v = t * MDB_TILE + (uint32_t)lane;
-            uint64_t key = MDB_KEY_MAX;
-            if (t < f.cent_ntiles && v < f.num_clusters) {
-                TileLoader ld{f.cent_tiles + (size_t)t * f.cp.d4 * MDB_TILE + lane};
-                float raw[1];
-                exact_sums<MDB_METRIC_L2, 1, TileLoader, 0>(ld, qrow, 0, f.cp, raw);
-                const float dist = finish_distance<MDB_METRIC_L2>(raw[0]);
-                if (dist != dist) nan_seen = true;
-                key = make_key(dist, v);
-            }
-            if (first) { sel.warm_start(key); first = false; }
-            sel.offer(key);
-            sel.round_end();
+        constexpr int R1 = 8;   // <= 8 192 centroids
+        const uint32_t lpad = f.cent_ntiles * MDB_TILE;
+        const float* dist = f.cdist + (size_t)qi * lpad;
+        uint32_t v[R1];
+#pragma unroll
+        for (int r = 0; r < R1; ++r) {
+            const uint32_t idx = (uint32_t)(r * PQF_BLOCK + tid);
+            v[r] = idx < f.num_clusters ? f32_orderable(dist[idx]) : 0xFFFFFFFFu;
+            if (v[r] == 0xFFFFFFFFu && idx < f.num_clusters) v[r] = 0xFFFFFFFEu;   // (the image of a negative NaN: kept distinct from "none")
         }
-        sel.finish();
-        np = min(np, (int)sel.count());
-        if (tid < 64) probes_l[tid] = tid < np ? key_id(sel.buf[tid]) : 0xFFFFFFFFu;
+        np = min(np, (int)f.num_clusters);
+        const uint32_t T1 = block_kth_bound<R1>(v, (uint32_t)np, hist, red);
+#pragma unroll
+        for (int r = 0; r < R1; ++r) {
+            const bool in = v[r] <= T1 && v[r] != 0xFFFFFFFFu;
+            const unsigned long long bm = __ballot(in);
+            if (bm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&misc[2], (uint32_t)__popcll(bm));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t pos = base + (uint32_t)__popcll(bm & lt_mask);
+                if (in && pos < PQF_CAP) ck[pos] = ((uint64_t)v[r] << 32) | (uint32_t)(r * PQF_BLOCK + tid);
+            }
+        }
+        __syncthreads();
+        const uint32_t nc1 = misc[2];
+        if (nc1 <= PQF_CAP) {
+            // rank by counting: keys are distinct (the index is part of the key)
+            for (uint32_t i = tid; i < nc1; i += PQF_BLOCK) {
+                const uint64_t key = ck[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < nc1; ++j) rank += ck[j] < key ? 1u : 0u;
+                if (rank < (uint32_t)np) probes_l[rank] = (uint32_t)key;
+            }
+        } else {
+            // thousands of centroids tie with the np-th: the streaming selector over all of them
+            BlockSelect<PQF_BLOCK> sel;
+            sel.init(sel_lds, np);
+#pragma unroll
+            for (int r = 0; r < R1; ++r) {
+                sel.offer(v[r] == 0xFFFFFFFFu ? MDB_KEY_MAX : (((uint64_t)v[r] << 32) | (uint32_t)(r * PQF_BLOCK + tid)));
+                sel.round_end();
+            }
+            sel.finish();
+            if (tid < np) probes_l[tid] = (uint32_t)sel.buf[tid];
+        }
     } else {
         np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
         if (tid < 64) probes_l[tid] = tid < np ? a.probes[(size_t)qi * a.probe_stride + tid] : 0xFFFFFFFFu;
     }
-    // ---- 2. the query's codes (Q::QuantizedT::process_vector, index.rs:193): one wave per subspace
-    for (int s = wave; s < m; s += PQF_NW) {
-        const uint32_t code = pq_quantize_wave(qrow + (size_t)s * SUBDIM, cb + (size_t)s * K * SUBDIM, K, SUBDIM, f.sp, lane);
-        if (lane == 0) qcode[s] = code;
-    }
-    __syncthreads();
-    // ---- 3. the query's own codebook rows, then the bound table (ivf_scan_pq3_kernel's arithmetic)
+    PQF_STAMP(1);
+    // ---- 2. the query's own codebook rows (codes from ivf_prep_kernel), then the bound table (ivf_scan_pq3_kernel's arithmetic)
     for (int i = tid; i < m * SUBDIM; i += PQF_BLOCK) {
         const int s = i / SUBDIM;
-        qv[i] = cb[((size_t)s * K + qcode[s]) * SUBDIM + (i % SUBDIM)];
+        qv[i] = cb[((size_t)s * K + f.qcodes[(size_t)qi * m + s]) * SUBDIM + (i % SUBDIM)];
     }
+    __syncthreads();   // qv, probes_l
     // ... and the flattened tile sequence of the probed lists (wave 0; independent of the table)
     if (tid < 64) {
         uint32_t t0 = 0, cnt = 0;
@@ -1076,13 +1222,12 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         uint32_t incl = cnt;
 #pragma unroll
         for (int o = 1; o < MDB_WAVE; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
+            const uint32_t vv = __shfl_up(incl, o);
+            if (lane >= o) incl += vv;
         }
         ppref[tid + 1] = incl;   // entries past np repeat the total
         if (tid == 0) ppref[0] = 0;
     }
-    __syncthreads();
     for (int i = tid; i < m * K; i += PQF_BLOCK) {
         const float4* row = (const float4*)cb + (size_t)i * S4;
         const float4* q4 = (const float4*)qv + (i >> nbits) * S4;
@@ -1095,14 +1240,14 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
             sum = __fadd_rn(sum, acc_term<MDB_METRIC_L2>(0.0f, q.z, c.z));
             sum = __fadd_rn(sum, acc_term<MDB_METRIC_L2>(0.0f, q.w, c.w));
         }
-        // real row sum within (1 +- 8 eps) of `sum` (SUBDIM <= 32: (1 +- 32 eps)); the exact distance (the same terms in the
-        // reference's association) within (1 +- 2^-17) of the real total: shrink / stretch by 1e-5 / 2e-5, then round the bf16
-        // mantissa outwards
+        // real row sum within (1 +- 32 eps) of `sum`; the exact distance (the same terms in the reference's association) within
+        // (1 +- 2^-17) of the real total: shrink / stretch by 1e-5 / 2e-5, then round the bf16 mantissa outwards
         const uint32_t lo = __float_as_uint(__fmul_rn(sum, 0.99999f)) >> 16;
         const uint32_t hi = (__float_as_uint(__fmul_rn(sum, 1.00002f)) + 0xFFFFu) >> 16;
         btab[i] = sum != sum ? 0x7FC07FC0u : ((hi << 16) | lo);
     }
-    sel.init(lds, a.k);   // (ends with a barrier: btab, pstart, ppref are visible)
+    __syncthreads();   // btab, pstart, ppref
+    PQF_STAMP(2);
     const int T = (int)ppref[64];
 
     // lower / upper bound of one stored code against the query's
@@ -1152,110 +1297,115 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         if (rs != rs) nan_seen = true;
         return make_key(rs, vid);
     };
+    // tile t of the flattened sequence -> its tile index
+    auto tile_of = [&](int t) -> uint32_t {
+        const int j = __popcll(__ballot(ppref[lane + 1] <= (uint32_t)t));   // lists that end at or before t (entries past np hold T > t)
+        return pstart[j] + ((uint32_t)t - ppref[j]);
+    };
 
-    // ---- 4. bounds pass over the probed lists' tiles: 3-stage pipeline (fetch / tombstone + filter words / consume), as in
-    //         ivf_scan_pq3_kernel; wave w of round r takes tile r * NW + w of the flattened sequence
-    const int rounds = (T + PQF_NW - 1) / PQF_NW;
-    if (T > 0) {
-        uint32_t pid[3], tw[3], aw[3], cw[3][MW], slot0[3];
-        bool live[3] = {false, false, false};
+    // ---- 3. bounds pass, a chunk of 64 tiles at a time: wave w takes tiles c0 + w + 16 x (x < 4), all four fetched at once
+    uint32_t thr_ub = 0xFFFFFFFFu;   // image of an upper bound of the k-th exact distance (tightens chunk by chunk)
+    for (int c0 = 0; c0 < T; c0 += PQF_NW * PQF_TPW) {
+        uint32_t pid[PQF_TPW], cw[PQF_TPW][MW], slot0[PQF_TPW];
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            pid[x] = 0xFFFFFFFFu; tw[x] = 0; aw[x] = 0; slot0[x] = 0;
+        for (int x = 0; x < PQF_TPW; ++x) {
+            const int t = c0 + wave + PQF_NW * x;
+            pid[x] = 0xFFFFFFFFu;
+            slot0[x] = 0;
 #pragma unroll
             for (int w = 0; w < MW; ++w) cw[x][w] = 0;
-        }
-        const int jsafe = __popcll(__ballot(ppref[lane + 1] == 0u));   // first non-empty list: a safe tile for idle waves
-        auto iteration = [&](int r, auto PH) {
-            constexpr int FA = decltype(PH)::value, TB = (FA + 2) % 3, CC = (FA + 1) % 3;
-            {
-                const int t = r * PQF_NW + wave;
-                int j = __popcll(__ballot(ppref[lane + 1] <= (uint32_t)t));   // lists that end at or before t
-                live[FA] = r < rounds && t < T;
-                j = live[FA] ? j : jsafe;
-                const uint32_t tile = pstart[j] + (live[FA] ? (uint32_t)t - ppref[j] : 0u);
-                slot0[FA] = tile * MDB_TILE;
-                pid[FA] = a.slot_ids[(size_t)tile * MDB_TILE + lane];
+            if (t < T) {   // wave-uniform
+                const uint32_t tile = tile_of(t);
+                slot0[x] = tile * MDB_TILE;
+                pid[x] = a.slot_ids[(size_t)tile * MDB_TILE + lane];
                 const uint32_t* cwp = codes + (size_t)tile * MW * MDB_TILE + lane;
 #pragma unroll
-                for (int w = 0; w < MW; ++w) cw[FA][w] = cwp[(size_t)w * MDB_TILE];
+                for (int w = 0; w < MW; ++w) cw[x][w] = cwp[(size_t)w * MDB_TILE];
             }
-            {
-                const uint32_t pz = pid[TB] == 0xFFFFFFFFu ? 0u : pid[TB];
-                tw[TB] = a.tomb[u.tomb_base + (pz >> 5)];
-                aw[TB] = a.allow[(size_t)qi * a.allow_stride + ((pz >> 5) & a.allow_mask)];
+        }
+        uint32_t tw[PQF_TPW], aw[PQF_TPW];
+#pragma unroll
+        for (int x = 0; x < PQF_TPW; ++x) {
+            const uint32_t pz = pid[x] == 0xFFFFFFFFu ? 0u : pid[x];
+            tw[x] = a.tomb[u.tomb_base + (pz >> 5)];
+            aw[x] = a.allow[(size_t)qi * a.allow_stride + ((pz >> 5) & a.allow_mask)];
+        }
+        uint32_t ubi[PQF_TPW], lbi[PQF_TPW];
+#pragma unroll
+        for (int x = 0; x < PQF_TPW; ++x) {
+            const bool take = pid[x] != 0xFFFFFFFFu && !((tw[x] >> (pid[x] & 31)) & 1u) && ((aw[x] >> (pid[x] & 31)) & 1u);
+            ubi[x] = 0xFFFFFFFFu;
+            lbi[x] = 0xFFFFFFFFu;   // "not taken"
+            if (take) {
+                ++scored;
+                float lb, ub;
+                bounds(cw[x], lb, ub);
+                const uint32_t ui = f32_orderable(ub);
+                ubi[x] = ui == 0xFFFFFFFFu ? 0xFFFFFFFEu : ui;                      // NaN: sorts last, never lowers the bound
+                lbi[x] = lb == lb ? min(f32_orderable(__fmul_rn(lb, 0.99998f)), 0xFFFFFFFEu) : 0u;   // a NaN bound always survives: the exact pass reports it
             }
-            if (r >= 2) {
-                uint64_t key = MDB_KEY_MAX;
-                const bool take = live[CC] && pid[CC] != 0xFFFFFFFFu && !((tw[CC] >> (pid[CC] & 31)) & 1u) && ((aw[CC] >> (pid[CC] & 31)) & 1u);
-                float lb = 0.0f, ub = 0.0f;
-                if (take) {
-                    ++scored;
-                    bounds(cw[CC], lb, ub);
-                    key = make_key(ub, pid[CC]);   // NaN sorts last: it never lowers the threshold
-                }
-                if (r == 2) sel.warm_start(key);
-                // candidates against the threshold as it stands (it only tightens: a vector admitted early is merely superfluous)
-                const uint32_t thr_hi = (uint32_t)(*sel.thr >> 32);
-                const bool surv = take && !(lb == lb && f32_orderable(__fmul_rn(lb, 0.99998f)) > thr_hi);
-                const unsigned long long sm = __ballot(surv);
-                if (sm) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(ccnt, (uint32_t)__popcll(sm));
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    const uint32_t pos = base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
-                    if (surv && pos < f.cap) cand[pos] = slot0[CC] + (uint32_t)lane;
-                }
-                sel.offer(key);
-                sel.round_end((uint32_t)a.k + 64u);   // eager: a slack threshold costs exact evaluations
+        }
+        thr_ub = min(thr_ub, block_kth_bound<PQF_TPW>(ubi, (uint32_t)a.k, hist, red));
+#pragma unroll
+        for (int x = 0; x < PQF_TPW; ++x) {
+            const bool surv = lbi[x] != 0xFFFFFFFFu && lbi[x] <= thr_ub;
+            const unsigned long long sm = __ballot(surv);
+            if (sm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&misc[0], (uint32_t)__popcll(sm));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t pos = base + (uint32_t)__popcll(sm & lt_mask);
+                if (surv && pos < f.cap) cand[pos] = slot0[x] + (uint32_t)lane;
             }
-        };
-        for (int r = 0; r < rounds + 2; r += 3) {  // surplus iterations offer nothing (uniform)
-            iteration(r, std::integral_constant<int, 0>{});
-            iteration(r + 1, std::integral_constant<int, 1>{});
-            iteration(r + 2, std::integral_constant<int, 2>{});
         }
     }
-    sel.finish();
-    const uint32_t thr_fin = (uint32_t)(*sel.thr >> 32);   // k-th smallest upper bound (all ones: fewer than k vectors)
-    const uint32_t nc = *ccnt;
     {
         unsigned long long ws = scored;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) ws += __shfl_xor((unsigned)ws, o);
-        if (lane == 0 && ws) atomicAdd(scnt, (uint32_t)ws);
+        if (lane == 0 && ws) atomicAdd(&misc[1], (uint32_t)ws);
     }
-    __syncthreads();   // everybody has read the threshold and the count: the selector's memory is reused
+    __syncthreads();
+    PQF_STAMP(3);
     // one device-scope atomic per BLOCK: thousands of atomics on one cache line serialise
-    if (tid == 0 && *scnt) atomicAdd(&a.counters[2], (unsigned long long)*scnt);
-    // ---- 5. exact distances of the candidates, top-k by (distance, point id)
-    sel.init(lds, a.k);
+    if (tid == 0 && misc[1]) atomicAdd(&a.counters[2], (unsigned long long)misc[1]);
+    const uint32_t nc = misc[0];
+    int c = 0;   // winners
+    // ---- 4. exact distances of the candidates, top-k by (distance, point id)
     if (nc <= f.cap) {
-        bool first = true;
-        for (uint32_t base = 0; base < nc; base += PQF_BLOCK) {
-            const uint32_t i = base + (uint32_t)tid;
-            uint64_t key = MDB_KEY_MAX;
-            if (i < nc) {
-                const uint32_t slot = cand[i];
-                const uint32_t* cwp = codes + (size_t)(slot / MDB_TILE) * MW * MDB_TILE + (slot % MDB_TILE);
-                uint32_t cwv[MW];
+        for (uint32_t i = tid; i < nc; i += PQF_BLOCK) {
+            const uint32_t slot = cand[i];
+            const uint32_t* cwp = codes + (size_t)(slot / MDB_TILE) * MW * MDB_TILE + (slot % MDB_TILE);
+            uint32_t cwv[MW];
 #pragma unroll
-                for (int w = 0; w < MW; ++w) cwv[w] = cwp[(size_t)w * MDB_TILE];
-                key = exact_key(a.slot_ids[slot], cwv);
-            }
-            if (first) { sel.warm_start(key); first = false; }
-            sel.offer(key);
-            sel.round_end();
+            for (int w = 0; w < MW; ++w) cwv[w] = cwp[(size_t)w * MDB_TILE];
+            ck[i] = exact_key(a.slot_ids[slot], cwv);
         }
+        __syncthreads();
+        PQF_STAMP(4);
+        // rank by counting; equal keys (a point in two probed lists) are ordered by their place in the list
+        for (uint32_t i = tid; i < nc; i += PQF_BLOCK) {
+            const uint64_t key = ck[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < nc; ++j) {
+                const uint64_t o = ck[j];
+                rank += (o < key || (o == key && j < i)) ? 1u : 0u;
+            }
+            if (rank < (uint32_t)a.k) wkey[rank] = key;
+        }
+        c = (int)min(nc, (uint32_t)a.k);
+        __syncthreads();
     } else {
-        // the list overflowed (thousands of vectors within the bound: heavy ties): second pass over the tiles, exact evaluation
-        // of everything the FINAL bound lets through
+        // the list overflowed (thousands of vectors within the bound: heavy ties): second pass over the tiles with the streaming
+        // selector, exact evaluation of everything the FINAL bound lets through
+        BlockSelect<PQF_BLOCK> sel;
+        sel.init(sel_lds, a.k);
+        const int rounds = (T + PQF_NW - 1) / PQF_NW;
         for (int r = 0; r < rounds; ++r) {
             const int t = r * PQF_NW + wave;
             uint64_t key = MDB_KEY_MAX;
             if (t < T) {
-                const int j = __popcll(__ballot(ppref[lane + 1] <= (uint32_t)t));
-                const uint32_t tile = pstart[j] + ((uint32_t)t - ppref[j]);
+                const uint32_t tile = tile_of(t);
                 const uint32_t pidv = a.slot_ids[(size_t)tile * MDB_TILE + lane];
                 const uint32_t* cwp = codes + (size_t)tile * MW * MDB_TILE + lane;
                 uint32_t cwv[MW];
@@ -1268,26 +1418,29 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
                 if (take) {
                     float lb, ub;
                     bounds(cwv, lb, ub);
-                    if (!(lb == lb && f32_orderable(__fmul_rn(lb, 0.99998f)) > thr_fin)) key = exact_key(pidv, cwv);
+                    if (!(lb == lb && f32_orderable(__fmul_rn(lb, 0.99998f)) > thr_ub)) key = exact_key(pidv, cwv);
                 }
             }
             sel.offer(key);
             sel.round_end();
         }
+        sel.finish();
+        c = (int)sel.count();
+        if (tid < c) wkey[tid] = sel.buf[tid];
+        __syncthreads();
     }
+    PQF_STAMP(5);
     if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
     if (bad) atomicOr(a.flags, MDB_FLAG_RANGE);
-    sel.finish();
-    const int c = (int)sel.count();
     if (!f.doc_out) {  // (distance, point id) rows: search_with_centroids
         uint64_t* dst = a.partial + (size_t)qi * a.k;
-        for (int j = tid; j < a.k; j += PQF_BLOCK) dst[j] = j < c ? sel.buf[j] : MDB_KEY_MAX;
+        if (tid < a.k) dst[tid] = tid < c ? wkey[tid] : MDB_KEY_MAX;
         if (a.counts_out && tid == 0) a.counts_out[qi] = (uint32_t)c;
         return;
     }
-    // ---- 6. search_with_centroids_and_remap: doc ids, IdWithScore order (remap_kernel's rank sort; k <= 64)
+    // ---- 5. search_with_centroids_and_remap: doc ids, IdWithScore order (remap_kernel's rank sort; k <= 64)
     if (tid < c) {
-        const uint64_t key = sel.buf[tid];
+        const uint64_t key = wkey[tid];
         const uint64_t* dp = (const uint64_t*)(f.index_bytes + u.doc_ids_off + (size_t)key_id(key) * 16);
         rlo[tid] = dp[0];
         rhi[tid] = dp[1];
@@ -1312,6 +1465,8 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         }
     }
     if (tid == 0 && f.doc_counts_out) f.doc_counts_out[qi] = (uint32_t)c;
+    PQF_STAMP(6);
+#undef PQF_STAMP
 }
 
 // keys (distance, point id) -> (u128 doc id, score) rows ordered by IdWithScore (score, doc id).
@@ -1983,7 +2138,7 @@ bool IvfSet::fused_ok(size_t b, size_t k, size_t num_probes, bool have_probes) c
     if (!(pq.subdim == 4 || pq.subdim == 8 || pq.subdim == 16 || pq.subdim == 32)) return false;
     if (k < 1 || k > 64 || num_probes < 1 || num_probes > 64 || b == 0) return false;
     if (b >= (size_t)std::max<long long>(1, ctx->opt.pq_two_phase_min_b) && !ctx->opt.pq_no_two_phase) return false;
-    if (!have_probes && (num_probes > blobs[0].num_clusters || blobs[0].num_clusters > 16384)) return false;
+    if (!have_probes && (num_probes > blobs[0].num_clusters || blobs[0].num_clusters > 8192)) return false;
     return true;
 }
 
@@ -2002,6 +2157,7 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
                d_counts, nullptr, 1};
     const IvfBlobInfo& bi = blobs[0];
     const int d4 = ((int)num_features + 3) / 4;
+    const bool coarse_here = d_probes == nullptr;
     FusedArgs fa{};
     fa.q = d_q;
     fa.qstride = qstride;
@@ -2016,17 +2172,39 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
     fa.score_out = d_score;
     fa.doc_counts_out = d_doc_counts;
     fa.zero4 = ctx->d_counters + 16 + 4 * (par ^ 1);
+    fa.b = (uint32_t)b;
+    fa.m = (uint32_t)pq.m;
+    fa.tile_groups = (fa.cent_ntiles + 3) / 4;
+    fa.coarse_blocks = coarse_here ? fa.tile_groups * (uint32_t)((b + PQF_QT - 1) / PQF_QT) : 0u;
+    void *cdist = nullptr, *qcodes;
+    if (coarse_here) MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)fa.cent_ntiles * MDB_TILE * 4, &cdist));
+    MDB_TRY(mdb_scratch(ctx, 7, b * (size_t)pq.m + 16, &qcodes));
+    fa.cdist = (float*)cdist;
+    fa.qcodes = (uint8_t*)qcodes;
+    if (ctx->opt.pqf_dbg) {
+        void* dbg;
+        MDB_TRY(mdb_scratch(ctx, 12, 256, &dbg));
+        MDB_HIP(ctx, hipMemsetAsync(dbg, 0, 256, ctx->stream));
+        fa.dbg = (unsigned long long*)dbg;
+    }
     fa.cap = (uint32_t)std::min<long long>(PQF_CAP, std::max<long long>(1, ctx->opt.pqf_cap));
+    // launch 1: every (query, centroid) distance + the queries' codes
+    const unsigned quant_blocks = (unsigned)((b * (size_t)pq.m + 3) / 4);
+    ivf_prep_kernel<<<dim3(fa.coarse_blocks + quant_blocks), 256, 0, ctx->stream>>>(fa, pq.codebook.p, ctx->d_flags);
+    MDB_HIP(ctx, hipGetLastError());
+    // launch 2: one block per query
     const size_t sel_bytes = (BlockSelect<PQF_BLOCK>::lds_bytes((int)std::max(k, num_probes)) + 15) & ~(size_t)15;
-    const size_t lds = sel_bytes + (64 + 80 + 64 + 32) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * 256 * 4 + PQF_CAP * 4 + 64 * 20;
+    const size_t lds = (64 + PQF_NB + 16 + 16 + 64 + 80 + 64) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * 256 * 4 + PQF_CAP * 4 +
+                       PQF_CAP * 8 + 64 * 8 * 3 + 64 * 4 + sel_bytes;
+    {
     ProfScope prof(ctx);
 #define MDB_PQF_LAUNCH(SD, MWT, CO)                                                                                                       \
     do {                                                                                                                                  \
         if (lds > 48 * 1024)                                                                                                              \
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_pq_fused_kernel<SD, MWT, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        ivf_pq_fused_kernel<SD, MWT, CO><<<dim3((unsigned)b), PQF_BLOCK, lds, ctx->stream>>>(a, fa, d_codes.p, pq.codebook.p, sel_bytes);    \
+        ivf_pq_fused_kernel<SD, MWT, CO><<<dim3((unsigned)b), PQF_BLOCK, lds, ctx->stream>>>(a, fa, d_codes.p, pq.codebook.p);               \
     } while (0)
-#define MDB_PQF_CO(SD, MWT) do { if (d_probes) MDB_PQF_LAUNCH(SD, MWT, false); else MDB_PQF_LAUNCH(SD, MWT, true); } while (0)
+#define MDB_PQF_CO(SD, MWT) do { if (coarse_here) MDB_PQF_LAUNCH(SD, MWT, true); else MDB_PQF_LAUNCH(SD, MWT, false); } while (0)
 #define MDB_PQF_SD(MWT)                                       \
     do {                                                      \
         if (pq.subdim == 4) MDB_PQF_CO(4, MWT);               \
@@ -2038,7 +2216,15 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
 #undef MDB_PQF_SD
 #undef MDB_PQF_CO
 #undef MDB_PQF_LAUNCH
+    }
     MDB_HIP(ctx, hipGetLastError());
+    if (fa.dbg) {
+        unsigned long long h[16];
+        MDB_HIP(ctx, hipMemcpyAsync(h, fa.dbg, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[pqf] b=%zu P=%zu k=%zu cycles: probes %llu table %llu bounds %llu exact %llu rank %llu remap %llu total %llu\n", b, num_probes, k,
+                h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+    }
     return MDB_OK;
 }
 
