@@ -47,6 +47,7 @@
     X(ivf_coarse_sample_div, "MDB_IVF_COARSE_SAMPLE_DIV", 8) /* L */                                                \
     X(pq_no_fused, "MDB_PQ_NO_FUSED", 0)               /* small batches: the six-launch step instead of ivf_pq_fused_kernel */ \
     X(pqf_cap, "MDB_PQF_CAP", 2048)                    /* fused step: candidate slots (tests force the overflow pass) */      \
+    X(pqf_quant_in_prep, "MDB_PQF_QUANT_IN_PREP", 0)   /* fused step: query codes in the prep kernel instead of the per-query one */ \
     X(pqf_dbg, "MDB_PQF_DBG", 0)                       /* fused step: print block 0's phase cycle counts (synchronises) */    \
     X(pq_no_fast, "MDB_PQ_NO_FAST", 0)                                                                              \
     X(pq_no_filter, "MDB_PQ_NO_FILTER", 0)                                                                          \

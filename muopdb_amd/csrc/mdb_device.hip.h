@@ -90,7 +90,7 @@ struct Row4Loader {  // row-major row whose start is 16-byte aligned and whose l
 // QT queries against ONE stored vector (this thread's).  q[i] = qbase + i*qstride must be
 // wave-uniform (scalar loads).  Returns the raw cascade sum (squared L2 / positive dot).
 // DB (streaming scans only): register double buffer of the 16-lane passes, see below.
-template <int METRIC, int QT, class Loader, int DB = 0>   // DB: 0 / 2 / 3 register buffers of 8 loads
+template <int METRIC, int QT, class Loader, int DB = 0>   // DB: 0 / 2 / 3 register buffers of 8 loads (QT == 1); 4 = two buffers for any QT
 __device__ __forceinline__ void exact_sums(const Loader& ld, const float* __restrict__ qbase, int qstride,
                                            const DistPlan& p, float (&out)[QT]) {
     float ret[QT];
@@ -123,13 +123,13 @@ __device__ __forceinline__ void exact_sums(const Loader& ld, const float* __rest
                 for (int j = 0; j < 16; ++j) acc[i][j] = acc_term<METRIC>(acc[i][j], q[16 + j], yv[j]);
             }
         };
-        if (DB && QT == 1) {
+        if (DB && (QT == 1 || DB >= 4)) {   // DB 4: the two-buffer form for ANY QT (ivf_prep_kernel: 8 queries per centroid tile)
             // register double buffer: the next step's 8 loads are issued BEFORE this step's 32 QT accumulates, so a lane keeps
             // 16 loads (256 B) in flight instead of 8 — a streaming scan at one query per vector is a latency x
             // bytes-in-flight problem (the loop is unrolled by two steps so that the buffer roles are static).  NOT for gathers of single
             // rows (refine, quantize): the 64 extra registers cost them occupancy — 229 -> 300 us and 55 -> 105 us on C5's coarse refine / quantize
             const int pairs = p.n16 >> 1;
-            if (DB >= 3 && pairs > 0) {
+            if (DB == 3 && pairs > 0) {
                 // three buffers: 24 loads (384 B) per lane in flight — long vectors (d = 768: 24 steps) on short posting lists, where few
                 // waves stream at a time
                 float4 va[8], vb[8], vc[8];

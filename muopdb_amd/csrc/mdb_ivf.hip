@@ -987,12 +987,18 @@ __global__ __launch_bounds__(256) void ivf_pq3_refine_kernel(ScanArgs a, const u
 // Thousands of exact ties (candidate lists beyond their capacity) take the streaming selector instead: slower, still exact.
 // Requires: one index (no per-query user), L2, m == 4 MW, nbits == 8, k <= 64, probes <= 64 (<= 8 192 centroids when the
 // coarse search runs here).
+// 16 waves per query (four per SIMD): the heavy phases (bound lookups, table, exact rows) need the memory and LDS parallelism —
+// with four waves the lookups alone took 12.5 k cycles instead of 3.4 k.  The price: every instruction of the short serial
+// phases (reductions, scans, counting ranks) that all waves execute alike costs 16 cycles of its SIMD, so those phases are
+// written for instruction count (LDS atomics instead of per-wave loops over the other waves' partial results).
 #define PQF_BLOCK 1024
 #define PQF_NW (PQF_BLOCK / MDB_WAVE)
+#define PQF_LOG2_NB 10
 #define PQF_TPW 4      // tiles per wave and chunk: a chunk of the tile sequence = 64 tiles
+#define PQF_R1 8       // centroid distances per thread and chunk of the probe selection (8 192 centroids per chunk)
 #define PQF_CAP 2048   // candidate slots kept in LDS
-#define PQF_NB 1024    // histogram bins of block_kth_bound
-#define PQF_QT 8       // queries per block of the coarse part of ivf_prep_kernel
+#define PQF_NB PQF_BLOCK   // histogram bins of block_kth_bound: one per thread
+#define PQF_QT 4       // queries per block of the coarse part of ivf_prep_kernel (8: 232 VGPRs, two waves per SIMD, 24 us; 4: see DESIGN)
 struct FusedArgs {
     const float* q;             // query rows [B][qstride], read with scalar loads (wave-uniform addresses)
     int qstride;
@@ -1009,32 +1015,39 @@ struct FusedArgs {
     unsigned long long* zero4;  // four words cleared by block 0: the NEXT fused call's counters (no memset launch per call)
     unsigned long long* dbg;    // MDB_PQF_DBG: block 0 / thread 0 stores a cycle stamp after every phase
     uint32_t cap;               // candidate slots in use (<= PQF_CAP; tests shrink it to force the overflow pass)
-    uint32_t b, m, coarse_blocks, tile_groups;
+    uint32_t cand_words;        // LDS words reserved for the candidate records (even)
+    uint32_t b, m, coarse_blocks, quant_blocks, tile_groups;
 };
 
-__global__ __launch_bounds__(256) void ivf_prep_kernel(FusedArgs f, const float* __restrict__ cb, uint32_t* __restrict__ flags) {
+// The coarse part stages its PQF_QT query rows in LDS: every lane of a wave needs the same query element at the same time, an
+// LDS broadcast read (one ds_read_b128 per four elements, in order, partially awaitable) delivers it straight into vector
+// registers — per-lane vector loads of a uniform address cost an instruction per element (35 us for the kernel), scalar
+// loads must all be awaited together and moved into vector registers for the packed math (56 us).
+__global__ __launch_bounds__(256) void ivf_prep_kernel(FusedArgs f, const float* __restrict__ q, const float* __restrict__ cb,
+                                                       float* __restrict__ cdist, uint8_t* __restrict__ qcodes, uint32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];   // [PQF_QT][dpad]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (blockIdx.x < f.coarse_blocks) {
+    // the light, latency-bound quantize blocks come FIRST in dispatch order: they run in the shadow of the coarse blocks
+    if (blockIdx.x >= f.quant_blocks) {
         // ---- distances to 4 tiles of centroids (one per wave) for PQF_QT queries: sqrt-L2 with the reference's lane cascade
-        const uint32_t g = blockIdx.x % f.tile_groups, qg = blockIdx.x / f.tile_groups;
+        const uint32_t cbid = blockIdx.x - f.quant_blocks;
+        const uint32_t g = cbid % f.tile_groups, qg = cbid / f.tile_groups;
         const uint32_t t = g * 4 + (uint32_t)wave;
-        if (t >= f.cent_ntiles) return;
         const uint32_t q0 = qg * PQF_QT;
         const uint32_t qn = min((uint32_t)PQF_QT, f.b - q0);
-        // the last group may be short: its missing queries alias the last one (their results are not stored)
-        const uint32_t qlast = f.b - 1;
-        const float* qbase = f.q + (size_t)min(q0, qlast) * f.qstride;
+        const int d = f.cp.d, dpad = f.cp.d4 * 4 + 16;   // (+16: exact_sums forms, never dereferences, pointers past the row)
+        for (int i = threadIdx.x; i < PQF_QT * dpad; i += 256) {
+            const int qq = i / dpad, e = i % dpad;
+            qs[i] = ((uint32_t)qq < qn && e < d) ? q[(size_t)(q0 + qq) * f.qstride + e] : 0.0f;   // a short last group: zero rows, not stored
+        }
+        __syncthreads();
+        if (t >= f.cent_ntiles) return;
         TileLoader ld{f.cent_tiles + (size_t)t * f.cp.d4 * MDB_TILE + lane};
         float raw[PQF_QT];
-        if (qn == PQF_QT) {
-            exact_sums<MDB_METRIC_L2, PQF_QT, TileLoader, 0>(ld, qbase, f.qstride, f.cp, raw);
-        } else {
-            for (uint32_t i = 0; i < qn; ++i) {
-                float r1[1];
-                exact_sums<MDB_METRIC_L2, 1, TileLoader, 0>(ld, qbase + (size_t)i * f.qstride, 0, f.cp, r1);
-                raw[i] = r1[0];
-            }
-        }
+        // (tried: the two-buffer form of exact_sums — 35 us instead of 24, registers; the centroid's whole vector in registers,
+        // one load latency per tile — 29 us; 8 instead of 4 queries per block — 24 us: the kernel sits between its LDS
+        // broadcast reads and its packed arithmetic, ~7 us each per CU, not on a latency chain)
+        exact_sums<MDB_METRIC_L2, PQF_QT, TileLoader, 0>(ld, qs, dpad, f.cp, raw);
         const size_t lpad = (size_t)f.cent_ntiles * MDB_TILE;
         bool nan_seen = false;
         const bool valid = t * MDB_TILE + (uint32_t)lane < f.num_clusters;
@@ -1043,57 +1056,61 @@ __global__ __launch_bounds__(256) void ivf_prep_kernel(FusedArgs f, const float*
             if ((uint32_t)i < qn) {
                 const float dist = finish_distance<MDB_METRIC_L2>(raw[i]);
                 if (valid && dist != dist) nan_seen = true;
-                f.cdist[(size_t)(q0 + i) * lpad + (size_t)t * MDB_TILE + lane] = dist;
+                cdist[(size_t)(q0 + i) * lpad + (size_t)t * MDB_TILE + lane] = dist;
             }
         }
         if (nan_seen) atomicOr(flags, MDB_FLAG_NAN);
         return;
     }
     // ---- the queries' codes (Q::QuantizedT::process_vector, index.rs:193): one wave per (query, subspace)
-    const size_t task = (size_t)(blockIdx.x - f.coarse_blocks) * 4 + wave;
+    const size_t task = (size_t)blockIdx.x * 4 + wave;
     if (task >= (size_t)f.b * f.m) return;
     const size_t qi = task / f.m;
     const int s = (int)(task % f.m);
     const int subdim = f.sp.d;
-    const uint32_t code = pq_quantize_wave(f.q + qi * f.qstride + (size_t)s * subdim, cb + (size_t)s * 256 * subdim, 256, subdim, f.sp, lane);
-    if (lane == 0) f.qcodes[task] = (uint8_t)code;
+    const uint32_t code = pq_quantize_wave(q + qi * f.qstride + (size_t)s * subdim, cb + (size_t)s * 256 * subdim, 256, subdim, f.sp, lane);
+    if (lane == 0) qcodes[task] = (uint8_t)code;
 }
 
 // Block-wide (PQF_BLOCK threads, uniform control flow): a threshold T with #{v <= T} >= kth over the block's values
 // v[0..R) per thread (order-preserving u32 images; 0xFFFFFFFF = no value), close to the kth smallest: the images are mapped
 // monotonically onto PQF_NB bins between the block's minimum and maximum, T is the upper edge of the bin holding the kth
-// smallest.  All ones when fewer than kth values exist.  hist: PQF_NB + 1 words, red: 64 words of LDS.
+// smallest.  All ones when fewer than kth values exist.
+// hist2: two areas of PQF_NB + 16 words used alternately (`flip` toggles per call) — [0, NB) the histogram, [NB] the bin found,
+// [NB+1..NB+3] block minimum / maximum / count (LDS atomics of the waves' reductions), [NB+4 .. NB+4+NW) the waves' scan totals.
+// A call resets the OTHER area for its successor, so no barrier guards the reuse; the caller resets area 0 before the first
+// call (kth_area_reset).  Four barriers, ~120 instructions per wave.
+__device__ __forceinline__ void kth_area_reset(uint32_t* area) {
+    area[threadIdx.x] = 0;
+    if (threadIdx.x < 16) area[PQF_NB + threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;   // [NB+1] = minimum
+}
 template <int R>
-__device__ __forceinline__ uint32_t block_kth_bound(const uint32_t (&v)[R], uint32_t kth, uint32_t* hist, uint32_t* red) {
+__device__ __forceinline__ uint32_t block_kth_bound(const uint32_t (&v)[R], uint32_t kth, uint32_t* hist2, int& flip) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* hist = hist2 + flip * (PQF_NB + 32);
+    kth_area_reset(hist2 + (flip ^ 1) * (PQF_NB + 32));
+    flip ^= 1;
     uint32_t lmin = 0xFFFFFFFFu, lmax = 0u, lcnt = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bool have = v[r] != 0xFFFFFFFFu;
         lmin = min(lmin, v[r]);
         lmax = have ? max(lmax, v[r]) : lmax;
-        lcnt += have ? 1u : 0u;
+        lcnt += (uint32_t)__popcll(__ballot(have));   // scalar: the wave's count
     }
     const uint32_t wmin = mdb_wave_min_u32(lmin);
     const uint32_t wmax = ~mdb_wave_min_u32(~lmax);
-    uint32_t wc = lcnt;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) wc += __shfl_xor(wc, o);
-    hist[tid] = 0;
-    if (lane == 0) { red[wave] = wmin; red[16 + wave] = wmax; red[32 + wave] = wc; }
-    if (tid == 0) hist[PQF_NB] = 0;
+    if (lane == 0 && lcnt) { atomicMin(&hist[PQF_NB + 1], wmin); atomicMax(&hist[PQF_NB + 2], wmax); atomicAdd(&hist[PQF_NB + 3], lcnt); }
     __syncthreads();
-    uint32_t gmin = 0xFFFFFFFFu, gmax = 0u, total = 0;
-#pragma unroll
-    for (int w = 0; w < PQF_NW; ++w) { gmin = min(gmin, red[w]); gmax = max(gmax, red[16 + w]); total += red[32 + w]; }
-    if (total < kth || kth == 0) { __syncthreads(); return 0xFFFFFFFFu; }   // (uniform)
+    const uint32_t gmin = hist[PQF_NB + 1], gmax = hist[PQF_NB + 2], total = hist[PQF_NB + 3];
+    if (total < kth || kth == 0) { __syncthreads(); return 0xFFFFFFFFu; }   // (uniform; the barrier: a fast thread's NEXT call resets this area)
     const uint32_t range = gmax - gmin;
-    const int sh = max(0, 32 - (int)__clz(range | 1u) - 10);   // (v - gmin) >> sh < 1024
+    const int sh = max(0, 32 - (int)__clz(range | 1u) - PQF_LOG2_NB);   // (v - gmin) >> sh < PQF_NB
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (v[r] != 0xFFFFFFFFu) atomicAdd(&hist[(v[r] - gmin) >> sh], 1u);
     __syncthreads();
-    // inclusive scan of the 1024 bins: one bin per thread
+    // inclusive scan of the bins: one bin per thread; the waves' totals meet in LDS
     const uint32_t mine = hist[tid];
     uint32_t incl = mine;
 #pragma unroll
@@ -1101,17 +1118,17 @@ __device__ __forceinline__ uint32_t block_kth_bound(const uint32_t (&v)[R], uint
         const uint32_t u = __shfl_up(incl, o);
         if (lane >= o) incl += u;
     }
-    if (lane == 63) red[48 + wave] = incl;
+    if (lane == 63) hist[PQF_NB + 4 + wave] = incl;
     __syncthreads();
-    uint32_t before = 0;
+    uint32_t before = lane < wave ? hist[PQF_NB + 4 + lane] : 0u;   // lane w: the total of wave w (< this wave)
 #pragma unroll
-    for (int w = 0; w < PQF_NW; ++w) before += w < wave ? red[48 + w] : 0u;
+    for (int o = 8; o >= 1; o >>= 1) before += __shfl_xor(before, o);   // 16 waves
+    before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
     incl += before;
     if (incl >= kth && incl - mine < kth) hist[PQF_NB] = (uint32_t)tid;   // exactly one bin
     __syncthreads();
     const uint32_t B = hist[PQF_NB];
     const unsigned long long edge = (unsigned long long)gmin + (((unsigned long long)B + 1ull) << sh) - 1ull;
-    __syncthreads();   // hist / red may be reused at once
     return edge >= 0xFFFFFFFFull ? 0xFFFFFFFEu : (uint32_t)edge;   // never the "no value" image
 }
 
@@ -1121,15 +1138,16 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     constexpr int m = 4 * MW, nbits = 8, K = 256, S4 = SUBDIM / 4;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* red = (uint32_t*)lds;                        // [64]
-    uint32_t* hist = red + 64;                             // [PQF_NB + 1] (+ pad)
-    uint32_t* misc = hist + PQF_NB + 16;                   // [0] candidates [1] scored [2] coarse candidates
+    uint32_t* hist = red + 64;                             // 2 x [PQF_NB + 32]: block_kth_bound's alternating areas
+    uint32_t* misc = hist + 2 * (PQF_NB + 32);             // [0] candidates [1] scored [2] coarse candidates
     uint32_t* pstart = misc + 16;                          // [64]  first tile of probe j
     uint32_t* ppref = pstart + 64;                         // [65]  exclusive prefix of the probes' tile counts (+ pad to 80)
     uint32_t* probes_l = ppref + 80;                       // [64]
-    float* qv = (float*)(probes_l + 64);                   // the query's own codebook rows [m][SUBDIM]
-    uint32_t* btab = (uint32_t*)(qv + m * SUBDIM);         // [m * 256]: upper bound (bf16) << 16 | lower bound (bf16) of the row's sum
-    uint32_t* cand = btab + m * K;                         // [PQF_CAP] slot indices (tile * 64 + lane)
-    uint64_t* ck = (uint64_t*)(cand + PQF_CAP);            // [PQF_CAP] keys: coarse candidates, then the candidates' exact keys
+    uint32_t* qcode = probes_l + 64;                       // [m <= 32]
+    float* qv = (float*)(qcode + 32);                      // the query's own codebook rows [m][SUBDIM]
+    float2* btab = (float2*)(qv + m * SUBDIM);             // [m * 256]: (lower, upper) bound of the row's sum, both bf16-exact floats
+    uint32_t* cand = (uint32_t*)(btab + m * K);            // [PQF_CAP][1 + MW]: a candidate's point id and code words
+    uint64_t* ck = (uint64_t*)(cand + f.cand_words);      // [PQF_CAP] keys: coarse candidates, then the candidates' exact keys
     uint64_t* wkey = ck + PQF_CAP;                         // [64] the winners, ascending
     uint64_t* rlo = wkey + 64;                             // remap: [64] doc id halves, scores
     uint64_t* rhi = rlo + 64;
@@ -1143,37 +1161,54 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     unsigned scored = 0;
     if (f.zero4 && qi == 0 && tid < 4) f.zero4[tid] = 0ull;
     if (tid < 16) misc[tid] = 0;
+    kth_area_reset(hist);
+    int flip = 0;
 #define PQF_STAMP(i) do { if (f.dbg && qi == 0 && tid == 0) f.dbg[i] = __builtin_readcyclecounter(); } while (0)
+#define PQF_SUB(i) do { if (f.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); PQF_STAMP(i); } } while (0)
     PQF_STAMP(0);
+    // ---- 0. the query's codes (Q::QuantizedT::process_vector, index.rs:193): one wave per subspace (qcodes != nullptr: already
+    //         computed by ivf_prep_kernel)
+    if (!f.qcodes) {
+        const float* qrow = f.q + (size_t)qi * f.qstride;
+        for (int s0 = wave; s0 < m; s0 += PQF_NW) {
+            const uint32_t code = pq_quantize_wave(qrow + (size_t)s0 * SUBDIM, cb + (size_t)s0 * K * SUBDIM, K, SUBDIM, f.sp, lane);
+            if (lane == 0) qcode[s0] = code;
+        }
+    } else if (tid < m) qcode[tid] = f.qcodes[(size_t)qi * m + tid];
+    PQF_STAMP(7);
 
     // ---- 1. find_nearest_centroids: the num_probes nearest by (distance, index) among the distances of ivf_prep_kernel
     int np = f.num_probes;
     if (COARSE) {
-        constexpr int R1 = 8;   // <= 8 192 centroids
         const uint32_t lpad = f.cent_ntiles * MDB_TILE;
         const float* dist = f.cdist + (size_t)qi * lpad;
-        uint32_t v[R1];
-#pragma unroll
-        for (int r = 0; r < R1; ++r) {
-            const uint32_t idx = (uint32_t)(r * PQF_BLOCK + tid);
-            v[r] = idx < f.num_clusters ? f32_orderable(dist[idx]) : 0xFFFFFFFFu;
-            if (v[r] == 0xFFFFFFFFu && idx < f.num_clusters) v[r] = 0xFFFFFFFEu;   // (the image of a negative NaN: kept distinct from "none")
-        }
         np = min(np, (int)f.num_clusters);
-        const uint32_t T1 = block_kth_bound<R1>(v, (uint32_t)np, hist, red);
+        uint32_t thr1 = 0xFFFFFFFFu;   // image of an upper bound of the np-th distance (tightens chunk by chunk)
+        for (uint32_t c0 = 0; c0 < f.num_clusters; c0 += PQF_R1 * PQF_BLOCK) {
+            uint32_t v[PQF_R1];
 #pragma unroll
-        for (int r = 0; r < R1; ++r) {
-            const bool in = v[r] <= T1 && v[r] != 0xFFFFFFFFu;
-            const unsigned long long bm = __ballot(in);
-            if (bm) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&misc[2], (uint32_t)__popcll(bm));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                const uint32_t pos = base + (uint32_t)__popcll(bm & lt_mask);
-                if (in && pos < PQF_CAP) ck[pos] = ((uint64_t)v[r] << 32) | (uint32_t)(r * PQF_BLOCK + tid);
+            for (int r = 0; r < PQF_R1; ++r) {
+                const uint32_t idx = c0 + (uint32_t)(r * PQF_BLOCK + tid);
+                v[r] = idx < f.num_clusters ? min(f32_orderable(dist[idx]), 0xFFFFFFFEu) : 0xFFFFFFFFu;   // (all ones = "none")
+            }
+            if (c0 == 0) PQF_SUB(8);
+            thr1 = min(thr1, block_kth_bound<PQF_R1>(v, (uint32_t)np, hist, flip));
+            if (c0 == 0) PQF_SUB(9);
+#pragma unroll
+            for (int r = 0; r < PQF_R1; ++r) {
+                const bool in = v[r] <= thr1 && v[r] != 0xFFFFFFFFu;
+                const unsigned long long bm = __ballot(in);
+                if (bm) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&misc[2], (uint32_t)__popcll(bm));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const uint32_t pos = base + (uint32_t)__popcll(bm & lt_mask);
+                    if (in && pos < PQF_CAP) ck[pos] = ((uint64_t)v[r] << 32) | (c0 + (uint32_t)(r * PQF_BLOCK + tid));
+                }
             }
         }
         __syncthreads();
+        PQF_SUB(10);
         const uint32_t nc1 = misc[2];
         if (nc1 <= PQF_CAP) {
             // rank by counting: keys are distinct (the index is part of the key)
@@ -1187,9 +1222,9 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
             // thousands of centroids tie with the np-th: the streaming selector over all of them
             BlockSelect<PQF_BLOCK> sel;
             sel.init(sel_lds, np);
-#pragma unroll
-            for (int r = 0; r < R1; ++r) {
-                sel.offer(v[r] == 0xFFFFFFFFu ? MDB_KEY_MAX : (((uint64_t)v[r] << 32) | (uint32_t)(r * PQF_BLOCK + tid)));
+            for (uint32_t i0 = 0; i0 < f.num_clusters; i0 += PQF_BLOCK) {
+                const uint32_t idx = i0 + (uint32_t)tid;
+                sel.offer(idx < f.num_clusters ? (((uint64_t)min(f32_orderable(dist[idx]), 0xFFFFFFFEu) << 32) | idx) : MDB_KEY_MAX);
                 sel.round_end();
             }
             sel.finish();
@@ -1199,11 +1234,12 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
         if (tid < 64) probes_l[tid] = tid < np ? a.probes[(size_t)qi * a.probe_stride + tid] : 0xFFFFFFFFu;
     }
+    __syncthreads();   // qcode (and probes_l)
     PQF_STAMP(1);
     // ---- 2. the query's own codebook rows (codes from ivf_prep_kernel), then the bound table (ivf_scan_pq3_kernel's arithmetic)
     for (int i = tid; i < m * SUBDIM; i += PQF_BLOCK) {
         const int s = i / SUBDIM;
-        qv[i] = cb[((size_t)s * K + f.qcodes[(size_t)qi * m + s]) * SUBDIM + (i % SUBDIM)];
+        qv[i] = cb[((size_t)s * K + qcode[s]) * SUBDIM + (i % SUBDIM)];
     }
     __syncthreads();   // qv, probes_l
     // ... and the flattened tile sequence of the probed lists (wave 0; independent of the table)
@@ -1244,7 +1280,8 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         // (1 +- 2^-17) of the real total: shrink / stretch by 1e-5 / 2e-5, then round the bf16 mantissa outwards
         const uint32_t lo = __float_as_uint(__fmul_rn(sum, 0.99999f)) >> 16;
         const uint32_t hi = (__float_as_uint(__fmul_rn(sum, 1.00002f)) + 0xFFFFu) >> 16;
-        btab[i] = sum != sum ? 0x7FC07FC0u : ((hi << 16) | lo);
+        const float nanv = __uint_as_float(0x7FC00000u);
+        btab[i] = sum != sum ? make_float2(nanv, nanv) : make_float2(__uint_as_float(lo << 16), __uint_as_float(hi << 16));
     }
     __syncthreads();   // btab, pstart, ppref
     PQF_STAMP(2);
@@ -1258,9 +1295,9 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
 #pragma unroll
             for (int bi = 0; bi < 4; ++bi) {
                 const uint32_t code = (cwv[w] >> (8 * bi)) & 0xFFu;
-                const uint32_t e = btab[((w * 4 + bi) << nbits) + code];
-                lb = __fadd_rn(lb, __uint_as_float(e << 16));
-                ub = __fadd_rn(ub, __uint_as_float(e & 0xFFFF0000u));
+                const float2 e = btab[((w * 4 + bi) << nbits) + code];   // one 8-byte LDS read, one packed add
+                lb = __fadd_rn(lb, e.x);
+                ub = __fadd_rn(ub, e.y);
             }
         }
     };
@@ -1306,23 +1343,22 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     // ---- 3. bounds pass, a chunk of 64 tiles at a time: wave w takes tiles c0 + w + 16 x (x < 4), all four fetched at once
     uint32_t thr_ub = 0xFFFFFFFFu;   // image of an upper bound of the k-th exact distance (tightens chunk by chunk)
     for (int c0 = 0; c0 < T; c0 += PQF_NW * PQF_TPW) {
-        uint32_t pid[PQF_TPW], cw[PQF_TPW][MW], slot0[PQF_TPW];
+        uint32_t pid[PQF_TPW], cw[PQF_TPW][MW];
 #pragma unroll
         for (int x = 0; x < PQF_TPW; ++x) {
             const int t = c0 + wave + PQF_NW * x;
             pid[x] = 0xFFFFFFFFu;
-            slot0[x] = 0;
 #pragma unroll
             for (int w = 0; w < MW; ++w) cw[x][w] = 0;
             if (t < T) {   // wave-uniform
                 const uint32_t tile = tile_of(t);
-                slot0[x] = tile * MDB_TILE;
                 pid[x] = a.slot_ids[(size_t)tile * MDB_TILE + lane];
                 const uint32_t* cwp = codes + (size_t)tile * MW * MDB_TILE + lane;
 #pragma unroll
                 for (int w = 0; w < MW; ++w) cw[x][w] = cwp[(size_t)w * MDB_TILE];
             }
         }
+        if (c0 == 0) PQF_SUB(11);
         uint32_t tw[PQF_TPW], aw[PQF_TPW];
 #pragma unroll
         for (int x = 0; x < PQF_TPW; ++x) {
@@ -1330,6 +1366,7 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
             tw[x] = a.tomb[u.tomb_base + (pz >> 5)];
             aw[x] = a.allow[(size_t)qi * a.allow_stride + ((pz >> 5) & a.allow_mask)];
         }
+        if (c0 == 0) PQF_SUB(12);
         uint32_t ubi[PQF_TPW], lbi[PQF_TPW];
 #pragma unroll
         for (int x = 0; x < PQF_TPW; ++x) {
@@ -1345,7 +1382,9 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
                 lbi[x] = lb == lb ? min(f32_orderable(__fmul_rn(lb, 0.99998f)), 0xFFFFFFFEu) : 0u;   // a NaN bound always survives: the exact pass reports it
             }
         }
-        thr_ub = min(thr_ub, block_kth_bound<PQF_TPW>(ubi, (uint32_t)a.k, hist, red));
+        if (c0 == 0) PQF_SUB(13);
+        thr_ub = min(thr_ub, block_kth_bound<PQF_TPW>(ubi, (uint32_t)a.k, hist, flip));
+        if (c0 == 0) PQF_SUB(14);
 #pragma unroll
         for (int x = 0; x < PQF_TPW; ++x) {
             const bool surv = lbi[x] != 0xFFFFFFFFu && lbi[x] <= thr_ub;
@@ -1355,7 +1394,11 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
                 if (lane == 0) base = atomicAdd(&misc[0], (uint32_t)__popcll(sm));
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 const uint32_t pos = base + (uint32_t)__popcll(sm & lt_mask);
-                if (surv && pos < f.cap) cand[pos] = slot0[x] + (uint32_t)lane;
+                if (surv && pos < f.cap) {   // the exact pass needs no second trip to the posting list
+                    cand[pos * (1 + MW)] = pid[x];
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) cand[pos * (1 + MW) + 1 + w] = cw[x][w];
+                }
             }
         }
     }
@@ -1374,12 +1417,10 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     // ---- 4. exact distances of the candidates, top-k by (distance, point id)
     if (nc <= f.cap) {
         for (uint32_t i = tid; i < nc; i += PQF_BLOCK) {
-            const uint32_t slot = cand[i];
-            const uint32_t* cwp = codes + (size_t)(slot / MDB_TILE) * MW * MDB_TILE + (slot % MDB_TILE);
             uint32_t cwv[MW];
 #pragma unroll
-            for (int w = 0; w < MW; ++w) cwv[w] = cwp[(size_t)w * MDB_TILE];
-            ck[i] = exact_key(a.slot_ids[slot], cwv);
+            for (int w = 0; w < MW; ++w) cwv[w] = cand[i * (1 + MW) + 1 + w];
+            ck[i] = exact_key(cand[i * (1 + MW)], cwv);
         }
         __syncthreads();
         PQF_STAMP(4);
@@ -1467,6 +1508,7 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     if (tid == 0 && f.doc_counts_out) f.doc_counts_out[qi] = (uint32_t)c;
     PQF_STAMP(6);
 #undef PQF_STAMP
+#undef PQF_SUB
 }
 
 // keys (distance, point id) -> (u128 doc id, score) rows ordered by IdWithScore (score, doc id).
@@ -2138,7 +2180,7 @@ bool IvfSet::fused_ok(size_t b, size_t k, size_t num_probes, bool have_probes) c
     if (!(pq.subdim == 4 || pq.subdim == 8 || pq.subdim == 16 || pq.subdim == 32)) return false;
     if (k < 1 || k > 64 || num_probes < 1 || num_probes > 64 || b == 0) return false;
     if (b >= (size_t)std::max<long long>(1, ctx->opt.pq_two_phase_min_b) && !ctx->opt.pq_no_two_phase) return false;
-    if (!have_probes && (num_probes > blobs[0].num_clusters || blobs[0].num_clusters > 8192)) return false;
+    if (!have_probes && (num_probes > blobs[0].num_clusters || blobs[0].num_clusters > 16384)) return false;
     return true;
 }
 
@@ -2187,14 +2229,22 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
         MDB_HIP(ctx, hipMemsetAsync(dbg, 0, 256, ctx->stream));
         fa.dbg = (unsigned long long*)dbg;
     }
-    fa.cap = (uint32_t)std::min<long long>(PQF_CAP, std::max<long long>(1, ctx->opt.pqf_cap));
+    const uint32_t cap_max = mw == 8 ? 1024u : (uint32_t)PQF_CAP;   // (1 + MW) words per candidate: 8 code words leave room for 1 024
+    fa.cap = (uint32_t)std::min<long long>(cap_max, std::max<long long>(1, ctx->opt.pqf_cap));
+    fa.cand_words = (cap_max * (1u + (uint32_t)mw) + 1u) & ~1u;
     // launch 1: every (query, centroid) distance + the queries' codes
-    const unsigned quant_blocks = (unsigned)((b * (size_t)pq.m + 3) / 4);
-    ivf_prep_kernel<<<dim3(fa.coarse_blocks + quant_blocks), 256, 0, ctx->stream>>>(fa, pq.codebook.p, ctx->d_flags);
+    const bool quant_in_prep = ctx->opt.pqf_quant_in_prep != 0;
+    const unsigned quant_blocks = quant_in_prep ? (unsigned)((b * (size_t)pq.m + 3) / 4) : 0u;
+    fa.quant_blocks = quant_blocks;
+    if (!quant_in_prep) fa.qcodes = nullptr;
+    const size_t prep_lds = coarse_here ? (size_t)PQF_QT * (d4 * 4 + 16) * 4 : 0;
+    if (prep_lds > 48 * 1024) MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
+    if (fa.coarse_blocks + quant_blocks)
+        ivf_prep_kernel<<<dim3(fa.coarse_blocks + quant_blocks), 256, prep_lds, ctx->stream>>>(fa, d_q, pq.codebook.p, fa.cdist, (uint8_t*)qcodes, ctx->d_flags);
     MDB_HIP(ctx, hipGetLastError());
     // launch 2: one block per query
     const size_t sel_bytes = (BlockSelect<PQF_BLOCK>::lds_bytes((int)std::max(k, num_probes)) + 15) & ~(size_t)15;
-    const size_t lds = (64 + PQF_NB + 16 + 16 + 64 + 80 + 64) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * 256 * 4 + PQF_CAP * 4 +
+    const size_t lds = (64 + 2 * (PQF_NB + 32) + 16 + 64 + 80 + 64 + 32) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * 256 * 8 + (size_t)fa.cand_words * 4 +
                        PQF_CAP * 8 + 64 * 8 * 3 + 64 * 4 + sel_bytes;
     {
     ProfScope prof(ctx);
@@ -2222,8 +2272,10 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
         unsigned long long h[16];
         MDB_HIP(ctx, hipMemcpyAsync(h, fa.dbg, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
         MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[pqf] b=%zu P=%zu k=%zu cycles: probes %llu table %llu bounds %llu exact %llu rank %llu remap %llu total %llu\n", b, num_probes, k,
-                h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+        fprintf(stderr, "[pqf] b=%zu P=%zu k=%zu cycles: probes %llu (load %llu kth %llu append %llu rank %llu) table %llu bounds %llu (fetch %llu tomb %llu lookup %llu kth %llu "
+                "append %llu) exact %llu rank %llu remap %llu total %llu\n", b, num_probes, k,
+                h[1] - h[0], h[8] - h[0], h[9] - h[8], h[10] - h[9], h[1] - h[10], h[2] - h[1], h[3] - h[2], h[11] - h[2], h[12] - h[11], h[13] - h[12], h[14] - h[13], h[3] - h[14],
+                h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
     }
     return MDB_OK;
 }

@@ -363,6 +363,9 @@ def test_ivf_pq_fused_step(ctx, oracle, n, d, sub, L, P, k):
             st = ctx.stats()
             assert_result_rows(got, want, b)
             assert_result_rows(g.search_with_centroids_and_remap(q, probes, k), want, b)   # caller's probes
+    with ctx.option("MDB_PQF_QUANT_IN_PREP", 1):                                 # the queries' codes from the prep launch instead of the per-query kernel
+        assert_result_rows(g.search(q, k, P), want, b)
+        assert_result_rows(g.search_with_centroids_and_remap(q, probes, k), want, b)
     with ctx.option("MDB_PQ_NO_FUSED", 1):
         ref = g.search(q, k, P)
         st_ref = ctx.stats()
