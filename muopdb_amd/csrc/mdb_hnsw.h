@@ -39,7 +39,6 @@ struct HnswSet {
     std::vector<HnswBlobInfo> blobs;
     std::vector<HnswUserDev> h_users;
     uint32_t max_n = 0, max_stride = 0;
-    bool rows_unique = true;       // no adjacency row names a point twice (checked at load): the beam kernel may test a row's visited bits read-only ahead of time
     uint64_t total_rows = 0;
     DevBuf<uint8_t> d_index;       // uploaded graph file (doc ids are read from it)
     DevBuf<HnswUserDev> d_users;
@@ -55,7 +54,6 @@ struct HnswSet {
         pq.metric = src.pq.metric; pq.dimension = src.pq.dimension; pq.subdim = src.pq.subdim; pq.num_bits = src.pq.num_bits;
         pq.m = src.pq.m; pq.K = src.pq.K; pq.h_codebook = src.pq.h_codebook; pq.codebook.borrow(src.pq.codebook);
         blobs = src.blobs; h_users = src.h_users; max_n = src.max_n; max_stride = src.max_stride; total_rows = src.total_rows;
-        rows_unique = src.rows_unique;
         d_index.borrow(src.d_index); d_users.borrow(src.d_users); d_adj.borrow(src.d_adj);
         d_upper_first.borrow(src.d_upper_first); d_level.borrow(src.d_level); d_vecs.borrow(src.d_vecs);
     }

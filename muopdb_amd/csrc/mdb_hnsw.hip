@@ -49,7 +49,6 @@ struct HnswArgs {
     unsigned long long vis_words;   // words per query (global bitmap) or LDS words
     uint32_t* flags;
     unsigned long long* counters;   // [0] distance evals, [1] expanded nodes
-    int rows_unique;                // no adjacency row holds a point twice: the visited test of a row may run ahead, read-only
 };
 
 // candidate key: ascending u64 == (distance asc, id DESC): BinaryHeap<(-d, id)>::pop order
@@ -796,14 +795,6 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
     for (int c = 0; c < NCH; ++c) rowv[c] = rowr[c] = 0xFFFFFFFFu;
     uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
     bool ru_valid = false, stop = false;
-    // SPEC: the runner-up is the next node 92 % of the time and its row arrives while wave 0 would only wait at barrier 2 — its
-    // visited test runs there, READ-ONLY (nothing marks a bit between this step's P2 and the next one's), and the next P2 shrinks
-    // to fire-and-forget marks + the compaction store: no LDS round trip on wave 0's chain.  Needs rows without duplicate ids
-    // (a read-only test would call both copies new; checked when the graph is loaded).
-    constexpr bool SPEC = ROW64 && VIS_LDS && !PF;
-    const bool spec_on = SPEC && a.rows_unique != 0;
-    unsigned long long spec_mask = 0;   // new neighbours of the runner-up's row (valid while spec_have)
-    bool spec_have = false, spec_any = false, spec_ok = false;   // spec_ok: rowv IS that row and spec_mask its new neighbours
     int ru_closer = 0;                 // #{b in B : d_b < d_runner-up}, counted in the shadow of P3 (the stop test of P4)
     uint32_t evals = 0, expanded = 0;  // per query: far below 2^32
     bool nan_seen = false, overflow = false;
@@ -893,7 +884,6 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
             n = 1;
             fbound = SLOT_EMPTY;
             stop = false;
-            spec_ok = false;
             ru_valid = false;
             evals += 1;
             if (PF && lane == 0) misc[11] = 0;
@@ -904,17 +894,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
             PIPE_TB(t_p2);
             if (wave == 0) {
                 uint32_t nnew = 0xFFFFFFFFu;
-                if (SPEC && spec_ok && !stop && !overflow) {
-                    // the runner-up became the node: its row's new neighbours are known — mark (no return value: no wait), compact
-                    const uint32_t nbr = rowv[0];
-                    if ((spec_mask >> lane) & 1ull) {
-                        __hip_atomic_fetch_or(&vis[nbr >> 5], 1u << (nbr & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        nb_id[__popcll(spec_mask & lt_mask)] = nbr;
-                    }
-                    nnew = (uint32_t)__popcll(spec_mask);
-                    expanded += spec_any ? 1 : 0;
-                    evals += nnew;
-                } else if (!stop && !overflow) {
+                if (!stop && !overflow) {
                     nnew = 0;
                     bool any = false;
 #pragma unroll
@@ -966,17 +946,6 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                     ru_closer = 0;
 #pragma unroll
                     for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
-                }
-                if (SPEC) {
-                    spec_have = false;
-                    if (spec_on && ru_valid) {   // in the slack before barrier 2: the runner-up's visited test, read-only
-                        const uint32_t nbr = rowr[0];
-                        bool isnew = false;
-                        if (nbr != 0xFFFFFFFFu) isnew = !((vis[nbr >> 5] >> (nbr & 31)) & 1u);
-                        spec_mask = __ballot(isnew);
-                        spec_any = __ballot(nbr != 0xFFFFFFFFu) != 0;
-                        spec_have = true;
-                    }
                 }
             } else if (PF && wave == 5) {
                 // ---- prefetch wave: the runner-up's row, requested as soon as wave 0 names it (it arrives around the barrier)
@@ -1127,7 +1096,6 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                             }
                             ru_valid = beam_best_id(cdv, bi, ru_o, ru_id);  // may have been dropped too
                             if (ru_valid) load_row(ru_id, rowr);
-                            spec_have = false;   // (a new row: its visited test was not run)
                             ru_closer = 0;   // recount over the compacted B (it holds the earlier chunks' pushes)
 #pragma unroll
                             for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
@@ -1199,9 +1167,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                                 if (bi[r] == ru_id) cdv[r] = SLOT_EMPTY;   // ids are unique in B (unused slots: already EMPTY)
 #pragma unroll
                             for (int c = 0; c < NCH; ++c) rowv[c] = rowr[c];
-                            spec_ok = SPEC && spec_have;
                         } else {
-                            spec_ok = false;
 #pragma unroll
                             for (int r = 0; r < BREGS; ++r)
                                 if (bi[r] == best_id) cdv[r] = SLOT_EMPTY;
@@ -1372,19 +1338,6 @@ static mdb_status parse_hnsw_blob(mdb_ctx* ctx, const uint8_t* b, size_t len, si
     return MDB_OK;
 }
 
-// true when row[0..n) names no point twice (rows have at most HNSW_MAX_STRIDE entries; n <= 64 is what the beam kernel's
-// speculative visited test cares about)
-static bool hnsw_row_unique(const uint32_t* row, size_t n) {
-    if (n < 2) return true;
-    uint32_t tmp[64];
-    if (n > 64) return true;   // not a ROW64 graph: the speculation is off anyway
-    std::copy(row, row + n, tmp);
-    std::sort(tmp, tmp + n);
-    for (size_t i = 1; i < n; ++i)
-        if (tmp[i] == tmp[i - 1]) return false;
-    return true;
-}
-
 mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
                          const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant, uint32_t dim) {
     ctx = ctx_;
@@ -1484,7 +1437,6 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
                 if (e >= nv) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW edge %u of point %zu is outside the vector storage (%llu vectors)", e, p, (unsigned long long)nv);
                 h_adj[u.adj0_off + p * S0 + (x - a0)] = e;
             }
-            if (rows_unique && !hnsw_row_unique(&h_adj[u.adj0_off + p * S0], (size_t)(a1 - a0))) rows_unique = false;
         }
         // rows of the upper layers
         uint32_t rows = 0;
@@ -1506,7 +1458,6 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
                     if (e >= nv) return mdb_fail(ctx, MDB_ERR_FORMAT, "HNSW upper-layer edge %u is outside the vector storage", e);
                     h_adj[u.adjU_off + r * SU + (x - a0)] = e;
                 }
-                if (rows_unique && !hnsw_row_unique(&h_adj[u.adjU_off + r * SU], (size_t)(a1 - a0))) rows_unique = false;
             }
         }
         // dense upper layers (hnsw_upper_row): every (layer, point) gets a row slot — affordable up to 1 GiB per graph
@@ -1606,7 +1557,6 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     a.smax = std::max<int>(64, ((int)max_stride + 63) / 64 * 64);
     a.k = (int)k;
     a.out_keys = d_keys; a.out_counts = d_counts; a.flags = ctx->d_flags; a.counters = ctx->d_counters;
-    a.rows_unique = rows_unique && !ctx->opt.hnsw_no_spec ? 1 : 0;
     size_t lds_base = (size_t)a.ef_cap * 8 + (size_t)a.cand_cap * 8 + (size_t)a.smax * 8 + (size_t)dpad * 4 + 64;
     if (ef <= 256) lds_base = std::max<size_t>(lds_base, (size_t)BEAM_LDS_QS + (size_t)dpad * 4);  // the beam kernel's fixed layout
     size_t words = ((size_t)max_n + 31) / 32 + 1;
