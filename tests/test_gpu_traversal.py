@@ -204,6 +204,44 @@ def test_hnsw_beam_overflow_falls_back_to_general_kernel(ctx, oracle):
         assert st["distance_evals"] == evals and st["expanded_nodes"] == expanded
 
 
+def test_hnsw_rows_with_duplicate_edges(ctx, oracle):
+    """An adjacency row that names a point twice (nothing in the file format forbids it): the reference skips the second copy
+    as already visited, and so must the kernels' test-and-set (two lanes of one row hitting the same bit: exactly one is new) —
+    rows AND counters equal the oracle's."""
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import BlockBasedHnsw
+    rng = np.random.default_rng(41)
+    n, d, M = 1500, 32, 10
+    v = H.sift_like(n, d, n_clusters=12, seed=9)
+    b = oracle.HnswBuilder(d, M, 3, 40, 0, 1)
+    b.insert(v)
+    layers, eps = b.layers(), b.entry_points()
+    if len(layers) > 1:   # the reader's entry point: FIRST point of the top layer
+        top = layers[-1]
+        ordered = {eps[0]: top[eps[0]]}
+        ordered.update({p_: e for p_, e in top.items() if p_ != eps[0]})
+        layers[-1] = ordered
+    dup = 0
+    for p_ in list(layers[0].keys()):
+        e = list(layers[0][p_])
+        if len(e) >= 3 and rng.random() < 0.3:      # repeat one or two of its neighbours, anywhere in the row
+            for _ in range(int(rng.integers(1, 3))):
+                e.insert(int(rng.integers(0, len(e) + 1)), e[int(rng.integers(0, len(e)))])
+            layers[0][p_] = e
+            dup += 1
+    assert dup > 100
+    hidx, hvec = F.write_hnsw_index(layers, list(range(n)), d), F.write_vector_file(v)
+    g, o = BlockBasedHnsw(ctx, hidx, hvec, d), oracle.BlockBasedHnsw(hidx, hvec, d)
+    q = (v[rng.integers(0, n, 30)] + rng.normal(0, 4, (30, d))).astype(np.float32)
+    for k, ef in [(10, 100), (5, 16), (20, 256)]:
+        o.stats()
+        want = o.ann_search(q, k, ef)
+        evals, expanded = o.stats()
+        assert_result_rows(g.ann_search(q, k, ef), want, len(q))
+        st = ctx.stats()
+        assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded), (k, ef)
+
+
 def test_hnsw_ties_and_duplicates(ctx, oracle):
     # many exact distance ties: pop order (largest id first) and eviction order must match
     from muopdb_amd.index import BlockBasedHnsw
