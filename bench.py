@@ -66,6 +66,21 @@ def measured_traffic(kind, cfg):
     return None, None
 
 
+def measured_mfma(kind, cfg):
+    """roofline.mfma_busy: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of the matrix-core filter kernel from the committed PMC pass
+    (profiles/r*_traffic.json "_mfma"; same matching rule as measured_traffic), else None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        with open(path) as f:
+            j = json.load(f)
+        e, t = j.get("_mfma", {}).get(kind), j.get(kind)
+        if e and t and t["match"].get("data", "legacy") == cfg.get("data") and all(cfg.get(k) == v for k, v in t["match"].items() if k != "data"):
+            return dict(mfma_busy_of_sq_busy=e["mfma_busy_cycles"] / e["sq_busy_cycles"] if e.get("sq_busy_cycles") else None,
+                        mfma_busy_cycles=e["mfma_busy_cycles"], sq_busy_cycles=e.get("sq_busy_cycles"), grbm_gui_active=e.get("grbm_gui_active"),
+                        source=e["source"])
+    return None
+
+
 def dump(args, rank, sub, **files):
     """--dump-dir: the workload's files for examples/replay_search.cpp (torch-free PMC passes)."""
     if not args.dump_dir or rank != 0:
@@ -107,6 +122,7 @@ def parse():
     p.add_argument("--no-c4-full", action="store_true", help="all: skip the full-size C4 workload (1024 users, 30.7 GB, ~60 s)")
     p.add_argument("--streams", type=int, default=4, help="hnsw: extra measurement with this many batches in flight (0/1 = skip)")
     p.add_argument("--dump-dir", default=None, help="write index files + queries for examples/replay_search.cpp")
+    p.add_argument("--dump-big", action="store_true", help="--dump-dir also for workloads above 8 GB (full C4: 30 GB)")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--sift-dir", default=None, help="directory holding sift_base.fvecs / sift_query.fvecs / sift_groundtruth.ivecs: "
                                                     "the C2/C3 workloads then run on the real SIFT-1M (data: sift1m) instead of synthetic rows")
@@ -417,6 +433,8 @@ def run_flat(env, n=None, batch=None):
         r["mfma_tflops"] = 3 * 2.0 * batch * (hi - lo) * d / (r["kernel_ms"] * 1e-3) / 1e12
         r["mfma_frac_of_bf16_peak"] = r["mfma_tflops"] / 2500.0
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("flat_b64" if batched else "flat", out["config"])
+    if batched:
+        out["roofline"]["mfma_busy"] = measured_mfma("flat_b64", out["config"])
     if env.cpu:
         import oracle
         xb, qh = x[lo:hi].cpu().numpy(), queries[warm * batch:].cpu().numpy()
@@ -436,8 +454,9 @@ def run_flat(env, n=None, batch=None):
 
 # ------------------------------------------------------------------------------------------ IVF-PQ
 def pq_scan_kernel_name(batch):
-    """the library's choice (mdb_ivf.hip): two-phase scan (bounds, then exact distances of the candidates) from 512 queries per batch"""
-    return "ivf_scan_pq3_kernel+ivf_pq3_refine_kernel" if batch >= 512 else "ivf_scan_pq2_kernel"
+    """the library's choice (mdb_ivf.hip): two-phase scan (bounds, then exact distances of the candidates) from 512 queries per batch;
+    below, the fused step (ivf_prep_kernel + ivf_pq_fused_kernel: the bracketed kernel is the per-query one)"""
+    return "ivf_scan_pq3_kernel+ivf_pq3_refine_kernel" if batch >= 512 else "ivf_pq_fused_kernel"
 
 
 def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=0):
@@ -605,6 +624,7 @@ def run_c5(env, steps=None, warm=None):
                                      scored_per_query=m["scored"] / (steps * batch)))
     out["steps"], out["warmup"] = steps, warm
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("c5", out["config"])
+    out["roofline"]["coarse_filter_mfma_busy"] = measured_mfma("c5", out["config"])
     out["recall_note"] = "a shard's rows are a partial result (1/8 of the probed lists): recall is defined after the all-gather merge only"
     if env.cpu:
         import oracle
@@ -676,7 +696,7 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
         queries = torch.stack([base[int(u)][int(r)] for u, r in zip(quser.tolist(), qrow.tolist())]) + noise.cuda()
         queries = (queries / queries.norm(dim=1, keepdim=True)).contiguous()
         desc = "isotropic Gaussian unit-norm rows (round-1 generator)"
-    if args.dump_dir and U * per * d * 4 < (8 << 30):   # (the full C4 would write 30 GB)
+    if args.dump_dir and (U * per * d * 4 < (8 << 30) or args.dump_big):   # (the full C4 writes 30 GB: --dump-big)
         dump(args, rank, "spann", hnsw_index=cat["hnsw_index"], hnsw_vectors=cat["hnsw_vectors"], ivf_index=cat["ivf_index"],
              vectors=cat["ivf_vectors"], user_table=cat["user_table"],
              **{"queries.f32": queries.cpu().numpy(), "users.u64": (quser + 1).numpy().astype(np.uint64)})
@@ -733,7 +753,7 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
                        "data": args.data},
                roofline=hbm_roofline("ivf_scan_f32_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch), centroid_hnsw_kernel_ms=m["hnsw_ms"]))
-    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("spann", out["config"])
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("spann_full" if U >= 1024 else "spann", out["config"])
     out["steps"], out["warmup"] = steps, warm
     if not (args.no_sweep or no_sweep):
         sweep = []

@@ -17,12 +17,16 @@
 #include "muopdb_host.hpp"
 
 static std::vector<char> slurp(const std::string& p, bool required = true) {
-    std::ifstream f(p, std::ios::binary);
+    std::ifstream f(p, std::ios::binary | std::ios::ate);
     if (!f) {
         if (required) throw std::runtime_error("cannot open " + p);
         return {};
     }
-    return std::vector<char>(std::istreambuf_iterator<char>(f), {});
+    const std::streamsize n = f.tellg();   // (one read of the whole file: the full C4 dump is 30 GB)
+    f.seekg(0);
+    std::vector<char> out((size_t)n);
+    if (n && !f.read(out.data(), n)) throw std::runtime_error("short read of " + p);
+    return out;
 }
 
 int main(int argc, char** argv) {

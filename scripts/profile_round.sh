@@ -7,13 +7,16 @@
 #           with sys / runtime trace flags.
 # Output: gpurun_out/<tag>/<workload>_{kernel_stats.csv,pmc_FETCH_SIZE.csv,pmc_WRITE_SIZE.csv,replay.log} + bench_all.json;
 # the ones to be judged are copied to profiles/ by hand.
-# usage: scripts/profile_round.sh <tag> [workloads...]   (default: hnsw flat_b1 flat_b64 ivfpq spann c5)
+#   pass 4  (flat_b64, c5: the matrix-core filters) rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over the same replay:
+#           MFMA-busy against the kernel's own active cycles (north_star: "MFMA-busy against chip peak")
+#   c4full  the full-size C4 (1024 users, 30.7 GB): bench.py --users 1024 --dump-big writes the files, the replay is profiled like the others
+# usage: scripts/profile_round.sh <tag> [workloads...]   (default: hnsw flat_b1 flat_b64 ivfpq spann c5 c4full)
 TAG=$1; shift
-WL="$@"; [ -z "$WL" ] && WL="hnsw flat_b1 flat_b64 ivfpq spann c5"
+WL="$@"; [ -z "$WL" ] && WL="hnsw flat_b1 flat_b64 ivfpq spann c5 c4full"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 DUMP=/tmp/mdb_dump_round
-PAT="hnsw_|flat_scan|flat_mfma|flat_bf16|flat_refine|sample_bound|ivf_scan|ivf_pq3|merge_keys"
+PAT="hnsw_|flat_scan|flat_mfma|flat_bf16|flat_refine|sample_bound|ivf_scan|ivf_pq3|ivf_prep|ivf_pq_fused|merge_keys"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # every workload's files + the un-instrumented bench line
@@ -26,6 +29,9 @@ for W in $WL; do
     ivfpq)    SUB=ivfpq;    REPLAY="ivfpq $DUMP/ivfpq 128 10 16 256 20";      BARGS="--workload ivfpq --no-sweep --streams 0";;
     spann)    SUB=spann;    REPLAY="mspann $DUMP/spann 768 10 16 128 20 200"; BARGS="--workload spann --users 128 --no-sweep";;
     c5)       SUB=c5;       REPLAY="ivfpq $DUMP/c5 128 10 64 4096 6";         BARGS="";;
+    c4full)   SUB=spann;    REPLAY="mspann $DUMP/c4full/spann 768 10 16 1024 6 200"; BARGS="";
+              df -h /tmp | tail -1 > $OUT/c4full_df.log
+              (time timeout 900 python $REPO/bench.py --workload spann --users 1024 --no-sweep --steps 6 --warmup 2 --no-cpu-baseline --dump-dir $DUMP/c4full --dump-big) > $OUT/c4full_bench.json 2> $OUT/c4full_bench.err;;
   esac
   if [ -n "$BARGS" ]; then
     rm -rf /tmp/prof_stats_$W
@@ -44,6 +50,13 @@ for W in $WL; do
     echo "rc=$?" >> $OUT/${W}_replay_$C.log
     for f in /tmp/prof_${C}_$W/*counter_collection.csv; do [ -f "$f" ] && (head -1 $f; grep -E "$PAT" $f | head -400) > $OUT/${W}_pmc_$C.csv; done
   done
+  case $W in flat_b64|c5)
+    rm -rf /tmp/prof_MFMA_$W
+    timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/prof_MFMA_$W -o replay -- $REPO/muopdb_amd/replay_search $REPLAY > $OUT/${W}_replay_MFMA.log 2>&1
+    echo "rc=$?" >> $OUT/${W}_replay_MFMA.log
+    for f in /tmp/prof_MFMA_$W/*counter_collection.csv; do [ -f "$f" ] && (head -1 $f; grep -E "flat_bf16|flat_mfma" $f | head -600) > $OUT/${W}_pmc_MFMA.csv; done;;
+  esac
+  [ $W = c4full ] && rm -rf $DUMP/c4full
   echo "== $W: $(tail -1 $OUT/${W}_replay.log)"
 done
 rm -rf $DUMP

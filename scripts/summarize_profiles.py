@@ -7,18 +7,24 @@ import csv, json, os, shutil, sys
 tag, rnd = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
-OURS = ("hnsw_", "flat_", "sample_bound", "ivf_", "merge_", "remap_", "spann_", "pq_quantize", "mfma_prep", "unpack_", "kmeans_")
+OURS = ("hnsw_", "flat_", "sample_bound", "ivf_", "merge_", "remap_", "spann_", "pq_quantize", "mfma_prep", "unpack_", "kmeans_", "pad_queries")
 WL = {  # workload -> (dominant kernel prefix, bench.py traffic key, config match)
     "hnsw": ("hnsw_beam_kernel", "hnsw", {"n": 1000000, "dim": 128, "batch": 64, "ef": 200, "k": 10}),
     "flat_b1": ("flat_scan_kernel", "flat", {"n": 1000000, "dim": 128, "batch": 1, "k": 10}),
     "flat_b64": ("flat_bf16_filter_kernel<0, 2, 8, false>", "flat_b64", {"n": 1000000, "dim": 128, "batch": 64, "k": 10}),
-    "ivfpq": ("ivf_scan_pq2_kernel", "ivfpq", {"n": 1000000, "dim": 128, "batch": 256, "k": 10, "nprobe": 16}),
+    "ivfpq": ("ivf_pq_fused_kernel", "ivfpq", {"n": 1000000, "dim": 128, "batch": 256, "k": 10, "nprobe": 16}),
     "spann": ("ivf_scan_f32_kernel", "spann", {"n": 1250048, "dim": 768, "batch": 128, "k": 10}),
     "c5": ("ivf_scan_pq3_kernel", "c5", {"dim": 128, "batch": 4096, "k": 10, "nprobe": 64}),   # two-phase scan: phase 1 dominates
+    "c4full": ("ivf_scan_f32_kernel", "spann_full", {"n": 10000384, "dim": 768, "batch": 1024, "k": 10}),
 }
 bench = json.loads(open(os.path.join(src, "bench_all.json")).read().strip().splitlines()[-1])
 shutil.copy(os.path.join(src, "bench_all.json"), os.path.join(dst, "%s_bench_all.json" % rnd))
 lines = {"hnsw": bench}
+c4p = os.path.join(src, "c4full_bench.json")
+if os.path.exists(c4p):
+    c4l = [x for x in open(c4p) if x.startswith("{")]
+    if c4l:
+        lines["c4full"] = json.loads(c4l[-1])
 for k, v in bench.get("workloads", {}).items():
     lines[{"flat_1m_b1": "flat_b1", "flat_1m_b64": "flat_b64", "ivfpq_c3": "ivfpq", "spann_c4_128u": "spann", "c5_shard_per_gpu": "c5"}.get(k, k)] = v
 traffic = {"_note": "HBM traffic per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the torch-free "
@@ -51,6 +57,21 @@ for w, (kern, key, match) in WL.items():
                 per[r["Dispatch_Id"]] += float(r["Counter_Value"])   # one row per XCD / dimension instance: sum per dispatch
         disp = sorted(per.items(), key=lambda kv: int(kv[0]))[1:]     # skip the warm-up call
         vals[c] = sum(v for _, v in disp) / max(len(disp), 1)
+    # matrix-core busy cycles of the filter kernels against their own active cycles (SQ_BUSY_CYCLES) and the chip's (GRBM_GUI_ACTIVE)
+    pm = os.path.join(src, "%s_pmc_MFMA.csv" % w)
+    if os.path.exists(pm):
+        shutil.copy(pm, os.path.join(dst, "%s_%s_pmc_MFMA.csv" % (rnd, w)))
+        acc = {}
+        for r in csv.DictReader(open(pm)):
+            if "flat_bf16_filter_kernel" in r["Kernel_Name"] and "true>" not in r["Kernel_Name"].split("(")[0][-8:]:
+                acc.setdefault(r["Dispatch_Id"], {}).setdefault(r["Counter_Name"], 0.0)
+                acc[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp = [v for _, v in sorted(acc.items(), key=lambda kv: int(kv[0]))][1:]
+        if disp:
+            mf = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for d in disp) / len(disp)
+            sq = sum(d.get("SQ_BUSY_CYCLES", 0) for d in disp) / len(disp)
+            gr = sum(d.get("GRBM_GUI_ACTIVE", 0) for d in disp) / len(disp)
+            vals["MFMA"] = dict(mfma_busy_cycles=mf, sq_busy_cycles=sq, grbm_gui_active=gr, launches=len(disp))
     rp = os.path.join(src, "%s_replay.log" % w)
     if os.path.exists(rp):
         shutil.copy(rp, os.path.join(dst, "%s_%s_replay.log" % (rnd, w)))
@@ -58,13 +79,16 @@ for w, (kern, key, match) in WL.items():
     m = dict(match, data=cfg.get("data", "lowrank"))
     if w in ("spann", "c5") and "n" in cfg:
         m["n"] = cfg["n"]
+    if "MFMA" in vals:
+        traffic.setdefault("_mfma", {})[key] = dict(vals["MFMA"], source="profiles/%s_%s_pmc_MFMA.csv" % (rnd, w), kernel="flat_bf16_filter_kernel")
     if "FETCH_SIZE" in vals:
         traffic[key] = {"match": m, "kernel": kern.split("<")[0], "fetch_kib": round(vals["FETCH_SIZE"], 1), "write_kib": round(vals.get("WRITE_SIZE", 0.0), 1),
                         "fetch_correction": 2.0, "source": ["profiles/%s_%s_pmc_FETCH_SIZE.csv" % (rnd, w), "profiles/%s_%s_pmc_WRITE_SIZE.csv" % (rnd, w)]}
     r = lines.get(w, {}).get("roofline", {})
     summary[w] = dict(rocprof_avg_ms=avg_ms, bench_kernel_ms=r.get("kernel_ms"), bench_ms_per_step=lines.get(w, {}).get("ms_per_step"),
                       algorithmic_bytes=r.get("bytes_per_launch"),
-                      measured_traffic_bytes=(vals.get("FETCH_SIZE", 0) * 2 + vals.get("WRITE_SIZE", 0)) * 1024 if vals else None)
+                      measured_traffic_bytes=(vals.get("FETCH_SIZE", 0) * 2 + vals.get("WRITE_SIZE", 0)) * 1024 if "FETCH_SIZE" in vals else None,
+                      mfma=vals.get("MFMA"))
 # a partial re-profile (profile_round.sh <tag> hnsw spann) keeps the other workloads' entries of the round
 for name, new in (("traffic", traffic), ("summary", summary)):
     path = os.path.join(dst, "%s_%s.json" % (rnd, name))
