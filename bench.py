@@ -75,8 +75,11 @@ def measured_mfma(kind, cfg):
             j = json.load(f)
         e, t = j.get("_mfma", {}).get(kind), j.get(kind)
         if e and t and t["match"].get("data", "legacy") == cfg.get("data") and all(cfg.get(k) == v for k, v in t["match"].items() if k != "data"):
-            return dict(mfma_busy_of_sq_busy=e["mfma_busy_cycles"] / e["sq_busy_cycles"] if e.get("sq_busy_cycles") else None,
-                        mfma_busy_cycles=e["mfma_busy_cycles"], sq_busy_cycles=e.get("sq_busy_cycles"), grbm_gui_active=e.get("grbm_gui_active"),
+            # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs' matrix cores (32 per v_mfma_f32_32x32x16_bf16,
+            # MI355X_MICROARCH.md); GRBM_GUI_ACTIVE sums the 8 XCCs' active cycles over the launch
+            cyc = e["grbm_gui_active"] / 8.0 if e.get("grbm_gui_active") else None
+            return dict(mfma_busy_frac_of_chip=e["mfma_busy_cycles"] / (1024.0 * cyc) if cyc else None,
+                        mfma_busy_cycles=e["mfma_busy_cycles"], kernel_cycles=cyc, simds=1024, sq_busy_cycles=e.get("sq_busy_cycles"),
                         source=e["source"])
     return None
 

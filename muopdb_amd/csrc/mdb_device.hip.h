@@ -398,6 +398,31 @@ __device__ __forceinline__ uint32_t pq_quantize_wave(const float* __restrict__ s
                                                      const DistPlan& sp, int lane) {
     uint64_t best = ~0ull;  // no centroid strictly below f32::MAX yet (=> code 0)
     const bool rows16 = (subdim & 3) == 0;  // codebook rows are then whole, 16-byte aligned float4s (the arena is)
+    if (K == 256 && subdim == 8) {
+        // the usual codebook (8-bit codes, 8-float subvectors: C3 / C5): this lane's four rows are fetched TOGETHER (eight 16-byte loads,
+        // one latency instead of four dependent round trips), then scored with exact_sums' association for a single 8-lane chunk:
+        // acc[j] = 0 + (q[j] - x[j])^2, raw = 0 + (((0 + acc[0]) + acc[1]) + ... + acc[7])
+        float4 x[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4* row = (const float4*)(cbs + (size_t)(lane + 64 * r) * 8);
+            x[r][0] = row[0];
+            x[r][1] = row[1];
+        }
+        const float q[8] = {sub[0], sub[1], sub[2], sub[3], sub[4], sub[5], sub[6], sub[7]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xv[8] = {x[r][0].x, x[r][0].y, x[r][0].z, x[r][0].w, x[r][1].x, x[r][1].y, x[r][1].z, x[r][1].w};
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = acc_term<MDB_METRIC_L2>(0.0f, q[j], xv[j]);
+            const float raw = __fadd_rn(0.0f, reduce_ordered<8>(acc));
+            if (raw < 3.402823466e+38f) {
+                const uint64_t key = ((uint64_t)f32_orderable(raw) << 32) | (uint32_t)(lane + 64 * r);
+                best = key < best ? key : best;
+            }
+        }
+    } else
     for (int c = lane; c < K; c += 64) {
         float raw[1];
         if (rows16) {

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(BLOCK) void merge_keys_kernel(const uint64_t* __res
     for (int j = threadIdx.x; j < k; j += BLOCK) out[(size_t)blockIdx.x * k + j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
     if (threadIdx.x == 0 && counts) counts[blockIdx.x] = c;
     if (up.zero4 && blockIdx.x == 0 && threadIdx.x < 4) up.zero4[threadIdx.x] = 0ull;
+    if (up.word_dst && blockIdx.x == 0 && threadIdx.x == 0) *up.word_dst = *up.word_src;
     if (up.ids) {  // the caller's final (row id, distance) rows straight from here: no unpack launch, no counts copy
         for (int j = threadIdx.x; j < k; j += BLOCK) {
             const bool have = j < (int)c;
@@ -224,9 +225,9 @@ __global__ void unpack_keys_kernel(const uint64_t* __restrict__ keys, size_t tot
 }
 
 mdb_status merge_keys(mdb_ctx* ctx, const uint64_t* d_partial, size_t per_query, size_t b, size_t k, uint64_t* d_out,
-                      uint32_t* d_counts) {
+                      uint32_t* d_counts, const UnpackOut* unpack) {
     if (b == 0) return MDB_OK;
-    launch_merge_keys(ctx, d_partial, per_query, b, k, d_out, d_counts, nullptr);
+    launch_merge_keys(ctx, d_partial, per_query, b, k, d_out, d_counts, nullptr, unpack);
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
 }
@@ -365,10 +366,13 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     bool fused = false;
     MDB_TRY(mdb_scratch(ctx, 5, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4, &cnts));
-    if (batched)
+    if (batched) {
+        // device outputs: the last merge kernel of the batched path writes the caller's rows itself
+        UnpackOut up{ids_out, dist_out, counts_out};
+        fused = mem == MDB_MEM_DEVICE && k > 0;
         MDB_TRY(flat_topk_keys_mfma(ctx, view_of(flat->ts), flat->aux, flat->metric, dq, qstride, b, bpad, k, (uint64_t*)keys,
-                                    (uint32_t*)cnts, true));
-    else {
+                                    (uint32_t*)cnts, true, fused ? &up : nullptr));
+    } else {
         // device outputs: the merge kernel writes the caller's rows itself (scan + merge are the only two launches)
         UnpackOut up{ids_out, dist_out, counts_out};
         fused = mem == MDB_MEM_DEVICE && k > 0;

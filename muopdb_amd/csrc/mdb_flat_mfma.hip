@@ -84,7 +84,10 @@ void flat_aux_view(const FlatAux& src, FlatAux& dst) {
     dst.bhi.borrow(src.bhi); dst.blo.borrow(src.blo); dst.xnorm.borrow(src.xnorm); dst.rows.borrow(src.rows);
     dst.nk = src.nk; dst.nt32 = src.nt32; dst.split_metric = src.split_metric;
     dst.cooldown = 0;
-    if (src.sample.n && !dst.h_ovf && hipHostMalloc((void**)&dst.h_ovf, 4) == hipSuccess) *dst.h_ovf = 0;
+    if (src.sample.n && !dst.h_ovf && hipHostMalloc((void**)&dst.h_ovf, 4) == hipSuccess) {
+        *dst.h_ovf = 0;
+        if (hipHostGetDevicePointer((void**)&dst.d_ovf_host, dst.h_ovf, 0) != hipSuccess) dst.d_ovf_host = nullptr;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ bf16 x 3 split
@@ -225,10 +228,12 @@ mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t 
     if (!aux.h_ovf) {
         MDB_HIP(ctx, hipHostMalloc((void**)&aux.h_ovf, 4));
         *aux.h_ovf = 0;
+        if (hipHostGetDevicePointer((void**)&aux.d_ovf_host, aux.h_ovf, 0) != hipSuccess) aux.d_ovf_host = nullptr;
     }
     return MDB_OK;
 }
 
+#define QCNT_STRIDE 32   // words between the queries' candidate counters (a 128-byte line each)
 // ------------------------------------------------------------------------------------------ prep
 // one block per (padded) query row: centred query q' = q - mean into dqc, and the admission constant
 // crow[m]: the filter admits (m, x) iff  acc(q'_m.x') >= xh(x') + crow[m]   
@@ -239,9 +244,13 @@ mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t 
 __global__ __launch_bounds__(128) void mfma_prep_kernel(const float* __restrict__ dq, int qstride, int d,
                                                         const float* __restrict__ mean, const uint64_t* __restrict__ skeys,
                                                         const uint32_t* __restrict__ scounts, int k, float kappa, int metric,
-                                                        size_t b, float* __restrict__ dqc, float* __restrict__ crow) {
+                                                        size_t b, float* __restrict__ dqc, float* __restrict__ crow,
+                                                        uint32_t* __restrict__ qcnt, uint32_t* __restrict__ ovf) {
     __shared__ float red[128];
     const size_t m = blockIdx.x;
+    // this query's candidate counter line and (block 0) the batch's overflow line start at zero: no memset launch in the step
+    if (threadIdx.x < QCNT_STRIDE) qcnt[m * QCNT_STRIDE + threadIdx.x] = 0;
+    if (m == 0 && threadIdx.x < 64) ovf[threadIdx.x] = 0;
     const float* q = dq + m * qstride;
     float* qc = dqc + m * qstride;
     float part = 0.0f;
@@ -373,7 +382,6 @@ __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restri
 // Every counter sits on its own 128-byte line: device-scope atomics on one line are served one after the other by its L2
 // channel (~2 ns each — 64 queries' counters packed into one line cost the 1M x 64 workload 40 us for 20k candidates).
 #define WS_CAP 256   // pairs staged per wave (2 KB)
-#define QCNT_STRIDE 32
 __device__ __forceinline__ void ws_flush(uint64_t* __restrict__ wbuf, uint32_t& wcnt, uint32_t* __restrict__ qcnt, uint32_t* __restrict__ qids,
                                          uint32_t qcap, int lane) {
     // four pairs per lane, their atomics in flight together
@@ -702,12 +710,46 @@ __global__ __launch_bounds__(BLK) void flat_refine_kernel(const float4* __restri
                                                                 const float* __restrict__ dq, int qstride,
                                                                 const uint32_t* __restrict__ qcnt, const uint32_t* __restrict__ qids,
                                                                 uint32_t qcap, int k, uint64_t* __restrict__ keys,
-                                                                uint32_t* __restrict__ ovf, uint32_t* __restrict__ flags) {
+                                                                uint32_t* __restrict__ ovf, uint32_t* __restrict__ flags, size_t n) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const size_t m = blockIdx.y;
     const uint32_t np = qcnt[m * QCNT_STRIDE];
     if (np > qcap) {
+        // the query's candidate list overflowed (data below the filter's resolution: thousands of near-ties): this slice scans its
+        // share of the WHOLE base exactly — slow, rare, and no gated full-batch scan has to be launched behind every step.  The
+        // count still reaches the host, which keeps such an index on the exact kernels for a while (flat_mfma_applicable).
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(ovf, 1u);
+        const size_t v0 = n * blockIdx.x / gridDim.x, v1 = n * (blockIdx.x + 1) / gridDim.x;
+        BlockSelect<BLK> sel;
+        sel.init(lds, k);
+        __syncthreads();
+        const float* qb = dq + m * qstride;
+        bool nan_seen = false, first = true;
+        for (size_t base = v0; base < v1; base += BLK) {
+            const size_t v = base + threadIdx.x;
+            uint64_t key = MDB_KEY_MAX;
+            if (v < v1) {
+                float raw[1];
+                if (ROWS) {
+                    Row4Loader ld{tiles + v * p.d4};
+                    exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
+                } else {
+                    TileLoader ld{tiles + (v / MDB_TILE) * p.d4 * MDB_TILE + (v % MDB_TILE)};
+                    exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
+                }
+                const float dist = finish_distance<METRIC>(raw[0]);
+                if (dist != dist) nan_seen = true;
+                key = make_key(dist, (uint32_t)v);
+            }
+            if (first) { sel.warm_start(key); first = false; }
+            sel.offer(key);
+            sel.round_end();
+        }
+        if (nan_seen) atomicOr(flags, MDB_FLAG_NAN);
+        sel.finish();
+        const uint32_t cc = sel.count();
+        uint64_t* dst = keys + (m * gridDim.x + blockIdx.x) * (size_t)k;
+        for (int j = threadIdx.x; j < k; j += BLK) dst[j] = j < (int)cc ? sel.buf[j] : MDB_KEY_MAX;
         return;
     }
     const uint32_t lo = (uint32_t)((uint64_t)np * blockIdx.x / gridDim.x), c = (uint32_t)((uint64_t)np * (blockIdx.x + 1) / gridDim.x) - lo;
@@ -768,7 +810,7 @@ bool flat_mfma_applicable(const mdb_ctx* ctx, const TileView& ts, FlatAux& aux, 
 }
 
 mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, int metric, const float* dq, int qstride, size_t b,
-                               size_t bpad, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile) {
+                               size_t bpad, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile, const UnpackOut* unpack) {
     // queries are staged with bpad rows; the filter reads groups of BQ rows, so bpad must cover them
     const bool use_bf16 = aux.bhi.p && aux.split_metric == metric;
     int QB = ((size_t)(ts.d4 + MF_CH) * 4 * 65 * 4 <= 64 * 1024 && b > 32) ? 2 : 1;
@@ -811,9 +853,8 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     //   bf16 x 3 split (flat_bf16_filter_kernel): dropped cross terms 3 * 2^-18 and 3d f32 accumulations -> + 4 d eps + 2^-16
     const float kappa = 6.0f * (float)(ts.d4 * 4 + 4) * 5.9604645e-8f +
                         (use_bf16 ? 4.0f * (float)(aux.nk * 16) * 5.9604645e-8f + 1.52587890625e-5f : 0.0f);
-    MDB_HIP(ctx, hipMemsetAsync(qcnt, 0, bpadq * (size_t)QCNT_STRIDE * 4 + 256, ctx->stream));  // the queries' counters and ovf
     mfma_prep_kernel<<<dim3((unsigned)bpadq), 128, 0, ctx->stream>>>(dq, qstride, ts.d, aux.mean.p, smp_bf16 ? nullptr : skeys, scounts, (int)k,
-                                                                    kappa, metric, b, dqc, crow);
+                                                                    kappa, metric, b, dqc, crow, qcnt, ovf);   // (also clears the queries' counters and ovf)
     if (smp_bf16) {
         // the sample's products on the matrix cores -> U, then the k-th smallest bound per query -> crow (+ 8 eps: the roundings of
         // the bound's own arithmetic)
@@ -908,23 +949,28 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     // (C5 coarse: refine 157 / 167 / 175 us, merge 23 / 34 / 38 us)
     const unsigned rs = rs_env ? rs_env : (wave_slices ? 4 : MF_RS);
     MDB_TRY(mdb_scratch(ctx, 10, b * (size_t)rs * std::max<size_t>(k, 1) * 8, (void**)&rpart));
-    MDB_HIP(ctx, hipMemsetAsync(rpart, 0xFF, b * (size_t)rs * k * 8, ctx->stream));  // a slice that bails out leaves KEY_MAX
     const bool rows = aux.rows.p != nullptr;
     const float4* rsrc = rows ? (const float4*)aux.rows.p : (const float4*)ts.data;
 #define RF_LAUNCH(METRIC, ROWS)                                                                                                \
     do {                                                                                                                       \
         if (wave_slices)                                                                                                       \
             flat_refine_kernel<METRIC, ROWS, 64><<<dim3(rs, (unsigned)b), 64, sel_lds, ctx->stream>>>(rsrc, p, dq, qstride, qcnt, qids, qcap, \
-                                                                                                   (int)k, rpart, ovf, ctx->d_flags);        \
+                                                                                                   (int)k, rpart, ovf, ctx->d_flags, ts.n);  \
         else                                                                                                                   \
             flat_refine_kernel<METRIC, ROWS, MDB_BLOCK><<<dim3(rs, (unsigned)b), MDB_BLOCK, sel_lds, ctx->stream>>>(                          \
-                rsrc, p, dq, qstride, qcnt, qids, qcap, (int)k, rpart, ovf, ctx->d_flags);                                                    \
+                rsrc, p, dq, qstride, qcnt, qids, qcap, (int)k, rpart, ovf, ctx->d_flags, ts.n);                                              \
     } while (0)
     if (metric == MDB_METRIC_L2) { if (rows) RF_LAUNCH(MDB_METRIC_L2, true); else RF_LAUNCH(MDB_METRIC_L2, false); }
     else { if (rows) RF_LAUNCH(MDB_METRIC_DOT, true); else RF_LAUNCH(MDB_METRIC_DOT, false); }
 #undef RF_LAUNCH
     MDB_HIP(ctx, hipGetLastError());
-    MDB_TRY(merge_keys(ctx, rpart, (size_t)rs * k, b, k, d_keys, d_counts));
+    // the merge of the slices is the step's LAST kernel: it also writes the caller's rows (unpack) and hands the overflow count to
+    // the host (pinned word, read one call late) — no unpack launch, no counts copy, no device-to-host copy, and no gated exact
+    // scan behind it (an overflowing query was served exactly by its refine slices)
+    UnpackOut up = unpack ? *unpack : UnpackOut{};
+    if (aux.d_ovf_host) { up.word_src = ovf; up.word_dst = aux.d_ovf_host; }
+    MDB_TRY(merge_keys(ctx, rpart, (size_t)rs * k, b, k, d_keys, d_counts, &up));
+    if (!aux.d_ovf_host) MDB_HIP(ctx, hipMemcpyAsync(aux.h_ovf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->opt.mf_dbg) {
         uint32_t hn = 0, ho = 0;
         std::vector<uint32_t> hcnt(b * QCNT_STRIDE);
@@ -934,8 +980,5 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
         for (size_t gi = 0; gi < b; ++gi) hn += hcnt[gi * QCNT_STRIDE];
         fprintf(stderr, "[mf] b=%zu QB=%d candidate pairs %u (%.1f per query) overflowed %u\n", b, QB, hn, (double)hn / b, ho);
     }
-    // D. gated exact scan of the batch: both launches return at once unless a list overflowed
-    MDB_TRY(flat_topk_keys(ctx, ts, metric, dq, qstride, b, k, d_keys, d_counts, false, ovf));
-    MDB_HIP(ctx, hipMemcpyAsync(aux.h_ovf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
     return MDB_OK;
 }

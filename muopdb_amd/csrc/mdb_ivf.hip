@@ -2336,11 +2336,9 @@ mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, si
     void* keys;
     MDB_TRY(mdb_scratch(ctx, 5, b * num_probes * 8, &keys));
     if (ui == 0 && cent_aux.sample.n && bpad >= (b + 63) / 64 * 64 && flat_mfma_applicable(ctx, cv, cent_aux, b, num_probes)) {
-        MDB_TRY(flat_topk_keys_mfma(ctx, cv, cent_aux, MDB_METRIC_L2, d_q, qstride, b, bpad, num_probes, (uint64_t*)keys, nullptr));
-        void* dist;
-        MDB_TRY(mdb_scratch(ctx, 1, b * num_probes * 4 + 16, &dist));
-        MDB_TRY(unpack_keys(ctx, (const uint64_t*)keys, b * num_probes, d_probes, (float*)dist));
-        if (zero_counters) MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+        // the path's last merge writes the probe (centroid) ids itself and clears the context's device counters
+        const UnpackOut up{d_probes, nullptr, nullptr, zero_counters ? ctx->d_counters : nullptr};
+        MDB_TRY(flat_topk_keys_mfma(ctx, cv, cent_aux, MDB_METRIC_L2, d_q, qstride, b, bpad, num_probes, (uint64_t*)keys, nullptr, false, &up));
         return MDB_OK;
     }
     // always L2 (:155); the merge kernel writes the probe (centroid) ids itself: num_probes <= num_clusters, so every row is full

@@ -21,6 +21,8 @@ struct UnpackOut {
     float* dist = nullptr;        // [b][k] distances, +inf padded
     uint32_t* counts = nullptr;   // [b] (may be null)
     unsigned long long* zero4 = nullptr;  // four words cleared by block 0 (the context's device counters, ahead of the kernels that add to them)
+    const uint32_t* word_src = nullptr;   // block 0 copies *word_src to *word_dst (the batched path's overflow count -> pinned host memory:
+    uint32_t* word_dst = nullptr;         // no separate device-to-host copy in the step)
 };
 mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const float* d_queries_padded, int qstride,
                           size_t b, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false,
@@ -46,6 +48,7 @@ struct FlatAux {
     size_t nt32 = 0;         // 32-vector tiles
     int split_metric = -1;   // metric the split was built for (L2: centred; dot: as is)
     uint32_t* h_ovf = nullptr;  // pinned: candidate-list overflows of the last batch (read one call late)
+    uint32_t* d_ovf_host = nullptr;  // the same word as the device sees it (written by the step's last kernel)
     int cooldown = 0;        // batches left on the exact kernels after an overflow
     FlatAux() = default;
     FlatAux(const FlatAux&) = delete;
@@ -58,11 +61,12 @@ void flat_aux_view(const FlatAux& src, FlatAux& dst);
 mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles = 0, int metric = MDB_METRIC_L2, bool want_rows = false);
 bool flat_mfma_applicable(const mdb_ctx* ctx, const TileView& ts, FlatAux& aux, size_t b, size_t k);
 mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, int metric, const float* dq, int qstride, size_t b,
-                               size_t bpad, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false);
+                               size_t bpad, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false,
+                               const UnpackOut* unpack = nullptr);
 
 // k smallest of `per_query` candidate keys per query (one block per query), ascending
 mdb_status merge_keys(mdb_ctx* ctx, const uint64_t* d_partial, size_t per_query, size_t b, size_t k, uint64_t* d_out,
-                      uint32_t* d_counts);
+                      uint32_t* d_counts, const UnpackOut* unpack = nullptr);
 // (distance,id) keys -> ids / distances (KEY_MAX -> UINT32_MAX / +inf)
 mdb_status unpack_keys(mdb_ctx* ctx, const uint64_t* d_keys, size_t total, uint32_t* d_ids, float* d_dist);
 
