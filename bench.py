@@ -629,6 +629,39 @@ def run_c5(env, steps=None, warm=None):
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("c5", out["config"])
     out["roofline"]["coarse_filter_mfma_busy"] = measured_mfma("c5", out["config"])
     out["recall_note"] = "a shard's rows are a partial result (1/8 of the probed lists): recall is defined after the all-gather merge only"
+    # What a rank of the 8-GPU job REALLY runs per batch (muopdb_amd.distributed.sharded_probes + the exact sharded step): the coarse
+    # search over ITS 1/8 of the centroids (mdb_ivf_coarse_keys), the merge of the 8 ranks' coarse rows (here: 8 copies of its own —
+    # the all-gather itself needs 8 devices), then the search of its lists with the merged probes written as a points block.  The
+    # probes used by the search are the true ones (precomputed, untimed), so the scan does exactly the replicated step's work.
+    from muopdb_amd import distributed as D
+    from muopdb_amd import lib as L
+    nlist = sh["nlist"]
+    first, count = D.coarse_range(nlist, 0, 8)
+    ckeys = torch.empty((batch, P), dtype=torch.int64, device="cuda")
+    gathered = torch.empty((batch, 8, P), dtype=torch.int64, device="cuda")
+    mprobes = torch.empty((batch, P), dtype=torch.int32, device="cuda")
+    true_probes = torch.empty((steps + warm, batch, P), dtype=torch.int32, device="cuda")
+    for i in range(steps + warm):
+        q = queries[i * batch:(i + 1) * batch]
+        ctx.check(ctx.lib.mdb_ivf_find_nearest_centroids(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch), C.c_size_t(P), C.c_int(L.MEM_DEVICE),
+                                                         C.c_void_p(true_probes[i].data_ptr())))
+    block = torch.zeros(D.points_block_bytes(batch, k), dtype=torch.uint8, device="cuda")
+    ctx.sync()
+
+    def rank_step(i):
+        q = queries[i * batch:(i + 1) * batch]
+        ctx.check(ctx.lib.mdb_ivf_coarse_keys(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch), C.c_size_t(P), C.c_size_t(first), C.c_size_t(count),
+                                              C.c_int(L.MEM_DEVICE), C.c_void_p(ckeys.data_ptr())))
+        gathered.copy_(ckeys.view(batch, 1, P).expand(batch, 8, P))   # stand-in for the all-gather of 8 x [b][P] u64 rows
+        ctx.check(ctx.lib.mdb_ivf_merge_coarse_keys(ivf.h, C.c_void_p(gathered.data_ptr()), C.c_size_t(batch), C.c_size_t(8), C.c_size_t(P),
+                                                    C.c_int(L.MEM_DEVICE), C.c_void_p(mprobes.data_ptr())))
+        ctx.check(ctx.lib.mdb_ivf_search_shard(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch), C.c_void_p(true_probes[i].data_ptr()), C.c_size_t(P),
+                                               C.c_size_t(k), C.c_int(L.MEM_DEVICE), None, C.c_size_t(0), C.c_size_t(0), C.c_void_p(block.data_ptr())))
+
+    el, kms, nl = env.timed(rank_step, steps, warm)
+    out["rank_of_8_step"] = dict(ms_per_step=1000 * el / steps, value=steps * batch / el, scan_kernel_ms=kms / max(nl, 1),
+                                 coarse_centroids=count, note="coarse search over 1/8 of the centroids + merge of 8 coarse rows + search_shard with the "
+                                 "probes; excludes the two all-gathers (8 x 8 P and 8 x (8 k + 5) bytes per query: latency-bound on xGMI, needs 8 devices)")
     if env.cpu:
         import oracle
         o = oracle.BlockBasedIvf(sh["index"], sh["vectors"], oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, sh["codebook"]))

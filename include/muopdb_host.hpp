@@ -94,6 +94,13 @@ class Device {
     void check(mdb_status st) const {
         if (st != MDB_OK) throw Error(st, mdb_last_error(ctx_));
     }
+    // tuning / test switches of this context (mdb_set_option: defaults come from the environment once, at open)
+    void set_option(const char* name, long long value) { check(mdb_set_option(ctx_, name, value)); }
+    long long option(const char* name) const {
+        long long v = 0;
+        check(mdb_get_option(ctx_, name, &v));
+        return v;
+    }
 
   private:
     mdb_ctx* ctx_ = nullptr;

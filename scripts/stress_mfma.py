@@ -58,11 +58,9 @@ def main():
             q = make(rng, b, d, kind)
         idx = FlatIndex(ctx, base, metric)
         for rep in range(2):   # second call: the cooldown state after an overflow must not change results either
-            os.environ.pop("MDB_FLAT_NO_MFMA", None)
             ids, dist, cnt = idx.search(q, k)
-            os.environ["MDB_FLAT_NO_MFMA"] = "1"
-            eids, edist, ecnt = idx.search(q, k)
-            os.environ.pop("MDB_FLAT_NO_MFMA", None)
+            with ctx.option("MDB_FLAT_NO_MFMA", 1):
+                eids, edist, ecnt = idx.search(q, k)
             if not (np.array_equal(ids, eids) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32)) and np.array_equal(cnt, ecnt)):
                 bad = np.nonzero((ids != eids).any(1))[0]
                 print("MISMATCH it=%d seed=%d cfg=%s rows=%s" % (it, args.seed, dict(n=n, d=d, b=b, k=k, metric=metric, kind=kind), bad[:5]), flush=True)

@@ -126,6 +126,53 @@ def case_ivf(ctx, rng):
     return cfg, None
 
 
+def case_ivf_fused(ctx, rng):
+    """shapes inside the range of the fused small-batch step (ivf_prep_kernel + ivf_pq_fused_kernel: L2, 8-bit codes in whole
+    4-byte words, k and probes <= 64, batches < 512), with the library's own coarse search or caller-given probes, tombstones,
+    duplicate assignments, low-entropy data (masses of exact ties) and shrunk candidate lists (the in-kernel overflow pass)"""
+    n = int(rng.choice([200, 1500, 6000, 20000]))
+    sub = int(rng.choice([4, 8, 16, 32]))
+    mw = int(rng.choice([1, 2, 4, 8]))
+    d = sub * 4 * mw
+    if d > 256:
+        d, mw = sub * 4, 1
+    nl = int(rng.choice([1, 5, 40, 64, 130, 700]))
+    nl = min(nl, n)
+    P = int(rng.integers(1, min(nl, 64) + 1))
+    k = int(rng.choice([1, 3, 10, 33, 64]))
+    cpv = int(rng.choice([1, 1, 2]))
+    kind = int(rng.integers(0, 3))
+    cfg = dict(n=n, d=d, sub=sub, nl=nl, P=P, k=k, cpv=cpv, kind=kind)
+    v = data(rng, n, d, kind)
+    cent = H.kmeans(v, nl, iters=3, seed=int(rng.integers(1 << 30)))
+    doc = [int(x) for x in rng.permutation(n * 3)[:n]]
+    cb = H.train_pq_codebook(v[: min(n, 1500)], sub, 8, iters=2)
+    opq = oracle.ProductQuantizer(d, sub, 8, cb, 0)
+    index, vec, _ = H.build_ivf_files(v, doc, cent, quantize=opq.quantize, clusters_per_vector=cpv)
+    g = BlockBasedIvf(ctx, index, vec, ProductQuantizer(d, sub, 8, cb, 0))
+    o = oracle.BlockBasedIvf(index, vec, oracle.Quant(oracle.QUANT_PQ, 0, sub, 8, cb))
+    b = int(rng.choice([1, 7, 64, 256, 300]))
+    if n > 6000:
+        b = min(b, 64)
+    q = (v[rng.integers(0, n, b)] + rng.normal(0, 1, (b, d))).astype(np.float32)
+    cap = int(rng.choice([2048, 2048, 16]))
+    cfg.update(b=b, cap=cap)
+    with ctx.option("MDB_PQF_CAP", cap):
+        for step in range(2):
+            want = o.search(q, k, num_probes=P)
+            err = rows_equal(g.search(q, k, P), want, b)
+            if err:
+                return cfg, "search pass %d: %s" % (step, err)
+            probes = o.find_nearest_centroids(q, P)
+            err = rows_equal(g.search_with_centroids_and_remap(q, probes, k), want, b)
+            if err:
+                return cfg, "given probes, pass %d: %s" % (step, err)
+            for dd in rng.choice(doc, size=min(5, n), replace=False):
+                if g.invalidate(int(dd)) != o.invalidate(int(dd)):
+                    return cfg, "invalidate flag"
+    return cfg, None
+
+
 def case_hnsw(ctx, rng):
     n = int(rng.choice([1, 2, 40, 600, 2500]))
     d = int(rng.choice([3, 4, 16, 30, 48, 128]))
@@ -217,7 +264,7 @@ def case_spann(ctx, rng):
     return cfg, err
 
 
-CASES = {"flat": case_flat, "ivf": case_ivf, "hnsw": case_hnsw, "spann": case_spann}
+CASES = {"flat": case_flat, "ivf": case_ivf, "ivf_fused": case_ivf_fused, "hnsw": case_hnsw, "spann": case_spann}
 
 
 def main():
