@@ -90,6 +90,42 @@ void flat_aux_view(const FlatAux& src, FlatAux& dst) {
     }
 }
 
+template <class T>
+static void borrow_at(DevBuf<T>& dst, const DevBuf<T>& src, size_t off, size_t n) {
+    dst.release();
+    if (!src.p) return;
+    dst.p = src.p + off;
+    dst.n = n;
+    dst.borrowed = true;
+}
+
+bool flat_aux_subrange(const FlatAux& src, size_t first_tile, size_t ntiles, int d4, FlatAux& dst) {
+    const size_t st = src.sample_stride;
+    if (!src.sample.n || !st || !src.bhi.p || ntiles == 0 || first_tile % st || ntiles % st) return false;
+    const size_t s0 = first_tile / st, sn = ntiles / st;
+    if ((s0 + sn) > src.sample.ntiles) return false;
+    dst.sample_stride = st;
+    dst.sample.d = src.sample.d; dst.sample.d4 = src.sample.d4;
+    dst.sample.ntiles = sn;
+    dst.sample.n = sn * MDB_TILE;
+    borrow_at(dst.sample.data, src.sample.data, s0 * MDB_TILE * (size_t)d4 * 4, sn * MDB_TILE * (size_t)d4 * 4);
+    dst.ctiles.release();
+    dst.mean.borrow(src.mean);
+    borrow_at(dst.bhi, src.bhi, first_tile * 2 * (size_t)src.nk * 64, ntiles * 2 * (size_t)src.nk * 64);
+    borrow_at(dst.blo, src.blo, first_tile * 2 * (size_t)src.nk * 64, ntiles * 2 * (size_t)src.nk * 64);
+    borrow_at(dst.xnorm, src.xnorm, first_tile * MDB_TILE, ntiles * MDB_TILE);
+    if (src.rows.p) borrow_at(dst.rows, src.rows, first_tile * MDB_TILE * (size_t)d4 * 4, ntiles * MDB_TILE * (size_t)d4 * 4);
+    else dst.rows.release();
+    dst.nk = src.nk;
+    dst.nt32 = ntiles * 2;
+    dst.split_metric = src.split_metric;
+    if (!dst.h_ovf && hipHostMalloc((void**)&dst.h_ovf, 4) == hipSuccess) {
+        *dst.h_ovf = 0;
+        if (hipHostGetDevicePointer((void**)&dst.d_ovf_host, dst.h_ovf, 0) != hipSuccess) dst.d_ovf_host = nullptr;
+    }
+    return dst.h_ovf != nullptr;
+}
+
 // ------------------------------------------------------------------------------------------ bf16 x 3 split
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 

@@ -83,6 +83,8 @@ struct IvfSet {
     mdb_status set_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem);
     // single index with >= 64K centroids: sample / centred copy for the batched (MFMA-filtered) coarse search
     FlatAux cent_aux;
+    FlatAux cent_slice;            // view of a centroid range for mdb_ivf_coarse_keys (a rank's share of a sharded coarse search)
+    size_t slice_first = ~(size_t)0, slice_count = 0;
     // rows the queries must be staged with for coarse(): whole groups of 64 when the batched path may run
     size_t coarse_bpad(size_t b) const { return cent_aux.sample.n ? (b + 255) / 256 * 256 : (b + 3) / 4 * 4; }
     mdb_status coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes,

@@ -2550,11 +2550,23 @@ mdb_status mdb_ivf_coarse_keys(mdb_ivf* ivf, const float* queries, size_t b, siz
     } else {
         float* dq;
         int qstride;
-        MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, (b + 3) / 4 * 4, &dq, &qstride));
         const int d4 = ((int)s.num_features + 3) / 4;
         TileView cv{s.d_cent_tiles.p + ((size_t)s.h_users[0].cent_tile_base + first / MDB_TILE) * MDB_TILE * d4 * 4, count,
                     (count + MDB_TILE - 1) / MDB_TILE, (int)s.num_features, d4};
-        MDB_TRY(flat_topk_keys(ctx, cv, MDB_METRIC_L2, dq, qstride, b, num_probes, (uint64_t*)dkeys, nullptr));
+        // a slice of a LARGE coarse quantizer (a rank's share of C5's 65 536 centroids) takes the batched path too — sample bound,
+        // matrix-core filter, exact refine over the slice — through a view of the index's filter operands
+        bool batched = false;
+        if (s.cent_aux.sample.n && count % MDB_TILE == 0 && b >= 8) {
+            if (s.slice_first != first || s.slice_count != count) {
+                s.slice_first = ~(size_t)0;
+                if (flat_aux_subrange(s.cent_aux, first / MDB_TILE, count / MDB_TILE, d4, s.cent_slice)) { s.slice_first = first; s.slice_count = count; }
+            }
+            batched = s.slice_first == first && flat_mfma_applicable(ctx, cv, s.cent_slice, b, num_probes);
+        }
+        const size_t bpad = batched ? (b + 255) / 256 * 256 : (b + 3) / 4 * 4;
+        MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.num_features, mem, bpad, &dq, &qstride));
+        if (batched) MDB_TRY(flat_topk_keys_mfma(ctx, cv, s.cent_slice, MDB_METRIC_L2, dq, qstride, b, bpad, num_probes, (uint64_t*)dkeys, nullptr));
+        else MDB_TRY(flat_topk_keys(ctx, cv, MDB_METRIC_L2, dq, qstride, b, num_probes, (uint64_t*)dkeys, nullptr));
         if (first) keys_add_id_offset_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((uint64_t*)dkeys, total, (uint32_t)first);
         MDB_HIP(ctx, hipGetLastError());
     }

@@ -57,6 +57,10 @@ struct FlatAux {
 };
 // dst = a view of src's device arrays (attached handles) with its own overflow word / cooldown
 void flat_aux_view(const FlatAux& src, FlatAux& dst);
+// dst = a view of the tile range [first_tile, first_tile + ntiles) of src's base (whole tiles, first_tile a multiple of the sample
+// stride, ntiles a multiple of it): the batched path over a SLICE of the base — a rank's share of a sharded coarse quantizer.
+// false when the range does not fit those rules (the caller takes the exact kernels).
+bool flat_aux_subrange(const FlatAux& src, size_t first_tile, size_t ntiles, int d4, FlatAux& dst);
 // want_tiles: size of the strided sample in tiles (0: N/32 clamped to 16K..64K vectors, the flat index default)
 mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t want_tiles = 0, int metric = MDB_METRIC_L2, bool want_rows = false);
 bool flat_mfma_applicable(const mdb_ctx* ctx, const TileView& ts, FlatAux& aux, size_t b, size_t k);

@@ -1,10 +1,9 @@
 cd /root/repo
-run() { for v in 0 1; do MDB_HNSW_NO_DUAL=$v python bench.py --workload hnsw --steps 30 --warmup 5 --no-cpu-baseline --streams 0 2>/dev/null | python -c "
-import json,sys
-j=json.loads([x for x in sys.stdin if x.startswith('{')][-1]); print('$1 nodual=$v', j['ms_per_step'], j['roofline']['kernel_ms'])"; done; }
-run normal
-for b in 1 16 256; do for v in 0 1; do MDB_HNSW_NO_DUAL=$v python bench.py --workload hnsw --batch $b --steps 30 --warmup 5 --no-cpu-baseline --streams 0 2>/dev/null | python -c "
-import json,sys
-j=json.loads([x for x in sys.stdin if x.startswith('{')][-1]); print('batch $b nodual=$v', j['ms_per_step'], j['roofline']['kernel_ms'])"; done; done
-rm -f muopdb_amd/csrc/build/mdb_hnsw.o; MDB_EXTRA_FLAGS=-DMDB_PIPE_DBG bash muopdb_amd/csrc/build.sh > /tmp/b.log 2>&1; tail -1 /tmp/b.log
-run dbg
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "large_coarse or sharded_coarse or flat" 2>&1 | tail -4
+python bench.py --workload c5 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null > gpurun_out/r3_c5.json
+python - <<'PY'
+import json
+j=json.loads([x for x in open('gpurun_out/r3_c5.json') if x.startswith('{')][-1])
+print('c5', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('rank_of_8_step'))
+PY
+cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/p1; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o bench -- python /root/repo/bench.py --workload c5 --steps 6 --warmup 2 --no-cpu-baseline > /tmp/p1.log 2>&1; f=$(ls /tmp/p1/*kernel_stats.csv | head -1); cp $f /root/repo/gpurun_out/r3_c5_rank8_kernel_stats.csv

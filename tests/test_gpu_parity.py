@@ -516,6 +516,13 @@ def test_ivf_large_coarse_quantizer_batched_path(ctx, oracle):
         assert np.array_equal(g.find_nearest_centroids(q, P), want)
     assert_result_rows(g.search(q, 10, P), o.search(q, 10, num_probes=P), len(q))
     assert_result_rows(g.search(q[:9], 3, 1), o.search(q[:9], 3, num_probes=1), 9)
+    # the coarse search SHARDED over 8 ranks' centroid slices (muopdb_amd.distributed.sharded_probes): aligned slices of a large
+    # coarse quantizer take the batched path over a view of the filter operands (mdb_ivf_coarse_keys), the ragged tail the exact
+    # kernels; the merged rows are find_nearest_centroids' probes
+    parts = [g.coarse_keys(q, P, first, 8192) for first in range(0, 65536, 8192)] + [g.coarse_keys(q, P, 65536, L - 65536)]
+    assert np.array_equal(g.merge_coarse_keys(np.stack(parts, 1), P), want)
+    parts5 = [g.coarse_keys(q[:5], P, first, 8192) for first in range(0, 65536, 8192)] + [g.coarse_keys(q[:5], P, 65536, L - 65536)]
+    assert np.array_equal(g.merge_coarse_keys(np.stack(parts5, 1), P), want[:5])
     # a per-call planner filter WITH the library's own (batched, matrix-core) coarse search: the staged host bitmaps must
     # survive the coarse search's scratch use (they once shared a slot).  Expected rows: the oracle under the same filter,
     # and the unfiltered rows with the dropped points removed wherever k of them remain.
