@@ -42,7 +42,6 @@
     X(closure_block, "MDB_CLOSURE_BLOCK", 0)                                                                        \
     X(hnsw_no_beam, "MDB_HNSW_NO_BEAM", 0)                                                                          \
     X(hnsw_no_row64, "MDB_HNSW_NO_ROW64", 0)                                                                        \
-    X(hnsw_no_slot_p2, "MDB_HNSW_NO_SLOT_P2", 0)       /* beam kernel: wave 0 test-and-sets the row itself (round 2's step) */ \
     X(hnsw_prefetch, "MDB_HNSW_PREFETCH", 0)                                                                        \
     X(hnsw_dbg, "MDB_HNSW_DBG", 0)                                                                                  \
     X(ivf_coarse_sample_div, "MDB_IVF_COARSE_SAMPLE_DIV", 8) /* L */                                                \

@@ -49,7 +49,6 @@ struct HnswArgs {
     unsigned long long vis_words;   // words per query (global bitmap) or LDS words
     uint32_t* flags;
     unsigned long long* counters;   // [0] distance evals, [1] expanded nodes
-    int slot_p2;                    // beam kernel, rows of <= 64 edges: the visited test-and-set runs in the distance groups, by row slot
 };
 
 // candidate key: ascending u64 == (distance asc, id DESC): BinaryHeap<(-d, id)>::pop order
@@ -743,8 +742,6 @@ __device__ __forceinline__ bool beam_best_id(const uint32_t (&cdv)[BREGS], const
 template <int METRIC, bool VIS_LDS, int N16T, bool PF, bool ROW64>
 __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     constexpr int NCH = ROW64 ? 1 : 4;   // 64-edge chunks of a row
-    constexpr bool SLOT = ROW64 && !PF && N16T > 0 && N16T <= 16;  // the visited test-and-set may run in the distance groups (a.slot_p2)
-    const bool slot_p2 = a.slot_p2 != 0;
     // the prefetch wave is wave 5: SIMD 1, which it shares with a distance wave that mostly waits for memory; wave 4 (it would share
     // SIMD 0 with wave 0, whose issue slots ARE the step time) only attends the barriers
     constexpr int BLK = PF ? HNSW_BLOCK + 128 : HNSW_BLOCK;
@@ -895,19 +892,6 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
         for (;;) {
             // ---- P2 (wave 0): visited test-and-set + ordered compaction of the popped node's row
             PIPE_TB(t_p2);
-            if (SLOT && slot_p2) {
-                // the row goes to LDS as it is: the distance groups test-and-set its slots themselves (below) — wave 0's own
-                // test + compaction (an LDS atomic round trip, a ballot, two dependent stores) leaves its chain
-                if (wave == 0) {
-                    uint32_t flag = 0xFFFFFFFFu;
-                    if (!stop && !overflow) {
-                        flag = 0;
-                        nb_id[lane] = rowv[0];
-                        expanded += __ballot(rowv[0] != 0xFFFFFFFFu) != 0 ? 1 : 0;
-                    }
-                    if (lane == 0) { misc[0] = flag; misc[12] = 0; misc[13] = 0; }
-                }
-            } else
             if (wave == 0) {
                 uint32_t nnew = 0xFFFFFFFFu;
                 if (!stop && !overflow) {
@@ -970,63 +954,6 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                 const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[10]);
                 PIPE_TE(6, t_sh);
                 if (rid != 0xFFFFFFFFu) load_row(rid, pf_row);
-            } else if (SLOT && slot_p2) {
-                // ---- P2 + P3 by ROW SLOT (waves 1-3): group g owns slots g, g + NG, ...: it test-and-sets their visited bits (all of
-                // its slots' atomics in flight together: one LDS round trip), then evaluates the new ones; results stay at their
-                // slot (lane = slot in P4: row order is lane order), the new slots' bits meet in misc[12..13]
-                constexpr int NG = (HNSW_BLOCK - 64) / 16;
-                constexpr int MAXS = (64 + NG - 1) / NG;
-                const int g = grp - 4;
-                uint32_t nbv[MAXS];
-                bool nw[MAXS];
-#pragma unroll
-                for (int r = 0; r < MAXS; ++r) {
-                    const int sl = g + NG * r;
-                    nbv[r] = (sl < 64 && (uint32_t)sl < stride) ? nb_id[sl] : 0xFFFFFFFFu;
-                }
-                uint32_t oldv[MAXS];
-#pragma unroll
-                for (int r = 0; r < MAXS; ++r) {
-                    oldv[r] = 0xFFFFFFFFu;
-                    if (nbv[r] != 0xFFFFFFFFu && j == 0) oldv[r] = atomicOr(&vis[nbv[r] >> 5], 1u << (nbv[r] & 31));
-                }
-#pragma unroll
-                for (int r = 0; r < MAXS; ++r) {
-                    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)oldv[r], 0x150, 0xF, 0xF, false);   // lane 0 of the group
-                    nw[r] = nbv[r] != 0xFFFFFFFFu && !((o >> (nbv[r] & 31)) & 1u);
-                }
-                // all of the group's new rows are requested before the first accumulate: an uneven draw (two or three new slots
-                // in one group) costs issue slots, not gather latencies
-                constexpr int NT = N16T > 0 ? N16T : 4;
-                float4 xv[MAXS][NT / 4];
-#pragma unroll
-                for (int r = 0; r < MAXS; ++r) {
-                    if (nw[r]) {   // group-uniform
-                        const float4* x4 = (const float4*)(vecs + (size_t)nbv[r] * a.dpad + j * NT);
-#pragma unroll
-                        for (int c = 0; c < NT / 4; ++c) xv[r][c] = x4[c];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < MAXS; ++r) {
-                    if (nw[r]) {
-                        const int sl = g + NG * r;
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int c = 0; c < NT / 4; ++c) {
-                            acc = acc_term<METRIC>(acc, qr[4 * c + 0], xv[r][c].x);
-                            acc = acc_term<METRIC>(acc, qr[4 * c + 1], xv[r][c].y);
-                            acc = acc_term<METRIC>(acc, qr[4 * c + 2], xv[r][c].z);
-                            acc = acc_term<METRIC>(acc, qr[4 * c + 3], xv[r][c].w);
-                        }
-                        const float d = finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce16_dpp(acc)));
-                        if (j == 0) {
-                            nb_od[sl] = f32_orderable(d);
-                            atomicOr(&misc[12 + (sl >> 5)], 1u << (sl & 31));
-                            if (d != d) atomicOr(a.flags, MDB_FLAG_NAN);
-                        }
-                    }
-                }
             } else if (!PF || wave <= 3) {
                 // ---- P3 (waves 1-3): exact distances, one 16-lane group per neighbour
                 // (the groups also take the order-preserving integer image and the NaN check off wave 0's path)
@@ -1101,24 +1028,16 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
             if (wave == 0) {
                 uint32_t best_o = SLOT_EMPTY, best_id = 0;  // best accepted neighbour in pop order
                 bool best_have = false;
-                const bool byslot = SLOT && slot_p2;
-                unsigned long long newmask = 0;
-                uint32_t nnew_eff = nnew;
-                if (byslot) {   // the new neighbours sit at their row slots: lane = slot, ids are still in rowv
-                    newmask = ((unsigned long long)misc[13] << 32) | misc[12];
-                    nnew_eff = (uint32_t)__popcll(newmask);
-                    evals += nnew_eff;
-                }
-                for (uint32_t c0 = 0; c0 < nnew_eff; c0 += 64) {
+                for (uint32_t c0 = 0; c0 < nnew; c0 += 64) {
                     const uint32_t i = c0 + lane;
-                    const bool have = byslot ? (bool)((newmask >> lane) & 1ull) : i < nnew;
+                    const bool have = i < nnew;
                     const uint32_t od = have ? nb_od[i] : SLOT_EMPTY;
-                    const uint32_t id = byslot ? rowv[0] : (have ? nb_id[i] : 0);
+                    const uint32_t id = have ? nb_id[i] : 0;
                     unsigned long long surv = __ballot(have && od < fbound);
                     unsigned long long accepted = 0;
                     // fill phase of a layer (every layer restarts from its entry point): with this chunk B still holds
                     // at most ef elements, so every count below is < ef — all neighbours are accepted without counting
-                    if (n + (int)min(nnew_eff - c0, 64u) <= ef) { accepted = surv; surv = 0; }
+                    if (n + (int)min(nnew - c0, 64u) <= ef) { accepted = surv; surv = 0; }
                     while (surv) {
                         const int sidx = __ffsll((long long)surv) - 1;
                         surv &= surv - 1;
@@ -1638,7 +1557,6 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     a.smax = std::max<int>(64, ((int)max_stride + 63) / 64 * 64);
     a.k = (int)k;
     a.out_keys = d_keys; a.out_counts = d_counts; a.flags = ctx->d_flags; a.counters = ctx->d_counters;
-    a.slot_p2 = ctx->opt.hnsw_no_slot_p2 ? 0 : 1;
     size_t lds_base = (size_t)a.ef_cap * 8 + (size_t)a.cand_cap * 8 + (size_t)a.smax * 8 + (size_t)dpad * 4 + 64;
     if (ef <= 256) lds_base = std::max<size_t>(lds_base, (size_t)BEAM_LDS_QS + (size_t)dpad * 4);  // the beam kernel's fixed layout
     size_t words = ((size_t)max_n + 31) / 32 + 1;

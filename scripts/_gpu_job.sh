@@ -1,9 +1,11 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "large_coarse or sharded_coarse or flat" 2>&1 | tail -4
-python bench.py --workload c5 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null > gpurun_out/r3_c5.json
-python - <<'PY'
+timeout 1200 python -m pytest tests/test_gpu_traversal.py -x -q -m gpu -k "hnsw" 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "hnsw or c2" 2>&1 | tail -4
+for v in 0 1; do
+MDB_HNSW_NO_SLOT_P2=$v python bench.py --workload hnsw --steps 30 --warmup 5 --no-cpu-baseline --streams 0 2>/dev/null > gpurun_out/r3_h$v.json
+python - <<PY
 import json
-j=json.loads([x for x in open('gpurun_out/r3_c5.json') if x.startswith('{')][-1])
-print('c5', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('rank_of_8_step'))
+j=json.loads([x for x in open('gpurun_out/r3_h$v.json') if x.startswith('{')][-1])
+print('noslot=$v', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('recall'))
 PY
-cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/p1; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o bench -- python /root/repo/bench.py --workload c5 --steps 6 --warmup 2 --no-cpu-baseline > /tmp/p1.log 2>&1; f=$(ls /tmp/p1/*kernel_stats.csv | head -1); cp $f /root/repo/gpurun_out/r3_c5_rank8_kernel_stats.csv
+done
