@@ -36,6 +36,9 @@
     X(bf_exact_sample, "MDB_BF_EXACT_SAMPLE", 0)                                                                    \
     X(refine_wave_min_b, "MDB_REFINE_WAVE_MIN_B", 512)                                                              \
     X(refine_slices, "MDB_REFINE_SLICES", 0)                                                                        \
+    X(refine_no_groups, "MDB_REFINE_NO_GROUPS", 0)                                                                  \
+    X(refine_no_second_bound, "MDB_REFINE_NO_SECOND_BOUND", 0)                                                      \
+    X(mf_cooldown, "MDB_MF_COOLDOWN", 256)             /* calls served by the exact kernels after a candidate list overflowed */ \
     X(hnsw_no_dense, "MDB_HNSW_NO_DENSE", 0)           /* L */                                                      \
     X(hnsw_generic_dist, "MDB_HNSW_GENERIC_DIST", 0)                                                                \
     X(hnsw_no_closure, "MDB_HNSW_NO_CLOSURE", 0)                                                                    \

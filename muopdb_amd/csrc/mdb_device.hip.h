@@ -241,6 +241,39 @@ __device__ __forceinline__ float finish_distance(float raw) {
     return METRIC == MDB_METRIC_L2 ? mdb_sqrtf(raw) : (METRIC == MDB_METRIC_DOT ? -raw : raw);
 }
 
+// ------------------------------------------------------------------------------------------ 16-lane groups
+// lane t of each 16-lane row broadcast to the whole row: one DPP instruction (row_newbcast),
+// no LDS crossbar round trip
+#define MDB_ROW_BCAST(x, t) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0x150 + (t), 0xF, 0xF, false))
+
+// ordered horizontal sum of the first L lanes of each 16-lane group (reduce_sum, lane 0..L-1)
+template <int L>
+__device__ __forceinline__ float group_reduce(float acc) {
+    float s = 0.0f;
+    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 0));
+    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 1));
+    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 2));
+    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 3));
+    if (L > 4) {
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 4));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 5));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 6));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 7));
+    }
+    if (L > 8) {
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 8));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 9));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 10));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 11));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 12));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 13));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 14));
+        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 15));
+    }
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------ BlockSelect
 // Streaming selection of the k smallest u64 keys seen by a block.  Usage per block:
 //   sel.init(...); loop { sel.offer(key) by every thread (MDB_KEY_MAX = nothing); sel.round_end(); }

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(128) void mfma_prep_kernel(const float* __restrict_
 // constant exactly as mfma_prep_kernel derives it from an exact bound.
 #define SB_SUB 1024
 __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restrict__ U, uint32_t ns, int k, float kappa, int metric,
-                                                           float* __restrict__ crow) {
+                                                           float* __restrict__ crow, float* __restrict__ qnorm) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh_prefix, sh_need;
     const size_t m = blockIdx.x;
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restri
     }
     if (tid) return;
     const float qn = crow[m];                        // mfma_prep_kernel left the norm here
+    if (qnorm) qnorm[m] = qn;
     const float t = f32_from_orderable(prefix);      // the k-th smallest bound
     float c;
     if (!(qn < __uint_as_float(0x7F800000u)) || !(t < __uint_as_float(0x7F800000u))) {
@@ -418,8 +419,10 @@ __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restri
 // Every counter sits on its own 128-byte line: device-scope atomics on one line are served one after the other by its L2
 // channel (~2 ns each — 64 queries' counters packed into one line cost the 1M x 64 workload 40 us for 20k candidates).
 #define WS_CAP 256   // pairs staged per wave (2 KB)
+// wapx / qapx (optional): one float per pair travels with it (the filter's product: the refine of a large batch derives a second,
+// much tighter bound from them — flat_refine_group_kernel)
 __device__ __forceinline__ void ws_flush(uint64_t* __restrict__ wbuf, uint32_t& wcnt, uint32_t* __restrict__ qcnt, uint32_t* __restrict__ qids,
-                                         uint32_t qcap, int lane) {
+                                         uint32_t qcap, int lane, const float* __restrict__ wapx = nullptr, float* __restrict__ qapx = nullptr) {
     // four pairs per lane, their atomics in flight together
     uint64_t pr[WS_CAP / 64];
     uint32_t pos[WS_CAP / 64];
@@ -432,15 +435,23 @@ __device__ __forceinline__ void ws_flush(uint64_t* __restrict__ wbuf, uint32_t& 
 #pragma unroll
     for (int x = 0; x < WS_CAP / 64; ++x) {
         const uint32_t i = lane + 64 * x;
-        if (i < wcnt && pos[x] < qcap) qids[(size_t)(uint32_t)(pr[x] >> 32) * qcap + pos[x]] = (uint32_t)pr[x];
+        if (i < wcnt && pos[x] < qcap) {
+            qids[(size_t)(uint32_t)(pr[x] >> 32) * qcap + pos[x]] = (uint32_t)pr[x];
+            if (qapx) qapx[(size_t)(uint32_t)(pr[x] >> 32) * qcap + pos[x]] = wapx[i];
+        }
     }
     wcnt = 0;
 }
 __device__ __forceinline__ void ws_push(bool has, uint64_t pr, uint64_t* __restrict__ wbuf, uint32_t& wcnt, uint32_t* __restrict__ qcnt,
-                                        uint32_t* __restrict__ qids, uint32_t qcap, int lane) {
-    if (wcnt + 64 > WS_CAP) ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane);
+                                        uint32_t* __restrict__ qids, uint32_t qcap, int lane, float apx = 0.0f, float* __restrict__ wapx = nullptr,
+                                        float* __restrict__ qapx = nullptr) {
+    if (wcnt + 64 > WS_CAP) ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane, wapx, qapx);
     const unsigned long long bal = __ballot(has);
-    if (has) wbuf[wcnt + __popcll(bal & ((1ull << lane) - 1ull))] = pr;
+    if (has) {
+        const uint32_t at = wcnt + __popcll(bal & ((1ull << lane) - 1ull));
+        wbuf[at] = pr;
+        if (qapx) wapx[at] = apx;
+    }
     wcnt += (uint32_t)__popcll(bal);
 }
 
@@ -603,7 +614,7 @@ template <int METRIC, int QB, int NKT, bool SMP = false>   // NKT: compile-time 
 __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kernel(
     const uint4* __restrict__ bhi, const uint4* __restrict__ blo, const float* __restrict__ xnorm, size_t n, size_t nt32, int nk_rt,
     const float* __restrict__ dqc, int qstride, const float* __restrict__ crow, float kappa, uint32_t* __restrict__ qcnt,
-    uint32_t* __restrict__ qids, uint32_t qcap, size_t b, uint32_t* __restrict__ flags, size_t smp_stride) {
+    uint32_t* __restrict__ qids, uint32_t qcap, size_t b, uint32_t* __restrict__ flags, size_t smp_stride, float* __restrict__ qapx) {
     constexpr int BQ = 32 * QB;
     const int nk = NKT ? NKT : nk_rt;
     auto base_tile = [&](size_t t) -> size_t { return SMP ? (t >> 1) * 2 * smp_stride + (t & 1) : t; };
@@ -613,6 +624,7 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
     float* Cr = (float*)(Alo + (size_t)QB * nk * 64); // [BQ]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     uint64_t* const wbuf = (uint64_t*)(Cr + BQ) + wave * WS_CAP;   // this wave's staged pairs
+    float* const wapx = (float*)((uint64_t*)(Cr + BQ) + 4 * WS_CAP) + wave * WS_CAP;   // and their products (when qapx is given)
     uint32_t wcnt = 0;
     const size_t q0 = (size_t)blockIdx.y * BQ;
     for (int i = tid; i < QB * nk * 64; i += 256) {
@@ -710,7 +722,22 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
                 const int r = has ? __ffs((int)hits) - 1 : 0;
                 hits &= hits - 1;
                 const size_t m = q0 + (size_t)(qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
-                ws_push(has && m < b, ((uint64_t)m << 32) | (uint32_t)v, wbuf, wcnt, qcnt, qids, qcap, lane);
+                float av = 0.0f;
+                if (qapx) {   // this lane's accumulator r (a uniform r would be a readlane; r differs per lane: a 16-way select)
+                    // a select tree on r's bits: 15 conditional moves
+                    // (the accumulators pass through empty asm statements: left visible, the selects below are folded into ONE
+                    // dynamic element extract and lowered to sixteen compare-and-move pairs per level — 300 instructions)
+                    float c[16];
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) { c[x] = acc[qb][x]; asm volatile("" : "+v"(c[x])); }
+                    const bool b0 = r & 1, b1 = r & 2, b2 = r & 4, b3 = r & 8;
+                    const float e0 = b0 ? c[1] : c[0], e1 = b0 ? c[3] : c[2], e2 = b0 ? c[5] : c[4], e3 = b0 ? c[7] : c[6],
+                                e4 = b0 ? c[9] : c[8], e5 = b0 ? c[11] : c[10], e6 = b0 ? c[13] : c[12], e7 = b0 ? c[15] : c[14];
+                    const float f0 = b1 ? e1 : e0, f1 = b1 ? e3 : e2, f2 = b1 ? e5 : e4, f3 = b1 ? e7 : e6;
+                    const float u0 = b2 ? f1 : f0, u1 = b2 ? f3 : f2;
+                    av = b3 ? u1 : u0;
+                }
+                ws_push(has && m < b, ((uint64_t)m << 32) | (uint32_t)v, wbuf, wcnt, qcnt, qids, qcap, lane, av, wapx, qapx);
             }
         }
     };
@@ -734,7 +761,7 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
         epilogue(t, xnt);
         t = tn;
     }
-    if (!SMP) ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane);
+    if (!SMP) ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane, wapx, qapx);
 }
 
 // ------------------------------------------------------------------------------------------ refine
@@ -823,6 +850,243 @@ __global__ __launch_bounds__(BLK) void flat_refine_kernel(const float4* __restri
     for (int j = threadIdx.x; j < k; j += BLK) dst[j] = j < (int)cc ? sel.buf[j] : MDB_KEY_MAX;
 }
 
+
+// ------------------------------------------------------------------------------------------ refine, large batches
+// One block per query over its WHOLE candidate list, rows from the row-major copy: a 16-lane group per candidate (lane j holds
+// SIMD lane j of the reference's 16/8/4 passes: loads of 64 contiguous bytes per group instead of one 512-byte row per LANE,
+// which made flat_refine_kernel<.., 64> 8x over-fetching and TA bound at C5's coarse step), two candidates in flight per group,
+// keys into LDS, then the k smallest by RANK COUNTING (keys are distinct: rank = #smaller = final position) — the rows come out
+// final and sorted: no partial lists, no merge launch.  Lists longer than RG_CAP - k go through in chunks (the running top-k
+// stays at the front); an overflowed list (np > qcap) means the whole base, same loop.
+#define RG_CAP 2048
+#define RG_SURV 1024
+// k-th smallest distance image (high key word) among keys[0 .. tot): four 8-bit radix passes, 256 threads (sample_bound_kernel's scan)
+__device__ __forceinline__ uint32_t rg_kth_image(const uint64_t* keys, uint32_t tot, uint32_t need, uint32_t* hist, int tid) {
+    const int lane = tid & 63;
+    uint32_t prefix = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < tot; i += 256) {
+            const uint32_t h = (uint32_t)(keys[i] >> 32);
+            if (pass == 0 || (h >> (shift + 8)) == prefix) atomicAdd(&hist[(h >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {  // first digit whose cumulative count reaches `need` (it exists: tot >= need)
+            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const uint32_t sum = h0 + h1 + h2 + h3;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const unsigned long long reach = __ballot(incl >= need);
+            const int first = __ffsll((long long)reach) - 1;
+            if (lane == first) {
+                uint32_t before = incl - sum, d = 0;
+                if (before + h0 >= need) d = 0;
+                else if (before + h0 + h1 >= need) { d = 1; before += h0; }
+                else if (before + h0 + h1 + h2 >= need) { d = 2; before += h0 + h1; }
+                else { d = 3; before += h0 + h1 + h2; }
+                hist[256] = (prefix << 8) | (4u * lane + d);
+                hist[257] = need - before;
+            }
+        }
+        __syncthreads();
+        prefix = hist[256];
+        need = hist[257];
+        __syncthreads();
+    }
+    return prefix;
+}
+template <int METRIC, int N16C>   // N16C: compile-time 16-chunks (8: d = 128), 0 = the general cascade
+__global__ __launch_bounds__(256) void flat_refine_group_kernel(const float* __restrict__ rows, DistPlan p, const float* __restrict__ dq,
+                                                                int qstride, const uint32_t* __restrict__ qcnt,
+                                                                const uint32_t* __restrict__ qids, uint32_t qcap, int k,
+                                                                uint64_t* __restrict__ out, uint32_t* __restrict__ counts,
+                                                                uint32_t* __restrict__ ovf, uint32_t* __restrict__ flags, size_t n, UnpackOut up,
+                                                                const float* __restrict__ qapx, const float* __restrict__ xnorm,
+                                                                const float* __restrict__ qnorm, float kappa_s) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint64_t* keys = (uint64_t*)lds;          // [RG_CAP]
+    uint64_t* surv = keys + RG_CAP;           // [RG_SURV]
+    uint64_t* best = surv + RG_SURV;          // [k]
+    uint32_t* hist = (uint32_t*)(best + k);   // [256] + prefix, need, survivor count
+    uint32_t* ids2 = hist + 260;              // [RG_CAP] the candidates left by the second bound
+    float* qs = (float*)(ids2 + RG_CAP);      // [d4 * 4]
+    const size_t m = blockIdx.x;
+    const int tid = threadIdx.x, grp = tid >> 4, j = tid & 15;
+    const uint32_t np = qcnt[m * QCNT_STRIDE];
+    const bool whole = np > qcap;
+    if (whole && tid == 0) atomicAdd(ovf, 1u);
+    size_t total = whole ? n : np;
+    const uint32_t* __restrict__ mine = qids + m * (size_t)qcap;
+    const size_t rstride = (size_t)p.d4 * 4;
+    for (int i = tid; i < p.d4 * 4; i += 256) qs[i] = dq[m * qstride + i];
+    bool second = false;
+    if (qapx && !whole && np > (uint32_t)k && np <= RG_CAP) {
+        // ---- second bound.  The filter's threshold comes from a SAMPLE (k-th smallest bound of 1/32 of the base): it admits ~8 k
+        // candidates per query, and their 512-byte rows — 1 GB per 4096-query batch through the fabric — were the whole cost of
+        // this kernel.  The candidates' own products give every one a bracket  lo <= reference distance <= up  (the filter's
+        // error budget, both directions, exactly as the sample's U is formed); the k-th smallest `up` bounds the k-th distance,
+        // and a candidate whose `lo` exceeds it is not in the top k.  Left: k and a handful.
+        second = true;
+        const float qn = qnorm[m];
+        for (uint32_t i = tid; i < np; i += 256) {
+            const float a = qapx[m * (size_t)qcap + i];
+            const float nn = qn + xnorm[mine[i]];
+            float upv, lov;
+            if (METRIC == MDB_METRIC_L2) { const float sd = nn - 2.0f * a; upv = sd + kappa_s * nn; lov = sd - kappa_s * nn; }
+            else { upv = kappa_s * 0.5f * nn - a; lov = -a - kappa_s * 0.5f * nn; }
+            if (!(upv == upv) || !(lov == lov)) { upv = __uint_as_float(0x7F800000u); lov = -__uint_as_float(0x7F800000u); }   // NaN / inf operands: kept
+            keys[i] = ((uint64_t)f32_orderable(upv) << 32) | f32_orderable(lov);
+        }
+    }
+    __syncthreads();
+    if (second) {
+        // (the brackets are on SQUARED distances, the keys on their square roots: two squares a few ulps apart can share a root
+        // and then order by id, so the bound is widened by 2e-6 like the filter's own — mfma_prep_kernel)
+        const float t1 = f32_from_orderable(rg_kth_image(keys, np, (uint32_t)k, hist, tid));
+        const uint32_t T = t1 < __uint_as_float(0x7F800000u) ? f32_orderable(t1 + fabsf(t1) * 2e-6f + 1e-30f) : 0xFFFFFFFFu;
+        if (tid == 0) hist[258] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < np; i += 256) {
+            if ((uint32_t)keys[i] <= T) ids2[atomicAdd(&hist[258], 1u)] = mine[i];
+        }
+        __syncthreads();
+        total = hist[258];
+        __syncthreads();
+    }
+    float qr[N16C ? N16C : 1];
+    if (N16C) {
+#pragma unroll
+        for (int c = 0; c < N16C; ++c) qr[c] = qs[16 * c + j];
+    }
+    auto dist_of = [&](const float* __restrict__ x) -> float {
+        if (N16C) {
+            float xv[N16C ? N16C : 1];
+#pragma unroll
+            for (int c = 0; c < N16C; ++c) xv[c] = x[16 * c + j];
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < N16C; ++c) acc = acc_term<METRIC>(acc, qr[c], xv[c]);
+            return finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce<16>(acc)));
+        }
+        float ret = 0.0f;
+        if (p.n16 > 0) {
+            float acc = 0.0f;
+            for (int c = 0; c < p.n16; ++c) acc = acc_term<METRIC>(acc, qs[16 * c + j], x[16 * c + j]);
+            ret = __fadd_rn(ret, group_reduce<16>(acc));
+        }
+        if (p.n8 > 0) {
+            float acc = 0.0f;
+            if (j < 8)
+                for (int c = 0; c < p.n8; ++c) acc = acc_term<METRIC>(acc, qs[p.off8 + 8 * c + j], x[p.off8 + 8 * c + j]);
+            ret = __fadd_rn(ret, group_reduce<8>(acc));
+        }
+        if (p.n4 > 0) {
+            float acc = 0.0f;
+            if (j < 4)
+                for (int c = 0; c < p.n4; ++c) acc = acc_term<METRIC>(acc, qs[p.off4 + 4 * c + j], x[p.off4 + 4 * c + j]);
+            ret = __fadd_rn(ret, group_reduce<4>(acc));
+        }
+        for (int t = 0; t < p.ntail; ++t) ret = acc_term<METRIC>(ret, qs[p.offt + t], x[p.offt + t]);
+        return finish_distance<METRIC>(ret);
+    };
+    const uint32_t chunk = (uint32_t)(RG_CAP - k) & ~31u;
+    uint32_t have = 0;
+    bool nan_seen = false;
+    for (size_t c0 = 0; c0 < total || c0 == 0; c0 += chunk) {
+        const uint32_t cn = (uint32_t)min((size_t)chunk, total - c0);
+        for (uint32_t i = grp; i < cn; i += 32) {
+            const bool two = i + 16 < cn;
+            const uint32_t i2 = two ? i + 16 : i;
+            const uint32_t va = whole ? (uint32_t)(c0 + i) : second ? ids2[c0 + i] : mine[c0 + i];
+            const uint32_t vb = whole ? (uint32_t)(c0 + i2) : second ? ids2[c0 + i2] : mine[c0 + i2];
+            float da, db;
+            if (N16C) {
+                // both candidates' loads are issued before the first accumulate
+                const float* __restrict__ xa = rows + (size_t)va * rstride;
+                const float* __restrict__ xb = rows + (size_t)vb * rstride;
+                float ua[N16C ? N16C : 1], ub[N16C ? N16C : 1];
+#pragma unroll
+                for (int c = 0; c < N16C; ++c) ua[c] = xa[16 * c + j];
+#pragma unroll
+                for (int c = 0; c < N16C; ++c) ub[c] = xb[16 * c + j];
+                float acc = 0.0f, bcc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < N16C; ++c) acc = acc_term<METRIC>(acc, qr[c], ua[c]);
+#pragma unroll
+                for (int c = 0; c < N16C; ++c) bcc = acc_term<METRIC>(bcc, qr[c], ub[c]);
+                da = finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce<16>(acc)));
+                db = finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce<16>(bcc)));
+            } else {
+                da = dist_of(rows + (size_t)va * rstride);
+                db = two ? dist_of(rows + (size_t)vb * rstride) : da;
+            }
+            if (da != da || db != db) nan_seen = true;
+            if (j == 0) {
+                keys[have + i] = make_key(da, va);
+                if (two) keys[have + i2] = make_key(db, vb);
+            }
+        }
+        __syncthreads();
+        // the k smallest of keys[0 .. tot), sorted, into `best`: the k-th smallest distance image T by a radix select, the keys at or
+        // below T (k of them, plus T's ties) compacted, and among those every key's RANK = its final position (keys are distinct).
+        // Rank counting over all of a 512-candidate list was measured first: 205 us of 64-bit compares at C5's coarse step.
+        const uint32_t tot = have + cn;
+        const uint32_t keep = min(tot, (uint32_t)k);
+        const uint64_t* src = keys;
+        uint32_t scnt = tot;
+        if (tot > (uint32_t)k) {
+            const uint32_t T = rg_kth_image(keys, tot, (uint32_t)k, hist, tid);
+            if (tid == 0) hist[258] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < tot; i += 256) {
+                const uint64_t kk = keys[i];
+                if ((uint32_t)(kk >> 32) <= T) {
+                    const uint32_t pos = atomicAdd(&hist[258], 1u);
+                    if (pos < RG_SURV) surv[pos] = kk;
+                }
+            }
+            __syncthreads();
+            if (hist[258] <= RG_SURV) { src = surv; scnt = hist[258]; }   // else: > RG_SURV keys tie with the k-th distance — count over all
+        }
+        for (uint32_t i0 = 0; i0 < scnt; i0 += 256) {
+            const uint32_t ia = i0 + tid;
+            const uint64_t ka = ia < scnt ? src[ia] : MDB_KEY_MAX;
+            uint32_t ra = 0;
+            for (uint32_t t = 0; t < scnt; ++t) ra += src[t] < ka ? 1u : 0u;   // broadcast reads
+            if (ia < scnt && ra < keep) best[ra] = ka;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < keep; i += 256) keys[i] = best[i];
+        have = keep;
+        __syncthreads();
+        if (total == 0) break;
+    }
+    if (nan_seen) atomicOr(flags, MDB_FLAG_NAN);
+    for (int i = tid; i < k; i += 256) {
+        const bool got = i < (int)have;
+        const uint64_t kk = got ? keys[i] : MDB_KEY_MAX;
+        out[m * (size_t)k + i] = kk;
+        if (up.ids) {
+            up.ids[m * (size_t)k + i] = got ? key_id(kk) : 0xFFFFFFFFu;
+            if (up.dist) up.dist[m * (size_t)k + i] = got ? key_dist(kk) : __uint_as_float(0x7F800000u);
+        }
+    }
+    if (tid == 0) {
+        if (counts) counts[m] = have;
+        if (up.ids && up.counts) up.counts[m] = have;
+    }
+    if (up.zero4 && m == 0 && tid < 4) up.zero4[tid] = 0ull;
+}
+
+// the overflow count's hand-over to the host (merge_keys does it on the other route): after the refine, so that it sees every block's add
+__global__ void copy_word_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) { *dst = *src; }
+
 // ------------------------------------------------------------------------------------------ host
 bool flat_mfma_applicable(const mdb_ctx* ctx, const TileView& ts, FlatAux& aux, size_t b, size_t k) {
     if (ctx->opt.flat_no_mfma) return false;
@@ -836,7 +1100,7 @@ bool flat_mfma_applicable(const mdb_ctx* ctx, const TileView& ts, FlatAux& aux, 
     // sends the index back to the exact kernels for a while
     if (aux.h_ovf && *aux.h_ovf) {
         *aux.h_ovf = 0;
-        aux.cooldown = 256;
+        aux.cooldown = (int)std::max<long long>(0, ctx->opt.mf_cooldown);
     }
     if (aux.cooldown > 0) {
         --aux.cooldown;
@@ -859,12 +1123,13 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     const size_t BQ = 32 * QB, groups = (b + BQ - 1) / BQ, bpadq = groups * BQ;
     if (bpadq > bpad) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "internal: queries staged with %zu rows, filter needs %zu", bpad, bpadq);
     char* ax;
-    size_t off_sc = align_up(b * k * 8, 16), off_cr = off_sc + align_up(b * 4, 16), off_np = off_cr + align_up(bpadq * 4, 256),
-           off_ov = off_np + bpadq * (size_t)QCNT_STRIDE * 4, off_qc = off_ov + 256;
+    size_t off_sc = align_up(b * k * 8, 16), off_cr = off_sc + align_up(b * 4, 16), off_qn = off_cr + align_up(bpadq * 4, 256),
+           off_np = off_qn + align_up(bpadq * 4, 256), off_ov = off_np + bpadq * (size_t)QCNT_STRIDE * 4, off_qc = off_ov + 256;
     MDB_TRY(mdb_scratch(ctx, 8, off_qc + bpadq * (size_t)qstride * 4, (void**)&ax));
     uint64_t* skeys = (uint64_t*)ax;
     uint32_t* scounts = (uint32_t*)(ax + off_sc);
     float* crow = (float*)(ax + off_cr);
+    float* qnorm = (float*)(ax + off_qn);         // the centred queries' squared norms (sample_bound_kernel keeps them for the refine)
     uint32_t* qcnt = (uint32_t*)(ax + off_np);    // per-query candidate counts (device-scope atomics)
     uint32_t* ovf = (uint32_t*)(ax + off_ov);     // own 256-byte line
     float* dqc = (float*)(ax + off_qc);
@@ -880,6 +1145,11 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     float* umat = nullptr;
     if (smp_bf16) MDB_TRY(mdb_scratch(ctx, 12, b * ns * 4, (void**)&umat));
     else MDB_TRY(flat_topk_keys(ctx, view_of(aux.sample), metric, dq, qstride, b, k, skeys, scounts, false));
+    // large batches over a store with a row-major copy (a coarse quantizer) are refined one block per query, and the filter hands
+    // its products over with the candidates (flat_refine_group_kernel)
+    const bool by_groups = aux.rows.p && b >= (size_t)std::max<long long>(0, ctx->opt.refine_wave_min_b) && k <= 256 && !ctx->opt.refine_no_groups;
+    float* qapx = nullptr;
+    if (by_groups && smp_bf16 && !ctx->opt.refine_no_second_bound) MDB_TRY(mdb_scratch(ctx, 10, bpadq * (size_t)qcap * 4, (void**)&qapx));
     // error budget of the filter, eps = 2^-24, all norms of the centred operands:
     //   centring (eps per component)            : |a' - ||q-x||^2| <= 4 eps (qn + xn)
     //   reference association vs real arithmetic: s_ref >= s* (1 - (d+2) eps)  -> 2(d+3) eps (qn + xn)
@@ -906,7 +1176,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss));                       \
         flat_bf16_filter_kernel<METRIC, QBT, NKT, true><<<grids, 256, ldss, ctx->stream>>>(                                   \
             aux.bhi.p, aux.blo.p, aux.xnorm.p, ts.n, snt32, aux.nk, dqc, qstride, crow, kappa_s, nullptr, (uint32_t*)umat, (uint32_t)ns, b, \
-            ctx->d_flags, aux.sample_stride);                                                                                \
+            ctx->d_flags, aux.sample_stride, nullptr);                                                                                \
     } while (0)
 #define BS_QB(METRIC, NKT)                                             \
     do {                                                               \
@@ -920,7 +1190,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
 #undef BS_QB
 #undef BS_LAUNCH
         MDB_HIP(ctx, hipGetLastError());
-        sample_bound_kernel<<<dim3((unsigned)b), 256, 0, ctx->stream>>>(umat, (uint32_t)ns, (int)k, kappa, metric, crow);
+        sample_bound_kernel<<<dim3((unsigned)b), 256, 0, ctx->stream>>>(umat, (uint32_t)ns, (int)k, kappa, metric, crow, qnorm);
         MDB_HIP(ctx, hipGetLastError());
     }
     // B. filter on the centred copy (L2) / the base itself (dot)
@@ -934,7 +1204,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
         if (use_bf16) {
             const unsigned nblk_b = (unsigned)std::max<size_t>(1, std::min<size_t>((aux.nt32 + 3) / 4, std::max<size_t>(1, 512 / groups)));
             dim3 gridb(nblk_b, (unsigned)groups);
-            const size_t ldsb = (size_t)QB * aux.nk * 2048 + BQ * 4 + BF_LBUF * 8 + 64;
+            const size_t ldsb = (size_t)QB * aux.nk * 2048 + BQ * 4 + BF_LBUF * 8 + 64 + (qapx ? BF_LBUF * 4 : 0);
 #define BF_LAUNCH(METRIC, QBT, NKT)                                                                                  \
     do {                                                                                                             \
         if (ldsb > 48 * 1024)                                                                                        \
@@ -942,7 +1212,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));               \
         flat_bf16_filter_kernel<METRIC, QBT, NKT><<<gridb, 256, ldsb, ctx->stream>>>(aux.bhi.p, aux.blo.p, aux.xnorm.p, ts.n, aux.nt32,    \
                                                                                      aux.nk, dqc, qstride, crow, kappa, qcnt, qids,       \
-                                                                                     qcap, b, ctx->d_flags, 0);                           \
+                                                                                     qcap, b, ctx->d_flags, 0, qapx);                     \
     } while (0)
 #define BF_QB(METRIC, NKT)                                             \
     do {                                                               \
@@ -976,6 +1246,23 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     }
     // C. refine
     DistPlan p = make_plan(ts.d, metric);
+    if (by_groups) {
+        const size_t ldsg = (size_t)(RG_CAP + RG_SURV) * 8 + k * 8 + 260 * 4 + (size_t)RG_CAP * 4 + (size_t)ts.d4 * 16;
+        const float kappa_s = kappa + 8.0f * 5.9604645e-8f;
+        UnpackOut up = unpack ? *unpack : UnpackOut{};
+        const bool n8 = metric == MDB_METRIC_L2 && ts.d == 128;
+#define RG_LAUNCH(METRIC, N16C)                                                                                                        \
+    flat_refine_group_kernel<METRIC, N16C><<<dim3((unsigned)b), 256, ldsg, ctx->stream>>>(aux.rows.p, p, dq, qstride, qcnt, qids, qcap, (int)k, \
+                                                                                         d_keys, d_counts, ovf, ctx->d_flags, ts.n, up, qapx, \
+                                                                                         aux.xnorm.p, qnorm, kappa_s)
+        if (metric == MDB_METRIC_L2) { if (n8) RG_LAUNCH(MDB_METRIC_L2, 8); else RG_LAUNCH(MDB_METRIC_L2, 0); }
+        else RG_LAUNCH(MDB_METRIC_DOT, 0);
+#undef RG_LAUNCH
+        MDB_HIP(ctx, hipGetLastError());
+        if (aux.d_ovf_host) copy_word_kernel<<<1, 1, 0, ctx->stream>>>(ovf, aux.d_ovf_host);
+        else MDB_HIP(ctx, hipMemcpyAsync(aux.h_ovf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+        return MDB_OK;
+    }
     const size_t wave_min_b = (size_t)std::max<long long>(0, ctx->opt.refine_wave_min_b);
     const bool wave_slices = b >= wave_min_b && k <= 64;   // one wave per slice
     size_t sel_lds = ((std::max(BlockSelect<MDB_BLOCK>::lds_bytes((int)k), BlockSelect<64>::lds_bytes((int)k)) + 15) & ~(size_t)15) + 16;

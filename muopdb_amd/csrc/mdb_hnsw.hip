@@ -55,38 +55,6 @@ struct HnswArgs {
 __device__ __forceinline__ uint64_t cand_key(float d, uint32_t id) { return ((uint64_t)f32_orderable(d) << 32) | (uint32_t)~id; }
 __device__ __forceinline__ uint32_t cand_id(uint64_t k) { return ~(uint32_t)k; }
 
-// lane t of each 16-lane row broadcast to the whole row: one DPP instruction (row_newbcast),
-// no LDS crossbar round trip
-#define MDB_ROW_BCAST(x, t) \
-    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0x150 + (t), 0xF, 0xF, false))
-
-// ordered horizontal sum of the first L lanes of each 16-lane group (reduce_sum, lane 0..L-1)
-template <int L>
-__device__ __forceinline__ float group_reduce(float acc) {
-    float s = 0.0f;
-    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 0));
-    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 1));
-    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 2));
-    s = __fadd_rn(s, MDB_ROW_BCAST(acc, 3));
-    if (L > 4) {
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 4));
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 5));
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 6));
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 7));
-    }
-    if (L > 8) {
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 8));
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 9));
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 10));
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 11));
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 12));
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 13));
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 14));
-        s = __fadd_rn(s, MDB_ROW_BCAST(acc, 15));
-    }
-    return s;
-}
-
 // group_reduce<16> with the broadcast folded into the add (v_add_f32_dpp): 17 issue slots instead of 33 on the distance groups'
 // chain; the same sixteen additions in the same order (0 + lane 0, + lane 1, ...; a + b == b + a bit for bit).
 __device__ __forceinline__ float group_reduce16_dpp(float acc) {

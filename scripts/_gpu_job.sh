@@ -1,11 +1,10 @@
 cd /root/repo
-timeout 1200 python -m pytest tests/test_gpu_traversal.py -x -q -m gpu -k "hnsw" 2>&1 | tail -4
-timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "hnsw or c2" 2>&1 | tail -4
-for v in 0 1; do
-MDB_HNSW_NO_SLOT_P2=$v python bench.py --workload hnsw --steps 30 --warmup 5 --no-cpu-baseline --streams 0 2>/dev/null > gpurun_out/r3_h$v.json
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+for w in c5 flat; do
+python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null > gpurun_out/r3_$w.json
 python - <<PY
 import json
-j=json.loads([x for x in open('gpurun_out/r3_h$v.json') if x.startswith('{')][-1])
-print('noslot=$v', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('recall'))
+j=json.loads([x for x in open('gpurun_out/r3_$w.json') if x.startswith('{')][-1])
+print('$w', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('rank_of_8_step',{}).get('ms_per_step'), j['config'].get('workload'))
 PY
 done

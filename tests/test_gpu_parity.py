@@ -546,6 +546,46 @@ def test_ivf_large_coarse_quantizer_batched_path(ctx, oracle):
             assert filt.doc_ids(qi) == expect
 
 
+@pytest.mark.parametrize("d", [24, 128])
+def test_coarse_refine_by_groups_ties_chunks_overflow(ctx, oracle, d):
+    """Large batches over a coarse quantizer are refined one block per query (flat_refine_group_kernel: a 16-lane group per
+    candidate, radix select + rank counting, final rows without a merge).  Forced on a small batch (MDB_REFINE_WAVE_MIN_B)
+    over centroids with blocks of 1 200 / 3 000 / 9 000 IDENTICAL rows: ties beyond the survivor buffer (the count over all
+    keys), lists longer than one chunk, and a list that overflows its capacity (the block scans the whole base) — probes must
+    equal the oracle's, for d = 24 (general cascade) and d = 128 (the unrolled 16-lane pass), for k below and above 64."""
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import BlockBasedIvf
+    rng = np.random.default_rng(d)
+    L = 65_600
+    cent = (rng.standard_normal((L, d)) * 30).astype(np.float32)
+    sets = {}
+    at = 500
+    for cnt in (1200, 3000, 9000):
+        rows = rng.choice(np.arange(at, at + 3 * cnt), cnt, replace=False)
+        cent[rows] = cent[rows[0]]
+        sets[cnt] = rows
+        at += 3 * cnt
+    pls = [np.array([i], dtype=np.uint64) for i in range(L)]
+    index, vec = F.write_ivf_index(cent, list(range(1, L + 1)), pls), F.write_vector_file(cent)
+    g, o = BlockBasedIvf(ctx, index, vec), oracle.BlockBasedIvf(index, vec)
+    q = (cent[rng.integers(0, L, 40)] + rng.standard_normal((40, d)) * 2).astype(np.float32)
+    q[1] = cent[sets[1200][0]]
+    q[2] = cent[sets[3000][0]]
+    q[3] = cent[sets[9000][0]]
+    q[4] = cent[sets[3000][0]] + 0.5
+    q[5] = cent[sets[9000][0]] - 0.25
+    for P in (24, 200):
+        want = o.find_nearest_centroids(q, P)
+        with ctx.option("MDB_REFINE_WAVE_MIN_B", 8), ctx.option("MDB_MF_COOLDOWN", 0):
+            assert np.array_equal(g.find_nearest_centroids(q, P), want), P
+            assert np.array_equal(g.find_nearest_centroids(q[:9], P), want[:9]), P
+            with ctx.option("MDB_REFINE_NO_GROUPS", 1):
+                assert np.array_equal(g.find_nearest_centroids(q, P), want), P
+            with ctx.option("MDB_REFINE_NO_SECOND_BOUND", 1):     # the filter's candidates refined as they are
+                assert np.array_equal(g.find_nearest_centroids(q, P), want), P
+        assert np.array_equal(g.find_nearest_centroids(q, P), want), P
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_ivf_sharded_coarse_search_equals_unsharded(ctx, oracle, world):
     """Multi-GPU IVF shards the coarse quantizer too (muopdb_amd.distributed.sharded_probes): every rank scans its
