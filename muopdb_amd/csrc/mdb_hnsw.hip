@@ -650,7 +650,9 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 // A lone wave pays ~10-15 cycles per dependent instruction (VALU<->SALU round trips), so the design
 // goal is instruction count on wave 0's path, not bandwidth.
 // ==========================================================================================
+#ifndef BREGS
 #define BREGS 5
+#endif
 #define BEAM_LDS_C 2048
 #define BEAM_LDS_NBID (BEAM_LDS_C + 8192)
 #define BEAM_LDS_NBDIST (BEAM_LDS_NBID + 1024)
