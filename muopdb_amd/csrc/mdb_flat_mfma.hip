@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
 // U[m][t' * 32 + column] = approximate distance + its error budget (crow[m] holds the query's norm at that point):
 //   L2 : qn + xn - 2 acc + kappa (qn + xn)        dot: -acc + kappa (qn + xn) / 2
 // `qids` is U (as floats), `qcap` the sample size, `nt32` the sample's tile count.
-template <int METRIC, int QB, int NKT, bool SMP = false>   // NKT: compile-time number of 16-dim chunks (8 = d <= 128: LDS offsets become immediates), 0 = run time
+template <int METRIC, int QB, int NKT, bool SMP = false, bool APX = false>   // APX: candidates carry their products (qapx); NKT: compile-time number of 16-dim chunks (8 = d <= 128: LDS offsets become immediates), 0 = run time
 __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kernel(
     const uint4* __restrict__ bhi, const uint4* __restrict__ blo, const float* __restrict__ xnorm, size_t n, size_t nt32, int nk_rt,
     const float* __restrict__ dqc, int qstride, const float* __restrict__ crow, float kappa, uint32_t* __restrict__ qcnt,
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
                 hits &= hits - 1;
                 const size_t m = q0 + (size_t)(qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
                 float av = 0.0f;
-                if (qapx) {   // this lane's accumulator r (a uniform r would be a readlane; r differs per lane: a 16-way select)
+                if (APX) {   // this lane's accumulator r (a uniform r would be a readlane; r differs per lane: a 16-way select)
                     // a select tree on r's bits: 15 conditional moves
                     // (the accumulators pass through empty asm statements: left visible, the selects below are folded into ONE
                     // dynamic element extract and lowered to sixteen compare-and-move pairs per level — 300 instructions)
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
                     const float u0 = b2 ? f1 : f0, u1 = b2 ? f3 : f2;
                     av = b3 ? u1 : u0;
                 }
-                ws_push(has && m < b, ((uint64_t)m << 32) | (uint32_t)v, wbuf, wcnt, qcnt, qids, qcap, lane, av, wapx, qapx);
+                ws_push(has && m < b, ((uint64_t)m << 32) | (uint32_t)v, wbuf, wcnt, qcnt, qids, qcap, lane, av, wapx, APX ? qapx : nullptr);
             }
         }
     };
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
         epilogue(t, xnt);
         t = tn;
     }
-    if (!SMP) ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane, wapx, qapx);
+    if (!SMP) ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane, wapx, APX ? qapx : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------ refine
@@ -1205,14 +1205,18 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
             const unsigned nblk_b = (unsigned)std::max<size_t>(1, std::min<size_t>((aux.nt32 + 3) / 4, std::max<size_t>(1, 512 / groups)));
             dim3 gridb(nblk_b, (unsigned)groups);
             const size_t ldsb = (size_t)QB * aux.nk * 2048 + BQ * 4 + BF_LBUF * 8 + 64 + (qapx ? BF_LBUF * 4 : 0);
-#define BF_LAUNCH(METRIC, QBT, NKT)                                                                                  \
+#define BF_LAUNCH1(METRIC, QBT, NKT, APXT)                                                                           \
     do {                                                                                                             \
         if (ldsb > 48 * 1024)                                                                                        \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_bf16_filter_kernel<METRIC, QBT, NKT>,                 \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_bf16_filter_kernel<METRIC, QBT, NKT, false, APXT>,    \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));               \
-        flat_bf16_filter_kernel<METRIC, QBT, NKT><<<gridb, 256, ldsb, ctx->stream>>>(aux.bhi.p, aux.blo.p, aux.xnorm.p, ts.n, aux.nt32,    \
-                                                                                     aux.nk, dqc, qstride, crow, kappa, qcnt, qids,       \
-                                                                                     qcap, b, ctx->d_flags, 0, qapx);                     \
+        flat_bf16_filter_kernel<METRIC, QBT, NKT, false, APXT><<<gridb, 256, ldsb, ctx->stream>>>(                    \
+            aux.bhi.p, aux.blo.p, aux.xnorm.p, ts.n, aux.nt32, aux.nk, dqc, qstride, crow, kappa, qcnt, qids, qcap, b, ctx->d_flags, 0, qapx); \
+    } while (0)
+#define BF_LAUNCH(METRIC, QBT, NKT)                  \
+    do {                                             \
+        if (qapx) BF_LAUNCH1(METRIC, QBT, NKT, true); \
+        else BF_LAUNCH1(METRIC, QBT, NKT, false);    \
     } while (0)
 #define BF_QB(METRIC, NKT)                                             \
     do {                                                               \
@@ -1225,6 +1229,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
             else { if (aux.nk == 8) BF_QB(MDB_METRIC_DOT, 8); else BF_QB(MDB_METRIC_DOT, 0); }
 #undef BF_QB
 #undef BF_LAUNCH
+#undef BF_LAUNCH1
             MDB_HIP(ctx, hipGetLastError());
         } else {
         unsigned nblk = (unsigned)std::min<size_t>((ts.ntiles + 3) / 4, groups >= 4 ? 256 : 512);

@@ -4,6 +4,8 @@ the same index: any missed neighbour (a hole in the filter's error bound) shows 
 Data kinds include large common offsets, tiny spreads, huge magnitudes, duplicates and near-ties.
 
     python scripts/stress_mfma.py --seconds 300 [--seed 0]
+    python scripts/stress_mfma.py --coarse --seconds 300     # the same data as an IVF coarse quantizer: the large-batch refine
+                                                             # (flat_refine_group_kernel + second bound) forced on every batch
 """
 import argparse
 import os
@@ -36,12 +38,56 @@ def make(rng, n, d, kind):
     return x.astype(np.float32)
 
 
+def coarse(ctx, args):
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import BlockBasedIvf
+    t0, it = time.time(), 0
+    ctx.set_option("MDB_MF_COOLDOWN", 0)
+    while time.time() - t0 < args.seconds:
+        rng = np.random.default_rng(args.seed * 104729 + it)
+        n = int(rng.choice([65600, 70000, 100000]))
+        d = int(rng.choice([4, 16, 30, 64, 128, 200]))
+        b = int(rng.choice([8, 17, 33, 64, 130, 600]))
+        P = int(rng.choice([1, 10, 24, 64, 200]))
+        kind = int(rng.integers(0, 6))
+        cent = make(rng, n, d, kind)
+        if rng.integers(0, 3) == 0:   # blocks of identical centroids: ties beyond the survivor buffer / the chunk / the list capacity
+            for cnt in rng.choice([300, 1200, 3000, 9000], int(rng.integers(1, 3))):
+                rows = rng.choice(n, int(cnt), replace=False)
+                cent[rows] = cent[rows[0]]
+        pls = [np.array([i], dtype=np.uint64) for i in range(n)]
+        g = BlockBasedIvf(ctx, F.write_ivf_index(cent, list(range(1, n + 1)), pls), F.write_vector_file(cent))
+        if rng.integers(0, 2):
+            q = (cent[rng.integers(0, n, b)] + rng.standard_normal((b, d)).astype(np.float32) * np.float32(rng.choice([0, 1e-3, 1]))).astype(np.float32)
+        else:
+            q = make(rng, b, d, kind)
+        with ctx.option("MDB_FLAT_NO_MFMA", 1):
+            want = g.find_nearest_centroids(q, P)
+        for opts in ({"MDB_REFINE_WAVE_MIN_B": 8}, {"MDB_REFINE_WAVE_MIN_B": 8, "MDB_REFINE_NO_SECOND_BOUND": 1}, {}):
+            for kk, vv in opts.items():
+                ctx.set_option(kk, vv)
+            got = g.find_nearest_centroids(q, P)
+            ctx.set_option("MDB_REFINE_WAVE_MIN_B", 512)
+            ctx.set_option("MDB_REFINE_NO_SECOND_BOUND", 0)
+            if not np.array_equal(got, want):
+                bad = np.nonzero((got != want).any(1))[0]
+                print("MISMATCH it=%d seed=%d cfg=%s opts=%s rows=%s" % (it, args.seed, dict(n=n, d=d, b=b, P=P, kind=kind), opts, bad[:5]), flush=True)
+                print(got[bad[0]], want[bad[0]])
+                sys.exit(1)
+        g.close()
+        it += 1
+    print("coarse refine stress OK: %d index/query sets in %.0f s" % (it, time.time() - t0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--coarse", action="store_true")
     args = ap.parse_args()
     ctx = L.Context(0)
+    if args.coarse:
+        return coarse(ctx, args)
     t0, it, used = time.time(), 0, 0
     while time.time() - t0 < args.seconds:
         rng = np.random.default_rng(args.seed * 7919 + it)
