@@ -650,6 +650,9 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 // A lone wave pays ~10-15 cycles per dependent instruction (VALU<->SALU round trips), so the design
 // goal is instruction count on wave 0's path, not bandwidth.
 // ==========================================================================================
+#ifndef MDB_HNSW_SPEC
+#define MDB_HNSW_SPEC 1
+#endif
 #ifndef BREGS
 #define BREGS 5
 #endif
@@ -712,6 +715,7 @@ __device__ __forceinline__ bool beam_best_id(const uint32_t (&cdv)[BREGS], const
 template <int METRIC, bool VIS_LDS, int N16T, bool PF, bool ROW64>
 __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     constexpr int NCH = ROW64 ? 1 : 4;   // 64-edge chunks of a row
+    constexpr bool SPEC = MDB_HNSW_SPEC && !PF && N16T > 0 && N16T <= 16;   // the groups' first vector is requested ahead of the list length
     // the prefetch wave is wave 5: SIMD 1, which it shares with a distance wave that mostly waits for memory; wave 4 (it would share
     // SIMD 0 with wave 0, whose issue slots ARE the step time) only attends the barriers
     constexpr int BLK = PF ? HNSW_BLOCK + 128 : HNSW_BLOCK;
@@ -742,6 +746,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
     for (int i = tid; i < a.dpad; i += BLK) qs[i] = a.q[(size_t)qi * a.qstride + i];
     if (VIS_LDS)
         for (unsigned long long i = tid; i < a.vis_words; i += BLK) vis[i] = 0;
+    if (tid < 16) nb_id[tid] = 0;   // the groups' speculative first fetch reads its slot before any list was written: row 0 exists
     __syncthreads();
 
     const float* vecs = a.vecs + u.vec_off;
@@ -893,6 +898,15 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
             __syncthreads();
             if (wave == 0) PIPE_TE(1, t_b1);
             PIPE_TB(t_sh);
+            // the groups' FIRST neighbour is fetched before the list length is known: nb_id[group] and then the vector are requested
+            // right behind the barrier, in parallel with the read of misc[0] (slots past the list hold ids of earlier steps — valid
+            // rows, their values unused); the length used to sit in front of both round trips
+            float4 sx[SPEC ? N16T / 4 : 1];
+            if (SPEC && wave != 0) {
+                const float4* x4 = (const float4*)(vecs + (size_t)nb_id[grp - 4] * a.dpad + j * N16T);
+#pragma unroll
+                for (int c = 0; c < (SPEC ? N16T / 4 : 1); ++c) sx[c] = x4[c];
+            }
             const uint32_t nnew = misc[0];
             if (nnew == 0xFFFFFFFFu) break;
             ++sg;
@@ -942,6 +956,23 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                             nb_od[i] = f32_orderable(da);
                             if (two) nb_od[i2] = f32_orderable(db);
                             if (da != da || db != db) atomicOr(a.flags, MDB_FLAG_NAN);
+                        }
+                    }
+                } else if (SPEC) {
+                    const uint32_t i = grp - 4;   // nnew <= NG: one neighbour per group at most, already on its way
+                    if (i < nnew) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < (SPEC ? N16T / 4 : 1); ++c) {
+                            acc = acc_term<METRIC>(acc, qr[4 * c + 0], sx[c].x);
+                            acc = acc_term<METRIC>(acc, qr[4 * c + 1], sx[c].y);
+                            acc = acc_term<METRIC>(acc, qr[4 * c + 2], sx[c].z);
+                            acc = acc_term<METRIC>(acc, qr[4 * c + 3], sx[c].w);
+                        }
+                        const float d = finish_distance<METRIC>(__fadd_rn(0.0f, group_reduce16_dpp(acc)));
+                        if (j == 0) {
+                            nb_od[i] = f32_orderable(d);
+                            if (d != d) atomicOr(a.flags, MDB_FLAG_NAN);
                         }
                     }
                 } else {

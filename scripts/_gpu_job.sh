@@ -1,15 +1,11 @@
 cd /root/repo
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "coarse or flat" 2>&1 | tail -3
-python bench.py --workload flat --n 1000000 --batch 64 --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null > gpurun_out/r3_flat.json
+timeout 1200 python -m pytest tests/test_gpu_traversal.py -x -q -m gpu -k "hnsw" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "hnsw or c2" 2>&1 | tail -3
+for i in 1 2; do
+python bench.py --workload hnsw --steps 30 --warmup 5 --no-cpu-baseline --streams 0 2>/dev/null > gpurun_out/r3_h.json
 python - <<PY
 import json
-j=json.loads([x for x in open('gpurun_out/r3_flat.json') if x.startswith('{')][-1])
-print('flat b64', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'])
+j=json.loads([x for x in open('gpurun_out/r3_h.json') if x.startswith('{')][-1])
+print('spec', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('recall_at_10'))
 PY
-python bench.py --workload c5 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null > gpurun_out/r3_c5.json
-python - <<PY
-import json
-j=json.loads([x for x in open('gpurun_out/r3_c5.json') if x.startswith('{')][-1])
-print('c5', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('rank_of_8_step',{}).get('ms_per_step'))
-PY
-timeout 700 python scripts/stress_mfma.py --coarse --seconds 420 --seed 3 2>&1 | tail -4
+done
