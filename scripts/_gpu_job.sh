@@ -1,11 +1,8 @@
 cd /root/repo
-timeout 1200 python -m pytest tests/test_gpu_traversal.py -x -q -m gpu -k "hnsw" 2>&1 | tail -3
-timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "hnsw or c2" 2>&1 | tail -3
-for i in 1 2; do
-python bench.py --workload hnsw --steps 30 --warmup 5 --no-cpu-baseline --streams 0 2>/dev/null > gpurun_out/r3_h.json
-python - <<PY
-import json
-j=json.loads([x for x in open('gpurun_out/r3_h.json') if x.startswith('{')][-1])
-print('spec', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('recall_at_10'))
-PY
-done
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 800 python scripts/stress_parity.py --seconds 600 --seed 20260930 2>&1 | tail -3
+timeout 400 python scripts/stress_mfma.py --seconds 240 --seed 11 2>&1 | tail -2
+timeout 400 python scripts/stress_mfma.py --coarse --seconds 240 --seed 12 2>&1 | tail -2
+bash scripts/profile_round.sh r3d > gpurun_out/r3d_round.log 2>&1
+tail -2 gpurun_out/r3d_round.log
