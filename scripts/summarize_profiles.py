@@ -11,12 +11,21 @@ OURS = ("hnsw_", "flat_", "sample_bound", "ivf_", "merge_", "remap_", "spann_", 
 WL = {  # workload -> (dominant kernel prefix, bench.py traffic key, config match)
     "hnsw": ("hnsw_beam_kernel", "hnsw", {"n": 1000000, "dim": 128, "batch": 64, "ef": 200, "k": 10}),
     "flat_b1": ("flat_scan_kernel", "flat", {"n": 1000000, "dim": 128, "batch": 1, "k": 10}),
-    "flat_b64": ("flat_bf16_filter_kernel<0, 2, 8, false>", "flat_b64", {"n": 1000000, "dim": 128, "batch": 64, "k": 10}),
+    # <METRIC, QB, NKT, SMP = false, APX>: the filter proper, not its sample pass
+    "flat_b64": ("flat_bf16_filter_kernel<0, 2, 8, false", "flat_b64", {"n": 1000000, "dim": 128, "batch": 64, "k": 10}),
     "ivfpq": ("ivf_pq_fused_kernel", "ivfpq", {"n": 1000000, "dim": 128, "batch": 256, "k": 10, "nprobe": 16}),
     "spann": ("ivf_scan_f32_kernel", "spann", {"n": 1250048, "dim": 768, "batch": 128, "k": 10}),
     "c5": ("ivf_scan_pq3_kernel", "c5", {"dim": 128, "batch": 4096, "k": 10, "nprobe": 64}),   # two-phase scan: phase 1 dominates
     "c4full": ("ivf_scan_f32_kernel", "spann_full", {"n": 10000384, "dim": 768, "batch": 1024, "k": 10}),
 }
+def main_filter(name):
+    """flat_bf16_filter_kernel<METRIC, QB, NKT, SMP, APX> with SMP == false (the sample pass has its own launches)"""
+    if "flat_bf16_filter_kernel<" not in name:
+        return False
+    targs = name.split("flat_bf16_filter_kernel<", 1)[1].split(">", 1)[0].split(",")
+    return len(targs) >= 4 and targs[3].strip() == "false"
+
+
 bench = json.loads(open(os.path.join(src, "bench_all.json")).read().strip().splitlines()[-1])
 shutil.copy(os.path.join(src, "bench_all.json"), os.path.join(dst, "%s_bench_all.json" % rnd))
 lines = {"hnsw": bench}
@@ -63,7 +72,7 @@ for w, (kern, key, match) in WL.items():
         shutil.copy(pm, os.path.join(dst, "%s_%s_pmc_MFMA.csv" % (rnd, w)))
         acc = {}
         for r in csv.DictReader(open(pm)):
-            if "flat_bf16_filter_kernel" in r["Kernel_Name"] and "true>" not in r["Kernel_Name"].split("(")[0][-8:]:
+            if main_filter(r["Kernel_Name"]):
                 acc.setdefault(r["Dispatch_Id"], {}).setdefault(r["Counter_Name"], 0.0)
                 acc[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
         disp = [v for _, v in sorted(acc.items(), key=lambda kv: int(kv[0]))][1:]
