@@ -714,7 +714,7 @@ __global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uin
     uint32_t* ppref = pstart + PQ2_PCH;
     uint32_t* ccnt = ppref + PQ2_PCH + 8;            // candidates of this block
     float* qv = (float*)(ppref + PQ2_PCH + 16);      // the query's own codebook rows [m][subdim]
-    uint32_t* btab = (uint32_t*)(qv + m * subdim);   // [m << nbits]: upper bound (bf16) << 16 | lower bound (bf16) of the row's sum
+    uint32_t* btab = (uint32_t*)(qv + m * subdim);   // [m << nbits]: the f32 sum of the row (as bits)
     const int qi = blockIdx.y, split = blockIdx.x, nsplit = gridDim.x;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / MDB_WAVE), lane = tid % MDB_WAVE;
     const IvfUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     uint32_t* probes_l = ppref + 80;                       // [64]
     uint32_t* qcode = probes_l + 64;                       // [m <= 32]
     float* qv = (float*)(qcode + 32);                      // the query's own codebook rows [m][SUBDIM]
-    float2* btab = (float2*)(qv + m * SUBDIM);             // [m * 256]: (lower, upper) bound of the row's sum, both bf16-exact floats
+    float* btab = qv + m * SUBDIM;                         // [m * 256]: the row's f32 sum (ivf_scan_pq3_kernel's table and bracket)
     uint32_t* cand = (uint32_t*)(btab + m * K);            // [PQF_CAP][1 + MW]: a candidate's point id and code words
     uint64_t* ck = (uint64_t*)(cand + f.cand_words);      // [PQF_CAP] keys: coarse candidates, then the candidates' exact keys
     uint64_t* wkey = ck + PQF_CAP;                         // [64] the winners, ascending
@@ -1280,30 +1280,27 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
             sum = __fadd_rn(sum, acc_term<MDB_METRIC_L2>(0.0f, q.z, c.z));
             sum = __fadd_rn(sum, acc_term<MDB_METRIC_L2>(0.0f, q.w, c.w));
         }
-        // real row sum within (1 +- 32 eps) of `sum`; the exact distance (the same terms in the reference's association) within
-        // (1 +- 2^-17) of the real total: shrink / stretch by 1e-5 / 2e-5, then round the bf16 mantissa outwards
-        const uint32_t lo = __float_as_uint(__fmul_rn(sum, 0.99999f)) >> 16;
-        const uint32_t hi = (__float_as_uint(__fmul_rn(sum, 1.00002f)) + 0xFFFFu) >> 16;
-        const float nanv = __uint_as_float(0x7FC00000u);
-        btab[i] = sum != sum ? make_float2(nanv, nanv) : make_float2(__uint_as_float(lo << 16), __uint_as_float(hi << 16));
+        btab[i] = sum;   // S (1 - g) <= exact <= S (1 + g) for the total S of m such words, g as in ivf_scan_pq3_kernel
     }
+    const float gmar = 1.5f * (float)(m * SUBDIM + m + SUBDIM + 16) * 5.9604645e-8f;
+    const float lo_f = 1.0f - gmar, hi_f = 1.0f + gmar;
     __syncthreads();   // btab, pstart, ppref
     PQF_STAMP(2);
     const int T = (int)ppref[64];
 
     // lower / upper bound of one stored code against the query's
     auto bounds = [&](const uint32_t (&cwv)[MW], float& lb, float& ub) {
-        lb = 0.0f; ub = 0.0f;
+        float tot = 0.0f;
 #pragma unroll
         for (int w = 0; w < MW; ++w) {
 #pragma unroll
             for (int bi = 0; bi < 4; ++bi) {
                 const uint32_t code = (cwv[w] >> (8 * bi)) & 0xFFu;
-                const float2 e = btab[((w * 4 + bi) << nbits) + code];   // one 8-byte LDS read, one packed add
-                lb = __fadd_rn(lb, e.x);
-                ub = __fadd_rn(ub, e.y);
+                tot = __fadd_rn(tot, btab[((w * 4 + bi) << nbits) + code]);
             }
         }
+        lb = __fmul_rn(tot, lo_f);
+        ub = __fmul_rn(tot, hi_f);
     };
     // exact symmetric distance of one stored code (ivf_scan_pq2_kernel::exact_key's terms and association; rows from L2)
     auto exact_key = [&](uint32_t vid, const uint32_t (&cwv)[MW]) -> uint64_t {
@@ -1383,7 +1380,7 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
                 bounds(cw[x], lb, ub);
                 const uint32_t ui = f32_orderable(ub);
                 ubi[x] = ui == 0xFFFFFFFFu ? 0xFFFFFFFEu : ui;                      // NaN: sorts last, never lowers the bound
-                lbi[x] = lb == lb ? min(f32_orderable(__fmul_rn(lb, 0.99998f)), 0xFFFFFFFEu) : 0u;   // a NaN bound always survives: the exact pass reports it
+                lbi[x] = lb == lb ? min(f32_orderable(lb), 0xFFFFFFFEu) : 0u;   // a NaN bound always survives: the exact pass reports it
             }
         }
         if (c0 == 0) PQF_SUB(13);
@@ -2248,7 +2245,7 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
     MDB_HIP(ctx, hipGetLastError());
     // launch 2: one block per query
     const size_t sel_bytes = (BlockSelect<PQF_BLOCK>::lds_bytes((int)std::max(k, num_probes)) + 15) & ~(size_t)15;
-    const size_t lds = (64 + 2 * (PQF_NB + 32) + 16 + 64 + 80 + 64 + 32) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * 256 * 8 + (size_t)fa.cand_words * 4 +
+    const size_t lds = (64 + 2 * (PQF_NB + 32) + 16 + 64 + 80 + 64 + 32) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * 256 * 4 + (size_t)fa.cand_words * 4 +
                        PQF_CAP * 8 + 64 * 8 * 3 + 64 * 4 + sel_bytes;
     {
     ProfScope prof(ctx);

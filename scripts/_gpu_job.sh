@@ -1,10 +1,12 @@
 cd /root/repo
 timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "ivf or pq" 2>&1 | tail -3
-timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "c5 or c3" 2>&1 | tail -3
-python bench.py --workload c5 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null > gpurun_out/r3_c5.json
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "c3" 2>&1 | tail -3
+for i in 1 2; do
+python bench.py --workload ivfpq --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null > gpurun_out/r3_c3.json
 python - <<PY
 import json
-j=json.loads([x for x in open('gpurun_out/r3_c5.json') if x.startswith('{')][-1])
-print('c5', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('rank_of_8_step',{}).get('ms_per_step'))
+j=json.loads([x for x in open('gpurun_out/r3_c3.json') if x.startswith('{')][-1])
+print('c3', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('recall_at_10'), [ (x.get('nprobe'), round(x.get('ms_per_step'),4)) for x in j.get('nprobe_sweep',[])])
 PY
-cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/p1; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o bench -- python /root/repo/bench.py --workload c5 --steps 6 --warmup 2 --no-cpu-baseline > /tmp/p1.log 2>&1; f=$(ls /tmp/p1/*kernel_stats.csv | head -1); cp $f /root/repo/gpurun_out/r3_c5_kernel_stats.csv
+done
+timeout 400 python scripts/stress_parity.py --seconds 240 --seed 5 2>&1 | tail -2
