@@ -47,7 +47,7 @@
     X(hnsw_no_row64, "MDB_HNSW_NO_ROW64", 0)                                                                        \
     X(hnsw_prefetch, "MDB_HNSW_PREFETCH", 0)                                                                        \
     X(hnsw_dbg, "MDB_HNSW_DBG", 0)                                                                                  \
-    X(ivf_coarse_sample_div, "MDB_IVF_COARSE_SAMPLE_DIV", 8) /* L */                                                \
+    X(ivf_coarse_sample_div, "MDB_IVF_COARSE_SAMPLE_DIV", 4) /* L */                                                \
     X(pq_no_fused, "MDB_PQ_NO_FUSED", 0)               /* small batches: the six-launch step instead of ivf_pq_fused_kernel */ \
     X(pqf_cap, "MDB_PQF_CAP", 2048)                    /* fused step: candidate slots (tests force the overflow pass) */      \
     X(pqf_quant_in_prep, "MDB_PQF_QUANT_IN_PREP", 0)   /* fused step: query codes in the prep kernel instead of the per-query one */ \
