@@ -1297,7 +1297,8 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     // scan behind it (an overflowing query was served exactly by its refine slices)
     UnpackOut up = unpack ? *unpack : UnpackOut{};
     if (aux.d_ovf_host) { up.word_src = ovf; up.word_dst = aux.d_ovf_host; }
-    MDB_TRY(merge_keys(ctx, rpart, (size_t)rs * k, b, k, d_keys, d_counts, &up));
+    if ((size_t)rs * k * 8 <= 48 * 1024) MDB_TRY(merge_sorted_rows(ctx, rpart, rs, k, b, d_keys, d_counts, nullptr, &up));   // the slices' rows are sorted
+    else MDB_TRY(merge_keys(ctx, rpart, (size_t)rs * k, b, k, d_keys, d_counts, &up));
     if (!aux.d_ovf_host) MDB_HIP(ctx, hipMemcpyAsync(aux.h_ovf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->opt.mf_dbg) {
         uint32_t hn = 0, ho = 0;

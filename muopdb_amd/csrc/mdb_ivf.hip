@@ -2468,49 +2468,6 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
     return mdb_return_to_host(ctx, back, 3);
 }
 
-// ---- merge of `parts` ASCENDING key rows per query (every rank's coarse row after the all-gather) -> the P smallest ids.
-// A key's rank in the union is its index in its own row plus, per other row, the number of keys before it (one binary search;
-// equal keys — they cannot occur between disjoint centroid slices, but the contract does not forbid them — are ordered by row).
-// One block per query, no selector, no sort, and the ids leave from here (merge_keys + unpack_keys took 62 + 5 us for 4096
-// queries x 8 rows x 64 keys).  A row that is NOT ascending sends its block to rank counting over all keys: correct for any input.
-__global__ __launch_bounds__(256) void merge_sorted_rows_kernel(const uint64_t* __restrict__ keys, int parts, int P, uint32_t* __restrict__ ids_out) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    uint64_t* K = (uint64_t*)lds;
-    __shared__ uint32_t unsorted;
-    const int per = parts * P, tid = threadIdx.x;
-    const uint64_t* src = keys + (size_t)blockIdx.x * per;
-    if (tid == 0) unsorted = 0;
-    for (int i = tid; i < per; i += 256) K[i] = src[i];
-    __syncthreads();
-    for (int i = tid; i + 1 < per; i += 256)
-        if ((i + 1) % P != 0 && K[i] > K[i + 1]) unsorted = 1;
-    __syncthreads();
-    const bool sorted = unsorted == 0;
-    for (int i = tid; i < per; i += 256) {
-        const uint64_t key = K[i];
-        const int row = i / P;
-        int rank;
-        if (sorted) {
-            rank = i - row * P;
-            for (int o = 0; o < parts; ++o) {
-                if (o == row) continue;
-                const uint64_t* R = K + o * P;
-                int lo = 0, hi = P;   // first index whose key is not before `key` (rows below this one win ties)
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const bool before = o < row ? R[mid] <= key : R[mid] < key;
-                    if (before) lo = mid + 1; else hi = mid;
-                }
-                rank += lo;
-            }
-        } else {
-            rank = 0;
-            for (int t = 0; t < per; ++t) rank += (K[t] < key || (K[t] == key && t < i)) ? 1 : 0;
-        }
-        if (rank < P) ids_out[(size_t)blockIdx.x * P + rank] = key == MDB_KEY_MAX ? 0xFFFFFFFFu : key_id(key);
-    }
-}
-
 extern "C" {
 
 mdb_status mdb_ivf_load(mdb_ctx* ctx, const void* index_bytes, size_t index_len, size_t index_offset,
@@ -2647,8 +2604,7 @@ mdb_status mdb_ivf_merge_coarse_keys(mdb_ivf* ivf, const uint64_t* keys, size_t 
         MDB_TRY(mdb_scratch(ctx, 2, total * 4, &dids));
     }
     if (per * 8 <= 48 * 1024) {
-        merge_sorted_rows_kernel<<<dim3((unsigned)b), 256, per * 8, ctx->stream>>>(din, (int)parts, (int)num_probes, (uint32_t*)dids);
-        MDB_HIP(ctx, hipGetLastError());
+        MDB_TRY(merge_sorted_rows(ctx, din, parts, num_probes, b, nullptr, nullptr, (uint32_t*)dids, nullptr));
     } else {
         MDB_TRY(mdb_scratch(ctx, 5, total * 8, &merged));
         MDB_TRY(mdb_scratch(ctx, 1, total * 4 + 16, &dist));

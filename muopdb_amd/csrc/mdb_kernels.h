@@ -24,6 +24,10 @@ struct UnpackOut {
     const uint32_t* word_src = nullptr;   // block 0 copies *word_src to *word_dst (the batched path's overflow count -> pinned host memory:
     uint32_t* word_dst = nullptr;         // no separate device-to-host copy in the step)
 };
+// `rows` ascending rows of k keys per query -> the k smallest (ranks by binary search; any of the outputs may be null).  rows * k * 8
+// bytes must fit 48 KB of LDS.
+mdb_status merge_sorted_rows(mdb_ctx* ctx, const uint64_t* d_rows, size_t rows, size_t k, size_t b, uint64_t* d_out, uint32_t* d_counts,
+                             uint32_t* d_ids32, const UnpackOut* unpack);
 mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const float* d_queries_padded, int qstride,
                           size_t b, size_t k, uint64_t* d_keys, uint32_t* d_counts, bool profile = false,
                           const uint32_t* gate = nullptr, const UnpackOut* unpack = nullptr);
