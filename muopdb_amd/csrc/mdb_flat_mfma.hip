@@ -817,6 +817,37 @@ __global__ __launch_bounds__(BLK) void flat_refine_kernel(const float4* __restri
     }
     const uint32_t lo = (uint32_t)((uint64_t)np * blockIdx.x / gridDim.x), c = (uint32_t)((uint64_t)np * (blockIdx.x + 1) / gridDim.x) - lo;
     const uint32_t* __restrict__ mine = qids + m * (size_t)qcap + lo;
+    if (c <= (uint32_t)BLK) {
+        // the usual slice (a few dozen candidates): one key per thread, and a key's RANK among the slice's (distinct) keys is its
+        // place in the slice's sorted row — no selector, whose final sort of a 512-slot queue was most of this kernel's time
+        uint64_t* keys_l = (uint64_t*)lds;
+        const float* qb = dq + m * qstride;
+        uint64_t key = MDB_KEY_MAX;
+        if (threadIdx.x < c) {
+            const uint32_t v = mine[threadIdx.x];
+            float raw[1];
+            if (ROWS) {
+                Row4Loader ld{tiles + (size_t)v * p.d4};
+                exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
+            } else {
+                TileLoader ld{tiles + (size_t)(v / MDB_TILE) * p.d4 * MDB_TILE + (v % MDB_TILE)};
+                exact_sums<METRIC, 1>(ld, qb, 0, p, raw);
+            }
+            const float dist = finish_distance<METRIC>(raw[0]);
+            if (dist != dist) atomicOr(flags, MDB_FLAG_NAN);
+            key = make_key(dist, v);
+            keys_l[threadIdx.x] = key;
+        }
+        __syncthreads();
+        uint64_t* dst = keys + (m * gridDim.x + blockIdx.x) * (size_t)k;  // partial [query][slice][k]
+        if (threadIdx.x < c) {
+            uint32_t rank = 0;
+            for (uint32_t t = 0; t < c; ++t) rank += keys_l[t] < key ? 1u : 0u;   // broadcast reads
+            if (rank < (uint32_t)k) dst[rank] = key;
+        }
+        for (int j = (int)min(c, (uint32_t)k) + (int)threadIdx.x; j < k; j += BLK) dst[j] = MDB_KEY_MAX;
+        return;
+    }
     BlockSelect<BLK> sel;
     sel.init(lds, k);
     __syncthreads();
