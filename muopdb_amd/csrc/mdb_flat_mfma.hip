@@ -333,35 +333,40 @@ __global__ __launch_bounds__(128) void mfma_prep_kernel(const float* __restrict_
 // at most ~15 % of the top-k share a subset, so the bound sits within a few ranks of the exact k-th).  Then the admission
 // constant exactly as mfma_prep_kernel derives it from an exact bound.
 #define SB_SUB 1024
-__global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restrict__ U, uint32_t ns, int k, float kappa, int metric,
+template <int BLK>   // 256 threads (4 subsets each), or 1024 (one each) for small batches: a block per query is all the parallelism there is
+__global__ __launch_bounds__(BLK) void sample_bound_kernel(const float* __restrict__ U, uint32_t ns, int k, float kappa, int metric,
                                                            float* __restrict__ crow, float* __restrict__ qnorm) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh_prefix, sh_need;
+    constexpr int PER = SB_SUB / BLK;   // subsets per thread
     const size_t m = blockIdx.x;
     const float* __restrict__ row = U + m * (size_t)ns;
     const int tid = threadIdx.x, lane = tid & 63;
-    uint32_t mn[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // an empty subset never counts
-    for (uint32_t i0 = 0; i0 < ns; i0 += 4 * SB_SUB) {   // 16 independent loads in flight per thread
-        float v[4][4];
+    uint32_t mn[PER];
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+    for (int x = 0; x < PER; ++x) mn[x] = 0xFFFFFFFFu;   // an empty subset never counts
+    constexpr int YU = 16 / PER;   // 16 independent loads in flight per thread
+    for (uint32_t i0 = 0; i0 < ns; i0 += YU * SB_SUB) {
+        float v[YU][PER];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const uint32_t i = i0 + SB_SUB * y + 256 * x + tid;
+        for (int y = 0; y < YU; ++y)
+#pragma unroll
+            for (int x = 0; x < PER; ++x) {
+                const uint32_t i = i0 + SB_SUB * y + BLK * x + tid;
                 v[y][x] = i < ns ? row[i] : __uint_as_float(0x7FFFFFFFu);   // image 0xFFFFFFFF: counts as empty
             }
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+        for (int y = 0; y < YU; ++y)
 #pragma unroll
-            for (int x = 0; x < 4; ++x) mn[x] = min(mn[x], f32_orderable(v[y][x]));
+            for (int x = 0; x < PER; ++x) mn[x] = min(mn[x], f32_orderable(v[y][x]));
     }
     uint32_t prefix = 0, need = (uint32_t)k;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        hist[tid] = 0;
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int x = 0; x < PER; ++x)
             if (mn[x] != 0xFFFFFFFFu && (pass == 0 || (mn[x] >> (shift + 8)) == prefix)) atomicAdd(&hist[(mn[x] >> shift) & 255u], 1u);
         __syncthreads();
         if (tid < 64) {  // first digit whose cumulative count reaches `need`
@@ -1221,7 +1226,8 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
 #undef BS_QB
 #undef BS_LAUNCH
         MDB_HIP(ctx, hipGetLastError());
-        sample_bound_kernel<<<dim3((unsigned)b), 256, 0, ctx->stream>>>(umat, (uint32_t)ns, (int)k, kappa, metric, crow, qnorm);
+        if (b <= 256) sample_bound_kernel<1024><<<dim3((unsigned)b), 1024, 0, ctx->stream>>>(umat, (uint32_t)ns, (int)k, kappa, metric, crow, qnorm);
+        else sample_bound_kernel<256><<<dim3((unsigned)b), 256, 0, ctx->stream>>>(umat, (uint32_t)ns, (int)k, kappa, metric, crow, qnorm);
         MDB_HIP(ctx, hipGetLastError());
     }
     // B. filter on the centred copy (L2) / the base itself (dot)
