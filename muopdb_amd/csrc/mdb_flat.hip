@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void merge_sorted_rows_kernel(const uint64_t* 
 
 mdb_status merge_sorted_rows(mdb_ctx* ctx, const uint64_t* d_rows, size_t rows, size_t k, size_t b, uint64_t* d_out, uint32_t* d_counts,
                              uint32_t* d_ids32, const UnpackOut* unpack) {
-    if (b == 0 || k == 0) return MDB_OK;
+    if (b == 0) return MDB_OK;
+    if (k == 0) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "internal: sorted-rows merge of empty rows");   // (callers keep k == 0 on the selector merge, which zeroes the counts)
     if (rows * k * 8 > 48 * 1024) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "internal: %zu rows of %zu keys do not fit the sorted-rows merge", rows, k);
     merge_sorted_rows_kernel<<<dim3((unsigned)b), 256, rows * k * 8, ctx->stream>>>(d_rows, (int)rows, (int)k, d_out, d_counts, d_ids32,
                                                                                     unpack ? *unpack : UnpackOut{});

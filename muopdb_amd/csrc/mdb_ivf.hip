@@ -2176,7 +2176,10 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     }
     }
     MDB_HIP(ctx, hipGetLastError());
-    if (!direct) MDB_TRY(merge_keys(ctx, (const uint64_t*)partial, (size_t)nsplit * k, b, k, d_keys, d_counts));
+    if (!direct) {   // the splits' rows are sorted: ranks by binary search when they fit LDS, the selector merge otherwise
+        if (k > 0 && (size_t)nsplit * k * 8 <= 48 * 1024) MDB_TRY(merge_sorted_rows(ctx, (const uint64_t*)partial, (size_t)nsplit, k, b, d_keys, d_counts, nullptr, nullptr));
+        else MDB_TRY(merge_keys(ctx, (const uint64_t*)partial, (size_t)nsplit * k, b, k, d_keys, d_counts));
+    }
     return MDB_OK;
 }
 

@@ -1,6 +1,11 @@
 cd /root/repo
 timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 500 python scripts/stress_parity.py --seconds 360 --seed 20261001 2>&1 | tail -2
-bash scripts/profile_round.sh r3f > gpurun_out/r3f_round.log 2>&1
-tail -2 gpurun_out/r3f_round.log
+for i in 1 2; do
+python bench.py --workload spann --steps 40 --warmup 5 --no-cpu-baseline --no-sweep 2>/dev/null > gpurun_out/r3_s.json
+python - <<PY
+import json
+j=json.loads([x for x in open('gpurun_out/r3_s.json') if x.startswith('{')][-1])
+print('spann128', round(j['value']), j['ms_per_step'], j['roofline']['kernel_ms'], j.get('recall_at_10'))
+PY
+done
+timeout 400 python scripts/stress_parity.py --seconds 240 --seed 123 2>&1 | tail -1
