@@ -586,6 +586,44 @@ def test_coarse_refine_by_groups_ties_chunks_overflow(ctx, oracle, d):
         assert np.array_equal(g.find_nearest_centroids(q, P), want), P
 
 
+def test_merge_coarse_keys_rows_sorted_unsorted_duplicates_padding(ctx):
+    """mdb_ivf_merge_coarse_keys on hand-made rows: ascending rows (ranks by binary search), rows that are NOT ascending (the
+    block falls back to rank counting), the same key in several rows (both copies kept, ordered by row), rows padded with
+    UINT64_MAX, one part, more keys than fit LDS (the selector merge), fewer valid keys than num_probes."""
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import BlockBasedIvf
+    rng = np.random.default_rng(5)
+    cent = rng.standard_normal((8, 4)).astype(np.float32)
+    g = BlockBasedIvf(ctx, F.write_ivf_index(cent, [1, 2, 3, 4, 5, 6, 7, 8], [np.array([i], dtype=np.uint64) for i in range(8)]),
+                      F.write_vector_file(cent))
+    MAXK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def expect(keys, P):
+        b = keys.shape[0]
+        out = np.empty((b, P), np.uint32)
+        for q in range(b):
+            flat = np.sort(keys[q].reshape(-1), kind="stable")[:P]
+            out[q] = [0xFFFFFFFF if kk == MAXK else int(kk) & 0xFFFFFFFF for kk in flat]
+        return out
+
+    for b, parts, P, mode in [(5, 8, 64, "sorted"), (5, 8, 64, "unsorted"), (3, 1, 17, "sorted"), (4, 3, 10, "dups"), (4, 5, 33, "padded"),
+                              (2, 8, 1024, "sorted"), (3, 4, 7, "few")]:
+        dist = rng.integers(0, 1 << 20, (b, parts, P)).astype(np.uint64)
+        ids = rng.permutation(1 << 22)[: b * parts * P].reshape(b, parts, P).astype(np.uint64)
+        keys = (dist << np.uint64(32)) | ids
+        if mode == "dups":
+            keys[:, 1, :] = keys[:, 0, :]          # a whole row twice: both copies are kept
+        if mode != "unsorted":
+            keys = np.sort(keys, axis=2)
+        if mode == "padded":
+            keys[:, :, P // 2:] = MAXK
+            keys[:, 0, 3:] = MAXK
+        if mode == "few":
+            keys[:, :, 1:] = MAXK                  # 4 valid keys for 7 probes
+        got = g.merge_coarse_keys(keys, P)
+        assert np.array_equal(got, expect(keys, P)), (b, parts, P, mode)
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_ivf_sharded_coarse_search_equals_unsharded(ctx, oracle, world):
     """Multi-GPU IVF shards the coarse quantizer too (muopdb_amd.distributed.sharded_probes): every rank scans its
