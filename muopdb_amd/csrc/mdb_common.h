@@ -57,6 +57,7 @@
     X(pq_no_full, "MDB_PQ_NO_FULL", 0)                                                                              \
     X(pq_blocks, "MDB_PQ_BLOCKS", 256)                                                                              \
     X(pq_eager_trim, "MDB_PQ_EAGER_TRIM", 1)                                                                        \
+    X(pq_no_quantize8, "MDB_PQ_NO_QUANTIZE8", 0)       /* one wave per (vector, subspace) for every codebook */     \
     X(pq_two_phase_min_b, "MDB_PQ_TWO_PHASE_MIN_B", 512)                                                            \
     X(pq_no_two_phase, "MDB_PQ_NO_TWO_PHASE", 0)                                                                    \
     X(pq3_blocks, "MDB_PQ3_BLOCKS", 512)                                                                            \

@@ -424,6 +424,42 @@ struct BlockSelect {
 };
 
 // ------------------------------------------------------------------------------------------ PQ quantize, one wave per subspace
+// the usual codebook (8-bit codes, 8-float subvectors: C3 / C5), in two steps so that a wave can keep its rows for several vectors:
+// this lane's four rows (lane + 64 r) fetched TOGETHER (eight 16-byte loads, one latency instead of four dependent round trips) ...
+__device__ __forceinline__ void pq8_load_rows(const float* __restrict__ cbs, int lane, float4 (&x)[4][2]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float4* row = (const float4*)(cbs + (size_t)(lane + 64 * r) * 8);
+        x[r][0] = row[0];
+        x[r][1] = row[1];
+    }
+}
+// ... and scored with exact_sums' association for a single 8-lane chunk: acc[j] = 0 + (q[j] - x[j])^2,
+// raw = 0 + (((0 + acc[0]) + acc[1]) + ... + acc[7]); returns this lane's best (distance image, centroid) key
+__device__ __forceinline__ uint64_t pq8_score_rows(const float4 (&x)[4][2], const float* __restrict__ sub, int lane) {
+    uint64_t best = ~0ull;
+    const float q[8] = {sub[0], sub[1], sub[2], sub[3], sub[4], sub[5], sub[6], sub[7]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float xv[8] = {x[r][0].x, x[r][0].y, x[r][0].z, x[r][0].w, x[r][1].x, x[r][1].y, x[r][1].z, x[r][1].w};
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = acc_term<MDB_METRIC_L2>(0.0f, q[j], xv[j]);
+        const float raw = __fadd_rn(0.0f, reduce_ordered<8>(acc));
+        if (raw < 3.402823466e+38f) {
+            const uint64_t key = ((uint64_t)f32_orderable(raw) << 32) | (uint32_t)(lane + 64 * r);
+            best = key < best ? key : best;
+        }
+    }
+    return best;
+}
+// minimum of the (distance image, centroid) keys over the wave: smallest image first, then the smallest index among its holders
+__device__ __forceinline__ uint32_t pq_best_code(uint64_t best) {
+    const uint32_t mo = mdb_wave_min_u32((uint32_t)(best >> 32));
+    const uint32_t mi = mdb_wave_min_u32((uint32_t)(best >> 32) == mo ? (uint32_t)best : 0xFFFFFFFFu);
+    return mo == 0xFFFFFFFFu ? 0u : mi;
+}
+
 // ProductQuantizer::quantize pq/mod.rs:152-177 for ONE (vector, subspace): lane l scores centroids l, l+64, ... with the EXACT
 // squared-L2 cascade; "first minimum wins (strict <), start f32::MAX" is the minimum of (distance, centroid index) keys; a NaN
 // distance never wins (`NaN < best` is false).  `sub` (the query's subvector) must be wave-uniform; all 64 lanes call.
@@ -432,29 +468,9 @@ __device__ __forceinline__ uint32_t pq_quantize_wave(const float* __restrict__ s
     uint64_t best = ~0ull;  // no centroid strictly below f32::MAX yet (=> code 0)
     const bool rows16 = (subdim & 3) == 0;  // codebook rows are then whole, 16-byte aligned float4s (the arena is)
     if (K == 256 && subdim == 8) {
-        // the usual codebook (8-bit codes, 8-float subvectors: C3 / C5): this lane's four rows are fetched TOGETHER (eight 16-byte loads,
-        // one latency instead of four dependent round trips), then scored with exact_sums' association for a single 8-lane chunk:
-        // acc[j] = 0 + (q[j] - x[j])^2, raw = 0 + (((0 + acc[0]) + acc[1]) + ... + acc[7])
         float4 x[4][2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float4* row = (const float4*)(cbs + (size_t)(lane + 64 * r) * 8);
-            x[r][0] = row[0];
-            x[r][1] = row[1];
-        }
-        const float q[8] = {sub[0], sub[1], sub[2], sub[3], sub[4], sub[5], sub[6], sub[7]};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float xv[8] = {x[r][0].x, x[r][0].y, x[r][0].z, x[r][0].w, x[r][1].x, x[r][1].y, x[r][1].z, x[r][1].w};
-            float acc[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = acc_term<MDB_METRIC_L2>(0.0f, q[j], xv[j]);
-            const float raw = __fadd_rn(0.0f, reduce_ordered<8>(acc));
-            if (raw < 3.402823466e+38f) {
-                const uint64_t key = ((uint64_t)f32_orderable(raw) << 32) | (uint32_t)(lane + 64 * r);
-                best = key < best ? key : best;
-            }
-        }
+        pq8_load_rows(cbs, lane, x);
+        best = pq8_score_rows(x, sub, lane);
     } else
     for (int c = lane; c < K; c += 64) {
         float raw[1];
@@ -470,10 +486,7 @@ __device__ __forceinline__ uint32_t pq_quantize_wave(const float* __restrict__ s
             best = key < best ? key : best;
         }
     }
-    // minimum of the (distance image, centroid) keys over the wave: smallest image first, then the smallest index among its holders
-    const uint32_t mo = mdb_wave_min_u32((uint32_t)(best >> 32));
-    const uint32_t mi = mdb_wave_min_u32((uint32_t)(best >> 32) == mo ? (uint32_t)best : 0xFFFFFFFFu);
-    return mo == 0xFFFFFFFFu ? 0u : mi;
+    return pq_best_code(best);
 }
 
 // ------------------------------------------------------------------------------------------ PQ (symmetric) distance
