@@ -29,6 +29,35 @@ struct HnswBlobInfo {
     size_t vec_data_offset = 0;
 };
 
+// Compact copy of the UPPER layers of one graph (single-index HNSW), built at load for the table path of
+// mdb_hnsw_upper.hip: the points that occur on a layer >= 1 (as a node or as an edge target) renumbered 0 .. nu-1 in ascending
+// point id — so every (distance, id) tie-break among them reads the same in compact indices — with
+//   rows  [(layer-1) * nu + c] * su   adjacency rows in compact indices (0xFFFFFFFF = no edge; packed like the file's),
+//   ids   [c]                         the point id of compact index c,
+//   tiles                             their vectors as list-contiguous SoA tiles (the flat scan's layout).
+struct HnswUpper {
+    uint32_t nu = 0, su = 0, layers = 0, small_layer = 0, entry_c = 0;
+    DevBuf<uint32_t> rows, ids;
+    TileStore tiles;
+    void view_of(const HnswUpper& s) {
+        nu = s.nu; su = s.su; layers = s.layers; small_layer = s.small_layer; entry_c = s.entry_c;
+        rows.borrow(s.rows); ids.borrow(s.ids);
+        tiles.data.borrow(s.tiles.data); tiles.n = s.tiles.n; tiles.ntiles = s.tiles.ntiles; tiles.d = s.tiles.d; tiles.d4 = s.tiles.d4;
+    }
+};
+// per-batch state handed from hnsw_upper_kernel to the layer-0 instance of hnsw_beam_kernel
+struct HnswUpperOut {
+    uint32_t* ep = nullptr;        // [b] layer-0 entry point (point id)
+    uint32_t* ovf = nullptr;       // [b] 1 = the upper beam overflowed: the layer-0 block re-runs the whole query (general traversal)
+    uint32_t* vis = nullptr;       // [b][words] visited bitmap over compact indices
+    uint32_t words = 0;
+};
+// table[q][c] = order-preserving image of distance(query q, compact point c), exact association (mdb_device.hip.h exact_sums)
+mdb_status hnsw_upper_table(mdb_ctx* ctx, const HnswUpper& up, int metric, const DistPlan& p, const float* d_q, int qstride, size_t b,
+                            uint32_t* d_table);
+// layers num_layers-1 .. 1 of ann_search on the table; fills `out`, adds the layers' evaluations / expansions to ctx->d_counters
+mdb_status hnsw_upper_traverse(mdb_ctx* ctx, const HnswUpper& up, const uint32_t* d_table, size_t b, uint32_t ef, const HnswUpperOut& out);
+
 struct HnswSet {
     mdb_ctx* ctx = nullptr;
     int metric = MDB_METRIC_L2;
@@ -46,6 +75,7 @@ struct HnswSet {
     DevBuf<uint32_t> d_upper_first;
     DevBuf<uint8_t> d_level;
     DevBuf<float> d_vecs;          // [total_rows][dpad], 16-byte aligned rows
+    HnswUpper upper;               // single graph with >= 2 layers and f32 rows: the table path's structures (nu == 0: not built)
 
     // a view of `src` (same device arrays, not owned) bound to another context
     void view_of(const HnswSet& src, mdb_ctx* ctx2) {
@@ -56,6 +86,7 @@ struct HnswSet {
         blobs = src.blobs; h_users = src.h_users; max_n = src.max_n; max_stride = src.max_stride; total_rows = src.total_rows;
         d_index.borrow(src.d_index); d_users.borrow(src.d_users); d_adj.borrow(src.d_adj);
         d_upper_first.borrow(src.d_upper_first); d_level.borrow(src.d_level); d_vecs.borrow(src.d_vecs);
+        upper.view_of(src.upper);
     }
     mdb_status load(mdb_ctx* ctx, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
                     const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant, uint32_t dimension);

@@ -24,6 +24,7 @@
 
 #include "mdb_device.hip.h"
 #include "mdb_hnsw.h"
+#include "mdb_hnsw_dev.hip.h"
 #include "mdb_kernels.h"
 
 #define HNSW_BLOCK 256
@@ -49,6 +50,12 @@ struct HnswArgs {
     unsigned long long vis_words;   // words per query (global bitmap) or LDS words
     uint32_t* flags;
     unsigned long long* counters;   // [0] distance evals, [1] expanded nodes
+    // layer-0 instance of hnsw_beam_kernel (L0): what hnsw_upper_kernel (mdb_hnsw_upper.hip) hands over, read in the prologue only
+    const uint32_t* up_ep;          // [b] layer-0 entry point
+    const uint32_t* up_ovf;         // [b] 1 = re-run the whole query with the general traversal
+    const uint32_t* up_vis;         // [b][up_words] points visited on the upper layers, bitmap over compact indices
+    const uint32_t* up_ids;         // compact index -> point id
+    uint32_t up_words;
 };
 
 // candidate key: ascending u64 == (distance asc, id DESC): BinaryHeap<(-d, id)>::pop order
@@ -230,19 +237,6 @@ __device__ __forceinline__ void cand_drop_dead(const uint64_t* C, int& cbase, in
 }
 
 
-// ---- wave-wide reductions for the register-resident beam (hnsw_beam_kernel)
-#define SLOT_EMPTY 0xFFFFFFFFu
-
-#define MDB_DPP_U32(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rmask), 0xF, false))
-// Volatile accesses through a GENERIC pointer are never rewritten to the LDS address space (InferAddressSpaces leaves volatile
-// memory operations alone): they compile to flat_load / flat_store with system scope and an s_waitcnt vmcnt(0) each — a poll of
-// the mailbox then costs a flat round trip AND waits for every outstanding global load of the wave.  These accessors name the
-// address space, so the accesses are plain ds_read / ds_write.
-typedef __attribute__((address_space(3))) uint32_t mdb_lds_u32;
-typedef __attribute__((address_space(3))) uint64_t mdb_lds_u64;
-__device__ __forceinline__ uint32_t lds_vload(const uint32_t* p) { return *(const volatile mdb_lds_u32*)p; }
-__device__ __forceinline__ uint64_t lds_vload(const uint64_t* p) { return *(const volatile mdb_lds_u64*)p; }
-__device__ __forceinline__ void lds_vstore(uint32_t* p, uint32_t v) { *(volatile mdb_lds_u32*)p = v; }
 // Adjacency row of `node` on an UPPER layer.  Compact form (the file's own economy): level[node] and upper_first[node], then the
 // row — two dependent round trips.  Dense form (built at load when (layers-1) * n * SU * 4 bytes is affordable): the row's address
 // is a function of (layer, node) alone, ONE round trip like layer 0; a point that is not on the layer has an all-empty row, which
@@ -252,27 +246,6 @@ __device__ __forceinline__ const uint32_t* hnsw_upper_row(const HnswArgs& a, con
     if (u.adjD_off != ~0ull) return a.adj + u.adjD_off + ((size_t)(layer - 1) * u.n + node) * u.SU;
     if (a.level[u.upper_off + node] >= layer) return a.adj + u.adjU_off + ((size_t)a.upper_first[u.upper_off + node] + (layer - 1)) * u.SU;
     return nullptr;
-}
-
-// Wave-wide min / max in six DPP steps, the DPP operand folded into the min / max itself (v_min_u32_dpp): 12 issue slots
-// instead of the 24 of "copy, nop, dpp-move, min" — these reductions sit on wave 0's serial chain, where a slot is ~10 cycles.
-// (s_nop 1 = the two wait states a DPP read of a just-written VGPR needs; nobody adds them inside asm.)
-#define MDB_WAVE_REDUCE_ASM(op)                                                        \
-    asm volatile("s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
-                 "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
-                 "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
-                 "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
-                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
-                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
-                 "s_nop 1"                                                             \
-                 : "+v"(v))
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    MDB_WAVE_REDUCE_ASM("v_min_u32_dpp");
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    MDB_WAVE_REDUCE_ASM("v_max_u32_dpp");
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // hnsw_search_kernel — the general traversal kernel (any ef <= 2*MDB_MAX_K): the working set W and the
@@ -653,42 +626,11 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 #ifndef MDB_HNSW_SPEC
 #define MDB_HNSW_SPEC 1
 #endif
-#ifndef BREGS
-#define BREGS 5
-#endif
 #define BEAM_LDS_C 2048
 #define BEAM_LDS_NBID (BEAM_LDS_C + 8192)
 #define BEAM_LDS_NBDIST (BEAM_LDS_NBID + 1024)
 #define BEAM_LDS_MISC (BEAM_LDS_NBDIST + 1024)
 #define BEAM_LDS_QS (BEAM_LDS_MISC + 64)
-#define BEAM_CAP (64 * BREGS)
-
-// nearest unexpanded candidate in pop order (smallest distance image, LARGEST id among equals); `cdv` holds the distance
-// image of unexpanded slots and SLOT_EMPTY elsewhere.  Returns false if none.  Ids are unique in B, so the kernel marks
-// the popped slot by id and needs no slot index (the kernel is SGPR-bound: every spilled scalar costs a v_readlane on wave
-// 0's critical path).
-// One min reduction; the winner's id is the per-lane maximum over the lane's matching slots (in-lane ties resolved for free),
-// read from the single matching lane — only distance ties ACROSS lanes pay a second reduction.
-__device__ __forceinline__ bool beam_best_id(const uint32_t (&cdv)[BREGS], const uint32_t (&bi)[BREGS], uint32_t& o_out, uint32_t& id_out) {
-    uint32_t lm = cdv[0];
-#pragma unroll
-    for (int r = 1; r < BREGS; ++r) lm = min(lm, cdv[r]);
-    const uint32_t m = wave_min_u32(lm);
-    o_out = m;
-    if (m == SLOT_EMPTY) return false;
-    uint32_t li = 0;
-#pragma unroll
-    for (int r = 0; r < BREGS; ++r) li = max(li, cdv[r] == m ? bi[r] : 0u);
-    const unsigned long long hm = __ballot(lm == m);
-    uint32_t id;
-    if (__builtin_expect((hm & (hm - 1)) == 0, 1)) {
-        id = (uint32_t)__builtin_amdgcn_readlane((int)li, __ffsll((long long)hm) - 1);
-    } else {
-        id = wave_max_u32(lm == m ? li : 0u);
-    }
-    id_out = id;
-    return true;
-}
 
 #ifdef MDB_PIPE_DBG   // cycle / event accounting of the roles into counters[4..15] (MDB_HNSW_DBG=1 prints them)
 #define PIPE_TB(t) const unsigned long long t = __builtin_readcyclecounter()
@@ -712,7 +654,9 @@ __device__ __forceinline__ bool beam_best_id(const uint32_t (&cdv)[BREGS], const
 // ROW64: every adjacency row of the index has at most 64 edges (max_neighbors <= 32: the configurations' graphs) — a row is ONE
 // register per lane, a step has ONE chunk: the per-chunk loops, their scalar branches and three of four register copies leave
 // wave 0's chain.
-template <int METRIC, bool VIS_LDS, int N16T, bool PF, bool ROW64>
+// L0: the upper layers were traversed by hnsw_upper_kernel on the distance table (mdb_hnsw_upper.hip) — this instance marks the points
+// visited there, takes the handed-down entry point and runs layer 0 only.
+template <int METRIC, bool VIS_LDS, int N16T, bool PF, bool ROW64, bool L0 = false>
 __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     constexpr int NCH = ROW64 ? 1 : 4;   // 64-edge chunks of a row
     constexpr bool SPEC = MDB_HNSW_SPEC && !PF && N16T > 0 && N16T <= 16;   // the groups' first vector is requested ahead of the list length
@@ -748,6 +692,20 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
         for (unsigned long long i = tid; i < a.vis_words; i += BLK) vis[i] = 0;
     if (tid < 16) nb_id[tid] = 0;   // the groups' speculative first fetch reads its slot before any list was written: row 0 exists
     __syncthreads();
+    if (L0) {
+        // the visited set is shared by the layers (one SearchContext per ann_search, index.rs:172)
+        const uint32_t* const uv = a.up_vis + (size_t)qi * a.up_words;
+        for (uint32_t w = tid; w < a.up_words; w += BLK) {
+            uint32_t bits = uv[w];
+            while (bits) {
+                const uint32_t c = 32u * w + (uint32_t)__ffs((int)bits) - 1u;
+                bits &= bits - 1u;
+                const uint32_t p = a.up_ids[c];
+                atomicOr(&vis[p >> 5], 1u << (p & 31));
+            }
+        }
+        __syncthreads();
+    }
 
     const float* vecs = a.vecs + u.vec_off;
     const int ef = a.ef;
@@ -772,8 +730,8 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
     bool ru_valid = false, stop = false;
     int ru_closer = 0;                 // #{b in B : d_b < d_runner-up}, counted in the shadow of P3 (the stop test of P4)
     uint32_t evals = 0, expanded = 0;  // per query: far below 2^32
-    bool nan_seen = false, overflow = false;
-    uint32_t ep = u.entry_point;
+    bool nan_seen = false, overflow = L0 ? a.up_ovf[qi] != 0u : false;
+    uint32_t ep = L0 ? a.up_ep[qi] : u.entry_point;
     uint32_t sg = 0;                   // PF: step tag (every wave counts alike)
 #ifdef MDB_PIPE_DBG
     unsigned long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -782,7 +740,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
 #pragma unroll
     for (int r = 0; r < BEAM_PF_ROUNDS; ++r) pf_hold[r] = 0.0f;
 
-    for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
+    for (int layer = L0 ? 0 : (int)u.num_layers - 1; layer >= 0; --layer) {
         const uint32_t stride = layer == 0 ? u.S0 : u.SU;
         const uint32_t* const adj_base = a.adj + (layer == 0 ? u.adj0_off : u.adjU_off);
         // adjacency row of `node` at this layer -> dst (lane + 64 c); the loads stay in flight
@@ -1499,6 +1457,58 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
         max_n = std::max(max_n, u.n);
     }
     total_rows = row_src.size();
+    // ---- the table path's compact upper layers (mdb_hnsw_upper.hip): one graph, >= 2 layers, f32 rows, rows of <= 64 edges
+    std::vector<uint32_t> h_cids, h_crows;
+    std::vector<float> h_cvecs;
+    upper.nu = 0;
+    if (U == 1 && kind != MDB_QUANT_PQ && !ctx->opt.hnsw_no_table && h_users[0].num_layers >= 2 && h_users[0].SU <= 64 &&
+        h_users[0].n > 0) {
+        const HnswUserDev& u = h_users[0];
+        const HnswBlobInfo& bi = blobs[0];
+        const uint32_t nl = u.num_layers, SU = u.SU;
+        // compact set: every point on a layer >= 1 and every target of an upper-layer edge (a target that is not on the layer
+        // itself has an empty row there, as in the dense form)
+        std::vector<uint8_t> in_set(u.n, 0);
+        for (uint64_t p = 0; p < u.n; ++p)
+            if (h_level[u.upper_off + p]) in_set[p] = 1;
+        for (uint64_t p = 0; p < u.n; ++p) {
+            const uint32_t lv = h_level[u.upper_off + p];
+            for (uint32_t layer = 1; layer <= lv && layer < nl; ++layer) {
+                const size_t r = (size_t)h_upper_first[u.upper_off + p] + (layer - 1);
+                for (uint32_t t = 0; t < SU; ++t) {
+                    const uint32_t e = h_adj[u.adjU_off + r * SU + t];
+                    if (e != 0xFFFFFFFFu) in_set[e] = 1;
+                }
+            }
+        }
+        std::vector<uint32_t> cidx(u.n, 0xFFFFFFFFu);
+        for (uint64_t p = 0; p < u.n; ++p)
+            if (in_set[p]) { cidx[p] = (uint32_t)h_cids.size(); h_cids.push_back((uint32_t)p); }
+        const size_t nu = h_cids.size();
+        // affordable: rows (nl-1) * nu * SU words, vectors nu * d floats — a small fraction of the graph unless it is degenerate
+        if (nu > 0 && nu <= ((size_t)1 << 22) && nu * 4 <= (size_t)u.n + 4096 && in_set[u.entry_point]) {
+            h_crows.assign((size_t)(nl - 1) * nu * SU, 0xFFFFFFFFu);
+            for (size_t c = 0; c < nu; ++c) {
+                const uint32_t p = h_cids[c];
+                const uint32_t lv = h_level[u.upper_off + p];
+                for (uint32_t layer = 1; layer <= lv && layer < nl; ++layer) {
+                    const size_t r = (size_t)h_upper_first[u.upper_off + p] + (layer - 1);
+                    for (uint32_t t = 0; t < SU; ++t) {
+                        const uint32_t e = h_adj[u.adjU_off + r * SU + t];
+                        h_crows[((size_t)(layer - 1) * nu + c) * SU + t] = e == 0xFFFFFFFFu ? e : cidx[e];
+                    }
+                }
+            }
+            h_cvecs.resize(nu * (size_t)dim);
+            for (size_t c = 0; c < nu; ++c)
+                memcpy(&h_cvecs[c * (size_t)dim], vectors + bi.vec_data_offset + (size_t)h_cids[c] * file_row, (size_t)dim * 4);
+            upper.nu = (uint32_t)nu;
+            upper.su = SU;
+            upper.layers = nl - 1;
+            upper.small_layer = u.small_layer;
+            upper.entry_c = cidx[u.entry_point];
+        }
+    }
     // ---- uploads
     DevBuf<uint8_t> d_vec;
     DevBuf<uint64_t> d_row_src;
@@ -1522,6 +1532,17 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
         copy_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>(d_vec.p, d_row_src.p, (int)dim, dpad,
                                                                                         make_plan((int)dim, metric).n16, d_vecs.p, total);
     MDB_HIP(ctx, hipGetLastError());
+    if (upper.nu) {
+        DevBuf<float> d_cvecs;
+        if (upper.rows.alloc(h_crows.size() + 1) != hipSuccess || upper.ids.alloc(h_cids.size() + 1) != hipSuccess ||
+            d_cvecs.alloc(h_cvecs.size() + 4) != hipSuccess)
+            return mdb_fail(ctx, MDB_ERR_OOM, "HNSW upper-layer table structures");
+        MDB_HIP(ctx, hipMemcpyAsync(upper.rows.p, h_crows.data(), h_crows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        MDB_HIP(ctx, hipMemcpyAsync(upper.ids.p, h_cids.data(), h_cids.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        MDB_HIP(ctx, hipMemcpyAsync(d_cvecs.p, h_cvecs.data(), h_cvecs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        MDB_TRY(tiles_from_rows(ctx, d_cvecs.p, upper.nu, (int)dim, upper.tiles));
+        MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // d_cvecs and the host vectors are released below
+    }
     MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MDB_OK;
 }
@@ -1587,9 +1608,21 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
         hnsw_beam_kernel<METRIC, VL, NF, PF, R64><<<dim3((unsigned)b), (PF) ? HNSW_BLOCK + 128 : HNSW_BLOCK, lds, ctx->stream>>>(a); \
     } while (0)
+#define MDB_BEAM_LAUNCH_L0(METRIC, VL, NF, PF)                                                                              \
+    do {                                                                                                                    \
+        if (lds > 48 * 1024)                                                                                                \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF, PF, true, true>,                 \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hnsw_beam_kernel<METRIC, VL, NF, PF, true, true><<<dim3((unsigned)b), (PF) ? HNSW_BLOCK + 128 : HNSW_BLOCK, lds, ctx->stream>>>(a); \
+    } while (0)
 #define MDB_HNSW_LAUNCH(METRIC, VL)                                                                              \
     do {                                                                                                           \
-        if (beam && prefetch) {                                                                             \
+        if (table) {                                                                                               \
+            if (nf == 8 && l0_prefetch) MDB_BEAM_LAUNCH_L0(METRIC, VL, 8, true);                                   \
+            else if (nf == 8) MDB_BEAM_LAUNCH_L0(METRIC, VL, 8, false);                                            \
+            else if (nf == 48) MDB_BEAM_LAUNCH_L0(METRIC, VL, 48, false);                                          \
+            else MDB_BEAM_LAUNCH_L0(METRIC, VL, 0, false);                                                         \
+        } else if (beam && prefetch) {                                                                             \
             if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, true, true);                                               \
             else MDB_BEAM_LAUNCH(METRIC, VL, 48, true, true);                                                      \
         } else if (beam && row64) {                                                                                \
@@ -1640,13 +1673,35 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     const bool beam = ef <= 256 && !ctx->opt.hnsw_no_beam;
     // hnsw_beam_kernel with its prefetch wave (see the kernel): f32 rows of whole 16-lane chunks
     const bool row64 = max_stride <= 64 && !ctx->opt.hnsw_no_row64;   // hnsw_beam_kernel's one-chunk specialisation
-    const bool prefetch = beam && row64 && (nf == 8 || nf == 48) && ctx->opt.hnsw_prefetch;   // OPT-IN: measured slower
+    const bool prefetch = beam && row64 && (nf == 8 || nf == 48) && ctx->opt.hnsw_prefetch == 1;   // OPT-IN: measured slower
+    // upper layers on the distance table (mdb_hnsw_upper.hip): table pass, single-wave traversal, then the layer-0 instance of
+    // the beam kernel.  One graph (no per-query user), f32 rows; the table is b * nu words of scratch
+    const uint32_t nu_pad = (uint32_t)upper.tiles.ntiles * MDB_TILE;
+    const bool l0_prefetch = ctx->opt.hnsw_prefetch == 2;   // experiment: the prefetch wave beside the layer-0 instance
+    const bool table = upper.nu > 0 && !d_q_user && beam && row64 && (!prefetch || l0_prefetch) && kind != MDB_QUANT_PQ && !ctx->opt.hnsw_no_table &&
+                       (long long)b >= ctx->opt.hnsw_table_min_b && (uint64_t)b * nu_pad * 4 <= ((uint64_t)2 << 30) &&
+                       (size_t)(upper.nu / 32 + 4) * 4 <= 96 * 1024;
+    if (table) {
+        const uint32_t words = (upper.nu / 32 + 4) & ~3u;   // a multiple of 4: hnsw_upper_kernel puts the table row's LDS copy (16-byte stores) behind the bitmap
+        void *tab, *st;
+        MDB_TRY(mdb_scratch(ctx, 8, (size_t)b * nu_pad * 4 + 64, &tab));
+        MDB_TRY(mdb_scratch(ctx, 9, (size_t)b * (words + 2) * 4 + 64, &st));
+        HnswUpperOut uo;
+        uo.ep = (uint32_t*)st;
+        uo.ovf = uo.ep + b;
+        uo.vis = uo.ovf + b;
+        uo.words = words;
+        MDB_TRY(hnsw_upper_table(ctx, upper, metric, a.p, d_q, qstride, b, (uint32_t*)tab));
+        MDB_TRY(hnsw_upper_traverse(ctx, upper, (const uint32_t*)tab, b, ef, uo));
+        a.up_ep = uo.ep; a.up_ovf = uo.ovf; a.up_vis = uo.vis; a.up_ids = upper.ids.p; a.up_words = words;
+    }
     if (metric == MDB_METRIC_L2) {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false);
     } else {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_DOT, true); else MDB_HNSW_LAUNCH(MDB_METRIC_DOT, false);
     }
 #undef MDB_BEAM_LAUNCH
+#undef MDB_BEAM_LAUNCH_L0
 #undef MDB_HNSW_LAUNCH4
 #undef MDB_HNSW_LAUNCH
     MDB_HIP(ctx, hipGetLastError());

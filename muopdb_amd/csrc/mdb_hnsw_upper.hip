@@ -1,0 +1,499 @@
+// mdb_hnsw_upper.hip — the UPPER layers of BlockBasedHnsw::ann_search (hnsw/block_based/index.rs:159-190) as a table pass
+// plus a single-wave traversal.
+//
+// The reference runs search_layer with the full ef on EVERY layer (index.rs:174-186), so 60 % of a query's node expansions
+// happen on layers >= 1 — which together hold only ~n/31 points (32 k of 1 M).  Instead of gathering neighbour vectors step by
+// step there, one streaming pass evaluates every (query, upper point) distance with the exact lane association
+// (hnsw_upper_table_kernel: the flat scan's thread-per-vector exact_sums over SoA tiles, queries as scalar operands; 16 MB read
+// once per batch, QT queries per load) and the traversal of those layers becomes bookkeeping on table lookups:
+//   * one WAVE per query, no block barrier, no distance waves, no LDS hand-off: the step's visited test-and-set (LDS atomics)
+//     and its table lookups are issued together and land while the wave selects the runner-up and requests its row;
+//   * the neighbours stay in their row lanes (lane = edge slot): no ordered compaction — the acceptance-by-counting lemma of
+//     hnsw_beam_kernel only needs edge order = lane order;
+//   * everything is indexed by COMPACT index (ascending point id, so tie-breaks are unchanged): 4 KB visited bitmap per query.
+// The evaluation / expansion counters count lookups exactly where the reference evaluates a distance, the visited set (shared by
+// the layers, index.rs:172) is handed to the layer-0 kernel as a bitmap over compact indices, and a query whose beam overflows
+// (> ~120 exact ties with furthest) is flagged for the general traversal there.  Rows, score bits and both counters equal the
+// all-in-one kernel's and the oracle's (tests/test_gpu_traversal.py, test_gpu_fullsize.py).
+#include "mdb_hnsw.h"
+#include "mdb_hnsw_dev.hip.h"
+#include "mdb_kernels.h"
+
+// ------------------------------------------------------------------------------------------ table
+// grid (tiles, query groups of QT); one wave = one tile of 64 upper points, thread = point
+template <int METRIC, int QT>
+__global__ __launch_bounds__(64) void hnsw_upper_table_kernel(const float4* __restrict__ tiles, uint32_t nu, DistPlan p,
+                                                              const float* __restrict__ q, int qstride, uint32_t q_first,
+                                                              uint32_t* __restrict__ table, uint32_t nu_pad) {
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    const uint32_t v = tile * MDB_TILE + lane;
+    const uint32_t q0 = q_first + blockIdx.y * QT;
+    float raw[QT];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) raw[i] = 0.0f;
+    if (v < nu) {
+        TileLoader ld{tiles + (size_t)tile * p.d4 * MDB_TILE + lane};
+        exact_sums<METRIC, QT, TileLoader, 0>(ld, q + (size_t)q0 * qstride, qstride, p, raw);
+    }
+#pragma unroll
+    for (int i = 0; i < QT; ++i)
+        table[(size_t)(q0 + i) * nu_pad + v] = v < nu ? f32_orderable(finish_distance<METRIC>(raw[i])) : SLOT_EMPTY;
+}
+
+// d = 16 * n16 (128, 768: the configurations' dimensions).  One wave = one tile, thread = point, QT queries per pass of the tile.
+// The 16 lane accumulators of the reference per (query, point) stay in registers (QT * 16).  A query's 16-float chunk is ONE
+// register (lane l holds element l % 16: a 64-byte load replicated over the four 16-lane rows) and reaches the arithmetic as the
+// DPP operand of the subtract / multiply itself (row_newbcast:j = element j to every lane of the row): no scalar loads (exact_sums
+// <QT = 8> takes 264-286 VGPRs and spills scalars; its s_load -> s_waitcnt lgkmcnt(0) per chunk left the SIMDs idle 80 % of the
+// time), no LDS, 3 VALU per element and query.  Two register buffers of the tile's chunks: the next chunk's loads are in flight
+// while the current one is accumulated.
+#define MDB_T16_TERM(J)                                                                                                     \
+    if (METRIC != MDB_METRIC_DOT) {                                                                                         \
+        float df;                                                                                                           \
+        asm("v_sub_f32_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "=v"(df) : "v"(vq), "v"(xv[J]));     \
+        ac[J] = __fadd_rn(ac[J], __fmul_rn(df, df));                                                                        \
+    } else {                                                                                                                \
+        float pr;                                                                                                           \
+        asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "=v"(pr) : "v"(vq), "v"(xv[J]));     \
+        ac[J] = __fadd_rn(ac[J], pr);                                                                                       \
+    }
+template <int METRIC>
+__device__ __forceinline__ void t16_accumulate(float (&ac)[16], const float vq, const float (&xv)[16]) {
+    MDB_T16_TERM(0) MDB_T16_TERM(1) MDB_T16_TERM(2) MDB_T16_TERM(3) MDB_T16_TERM(4) MDB_T16_TERM(5) MDB_T16_TERM(6) MDB_T16_TERM(7)
+    MDB_T16_TERM(8) MDB_T16_TERM(9) MDB_T16_TERM(10) MDB_T16_TERM(11) MDB_T16_TERM(12) MDB_T16_TERM(13) MDB_T16_TERM(14) MDB_T16_TERM(15)
+}
+#undef MDB_T16_TERM
+
+template <int METRIC, int QT>
+__global__ __launch_bounds__(256) void hnsw_upper_table16_kernel(const float4* __restrict__ tiles, uint32_t nu, uint32_t ntiles, int n16,
+                                                                 const float* __restrict__ q, int qstride, uint32_t q_first,
+                                                                 uint32_t* __restrict__ table, uint32_t nu_pad) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t tile = blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    const uint32_t v = tile * MDB_TILE + lane;
+    const float4* tp = tiles + (size_t)tile * (4 * n16) * MDB_TILE + lane;
+    const uint32_t q0 = q_first + blockIdx.y * QT;
+    const float* __restrict__ ql = q + (size_t)q0 * qstride + (lane & 15);   // this lane's element of every chunk
+    float acc[QT][16];
+#pragma unroll
+    for (int i = 0; i < QT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
+    float4 xa[4], xb[4];
+    float qa[QT], qb[QT];
+    auto load = [&](float4 (&x)[4], float (&qv)[QT], int c) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = tp[(size_t)(4 * c + t) * MDB_TILE];
+#pragma unroll
+        for (int i = 0; i < QT; ++i) qv[i] = ql[(size_t)i * qstride + 16 * c];
+    };
+    auto accumulate = [&](const float4 (&x)[4], const float (&qv)[QT]) {
+        const float xv[16] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w,
+                              x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
+#pragma unroll
+        for (int i = 0; i < QT; ++i) t16_accumulate<METRIC>(acc[i], qv[i], xv);
+    };
+    load(xa, qa, 0);
+    int c = 0;
+#pragma unroll 1
+    for (; c + 2 <= n16; c += 2) {
+        load(xb, qb, c + 1);
+        accumulate(xa, qa);
+        if (c + 2 < n16) load(xa, qa, c + 2);
+        accumulate(xb, qb);
+    }
+    if (c < n16) accumulate(xa, qa);
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        const float raw = __fadd_rn(0.0f, reduce_ordered<16>(acc[i]));   // exact_sums: ret = 0 + (ordered sum of the 16 lanes)
+        table[(size_t)(q0 + i) * nu_pad + v] = v < nu ? f32_orderable(finish_distance<METRIC>(raw)) : SLOT_EMPTY;
+    }
+}
+
+mdb_status hnsw_upper_table(mdb_ctx* ctx, const HnswUpper& up, int metric, const DistPlan& p, const float* d_q, int qstride, size_t b,
+                            uint32_t* d_table) {
+    const uint32_t nu_pad = (uint32_t)up.tiles.ntiles * MDB_TILE;
+    const float4* tiles = (const float4*)up.tiles.data.p;
+    if (p.n16 > 0 && p.n8 == 0 && p.n4 == 0 && p.ntail == 0) {
+        const unsigned gx = (unsigned)((up.tiles.ntiles + 3) / 4);
+        const int qf = ctx->opt.hnsw_table_qt == 8 ? 8 : ctx->opt.hnsw_table_qt == 2 ? 2 : 4;
+#define MDB_UT16_GO(METRIC, QF, first, groups)                                                                                     \
+    hnsw_upper_table16_kernel<METRIC, QF><<<dim3(gx, (groups)), 256, 0, ctx->stream>>>(                                            \
+        tiles, up.nu, (uint32_t)up.tiles.ntiles, p.n16, d_q, qstride, (first), d_table, nu_pad)
+#define MDB_UT16_LAUNCH(METRIC)                                                                                                   \
+    do {                                                                                                                          \
+        const uint32_t full = (uint32_t)(b / qf), rest = (uint32_t)(b % qf);                                                      \
+        if (full) {                                                                                                               \
+            if (qf == 8) MDB_UT16_GO(METRIC, 8, 0u, full);                                                                        \
+            else if (qf == 4) MDB_UT16_GO(METRIC, 4, 0u, full);                                                                   \
+            else MDB_UT16_GO(METRIC, 2, 0u, full);                                                                                \
+        }                                                                                                                         \
+        if (rest) MDB_UT16_GO(METRIC, 1, full * qf, rest);                                                                        \
+    } while (0)
+        if (metric == MDB_METRIC_L2) MDB_UT16_LAUNCH(MDB_METRIC_L2); else MDB_UT16_LAUNCH(MDB_METRIC_DOT);
+#undef MDB_UT16_LAUNCH
+#undef MDB_UT16_GO
+        MDB_HIP(ctx, hipGetLastError());
+        return MDB_OK;
+    }
+    constexpr int QT = 2;   // any dimension: the cascade of exact_sums
+    const uint32_t full = (uint32_t)(b / QT), rest = (uint32_t)(b % QT);
+#define MDB_UT_LAUNCH(METRIC)                                                                                                     \
+    do {                                                                                                                          \
+        if (full)                                                                                                                 \
+            hnsw_upper_table_kernel<METRIC, QT><<<dim3((unsigned)up.tiles.ntiles, full), 64, 0, ctx->stream>>>(                    \
+                tiles, up.nu, p, d_q, qstride, 0u, d_table, nu_pad);                                                              \
+        if (rest)                                                                                                                 \
+            hnsw_upper_table_kernel<METRIC, 1><<<dim3((unsigned)up.tiles.ntiles, rest), 64, 0, ctx->stream>>>(                     \
+                tiles, up.nu, p, d_q, qstride, full * QT, d_table, nu_pad);                                                       \
+    } while (0)
+    if (metric == MDB_METRIC_L2) MDB_UT_LAUNCH(MDB_METRIC_L2); else MDB_UT_LAUNCH(MDB_METRIC_DOT);
+#undef MDB_UT_LAUNCH
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
+
+// ------------------------------------------------------------------------------------------ traversal
+struct HnswUpArgs {
+    const uint32_t* rows;     // [(layer-1) * nu + c] * su
+    const uint32_t* ids;      // compact index -> point id
+    const uint32_t* table;    // [b][nu_pad] distance images
+    uint32_t nu, nu_pad, su, layers, small_layer, entry_c;
+    int ef;
+    uint32_t vis_words;
+    uint32_t* out_ep;
+    uint32_t* out_ovf;
+    uint32_t* out_vis;
+    uint32_t* flags;
+    unsigned long long* counters;
+};
+
+#define UP_LDS_STAGE 0                 // 512 keys (compaction staging)
+#define UP_LDS_FLAG 4096               // 512 words
+#define UP_LDS_FR 6144                 // two frontier lists of 64 (closure of tiny layers)
+#define UP_LDS_VIS 6656
+
+// One wave per query.  State and step logic are hnsw_beam_kernel's wave 0 (over-full unsorted register beam B, acceptance and stop
+// test by counting, runner-up + its row fetched ahead); what is gone is everything between its P2 and P4.
+// TLDS: the query's table row (nu_pad words, 129 KB at 1 M points / 32 k upper points) is copied into LDS by the whole block first —
+// a lookup is then an LDS read (~100 cycles) instead of a first-touch miss of a line the table kernel wrote from another XCD
+// (the L2s are not coherent: the row comes back from the Infinity Cache / HBM, ~1 k cycles, 40 % of the lookups).  Waves 1-3 only
+// help with that copy.
+#define UP_BLOCK 256
+template <bool TLDS>
+__global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint64_t* const C = (uint64_t*)(lds + UP_LDS_STAGE);
+    uint32_t* const stage_flag = (uint32_t*)(lds + UP_LDS_FLAG);
+    uint32_t* const fr = (uint32_t*)(lds + UP_LDS_FR);
+    uint32_t* const vis = (uint32_t*)(lds + UP_LDS_VIS);
+    const int qi = blockIdx.x, lane = threadIdx.x & 63;
+    const uint32_t* const tg = a.table + (size_t)qi * a.nu_pad;
+    uint32_t* const tl = vis + a.vis_words;   // TLDS: the row's copy (vis_words is a multiple of 4: 16-byte aligned; nu_pad is a multiple of 64)
+    for (uint32_t i = threadIdx.x; i < a.vis_words; i += UP_BLOCK) vis[i] = 0;
+    if (TLDS) {
+        const uint4* src = (const uint4*)tg;
+        uint4* dst = (uint4*)tl;
+        for (uint32_t i = threadIdx.x; i < a.nu_pad / 4; i += UP_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const uint32_t* const tq = TLDS ? tl : tg;
+    const int ef = a.ef;
+    const uint32_t su = a.su;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t bd[BREGS], bi[BREGS], cdv[BREGS];
+    int n = 0;
+    uint32_t fbound = SLOT_EMPTY;
+    uint32_t rowv = 0xFFFFFFFFu, rowr = 0xFFFFFFFFu;
+    uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
+    bool ru_valid = false, stop = false, overflow = false, nan_lane = false;
+    int ru_closer = 0;
+    // expanded slots of B.  Every unexpanded slot is at least as far as the candidate about to be popped, so the stop count
+    // #{b : d_b < d_candidate} is at most nexp: no count is taken while nexp < ef (a layer stops after >= ef expansions or not at all)
+    int nexp = 0;
+    uint32_t evals = 0, expanded = 0;
+    uint32_t ep = a.entry_c;
+
+    for (int layer = (int)a.layers; layer >= 1 && !overflow; --layer) {
+        const uint32_t* const lrows = a.rows + (size_t)(layer - 1) * a.nu * su;
+        auto load_row = [&](uint32_t node) -> uint32_t { return (uint32_t)lane < su ? lrows[(size_t)node * su + lane] : 0xFFFFFFFFu; };
+        if ((uint32_t)layer >= a.small_layer && ef >= 64) {
+            // ---- a layer with no more points than ef (<= 64, edges only among them): its result is the closure of the entry
+            // point whatever the pop order (see hnsw_closure_kernel) — whole frontiers per round, 64 / sp points per pass
+            uint32_t sp = 1;
+            while (sp < su) sp <<= 1;
+            const uint32_t per = 64u / sp;
+            uint32_t* cur = fr;
+            uint32_t* nxt = fr + 64;
+            if (lane == 0) { atomicOr(&vis[ep >> 5], 1u << (ep & 31)); cur[0] = ep; }
+            uint32_t ncur = 1;
+            uint64_t best = MDB_KEY_MAX;
+            while (ncur > 0) {
+                uint32_t nnext = 0;
+                for (uint32_t base = 0; base < ncur; base += per) {
+                    const uint32_t pi = base + lane / sp, slot = lane % sp;
+                    const bool act = pi < ncur;
+                    const uint32_t f = act ? cur[pi] : 0u;
+                    const uint32_t nbr = (act && slot < su) ? lrows[(size_t)f * su + slot] : 0xFFFFFFFFu;
+                    if (act && slot == 0) {
+                        const uint32_t od = tq[f];
+                        const float fd = f32_from_orderable(od);
+                        if (fd != fd) nan_lane = true;
+                        const uint64_t key = ((uint64_t)od << 32) | f;
+                        best = key < best ? key : best;
+                    }
+                    expanded += (uint32_t)__popcll(__ballot(act && slot == 0 && nbr != 0xFFFFFFFFu));  // rows are packed
+                    bool isnew = false;
+                    if (nbr != 0xFFFFFFFFu) {
+                        const uint32_t bit = 1u << (nbr & 31);
+                        isnew = !(atomicOr(&vis[nbr >> 5], bit) & bit);
+                    }
+                    const unsigned long long bal = __ballot(isnew);
+                    if (isnew) nxt[nnext + __popcll(bal & lt_mask)] = nbr;
+                    nnext += (uint32_t)__popcll(bal);
+                }
+                evals += ncur;
+                ncur = nnext;
+                uint32_t* t = cur; cur = nxt; nxt = t;
+            }
+            // smallest (distance, id) of the layer's points
+            const uint32_t mo = wave_min_u32((uint32_t)(best >> 32));
+            ep = wave_min_u32((uint32_t)(best >> 32) == mo ? (uint32_t)best : 0xFFFFFFFFu);
+            continue;
+        }
+        // ---- entry point: mark visited, look its distance up, seed B (index.rs:219-231) and pop it at once
+        {
+            if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
+            rowv = load_row(ep);
+            const uint32_t od0 = tq[ep];
+            const float f0 = f32_from_orderable(od0);
+            if (f0 != f0) nan_lane = true;
+#pragma unroll
+            for (int r = 0; r < BREGS; ++r) { bd[r] = SLOT_EMPTY; bi[r] = 0; cdv[r] = SLOT_EMPTY; }
+            if (lane == 0) { bd[0] = od0; bi[0] = ep; }
+            n = 1;
+            nexp = 1;
+            fbound = SLOT_EMPTY;
+            stop = false;
+            ru_valid = false;
+            evals += 1;
+        }
+        while (!stop && !overflow) {
+            // ---- visited test-and-set and table lookups of the popped node's row: issued together ...
+            const uint32_t nbr = rowv;
+            const bool valid = nbr != 0xFFFFFFFFu;
+            uint32_t old = 0, od = SLOT_EMPTY;
+            const uint32_t bit = 1u << (nbr & 31);
+            if (valid) {
+                old = atomicOr(&vis[nbr >> 5], bit);
+                od = tq[nbr];
+            }
+            // ---- ... and in flight while the wave finds the best candidate already in B (the next pop unless a neighbour accepted
+            // below beats it), requests its row and takes its stop count
+            ru_valid = beam_best_id(cdv, bi, ru_o, ru_id);
+            if (ru_valid) {
+                rowr = load_row(ru_id);
+                ru_closer = 0;
+                if (nexp >= ef) {
+#pragma unroll
+                    for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
+                }
+            }
+            const bool have = valid && !(old & bit);
+            const unsigned long long hm = __ballot(have);
+            const uint32_t nnew = (uint32_t)__popcll(hm);
+            expanded += __ballot(valid) != 0 ? 1u : 0u;
+            evals += nnew;
+            od = have ? od : SLOT_EMPTY;
+            if (have) {
+                const float fd = f32_from_orderable(od);
+                if (fd != fd) nan_lane = true;   // the reference panics (NotNan::new(..).unwrap())
+            }
+            const uint32_t id = nbr;
+            // ---- accept + push (hnsw_beam_kernel P4 on row lanes), then choose the next node
+            uint32_t best_o = SLOT_EMPTY, best_id = 0;
+            bool best_have = false;
+            if (nnew) {
+                unsigned long long surv = __ballot(have && od < fbound);
+                unsigned long long accepted = 0;
+                // fill phase of a layer: B still holds at most ef elements after this step — every count below would be < ef
+                if (n + (int)nnew <= ef) { accepted = surv; surv = 0; }
+                while (surv) {
+                    const int sidx = __ffsll((long long)surv) - 1;
+                    surv &= surv - 1;
+                    const uint32_t ds = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                    int cnt = __popcll(__ballot(have && od <= ds) & ((1ull << sidx) - 1ull));
+#pragma unroll
+                    for (int r = 0; r < BREGS; ++r) cnt += __popcll(__ballot(bd[r] <= ds));
+                    if (cnt < ef) accepted |= 1ull << sidx;
+                    else fbound = min(fbound, ds);
+                }
+                const int na = __popcll(accepted);
+                if (na) {
+                    if (n + na > BEAM_CAP) {
+                        // ---- compaction: f = ef-th smallest distance image in B (32-step radix select by ballots), drop what is farther
+                        uint32_t prefix = 0;
+                        int need = ef;
+                        for (int b = 31; b >= 0; --b) {
+                            const uint32_t hi_mask = b == 31 ? 0u : (0xFFFFFFFFu << (b + 1));
+                            int cnt0 = 0;
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r)
+                                cnt0 += __popcll(__ballot((((bd[r] ^ prefix) & hi_mask) == 0u) && !((bd[r] >> b) & 1u)));
+                            if (cnt0 < need) { need -= cnt0; prefix |= 1u << b; }
+                        }
+                        const uint32_t f = prefix;
+                        int kept = 0;
+#pragma unroll
+                        for (int r = 0; r < BREGS; ++r) {
+                            const bool keep = bd[r] <= f;
+                            const unsigned long long km = __ballot(keep);
+                            if (keep) {
+                                const int pos = kept + __popcll(km & lt_mask);
+                                C[pos] = ((uint64_t)bd[r] << 32) | bi[r];
+                                stage_flag[pos] = cdv[r] != SLOT_EMPTY ? 1u : 0u;
+                            }
+                            kept += __popcll(km);
+                        }
+#pragma unroll
+                        for (int r = 0; r < BREGS; ++r) {
+                            const int idx = lane + 64 * r;
+                            const bool in = idx < kept;
+                            const uint64_t kk = in ? C[idx] : 0;
+                            bd[r] = in ? (uint32_t)(kk >> 32) : SLOT_EMPTY;
+                            bi[r] = in ? (uint32_t)kk : 0u;
+                            cdv[r] = (in && stage_flag[idx] != 0u) ? bd[r] : SLOT_EMPTY;
+                        }
+                        n = kept;
+                        nexp = 0;
+#pragma unroll
+                        for (int r = 0; r < BREGS; ++r) nexp += __popcll(__ballot(bd[r] != SLOT_EMPTY && cdv[r] == SLOT_EMPTY));
+                        fbound = min(fbound, f);
+                        if (n + na > BEAM_CAP) { overflow = true; break; }
+                        ru_valid = beam_best_id(cdv, bi, ru_o, ru_id);  // may have been dropped
+                        if (ru_valid) rowr = load_row(ru_id);
+                        ru_closer = 0;
+                        if (nexp >= ef) {
+#pragma unroll
+                            for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
+                        }
+                    }
+                    if (nexp >= ef) ru_closer += __popcll(accepted & __ballot(od < ru_o));
+                    // ---- push all accepted neighbours: slots n .. n+na-1, in edge order (forward lane permute)
+                    {
+                        const bool mine = (accepted >> lane) & 1ull;
+                        const int dest = mine ? (n + __popcll(accepted & lt_mask)) & 63 : (n + na) & 63;
+                        const uint32_t rod = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)od);
+                        const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)id);
+                        const int rel = (lane - n) & 63;
+                        const bool got = rel < na;
+                        const int reg = (n + rel) >> 6;
+#pragma unroll
+                        for (int r = 0; r < BREGS; ++r) {
+                            const bool w = got && reg == r;
+                            bd[r] = w ? rod : bd[r];
+                            bi[r] = w ? rid : bi[r];
+                            cdv[r] = w ? rod : cdv[r];
+                        }
+                    }
+                    // best accepted neighbour in pop order (smallest distance, largest id)
+                    if (na > 2) {
+                        const bool mine = (accepted >> lane) & 1ull;
+                        best_o = wave_min_u32(mine ? od : SLOT_EMPTY);
+                        best_id = wave_max_u32(mine && od == best_o ? id : 0u);
+                        best_have = true;
+                    } else {
+                        unsigned long long am = accepted;
+                        while (am) {
+                            const int sidx = __ffsll((long long)am) - 1;
+                            am &= am - 1;
+                            const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                            const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
+                            if (!best_have || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_have = true; }
+                        }
+                    }
+                    n += na;
+                }
+            }
+            // ---- candidates.pop(): runner-up vs best accepted; stop when it is farther than furthest
+            const bool take_ru = ru_valid && (!best_have || ru_o < best_o || (ru_o == best_o && ru_id > best_id));
+            if (!take_ru && !best_have) {
+                stop = true;  // no candidate left
+            } else {
+                int closer = nexp >= ef ? ru_closer : 0;
+                if (!take_ru) {
+                    closer = 0;
+                    if (nexp >= ef) {
+#pragma unroll
+                        for (int r = 0; r < BREGS; ++r) closer += __popcll(__ballot(bd[r] < best_o));
+                    }
+                }
+                if (closer >= ef) {
+                    stop = true;  // `distance > furthest.distance` (index.rs:246-248)
+                } else if (take_ru) {
+#pragma unroll
+                    for (int r = 0; r < BREGS; ++r)
+                        if (bi[r] == ru_id) cdv[r] = SLOT_EMPTY;   // ids are unique in B
+                    rowv = rowr;
+                    ++nexp;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < BREGS; ++r)
+                        if (bi[r] == best_id) cdv[r] = SLOT_EMPTY;
+                    rowv = load_row(best_id);
+                    ++nexp;
+                }
+            }
+        }
+        if (overflow) break;
+        // ---- a layer hands its nearest point down (index.rs:177-181: smallest distance, then smallest id)
+        {
+            uint32_t m = bd[0];
+#pragma unroll
+            for (int r = 1; r < BREGS; ++r) m = min(m, bd[r]);
+            m = wave_min_u32(m);
+            uint32_t im = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < BREGS; ++r) im = bd[r] == m ? min(im, bi[r]) : im;
+            ep = wave_min_u32(im);
+        }
+    }
+    for (uint32_t i = lane; i < a.vis_words; i += 64) a.out_vis[(size_t)qi * a.vis_words + i] = vis[i];
+    const bool nan_seen = __ballot(nan_lane) != 0;
+    if (lane == 0) {
+        a.out_ep[qi] = overflow ? 0u : a.ids[ep];
+        a.out_ovf[qi] = overflow ? 1u : 0u;
+        if (!overflow) {
+            atomicAdd(&a.counters[0], (unsigned long long)evals);
+            atomicAdd(&a.counters[1], (unsigned long long)expanded);
+            if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
+        }
+    }
+}
+
+mdb_status hnsw_upper_traverse(mdb_ctx* ctx, const HnswUpper& up, const uint32_t* d_table, size_t b, uint32_t ef, const HnswUpperOut& out) {
+    HnswUpArgs a{};
+    a.rows = up.rows.p; a.ids = up.ids.p; a.table = d_table;
+    a.nu = up.nu; a.nu_pad = (uint32_t)up.tiles.ntiles * MDB_TILE; a.su = up.su; a.layers = up.layers; a.small_layer = up.small_layer;
+    a.entry_c = up.entry_c;
+    a.ef = (int)ef;
+    a.vis_words = out.words;
+    a.out_ep = out.ep; a.out_ovf = out.ovf; a.out_vis = out.vis;
+    a.flags = ctx->d_flags; a.counters = ctx->d_counters;
+    const size_t lds_base = UP_LDS_VIS + (size_t)out.words * 4;
+    const bool tlds = lds_base + (size_t)a.nu_pad * 4 <= 160 * 1024 - 512 && !ctx->opt.hnsw_table_no_lds;
+    const size_t lds = lds_base + (tlds ? (size_t)a.nu_pad * 4 : 0);
+    if (tlds) {
+        if (lds > 48 * 1024)
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hnsw_upper_kernel<true><<<dim3((unsigned)b), UP_BLOCK, lds, ctx->stream>>>(a);
+    } else {
+        if (lds > 48 * 1024)
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hnsw_upper_kernel<false><<<dim3((unsigned)b), UP_BLOCK, lds, ctx->stream>>>(a);
+    }
+    MDB_HIP(ctx, hipGetLastError());
+    return MDB_OK;
+}
