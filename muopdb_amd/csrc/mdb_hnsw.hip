@@ -626,6 +626,9 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 #ifndef MDB_HNSW_SPEC
 #define MDB_HNSW_SPEC 1
 #endif
+#ifndef MDB_HNSW_L0TOUCH
+#define MDB_HNSW_L0TOUCH 1
+#endif
 #define BEAM_LDS_C 2048
 #define BEAM_LDS_NBID (BEAM_LDS_C + 8192)
 #define BEAM_LDS_NBDIST (BEAM_LDS_NBID + 1024)
@@ -736,6 +739,14 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
 #ifdef MDB_PIPE_DBG
     unsigned long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    // L0TOUCH (layer-0 instance, rows of one register, f32 vectors of at most 8 lines): wave 0 touches the runner-up's unvisited
+    // neighbours' vectors in its barrier slack (see the shadow below)
+    constexpr bool L0TOUCH = L0 && ROW64 && !PF && N16T > 0 && N16T <= 16 && MDB_HNSW_L0TOUCH;
+    constexpr int L0_LINES = L0TOUCH ? (N16T + 1) / 2 : 1;   // 128-byte lines per vector
+    float l0_hold[L0_LINES];
+    uint32_t row_hold = 0;
+#pragma unroll
+    for (int t = 0; t < L0_LINES; ++t) l0_hold[t] = 0.0f;
     float pf_hold[BEAM_PF_ROUNDS];     // PF: the touched words, "used" one step later
 #pragma unroll
     for (int r = 0; r < BEAM_PF_ROUNDS; ++r) pf_hold[r] = 0.0f;
@@ -888,6 +899,24 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                     ru_closer = 0;
 #pragma unroll
                     for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
+                    if (L0TOUCH) {
+                        // ---- layer 0: the distance waves' gather is the long side of a step (1.5 k cycles against 0.7 k here: the
+                        // 512 MB of vectors miss L2 and the Infinity Cache) and wave 0 would wait ~0.9 k cycles at the barrier below.
+                        // It waits for the runner-up's row instead, drops the neighbours already visited (a plain read of the set: a
+                        // stale answer costs or saves a touch, nothing else) and touches every 128-byte line of the others' vectors
+                        // — one neighbour per lane, no compaction — a whole P4 + P2 ahead of the gather that will ask for them.
+                        // A touch is a load whose value is "used" one step later: nothing ever waits for it.
+#pragma unroll
+                        for (int t = 0; t < L0_LINES; ++t) asm volatile("" ::"v"(l0_hold[t]));   // last step's touches end here
+                        const uint32_t nb = rowr[0];
+                        bool want = nb != 0xFFFFFFFFu;
+                        if (VIS_LDS && want) want = !((vis[nb >> 5] >> (nb & 31)) & 1u);
+                        if (want) {
+                            const float* vp = vecs + (size_t)nb * a.dpad;
+#pragma unroll
+                            for (int t = 0; t < L0_LINES; ++t) l0_hold[t] = vp[32 * t];
+                        }
+                    }
                 }
             } else if (PF && wave == 5) {
                 // ---- prefetch wave: the runner-up's row, requested as soon as wave 0 names it (it arrives around the barrier)
@@ -942,6 +971,15 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                         }
                     }
                 }
+            }
+            if (L0TOUCH && wave != 0) {
+                // ---- layer 0: every point that is evaluated may be popped later, and its adjacency row (256 MB of rows at 1 M points)
+                // then comes from HBM, ~1.1 k cycles, in front of wave 0's touches.  The group that evaluates a point touches the
+                // point's row lines as well: when the point becomes the runner-up, its row is in L2 or the Infinity Cache.
+                asm volatile("" ::"v"(row_hold));   // last step's touch ends here (the distances above are done: the groups only wait for wave 0 now)
+                const uint32_t lines = (stride + 31) / 32;
+                for (uint32_t i = grp - 4; i < nnew; i += (HNSW_BLOCK - 64) / 16)
+                    if ((uint32_t)j < lines) row_hold = adj_base[(size_t)nb_id[i] * stride + 32 * j];
             }
             if (wave == 0) PIPE_TE(2, t_sh);
             if (wave == 1) PIPE_TE(9, t_sh);

@@ -169,6 +169,13 @@ struct HnswUpArgs {
     unsigned long long* counters;
 };
 
+#ifdef MDB_PIPE_DBG   // -DMDB_PIPE_DBG + MDB_HNSW_DBG=1: cycle / event sums into counters[4..15] (the traversal kernels print the same words)
+#define UP_T(t) const unsigned long long t = __builtin_readcyclecounter()
+#define UP_ACC(slot, v) dbg_acc[slot] += (v)
+#else
+#define UP_T(t) do {} while (0)
+#define UP_ACC(slot, v) do {} while (0)
+#endif
 #define UP_LDS_STAGE 0                 // 512 keys (compaction staging)
 #define UP_LDS_FLAG 4096               // 512 words
 #define UP_LDS_FR 6144                 // two frontier lists of 64 (closure of tiny layers)
@@ -215,6 +222,9 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
     int nexp = 0;
     uint32_t evals = 0, expanded = 0;
     uint32_t ep = a.entry_c;
+#ifdef MDB_PIPE_DBG
+    unsigned long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     for (int layer = (int)a.layers; layer >= 1 && !overflow; --layer) {
         const uint32_t* const lrows = a.rows + (size_t)(layer - 1) * a.nu * su;
@@ -282,6 +292,7 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
         }
         while (!stop && !overflow) {
             // ---- visited test-and-set and table lookups of the popped node's row: issued together ...
+            UP_T(t0);
             const uint32_t nbr = rowv;
             const bool valid = nbr != 0xFFFFFFFFu;
             uint32_t old = 0, od = SLOT_EMPTY;
@@ -301,6 +312,7 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
                     for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
                 }
             }
+            UP_T(t1);
             const bool have = valid && !(old & bit);
             const unsigned long long hm = __ballot(have);
             const uint32_t nnew = (uint32_t)__popcll(hm);
@@ -315,8 +327,11 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
             // ---- accept + push (hnsw_beam_kernel P4 on row lanes), then choose the next node
             uint32_t best_o = SLOT_EMPTY, best_id = 0;
             bool best_have = false;
+            UP_T(t2);
+            UP_ACC(0, t1 - t0); UP_ACC(1, t2 - t1); UP_ACC(5, 1); UP_ACC(6, nnew);
             if (nnew) {
                 unsigned long long surv = __ballot(have && od < fbound);
+                UP_ACC(7, __popcll(surv));
                 unsigned long long accepted = 0;
                 // fill phase of a layer: B still holds at most ef elements after this step — every count below would be < ef
                 if (n + (int)nnew <= ef) { accepted = surv; surv = 0; }
@@ -331,8 +346,11 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
                     else fbound = min(fbound, ds);
                 }
                 const int na = __popcll(accepted);
+                UP_T(t3);
+                UP_ACC(2, t3 - t2); UP_ACC(8, na); UP_ACC(9, na == 1 ? 1 : 0); UP_ACC(10, na >= 3 ? 1 : 0);
                 if (na) {
                     if (n + na > BEAM_CAP) {
+                        UP_ACC(11, 1);
                         // ---- compaction: f = ef-th smallest distance image in B (32-step radix select by ballots), drop what is farther
                         uint32_t prefix = 0;
                         int need = ef;
@@ -416,7 +434,10 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
                     }
                     n += na;
                 }
+                UP_T(t4);
+                UP_ACC(3, t4 - t3);
             }
+            UP_T(t5);
             // ---- candidates.pop(): runner-up vs best accepted; stop when it is farther than furthest
             const bool take_ru = ru_valid && (!best_have || ru_o < best_o || (ru_o == best_o && ru_id > best_id));
             if (!take_ru && !best_have) {
@@ -446,6 +467,8 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
                     ++nexp;
                 }
             }
+            UP_T(t6);
+            UP_ACC(4, t6 - t5);
         }
         if (overflow) break;
         // ---- a layer hands its nearest point down (index.rs:177-181: smallest distance, then smallest id)
@@ -462,6 +485,11 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
     }
     for (uint32_t i = lane; i < a.vis_words; i += 64) a.out_vis[(size_t)qi * a.vis_words + i] = vis[i];
     const bool nan_seen = __ballot(nan_lane) != 0;
+#ifdef MDB_PIPE_DBG
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i)
+            if (dbg_acc[i]) atomicAdd(&a.counters[4 + i], dbg_acc[i]);
+#endif
     if (lane == 0) {
         a.out_ep[qi] = overflow ? 0u : a.ids[ep];
         a.out_ovf[qi] = overflow ? 1u : 0u;
