@@ -39,9 +39,10 @@ struct HnswUpper {
     uint32_t nu = 0, su = 0, layers = 0, small_layer = 0, entry_c = 0;
     DevBuf<uint32_t> rows, ids;
     TileStore tiles;
+    DevBuf<float> rows_nat;   // the same vectors row-major [nu + 64][d] (d a multiple of 16, at most 128): hnsw_upper_table64_kernel's operand
     void view_of(const HnswUpper& s) {
         nu = s.nu; su = s.su; layers = s.layers; small_layer = s.small_layer; entry_c = s.entry_c;
-        rows.borrow(s.rows); ids.borrow(s.ids);
+        rows.borrow(s.rows); ids.borrow(s.ids); rows_nat.borrow(s.rows_nat);
         tiles.data.borrow(s.tiles.data); tiles.n = s.tiles.n; tiles.ntiles = s.tiles.ntiles; tiles.d = s.tiles.d; tiles.d4 = s.tiles.d4;
     }
 };
@@ -53,10 +54,19 @@ struct HnswUpperOut {
     uint32_t words = 0;
 };
 // table[q][c] = order-preserving image of distance(query q, compact point c), exact association (mdb_device.hip.h exact_sums)
+// (zero16 != nullptr: the kernel also clears those 16 counter words — stream order puts that ahead of the traversal kernels)
 mdb_status hnsw_upper_table(mdb_ctx* ctx, const HnswUpper& up, int metric, const DistPlan& p, const float* d_q, int qstride, size_t b,
-                            uint32_t* d_table);
+                            uint32_t* d_table, unsigned long long* zero16 = nullptr);
 // layers num_layers-1 .. 1 of ann_search on the table; fills `out`, adds the layers' evaluations / expansions to ctx->d_counters
 mdb_status hnsw_upper_traverse(mdb_ctx* ctx, const HnswUpper& up, const uint32_t* d_table, size_t b, uint32_t ef, const HnswUpperOut& out);
+
+// device-resident calls: where the layer-0 kernel may write the caller's (doc id, score) rows itself; done = it did
+struct HnswRemapOut {
+    mdb_u128* doc = nullptr;
+    float* score = nullptr;
+    uint32_t* counts = nullptr;
+    bool done = false;
+};
 
 struct HnswSet {
     mdb_ctx* ctx = nullptr;
@@ -92,8 +102,9 @@ struct HnswSet {
                     const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant, uint32_t dimension);
     // beam search of every query through its user's graph: device keys [b][k] (distance, point id)
     // ascending + counts.  d_q_user == nullptr => user 0.
+    // zero_counters: clear ctx->d_counters[0..15] ahead of the traversal (callers that did not do it themselves)
     mdb_status search(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, size_t k, uint32_t ef,
-                      uint64_t* d_keys, uint32_t* d_counts);
+                      uint64_t* d_keys, uint32_t* d_counts, bool zero_counters = false, HnswRemapOut* fuse = nullptr);
     // keys -> (u128 doc id, score) rows in key order (ann_search :192-208 does not re-sort)
     mdb_status remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,
                      mdb_u128* d_doc, float* d_score, uint32_t* d_counts_out);

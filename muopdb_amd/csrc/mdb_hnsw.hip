@@ -56,6 +56,11 @@ struct HnswArgs {
     const uint32_t* up_vis;         // [b][up_words] points visited on the upper layers, bitmap over compact indices
     const uint32_t* up_ids;         // compact index -> point id
     uint32_t up_words;
+    // L0, device-resident calls: the block writes the caller's (doc id, score) rows itself (ann_search :192-208) — no remap launch
+    const uint8_t* rm_index;        // uploaded index bytes (doc ids); nullptr: keys only
+    mdb_u128* rm_doc;
+    float* rm_score;
+    uint32_t* rm_counts;            // may be null
 };
 
 // candidate key: ascending u64 == (distance asc, id DESC): BinaryHeap<(-d, id)>::pop order
@@ -1250,6 +1255,24 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
         const HnswArgs a2 = *ap;
         hnsw_general_traverse<METRIC, VIS_LDS, N16T>(a2, qi, lds, true);
     }
+    if (L0 && ap->rm_doc) {
+        __syncthreads();   // the keys (this block's own stores, whichever traversal wrote them) are visible to the whole block
+        const uint32_t cnt = ap->out_counts[qi];
+        const uint8_t* const docs = ap->rm_index + ap->users[0].doc_ids_off;   // the table path serves one graph
+        for (int i = tid; i < kk; i += BLK) {
+            const size_t t = (size_t)qi * kk + i;
+            if ((uint32_t)i < cnt) {
+                const uint64_t key = okeys[t];
+                const uint64_t* dp = (const uint64_t*)(docs + (size_t)key_id(key) * 16);
+                ap->rm_doc[t] = mdb_u128{dp[0], dp[1]};
+                ap->rm_score[t] = key_dist(key);
+            } else {
+                ap->rm_doc[t] = mdb_u128{~0ull, ~0ull};
+                ap->rm_score[t] = __uint_as_float(0x7F800000u);
+            }
+        }
+        if (tid == 0 && ap->rm_counts) ap->rm_counts[qi] = cnt;
+    }
 }
 
 
@@ -1579,6 +1602,11 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
         MDB_HIP(ctx, hipMemcpyAsync(upper.ids.p, h_cids.data(), h_cids.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         MDB_HIP(ctx, hipMemcpyAsync(d_cvecs.p, h_cvecs.data(), h_cvecs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         MDB_TRY(tiles_from_rows(ctx, d_cvecs.p, upper.nu, (int)dim, upper.tiles));
+        if (dim % 16 == 0 && dim <= 128) {   // row-major copy for the lane = query table kernel (+64 rows of slack: a wave's last loads)
+            if (upper.rows_nat.alloc(((size_t)upper.nu + 64) * dim) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "HNSW upper-layer rows");
+            MDB_HIP(ctx, hipMemsetAsync(upper.rows_nat.p, 0, ((size_t)upper.nu + 64) * dim * 4, ctx->stream));
+            MDB_HIP(ctx, hipMemcpyAsync(upper.rows_nat.p, d_cvecs.p, (size_t)upper.nu * dim * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
         MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // d_cvecs and the host vectors are released below
     }
     MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1587,7 +1615,8 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
 
 // ------------------------------------------------------------------------------------------ search
 mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, size_t k, uint32_t ef,
-                           uint64_t* d_keys, uint32_t* d_counts) {
+                           uint64_t* d_keys, uint32_t* d_counts, bool zero_counters, HnswRemapOut* fuse) {
+    if (fuse) fuse->done = false;
     if (b == 0) return MDB_OK;
     if (ef == 0) ef = 1;  // `len < ef` is never true and every push is followed by a pop: same as ef = 1
     if (ef > MDB_MAX_K * 2) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "ef=%u exceeds %d", ef, MDB_MAX_K * 2);
@@ -1656,8 +1685,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
 #define MDB_HNSW_LAUNCH(METRIC, VL)                                                                              \
     do {                                                                                                           \
         if (table) {                                                                                               \
-            if (nf == 8 && l0_prefetch) MDB_BEAM_LAUNCH_L0(METRIC, VL, 8, true);                                   \
-            else if (nf == 8) MDB_BEAM_LAUNCH_L0(METRIC, VL, 8, false);                                            \
+            if (nf == 8) MDB_BEAM_LAUNCH_L0(METRIC, VL, 8, false);                                                 \
             else if (nf == 48) MDB_BEAM_LAUNCH_L0(METRIC, VL, 48, false);                                          \
             else MDB_BEAM_LAUNCH_L0(METRIC, VL, 0, false);                                                         \
         } else if (beam && prefetch) {                                                                             \
@@ -1677,6 +1705,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     } while (0)
     // graphs no larger than ef (SPANN centroid graphs): frontier-parallel closure, see hnsw_closure_kernel
     if (max_n <= ef && max_n <= 4096 && !ctx->opt.hnsw_no_closure) {
+        if (zero_counters) MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, ctx->stream));
         int wcap = 64;
         while ((uint32_t)wcap < max_n) wcap <<= 1;
         // small batches: 64 groups per query (latency); large ones: 256-thread blocks, four resident per CU
@@ -1711,12 +1740,11 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     const bool beam = ef <= 256 && !ctx->opt.hnsw_no_beam;
     // hnsw_beam_kernel with its prefetch wave (see the kernel): f32 rows of whole 16-lane chunks
     const bool row64 = max_stride <= 64 && !ctx->opt.hnsw_no_row64;   // hnsw_beam_kernel's one-chunk specialisation
-    const bool prefetch = beam && row64 && (nf == 8 || nf == 48) && ctx->opt.hnsw_prefetch == 1;   // OPT-IN: measured slower
+    const bool prefetch = beam && row64 && (nf == 8 || nf == 48) && ctx->opt.hnsw_prefetch;   // OPT-IN: measured slower
     // upper layers on the distance table (mdb_hnsw_upper.hip): table pass, single-wave traversal, then the layer-0 instance of
     // the beam kernel.  One graph (no per-query user), f32 rows; the table is b * nu words of scratch
     const uint32_t nu_pad = (uint32_t)upper.tiles.ntiles * MDB_TILE;
-    const bool l0_prefetch = ctx->opt.hnsw_prefetch == 2;   // experiment: the prefetch wave beside the layer-0 instance
-    const bool table = upper.nu > 0 && !d_q_user && beam && row64 && (!prefetch || l0_prefetch) && kind != MDB_QUANT_PQ && !ctx->opt.hnsw_no_table &&
+    const bool table = upper.nu > 0 && !d_q_user && beam && row64 && !prefetch && kind != MDB_QUANT_PQ && !ctx->opt.hnsw_no_table &&
                        (long long)b >= ctx->opt.hnsw_table_min_b && (uint64_t)b * nu_pad * 4 <= ((uint64_t)2 << 30) &&
                        (size_t)(upper.nu / 32 + 4) * 4 <= 96 * 1024;
     if (table) {
@@ -1729,10 +1757,17 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         uo.ovf = uo.ep + b;
         uo.vis = uo.ovf + b;
         uo.words = words;
-        MDB_TRY(hnsw_upper_table(ctx, upper, metric, a.p, d_q, qstride, b, (uint32_t*)tab));
+        // (the table kernel clears the context's traversal counters on its way: no memset launch in front of the step)
+        MDB_TRY(hnsw_upper_table(ctx, upper, metric, a.p, d_q, qstride, b, (uint32_t*)tab, zero_counters ? ctx->d_counters : nullptr));
+        zero_counters = false;
         MDB_TRY(hnsw_upper_traverse(ctx, upper, (const uint32_t*)tab, b, ef, uo));
         a.up_ep = uo.ep; a.up_ovf = uo.ovf; a.up_vis = uo.vis; a.up_ids = upper.ids.p; a.up_words = words;
+        if (fuse && fuse->doc && k > 0) {
+            a.rm_index = d_index.p; a.rm_doc = fuse->doc; a.rm_score = fuse->score; a.rm_counts = fuse->counts;
+            fuse->done = true;
+        }
     }
+    if (zero_counters) MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, ctx->stream));
     if (metric == MDB_METRIC_L2) {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false);
     } else {
@@ -1850,20 +1885,28 @@ static mdb_status hnsw_ann_search_impl(mdb_hnsw* h, const float* queries, size_t
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     float* dq;
     int qstride;
-    MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.dimension, mem, b, &dq, &qstride));
+    if (mem == MDB_MEM_DEVICE && s.kind != MDB_QUANT_PQ && s.dimension % 4 == 0 && ((uintptr_t)queries & 15) == 0) {
+        // device-resident f32 rows that are already whole float4s: the kernels read the caller's rows in place (no staging launch)
+        dq = const_cast<float*>(queries);
+        qstride = (int)s.dimension;
+    } else {
+        MDB_TRY(stage_queries(ctx, 0, queries, b, (int)s.dimension, mem, b, &dq, &qstride));
+    }
     void *keys, *cnts;
     MDB_TRY(mdb_scratch(ctx, 3, b * std::max<size_t>(k, 1) * 8, &keys));
     MDB_TRY(mdb_scratch(ctx, 6, b * 4 + 16, &cnts));
-    MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, ctx->stream));
     ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
     ctx->counter_base = 0;
     // d*4 B vector + 4 B edge id per distance evaluation, 16 B offsets per expanded node
     ctx->stat_bytes_per_eval = (s.kind == MDB_QUANT_PQ ? (uint64_t)s.pq.m : (uint64_t)s.dimension * 4) + 4;
     ctx->stat_bytes_per_scored = 0; ctx->stat_fixed_bytes = 0;
-    MDB_TRY(s.search(dq, qstride, b, nullptr, k, ef, (uint64_t*)keys, (uint32_t*)cnts));
+    HnswRemapOut fuse;
+    if (mem == MDB_MEM_DEVICE) { fuse.doc = doc_ids_out; fuse.score = scores_out; fuse.counts = counts_out; }
+    MDB_TRY(s.search(dq, qstride, b, nullptr, k, ef, (uint64_t*)keys, (uint32_t*)cnts, /*zero_counters=*/true, &fuse));
     size_t total = b * k;
-    if (mem == MDB_MEM_DEVICE) return s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, doc_ids_out, scores_out, counts_out);
+    if (mem == MDB_MEM_DEVICE)
+        return fuse.done ? MDB_OK : s.remap((uint64_t*)keys, (uint32_t*)cnts, b, k, nullptr, doc_ids_out, scores_out, counts_out);
     void *dids, *dsc;
     MDB_TRY(mdb_scratch(ctx, 5, total * 16 + 16, &dids));
     MDB_TRY(mdb_scratch(ctx, 1, total * 4 + 16, &dsc));

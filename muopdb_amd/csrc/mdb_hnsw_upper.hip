@@ -24,8 +24,9 @@
 template <int METRIC, int QT>
 __global__ __launch_bounds__(64) void hnsw_upper_table_kernel(const float4* __restrict__ tiles, uint32_t nu, DistPlan p,
                                                               const float* __restrict__ q, int qstride, uint32_t q_first,
-                                                              uint32_t* __restrict__ table, uint32_t nu_pad) {
+                                                              uint32_t* __restrict__ table, uint32_t nu_pad, unsigned long long* zero16) {
     const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    if (zero16 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0ull;
     const uint32_t v = tile * MDB_TILE + lane;
     const uint32_t q0 = q_first + blockIdx.y * QT;
     float raw[QT];
@@ -67,8 +68,9 @@ __device__ __forceinline__ void t16_accumulate(float (&ac)[16], const float vq, 
 template <int METRIC, int QT>
 __global__ __launch_bounds__(256) void hnsw_upper_table16_kernel(const float4* __restrict__ tiles, uint32_t nu, uint32_t ntiles, int n16,
                                                                  const float* __restrict__ q, int qstride, uint32_t q_first,
-                                                                 uint32_t* __restrict__ table, uint32_t nu_pad) {
+                                                                 uint32_t* __restrict__ table, uint32_t nu_pad, unsigned long long* zero16) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (zero16 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0ull;
     const uint32_t tile = blockIdx.x * 4 + wave;
     if (tile >= ntiles) return;
     const uint32_t v = tile * MDB_TILE + lane;
@@ -111,16 +113,126 @@ __global__ __launch_bounds__(256) void hnsw_upper_table16_kernel(const float4* _
     }
 }
 
+// Batches of >= 32 queries, d = 16 * N16 <= 128: the roles swapped — LANE = QUERY (64 queries per wave, a query's d floats resident in
+// registers), the POINT's 16-float chunk is the one register that reaches the arithmetic through the DPP operand (lane l of every 16-lane
+// row loads element l % 16: a 64-byte load).  Every point is then read ONCE per 64 queries instead of once per QT (the thread = point
+// kernel above re-reads the 16 MB of upper vectors b / QT times and ran at the L2's bandwidth, 38 us at batch 64); what is left is the
+// arithmetic itself, 3 VALU per element and query.  A wave takes PPW consecutive points; four results per lane are stored together.
+#define MDB_T64_TERM(J)                                                                                                       \
+    if (METRIC != MDB_METRIC_DOT) {                                                                                           \
+        float df;                                                                                                             \
+        asm("v_sub_f32_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "=v"(df) : "v"(xv), "v"(qr[16 * C + J])); \
+        ac[J] = __fadd_rn(ac[J], __fmul_rn(df, df));                                                                          \
+    } else {                                                                                                                  \
+        float pr;                                                                                                             \
+        asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:" #J " row_mask:0xf bank_mask:0xf" : "=v"(pr) : "v"(xv), "v"(qr[16 * C + J])); \
+        ac[J] = __fadd_rn(ac[J], pr);                                                                                         \
+    }
+template <int METRIC, int N16, int C>
+__device__ __forceinline__ void t64_chunk(float (&ac)[16], const float xv, const float (&qr)[16 * N16]) {
+    MDB_T64_TERM(0) MDB_T64_TERM(1) MDB_T64_TERM(2) MDB_T64_TERM(3) MDB_T64_TERM(4) MDB_T64_TERM(5) MDB_T64_TERM(6) MDB_T64_TERM(7)
+    MDB_T64_TERM(8) MDB_T64_TERM(9) MDB_T64_TERM(10) MDB_T64_TERM(11) MDB_T64_TERM(12) MDB_T64_TERM(13) MDB_T64_TERM(14) MDB_T64_TERM(15)
+}
+#undef MDB_T64_TERM
+template <int METRIC, int N16, int C>
+struct T64Point {
+    static __device__ __forceinline__ void run(float (&ac)[16], const float (&xc)[N16], const float (&qr)[16 * N16]) {
+        t64_chunk<METRIC, N16, C>(ac, xc[C], qr);
+        T64Point<METRIC, N16, C + 1>::run(ac, xc, qr);
+    }
+};
+template <int METRIC, int N16>
+struct T64Point<METRIC, N16, N16> {
+    static __device__ __forceinline__ void run(float (&)[16], const float (&)[N16], const float (&)[16 * N16]) {}
+};
+
+#define T64_PPW 16   // points per wave
+template <int METRIC, int N16>
+__global__ __launch_bounds__(256, 2) void hnsw_upper_table64_kernel(const float* __restrict__ rows, uint32_t nu, const float* __restrict__ q,
+                                                                 int qstride, uint32_t b, uint32_t* __restrict__ table, uint32_t nu_pad,
+                                                                 unsigned long long* zero16) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (zero16 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0ull;
+    const uint32_t p0 = (blockIdx.x * 4 + wave) * T64_PPW;
+    if (p0 >= nu) return;
+    const uint32_t qi = blockIdx.y * 64 + lane;
+    const bool qok = qi < b;
+    const float4* q4 = (const float4*)(q + (size_t)(qok ? qi : b - 1) * qstride);   // rows are 16-byte aligned (stage_queries)
+    float qr[16 * N16];
+#pragma unroll
+    for (int t = 0; t < 4 * N16; ++t) {
+        const float4 v = q4[t];
+        qr[4 * t + 0] = v.x; qr[4 * t + 1] = v.y; qr[4 * t + 2] = v.z; qr[4 * t + 3] = v.w;
+    }
+    const float* xp = rows + (size_t)p0 * (16 * N16) + (lane & 15);
+    float xa[N16], xb[N16];
+#pragma unroll
+    for (int c = 0; c < N16; ++c) xa[c] = xp[16 * c];
+    uint32_t* const trow = table + (size_t)qi * nu_pad + p0;
+    uint32_t img[4];
+#pragma unroll 1
+    for (uint32_t i = 0; i < T64_PPW; i += 2) {
+        // two points per trip: the other buffer's loads are in flight while one is accumulated (points past nu: the last valid row again)
+        {
+            const uint32_t pn = p0 + i + 1 < nu ? i + 1 : i;
+#pragma unroll
+            for (int c = 0; c < N16; ++c) xb[c] = xp[(size_t)pn * (16 * N16) + 16 * c];
+            float ac[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) ac[j] = 0.0f;
+            T64Point<METRIC, N16, 0>::run(ac, xa, qr);
+            img[i & 3] = f32_orderable(finish_distance<METRIC>(__fadd_rn(0.0f, reduce_ordered<16>(ac))));
+        }
+        {
+            const uint32_t pn = p0 + i + 2 < nu ? i + 2 : i;
+#pragma unroll
+            for (int c = 0; c < N16; ++c) xa[c] = xp[(size_t)pn * (16 * N16) + 16 * c];
+            float ac[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) ac[j] = 0.0f;
+            T64Point<METRIC, N16, 0>::run(ac, xb, qr);
+            img[(i + 1) & 3] = f32_orderable(finish_distance<METRIC>(__fadd_rn(0.0f, reduce_ordered<16>(ac))));
+        }
+        if ((i & 3) == 2 && qok) {   // p0 and nu_pad are multiples of 16 / 64: 16-byte aligned (slots past nu are never read)
+            uint4 o; o.x = img[0]; o.y = img[1]; o.z = img[2]; o.w = img[3];
+            *(uint4*)(trow + (i - 2)) = o;
+        }
+    }
+}
+
 mdb_status hnsw_upper_table(mdb_ctx* ctx, const HnswUpper& up, int metric, const DistPlan& p, const float* d_q, int qstride, size_t b,
-                            uint32_t* d_table) {
+                            uint32_t* d_table, unsigned long long* zero16) {
     const uint32_t nu_pad = (uint32_t)up.tiles.ntiles * MDB_TILE;
     const float4* tiles = (const float4*)up.tiles.data.p;
+    if (up.rows_nat.p && p.n16 > 0 && p.n16 <= 8 && p.n8 == 0 && p.n4 == 0 && p.ntail == 0 && (long long)b >= ctx->opt.hnsw_table64_min_b) {
+        const unsigned gx = (unsigned)((up.nu + 4 * T64_PPW - 1) / (4 * T64_PPW)), gy = (unsigned)((b + 63) / 64);
+#define MDB_UT64_GO(METRIC, N)                                                                               \
+    hnsw_upper_table64_kernel<METRIC, N><<<dim3(gx, gy), 256, 0, ctx->stream>>>(up.rows_nat.p, up.nu, d_q, qstride, (uint32_t)b, d_table, nu_pad, zero16)
+#define MDB_UT64_LAUNCH(METRIC)                            \
+    do {                                                   \
+        switch (p.n16) {                                   \
+            case 1: MDB_UT64_GO(METRIC, 1); break;         \
+            case 2: MDB_UT64_GO(METRIC, 2); break;         \
+            case 3: MDB_UT64_GO(METRIC, 3); break;         \
+            case 4: MDB_UT64_GO(METRIC, 4); break;         \
+            case 5: MDB_UT64_GO(METRIC, 5); break;         \
+            case 6: MDB_UT64_GO(METRIC, 6); break;         \
+            case 7: MDB_UT64_GO(METRIC, 7); break;         \
+            default: MDB_UT64_GO(METRIC, 8); break;        \
+        }                                                  \
+    } while (0)
+        if (metric == MDB_METRIC_L2) MDB_UT64_LAUNCH(MDB_METRIC_L2); else MDB_UT64_LAUNCH(MDB_METRIC_DOT);
+#undef MDB_UT64_LAUNCH
+#undef MDB_UT64_GO
+        MDB_HIP(ctx, hipGetLastError());
+        return MDB_OK;
+    }
     if (p.n16 > 0 && p.n8 == 0 && p.n4 == 0 && p.ntail == 0) {
         const unsigned gx = (unsigned)((up.tiles.ntiles + 3) / 4);
         const int qf = ctx->opt.hnsw_table_qt == 8 ? 8 : ctx->opt.hnsw_table_qt == 2 ? 2 : 4;
 #define MDB_UT16_GO(METRIC, QF, first, groups)                                                                                     \
     hnsw_upper_table16_kernel<METRIC, QF><<<dim3(gx, (groups)), 256, 0, ctx->stream>>>(                                            \
-        tiles, up.nu, (uint32_t)up.tiles.ntiles, p.n16, d_q, qstride, (first), d_table, nu_pad)
+        tiles, up.nu, (uint32_t)up.tiles.ntiles, p.n16, d_q, qstride, (first), d_table, nu_pad, (first) == 0u ? zero16 : nullptr)
 #define MDB_UT16_LAUNCH(METRIC)                                                                                                   \
     do {                                                                                                                          \
         const uint32_t full = (uint32_t)(b / qf), rest = (uint32_t)(b % qf);                                                      \
@@ -143,10 +255,10 @@ mdb_status hnsw_upper_table(mdb_ctx* ctx, const HnswUpper& up, int metric, const
     do {                                                                                                                          \
         if (full)                                                                                                                 \
             hnsw_upper_table_kernel<METRIC, QT><<<dim3((unsigned)up.tiles.ntiles, full), 64, 0, ctx->stream>>>(                    \
-                tiles, up.nu, p, d_q, qstride, 0u, d_table, nu_pad);                                                              \
+                tiles, up.nu, p, d_q, qstride, 0u, d_table, nu_pad, zero16);                                                              \
         if (rest)                                                                                                                 \
             hnsw_upper_table_kernel<METRIC, 1><<<dim3((unsigned)up.tiles.ntiles, rest), 64, 0, ctx->stream>>>(                     \
-                tiles, up.nu, p, d_q, qstride, full * QT, d_table, nu_pad);                                                       \
+                tiles, up.nu, p, d_q, qstride, full * QT, d_table, nu_pad, full ? nullptr : zero16);                                                       \
     } while (0)
     if (metric == MDB_METRIC_L2) MDB_UT_LAUNCH(MDB_METRIC_L2); else MDB_UT_LAUNCH(MDB_METRIC_DOT);
 #undef MDB_UT_LAUNCH
