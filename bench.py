@@ -49,6 +49,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+DISP_REGIONS = 4       # extra timed regions per workload for the dispersion entry (Env.timed)
 METRIC = "QPS @ recall@10, SIFT-1M d=128 top-10, batch=1/64; 1/2/4/8 GPUs"
 
 
@@ -192,9 +193,12 @@ class Env:
             return float(t.item())
         return seconds
 
-    def timed(self, step, steps, warm, profiling=True):
+    def timed(self, step, steps, warm, profiling=True, disperse=True):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.
-        Returns (seconds, dominant-kernel ms summed, launches)."""
+        Returns (seconds, dominant-kernel ms summed, launches).  The region that is returned is the FIRST one; `last_dispersion`
+        then holds how much the same K steps vary when repeated (a 17 ms region alone cannot tell a 3 % change
+        from noise): DISP_REGIONS more regions bracketed the same way (region-level min / median / max of ms per step, the
+        returned region included), and one region with an event after every step on the launch stream (per-step GPU time)."""
         for i in range(warm):
             step(i)
         self.ctx.sync()
@@ -208,7 +212,31 @@ class Env:
         elapsed = time.perf_counter() - t0
         kernel_ms, launches = self.ctx.get_profile()
         self.ctx.set_profiling(False)
-        return self.max_over_ranks(elapsed), kernel_ms, launches
+        elapsed = self.max_over_ranks(elapsed)
+        self.last_dispersion = None
+        if disperse and steps > 0:
+            regions = [1000 * elapsed / steps]
+            for _ in range(DISP_REGIONS):
+                self.barrier()
+                t0 = time.perf_counter()
+                for i in range(warm, warm + steps):
+                    step(i)
+                self.barrier()
+                regions.append(1000 * self.max_over_ranks(time.perf_counter() - t0) / steps)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            self.barrier()
+            ev[0].record()
+            for j, i in enumerate(range(warm, warm + steps)):
+                step(i)
+                ev[j + 1].record()
+            self.barrier()
+            per = sorted(ev[j].elapsed_time(ev[j + 1]) for j in range(steps))
+            rs = sorted(regions)
+            self.last_dispersion = dict(
+                regions=len(regions), region_ms_per_step=dict(first=regions[0], min=rs[0], median=rs[len(rs) // 2], max=rs[-1]),
+                per_step_gpu_ms=dict(min=per[0], median=per[len(per) // 2], max=per[-1], steps=steps,
+                                     note="events on the launch stream after every step of one more region (this rank)"))
+        return elapsed, kernel_ms, launches
 
     def sift(self, n, d, nq, qseed):
         """(base rows, queries, description) of the C2/C3 synthetic SIFT-1M; the base is cached across workloads."""
@@ -261,6 +289,15 @@ def hbm_roofline(kernel, abytes_per_launch, kernel_ms, launches, **extra):
     return r
 
 
+def finish(out, disp, step_bytes):
+    """every workload: `step_frac` = the step's algorithmic bytes / ms_per_step / 8 TB/s (the whole step against the HBM roof, not
+    only its dominant kernel) and the dispersion of the timed region (Env.timed)."""
+    out["step_frac"] = step_bytes / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS if step_bytes else None
+    out["step_bytes"] = step_bytes
+    out["dispersion"] = disp
+    return out
+
+
 # ------------------------------------------------------------------------------------------ HNSW (headline)
 def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=None):
     """BASELINE config C2.  batch 64 = the headline; batch 1 = the metric's other batch size (same resident graph);
@@ -306,6 +343,7 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
             keep.append(ids[:, :, 0].clone())
 
     elapsed, kernel_ms, launches = env.timed(step, steps, warm)
+    disp = env.last_dispersion
     # untimed re-run of the timed batches: results for recall + exact traversal counters per launch
     found, evals, expanded, abytes = [], 0, 0, 0
     for i in range(warm, warm + steps):
@@ -324,9 +362,13 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
                             % ("SIFT-1M" if args.sift_dir else "SIFT-1M-like synthetic", n, d, desc, args.max_neighbors, ef, k, batch, how),
                 "n": n, "dim": d, "batch": batch, "ef": ef, "k": k, "index": "hnsw", "graph": graph,
                 "data": "sift1m" if args.sift_dir else args.data, "parallelism": "replica x%d" % world, "graph_build_s": build_s},
-        roofline=hbm_roofline("hnsw_beam_kernel" if ef <= 256 else "hnsw_search_kernel", abytes / steps, kernel_ms, launches,
+        # ef <= 256: the traversal is three kernels — the upper layers' distance table, their single-wave traversal and the layer-0
+        # instance of the beam kernel (mdb_hnsw_upper.hip); the bracket is their sum, the algorithmic bytes are the whole traversal's
+        roofline=hbm_roofline("hnsw_upper_table64_kernel+hnsw_upper_kernel+hnsw_beam_kernel<L0>" if ef <= 256 else "hnsw_search_kernel",
+                              abytes / steps, kernel_ms, launches,
                               evals_per_query=evals / (steps * batch), expanded_per_query=expanded / (steps * batch)),
     )
+    finish(out, disp, abytes / steps)
     out["steps"], out["warmup"] = steps, warm
     if batch == 64 and graph == "knn":
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("hnsw", out["config"])
@@ -413,6 +455,7 @@ def run_flat(env, n=None, batch=None):
         idx.search_device(queries[i * batch:(i + 1) * batch].data_ptr(), batch, k, ids.data_ptr(), ds.data_ptr())
 
     elapsed, kernel_ms, launches = env.timed(step, steps, warm)
+    disp = env.last_dispersion
     abytes = (hi - lo) * d * 4 + batch * d * 4 + batch * k * 8
     # recall@k of the last timed batch against the f64 brute force (untimed re-run of that batch)
     last = warm + steps - 1
@@ -424,6 +467,7 @@ def run_flat(env, n=None, batch=None):
                config={"workload": "flat brute-force L2 %dx%d f32 (%s), batch=%d, top-%d (row-sharded x%d)" % (n, d, desc, batch, k, world),
                        "n": n, "dim": d, "batch": batch, "k": k, "index": "flat", "data": args.data},
                roofline=hbm_roofline("flat_bf16_filter_kernel" if batched else "flat_scan_kernel", abytes, kernel_ms, launches))
+    finish(out, disp, abytes)   # the step's algorithmic bytes: the base once (however many passes the filter takes)
     if batched:
         # the filter streams the bf16 hi/lo split of the base (2 + 2 bytes per element: the base's own size) once per group of
         # 32 QB queries (QB = 1 / 2 / 4 for batches up to 32 / 64 / more) and issues three bf16 MFMA products per element pair
@@ -462,7 +506,7 @@ def pq_scan_kernel_name(batch):
     return "ivf_scan_pq3_kernel+ivf_pq3_refine_kernel" if batch >= 512 else "ivf_pq_fused_kernel"
 
 
-def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=0):
+def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=0, disperse=True):
     """one (nprobe) setting: timed steps + untimed re-run for results / counters"""
     from muopdb_amd import lib as L
     from muopdb_amd import distributed as D
@@ -491,14 +535,15 @@ def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=
         if keep is not None:
             keep.append(res[:, :, 0].clone())
 
-    elapsed, kernel_ms, launches = env.timed(step, steps, warm)
+    elapsed, kernel_ms, launches = env.timed(step, steps, warm, disperse=disperse)
+    disp = env.last_dispersion
     found, scored, abytes = [], 0, 0
     for i in range(warm, warm + steps):
         step(i, found)
         st = ctx.stats(); scored += st["scored_vectors"]; abytes += st["algorithmic_bytes"]
     found = torch.cat(found).cpu().numpy()
     rec = recall_at_k(found[:nrec], gt, k) if gt is not None else None
-    return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes, recall=rec)
+    return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes, recall=rec, disp=disp)
 
 
 def build_ivfpq(env, x, nlist, seed=3):
@@ -545,6 +590,7 @@ def run_ivfpq(env):
                        "n": n, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": args.data},
                roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
+    finish(out, m["disp"], m["abytes"] / steps)
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ivfpq", out["config"])
     if args.streams > 1 and world == 1:
         # Extra: the same batches round-robin on several HIP streams, each through its own handle ATTACHED to the one resident
@@ -584,7 +630,7 @@ def run_ivfpq(env):
         for p in (1, 8, 16, 32, 64):
             if p > nlist:
                 continue
-            s = m if p == P else ivfpq_measure(env, ivf, x, queries, batch, k, p, steps, warm, gt, nrec)
+            s = m if p == P else ivfpq_measure(env, ivf, x, queries, batch, k, p, steps, warm, gt, nrec, disperse=False)
             sweep.append(dict(nprobe=p, recall_at_10=s["recall"], value=steps * batch / s["elapsed"], ms_per_step=1000 * s["elapsed"] / steps,
                               scan_kernel_ms=s["kernel_ms"] / max(s["launches"], 1), scored_per_query=s["scored"] / (steps * batch)))
         out["sweep"] = sweep
@@ -625,6 +671,7 @@ def run_c5(env, steps=None, warm=None):
                        "n": sh["n"], "dim": 128, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": "lowrank"},
                roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
+    finish(out, m["disp"], m["abytes"] / steps)
     out["steps"], out["warmup"] = steps, warm
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("c5", out["config"])
     out["roofline"]["coarse_filter_mfma_busy"] = measured_mfma("c5", out["config"])
@@ -660,6 +707,7 @@ def run_c5(env, steps=None, warm=None):
 
     el, kms, nl = env.timed(rank_step, steps, warm)
     out["rank_of_8_step"] = dict(ms_per_step=1000 * el / steps, value=steps * batch / el, scan_kernel_ms=kms / max(nl, 1),
+                                 dispersion=env.last_dispersion,
                                  coarse_centroids=count, note="coarse search over 1/8 of the centroids + merge of 8 coarse rows + search_shard with the "
                                  "probes; excludes the two all-gathers (8 x 8 P and 8 x (8 k + 5) bytes per query: latency-bound on xGMI, needs 8 devices)")
     if env.cpu:
@@ -751,7 +799,7 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
         gts.append((torch.topk(dd, k, largest=False).indices + u * per))
     gts = torch.stack(gts).cpu().numpy()
 
-    def measure(P_, ratio_):
+    def measure(P_, ratio_, disperse=True):
         params = SearchParams(k, args.ef).with_num_explored_centroids(P_).with_centroid_distance_ratio(ratio_).to_c()
 
         def step(i, keep=None):
@@ -769,15 +817,21 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
             if keep is not None:
                 keep.append(res[:, :, 0].clone())
 
-        elapsed, kernel_ms, launches = env.timed(step, steps, warm, profiling=1)  # 1: posting-list scan only
-        found, scored, abytes = [], 0, 0
+        elapsed, kernel_ms, launches = env.timed(step, steps, warm, profiling=1, disperse=disperse)  # 1: posting-list scan only
+        disp = env.last_dispersion
+        found, scored, abytes, evals, expanded = [], 0, 0, 0, 0
         ctx.set_profiling(2); ctx.get_profile()  # untimed re-run: centroid-graph traversal kernel time
         for i in range(warm, warm + steps):
             step(i, found)
             st = ctx.stats(); scored += st["scored_vectors"]; abytes += st["algorithmic_bytes"]
+            evals += st["distance_evals"]; expanded += st["expanded_nodes"]
         hnsw_ms, hnsw_launches = ctx.get_profile(); ctx.set_profiling(False)
         found = torch.cat(found).cpu().numpy()
+        # a SPANN call's algorithmic bytes = the centroid graphs' traversal (evaluations x (4 d + 4) + expansions x 16: ANOTHER kernel,
+        # hnsw_closure_kernel) + the posting-list scan (scored x bytes per scored vector): each kernel is priced with its own bytes
+        graph_bytes = evals * (d * 4 + 4) + expanded * 16
         return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes,
+                    scan_bytes=abytes - graph_bytes, graph_bytes=graph_bytes, evals=evals, disp=disp,
                     recall=recall_at_k(found, gts, k), hnsw_ms=hnsw_ms / max(hnsw_launches, 1))
 
     m = measure(P, ratio)
@@ -787,14 +841,18 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
                                    % (U, per, d, desc, batch, args.ef, P, ratio, k, world),
                        "users": U, "n": U * per, "dim": d, "batch": batch, "k": k, "nprobe": P, "ratio": ratio, "index": "multi-spann",
                        "data": args.data},
-               roofline=hbm_roofline("ivf_scan_f32_kernel", m["abytes"] / steps, m["kernel_ms"], m["launches"],
-                                     scored_per_query=m["scored"] / (steps * batch), centroid_hnsw_kernel_ms=m["hnsw_ms"]))
+               roofline=hbm_roofline("ivf_scan_f32_kernel", m["scan_bytes"] / steps, m["kernel_ms"], m["launches"],
+                                     scored_per_query=m["scored"] / (steps * batch)))
+    # the centroid-graph kernel as its own entry (r3 divided its bytes by the scan kernel's time: VERDICT r3 weak #1)
+    out["roofline"]["centroid_graph"] = hbm_roofline("hnsw_closure_kernel", m["graph_bytes"] / steps, m["hnsw_ms"], 1,
+                                                     evals_per_query=m["evals"] / (steps * batch))
+    finish(out, m["disp"], m["abytes"] / steps)
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("spann_full" if U >= 1024 else "spann", out["config"])
     out["steps"], out["warmup"] = steps, warm
     if not (args.no_sweep or no_sweep):
         sweep = []
         for p_, r_ in ((4, 0.1), (16, 0.1), (64, 0.1), (4, 0.3), (16, 0.3), (64, 0.3), (16, 1.0)):
-            s = m if (p_, r_) == (P, ratio) else measure(p_, r_)
+            s = m if (p_, r_) == (P, ratio) else measure(p_, r_, disperse=False)
             sweep.append(dict(num_explored_centroids=p_, centroid_distance_ratio=r_, recall_at_10=s["recall"],
                               value=steps * batch / s["elapsed"], ms_per_step=1000 * s["elapsed"] / steps,
                               scan_kernel_ms=s["kernel_ms"] / max(s["launches"], 1), scored_per_query=s["scored"] / (steps * batch)))

@@ -231,19 +231,14 @@ mdb_status mdb_ivf_search_points(mdb_ivf* ivf, const float* queries, size_t b, c
                                  uint32_t* counts_out);
 /* BlockBasedIvf::invalidate / invalidate_batch / is_invalidated :421-470; flags_out[i] = 1 if
  * newly invalidated (resp. currently invalid) */
-/* Planner hook of scan_posting_list (ivf/block_based/index.rs:214-226): the planner keeps the subset of the
- * scanned POINT ids that match the document filter.  Here that subset is an allow bitmap (bit p set = point p
- * kept) applied by every following search on the handle until cleared with allow == NULL: n_bitmaps == 1 ->
- * one bitmap shared by all queries, otherwise one per query of the batch ([n_bitmaps][words_per_bitmap] u32).
- * Host bitmaps are copied; device bitmaps are borrowed until cleared.  Filtered points are skipped BEFORE the
- * distance (the reference drops them after it). */
-mdb_status mdb_ivf_set_filter(mdb_ivf* ivf, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem);
-/* The planner as a PER-CALL argument, the way the reference passes it (scan_posting_list(.., planner), index.rs:175-237):
- * mdb_ivf_search with allow bitmaps that apply to THIS call only (allow == NULL: no filter).  `allow` lives where `mem`
- * says; n_bitmaps == 1 -> one bitmap for every query, otherwise at least b bitmaps (one per query), each of
- * words_per_bitmap >= ceil(num_vectors / 32) u32 words — anything shorter is MDB_ERR_INVALID_ARG, never an
- * out-of-bounds read.  Two host threads with different filters on handles over one index do not interact.
- * mdb_ivf_set_filter above is the DEPRECATED stateful form (handle-global until cleared). */
+/* Planner hook of scan_posting_list (ivf/block_based/index.rs:214-226): the planner keeps the subset of the scanned POINT
+ * ids that match the document filter.  Here that subset is an allow bitmap (bit p set = point p kept), passed PER CALL the
+ * way the reference passes the planner (scan_posting_list(.., planner), index.rs:175-237): mdb_ivf_search with allow bitmaps
+ * that apply to THIS call only (allow == NULL: no filter).  `allow` lives where `mem` says; n_bitmaps == 1 -> one bitmap for
+ * every query, otherwise at least b bitmaps (one per query, [n_bitmaps][words_per_bitmap] u32), each of words_per_bitmap >=
+ * ceil(num_vectors / 32) words — anything shorter is MDB_ERR_INVALID_ARG, never an out-of-bounds read.  Filtered points are
+ * skipped BEFORE the distance (the reference drops them after it).  Two host threads with different filters on handles over one
+ * index do not interact.  (The stateful mdb_*_set_filter entries of rounds 1-3 are gone: one way to pass a planner.) */
 mdb_status mdb_ivf_search_filtered(mdb_ivf* ivf, const float* queries, size_t b, const uint32_t* probes, size_t num_probes, size_t k,
                                    mdb_mem mem, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap,
                                    mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out);
@@ -314,7 +309,6 @@ mdb_status mdb_spann_attach(mdb_ctx* ctx, mdb_spann* src, mdb_spann** out);
 mdb_status mdb_spann_search_submit(mdb_spann* spann, const float* queries, size_t b, const mdb_search_params* params,
                                    const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_u128* doc_ids_out,
                                    float* scores_out, uint32_t* counts_out, uint8_t* found_out);
-mdb_status mdb_spann_set_filter(mdb_spann* spann, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem);
 mdb_status mdb_spann_invalidate(mdb_spann* spann, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
 mdb_status mdb_spann_is_invalidated(mdb_spann* spann, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out);
 
@@ -351,9 +345,6 @@ mdb_status mdb_multi_spann_search_submit(mdb_multi_spann* ms, const mdb_u128* us
                                          const mdb_search_params* params, const uint32_t* allow, size_t n_bitmaps,
                                          size_t words_per_bitmap, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out,
                                          uint8_t* found_out);
-/* DEPRECATED stateful planner hook: bitmaps are over the USER-LOCAL point ids of each query's user (see mdb_ivf_set_filter) */
-mdb_status mdb_multi_spann_set_filter(mdb_multi_spann* ms, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap,
-                                      mdb_mem mem);
 mdb_status mdb_multi_spann_invalidate(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,
                                       uint8_t* flags_out);
 

@@ -186,11 +186,14 @@ class BlockBasedIvf {
         dev_.check(mdb_ivf_search(h_, queries, b, centroids, num_probes, k, MDB_MEM_HOST, r.ids.data(), r.scores.data(), r.counts.data()));
         return r.take(b, k);
     }
-    // Planner hook (scan_posting_list :214-226): allow bitmaps over point ids for the following searches;
-    // n_bitmaps == 1 -> shared by every query; empty vector clears
-    void set_filter(const std::vector<uint32_t>& bitmaps, size_t n_bitmaps = 1) {
-        if (bitmaps.empty()) { dev_.check(mdb_ivf_set_filter(h_, nullptr, 0, 0, MDB_MEM_HOST)); return; }
-        dev_.check(mdb_ivf_set_filter(h_, bitmaps.data(), n_bitmaps, bitmaps.size() / n_bitmaps, MDB_MEM_HOST));
+    // search with the planner's allow bitmaps over point ids for THIS call (scan_posting_list(.., planner) :175-237);
+    // n_bitmaps == 1 -> shared by every query, else one per query
+    std::vector<std::optional<SearchResult>> search_filtered(const float* queries, size_t b, size_t k, size_t num_probes,
+                                                             const std::vector<uint32_t>& bitmaps, size_t n_bitmaps = 1) {
+        detail::Rows r(b, k);
+        dev_.check(mdb_ivf_search_filtered(h_, queries, b, nullptr, num_probes, k, MDB_MEM_HOST, bitmaps.data(), n_bitmaps,
+                                           bitmaps.size() / n_bitmaps, r.ids.data(), r.scores.data(), r.counts.data()));
+        return r.take(b, k);
     }
     bool invalidate(u128 doc_id) {
         mdb_u128 d = detail::split(doc_id);

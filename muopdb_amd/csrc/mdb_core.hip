@@ -134,7 +134,9 @@ extern "C" mdb_status mdb_wait(mdb_ctx* ctx) {
 
 extern "C" int mdb_poll(mdb_ctx* ctx) {
     if (!ctx) return 1;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    // non-blocking by contract: a search on another thread holds ctx->mu for its whole host side — then the answer is "not yet"
+    std::unique_lock<std::mutex> g(ctx->mu, std::try_to_lock);
+    if (!g.owns_lock()) return 0;
     if (!ctx->has_pending) return 1;
     (void)hipSetDevice(ctx->device);
     return hipStreamQuery(ctx->stream) == hipSuccess ? 1 : 0;
@@ -182,7 +184,15 @@ mdb_status mdb_device_open(int gpu, mdb_ctx** out) {
     }
     ctx->own_stream = true;
     // the ONE place the library reads the environment: option defaults of this context (mdb_set_option changes them later)
-#define X(field, name, dflt) if (const char* v = getenv(name)) ctx->opt.field = atoll(v);
+    // NAME=<integer> sets the value; NAME set to anything that is not an integer (empty, "yes", "true": the presence switches of
+    // earlier builds) means 1 — never a silent 0
+    auto env_value = [](const char* v) -> long long {
+        char* end = nullptr;
+        const long long x = strtoll(v, &end, 10);
+        while (end && (*end == ' ' || *end == '\t')) ++end;
+        return (end == v || (end && *end != '\0')) ? 1 : x;
+    };
+#define X(field, name, dflt) if (const char* v = getenv(name)) ctx->opt.field = env_value(v);
     MDB_OPTIONS(X)
 #undef X
     *out = ctx;

@@ -1189,7 +1189,9 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     else MDB_TRY(flat_topk_keys(ctx, view_of(aux.sample), metric, dq, qstride, b, k, skeys, scounts, false));
     // large batches over a store with a row-major copy (a coarse quantizer) are refined one block per query, and the filter hands
     // its products over with the candidates (flat_refine_group_kernel)
-    const bool by_groups = aux.rows.p && b >= (size_t)std::max<long long>(0, ctx->opt.refine_wave_min_b) && k <= 256 && !ctx->opt.refine_no_groups;
+    // (flat_refine_group_kernel's dynamic LDS must fit the 48 KB a launch gets without an attribute: d <= ~3000)
+    const bool by_groups = aux.rows.p && b >= (size_t)std::max<long long>(0, ctx->opt.refine_wave_min_b) && k <= 256 && !ctx->opt.refine_no_groups &&
+                           (size_t)(RG_CAP + RG_SURV) * 8 + k * 8 + 260 * 4 + (size_t)RG_CAP * 4 + (size_t)ts.d4 * 16 <= 48 * 1024;
     float* qapx = nullptr;
     if (by_groups && smp_bf16 && !ctx->opt.refine_no_second_bound) MDB_TRY(mdb_scratch(ctx, 10, bpadq * (size_t)qcap * 4, (void**)&qapx));
     // error budget of the filter, eps = 2^-24, all norms of the centred operands:

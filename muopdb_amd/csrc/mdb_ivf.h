@@ -57,15 +57,13 @@ struct IvfSet {
     PqDev pq;
     int mw = 0;
     // Planner hook (scan_posting_list, index.rs:214-226): allow bitmaps over point ids.  The reference passes the planner
-    // PER CALL; so does scan() (ScanFilter argument).  The stateful form (set_filter, deprecated) stores one here.
+    // PER CALL; so does scan() (ScanFilter argument).
     struct ScanFilter {
         const uint32_t* allow = nullptr;  // device; nullptr = no filter
         size_t n_bitmaps = 0, words = 0;  // n_bitmaps == 1: shared by every query, else >= batch
     };
-    ScanFilter flt;
     size_t ones_word = 0;
     uint64_t max_user_vectors = 0;        // bitmaps must cover every point id of every user
-    DevBuf<uint32_t> flt_own;
     std::vector<std::unordered_map<U128Key, uint32_t, U128Hash>> doc_maps;
     // attached view (mdb_*_attach): device arrays borrowed from `root`, own context / scratch; the mutable host state
     // (tombstone mirror, doc-id maps) lives in the root and is guarded by its tomb_mu
@@ -80,7 +78,6 @@ struct IvfSet {
                     uint32_t shard_rank, uint32_t shard_world);
     mdb_status build_doc_map(size_t ui, mdb_ctx* ectx);
     mdb_status invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out, bool test_only);
-    mdb_status set_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem);
     // single index with >= 64K centroids: sample / centred copy for the batched (MFMA-filtered) coarse search
     FlatAux cent_aux;
     FlatAux cent_slice;            // view of a centroid range for mdb_ivf_coarse_keys (a rank's share of a sharded coarse search)

@@ -1089,8 +1089,9 @@ __global__ __launch_bounds__(256) void ivf_prep_kernel(FusedArgs f, const float*
 // smallest.  All ones when fewer than kth values exist.
 // hist2: two areas of PQF_NB + 16 words used alternately (`flip` toggles per call) — [0, NB) the histogram, [NB] the bin found,
 // [NB+1..NB+3] block minimum / maximum / count (LDS atomics of the waves' reductions), [NB+4 .. NB+4+NW) the waves' scan totals.
-// A call resets the OTHER area for its successor, so no barrier guards the reuse; the caller resets area 0 before the first
-// call (kth_area_reset).  Four barriers, ~120 instructions per wave.
+// A call resets the OTHER area for its successor BEHIND its own first barrier (no thread is still inside the previous call then),
+// so no extra barrier guards the reuse; the caller resets area 0 — and synchronises — before the first call (kth_area_reset).
+// Four barriers, ~120 instructions per wave.
 __device__ __forceinline__ void kth_area_reset(uint32_t* area) {
     area[threadIdx.x] = 0;
     if (threadIdx.x < 16) area[PQF_NB + threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;   // [NB+1] = minimum
@@ -1099,7 +1100,7 @@ template <int R>
 __device__ __forceinline__ uint32_t block_kth_bound(const uint32_t (&v)[R], uint32_t kth, uint32_t* hist2, int& flip) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* hist = hist2 + flip * (PQF_NB + 32);
-    kth_area_reset(hist2 + (flip ^ 1) * (PQF_NB + 32));
+    uint32_t* const other = hist2 + (flip ^ 1) * (PQF_NB + 32);
     flip ^= 1;
     uint32_t lmin = 0xFFFFFFFFu, lmax = 0u, lcnt = 0;
 #pragma unroll
@@ -1113,6 +1114,10 @@ __device__ __forceinline__ uint32_t block_kth_bound(const uint32_t (&v)[R], uint
     const uint32_t wmax = ~mdb_wave_min_u32(~lmax);
     if (lane == 0 && lcnt) { atomicMin(&hist[PQF_NB + 1], wmin); atomicMax(&hist[PQF_NB + 2], wmax); atomicAdd(&hist[PQF_NB + 3], lcnt); }
     __syncthreads();
+    // the OTHER area (the previous call's) is cleared for the next call only here, behind this call's first barrier: every thread
+    // has left the previous call by now — cleared at the top, a fast thread zeroed hist[PQF_NB] (the bin found) under a slow one
+    // that was still reading it
+    kth_area_reset(other);
     const uint32_t gmin = hist[PQF_NB + 1], gmax = hist[PQF_NB + 2], total = hist[PQF_NB + 3];
     if (total < kth || kth == 0) { __syncthreads(); return 0xFFFFFFFFu; }   // (uniform; the barrier: a fast thread's NEXT call resets this area)
     const uint32_t range = gmax - gmin;
@@ -1174,6 +1179,7 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     if (tid < 16) misc[tid] = 0;
     kth_area_reset(hist);
     int flip = 0;
+    __syncthreads();   // the first block_kth_bound call adds to the area's min / max / count words: they must be cleared by then
 #define PQF_STAMP(i) do { if (f.dbg && qi == 0 && tid == 0) f.dbg[i] = __builtin_readcyclecounter(); } while (0)
 #define PQF_SUB(i) do { if (f.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); PQF_STAMP(i); } } while (0)
     PQF_STAMP(0);
@@ -1977,27 +1983,6 @@ mdb_status IvfSet::stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t 
     return MDB_OK;
 }
 
-// DEPRECATED stateful form (kept for callers of round 1's ABI): the filter applies to every following search on THIS
-// handle until cleared; two host threads with different filters must use the per-call *_search_filtered entries.
-mdb_status IvfSet::set_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem) {
-    flt = ScanFilter{};
-    if (!allow) return MDB_OK;
-    if (n_bitmaps == 0 || words == 0) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "empty filter bitmap");
-    if (words < (max_user_vectors + 31) / 32)
-        return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "filter bitmaps of %zu words do not cover %zu point ids", words, (size_t)max_user_vectors);
-    if (mem == MDB_MEM_DEVICE) {
-        flt.allow = allow;
-    } else {
-        if (flt_own.alloc(n_bitmaps * words + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "filter bitmap alloc");
-        MDB_HIP(ctx, hipMemcpyAsync(flt_own.p, allow, n_bitmaps * words * 4, hipMemcpyHostToDevice, ctx->stream));
-        MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        flt.allow = flt_own.p;
-    }
-    flt.n_bitmaps = n_bitmaps;
-    flt.words = words;
-    return MDB_OK;
-}
-
 // ------------------------------------------------------------------------------------------ IvfSet: search
 // d_q: staged queries [b][qstride]; probes: device [b][probe_stride]; outputs: device keys [b][k] + counts
 mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
@@ -2005,7 +1990,8 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
                         const ScanFilter* filter) {
     if (b == 0) return MDB_OK;
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
-    const ScanFilter& f = filter && filter->allow ? *filter : flt;
+    static const ScanFilter no_filter{};
+    const ScanFilter& f = filter && filter->allow ? *filter : no_filter;
     if (f.allow && f.n_bitmaps != 1 && f.n_bitmaps < b)
         return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "%zu filter bitmaps for a batch of %zu queries", f.n_bitmaps, b);
     int nsplit = 1;
@@ -2198,7 +2184,8 @@ bool IvfSet::fused_ok(size_t b, size_t k, size_t num_probes, bool have_probes) c
 mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const uint32_t* d_probes, size_t num_probes, size_t k,
                                 const ScanFilter* filter, uint64_t* d_keys, uint32_t* d_counts, mdb_u128* d_doc, float* d_score,
                                 uint32_t* d_doc_counts) {
-    const ScanFilter& f = filter && filter->allow ? *filter : flt;
+    static const ScanFilter no_filter{};
+    const ScanFilter& f = filter && filter->allow ? *filter : no_filter;
     if (f.allow && f.n_bitmaps != 1 && f.n_bitmaps < b)
         return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "%zu filter bitmaps for a batch of %zu queries", f.n_bitmaps, b);
     const int par = ctx->fused_parity;
@@ -2677,12 +2664,6 @@ mdb_status mdb_ivf_merge_shards(mdb_ivf* ivf, const void* blocks, size_t world, 
     return s.merge_points(blocks, world, b, k, nullptr, doc_ids_out, scores_out, counts_out, nullptr);
 }
 
-mdb_status mdb_ivf_set_filter(mdb_ivf* ivf, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem) {
-    if (!ivf) return MDB_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> g(ivf->set.ctx->mu);
-    MDB_HIP(ivf->set.ctx, hipSetDevice(ivf->set.ctx->device));
-    return ivf->set.set_filter(allow, n_bitmaps, words_per_bitmap, mem);
-}
 
 mdb_status mdb_ivf_invalidate(mdb_ivf* ivf, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out) {
     if (!ivf || (!doc_ids && n) || !flags_out) return MDB_ERR_INVALID_ARG;

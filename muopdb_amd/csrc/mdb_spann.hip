@@ -437,12 +437,6 @@ mdb_status mdb_spann_merge_shards(mdb_spann* sp, const void* blocks, size_t worl
     return spann_merge_impl(sp->set, nullptr, blocks, world, b, k, doc_ids_out, scores_out, counts_out, found_out);
 }
 
-mdb_status mdb_spann_set_filter(mdb_spann* sp, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap, mdb_mem mem) {
-    if (!sp) return MDB_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> g(sp->set.ctx->mu);
-    MDB_HIP(sp->set.ctx, hipSetDevice(sp->set.ctx->device));
-    return sp->set.ivf.set_filter(allow, n_bitmaps, words_per_bitmap, mem);
-}
 
 mdb_status mdb_spann_invalidate(mdb_spann* sp, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out) {
     if (!sp || (!doc_ids && n) || !flags_out) return MDB_ERR_INVALID_ARG;
@@ -601,13 +595,6 @@ mdb_status mdb_multi_spann_merge_shards(mdb_multi_spann* ms, const mdb_u128* use
     return spann_merge_impl(ms->set, qu.data(), blocks, world, b, k, doc_ids_out, scores_out, counts_out, found_out);
 }
 
-mdb_status mdb_multi_spann_set_filter(mdb_multi_spann* ms, const uint32_t* allow, size_t n_bitmaps, size_t words_per_bitmap,
-                                      mdb_mem mem) {
-    if (!ms) return MDB_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> g(ms->set.ctx->mu);
-    MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
-    return ms->set.ivf.set_filter(allow, n_bitmaps, words_per_bitmap, mem);
-}
 
 mdb_status mdb_multi_spann_invalidate(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,
                                       uint8_t* flags_out) {

@@ -219,16 +219,6 @@ class FlatIndex:
 
 # ------------------------------------------------------------------------------------------ IVF
 
-def _set_filter(ctx, fn, handle, bitmaps):
-    """bitmaps: None (clear) | uint32 [words] (shared) | uint32 [b][words] (one per query)."""
-    if bitmaps is None:
-        ctx.check(fn(handle, None, C.c_size_t(0), C.c_size_t(0), C.c_int(L.MEM_HOST)))
-        return
-    bm = np.ascontiguousarray(bitmaps, dtype=np.uint32)
-    nb, words = (1, bm.shape[0]) if bm.ndim == 1 else bm.shape
-    ctx.check(fn(handle, L.ptr(bm, C.c_uint32), C.c_size_t(nb), C.c_size_t(words), C.c_int(L.MEM_HOST)))
-
-
 def _planner_args(planner):
     """per-call planner filter -> (allow pointer, n_bitmaps, words_per_bitmap, keepalive)"""
     if planner is None:
@@ -429,10 +419,6 @@ class BlockBasedIvf:
         """`blocks`: the ranks' points blocks (list of uint8 arrays, rank order) -> SearchResult equal to the unsharded search."""
         return _merge_shards(self.ctx, lambda *a: self.ctx.lib.mdb_ivf_merge_shards(self.h, *a), blocks, b, k, False)
 
-    def set_filter(self, bitmaps):
-        """Planner hook (scan_posting_list :214-226): allow bitmaps over point ids for the following searches."""
-        _set_filter(self.ctx, self.ctx.lib.mdb_ivf_set_filter, self.h, bitmaps)
-
     def invalidate(self, doc_id):
         return bool(self.invalidate_batch([doc_id])[0])
 
@@ -608,9 +594,6 @@ class Spann:
     def merge_shards(self, blocks, b, k):
         return _merge_shards(self.ctx, lambda *a: self.ctx.lib.mdb_spann_merge_shards(self.h, *a), blocks, b, k, True)
 
-    def set_filter(self, bitmaps):
-        _set_filter(self.ctx, self.ctx.lib.mdb_spann_set_filter, self.h, bitmaps)
-
     def invalidate(self, doc_id):
         flags = np.zeros(1, np.uint8)
         self.ctx.check(self.ctx.lib.mdb_spann_invalidate(self.h, L.u128_array([doc_id]), C.c_size_t(1),
@@ -754,10 +737,6 @@ class MultiSpannIndex:
                 rows += res.id_with_scores(i)
         rows.sort(key=lambda r: (np.isnan(r[1]), r[1], r[0]))
         return rows[:params.top_k]
-
-    def set_filter(self, bitmaps):
-        """bitmaps over the user-local point ids of each query's user"""
-        _set_filter(self.ctx, self.ctx.lib.mdb_multi_spann_set_filter, self.h, bitmaps)
 
     def invalidate(self, user_id, doc_id):
         flags = np.zeros(1, np.uint8)

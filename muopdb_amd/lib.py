@@ -24,12 +24,12 @@ EXPORTED_SYMBOLS = [
     "mdb_version", "mdb_set_profiling", "mdb_get_profile", "mdb_l2_distance", "mdb_dot_distance", "mdb_lane_conforming_distance", "mdb_pq_quantize", "mdb_pq_original_vector", "mdb_pq_distance", "mdb_ef_decode",
     "mdb_ivf_assign", "mdb_kmeans_fit", "mdb_flat_create", "mdb_flat_free", "mdb_flat_search", "mdb_flat_topk",
     "mdb_ivf_load", "mdb_ivf_free", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_ivf_num_resident_vectors",
-    "mdb_ivf_find_nearest_centroids", "mdb_ivf_coarse_keys", "mdb_ivf_merge_coarse_keys", "mdb_ivf_search", "mdb_ivf_search_points", "mdb_ivf_set_filter", "mdb_ivf_invalidate",
+    "mdb_ivf_find_nearest_centroids", "mdb_ivf_coarse_keys", "mdb_ivf_merge_coarse_keys", "mdb_ivf_search", "mdb_ivf_search_points", "mdb_ivf_invalidate",
     "mdb_ivf_is_invalidated",
     "mdb_hnsw_load", "mdb_hnsw_attach", "mdb_hnsw_free", "mdb_hnsw_num_vectors", "mdb_hnsw_ann_search",
-    "mdb_spann_load", "mdb_spann_free", "mdb_spann_search", "mdb_spann_set_filter", "mdb_spann_invalidate", "mdb_spann_is_invalidated",
+    "mdb_spann_load", "mdb_spann_free", "mdb_spann_search", "mdb_spann_invalidate", "mdb_spann_is_invalidated",
     "mdb_multi_spann_load", "mdb_multi_spann_free", "mdb_multi_spann_num_users", "mdb_multi_spann_search",
-    "mdb_multi_spann_set_filter", "mdb_multi_spann_invalidate", "mdb_merge_shards",
+    "mdb_multi_spann_invalidate", "mdb_merge_shards",
     "mdb_shard_block_bytes", "mdb_shard_block_views", "mdb_merge_shards_packed", "mdb_allgather_merge",
     "mdb_odht_user_table", "mdb_hnsw_select_neighbors", "mdb_wait", "mdb_poll", "mdb_ivf_search_filtered", "mdb_ivf_attach", "mdb_ivf_search_submit", "mdb_hnsw_ann_search_submit",
     "mdb_spann_search_filtered", "mdb_spann_attach", "mdb_spann_search_submit",

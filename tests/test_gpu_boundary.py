@@ -77,7 +77,8 @@ def test_per_call_filter_equals_oracle_and_leaves_no_state(ctx, oracle, case):
 
 def test_filter_bitmaps_are_validated(ctx, case):
     """a bitmap shorter than ceil(num_vectors / 32) words, or fewer per-query bitmaps than queries, used to be
-    read out of bounds by the scan; now both are MDB_ERR_INVALID_ARG — per call and in the deprecated stateful form."""
+    read out of bounds by the scan; now both are MDB_ERR_INVALID_ARG (the planner is a per-call argument: the stateful
+    mdb_*_set_filter entries were removed in round 4)."""
     from muopdb_amd import lib as L
     from muopdb_amd.index import BlockBasedIvf
     f, q = case["files"], case["q"]
@@ -87,15 +88,7 @@ def test_filter_bitmaps_are_validated(ctx, case):
         with pytest.raises(L.MuopdbError) as e:
             g.search(q, 10, 12, planner=bad)
         assert e.value.status == L.MDB_ERR_INVALID_ARG
-    with pytest.raises(L.MuopdbError) as e:
-        g.set_filter(short)
-    assert e.value.status == L.MDB_ERR_INVALID_ARG
-    g.set_filter(case["per_query"][:5])         # stateful: the batch size is only known at search time
-    with pytest.raises(L.MuopdbError) as e:
-        g.search(q, 10, 12)
-    assert e.value.status == L.MDB_ERR_INVALID_ARG
-    g.search(q[:5], 10, 12)                     # ... and a batch the bitmaps cover is served
-    g.set_filter(None)
+    g.search(q[:5], 10, 12, planner=case["per_query"][:5])   # a batch the bitmaps cover is served
     g.search(q, 10, 12, planner=case["per_query"])
 
 

@@ -639,31 +639,27 @@ def test_planner_filter_hook(ctx, oracle, pq):
     g = BlockBasedIvf(ctx, files["ivf_index"], files["ivf_vectors"], quant)
     o = oracle.BlockBasedIvf(files["ivf_index"], files["ivf_vectors"], oquant)
     for bm in (even, per_query):
-        g.set_filter(bm)
         with oracle.planner_filter(bm):
             want = o.search(q, 10, num_probes=12)
-        got = g.search(q, 10, 12)
+        got = g.search(q, 10, 12, planner=bm)
         assert_result_rows(got, want, len(q))
         if bm is even:
             assert all(x % 2 == 0 for i in range(len(q)) for x in got.doc_ids(i))
-    g.set_filter(None)
-    assert_result_rows(g.search(q, 10, 12), o.search(q, 10, num_probes=12), len(q))
+    assert_result_rows(g.search(q, 10, 12), o.search(q, 10, num_probes=12), len(q))   # a filter never outlives its call
     # SPANN
     sp = Spann(ctx, files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"], quant)
     osp = oracle.Spann(files["hnsw_index"], files["hnsw_vectors"], files["ivf_index"], files["ivf_vectors"], oquant)
     p, op = SearchParams(10, 50).with_num_explored_centroids(6), oracle.SearchParams(10, 50, num_explored_centroids=6)
-    sp.set_filter(per_query)
     with oracle.planner_filter(per_query):
         want = osp.search(q, op)
-    assert_result_rows(sp.search(q, p), want, len(q))
+    assert_result_rows(sp.search(q, p, planner=per_query), want, len(q))
     # multi-user (one user): bitmaps are over the user's local point ids
     cat = F.concat_multi_spann({5: files})
     ms = MultiSpannIndex(ctx, cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], quant)
     oms = oracle.MultiSpannIndex(cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], oquant)
-    ms.set_filter(even)
     with oracle.planner_filter(even):
         want = oms.search_for_user([5] * len(q), q, op)
-    got = ms.search_for_user([5] * len(q), q, p)
+    got = ms.search_for_user([5] * len(q), q, p, planner=even)
     assert_result_rows(got, want, len(q))
     assert all(x % 2 == 0 for i in range(len(q)) for x in got.doc_ids(i))
 
