@@ -107,7 +107,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="all", choices=["all", "hnsw", "flat", "ivfpq", "spann", "c5"])
+    p.add_argument("--workload", default="all", choices=["all", "hnsw", "flat", "ivfpq", "spann", "c5", "c5full"])
     p.add_argument("--data", default="lowrank", choices=["lowrank", "legacy"],
                    help="lowrank: muopdb_amd.build.SiftLike / EmbedLike; legacy: round 1's isotropic Gaussian generators")
     p.add_argument("--n", type=int, default=None, help="base vectors (default: the config's size)")
@@ -123,6 +123,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-sweep", action="store_true")
     p.add_argument("--no-c5", action="store_true", help="all: skip the C5 per-GPU shard workload (~50 s of build)")
+    p.add_argument("--no-c5-full", action="store_true", help="all: skip the whole-C5-on-one-GPU workload (100M codes, ~2-3 min of build)")
     p.add_argument("--no-c4-full", action="store_true", help="all: skip the full-size C4 workload (1024 users, 30.7 GB, ~60 s)")
     p.add_argument("--streams", type=int, default=4, help="hnsw: extra measurement with this many batches in flight (0/1 = skip)")
     p.add_argument("--dump-dir", default=None, help="write index files + queries for examples/replay_search.cpp")
@@ -185,6 +186,51 @@ class Env:
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def shared_build(self, tag, build_fn):
+        """Index files of a list-sharded workload, built ONCE per job: world == 1 -> build_fn() as is.  world > 1 -> rank 0 builds
+        (on its GPU), writes every bytes-like value of the returned dict under MDB_BENCH_TMP (default /tmp) and the small values
+        into a pickle; the other ranks wait at a barrier and np.memmap the files — every rank then hands the loader the SAME bytes
+        (it keeps the posting lists it owns: mdb_*_load(.., shard_rank, shard_world)), the host holds them once (page cache)
+        instead of once per rank (full C4: 30.7 GB -> 250 GB at 8 ranks), and nothing is generated / clustered eight times over.
+        Returns (dict, cleanup): call cleanup() once the indexes are loaded."""
+        if self.world == 1:
+            return build_fn(), (lambda: None)
+        import pickle
+        import shutil
+        base = os.path.join(os.environ.get("MDB_BENCH_TMP", "/tmp"), "mdb_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag))
+        t0 = time.time()
+        if self.rank == 0:
+            shutil.rmtree(base, ignore_errors=True)
+            os.makedirs(base)
+            built = build_fn()
+            small = {}
+            for key, val in built.items():
+                if isinstance(val, (bytes, bytearray, memoryview)) or (isinstance(val, np.ndarray) and val.nbytes >= (1 << 20)):
+                    arr = np.frombuffer(val, np.uint8) if not isinstance(val, np.ndarray) else val
+                    arr.tofile(os.path.join(base, key + ".bin"))
+                    small[key] = ("file", str(arr.dtype), arr.shape)
+                else:
+                    small[key] = ("value", val)
+            with open(os.path.join(base, "meta.pkl"), "wb") as f:
+                pickle.dump(small, f)
+            del built
+        dist.barrier()
+        with open(os.path.join(base, "meta.pkl"), "rb") as f:
+            small = pickle.load(f)
+        out = {}
+        for key, rec in small.items():
+            if rec[0] == "file":
+                out[key] = np.memmap(os.path.join(base, key + ".bin"), dtype=np.dtype(rec[1]), mode="r", shape=tuple(rec[2]))
+            else:
+                out[key] = rec[1]
+        log("%s: shared build %.1fs (rank 0 builds, %d ranks map %s)" % (tag, time.time() - t0, self.world, base))
+
+        def cleanup():
+            dist.barrier()   # every rank has uploaded what it owns
+            if self.rank == 0:
+                shutil.rmtree(base, ignore_errors=True)
+        return out, cleanup
 
     def max_over_ranks(self, seconds):
         if self.world > 1:
@@ -287,6 +333,28 @@ def hbm_roofline(kernel, abytes_per_launch, kernel_ms, launches, **extra):
              traffic=None, bytes_per_launch=abytes_per_launch, kernel_ms=ms)
     r.update(extra)
     return r
+
+
+def exchange_times(env, step, steps, warm):
+    """world > 1: one more (untimed) pass over the timed steps with events around every collective and merge call
+    (muopdb_amd.distributed.StepTimer): the all-gathers' own device time and the merge kernels', per step, max over ranks."""
+    if env.world == 1:
+        return None
+    from muopdb_amd import distributed as D
+    D.TIMER = D.StepTimer()
+    env.barrier()
+    for i in range(warm, warm + steps):
+        step(i)
+    env.barrier()
+    ms = D.TIMER.ms()
+    D.TIMER = None
+    out = {}
+    for kind in ("coarse_allgather", "merge_coarse", "points_allgather", "merge_points"):
+        if kind in ms:
+            out[kind + "_ms_per_step"] = env.max_over_ranks(ms[kind]["total_ms"] / steps)
+    out["ranks"] = env.world
+    out["backend"] = dist.get_backend()
+    return out
 
 
 def finish(out, disp, step_bytes):
@@ -543,7 +611,9 @@ def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=
         st = ctx.stats(); scored += st["scored_vectors"]; abytes += st["algorithmic_bytes"]
     found = torch.cat(found).cpu().numpy()
     rec = recall_at_k(found[:nrec], gt, k) if gt is not None else None
-    return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes, recall=rec, disp=disp)
+    ex = exchange_times(env, step, steps, warm) if disperse else None
+    return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes, recall=rec, disp=disp,
+                exchange=ex)
 
 
 def build_ivfpq(env, x, nlist, seed=3):
@@ -591,6 +661,8 @@ def run_ivfpq(env):
                roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
     finish(out, m["disp"], m["abytes"] / steps)
+    if m["exchange"]:
+        out["exchange"] = m["exchange"]
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ivfpq", out["config"])
     if args.streams > 1 and world == 1:
         # Extra: the same batches round-robin on several HIP streams, each through its own handle ATTACHED to the one resident
@@ -643,6 +715,94 @@ def run_ivfpq(env):
             args.cpu_seconds, min(32, len(qh)),
             lambda r, m_: all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(m_, 256))),
             "%d queries, one thread")
+    ivf.close()
+    return out
+
+
+def run_c5_full(env, steps=None, warm=None):
+    """BASELINE config C5 WHOLE on ONE GPU: all 100M x 128 rows as 16-byte PQ codes (1.6 GB) in 65 536 posting lists, nprobe 64,
+    batch 4096 — the N = 1 point C5's strong scaling is read against (8 x the per-GPU shard step of c5_shard_per_gpu vs this)."""
+    from muopdb_amd import synth as S
+    from muopdb_amd.index import BlockBasedIvf
+    args, ctx = env.args, env.ctx
+    batch = args.batch or 4096
+    k, P = args.k, args.nprobe or 64
+    steps, warm = steps or args.steps, args.warmup if warm is None else warm
+    total = args.n or 100_000_000
+    t0 = time.time()
+    full = S.c5_index(ctx, total=total, world=1, rank=0, nlist=args.nlist or 65536, log=log)
+    build_s = time.time() - t0
+    log("C5 full build %.1fs: %d vectors in %d lists" % (build_s, full["n"], full["owned_lists"]))
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    ivf = BlockBasedIvf(ctx, full["index"], full["vectors"], full["pq"])
+    load_s = time.time() - t0
+    queries = full["gen"].draw((steps + warm) * batch, seed=5000).contiguous()
+    m = ivfpq_measure(env, ivf, None, queries, batch, k, P, steps, warm)
+    out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=None, scaling="strong",
+               config={"workload": "C5 on ONE GPU: %d x 128 SiftLike rows as 16-byte PQ codes in %d posting lists (all resident), nprobe=%d, "
+                                   "batch=%d, top-%d" % (full["n"], full["nlist"], P, batch, k),
+                       "n": full["n"], "dim": 128, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": "lowrank",
+                       "build_s": build_s, "load_s": load_s},
+               roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
+                                     scored_per_query=m["scored"] / (steps * batch)))
+    finish(out, m["disp"], m["abytes"] / steps)
+    out["steps"], out["warmup"] = steps, warm
+    if env.cpu:
+        import oracle
+        o = oracle.BlockBasedIvf(full["index"], full["vectors"], oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, full["codebook"]))
+        qh = queries[warm * batch:].cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(
+            lambda m_: o.search(qh[:m_], k, num_probes=P, threads=1), lambda m_, t: o.search(qh[:m_], k, num_probes=P, threads=t), len(qh),
+            min(args.cpu_seconds, 6.0), min(8, len(qh)),
+            lambda r, m_: all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(m_, 256))),
+            "%d queries, one thread")
+    ivf.close()
+    return out
+
+
+def run_c5_sharded(env, steps=None, warm=None):
+    """BASELINE config C5 over the ranks of this job (world > 1): the 100M-code index is built ONCE (rank 0, Env.shared_build), every
+    rank loads the posting lists it owns from the same files (size-balanced owners, mdb_ivf_load(.., rank, world)) plus the
+    replicated coarse quantizer, and a step is the EXACT sharded search: coarse search over 1/world of the centroids + one all-gather
+    of [b][P] keys, search of the owned lists into a points block, ONE all-gather of the blocks, (distance, point id) merge and
+    remap on every rank.  Strong scaling: the same batch on every rank; compare with c5_full_1gpu (N = 1)."""
+    from muopdb_amd import synth as S
+    from muopdb_amd.index import BlockBasedIvf
+    args, ctx, rank, world = env.args, env.ctx, env.rank, env.world
+    batch = args.batch or 4096
+    k, P = args.k, args.nprobe or 64
+    steps, warm = steps or args.steps, args.warmup if warm is None else warm
+    total = args.n or 100_000_000
+    t0 = time.time()
+
+    def build():
+        full = S.c5_index(ctx, total=total, world=1, rank=0, nlist=args.nlist or 65536, log=log)
+        return dict(index=full["index"], vectors=full["vectors"], codebook=np.asarray(full["codebook"], np.float32), n=full["n"],
+                    nlist=full["nlist"])
+
+    full, cleanup = env.shared_build("c5", build)
+    build_s = time.time() - t0
+    from muopdb_amd.index import ProductQuantizer
+    pq = ProductQuantizer(128, 8, 8, full["codebook"])
+    t0 = time.time()
+    ivf = BlockBasedIvf(ctx, full["index"], full["vectors"], pq, shard_rank=rank, shard_world=world)
+    load_s = time.time() - t0
+    cleanup()
+    queries = S.SiftLike(128, seed=4).draw((steps + warm) * batch, seed=5000).contiguous()   # the same batch on every rank
+    m = ivfpq_measure(env, ivf, None, queries, batch, k, P, steps, warm)
+    out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=None, scaling="strong",
+               config={"workload": "C5 sharded x%d: %d x 128 SiftLike rows as 16-byte PQ codes in %d posting lists dealt size-balanced to the "
+                                   "ranks, coarse quantizer sharded for the search, nprobe=%d, batch=%d, top-%d"
+                                   % (world, full["n"], full["nlist"], P, batch, k),
+                       "n": full["n"], "dim": 128, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": "lowrank",
+                       "build_s": build_s, "load_s": load_s, "parallelism": "list shards x%d" % world},
+               roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
+                                     scored_per_query_this_rank=m["scored"] / (steps * batch)))
+    finish(out, m["disp"], m["abytes"] / steps)
+    if m["exchange"]:
+        out["exchange"] = m["exchange"]
+    out["steps"], out["warmup"] = steps, warm
     ivf.close()
     return out
 
@@ -744,28 +904,40 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
     nlist = max(1, per // 64)
     t0 = time.time()
     gen = S.EmbedLike(d, seed=3) if args.data == "lowrank" else None
-    users_, base, ucent = {}, [], []
-    for u in range(U):
-        if gen is not None:
-            ucent.append(gen.user(u))
-            x = gen.draw(ucent[u], per, seed=3_000_000 + u)
-        else:
-            x = S.unit_gaussian(per, d, seed=3_000_000 + u)
-        cent = B.kmeans(ctx, x, nlist, iters=4, seed=u)
-        pls = B.posting_lists_from_assignment(B.assign_nearest(ctx, x, cent), cent.shape[0])
-        hi, hv = S.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
-        docs = np.arange(u * per, (u + 1) * per, dtype=np.uint64)
-        users_[u + 1] = dict(hnsw_index=hi, hnsw_vectors=hv, ivf_index=F.write_ivf_index(cent.cpu().numpy(), docs, pls),
-                             ivf_vectors=F.write_vector_file(x.cpu().numpy()))
-        base.append(x)
-    cat = F.concat_multi_spann(users_)
-    del users_
+    ucent = [gen.user(u) for u in range(U)] if gen is not None else []
+    base = []   # the users' rows on the device (rank 0 / single process): exact ground truth, legacy queries
+
+    def build():
+        users_ = {}
+        for u in range(U):
+            if gen is not None:
+                x = gen.draw(ucent[u], per, seed=3_000_000 + u)
+            else:
+                x = S.unit_gaussian(per, d, seed=3_000_000 + u)
+            cent = B.kmeans(ctx, x, nlist, iters=4, seed=u)
+            pls = B.posting_lists_from_assignment(B.assign_nearest(ctx, x, cent), cent.shape[0])
+            hi, hv = S.hnsw_files(cent, max_neighbors=16, max_layers=4, kcand=32, seed=u)
+            docs = np.arange(u * per, (u + 1) * per, dtype=np.uint64)
+            users_[u + 1] = dict(hnsw_index=hi, hnsw_vectors=hv, ivf_index=F.write_ivf_index(cent.cpu().numpy(), docs, pls),
+                                 ivf_vectors=F.write_vector_file(x.cpu().numpy()))
+            base.append(x)
+        cat_ = F.concat_multi_spann(users_)
+        del users_
+        return {key: cat_[key] for key in ("user_table", "hnsw_index", "hnsw_vectors", "ivf_index", "ivf_vectors")}
+
+    if world > 1 and gen is None:
+        raise SystemExit("the sharded SPANN workload needs --data lowrank (queries are drawn from the generator, not from rank-local rows)")
+    # world > 1: rank 0 builds the collection ONCE and the ranks map the same files (Env.shared_build) — every rank used to build all
+    # 1024 users itself: 35 s and 30.7 GB of host bytes PER RANK
+    cat, cleanup = env.shared_build("spann_%du" % U, build)
     log("multi-user SPANN build: %d users x %d x %d, %.1fs, ivf_vectors %.2f GB" % (U, per, d, time.time() - t0,
                                                                                     len(cat["ivf_vectors"]) / 1e9))
     t0 = time.time()
     ms = MultiSpannIndex(ctx, cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"],
                          None, rank, world)
     log("load %.1fs" % (time.time() - t0))
+    cleanup()
+    have_base = len(base) == U
     nq = (steps + warm) * batch
     quser = (torch.arange(nq) % U)
     if gen is not None:  # queries: fresh draws of each user's own distribution (same pairs on every rank: lists are sharded)
@@ -790,14 +962,16 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
     cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
     fo = torch.zeros(batch, dtype=torch.uint8, device="cuda")
     uid_arrays = [L.u128_array([int(u) + 1 for u in quser[i * batch:(i + 1) * batch].tolist()]) for i in range(steps + warm)]
-    # exact per-user ground truth (f64) of the timed queries
-    gts = []
-    for j in range(steps * batch):
-        qi = warm * batch + j
-        u = int(quser[qi])
-        dd = ((base[u].double() - queries[qi].double()[None, :]) ** 2).sum(1)
-        gts.append((torch.topk(dd, k, largest=False).indices + u * per))
-    gts = torch.stack(gts).cpu().numpy()
+    # exact per-user ground truth (f64) of the timed queries (the rank that built the collection holds the rows)
+    gts = None
+    if have_base:
+        gts = []
+        for j in range(steps * batch):
+            qi = warm * batch + j
+            u = int(quser[qi])
+            dd = ((base[u].double() - queries[qi].double()[None, :]) ** 2).sum(1)
+            gts.append((torch.topk(dd, k, largest=False).indices + u * per))
+        gts = torch.stack(gts).cpu().numpy()
 
     def measure(P_, ratio_, disperse=True):
         params = SearchParams(k, args.ef).with_num_explored_centroids(P_).with_centroid_distance_ratio(ratio_).to_c()
@@ -830,9 +1004,10 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
         # a SPANN call's algorithmic bytes = the centroid graphs' traversal (evaluations x (4 d + 4) + expansions x 16: ANOTHER kernel,
         # hnsw_closure_kernel) + the posting-list scan (scored x bytes per scored vector): each kernel is priced with its own bytes
         graph_bytes = evals * (d * 4 + 4) + expanded * 16
-        return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes,
+        ex = exchange_times(env, step, steps, warm) if disperse else None
+        return dict(exchange=ex, elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes,
                     scan_bytes=abytes - graph_bytes, graph_bytes=graph_bytes, evals=evals, disp=disp,
-                    recall=recall_at_k(found, gts, k), hnsw_ms=hnsw_ms / max(hnsw_launches, 1))
+                    recall=recall_at_k(found, gts, k) if gts is not None else None, hnsw_ms=hnsw_ms / max(hnsw_launches, 1))
 
     m = measure(P, ratio)
     out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=m["recall"], scaling="strong",
@@ -847,6 +1022,8 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
     out["roofline"]["centroid_graph"] = hbm_roofline("hnsw_closure_kernel", m["graph_bytes"] / steps, m["hnsw_ms"], 1,
                                                      evals_per_query=m["evals"] / (steps * batch))
     finish(out, m["disp"], m["abytes"] / steps)
+    if m["exchange"]:
+        out["exchange"] = m["exchange"]
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("spann_full" if U >= 1024 else "spann", out["config"])
     out["steps"], out["warmup"] = steps, warm
     if not (args.no_sweep or no_sweep):
@@ -920,7 +1097,8 @@ def main():
     ctx = L.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     env = Env(args, ctx, rank, world)
-    single = {"hnsw": run_hnsw, "flat": run_flat, "ivfpq": run_ivfpq, "spann": run_spann, "c5": run_c5}
+    single = {"hnsw": run_hnsw, "flat": run_flat, "ivfpq": run_ivfpq, "spann": run_spann, "c5": run_c5,
+              "c5full": run_c5_full if world == 1 else run_c5_sharded}
     if args.workload != "all":
         res = single[args.workload](env)
     else:
@@ -930,8 +1108,15 @@ def main():
         plan = [("hnsw_c2_b1", lambda: run_hnsw(env, batch=1, graph="knn", extras=False, steps=max(args.steps, 200), warm=max(args.warmup, 20))),
                 ("flat_1m_b1", lambda: run_flat(env, n=1_000_000, batch=1)), ("flat_1m_b64", lambda: run_flat(env, n=1_000_000, batch=64)),
                 ("ivfpq_c3", lambda: run_ivfpq(env)), ("spann_c4_128u", lambda: run_spann(env, users=128))]
+        if world > 1:   # the list-sharded configurations at full size over this job's ranks (C4: 1024 users; C5: 100M codes)
+            if not args.no_c4_full:
+                plan.append(("spann_c4_full_sharded", lambda: run_spann(env, users=1024, no_sweep=True, steps=min(args.steps, 10), warm=min(args.warmup, 3))))
+            if not args.no_c5_full:
+                plan.append(("c5_sharded", lambda: run_c5_sharded(env, steps=min(args.steps, 6), warm=min(args.warmup, 2))))
         if world == 1 and not args.no_c5:  # one GPU's share of C5 (a 1/8 shard of 100M x 16-byte codes: ~50 s of build)
             plan.append(("c5_shard_per_gpu", lambda: run_c5(env, steps=min(args.steps, 8), warm=min(args.warmup, 2))))
+        if world == 1 and not args.no_c5_full:  # the whole of C5 on one GPU: the N = 1 anchor of its strong scaling
+            plan.append(("c5_full_1gpu", lambda: run_c5_full(env, steps=min(args.steps, 6), warm=min(args.warmup, 2))))
         if world == 1 and not args.no_c4_full:  # the whole of C4 on one GPU: 1024 users x 9766 x 768 = 30.7 GB resident (~60 s of build + load)
             plan.append(("spann_c4_full_1024u", lambda: run_spann(env, users=1024, no_sweep=True, steps=min(args.steps, 10), warm=min(args.warmup, 3))))
         if world == 1 and not args.no_insert_graph:  # C2 again on a graph built the way MuopDB builds it (HnswBuilder::insert)

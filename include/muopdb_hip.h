@@ -147,6 +147,9 @@ mdb_status mdb_lane_conforming_distance(mdb_ctx* ctx, const float* a, const floa
                                         mdb_metric metric, float* out);
 /* ProductQuantizer::quantize pq/mod.rs:152-177 — vectors [n][dimension] -> codes [n][m] */
 mdb_status mdb_pq_quantize(mdb_ctx* ctx, const mdb_quant_desc* pq, const float* vectors, size_t n, uint8_t* codes_out);
+/* the same with vectors and codes where `mem` says (MDB_MEM_DEVICE: rows of an index build that never leave HBM — the corpus
+ * quantization of IvfBuilder::build, ivf/builder.rs:596-680; returns when the codes are written) */
+mdb_status mdb_pq_quantize_mem(mdb_ctx* ctx, const mdb_quant_desc* pq, const float* vectors, size_t n, mdb_mem mem, uint8_t* codes_out);
 /* ProductQuantizer::original_vector pq/mod.rs:184-200 — codes [n][m] -> the concatenated codebook rows [n][dimension] */
 mdb_status mdb_pq_original_vector(mdb_ctx* ctx, const mdb_quant_desc* pq, const uint8_t* codes, size_t n, float* vectors_out);
 /* ProductQuantizer::distance pq/mod.rs:202-278 — code pairs a[i], b[i] ([n][m]) */

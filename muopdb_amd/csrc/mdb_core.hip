@@ -513,6 +513,20 @@ extern "C" mdb_status mdb_pq_quantize(mdb_ctx* ctx, const mdb_quant_desc* q, con
     return MDB_OK;
 }
 
+extern "C" mdb_status mdb_pq_quantize_mem(mdb_ctx* ctx, const mdb_quant_desc* q, const float* vectors, size_t n, mdb_mem mem,
+                                          uint8_t* codes_out) {
+    if (mem != MDB_MEM_DEVICE) return mdb_pq_quantize(ctx, q, vectors, n, codes_out);
+    if (!ctx || !q || !vectors || !codes_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    PqDev pq;
+    MDB_TRY(pq_upload(ctx, q, pq));
+    if (n == 0) return MDB_OK;
+    MDB_TRY(pq_quantize_device(ctx, pq, vectors, n, codes_out));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `pq` (the uploaded codebook) is released on return
+    return MDB_OK;
+}
+
 // ProductQuantizer::original_vector (pq/mod.rs:184-200): out[i][s*subdim + e] = codebook[s][codes[i][s]][e]
 __global__ void pq_original_vector_kernel(const uint8_t* __restrict__ codes, int m, int subdim, int K, const float* __restrict__ cb,
                                           float* __restrict__ out, size_t total) {

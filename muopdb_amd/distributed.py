@@ -33,6 +33,52 @@ import torch
 import torch.distributed as dist
 
 
+class StepTimer:
+    """Device time of the exchange steps of a sharded search (bench.py --gpus N: the all-gathers' own time and the merge kernels'):
+    event pairs on the current stream around each collective / merge call, resolved once at the end (`ms()` synchronises).
+    Off (the default) it costs nothing: `TIMER = None`."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def span(self, kind):
+        return _Span(self, kind)
+
+    def ms(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, e0, e1 in self.pairs:
+            tot, cnt = out.get(kind, (0.0, 0))
+            out[kind] = (tot + e0.elapsed_time(e1), cnt + 1)
+        self.pairs = []
+        return {kind: dict(total_ms=t, calls=c, ms_per_call=t / max(c, 1)) for kind, (t, c) in out.items()}
+
+
+class _Span:
+    def __init__(self, timer, kind):
+        self.t, self.kind = timer, kind
+
+    def __enter__(self):
+        if self.t is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.t.pairs.append((self.kind, self.e0, e1))
+        return False
+
+
+TIMER = None   # a StepTimer while bench.py measures the exchange steps
+
+
+def _span(kind):
+    return _Span(TIMER, kind)
+
+
 def shard_of_list(list_index, world):
     """Owner rank of posting list `list_index` of every user of a MULTI-USER collection (mdb_multi_spann_load)."""
     return list_index % world
@@ -152,7 +198,8 @@ class PointsGather:
         if self.world == 1:
             self.recv.copy_(self.send)
         else:
-            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)  # rank-major blocks
+            with _span("points_allgather"):
+                dist.all_gather_into_tensor(self.recv, self.send, group=self.group)  # rank-major blocks
         return self.recv
 
     def recv_views(self):
@@ -167,18 +214,21 @@ class PointsGather:
 
     def gather_merge_ivf(self, ivf):
         self.gather()
-        self.ctx.check(self.ctx.lib.mdb_ivf_merge_shards(ivf.h, *self._tail(False)))
+        with _span("merge_points"):
+            self.ctx.check(self.ctx.lib.mdb_ivf_merge_shards(ivf.h, *self._tail(False)))
         return self.out_docs, self.out_scores, self.out_counts
 
     def gather_merge_spann(self, spann):
         self.gather()
-        self.ctx.check(self.ctx.lib.mdb_spann_merge_shards(spann.h, *self._tail(True)))
+        with _span("merge_points"):
+            self.ctx.check(self.ctx.lib.mdb_spann_merge_shards(spann.h, *self._tail(True)))
         return self.out_docs, self.out_scores, self.out_counts
 
     def gather_merge_multi(self, ms, user_ids_c):
         """user_ids_c: the same ctypes U128 array the search was called with"""
         self.gather()
-        self.ctx.check(self.ctx.lib.mdb_multi_spann_merge_shards(ms.h, user_ids_c, *self._tail(True)))
+        with _span("merge_points"):
+            self.ctx.check(self.ctx.lib.mdb_multi_spann_merge_shards(ms.h, user_ids_c, *self._tail(True)))
         return self.out_docs, self.out_scores, self.out_counts
 
 def all_gather_topk(doc_ids, scores, counts, group=None):
@@ -237,7 +287,8 @@ def gather_coarse_rows(keys, group=None):
     world = dist.get_world_size(group)
     b, p = keys.shape
     allk = torch.empty((world * b, p), dtype=keys.dtype, device=keys.device)
-    dist.all_gather_into_tensor(allk, keys.contiguous(), group=group)  # rank-major
+    with _span("coarse_allgather"):
+        dist.all_gather_into_tensor(allk, keys.contiguous(), group=group)  # rank-major
     return allk.view(world, b, p).permute(1, 0, 2).contiguous()
 
 
@@ -253,6 +304,7 @@ def sharded_probes(ctx, ivf, q_ptr, b, num_probes, device, group=None):
                                           C.c_size_t(count), C.c_int(1), C.c_void_p(keys.data_ptr())))
     keys = gather_coarse_rows(keys, group)  # [b][world][P]
     probes = torch.empty((b, num_probes), dtype=torch.int32, device=device)
-    ctx.check(ctx.lib.mdb_ivf_merge_coarse_keys(ivf.h, C.c_void_p(keys.data_ptr()), C.c_size_t(b), C.c_size_t(world), C.c_size_t(num_probes),
-                                                C.c_int(1), C.c_void_p(probes.data_ptr())))
+    with _span("merge_coarse"):
+        ctx.check(ctx.lib.mdb_ivf_merge_coarse_keys(ivf.h, C.c_void_p(keys.data_ptr()), C.c_size_t(b), C.c_size_t(world), C.c_size_t(num_probes),
+                                                    C.c_int(1), C.c_void_p(probes.data_ptr())))
     return probes

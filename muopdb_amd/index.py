@@ -143,6 +143,13 @@ class ProductQuantizer:
                                           L.ptr(out, C.c_uint8)))
         return out
 
+    def quantize_device(self, ctx, rows_ptr, n, codes_ptr):
+        """quantize n device-resident f32 rows into device codes [n][m] (mdb_pq_quantize_mem): an index build's corpus never
+        leaves HBM."""
+        q, keep = self.desc()
+        ctx.check(ctx.lib.mdb_pq_quantize_mem(ctx.h, C.byref(q), C.c_void_p(rows_ptr), C.c_size_t(n), C.c_int(L.MEM_DEVICE),
+                                              C.c_void_p(codes_ptr)))
+
     def original_vector(self, ctx, codes):
         """ProductQuantizer::original_vector (pq/mod.rs:184-200): codes [n][m] -> reconstructed vectors [n][dimension]."""
         m = self.quantized_dimension()

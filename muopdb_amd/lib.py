@@ -21,7 +21,7 @@ IMPL_SCALAR, IMPL_SIMD, IMPL_STREAMING_SIMD = 0, 1, 2
 
 EXPORTED_SYMBOLS = [
     "mdb_device_open", "mdb_device_close", "mdb_set_stream", "mdb_sync", "mdb_last_error", "mdb_get_stats",
-    "mdb_version", "mdb_set_profiling", "mdb_get_profile", "mdb_l2_distance", "mdb_dot_distance", "mdb_lane_conforming_distance", "mdb_pq_quantize", "mdb_pq_original_vector", "mdb_pq_distance", "mdb_ef_decode",
+    "mdb_version", "mdb_set_profiling", "mdb_get_profile", "mdb_l2_distance", "mdb_dot_distance", "mdb_lane_conforming_distance", "mdb_pq_quantize", "mdb_pq_quantize_mem", "mdb_pq_original_vector", "mdb_pq_distance", "mdb_ef_decode",
     "mdb_ivf_assign", "mdb_kmeans_fit", "mdb_flat_create", "mdb_flat_free", "mdb_flat_search", "mdb_flat_topk",
     "mdb_ivf_load", "mdb_ivf_free", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_ivf_num_resident_vectors",
     "mdb_ivf_find_nearest_centroids", "mdb_ivf_coarse_keys", "mdb_ivf_merge_coarse_keys", "mdb_ivf_search", "mdb_ivf_search_points", "mdb_ivf_invalidate",

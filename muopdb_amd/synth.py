@@ -234,13 +234,15 @@ def hnsw_files(x, doc_ids=None, **kw):
 
 
 # ------------------------------------------------------------------------------------------ BASELINE config C5, one GPU's shard
-def c5_shard(ctx, total=100_000_000, world=8, rank=0, nlist=65536, d=128, chunk=2_000_000, seed=4, log=None):
-    """What ONE of the 8 GPUs holds of BASELINE config C5 (100M x 128 as 16-byte PQ codes, IVF nlist 65 536, posting lists
-    sharded l % world): the full coarse quantizer, the shared PQ codebook, and the posting lists this rank owns with
-    their codes (~total/world vectors, ~total/nlist per list).  The 100M rows are generated chunk by chunk (SiftLike),
-    assigned to their nearest of the 65 536 centroids, and only the rows of owned lists are kept — the other ranks'
-    lists are EMPTY in the returned index file, so loading it unsharded reproduces this rank's work exactly.
+def c5_index(ctx, total=100_000_000, world=8, rank=0, nlist=65536, d=128, chunk=2_000_000, seed=4, log=None):
+    """BASELINE config C5 (100M x 128 as 16-byte PQ codes, IVF nlist 65 536) — as ONE of `world` GPUs holds it with the posting lists
+    sharded l % world (world = 8: ~total/8 vectors), or whole (world = 1: all 100 M codes, 1.6 GB — the N = 1 anchor of C5's strong
+    scaling): the full coarse quantizer, the shared PQ codebook, and the posting lists this rank owns with their codes.  The rows
+    are generated chunk by chunk (SiftLike), assigned to their nearest of the nlist centroids and quantized ON THE DEVICE
+    (mdb_pq_quantize_mem: the f32 rows never leave HBM); only the rows of owned lists are kept — the other ranks' lists are EMPTY in
+    the returned index file, so loading it unsharded reproduces this rank's work exactly.
     Returns dict(index, vectors, pq, codebook, gen, n, nlist, owned_lists, centroids)."""
+    import torch
     from .index import ProductQuantizer
     from . import build as B
     gen = SiftLike(d, seed=seed)
@@ -257,14 +259,22 @@ def c5_shard(ctx, total=100_000_000, world=8, rank=0, nlist=65536, d=128, chunk=
         m = min(chunk, total - done)
         x = gen.draw(m, seed=seed * 1000 + ci)
         a = gemm_assign_nearest(x, cent, chunk=1 << 14)   # 100M x 65 536 bulk labelling of SYNTHETIC rows: GEMM form
-        own = (a % world) == rank
-        xo = x[own]
-        keep_list.append(a[own].cpu().numpy().astype(np.int64))
-        keep_codes.append(pq.quantize(ctx, xo.cpu().numpy()))
+        if world > 1:
+            own = (a % world) == rank
+            xo = x[own].contiguous()
+            ao = a[own]
+        else:
+            xo, ao = x.contiguous(), a
+        keep_list.append(ao.cpu().numpy().astype(np.int32))
+        codes_d = torch.empty((xo.shape[0], d // 8), dtype=torch.uint8, device=xo.device)
+        if xo.shape[0]:
+            pq.quantize_device(ctx, xo.data_ptr(), xo.shape[0], codes_d.data_ptr())
+        keep_codes.append(codes_d.cpu().numpy())
+        del x, xo, codes_d
         done += m
         ci += 1
         if log and ci % 10 == 0:
-            log("c5 shard: %d / %d rows assigned" % (done, total))
+            log("c5 index: %d / %d rows assigned" % (done, total))
     lists = np.concatenate(keep_list)
     codes = np.concatenate(keep_codes)
     del keep_list, keep_codes
@@ -273,12 +283,16 @@ def c5_shard(ctx, total=100_000_000, world=8, rank=0, nlist=65536, d=128, chunk=
     order = np.argsort(lists, kind="stable")
     codes = codes[order]
     bounds = np.searchsorted(lists[order], np.arange(nlist + 1))
+    del order, lists
     pls = [np.arange(bounds[i], bounds[i + 1], dtype=np.uint64) for i in range(nlist)]
     # this rank's global doc ids: an arbitrary injective labelling (rank-strided)
     docs = np.arange(n, dtype=np.uint64) * np.uint64(world) + np.uint64(rank)
     index = F.write_ivf_index(cent.cpu().numpy(), docs, pls, quantized_dimension=d // 8)
     return dict(index=index, vectors=F.write_vector_file(codes), pq=pq, codebook=cb, gen=gen, n=n, nlist=nlist,
                 owned_lists=int((np.diff(bounds) > 0).sum()), centroids=cent)
+
+
+c5_shard = c5_index   # rounds 1-3's name (world = 8: a rank's shard)
 
 
 def gemm_assign_nearest(x, c, chunk=1 << 16):

@@ -1,3 +1,4 @@
 cd /root/repo
-timeout 2700 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+(time timeout 1500 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "c5_full" 2>&1 | tail -15) 2>&1
+(time timeout 1200 python bench.py --workload c5full --steps 6 --warmup 2 > gpurun_out/c5full.json 2> gpurun_out/c5full.err) 2>&1 | tail -3
+tail -5 gpurun_out/c5full.err; tail -c 2500 gpurun_out/c5full.json

@@ -346,3 +346,49 @@ def test_c5_shard_ivfpq(ctx, oracle):
     for i in range(12):
         kept = [dd for dd in res.doc_ids(i) if dd not in victims]
         assert after.doc_ids(i)[:len(kept)] == kept
+
+
+def test_c5_full_ivfpq_one_gpu_equals_merge_of_8_shards(ctx, oracle):
+    """BASELINE config C5 WHOLE on one GPU: all 100 M x 16-byte PQ codes / 65 536 posting lists resident (1.6 GB
+    of codes: 180 x under one MI355X's HBM), nprobe 64, batch 4096 — the N = 1 anchor of C5's strong scaling.  The unsharded rows
+    must equal (a) the exact merge of the points blocks of 8 simulated list shards (l % 8 == r, loaded from the SAME files:
+    ivf/block_based/index.rs:250-332 per shard, then the (distance, point id) merge + remap) on 256 queries, with the probes found
+    by the coarse search sharded over the same world of 8; (b) the oracle's rows on 8 queries."""
+    import torch
+    from muopdb_amd import synth as S
+    from muopdb_amd.distributed import coarse_range
+    from muopdb_amd.index import BlockBasedIvf
+    full = S.c5_index(ctx, total=100_000_000, world=1, rank=0, nlist=65536)
+    torch.cuda.empty_cache()
+    assert full["n"] == 100_000_000 and full["nlist"] == 65536 and full["owned_lists"] > 60000
+    g = BlockBasedIvf(ctx, full["index"], full["vectors"], full["pq"])
+    assert g.num_vectors() == 100_000_000 and g.num_clusters() == 65536
+    P, B_ = 64, 4096
+    q = full["gen"].draw(B_, seed=5000).cpu().numpy()
+    res = g.search(q, K, P)                                                                # the configuration's batch
+    assert_sorted(res, B_)
+    whole = rows_of(res, B_)
+    assert all(len(r[0]) == K for r in whole)                                              # 64 probes x ~1500 codes per query
+    assert rows_of(g.search(q, K, P), B_) == whole                                         # idempotent
+    for lo, hi in [(0, 1), (1, 6), (500, 1525)]:                                           # batch-split invariance
+        assert rows_of(g.search(q[lo:hi], K, P), hi - lo) == whole[lo:hi]
+    nq = 256
+    probes = g.find_nearest_centroids(q[:nq], P)
+    rows = []
+    for r in range(8):                                                                     # the coarse search, sharded over 8
+        first, count = coarse_range(65536, r, 8)
+        rows.append(g.coarse_keys(q[:nq], P, first, count))
+    assert np.array_equal(g.merge_coarse_keys(np.stack(rows, axis=1), P), probes)
+    blocks, sh = [], None
+    for r in range(8):                                                                     # 8 list shards of the same files
+        if sh is not None:
+            sh.close()
+        sh = BlockBasedIvf(ctx, full["index"], full["vectors"], full["pq"], shard_rank=r, shard_world=8)
+        blocks.append(sh.search_shard(q[:nq], K, probes=probes))
+    merged = sh.merge_shards(blocks, nq, K)                                                # any rank merges: doc-id tables are replicated
+    sh.close()
+    assert rows_of(merged, nq) == whole[:nq]
+    o = oracle.BlockBasedIvf(full["index"], full["vectors"], oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, full["codebook"]))
+    assert np.array_equal(o.find_nearest_centroids(q[:8], P), probes[:8])
+    assert rows_of(o.search(q[:8], K, num_probes=P), 8) == whole[:8]                       # the oracle on the full index
+    g.close()
