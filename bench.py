@@ -110,7 +110,9 @@ def parse():
     p.add_argument("--workload", default="all", choices=["all", "hnsw", "flat", "ivfpq", "spann", "c5", "c5full"])
     p.add_argument("--data", default="lowrank", choices=["lowrank", "legacy"],
                    help="lowrank: muopdb_amd.build.SiftLike / EmbedLike; legacy: round 1's isotropic Gaussian generators")
-    p.add_argument("--n", type=int, default=None, help="base vectors (default: the config's size)")
+    p.add_argument("--n", "--base-n", dest="n", type=int, default=None,
+                   help="base vectors (default: the config's size); spell it --base-n under a torch.distributed.run launch (its own "
+                        "argument parser rejects --n as an ambiguous prefix of --nnodes / --nproc-per-node / ...)")
     p.add_argument("--dim", type=int, default=None)
     p.add_argument("--batch", type=int, default=None)
     p.add_argument("--ef", type=int, default=200)
@@ -136,6 +138,9 @@ def parse():
                         "insert: HnswBuilder::insert's algorithm, wave-batched on the GPU (muopdb_amd.build.insert_hnsw)")
     p.add_argument("--no-insert-graph", action="store_true", help="all: skip the second HNSW line on an insert-built graph")
     p.add_argument("--insert-n", type=int, default=None, help="all: base size of the insert-built HNSW workload (default: --n)")
+    p.add_argument("--plan", action="store_true",
+                   help="print what `--gpus N` (workload all) will build and hold — per workload: who builds, estimated build / load "
+                        "seconds, host bytes private to a rank and shared through the page cache, HBM per rank — and exit (no GPU needed)")
     p.add_argument("--sift-clusters", type=int, default=None, help="SiftLike mixture components (generator exploration)")
     p.add_argument("--sift-sigma", type=float, default=None)
     p.add_argument("--sift-noise", type=float, default=None)
@@ -1066,8 +1071,45 @@ def launch_ranks(args):
     os.execv(sys.executable, cmd)
 
 
+def print_plan(args):
+    """--plan: the dry run of `bench.py --gpus N` (VERDICT r3 next #7d).  Seconds are this round's single-GPU measurements (gpurun
+    boxes: 2 x EPYC 9575F, one MI355X), bytes follow from the sizes; nothing here touches a device."""
+    w = max(1, args.gpus)
+    GB = 1e9
+    rows = []
+    rows.append(dict(workload="hnsw C2 (headline, replicas) + batch 1", builder="every rank, on its own GPU", build_s=17, load_s=3,
+                     host_private_gb=0.8, host_shared_gb=0, hbm_per_rank_gb=2.4,
+                     note="1M x 128 graph per rank: 0.77 GB of files, no collective in the step"))
+    rows.append(dict(workload="flat 1M b1 / b64 (row shards)", builder="every rank (shares the C2 base)", build_s=0, load_s=1,
+                     host_private_gb=0, host_shared_gb=0, hbm_per_rank_gb=1.1 / w + 0.6))
+    rows.append(dict(workload="ivfpq C3 (list shards)", builder="every rank (k-means + PQ training on the device, ~10 s)", build_s=10, load_s=1,
+                     host_private_gb=0.1, host_shared_gb=0, hbm_per_rank_gb=0.7))
+    rows.append(dict(workload="spann_c4_128u (list shards)", builder="rank 0, files shared" if w > 1 else "the process", build_s=5, load_s=1,
+                     host_private_gb=0.1 if w > 1 else 3.9, host_shared_gb=3.9 if w > 1 else 0, hbm_per_rank_gb=3.9 / w + 3.9 * (w > 1)))
+    if w > 1:
+        rows.append(dict(workload="spann_c4_full_sharded (1024 users x 9766 x 768)", builder="rank 0, files shared", build_s=35 + 25, load_s=12,
+                         host_private_gb=0.3, host_shared_gb=31.0, host_rank0_peak_gb=62.0,
+                         hbm_per_rank_gb=30.7 + 30.7 / w, note="rank 0 holds the collection once more while it writes it (peak 2 x 30.7 GB); "
+                         "every rank uploads the shared vector file (30.7 GB, released after the gather of its lists) and keeps 1/%d" % w))
+        rows.append(dict(workload="c5_sharded (100M x 16-byte codes, 65 536 lists)", builder="rank 0, files shared", build_s=70 + 8, load_s=3,
+                         host_private_gb=0.3, host_shared_gb=3.9, host_rank0_peak_gb=12.0, hbm_per_rank_gb=3.9 + 1.6 / w + 0.3,
+                         note="the other ranks wait at a barrier for ~80 s: well inside the process group's timeout (10 min)"))
+    else:
+        rows.append(dict(workload="c5_shard_per_gpu", builder="the process", build_s=50, load_s=1, host_private_gb=1.5, host_shared_gb=0, hbm_per_rank_gb=1.0))
+        rows.append(dict(workload="c5_full_1gpu", builder="the process", build_s=66, load_s=1, host_private_gb=12.0, host_shared_gb=0, hbm_per_rank_gb=4.5))
+        rows.append(dict(workload="spann_c4_full_1024u", builder="the process", build_s=35, load_s=4, host_private_gb=62.0, host_shared_gb=0, hbm_per_rank_gb=61.4))
+        rows.append(dict(workload="hnsw_c2_insert_graph", builder="the process", build_s=60, load_s=3, host_private_gb=0.8, host_shared_gb=0, hbm_per_rank_gb=2.4))
+    total_s = sum(r["build_s"] + r["load_s"] for r in rows) + 60   # + timed regions, dispersion, recall / ground truth
+    print(json.dumps(dict(gpus=w, estimated_wall_s=total_s, peak_host_gb=max(r.get("host_rank0_peak_gb", 0) + w * r["host_private_gb"] for r in rows),
+                          workloads=rows, tmp_dir=os.environ.get("MDB_BENCH_TMP", "/tmp"),
+                          note="estimates from round 4's one-GPU runs; shared = one copy in the page cache (np.memmap of rank 0's files)"), indent=1))
+
+
 def main():
     args = parse()
+    if args.plan:
+        print_plan(args)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args)   # does not return
     rank = int(os.environ.get("RANK", "0"))

@@ -1,4 +1,6 @@
 cd /root/repo
-(time timeout 1500 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "c5_full" 2>&1 | tail -15) 2>&1
-(time timeout 1200 python bench.py --workload c5full --steps 6 --warmup 2 > gpurun_out/c5full.json 2> gpurun_out/c5full.err) 2>&1 | tail -3
-tail -5 gpurun_out/c5full.err; tail -c 2500 gpurun_out/c5full.json
+export MDB_BENCH_BACKEND=gloo MDB_BENCH_DEVICE=0
+(time timeout 900 python bench.py --gpus 2 --workload c5full --base-n 4000000 --nlist 4096 --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/g2_c5.json 2> gpurun_out/g2_c5.err) 2>&1 | tail -3
+tail -4 gpurun_out/g2_c5.err; tail -c 1500 gpurun_out/g2_c5.json; echo
+unset MDB_BENCH_BACKEND MDB_BENCH_DEVICE
+python bench.py --workload c5full --base-n 4000000 --nlist 4096 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('1gpu', d['value'], d['ms_per_step'])"

@@ -180,18 +180,19 @@ def test_sharded_search_over_rccl_world2():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs (one process per GPU over RCCL); single-GPU boxes run the gloo / simulated-rank tests")
     import torch.multiprocessing as mp
-    world = 2
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [out.get(timeout=600) for _ in range(world)]
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert all(ok for _, ok, _ in results), results
+    # 2 ranks, and — on the driver's 8-GPU node — every visible device (the coarse ranges and the size-balanced owners of 3..8 ranks)
+    for world in sorted({2, min(8, torch.cuda.device_count())}):
+        ctx = mp.get_context("spawn")
+        out = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results = [out.get(timeout=600) for _ in range(world)]
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert all(ok for _, ok, _ in results), (world, results)
 
 
 def test_rccl_path_single_rank_dry_run():
