@@ -138,6 +138,71 @@ def posting_lists_from_assignment(assign, num_lists):
 
 
 
+def reassigned_ids(posting_lists, num_vectors):
+    """IvfBuilder::get_reassigned_ids (rs/index/src/ivf/builder.rs:596-676): new point ids that make every posting list a run of
+    consecutive ids as far as vectors shared by several lists (max_clusters_per_vector > 1: the "stopping points") allow.
+    Lists that share a vector are drained up to it, smallest shared vector first (ties: list contents), then the shared vector itself
+    is numbered; whatever is left is numbered list by list.  Returns int64 [num_vectors], -1 for vectors in no list.
+    Without shared vectors (max_clusters_per_vector == 1) the answer is the list order itself: vectorised."""
+    import heapq
+    lists = [np.asarray(pl, np.int64).reshape(-1) for pl in posting_lists]
+    out = np.full(num_vectors, -1, np.int64)
+    if not lists:
+        return out
+    allv = np.concatenate(lists) if len(lists) else np.zeros(0, np.int64)
+    occ = np.bincount(allv, minlength=num_vectors) if allv.size else np.zeros(num_vectors, np.int64)
+    cur = 0
+    if allv.size and occ.max() > 1:
+        shared = occ > 1
+        heap = []
+        for pl in lists:
+            sp = np.unique(pl[shared[pl]])
+            if sp.size:
+                heap.append((int(sp[0]), tuple(int(v) for v in pl), tuple(int(v) for v in sp)))
+        heapq.heapify(heap)
+        while heap:
+            stop = heap[0][0]
+            work = []
+            while heap and heap[0][0] == stop:     # every list whose next shared vector is `stop`, in heap order
+                work.append(heapq.heappop(heap))
+            for _, pl, sps in work:
+                for i, v in enumerate(pl):
+                    if v == stop:
+                        if len(sps) > 1:
+                            heapq.heappush(heap, (sps[1], pl[i + 1:], sps[1:]))
+                        break
+                    if out[v] >= 0:
+                        raise ValueError("Vectors that come before a stopping point should not be reassigned")
+                    out[v] = cur
+                    cur += 1
+            out[stop] = cur
+            cur += 1
+    # the rest, list by list (:663-674): first occurrence wins
+    if allv.size:
+        first = np.ones(allv.size, bool)
+        order = np.argsort(allv, kind="stable")
+        first[order[1:]] = allv[order[1:]] != allv[order[:-1]]
+        todo = allv[first & (out[allv] < 0)]
+        out[todo] = cur + np.arange(todo.size)
+    return out
+
+
+def reindex(posting_lists, doc_ids, vectors):
+    """IvfBuilder::reindex (ivf/builder.rs:682-761): renumber the points with reassigned_ids and move doc ids and vectors to their
+    new places.  Returns (posting lists in new ids — kept in list order, so NOT necessarily ascending when lists share vectors,
+    doc ids [n'], vectors [n'], mapping u32 [n] old -> new: the bytes of the segment's `reassigned_mappings` file, 0xFFFFFFFF for a
+    vector that is in no list).  n' = number of vectors that are in some list."""
+    vectors = np.asarray(vectors)
+    n = vectors.shape[0]
+    ids = reassigned_ids(posting_lists, n)
+    new_lists = [ids[np.asarray(pl, np.int64)].astype(np.uint64) for pl in posting_lists]
+    valid = np.flatnonzero(ids >= 0)
+    rev = np.empty(valid.size, np.int64)
+    rev[ids[valid]] = valid
+    docs = doc_ids if isinstance(doc_ids, np.ndarray) else np.asarray(list(doc_ids), dtype=object)
+    return new_lists, docs[rev], vectors[rev], ids.astype(np.uint32)   # (-1 as u32 = 0xFFFFFFFF, `*x as u32` at :684)
+
+
 def ivf_build_centroids(ctx, x, num_clusters, max_posting_list_size, num_data_points_for_clustering=20_000, max_iteration=10,
                         tolerance=0.0, seed=0):
     """IvfBuilder::build_centroids (rs/index/src/ivf/builder.rs:460-541): first pass = k-means over a sample with

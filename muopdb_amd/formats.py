@@ -457,11 +457,13 @@ def user_table_from_odht(raw):
 
 
 # --------------------------------------------------------------------------- segment directory
-def write_segment(directory, cat, num_features, pq=None):
+def write_segment(directory, cat, num_features, pq=None, reassigned=None):
     """One (multi-user) SPANN segment as the reference lays it out on disk (multi_spann/writer.rs:82-298; SURVEY.md
     Appendix A) from concat_multi_spann's result: the reference's readers (MultiSpannReader::read, multi_spann/reader.rs:35)
     open this tree.  pq = (dimension, subvector_dimension, num_bits) when the posting lists hold PQ codes (cat["codebook"]).
-    bloom_filter/ and invalidated_ids_storage/ (delete path) are created empty."""
+    reassigned = {user_id: u32 [n] old -> new point id} for users whose IVF was reindexed (muopdb_amd.build.reindex): written as
+    `reassigned_mappings.<user_id>`, 4 little-endian bytes per vector (ivf/writer.rs:52-66, moved to the top level by
+    multi_spann/writer.rs:264-273).  bloom_filter/ and invalidated_ids_storage/ (delete path) are created empty."""
     import os
     def put(rel, data):
         path = os.path.join(directory, rel)
@@ -480,6 +482,8 @@ def write_segment(directory, cat, num_features, pq=None):
     put("ivf/index", cat["ivf_index"])
     put("ivf/vectors", cat["ivf_vectors"])
     put("ivf/raw_vectors", cat.get("ivf_raw_vectors", b""))
+    for user_id, mapping in (reassigned or {}).items():
+        put("reassigned_mappings.%d" % int(user_id), np.ascontiguousarray(mapping, dtype="<u4").tobytes())
     for sub in ("bloom_filter", "invalidated_ids_storage"):
         os.makedirs(os.path.join(directory, sub), exist_ok=True)
 
@@ -500,4 +504,6 @@ def read_segment(directory):
         y = parse_simple_yaml(get("ivf/quantizer/product_quantizer_config.yaml").decode())
         out["pq"] = (y["dimension"], y["subvector_dimension"], y["num_bits"])
         out["codebook"] = np.frombuffer(get("ivf/quantizer/codebook"), np.float32)
+    out["reassigned"] = {int(name.split(".", 1)[1]): np.frombuffer(get(name), "<u4")
+                         for name in os.listdir(directory) if name.startswith("reassigned_mappings.")}
     return out

@@ -571,3 +571,60 @@ class HnswBuilder:
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+# --------------------------------------------------------------------------- IvfBuilder::reindex
+def reassigned_ids(posting_lists, num_vectors):
+    """IvfBuilder::get_reassigned_ids + assign_ids_until_last_stopping_point, rs/index/src/ivf/builder.rs:596-676, statement by
+    statement (pure Python: test infrastructure for small cases).  The heap is BinaryHeap<Reverse<PostingListWithStoppingPoints>>:
+    smallest first stopping point first, ties by the posting list's contents (:114-126)."""
+    import heapq
+    occurrence = {}
+    for li, pl in enumerate(posting_lists):                      # build_posting_lists_with_stopping_points :557-593
+        for v in pl:
+            occurrence.setdefault(int(v), []).append(li)
+    stops = [[] for _ in posting_lists]
+    for v, where in occurrence.items():
+        if len(where) > 1:
+            for li in where:
+                stops[li].append(v)
+    heap = [(sorted(sp)[0], [int(v) for v in pl], sorted(sp)) for pl, sp in zip(posting_lists, stops) if sp]
+    heapq.heapify(heap)
+    assigned = [-1] * num_vectors
+    cur = 0
+    while heap:                                                  # :603-655
+        first = heapq.heappop(heap)
+        stop = first[2][0]
+        working = [first]
+        while heap and heap[0][2][0] == stop:
+            working.append(heapq.heappop(heap))
+        for _, pl, sp in working:
+            for i, v in enumerate(pl):
+                if v == stop:
+                    if len(sp) > 1:
+                        heapq.heappush(heap, (sp[1], pl[i + 1:], sp[1:]))
+                    break
+                if assigned[v] >= 0:
+                    raise ValueError("Vectors that come before a stopping point should not be reassigned")
+                assigned[v] = cur
+                cur += 1
+        assigned[stop] = cur
+        cur += 1
+    for pl in posting_lists:                                     # :663-674
+        for v in pl:
+            if assigned[int(v)] < 0:
+                assigned[int(v)] = cur
+                cur += 1
+    return assigned
+
+
+def reindex(posting_lists, doc_ids, vectors):
+    """IvfBuilder::reindex :682-761 -> (posting lists, doc ids, vectors, mapping) in the new numbering."""
+    ids = reassigned_ids(posting_lists, len(vectors))
+    new_lists = [[ids[int(v)] for v in pl] for pl in posting_lists]
+    n_valid = sum(1 for x in ids if x >= 0)
+    docs, vecs = [None] * n_valid, [None] * n_valid
+    for old, new in enumerate(ids):
+        if new >= 0:
+            docs[new], vecs[new] = doc_ids[old], vectors[old]
+    return new_lists, docs, vecs, [x & 0xFFFFFFFF for x in ids]

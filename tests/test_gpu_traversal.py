@@ -747,3 +747,63 @@ def test_hnsw_attached_handles_share_one_resident_index(ctx, oracle):
         vw.close()
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("pq", [False, True])
+def test_reindexed_segment_sharded_x8_equals_unsharded_equals_oracle(ctx, oracle, pq):
+    """SURVEY §8f-2 / VERDICT r3 #8: an IVF whose vectors sit in up to two posting lists (max_clusters_per_vector = 2) is renumbered
+    by IvfBuilder::reindex's algorithm (muopdb_amd.build.reindex, ivf/builder.rs:596-761: list-contiguous new point ids around the
+    shared "stopping points") — doc ids are then NOT monotone in point ids and the same point is scored from two lists (no dedup,
+    index.rs:250-286).  The segment searched as 8 list shards + the exact (distance, point id) merge == unsharded == the oracle,
+    row for row; the mapping file round-trips through the segment tree."""
+    import os
+    import tempfile
+    from muopdb_amd import build as B
+    from muopdb_amd.index import BlockBasedIvf, ProductQuantizer
+    rng = np.random.default_rng(77)
+    n, d, nl, k, P = 4000, 24, 48, 10, 10
+    v = H.sift_like(n, d, n_clusters=30, seed=12)
+    cent = H.kmeans(v, nl, iters=3, seed=2)
+    dist = ((v[:, None, :] - cent[None, :, :]) ** 2).sum(2)
+    near = np.argsort(dist, axis=1, kind="stable")[:, :2]
+    lists = [[] for _ in range(nl)]
+    for pid in range(n):                                       # second list only for a third of the vectors
+        lists[int(near[pid, 0])].append(pid)
+        if pid % 3 == 0:
+            lists[int(near[pid, 1])].append(pid)
+    docs = np.asarray([int(x) for x in (rng.permutation(n).astype(np.int64) * 7 + 3)], dtype=object)
+    new_lists, ndocs, nvec, mapping = B.reindex(lists, docs, v)
+    assert [int(x) for x in mapping] == [x & 0xFFFFFFFF for x in oracle.reassigned_ids(lists, n)]
+    assert all(np.all(np.diff(np.asarray(pl, np.int64)) > 0) for pl in new_lists if len(pl) > 1)   # Elias-Fano needs ascending lists
+    assert any(int(ndocs[i]) > int(ndocs[i + 1]) for i in range(n - 1))                              # doc ids not monotone in point ids
+    if pq:
+        cb = H.train_pq_codebook(v[:1500], 8, 5, iters=3)
+        opq = oracle.ProductQuantizer(d, 8, 5, cb)
+        stored, quant, oquant, qd = opq.quantize(nvec), ProductQuantizer(d, 8, 5, cb), oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 5, cb), d // 8
+    else:
+        stored, quant, oquant, qd = nvec, None, oracle.Quant(oracle.QUANT_NONE, oracle.METRIC_L2), d
+    index = F.write_ivf_index(cent, [int(x) for x in ndocs], new_lists, quantized_dimension=qd)
+    vec = F.write_vector_file(stored)
+    full = BlockBasedIvf(ctx, index, vec, quant)
+    o = oracle.BlockBasedIvf(index, vec, oquant)
+    q = (v[rng.integers(0, n, 32)] + rng.normal(0, 3, (32, d))).astype(np.float32)
+    want = o.search(q, k, num_probes=P)
+    got = full.search(q, k, P)
+    assert_result_rows(got, want, len(q))
+    probes = full.find_nearest_centroids(q, P)
+    blocks, sh = [], None
+    for r in range(8):
+        if sh is not None:
+            sh.close()
+        sh = BlockBasedIvf(ctx, index, vec, quant, shard_rank=r, shard_world=8)
+        blocks.append(sh.search_shard(q, k, probes=probes))
+    merged = sh.merge_shards(blocks, len(q), k)
+    sh.close()
+    assert_result_rows(merged, want, len(q))
+    with tempfile.TemporaryDirectory() as tmp:                  # the mapping travels with the segment (reassigned_mappings.<user_id>)
+        hn = F.write_hnsw_index([{0: [1], 1: [0]}], [0, 1], d)
+        cat = F.concat_multi_spann({9: dict(hnsw_index=hn, hnsw_vectors=F.write_vector_file(cent[:2]), ivf_index=index, ivf_vectors=vec)})
+        F.write_segment(os.path.join(tmp, "seg"), cat, d, reassigned={9: mapping})
+        back = F.read_segment(os.path.join(tmp, "seg"))
+        assert np.array_equal(back["reassigned"][9], mapping) and back["ivf_index"] == cat["ivf_index"]
+    full.close()

@@ -522,3 +522,66 @@ def test_golden_index_fixtures(oracle):
         if f:
             assert r.doc_ids(i) == docs[i]
             assert [int(x) for x in np.asarray(r.scores[i, :len(docs[i])], np.float32).view(np.uint32)] == bits[i]
+
+
+# ----------------------------------------------------------------------------------- K15: IvfBuilder::reindex
+# the reference's own known answers: rs/index/src/ivf/builder.rs:1037-1108 (ids_0), 1110-1181 (ids_1), 1183-1266 (ids_2),
+# 1268-1343 (ids_3), 1345-1406 (reindex: vectors [i] and doc ids i + 100 in their new places)
+K15_CASES = [
+    (22, [[11, 12, 13], [0, 2, 4, 6, 8, 20], [9, 18, 20], [14, 15, 16, 18], [1, 3, 5, 7, 18, 20], [10, 15, 21], [10, 15, 17, 19]],
+     {10: 0, 14: 1, 15: 2, 1: 3, 3: 4, 5: 5, 7: 6, 9: 7, 16: 8, 18: 9, 0: 10, 2: 11, 4: 12, 6: 13, 8: 14, 20: 15, 11: 16, 12: 17,
+      13: 18, 21: 19, 17: 20, 19: 21}),
+    (22, [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15], [16, 17, 18, 19], [0, 4, 8, 12, 16], [1, 5, 9, 13, 17],
+          [2, 6, 10, 14, 18], [3, 7, 11, 15, 19]], {i: i for i in range(20)}),
+    (30, [[0, 5, 10, 15, 20, 25], [1, 6, 11, 16, 21, 26], [0, 7, 12, 17, 22, 27], [2, 8, 13, 18, 23, 28], [3, 9, 14, 19, 24, 29],
+          [4, 20, 21, 22, 23, 24], [1, 25, 26, 27, 28, 29]],
+     {0: 0, 1: 1, 4: 2, 5: 3, 10: 4, 15: 5, 20: 6, 6: 7, 11: 8, 16: 9, 21: 10, 7: 11, 12: 12, 17: 13, 22: 14, 2: 15, 8: 16, 13: 17,
+      18: 18, 23: 19, 3: 20, 9: 21, 14: 22, 19: 23, 24: 24, 25: 25, 26: 26, 27: 27, 28: 28, 29: 29}),
+    (30, [[0, 4, 8, 12, 16, 20], [1, 5, 9, 13, 17, 21], [2, 6, 10, 14, 18, 22], [3, 7, 11, 15, 19, 23], [0, 6, 12, 18], [1, 7, 13, 19]],
+     {0: 0, 1: 1, 2: 2, 6: 3, 3: 4, 7: 5, 4: 6, 8: 7, 12: 8, 5: 9, 9: 10, 13: 11, 10: 12, 14: 13, 18: 14, 11: 15, 15: 16, 19: 17,
+      16: 18, 20: 19, 17: 20, 21: 21, 22: 22, 23: 23}),
+]
+
+
+@pytest.mark.parametrize("n,lists,want", K15_CASES)
+def test_k15_reassigned_ids(oracle, n, lists, want):
+    from muopdb_amd import build as B
+    got = oracle.reassigned_ids(lists, n)
+    for old, new in want.items():
+        assert got[old] == new, (old, new, got[old])
+    prod = B.reassigned_ids(lists, n)                                   # the product's host logic, same answers
+    assert [int(x) for x in prod] == list(got)
+
+
+def test_k15_reindex_moves_vectors_and_doc_ids(oracle):
+    from muopdb_amd import build as B
+    n, lists, _ = K15_CASES[0]
+    vec = np.arange(n, dtype=np.float32)[:, None]
+    docs = np.asarray([i + 100 for i in range(n)], dtype=object)
+    want_vec = [10, 14, 15, 1, 3, 5, 7, 9, 16, 18, 0, 2, 4, 6, 8, 20, 11, 12, 13, 21, 17, 19]
+    for impl in (oracle.reindex, B.reindex):
+        new_lists, ndocs, nvec, mapping = impl(lists, docs, vec)
+        assert [float(v[0]) for v in nvec] == [float(x) for x in want_vec]
+        assert [int(d) for d in ndocs] == [x + 100 for x in want_vec]
+        for old_l, new_l in zip(lists, new_lists):                      # a list keeps its members (under their new names), in order
+            assert [int(mapping[o]) for o in old_l] == [int(x) for x in new_l]
+
+
+def test_reassigned_ids_product_equals_oracle_on_random_lists(oracle):
+    """max_clusters_per_vector in {1, 2, 3}, vectors in no list, empty lists: the product's (vectorised) host logic == the restatement."""
+    from muopdb_amd import build as B
+    rng = np.random.default_rng(15)
+    for trial in range(60):
+        n = int(rng.integers(1, 120))
+        nl = int(rng.integers(1, 12))
+        mc = int(rng.integers(1, 4))
+        lists = [[] for _ in range(nl)]
+        for v in range(n):                                              # vectors are added in id order: lists are ascending (:563-575)
+            if rng.random() < 0.1:
+                continue
+            for l in rng.choice(nl, size=min(mc, nl) if rng.random() < 0.4 else 1, replace=False):
+                lists[int(l)].append(v)
+        want = oracle.reassigned_ids(lists, n)
+        assert [int(x) for x in B.reassigned_ids(lists, n)] == want
+        valid = sorted(x for x in want if x >= 0)
+        assert valid == list(range(len(valid)))                          # a permutation of 0 .. n' - 1

@@ -56,6 +56,53 @@ def test_odht_two_entry_table_by_hand():
     assert F.odht_get(t, (2).to_bytes(16, "little")) is None
 
 
+def test_odht_three_entry_collision_chain_by_hand():
+    """users 5, 27 and 28 all hash into start slot 15 of a 16-slot table (0x6337b94f, 0x73c076ff, 0xeb7546ff: & 15 = 15) — one
+    collision chain.  odht's insert (raw_table.rs, RawTableMut::insert -> find_or_insert) scans the 16-byte GROUP that starts at the
+    key's slot — bytes 15, 16, .. 30 of the metadata array, i.e. slot 15 followed by the MIRROR of slots 0 .. 14 — and takes the
+    first control byte with bit 7 set: 15, then 0 (seen through mirror byte 16), then 1.  Control bytes = hash >> 25 = 49, 57, 117;
+    every slot below 16 is written twice (slot and mirror).  Published semantics this pins (the crate itself is absent here:
+    parity unpinned against it — see the module docstring):
+        | what                               | value                                                                        |
+        | empty control byte                 | bit 7 set: lookups take the group's sign mask (`match_empty` = movemask), so  |
+        |                                    | 0x80 and 0xFF both read as empty; an occupied slot holds h2 = top 7 hash bits |
+        | group                              | 16 consecutive control bytes from the key's slot, no alignment, no wrap: the  |
+        |                                    | first 16 bytes are repeated after the last slot                               |
+        | what from_raw_bytes checks         | tag "ODHT", the four size bytes against the Config, format version [0,0,0,2], |
+        |                                    | slot_count a power of two, len == 32 + slots * 128 + slots + 16 — never a     |
+        |                                    | control byte: a table the WRITER below emits is accepted whichever of the two |
+        |                                    | empty encodings the crate itself would have chosen                            |"""
+    recs = [F.pack_user_index_info(u, centroid_vector_offset=u) for u in (5, 27, 28)]
+    for u, h in zip((5, 27, 28), (0x6337B94F, 0x73C076FF, 0xEB7546FF)):
+        assert F.fx_hash32(u.to_bytes(16, "little")) == h and h & 15 == 15
+    t = F.user_index_info_table(b"".join(recs))
+    assert len(t) == 32 + 16 * 128 + 32 and struct.unpack_from("<QQ", t, 8) == (3, 16)
+    entries, meta = t[32:32 + 16 * 128], t[32 + 16 * 128:]
+    for slot, u, rec in ((15, 5, recs[0]), (0, 27, recs[1]), (1, 28, recs[2])):
+        assert entries[slot * 128:slot * 128 + 16] == u.to_bytes(16, "little") and entries[slot * 128 + 16:(slot + 1) * 128] == rec
+    want = [0xFF] * 32
+    want[15] = want[31] = 0x6337B94F >> 25
+    want[0] = want[16] = 0x73C076FF >> 25
+    want[1] = want[17] = 0xEB7546FF >> 25
+    assert list(meta) == want and (want[15], want[0], want[1]) == (49, 57, 117)
+    for u, rec in zip((5, 27, 28), recs):                                     # the chain is walked on lookup
+        assert F.odht_get(t, u.to_bytes(16, "little")) == rec
+    assert F.odht_get(t, (53).to_bytes(16, "little")) is None                 # same start slot, not present: stops at the first empty
+    # a writer that fills with 0x80 instead (the other encoding a bit-7 reader accepts) reads the same — here and in the library
+    t80 = bytearray(t)
+    for i, b in enumerate(meta):
+        if b == 0xFF:
+            t80[32 + 16 * 128 + i] = 0x80
+    assert F.user_table_from_odht(bytes(t80)) == F.user_table_from_odht(t)
+    lib = L.load()
+    for raw in (t, bytes(t80)):
+        buf = np.frombuffer(raw, np.uint8)
+        cnt = C.c_size_t()
+        out = np.zeros(3 * 112, np.uint8)
+        assert lib.mdb_odht_user_table(L.ptr(buf, C.c_uint8), C.c_size_t(buf.size), L.ptr(out, C.c_uint8), C.c_size_t(3), C.byref(cnt)) == 0
+        assert cnt.value == 3 and out.tobytes() == F.user_table_from_odht(t)
+
+
 def test_odht_probing_wrap_and_round_trip_and_native_reader():
     rng = np.random.default_rng(4)
     for n in (1, 3, 14, 15, 33, 200, 1024):
@@ -118,7 +165,8 @@ def test_write_segment_tree_and_read_back(tmp_path):
                         ivf_raw_vectors=F.write_vector_file(v))
     cat = F.concat_multi_spann(users)
     seg = str(tmp_path / "segment")
-    F.write_segment(seg, cat, 4)
+    mapping = {3: np.asarray([2, 0, 1] + list(range(3, 20)), np.uint32), (1 << 90) + 2: np.arange(20, dtype=np.uint32)[::-1]}
+    F.write_segment(seg, cat, 4, reassigned=mapping)
     for rel in ("user_index_info", "centroids/quantizer/no_op_quantizer_config.yaml", "centroids/hnsw/index", "centroids/hnsw/vector_storage",
                 "ivf/quantizer/no_op_quantizer_config.yaml", "ivf/index", "ivf/vectors", "ivf/raw_vectors"):
         assert os.path.isfile(os.path.join(seg, rel)), rel
@@ -127,6 +175,11 @@ def test_write_segment_tree_and_read_back(tmp_path):
     assert back["user_table"] == cat["user_table"] and back["num_features"] == 4 and back["pq"] is None
     for kf in ("hnsw_index", "hnsw_vectors", "ivf_index", "ivf_vectors"):
         assert back[kf] == cat[kf]
+    # reassigned_mappings.<user_id>: 4 LE bytes per vector at the segment's top level (ivf/writer.rs:52-66, multi_spann/writer.rs:264-273)
+    assert open(os.path.join(seg, "reassigned_mappings.3"), "rb").read()[:12] == struct.pack("<III", 2, 0, 1)
+    assert sorted(back["reassigned"]) == sorted(mapping)
+    for u, m in mapping.items():
+        assert np.array_equal(back["reassigned"][u], m)
     # PQ variant: product_quantizer_config.yaml + codebook instead of the no-op config
     cat["codebook"] = np.arange(2 * 4 * 2, dtype=np.float32).tobytes()
     seg2 = str(tmp_path / "segment_pq")
