@@ -372,7 +372,7 @@ def finish(out, disp, step_bytes):
 
 
 # ------------------------------------------------------------------------------------------ HNSW (headline)
-def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=None):
+def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=None, ef=None):
     """BASELINE config C2.  batch 64 = the headline; batch 1 = the metric's other batch size (same resident graph);
     graph "insert" = the same workload on a graph built by HnswBuilder::insert's algorithm (what MuopDB itself would write)."""
     from muopdb_amd import build as B, synth as S
@@ -382,7 +382,7 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
     d = args.dim or 128
     batch = batch or args.batch or 64
     graph = graph or args.graph
-    k, ef = args.k, args.ef
+    k, ef = args.k, ef or args.ef
     steps, warm = steps or args.steps, warm if warm is not None else args.warmup
     t0 = time.time()
     nq = (steps + warm) * batch
@@ -1148,6 +1148,8 @@ def main():
         extra = {}
         # the metric's other batch size over the same resident graph (one sequential chain on one CU: latency, not throughput)
         plan = [("hnsw_c2_b1", lambda: run_hnsw(env, batch=1, graph="knn", extras=False, steps=max(args.steps, 200), warm=max(args.warmup, 20))),
+                # ef above 256 leaves the register beam: hnsw_search_kernel (sorted LDS sets), the same resident graph
+                ("hnsw_c2_ef400", lambda: run_hnsw(env, batch=64, graph="knn", extras=False, ef=400)),
                 ("flat_1m_b1", lambda: run_flat(env, n=1_000_000, batch=1)), ("flat_1m_b64", lambda: run_flat(env, n=1_000_000, batch=64)),
                 ("ivfpq_c3", lambda: run_ivfpq(env)), ("spann_c4_128u", lambda: run_spann(env, users=128))]
         if world > 1:   # the list-sharded configurations at full size over this job's ranks (C4: 1024 users; C5: 100M codes)

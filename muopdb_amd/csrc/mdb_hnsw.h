@@ -40,9 +40,17 @@ struct HnswUpper {
     DevBuf<uint32_t> rows, ids;
     TileStore tiles;
     DevBuf<float> rows_nat;   // the same vectors row-major [nu + 64][d] (d a multiple of 16, at most 128): hnsw_upper_table64_kernel's operand
+    // the TOP set (graphs of >= 3 layers): the points that occur on a layer >= 2, renumbered 0 .. nu2-1 the same way — what the split
+    // path's first launch traverses while the table of all upper points is still being computed (hnsw_upper_top_kernel)
+    uint32_t nu2 = 0, entry_c2 = 0;
+    DevBuf<uint32_t> rows2;   // [(layer-2) * nu2 + c2] * su, neighbours in TOP indices
+    DevBuf<uint32_t> map21;   // TOP index -> compact index
+    TileStore tiles2;
     void view_of(const HnswUpper& s) {
         nu = s.nu; su = s.su; layers = s.layers; small_layer = s.small_layer; entry_c = s.entry_c;
         rows.borrow(s.rows); ids.borrow(s.ids); rows_nat.borrow(s.rows_nat);
+        nu2 = s.nu2; entry_c2 = s.entry_c2; rows2.borrow(s.rows2); map21.borrow(s.map21);
+        tiles2.data.borrow(s.tiles2.data); tiles2.n = s.tiles2.n; tiles2.ntiles = s.tiles2.ntiles; tiles2.d = s.tiles2.d; tiles2.d4 = s.tiles2.d4;
         tiles.data.borrow(s.tiles.data); tiles.n = s.tiles.n; tiles.ntiles = s.tiles.ntiles; tiles.d = s.tiles.d; tiles.d4 = s.tiles.d4;
     }
 };
@@ -59,6 +67,11 @@ mdb_status hnsw_upper_table(mdb_ctx* ctx, const HnswUpper& up, int metric, const
                             uint32_t* d_table, unsigned long long* zero16 = nullptr);
 // layers num_layers-1 .. 1 of ann_search on the table; fills `out`, adds the layers' evaluations / expansions to ctx->d_counters
 mdb_status hnsw_upper_traverse(mdb_ctx* ctx, const HnswUpper& up, const uint32_t* d_table, size_t b, uint32_t ef, const HnswUpperOut& out);
+// table + traversal in the shape that suits the batch: hnsw_upper_table then hnsw_upper_traverse, or — batches of >= 32 queries over a
+// graph of >= 3 layers — the split path (mdb_hnsw_upper.hip: top layers and the table pass in one launch, then layer 1).
+// d_table: b * nu_pad words; d_state: (b * (words + 8) + 64) words of scratch for the hand-over between the two launches.
+mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const DistPlan& p, const float* d_q, int qstride, size_t b,
+                          uint32_t ef, uint32_t* d_table, uint32_t* d_state, const HnswUpperOut& out, unsigned long long* zero16);
 
 // device-resident calls: where the layer-0 kernel may write the caller's (doc id, score) rows itself; done = it did
 struct HnswRemapOut {

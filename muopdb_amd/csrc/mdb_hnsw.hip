@@ -1519,8 +1519,8 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
     }
     total_rows = row_src.size();
     // ---- the table path's compact upper layers (mdb_hnsw_upper.hip): one graph, >= 2 layers, f32 rows, rows of <= 64 edges
-    std::vector<uint32_t> h_cids, h_crows;
-    std::vector<float> h_cvecs;
+    std::vector<uint32_t> h_cids, h_crows, h_crows2, h_map21;
+    std::vector<float> h_cvecs, h_cvecs2;
     upper.nu = 0;
     if (U == 1 && kind != MDB_QUANT_PQ && !ctx->opt.hnsw_no_table && h_users[0].num_layers >= 2 && h_users[0].SU <= 64 &&
         h_users[0].n > 0) {
@@ -1568,6 +1568,38 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
             upper.layers = nl - 1;
             upper.small_layer = u.small_layer;
             upper.entry_c = cidx[u.entry_point];
+            // the TOP set: points on a layer >= 2 and the targets of those layers' edges
+            upper.nu2 = 0;
+            if (nl >= 3) {
+                std::vector<uint8_t> in2(nu, 0);
+                for (size_t c = 0; c < nu; ++c) {
+                    const uint32_t lv = h_level[u.upper_off + h_cids[c]];
+                    if (lv >= 2) in2[c] = 1;
+                    for (uint32_t layer = 2; layer <= lv && layer < nl; ++layer)
+                        for (uint32_t t = 0; t < SU; ++t) {
+                            const uint32_t e = h_crows[((size_t)(layer - 1) * nu + c) * SU + t];
+                            if (e != 0xFFFFFFFFu) in2[e] = 1;
+                        }
+                }
+                std::vector<uint32_t> c2of(nu, 0xFFFFFFFFu);
+                for (size_t c = 0; c < nu; ++c)
+                    if (in2[c]) { c2of[c] = (uint32_t)h_map21.size(); h_map21.push_back((uint32_t)c); }
+                const size_t nu2 = h_map21.size();
+                if (nu2 > 0 && nu2 <= 16384 && in2[upper.entry_c]) {
+                    h_crows2.assign((size_t)(nl - 2) * nu2 * SU, 0xFFFFFFFFu);
+                    for (size_t c2 = 0; c2 < nu2; ++c2)
+                        for (uint32_t layer = 2; layer < nl; ++layer)
+                            for (uint32_t t = 0; t < SU; ++t) {
+                                const uint32_t e = h_crows[((size_t)(layer - 1) * nu + h_map21[c2]) * SU + t];
+                                h_crows2[((size_t)(layer - 2) * nu2 + c2) * SU + t] = e == 0xFFFFFFFFu ? e : c2of[e];
+                            }
+                    h_cvecs2.resize(nu2 * (size_t)dim);
+                    for (size_t c2 = 0; c2 < nu2; ++c2)
+                        memcpy(&h_cvecs2[c2 * (size_t)dim], &h_cvecs[(size_t)h_map21[c2] * dim], (size_t)dim * 4);
+                    upper.nu2 = (uint32_t)nu2;
+                    upper.entry_c2 = c2of[upper.entry_c];
+                }
+            }
         }
     }
     // ---- uploads
@@ -1606,6 +1638,17 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
             if (upper.rows_nat.alloc(((size_t)upper.nu + 64) * dim) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "HNSW upper-layer rows");
             MDB_HIP(ctx, hipMemsetAsync(upper.rows_nat.p, 0, ((size_t)upper.nu + 64) * dim * 4, ctx->stream));
             MDB_HIP(ctx, hipMemcpyAsync(upper.rows_nat.p, d_cvecs.p, (size_t)upper.nu * dim * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        if (upper.nu2) {
+            DevBuf<float> d_cvecs2;
+            if (upper.rows2.alloc(h_crows2.size() + 1) != hipSuccess || upper.map21.alloc(h_map21.size() + 1) != hipSuccess ||
+                d_cvecs2.alloc(h_cvecs2.size() + 4) != hipSuccess)
+                return mdb_fail(ctx, MDB_ERR_OOM, "HNSW top-layer structures");
+            MDB_HIP(ctx, hipMemcpyAsync(upper.rows2.p, h_crows2.data(), h_crows2.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            MDB_HIP(ctx, hipMemcpyAsync(upper.map21.p, h_map21.data(), h_map21.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            MDB_HIP(ctx, hipMemcpyAsync(d_cvecs2.p, h_cvecs2.data(), h_cvecs2.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            MDB_TRY(tiles_from_rows(ctx, d_cvecs2.p, upper.nu2, (int)dim, upper.tiles2));
+            MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // d_cvecs and the host vectors are released below
     }
@@ -1752,15 +1795,17 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         void *tab, *st;
         MDB_TRY(mdb_scratch(ctx, 8, (size_t)b * nu_pad * 4 + 64, &tab));
         MDB_TRY(mdb_scratch(ctx, 9, (size_t)b * (words + 2) * 4 + 64, &st));
+        void* st2;
+        MDB_TRY(mdb_scratch(ctx, 10, ((size_t)b * (words + 8) + 64) * 4, &st2));
         HnswUpperOut uo;
         uo.ep = (uint32_t*)st;
         uo.ovf = uo.ep + b;
         uo.vis = uo.ovf + b;
         uo.words = words;
         // (the table kernel clears the context's traversal counters on its way: no memset launch in front of the step)
-        MDB_TRY(hnsw_upper_table(ctx, upper, metric, a.p, d_q, qstride, b, (uint32_t*)tab, zero_counters ? ctx->d_counters : nullptr));
+        MDB_TRY(hnsw_upper_run(ctx, upper, metric, a.p, d_q, qstride, b, ef, (uint32_t*)tab, (uint32_t*)st2, uo,
+                               zero_counters ? ctx->d_counters : nullptr));
         zero_counters = false;
-        MDB_TRY(hnsw_upper_traverse(ctx, upper, (const uint32_t*)tab, b, ef, uo));
         a.up_ep = uo.ep; a.up_ovf = uo.ovf; a.up_vis = uo.vis; a.up_ids = upper.ids.p; a.up_words = words;
         if (fuse && fuse->doc && k > 0) {
             a.rm_index = d_index.p; a.rm_doc = fuse->doc; a.rm_score = fuse->score; a.rm_counts = fuse->counts;

@@ -147,15 +147,14 @@ struct T64Point<METRIC, N16, N16> {
 };
 
 #define T64_PPW 16   // points per wave
+// (a block of 256 threads; bx = its slice of the points, by = its group of 64 queries)
 template <int METRIC, int N16>
-__global__ __launch_bounds__(256, 2) void hnsw_upper_table64_kernel(const float* __restrict__ rows, uint32_t nu, const float* __restrict__ q,
-                                                                 int qstride, uint32_t b, uint32_t* __restrict__ table, uint32_t nu_pad,
-                                                                 unsigned long long* zero16) {
+__device__ __forceinline__ void table64_block(const float* __restrict__ rows, uint32_t nu, const float* __restrict__ q, int qstride, uint32_t b,
+                                              uint32_t* __restrict__ table, uint32_t nu_pad, const uint32_t bx, const uint32_t by) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (zero16 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0ull;
-    const uint32_t p0 = (blockIdx.x * 4 + wave) * T64_PPW;
+    const uint32_t p0 = (bx * 4 + wave) * T64_PPW;
     if (p0 >= nu) return;
-    const uint32_t qi = blockIdx.y * 64 + lane;
+    const uint32_t qi = by * 64 + lane;
     const bool qok = qi < b;
     const float4* q4 = (const float4*)(q + (size_t)(qok ? qi : b - 1) * qstride);   // rows are 16-byte aligned (stage_queries)
     float qr[16 * N16];
@@ -198,6 +197,14 @@ __global__ __launch_bounds__(256, 2) void hnsw_upper_table64_kernel(const float*
             *(uint4*)(trow + (i - 2)) = o;
         }
     }
+}
+
+template <int METRIC, int N16>
+__global__ __launch_bounds__(256, 2) void hnsw_upper_table64_kernel(const float* __restrict__ rows, uint32_t nu, const float* __restrict__ q,
+                                                                 int qstride, uint32_t b, uint32_t* __restrict__ table, uint32_t nu_pad,
+                                                                 unsigned long long* zero16) {
+    if (zero16 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0ull;
+    table64_block<METRIC, N16>(rows, nu, q, qstride, b, table, nu_pad, blockIdx.x, blockIdx.y);
 }
 
 mdb_status hnsw_upper_table(mdb_ctx* ctx, const HnswUpper& up, int metric, const DistPlan& p, const float* d_q, int qstride, size_t b,
@@ -268,17 +275,35 @@ mdb_status hnsw_upper_table(mdb_ctx* ctx, const HnswUpper& up, int metric, const
 
 // ------------------------------------------------------------------------------------------ traversal
 struct HnswUpArgs {
-    const uint32_t* rows;     // [(layer-1) * nu + c] * su
-    const uint32_t* ids;      // compact index -> point id
-    const uint32_t* table;    // [b][nu_pad] distance images
-    uint32_t nu, nu_pad, su, layers, small_layer, entry_c;
+    const uint32_t* rows;     // [(layer - row_layer0) * nu + c] * su: adjacency rows of layers row_layer0 .. in this launch's compact numbering
+    const uint32_t* table;    // [b][nu_pad] distance images (the top phase of the split path computes its row itself)
+    uint32_t nu, nu_pad, su, small_layer, entry_c;
+    int row_layer0;
+    int layer_hi, layer_lo;   // this launch traverses layers layer_hi .. layer_lo (>= 1)
     int ef;
     uint32_t vis_words;
+    // state handed over by the launch that traversed the layers above (nullptr: start at entry_c with an empty visited set)
+    const uint32_t* in_ep;    // [b] entry point, this launch's numbering
+    const uint32_t* in_ovf;   // [b]
+    const uint32_t* in_vis;   // [b][vis_words]
+    const uint32_t* in_cnt;   // [b][4] evaluations, expansions, NaN seen
+    // state handed on
+    const uint32_t* ep_map;   // index -> what out_ep holds: the point id (layer 0 follows) or the next launch's compact index
+    const uint32_t* vis_map;  // nullptr: out_vis = the bitmap as is; else bit c of it -> bit vis_map[c] of a bitmap of out_words words
+    uint32_t out_words;
     uint32_t* out_ep;
     uint32_t* out_ovf;
     uint32_t* out_vis;
+    uint32_t* out_cnt;        // non-null: the counters go here ([b][4]) instead of the context's (a later launch adds them: a beam that
+                              // overflows further down re-runs the WHOLE query, and nothing of it may have been counted)
     uint32_t* flags;
     unsigned long long* counters;
+    // top phase of the split path: the block evaluates its query against this compact set itself (tiles, d = 16 n16)
+    const float4* self_tiles;
+    uint32_t self_ntiles;
+    int n16;
+    const float* q;
+    int qstride;
 };
 
 #ifdef MDB_PIPE_DBG   // -DMDB_PIPE_DBG + MDB_HNSW_DBG=1: cycle / event sums into counters[4..15] (the traversal kernels print the same words)
@@ -300,25 +325,13 @@ struct HnswUpArgs {
 // (the L2s are not coherent: the row comes back from the Infinity Cache / HBM, ~1 k cycles, 40 % of the lookups).  Waves 1-3 only
 // help with that copy.
 #define UP_BLOCK 256
-template <bool TLDS>
-__global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+// wave 0 of the block (64 lanes): layers a.layer_hi .. a.layer_lo on the table row `tq`, visited set `vis` (LDS, initialised by the
+// caller), then the hand-over.  `vis_out`: LDS scratch of a.out_words words when a.vis_map is set.
+__device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const int qi, const int lane, char* lds, const uint32_t* tq,
+                                                     uint32_t* vis, uint32_t* vis_out) {
     uint64_t* const C = (uint64_t*)(lds + UP_LDS_STAGE);
     uint32_t* const stage_flag = (uint32_t*)(lds + UP_LDS_FLAG);
     uint32_t* const fr = (uint32_t*)(lds + UP_LDS_FR);
-    uint32_t* const vis = (uint32_t*)(lds + UP_LDS_VIS);
-    const int qi = blockIdx.x, lane = threadIdx.x & 63;
-    const uint32_t* const tg = a.table + (size_t)qi * a.nu_pad;
-    uint32_t* const tl = vis + a.vis_words;   // TLDS: the row's copy (vis_words is a multiple of 4: 16-byte aligned; nu_pad is a multiple of 64)
-    for (uint32_t i = threadIdx.x; i < a.vis_words; i += UP_BLOCK) vis[i] = 0;
-    if (TLDS) {
-        const uint4* src = (const uint4*)tg;
-        uint4* dst = (uint4*)tl;
-        for (uint32_t i = threadIdx.x; i < a.nu_pad / 4; i += UP_BLOCK) dst[i] = src[i];
-    }
-    __syncthreads();
-    if (threadIdx.x >= 64) return;
-    const uint32_t* const tq = TLDS ? tl : tg;
     const int ef = a.ef;
     const uint32_t su = a.su;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -327,19 +340,20 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
     uint32_t fbound = SLOT_EMPTY;
     uint32_t rowv = 0xFFFFFFFFu, rowr = 0xFFFFFFFFu;
     uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
-    bool ru_valid = false, stop = false, overflow = false, nan_lane = false;
+    bool ru_valid = false, stop = false, overflow = a.in_ovf ? a.in_ovf[qi] != 0u : false, nan_lane = false;
     int ru_closer = 0;
     // expanded slots of B.  Every unexpanded slot is at least as far as the candidate about to be popped, so the stop count
     // #{b : d_b < d_candidate} is at most nexp: no count is taken while nexp < ef (a layer stops after >= ef expansions or not at all)
     int nexp = 0;
-    uint32_t evals = 0, expanded = 0;
-    uint32_t ep = a.entry_c;
+    uint32_t evals = a.in_cnt ? a.in_cnt[4 * qi + 0] : 0u, expanded = a.in_cnt ? a.in_cnt[4 * qi + 1] : 0u;
+    if (a.in_cnt && a.in_cnt[4 * qi + 2]) nan_lane = true;
+    uint32_t ep = a.in_ep ? a.in_ep[qi] : a.entry_c;
 #ifdef MDB_PIPE_DBG
     unsigned long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
-    for (int layer = (int)a.layers; layer >= 1 && !overflow; --layer) {
-        const uint32_t* const lrows = a.rows + (size_t)(layer - 1) * a.nu * su;
+    for (int layer = a.layer_hi; layer >= a.layer_lo && !overflow; --layer) {
+        const uint32_t* const lrows = a.rows + (size_t)(layer - a.row_layer0) * a.nu * su;
         auto load_row = [&](uint32_t node) -> uint32_t { return (uint32_t)lane < su ? lrows[(size_t)node * su + lane] : 0xFFFFFFFFu; };
         if ((uint32_t)layer >= a.small_layer && ef >= 64) {
             // ---- a layer with no more points than ef (<= 64, edges only among them): its result is the closure of the entry
@@ -595,32 +609,125 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
             ep = wave_min_u32(im);
         }
     }
-    for (uint32_t i = lane; i < a.vis_words; i += 64) a.out_vis[(size_t)qi * a.vis_words + i] = vis[i];
     const bool nan_seen = __ballot(nan_lane) != 0;
+    // the hand-over fields are re-read from the kernarg segment (HnswUpArgs is the first kernel argument of both kernels) behind an opaque
+    // barrier: kept in `a` they stay live — as spilled scalars, reloaded by v_readlane — through the whole traversal loop
+    const HnswUpArgs* ap = (const HnswUpArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    const HnswUpArgs& e = *ap;
+    if (e.vis_map) {
+        // the next launch numbers the points differently (a superset): bit c -> bit vis_map[c]
+        for (uint32_t i = lane; i < e.out_words; i += 64) vis_out[i] = 0;
+        for (uint32_t w = lane; w < e.vis_words; w += 64) {
+            uint32_t bits = vis[w];
+            while (bits) {
+                const uint32_t c = 32u * w + (uint32_t)__ffs((int)bits) - 1u;
+                bits &= bits - 1u;
+                const uint32_t t = e.vis_map[c];
+                atomicOr(&vis_out[t >> 5], 1u << (t & 31));
+            }
+        }
+        for (uint32_t i = lane; i < e.out_words; i += 64) e.out_vis[(size_t)qi * e.out_words + i] = vis_out[i];
+    } else {
+        for (uint32_t i = lane; i < e.vis_words; i += 64) e.out_vis[(size_t)qi * e.vis_words + i] = vis[i];
+    }
 #ifdef MDB_PIPE_DBG
     if (lane == 0)
         for (int i = 0; i < 12; ++i)
-            if (dbg_acc[i]) atomicAdd(&a.counters[4 + i], dbg_acc[i]);
+            if (dbg_acc[i]) atomicAdd(&e.counters[4 + i], dbg_acc[i]);
 #endif
     if (lane == 0) {
-        a.out_ep[qi] = overflow ? 0u : a.ids[ep];
-        a.out_ovf[qi] = overflow ? 1u : 0u;
-        if (!overflow) {
-            atomicAdd(&a.counters[0], (unsigned long long)evals);
-            atomicAdd(&a.counters[1], (unsigned long long)expanded);
-            if (nan_seen) atomicOr(a.flags, MDB_FLAG_NAN);
+        e.out_ep[qi] = overflow ? 0u : e.ep_map[ep];
+        e.out_ovf[qi] = overflow ? 1u : 0u;
+        if (e.out_cnt) {
+            e.out_cnt[4 * qi + 0] = evals; e.out_cnt[4 * qi + 1] = expanded; e.out_cnt[4 * qi + 2] = nan_seen ? 1u : 0u;
+        } else if (!overflow) {
+            atomicAdd(&e.counters[0], (unsigned long long)evals);
+            atomicAdd(&e.counters[1], (unsigned long long)expanded);
+            if (nan_seen) atomicOr(e.flags, MDB_FLAG_NAN);
         }
     }
 }
 
-mdb_status hnsw_upper_traverse(mdb_ctx* ctx, const HnswUpper& up, const uint32_t* d_table, size_t b, uint32_t ef, const HnswUpperOut& out) {
+// TLDS: the query's table row (nu_pad words, 129 KB at 1 M points / 32 k upper points) is copied into LDS by the whole block first —
+// a lookup is then an LDS read (~100 cycles) instead of a first-touch miss of a line the table kernel wrote from another XCD
+// (the L2s are not coherent: the row comes back from the Infinity Cache / HBM, ~1 k cycles, 40 % of the lookups).  Waves 1-3 only
+// help with that copy.
+template <bool TLDS>
+__global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint32_t* const vis = (uint32_t*)(lds + UP_LDS_VIS);
+    const int qi = blockIdx.x, lane = threadIdx.x & 63;
+    const uint32_t* const tg = a.table + (size_t)qi * a.nu_pad;
+    uint32_t* const tl = vis + a.vis_words;   // TLDS: the row's copy (vis_words is a multiple of 4: 16-byte aligned; nu_pad is a multiple of 64)
+    for (uint32_t i = threadIdx.x; i < a.vis_words; i += UP_BLOCK) vis[i] = a.in_vis ? a.in_vis[(size_t)qi * a.vis_words + i] : 0u;
+    if (TLDS) {
+        const uint4* src = (const uint4*)tg;
+        uint4* dst = (uint4*)tl;
+        for (uint32_t i = threadIdx.x; i < a.nu_pad / 4; i += UP_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    upper_traverse_wave0(a, qi, lane, lds, TLDS ? tl : tg, vis, tl + (TLDS ? a.nu_pad : 0));
+}
+
+// The split path (batches of >= 32 queries, d = 16 n16 <= 128): ONE launch whose first b blocks traverse the layers >= 2 — ~1 k points:
+// each block evaluates its query against them itself (the thread = point arithmetic of hnsw_upper_table16_kernel, the row goes
+// straight into LDS) — while the remaining blocks are the lane = query table pass over ALL upper points (hnsw_upper_table64_kernel's
+// body) that layer 1 needs: the 35 us of that pass run on the 192 CUs the 64 traversals leave idle instead of in front of them.
+// The layer-1 launch (hnsw_upper_kernel) picks the state up: entry point and visited set in ITS numbering, counters not yet counted.
+template <int METRIC, int N16>
+__global__ __launch_bounds__(256, 2) void hnsw_upper_top_kernel(HnswUpArgs a, uint32_t nq, const float* __restrict__ rows_nat, uint32_t nu_all,
+                                                                uint32_t* __restrict__ table_all, uint32_t nu_all_pad, uint32_t tgx,
+                                                                unsigned long long* zero16) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (blockIdx.x >= nq) {
+        const uint32_t t = blockIdx.x - nq;
+        table64_block<METRIC, N16>(rows_nat, nu_all, a.q, a.qstride, nq, table_all, nu_all_pad, t % tgx, t / tgx);
+        return;
+    }
+    if (zero16 && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0ull;
+    uint32_t* const vis = (uint32_t*)(lds + UP_LDS_VIS);
+    const int qi = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* const tl = vis + a.vis_words;
+    for (uint32_t i = threadIdx.x; i < a.vis_words; i += UP_BLOCK) vis[i] = 0u;
+    // the block's own table row: one wave per tile of 64 points, thread = point (exact association, DPP-broadcast query chunks)
+    const float* const ql = a.q + (size_t)qi * a.qstride + (lane & 15);
+    for (uint32_t tile = wave; tile < a.self_ntiles; tile += UP_BLOCK / 64) {
+        const float4* tp = a.self_tiles + (size_t)tile * (4 * N16) * MDB_TILE + lane;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < N16; ++c) {
+            float4 x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = tp[(size_t)(4 * c + t) * MDB_TILE];
+            const float xv[16] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w,
+                                  x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
+            t16_accumulate<METRIC>(acc, ql[16 * c], xv);
+        }
+        const uint32_t v = tile * MDB_TILE + lane;
+        tl[v] = v < a.nu ? f32_orderable(finish_distance<METRIC>(__fadd_rn(0.0f, reduce_ordered<16>(acc)))) : SLOT_EMPTY;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    upper_traverse_wave0(a, qi, lane, lds, tl, vis, tl + a.nu_pad);
+}
+
+// launch of hnsw_upper_kernel over layers layer_hi .. 1 (the last launch before layer 0: out_ep holds point ids, the bitmap as is)
+static mdb_status upper_launch_bottom(mdb_ctx* ctx, const HnswUpper& up, const uint32_t* d_table, size_t b, uint32_t ef, const HnswUpperOut& out,
+                                      int layer_hi, const uint32_t* in_ep, const uint32_t* in_ovf, const uint32_t* in_vis, const uint32_t* in_cnt) {
     HnswUpArgs a{};
-    a.rows = up.rows.p; a.ids = up.ids.p; a.table = d_table;
-    a.nu = up.nu; a.nu_pad = (uint32_t)up.tiles.ntiles * MDB_TILE; a.su = up.su; a.layers = up.layers; a.small_layer = up.small_layer;
+    a.rows = up.rows.p; a.table = d_table; a.row_layer0 = 1;
+    a.nu = up.nu; a.nu_pad = (uint32_t)up.tiles.ntiles * MDB_TILE; a.su = up.su; a.small_layer = up.small_layer;
     a.entry_c = up.entry_c;
+    a.layer_hi = layer_hi; a.layer_lo = 1;
     a.ef = (int)ef;
     a.vis_words = out.words;
-    a.out_ep = out.ep; a.out_ovf = out.ovf; a.out_vis = out.vis;
+    a.in_ep = in_ep; a.in_ovf = in_ovf; a.in_vis = in_vis; a.in_cnt = in_cnt;
+    a.ep_map = up.ids.p; a.vis_map = nullptr; a.out_words = out.words;
+    a.out_ep = out.ep; a.out_ovf = out.ovf; a.out_vis = out.vis; a.out_cnt = nullptr;
     a.flags = ctx->d_flags; a.counters = ctx->d_counters;
     const size_t lds_base = UP_LDS_VIS + (size_t)out.words * 4;
     const bool tlds = lds_base + (size_t)a.nu_pad * 4 <= 160 * 1024 - 512 && !ctx->opt.hnsw_table_no_lds;
@@ -636,4 +743,65 @@ mdb_status hnsw_upper_traverse(mdb_ctx* ctx, const HnswUpper& up, const uint32_t
     }
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
+}
+
+mdb_status hnsw_upper_traverse(mdb_ctx* ctx, const HnswUpper& up, const uint32_t* d_table, size_t b, uint32_t ef, const HnswUpperOut& out) {
+    return upper_launch_bottom(ctx, up, d_table, b, ef, out, (int)up.layers, nullptr, nullptr, nullptr, nullptr);
+}
+
+mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const DistPlan& p, const float* d_q, int qstride, size_t b,
+                          uint32_t ef, uint32_t* d_table, uint32_t* d_state, const HnswUpperOut& out, unsigned long long* zero16) {
+    const uint32_t nu_pad = (uint32_t)up.tiles.ntiles * MDB_TILE;
+    const uint32_t nu2_pad = (uint32_t)up.tiles2.ntiles * MDB_TILE;
+    const uint32_t words2 = (up.nu2 / 32 + 4) & ~3u;
+    const size_t lds_top = UP_LDS_VIS + (size_t)words2 * 4 + (size_t)nu2_pad * 4 + (size_t)out.words * 4;
+    const bool split = up.nu2 > 0 && up.layers >= 2 && up.rows_nat.p && p.n16 > 0 && p.n16 <= 8 && p.n8 == 0 && p.n4 == 0 && p.ntail == 0 &&
+                       (long long)b >= ctx->opt.hnsw_table64_min_b && !ctx->opt.hnsw_no_split && lds_top <= 160 * 1024 - 512;
+    if (!split) {
+        MDB_TRY(hnsw_upper_table(ctx, up, metric, p, d_q, qstride, b, d_table, zero16));
+        return hnsw_upper_traverse(ctx, up, d_table, b, ef, out);
+    }
+    // hand-over between the two launches: entry point and visited set in the layer-1 numbering, overflow flag, counters
+    uint32_t* const st_ep = d_state;
+    uint32_t* const st_ovf = st_ep + b;
+    uint32_t* const st_cnt = st_ovf + b;
+    uint32_t* const st_vis = st_cnt + 4 * b;
+    HnswUpArgs a{};
+    a.rows = up.rows2.p; a.table = nullptr; a.row_layer0 = 2;
+    a.nu = up.nu2; a.nu_pad = nu2_pad; a.su = up.su; a.small_layer = up.small_layer; a.entry_c = up.entry_c2;
+    a.layer_hi = (int)up.layers; a.layer_lo = 2;
+    a.ef = (int)ef;
+    a.vis_words = words2;
+    a.ep_map = up.map21.p; a.vis_map = up.map21.p; a.out_words = out.words;
+    a.out_ep = st_ep; a.out_ovf = st_ovf; a.out_vis = st_vis; a.out_cnt = st_cnt;
+    a.flags = ctx->d_flags; a.counters = ctx->d_counters;
+    a.self_tiles = (const float4*)up.tiles2.data.p; a.self_ntiles = (uint32_t)up.tiles2.ntiles; a.n16 = p.n16; a.q = d_q; a.qstride = qstride;
+    const unsigned tgx = (unsigned)((up.nu + 4 * T64_PPW - 1) / (4 * T64_PPW)), tgy = (unsigned)((b + 63) / 64);
+    const unsigned grid = (unsigned)b + tgx * tgy;
+#define MDB_TOP_GO(METRIC, N)                                                                                                          \
+    do {                                                                                                                               \
+        if (lds_top > 48 * 1024)                                                                                                       \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_top_kernel<METRIC, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                             (int)lds_top));                                                                           \
+        hnsw_upper_top_kernel<METRIC, N><<<dim3(grid), 256, lds_top, ctx->stream>>>(a, (uint32_t)b, up.rows_nat.p, up.nu, d_table, nu_pad, \
+                                                                                    tgx, zero16);                                     \
+    } while (0)
+#define MDB_TOP_LAUNCH(METRIC)                           \
+    do {                                                 \
+        switch (p.n16) {                                 \
+            case 1: MDB_TOP_GO(METRIC, 1); break;        \
+            case 2: MDB_TOP_GO(METRIC, 2); break;        \
+            case 3: MDB_TOP_GO(METRIC, 3); break;        \
+            case 4: MDB_TOP_GO(METRIC, 4); break;        \
+            case 5: MDB_TOP_GO(METRIC, 5); break;        \
+            case 6: MDB_TOP_GO(METRIC, 6); break;        \
+            case 7: MDB_TOP_GO(METRIC, 7); break;        \
+            default: MDB_TOP_GO(METRIC, 8); break;       \
+        }                                                \
+    } while (0)
+    if (metric == MDB_METRIC_L2) MDB_TOP_LAUNCH(MDB_METRIC_L2); else MDB_TOP_LAUNCH(MDB_METRIC_DOT);
+#undef MDB_TOP_LAUNCH
+#undef MDB_TOP_GO
+    MDB_HIP(ctx, hipGetLastError());
+    return upper_launch_bottom(ctx, up, d_table, b, ef, out, 1, st_ep, st_ovf, st_vis, st_cnt);
 }

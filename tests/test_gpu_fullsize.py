@@ -129,11 +129,14 @@ def test_c2_hnsw_1m_ef200(ctx, oracle, base, flat_1m, hnsw_1m):
     hit = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(64))
     assert hit / (64 * K) >= 0.99
     # ef is monotone for the result quality: a larger ef never loses exact neighbours on this base
-    wide = g.ann_search(q[:16], K, 400)   # > 256: the general kernel
-    hit_w = sum(len(set(wide.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(16))
-    hit_n = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(16))
+    wide = g.ann_search(q[:24], K, 400)   # > 256: the general kernel (hnsw_search_kernel)
+    st_w = ctx.stats()
+    hit_w = sum(len(set(wide.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(24))
+    hit_n = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(24))
     assert hit_w >= hit_n
-    assert rows_of(o.ann_search(q[:4], K, 400), 4) == rows_of(wide, 4)[:4]
+    o.stats()
+    assert rows_of(o.ann_search(q[:24], K, 400), 24) == rows_of(wide, 24)                # the oracle's rows on 24 queries at ef = 400 ...
+    assert (st_w["distance_evals"], st_w["expanded_nodes"]) == tuple(o.stats())          # ... and its traversal, step for step
 
 
 def test_c3_ivfpq_1m_nprobe16(ctx, oracle, base):
