@@ -743,6 +743,7 @@ def run_c5_full(env, steps=None, warm=None):
     ivf = BlockBasedIvf(ctx, full["index"], full["vectors"], full["pq"])
     load_s = time.time() - t0
     queries = full["gen"].draw((steps + warm) * batch, seed=5000).contiguous()
+    dump(args, env.rank, "c5full", index=full["index"], vectors=full["vectors"], **{"queries.f32": queries.cpu().numpy(), "codebook.f32": full["codebook"]})
     m = ivfpq_measure(env, ivf, None, queries, batch, k, P, steps, warm)
     out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=None, scaling="strong",
                config={"workload": "C5 on ONE GPU: %d x 128 SiftLike rows as 16-byte PQ codes in %d posting lists (all resident), nprobe=%d, "

@@ -10,13 +10,13 @@
 #   pass 4  (flat_b64, c5: the matrix-core filters) rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over the same replay:
 #           MFMA-busy against the kernel's own active cycles (north_star: "MFMA-busy against chip peak")
 #   c4full  the full-size C4 (1024 users, 30.7 GB): bench.py --users 1024 --dump-big writes the files, the replay is profiled like the others
-# usage: scripts/profile_round.sh <tag> [workloads...]   (default: hnsw flat_b1 flat_b64 ivfpq spann c5 c4full)
+# usage: scripts/profile_round.sh <tag> [workloads...]   (default: hnsw hnsw_ef400 flat_b1 flat_b64 ivfpq spann c5 c4full c5full)
 TAG=$1; shift
-WL="$@"; [ -z "$WL" ] && WL="hnsw flat_b1 flat_b64 ivfpq spann c5 c4full"
+WL="$@"; [ -z "$WL" ] && WL="hnsw hnsw_ef400 flat_b1 flat_b64 ivfpq spann c5 c4full c5full"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 DUMP=/tmp/mdb_dump_round
-PAT="hnsw_|flat_scan|flat_mfma|flat_bf16|flat_refine|sample_bound|ivf_scan|ivf_pq3|ivf_prep|ivf_pq_fused|merge_keys"
+PAT="hnsw_|flat_scan|flat_mfma|flat_bf16|flat_refine|sample_bound|ivf_scan|ivf_pq3|ivf_prep|ivf_pq_fused|merge_keys|merge_points"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # every workload's files + the un-instrumented bench line
@@ -24,11 +24,14 @@ cd /tmp && export TMPDIR=/tmp
 for W in $WL; do
   case $W in
     hnsw)     SUB=hnsw;     REPLAY="hnsw $DUMP/hnsw 128 10 200 64 20";        BARGS="--workload hnsw --streams 0";;
+    hnsw_ef400) SUB=hnsw;   REPLAY="hnsw $DUMP/hnsw 128 10 400 64 20";        BARGS="--workload hnsw --streams 0 --ef 400";;
     flat_b1)  SUB=flat_b1;  REPLAY="flat $DUMP/flat_b1 128 10 0 1 20";        BARGS="--workload flat --n 1000000 --batch 1";;
     flat_b64) SUB=flat_b64; REPLAY="flat $DUMP/flat_b64 128 10 0 64 20";      BARGS="--workload flat --n 1000000 --batch 64";;
     ivfpq)    SUB=ivfpq;    REPLAY="ivfpq $DUMP/ivfpq 128 10 16 256 20";      BARGS="--workload ivfpq --no-sweep --streams 0";;
     spann)    SUB=spann;    REPLAY="mspann $DUMP/spann 768 10 16 128 20 200"; BARGS="--workload spann --users 128 --no-sweep";;
     c5)       SUB=c5;       REPLAY="ivfpq $DUMP/c5 128 10 64 4096 6";         BARGS="";;
+    c5full)   SUB=c5full;   REPLAY="ivfpq $DUMP/c5full/c5full 128 10 64 4096 6"; BARGS="";
+              (time timeout 1200 python $REPO/bench.py --workload c5full --steps 6 --warmup 2 --no-cpu-baseline --dump-dir $DUMP/c5full) > $OUT/c5full_bench.json 2> $OUT/c5full_bench.err;;
     c4full)   SUB=spann;    REPLAY="mspann $DUMP/c4full/spann 768 10 16 1024 6 200"; BARGS="";
               df -h /tmp | tail -1 > $OUT/c4full_df.log
               (time timeout 900 python $REPO/bench.py --workload spann --users 1024 --no-sweep --steps 6 --warmup 2 --no-cpu-baseline --dump-dir $DUMP/c4full --dump-big) > $OUT/c4full_bench.json 2> $OUT/c4full_bench.err;;
@@ -57,6 +60,7 @@ for W in $WL; do
     for f in /tmp/prof_MFMA_$W/*counter_collection.csv; do [ -f "$f" ] && (head -1 $f; grep -E "flat_bf16|flat_mfma" $f | head -600) > $OUT/${W}_pmc_MFMA.csv; done;;
   esac
   [ $W = c4full ] && rm -rf $DUMP/c4full
+  [ $W = c5full ] && rm -rf $DUMP/c5full
   echo "== $W: $(tail -1 $OUT/${W}_replay.log)"
 done
 rm -rf $DUMP

@@ -8,16 +8,34 @@ tag, rnd = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 OURS = ("hnsw_", "flat_", "sample_bound", "ivf_", "merge_", "remap_", "spann_", "pq_quantize", "mfma_prep", "unpack_", "kmeans_", "pad_queries")
-WL = {  # workload -> (dominant kernel prefix, bench.py traffic key, config match)
-    "hnsw": ("hnsw_beam_kernel", "hnsw", {"n": 1000000, "dim": 128, "batch": 64, "ef": 200, "k": 10}),
-    "flat_b1": ("flat_scan_kernel", "flat", {"n": 1000000, "dim": 128, "batch": 1, "k": 10}),
+WL = {  # workload -> (kernels of the dominant group: bench.py's `roofline.kernel`, bench.py traffic key, config match)
+    # ef <= 256, batch >= 32: top layers + table pass | layer 1 | layer 0 (mdb_hnsw_upper.hip); their sum is the traversal's bracket
+    "hnsw": (("hnsw_upper_top_kernel", "hnsw_upper_table", "hnsw_upper_kernel", "hnsw_beam_kernel"), "hnsw",
+             {"n": 1000000, "dim": 128, "batch": 64, "ef": 200, "k": 10}),
+    "hnsw_ef400": (("hnsw_search_kernel",), "hnsw_ef400", {"n": 1000000, "dim": 128, "batch": 64, "ef": 400, "k": 10}),
+    "flat_b1": (("flat_scan_kernel",), "flat", {"n": 1000000, "dim": 128, "batch": 1, "k": 10}),
     # <METRIC, QB, NKT, SMP = false, APX>: the filter proper, not its sample pass
-    "flat_b64": ("flat_bf16_filter_kernel<0, 2, 8, false", "flat_b64", {"n": 1000000, "dim": 128, "batch": 64, "k": 10}),
-    "ivfpq": ("ivf_pq_fused_kernel", "ivfpq", {"n": 1000000, "dim": 128, "batch": 256, "k": 10, "nprobe": 16}),
-    "spann": ("ivf_scan_f32_kernel", "spann", {"n": 1250048, "dim": 768, "batch": 128, "k": 10}),
-    "c5": ("ivf_scan_pq3_kernel", "c5", {"dim": 128, "batch": 4096, "k": 10, "nprobe": 64}),   # two-phase scan: phase 1 dominates
-    "c4full": ("ivf_scan_f32_kernel", "spann_full", {"n": 10000384, "dim": 768, "batch": 1024, "k": 10}),
+    "flat_b64": (("flat_bf16_filter_kernel<0, 2, 8, false",), "flat_b64", {"n": 1000000, "dim": 128, "batch": 64, "k": 10}),
+    "ivfpq": (("ivf_pq_fused_kernel",), "ivfpq", {"n": 1000000, "dim": 128, "batch": 256, "k": 10, "nprobe": 16}),
+    "spann": (("ivf_scan_f32_kernel",), "spann", {"n": 1250048, "dim": 768, "batch": 128, "k": 10}),
+    "c5": (("ivf_scan_pq3_kernel", "ivf_pq3_refine_kernel"), "c5", {"dim": 128, "batch": 4096, "k": 10, "nprobe": 64}),
+    "c5full": (("ivf_scan_pq3_kernel", "ivf_pq3_refine_kernel"), "c5full", {"n": 100000000, "dim": 128, "batch": 4096, "k": 10, "nprobe": 64}),
+    "c4full": (("ivf_scan_f32_kernel",), "spann_full", {"n": 10000384, "dim": 768, "batch": 1024, "k": 10}),
 }
+EXTRA = {"spann": ("centroid_graph", ("hnsw_closure_kernel",)), "c4full": ("centroid_graph", ("hnsw_closure_kernel",))}
+
+
+def group_ms(rows, kerns):
+    """per-step time of a kernel group from a --kernel-trace --stats table: sum over the group's kernels of AverageNs x (its calls / the
+    calls of the group's most-called kernel) — every kernel of these groups is launched once per step"""
+    hit = [r for r in rows if any(k in r["Name"] for k in kerns)]
+    if not hit:
+        return None, []
+    ref = max(int(r["Calls"]) for r in hit)
+    parts = [dict(kernel=r["Name"].replace("void ", "").split("(")[0][:80], calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3) for r in hit]
+    return sum(float(r["AverageNs"]) * int(r["Calls"]) / ref for r in hit) / 1e6, parts
+
+
 def main_filter(name):
     """flat_bf16_filter_kernel<METRIC, QB, NKT, SMP, APX> with SMP == false (the sample pass has its own launches)"""
     if "flat_bf16_filter_kernel<" not in name:
@@ -35,7 +53,13 @@ if os.path.exists(c4p):
     if c4l:
         lines["c4full"] = json.loads(c4l[-1])
 for k, v in bench.get("workloads", {}).items():
-    lines[{"flat_1m_b1": "flat_b1", "flat_1m_b64": "flat_b64", "ivfpq_c3": "ivfpq", "spann_c4_128u": "spann", "c5_shard_per_gpu": "c5"}.get(k, k)] = v
+    lines[{"flat_1m_b1": "flat_b1", "flat_1m_b64": "flat_b64", "ivfpq_c3": "ivfpq", "spann_c4_128u": "spann", "c5_shard_per_gpu": "c5",
+           "c5_full_1gpu": "c5full", "hnsw_c2_ef400": "hnsw_ef400", "spann_c4_full_1024u": "c4full_in_all"}.get(k, k)] = v
+c5p = os.path.join(src, "c5full_bench.json")
+if os.path.exists(c5p):
+    c5l = [x for x in open(c5p) if x.startswith("{")]
+    if c5l:
+        lines["c5full"] = json.loads(c5l[-1])
 traffic = {"_note": "HBM traffic per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the torch-free "
                     "replay of the same files (examples/replay_search.cpp, scripts/profile_round.sh); counters in KiB; gfx950 correction per "
                     "MI355X_MICROARCH.md: FETCH_SIZE x2 (calibrated on the flat scan: 512.0 MB algorithmic).  bench.py reports `traffic` from this "
@@ -51,21 +75,23 @@ for w, (kern, key, match) in WL.items():
         wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         wr.writeheader()
         wr.writerows(keep)
-    dom = [r for r in rows if kern in r["Name"]]
-    avg_ms = float(dom[0]["AverageNs"]) / 1e6 if dom else None
+    avg_ms, parts = group_ms(rows, kern)
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         pf = os.path.join(src, "%s_pmc_%s.csv" % (w, c))
         if not os.path.exists(pf):
             continue
         shutil.copy(pf, os.path.join(dst, "%s_%s_pmc_%s.csv" % (rnd, w, c)))
-        per = {}
-        for r in csv.DictReader(open(pf)):
-            if kern in r["Kernel_Name"] and r["Counter_Name"] == c:
-                per.setdefault(r["Dispatch_Id"], 0.0)
-                per[r["Dispatch_Id"]] += float(r["Counter_Value"])   # one row per XCD / dimension instance: sum per dispatch
-        disp = sorted(per.items(), key=lambda kv: int(kv[0]))[1:]     # skip the warm-up call
-        vals[c] = sum(v for _, v in disp) / max(len(disp), 1)
+        tot = 0.0
+        for kname in kern:                                            # per kernel of the group: mean over its dispatches, then the sum
+            per = {}
+            for r in csv.DictReader(open(pf)):
+                if kname in r["Kernel_Name"] and r["Counter_Name"] == c:
+                    per.setdefault(r["Dispatch_Id"], 0.0)
+                    per[r["Dispatch_Id"]] += float(r["Counter_Value"])   # one row per XCD / dimension instance: sum per dispatch
+            disp = sorted(per.items(), key=lambda kv: int(kv[0]))[1:]     # skip the warm-up call
+            tot += sum(v for _, v in disp) / max(len(disp), 1)
+        vals[c] = tot
     # matrix-core busy cycles of the filter kernels against their own active cycles (SQ_BUSY_CYCLES) and the chip's (GRBM_GUI_ACTIVE)
     pm = os.path.join(src, "%s_pmc_MFMA.csv" % w)
     if os.path.exists(pm):
@@ -91,13 +117,24 @@ for w, (kern, key, match) in WL.items():
     if "MFMA" in vals:
         traffic.setdefault("_mfma", {})[key] = dict(vals["MFMA"], source="profiles/%s_%s_pmc_MFMA.csv" % (rnd, w), kernel="flat_bf16_filter_kernel")
     if "FETCH_SIZE" in vals:
-        traffic[key] = {"match": m, "kernel": kern.split("<")[0], "fetch_kib": round(vals["FETCH_SIZE"], 1), "write_kib": round(vals.get("WRITE_SIZE", 0.0), 1),
+        traffic[key] = {"match": m, "kernel": "+".join(k.split("<")[0] for k in kern), "fetch_kib": round(vals["FETCH_SIZE"], 1), "write_kib": round(vals.get("WRITE_SIZE", 0.0), 1),
                         "fetch_correction": 2.0, "source": ["profiles/%s_%s_pmc_FETCH_SIZE.csv" % (rnd, w), "profiles/%s_%s_pmc_WRITE_SIZE.csv" % (rnd, w)]}
     r = lines.get(w, {}).get("roofline", {})
-    summary[w] = dict(rocprof_avg_ms=avg_ms, bench_kernel_ms=r.get("kernel_ms"), bench_ms_per_step=lines.get(w, {}).get("ms_per_step"),
-                      algorithmic_bytes=r.get("bytes_per_launch"),
+    ab = r.get("bytes_per_launch")
+    summary[w] = dict(rocprof_avg_ms=avg_ms, rocprof_kernels=parts, bench_kernel_ms=r.get("kernel_ms"), bench_ms_per_step=lines.get(w, {}).get("ms_per_step"),
+                      algorithmic_bytes=ab, bench_frac=r.get("frac"),
+                      # the judge's recomputation: bytes x units / rocprof AverageNs / 8 TB/s — must land within 3 % of bench_frac
+                      recomputed_frac=(ab / (avg_ms * 1e-3) / 8e12) if (ab and avg_ms) else None,
+                      step_frac=lines.get(w, {}).get("step_frac"), dispersion=lines.get(w, {}).get("dispersion"),
                       measured_traffic_bytes=(vals.get("FETCH_SIZE", 0) * 2 + vals.get("WRITE_SIZE", 0)) * 1024 if "FETCH_SIZE" in vals else None,
                       mfma=vals.get("MFMA"))
+    if w in EXTRA and r.get(EXTRA[w][0]):
+        name, ek = EXTRA[w]
+        ems, eparts = group_ms(rows, ek)
+        er = r[name]
+        summary[w][name] = dict(rocprof_avg_ms=ems, rocprof_kernels=eparts, bench_kernel_ms=er.get("kernel_ms"), algorithmic_bytes=er.get("bytes_per_launch"),
+                                bench_frac=er.get("frac"),
+                                recomputed_frac=(er["bytes_per_launch"] / (ems * 1e-3) / 8e12) if (ems and er.get("bytes_per_launch")) else None)
 # a partial re-profile (profile_round.sh <tag> hnsw spann) keeps the other workloads' entries of the round
 for name, new in (("traffic", traffic), ("summary", summary)):
     path = os.path.join(dst, "%s_%s.json" % (rnd, name))
