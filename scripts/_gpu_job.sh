@@ -1,2 +1,4 @@
 cd /root/repo
-MDB_HNSW_DBG=1 python bench.py --workload hnsw --steps 5 --warmup 2 --no-cpu-baseline --streams 0 2>&1 | grep "hnsw dbg" | tail -2
+timeout 2700 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 400 python scripts/stress_parity.py --seconds 300 --seed 20261004 2>&1 | tail -2
