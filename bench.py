@@ -435,9 +435,10 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
                             % ("SIFT-1M" if args.sift_dir else "SIFT-1M-like synthetic", n, d, desc, args.max_neighbors, ef, k, batch, how),
                 "n": n, "dim": d, "batch": batch, "ef": ef, "k": k, "index": "hnsw", "graph": graph,
                 "data": "sift1m" if args.sift_dir else args.data, "parallelism": "replica x%d" % world, "graph_build_s": build_s},
-        # ef <= 256: the traversal is three kernels — the upper layers' distance table, their single-wave traversal and the layer-0
-        # instance of the beam kernel (mdb_hnsw_upper.hip); the bracket is their sum, the algorithmic bytes are the whole traversal's
-        roofline=hbm_roofline("hnsw_upper_table64_kernel+hnsw_upper_kernel+hnsw_beam_kernel<L0>" if ef <= 256 else "hnsw_search_kernel",
+        # ef <= 448: the traversal is three kernels — the upper layers' distance table (fused with the top layers' traversal for batches
+        # >= 32), their single-wave traversal and the layer-0 instance of the beam kernel (mdb_hnsw_upper.hip; 5 beam registers up to ef
+        # 256, 8 above); the bracket is their sum, the algorithmic bytes are the whole traversal's
+        roofline=hbm_roofline("hnsw_upper_top_kernel|hnsw_upper_table*_kernel+hnsw_upper_kernel+hnsw_beam_kernel<L0>" if ef <= 448 else "hnsw_search_kernel",
                               abytes / steps, kernel_ms, launches,
                               evals_per_query=evals / (steps * batch), expanded_per_query=expanded / (steps * batch)),
     )
@@ -1149,7 +1150,7 @@ def main():
         extra = {}
         # the metric's other batch size over the same resident graph (one sequential chain on one CU: latency, not throughput)
         plan = [("hnsw_c2_b1", lambda: run_hnsw(env, batch=1, graph="knn", extras=False, steps=max(args.steps, 200), warm=max(args.warmup, 20))),
-                # ef above 256 leaves the register beam: hnsw_search_kernel (sorted LDS sets), the same resident graph
+                # ef above 256: the 8-register beam of the table path (up to 448; beyond: hnsw_search_kernel), the same resident graph
                 ("hnsw_c2_ef400", lambda: run_hnsw(env, batch=64, graph="knn", extras=False, ef=400)),
                 ("flat_1m_b1", lambda: run_flat(env, n=1_000_000, batch=1)), ("flat_1m_b64", lambda: run_flat(env, n=1_000_000, batch=64)),
                 ("ivfpq_c3", lambda: run_ivfpq(env)), ("spann_c4_128u", lambda: run_spann(env, users=128))]

@@ -50,6 +50,7 @@
     X(hnsw_table_qt, "MDB_HNSW_TABLE_QT", 4)          /* queries per pass of the upper-layer table kernel (2 / 4 / 8) */ \
     X(hnsw_table_no_lds, "MDB_HNSW_TABLE_NO_LDS", 0)   /* upper-layer traversal: table lookups from global memory even when the row fits LDS */ \
     X(hnsw_table64_min_b, "MDB_HNSW_TABLE64_MIN_B", 32) /* smallest batch that takes the lane = query table kernel */ \
+    X(hnsw_no_wide, "MDB_HNSW_NO_WIDE", 0)             /* 256 < ef <= 448 through the general kernel instead of the 8-register beam */ \
     X(hnsw_no_split, "MDB_HNSW_NO_SPLIT", 0)           /* upper layers: table pass, then ONE traversal launch (no top / layer-1 split) */ \
     X(hnsw_table_min_b, "MDB_HNSW_TABLE_MIN_B", 1)     /* smallest batch served by the table path */               \
     X(hnsw_dbg, "MDB_HNSW_DBG", 0)                                                                                  \

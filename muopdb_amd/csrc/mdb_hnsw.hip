@@ -634,11 +634,9 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 #ifndef MDB_HNSW_L0TOUCH
 #define MDB_HNSW_L0TOUCH 1
 #endif
-#define BEAM_LDS_C 2048
-#define BEAM_LDS_NBID (BEAM_LDS_C + 8192)
-#define BEAM_LDS_NBDIST (BEAM_LDS_NBID + 1024)
-#define BEAM_LDS_MISC (BEAM_LDS_NBDIST + 1024)
-#define BEAM_LDS_QS (BEAM_LDS_MISC + 64)
+// W (the sorted working set of the result: 64 NB keys rounded to 2 / 4 KB) | C 1024 keys | nb_id | nb_dist | misc | qs | vis
+__host__ __device__ constexpr int beam_lds_c(int nb) { return nb <= 5 ? 2048 : 4096; }
+__host__ __device__ constexpr int beam_lds_qs(int nb) { return beam_lds_c(nb) + 8192 + 1024 + 1024 + 64; }
 
 #ifdef MDB_PIPE_DBG   // cycle / event accounting of the roles into counters[4..15] (MDB_HNSW_DBG=1 prints them)
 #define PIPE_TB(t) const unsigned long long t = __builtin_readcyclecounter()
@@ -664,7 +662,9 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 // wave 0's chain.
 // L0: the upper layers were traversed by hnsw_upper_kernel on the distance table (mdb_hnsw_upper.hip) — this instance marks the points
 // visited there, takes the handed-down entry point and runs layer 0 only.
-template <int METRIC, bool VIS_LDS, int N16T, bool PF, bool ROW64, bool L0 = false>
+// NB: registers of 64 beam slots — 5 (320 slots) serves ef <= 256, 8 (512 slots; layer-0 instance only) ef <= 448: both leave >= 64 slots
+// for ties with furthest before the general traversal has to take the query over.
+template <int METRIC, bool VIS_LDS, int N16T, bool PF, bool ROW64, bool L0 = false, int NB = 5>
 __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     constexpr int NCH = ROW64 ? 1 : 4;   // 64-edge chunks of a row
     constexpr bool SPEC = MDB_HNSW_SPEC && !PF && N16T > 0 && N16T <= 16;   // the groups' first vector is requested ahead of the list length
@@ -675,14 +675,16 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
     // FIXED LDS layout (compile-time offsets: the kernel is SGPR-bound, eight live LDS pointers are eight
     // scalars it does not have): W 256 keys | C 1024 keys | nb_id 256 | nb_dist 256 | misc 16 | qs dpad | vis
     uint64_t* const W = (uint64_t*)lds;
-    uint64_t* const C = (uint64_t*)(lds + BEAM_LDS_C);  // [0..512): staging / sort buffer, [512..768) as u32 flags
-    uint32_t* const nb_id = (uint32_t*)(lds + BEAM_LDS_NBID);
-    uint32_t* const nb_od = (uint32_t*)(lds + BEAM_LDS_NBDIST);  // order-preserving images of the neighbours' distances
-    uint32_t* const misc = (uint32_t*)(lds + BEAM_LDS_MISC);  // [0] nnew (0xFFFFFFFF = stop), [2] wsize, [3] overflow,
+    constexpr int LDS_C = beam_lds_c(NB), LDS_NBID = LDS_C + 8192, LDS_NBDIST = LDS_NBID + 1024, LDS_MISC = LDS_NBDIST + 1024,
+                  LDS_QS = LDS_MISC + 64;
+    uint64_t* const C = (uint64_t*)(lds + LDS_C);  // [0..512): staging / sort buffer, [512..768) as u32 flags
+    uint32_t* const nb_id = (uint32_t*)(lds + LDS_NBID);
+    uint32_t* const nb_od = (uint32_t*)(lds + LDS_NBDIST);  // order-preserving images of the neighbours' distances
+    uint32_t* const misc = (uint32_t*)(lds + LDS_MISC);  // [0] nnew (0xFFFFFFFF = stop), [2] wsize, [3] overflow,
                                                               // PF: [10] runner-up id (0xFFFFFFFF = none), [11] step tag of [10]
     uint32_t* const pf_list = (uint32_t*)(C + 768);           // PF: the prefetch wave's compacted neighbour list (512 ids; C[768..) is free)
-    float* const qs = (float*)(lds + BEAM_LDS_QS);
-    uint32_t* vis = VIS_LDS ? (uint32_t*)(lds + BEAM_LDS_QS + (size_t)a.dpad * 4) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
+    float* const qs = (float*)(lds + LDS_QS);
+    uint32_t* vis = VIS_LDS ? (uint32_t*)(lds + LDS_QS + (size_t)a.dpad * 4) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
     uint32_t* const stage_flag = (uint32_t*)(C + 512);
 
     const int qi = blockIdx.x;
@@ -727,8 +729,8 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                                                       : group16_distance<METRIC>((rowptr), qs, a.p, j)))
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // ---- wave-0 state
-    uint32_t bd[BREGS], bi[BREGS];  // B: distance image / id per slot (SLOT_EMPTY beyond n)
-    uint32_t cdv[BREGS];            // = bd for unexpanded slots, SLOT_EMPTY otherwise (the candidates)
+    uint32_t bd[NB], bi[NB];  // B: distance image / id per slot (SLOT_EMPTY beyond n)
+    uint32_t cdv[NB];            // = bd for unexpanded slots, SLOT_EMPTY otherwise (the candidates)
     int n = 0;                      // used slots
     uint32_t fbound = SLOT_EMPTY;   // an upper bound of furthest.distance (prefilter only)
     uint32_t rowv[NCH], rowr[NCH];   // row of the node being expanded / of the runner-up (speculative)
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
             d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), 0));
             if (d0 != d0) nan_seen = true;
 #pragma unroll
-            for (int r = 0; r < BREGS; ++r) { bd[r] = SLOT_EMPTY; bi[r] = 0; cdv[r] = SLOT_EMPTY; }
+            for (int r = 0; r < NB; ++r) { bd[r] = SLOT_EMPTY; bi[r] = 0; cdv[r] = SLOT_EMPTY; }
             if (lane == 0) { bd[0] = f32_orderable(d0); bi[0] = ep; }
             n = 1;
             fbound = SLOT_EMPTY;
@@ -903,7 +905,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                     // wait for the distance waves here
                     ru_closer = 0;
 #pragma unroll
-                    for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
+                    for (int r = 0; r < NB; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
                     if (L0TOUCH) {
                         // ---- layer 0: the distance waves' gather is the long side of a step (1.5 k cycles against 0.7 k here: the
                         // 512 MB of vectors miss L2 and the Infinity Cache) and wave 0 would wait ~0.9 k cycles at the barrier below.
@@ -1046,13 +1048,13 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                         const uint32_t ds = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
                         int cnt = __popcll(__ballot(have && od <= ds) & ((1ull << sidx) - 1ull));
 #pragma unroll
-                        for (int r = 0; r < BREGS; ++r) cnt += __popcll(__ballot(bd[r] <= ds));
+                        for (int r = 0; r < NB; ++r) cnt += __popcll(__ballot(bd[r] <= ds));
                         if (cnt < ef) accepted |= 1ull << sidx;
                         else fbound = min(fbound, ds);  // >= ef elements within ds: furthest <= ds from now on
                     }
                     const int na = __popcll(accepted);
                     if (na) {
-                        if (n + na > BEAM_CAP) {
+                        if (n + na > (64 * NB)) {
                             // ---- compaction: f = ef-th smallest distance image in B (32-step radix select by
                             // ballots; EMPTY = 0xFFFFFFFF sorts last), drop everything farther than f
                             uint32_t prefix = 0;
@@ -1061,14 +1063,14 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                                 const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
                                 int cnt0 = 0;
 #pragma unroll
-                                for (int r = 0; r < BREGS; ++r)
+                                for (int r = 0; r < NB; ++r)
                                     cnt0 += __popcll(__ballot((((bd[r] ^ prefix) & hi_mask) == 0u) && !((bd[r] >> bit) & 1u)));
                                 if (cnt0 < need) { need -= cnt0; prefix |= 1u << bit; }
                             }
                             const uint32_t f = prefix;
                             int kept = 0;
 #pragma unroll
-                            for (int r = 0; r < BREGS; ++r) {
+                            for (int r = 0; r < NB; ++r) {
                                 const bool keep = bd[r] <= f;  // EMPTY never kept (f is a real distance: n > ef here)
                                 const unsigned long long km = __ballot(keep);
                                 if (keep) {
@@ -1079,7 +1081,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                                 kept += __popcll(km);
                             }
 #pragma unroll
-                            for (int r = 0; r < BREGS; ++r) {
+                            for (int r = 0; r < NB; ++r) {
                                 const int idx = lane + 64 * r;
                                 const bool in = idx < kept;
                                 const uint64_t kk = in ? C[idx] : 0;
@@ -1089,18 +1091,18 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                             }
                             n = kept;
                             fbound = min(fbound, f);
-                            if (n + na > BEAM_CAP) { overflow = true; break; }  // > ~120 exact ties with furthest
+                            if (n + na > (64 * NB)) { overflow = true; break; }  // > ~120 exact ties with furthest
                             if (best_have) {  // the best accepted so far may have been dropped (rare)
                                 bool still = false;
 #pragma unroll
-                                for (int r = 0; r < BREGS; ++r) still = still || __ballot(cdv[r] == best_o && bi[r] == best_id) != 0;
+                                for (int r = 0; r < NB; ++r) still = still || __ballot(cdv[r] == best_o && bi[r] == best_id) != 0;
                                 best_have = still;
                             }
                             ru_valid = beam_best_id(cdv, bi, ru_o, ru_id);  // may have been dropped too
                             if (ru_valid) load_row(ru_id, rowr);
                             ru_closer = 0;   // recount over the compacted B (it holds the earlier chunks' pushes)
 #pragma unroll
-                            for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
+                            for (int r = 0; r < NB; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
                         }
                         ru_closer += __popcll(accepted & __ballot(od < ru_o));   // this chunk's pushes
                         // ---- push all accepted neighbours: slots n .. n+na-1, in edge order
@@ -1115,7 +1117,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                             const bool got = rel < na;
                             const int reg = (n + rel) >> 6;
 #pragma unroll
-                            for (int r = 0; r < BREGS; ++r) {
+                            for (int r = 0; r < NB; ++r) {
                                 const bool w = got && reg == r;
                                 bd[r] = w ? rod : bd[r];
                                 bi[r] = w ? rid : bi[r];
@@ -1158,20 +1160,20 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                             closer = 0;
                             if (n >= ef) {  // fewer than ef elements in B: the popped candidate cannot be beyond furthest
 #pragma unroll
-                                for (int r = 0; r < BREGS; ++r) closer += __popcll(__ballot(bd[r] < best_o));
+                                for (int r = 0; r < NB; ++r) closer += __popcll(__ballot(bd[r] < best_o));
                             }
                         }
                         if (closer >= ef) {
                             stop = true;  // `distance > furthest.distance` (index.rs:246-248)
                         } else if (take_ru) {
 #pragma unroll
-                            for (int r = 0; r < BREGS; ++r)
+                            for (int r = 0; r < NB; ++r)
                                 if (bi[r] == ru_id) cdv[r] = SLOT_EMPTY;   // ids are unique in B (unused slots: already EMPTY)
 #pragma unroll
                             for (int c = 0; c < NCH; ++c) rowv[c] = rowr[c];
                         } else {
 #pragma unroll
-                            for (int r = 0; r < BREGS; ++r)
+                            for (int r = 0; r < NB; ++r)
                                 if (bi[r] == best_id) cdv[r] = SLOT_EMPTY;
                             load_row(best_id, rowv);
                         }
@@ -1187,11 +1189,11 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
             if (wave == 0) {
                 uint32_t m = bd[0];
 #pragma unroll
-                for (int r = 1; r < BREGS; ++r) m = min(m, bd[r]);
+                for (int r = 1; r < NB; ++r) m = min(m, bd[r]);
                 m = wave_min_u32(m);
                 uint32_t im = 0xFFFFFFFFu;
 #pragma unroll
-                for (int r = 0; r < BREGS; ++r) im = bd[r] == m ? min(im, bi[r]) : im;
+                for (int r = 0; r < NB; ++r) im = bd[r] == m ? min(im, bi[r]) : im;
                 im = wave_min_u32(im);
                 if (lane == 0) misc[1] = im;
             }
@@ -1202,9 +1204,9 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
         // ---- layer 0 done: spill B and sort it (block-wide bitonic); W = its ef smallest keys
         if (wave == 0) {
 #pragma unroll
-            for (int r = 0; r < BREGS; ++r)
+            for (int r = 0; r < NB; ++r)
                 C[lane + 64 * r] = bd[r] == SLOT_EMPTY ? MDB_KEY_MAX : (((uint64_t)bd[r] << 32) | bi[r]);
-            for (int i = BEAM_CAP + lane; i < 512; i += 64) C[i] = MDB_KEY_MAX;
+            for (int i = (64 * NB) + lane; i < 512; i += 64) C[i] = MDB_KEY_MAX;
             if (lane == 0) misc[2] = (uint32_t)(n < ef ? n : ef);
         }
         __syncthreads();
@@ -1690,7 +1692,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     a.k = (int)k;
     a.out_keys = d_keys; a.out_counts = d_counts; a.flags = ctx->d_flags; a.counters = ctx->d_counters;
     size_t lds_base = (size_t)a.ef_cap * 8 + (size_t)a.cand_cap * 8 + (size_t)a.smax * 8 + (size_t)dpad * 4 + 64;
-    if (ef <= 256) lds_base = std::max<size_t>(lds_base, (size_t)BEAM_LDS_QS + (size_t)dpad * 4);  // the beam kernel's fixed layout
+    if (ef <= 448) lds_base = std::max<size_t>(lds_base, (size_t)beam_lds_qs(ef <= 256 ? 5 : 8) + (size_t)dpad * 4);  // the beam kernel's fixed layout
     size_t words = ((size_t)max_n + 31) / 32 + 1;
     bool vis_lds = lds_base + words * 4 <= 160 * 1024 - 256;
     size_t lds = lds_base + (vis_lds ? words * 4 : 0);
@@ -1718,12 +1720,16 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
         hnsw_beam_kernel<METRIC, VL, NF, PF, R64><<<dim3((unsigned)b), (PF) ? HNSW_BLOCK + 128 : HNSW_BLOCK, lds, ctx->stream>>>(a); \
     } while (0)
-#define MDB_BEAM_LAUNCH_L0(METRIC, VL, NF, PF)                                                                              \
+#define MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, NBV)                                                                            \
     do {                                                                                                                    \
         if (lds > 48 * 1024)                                                                                                \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF, PF, true, true>,                 \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF, false, true, true, NBV>,         \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hnsw_beam_kernel<METRIC, VL, NF, PF, true, true><<<dim3((unsigned)b), (PF) ? HNSW_BLOCK + 128 : HNSW_BLOCK, lds, ctx->stream>>>(a); \
+        hnsw_beam_kernel<METRIC, VL, NF, false, true, true, NBV><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);   \
+    } while (0)
+#define MDB_BEAM_LAUNCH_L0(METRIC, VL, NF, PF)                                                                              \
+    do {                                                                                                                    \
+        if (ef <= 256) MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, 5); else MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, 8);                 \
     } while (0)
 #define MDB_HNSW_LAUNCH(METRIC, VL)                                                                              \
     do {                                                                                                           \
@@ -1781,13 +1787,16 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     }
     // ef <= 256: register-resident beam; above: sorted LDS sets (MDB_HNSW_NO_BEAM forces the latter, for tests)
     const bool beam = ef <= 256 && !ctx->opt.hnsw_no_beam;
+    // the table path's kernels exist with an 8-register beam as well (512 slots): ef up to 448 (SearchParams.ef_construction is the
+    // caller's, rs/config/src/search_params.rs:1-34) stays off the general kernel, which is 3x slower per expansion
+    const bool beam_wide = ef > 256 && ef <= 448 && !ctx->opt.hnsw_no_beam && !ctx->opt.hnsw_no_wide;
     // hnsw_beam_kernel with its prefetch wave (see the kernel): f32 rows of whole 16-lane chunks
     const bool row64 = max_stride <= 64 && !ctx->opt.hnsw_no_row64;   // hnsw_beam_kernel's one-chunk specialisation
     const bool prefetch = beam && row64 && (nf == 8 || nf == 48) && ctx->opt.hnsw_prefetch;   // OPT-IN: measured slower
     // upper layers on the distance table (mdb_hnsw_upper.hip): table pass, single-wave traversal, then the layer-0 instance of
     // the beam kernel.  One graph (no per-query user), f32 rows; the table is b * nu words of scratch
     const uint32_t nu_pad = (uint32_t)upper.tiles.ntiles * MDB_TILE;
-    const bool table = upper.nu > 0 && !d_q_user && beam && row64 && !prefetch && kind != MDB_QUANT_PQ && !ctx->opt.hnsw_no_table &&
+    const bool table = upper.nu > 0 && !d_q_user && (beam || beam_wide) && row64 && !prefetch && kind != MDB_QUANT_PQ && !ctx->opt.hnsw_no_table &&
                        (long long)b >= ctx->opt.hnsw_table_min_b && (uint64_t)b * nu_pad * 4 <= ((uint64_t)2 << 30) &&
                        (size_t)(upper.nu / 32 + 4) * 4 <= 96 * 1024;
     if (table) {
@@ -1820,6 +1829,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     }
 #undef MDB_BEAM_LAUNCH
 #undef MDB_BEAM_LAUNCH_L0
+#undef MDB_BEAM_LAUNCH_L0N
 #undef MDB_HNSW_LAUNCH4
 #undef MDB_HNSW_LAUNCH
     MDB_HIP(ctx, hipGetLastError());

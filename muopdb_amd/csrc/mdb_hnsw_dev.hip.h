@@ -37,10 +37,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-#ifndef BREGS
-#define BREGS 5
-#endif
-#define BEAM_CAP (64 * BREGS)
+// the register beam: NB registers of 64 slots per array (5: ef <= 256; 8: ef <= 448) — a template parameter of the traversal kernels
 
 // nearest unexpanded candidate in pop order (smallest distance image, LARGEST id among equals); `cdv` holds the distance
 // image of unexpanded slots and SLOT_EMPTY elsewhere.  Returns false if none.  Ids are unique in B, so the kernel marks
@@ -48,16 +45,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // 0's critical path).
 // One min reduction; the winner's id is the per-lane maximum over the lane's matching slots (in-lane ties resolved for free),
 // read from the single matching lane — only distance ties ACROSS lanes pay a second reduction.
-__device__ __forceinline__ bool beam_best_id(const uint32_t (&cdv)[BREGS], const uint32_t (&bi)[BREGS], uint32_t& o_out, uint32_t& id_out) {
+template <int NB>
+__device__ __forceinline__ bool beam_best_id(const uint32_t (&cdv)[NB], const uint32_t (&bi)[NB], uint32_t& o_out, uint32_t& id_out) {
     uint32_t lm = cdv[0];
 #pragma unroll
-    for (int r = 1; r < BREGS; ++r) lm = min(lm, cdv[r]);
+    for (int r = 1; r < NB; ++r) lm = min(lm, cdv[r]);
     const uint32_t m = wave_min_u32(lm);
     o_out = m;
     if (m == SLOT_EMPTY) return false;
     uint32_t li = 0;
 #pragma unroll
-    for (int r = 0; r < BREGS; ++r) li = max(li, cdv[r] == m ? bi[r] : 0u);
+    for (int r = 0; r < NB; ++r) li = max(li, cdv[r] == m ? bi[r] : 0u);
     const unsigned long long hm = __ballot(lm == m);
     uint32_t id;
     if (__builtin_expect((hm & (hm - 1)) == 0, 1)) {

@@ -327,6 +327,7 @@ struct HnswUpArgs {
 #define UP_BLOCK 256
 // wave 0 of the block (64 lanes): layers a.layer_hi .. a.layer_lo on the table row `tq`, visited set `vis` (LDS, initialised by the
 // caller), then the hand-over.  `vis_out`: LDS scratch of a.out_words words when a.vis_map is set.
+template <int NB>
 __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const int qi, const int lane, char* lds, const uint32_t* tq,
                                                      uint32_t* vis, uint32_t* vis_out) {
     uint64_t* const C = (uint64_t*)(lds + UP_LDS_STAGE);
@@ -335,7 +336,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
     const int ef = a.ef;
     const uint32_t su = a.su;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t bd[BREGS], bi[BREGS], cdv[BREGS];
+    uint32_t bd[NB], bi[NB], cdv[NB];
     int n = 0;
     uint32_t fbound = SLOT_EMPTY;
     uint32_t rowv = 0xFFFFFFFFu, rowr = 0xFFFFFFFFu;
@@ -407,7 +408,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
             const float f0 = f32_from_orderable(od0);
             if (f0 != f0) nan_lane = true;
 #pragma unroll
-            for (int r = 0; r < BREGS; ++r) { bd[r] = SLOT_EMPTY; bi[r] = 0; cdv[r] = SLOT_EMPTY; }
+            for (int r = 0; r < NB; ++r) { bd[r] = SLOT_EMPTY; bi[r] = 0; cdv[r] = SLOT_EMPTY; }
             if (lane == 0) { bd[0] = od0; bi[0] = ep; }
             n = 1;
             nexp = 1;
@@ -435,7 +436,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                 ru_closer = 0;
                 if (nexp >= ef) {
 #pragma unroll
-                    for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
+                    for (int r = 0; r < NB; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
                 }
             }
             UP_T(t1);
@@ -467,7 +468,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                     const uint32_t ds = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
                     int cnt = __popcll(__ballot(have && od <= ds) & ((1ull << sidx) - 1ull));
 #pragma unroll
-                    for (int r = 0; r < BREGS; ++r) cnt += __popcll(__ballot(bd[r] <= ds));
+                    for (int r = 0; r < NB; ++r) cnt += __popcll(__ballot(bd[r] <= ds));
                     if (cnt < ef) accepted |= 1ull << sidx;
                     else fbound = min(fbound, ds);
                 }
@@ -475,7 +476,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                 UP_T(t3);
                 UP_ACC(2, t3 - t2); UP_ACC(8, na); UP_ACC(9, na == 1 ? 1 : 0); UP_ACC(10, na >= 3 ? 1 : 0);
                 if (na) {
-                    if (n + na > BEAM_CAP) {
+                    if (n + na > (64 * NB)) {
                         UP_ACC(11, 1);
                         // ---- compaction: f = ef-th smallest distance image in B (32-step radix select by ballots), drop what is farther
                         uint32_t prefix = 0;
@@ -484,14 +485,14 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                             const uint32_t hi_mask = b == 31 ? 0u : (0xFFFFFFFFu << (b + 1));
                             int cnt0 = 0;
 #pragma unroll
-                            for (int r = 0; r < BREGS; ++r)
+                            for (int r = 0; r < NB; ++r)
                                 cnt0 += __popcll(__ballot((((bd[r] ^ prefix) & hi_mask) == 0u) && !((bd[r] >> b) & 1u)));
                             if (cnt0 < need) { need -= cnt0; prefix |= 1u << b; }
                         }
                         const uint32_t f = prefix;
                         int kept = 0;
 #pragma unroll
-                        for (int r = 0; r < BREGS; ++r) {
+                        for (int r = 0; r < NB; ++r) {
                             const bool keep = bd[r] <= f;
                             const unsigned long long km = __ballot(keep);
                             if (keep) {
@@ -502,7 +503,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                             kept += __popcll(km);
                         }
 #pragma unroll
-                        for (int r = 0; r < BREGS; ++r) {
+                        for (int r = 0; r < NB; ++r) {
                             const int idx = lane + 64 * r;
                             const bool in = idx < kept;
                             const uint64_t kk = in ? C[idx] : 0;
@@ -513,15 +514,15 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                         n = kept;
                         nexp = 0;
 #pragma unroll
-                        for (int r = 0; r < BREGS; ++r) nexp += __popcll(__ballot(bd[r] != SLOT_EMPTY && cdv[r] == SLOT_EMPTY));
+                        for (int r = 0; r < NB; ++r) nexp += __popcll(__ballot(bd[r] != SLOT_EMPTY && cdv[r] == SLOT_EMPTY));
                         fbound = min(fbound, f);
-                        if (n + na > BEAM_CAP) { overflow = true; break; }
+                        if (n + na > (64 * NB)) { overflow = true; break; }
                         ru_valid = beam_best_id(cdv, bi, ru_o, ru_id);  // may have been dropped
                         if (ru_valid) rowr = load_row(ru_id);
                         ru_closer = 0;
                         if (nexp >= ef) {
 #pragma unroll
-                            for (int r = 0; r < BREGS; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
+                            for (int r = 0; r < NB; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
                         }
                     }
                     if (nexp >= ef) ru_closer += __popcll(accepted & __ballot(od < ru_o));
@@ -535,7 +536,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                         const bool got = rel < na;
                         const int reg = (n + rel) >> 6;
 #pragma unroll
-                        for (int r = 0; r < BREGS; ++r) {
+                        for (int r = 0; r < NB; ++r) {
                             const bool w = got && reg == r;
                             bd[r] = w ? rod : bd[r];
                             bi[r] = w ? rid : bi[r];
@@ -574,20 +575,20 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                     closer = 0;
                     if (nexp >= ef) {
 #pragma unroll
-                        for (int r = 0; r < BREGS; ++r) closer += __popcll(__ballot(bd[r] < best_o));
+                        for (int r = 0; r < NB; ++r) closer += __popcll(__ballot(bd[r] < best_o));
                     }
                 }
                 if (closer >= ef) {
                     stop = true;  // `distance > furthest.distance` (index.rs:246-248)
                 } else if (take_ru) {
 #pragma unroll
-                    for (int r = 0; r < BREGS; ++r)
+                    for (int r = 0; r < NB; ++r)
                         if (bi[r] == ru_id) cdv[r] = SLOT_EMPTY;   // ids are unique in B
                     rowv = rowr;
                     ++nexp;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < BREGS; ++r)
+                    for (int r = 0; r < NB; ++r)
                         if (bi[r] == best_id) cdv[r] = SLOT_EMPTY;
                     rowv = load_row(best_id);
                     ++nexp;
@@ -601,11 +602,11 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
         {
             uint32_t m = bd[0];
 #pragma unroll
-            for (int r = 1; r < BREGS; ++r) m = min(m, bd[r]);
+            for (int r = 1; r < NB; ++r) m = min(m, bd[r]);
             m = wave_min_u32(m);
             uint32_t im = 0xFFFFFFFFu;
 #pragma unroll
-            for (int r = 0; r < BREGS; ++r) im = bd[r] == m ? min(im, bi[r]) : im;
+            for (int r = 0; r < NB; ++r) im = bd[r] == m ? min(im, bi[r]) : im;
             ep = wave_min_u32(im);
         }
     }
@@ -653,7 +654,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
 // a lookup is then an LDS read (~100 cycles) instead of a first-touch miss of a line the table kernel wrote from another XCD
 // (the L2s are not coherent: the row comes back from the Infinity Cache / HBM, ~1 k cycles, 40 % of the lookups).  Waves 1-3 only
 // help with that copy.
-template <bool TLDS>
+template <bool TLDS, int NB>
 __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* const vis = (uint32_t*)(lds + UP_LDS_VIS);
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
-    upper_traverse_wave0(a, qi, lane, lds, TLDS ? tl : tg, vis, tl + (TLDS ? a.nu_pad : 0));
+    upper_traverse_wave0<NB>(a, qi, lane, lds, TLDS ? tl : tg, vis, tl + (TLDS ? a.nu_pad : 0));
 }
 
 // The split path (batches of >= 32 queries, d = 16 n16 <= 128): ONE launch whose first b blocks traverse the layers >= 2 — ~1 k points:
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
 // straight into LDS) — while the remaining blocks are the lane = query table pass over ALL upper points (hnsw_upper_table64_kernel's
 // body) that layer 1 needs: the 35 us of that pass run on the 192 CUs the 64 traversals leave idle instead of in front of them.
 // The layer-1 launch (hnsw_upper_kernel) picks the state up: entry point and visited set in ITS numbering, counters not yet counted.
-template <int METRIC, int N16>
+template <int METRIC, int N16, int NB>
 __global__ __launch_bounds__(256, 2) void hnsw_upper_top_kernel(HnswUpArgs a, uint32_t nq, const float* __restrict__ rows_nat, uint32_t nu_all,
                                                                 uint32_t* __restrict__ table_all, uint32_t nu_all_pad, uint32_t tgx,
                                                                 unsigned long long* zero16) {
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void hnsw_upper_top_kernel(HnswUpArgs a, ui
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
-    upper_traverse_wave0(a, qi, lane, lds, tl, vis, tl + a.nu_pad);
+    upper_traverse_wave0<NB>(a, qi, lane, lds, tl, vis, tl + a.nu_pad);
 }
 
 // launch of hnsw_upper_kernel over layers layer_hi .. 1 (the last launch before layer 0: out_ep holds point ids, the bitmap as is)
@@ -732,15 +733,15 @@ static mdb_status upper_launch_bottom(mdb_ctx* ctx, const HnswUpper& up, const u
     const size_t lds_base = UP_LDS_VIS + (size_t)out.words * 4;
     const bool tlds = lds_base + (size_t)a.nu_pad * 4 <= 160 * 1024 - 512 && !ctx->opt.hnsw_table_no_lds;
     const size_t lds = lds_base + (tlds ? (size_t)a.nu_pad * 4 : 0);
-    if (tlds) {
-        if (lds > 48 * 1024)
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hnsw_upper_kernel<true><<<dim3((unsigned)b), UP_BLOCK, lds, ctx->stream>>>(a);
-    } else {
-        if (lds > 48 * 1024)
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hnsw_upper_kernel<false><<<dim3((unsigned)b), UP_BLOCK, lds, ctx->stream>>>(a);
-    }
+#define MDB_UPK_GO(TL, NBV)                                                                                                           \
+    do {                                                                                                                              \
+        if (lds > 48 * 1024)                                                                                                          \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_kernel<TL, NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hnsw_upper_kernel<TL, NBV><<<dim3((unsigned)b), UP_BLOCK, lds, ctx->stream>>>(a);                                            \
+    } while (0)
+    if (ef <= 256) { if (tlds) MDB_UPK_GO(true, 5); else MDB_UPK_GO(false, 5); }
+    else { if (tlds) MDB_UPK_GO(true, 8); else MDB_UPK_GO(false, 8); }
+#undef MDB_UPK_GO
     MDB_HIP(ctx, hipGetLastError());
     return MDB_OK;
 }
@@ -756,7 +757,7 @@ mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const D
     const uint32_t words2 = (up.nu2 / 32 + 4) & ~3u;
     const size_t lds_top = UP_LDS_VIS + (size_t)words2 * 4 + (size_t)nu2_pad * 4 + (size_t)out.words * 4;
     const bool split = up.nu2 > 0 && up.layers >= 2 && up.rows_nat.p && p.n16 > 0 && p.n16 <= 8 && p.n8 == 0 && p.n4 == 0 && p.ntail == 0 &&
-                       (long long)b >= ctx->opt.hnsw_table64_min_b && !ctx->opt.hnsw_no_split && lds_top <= 160 * 1024 - 512;
+                       (long long)b >= ctx->opt.hnsw_table64_min_b && !ctx->opt.hnsw_no_split && lds_top <= 160 * 1024 - 512 && ef <= 256;
     if (!split) {
         MDB_TRY(hnsw_upper_table(ctx, up, metric, p, d_q, qstride, b, d_table, zero16));
         return hnsw_upper_traverse(ctx, up, d_table, b, ef, out);
@@ -781,10 +782,10 @@ mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const D
 #define MDB_TOP_GO(METRIC, N)                                                                                                          \
     do {                                                                                                                               \
         if (lds_top > 48 * 1024)                                                                                                       \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_top_kernel<METRIC, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_top_kernel<METRIC, N, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                              (int)lds_top));                                                                           \
-        hnsw_upper_top_kernel<METRIC, N><<<dim3(grid), 256, lds_top, ctx->stream>>>(a, (uint32_t)b, up.rows_nat.p, up.nu, d_table, nu_pad, \
-                                                                                    tgx, zero16);                                     \
+        hnsw_upper_top_kernel<METRIC, N, 5><<<dim3(grid), 256, lds_top, ctx->stream>>>(a, (uint32_t)b, up.rows_nat.p, up.nu, d_table, nu_pad, \
+                                                                                       tgx, zero16);                                  \
     } while (0)
 #define MDB_TOP_LAUNCH(METRIC)                           \
     do {                                                 \

@@ -158,7 +158,8 @@ def test_hnsw_general_kernel_equals_beam_kernel(ctx, oracle):
     assert_result_rows(g.ann_search(q, 10, 600), o.ann_search(q, 10, 600), len(q))
 
 
-@pytest.mark.parametrize("variant", ["MDB_HNSW_PREFETCH", "MDB_HNSW_NO_ROW64", "MDB_HNSW_GENERIC_DIST", "MDB_HNSW_NO_TABLE"])
+@pytest.mark.parametrize("variant", ["MDB_HNSW_PREFETCH", "MDB_HNSW_NO_ROW64", "MDB_HNSW_GENERIC_DIST", "MDB_HNSW_NO_TABLE", "MDB_HNSW_NO_SPLIT",
+                                     "MDB_HNSW_NO_WIDE", "MDB_HNSW_TABLE_NO_LDS"])
 @pytest.mark.parametrize("d,metric", [(128, 0), (768, 1), (128, 1)])
 def test_hnsw_beam_kernel_variants_equal_oracle(ctx, oracle, d, metric, variant):
     """hnsw_beam_kernel's variants — the prefetch wave (touches the runner-up's neighbours ahead of the step that needs them),
@@ -176,7 +177,7 @@ def test_hnsw_beam_kernel_variants_equal_oracle(ctx, oracle, d, metric, variant)
     o = oracle.BlockBasedHnsw(hidx, hvec, d, oracle.Quant(oracle.QUANT_NONE, metric))
     q = (v[rng.integers(0, n, 40)] + rng.normal(0, 0.05 if metric == 1 else 4, (40, d))).astype(np.float32)
     with ctx.option(variant, 1):
-        for k, ef in [(10, 100), (5, 8), (20, 256), (10, 1), (10, 40)]:
+        for k, ef in [(10, 100), (5, 8), (20, 256), (10, 1), (10, 40), (10, 300), (20, 448)]:   # (the last two: the 8-register beam)
             want = o.ann_search(q, k, ef)
             evals, expanded = o.stats()
             got = g.ann_search(q, k, ef)
@@ -807,3 +808,30 @@ def test_reindexed_segment_sharded_x8_equals_unsharded_equals_oracle(ctx, oracle
         back = F.read_segment(os.path.join(tmp, "seg"))
         assert np.array_equal(back["reassigned"][9], mapping) and back["ivf_index"] == cat["ivf_index"]
     full.close()
+
+
+@pytest.mark.parametrize("d,metric,nq", [(128, 0, 40), (16, 1, 33), (48, 0, 7)])
+def test_hnsw_wide_beam_and_split_path_equal_oracle(ctx, oracle, d, metric, nq):
+    """The default routes of round 4 on a 5-layer graph: batches >= 32 take the split path (top layers + table pass in one launch, then
+    layer 1, then layer 0), 256 < ef <= 448 the 8-register beam, ef = 449 the general kernel — rows AND traversal counters equal the
+    oracle's everywhere, including duplicate vectors (exact ties) and ef below / at / above the beam limits."""
+    from muopdb_amd.index import BlockBasedHnsw, NoQuantizer
+    rng = np.random.default_rng(41 + d)
+    n = 4000
+    v = H.sift_like(n, d, n_clusters=16, seed=9)
+    v[n // 2:n // 2 + 200] = v[7]                      # 200 exact duplicates: ties with furthest
+    if metric == 1:
+        v = (v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-6)).astype(np.float32)
+    hidx, hvec = H.build_hnsw_files(oracle, v, list(range(n)), max_neighbors=6, max_layers=6, ef_construction=40, metric=metric, seed=3)
+    g = BlockBasedHnsw(ctx, hidx, hvec, d, NoQuantizer(d, metric))
+    o = oracle.BlockBasedHnsw(hidx, hvec, d, oracle.Quant(oracle.QUANT_NONE, metric))
+    q = (v[rng.integers(0, n, nq)] + rng.normal(0, 0.05 if metric == 1 else 4, (nq, d))).astype(np.float32)
+    q[0] = v[7]
+    for k, ef in [(10, 200), (10, 256), (10, 257), (30, 400), (10, 448), (10, 449), (5, 64)]:
+        o.stats()
+        want = o.ann_search(q, k, ef)
+        evals, expanded = o.stats()
+        got = g.ann_search(q, k, ef)
+        st = ctx.stats()
+        assert_result_rows(got, want, len(q))
+        assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded), (k, ef)
