@@ -45,7 +45,6 @@
     X(closure_block, "MDB_CLOSURE_BLOCK", 0)                                                                        \
     X(hnsw_no_beam, "MDB_HNSW_NO_BEAM", 0)                                                                          \
     X(hnsw_no_row64, "MDB_HNSW_NO_ROW64", 0)                                                                        \
-    X(hnsw_prefetch, "MDB_HNSW_PREFETCH", 0)                                                                        \
     X(hnsw_no_table, "MDB_HNSW_NO_TABLE", 0)           /* upper layers by the all-in-one traversal kernel instead of table + single-wave kernel */ \
     X(hnsw_table_qt, "MDB_HNSW_TABLE_QT", 4)          /* queries per pass of the upper-layer table kernel (2 / 4 / 8) */ \
     X(hnsw_table_no_lds, "MDB_HNSW_TABLE_NO_LDS", 0)   /* upper-layer traversal: table lookups from global memory even when the row fits LDS */ \

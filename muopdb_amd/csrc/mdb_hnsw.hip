@@ -648,15 +648,6 @@ __host__ __device__ constexpr int beam_lds_qs(int nb) { return beam_lds_c(nb) + 
 #define PIPE_CNT(slot, v) do {} while (0)
 #endif
 
-// PF (f32 rows that are whole 16-lane chunks): one more wave that takes no decision and computes nothing — it warms the cache.
-// The next node is the beam's runner-up 92 % of the time and wave 0 knows the runner-up ~0.15 us into a step, two phases before
-// it needs that node's neighbours; the gather of those neighbours' vectors from HBM is the longest single wait of a step (P3).
-// So wave 0 publishes the runner-up's id, and the prefetch wave fetches its row, drops the neighbours already visited (a plain
-// read of the set: stale answers only cost or save a touch) and touches every 128-byte line of the others' vectors while wave 0
-// is still accepting / choosing / testing: when P3 of the next step asks for them they are in L2 or on their way.  A touch is
-// a load whose value is only "used" a step later, so nothing ever waits for it.  Results and counters cannot change: the
-// wave writes nothing but its own scratch list.
-#define BEAM_PF_ROUNDS 8   // touches per lane and step (64 x 8 lines = 128 vectors of d 128, 21 of d 768)
 // ROW64: every adjacency row of the index has at most 64 edges (max_neighbors <= 32: the configurations' graphs) — a row is ONE
 // register per lane, a step has ONE chunk: the per-chunk loops, their scalar branches and three of four register copies leave
 // wave 0's chain.
@@ -664,13 +655,11 @@ __host__ __device__ constexpr int beam_lds_qs(int nb) { return beam_lds_c(nb) + 
 // visited there, takes the handed-down entry point and runs layer 0 only.
 // NB: registers of 64 beam slots — 5 (320 slots) serves ef <= 256, 8 (512 slots; layer-0 instance only) ef <= 448: both leave >= 64 slots
 // for ties with furthest before the general traversal has to take the query over.
-template <int METRIC, bool VIS_LDS, int N16T, bool PF, bool ROW64, bool L0 = false, int NB = 5>
-__global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
+template <int METRIC, bool VIS_LDS, int N16T, bool ROW64, bool L0 = false, int NB = 5>
+__global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     constexpr int NCH = ROW64 ? 1 : 4;   // 64-edge chunks of a row
-    constexpr bool SPEC = MDB_HNSW_SPEC && !PF && N16T > 0 && N16T <= 16;   // the groups' first vector is requested ahead of the list length
-    // the prefetch wave is wave 5: SIMD 1, which it shares with a distance wave that mostly waits for memory; wave 4 (it would share
-    // SIMD 0 with wave 0, whose issue slots ARE the step time) only attends the barriers
-    constexpr int BLK = PF ? HNSW_BLOCK + 128 : HNSW_BLOCK;
+    constexpr bool SPEC = MDB_HNSW_SPEC && N16T > 0 && N16T <= 16;   // the groups' first vector is requested ahead of the list length
+    constexpr int BLK = HNSW_BLOCK;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // FIXED LDS layout (compile-time offsets: the kernel is SGPR-bound, eight live LDS pointers are eight
     // scalars it does not have): W 256 keys | C 1024 keys | nb_id 256 | nb_dist 256 | misc 16 | qs dpad | vis
@@ -680,9 +669,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
     uint64_t* const C = (uint64_t*)(lds + LDS_C);  // [0..512): staging / sort buffer, [512..768) as u32 flags
     uint32_t* const nb_id = (uint32_t*)(lds + LDS_NBID);
     uint32_t* const nb_od = (uint32_t*)(lds + LDS_NBDIST);  // order-preserving images of the neighbours' distances
-    uint32_t* const misc = (uint32_t*)(lds + LDS_MISC);  // [0] nnew (0xFFFFFFFF = stop), [2] wsize, [3] overflow,
-                                                              // PF: [10] runner-up id (0xFFFFFFFF = none), [11] step tag of [10]
-    uint32_t* const pf_list = (uint32_t*)(C + 768);           // PF: the prefetch wave's compacted neighbour list (512 ids; C[768..) is free)
+    uint32_t* const misc = (uint32_t*)(lds + LDS_MISC);  // [0] nnew (0xFFFFFFFF = stop), [2] wsize, [3] overflow
     float* const qs = (float*)(lds + LDS_QS);
     uint32_t* vis = VIS_LDS ? (uint32_t*)(lds + LDS_QS + (size_t)a.dpad * 4) : (a.vis_global + (size_t)blockIdx.x * a.vis_words);
     uint32_t* const stage_flag = (uint32_t*)(C + 512);
@@ -742,21 +729,17 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
     uint32_t evals = 0, expanded = 0;  // per query: far below 2^32
     bool nan_seen = false, overflow = L0 ? a.up_ovf[qi] != 0u : false;
     uint32_t ep = L0 ? a.up_ep[qi] : u.entry_point;
-    uint32_t sg = 0;                   // PF: step tag (every wave counts alike)
 #ifdef MDB_PIPE_DBG
     unsigned long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     // L0TOUCH (layer-0 instance, rows of one register, f32 vectors of at most 8 lines): wave 0 touches the runner-up's unvisited
     // neighbours' vectors in its barrier slack (see the shadow below)
-    constexpr bool L0TOUCH = L0 && ROW64 && !PF && N16T > 0 && N16T <= 16 && MDB_HNSW_L0TOUCH;
+    constexpr bool L0TOUCH = L0 && ROW64 && N16T > 0 && N16T <= 16 && MDB_HNSW_L0TOUCH;
     constexpr int L0_LINES = L0TOUCH ? (N16T + 1) / 2 : 1;   // 128-byte lines per vector
     float l0_hold[L0_LINES];
     uint32_t row_hold = 0;
 #pragma unroll
     for (int t = 0; t < L0_LINES; ++t) l0_hold[t] = 0.0f;
-    float pf_hold[BEAM_PF_ROUNDS];     // PF: the touched words, "used" one step later
-#pragma unroll
-    for (int r = 0; r < BEAM_PF_ROUNDS; ++r) pf_hold[r] = 0.0f;
 
     for (int layer = L0 ? 0 : (int)u.num_layers - 1; layer >= 0; --layer) {
         const uint32_t stride = layer == 0 ? u.S0 : u.SU;
@@ -837,9 +820,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
             stop = false;
             ru_valid = false;
             evals += 1;
-            if (PF && lane == 0) misc[11] = 0;
         }
-        sg = 0;
         for (;;) {
             // ---- P2 (wave 0): visited test-and-set + ordered compaction of the popped node's row
             PIPE_TB(t_p2);
@@ -885,20 +866,11 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
             }
             const uint32_t nnew = misc[0];
             if (nnew == 0xFFFFFFFFu) break;
-            ++sg;
             if (wave == 0) PIPE_CNT(5, 1);
-            uint32_t pf_row[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) pf_row[c] = 0xFFFFFFFFu;
             if (wave == 0) {
                 // ---- in the shadow of P3: the best candidate already in B (the next pop unless a neighbour
                 // accepted below beats it) and, speculatively, its adjacency row
                 ru_valid = beam_best_id(cdv, bi, ru_o, ru_id);
-                if (PF) {
-                    if (lane == 0) misc[10] = ru_valid ? ru_id : 0xFFFFFFFFu;
-                    asm volatile("" ::: "memory");
-                    if (lane == 0) lds_vstore(misc + 11, sg);
-                }
                 if (ru_valid) {
                     load_row(ru_id, rowr);
                     // the stop test of the runner-up (92 % of the pops), minus the neighbours this step will add: wave 0 would only
@@ -925,14 +897,7 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
                         }
                     }
                 }
-            } else if (PF && wave == 5) {
-                // ---- prefetch wave: the runner-up's row, requested as soon as wave 0 names it (it arrives around the barrier)
-                while (lds_vload(misc + 11) != sg) __builtin_amdgcn_s_sleep(1);
-                asm volatile("" ::: "memory");
-                const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[10]);
-                PIPE_TE(6, t_sh);
-                if (rid != 0xFFFFFFFFu) load_row(rid, pf_row);
-            } else if (!PF || wave <= 3) {
+            } else {
                 // ---- P3 (waves 1-3): exact distances, one 16-lane group per neighbour
                 // (the groups also take the order-preserving integer image and the NaN check off wave 0's path)
                 constexpr int NG = (HNSW_BLOCK - 64) / 16;
@@ -994,40 +959,6 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
             __syncthreads();
             if (wave == 0) PIPE_TE(3, t_b2);
             PIPE_TB(t_p4);
-            if (PF && wave == 5) {
-#ifdef MDB_PIPE_DBG
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-                PIPE_TE(7, t_p4);
-                // ---- prefetch wave, while wave 0 runs P4 and the next P2: touch the unvisited neighbours' vectors
-                constexpr int LPV = N16T > 0 ? N16T / 2 : 1;   // 128-byte lines per vector
-#pragma unroll
-                for (int r = 0; r < BEAM_PF_ROUNDS; ++r) asm volatile("" ::"v"(pf_hold[r]));   // last step's touches end here
-                uint32_t cnt = 0;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (ROW64 || (uint32_t)(64 * c) < stride) {
-                        const uint32_t nbr = pf_row[c];
-                        bool want = nbr != 0xFFFFFFFFu;
-                        if (VIS_LDS && want) want = !((vis[nbr >> 5] >> (nbr & 31)) & 1u);
-                        const unsigned long long bal = __ballot(want);
-                        if (want) pf_list[cnt + __popcll(bal & lt_mask)] = nbr;
-                        cnt += __popcll(bal);
-                    }
-                }
-                const uint32_t touches = cnt * LPV;
-                if (touches) {
-                    // branch-free: a lane without a touch of its own repeats touch 0 (same address as lane 0's: one request)
-#pragma unroll
-                    for (int r = 0; r < BEAM_PF_ROUNDS; ++r) {
-                        uint32_t t = lane + 64 * r;
-                        t = t < touches ? t : 0u;
-                        pf_hold[r] = vecs[(size_t)pf_list[t / LPV] * a.dpad + (t % LPV) * 32];
-                    }
-                }
-                PIPE_TE(8, t_p4);
-                PIPE_CNT(10, touches);
-            }
             // ---- P4 (wave 0): accept + push, then choose the next node
             if (wave == 0) {
                 uint32_t best_o = SLOT_EMPTY, best_id = 0;  // best accepted neighbour in pop order
@@ -1250,7 +1181,6 @@ __global__ __launch_bounds__(PF ? HNSW_BLOCK + 128 : HNSW_BLOCK) void hnsw_beam_
         }
     }
     __syncthreads();
-    if (PF && wave >= 4) return;   // the fall-back below is written for HNSW_BLOCK threads
     // > ~120 exact distance ties with furthest overflow the 320-slot beam: this block re-runs its query with
     // the general algorithm (sorted LDS sets, room for ~800 ties); rows and counters come from that run
     if (misc[3]) {
@@ -1713,41 +1643,38 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     } while (0)
     // specialised distance when the whole vector is 16-lane chunks (d = 128 / 768: the configs' dims)
     const int nf = (kind != MDB_QUANT_PQ && a.p.n8 == 0 && a.p.n4 == 0 && a.p.ntail == 0 && !ctx->opt.hnsw_generic_dist) ? a.p.n16 : 0;
-#define MDB_BEAM_LAUNCH(METRIC, VL, NF, PF, R64)                                                                                   \
+#define MDB_BEAM_LAUNCH(METRIC, VL, NF, R64)                                                                                   \
     do {                                                                                                                    \
         if (lds > 48 * 1024)                                                                                                \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF, PF, R64>,                             \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF, R64>,                             \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hnsw_beam_kernel<METRIC, VL, NF, PF, R64><<<dim3((unsigned)b), (PF) ? HNSW_BLOCK + 128 : HNSW_BLOCK, lds, ctx->stream>>>(a); \
+        hnsw_beam_kernel<METRIC, VL, NF, R64><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a); \
     } while (0)
 #define MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, NBV)                                                                            \
     do {                                                                                                                    \
         if (lds > 48 * 1024)                                                                                                \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF, false, true, true, NBV>,         \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_beam_kernel<METRIC, VL, NF, true, true, NBV>,         \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hnsw_beam_kernel<METRIC, VL, NF, false, true, true, NBV><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);   \
+        hnsw_beam_kernel<METRIC, VL, NF, true, true, NBV><<<dim3((unsigned)b), HNSW_BLOCK, lds, ctx->stream>>>(a);   \
     } while (0)
-#define MDB_BEAM_LAUNCH_L0(METRIC, VL, NF, PF)                                                                              \
+#define MDB_BEAM_LAUNCH_L0(METRIC, VL, NF)                                                                              \
     do {                                                                                                                    \
         if (ef <= 256) MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, 5); else MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, 8);                 \
     } while (0)
 #define MDB_HNSW_LAUNCH(METRIC, VL)                                                                              \
     do {                                                                                                           \
         if (table) {                                                                                               \
-            if (nf == 8) MDB_BEAM_LAUNCH_L0(METRIC, VL, 8, false);                                                 \
-            else if (nf == 48) MDB_BEAM_LAUNCH_L0(METRIC, VL, 48, false);                                          \
-            else MDB_BEAM_LAUNCH_L0(METRIC, VL, 0, false);                                                         \
-        } else if (beam && prefetch) {                                                                             \
-            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, true, true);                                               \
-            else MDB_BEAM_LAUNCH(METRIC, VL, 48, true, true);                                                      \
+            if (nf == 8) MDB_BEAM_LAUNCH_L0(METRIC, VL, 8);                                                 \
+            else if (nf == 48) MDB_BEAM_LAUNCH_L0(METRIC, VL, 48);                                          \
+            else MDB_BEAM_LAUNCH_L0(METRIC, VL, 0);                                                         \
         } else if (beam && row64) {                                                                                \
-            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, false, true);                                              \
-            else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48, false, true);                                       \
-            else MDB_BEAM_LAUNCH(METRIC, VL, 0, false, true);                                                      \
+            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, true);                                              \
+            else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48, true);                                       \
+            else MDB_BEAM_LAUNCH(METRIC, VL, 0, true);                                                      \
         } else if (beam) {                                                                                         \
-            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, false, false);                                             \
-            else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48, false, false);                                      \
-            else MDB_BEAM_LAUNCH(METRIC, VL, 0, false, false);                                                     \
+            if (nf == 8) MDB_BEAM_LAUNCH(METRIC, VL, 8, false);                                             \
+            else if (nf == 48) MDB_BEAM_LAUNCH(METRIC, VL, 48, false);                                      \
+            else MDB_BEAM_LAUNCH(METRIC, VL, 0, false);                                                     \
         } else if (nf == 8) MDB_HNSW_LAUNCH4(METRIC, VL, 8);                                                       \
         else if (nf == 48) MDB_HNSW_LAUNCH4(METRIC, VL, 48);                                                       \
         else MDB_HNSW_LAUNCH4(METRIC, VL, 0);                                                                      \
@@ -1790,13 +1717,11 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     // the table path's kernels exist with an 8-register beam as well (512 slots): ef up to 448 (SearchParams.ef_construction is the
     // caller's, rs/config/src/search_params.rs:1-34) stays off the general kernel, which is 3x slower per expansion
     const bool beam_wide = ef > 256 && ef <= 448 && !ctx->opt.hnsw_no_beam && !ctx->opt.hnsw_no_wide;
-    // hnsw_beam_kernel with its prefetch wave (see the kernel): f32 rows of whole 16-lane chunks
     const bool row64 = max_stride <= 64 && !ctx->opt.hnsw_no_row64;   // hnsw_beam_kernel's one-chunk specialisation
-    const bool prefetch = beam && row64 && (nf == 8 || nf == 48) && ctx->opt.hnsw_prefetch;   // OPT-IN: measured slower
     // upper layers on the distance table (mdb_hnsw_upper.hip): table pass, single-wave traversal, then the layer-0 instance of
     // the beam kernel.  One graph (no per-query user), f32 rows; the table is b * nu words of scratch
     const uint32_t nu_pad = (uint32_t)upper.tiles.ntiles * MDB_TILE;
-    const bool table = upper.nu > 0 && !d_q_user && (beam || beam_wide) && row64 && !prefetch && kind != MDB_QUANT_PQ && !ctx->opt.hnsw_no_table &&
+    const bool table = upper.nu > 0 && !d_q_user && (beam || beam_wide) && row64 && kind != MDB_QUANT_PQ && !ctx->opt.hnsw_no_table &&
                        (long long)b >= ctx->opt.hnsw_table_min_b && (uint64_t)b * nu_pad * 4 <= ((uint64_t)2 << 30) &&
                        (size_t)(upper.nu / 32 + 4) * 4 <= 96 * 1024;
     if (table) {

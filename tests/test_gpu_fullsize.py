@@ -118,7 +118,7 @@ def test_c2_hnsw_1m_ef200(ctx, oracle, base, flat_1m, hnsw_1m):
     st = ctx.stats()
     assert rows_of(ores, 24) == whole[:24]
     assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)             # same traversal, step for step
-    for variant in ("MDB_HNSW_PREFETCH", "MDB_HNSW_NO_ROW64", "MDB_HNSW_NO_TABLE"):   # the prefetch wave (opt-in); rows of any length; the all-in-one kernel
+    for variant in ("MDB_HNSW_NO_ROW64", "MDB_HNSW_NO_TABLE"):   # rows of any length; the all-in-one kernel
         with ctx.option(variant, 1):
             pres = g.ann_search(q[:64], K, 200)
             assert rows_of(pres, 64) == whole

@@ -158,12 +158,11 @@ def test_hnsw_general_kernel_equals_beam_kernel(ctx, oracle):
     assert_result_rows(g.ann_search(q, 10, 600), o.ann_search(q, 10, 600), len(q))
 
 
-@pytest.mark.parametrize("variant", ["MDB_HNSW_PREFETCH", "MDB_HNSW_NO_ROW64", "MDB_HNSW_GENERIC_DIST", "MDB_HNSW_NO_TABLE", "MDB_HNSW_NO_SPLIT",
+@pytest.mark.parametrize("variant", ["MDB_HNSW_NO_ROW64", "MDB_HNSW_GENERIC_DIST", "MDB_HNSW_NO_TABLE", "MDB_HNSW_NO_SPLIT",
                                      "MDB_HNSW_NO_WIDE", "MDB_HNSW_TABLE_NO_LDS"])
 @pytest.mark.parametrize("d,metric", [(128, 0), (768, 1), (128, 1)])
 def test_hnsw_beam_kernel_variants_equal_oracle(ctx, oracle, d, metric, variant):
-    """hnsw_beam_kernel's variants — the prefetch wave (touches the runner-up's neighbours ahead of the step that needs them),
-    rows of any length (NO_ROW64), the generic distance cascade and the all-in-one kernel (NO_TABLE: the default route takes the
+    """hnsw_beam_kernel's variants — rows of any length (NO_ROW64), the generic distance cascade and the all-in-one kernel (NO_TABLE: the default route takes the
     upper layers through the distance table + hnsw_upper_kernel) — must give the oracle's rows AND counters: no speculative
     touch may be counted."""
     from muopdb_amd.index import BlockBasedHnsw, NoQuantizer

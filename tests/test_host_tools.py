@@ -52,3 +52,50 @@ def test_bench_gpus_flag_never_runs_fewer_ranks_silently():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 2 and "WORLD_SIZE=1" in p.stderr
+
+
+def _shared_build_worker(rank, world, port, tmp, out):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), MDB_BENCH_TMP=tmp)
+    import numpy as np
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    env = object.__new__(bench.Env)
+    env.rank, env.world = rank, world
+    calls = []
+
+    def build():
+        calls.append(rank)
+        return dict(index=bytes(range(256)) * 4096, vectors=np.arange(1 << 19, dtype=np.uint8).reshape(-1), codebook=np.arange(24, dtype=np.float32),
+                    n=12345, name="c5")
+
+    got, cleanup = env.shared_build("unit", build)
+    ok = (calls == ([0] if rank == 0 else [])                                    # ONE builder per job
+          and bytes(np.ascontiguousarray(got["index"]).tobytes()) == bytes(range(256)) * 4096
+          and np.array_equal(np.asarray(got["vectors"]), np.arange(1 << 19, dtype=np.uint8))
+          and np.array_equal(got["codebook"], np.arange(24, dtype=np.float32)) and got["n"] == 12345 and got["name"] == "c5")
+    base = os.path.join(tmp, "mdb_bench_%s_unit" % port)
+    there = os.path.isdir(base)
+    cleanup()
+    dist.barrier()
+    out.put((rank, ok, there, os.path.isdir(base)))
+    dist.destroy_process_group()
+
+
+def test_bench_shared_build_one_builder_per_job(tmp_path):
+    """bench.py's Env.shared_build under world_size-2 gloo: rank 0 builds, both ranks read the same bytes (memory-mapped files under
+    MDB_BENCH_TMP), the small values travel by pickle, cleanup removes the directory after every rank has loaded."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_shared_build_worker, args=(r, 2, port, str(tmp_path), out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok and there and not after for _, ok, there, after in res), res
