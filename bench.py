@@ -763,6 +763,7 @@ def run_c5_full(env, steps=None, warm=None):
                                      scored_per_query=m["scored"] / (steps * batch)))
     finish(out, m["disp"], m["abytes"] / steps)
     out["steps"], out["warmup"] = steps, warm
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("c5full", out["config"])
     if env.cpu:
         import oracle
         o = oracle.BlockBasedIvf(full["index"], full["vectors"], oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, full["codebook"]))
@@ -773,6 +774,7 @@ def run_c5_full(env, steps=None, warm=None):
             lambda r, m_: all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(m_, 256))),
             "%d queries, one thread")
     ivf.close()
+    env.c5_full = full   # run_c5 reads rank 0's shard of 8 out of the same files instead of generating its own
     return out
 
 
@@ -823,8 +825,9 @@ def run_c5_sharded(env, steps=None, warm=None):
 
 
 def run_c5(env, steps=None, warm=None):
-    """BASELINE config C5 as ONE GPU of the 8 sees it: rank 0's shard (posting lists l % 8 == 0) of a 100M x 128 index
-    stored as 16-byte PQ codes, the FULL coarse quantizer (65 536 centroids, replicated), nprobe 64, batch 4096."""
+    """BASELINE config C5 as ONE GPU of the 8 sees it: rank 0's share (size-balanced owners, 1/8 of the entries) of the posting lists
+    of a 100M x 128 index stored as 16-byte PQ codes, loaded from the WHOLE index's files the way a rank of the 8-GPU job loads them,
+    the FULL coarse quantizer (65 536 centroids, replicated), nprobe 64, batch 4096."""
     from muopdb_amd import build as B, synth as S
     from muopdb_amd.index import BlockBasedIvf
     args, ctx = env.args, env.ctx
@@ -833,16 +836,27 @@ def run_c5(env, steps=None, warm=None):
     steps, warm = steps or args.steps, args.warmup if warm is None else warm
     total = args.n or 100_000_000
     t0 = time.time()
-    sh = S.c5_shard(ctx, total=total, world=8, rank=0, nlist=args.nlist or 65536, log=log)
-    log("C5 shard build %.1fs: %d vectors in %d owned lists" % (time.time() - t0, sh["n"], sh["owned_lists"]))
-    ivf = BlockBasedIvf(ctx, sh["index"], sh["vectors"], sh["pq"])
+    full = getattr(env, "c5_full", None)
+    if full is None or full["n"] != total:   # (c5_full_1gpu leaves its files behind when it ran first)
+        full = S.c5_index(ctx, total=total, world=1, rank=0, nlist=args.nlist or 65536, log=log)
+        torch.cuda.empty_cache()
+    # what rank 0 of an 8-rank job loads from the whole index's files (size-balanced owners, mdb_ivf_load(.., 0, 8)) — exactly what
+    # run_c5_sharded's ranks do
+    ivf = BlockBasedIvf(ctx, full["index"], full["vectors"], full["pq"], shard_rank=0, shard_world=8)
+    from muopdb_amd import distributed as D0
+    owner = np.asarray(D0.balanced_owners(full["list_sizes"], 8))
+    sh = dict(full, n=int(ivf.num_resident_vectors()), owned_lists=int(((owner == 0) & (full["list_sizes"] > 0)).sum()))
+    assert sh["n"] == int(full["list_sizes"][owner == 0].sum()), "the library's owner rule and distributed.balanced_owners differ"
+    owner_rule = "size-balanced owners"
+    env.c5_full = full = None
+    log("C5 shard build+load %.1fs: %d vectors in %d owned lists" % (time.time() - t0, sh["n"], sh["owned_lists"]))
     queries = sh["gen"].draw((steps + warm) * batch, seed=5000).contiguous()
     dump(args, env.rank, "c5", index=sh["index"], vectors=sh["vectors"], **{"queries.f32": queries.cpu().numpy(), "codebook.f32": sh["codebook"]})
     m = ivfpq_measure(env, ivf, None, queries, batch, k, P, steps, warm)
     out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=None, scaling="strong",
-               config={"workload": "C5 per-GPU: rank 0's shard (lists l %% 8 == 0: %d vectors, %d lists) of a %d x 128 SiftLike index as 16-byte PQ "
+               config={"workload": "C5 per-GPU: rank 0's shard (%s: %d vectors, %d lists) of a %d x 128 SiftLike index as 16-byte PQ "
                                    "codes, full coarse quantizer nlist=%d, nprobe=%d, batch=%d, top-%d"
-                                   % (sh["n"], sh["owned_lists"], total, sh["nlist"], P, batch, k),
+                                   % (owner_rule, sh["n"], sh["owned_lists"], total, sh["nlist"], P, batch, k),
                        "n": sh["n"], "dim": 128, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": "lowrank"},
                roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
@@ -885,15 +899,6 @@ def run_c5(env, steps=None, warm=None):
                                  dispersion=env.last_dispersion,
                                  coarse_centroids=count, note="coarse search over 1/8 of the centroids + merge of 8 coarse rows + search_shard with the "
                                  "probes; excludes the two all-gathers (8 x 8 P and 8 x (8 k + 5) bytes per query: latency-bound on xGMI, needs 8 devices)")
-    if env.cpu:
-        import oracle
-        o = oracle.BlockBasedIvf(sh["index"], sh["vectors"], oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, sh["codebook"]))
-        qh = queries[warm * batch:].cpu().numpy()
-        out["cpu_baseline"] = cpu_baseline(
-            lambda m_: o.search(qh[:m_], k, num_probes=P, threads=1), lambda m_, t: o.search(qh[:m_], k, num_probes=P, threads=t), len(qh),
-            args.cpu_seconds, min(16, len(qh)),
-            lambda r, m_: all(r.doc_ids(i) == [int(v) for v in m["found"][i][:int(r.counts[i])]] for i in range(min(m_, 256))),
-            "%d queries, one thread")
     ivf.close()
     return out
 
@@ -1105,8 +1110,8 @@ def print_plan(args):
                          host_private_gb=0.3, host_shared_gb=3.9, host_rank0_peak_gb=12.0, hbm_per_rank_gb=3.9 + 1.6 / w + 0.3,
                          note="the other ranks wait at a barrier for ~80 s: well inside the process group's timeout (10 min)"))
     else:
-        rows.append(dict(workload="c5_shard_per_gpu", builder="the process", build_s=50, load_s=1, host_private_gb=1.5, host_shared_gb=0, hbm_per_rank_gb=1.0))
         rows.append(dict(workload="c5_full_1gpu", builder="the process", build_s=66, load_s=1, host_private_gb=12.0, host_shared_gb=0, hbm_per_rank_gb=4.5))
+        rows.append(dict(workload="c5_shard_per_gpu", builder="the process (reads c5_full_1gpu's files)", build_s=0, load_s=2, host_private_gb=12.0, host_shared_gb=0, hbm_per_rank_gb=1.0))
         rows.append(dict(workload="spann_c4_full_1024u", builder="the process", build_s=35, load_s=4, host_private_gb=62.0, host_shared_gb=0, hbm_per_rank_gb=61.4))
         rows.append(dict(workload="hnsw_c2_insert_graph", builder="the process", build_s=60, load_s=3, host_private_gb=0.8, host_shared_gb=0, hbm_per_rank_gb=2.4))
     total_s = sum(r["build_s"] + r["load_s"] for r in rows) + 60   # + timed regions, dispersion, recall / ground truth
@@ -1167,10 +1172,10 @@ def main():
                 plan.append(("spann_c4_full_sharded", lambda: run_spann(env, users=1024, no_sweep=True, steps=min(args.steps, 10), warm=min(args.warmup, 3))))
             if not args.no_c5_full:
                 plan.append(("c5_sharded", lambda: run_c5_sharded(env, steps=min(args.steps, 6), warm=min(args.warmup, 2))))
-        if world == 1 and not args.no_c5:  # one GPU's share of C5 (a 1/8 shard of 100M x 16-byte codes: ~50 s of build)
-            plan.append(("c5_shard_per_gpu", lambda: run_c5(env, steps=min(args.steps, 8), warm=min(args.warmup, 2))))
         if world == 1 and not args.no_c5_full:  # the whole of C5 on one GPU: the N = 1 anchor of its strong scaling
             plan.append(("c5_full_1gpu", lambda: run_c5_full(env, steps=min(args.steps, 6), warm=min(args.warmup, 2))))
+        if world == 1 and not args.no_c5:  # one GPU's share of C5: rank 0's 1/8 of the lists, read from c5_full_1gpu's files when it ran
+            plan.append(("c5_shard_per_gpu", lambda: run_c5(env, steps=min(args.steps, 8), warm=min(args.warmup, 2))))
         if world == 1 and not args.no_c4_full:  # the whole of C4 on one GPU: 1024 users x 9766 x 768 = 30.7 GB resident (~60 s of build + load)
             plan.append(("spann_c4_full_1024u", lambda: run_spann(env, users=1024, no_sweep=True, steps=min(args.steps, 10), warm=min(args.warmup, 3))))
         if world == 1 and not args.no_insert_graph:  # C2 again on a graph built the way MuopDB builds it (HnswBuilder::insert)

@@ -241,7 +241,7 @@ def c5_index(ctx, total=100_000_000, world=8, rank=0, nlist=65536, d=128, chunk=
     are generated chunk by chunk (SiftLike), assigned to their nearest of the nlist centroids and quantized ON THE DEVICE
     (mdb_pq_quantize_mem: the f32 rows never leave HBM); only the rows of owned lists are kept — the other ranks' lists are EMPTY in
     the returned index file, so loading it unsharded reproduces this rank's work exactly.
-    Returns dict(index, vectors, pq, codebook, gen, n, nlist, owned_lists, centroids)."""
+    Returns dict(index, vectors, pq, codebook, gen, n, nlist, owned_lists, centroids, list_sizes)."""
     import torch
     from .index import ProductQuantizer
     from . import build as B
@@ -289,7 +289,7 @@ def c5_index(ctx, total=100_000_000, world=8, rank=0, nlist=65536, d=128, chunk=
     docs = np.arange(n, dtype=np.uint64) * np.uint64(world) + np.uint64(rank)
     index = F.write_ivf_index(cent.cpu().numpy(), docs, pls, quantized_dimension=d // 8)
     return dict(index=index, vectors=F.write_vector_file(codes), pq=pq, codebook=cb, gen=gen, n=n, nlist=nlist,
-                owned_lists=int((np.diff(bounds) > 0).sum()), centroids=cent)
+                owned_lists=int((np.diff(bounds) > 0).sum()), centroids=cent, list_sizes=np.diff(bounds).astype(np.int64))
 
 
 c5_shard = c5_index   # rounds 1-3's name (world = 8: a rank's shard)
