@@ -33,6 +33,9 @@
     X(mf_f32, "MDB_MF_F32", 0)                         /* L: f32-MFMA filter instead of bf16 x 3 */                 \
     X(mf_dbg, "MDB_MF_DBG", 0)                                                                                      \
     X(bf_qb, "MDB_BF_QB", 4)                           /* max query blocks of 32 per filter block */                \
+    X(bf_x1, "MDB_BF_X1", 1)                           /* bf16 filter with ONE product per pair: 0 never, 1 L2 stores, 2 always */ \
+    X(bf_block_min_b, "MDB_BF_BLOCK_MIN_B", 512)        /* batches from here on: the block-shared x 1 filter (d <= 128) */ \
+    X(bf_no_full_bound, "MDB_BF_NO_FULL_BOUND", 0)      /* the block-shared filter takes its bound from the 1/4 sample again */ \
     X(bf_exact_sample, "MDB_BF_EXACT_SAMPLE", 0)                                                                    \
     X(refine_wave_min_b, "MDB_REFINE_WAVE_MIN_B", 512)                                                              \
     X(refine_slices, "MDB_REFINE_SLICES", 0)                                                                        \
@@ -65,6 +68,7 @@
     X(pq_eager_trim, "MDB_PQ_EAGER_TRIM", 1)                                                                        \
     X(pq_no_quantize8, "MDB_PQ_NO_QUANTIZE8", 0)       /* one wave per (vector, subspace) for every codebook */     \
     X(pq_two_phase_min_b, "MDB_PQ_TWO_PHASE_MIN_B", 512)                                                            \
+    X(pq_sdc_max_mb, "MDB_PQ_SDC_MAX_MB", 64)          /* code-to-code row-sum table of an L2 PQ index up to this size (0: never) */ \
     X(pq_no_two_phase, "MDB_PQ_NO_TWO_PHASE", 0)                                                                    \
     X(pq3_blocks, "MDB_PQ3_BLOCKS", 512)                                                                            \
     X(pq3_cap, "MDB_PQ3_CAP", 2048)                                                                                 \
@@ -266,6 +270,7 @@ inline TileView view_of(const TileStore& t) { return TileView{t.data.p, t.n, t.n
 struct PqDev {
     int metric = 0, dimension = 0, subdim = 0, num_bits = 0, m = 0, K = 0;
     DevBuf<float> codebook;            // [m][K][subdim]
+    DevBuf<float> sdc;                 // [m][K][K] (optional, ivf_sdc_build): row sums of code a against code c per subspace
     std::vector<float> h_codebook;
 };
 

@@ -142,7 +142,7 @@ __device__ __forceinline__ void bf16_split8(const float (&x)[8], uint4& hi, uint
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         h[i] = bf16_rne(x[i]);
-        l[i] = bf16_rne(x[i] - bf16_to_f32(h[i]));   // exact subtraction (hi shares x's leading bits), then rounded: |x - hi - lo| <= 2^-18 |x|
+        l[i] = bf16_rne(x[i] - bf16_to_f32(h[i]));   // exact subtraction (hi shares x's leading bits), then rounded: |x - hi| <= 2^-8 |x|, |x - hi - lo| <= 2^-16 |x|
     }
     hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
@@ -601,11 +601,11 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
 
 // ------------------------------------------------------------------------------------------ bf16 x 3 filter
 // Same admission test as flat_mfma_filter_kernel, the dot products on the bf16 matrix cores (16x the f32-MFMA rate):
-//   q'.x' ~ qh.xh + qh.xl + ql.xh   with  v = vh + vl + r,  vh = bf16(v), vl = bf16(v - vh), |r| <= 2^-18 |v| per coordinate,
+//   q'.x' ~ qh.xh + qh.xl + ql.xh   with  v = vh + vl + r,  vh = bf16(v), vl = bf16(v - vh), |r| <= 2^-16 |v| per coordinate,
 // every bf16 x bf16 product is exact in f32 and the sums run in f32 accumulators.  What is dropped or rounded:
-//   ql.xl + qr.x + q.xr  <= 3 * 2^-18 |q'||x'| (1 + 2^-8)   (Cauchy-Schwarz on the per-coordinate bounds)
+//   ql.xl + qr.x + q.xr  <= 3 * 2^-16 |q'||x'| (1 + 2^-7)   (Cauchy-Schwarz on the per-coordinate bounds)
 //   f32 accumulation of 3d products: <= 3 d eps (|qh||xh| + |qh||xl| + |ql||xh|) <= 3.03 d eps |q'||x'|
-// and |q'||x'| <= (qn + xn) / 2, so the host widens kappa by 4 d eps + 2^-16 (> 1.01 (3 d eps + 3 * 2^-18)) and the test
+// and |q'||x'| <= (qn + xn) / 2, so the host widens kappa by 4 d eps + 2^-14 (> 1.01 (3 d eps + 3 * 2^-16)) and the test
 // stays a NECESSARY condition for membership in the top-k: a true neighbour is never dropped (NaN / inf still admit).
 // A fragments (queries, 32 rows x 16 dims per MFMA) live in LDS, converted once per block; B fragments stream from the
 // precomputed split (coalesced 16-byte loads, one k-chunk ahead of the matrix cores).  grid (nblk, query groups of 32 * QB).
@@ -615,7 +615,13 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_filter_kernel(const float4* 
 // U[m][t' * 32 + column] = approximate distance + its error budget (crow[m] holds the query's norm at that point):
 //   L2 : qn + xn - 2 acc + kappa (qn + xn)        dot: -acc + kappa (qn + xn) / 2
 // `qids` is U (as floats), `qcap` the sample size, `nt32` the sample's tile count.
-template <int METRIC, int QB, int NKT, bool SMP = false, bool APX = false>   // APX: candidates carry their products (qapx); NKT: compile-time number of 16-dim chunks (8 = d <= 128: LDS offsets become immediates), 0 = run time
+// X1: ONE bf16 product per pair (qh.xh only): a third of the matrix-core work and half of the base's bytes (the lo fragments are never
+// read), for a wider budget — what is dropped is  qr.x' + qh.xr,  |qr_i| <= 2^-8 |q'_i|, |xr_i| <= 2^-8 |x'_i|  (bf16 keeps 8 significant
+// bits, round to nearest even), so |q'.x' - qh.xh| <= 2^-7 (1 + 2^-9) |q'||x'| plus d f32 accumulations: the host's kappa carries
+// 2^-7 (1 + 2^-8) + 2 d eps instead of the x 3 split's 2^-14 + 4 d eps.  On SiftLike rows the wider test admits 1.25x (coarse quantizer,
+// k = 64 of 65 536) to 1.5x (k = 10 of 1M) the candidates of the x 3 test; the exact refine behind it returns the same rows.
+// AREG (X1, NKT > 0, QB * NKT <= 32): the block's A fragments live in registers for the whole launch (no LDS reads in the tile loop).
+template <int METRIC, int QB, int NKT, bool SMP = false, bool APX = false, bool X1 = false>   // APX: candidates carry their products (qapx); NKT: compile-time number of 16-dim chunks (8 = d <= 128: LDS offsets become immediates), 0 = run time
 __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kernel(
     const uint4* __restrict__ bhi, const uint4* __restrict__ blo, const float* __restrict__ xnorm, size_t n, size_t nt32, int nk_rt,
     const float* __restrict__ dqc, int qstride, const float* __restrict__ crow, float kappa, uint32_t* __restrict__ qcnt,
@@ -641,21 +647,49 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
         uint4 h, lo;
         bf16_split8(x, h, lo);
         Ahi[i] = h;
-        Alo[i] = lo;
+        if (!X1) Alo[i] = lo;
     }
     if (tid < BQ) Cr[tid] = crow[q0 + tid];
     __syncthreads();
     const size_t tstep = (size_t)gridDim.x * 4;
     f32x16 acc[QB];
+#ifndef MDB_BF_AREG_MAX
+#define MDB_BF_AREG_MAX 32
+#endif
+    // (the sampling epilogue needs 16 * QB more live values: its QB = 4 form spills 100 registers with the fragments resident)
+    constexpr bool AREG = X1 && NKT > 0 && QB * NKT <= (SMP ? 16 : MDB_BF_AREG_MAX);
+    constexpr int UNR = NKT ? NKT : 1;   // (the chunk loop unrolls when its trip count is a compile-time one: areg's indices become static)
+    bf16x8 areg[AREG ? QB : 1][AREG ? NKT : 1];
+    if (AREG) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kc = 0; kc < (AREG ? NKT : 1); ++kc) areg[qb][kc] = __builtin_bit_cast(bf16x8, Ahi[((size_t)qb * nk + kc) * 64 + lane]);
+    }
     size_t t = (size_t)blockIdx.x * 4 + wave;
     // B fragments stream one k-chunk ahead of the matrix cores (a whole tile ahead was measured: no faster on an L2-resident
     // base, slower on an HBM-resident one — 128 more registers halve the occupancy)
     uint4 ch, cl, nh, nl;   // current / next fragment pair
     if (t < nt32) {
         ch = bhi[(base_tile(t) * nk) * 64 + lane];
-        cl = blo[(base_tile(t) * nk) * 64 + lane];
+        if (!X1) cl = blo[(base_tile(t) * nk) * 64 + lane];
     }
     auto mma_chunk = [&](const uint4& xh_, const uint4& xl_, int kc) {
+        if (X1) {
+            const bf16x8 vbh = __builtin_bit_cast(bf16x8, xh_);
+            if (AREG) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[qb][AREG ? kc : 0], vbh, acc[qb], 0, 0, 0);
+            } else {
+                asm volatile("" ::: "memory");   // (as below: the A fragments are re-read per chunk)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    const bf16x8 va = __builtin_bit_cast(bf16x8, Ahi[((size_t)qb * nk + kc) * 64 + lane]);
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vbh, acc[qb], 0, 0, 0);
+                }
+            }
+            return;
+        }
         // the A fragments are loop invariant: without the barrier the compiler hoists all QB * nk * 2 LDS loads out of the tile
         // loop and spills (512 registers at QB = 8); they are re-read per chunk instead (2 QB ds_read_b128 per 3 QB MFMAs)
         asm volatile("" ::: "memory");
@@ -750,23 +784,210 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
         zero_acc();
         const size_t tn = t + tstep;
         const float xnt = xnorm[base_tile(t) * 32 + l31];   // issued ahead of the tile's prefetches: vmcnt counts in order
+#pragma unroll UNR
         for (int kc = 0; kc < nk; ++kc) {
             // prefetch the next fragment pair (the next tile's first when this is the last chunk)
             const bool last = kc + 1 == nk;
             const size_t pt = base_tile(last ? (tn < nt32 ? tn : t) : t);
             const size_t po = (pt * nk + (last ? 0 : kc + 1)) * 64 + lane;
             nh = bhi[po];
-            nl = blo[po];
+            if (!X1) nl = blo[po];
             __builtin_amdgcn_sched_barrier(0);
             mma_chunk(ch, cl, kc);
             __builtin_amdgcn_sched_barrier(0);
             ch = nh;
-            cl = nl;
+            if (!X1) cl = nl;
         }
         epilogue(t, xnt);
         t = tn;
     }
     if (!SMP) ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane, wapx, APX ? qapx : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------ bf16 x 1 filter, large batches
+// flat_bf16_filter_kernel<.., X1> streams every wave's B fragments straight from L2, one 16-dim chunk (4 MFMAs) ahead: with a third
+// of the x 3 kernel's matrix-core work per fragment the waves of a 4096-query coarse search wait for L2 (four MFMAs cover 60 ns of a
+// 500 ns round trip), and at full rate they would pull 17 TB/s out of it.  Here a block's four waves work on the SAME 32-vector tile
+// and on DIFFERENT queries:
+//   * a wave keeps its 32 QB queries' A fragments in registers for the whole launch (QB query blocks x 8 chunks x 4 VGPRs, converted
+//     from the centred f32 rows in the prologue: no LDS copy of the queries at all);
+//   * the tile's eight B fragments (8 KB) are fetched ONCE per block — two 16-byte loads per thread, issued a whole tile ahead —
+//     and handed round through a double-buffered LDS tile (one barrier per tile): a quarter of the L2 traffic, 8 ds_read_b128
+//     per 8 QB MFMAs, read one chunk ahead of the matrix cores.
+// Two passes over the WHOLE base, d <= 128 (eight chunks), grid (tile strides, groups of 128 QB queries):
+//   BOUND (QB = 2): no sample at all.  Every lane keeps, per accumulator, the running maximum of  acc - c(x)  over the tiles its
+//     block visits (c = xn (1 + kappa) / 2 for L2, kappa xn / 2 for dot): U'[m][block * 32 + column] = the smallest upper bound
+//     qn (1 + kappa) - 2 max  of the distances of query m to that column's vectors — the minimum over a strided SUBSET of the
+//     base.  The k-th smallest of >= 4 k subset minima has k distinct vectors at or below it (sample_bound_kernel's argument, its
+//     subsets now cover the whole base instead of a quarter of it): with 1024 subsets of 64 centroids the bound of a 64-probe
+//     coarse search sits at the ~66th true distance, and the filter pass admits ~70 candidates per query instead of ~300 from a
+//     1/4 sample — a quarter of the candidate handling and of the exact refine, and U' is 16 MB instead of 268 (C5: 4096 x 65 536).
+//   FILTER (QB = 4): the admission test first asks only WHETHER the tile holds a candidate for the query block (an add and a
+//     compare per accumulator, the lanes' verdicts OR-ed as wave masks on the scalar unit), then the bit-per-row form of
+//     flat_bf16_filter_kernel for the pairs that do.  Products, test and candidate lists are that kernel's, value for value.
+template <int METRIC, int QB, bool BOUND, bool APX>
+__global__ __launch_bounds__(256, 2) void flat_bf16x1_block_kernel(
+    const uint4* __restrict__ bhi, const float* __restrict__ xnorm, size_t n, size_t nt32, const float* __restrict__ dqc, int qstride,
+    size_t qrows, const float* __restrict__ crow, float kappa, uint32_t* __restrict__ qcnt, uint32_t* __restrict__ qids, uint32_t qcap,
+    size_t b, uint32_t* __restrict__ flags, float* __restrict__ qapx) {
+    constexpr int NK = 8, WQ = 32 * QB, BQ = 4 * WQ;   // queries per wave / per block
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint4* Bbuf = (uint4*)lds;                      // [2][NK][64]
+    float* Cr = (float*)(Bbuf + 2 * NK * 64);       // [BQ]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    uint64_t* const wbuf = (uint64_t*)(Cr + BQ) + wave * WS_CAP;
+    float* const wapx = (float*)((uint64_t*)(Cr + BQ) + 4 * WS_CAP) + wave * WS_CAP;
+    uint32_t wcnt = 0;
+    const size_t q0 = (size_t)blockIdx.y * BQ, qw = q0 + (size_t)wave * WQ;   // this wave's first query
+    // rows past the staged ones (the last group of a batch that is no multiple of BQ) repeat the last staged row; nothing of
+    // theirs is kept (m < b below)
+    bf16x8 areg[QB][NK];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const size_t row = min(qw + (size_t)(qb * 32 + l31), qrows - 1);
+        const float4* src = (const float4*)(dqc + row * (size_t)qstride + 8 * hi);
+#pragma unroll
+        for (int kc = 0; kc < NK; ++kc) {
+            const float4 f0 = src[kc * 4], f1 = src[kc * 4 + 1];
+            const uint4 h = make_uint4(bf16_rne(f0.x) | (bf16_rne(f0.y) << 16), bf16_rne(f0.z) | (bf16_rne(f0.w) << 16),
+                                       bf16_rne(f1.x) | (bf16_rne(f1.y) << 16), bf16_rne(f1.z) | (bf16_rne(f1.w) << 16));
+            areg[qb][kc] = __builtin_bit_cast(bf16x8, h);
+        }
+    }
+    for (int i = tid; i < BQ; i += 256) Cr[i] = crow[min(q0 + (size_t)i, qrows - 1)];
+    const size_t tstep = gridDim.x;
+    size_t t = blockIdx.x;
+    uint4 n0, n1;   // the next tile's fragments (tid, tid + 256 of its 512)
+    float xnn = 0.0f;
+    if (t < nt32) {
+        const uint4* src = bhi + t * (size_t)(NK * 64);
+        Bbuf[tid] = src[tid];
+        Bbuf[tid + 256] = src[tid + 256];
+        xnn = xnorm[t * 32 + l31];
+    }
+    int cur = 0;
+    f32x16 acc[QB];
+    f32x16 mx[BOUND ? QB : 1];   // BOUND: running maxima of acc - c
+    if (BOUND) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx[qb][r] = -__uint_as_float(0x7F800000u);
+    }
+    while (t < nt32) {
+        const size_t tn = t + tstep;
+        const float xnh = xnn;
+        if (tn < nt32) {
+            const uint4* src = bhi + tn * (size_t)(NK * 64);
+            n0 = src[tid];
+            n1 = src[tid + 256];
+            xnn = xnorm[tn * 32 + l31];
+        }
+        __syncthreads();   // tile t is in Bbuf[cur]; every wave is done with Bbuf[cur ^ 1]
+        const uint4* Bc = Bbuf + cur * (NK * 64) + lane;
+        uint4 bf = Bc[0], bn = bf;   // the LDS reads run one chunk ahead of the matrix cores
+#pragma unroll
+        for (int kc = 0; kc < NK; ++kc) {
+            if (kc + 1 < NK) bn = Bc[(kc + 1) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 vb = __builtin_bit_cast(bf16x8, bf);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (kc == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[qb][kc], vb, z, 0, 0, 0);
+                } else {
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[qb][kc], vb, acc[qb], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bf = bn;
+        }
+        // epilogue: D[i][j], column j = lane & 31 (vector), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query)
+        const size_t v = t * 32 + l31;
+        if (BOUND) {
+            // padded columns never win (c = +inf); a NaN / infinite norm leaves the maxima alone (v_max_f32 drops a NaN operand):
+            // such a vector is simply not one of the k the bound counts
+            const float c = v < n ? xnh * (METRIC == MDB_METRIC_L2 ? 0.5f + 0.5f * kappa : 0.5f * kappa) : __uint_as_float(0x7F800000u);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx[qb][r] = fmaxf(mx[qb][r], acc[qb][r] - c);
+        } else {
+            const float xh = METRIC == MDB_METRIC_L2 ? xnh * (0.5f - kappa) : -kappa * xnh;
+            const bool force = !(xnh < __uint_as_float(0x7F800000u));   // infinite / NaN norm: admitted for every query
+            const unsigned long long fm = __ballot(force), valid = __ballot(v < n);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                asm volatile("" ::: "memory");   // one query block's constants at a time (hoisted together they spill)
+                const float4* c4 = (const float4*)(Cr + wave * WQ + qb * 32 + 4 * hi);
+                const float4 t0 = c4[0], t1 = c4[2], t2 = c4[4], t3 = c4[6];   // rows +0..3, +8..11, +16..19, +24..27
+                f32x16 thr;
+                thr[0] = t0.x; thr[1] = t0.y; thr[2] = t0.z; thr[3] = t0.w; thr[4] = t1.x; thr[5] = t1.y; thr[6] = t1.z; thr[7] = t1.w;
+                thr[8] = t2.x; thr[9] = t2.y; thr[10] = t2.z; thr[11] = t2.w; thr[12] = t3.x; thr[13] = t3.y; thr[14] = t3.z; thr[15] = t3.w;
+                // does the tile hold a candidate for this query block at all?  One add and one compare per accumulator; the lanes'
+                // verdicts are wave masks OR-ed on the scalar unit (FCMP_UGE = !(a < b): NaN on either side admits)
+                unsigned long long any = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) any |= __builtin_amdgcn_fcmpf(acc[qb][r], xh + thr[r], 11);
+                any = (any | fm) & valid;
+                if (any != 0) {   // wave-uniform
+                    uint32_t hits = 0;   // bit r: row r of this lane's column is a candidate
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hits |= (acc[qb][r] < xh + thr[r]) ? 0u : (1u << r);
+                    if (force) hits = 0xFFFFu;
+                    if (v >= n) hits = 0;
+                    while (__ballot(hits != 0)) {   // every lane's lowest set bit per round
+                        const bool has = hits != 0;
+                        const int r = has ? __ffs((int)hits) - 1 : 0;
+                        hits &= hits - 1;
+                        const size_t m = qw + (size_t)(qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                        float av = 0.0f;
+                        if (APX) {   // this lane's accumulator r: a select tree on r's bits (as in flat_bf16_filter_kernel)
+                            float c[16];
+#pragma unroll
+                            for (int x = 0; x < 16; ++x) { c[x] = acc[qb][x]; asm volatile("" : "+v"(c[x])); }
+                            const bool b0 = r & 1, b1 = r & 2, b2 = r & 4, b3 = r & 8;
+                            const float e0 = b0 ? c[1] : c[0], e1 = b0 ? c[3] : c[2], e2 = b0 ? c[5] : c[4], e3 = b0 ? c[7] : c[6],
+                                        e4 = b0 ? c[9] : c[8], e5 = b0 ? c[11] : c[10], e6 = b0 ? c[13] : c[12], e7 = b0 ? c[15] : c[14];
+                            const float f0 = b1 ? e1 : e0, f1 = b1 ? e3 : e2, f2 = b1 ? e5 : e4, f3 = b1 ? e7 : e6;
+                            const float u0 = b2 ? f1 : f0, u1 = b2 ? f3 : f2;
+                            av = b3 ? u1 : u0;
+                        }
+                        ws_push(has && m < b, ((uint64_t)m << 32) | (uint32_t)v, wbuf, wcnt, qcnt, qids, qcap, lane, av, wapx, APX ? qapx : nullptr);
+                    }
+                }
+            }
+        }
+        if (tn < nt32) {
+            uint4* Bn = Bbuf + (cur ^ 1) * (NK * 64);
+            Bn[tid] = n0;
+            Bn[tid + 256] = n1;
+        }
+        cur ^= 1;
+        t = tn;
+    }
+    if (BOUND) {
+        // U'[m][blockIdx.x * 32 + column], row stride qcap (= 32 gridDim.x); crow still holds the query's squared norm here
+        float* __restrict__ U = (float*)qids;
+        const uint32_t lane_off = (uint32_t)(4 * hi) * qcap + blockIdx.x * 32u + (uint32_t)l31;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float4* c4 = (const float4*)(Cr + wave * WQ + qb * 32 + 4 * hi);
+            const float4 t0 = c4[0], t1 = c4[2], t2 = c4[4], t3 = c4[6];
+            const float qnr[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t mu = qw + (size_t)(qb * 32 + (r & 3) + 8 * (r >> 2));   // + 4 hi: this lane's query
+                const float u = METRIC == MDB_METRIC_L2 ? (qnr[r] + kappa * qnr[r]) - 2.0f * mx[qb][r] : 0.5f * kappa * qnr[r] - mx[qb][r];
+                if (mu + (size_t)(4 * hi) < b) (U + mu * (size_t)qcap)[lane_off] = u;
+            }
+        }
+    } else {
+        ws_flush(wbuf, wcnt, qcnt, qids, qcap, lane, wapx, APX ? qapx : nullptr);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ refine
@@ -1182,7 +1403,15 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     MDB_TRY(mdb_scratch(ctx, 9, bpadq * (size_t)qcap * 4, (void**)&qids));
     // A. bound of the k-th distance from the sample: its exact top-k (f32 route), or the k-th smallest of matrix-core upper
     //    bounds (bf16 route: no exact pass over the sample at all — the U matrix must fit 1 GiB, else the exact sample scan)
-    const size_t ns = aux.sample.n;
+    const bool x1 = use_bf16 && (ctx->opt.bf_x1 >= 2 || (ctx->opt.bf_x1 == 1 && metric == MDB_METRIC_L2));   // one bf16 product per pair (below)
+    // large batches of d <= 128: the block-shared form (flat_bf16x1_block_kernel), its bound from a pass over the WHOLE base: U' has
+    // one column per (tile stride, tile column) — 32 per block of the bound pass's grid — instead of one per sample row
+    const bool xblock = x1 && aux.nk == 8 && b >= (size_t)std::max<long long>(1, ctx->opt.bf_block_min_b);
+    constexpr size_t BX_LDS = 2 * 8 * 64 * 16 + 512 * 4 + 4 * WS_CAP * 8 + 4 * WS_CAP * 4 + 64;
+    const size_t gxb = (b + 255) / 256;   // groups of the bound pass (QB = 2: 256 queries per block)
+    const dim3 gridxb((unsigned)std::max<size_t>(1, std::min<size_t>(aux.nt32, std::max<size_t>(1, 512 / gxb))), (unsigned)gxb);
+    const bool xbound = xblock && !ctx->opt.bf_no_full_bound && k * 4 <= (size_t)gridxb.x * 32;
+    const size_t ns = xbound ? (size_t)gridxb.x * 32 : aux.sample.n;
     const bool smp_bf16 = use_bf16 && aux.sample_stride && k <= SB_SUB / 4 && b * ns * 4 <= ((size_t)1 << 30) && !ctx->opt.bf_exact_sample;
     float* umat = nullptr;
     if (smp_bf16) MDB_TRY(mdb_scratch(ctx, 12, b * ns * 4, (void**)&umat));
@@ -1200,9 +1429,14 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     //   fl(q'.x') on the matrix cores (fmaf chain): d eps |q'||x'| <= d eps (qn + xn) / 2
     //   fl(qn), fl(xn) (fmaf chains)             : d eps each
     // => a member of the true top-k passes the test when kappa >= (4d + 10) eps / (1 - d eps); 6 (d + 4) eps is used.
-    //   bf16 x 3 split (flat_bf16_filter_kernel): dropped cross terms 3 * 2^-18 and 3d f32 accumulations -> + 4 d eps + 2^-16
+    //   bf16 x 3 split (flat_bf16_filter_kernel): bf16 keeps 8 significant bits (unit roundoff 2^-8), so v = vh + vl + r with
+    //     |r| <= 2^-16 |v| per coordinate; dropped ql.xl + qr.x + q.xr <= 3 * 2^-16 (1 + 2^-7) |q'||x'| and 3d f32 accumulations
+    //     (3.03 d eps |q'||x'|); a' = qn + xn - 2 acc and 2 |q'||x'| <= qn + xn                       -> + 4 d eps + 2^-14
+    //   bf16 x 1 (X1: qh.xh only): dropped qr.x' + qh.xr <= 2^-7 (1 + 2^-9) |q'||x'|, d accumulations -> + 2 d eps + 2^-7 (1 + 2^-8)
     const float kappa = 6.0f * (float)(ts.d4 * 4 + 4) * 5.9604645e-8f +
-                        (use_bf16 ? 4.0f * (float)(aux.nk * 16) * 5.9604645e-8f + 1.52587890625e-5f : 0.0f);
+                        (!use_bf16 ? 0.0f
+                         : x1     ? 2.0f * (float)(aux.nk * 16) * 5.9604645e-8f + 0.0078125f * (1.0f + 0.00390625f)
+                                  : 4.0f * (float)(aux.nk * 16) * 5.9604645e-8f + 6.103515625e-5f);
     mfma_prep_kernel<<<dim3((unsigned)bpadq), 128, 0, ctx->stream>>>(dq, qstride, ts.d, aux.mean.p, smp_bf16 ? nullptr : skeys, scounts, (int)k,
                                                                     kappa, metric, b, dqc, crow, qcnt, ovf);   // (also clears the queries' counters and ovf)
     if (smp_bf16) {
@@ -1213,15 +1447,16 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
         dim3 grids(nblk_s, (unsigned)groups);
         const size_t ldss = (size_t)QB * aux.nk * 2048 + BQ * 4 + BF_LBUF * 8 + 64;
         const float kappa_s = kappa + 8.0f * 5.9604645e-8f;
-#define BS_LAUNCH(METRIC, QBT, NKT)                                                                                          \
+#define BS_LAUNCH1(METRIC, QBT, NKT, X1T)                                                                                    \
     do {                                                                                                                     \
         if (ldss > 48 * 1024)                                                                                                \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_bf16_filter_kernel<METRIC, QBT, NKT, true>,                   \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_bf16_filter_kernel<METRIC, QBT, NKT, true, false, X1T>,       \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss));                       \
-        flat_bf16_filter_kernel<METRIC, QBT, NKT, true><<<grids, 256, ldss, ctx->stream>>>(                                   \
+        flat_bf16_filter_kernel<METRIC, QBT, NKT, true, false, X1T><<<grids, 256, ldss, ctx->stream>>>(                       \
             aux.bhi.p, aux.blo.p, aux.xnorm.p, ts.n, snt32, aux.nk, dqc, qstride, crow, kappa_s, nullptr, (uint32_t*)umat, (uint32_t)ns, b, \
             ctx->d_flags, aux.sample_stride, nullptr);                                                                                \
     } while (0)
+#define BS_LAUNCH(METRIC, QBT, NKT) do { if (x1) BS_LAUNCH1(METRIC, QBT, NKT, true); else BS_LAUNCH1(METRIC, QBT, NKT, false); } while (0)
 #define BS_QB(METRIC, NKT)                                             \
     do {                                                               \
         if (QB == 8) BS_LAUNCH(METRIC, 8, NKT);                        \
@@ -1229,10 +1464,18 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
         else if (QB == 2) BS_LAUNCH(METRIC, 2, NKT);                   \
         else BS_LAUNCH(METRIC, 1, NKT);                                \
     } while (0)
-        if (metric == MDB_METRIC_L2) { if (aux.nk == 8) BS_QB(MDB_METRIC_L2, 8); else BS_QB(MDB_METRIC_L2, 0); }
+        if (xbound && smp_bf16) {
+            if (metric == MDB_METRIC_L2)
+                flat_bf16x1_block_kernel<MDB_METRIC_L2, 2, true, false><<<gridxb, 256, BX_LDS, ctx->stream>>>(
+                    aux.bhi.p, aux.xnorm.p, ts.n, aux.nt32, dqc, qstride, bpadq, crow, kappa_s, nullptr, (uint32_t*)umat, (uint32_t)ns, b, ctx->d_flags, nullptr);
+            else
+                flat_bf16x1_block_kernel<MDB_METRIC_DOT, 2, true, false><<<gridxb, 256, BX_LDS, ctx->stream>>>(
+                    aux.bhi.p, aux.xnorm.p, ts.n, aux.nt32, dqc, qstride, bpadq, crow, kappa_s, nullptr, (uint32_t*)umat, (uint32_t)ns, b, ctx->d_flags, nullptr);
+        } else if (metric == MDB_METRIC_L2) { if (aux.nk == 8) BS_QB(MDB_METRIC_L2, 8); else BS_QB(MDB_METRIC_L2, 0); }
         else { if (aux.nk == 8) BS_QB(MDB_METRIC_DOT, 8); else BS_QB(MDB_METRIC_DOT, 0); }
 #undef BS_QB
 #undef BS_LAUNCH
+#undef BS_LAUNCH1
         MDB_HIP(ctx, hipGetLastError());
         if (b <= 256) sample_bound_kernel<1024><<<dim3((unsigned)b), 1024, 0, ctx->stream>>>(umat, (uint32_t)ns, (int)k, kappa, metric, crow, qnorm);
         else sample_bound_kernel<256><<<dim3((unsigned)b), 256, 0, ctx->stream>>>(umat, (uint32_t)ns, (int)k, kappa, metric, crow, qnorm);
@@ -1250,19 +1493,20 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
             const unsigned nblk_b = (unsigned)std::max<size_t>(1, std::min<size_t>((aux.nt32 + 3) / 4, std::max<size_t>(1, 512 / groups)));
             dim3 gridb(nblk_b, (unsigned)groups);
             const size_t ldsb = (size_t)QB * aux.nk * 2048 + BQ * 4 + BF_LBUF * 8 + 64 + (qapx ? BF_LBUF * 4 : 0);
-#define BF_LAUNCH1(METRIC, QBT, NKT, APXT)                                                                           \
+#define BF_LAUNCH1(METRIC, QBT, NKT, APXT, X1T)                                                                      \
     do {                                                                                                             \
         if (ldsb > 48 * 1024)                                                                                        \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_bf16_filter_kernel<METRIC, QBT, NKT, false, APXT>,    \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)flat_bf16_filter_kernel<METRIC, QBT, NKT, false, APXT, X1T>, \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));               \
-        flat_bf16_filter_kernel<METRIC, QBT, NKT, false, APXT><<<gridb, 256, ldsb, ctx->stream>>>(                    \
+        flat_bf16_filter_kernel<METRIC, QBT, NKT, false, APXT, X1T><<<gridb, 256, ldsb, ctx->stream>>>(               \
             aux.bhi.p, aux.blo.p, aux.xnorm.p, ts.n, aux.nt32, aux.nk, dqc, qstride, crow, kappa, qcnt, qids, qcap, b, ctx->d_flags, 0, qapx); \
     } while (0)
-#define BF_LAUNCH(METRIC, QBT, NKT)                  \
-    do {                                             \
-        if (qapx) BF_LAUNCH1(METRIC, QBT, NKT, true); \
-        else BF_LAUNCH1(METRIC, QBT, NKT, false);    \
+#define BF_LAUNCH0(METRIC, QBT, NKT, X1T)                  \
+    do {                                                   \
+        if (qapx) BF_LAUNCH1(METRIC, QBT, NKT, true, X1T); \
+        else BF_LAUNCH1(METRIC, QBT, NKT, false, X1T);     \
     } while (0)
+#define BF_LAUNCH(METRIC, QBT, NKT) do { if (x1) BF_LAUNCH0(METRIC, QBT, NKT, true); else BF_LAUNCH0(METRIC, QBT, NKT, false); } while (0)
 #define BF_QB(METRIC, NKT)                                             \
     do {                                                               \
         if (QB == 8) BF_LAUNCH(METRIC, 8, NKT);                        \
@@ -1270,10 +1514,20 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
         else if (QB == 2) BF_LAUNCH(METRIC, 2, NKT);                   \
         else BF_LAUNCH(METRIC, 1, NKT);                                \
     } while (0)
-            if (metric == MDB_METRIC_L2) { if (aux.nk == 8) BF_QB(MDB_METRIC_L2, 8); else BF_QB(MDB_METRIC_L2, 0); }
+            if (xblock) {
+                const size_t g5 = (b + 511) / 512;
+                dim3 gridx((unsigned)std::max<size_t>(1, std::min<size_t>(aux.nt32, std::max<size_t>(1, 512 / g5))), (unsigned)g5);
+#define BX_LAUNCH(METRIC, APXT)                                                                                                      \
+    flat_bf16x1_block_kernel<METRIC, 4, false, APXT><<<gridx, 256, BX_LDS, ctx->stream>>>(aux.bhi.p, aux.xnorm.p, ts.n, aux.nt32, dqc, qstride, bpadq, \
+                                                                                         crow, kappa, qcnt, qids, qcap, b, ctx->d_flags, qapx)
+                if (metric == MDB_METRIC_L2) { if (qapx) BX_LAUNCH(MDB_METRIC_L2, true); else BX_LAUNCH(MDB_METRIC_L2, false); }
+                else { if (qapx) BX_LAUNCH(MDB_METRIC_DOT, true); else BX_LAUNCH(MDB_METRIC_DOT, false); }
+#undef BX_LAUNCH
+            } else if (metric == MDB_METRIC_L2) { if (aux.nk == 8) BF_QB(MDB_METRIC_L2, 8); else BF_QB(MDB_METRIC_L2, 0); }
             else { if (aux.nk == 8) BF_QB(MDB_METRIC_DOT, 8); else BF_QB(MDB_METRIC_DOT, 0); }
 #undef BF_QB
 #undef BF_LAUNCH
+#undef BF_LAUNCH0
 #undef BF_LAUNCH1
             MDB_HIP(ctx, hipGetLastError());
         } else {

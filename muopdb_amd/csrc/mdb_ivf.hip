@@ -696,6 +696,23 @@ __global__ __launch_bounds__(PQ2_BLOCK) void ivf_scan_pq2_kernel(ScanArgs a, con
 //     same association as the table kernel, rows taken from the codebook in L2 — and selects the top-k: identical keys.
 // A list that outgrows its capacity raises `ovf`; the one-phase kernel, launched behind it and gated on that word, then redoes
 // the batch (both launches return at once otherwise).
+// Row-sum table of the codebook against itself: sdc[s][a][c] = the f32 sum, in ivf_scan_pq3_kernel's own association, of the
+// per-element terms of code a against code c in subspace s.  MuopDB's PQ distance is SYMMETRIC (the query is quantized too,
+// quantization/pq.rs), so the 4 m K words a scan block needs are m rows of this table — a 16 KB copy out of L2 instead of 128 KB of
+// codebook reads and 32 K term evaluations per block: on a C5 shard (12 K scanned vectors per query) the build was a third of the
+// scan kernel.  Same arithmetic, same bits.
+__global__ void pq_sdc_kernel(const float* __restrict__ cb, int m, int K, int subdim, float* __restrict__ sdc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)m * K * K;
+    if (i >= total) return;
+    const size_t c = i % K, a = (i / K) % K, s = i / ((size_t)K * K);
+    const float* row = cb + (s * K + c) * subdim;
+    const float* q = cb + (s * K + a) * subdim;
+    float sum = 0.0f;
+    for (int e = 0; e < subdim; ++e) sum = __fadd_rn(sum, acc_term<MDB_METRIC_L2>(0.0f, q[e], row[e]));
+    sdc[i] = sum;
+}
+
 struct Pq3Args {
     uint32_t* cand;       // [B][nsplit][cap] slot indices (tile * 64 + lane)
     uint32_t* cand_cnt;   // [B][nsplit]
@@ -705,7 +722,8 @@ struct Pq3Args {
 
 template <int MW, int BLK, bool FULL>   // FULL: as in ivf_scan_pq2_kernel
 __global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uint32_t* __restrict__ codes, int m_rt, int nbits_rt, int subdim,
-                                                                 const float* __restrict__ cb, const uint8_t* __restrict__ qcodes, Pq3Args c3) {
+                                                                 const float* __restrict__ cb, const uint8_t* __restrict__ qcodes, Pq3Args c3,
+                                                                 const float* __restrict__ sdc) {
     const int m = FULL ? 4 * MW : m_rt, nbits = FULL ? 8 : nbits_rt;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     BlockSelect<BLK> sel;
@@ -728,6 +746,9 @@ __global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uin
     const float lo_f = 1.0f - gmar, hi_f = 1.0f + gmar;
     const int sel_mask = a.eager_trim >= 2 ? 0 : 7;   // MDB_PQ_EAGER_TRIM=2: the selector on every round (round 2's scan)
     if (tid == 0) *ccnt = 0;
+    if (sdc) {   // the query's rows of the code-to-code table (pq_sdc_kernel: the words the loop below computes)
+        for (int i = tid; i < (m << nbits); i += BLK) btab[i] = __float_as_uint(sdc[((size_t)(i >> nbits) * K + qc[i >> nbits]) * K + (i & (K - 1))]);
+    } else {
     for (int i = tid; i < m * subdim; i += BLK) {
         int s = i / subdim;
         qv[i] = cb[((size_t)s * K + qc[s]) * subdim + (i % subdim)];
@@ -745,6 +766,7 @@ __global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uin
         // (Round 2 kept a bf16 lower and a bf16 upper bound per word and added both per subspace: seven instructions per subspace
         // instead of four on a VALU-bound scan, and brackets 0.8 % wide instead of 6e-5.)
         btab[i] = __float_as_uint(sum);
+    }
     }
     __syncthreads();
 
@@ -1150,7 +1172,7 @@ __device__ __forceinline__ uint32_t block_kth_bound(const uint32_t (&v)[R], uint
 
 template <int SUBDIM, int MW, bool COARSE>
 __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, FusedArgs f, const uint32_t* __restrict__ codes,
-                                                                 const float* __restrict__ cb) {
+                                                                 const float* __restrict__ cb, const float* __restrict__ sdc) {
     constexpr int m = 4 * MW, nbits = 8, K = 256, S4 = SUBDIM / 4;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* red = (uint32_t*)lds;                        // [64]
@@ -1281,6 +1303,9 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         ppref[tid + 1] = incl;   // entries past np repeat the total
         if (tid == 0) ppref[0] = 0;
     }
+    if (sdc) {   // the query's rows of the code-to-code table (pq_sdc_kernel: the values the loop below computes)
+        for (int i = tid; i < m * K; i += PQF_BLOCK) btab[i] = sdc[((size_t)(i >> nbits) * K + qcode[i >> nbits]) * K + (i & (K - 1))];
+    } else
     for (int i = tid; i < m * K; i += PQF_BLOCK) {
         const float4* row = (const float4*)cb + (size_t)i * S4;
         const float4* q4 = (const float4*)qv + (i >> nbits) * S4;
@@ -1855,6 +1880,14 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
     // ---- re-lay the vectors list-contiguous
     if (kind == MDB_QUANT_PQ) {
         MDB_TRY(pq_upload(ctx, quant, pq));
+        {   // the code-to-code row-sum table of the symmetric L2 distance (pq_sdc_kernel), when it is small enough to stay in L2 / MALL
+            const size_t words = (size_t)pq.m * pq.K * pq.K;
+            if (metric == MDB_METRIC_L2 && words && words * 4 <= (size_t)std::max<long long>(0, ctx->opt.pq_sdc_max_mb) << 20) {
+                if (pq.sdc.alloc(words + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "PQ row-sum table alloc");
+                pq_sdc_kernel<<<dim3((unsigned)((words + 255) / 256)), 256, 0, ctx->stream>>>(pq.codebook.p, pq.m, pq.K, pq.subdim, pq.sdc.p);
+                MDB_HIP(ctx, hipGetLastError());
+            }
+        }
         if ((uint32_t)pq.m != quantized_dimension) return mdb_fail(ctx, MDB_ERR_FORMAT, "quantized_dimension != dimension / subvector_dimension");
         if ((uint32_t)pq.dimension != num_features) return mdb_fail(ctx, MDB_ERR_FORMAT, "quantizer dimension != num_features");
         mw = (pq.m + 3) / 4;
@@ -1953,7 +1986,7 @@ void IvfSet::view_of(IvfSet& src, mdb_ctx* ctx2) {
     d_index.borrow(src.d_index); d_list_tile_off.borrow(src.d_list_tile_off); d_users.borrow(src.d_users); d_tomb.borrow(src.d_tomb);
     d_slot_ids.borrow(src.d_slot_ids); d_codes.borrow(src.d_codes); d_tiles.borrow(src.d_tiles); d_cent_tiles.borrow(src.d_cent_tiles);
     pq.metric = src.pq.metric; pq.dimension = src.pq.dimension; pq.subdim = src.pq.subdim; pq.num_bits = src.pq.num_bits;
-    pq.m = src.pq.m; pq.K = src.pq.K; pq.h_codebook = src.pq.h_codebook; pq.codebook.borrow(src.pq.codebook);
+    pq.m = src.pq.m; pq.K = src.pq.K; pq.h_codebook = src.pq.h_codebook; pq.codebook.borrow(src.pq.codebook); pq.sdc.borrow(src.pq.sdc);
     mw = src.mw; ones_word = src.ones_word; max_user_vectors = src.max_user_vectors;
     flat_aux_view(src.cent_aux, cent_aux);
 }
@@ -2077,6 +2110,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         // pass over the candidates cost more than the table build they save: 0.113 vs 0.105 ms per step.)
         const size_t pq3_min_b = (size_t)std::max<long long>(0, ctx->opt.pq_two_phase_min_b);
         const bool pq3 = pq2 && metric == MDB_METRIC_L2 && direct && k <= 64 && b >= pq3_min_b && !ctx->opt.pq_no_two_phase;
+        const float* sdc_tab = ctx->opt.pq_sdc_max_mb > 0 ? pq.sdc.p : nullptr;   // (MDB_PQ_SDC_MAX_MB=0 at search time: the in-block build)
         if (pq3) {
             const size_t tgt3 = (size_t)std::max<long long>(1, ctx->opt.pq3_blocks);
             const int ns3 = (int)std::min<size_t>(std::max<size_t>((tgt3 + b - 1) / b, 1), std::min<size_t>(16, (size_t)std::max(probe_stride, 1)));
@@ -2098,7 +2132,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         if (lds3 > 48 * 1024)                                                                                                      \
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_pq3_kernel<MWT, BLKT, FULLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
         ivf_scan_pq3_kernel<MWT, BLKT, FULLT><<<dim3((unsigned)ns3, (unsigned)b), BLKT, lds3, ctx->stream>>>(a3, d_codes.p, pq.m, pq.num_bits, pq.subdim, \
-                                                                                                           pq.codebook.p, (uint8_t*)qcodes, c3);  \
+                                                                                                           pq.codebook.p, (uint8_t*)qcodes, c3, sdc_tab);  \
     } while (0)
 #define MDB_PQ3_SCAN_B(MWT, BLKT) do { if (pq_full) MDB_PQ3_SCAN_F(MWT, BLKT, true); else MDB_PQ3_SCAN_F(MWT, BLKT, false); } while (0)
 #define MDB_PQ3_SCAN(MWT) do { if (blk3 == 1024) MDB_PQ3_SCAN_B(MWT, 1024); else MDB_PQ3_SCAN_B(MWT, 512); } while (0)
@@ -2244,13 +2278,14 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
     const size_t sel_bytes = (BlockSelect<PQF_BLOCK>::lds_bytes((int)std::max(k, num_probes)) + 15) & ~(size_t)15;
     const size_t lds = (64 + 2 * (PQF_NB + 32) + 16 + 64 + 80 + 64 + 32) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * 256 * 4 + (size_t)fa.cand_words * 4 +
                        PQF_CAP * 8 + 64 * 8 * 3 + 64 * 4 + sel_bytes;
+    const float* sdc_tab = ctx->opt.pq_sdc_max_mb > 0 ? pq.sdc.p : nullptr;   // (MDB_PQ_SDC_MAX_MB=0 at search time: the in-block build)
     {
     ProfScope prof(ctx);
 #define MDB_PQF_LAUNCH(SD, MWT, CO)                                                                                                       \
     do {                                                                                                                                  \
         if (lds > 48 * 1024)                                                                                                              \
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_pq_fused_kernel<SD, MWT, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        ivf_pq_fused_kernel<SD, MWT, CO><<<dim3((unsigned)b), PQF_BLOCK, lds, ctx->stream>>>(a, fa, d_codes.p, pq.codebook.p);               \
+        ivf_pq_fused_kernel<SD, MWT, CO><<<dim3((unsigned)b), PQF_BLOCK, lds, ctx->stream>>>(a, fa, d_codes.p, pq.codebook.p, sdc_tab);      \
     } while (0)
 #define MDB_PQF_CO(SD, MWT) do { if (coarse_here) MDB_PQF_LAUNCH(SD, MWT, true); else MDB_PQF_LAUNCH(SD, MWT, false); } while (0)
 #define MDB_PQF_SD(MWT)                                       \

@@ -161,6 +161,36 @@ def test_flat_c1_dataset_and_ties(ctx, oracle):
     assert ids2[0, :4].tolist() == [0, 1, 2, 3]
 
 
+@pytest.mark.parametrize("n,d,b,k,metric", [(120_000, 128, 600, 10, 0), (90_000, 120, 1100, 20, 0), (70_000, 128, 513, 10, 1)])
+def test_flat_large_batch_block_filter_equals_exact(ctx, oracle, n, d, b, k, metric):
+    """Batches of >= 512 queries over d <= 128 take the block-shared bf16 x 1 filter (flat_bf16x1_block_kernel: a bound pass and a
+    filter pass over the whole base, a tile's B fragments through LDS, the A fragments in registers, a batch that is no multiple of
+    the query groups): rows must be bit-identical to the exact kernels', to the per-wave x 1 filter's, to the sample-bounded block
+    filter's, to the x 3 filter's and to the oracle's."""
+    from muopdb_amd.index import FlatIndex
+    rng = np.random.default_rng(n + b)
+    base = H.sift_like(n, d, n_clusters=60, seed=n)
+    q = (base[rng.integers(0, n, b)] + rng.normal(0, 12, (b, d))).astype(np.float32)
+    idx = FlatIndex(ctx, base, metric)
+    with ctx.option("MDB_BF_X1", 2):   # (dot stores take the x 3 filter by default)
+        ids, dist, counts = idx.search(q, k)
+        with ctx.option("MDB_BF_BLOCK_MIN_B", 1 << 30):
+            wids, wdist, wcounts = idx.search(q, k)
+        with ctx.option("MDB_BF_NO_FULL_BOUND", 1):   # the block filter behind the 1/4 sample's bound instead of the whole-base bound pass
+            sids, sdist, scounts = idx.search(q, k)
+    with ctx.option("MDB_BF_X1", 0):
+        tids, tdist, tcounts = idx.search(q, k)
+    with ctx.option("MDB_FLAT_NO_MFMA", 1):
+        eids, edist, ecounts = idx.search(q, k)
+    for a_ids, a_dist, a_counts in ((wids, wdist, wcounts), (sids, sdist, scounts), (tids, tdist, tcounts), (eids, edist, ecounts)):
+        assert np.array_equal(ids, a_ids) and np.array_equal(counts, a_counts)
+        assert np.array_equal(dist.view(np.uint32), a_dist.view(np.uint32))
+    sel = np.r_[0:6, b - 2:b]
+    oids, odist = oracle.flat_topk(metric, base, q[sel], k)
+    assert np.array_equal(ids[sel], oids)
+    assert_scores(dist[sel], odist)
+
+
 @pytest.mark.parametrize("n,d,b,k,metric,kind", [
     (100_000, 128, 40, 10, 0, "sift"), (100_000, 128, 100, 10, 1, "gauss"), (70_000, 30, 17, 5, 0, "gauss"),
     (66_000, 768, 33, 10, 0, "unit"), (80_000, 4, 64, 3, 0, "ramp"), (70_000, 16, 9, 10, 0, "same"),
@@ -471,6 +501,9 @@ def test_ivf_pq_bound_filter_adversarial(ctx, oracle, case):
         assert_result_rows(gres1, ores, len(q))
         assert_result_rows(gres2, ores, len(q))
         assert st["scored_vectors"] == st1["scored_vectors"] == st2["scored_vectors"] == n * len(q)
+        with ctx.option("MDB_PQ_SDC_MAX_MB", 0):   # the blocks build their row-sum words themselves instead of copying rows of the table
+            assert_result_rows(g.search_with_centroids_and_remap(q, probes, kk), ores, len(q))
+            assert ctx.stats()["scored_vectors"] == n * len(q)
         if kk <= 64:
             # the two-phase scan (bf16 lower / upper bounds, then exact distances of the candidates: batches >= 512);
             # then with candidate lists of 8 slots: every list overflows and the gated one-phase launch behind redoes the batch
@@ -485,6 +518,8 @@ def test_ivf_pq_bound_filter_adversarial(ctx, oracle, case):
                 assert_result_rows(gres3, oresb, len(qb))
                 assert st3["scored_vectors"] == n * len(qb), (cap, st3["scored_vectors"])
             with ctx.option("MDB_PQ_NO_TWO_PHASE", 1):                                                 # and the one-phase kernel on the same batch
+                assert_result_rows(g.search_with_centroids_and_remap(qb, pb, kk), oresb, len(qb))
+            with ctx.option("MDB_PQ_SDC_MAX_MB", 0):                                                   # the two-phase scan without the row-sum table
                 assert_result_rows(g.search_with_centroids_and_remap(qb, pb, kk), oresb, len(qb))
 
 
