@@ -551,15 +551,22 @@ def run_flat(env, n=None, batch=None):
                roofline=hbm_roofline("flat_bf16_filter_kernel" if batched else "flat_scan_kernel", abytes, kernel_ms, launches))
     finish(out, disp, abytes)   # the step's algorithmic bytes: the base once (however many passes the filter takes)
     if batched:
-        # the filter streams the bf16 hi/lo split of the base (2 + 2 bytes per element: the base's own size) once per group of
-        # 32 QB queries (QB = 1 / 2 / 4 for batches up to 32 / 64 / more) and issues three bf16 MFMA products per element pair
+        # the filter streams a bf16 copy of the base in matrix-core fragment order — the hi halves only (2 bytes per element, one
+        # MFMA product per pair: MDB_BF_X1, the default for L2 stores) or hi + lo (4 bytes, three products) — plus a 4-byte norm per
+        # row, once per group of queries: 32 QB per block (QB = 1 / 2 / 4 for batches up to 32 / 64 / more), 512 in the block-shared
+        # form of batches >= 512.  The roofline is priced on THOSE bytes: what the launch has to read.
+        x1 = int(os.environ.get("MDB_BF_X1", "1")) >= 1
+        blocked = x1 and d <= 128 and d > 112 and batch >= int(os.environ.get("MDB_BF_BLOCK_MIN_B", "512"))
         qb = 4 if batch > 64 else 2 if batch > 32 else 1
-        groups = (batch + 32 * qb - 1) // (32 * qb)
+        groups = (batch + 511) // 512 if blocked else (batch + 32 * qb - 1) // (32 * qb)
+        dpad = (d + 15) // 16 * 16
         r = out["roofline"]
-        r["bytes_per_launch"] = abytes * groups
-        r["achieved"] *= groups
+        r["kernel"] = "flat_bf16x1_block_kernel (filter pass)" if blocked else "flat_bf16_filter_kernel"
+        r["operand"] = "bf16 hi fragments (2 B/element) + norms" if x1 else "bf16 hi + lo fragments (4 B/element) + norms"
+        r["bytes_per_launch"] = float((hi - lo) * (dpad * (2 if x1 else 4) + 4) * groups)
+        r["achieved"] = r["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9
         r["frac"] = r["achieved"] / HBM_PEAK_GBS
-        r["mfma_tflops"] = 3 * 2.0 * batch * (hi - lo) * d / (r["kernel_ms"] * 1e-3) / 1e12
+        r["mfma_tflops"] = (1 if x1 else 3) * 2.0 * batch * (hi - lo) * d / (r["kernel_ms"] * 1e-3) / 1e12
         r["mfma_frac_of_bf16_peak"] = r["mfma_tflops"] / 2500.0
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("flat_b64" if batched else "flat", out["config"])
     if batched:

@@ -654,9 +654,9 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
     const size_t tstep = (size_t)gridDim.x * 4;
     f32x16 acc[QB];
 #ifndef MDB_BF_AREG_MAX
-#define MDB_BF_AREG_MAX 32
+#define MDB_BF_AREG_MAX 16
 #endif
-    // (the sampling epilogue needs 16 * QB more live values: its QB = 4 form spills 100 registers with the fragments resident)
+    // (QB = 4: 128 fragment registers beside 64 accumulators spill in every form; the fragments stay in LDS there)
     constexpr bool AREG = X1 && NKT > 0 && QB * NKT <= (SMP ? 16 : MDB_BF_AREG_MAX);
     constexpr int UNR = NKT ? NKT : 1;   // (the chunk loop unrolls when its trip count is a compile-time one: areg's indices become static)
     bf16x8 areg[AREG ? QB : 1][AREG ? NKT : 1];
@@ -780,6 +780,34 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
             }
         }
     };
+    if (X1 && NKT == 8) {
+        // one product per fragment: a chunk's MFMAs cover a third of the x 3 form's time, so the fragments run THREE chunks ahead
+        // (a ring of four: 8 chunks per tile keep the slots aligned across tiles)
+        uint4 ring[4];
+        auto frag = [&](size_t tile, size_t tnext, int c) -> const uint4* {   // chunk c (0 .. 10) counted from `tile`'s first
+            const size_t pt = base_tile(c < 8 ? tile : (tnext < nt32 ? tnext : tile));
+            return bhi + (pt * 8 + (size_t)(c & 7)) * 64 + lane;
+        };
+        if (t < nt32) {
+            ring[0] = ch;
+            ring[1] = *frag(t, t + tstep, 1);
+            ring[2] = *frag(t, t + tstep, 2);
+        }
+        while (t < nt32) {
+            zero_acc();
+            const size_t tn = t + tstep;
+            const float xnt = xnorm[base_tile(t) * 32 + l31];
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                ring[(kc + 3) & 3] = *frag(t, tn, kc + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_chunk(ring[kc & 3], ring[kc & 3], kc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            epilogue(t, xnt);
+            t = tn;
+        }
+    } else
     while (t < nt32) {
         zero_acc();
         const size_t tn = t + tstep;
@@ -1117,6 +1145,7 @@ __global__ __launch_bounds__(BLK) void flat_refine_kernel(const float4* __restri
 // stays at the front); an overflowed list (np > qcap) means the whole base, same loop.
 #define RG_CAP 2048
 #define RG_SURV 1024
+#define RG_DIRECT 192
 // k-th smallest distance image (high key word) among keys[0 .. tot): four 8-bit radix passes, 256 threads (sample_bound_kernel's scan)
 __device__ __forceinline__ uint32_t rg_kth_image(const uint64_t* keys, uint32_t tot, uint32_t need, uint32_t* hist, int tid) {
     const int lane = tid & 63;
@@ -1183,7 +1212,9 @@ __global__ __launch_bounds__(256) void flat_refine_group_kernel(const float* __r
     const size_t rstride = (size_t)p.d4 * 4;
     for (int i = tid; i < p.d4 * 4; i += 256) qs[i] = dq[m * qstride + i];
     bool second = false;
-    if (qapx && !whole && np > (uint32_t)k && np <= RG_CAP) {
+    // (a list of at most 2 k candidates — the rule behind the whole-base bound pass, flat_bf16x1_block_kernel — is evaluated as it is:
+    // the select below costs more than the rows it would save)
+    if (qapx && !whole && np > 2 * (uint32_t)k && np <= RG_CAP) {
         // ---- second bound.  The filter's threshold comes from a SAMPLE (k-th smallest bound of 1/32 of the base): it admits ~8 k
         // candidates per query, and their 512-byte rows — 1 GB per 4096-query batch through the fabric — were the whole cost of
         // this kernel.  The candidates' own products give every one a bracket  lo <= reference distance <= up  (the filter's
@@ -1297,7 +1328,7 @@ __global__ __launch_bounds__(256) void flat_refine_group_kernel(const float* __r
         const uint32_t keep = min(tot, (uint32_t)k);
         const uint64_t* src = keys;
         uint32_t scnt = tot;
-        if (tot > (uint32_t)k) {
+        if (tot > (uint32_t)k && tot > RG_DIRECT) {   // (up to RG_DIRECT keys: ranks counted over all of them, one pass of broadcast reads)
             const uint32_t T = rg_kth_image(keys, tot, (uint32_t)k, hist, tid);
             if (tid == 0) hist[258] = 0;
             __syncthreads();
