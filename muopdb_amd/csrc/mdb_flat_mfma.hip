@@ -358,7 +358,13 @@ __global__ __launch_bounds__(BLK) void sample_bound_kernel(const float* __restri
 #pragma unroll
         for (int y = 0; y < YU; ++y)
 #pragma unroll
-            for (int x = 0; x < PER; ++x) mn[x] = min(mn[x], f32_orderable(v[y][x]));
+            for (int x = 0; x < PER; ++x) {
+                // a NaN bound (a row with an infinite component: inf - inf in the bound's own arithmetic, of EITHER sign — the image
+                // of a negative NaN would sort below every distance and drag the k-th smallest down with it) counts as +inf
+                const uint32_t i = i0 + SB_SUB * y + BLK * x + tid;
+                const float vv = v[y][x];
+                mn[x] = min(mn[x], i < ns ? (vv == vv ? f32_orderable(vv) : 0xFF800000u) : 0xFFFFFFFFu);
+            }
     }
     uint32_t prefix = 0, need = (uint32_t)k;
     for (int pass = 0; pass < 4; ++pass) {

@@ -59,6 +59,9 @@ struct HnswUpperOut {
     uint32_t* ep = nullptr;        // [b] layer-0 entry point (point id)
     uint32_t* ovf = nullptr;       // [b] 1 = the upper beam overflowed: the layer-0 block re-runs the whole query (general traversal)
     uint32_t* vis = nullptr;       // [b][words] visited bitmap over compact indices
+    uint32_t* cnt = nullptr;       // [b][4] evaluations, expansions, NaN seen on the upper layers: the layer-0 block adds them to its own and
+                                   // to the context's counters only when the WHOLE query stayed inside the beam (an overflow anywhere re-runs
+                                   // it from the top with the general traversal, which counts everything itself)
     uint32_t words = 0;
 };
 // table[q][c] = order-preserving image of distance(query q, compact point c), exact association (mdb_device.hip.h exact_sums)

@@ -55,6 +55,7 @@ struct HnswArgs {
     const uint32_t* up_ovf;         // [b] 1 = re-run the whole query with the general traversal
     const uint32_t* up_vis;         // [b][up_words] points visited on the upper layers, bitmap over compact indices
     const uint32_t* up_ids;         // compact index -> point id
+    const uint32_t* up_cnt;         // [b][4] the upper layers' evaluations, expansions, NaN seen (counted here when the query ends in the beam)
     uint32_t up_words;
     // L0, device-resident calls: the block writes the caller's (doc id, score) rows itself (ann_search :192-208) — no remap launch
     const uint8_t* rm_index;        // uploaded index bytes (doc ids); nullptr: keys only
@@ -726,8 +727,8 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
     uint32_t ru_o = SLOT_EMPTY, ru_id = 0;
     bool ru_valid = false, stop = false;
     int ru_closer = 0;                 // #{b in B : d_b < d_runner-up}, counted in the shadow of P3 (the stop test of P4)
-    uint32_t evals = 0, expanded = 0;  // per query: far below 2^32
-    bool nan_seen = false, overflow = L0 ? a.up_ovf[qi] != 0u : false;
+    uint32_t evals = L0 ? a.up_cnt[4 * qi + 0] : 0u, expanded = L0 ? a.up_cnt[4 * qi + 1] : 0u;  // per query: far below 2^32
+    bool nan_seen = L0 ? a.up_cnt[4 * qi + 2] != 0u : false, overflow = L0 ? a.up_ovf[qi] != 0u : false;
     uint32_t ep = L0 ? a.up_ep[qi] : u.entry_point;
 #ifdef MDB_PIPE_DBG
     unsigned long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1728,19 +1729,20 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         const uint32_t words = (upper.nu / 32 + 4) & ~3u;   // a multiple of 4: hnsw_upper_kernel puts the table row's LDS copy (16-byte stores) behind the bitmap
         void *tab, *st;
         MDB_TRY(mdb_scratch(ctx, 8, (size_t)b * nu_pad * 4 + 64, &tab));
-        MDB_TRY(mdb_scratch(ctx, 9, (size_t)b * (words + 2) * 4 + 64, &st));
+        MDB_TRY(mdb_scratch(ctx, 9, (size_t)b * (words + 6) * 4 + 64, &st));
         void* st2;
         MDB_TRY(mdb_scratch(ctx, 10, ((size_t)b * (words + 8) + 64) * 4, &st2));
         HnswUpperOut uo;
         uo.ep = (uint32_t*)st;
         uo.ovf = uo.ep + b;
-        uo.vis = uo.ovf + b;
+        uo.cnt = uo.ovf + b;
+        uo.vis = uo.cnt + 4 * b;
         uo.words = words;
         // (the table kernel clears the context's traversal counters on its way: no memset launch in front of the step)
         MDB_TRY(hnsw_upper_run(ctx, upper, metric, a.p, d_q, qstride, b, ef, (uint32_t*)tab, (uint32_t*)st2, uo,
                                zero_counters ? ctx->d_counters : nullptr));
         zero_counters = false;
-        a.up_ep = uo.ep; a.up_ovf = uo.ovf; a.up_vis = uo.vis; a.up_ids = upper.ids.p; a.up_words = words;
+        a.up_ep = uo.ep; a.up_ovf = uo.ovf; a.up_vis = uo.vis; a.up_cnt = uo.cnt; a.up_ids = upper.ids.p; a.up_words = words;
         if (fuse && fuse->doc && k > 0) {
             a.rm_index = d_index.p; a.rm_doc = fuse->doc; a.rm_score = fuse->score; a.rm_counts = fuse->counts;
             fuse->done = true;

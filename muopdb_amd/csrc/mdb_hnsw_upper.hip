@@ -294,8 +294,9 @@ struct HnswUpArgs {
     uint32_t* out_ep;
     uint32_t* out_ovf;
     uint32_t* out_vis;
-    uint32_t* out_cnt;        // non-null: the counters go here ([b][4]) instead of the context's (a later launch adds them: a beam that
-                              // overflows further down re-runs the WHOLE query, and nothing of it may have been counted)
+    uint32_t* out_cnt;        // the counters go here ([b][4]), not to the context: the layer-0 block adds them with its own when the query
+                              // ends inside the beam — a beam that overflows further down re-runs the WHOLE query, and nothing of it may
+                              // have been counted (nullptr: a caller with nothing below it; counted here unless overflowed)
     uint32_t* flags;
     unsigned long long* counters;
     // top phase of the split path: the block evaluates its query against this compact set itself (tiles, d = 16 n16)
@@ -728,7 +729,7 @@ static mdb_status upper_launch_bottom(mdb_ctx* ctx, const HnswUpper& up, const u
     a.vis_words = out.words;
     a.in_ep = in_ep; a.in_ovf = in_ovf; a.in_vis = in_vis; a.in_cnt = in_cnt;
     a.ep_map = up.ids.p; a.vis_map = nullptr; a.out_words = out.words;
-    a.out_ep = out.ep; a.out_ovf = out.ovf; a.out_vis = out.vis; a.out_cnt = nullptr;
+    a.out_ep = out.ep; a.out_ovf = out.ovf; a.out_vis = out.vis; a.out_cnt = out.cnt;
     a.flags = ctx->d_flags; a.counters = ctx->d_counters;
     const size_t lds_base = UP_LDS_VIS + (size_t)out.words * 4;
     const bool tlds = lds_base + (size_t)a.nu_pad * 4 <= 160 * 1024 - 512 && !ctx->opt.hnsw_table_no_lds;

@@ -272,12 +272,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", default="flat,ivf,hnsw,spann")
+    ap.add_argument("--start", type=int, default=0, help="first iteration (a case's generator is seeded by its iteration number)")
     args = ap.parse_args()
     ctx = L.Context(0)
     names = args.only.split(",")
     t0 = time.time()
     counts = {n: 0 for n in names}
-    it = 0
+    it = args.start
     while time.time() - t0 < args.seconds:
         name = names[it % len(names)]
         seed = args.seed * 1_000_003 + it

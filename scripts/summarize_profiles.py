@@ -38,6 +38,9 @@ def group_ms(rows, kerns):
 
 def main_filter(name):
     """flat_bf16_filter_kernel<METRIC, QB, NKT, SMP, APX> with SMP == false (the sample pass has its own launches)"""
+    if "flat_bf16x1_block_kernel<" in name:   # <METRIC, QB, BOUND, APX>: the filter pass of a large batch (BOUND == false)
+        targs = name.split("flat_bf16x1_block_kernel<", 1)[1].split(">", 1)[0].split(",")
+        return len(targs) >= 3 and targs[2].strip() == "false"
     if "flat_bf16_filter_kernel<" not in name:
         return False
     targs = name.split("flat_bf16_filter_kernel<", 1)[1].split(">", 1)[0].split(",")
@@ -115,7 +118,8 @@ for w, (kern, key, match) in WL.items():
     if w in ("spann", "c5") and "n" in cfg:
         m["n"] = cfg["n"]
     if "MFMA" in vals:
-        traffic.setdefault("_mfma", {})[key] = dict(vals["MFMA"], source="profiles/%s_%s_pmc_MFMA.csv" % (rnd, w), kernel="flat_bf16_filter_kernel")
+        traffic.setdefault("_mfma", {})[key] = dict(vals["MFMA"], source="profiles/%s_%s_pmc_MFMA.csv" % (rnd, w),
+                                                    kernel="flat_bf16x1_block_kernel (filter pass)" if w == "c5" else "flat_bf16_filter_kernel")
     if "FETCH_SIZE" in vals:
         traffic[key] = {"match": m, "kernel": "+".join(k.split("<")[0] for k in kern), "fetch_kib": round(vals["FETCH_SIZE"], 1), "write_kib": round(vals.get("WRITE_SIZE", 0.0), 1),
                         "fetch_correction": 2.0, "source": ["profiles/%s_%s_pmc_FETCH_SIZE.csv" % (rnd, w), "profiles/%s_%s_pmc_WRITE_SIZE.csv" % (rnd, w)]}

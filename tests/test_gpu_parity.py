@@ -161,6 +161,34 @@ def test_flat_c1_dataset_and_ties(ctx, oracle):
     assert ids2[0, :4].tolist() == [0, 1, 2, 3]
 
 
+def test_flat_batched_filter_rows_with_infinite_components(ctx, oracle):
+    """scripts/stress_parity.py case 3900 (round 4): 70 000 x 30 rows, one in fifty with an infinite component, batch 33, top-200.
+    With one bf16 product per pair the sample's bounds of such rows are inf - inf = NaN made by the bound's own arithmetic, and the
+    image of a NEGATIVE NaN sorted below every distance: the k-th smallest bound fell, true neighbours were filtered out.  NaN
+    bounds count as +inf now (sample_bound_kernel); rows must equal the exact kernels' and the oracle's."""
+    from muopdb_amd.index import FlatIndex
+    rng = np.random.default_rng(3900)
+    n, d, b, k = 70_000, 30, 33, 200
+    base = (rng.standard_normal((n, d)) * 10).astype(np.float32)
+    rows = rng.integers(0, n, n // 50)
+    base[rows, rng.integers(0, d, len(rows))] = np.inf
+    q = (base[rng.integers(0, n, b)] + rng.normal(0, 1, (b, d))).astype(np.float32)
+    q = np.where(np.isfinite(q), q, np.float32(0))
+    idx = FlatIndex(ctx, base, 0)
+    ids, dist, counts = idx.search(q, k)
+    for opt in ("MDB_FLAT_NO_MFMA", "MDB_BF_EXACT_SAMPLE"):
+        with ctx.option(opt, 1):
+            eids, edist, ecounts = idx.search(q, k)
+        assert np.array_equal(ids, eids) and np.array_equal(counts, ecounts), opt
+        assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32)), opt
+    with ctx.option("MDB_BF_X1", 0):
+        tids, tdist, _ = idx.search(q, k)
+    assert np.array_equal(ids, tids) and np.array_equal(dist.view(np.uint32), tdist.view(np.uint32))
+    oids, odist = oracle.flat_topk(0, base, q[:4], k)
+    assert np.array_equal(ids[:4], oids)
+    assert_scores(dist[:4], odist)
+
+
 @pytest.mark.parametrize("n,d,b,k,metric", [(120_000, 128, 600, 10, 0), (90_000, 120, 1100, 20, 0), (70_000, 128, 513, 10, 1)])
 def test_flat_large_batch_block_filter_equals_exact(ctx, oracle, n, d, b, k, metric):
     """Batches of >= 512 queries over d <= 128 take the block-shared bf16 x 1 filter (flat_bf16x1_block_kernel: a bound pass and a

@@ -205,6 +205,30 @@ def test_hnsw_beam_overflow_falls_back_to_general_kernel(ctx, oracle):
         assert st["distance_evals"] == evals and st["expanded_nodes"] == expanded
 
 
+@pytest.mark.parametrize("layers,nq", [(2, 9), (3, 40), (4, 9)])
+def test_hnsw_layer0_overflow_behind_a_clean_upper_traversal_counts_once(ctx, oracle, layers, nq):
+    """scripts/stress_parity.py case 3958 (round 4): 2500 copies of 64 distinct points, dot product, ef 256.  The upper layers hold
+    fewer points than ef (traversed completely, no overflow), the layer-0 beam then overflows on the ties and the block re-runs the
+    WHOLE query with the general traversal: the upper launch's evaluations must not have been counted already (they travel with the
+    hand-over state now and are added by the layer-0 block only when the query ends inside the beam).  Split path (>= 3 layers,
+    batch >= 32) and single upper launch alike."""
+    from muopdb_amd.index import BlockBasedHnsw, NoQuantizer
+    rng = np.random.default_rng(3958 + layers)
+    base = rng.integers(0, 4, (312, 3)).astype(np.float32)
+    v = base[rng.integers(0, 312, 2500)]
+    hidx, hvec = H.build_hnsw_files(oracle, v, list(range(len(v))), max_neighbors=32, max_layers=layers, ef_construction=40, metric=1)
+    g = BlockBasedHnsw(ctx, hidx, hvec, 3, NoQuantizer(3, 1))
+    o = oracle.BlockBasedHnsw(hidx, hvec, 3, oracle.Quant(oracle.QUANT_NONE, 1))
+    q = (v[rng.integers(0, len(v), nq)] + rng.normal(0, 1, (nq, 3))).astype(np.float32)
+    for k, ef in [(1, 256), (10, 200), (5, 400)]:
+        o.stats()
+        ores = o.ann_search(q, k, ef)
+        evals, expanded = o.stats()
+        assert_result_rows(g.ann_search(q, k, ef), ores, len(q))
+        st = ctx.stats()
+        assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded), (k, ef)
+
+
 def test_hnsw_rows_with_duplicate_edges(ctx, oracle):
     """An adjacency row that names a point twice (nothing in the file format forbids it): the reference skips the second copy
     as already visited, and so must the kernels' test-and-set (two lanes of one row hitting the same bit: exactly one is new) —
