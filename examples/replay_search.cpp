@@ -3,7 +3,7 @@
 // torch's own kernels on this image, so the counter passes run on this binary instead).
 //   replay_search <kind> <dir> <dim> <k> <ef|nprobe> <batch> <steps> [ef for mspann]
 // kind = hnsw | hnsw-async (argv[8] = batches in flight, submit / wait on attached handles) | ivf | ivfpq | flat | mspann.  <dir> is what `bench.py --dump-dir` wrote:
-//   hnsw : index, vectors, queries.f32        ivf/ivfpq : index, vectors, queries.f32 [, codebook.f32]
+//   hnsw : index, vectors, queries.f32        ivf/ivfpq : index, vectors, queries.f32 [, codebook.f32]  (+ argv[8] argv[9]: shard rank, world)
 //   flat : vectors (reference vector-file format: u64 n + rows), queries.f32
 // Prints a checksum of the returned ids so a replay can be compared with bench.py's run.
 #include <chrono>
@@ -108,7 +108,9 @@ int main(int argc, char** argv) {
                 std::memcpy(cbf.data(), cb.data(), cbf.size() * 4);
                 qz = muopdb::Quantizer::product(dim, 8, 8, std::move(cbf));
             }
-            muopdb::BlockBasedIvf ivf(dev, idx.data(), idx.size(), vec.data(), vec.size(), std::move(qz));
+            // argv[8], argv[9]: load what rank argv[8] of argv[9] owns (size-balanced list shards, mdb_ivf_load): a rank's share of C5
+            const uint32_t srank = argc > 8 ? (uint32_t)std::stoul(argv[8]) : 0, sworld = argc > 9 ? (uint32_t)std::stoul(argv[9]) : 1;
+            muopdb::BlockBasedIvf ivf(dev, idx.data(), idx.size(), vec.data(), vec.size(), std::move(qz), 0, 0, srank, sworld);
             (void)ivf.search(q, batch, k, knob);  // untimed warm-up call
             t0 = std::chrono::steady_clock::now();
             for (size_t s = 0; s < steps; ++s)

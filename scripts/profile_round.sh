@@ -29,7 +29,7 @@ for W in $WL; do
     flat_b64) SUB=flat_b64; REPLAY="flat $DUMP/flat_b64 128 10 0 64 20";      BARGS="--workload flat --n 1000000 --batch 64";;
     ivfpq)    SUB=ivfpq;    REPLAY="ivfpq $DUMP/ivfpq 128 10 16 256 20";      BARGS="--workload ivfpq --no-sweep --streams 0";;
     spann)    SUB=spann;    REPLAY="mspann $DUMP/spann 768 10 16 128 20 200"; BARGS="--workload spann --users 128 --no-sweep";;
-    c5)       SUB=c5;       REPLAY="ivfpq $DUMP/c5 128 10 64 4096 6";         BARGS="";;
+    c5)       SUB=c5;       REPLAY="ivfpq $DUMP/c5 128 10 64 4096 6 0 8";     BARGS="";;   # the whole index's files, rank 0 of 8's share loaded
     c5full)   SUB=c5full;   REPLAY="ivfpq $DUMP/c5full/c5full 128 10 64 4096 6"; BARGS="";
               (time timeout 1200 python $REPO/bench.py --workload c5full --steps 6 --warmup 2 --no-cpu-baseline --dump-dir $DUMP/c5full) > $OUT/c5full_bench.json 2> $OUT/c5full_bench.err;;
     c4full)   SUB=spann;    REPLAY="mspann $DUMP/c4full/spann 768 10 16 1024 6 200"; BARGS="";

@@ -551,6 +551,34 @@ def test_ivf_pq_bound_filter_adversarial(ctx, oracle, case):
                 assert_result_rows(g.search_with_centroids_and_remap(qb, pb, kk), oresb, len(qb))
 
 
+def test_ivf_large_coarse_quantizer_block_filter_and_slices(ctx, oracle):
+    """65 536 centroids of d = 128 (C5's coarse quantizer) and a batch of 600: the coarse search runs the block-shared bf16 x 1 filter
+    (bound pass + filter pass over the whole quantizer, products handed to the group refine).  Probe ids must equal the exact
+    kernels', the sample-bounded and the three-product filters', the oracle's — and the merge of the eight ranks' slice searches
+    (mdb_ivf_coarse_keys over views of the filter operands: 256 tiles each, the same kernels)."""
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import BlockBasedIvf
+    rng = np.random.default_rng(128)
+    L, d, P, b = 65_536, 128, 48, 600
+    cent = H.sift_like(L, d, n_clusters=300, seed=5)
+    cent[4242] = cent[17]                                  # duplicate centroids: ties broken by index
+    v = cent[:2000] + rng.standard_normal((2000, d)).astype(np.float32)
+    pls = [np.array([i], np.uint64) if i < 2000 else np.zeros(0, np.uint64) for i in range(L)]
+    index, vec = F.write_ivf_index(cent, list(range(2000)), pls), F.write_vector_file(v.astype(np.float32))
+    g, o = BlockBasedIvf(ctx, index, vec), oracle.BlockBasedIvf(index, vec)
+    q = (cent[rng.integers(0, L, b)] + rng.normal(0, 15, (b, d))).astype(np.float32)
+    q[3] = cent[17]
+    got = g.find_nearest_centroids(q, P)
+    with ctx.option("MDB_FLAT_NO_MFMA", 1):
+        assert np.array_equal(got, g.find_nearest_centroids(q, P))
+    for opt, val in (("MDB_BF_NO_FULL_BOUND", 1), ("MDB_BF_BLOCK_MIN_B", 1 << 30), ("MDB_BF_X1", 0), ("MDB_REFINE_NO_SECOND_BOUND", 1)):
+        with ctx.option(opt, val):
+            assert np.array_equal(got, g.find_nearest_centroids(q, P)), opt
+    assert np.array_equal(got[:6], o.find_nearest_centroids(q[:6], P))
+    parts = [g.coarse_keys(q, P, first, 8192) for first in range(0, L, 8192)]
+    assert np.array_equal(g.merge_coarse_keys(np.stack(parts, 1), P), got)
+
+
 def test_ivf_large_coarse_quantizer_batched_path(ctx, oracle):
     """>= 64K centroids (C5 has 65 536 lists): batches of >= 8 queries find their probes through the batched flat path
     (sample bound + matrix-core filter + exact refine) — probe ids and final rows must equal the oracle's, for a batch

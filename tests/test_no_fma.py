@@ -30,7 +30,7 @@ EXACT = re.compile(r"(flat_scan_kernel|flat_refine_kernel|ivf_scan_f32_kernel|iv
 # address space and compiles to flat_load / flat_store + s_waitcnt vmcnt(0) (round 2: the pipelined HNSW kernel's mailbox polls;
 # a non-inlined lambda did the same to the PQ table reads).  The HNSW kernels keep the flat accesses of their shared fallback
 # (hnsw_general_traverse: the visited set may live in HBM there), so for those the bound is the beam kernel's own count.
-NO_FLAT = re.compile(r"(ivf_scan_pq3_kernel|ivf_pq3_refine_kernel|ivf_scan_pq2_kernel|ivf_scan_f32_kernel|flat_scan_kernel|flat_bf16_filter_kernel|"
+NO_FLAT = re.compile(r"(ivf_scan_pq3_kernel|ivf_pq3_refine_kernel|ivf_scan_pq2_kernel|ivf_scan_f32_kernel|flat_scan_kernel|flat_bf16_filter_kernel|flat_bf16x1_block_kernel|"
                      r"flat_refine_kernel|sample_bound_kernel)")
 
 
