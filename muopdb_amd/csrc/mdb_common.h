@@ -65,6 +65,7 @@
     X(pq_no_filter, "MDB_PQ_NO_FILTER", 0)                                                                          \
     X(pq_no_full, "MDB_PQ_NO_FULL", 0)                                                                              \
     X(pq_blocks, "MDB_PQ_BLOCKS", 256)                                                                              \
+    X(pq3_warm_rounds, "MDB_PQ3_WARM_ROUNDS", 4)        /* two-phase PQ scan: rounds the selector runs on before it drops to every eighth */ \
     X(pq_eager_trim, "MDB_PQ_EAGER_TRIM", 1)                                                                        \
     X(pq_no_quantize8, "MDB_PQ_NO_QUANTIZE8", 0)       /* one wave per (vector, subspace) for every codebook */     \
     X(pq_two_phase_min_b, "MDB_PQ_TWO_PHASE_MIN_B", 512)                                                            \

@@ -744,7 +744,8 @@ __global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uin
     uint32_t* const my_cand = c3.cand + ((size_t)qi * nsplit + split) * c3.cap;
     const float gmar = 1.5f * (float)(m * subdim + m + subdim + 16) * 5.9604645e-8f;   // the bracket's relative half width (below)
     const float lo_f = 1.0f - gmar, hi_f = 1.0f + gmar;
-    const int sel_mask = a.eager_trim >= 2 ? 0 : 7;   // MDB_PQ_EAGER_TRIM=2: the selector on every round (round 2's scan)
+    const int sel_mask = (a.eager_trim & 0xFF) >= 2 ? 0 : 7;   // MDB_PQ_EAGER_TRIM=2: the selector on every round (round 2's scan)
+    const int sel_warm = 2 + ((a.eager_trim >> 8) & 0xFF);    // the selector's first rounds (MDB_PQ3_WARM_ROUNDS; r counts from the pipeline's fill)
     if (tid == 0) *ccnt = 0;
     if (sdc) {   // the query's rows of the code-to-code table (pq_sdc_kernel: the words the loop below computes)
         for (int i = tid; i < (m << nbits); i += BLK) btab[i] = __float_as_uint(sdc[((size_t)(i >> nbits) * K + qc[i >> nbits]) * K + (i & (K - 1))]);
@@ -879,10 +880,11 @@ __global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uin
                         if (surv && pos < c3.cap) my_cand[pos] = slot0[CC] + (uint32_t)lane;
                     }
                     // The selector only has to supply A bound of the k-th distance, and any k upper bounds seen so far do: it runs on
-                    // the first eight rounds (the nearest probed lists come first in the tile sequence: the bound is nearly final
-                    // after them) and on every eighth round after that — its block barrier per round cost 17 % of this kernel for
-                    // 5 % fewer candidates (C5: 362 -> 300 us, phase 2 58.6 -> 61.3 us with the selector frozen after four rounds).
-                    if (r < 10 || ((r - 2) & sel_mask) == 0) {   // block-uniform
+                    // the first rounds (MDB_PQ3_WARM_ROUNDS, 4: the nearest probed lists come first in the tile sequence, the bound
+                    // is nearly final after them) and on every eighth round after that — its block barrier per round cost 17 % of
+                    // this kernel for 5 % fewer candidates.  (Round 4, a C5 share at 30 M rows: 8 / 6 / 4 / 3 / 2 first rounds ->
+                    // scan + refine 218 / 211 / 207 / 203 / 204 us; the whole index: no difference.)
+                    if (r < sel_warm || ((r - 2) & sel_mask) == 0) {   // block-uniform
                         sel.offer(key);
                         sel.round_end((uint32_t)a.k + 64u);   // eager: a slack threshold costs phase 2 exact evaluations
                     }
@@ -2127,6 +2129,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
             const size_t ldsr = ((BlockSelect<256>::lds_bytes((int)k) + 15) & ~(size_t)15) + (size_t)pq.m * pq.subdim * 4;
             ScanArgs a3 = a;
             a3.counts_out = nullptr;
+            a3.eager_trim = (a.eager_trim & 0xFF) | ((int)std::min<long long>(255, std::max<long long>(0, ctx->opt.pq3_warm_rounds)) << 8);
 #define MDB_PQ3_SCAN_F(MWT, BLKT, FULLT)                                                                                          \
     do {                                                                                                                           \
         if (lds3 > 48 * 1024)                                                                                                      \
