@@ -12,11 +12,17 @@
 //   MultiSpannIndex::search_for_user  multi_spann/index.rs:282  muopdb::MultiSpannIndex
 //   SearchParams  rs/config/src/search_params.rs                muopdb::SearchParams
 //   SearchResult / IdWithScore  rs/index/src/utils.rs:89-176    muopdb::SearchResult / IdWithScore
+//   PendingSegment::search_with_id  segment/pending_segment.rs:285-335   muopdb::PendingSegment
+//   Snapshot::search_for_user / search_for_users  collection/snapshot.rs:39-110   muopdb::Snapshot
 // Every search takes a batch; row i is what the reference returns for query i.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <optional>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -296,10 +302,117 @@ class MultiSpannIndex {
                                           r.counts.data(), r.found.data()));
         return r.take(b, p.top_k);
     }
+    // ... with the planner's allow bitmaps over the user-local point ids for THIS call (n_bitmaps == 1: shared by every query)
+    std::vector<std::optional<SearchResult>> search_for_user(const std::vector<u128>& user_ids, const float* queries,
+                                                             const SearchParams& p, const std::vector<uint32_t>& bitmaps,
+                                                             size_t n_bitmaps = 1) {
+        const size_t b = user_ids.size();
+        std::vector<mdb_u128> ids(b);
+        for (size_t i = 0; i < b; ++i) ids[i] = detail::split(user_ids[i]);
+        detail::Rows r(b, p.top_k);
+        mdb_search_params c = p.c();
+        dev_.check(mdb_multi_spann_search_filtered(h_, ids.data(), queries, b, &c, MDB_MEM_HOST, bitmaps.data(), n_bitmaps,
+                                                   bitmaps.size() / n_bitmaps, r.ids.data(), r.scores.data(), r.counts.data(),
+                                                   r.found.data()));
+        return r.take(b, p.top_k);
+    }
+    // Segment::search_with_id (segment/immutable_segment.rs): one user, one query, optional planner
+    std::optional<SearchResult> search_with_id(u128 user_id, const float* query, const SearchParams& p,
+                                               const std::vector<uint32_t>* planner = nullptr) {
+        auto rows = planner ? search_for_user({user_id}, query, p, *planner) : search_for_user({user_id}, query, p);
+        return std::move(rows[0]);
+    }
+    bool invalidate(u128 user_id, u128 doc_id) {
+        mdb_u128 u = detail::split(user_id), d = detail::split(doc_id);
+        uint8_t f = 0;
+        dev_.check(mdb_multi_spann_invalidate(h_, &u, &d, 1, &f));
+        return f != 0;
+    }
 
   private:
     Device& dev_;
     mdb_multi_spann* h_ = nullptr;
+};
+
+// ---- the callers of the path: segment fan-out (host logic over GPU-resident segments)
+// IdWithScore order (rs/index/src/utils.rs:95-114): score ascending — total order, NaN last — then doc id
+inline bool id_with_score_less(const IdWithScore& a, const IdWithScore& b) {
+    const bool an = std::isnan(a.score), bn = std::isnan(b.score);
+    if (an != bn) return bn;
+    if (!an && a.score != b.score) return a.score < b.score;
+    return a.doc_id < b.doc_id;
+}
+
+// PendingSegment::search_with_id while the merged index is not built yet (segment/pending_segment.rs:285-335): every inner
+// segment is searched with an OVER-FETCH of top_k + |temporarily invalidated ids of the user| and NO planner (:316-323), the
+// invalidated documents are dropped from every inner result and the rows are CONCATENATED — neither sorted nor truncated
+// here (the caller, Snapshot::search_for_user, does both).  Some(empty) when no inner segment knows the user (:333).
+class PendingSegment {
+  public:
+    explicit PendingSegment(std::vector<MultiSpannIndex*> inner_segments) : inner_(std::move(inner_segments)) {}
+    // temp_invalidated_ids (pending_segment.rs: `invalidate`)
+    void invalidate(u128 user_id, u128 doc_id) { dead_[user_id].insert(doc_id); }
+    std::optional<SearchResult> search_with_id(u128 user_id, const float* query, const SearchParams& params) {
+        static const std::set<u128> none;
+        auto it = dead_.find(user_id);
+        const std::set<u128>& dead = it == dead_.end() ? none : it->second;
+        SearchParams adjusted = params;
+        adjusted.top_k = params.top_k + dead.size();
+        SearchResult out;
+        for (MultiSpannIndex* seg : inner_) {
+            auto r = seg->search_with_id(user_id, query, adjusted);
+            if (!r) continue;
+            for (const IdWithScore& e : r->id_with_scores)
+                if (!dead.count(e.doc_id)) out.id_with_scores.push_back(e);
+        }
+        return out;
+    }
+
+  private:
+    std::vector<MultiSpannIndex*> inner_;
+    std::map<u128, std::set<u128>> dead_;
+};
+
+// BoxedImmutableSegment (segment/mod.rs): a finalized multi-user segment or a pending one (which takes no planner)
+struct Segment {
+    MultiSpannIndex* finalized = nullptr;
+    PendingSegment* pending = nullptr;
+    Segment(MultiSpannIndex* s) : finalized(s) {}
+    Segment(PendingSegment* s) : pending(s) {}
+};
+
+// Snapshot::search_for_user (collection/snapshot.rs:69-110): every segment is searched, the rows are concatenated, sorted by
+// IdWithScore and truncated to top_k; search_for_users (:39-66) does the same over several users' results.
+class Snapshot {
+  public:
+    explicit Snapshot(std::vector<Segment> segments) : segments_(std::move(segments)) {}
+    SearchResult search_for_user(u128 user_id, const float* query, const SearchParams& params,
+                                 const std::vector<uint32_t>* planner = nullptr) {
+        SearchResult out;
+        for (const Segment& s : segments_) {
+            auto r = s.pending ? s.pending->search_with_id(user_id, query, params) : s.finalized->search_with_id(user_id, query, params, planner);
+            if (r) out.id_with_scores.insert(out.id_with_scores.end(), r->id_with_scores.begin(), r->id_with_scores.end());
+        }
+        finish(out, params.top_k);
+        return out;
+    }
+    SearchResult search_for_users(const std::vector<u128>& user_ids, const float* query, const SearchParams& params,
+                                  const std::vector<uint32_t>* planner = nullptr) {
+        SearchResult out;
+        for (u128 u : user_ids) {
+            SearchResult r = search_for_user(u, query, params, planner);
+            out.id_with_scores.insert(out.id_with_scores.end(), r.id_with_scores.begin(), r.id_with_scores.end());
+        }
+        finish(out, params.top_k);
+        return out;
+    }
+
+  private:
+    static void finish(SearchResult& r, size_t top_k) {
+        std::stable_sort(r.id_with_scores.begin(), r.id_with_scores.end(), id_with_score_less);
+        if (r.id_with_scores.size() > top_k) r.id_with_scores.resize(top_k);
+    }
+    std::vector<Segment> segments_;
 };
 
 }  // namespace muopdb

@@ -533,3 +533,73 @@ __device__ __forceinline__ float pq_streaming_distance(const uint8_t* a, const u
     return metric == MDB_METRIC_L2 ? pq_streaming_distance_t<MDB_METRIC_L2>(a, b, subdim, m, K, cb, sp)
                                    : pq_streaming_distance_t<MDB_METRIC_DOT>(a, b, subdim, m, K, cb, sp);
 }
+
+// ------------------------------------------------------------------------------------------ block-wide k-th bound (1024 threads)
+#define PQF_BLOCK 1024
+#define PQF_LOG2_NB 10
+#define PQF_NB PQF_BLOCK   // histogram bins of block_kth_bound: one per thread
+// Block-wide (PQF_BLOCK threads, uniform control flow): a threshold T with #{v <= T} >= kth over the block's values
+// v[0..R) per thread (order-preserving u32 images; 0xFFFFFFFF = no value), close to the kth smallest: the images are mapped
+// monotonically onto PQF_NB bins between the block's minimum and maximum, T is the upper edge of the bin holding the kth
+// smallest.  All ones when fewer than kth values exist.
+// hist2: two areas of PQF_NB + 16 words used alternately (`flip` toggles per call) — [0, NB) the histogram, [NB] the bin found,
+// [NB+1..NB+3] block minimum / maximum / count (LDS atomics of the waves' reductions), [NB+4 .. NB+4+NW) the waves' scan totals.
+// A call resets the OTHER area for its successor BEHIND its own first barrier (no thread is still inside the previous call then),
+// so no extra barrier guards the reuse; the caller resets area 0 — and synchronises — before the first call (kth_area_reset).
+// Four barriers, ~120 instructions per wave.
+__device__ __forceinline__ void kth_area_reset(uint32_t* area) {
+    area[threadIdx.x] = 0;
+    if (threadIdx.x < 16) area[PQF_NB + threadIdx.x] = threadIdx.x == 1 ? 0xFFFFFFFFu : 0u;   // [NB+1] = minimum
+}
+template <int R>
+__device__ __forceinline__ uint32_t block_kth_bound(const uint32_t (&v)[R], uint32_t kth, uint32_t* hist2, int& flip) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* hist = hist2 + flip * (PQF_NB + 32);
+    uint32_t* const other = hist2 + (flip ^ 1) * (PQF_NB + 32);
+    flip ^= 1;
+    uint32_t lmin = 0xFFFFFFFFu, lmax = 0u, lcnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool have = v[r] != 0xFFFFFFFFu;
+        lmin = min(lmin, v[r]);
+        lmax = have ? max(lmax, v[r]) : lmax;
+        lcnt += (uint32_t)__popcll(__ballot(have));   // scalar: the wave's count
+    }
+    const uint32_t wmin = mdb_wave_min_u32(lmin);
+    const uint32_t wmax = ~mdb_wave_min_u32(~lmax);
+    if (lane == 0 && lcnt) { atomicMin(&hist[PQF_NB + 1], wmin); atomicMax(&hist[PQF_NB + 2], wmax); atomicAdd(&hist[PQF_NB + 3], lcnt); }
+    __syncthreads();
+    // the OTHER area (the previous call's) is cleared for the next call only here, behind this call's first barrier: every thread
+    // has left the previous call by now — cleared at the top, a fast thread zeroed hist[PQF_NB] (the bin found) under a slow one
+    // that was still reading it
+    kth_area_reset(other);
+    const uint32_t gmin = hist[PQF_NB + 1], gmax = hist[PQF_NB + 2], total = hist[PQF_NB + 3];
+    if (total < kth || kth == 0) { __syncthreads(); return 0xFFFFFFFFu; }   // (uniform; the barrier: a fast thread's NEXT call resets this area)
+    const uint32_t range = gmax - gmin;
+    const int sh = max(0, 32 - (int)__clz(range | 1u) - PQF_LOG2_NB);   // (v - gmin) >> sh < PQF_NB
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (v[r] != 0xFFFFFFFFu) atomicAdd(&hist[(v[r] - gmin) >> sh], 1u);
+    __syncthreads();
+    // inclusive scan of the bins: one bin per thread; the waves' totals meet in LDS
+    const uint32_t mine = hist[tid];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < MDB_WAVE; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) hist[PQF_NB + 4 + wave] = incl;
+    __syncthreads();
+    uint32_t before = lane < wave ? hist[PQF_NB + 4 + lane] : 0u;   // lane w: the total of wave w (< this wave)
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) before += __shfl_xor(before, o);   // 16 waves
+    before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+    incl += before;
+    if (incl >= kth && incl - mine < kth) hist[PQF_NB] = (uint32_t)tid;   // exactly one bin
+    __syncthreads();
+    const uint32_t B = hist[PQF_NB];
+    const unsigned long long edge = (unsigned long long)gmin + (((unsigned long long)B + 1ull) << sh) - 1ull;
+    return edge >= 0xFFFFFFFFull ? 0xFFFFFFFEu : (uint32_t)edge;   // never the "no value" image
+}
+

@@ -58,6 +58,16 @@ __global__ void pad_queries_kernel(const float* __restrict__ q, size_t b, int d,
 
 mdb_status stage_queries(mdb_ctx* ctx, int slot, const float* queries, size_t b, int d, mdb_mem mem, size_t bpad,
                          float** d_out, int* qstride) {
+    if (mem == MDB_MEM_DEVICE && (b == bpad || b % 4 == 0) && d % 16 == 0 && ((uintptr_t)queries & 15) == 0 && !ctx->opt.no_inplace) {
+        // device-resident f32 rows that are whole 16-float chunks, in a batch of whole query groups: every kernel reads the
+        // caller's rows in place (no staging launch: 4-10 us of a 50-150 us step).  What reads rows past b are the exact
+        // scans' groups of <= 4 queries only (the matrix-core filter's row groups are cut from ITS OWN centred copy, which
+        // mfma_prep_kernel fills with zero rows past b), and no kernel dereferences past element d of a row (the staged
+        // form's 16 slack floats only keep FORMED pointers inside the buffer).
+        *d_out = const_cast<float*>(queries);
+        *qstride = d;
+        return MDB_OK;
+    }
     int qs = ((d + 3) / 4) * 4 + 16;  // +16: exact_sums may form (never dereference) pointers past the row
     void* dq;
     MDB_TRY(mdb_scratch(ctx, slot, bpad * (size_t)qs * 4 + 64, &dq));
@@ -133,12 +143,73 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_scan_kernel(const float4* __re
     }
 }
 
+// Many ASCENDING partial lists of k keys (one query over a large base: a list per scan block) -> the k smallest, by a BOUND
+// instead of a selector: the k-th smallest of the lists' first keys has k distinct keys at or below it, so block_kth_bound over
+// the minima (one histogram, four barriers) gives a threshold T that only a few dozen keys pass; the lists whose minimum passes
+// are fetched whole (every load of a thread in flight together: ONE memory latency), what passes is ranked by counting.  The
+// streaming selector took k rounds of offer + round_end for the same lists: 12 us of a 110 us flat step at one query, this: ~4.
+// Returns false (uniform) when more than MLF_CAP keys pass (thousands of ties at the k-th distance): the caller streams.
+#define MLF_CAP 1024
+#define MLF_R 4        // lists per thread: up to 4096 lists
+__device__ __forceinline__ bool merge_lists_fast(const uint64_t* __restrict__ src, size_t L, int k, uint64_t* __restrict__ res, uint32_t& c_out) {
+    __shared__ uint32_t hist2[2 * (PQF_NB + 32)];
+    __shared__ uint64_t cand[MLF_CAP];
+    __shared__ uint32_t ncand;
+    const int tid = threadIdx.x;
+    uint32_t v[MLF_R];
+#pragma unroll
+    for (int r = 0; r < MLF_R; ++r) {
+        const size_t l = (size_t)r * PQF_BLOCK + tid;
+        const uint64_t k0 = l < L ? src[l * (size_t)k] : MDB_KEY_MAX;
+        v[r] = k0 == MDB_KEY_MAX ? 0xFFFFFFFFu : min((uint32_t)(k0 >> 32), 0xFFFFFFFEu);   // (all ones = "no value")
+    }
+    kth_area_reset(hist2);
+    if (tid == 0) ncand = 0;
+    __syncthreads();
+    int flip = 0;
+    const uint32_t T = block_kth_bound<MLF_R>(v, (uint32_t)k, hist2, flip);   // all ones: fewer than k lists hold a key — everything passes
+#pragma unroll
+    for (int r = 0; r < MLF_R; ++r) {
+        if (v[r] == 0xFFFFFFFFu || v[r] > T) continue;
+        const uint64_t* lp = src + ((size_t)r * PQF_BLOCK + tid) * (size_t)k;
+        bool more = true;
+        for (int j0 = 0; j0 < k && more; j0 += 16) {
+            uint64_t kk[16];
+#pragma unroll
+            for (int x = 0; x < 16; ++x) kk[x] = j0 + x < k ? lp[j0 + x] : MDB_KEY_MAX;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                if (more && kk[x] != MDB_KEY_MAX && min((uint32_t)(kk[x] >> 32), 0xFFFFFFFEu) <= T) {
+                    const uint32_t pos = atomicAdd(&ncand, 1u);
+                    if (pos < MLF_CAP) cand[pos] = kk[x];
+                } else more = false;   // ascending: nothing further in this list passes
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nc = ncand;
+    if (nc > MLF_CAP) return false;
+    for (uint32_t i = tid; i < nc; i += PQF_BLOCK) {
+        const uint64_t key = cand[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nc; ++j) {
+            const uint64_t o = cand[j];
+            rank += (o < key || (o == key && j < i)) ? 1u : 0u;   // (equal keys — a point in two posting lists — keep both, like the selector)
+        }
+        if (rank < (uint32_t)k) res[rank] = key;
+    }
+    c_out = min(nc, (uint32_t)k);
+    __syncthreads();
+    return true;
+}
+
 // one block per query: stream `per_query` candidate keys, keep the k smallest, ascending.  The partial
 // lists are sorted, so the first round already holds good keys and warm_start bounds the rest.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void merge_keys_kernel(const uint64_t* __restrict__ partial, size_t per_query, int k,
                                                            uint64_t* __restrict__ out, uint32_t* __restrict__ counts,
-                                                           const uint32_t* __restrict__ gate = nullptr, UnpackOut up = UnpackOut{}) {
+                                                           const uint32_t* __restrict__ gate = nullptr, UnpackOut up = UnpackOut{},
+                                                           int fast = 0) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (gate && *gate == 0) return;
     BlockSelect<BLOCK> sel;
@@ -146,7 +217,18 @@ __global__ __launch_bounds__(BLOCK) void merge_keys_kernel(const uint64_t* __res
     const uint64_t* src = partial + (size_t)blockIdx.x * per_query;
     constexpr int PF = 8;  // rounds fetched ahead: one load latency per PF rounds instead of one per round
     const size_t L = k > 0 && per_query % (size_t)k == 0 ? per_query / (size_t)k : 0;
-    if (L >= BLOCK / 2) {
+    __shared__ uint64_t fres[64];
+    const uint64_t* rb = sel.buf;
+    uint32_t c = 0;
+    bool done = false;
+    if constexpr (BLOCK == PQF_BLOCK) {
+        if (fast && L >= BLOCK / 2 && L <= (size_t)MLF_R * BLOCK && k <= 64) {
+            done = merge_lists_fast(src, L, k, fres, c);
+            rb = fres;
+        }
+    }
+    if (done) {
+    } else if (L >= BLOCK / 2) {
         // many sorted partial lists (one query over a large base): thread = list, round j offers every list's j-th
         // key.  Round 0 holds the list minima, so the warm-start threshold is already close to the final one and
         // almost nothing is admitted afterwards (linear order admitted ~15 % of the keys and sorted a full queue).
@@ -183,17 +265,20 @@ __global__ __launch_bounds__(BLOCK) void merge_keys_kernel(const uint64_t* __res
             }
         }
     }
-    sel.finish();
-    uint32_t c = sel.count();
-    for (int j = threadIdx.x; j < k; j += BLOCK) out[(size_t)blockIdx.x * k + j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+    if (!done) {
+        sel.finish();
+        c = sel.count();
+        rb = sel.buf;
+    }
+    for (int j = threadIdx.x; j < k; j += BLOCK) out[(size_t)blockIdx.x * k + j] = j < (int)c ? rb[j] : MDB_KEY_MAX;
     if (threadIdx.x == 0 && counts) counts[blockIdx.x] = c;
     if (up.zero4 && blockIdx.x == 0 && threadIdx.x < 4) up.zero4[threadIdx.x] = 0ull;
     if (up.word_dst && blockIdx.x == 0 && threadIdx.x == 0) *up.word_dst = *up.word_src;
     if (up.ids) {  // the caller's final (row id, distance) rows straight from here: no unpack launch, no counts copy
         for (int j = threadIdx.x; j < k; j += BLOCK) {
             const bool have = j < (int)c;
-            up.ids[(size_t)blockIdx.x * k + j] = have ? key_id(sel.buf[j]) : 0xFFFFFFFFu;
-            if (up.dist) up.dist[(size_t)blockIdx.x * k + j] = have ? key_dist(sel.buf[j]) : __uint_as_float(0x7F800000u);
+            up.ids[(size_t)blockIdx.x * k + j] = have ? key_id(rb[j]) : 0xFFFFFFFFu;
+            if (up.dist) up.dist[(size_t)blockIdx.x * k + j] = have ? key_dist(rb[j]) : __uint_as_float(0x7F800000u);
         }
         if (threadIdx.x == 0 && up.counts) up.counts[blockIdx.x] = c;
     }
@@ -204,7 +289,8 @@ static void launch_merge_keys(mdb_ctx* ctx, const uint64_t* d_partial, size_t pe
     const UnpackOut up = unpack ? *unpack : UnpackOut{};
     if (per_query >= 2048)  // many partial lists (one query over a large base): 4x fewer rounds
         merge_keys_kernel<1024><<<dim3((unsigned)b), 1024, BlockSelect<1024>::lds_bytes((int)k), ctx->stream>>>(d_partial, per_query, (int)k,
-                                                                                                               d_out, d_counts, gate, up);
+                                                                                                               d_out, d_counts, gate, up,
+                                                                                                               ctx->opt.flat_merge_old ? 0 : 1);
     else
         merge_keys_kernel<MDB_BLOCK><<<dim3((unsigned)b), MDB_BLOCK, BlockSelect<MDB_BLOCK>::lds_bytes((int)k), ctx->stream>>>(
             d_partial, per_query, (int)k, d_out, d_counts, gate, up);
@@ -433,7 +519,8 @@ mdb_status mdb_flat_search(mdb_flat* flat, const float* queries, size_t b, size_
     float* dq;
     int qstride;
     const bool batched = flat_mfma_applicable(ctx, view_of(flat->ts), flat->aux, b, k);
-    const size_t bpad = batched ? (b + 255) / 256 * 256 : (b + 3) / 4 * 4;  // whole query groups of the matrix-core filter (up to 8 x 32 rows)
+    // whole query groups of the matrix-core filter (up to 8 x 32 rows) / of the exact scan (flat_choose_qt: one query is its own group)
+    const size_t bpad = batched ? (b + 255) / 256 * 256 : (b == 1 ? 1 : (b + 3) / 4 * 4);
     MDB_TRY(stage_queries(ctx, 0, queries, b, flat->ts.d, mem, bpad, &dq, &qstride));
     void *keys, *cnts;
     bool fused = false;
