@@ -1,6 +1,10 @@
 // host_mirror_demo — drives include/muopdb_host.hpp (the C++ mirror of the reference's Spann /
 // BlockBasedHnsw / BlockBasedIvf surface) end to end on reference-format files.
 //   host_mirror_demo <dir> <dim> <k> <ef> <nprobe> <ratio>
+//   host_mirror_demo segments <dir> <dim> <k> <ef> <nexplored> <ratio>
+//     <dir>/seg0, <dir>/seg1: multi-user segments (user_table = 112-byte UserIndexInfo records + the four data files);
+//     <dir>/dead.txt: "<user> <doc>" lines, the pending segment's temporarily invalidated ids; <dir>/users.txt: user ids of
+//     search_for_users.  seg0 is wrapped in a PendingSegment, seg1 is a finalized segment of the same Snapshot.
 // <dir> holds hnsw_index, hnsw_vectors, ivf_index, ivf_vectors (reference formats) and queries.f32.
 // Prints one line per (searcher, query): "<name> <q> <n> id:scorebits ..." — the GPU test compares
 // the lines with the ctypes binding's results (tests/test_gpu_traversal.py).
@@ -8,6 +12,7 @@
 #include <cstring>
 #include <fstream>
 #include <iterator>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -30,7 +35,61 @@ static void print_row(const char* name, size_t q, const muopdb::SearchResult* r)
     std::printf("\n");
 }
 
+// PendingSegment / Snapshot (include/muopdb_host.hpp) over two GPU-resident segments: lines "pending", "snap_user", "snap_users"
+static int run_segments(int argc, char** argv) {
+    if (argc < 8) { std::fprintf(stderr, "usage: %s segments dir dim k ef nexplored ratio\n", argv[0]); return 2; }
+    const std::string dir = argv[2];
+    const uint32_t dim = std::stoul(argv[3]);
+    muopdb::SearchParams p(std::stoul(argv[4]), (uint32_t)std::stoul(argv[5]));
+    p.with_num_explored_centroids(std::stoul(argv[6])).with_centroid_distance_ratio(std::stof(argv[7]));
+    auto qb = slurp(dir + "/queries.f32");
+    const float* q = reinterpret_cast<const float*>(qb.data());
+    const size_t b = qb.size() / 4 / dim;
+    muopdb::Device dev(0);
+    std::vector<std::unique_ptr<muopdb::MultiSpannIndex>> segs;
+    std::vector<std::vector<char>> keep;
+    for (int s = 0; s < 2; ++s) {
+        const std::string sd = dir + "/seg" + std::to_string(s);
+        auto ut = slurp(sd + "/user_table");
+        std::vector<mdb_user_index_info> users(ut.size() / sizeof(mdb_user_index_info));
+        std::memcpy(users.data(), ut.data(), users.size() * sizeof(mdb_user_index_info));
+        keep.push_back(slurp(sd + "/hnsw_index")); keep.push_back(slurp(sd + "/hnsw_vectors"));
+        keep.push_back(slurp(sd + "/ivf_index")); keep.push_back(slurp(sd + "/ivf_vectors"));
+        const size_t o = keep.size() - 4;
+        segs.push_back(std::make_unique<muopdb::MultiSpannIndex>(dev, users, dim, keep[o].data(), keep[o].size(), keep[o + 1].data(),
+                                                                 keep[o + 1].size(), keep[o + 2].data(), keep[o + 2].size(),
+                                                                 keep[o + 3].data(), keep[o + 3].size(), muopdb::Quantizer::none(dim)));
+    }
+    muopdb::PendingSegment pending({segs[0].get()});
+    {
+        std::ifstream f(dir + "/dead.txt");
+        unsigned long long u, d;
+        while (f >> u >> d) pending.invalidate(u, d);
+    }
+    std::vector<muopdb::u128> users;
+    {
+        std::ifstream f(dir + "/users.txt");
+        unsigned long long u;
+        while (f >> u) users.push_back(u);
+    }
+    muopdb::Snapshot snap({muopdb::Segment(&pending), muopdb::Segment(segs[1].get())});
+    for (size_t i = 0; i < b; ++i) {
+        const float* qi = q + i * dim;
+        auto pr = pending.search_with_id(users[0], qi, p);
+        print_row("pending", i, pr ? &*pr : nullptr);
+        auto su = snap.search_for_user(users[0], qi, p);
+        print_row("snap_user", i, &su);
+        auto sm = snap.search_for_users(users, qi, p);
+        print_row("snap_users", i, &sm);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 2 && std::string(argv[1]) == "segments") {
+        try { return run_segments(argc, argv); }
+        catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if (argc < 7) { std::fprintf(stderr, "usage: %s dir dim k ef nprobe ratio\n", argv[0]); return 2; }
     try {
         const std::string dir = argv[1];

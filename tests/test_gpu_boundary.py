@@ -303,3 +303,53 @@ def test_pending_segment_over_fetch_and_snapshot_merge(ctx, oracle, case):
     many = snap.search_for_users([7, 8, 999], q[1], p)
     o3 = osegs[1].search_for_user([8], q[1:2], oracle.SearchParams(5, 50, num_explored_centroids=6))
     assert many == sorted(merged + o3.id_with_scores(0), key=lambda r: (r[1], r[0]))[:5]
+
+
+def test_cpp_pending_segment_and_snapshot_match_python(ctx, oracle, tmp_path):
+    """include/muopdb_host.hpp's PendingSegment / Snapshot (the compiled host logic a Rust or C++ host links; segment/
+    pending_segment.rs:285-335, collection/snapshot.rs:39-110) through examples/host_mirror_demo.cpp `segments`: its rows must
+    equal the Python mirror's — which the test above checks against the oracle — incl. the over-fetch around two temporarily
+    invalidated documents, a user one segment does not know and an unknown user in search_for_users."""
+    import os
+    import struct
+    import subprocess
+    from muopdb_amd.index import MultiSpannIndex, PendingSegment, SearchParams, Snapshot
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "muopdb_amd", "host_mirror_demo")
+    assert os.path.exists(exe), "host_mirror_demo not built (run __graft_entry__.build())"
+    d = 32
+    rng = np.random.default_rng(31)
+    v1 = H.sift_like(3000, d, n_clusters=20, seed=41)
+    v2 = H.sift_like(1500, d, n_clusters=12, seed=42)
+    f1, _, _ = H.build_spann_files(oracle, v1, list(range(3000)), 30, max_neighbors=8, max_layers=3, ef_construction=50)
+    f2, _, _ = H.build_spann_files(oracle, v2, list(range(100_000, 101_500)), 15, max_neighbors=8, max_layers=3, ef_construction=50)
+    cats = [F.concat_multi_spann({7: f1}), F.concat_multi_spann({7: f2, 8: f2})]
+    q = (v1[rng.integers(0, 3000, 6)] + rng.normal(0, 3, (6, d))).astype(np.float32)
+    segs = []
+    for s, cat in enumerate(cats):
+        sd = tmp_path / ("seg%d" % s)
+        sd.mkdir()
+        for name in ("user_table", "hnsw_index", "hnsw_vectors", "ivf_index", "ivf_vectors"):
+            (sd / name).write_bytes(bytes(cat[name]))
+        segs.append(MultiSpannIndex(ctx, cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"]))
+    p = SearchParams(5, 50).with_num_explored_centroids(6).with_centroid_distance_ratio(0.3)
+    first = PendingSegment(segs[:1]).search_with_id(7, q[0], p)
+    dead = {7: [first[0][0], first[2][0]]}
+    (tmp_path / "dead.txt").write_text("".join("7 %d\n" % doc for doc in dead[7]))
+    (tmp_path / "users.txt").write_text("7\n8\n999\n")
+    (tmp_path / "queries.f32").write_bytes(q.tobytes())
+    out = subprocess.run([exe, "segments", str(tmp_path), str(d), "5", "50", "6", "0.3"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = {}
+    for line in out.stdout.splitlines():
+        t = line.split()
+        got[(t[0], int(t[1]))] = None if t[2] == "none" else [(int(x.split(":")[0]), int(x.split(":")[1], 16)) for x in t[3:]]
+
+    def bits(rows):
+        return [(int(i), struct.unpack("<I", struct.pack("<f", float(s)))[0]) for i, s in rows]
+    pend = PendingSegment(segs[:1], dead)
+    snap = Snapshot([pend, segs[1]])
+    for i in range(len(q)):
+        assert got[("pending", i)] == bits(pend.search_with_id(7, q[i], p)), i
+        assert got[("snap_user", i)] == bits(snap.search_for_user(7, q[i], p)), i
+        assert got[("snap_users", i)] == bits(snap.search_for_users([7, 8, 999], q[i], p)), i
+    assert all(doc not in [r[0] for r in got[("pending", 0)]] for doc in dead[7]) and len(got[("pending", 0)]) == 5
