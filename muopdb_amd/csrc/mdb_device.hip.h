@@ -603,3 +603,45 @@ __device__ __forceinline__ uint32_t block_kth_bound(const uint32_t (&v)[R], uint
     return edge >= 0xFFFFFFFFull ? 0xFFFFFFFEu : (uint32_t)edge;   // never the "no value" image
 }
 
+// The same contract from 64 group minima: every quarter wave (16 lanes x R values) reports its minimum — 64 DISTINCT values of the
+// block — and T is the upper edge, at GB_BITS leading bits of the image, of the kth smallest of them: at least kth values lie at or
+// below it.  With kth = 16 the kth smallest group minimum is about the 19th smallest value of the block (few of the smallest share a
+// group); the histogram form cost ~7 k cycles per call in a 16-wave block (8 k LDS atomics on clustered bins, four barriers), this
+// one ~1.5 k: a row reduction, two barriers and a GB_BITS-step radix select by ballots on wave 0.  All ones when fewer than kth
+// groups hold a value.  gm: LDS [64 + 3] words — [0, 64) the minima, then three result words used in rotation (`rot`), so a slow
+// reader of call N never meets the writer of call N + 1; no initialisation needed.
+#define GB_BITS 20
+template <int R>
+__device__ __forceinline__ uint32_t block_group_bound(const uint32_t (&v)[R], uint32_t kth, uint32_t* gm, int& rot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t m = v[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) m = min(m, v[r]);
+    MDB_DPP_MIN_STEP(m, 0xB1, 0xF);   // quad_perm [1,0,3,2]
+    MDB_DPP_MIN_STEP(m, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+    MDB_DPP_MIN_STEP(m, 0x141, 0xF);  // row_half_mirror
+    MDB_DPP_MIN_STEP(m, 0x140, 0xF);  // row_mirror: every lane of a row holds the row's minimum
+    if ((lane & 15) == 0) gm[wave * 4 + (lane >> 4)] = m;
+    uint32_t* const res = gm + 64 + rot;
+    rot = rot == 2 ? 0 : rot + 1;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t g = gm[lane];
+        uint32_t T = 0xFFFFFFFFu;
+        if (kth >= 1u && (uint32_t)__popcll(__ballot(g != 0xFFFFFFFFu)) >= kth) {
+            uint32_t prefix = 0;
+            int need = (int)kth;
+#pragma unroll 4
+            for (int b = 31; b >= 32 - GB_BITS; --b) {
+                const uint32_t hi_mask = b == 31 ? 0u : (0xFFFFFFFFu << (b + 1));
+                const int cnt0 = __popcll(__ballot((((g ^ prefix) & hi_mask) == 0u) && !((g >> b) & 1u)));
+                if (cnt0 < need) { need -= cnt0; prefix |= 1u << b; }
+            }
+            T = prefix | ((1u << (32 - GB_BITS)) - 1u);
+            T = T == 0xFFFFFFFFu ? 0xFFFFFFFEu : T;   // never the "no value" image
+        }
+        if (lane == 0) *res = T;
+    }
+    __syncthreads();
+    return *res;
+}

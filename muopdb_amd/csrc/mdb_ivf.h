@@ -1,6 +1,7 @@
 // mdb_ivf.h — IvfSet: one or many (multi-user) IVF blobs resident in HBM, shared by the
 // single-index, SPANN and multi-user SPANN handles.
 #pragma once
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <utility>
@@ -69,6 +70,7 @@ struct IvfSet {
     // (tombstone mirror, doc-id maps) lives in the root and is guarded by its tomb_mu
     IvfSet* root = nullptr;
     std::mutex tomb_mu;
+    std::atomic<uint32_t> tomb_any{0};    // root: set by the first invalidate — searches of an index nobody invalidated skip the tombstone words
     void view_of(IvfSet& src, mdb_ctx* ctx2);
     // validates a per-call filter against the batch size and the largest point id; host bitmaps are staged (async, pinned)
     mdb_status stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem, size_t b, ScanFilter* out);

@@ -1027,7 +1027,14 @@ __global__ __launch_bounds__(256) void ivf_pq3_refine_kernel(ScanArgs a, const u
 // phases (reductions, scans, counting ranks) that all waves execute alike costs 16 cycles of its SIMD, so those phases are
 // written for instruction count (LDS atomics instead of per-wave loops over the other waves' partial results).
 #define PQF_NW (PQF_BLOCK / MDB_WAVE)
-#define PQF_TPW 4      // tiles per wave and chunk: a chunk of the tile sequence = 64 tiles
+#ifndef PQF_TPW_MAX
+#define PQF_TPW_MAX 6
+#endif
+                       // PQF_TPW_MAX: tiles per wave and chunk (6 with <= 4 code words per vector: a chunk = 96 tiles — C3's 16 probes are 64-75 tiles,
+                       // and a second chunk of a handful of tiles cost a whole round of fetch + bound + append: 7 k of 63 k cycles)
+#ifndef PQF_GROUP_BOUND
+#define PQF_GROUP_BOUND 1   // the k-th bounds from 64 group minima (block_group_bound) instead of the histogram (block_kth_bound)
+#endif
 #define PQF_R1 8       // centroid distances per thread and chunk of the probe selection (8 192 centroids per chunk)
 #define PQF_CAP 2048   // candidate slots kept in LDS
 #define PQF_QT 4       // queries per block of the coarse part of ivf_prep_kernel (8: 232 VGPRs, two waves per SIMD, 24 us; 4: see DESIGN)
@@ -1049,6 +1056,7 @@ struct FusedArgs {
     uint32_t cap;               // candidate slots in use (<= PQF_CAP; tests shrink it to force the overflow pass)
     uint32_t cand_words;        // LDS words reserved for the candidate records (even)
     uint32_t b, m, coarse_blocks, quant_blocks, tile_groups;
+    uint32_t no_masks;          // nothing was ever invalidated and the call has no planner filter: the scan reads neither tombstone nor allow words
 };
 
 // The coarse part stages its PQF_QT query rows in LDS: every lane of a wave needs the same query element at the same time, an
@@ -1113,7 +1121,8 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     uint32_t* red = (uint32_t*)lds;                        // [64]
     uint32_t* hist = red + 64;                             // 2 x [PQF_NB + 32]: block_kth_bound's alternating areas
     uint32_t* misc = hist + 2 * (PQF_NB + 32);             // [0] candidates [1] scored [2] coarse candidates
-    uint32_t* pstart = misc + 16;                          // [64]  first tile of probe j
+    uint32_t* gm = misc + 16;                              // [64 + 3 (+ pad to 80)] block_group_bound's minima and result words
+    uint32_t* pstart = gm + 80;                            // [64]  first tile of probe j
     uint32_t* ppref = pstart + 64;                         // [65]  exclusive prefix of the probes' tile counts (+ pad to 80)
     uint32_t* probes_l = ppref + 80;                       // [64]
     uint32_t* qcode = probes_l + 64;                       // [m <= 32]
@@ -1135,11 +1144,23 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     if (f.zero4 && qi == 0 && tid < 4) f.zero4[tid] = 0ull;
     if (tid < 16) misc[tid] = 0;
     kth_area_reset(hist);
-    int flip = 0;
+    int flip = 0, rot = 0;
+    constexpr int TPW = MW <= 4 ? PQF_TPW_MAX : 4;
     __syncthreads();   // the first block_kth_bound call adds to the area's min / max / count words: they must be cleared by then
 #define PQF_STAMP(i) do { if (f.dbg && qi == 0 && tid == 0) f.dbg[i] = __builtin_readcyclecounter(); } while (0)
 #define PQF_SUB(i) do { if (f.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); PQF_STAMP(i); } } while (0)
     PQF_STAMP(0);
+    // the first chunk of the query's centroid distances (ivf_prep_kernel's rows: written by another launch, so they come from the
+    // Infinity Cache / HBM) is requested BEFORE the quantization below and used behind it
+    uint32_t v0[PQF_R1];
+    if (COARSE) {
+        const float* dist = f.cdist + (size_t)qi * (f.cent_ntiles * MDB_TILE);
+#pragma unroll
+        for (int r = 0; r < PQF_R1; ++r) {
+            const uint32_t idx = (uint32_t)(r * PQF_BLOCK + tid);
+            v0[r] = idx < f.num_clusters ? min(f32_orderable(dist[idx]), 0xFFFFFFFEu) : 0xFFFFFFFFu;   // (all ones = "none")
+        }
+    }
     // ---- 0. the query's codes (Q::QuantizedT::process_vector, index.rs:193): one wave per subspace (qcodes != nullptr: already
     //         computed by ivf_prep_kernel)
     if (!f.qcodes) {
@@ -1163,10 +1184,12 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
 #pragma unroll
             for (int r = 0; r < PQF_R1; ++r) {
                 const uint32_t idx = c0 + (uint32_t)(r * PQF_BLOCK + tid);
-                v[r] = idx < f.num_clusters ? min(f32_orderable(dist[idx]), 0xFFFFFFFEu) : 0xFFFFFFFFu;   // (all ones = "none")
+                if (c0 == 0) v[r] = v0[r];
+                else v[r] = idx < f.num_clusters ? min(f32_orderable(dist[idx]), 0xFFFFFFFEu) : 0xFFFFFFFFu;   // (all ones = "none")
             }
             if (c0 == 0) PQF_SUB(8);
-            thr1 = min(thr1, block_kth_bound<PQF_R1>(v, (uint32_t)np, hist, flip));
+            thr1 = min(thr1, PQF_GROUP_BOUND ? block_group_bound<PQF_R1>(v, (uint32_t)np, gm, rot)
+                                             : block_kth_bound<PQF_R1>(v, (uint32_t)np, hist, flip));
             if (c0 == 0) PQF_SUB(9);
 #pragma unroll
             for (int r = 0; r < PQF_R1; ++r) {
@@ -1314,12 +1337,12 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         return pstart[j] + ((uint32_t)t - ppref[j]);
     };
 
-    // ---- 3. bounds pass, a chunk of 64 tiles at a time: wave w takes tiles c0 + w + 16 x (x < 4), all four fetched at once
+    // ---- 3. bounds pass, a chunk of 16 TPW tiles at a time: wave w takes tiles c0 + w + 16 x (x < TPW), all fetched at once
     uint32_t thr_ub = 0xFFFFFFFFu;   // image of an upper bound of the k-th exact distance (tightens chunk by chunk)
-    for (int c0 = 0; c0 < T; c0 += PQF_NW * PQF_TPW) {
-        uint32_t pid[PQF_TPW], cw[PQF_TPW][MW];
+    for (int c0 = 0; c0 < T; c0 += PQF_NW * TPW) {
+        uint32_t pid[TPW], cw[TPW][MW];
 #pragma unroll
-        for (int x = 0; x < PQF_TPW; ++x) {
+        for (int x = 0; x < TPW; ++x) {
             const int t = c0 + wave + PQF_NW * x;
             pid[x] = 0xFFFFFFFFu;
 #pragma unroll
@@ -1333,17 +1356,21 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
             }
         }
         if (c0 == 0) PQF_SUB(11);
-        uint32_t tw[PQF_TPW], aw[PQF_TPW];
+        uint32_t tw[TPW], aw[TPW];
 #pragma unroll
-        for (int x = 0; x < PQF_TPW; ++x) {
-            const uint32_t pz = pid[x] == 0xFFFFFFFFu ? 0u : pid[x];
-            tw[x] = a.tomb[u.tomb_base + (pz >> 5)];
-            aw[x] = a.allow[(size_t)qi * a.allow_stride + ((pz >> 5) & a.allow_mask)];
+        for (int x = 0; x < TPW; ++x) { tw[x] = 0u; aw[x] = 0xFFFFFFFFu; }
+        if (!f.no_masks) {   // (a dependent memory trip of the chain: ~3 k of the step's 54 k cycles)
+#pragma unroll
+            for (int x = 0; x < TPW; ++x) {
+                const uint32_t pz = pid[x] == 0xFFFFFFFFu ? 0u : pid[x];
+                tw[x] = a.tomb[u.tomb_base + (pz >> 5)];
+                aw[x] = a.allow[(size_t)qi * a.allow_stride + ((pz >> 5) & a.allow_mask)];
+            }
         }
         if (c0 == 0) PQF_SUB(12);
-        uint32_t ubi[PQF_TPW], lbi[PQF_TPW];
+        uint32_t ubi[TPW], lbi[TPW];
 #pragma unroll
-        for (int x = 0; x < PQF_TPW; ++x) {
+        for (int x = 0; x < TPW; ++x) {
             const bool take = pid[x] != 0xFFFFFFFFu && !((tw[x] >> (pid[x] & 31)) & 1u) && ((aw[x] >> (pid[x] & 31)) & 1u);
             ubi[x] = 0xFFFFFFFFu;
             lbi[x] = 0xFFFFFFFFu;   // "not taken"
@@ -1357,10 +1384,11 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
             }
         }
         if (c0 == 0) PQF_SUB(13);
-        thr_ub = min(thr_ub, block_kth_bound<PQF_TPW>(ubi, (uint32_t)a.k, hist, flip));
+        thr_ub = min(thr_ub, PQF_GROUP_BOUND ? block_group_bound<TPW>(ubi, (uint32_t)a.k, gm, rot)
+                                             : block_kth_bound<TPW>(ubi, (uint32_t)a.k, hist, flip));
         if (c0 == 0) PQF_SUB(14);
 #pragma unroll
-        for (int x = 0; x < PQF_TPW; ++x) {
+        for (int x = 0; x < TPW; ++x) {
             const bool surv = lbi[x] != 0xFFFFFFFFu && lbi[x] <= thr_ub;
             const unsigned long long sm = __ballot(surv);
             if (sm) {
@@ -1905,6 +1933,7 @@ mdb_status IvfSet::invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint
         flags_out[i] = !was;  // DashSet::insert returns true when newly inserted (index.rs:421-426)
         if (!was) {
             r.h_tomb[w] |= bit;
+            r.tomb_any.store(1u);
             MDB_HIP(ctx, hipMemcpyAsync(d_tomb.p + w, &r.h_tomb[w], 4, hipMemcpyHostToDevice, ctx->stream));
             dirty = true;
         }
@@ -2185,6 +2214,7 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
     fa.b = (uint32_t)b;
     fa.m = (uint32_t)pq.m;
     fa.tile_groups = (fa.cent_ntiles + 3) / 4;
+    fa.no_masks = (!f.allow && (root ? root : this)->tomb_any.load() == 0u) ? 1u : 0u;
     fa.coarse_blocks = coarse_here ? fa.tile_groups * (uint32_t)((b + PQF_QT - 1) / PQF_QT) : 0u;
     void *cdist = nullptr, *qcodes;
     if (coarse_here) MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)fa.cent_ntiles * MDB_TILE * 4, &cdist));
@@ -2212,7 +2242,7 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
     MDB_HIP(ctx, hipGetLastError());
     // launch 2: one block per query
     const size_t sel_bytes = (BlockSelect<PQF_BLOCK>::lds_bytes((int)std::max(k, num_probes)) + 15) & ~(size_t)15;
-    const size_t lds = (64 + 2 * (PQF_NB + 32) + 16 + 64 + 80 + 64 + 32) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * 256 * 4 + (size_t)fa.cand_words * 4 +
+    const size_t lds = (64 + 2 * (PQF_NB + 32) + 16 + 80 + 64 + 80 + 64 + 32) * 4 + (size_t)pq.m * pq.subdim * 4 + (size_t)pq.m * 256 * 4 + (size_t)fa.cand_words * 4 +
                        PQF_CAP * 8 + 64 * 8 * 3 + 64 * 4 + sel_bytes;
     const float* sdc_tab = ctx->opt.pq_sdc_max_mb > 0 ? pq.sdc.p : nullptr;   // (MDB_PQ_SDC_MAX_MB=0 at search time: the in-block build)
     {
