@@ -1059,6 +1059,56 @@ struct FusedArgs {
     uint32_t no_masks;          // nothing was ever invalidated and the call has no planner filter: the scan reads neither tombstone nor allow words
 };
 
+// exact_sums<L2, QT> for vectors of whole 16-float chunks, written on float2: every subtract / multiply / add of the lane cascade
+// is ONE v_pk_*_f32 on register pairs that are adjacent as loaded (the float4 halves of the centroid and of the LDS broadcast of the
+// query; accumulator pairs (2p, 2p + 1)) — the generic form compiled to the same packed operations plus as many v_mov_b32 arranging
+// their operands (502 moves beside 676 packed operations in ivf_prep_kernel).  Same operations in the same order per accumulator:
+// (q - x) rounded, squared rounded, added rounded; chunk c before chunk c + 1; the ordered horizontal sum at the end.
+typedef float mdb_f2 __attribute__((ext_vector_type(2)));
+template <int QT>
+__device__ __forceinline__ void l2_sums16_packed(const TileLoader& ld, const float* __restrict__ qs, int dpad, int n16, float (&out)[QT]) {
+    mdb_f2 acc[QT][8];
+#pragma unroll
+    for (int i = 0; i < QT; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = mdb_f2{0.0f, 0.0f};
+    auto add4 = [&](const float4 (&x)[4], int c) {
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            const float4* q4 = (const float4*)(qs + (size_t)i * dpad + 16 * c);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float4 q = q4[kk];
+                const mdb_f2 d0 = mdb_f2{q.x, q.y} - mdb_f2{x[kk].x, x[kk].y};
+                const mdb_f2 d1 = mdb_f2{q.z, q.w} - mdb_f2{x[kk].z, x[kk].w};
+                acc[i][2 * kk] = acc[i][2 * kk] + d0 * d0;
+                acc[i][2 * kk + 1] = acc[i][2 * kk + 1] + d1 * d1;
+            }
+        }
+    };
+    int c = 0;
+    for (; c + 2 <= n16; c += 2) {   // two chunks' loads in flight, as exact_sums issues them
+        float4 xa[4], xb[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { xa[kk] = ld.get4(4 * c + kk); xb[kk] = ld.get4(4 * c + 4 + kk); }
+        add4(xa, c);
+        add4(xb, c + 1);
+    }
+    if (c < n16) {
+        float4 xa[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xa[kk] = ld.get4(4 * c + kk);
+        add4(xa, c);
+    }
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        float s = 0.0f;   // simd_reduce_add_ordered
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s = __fadd_rn(s, acc[i][j].x); s = __fadd_rn(s, acc[i][j].y); }
+        out[i] = __fadd_rn(0.0f, s);
+    }
+}
+
 // The coarse part stages its PQF_QT query rows in LDS: every lane of a wave needs the same query element at the same time, an
 // LDS broadcast read (one ds_read_b128 per four elements, in order, partially awaitable) delivers it straight into vector
 // registers — per-lane vector loads of a uniform address cost an instruction per element (35 us for the kernel), scalar
@@ -1087,6 +1137,10 @@ __global__ __launch_bounds__(256) void ivf_prep_kernel(FusedArgs f, const float*
         // (tried: the two-buffer form of exact_sums — 35 us instead of 24, registers; the centroid's whole vector in registers,
         // one load latency per tile — 29 us; 8 instead of 4 queries per block — 24 us: the kernel sits between its LDS
         // broadcast reads and its packed arithmetic, ~7 us each per CU, not on a latency chain)
+#ifndef PQF_NO_PACKED_PREP
+        if (f.cp.n8 == 0 && f.cp.n4 == 0 && f.cp.ntail == 0) l2_sums16_packed<PQF_QT>(ld, qs, dpad, f.cp.n16, raw);
+        else
+#endif
         exact_sums<MDB_METRIC_L2, PQF_QT, TileLoader, 0>(ld, qs, dpad, f.cp, raw);
         const size_t lpad = (size_t)f.cent_ntiles * MDB_TILE;
         bool nan_seen = false;
