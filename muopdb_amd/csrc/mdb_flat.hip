@@ -436,8 +436,10 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     size_t ngroups = (ts.ntiles + 3) / 4;
     // blocks: enough to fill the chip (~4 per CU), but several rounds per block when there are many query
     // groups — a block that scans one round pays its selectors' warm-up and final sort for nothing
-    const size_t target = ctx->opt.flat_blocks > 0 ? (size_t)ctx->opt.flat_blocks : 1024;   // (HBM-resident base, batch 1: 512 blocks 0.0996 ms + merge, 1024: 0.0959, 2048: 0.0934 but a slower merge)
+    // (HBM-resident base, one query: 1024 blocks of ~4 rounds 98.0 us, 2048: 93-97, 4096 blocks of ONE round each — handed out as CUs
+    // free up, no block waits for its slowest wave's last round — 92.0; the bound + rank merge takes up to 4096 lists of k <= 64)
     const size_t qgroups = bpad / qt;
+    const size_t target = ctx->opt.flat_blocks > 0 ? (size_t)ctx->opt.flat_blocks : (qgroups == 1 && k <= 64 && !l2_resident ? 4096 : 1024);
     unsigned nblk = (unsigned)std::min<size_t>(std::max<size_t>(ngroups, 1), std::max<size_t>((target + qgroups - 1) / qgroups, 1));
     // keep the partial buffer bounded (<= 256 MiB)
     while (nblk > 32 && (size_t)nblk * bpad * std::max<size_t>(k, 1) * 8 > (256u << 20)) nblk /= 2;

@@ -173,3 +173,26 @@ def test_ivf_and_spann_device_rows_in_place(ctx, oracle):
         rows_s, sc_s = spann_dev()
     assert rows == rows_s == [owant.doc_ids(i) for i in range(b)]
     assert np.array_equal(sc.view(np.uint32), sc_s.view(np.uint32))
+
+
+def test_flat_list_merge_beyond_one_list_per_thread(ctx, oracle):
+    """300 k x 16: 1172 scan blocks for one query (one round each) -> more lists than the merge block has threads."""
+    import torch
+    from muopdb_amd.index import FlatIndex
+    n, d, k = 300_000, 16, 10
+    x = H.sift_like(n, d, n_clusters=40, seed=9)
+    rng = np.random.default_rng(10)
+    q = (x[rng.integers(0, n, 2)] + rng.normal(0, 2, (2, d))).astype(np.float32)
+    g = FlatIndex(ctx, x)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    oids, odist = oracle.flat_topk(oracle.METRIC_L2, x, q, k)
+    for i in range(2):
+        qd = torch.from_numpy(q[i:i + 1].copy()).to(dev)
+        with ctx.option("MDB_FLAT_NO_MFMA", 1):
+            got = _flat_device(ctx, g, qd, 1, k)
+            with ctx.option("MDB_FLAT_MERGE_OLD", 1):
+                old = _flat_device(ctx, g, qd, 1, k)
+            with ctx.option("MDB_FLAT_BLOCKS", 1024):
+                few = _flat_device(ctx, g, qd, 1, k)
+        assert _same(got, old) and _same(got, few)
+        assert np.array_equal(got[0][0], oids[i]) and np.array_equal(got[1][0].view(np.uint32), odist[i].view(np.uint32))
