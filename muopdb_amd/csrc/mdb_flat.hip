@@ -493,7 +493,9 @@ mdb_status mdb_flat_create(mdb_ctx* ctx, const float* base, size_t n, size_t d, 
         d_rows = staging.p;
     }
     mdb_status st = tiles_from_rows(ctx, d_rows, n, (int)d, f->ts);
-    if (st == MDB_OK) st = flat_build_aux(ctx, view_of(f->ts), f->aux, 0, f->metric);
+    // the refine gathers single vectors: in the tile store a vector is spread over d / 4 lines of 128 bytes (16 of them used each),
+    // in the row-major copy it is d / 32 whole lines — 288 GB of HBM pays for the second copy
+    if (st == MDB_OK) st = flat_build_aux(ctx, view_of(f->ts), f->aux, 0, f->metric, ctx->opt.flat_rows != 0 && n * d * 4 <= ((size_t)64 << 30));
     if (st == MDB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = mdb_fail(ctx, MDB_ERR_HIP, "sync failed");
     if (st != MDB_OK) { delete f; return st; }
     mdb_ctx_retain(ctx);
