@@ -1,5 +1,6 @@
-#!/bin/bash
-# scratch job of the moment (gpurun runs it from the repo root)
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -3
-bash scripts/profile_round.sh r04d c5 c5full
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 300 python scripts/stress_mfma.py --seconds 60 2>&1 | tail -2
+timeout 300 python scripts/stress_mfma.py --seconds 40 --coarse 2>&1 | tail -2
+timeout 400 python scripts/stress_parity.py --seconds 120 2>&1 | tail -3
