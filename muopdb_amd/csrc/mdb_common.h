@@ -64,6 +64,8 @@
     X(pqf_cap, "MDB_PQF_CAP", 2048)                    /* fused step: candidate slots (tests force the overflow pass) */      \
     X(pqf_quant_in_prep, "MDB_PQF_QUANT_IN_PREP", 0)   /* fused step: query codes in the prep kernel instead of the per-query one */ \
     X(pqf_dbg, "MDB_PQF_DBG", 0)                       /* fused step: print block 0's phase cycle counts (synchronises) */    \
+    X(scan_f32_blk, "MDB_SCAN_F32_BLK", 0)             /* f32 posting-list scan: threads per block (64 / 128; else 256) */ \
+    X(scan_f32_nsplit, "MDB_SCAN_F32_NSPLIT", 0)       /* f32 posting-list scan: blocks per query (0 = choose) */ \
     X(pq_no_fast, "MDB_PQ_NO_FAST", 0)                                                                              \
     X(pq_no_filter, "MDB_PQ_NO_FILTER", 0)                                                                          \
     X(pq_no_full, "MDB_PQ_NO_FULL", 0)                                                                              \

@@ -184,25 +184,45 @@ struct TileMap {
 };
 
 // NoQuantizer<D>: distance = D::calculate(query, vector) (noq/mod.rs:44-51): sqrt L2 / neg dot
-template <int METRIC>
-__global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, const float4* __restrict__ tiles, DistPlan p,
+// BLK: threads per block (256; 128 / 64 for short probe sets: a block ends with its slowest wave, so 9 tiles on 4 waves idle a quarter
+// of the block's wave rounds; fewer waves per block, and more splits of the tile sequence, waste less)
+template <int METRIC, int BLK>
+__global__ __launch_bounds__(BLK) void ivf_scan_f32_kernel(ScanArgs a, const float4* __restrict__ tiles, DistPlan p,
                                                                  const float* __restrict__ q, int qstride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    BlockSelect<MDB_BLOCK> sel;
-    sel.init(lds, a.k);
     TileMap map;
-    map.init(lds + ((BlockSelect<MDB_BLOCK>::lds_bytes(a.k) + 15) & ~(size_t)15));
-    const int qi = blockIdx.y, split = blockIdx.x, nsplit = gridDim.x;
+    map.init(lds + ((BlockSelect<BLK>::lds_bytes(a.k) + 15) & ~(size_t)15));
+    // workgroups go to the 8 XCDs round robin (id = query x nsplit + blockIdx.x), and the splits of a query are unequal — the first
+    // ones hold four tiles, the last one the remainder, those beyond return at once.  Taken as is, 8 splits put every query's split s
+    // on XCD s: four XCDs stream, four run empty blocks (full C4: 0.65 ms per step at 8 splits, 0.97 at 16, 0.55 at 4 and 12 against
+    // 0.49-0.50 at 3, 5, 6).  The split index is rotated by the query index, slowed to the period the XCD assignment has in it.
+    const int qi = blockIdx.y, nsplit = gridDim.x;
+    const int xg = (nsplit & 7) == 0 ? 8 : ((nsplit & 3) == 0 ? 4 : ((nsplit & 1) == 0 ? 2 : 1));   // gcd(nsplit, 8)
+    const int split = (int)((blockIdx.x + (unsigned)qi / (unsigned)(8 / xg)) % (unsigned)nsplit);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / MDB_WAVE), lane = threadIdx.x % MDB_WAVE;
-    constexpr int NW = MDB_BLOCK / MDB_WAVE;
+    constexpr int NW = BLK / MDB_WAVE;
     const IvfUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
     const float* qb = q + (size_t)qi * qstride;
     const int np = a.probe_cnt ? (int)a.probe_cnt[qi] : a.probe_stride;
     bool nan_seen = false, bad = false, first = true;
     unsigned scored = 0;
+    int T0 = -1;
+    if (u.valid && np <= MAP_PCH && nsplit > 1) {
+        // one chunk of probes (the usual case): a split beyond the query's tiles has nothing to scan — it leaves an empty row behind
+        // without setting a selector up, so the launch can afford as many splits as the LONGEST probe sets want
+        T0 = map.build(a, u, qi, 0, np, bad);
+        if (split * NW >= T0) {   // uniform
+            if (bad) atomicOr(a.flags, MDB_FLAG_RANGE);
+            uint64_t* dst0 = a.partial + ((size_t)qi * nsplit + split) * a.k;
+            for (int j = threadIdx.x; j < a.k; j += BLK) dst0[j] = MDB_KEY_MAX;
+            return;
+        }
+    }
+    BlockSelect<BLK> sel;
+    sel.init(lds, a.k);
     if (u.valid) {
         for (int p0 = 0; p0 < np; p0 += MAP_PCH) {
-            const int T = map.build(a, u, qi, p0, min(MAP_PCH, np - p0), bad);
+            const int T = T0 >= 0 ? T0 : map.build(a, u, qi, p0, min(MAP_PCH, np - p0), bad);
             const int per_round = NW * nsplit;
             const int rounds = (T + per_round - 1) / per_round;
             for (int r = 0; r < rounds; ++r) {
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(MDB_BLOCK) void ivf_scan_f32_kernel(ScanArgs a, con
     if (threadIdx.x == 0 && *sel.spare()) atomicAdd(&a.counters[2], (unsigned long long)*sel.spare());
     uint64_t* dst = a.partial + ((size_t)qi * nsplit + split) * a.k;
     uint32_t c = sel.count();
-    for (int j = threadIdx.x; j < a.k; j += MDB_BLOCK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
+    for (int j = threadIdx.x; j < a.k; j += BLK) dst[j] = j < (int)c ? sel.buf[j] : MDB_KEY_MAX;
     if (a.counts_out && threadIdx.x == 0) a.counts_out[qi] = c;
 }
 
@@ -2051,6 +2071,16 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         nsplit = (int)std::min<size_t>(std::max<size_t>(want, 1), (size_t)probe_stride);
         nsplit = std::min(nsplit, 64);
     }
+    if (kind != MDB_QUANT_PQ && probe_stride > 1) {
+        // f32 posting lists: a block's four waves take one tile each per round, so a query wants about (its tiles) / 4 blocks — all of
+        // its tiles stream at once and no block waits through a last round with one busy wave.  The tiles of a query are estimated on
+        // the host: average tiles per list x probes (x 0.6 when a ratio filter trims the probe lists: SPANN).  Full C4 (1024 queries of
+        // ~9 lists): 1 block per query 0.522 ms per step, 3: 0.493, 5: 0.488, 4 (= 3 + an empty block each): 0.521, 12: 0.595.
+        const double tiles = (double)total_tiles / (double)std::max<size_t>(G, 1) * probe_stride;   // (a split beyond a query's tiles returns at once)
+        const int by_tiles = (int)std::min<double>(16.0, std::max(1.0, std::ceil(tiles / 4.0)));
+        nsplit = std::min(std::max(nsplit, by_tiles), probe_stride);
+        if (ctx->opt.scan_f32_nsplit > 0) nsplit = (int)std::min<long long>(ctx->opt.scan_f32_nsplit, probe_stride);
+    }
     // PQ fast path (ivf_scan_pq2_kernel): compile-time subvector width, table + selector + tile map in LDS
     size_t pq2_lds = 0, pq2_lds_f = 0;
     bool pq2 = false, pq2_filt = false, pq_full = false;
@@ -2203,15 +2233,20 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
 #undef MDB_PQ_LAUNCH
     } else {
         DistPlan p = make_plan((int)num_features, metric);
-        const size_t f32_lds = ((sel_lds + 15) & ~(size_t)15) + TileMap::lds_bytes();
-        if (f32_lds > 48 * 1024) {
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_f32_kernel<MDB_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32_lds));
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_f32_kernel<MDB_METRIC_DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32_lds));
-        }
-        if (metric == MDB_METRIC_L2)
-            ivf_scan_f32_kernel<MDB_METRIC_L2><<<grid, MDB_BLOCK, f32_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);
-        else
-            ivf_scan_f32_kernel<MDB_METRIC_DOT><<<grid, MDB_BLOCK, f32_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);
+        const int fblk = (int)ctx->opt.scan_f32_blk == 64 ? 64 : ((int)ctx->opt.scan_f32_blk == 128 ? 128 : MDB_BLOCK);
+        const size_t fsel = fblk == 64 ? BlockSelect<64>::lds_bytes((int)k) : (fblk == 128 ? BlockSelect<128>::lds_bytes((int)k) : sel_lds);
+        const size_t f32_lds = ((fsel + 15) & ~(size_t)15) + TileMap::lds_bytes();
+#define MDB_F32_LAUNCH(METRIC, BLKT)                                                                                              \
+    do {                                                                                                                          \
+        if (f32_lds > 48 * 1024)                                                                                                  \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_scan_f32_kernel<METRIC, BLKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f32_lds)); \
+        ivf_scan_f32_kernel<METRIC, BLKT><<<grid, BLKT, f32_lds, ctx->stream>>>(a, (const float4*)d_tiles.p, p, d_q, qstride);   \
+    } while (0)
+#define MDB_F32_BLK(METRIC) do { if (fblk == 64) MDB_F32_LAUNCH(METRIC, 64); else if (fblk == 128) MDB_F32_LAUNCH(METRIC, 128); else MDB_F32_LAUNCH(METRIC, MDB_BLOCK); } while (0)
+        if (metric == MDB_METRIC_L2) MDB_F32_BLK(MDB_METRIC_L2);
+        else MDB_F32_BLK(MDB_METRIC_DOT);
+#undef MDB_F32_BLK
+#undef MDB_F32_LAUNCH
     }
     }
     MDB_HIP(ctx, hipGetLastError());
