@@ -197,8 +197,11 @@ __global__ __launch_bounds__(BLK) void ivf_scan_f32_kernel(ScanArgs a, const flo
     // on XCD s: four XCDs stream, four run empty blocks (full C4: 0.65 ms per step at 8 splits, 0.97 at 16, 0.55 at 4 and 12 against
     // 0.49-0.50 at 3, 5, 6).  The split index is rotated by the query index, slowed to the period the XCD assignment has in it.
     const int qi = blockIdx.y, nsplit = gridDim.x;
-    const int xg = (nsplit & 7) == 0 ? 8 : ((nsplit & 3) == 0 ? 4 : ((nsplit & 1) == 0 ? 2 : 1));   // gcd(nsplit, 8)
-    const int split = (int)((blockIdx.x + (unsigned)qi / (unsigned)(8 / xg)) % (unsigned)nsplit);
+    // (shifts and a subtract loop, no integer division: its expansion goes through v_rcp / v_fma, which the exact kernels' code
+    // objects are checked not to contain)
+    const int xsh = (nsplit & 7) == 0 ? 0 : ((nsplit & 3) == 0 ? 1 : ((nsplit & 1) == 0 ? 2 : 3));   // log2(8 / gcd(nsplit, 8))
+    int split = (int)blockIdx.x + ((qi >> xsh) & 15);
+    while (split >= nsplit) split -= nsplit;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / MDB_WAVE), lane = threadIdx.x % MDB_WAVE;
     constexpr int NW = BLK / MDB_WAVE;
     const IvfUserDev u = a.users[a.q_user ? a.q_user[qi] : 0];
