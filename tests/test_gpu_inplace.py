@@ -196,3 +196,28 @@ def test_flat_list_merge_beyond_one_list_per_thread(ctx, oracle):
                 few = _flat_device(ctx, g, qd, 1, k)
         assert _same(got, old) and _same(got, few)
         assert np.array_equal(got[0][0], oids[i]) and np.array_equal(got[1][0].view(np.uint32), odist[i].view(np.uint32))
+
+
+@pytest.mark.parametrize("nsplit,blk", [(1, 0), (2, 0), (3, 0), (8, 0), (16, 0), (5, 64), (4, 128)])
+def test_f32_posting_scan_splits_and_block_sizes(ctx, oracle, nsplit, blk):
+    """ivf_scan_f32_kernel under every blocks-per-query / threads-per-block choice: splits beyond a query's tiles return empty rows,
+    the split index is rotated by the query index (XCD-aware) — the rows must not notice."""
+    from muopdb_amd.index import BlockBasedIvf
+    rng = np.random.default_rng(100 + nsplit)
+    n, d, nl, P, k, b = 6000, 64, 50, 12, 10, 37
+    v = H.sift_like(n, d, n_clusters=25, seed=21)
+    cent = H.kmeans(v, nl, iters=3, seed=2)
+    index, vec, _ = H.build_ivf_files(v, list(range(n)), cent)
+    g = BlockBasedIvf(ctx, index, vec, None)
+    o = oracle.BlockBasedIvf(index, vec, None)
+    q = (v[rng.integers(0, n, b)] + rng.normal(0, 2, (b, d))).astype(np.float32)
+    want = o.search(q, k, num_probes=P)
+    with ctx.option("MDB_SCAN_F32_NSPLIT", nsplit), ctx.option("MDB_SCAN_F32_BLK", blk):
+        got = g.search(q, k, P)
+        one = g.search(q, k, 1)          # one probe: every split but the first is beyond the tiles
+    for i in range(b):
+        assert got.doc_ids(i) == want.doc_ids(i)
+        c = int(want.counts[i])
+        assert np.array_equal(np.asarray(got.scores[i, :c], np.float32).view(np.uint32), np.asarray(want.scores[i, :c], np.float32).view(np.uint32))
+    want1 = o.search(q, k, num_probes=1)
+    assert all(one.doc_ids(i) == want1.doc_ids(i) for i in range(b))
