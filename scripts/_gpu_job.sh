@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
-bash scripts/profile_round.sh r04f > gpurun_out/profile_round.log 2>&1; tail -15 gpurun_out/profile_round.log
+timeout 900 python -m pytest tests/test_gpu_inplace.py tests/test_gpu_traversal.py tests/test_gpu_boundary.py -x -q > gpurun_out/t_last.log 2>&1; tail -2 gpurun_out/t_last.log
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -k "c4 or spann" > gpurun_out/t_c4.log 2>&1; tail -2 gpurun_out/t_c4.log
