@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_inplace.py tests/test_gpu_traversal.py tests/test_gpu_boundary.py -x -q > gpurun_out/t_last.log 2>&1; tail -2 gpurun_out/t_last.log
-timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -k "c4 or spann" > gpurun_out/t_c4.log 2>&1; tail -2 gpurun_out/t_c4.log
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -2 gpurun_out/pytest_gpu.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 500 python scripts/stress_parity.py --seconds 240 2>&1 | tail -2
+timeout 300 python scripts/stress_mfma.py --seconds 60 2>&1 | tail -1
