@@ -737,7 +737,7 @@ __global__ void pq_sdc_kernel(const float* __restrict__ cb, int m, int K, int su
 }
 
 struct Pq3Args {
-    uint32_t* cand;       // [B][nsplit][cap] slot indices (tile * 64 + lane)
+    uint32_t* cand;       // [B][nsplit][cap] records of 1 + MW words: point id, the vector's code words (phase 2 makes no trip to the lists)
     uint32_t* cand_cnt;   // [B][nsplit]
     uint32_t cap;
     uint32_t* ovf;
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uin
     const int K = 1 << nbits;
     bool bad = false;
     unsigned scored = 0;
-    uint32_t* const my_cand = c3.cand + ((size_t)qi * nsplit + split) * c3.cap;
+    uint32_t* const my_cand = c3.cand + ((size_t)qi * nsplit + split) * c3.cap * (1 + MW);
     const float gmar = 1.5f * (float)(m * subdim + m + subdim + 16) * 5.9604645e-8f;   // the bracket's relative half width (below)
     const float lo_f = 1.0f - gmar, hi_f = 1.0f + gmar;
     const int sel_mask = (a.eager_trim & 0xFF) >= 2 ? 0 : 7;   // MDB_PQ_EAGER_TRIM=2: the selector on every round (round 2's scan)
@@ -900,7 +900,11 @@ __global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uin
                         if (lane == 0) base = atomicAdd(ccnt, (uint32_t)__popcll(sm));
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                         const uint32_t pos = base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
-                        if (surv && pos < c3.cap) my_cand[pos] = slot0[CC] + (uint32_t)lane;
+                        if (surv && pos < c3.cap) {   // the record phase 2 evaluates: no second, scattered trip to slot ids and code tiles
+                            my_cand[pos * (1 + MW)] = pid[CC];
+#pragma unroll
+                            for (int w = 0; w < MW; ++w) my_cand[pos * (1 + MW) + 1 + w] = cw[CC][w];
+                        }
                     }
                     // The selector only has to supply A bound of the k-th distance, and any k upper bounds seen so far do: it runs on
                     // the first rounds (MDB_PQ3_WARM_ROUNDS, 4: the nearest probed lists come first in the tile sequence, the bound
@@ -965,14 +969,13 @@ __global__ __launch_bounds__(256) void ivf_pq3_refine_kernel(ScanArgs a, const u
     bool nan_seen = false, first = true;
     for (int sp = 0; sp < nsplit; ++sp) {
         const uint32_t c = c3.cand_cnt[(size_t)qi * nsplit + sp];
-        const uint32_t* __restrict__ list = c3.cand + ((size_t)qi * nsplit + sp) * c3.cap;
+        const uint32_t* __restrict__ list = c3.cand + ((size_t)qi * nsplit + sp) * c3.cap * (1 + MW);
         for (uint32_t base = 0; base < c; base += 256) {
             const uint32_t i = base + tid;
             uint64_t key = MDB_KEY_MAX;
             if (i < c) {
-                const uint32_t slot = list[i];
-                const uint32_t vid = a.slot_ids[slot];
-                const uint32_t* cwp = codes + (size_t)(slot / MDB_TILE) * MW * MDB_TILE + (slot % MDB_TILE);
+                const uint32_t* rec = list + (size_t)i * (1 + MW);
+                const uint32_t vid = rec[0];
                 float s16[16], s8[8], s4[4];
 #pragma unroll
                 for (int x = 0; x < 16; ++x) s16[x] = 0.0f;
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(256) void ivf_pq3_refine_kernel(ScanArgs a, const u
                 for (int x = 0; x < 4; ++x) s4[x] = 0.0f;
 #pragma unroll
                 for (int w = 0; w < MW; ++w) {
-                    const uint32_t word = cwp[(size_t)w * MDB_TILE];
+                    const uint32_t word = rec[1 + w];
 #pragma unroll
                     for (int bi = 0; bi < 4; ++bi) {
                         const int s = w * 4 + bi;
@@ -2167,7 +2170,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
             const int ns3 = (int)std::min<size_t>(std::max<size_t>((tgt3 + b - 1) / b, 1), std::min<size_t>(16, (size_t)std::max(probe_stride, 1)));
             const uint32_t cap3 = (uint32_t)std::max<long long>(1, ctx->opt.pq3_cap);   // (tests force the overflow path)
             uint32_t *cand, *ccnt;
-            MDB_TRY(mdb_scratch(ctx, 13, b * (size_t)ns3 * cap3 * 4, (void**)&cand));
+            MDB_TRY(mdb_scratch(ctx, 13, b * (size_t)ns3 * cap3 * 4 * (1 + (size_t)mw), (void**)&cand));
             MDB_TRY(mdb_scratch(ctx, 14, b * (size_t)ns3 * 4 + 512, (void**)&ccnt));
             uint32_t* ovf3 = ccnt + ((b * (size_t)ns3 + 63) / 64) * 64;   // own 256-byte line
             MDB_HIP(ctx, hipMemsetAsync(ovf3, 0, 4, ctx->stream));
