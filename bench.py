@@ -142,6 +142,8 @@ def parse():
     p.add_argument("--plan", action="store_true",
                    help="print what `--gpus N` (workload all) will build and hold — per workload: who builds, estimated build / load "
                         "seconds, host bytes private to a rank and shared through the page cache, HBM per rank — and exit (no GPU needed)")
+    p.add_argument("--full-json", default=None, help="where rank 0 writes the full record (default gpurun_out/bench_full.json); stdout "
+                                                     "carries ONE compact line of at most %d bytes" % LINE_LIMIT)
     p.add_argument("--sift-clusters", type=int, default=None, help="SiftLike mixture components (generator exploration)")
     p.add_argument("--sift-sigma", type=float, default=None)
     p.add_argument("--sift-noise", type=float, default=None)
@@ -501,7 +503,7 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
 
 
 # ------------------------------------------------------------------------------------------ flat
-def run_flat(env, n=None, batch=None):
+def run_flat(env, n=None, batch=None, steps=None, warm=None):
     """flat brute-force L2: the C2/C3 1M base (default inside --workload all) or BASELINE config C1 (10k x 128, batch 1,
     py/create_test_hdf5.py-shaped data) with --workload flat."""
     from muopdb_amd import build as B, synth as S
@@ -511,7 +513,7 @@ def run_flat(env, n=None, batch=None):
     d = args.dim or 128
     batch = batch or args.batch or 1
     k = args.k
-    steps, warm = args.steps, args.warmup
+    steps, warm = steps or args.steps, args.warmup if warm is None else warm
     nq = (steps + warm) * batch
     if n >= 100_000:  # "flat SIFT-1M" of the north star: the C2/C3 synthetic SIFT-like base
         x, queries, desc = env.sift(n, d, nq, 2000 + rank)
@@ -550,6 +552,9 @@ def run_flat(env, n=None, batch=None):
                        "n": n, "dim": d, "batch": batch, "k": k, "index": "flat", "data": args.data},
                roofline=hbm_roofline("flat_bf16_filter_kernel" if batched else "flat_scan_kernel", abytes, kernel_ms, launches))
     finish(out, disp, abytes)   # the step's algorithmic bytes: the base once (however many passes the filter takes)
+    out["steps"], out["warmup"] = steps, warm
+    if (hi - lo) * d * 4 < (64 << 20):
+        out["note"] = "launch-latency bound: the base (%.1f MB) sits in the Infinity Cache, SURVEY 8d" % ((hi - lo) * d * 4 / 1e6)
     if batched:
         # the filter streams a bf16 copy of the base in matrix-core fragment order — the hi halves only (2 bytes per element, one
         # MFMA product per pair: MDB_BF_X1, the default for L2 stores) or hi + lo (4 bytes, three products) — plus a 4-byte norm per
@@ -1076,6 +1081,136 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
     return out
 
 
+LINE_LIMIT = 6144   # bytes of the ONE stdout line (the driver parses it from a bounded stdout tail; round 4's 24.8 KB line did not parse)
+
+
+def _r(v, sig=5):
+    """floats to `sig` significant digits (the line is a record, not a checkpoint)"""
+    if isinstance(v, float):
+        return float("%.*g" % (sig, v)) if v == v and abs(v) != float("inf") else None
+    return v
+
+
+def _compact_roofline(r):
+    if not r:
+        return None
+    out = {"bound": r.get("bound"), "kernel": str(r.get("kernel"))[:96], "bytes_per_launch": _r(float(r["bytes_per_launch"])) if r.get("bytes_per_launch") else None,
+           "kernel_ms": _r(r.get("kernel_ms")), "achieved": _r(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"),
+           "frac": _r(r.get("frac")), "traffic": _r(float(r["traffic"])) if r.get("traffic") else None}
+    mb = r.get("mfma_busy")
+    if isinstance(mb, dict) and mb.get("mfma_busy_frac_of_chip") is not None:
+        out["mfma_busy"] = _r(mb["mfma_busy_frac_of_chip"])
+    return out
+
+
+def _compact_cpu(c):
+    if not c:
+        return None
+    return {"value": _r(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
+            "sample": str(c.get("sample"))[:64], "all_cores_value": _r(c.get("all_cores_value")), "all_cores": c.get("all_cores"),
+            "cpu_model": str(c.get("cpu_model"))[:48], "ids_match_gpu": c.get("ids_match_gpu")}
+
+
+def _compact_workload(w):
+    """one entry of `workloads`: the numbers a reader recomputes from, nothing else (prose, dispersion, sweeps: the full record)"""
+    if "error" in w:
+        return {"error": str(w["error"])[:120]}
+    r, c, cfg = w.get("roofline") or {}, w.get("cpu_baseline") or {}, w.get("config") or {}
+    out = {"value": _r(w.get("value")), "ms_per_step": _r(w.get("ms_per_step")), "steps": w.get("steps"), "recall": _r(w.get("recall_at_10"), 4),
+           "batch": cfg.get("batch"), "kernel_ms": _r(r.get("kernel_ms")), "frac": _r(r.get("frac"), 4), "step_frac": _r(w.get("step_frac"), 4),
+           "cpu1": _r(c.get("value"), 4), "cpuN": _r(c.get("all_cores_value"), 4), "ids_match": c.get("ids_match_gpu")}
+    if w.get("scaling") == "strong":
+        out["scaling"] = "strong"
+    if w.get("partitioning"):
+        out["partitioning"] = w["partitioning"]
+    ex = w.get("exchange")
+    if ex:
+        out["exchange_ms"] = _r(sum(v for k_, v in ex.items() if k_.endswith("_ms_per_step")), 4)
+    mb = r.get("mfma_busy")
+    if isinstance(mb, dict) and mb.get("mfma_busy_frac_of_chip") is not None:
+        out["mfma_busy"] = _r(mb["mfma_busy_frac_of_chip"], 3)
+    if w.get("hbm_resident_bytes"):
+        out["hbm_gb"] = _r(w["hbm_resident_bytes"] / 1e9, 3)
+    return {k_: v for k_, v in out.items() if v is not None}
+
+
+def compact_line(line):
+    """The ONE stdout line of the contract, bounded (LINE_LIMIT): top level = the headline's metric / value / ms_per_step / roofline /
+    cpu_baseline / recall, `config` with a short `workload` string, `workloads` = one compact dict per entry.  Everything else
+    (dispersion, notes, sweeps, prose) goes to the full record (`emit`)."""
+    cfg = dict(line.get("config") or {})
+    short = {"workload": short_workload(cfg)}
+    for k_ in ("n", "dim", "batch", "ef", "k", "nprobe", "users", "index", "graph", "data", "parallelism", "ratio"):
+        if k_ in cfg:
+            short[k_] = cfg[k_]
+    out = {k_: line.get(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                       "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _r(out["value"], 7), _r(out["ms_per_step"], 7)
+    out["config"] = short
+    out["recall_at_10"] = _r(line.get("recall_at_10"), 4)
+    out["roofline"] = _compact_roofline(line.get("roofline"))
+    out["cpu_baseline"] = _compact_cpu(line.get("cpu_baseline"))
+    out["step_frac"] = _r(line.get("step_frac"), 4)
+    for k_ in ("rccl_ranks", "collective_backend", "partitioning"):
+        if line.get(k_) is not None:
+            out[k_] = line[k_]
+    if line.get("exchange"):
+        out["exchange"] = {k_: _r(v) for k_, v in line["exchange"].items()}
+    if isinstance(line.get("concurrent"), dict):
+        out["concurrent"] = {"streams": line["concurrent"].get("streams"), "value": _r(line["concurrent"].get("value"))}
+    if line.get("workloads"):
+        out["workloads"] = {name: _compact_workload(w) for name, w in line["workloads"].items()}
+    if line.get("full_record"):
+        out["full_record"] = line["full_record"]
+    text = json.dumps(out, separators=(",", ":"))
+    if len(text) > LINE_LIMIT and "workloads" in out:   # never exceed the bound: drop per-workload fields from the back, then entries
+        for drop in ("hbm_gb", "mfma_busy", "steps", "batch", "kernel_ms", "cpuN", "exchange_ms"):
+            for w in out["workloads"].values():
+                w.pop(drop, None)
+            text = json.dumps(out, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+        names = list(out["workloads"])
+        while len(text) > LINE_LIMIT and names:
+            out["workloads"].pop(names.pop())
+            out["workloads_truncated"] = True
+            text = json.dumps(out, separators=(",", ":"))
+    return text
+
+
+def short_workload(cfg):
+    """`config.workload`: a name a reader maps to BASELINE.json's configs, no prose"""
+    idx = cfg.get("index")
+    if idx == "hnsw":
+        return "C2 sift1m-like %dx%d hnsw ef=%d k=%d b=%d" % (cfg.get("n", 0), cfg.get("dim", 0), cfg.get("ef", 0), cfg.get("k", 0), cfg.get("batch", 0))
+    if idx == "flat":
+        return "%s flat L2 %dx%d k=%d b=%d" % ("C1" if cfg.get("n", 0) < 100_000 else "flat-1m", cfg.get("n", 0), cfg.get("dim", 0), cfg.get("k", 0), cfg.get("batch", 0))
+    if idx == "ivf-pq":
+        return "%s ivf-pq m=16 %dx%d nprobe=%d k=%d b=%d" % ("C5" if cfg.get("n", 0) > 2_000_000 else "C3", cfg.get("n", 0), cfg.get("dim", 0),
+                                                            cfg.get("nprobe", 0), cfg.get("k", 0), cfg.get("batch", 0))
+    if idx == "multi-spann":
+        return "C4 multi-spann %du x %dx%d k=%d b=%d" % (cfg.get("users", 0), cfg.get("n", 0) // max(cfg.get("users", 1), 1), cfg.get("dim", 0),
+                                                         cfg.get("k", 0), cfg.get("batch", 0))
+    return str(cfg.get("workload", ""))[:80]
+
+
+def emit(args, line):
+    """rank 0: the full record (every workload's config prose, dispersion, sweeps, notes) goes to --full-json (default
+    gpurun_out/bench_full.json when that directory can be made) and to stderr; stdout gets exactly ONE bounded line."""
+    path = args.full_json or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(line, f)
+        line["full_record"] = os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT) else path
+    except OSError:
+        pass
+    sys.stderr.write("[bench-full] " + json.dumps(line) + "\n")
+    sys.stderr.flush()
+    sys.stdout.write(compact_line(line) + "\n")
+    sys.stdout.flush()
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks through torch.distributed.run — one process per
     GPU, RCCL over xGMI — exactly the command the driver uses.  Fewer than N visible devices is an ERROR (never a silent
@@ -1172,6 +1307,9 @@ def main():
         plan = [("hnsw_c2_b1", lambda: run_hnsw(env, batch=1, graph="knn", extras=False, steps=max(args.steps, 200), warm=max(args.warmup, 20))),
                 # ef above 256: the 8-register beam of the table path (up to 448; beyond: hnsw_search_kernel), the same resident graph
                 ("hnsw_c2_ef400", lambda: run_hnsw(env, batch=64, graph="knn", extras=False, ef=400)),
+                # BASELINE configs[0]: 10 k x 128 (py/create_test_hdf5.py-shaped rows), batch 1 (+ a batch-64 point): launch latency, not HBM
+                ("flat_c1_10k_b1", lambda: run_flat(env, n=10_000, batch=1, steps=max(args.steps, 200), warm=max(args.warmup, 20))),
+                ("flat_c1_10k_b64", lambda: run_flat(env, n=10_000, batch=64, steps=max(args.steps, 100), warm=max(args.warmup, 10))),
                 ("flat_1m_b1", lambda: run_flat(env, n=1_000_000, batch=1)), ("flat_1m_b64", lambda: run_flat(env, n=1_000_000, batch=64)),
                 ("ivfpq_c3", lambda: run_ivfpq(env)), ("spann_c4_128u", lambda: run_spann(env, users=128))]
         if world > 1:   # the list-sharded configurations at full size over this job's ranks (C4: 1024 users; C5: 100M codes)
@@ -1210,7 +1348,7 @@ def main():
             "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else 0, "collective_backend": backend}
     line.update(res)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(args, line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

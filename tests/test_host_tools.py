@@ -99,3 +99,45 @@ def test_bench_shared_build_one_builder_per_job(tmp_path):
         p.join(60)
         assert p.exitcode == 0
     assert all(ok and there and not after for _, ok, there, after in res), res
+
+
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, root
+
+
+def test_bench_final_line_is_bounded_and_parses():
+    """the driver parses ONE stdout line from a bounded tail — round 4's 24.8 KB line did not parse.  A canned FULL
+    record of that run (profiles/r04_bench_all.json, 10 workloads with dispersion blocks, prose and sweeps) must compact to < 8 KB,
+    round-trip through json and still carry the contract's fields, the roofline and the cpu_baseline at the top level."""
+    import json
+    bench, root = _load_bench()
+    with open(os.path.join(root, "profiles", "r04_bench_all.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000   # the canned record IS the oversized one
+    # a worst case on top: twice the workloads, an error entry with a long message
+    for name in list(full["workloads"]):
+        full["workloads"][name + "_again"] = full["workloads"][name]
+    full["workloads"]["broken"] = {"error": "RuntimeError: " + "x" * 5000}
+    text = bench.compact_line(full)
+    assert "\n" not in text and len(text) <= bench.LINE_LIMIT < 8192
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "workloads"):
+        assert key in line, key
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "bytes_per_launch", "kernel_ms"}
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "all_cores_value", "cpu_model", "ids_match_gpu"}
+    assert abs(line["value"] - full["value"]) / full["value"] < 1e-5
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) / full["roofline"]["frac"] < 1e-3
+    assert len(line["config"]["workload"]) < 80 and "model" not in line["config"]
+    w = line["workloads"]["ivfpq_c3"]
+    assert abs(w["value"] - full["workloads"]["ivfpq_c3"]["value"]) / w["value"] < 1e-3 and "frac" in w and "cpu1" in w
+    # the plain r04 record (10 workloads) keeps every entry
+    with open(os.path.join(root, "profiles", "r04_bench_all.json")) as f:
+        plain = json.load(f)
+    line = json.loads(bench.compact_line(plain))
+    assert set(line["workloads"]) == set(plain["workloads"]) and "workloads_truncated" not in line
