@@ -60,6 +60,11 @@
     X(hnsw_table_min_b, "MDB_HNSW_TABLE_MIN_B", 1)     /* smallest batch served by the table path */               \
     X(hnsw_dbg, "MDB_HNSW_DBG", 0)                                                                                  \
     X(ivf_coarse_sample_div, "MDB_IVF_COARSE_SAMPLE_DIV", 4) /* L */                                                \
+    X(ivf_coarse_mfma, "MDB_IVF_COARSE_MFMA", 1)       /* fused IVF-PQ step: coarse search as matrix-core filter + exact candidates (0: every distance exactly) */ \
+    X(ivf_coarse_mfma_min_b, "MDB_IVF_COARSE_MFMA_MIN_B", 32) /* ... from this batch size on */                    \
+    X(cm_global_bound, "MDB_CM_GLOBAL_BOUND", 1)       /* coarse matrix-core search: second-level filter by the bound over ALL of a query's candidates */ \
+    X(cm_split, "MDB_CM_SPLIT", 0)                     /* fused IVF-PQ step: the candidates' exact distances and ranks in a launch of their own */ \
+    X(cm_dbg, "MDB_CM_DBG", 0)                         /* coarse matrix-core search: print the candidates per query (synchronises) */ \
     X(pq_no_fused, "MDB_PQ_NO_FUSED", 0)               /* small batches: the six-launch step instead of ivf_pq_fused_kernel */ \
     X(pqf_cap, "MDB_PQF_CAP", 2048)                    /* fused step: candidate slots (tests force the overflow pass) */      \
     X(pqf_quant_in_prep, "MDB_PQF_QUANT_IN_PREP", 0)   /* fused step: query codes in the prep kernel instead of the per-query one */ \

@@ -63,6 +63,17 @@ __device__ __forceinline__ float reduce_ordered(const float (&acc)[L]) {
     return s;
 }
 
+// ------------------------------------------------------------------------------------------ matrix-core operand types
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// round-to-nearest-even f32 -> bf16 bits (|v - hi| <= 2^-9 |v| for normal values; NaN stays NaN, inf stays inf)
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+    const uint32_t u = __float_as_uint(f);
+    if (f != f) return 0x7FC0u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+
 // Loader concept: float4 get4(int c4) returns elements 4*c4 .. 4*c4+3 of the stored vector.
 struct TileLoader {  // list-contiguous SoA tile, this lane's vector
     const float4* p;  // &tile4[(tile * d4) * 64 + lane]

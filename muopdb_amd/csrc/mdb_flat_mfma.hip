@@ -26,7 +26,6 @@
 #include "mdb_kernels.h"
 
 #define MF_CAP 4096  // candidates refined per query (more => the batch falls back to the exact scan)
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------ aux store
 // every `stride`-th FULL tile of the source store, copied tile by tile (ids are irrelevant: only the
@@ -127,15 +126,7 @@ bool flat_aux_subrange(const FlatAux& src, size_t first_tile, size_t ntiles, int
 }
 
 // ------------------------------------------------------------------------------------------ bf16 x 3 split
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// round-to-nearest-even f32 -> bf16 bits (|v - hi| <= 2^-9 |v| for normal values; NaN stays NaN, inf stays inf)
-__device__ __forceinline__ uint32_t bf16_rne(float f) {
-    const uint32_t u = __float_as_uint(f);
-    if (f != f) return 0x7FC0u;
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+// (bf16x8 / f32x16 / bf16_rne / bf16_to_f32: mdb_device.hip.h — shared with the coarse search of the fused IVF-PQ step)
 // (hi, lo) halves of 8 consecutive values packed as two uint4 MFMA fragments
 __device__ __forceinline__ void bf16_split8(const float (&x)[8], uint4& hi, uint4& lo) {
     uint32_t h[8], l[8];

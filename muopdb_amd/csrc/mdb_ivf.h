@@ -39,6 +39,26 @@ struct U128Hash {
 
 size_t mdb_points_block_bytes_impl(size_t b, size_t k);
 
+// operands of the fused IVF-PQ step's coarse search on the matrix cores (mdb_ivf_coarse.hip.h), built at load for ONE L2 PQ index
+// with 1024 .. 16384 centroids of 64 / 96 / 128 / 192 / 256 dimensions; empty otherwise (the step keeps ivf_prep_kernel)
+struct CoarseMfma {
+    DevBuf<uint4> chi;           // bf16 fragments of the centred centroids
+    DevBuf<float> cneg, mean;    // -xn (1 + kappa) / 2 per centroid; the centre
+    DevBuf<float> rows;          // row-major copy of the centroids (the candidates' exact distances read whole lines)
+    DevBuf<uint32_t> xnmax_bits;
+    int nk = 0;
+    size_t nt32 = 0;
+    uint32_t n = 0;
+    float kappa = 0.0f, xnmax = 0.0f;
+    bool ready() const { return chi.p != nullptr; }
+    void release() { chi.release(); cneg.release(); mean.release(); rows.release(); xnmax_bits.release(); nk = 0; nt32 = 0; n = 0; }
+    void borrow(const CoarseMfma& o) {
+        chi.borrow(o.chi); cneg.borrow(o.cneg); mean.borrow(o.mean); rows.borrow(o.rows); xnmax_bits.borrow(o.xnmax_bits);
+        nk = o.nk; nt32 = o.nt32; n = o.n; kappa = o.kappa; xnmax = o.xnmax;
+    }
+    size_t bytes() const { return chi.n * 16 + (cneg.n + mean.n + rows.n) * 4; }
+};
+
 struct IvfSet {
     mdb_ctx* ctx = nullptr;
     int kind = MDB_QUANT_NONE, metric = MDB_METRIC_L2;
@@ -82,6 +102,7 @@ struct IvfSet {
     mdb_status invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint8_t* flags_out, bool test_only);
     // single index with >= 64K centroids: sample / centred copy for the batched (MFMA-filtered) coarse search
     FlatAux cent_aux;
+    CoarseMfma cmf;                // fused IVF-PQ step: coarse search on the matrix cores (mdb_ivf_coarse.hip.h)
     FlatAux cent_slice;            // view of a centroid range for mdb_ivf_coarse_keys (a rank's share of a sharded coarse search)
     size_t slice_first = ~(size_t)0, slice_count = 0;
     // rows the queries must be staged with for coarse(): whole groups of 64 when the batched path may run

@@ -1083,6 +1083,13 @@ struct FusedArgs {
     uint32_t cand_words;        // LDS words reserved for the candidate records (even)
     uint32_t b, m, coarse_blocks, quant_blocks, tile_groups;
     uint32_t no_masks;          // nothing was ever invalidated and the call has no planner filter: the scan reads neither tombstone nor allow words
+    // COARSE == 2 (ivf_coarse_mfma_kernel ran): the query's candidate centroids, S segments of `cm_caps` slots, and the row-major centroids
+    const uint2* cm_cand;
+    const uint32_t* cm_cnt;
+    const float* cent_rows;
+    uint32_t cm_S, cm_caps;
+    float cm_kappa, cm_xnmax;
+    uint32_t cm_global;
 };
 
 // exact_sums<L2, QT> for vectors of whole 16-float chunks, written on float2: every subtract / multiply / add of the lane cascade
@@ -1192,8 +1199,10 @@ __global__ __launch_bounds__(256) void ivf_prep_kernel(FusedArgs f, const float*
     if (lane == 0) qcodes[task] = (uint8_t)code;
 }
 
+#include "mdb_ivf_coarse.hip.h"
+
 // (block_kth_bound / kth_area_reset: mdb_device.hip.h — shared with the merge of many sorted partial lists, mdb_flat.hip)
-template <int SUBDIM, int MW, bool COARSE>
+template <int SUBDIM, int MW, int COARSE>   // COARSE: 0 probes given, 1 the [B][L] distances of ivf_prep_kernel, 2 the candidates of ivf_coarse_mfma_kernel
 __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, FusedArgs f, const uint32_t* __restrict__ codes,
                                                                  const float* __restrict__ cb, const float* __restrict__ sdc) {
     constexpr int m = 4 * MW, nbits = 8, K = 256, S4 = SUBDIM / 4;
@@ -1232,8 +1241,11 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     PQF_STAMP(0);
     // the first chunk of the query's centroid distances (ivf_prep_kernel's rows: written by another launch, so they come from the
     // Infinity Cache / HBM) is requested BEFORE the quantization below and used behind it
+    const CmSelect cs{f.cm_cand, f.cm_cnt, f.cent_rows, f.cent_tiles, f.cm_S, f.cm_caps, f.num_clusters, f.b, f.cm_kappa, f.cm_xnmax, f.cp, f.cm_global};
+    CmPre<PQF_BLOCK> cm_pre;
+    if (COARSE == 2) cm_prefetch<PQF_BLOCK>(cs, (uint32_t)qi, f.q + (size_t)qi * f.qstride, cm_pre);
     uint32_t v0[PQF_R1];
-    if (COARSE) {
+    if (COARSE == 1) {
         const float* dist = f.cdist + (size_t)qi * (f.cent_ntiles * MDB_TILE);
 #pragma unroll
         for (int r = 0; r < PQF_R1; ++r) {
@@ -1254,7 +1266,12 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
 
     // ---- 1. find_nearest_centroids: the num_probes nearest by (distance, index) among the distances of ivf_prep_kernel
     int np = f.num_probes;
-    if (COARSE) {
+    if (COARSE == 2) {
+        // the candidates ivf_coarse_mfma_kernel left for this query: exact distances, rank by (distance, index) (mdb_ivf_coarse.hip.h)
+        np = min(np, (int)f.num_clusters);
+        // (their ids, counts and the query row were requested at the start of the block: cm_pre; the candidate records' area is free until phase 3)
+        cm_select_probes<PQF_BLOCK>(cs, cm_pre, (uint32_t)qi, f.q + (size_t)qi * f.qstride, np, pstart, &misc[3], ck, (uint32_t)PQF_CAP, sel_lds, cand, probes_l, nan_seen, f.dbg);
+    } else if (COARSE == 1) {
         const uint32_t lpad = f.cent_ntiles * MDB_TILE;
         const float* dist = f.cdist + (size_t)qi * lpad;
         np = min(np, (int)f.num_clusters);
@@ -1967,6 +1984,12 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
         MDB_HIP(ctx, hipGetLastError());
         // one index with a large coarse quantizer (C5: 65 536 lists): large batches of queries go through the batched flat
         // path (sample bound + matrix-core filter + exact refine) — the same probe ids, several times faster
+        // one index with a mid-sized coarse quantizer (C3: 4096 lists): find_nearest_centroids — inside the fused step or alone — runs on the matrix
+        // cores (mdb_ivf_coarse.hip.h); an optional accelerator — cm_build leaves it empty when memory is short
+        if (U == 1 && ctx->opt.ivf_coarse_mfma) {   // (find_nearest_centroids is sqrt-L2 whatever the index's metric: index.rs:155)
+            TileView cv{d_cent_tiles.p, blobs[0].num_clusters, (blobs[0].num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
+            MDB_TRY(cm_build(ctx, cv, cmf));
+        }
         if (U == 1 && blobs[0].num_clusters >= 65536) {
             TileView cv{d_cent_tiles.p, blobs[0].num_clusters, (blobs[0].num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
             const size_t sdiv = (size_t)std::max<long long>(1, ctx->opt.ivf_coarse_sample_div);
@@ -2033,6 +2056,7 @@ void IvfSet::view_of(IvfSet& src, mdb_ctx* ctx2) {
     pq.m = src.pq.m; pq.K = src.pq.K; pq.h_codebook = src.pq.h_codebook; pq.codebook.borrow(src.pq.codebook); pq.sdc.borrow(src.pq.sdc);
     mw = src.mw; ones_word = src.ones_word; max_user_vectors = src.max_user_vectors;
     flat_aux_view(src.cent_aux, cent_aux);
+    cmf.borrow(src.cmf);
 }
 
 // allow bitmaps: bit p of bitmap i keeps point p for query i (n_bitmaps == 1: one bitmap for every query).  A bitmap
@@ -2310,9 +2334,36 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
     fa.m = (uint32_t)pq.m;
     fa.tile_groups = (fa.cent_ntiles + 3) / 4;
     fa.no_masks = (!f.allow && (root ? root : this)->tomb_any.load() == 0u) ? 1u : 0u;
-    fa.coarse_blocks = coarse_here ? fa.tile_groups * (uint32_t)((b + PQF_QT - 1) / PQF_QT) : 0u;
+    // coarse search of this step: 0 probes given, 1 every distance exactly (ivf_prep_kernel -> [B][L]), 2 matrix-core filter + candidates
+    int coarse_mode = !coarse_here ? 0
+                      : cm_usable(cmf, ctx, d_q, qstride, b, num_probes) ? 2 : 1;
+    if (coarse_mode == 2 && ctx->opt.cm_split) {
+        // the coarse search as its own two launches (filter + one small block per query: ivf_coarse_rank_kernel), the fused kernel takes the probes
+        void* pr;
+        MDB_TRY(mdb_scratch(ctx, 2, b * num_probes * 4, &pr));
+        MDB_TRY(cm_find_nearest(ctx, cmf, (const float4*)(d_cent_tiles.p + (size_t)h_users[0].cent_tile_base * MDB_TILE * d4 * 4), make_plan((int)num_features, MDB_METRIC_L2),
+                                d_q, qstride, b, num_probes, (uint32_t*)pr, nullptr));
+        a.probes = (const uint32_t*)pr;
+        coarse_mode = 0;
+    }
+    fa.coarse_blocks = coarse_mode == 1 ? fa.tile_groups * (uint32_t)((b + PQF_QT - 1) / PQF_QT) : 0u;
     void *cdist = nullptr, *qcodes;
-    if (coarse_here) MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)fa.cent_ntiles * MDB_TILE * 4, &cdist));
+    if (coarse_mode == 1) MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)fa.cent_ntiles * MDB_TILE * 4, &cdist));
+    CoarseShape csh{};
+    if (coarse_mode == 2) {
+        csh = cm_shape(cmf, b, num_probes, (uint32_t)PQF_CAP);
+        void *cand, *ccnt;
+        MDB_TRY(mdb_scratch(ctx, 4, b * (size_t)csh.S * csh.caps * 8, &cand));
+        MDB_TRY(mdb_scratch(ctx, 13, b * (size_t)(csh.S + 1) * 4 + 16, &ccnt));
+        fa.cm_global = ctx->opt.cm_global_bound ? 1u : 0u;
+        fa.cm_kappa = cmf.kappa;
+        fa.cm_xnmax = cmf.xnmax;
+        fa.cm_cand = (const uint2*)cand;
+        fa.cm_cnt = (const uint32_t*)ccnt;
+        fa.cent_rows = cmf.rows.p;
+        fa.cm_S = csh.S;
+        fa.cm_caps = csh.caps;
+    }
     MDB_TRY(mdb_scratch(ctx, 7, b * (size_t)pq.m + 16, &qcodes));
     fa.cdist = (float*)cdist;
     fa.qcodes = (uint8_t*)qcodes;
@@ -2330,7 +2381,8 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
     const unsigned quant_blocks = quant_in_prep ? (unsigned)((b * (size_t)pq.m + 3) / 4) : 0u;
     fa.quant_blocks = quant_blocks;
     if (!quant_in_prep) fa.qcodes = nullptr;
-    const size_t prep_lds = coarse_here ? (size_t)PQF_QT * (d4 * 4 + 16) * 4 : 0;
+    if (coarse_mode == 2) MDB_TRY(cm_launch(ctx, cmf, d_q, qstride, b, num_probes, csh, const_cast<uint2*>(fa.cm_cand), const_cast<uint32_t*>(fa.cm_cnt)));
+    const size_t prep_lds = coarse_mode == 1 ? (size_t)PQF_QT * (d4 * 4 + 16) * 4 : 0;
     if (prep_lds > 48 * 1024) MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
     if (fa.coarse_blocks + quant_blocks)
         ivf_prep_kernel<<<dim3(fa.coarse_blocks + quant_blocks), 256, prep_lds, ctx->stream>>>(fa, d_q, pq.codebook.p, fa.cdist, (uint8_t*)qcodes, ctx->d_flags);
@@ -2348,7 +2400,12 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_pq_fused_kernel<SD, MWT, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         ivf_pq_fused_kernel<SD, MWT, CO><<<dim3((unsigned)b), PQF_BLOCK, lds, ctx->stream>>>(a, fa, d_codes.p, pq.codebook.p, sdc_tab);      \
     } while (0)
-#define MDB_PQF_CO(SD, MWT) do { if (coarse_here) MDB_PQF_LAUNCH(SD, MWT, true); else MDB_PQF_LAUNCH(SD, MWT, false); } while (0)
+#define MDB_PQF_CO(SD, MWT)                                      \
+    do {                                                         \
+        if (coarse_mode == 2) MDB_PQF_LAUNCH(SD, MWT, 2);        \
+        else if (coarse_mode == 1) MDB_PQF_LAUNCH(SD, MWT, 1);   \
+        else MDB_PQF_LAUNCH(SD, MWT, 0);                         \
+    } while (0)
 #define MDB_PQF_SD(MWT)                                       \
     do {                                                      \
         if (pq.subdim == 4) MDB_PQF_CO(4, MWT);               \
@@ -2366,9 +2423,9 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
         unsigned long long h[16];
         MDB_HIP(ctx, hipMemcpyAsync(h, fa.dbg, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
         MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[pqf] b=%zu P=%zu k=%zu cycles: probes %llu (load %llu kth %llu append %llu rank %llu) table %llu bounds %llu (fetch %llu tomb %llu lookup %llu kth %llu "
+        fprintf(stderr, "[pqf] b=%zu P=%zu k=%zu cycles: quantize %llu probes %llu (load %llu kth %llu append %llu rank %llu) table %llu bounds %llu (fetch %llu tomb %llu lookup %llu kth %llu "
                 "append %llu) exact %llu rank %llu remap %llu total %llu\n", b, num_probes, k,
-                h[1] - h[0], h[8] - h[0], h[9] - h[8], h[10] - h[9], h[1] - h[10], h[2] - h[1], h[3] - h[2], h[11] - h[2], h[12] - h[11], h[13] - h[12], h[14] - h[13], h[3] - h[14],
+                h[7] - h[0], h[1] - h[0], h[8] - h[0], h[9] - h[8], h[10] - h[9], h[1] - h[10], h[2] - h[1], h[3] - h[2], h[11] - h[2], h[12] - h[11], h[13] - h[12], h[14] - h[13], h[3] - h[14],
                 h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
     }
     return MDB_OK;
@@ -2429,6 +2486,11 @@ mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, si
                 (bi.num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
     void* keys;
     MDB_TRY(mdb_scratch(ctx, 5, b * num_probes * 8, &keys));
+    if (ui == 0 && cm_usable(cmf, ctx, d_q, qstride, b, num_probes)) {
+        // mid-sized coarse quantizer of one L2 PQ index: matrix-core filter + exact candidates (mdb_ivf_coarse.hip.h), the same ids
+        return cm_find_nearest(ctx, cmf, (const float4*)cv.data, make_plan((int)num_features, MDB_METRIC_L2), d_q, qstride, b, num_probes, d_probes,
+                               zero_counters ? ctx->d_counters : nullptr);
+    }
     if (ui == 0 && cent_aux.sample.n && bpad >= (b + 63) / 64 * 64 && flat_mfma_applicable(ctx, cv, cent_aux, b, num_probes)) {
         // the path's last merge writes the probe (centroid) ids itself and clears the context's device counters
         const UnpackOut up{d_probes, nullptr, nullptr, zero_counters ? ctx->d_counters : nullptr};

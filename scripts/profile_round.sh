@@ -16,7 +16,7 @@ WL="$@"; [ -z "$WL" ] && WL="hnsw hnsw_ef400 flat_b1 flat_b64 ivfpq spann c5 c4f
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 DUMP=/tmp/mdb_dump_round
-PAT="hnsw_|flat_scan|flat_mfma|flat_bf16|flat_refine|sample_bound|ivf_scan|ivf_pq3|ivf_prep|ivf_pq_fused|merge_keys|merge_points"
+PAT="ivf_coarse|hnsw_|flat_scan|flat_mfma|flat_bf16|flat_refine|sample_bound|ivf_scan|ivf_pq3|ivf_prep|ivf_pq_fused|merge_keys|merge_points"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # every workload's files + the un-instrumented bench line
@@ -53,11 +53,11 @@ for W in $WL; do
     echo "rc=$?" >> $OUT/${W}_replay_$C.log
     for f in /tmp/prof_${C}_$W/*counter_collection.csv; do [ -f "$f" ] && (head -1 $f; grep -E "$PAT" $f | head -400) > $OUT/${W}_pmc_$C.csv; done
   done
-  case $W in flat_b64|c5)
+  case $W in flat_b64|c5|ivfpq)
     rm -rf /tmp/prof_MFMA_$W
     timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/prof_MFMA_$W -o replay -- $REPO/muopdb_amd/replay_search $REPLAY > $OUT/${W}_replay_MFMA.log 2>&1
     echo "rc=$?" >> $OUT/${W}_replay_MFMA.log
-    for f in /tmp/prof_MFMA_$W/*counter_collection.csv; do [ -f "$f" ] && (head -1 $f; grep -E "flat_bf16|flat_mfma" $f | head -600) > $OUT/${W}_pmc_MFMA.csv; done;;
+    for f in /tmp/prof_MFMA_$W/*counter_collection.csv; do [ -f "$f" ] && (head -1 $f; grep -E "flat_bf16|flat_mfma|ivf_coarse_mfma" $f | head -600) > $OUT/${W}_pmc_MFMA.csv; done;;
   esac
   [ $W = c4full ] && rm -rf $DUMP/c4full
   [ $W = c5full ] && rm -rf $DUMP/c5full
