@@ -50,6 +50,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 DISP_REGIONS = 4       # extra timed regions per workload for the dispersion entry (Env.timed)
+WARM_MIN_S = 0.05      # Env.timed: the untimed warm-up lasts at least this long (the W steps repeated)
 PROF_EVERY = 4         # steps of the timed region between two steps whose dominant kernels are bracketed by HIP events
 METRIC = "QPS @ recall@10, SIFT-1M d=128 top-10, batch=1/64; 1/2/4/8 GPUs"
 
@@ -139,6 +140,10 @@ def parse():
                         "insert: HnswBuilder::insert's algorithm, wave-batched on the GPU (muopdb_amd.build.insert_hnsw)")
     p.add_argument("--no-insert-graph", action="store_true", help="all: skip the second HNSW line on an insert-built graph")
     p.add_argument("--insert-n", type=int, default=None, help="all: base size of the insert-built HNSW workload (default: --n)")
+    p.add_argument("--shard", default="lists", choices=["lists", "users", "batch"],
+                   help="world > 1, single workloads: posting-list shards + exact merge (default, what north_star names), or a QUERY "
+                        "partitioning with an all-gather of finished rows only: users (spann: user slot u on rank u %% world) / batch (ivfpq, "
+                        "c5full: replicas, contiguous batch slices).  --workload all runs list shards AND the comparators (SURVEY 8e: measure both)")
     p.add_argument("--plan", action="store_true",
                    help="print what `--gpus N` (workload all) will build and hold — per workload: who builds, estimated build / load "
                         "seconds, host bytes private to a rank and shared through the page cache, HBM per rank — and exit (no GPU needed)")
@@ -189,6 +194,8 @@ class Env:
         self._sift = None
         self._real = None
         self.hnsw_cache = {}
+        self.keep_tags = set()     # shared builds that a later entry of the plan maps again (their files stay until drop_kept_builds)
+        self.kept_builds = {}
 
     def barrier(self):
         if self.world > 1:
@@ -208,10 +215,12 @@ class Env:
         import shutil
         base = os.path.join(os.environ.get("MDB_BENCH_TMP", "/tmp"), "mdb_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag))
         t0 = time.time()
-        if self.rank == 0:
+        reuse = tag in self.kept_builds   # a second partitioning of the same collection (keep_tags) maps the files of the first
+        if self.rank == 0 and not reuse:
             shutil.rmtree(base, ignore_errors=True)
             os.makedirs(base)
-            built = build_fn()
+        if self.rank == 0:
+            built = build_fn() if not reuse else {}
             small = {}
             for key, val in built.items():
                 if isinstance(val, (bytes, bytearray, memoryview)) or (isinstance(val, np.ndarray) and val.nbytes >= (1 << 20)):
@@ -220,8 +229,9 @@ class Env:
                     small[key] = ("file", str(arr.dtype), arr.shape)
                 else:
                     small[key] = ("value", val)
-            with open(os.path.join(base, "meta.pkl"), "wb") as f:
-                pickle.dump(small, f)
+            if not reuse:
+                with open(os.path.join(base, "meta.pkl"), "wb") as f:
+                    pickle.dump(small, f)
             del built
         dist.barrier()
         with open(os.path.join(base, "meta.pkl"), "rb") as f:
@@ -236,9 +246,20 @@ class Env:
 
         def cleanup():
             dist.barrier()   # every rank has uploaded what it owns
-            if self.rank == 0:
+            if tag in self.keep_tags:
+                self.kept_builds[tag] = base
+            elif self.rank == 0:
                 shutil.rmtree(base, ignore_errors=True)
         return out, cleanup
+
+    def drop_kept_builds(self):
+        import shutil
+        if self.world > 1:
+            dist.barrier()
+        if self.rank == 0:
+            for base in self.kept_builds.values():
+                shutil.rmtree(base, ignore_errors=True)
+        self.kept_builds = {}
 
     def max_over_ranks(self, seconds):
         if self.world > 1:
@@ -256,9 +277,18 @@ class Env:
         for i in range(warm):
             step(i)
         self.ctx.sync()
+        # ... and at least WARM_MIN_S of device work: a workload whose W steps are a few hundred microseconds starts its timed region
+        # on a GPU that has idled through the host-side preparation before it (r05a: ONE region of flat 1M batch 1 at 0.80 ms per
+        # step, the five repeats of the same region at 0.10; the host had issued all of it in 0.5 ms).  The same W steps, repeated.
+        t_w = time.perf_counter()
+        while warm > 0 and time.perf_counter() - t_w < WARM_MIN_S:
+            for i in range(warm):
+                step(i)
+            self.ctx.sync()
         self.ctx.set_profiling(False)
         self.ctx.get_profile()
         self.barrier()
+        host = []   # host time of every step's call in the returned region: where a region loses time to ONE blocking call, it shows here
         t0 = time.perf_counter()
         for j, i in enumerate(range(warm, warm + steps)):
             # the HIP events around the dominant kernel(s) are recorded on every PROF_EVERY-th step of the timed region only: an event
@@ -268,7 +298,10 @@ class Env:
                 self.ctx.set_profiling(profiling)
             elif j % PROF_EVERY == 1:
                 self.ctx.set_profiling(False)
+            th = time.perf_counter()
             step(i)
+            host.append(time.perf_counter() - th)
+        t_issue = time.perf_counter() - t0
         self.barrier()
         elapsed = time.perf_counter() - t0
         kernel_ms, launches = self.ctx.get_profile()
@@ -293,8 +326,11 @@ class Env:
             self.barrier()
             per = sorted(ev[j].elapsed_time(ev[j + 1]) for j in range(steps))
             rs = sorted(regions)
+            hs = sorted(host)
             self.last_dispersion = dict(
                 regions=len(regions), region_ms_per_step=dict(first=regions[0], min=rs[0], median=rs[len(rs) // 2], max=rs[-1]),
+                first_region_host=dict(issue_ms=1000 * t_issue, slowest_call_ms=1000 * hs[-1], slowest_call_step=int(np.argmax(host)),
+                                       median_call_ms=1000 * hs[len(hs) // 2]),
                 per_step_gpu_ms=dict(min=per[0], median=per[len(per) // 2], max=per[-1], steps=steps,
                                      note="events on the launch stream after every step of one more region (this rank)"))
         return elapsed, kernel_ms, launches
@@ -364,12 +400,21 @@ def exchange_times(env, step, steps, warm):
     ms = D.TIMER.ms()
     D.TIMER = None
     out = {}
-    for kind in ("coarse_allgather", "merge_coarse", "points_allgather", "merge_points"):
+    for kind in ("coarse_allgather", "merge_coarse", "points_allgather", "merge_points", "rows_allgather", "rows_permute"):
         if kind in ms:
             out[kind + "_ms_per_step"] = env.max_over_ranks(ms[kind]["total_ms"] / steps)
     out["ranks"] = env.world
     out["backend"] = dist.get_backend()
     return out
+
+
+def partitioning(shard, world):
+    """how a workload's data and queries are divided among the job's ranks (both partitionings are measured)"""
+    if world == 1:
+        return "one GPU"
+    return {"lists": "posting lists sharded x%d, every rank sees the whole batch, all-gather of points blocks + exact (distance, point id) merge",
+            "users": "users sharded x%d (user slot u on rank u %% world), pairs routed to their owner, all-gather of finished rows only",
+            "batch": "replicas x%d, contiguous batch slices, all-gather of finished rows only"}[shard] % world
 
 
 def finish(out, disp, step_bytes):
@@ -600,20 +645,29 @@ def pq_scan_kernel_name(batch):
     return "ivf_scan_pq3_kernel+ivf_pq3_refine_kernel" if batch >= 512 else "ivf_pq_fused_kernel"
 
 
-def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=0, disperse=True):
+def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=0, disperse=True, shard="lists"):
     """one (nprobe) setting: timed steps + untimed re-run for results / counters"""
     from muopdb_amd import lib as L
     from muopdb_amd import distributed as D
     ctx, world = env.ctx, env.world
+    by_batch = world > 1 and shard == "batch"
     # world > 1: the EXACT sharded step — the search writes this rank's (distance, point id) rows straight into its points block
-    gather = D.PointsGather(ctx, batch, k, "cuda") if world > 1 else None
+    gather = D.PointsGather(ctx, batch, k, "cuda") if (world > 1 and not by_batch) else None
+    # ... or replicas: this rank answers its contiguous slice of the batch whole, ONE all-gather of finished rows (no merge)
+    rows = D.RowsExchange(batch, k, D.route_by_batch(batch, world), env.rank, "cuda") if by_batch else None
     ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
     sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
     cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
 
     def step(i, keep=None):
         q = queries[i * batch:(i + 1) * batch]
-        if world > 1:
+        if by_batch:
+            ql = rows.local_queries(q)
+            ctx.check(ctx.lib.mdb_ivf_search(ivf.h, C.c_void_p(ql.data_ptr()), C.c_size_t(rows.n_local), None, C.c_size_t(P), C.c_size_t(k),
+                                             C.c_int(L.MEM_DEVICE), C.c_void_p(rows.ids.data_ptr()), C.c_void_p(rows.scores.data_ptr()),
+                                             C.c_void_p(rows.counts.data_ptr())))
+            res = rows.gather()[0]
+        elif world > 1:
             # the coarse quantizer is sharded too: 1/world of the centroids per rank + one all-gather of (distance, id) rows
             probes = D.sharded_probes(ctx, ivf, q.data_ptr(), batch, P, q.device)
             ctx.check(ctx.lib.mdb_ivf_search_shard(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch), C.c_void_p(probes.data_ptr()),
@@ -658,8 +712,9 @@ def build_ivfpq(env, x, nlist, seed=3):
     return index_bytes, F.write_vector_file(codes), pq, cb
 
 
-def run_ivfpq(env):
-    """BASELINE config C3: SIFT-1M-like, IVF nlist=4096 + PQ m=16 (subdim 8) nbits=8, batch 256; nprobe sweep."""
+def run_ivfpq(env, shard=None, no_sweep=False):
+    """BASELINE config C3: SIFT-1M-like, IVF nlist=4096 + PQ m=16 (subdim 8) nbits=8, batch 256; nprobe sweep.
+    world > 1: posting-list shards + exact merge, or (shard="batch") replicas answering contiguous slices of the batch."""
     from muopdb_amd import build as B, synth as S
     from muopdb_amd.index import BlockBasedIvf
     args, ctx, rank, world = env.args, env.ctx, env.rank, env.world
@@ -670,20 +725,24 @@ def run_ivfpq(env):
     steps, warm = args.steps, args.warmup
     nlist = args.nlist or max(1, min(4096, n // 244))
     nq = (steps + warm) * batch
-    x, queries, desc = env.sift(n, d, nq, 3000)  # lists are sharded: every rank sees the SAME batch
+    shard = (shard or args.shard) if world > 1 else "lists"
+    by_batch = shard == "batch"
+    x, queries, desc = env.sift(n, d, nq, 3000)  # every rank sees the SAME batch (list shards: all of it; batch split: its slice of it)
     t0 = time.time()
     index_bytes, vec_bytes, pq, cb = build_ivfpq(env, x, nlist)
     log("ivf-pq build %.1fs" % (time.time() - t0))
-    ivf = BlockBasedIvf(ctx, index_bytes, vec_bytes, pq, shard_rank=rank, shard_world=world)
+    ivf = BlockBasedIvf(ctx, index_bytes, vec_bytes, pq, shard_rank=0 if by_batch else rank, shard_world=1 if by_batch else world)
     dump(args, rank, "ivfpq", index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy(), "codebook.f32": cb})
     tq = queries[warm * batch:(warm + steps) * batch]
     nrec = min(len(tq), 2560, max(256, int(1.3e10 // n)))  # f64 ground truth for a bounded number of the timed queries
     gt = S.exact_knn(x, k, queries=tq[:nrec], f64=True)[0].cpu().numpy()
-    m = ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt, nrec)
+    m = ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt, nrec, shard=shard)
+    part = partitioning(shard, world)
     out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=m["recall"], scaling="strong",
+               partitioning=part, shard=shard if world > 1 else None,
                config={"workload": "SIFT-1M-like synthetic %dx%d (%s), IVF nlist=%d + PQ m=16 nbits=8 (symmetric distance), nprobe=%d, "
-                                   "batch=%d, top-%d, lists sharded x%d" % (n, d, desc, nlist, P, batch, k, world),
-                       "n": n, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": args.data},
+                                   "batch=%d, top-%d, %s" % (n, d, desc, nlist, P, batch, k, part),
+                       "n": n, "dim": d, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": args.data, "parallelism": part},
                roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
     finish(out, m["disp"], m["abytes"] / steps)
@@ -723,12 +782,12 @@ def run_ivfpq(env):
                                  note="same batches, several in flight on handles attached to ONE resident index; not the workload's value")
         for lane_ in lanes:
             lane_[2].close(); lane_[1].close()
-    if not args.no_sweep:
+    if not (args.no_sweep or no_sweep):
         sweep = []
         for p in (1, 8, 16, 32, 64):
             if p > nlist:
                 continue
-            s = m if p == P else ivfpq_measure(env, ivf, x, queries, batch, k, p, steps, warm, gt, nrec, disperse=False)
+            s = m if p == P else ivfpq_measure(env, ivf, x, queries, batch, k, p, steps, warm, gt, nrec, disperse=False, shard=shard)
             sweep.append(dict(nprobe=p, recall_at_10=s["recall"], value=steps * batch / s["elapsed"], ms_per_step=1000 * s["elapsed"] / steps,
                               scan_kernel_ms=s["kernel_ms"] / max(s["launches"], 1), scored_per_query=s["scored"] / (steps * batch)))
         out["sweep"] = sweep
@@ -790,7 +849,7 @@ def run_c5_full(env, steps=None, warm=None):
     return out
 
 
-def run_c5_sharded(env, steps=None, warm=None):
+def run_c5_sharded(env, steps=None, warm=None, shard=None):
     """BASELINE config C5 over the ranks of this job (world > 1): the 100M-code index is built ONCE (rank 0, Env.shared_build), every
     rank loads the posting lists it owns from the same files (size-balanced owners, mdb_ivf_load(.., rank, world)) plus the
     replicated coarse quantizer, and a step is the EXACT sharded search: coarse search over 1/world of the centroids + one all-gather
@@ -803,6 +862,8 @@ def run_c5_sharded(env, steps=None, warm=None):
     k, P = args.k, args.nprobe or 64
     steps, warm = steps or args.steps, args.warmup if warm is None else warm
     total = args.n or 100_000_000
+    shard = shard or args.shard
+    by_batch = shard == "batch"    # replicas (1.6 GB of codes fits a GPU 180 times over): the comparator SURVEY 8e asks for
     t0 = time.time()
 
     def build():
@@ -815,17 +876,18 @@ def run_c5_sharded(env, steps=None, warm=None):
     from muopdb_amd.index import ProductQuantizer
     pq = ProductQuantizer(128, 8, 8, full["codebook"])
     t0 = time.time()
-    ivf = BlockBasedIvf(ctx, full["index"], full["vectors"], pq, shard_rank=rank, shard_world=world)
+    ivf = BlockBasedIvf(ctx, full["index"], full["vectors"], pq, shard_rank=0 if by_batch else rank, shard_world=1 if by_batch else world)
     load_s = time.time() - t0
     cleanup()
     queries = S.SiftLike(128, seed=4).draw((steps + warm) * batch, seed=5000).contiguous()   # the same batch on every rank
-    m = ivfpq_measure(env, ivf, None, queries, batch, k, P, steps, warm)
+    m = ivfpq_measure(env, ivf, None, queries, batch, k, P, steps, warm, shard=shard)
+    part = partitioning(shard, world)
     out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=None, scaling="strong",
-               config={"workload": "C5 sharded x%d: %d x 128 SiftLike rows as 16-byte PQ codes in %d posting lists dealt size-balanced to the "
-                                   "ranks, coarse quantizer sharded for the search, nprobe=%d, batch=%d, top-%d"
-                                   % (world, full["n"], full["nlist"], P, batch, k),
+               partitioning=part, shard=shard if world > 1 else None,
+               config={"workload": "C5 x%d ranks: %d x 128 SiftLike rows as 16-byte PQ codes in %d posting lists, nprobe=%d, batch=%d, top-%d; %s"
+                                   % (world, full["n"], full["nlist"], P, batch, k, part),
                        "n": full["n"], "dim": 128, "batch": batch, "k": k, "nprobe": P, "index": "ivf-pq", "data": "lowrank",
-                       "build_s": build_s, "load_s": load_s, "parallelism": "list shards x%d" % world},
+                       "build_s": build_s, "load_s": load_s, "parallelism": part},
                roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query_this_rank=m["scored"] / (steps * batch)))
     finish(out, m["disp"], m["abytes"] / steps)
@@ -916,7 +978,7 @@ def run_c5(env, steps=None, warm=None):
 
 
 # ------------------------------------------------------------------------------------------ multi-user SPANN
-def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
+def run_spann(env, users=None, no_sweep=False, steps=None, warm=None, shard=None):
     """BASELINE.md C4 shape: multi-user SPANN over unit-norm f32 rows, one (user, query) pair per user
     per batch, posting lists sharded l % world, one all-gather + merge per batch.  Defaults are a
     1/8 slice (128 users x 9766 x 768 = 3.8 GB); --users 1024 is the full 10M x 768 (30.7 GB)."""
@@ -965,8 +1027,19 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
     log("multi-user SPANN build: %d users x %d x %d, %.1fs, ivf_vectors %.2f GB" % (U, per, d, time.time() - t0,
                                                                                     len(cat["ivf_vectors"]) / 1e9))
     t0 = time.time()
-    ms = MultiSpannIndex(ctx, cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"],
-                         None, rank, world)
+    shard = (shard or args.shard) if world > 1 else "lists"
+    by_user = shard == "users"
+    if shard == "batch":
+        raise SystemExit("spann: --shard batch is not offered (the collection does not fit one GPU at scale: shard by lists or by users)")
+    if by_user:
+        # user slot u -> rank u % world: this rank loads ONLY its users' records (112-byte UserIndexInfo rows carry absolute offsets into
+        # the shared files: graphs, centroids, lists and doc ids of the other users are never uploaded), whole, unsharded
+        table = np.frombuffer(bytes(cat["user_table"]), np.uint8).reshape(U, -1)
+        mine = D.users_of_rank(U, rank, world)
+        ms = MultiSpannIndex(ctx, table[mine].tobytes(), d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], None, 0, 1)
+    else:
+        ms = MultiSpannIndex(ctx, cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"],
+                             None, rank, world)
     log("load %.1fs" % (time.time() - t0))
     cleanup()
     have_base = len(base) == U
@@ -988,7 +1061,16 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
         dump(args, rank, "spann", hnsw_index=cat["hnsw_index"], hnsw_vectors=cat["hnsw_vectors"], ivf_index=cat["ivf_index"],
              vectors=cat["ivf_vectors"], user_table=cat["user_table"],
              **{"queries.f32": queries.cpu().numpy(), "users.u64": (quser + 1).numpy().astype(np.uint64)})
-    gather = D.PointsGather(ctx, batch, k, "cuda") if world > 1 else None   # the EXACT sharded step (points blocks)
+    gather = D.PointsGather(ctx, batch, k, "cuda") if (world > 1 and not by_user) else None   # the EXACT sharded step (points blocks)
+    # user sharding: the routing of a batch's pairs is host integer work on the user ids (the aggregator's role); it is prepared per
+    # step next to the u128 user-id arrays, outside the timed region like them; the row gather of the routed queries is inside it
+    rows_ex = [D.RowsExchange(batch, k, D.route_by_user(quser[i * batch:(i + 1) * batch].tolist(), world), rank, "cuda")
+               for i in range(steps + warm)] if by_user else None
+    if by_user:   # steps with the same routing share one exchange object (query i -> user i % U with batch = U: all of them)
+        for i in range(1, len(rows_ex)):
+            if torch.equal(rows_ex[i].perm, rows_ex[0].perm):
+                rows_ex[i] = rows_ex[0]
+        uid_local = [L.u128_array([int(u) + 1 for u in quser[i * batch:(i + 1) * batch][rows_ex[i].local.cpu()].tolist()]) for i in range(steps + warm)]
     ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
     sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
     cn = torch.zeros(batch, dtype=torch.int32, device="cuda")
@@ -1010,7 +1092,14 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
 
         def step(i, keep=None):
             q = queries[i * batch:(i + 1) * batch]
-            if world > 1:
+            if by_user:
+                ex = rows_ex[i]
+                ql = ex.local_queries(q)
+                ctx.check(ctx.lib.mdb_multi_spann_search(ms.h, uid_local[i], C.c_void_p(ql.data_ptr()), C.c_size_t(ex.n_local), C.byref(params),
+                                                         C.c_int(L.MEM_DEVICE), C.c_void_p(ex.ids.data_ptr()), C.c_void_p(ex.scores.data_ptr()),
+                                                         C.c_void_p(ex.counts.data_ptr()), C.c_void_p(ex.found.data_ptr())))
+                res = ex.gather()[0]
+            elif world > 1:
                 ctx.check(ctx.lib.mdb_multi_spann_search_shard(ms.h, uid_arrays[i], C.c_void_p(q.data_ptr()), C.c_size_t(batch),
                                                                C.byref(params), C.c_int(L.MEM_DEVICE), None, C.c_size_t(0), C.c_size_t(0),
                                                                C.c_void_p(gather.send.data_ptr())))
@@ -1042,12 +1131,14 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None):
                     recall=recall_at_k(found, gts, k) if gts is not None else None, hnsw_ms=hnsw_ms / max(hnsw_launches, 1))
 
     m = measure(P, ratio)
+    part = partitioning(shard, world)
     out = dict(value=steps * batch / m["elapsed"], ms_per_step=1000 * m["elapsed"] / steps, recall_at_10=m["recall"], scaling="strong",
+               partitioning=part, shard=shard if world > 1 else None,
                config={"workload": "multi-user SPANN, %d users x %d x %d f32 (%s; BASELINE.md C4 shape), batch=%d (user,query) "
-                                   "pairs, ef=%d, num_explored_centroids=%d, ratio=%g, top-%d, posting lists sharded x%d"
-                                   % (U, per, d, desc, batch, args.ef, P, ratio, k, world),
+                                   "pairs, ef=%d, num_explored_centroids=%d, ratio=%g, top-%d, %s"
+                                   % (U, per, d, desc, batch, args.ef, P, ratio, k, part),
                        "users": U, "n": U * per, "dim": d, "batch": batch, "k": k, "nprobe": P, "ratio": ratio, "index": "multi-spann",
-                       "data": args.data},
+                       "data": args.data, "parallelism": part},
                roofline=hbm_roofline("ivf_scan_f32_kernel", m["scan_bytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
     # the centroid-graph kernel as its own entry (r3 divided its bytes by the scan kernel's time: VERDICT r3 weak #1)
@@ -1121,8 +1212,8 @@ def _compact_workload(w):
            "cpu1": _r(c.get("value"), 4), "cpuN": _r(c.get("all_cores_value"), 4), "ids_match": c.get("ids_match_gpu")}
     if w.get("scaling") == "strong":
         out["scaling"] = "strong"
-    if w.get("partitioning"):
-        out["partitioning"] = w["partitioning"]
+    if w.get("shard"):
+        out["partitioning"] = w["shard"]     # lists | users | batch (prose: the full record's `partitioning`)
     ex = w.get("exchange")
     if ex:
         out["exchange_ms"] = _r(sum(v for k_, v in ex.items() if k_.endswith("_ms_per_step")), 4)
@@ -1151,7 +1242,7 @@ def compact_line(line):
     out["roofline"] = _compact_roofline(line.get("roofline"))
     out["cpu_baseline"] = _compact_cpu(line.get("cpu_baseline"))
     out["step_frac"] = _r(line.get("step_frac"), 4)
-    for k_ in ("rccl_ranks", "collective_backend", "partitioning"):
+    for k_ in ("rccl_ranks", "collective_backend", "shard"):
         if line.get(k_) is not None:
             out[k_] = line[k_]
     if line.get("exchange"):
@@ -1251,6 +1342,11 @@ def print_plan(args):
         rows.append(dict(workload="c5_sharded (100M x 16-byte codes, 65 536 lists)", builder="rank 0, files shared", build_s=70 + 8, load_s=3,
                          host_private_gb=0.3, host_shared_gb=3.9, host_rank0_peak_gb=12.0, hbm_per_rank_gb=3.9 + 1.6 / w + 0.3,
                          note="the other ranks wait at a barrier for ~80 s: well inside the process group's timeout (10 min)"))
+        rows.append(dict(workload="spann_c4_full_by_user (user slot u on rank u %% %d, rows all-gather only)" % w, builder="maps spann_c4_full_sharded's files", build_s=0,
+                         load_s=6, host_private_gb=0.3, host_shared_gb=31.0, hbm_per_rank_gb=2 * 30.7 / w, note="each rank uploads only its users' byte ranges"))
+        rows.append(dict(workload="c5_by_batch (replicas, batch slices, rows all-gather only)", builder="maps c5_sharded's files", build_s=0, load_s=3,
+                         host_private_gb=0.3, host_shared_gb=3.9, hbm_per_rank_gb=3.9 + 1.6 + 0.3))
+        rows.append(dict(workload="ivfpq_c3_by_batch (replicas)", builder="every rank", build_s=10, load_s=1, host_private_gb=0.1, host_shared_gb=0, hbm_per_rank_gb=0.7))
     else:
         rows.append(dict(workload="c5_full_1gpu", builder="the process", build_s=66, load_s=1, host_private_gb=12.0, host_shared_gb=0, hbm_per_rank_gb=4.5))
         rows.append(dict(workload="c5_shard_per_gpu", builder="the process (reads c5_full_1gpu's files)", build_s=0, load_s=2, host_private_gb=12.0, host_shared_gb=0, hbm_per_rank_gb=1.0))
@@ -1313,10 +1409,15 @@ def main():
                 ("flat_1m_b1", lambda: run_flat(env, n=1_000_000, batch=1)), ("flat_1m_b64", lambda: run_flat(env, n=1_000_000, batch=64)),
                 ("ivfpq_c3", lambda: run_ivfpq(env)), ("spann_c4_128u", lambda: run_spann(env, users=128))]
         if world > 1:   # the list-sharded configurations at full size over this job's ranks (C4: 1024 users; C5: 100M codes)
+            env.keep_tags = {"spann_1024u", "c5"}   # the second partitioning of a collection maps the first one's files
+            # both partitionings of SURVEY 8e: list shards (what north_star names; default) and the query partitionings next to them
             if not args.no_c4_full:
-                plan.append(("spann_c4_full_sharded", lambda: run_spann(env, users=1024, no_sweep=True, steps=min(args.steps, 10), warm=min(args.warmup, 3))))
+                plan.append(("spann_c4_full_sharded", lambda: run_spann(env, users=1024, no_sweep=True, steps=min(args.steps, 10), warm=min(args.warmup, 3), shard="lists")))
+                plan.append(("spann_c4_full_by_user", lambda: run_spann(env, users=1024, no_sweep=True, steps=min(args.steps, 10), warm=min(args.warmup, 3), shard="users")))
             if not args.no_c5_full:
-                plan.append(("c5_sharded", lambda: run_c5_sharded(env, steps=min(args.steps, 6), warm=min(args.warmup, 2))))
+                plan.append(("c5_sharded", lambda: run_c5_sharded(env, steps=min(args.steps, 6), warm=min(args.warmup, 2), shard="lists")))
+                plan.append(("c5_by_batch", lambda: run_c5_sharded(env, steps=min(args.steps, 6), warm=min(args.warmup, 2), shard="batch")))
+            plan.append(("ivfpq_c3_by_batch", lambda: run_ivfpq(env, shard="batch", no_sweep=True)))
         if world == 1 and not args.no_c5_full:  # the whole of C5 on one GPU: the N = 1 anchor of its strong scaling
             plan.append(("c5_full_1gpu", lambda: run_c5_full(env, steps=min(args.steps, 6), warm=min(args.warmup, 2))))
         if world == 1 and not args.no_c5:  # one GPU's share of C5: rank 0's 1/8 of the lists, read from c5_full_1gpu's files when it ran
@@ -1338,6 +1439,7 @@ def main():
                 extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             log("%s: %.1fs" % (name, time.time() - t0))
         res["workloads"] = extra
+    env.drop_kept_builds()
     for h in env.hnsw_cache.values():
         h[0].close()
     res.pop("steps", None); res.pop("warmup", None)

@@ -13,6 +13,8 @@
 #include <fstream>
 #include <iterator>
 #include <memory>
+#include <sstream>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -73,6 +75,26 @@ static int run_segments(int argc, char** argv) {
         while (f >> u) users.push_back(u);
     }
     muopdb::Snapshot snap({muopdb::Segment(&pending), muopdb::Segment(segs[1].get())});
+    // optional planners: lines "<segment> <user> <word> <word> ..." — the allow bitmap over that user's point ids in that segment
+    // (what Planner::new(user_id, filter, multi_term_index) of snapshot.rs:82-95 resolves to); a second snapshot of the two
+    // FINALIZED segments is searched through them: lines "plan_user", "plan_users"
+    std::map<std::pair<size_t, muopdb::u128>, std::vector<uint32_t>> plans;
+    {
+        std::ifstream f(dir + "/planners.txt");
+        std::string line;
+        while (std::getline(f, line)) {
+            std::istringstream is(line);
+            size_t si; unsigned long long u; uint32_t w;
+            if (!(is >> si >> u)) continue;
+            auto& bm = plans[{si, (muopdb::u128)u}];
+            while (is >> w) bm.push_back(w);
+        }
+    }
+    muopdb::Snapshot both({muopdb::Segment(segs[0].get()), muopdb::Segment(segs[1].get())});
+    const muopdb::PlannerFn planner = [&plans](size_t si, muopdb::u128 u) -> const std::vector<uint32_t>* {
+        auto it = plans.find({si, u});
+        return it == plans.end() ? nullptr : &it->second;
+    };
     for (size_t i = 0; i < b; ++i) {
         const float* qi = q + i * dim;
         auto pr = pending.search_with_id(users[0], qi, p);
@@ -81,6 +103,12 @@ static int run_segments(int argc, char** argv) {
         print_row("snap_user", i, &su);
         auto sm = snap.search_for_users(users, qi, p);
         print_row("snap_users", i, &sm);
+        if (!plans.empty()) {
+            auto pu = both.search_for_user(users[0], qi, p, planner);
+            print_row("plan_user", i, &pu);
+            auto pm = both.search_for_users(users, qi, p, planner);
+            print_row("plan_users", i, &pm);
+        }
     }
     return 0;
 }

@@ -119,6 +119,10 @@ mdb_status mdb_wait(mdb_ctx* ctx);
 int mdb_poll(mdb_ctx* ctx);
 const char* mdb_last_error(mdb_ctx* ctx);
 mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out);
+/* free / total bytes of the context's device after the stream has drained (hipMemGetInfo): the difference around a *_load /
+ * *_create call is what that index keeps resident in HBM — tiles, codes, graphs AND the load-time accelerators (bf16 fragments,
+ * row-major copies, sample stores), i.e. the multiplier over the file bytes.  No reference counterpart (the reference mmaps). */
+mdb_status mdb_device_mem_info(mdb_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* Tuning / test switches of ONE context (kernel variants, grid targets: the list is MDB_OPTIONS in csrc/mdb_common.h, e.g.
  * "MDB_FLAT_NO_MFMA", "MDB_PQ_NO_FILTER", "MDB_HNSW_NO_BEAM").  Defaults come from same-named environment variables read
  * ONCE in mdb_device_open; no search call reads the environment.  Serialised with the context's searches; load-time switches

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <optional>
@@ -157,6 +158,12 @@ struct Rows {
     }
 };
 inline mdb_u128 split(u128 v) { return mdb_u128{(uint64_t)v, (uint64_t)(v >> 64)}; }
+// allow bitmaps of a filtered call: n_bitmaps == 1 (shared by every query) or one per query, all of the same word count
+inline void check_bitmaps(const std::vector<uint32_t>& bitmaps, size_t n_bitmaps, size_t b) {
+    if (n_bitmaps == 0 || bitmaps.empty()) throw std::invalid_argument("filtered search: no allow bitmap given");
+    if (n_bitmaps != 1 && n_bitmaps != b) throw std::invalid_argument("filtered search: n_bitmaps must be 1 or the batch size");
+    if (bitmaps.size() % n_bitmaps != 0) throw std::invalid_argument("filtered search: bitmaps.size() is not a multiple of n_bitmaps");
+}
 }  // namespace detail
 
 class BlockBasedIvf {
@@ -196,6 +203,7 @@ class BlockBasedIvf {
     // n_bitmaps == 1 -> shared by every query, else one per query
     std::vector<std::optional<SearchResult>> search_filtered(const float* queries, size_t b, size_t k, size_t num_probes,
                                                              const std::vector<uint32_t>& bitmaps, size_t n_bitmaps = 1) {
+        detail::check_bitmaps(bitmaps, n_bitmaps, b);
         detail::Rows r(b, k);
         dev_.check(mdb_ivf_search_filtered(h_, queries, b, nullptr, num_probes, k, MDB_MEM_HOST, bitmaps.data(), n_bitmaps,
                                            bitmaps.size() / n_bitmaps, r.ids.data(), r.scores.data(), r.counts.data()));
@@ -307,6 +315,7 @@ class MultiSpannIndex {
                                                              const SearchParams& p, const std::vector<uint32_t>& bitmaps,
                                                              size_t n_bitmaps = 1) {
         const size_t b = user_ids.size();
+        detail::check_bitmaps(bitmaps, n_bitmaps, b);
         std::vector<mdb_u128> ids(b);
         for (size_t i = 0; i < b; ++i) ids[i] = detail::split(user_ids[i]);
         detail::Rows r(b, p.top_k);
@@ -383,21 +392,30 @@ struct Segment {
 
 // Snapshot::search_for_user (collection/snapshot.rs:69-110): every segment is searched, the rows are concatenated, sorted by
 // IdWithScore and truncated to top_k; search_for_users (:39-66) does the same over several users' results.
+// The reference builds ONE Planner per (segment, user) from the call's DocumentFilter (:82-95): its bitmap indexes that
+// user's point ids inside that segment.  The mirror of it is a callback (segment index, user id) -> allow bitmap over those
+// point ids, or nullptr for "this segment has no term index: no filter" (multi_term_index == None, :81); it is asked once per
+// finalized segment and user.  Pending segments take no planner (pending_segment.rs:316-323).
+using PlannerFn = std::function<const std::vector<uint32_t>*(size_t segment_index, u128 user_id)>;
+
 class Snapshot {
   public:
     explicit Snapshot(std::vector<Segment> segments) : segments_(std::move(segments)) {}
-    SearchResult search_for_user(u128 user_id, const float* query, const SearchParams& params,
-                                 const std::vector<uint32_t>* planner = nullptr) {
+    size_t num_segments() const { return segments_.size(); }
+    SearchResult search_for_user(u128 user_id, const float* query, const SearchParams& params, const PlannerFn& planner = nullptr) {
         SearchResult out;
-        for (const Segment& s : segments_) {
-            auto r = s.pending ? s.pending->search_with_id(user_id, query, params) : s.finalized->search_with_id(user_id, query, params, planner);
+        for (size_t si = 0; si < segments_.size(); ++si) {
+            const Segment& s = segments_[si];
+            std::optional<SearchResult> r;
+            if (s.pending) r = s.pending->search_with_id(user_id, query, params);
+            else r = s.finalized->search_with_id(user_id, query, params, planner ? planner(si, user_id) : nullptr);
             if (r) out.id_with_scores.insert(out.id_with_scores.end(), r->id_with_scores.begin(), r->id_with_scores.end());
         }
         finish(out, params.top_k);
         return out;
     }
     SearchResult search_for_users(const std::vector<u128>& user_ids, const float* query, const SearchParams& params,
-                                  const std::vector<uint32_t>* planner = nullptr) {
+                                  const PlannerFn& planner = nullptr) {
         SearchResult out;
         for (u128 u : user_ids) {
             SearchResult r = search_for_user(u, query, params, planner);
@@ -405,6 +423,16 @@ class Snapshot {
         }
         finish(out, params.top_k);
         return out;
+    }
+    // ONE bitmap for the whole call is only meaningful where the reference would build one planner: a single finalized
+    // segment and a single user.  Anything wider must come through the callback above (a bitmap indexes ONE (segment, user)'s points).
+    SearchResult search_for_user(u128 user_id, const float* query, const SearchParams& params, const std::vector<uint32_t>* planner) {
+        if (!planner) return search_for_user(user_id, query, params, PlannerFn(nullptr));
+        size_t finalized = 0;
+        for (const Segment& s : segments_) finalized += s.finalized ? 1 : 0;
+        if (finalized > 1)
+            throw std::invalid_argument("Snapshot::search_for_user: one allow bitmap for several finalized segments (pass a PlannerFn)");
+        return search_for_user(user_id, query, params, PlannerFn([planner](size_t, u128) { return planner; }));
     }
 
   private:

@@ -183,18 +183,34 @@ mdb_status mdb_device_open(int gpu, mdb_ctx** out) {
         return MDB_ERR_HIP;
     }
     ctx->own_stream = true;
-    // the ONE place the library reads the environment: option defaults of this context (mdb_set_option changes them later)
-    // NAME=<integer> sets the value; NAME set to anything that is not an integer (empty, "yes", "true": the presence switches of
-    // earlier builds) means 1 — never a silent 0
-    auto env_value = [](const char* v) -> long long {
+    // the ONE place the library reads the environment: option defaults of this context (mdb_set_option changes them later).
+    // NAME=<integer> sets the value; on / true / yes (any case) mean 1, off / false / no mean 0; anything else — empty, a typo —
+    // keeps the DEFAULT and is reported through mdb_last_error (the call still succeeds): MDB_FLAT_ROWS=off used to ENABLE the copy,
+    // MDB_FLAT_BLOCKS= became one block
+    auto env_value = [](const char* v, long long dflt, bool* bad) -> long long {
+        while (*v == ' ' || *v == '\t') ++v;
         char* end = nullptr;
         const long long x = strtoll(v, &end, 10);
-        while (end && (*end == ' ' || *end == '\t')) ++end;
-        return (end == v || (end && *end != '\0')) ? 1 : x;
+        const char* e = end;
+        while (e && (*e == ' ' || *e == '\t')) ++e;
+        if (end != v && e && *e == '\0') return x;
+        std::string w;
+        for (const char* c = v; *c && *c != ' ' && *c != '\t'; ++c) w.push_back((char)tolower((unsigned char)*c));
+        if (w == "on" || w == "true" || w == "yes") return 1;
+        if (w == "off" || w == "false" || w == "no") return 0;
+        *bad = true;
+        return dflt;
     };
-#define X(field, name, dflt) if (const char* v = getenv(name)) ctx->opt.field = env_value(v);
+    std::string ignored;
+#define X(field, name, dflt)                                                         \
+    if (const char* v = getenv(name)) {                                              \
+        bool bad = false;                                                            \
+        ctx->opt.field = env_value(v, dflt, &bad);                                   \
+        if (bad) ignored += std::string(ignored.empty() ? "" : ", ") + name + "=\"" + v + "\""; \
+    }
     MDB_OPTIONS(X)
 #undef X
+    if (!ignored.empty()) ctx->last_error = "ignored environment values (neither an integer nor on/off/true/false/yes/no; defaults kept): " + ignored;
     *out = ctx;
     return MDB_OK;
 }
@@ -265,6 +281,15 @@ mdb_status mdb_get_profile(mdb_ctx* ctx, double* kernel_ms_out, uint64_t* launch
 }
 
 const char* mdb_last_error(mdb_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "no context"; }
+
+mdb_status mdb_device_mem_info(mdb_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    MDB_HIP(ctx, hipSetDevice(ctx->device));
+    MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MDB_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return MDB_OK;
+}
 
 mdb_status mdb_get_stats(mdb_ctx* ctx, mdb_stats* out) {
     if (!ctx || !out) return MDB_ERR_INVALID_ARG;

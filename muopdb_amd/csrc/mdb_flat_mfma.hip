@@ -172,7 +172,7 @@ __global__ void bf16_split_kernel(const float4* __restrict__ tiles, size_t n, in
     uint4 hi, lo;
     bf16_split8(x, hi, lo);
     bhi[o] = hi;
-    blo[o] = lo;
+    if (blo) blo[o] = lo;   // (the lo halves are built only for stores whose filter reads them: flat_build_aux)
 }
 
 // squared norm of every (centred) vector, fmaf chain over its d coordinates (d eps relative, as in the error budget)
@@ -234,7 +234,12 @@ mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t 
         aux.nt32 = v.ntiles * 2;
         aux.split_metric = metric;
         const size_t total = aux.nt32 * (size_t)nk * 64;
-        if (aux.bhi.alloc(total + 1) != hipSuccess || aux.blo.alloc(total + 1) != hipSuccess || aux.xnorm.alloc(aux.nt32 * 32 + 4) != hipSuccess)
+        // the lo halves (+ n d 2 bytes) only where the filter reads them: the three-product form — dot stores, or MDB_BF_X1=0 set BEFORE
+        // the load.  The default L2 filter is one product per pair (qh.xh) and never touches them; a store built without them runs
+        // that form whatever MDB_BF_X1 says later (flat_topk_keys_mfma: x1 when aux.blo is empty — its kappa is the wider one).
+        const bool need_lo = !(ctx->opt.bf_x1 >= 2 || (ctx->opt.bf_x1 == 1 && metric == MDB_METRIC_L2));
+        aux.blo.release();
+        if (aux.bhi.alloc(total + 1) != hipSuccess || (need_lo && aux.blo.alloc(total + 1) != hipSuccess) || aux.xnorm.alloc(aux.nt32 * 32 + 4) != hipSuccess)
             return mdb_fail(ctx, MDB_ERR_OOM, "bf16 split alloc (%zu fragments)", total);
         const float* mean = metric == MDB_METRIC_L2 ? aux.mean.p : nullptr;
         bf16_split_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, ctx->stream>>>((const float4*)v.data, v.n, v.d, v.d4, mean, nk, total,
@@ -248,9 +253,14 @@ mdb_status flat_build_aux(mdb_ctx* ctx, const TileView& v, FlatAux& aux, size_t 
     }
     MDB_HIP(ctx, hipGetLastError());
     if (want_rows) {
-        if (aux.rows.alloc(v.n * (size_t)v.d4 * 4 + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "row-major copy alloc");
-        untile_rows_kernel<<<dim3((unsigned)((all4 + 255) / 256)), 256, 0, ctx->stream>>>((const float4*)v.data, v.n, v.d4, (float4*)aux.rows.p);
-        MDB_HIP(ctx, hipGetLastError());
+        // an OPTIONAL accelerator: when memory is short the index still loads (the refine gathers from the tile store as before)
+        if (aux.rows.alloc(v.n * (size_t)v.d4 * 4 + 4) != hipSuccess) {
+            (void)hipGetLastError();
+            aux.rows.release();
+        } else {
+            untile_rows_kernel<<<dim3((unsigned)((all4 + 255) / 256)), 256, 0, ctx->stream>>>((const float4*)v.data, v.n, v.d4, (float4*)aux.rows.p);
+            MDB_HIP(ctx, hipGetLastError());
+        }
     }
     if (!aux.h_ovf) {
         MDB_HIP(ctx, hipHostMalloc((void**)&aux.h_ovf, 4));
@@ -1431,7 +1441,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     MDB_TRY(mdb_scratch(ctx, 9, bpadq * (size_t)qcap * 4, (void**)&qids));
     // A. bound of the k-th distance from the sample: its exact top-k (f32 route), or the k-th smallest of matrix-core upper
     //    bounds (bf16 route: no exact pass over the sample at all — the U matrix must fit 1 GiB, else the exact sample scan)
-    const bool x1 = use_bf16 && (ctx->opt.bf_x1 >= 2 || (ctx->opt.bf_x1 == 1 && metric == MDB_METRIC_L2));   // one bf16 product per pair (below)
+    const bool x1 = use_bf16 && (ctx->opt.bf_x1 >= 2 || (ctx->opt.bf_x1 == 1 && metric == MDB_METRIC_L2) || !aux.blo.p);   // one bf16 product per pair (below); always when the store holds no lo halves
     // large batches of d <= 128: the block-shared form (flat_bf16x1_block_kernel), its bound from a pass over the WHOLE base: U' has
     // one column per (tile stride, tile column) — 32 per block of the bound pass's grid — instead of one per sample row
     const bool xblock = x1 && aux.nk == 8 && b >= (size_t)std::max<long long>(1, ctx->opt.bf_block_min_b);

@@ -84,7 +84,8 @@ struct IvfSet {
         size_t n_bitmaps = 0, words = 0;  // n_bitmaps == 1: shared by every query, else >= batch
     };
     size_t ones_word = 0;
-    uint64_t max_user_vectors = 0;        // bitmaps must cover every point id of every user
+    uint64_t max_user_vectors = 0;        // bitmaps must cover every point id of every user ...
+    std::vector<uint64_t> user_points;    // ... a call that names its users: of those users (a planner's bitmap indexes ONE user's points: snapshot.rs:82-95)
     std::vector<std::unordered_map<U128Key, uint32_t, U128Hash>> doc_maps;
     // attached view (mdb_*_attach): device arrays borrowed from `root`, own context / scratch; the mutable host state
     // (tombstone mirror, doc-id maps) lives in the root and is guarded by its tomb_mu
@@ -93,7 +94,9 @@ struct IvfSet {
     std::atomic<uint32_t> tomb_any{0};    // root: set by the first invalidate — searches of an index nobody invalidated skip the tombstone words
     void view_of(IvfSet& src, mdb_ctx* ctx2);
     // validates a per-call filter against the batch size and the largest point id; host bitmaps are staged (async, pinned)
-    mdb_status stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem, size_t b, ScanFilter* out);
+    // q_user (host, [b]; nullptr: every user of the set): the bitmaps must cover the point ids of the users THIS call searches
+    mdb_status stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem, size_t b, ScanFilter* out,
+                            const uint32_t* q_user = nullptr);
 
     mdb_status load(mdb_ctx* ctx, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
                     const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant,

@@ -1862,6 +1862,8 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
         u.tomb_base = (uint32_t)tomb_words;
         tomb_words += (std::max<uint64_t>(bi.num_vectors, nv) + 31) / 32 + 1;
         max_user_vectors = std::max<uint64_t>(max_user_vectors, std::max<uint64_t>(bi.num_vectors, nv));
+        if (user_points.size() <= ui) user_points.resize(ui + 1, 0);
+        user_points[ui] = std::max<uint64_t>(bi.num_vectors, nv);
         u.cent_tile_base = (uint32_t)cent_tile_src.size();
         for (uint32_t c0 = 0; c0 < bi.num_clusters; c0 += MDB_TILE) {
             cent_tile_src.push_back(bi.centroid_offset + 8);
@@ -1943,9 +1945,14 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
         {   // the code-to-code row-sum table of the symmetric L2 distance (pq_sdc_kernel), when it is small enough to stay in L2 / MALL
             const size_t words = (size_t)pq.m * pq.K * pq.K;
             if (metric == MDB_METRIC_L2 && words && words * 4 <= (size_t)std::max<long long>(0, ctx->opt.pq_sdc_max_mb) << 20) {
-                if (pq.sdc.alloc(words + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "PQ row-sum table alloc");
-                pq_sdc_kernel<<<dim3((unsigned)((words + 255) / 256)), 256, 0, ctx->stream>>>(pq.codebook.p, pq.m, pq.K, pq.subdim, pq.sdc.p);
-                MDB_HIP(ctx, hipGetLastError());
+                // an OPTIONAL accelerator: without it the scan blocks build their table rows themselves (sdc == nullptr), as before
+                if (pq.sdc.alloc(words + 4) != hipSuccess) {
+                    (void)hipGetLastError();
+                    pq.sdc.release();
+                } else {
+                    pq_sdc_kernel<<<dim3((unsigned)((words + 255) / 256)), 256, 0, ctx->stream>>>(pq.codebook.p, pq.m, pq.K, pq.subdim, pq.sdc.p);
+                    MDB_HIP(ctx, hipGetLastError());
+                }
             }
         }
         if ((uint32_t)pq.m != quantized_dimension) return mdb_fail(ctx, MDB_ERR_FORMAT, "quantized_dimension != dimension / subvector_dimension");
@@ -2054,7 +2061,7 @@ void IvfSet::view_of(IvfSet& src, mdb_ctx* ctx2) {
     d_slot_ids.borrow(src.d_slot_ids); d_codes.borrow(src.d_codes); d_tiles.borrow(src.d_tiles); d_cent_tiles.borrow(src.d_cent_tiles);
     pq.metric = src.pq.metric; pq.dimension = src.pq.dimension; pq.subdim = src.pq.subdim; pq.num_bits = src.pq.num_bits;
     pq.m = src.pq.m; pq.K = src.pq.K; pq.h_codebook = src.pq.h_codebook; pq.codebook.borrow(src.pq.codebook); pq.sdc.borrow(src.pq.sdc);
-    mw = src.mw; ones_word = src.ones_word; max_user_vectors = src.max_user_vectors;
+    mw = src.mw; ones_word = src.ones_word; max_user_vectors = src.max_user_vectors; user_points = src.user_points;
     flat_aux_view(src.cent_aux, cent_aux);
     cmf.borrow(src.cmf);
 }
@@ -2062,12 +2069,20 @@ void IvfSet::view_of(IvfSet& src, mdb_ctx* ctx2) {
 // allow bitmaps: bit p of bitmap i keeps point p for query i (n_bitmaps == 1: one bitmap for every query).  A bitmap
 // must cover every point id a scan can meet, a per-query set every query of the batch: anything shorter would be read
 // out of bounds by allow_test.
-mdb_status IvfSet::stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem, size_t b, ScanFilter* out) {
+mdb_status IvfSet::stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem, size_t b, ScanFilter* out,
+                                const uint32_t* q_user) {
     *out = ScanFilter{};
     if (!allow) return MDB_OK;
     if (n_bitmaps == 0 || words == 0) return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "empty filter bitmap");
-    if (words < (max_user_vectors + 31) / 32)
-        return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "filter bitmaps of %zu words do not cover %zu point ids", words, (size_t)max_user_vectors);
+    uint64_t need = max_user_vectors;
+    if (q_user) {   // only the users this call searches (unknown users — slot >= the table — scan nothing)
+        const std::vector<uint64_t>& up = root ? root->user_points : user_points;
+        need = 0;
+        for (size_t i = 0; i < b; ++i)
+            if (q_user[i] < up.size()) need = std::max(need, up[q_user[i]]);
+    }
+    if (words < (need + 31) / 32)
+        return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "filter bitmaps of %zu words do not cover %zu point ids", words, (size_t)need);
     if (n_bitmaps != 1 && n_bitmaps < b)
         return mdb_fail(ctx, MDB_ERR_INVALID_ARG, "%zu filter bitmaps for a batch of %zu queries", n_bitmaps, b);
     if (n_bitmaps != 1) n_bitmaps = b;

@@ -110,7 +110,7 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
         d_q_user = (uint32_t*)(base + o_qu);
     }
     IvfSet::ScanFilter filt;
-    if (fa) MDB_TRY(s.ivf.stage_filter(fa->allow, fa->n_bitmaps, fa->words, mem, b, &filt));
+    if (fa) MDB_TRY(s.ivf.stage_filter(fa->allow, fa->n_bitmaps, fa->words, mem, b, &filt, h_q_user));
     uint64_t* ckeys = (uint64_t*)(base + o_ckeys);
     uint32_t* ccnt = (uint32_t*)(base + o_ccnt);
     uint32_t* probes = (uint32_t*)(base + o_probes);

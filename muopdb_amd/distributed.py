@@ -231,6 +231,107 @@ class PointsGather:
             self.ctx.check(self.ctx.lib.mdb_multi_spann_merge_shards(ms.h, user_ids_c, *self._tail(True)))
         return self.out_docs, self.out_scores, self.out_counts
 
+# ------------------------------------------------------------------------------------------ query partitionings (no merge)
+# SURVEY.md §8e asks for BOTH partitionings to be measured: posting-list shards (above: every rank sees every query, one all-gather
+# of points blocks + an exact merge) and QUERY partitionings, where a rank answers a disjoint subset of the batch whole and the only
+# exchange is the finished result rows:
+#   * by user  (multi-user collections): user slot u (its record in the user table) lives on rank u % world — indexes, graphs and
+#     lists of that user only; a (user, query) pair is routed to its owner (the aggregator's role: rs/aggregator/src/aggregator.rs:80-135
+#     fans a request out to the nodes that hold the shard);
+#   * by batch (an index that fits one GPU many times over, C3 / C5): replicas, rank r takes the contiguous slice split_batch(b, r, world).
+# Either way the rows a rank produced ARE the reference's rows for those queries (no cross-rank merge exists to get wrong).
+
+def user_owner(user_slot, world):
+    """rank that holds user slot `user_slot` (index of the user's record in the collection's user table)"""
+    return int(user_slot) % world
+
+
+def users_of_rank(n_users, rank, world):
+    """user slots a rank loads under user sharding"""
+    return list(range(rank, n_users, world))
+
+
+def route_by_user(user_slots, world):
+    """positions of a batch's (user, query) pairs per owning rank: [world] lists of batch positions, in batch order"""
+    out = [[] for _ in range(world)]
+    for i, u in enumerate(user_slots):
+        out[user_owner(u, world)].append(i)
+    return out
+
+
+def route_by_batch(b, world):
+    """contiguous slices of a batch of b queries, as position lists (split_batch)"""
+    return [list(range(*split_batch(b, r, world))) for r in range(world)]
+
+
+def rows_block_bytes(b, k):
+    """one rank's block of finished result rows: doc ids [b][k] u128 | scores [b][k] f32 | counts [b] u32 | found [b] u8 | pad 16"""
+    return (b * k * 20 + b * 5 + 15) // 16 * 16
+
+
+class RowsExchange:
+    """Exchange of FINISHED result rows of a query partitioning: one all-gather of fixed-size blocks per batch, then a gather by a
+    precomputed permutation into batch order — no merge.  `routes` = positions per rank (route_by_user / route_by_batch); the
+    search of this rank's `len(routes[rank])` queries writes straight into the views `ids`, `scores`, `counts`, `found`.
+
+        ex = RowsExchange(b, k, routes, rank, "cuda")
+        mdb_*_search(..., n_local, ..., ex.ids.data_ptr(), ex.scores.data_ptr(), ex.counts.data_ptr(), ex.found.data_ptr())
+        docs, scores, counts, found = ex.gather()          # [b,k,2] int64 (lo, hi), [b,k], [b], [b] in batch order on every rank
+    """
+
+    def __init__(self, b, k, routes, rank, device, group=None):
+        self.b, self.k, self.group, self.rank = b, k, group, rank
+        self.world = len(routes)
+        seen = sorted(i for r in routes for i in r)
+        if seen != list(range(b)):
+            raise ValueError("RowsExchange: the routes must cover every query of the batch exactly once")
+        self.bmax = max(1, max(len(r) for r in routes))
+        self.n_local = len(routes[rank])
+        self.blk = rows_block_bytes(self.bmax, k)
+        self.send = torch.zeros(self.blk, dtype=torch.uint8, device=device)
+        self.recv = torch.zeros(self.world * self.blk, dtype=torch.uint8, device=device)
+        self.ids, self.scores, self.counts, self.found = self._views(self.send)
+        perm = [0] * b
+        for r, pos in enumerate(routes):
+            for j, i in enumerate(pos):
+                perm[i] = r * self.bmax + j
+        self.perm = torch.tensor(perm, dtype=torch.int64, device=device)
+        self.local = torch.tensor(routes[rank], dtype=torch.int64, device=device)
+        self.lo = routes[rank][0] if routes[rank] else 0
+        self.contiguous = routes[rank] == list(range(self.lo, self.lo + self.n_local))
+
+    def _views(self, block):
+        b, k = self.bmax, self.k
+        ids = block[:b * k * 16].view(torch.int64).view(b, k, 2)
+        scores = block[b * k * 16:b * k * 20].view(torch.float32).view(b, k)
+        counts = block[b * k * 20:b * k * 20 + b * 4].view(torch.int32)
+        found = block[b * k * 20 + b * 4:b * k * 20 + b * 5]
+        return ids, scores, counts, found
+
+    def local_queries(self, q):
+        """this rank's rows of the batch's query matrix (a view when the route is a contiguous slice)"""
+        if self.n_local == 0:
+            return q[:0]
+        if self.contiguous:
+            return q[self.lo:self.lo + self.n_local]
+        return q.index_select(0, self.local)
+
+    def gather(self):
+        with _span("rows_allgather"):
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            else:
+                self.recv.copy_(self.send)
+        with _span("rows_permute"):
+            b, k, w = self.bmax, self.k, self.world
+            blocks = self.recv.view(w, self.blk)
+            ids = blocks[:, :b * k * 16].contiguous().view(torch.int64).view(w * b, k, 2).index_select(0, self.perm)
+            scores = blocks[:, b * k * 16:b * k * 20].contiguous().view(torch.float32).view(w * b, k).index_select(0, self.perm)
+            counts = blocks[:, b * k * 20:b * k * 20 + b * 4].contiguous().view(torch.int32).view(w * b).index_select(0, self.perm)
+            found = blocks[:, b * k * 20 + b * 4:b * k * 20 + b * 5].contiguous().view(w * b).index_select(0, self.perm)
+        return ids, scores, counts, found
+
+
 def all_gather_topk(doc_ids, scores, counts, group=None):
     """Unpacked variant (three collectives; kept for callers that hold three separate tensors — the packed class above is
     the step's path): ([W,B,k,2], [W,B,k], [W,B]) on every rank."""

@@ -795,19 +795,35 @@ class Snapshot:
     def __init__(self, segments):
         self.segments = list(segments)
 
+    def _planner_for(self, planner, si, user_id):
+        """The reference builds ONE Planner per (segment, user) from the call's DocumentFilter (snapshot.rs:82-95): its bitmap
+        indexes that user's point ids inside that segment.  `planner` is therefore a callable (segment index, user id) ->
+        allow bitmap (uint32 words) or None (the segment has no term index: no filter).  A bare bitmap is accepted only where
+        the reference would build exactly one planner: one finalized segment in the snapshot."""
+        if planner is None:
+            return None
+        if callable(planner):
+            return planner(si, user_id)
+        if sum(0 if isinstance(s, PendingSegment) else 1 for s in self.segments) > 1:
+            raise ValueError("Snapshot: one allow bitmap for several finalized segments (pass a callable (segment, user) -> bitmap)")
+        return planner
+
     def search_for_user(self, user_id, query, params, planner=None):
         rows = []
-        for seg in self.segments:
+        for si, seg in enumerate(self.segments):
             if isinstance(seg, PendingSegment):   # BoxedImmutableSegment::PendingSegment passes no planner (segment/mod.rs)
                 rows += seg.search_with_id(user_id, query, params)
             else:
-                res = seg.search_for_user([user_id], np.asarray(query, np.float32).reshape(1, -1), params, planner=planner)
+                res = seg.search_for_user([user_id], np.asarray(query, np.float32).reshape(1, -1), params,
+                                          planner=self._planner_for(planner, si, user_id))
                 if res.found[0]:
                     rows += res.id_with_scores(0)
         rows.sort(key=_id_with_score_key)
         return rows[:params.top_k]
 
     def search_for_users(self, user_ids, query, params, planner=None):
+        if planner is not None and not callable(planner) and len(set(user_ids)) > 1:
+            raise ValueError("Snapshot.search_for_users: one allow bitmap for several users (pass a callable (segment, user) -> bitmap)")
         rows = []
         for u in user_ids:
             rows += self.search_for_user(u, query, params, planner=planner)

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "mdb_multi_spann_search_filtered", "mdb_multi_spann_attach", "mdb_multi_spann_search_submit",
     "mdb_set_option", "mdb_get_option", "mdb_points_block_bytes", "mdb_points_block_views", "mdb_ivf_search_shard", "mdb_ivf_merge_shards",
     "mdb_spann_search_shard", "mdb_spann_merge_shards", "mdb_multi_spann_search_shard", "mdb_multi_spann_merge_shards",
-    "mdb_allgather_blocks",
+    "mdb_allgather_blocks", "mdb_device_mem_info",
 ]
 
 
@@ -153,6 +153,12 @@ class Context:
     def set_option(self, name, value):
         """mdb_set_option: a tuning / test switch of THIS context (names: MDB_OPTIONS in csrc/mdb_common.h)."""
         self.check(self.lib.mdb_set_option(self.h, name.encode(), C.c_longlong(int(value))))
+
+    def mem_info(self):
+        """(free, total) bytes of the device after the stream drained: the drop of `free` across a load is the index's HBM footprint"""
+        f, t = C.c_size_t(), C.c_size_t()
+        self.check(self.lib.mdb_device_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def get_option(self, name):
         v = C.c_longlong()

@@ -238,3 +238,101 @@ def test_shard_assignment_covers_every_list_once():
         assert all(0 <= o < world for o in owners)
         spans = [D.split_batch(64, r, world) for r in range(world)]
         assert spans[0][0] == 0 and spans[-1][1] == 64 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _partition_worker(rank, world, port, out):
+    """users and batch partitionings (RowsExchange): this rank answers ITS queries whole with the oracle (a subset of the user table /
+    a replica of the index), one all-gather of finished rows, permutation into batch order == the unsharded rows"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from muopdb_amd import formats as F
+    rng = np.random.default_rng(21)
+    d, k = 16, 4
+    ok = True
+    # ---- by user: 5 users (odd: the ranks get 3 and 2), a batch with repeated users and uneven routing (6 pairs / 5 pairs)
+    files = {}
+    for u in range(5):
+        v = H.sift_like(300 + 40 * u, d, n_clusters=6, seed=30 + u)
+        files[u + 1], _, _ = H.build_spann_files(oracle, v, list(range(10_000 * u, 10_000 * u + len(v))), 6, max_neighbors=6, max_layers=2,
+                                                 ef_construction=30)
+    cat = F.concat_multi_spann(files)
+    a = (d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+    table = np.frombuffer(bytes(cat["user_table"]), np.uint8).reshape(5, -1)
+    full = oracle.MultiSpannIndex(bytes(cat["user_table"]), *a)
+    mine = oracle.MultiSpannIndex(table[D.users_of_rank(5, rank, world)].tobytes(), *a)
+    slots = [0, 3, 1, 1, 4, 2, 0, 4, 4, 3, 2]                       # the batch's pairs by user slot
+    b = len(slots)
+    q = H.sift_like(b, d, n_clusters=6, seed=77).astype(np.float32)
+    op = oracle.SearchParams(k, 30, num_explored_centroids=3)
+    ref = full.search_for_user([s_ + 1 for s_ in slots], q, op)
+    routes = D.route_by_user(slots, world)
+    ok &= sorted(i for r in routes for i in r) == list(range(b)) and all(D.user_owner(slots[i], world) == r for r, pos in enumerate(routes) for i in pos)
+    ex = D.RowsExchange(b, k, routes, rank, "cpu")
+    ql = ex.local_queries(torch.from_numpy(q)).numpy()
+    loc = mine.search_for_user([slots[i] + 1 for i in routes[rank]], ql, op)
+    n_loc = len(routes[rank])
+
+    def fill(ex_, res, n_):
+        ex_.send.zero_()
+        ids = np.zeros((ex_.bmax, k, 2), np.uint64)
+        ids[:n_, :, 0], ids[:n_, :, 1] = res.lo[:, :k], res.hi[:, :k]
+        ex_.ids.copy_(torch.from_numpy(ids.view(np.int64)))
+        sc = np.zeros((ex_.bmax, k), np.float32); sc[:n_] = res.scores[:, :k]
+        ex_.scores.copy_(torch.from_numpy(sc))
+        cn = np.zeros(ex_.bmax, np.int32); cn[:n_] = res.counts
+        ex_.counts.copy_(torch.from_numpy(cn))
+        fo = np.zeros(ex_.bmax, np.uint8); fo[:n_] = res.found if hasattr(res, "found") else 1
+        ex_.found.copy_(torch.from_numpy(fo))
+
+    def same(got, want):
+        gi, gs, gc, gf = (t.numpy() for t in got)
+        good = True
+        for i in range(len(gc)):
+            c_ = int(want.counts[i])
+            good &= int(gc[i]) == c_ and int(gf[i]) == (int(want.found[i]) if hasattr(want, "found") else 1)
+            good &= [int(x) for x in gi[i, :c_, 0].view(np.uint64)] == [int(x) for x in want.lo[i, :c_]]
+            good &= gs[i, :c_].tobytes() == np.asarray(want.scores[i, :c_], np.float32).tobytes()
+        return good
+    fill(ex, loc, n_loc)
+    ok &= same(ex.gather(), ref)
+    # ---- by batch: replicas of one IVF index, 11 queries over 2 ranks (5 + 6)
+    v = H.sift_like(1500, d, n_clusters=12, seed=4)
+    c = H.kmeans(v, 10, iters=3, seed=1)
+    index, vec, _ = H.build_ivf_files(v, [3 * i + 1 for i in range(1500)], c)
+    ivf = oracle.BlockBasedIvf(index, vec)
+    ref2 = ivf.search(q, k, num_probes=4)
+    ex2 = D.RowsExchange(b, k, D.route_by_batch(b, world), rank, "cpu")
+    lo, hi = D.split_batch(b, rank, world)
+    ok &= ex2.contiguous and ex2.n_local == hi - lo
+    ql2 = ex2.local_queries(torch.from_numpy(q)).numpy()
+    ok &= ql2.tobytes() == q[lo:hi].tobytes()
+    fill(ex2, ivf.search(ql2, k, num_probes=4), hi - lo)
+    ok &= same(ex2.gather(), ref2)
+    try:
+        D.RowsExchange(b, k, [[0, 1], [1, 2]], rank, "cpu")          # a query served twice / not at all is refused
+        ok = False
+    except ValueError:
+        pass
+    t = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(float(t.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_user_and_batch_partitionings_equal_unsharded_world2():
+    """SURVEY 8e 'measure both': next to the list shards (tests above) the QUERY partitionings of bench.py --shard users / batch —
+    user slot u on rank u % world with pairs routed to their owner, and replicas answering contiguous batch slices — return the
+    unsharded rows after one all-gather of finished rows (uneven routes, a batch that does not divide by the world size)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_partition_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) == 1.0

@@ -353,3 +353,113 @@ def test_cpp_pending_segment_and_snapshot_match_python(ctx, oracle, tmp_path):
         assert got[("snap_user", i)] == bits(snap.search_for_user(7, q[i], p)), i
         assert got[("snap_users", i)] == bits(snap.search_for_users([7, 8, 999], q[i], p)), i
     assert all(doc not in [r[0] for r in got[("pending", 0)]] for doc in dead[7]) and len(got[("pending", 0)]) == 5
+
+
+def test_snapshot_planner_is_per_segment_and_user(ctx, oracle, tmp_path):
+    """the reference builds ONE Planner per (segment, user) (collection/snapshot.rs:82-95) — its bitmap
+    indexes THAT user's point ids in THAT segment.  Two finalized segments of different sizes, two users, four different
+    bitmaps: Snapshot::search_for_user / search_for_users (Python mirror and include/muopdb_host.hpp through the demo) must
+    equal the per-segment oracle searches under their own filters, merged by IdWithScore; a bare bitmap for several finalized
+    segments (or several users) is refused instead of silently filtering the wrong points."""
+    import os
+    import struct
+    import subprocess
+    from muopdb_amd.index import MultiSpannIndex, SearchParams, Snapshot, allow_bitmap
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "muopdb_amd", "host_mirror_demo")
+    assert os.path.exists(exe), "host_mirror_demo not built (run __graft_entry__.build())"
+    d = 32
+    rng = np.random.default_rng(53)
+    sizes = {0: {7: 3000, 8: 900}, 1: {7: 1500, 8: 2100}}
+    cats, plans = [], {}
+    for si, users in sizes.items():
+        files = {}
+        for u, n in users.items():
+            v = H.sift_like(n, d, n_clusters=12, seed=100 + 10 * si + u)
+            base = 1_000_000 * si + 100_000 * u
+            files[u], _, _ = H.build_spann_files(oracle, v, list(range(base, base + n)), max(8, n // 100), max_neighbors=8, max_layers=3,
+                                                 ef_construction=50)
+            plans[(si, u)] = allow_bitmap(rng.choice(n, size=n // 3, replace=False), n)
+        cats.append(F.concat_multi_spann(files))
+    q = H.sift_like(6, d, n_clusters=12, seed=107).astype(np.float32)
+    segs, osegs = [], []
+    for s, cat in enumerate(cats):
+        sd = tmp_path / ("seg%d" % s)
+        sd.mkdir()
+        for name in ("user_table", "hnsw_index", "hnsw_vectors", "ivf_index", "ivf_vectors"):
+            (sd / name).write_bytes(bytes(cat[name]))
+        a = (cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+        segs.append(MultiSpannIndex(ctx, *a))
+        osegs.append(oracle.MultiSpannIndex(*a))
+    p = SearchParams(5, 50).with_num_explored_centroids(6).with_centroid_distance_ratio(0.3)
+    op = oracle.SearchParams(5, 50, num_explored_centroids=6, centroid_distance_ratio=0.3)
+    snap = Snapshot(segs)
+    planner = lambda si, u: plans.get((si, u))       # user 999 / unknown pairs: no planner
+
+    def want_user(u, qi):
+        rows = []
+        for si in range(2):
+            bm = plans.get((si, u))
+            if bm is None:
+                res = osegs[si].search_for_user([u], q[qi:qi + 1], op)
+            else:
+                with oracle.planner_filter(bm):
+                    res = osegs[si].search_for_user([u], q[qi:qi + 1], op)
+            if res.found[0]:
+                rows += res.id_with_scores(0)
+        return rows
+    key = lambda r: (r[1], r[0])
+    for qi in range(len(q)):
+        w7 = sorted(want_user(7, qi), key=key)[:5]
+        assert snap.search_for_user(7, q[qi], p, planner=planner) == w7, qi
+        many = sorted(w7 + sorted(want_user(8, qi), key=key)[:5], key=key)[:5]
+        assert snap.search_for_users([7, 8, 999], q[qi], p, planner=planner) == many, qi
+        assert len(w7) == 5
+    # the filters bite and differ per segment: the unfiltered snapshot returns other rows somewhere
+    assert any(snap.search_for_user(7, q[qi], p) != snap.search_for_user(7, q[qi], p, planner=planner) for qi in range(len(q)))
+    with pytest.raises(ValueError):
+        snap.search_for_user(7, q[0], p, planner=plans[(0, 7)])              # one bitmap, two finalized segments
+    with pytest.raises(ValueError):
+        Snapshot(segs[:1]).search_for_users([7, 8], q[0], p, planner=plans[(0, 7)])   # one bitmap, two users
+    assert Snapshot(segs[:1]).search_for_user(7, q[0], p, planner=plans[(0, 7)]) == \
+        Snapshot(segs[:1]).search_for_user(7, q[0], p, planner=lambda si, u: plans[(0, 7)])
+    # the compiled mirror
+    (tmp_path / "dead.txt").write_text("")
+    (tmp_path / "users.txt").write_text("7\n8\n999\n")
+    (tmp_path / "queries.f32").write_bytes(q.tobytes())
+    (tmp_path / "planners.txt").write_text("".join("%d %d %s\n" % (si, u, " ".join(str(int(w)) for w in bm)) for (si, u), bm in plans.items()))
+    out = subprocess.run([exe, "segments", str(tmp_path), str(d), "5", "50", "6", "0.3"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = {}
+    for line in out.stdout.splitlines():
+        t = line.split()
+        got[(t[0], int(t[1]))] = None if t[2] == "none" else [(int(x.split(":")[0]), int(x.split(":")[1], 16)) for x in t[3:]]
+
+    def bits(rows):
+        return [(int(i), struct.unpack("<I", struct.pack("<f", float(s)))[0]) for i, s in rows]
+    for qi in range(len(q)):
+        assert got[("plan_user", qi)] == bits(snap.search_for_user(7, q[qi], p, planner=planner)), qi
+        assert got[("plan_users", qi)] == bits(snap.search_for_users([7, 8, 999], q[qi], p, planner=planner)), qi
+
+
+def test_environment_option_words_and_typos():
+    """MDB_* environment values are integers or on/off/true/false/yes/no; anything else keeps the option's DEFAULT and
+    is reported through mdb_last_error — MDB_FLAT_ROWS=off used to ENABLE the row copy, MDB_FLAT_BLOCKS= meant one block."""
+    import os
+    import subprocess
+    import sys
+    code = ("from muopdb_amd import lib as L\n"
+            "c = L.Context(0)\n"
+            "print([c.get_option(n) for n in ('MDB_FLAT_ROWS', 'MDB_BF_X1', 'MDB_PQ_SDC_MAX_MB', 'MDB_FLAT_BLOCKS', 'MDB_HNSW_NO_DENSE', 'MDB_MF_SAMPLE_DIV')])\n"
+            "print((c.lib.mdb_last_error(c.h) or b'').decode())\n")
+    env = dict(os.environ, MDB_FLAT_ROWS="off", MDB_BF_X1="False", MDB_PQ_SDC_MAX_MB="none", MDB_FLAT_BLOCKS="", MDB_HNSW_NO_DENSE="YES",
+               MDB_MF_SAMPLE_DIV=" 16 ")
+    base = subprocess.run([sys.executable, "-c", code.replace("print((c.lib", "#")], capture_output=True, text=True, timeout=300,
+                          env={k_: v for k_, v in os.environ.items() if not k_.startswith("MDB_")}, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and base.returncode == 0, out.stderr + base.stderr
+    dflt = eval(base.stdout.splitlines()[0])
+    got = eval(out.stdout.splitlines()[0])
+    assert got == [0, 0, dflt[2], dflt[3], 1, 16], (got, dflt)
+    msg = out.stdout.splitlines()[1]
+    assert "MDB_PQ_SDC_MAX_MB" in msg and "MDB_FLAT_BLOCKS" in msg and "MDB_FLAT_ROWS" not in msg

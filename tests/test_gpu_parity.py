@@ -181,9 +181,12 @@ def test_flat_batched_filter_rows_with_infinite_components(ctx, oracle):
             eids, edist, ecounts = idx.search(q, k)
         assert np.array_equal(ids, eids) and np.array_equal(counts, ecounts), opt
         assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32)), opt
-    with ctx.option("MDB_BF_X1", 0):
-        tids, tdist, _ = idx.search(q, k)
+    with ctx.option("MDB_BF_X1", 0):   # the three-product filter: its lo halves exist only in a store LOADED under the option
+        idx3 = FlatIndex(ctx, base, 0)
+        tids, tdist, _ = idx3.search(q, k)
+        xids, xdist, _ = idx.search(q, k)   # a store without lo halves keeps the one-product form whatever the option says now
     assert np.array_equal(ids, tids) and np.array_equal(dist.view(np.uint32), tdist.view(np.uint32))
+    assert np.array_equal(ids, xids) and np.array_equal(dist.view(np.uint32), xdist.view(np.uint32))
     oids, odist = oracle.flat_topk(0, base, q[:4], k)
     assert np.array_equal(ids[:4], oids)
     assert_scores(dist[:4], odist)
@@ -206,8 +209,9 @@ def test_flat_large_batch_block_filter_equals_exact(ctx, oracle, n, d, b, k, met
             wids, wdist, wcounts = idx.search(q, k)
         with ctx.option("MDB_BF_NO_FULL_BOUND", 1):   # the block filter behind the 1/4 sample's bound instead of the whole-base bound pass
             sids, sdist, scounts = idx.search(q, k)
-    with ctx.option("MDB_BF_X1", 0):
-        tids, tdist, tcounts = idx.search(q, k)
+    with ctx.option("MDB_BF_X1", 0):   # (the lo halves are built at load: a store of its own for the three-product filter)
+        idx3 = FlatIndex(ctx, base, metric)
+        tids, tdist, tcounts = idx3.search(q, k)
     with ctx.option("MDB_FLAT_NO_MFMA", 1):
         eids, edist, ecounts = idx.search(q, k)
     for a_ids, a_dist, a_counts in ((wids, wdist, wcounts), (sids, sdist, scounts), (tids, tdist, tcounts), (eids, edist, ecounts)):
@@ -574,6 +578,10 @@ def test_ivf_large_coarse_quantizer_block_filter_and_slices(ctx, oracle):
     for opt, val in (("MDB_BF_NO_FULL_BOUND", 1), ("MDB_BF_BLOCK_MIN_B", 1 << 30), ("MDB_BF_X1", 0), ("MDB_REFINE_NO_SECOND_BOUND", 1)):
         with ctx.option(opt, val):
             assert np.array_equal(got, g.find_nearest_centroids(q, P)), opt
+    with ctx.option("MDB_BF_X1", 0):   # the three-product filter reads lo halves that only a load under the option builds
+        g3 = BlockBasedIvf(ctx, index, vec)
+        assert np.array_equal(got, g3.find_nearest_centroids(q, P))
+        g3.close()
     assert np.array_equal(got[:6], o.find_nearest_centroids(q[:6], P))
     parts = [g.coarse_keys(q, P, first, 8192) for first in range(0, L, 8192)]
     assert np.array_equal(g.merge_coarse_keys(np.stack(parts, 1), P), got)

@@ -63,6 +63,7 @@ def _shared_build_worker(rank, world, port, tmp, out):
     import bench
     env = object.__new__(bench.Env)
     env.rank, env.world = rank, world
+    env.keep_tags, env.kept_builds = {"kept"}, {}
     calls = []
 
     def build():
@@ -79,7 +80,21 @@ def _shared_build_worker(rank, world, port, tmp, out):
     there = os.path.isdir(base)
     cleanup()
     dist.barrier()
-    out.put((rank, ok, there, os.path.isdir(base)))
+    after = os.path.isdir(base)
+    # a tag in keep_tags survives its cleanup, a second shared_build of it maps the same files WITHOUT building, drop_kept_builds removes it
+    n0 = len(calls)
+    g1, c1 = env.shared_build("kept", build)
+    c1()
+    kbase = os.path.join(tmp, "mdb_bench_%s_kept" % port)
+    ok = ok and os.path.isdir(kbase) and "kept" in env.kept_builds
+    g2, c2 = env.shared_build("kept", build)
+    ok = ok and len(calls) == n0 + (1 if rank == 0 else 0) and np.array_equal(np.asarray(g2["vectors"]), np.asarray(g1["vectors"])) and g2["n"] == 12345
+    del g1, g2
+    c2()
+    env.drop_kept_builds()
+    dist.barrier()
+    ok = ok and not os.path.isdir(kbase) and env.kept_builds == {}
+    out.put((rank, ok, there, after))
     dist.destroy_process_group()
 
 
