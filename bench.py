@@ -51,7 +51,7 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 DISP_REGIONS = 4       # extra timed regions per workload for the dispersion entry (Env.timed)
 WARM_MIN_S = 0.05      # Env.timed: the untimed warm-up lasts at least this long (the W steps repeated)
-PROF_EVERY = 4         # steps of the timed region between two steps whose dominant kernels are bracketed by HIP events
+PROF_EVERY = 8         # steps of the timed region between two steps whose dominant kernels are bracketed by HIP events
 METRIC = "QPS @ recall@10, SIFT-1M d=128 top-10, batch=1/64; 1/2/4/8 GPUs"
 
 

@@ -58,6 +58,7 @@
     X(hnsw_no_wide, "MDB_HNSW_NO_WIDE", 0)             /* 256 < ef <= 448 through the general kernel instead of the 8-register beam */ \
     X(hnsw_no_split, "MDB_HNSW_NO_SPLIT", 0)           /* upper layers: table pass, then ONE traversal launch (no top / layer-1 split) */ \
     X(hnsw_table_min_b, "MDB_HNSW_TABLE_MIN_B", 1)     /* smallest batch served by the table path */               \
+    X(hnsw_nb4_slack, "MDB_HNSW_NB4_SLACK", 48)        /* table path: ef + this <= 256 runs the beam on FOUR registers of 64 slots (0: always five) */ \
     X(hnsw_dbg, "MDB_HNSW_DBG", 0)                                                                                  \
     X(ivf_coarse_sample_div, "MDB_IVF_COARSE_SAMPLE_DIV", 4) /* L */                                                \
     X(ivf_coarse_mfma, "MDB_IVF_COARSE_MFMA", 1)       /* fused IVF-PQ step: coarse search as matrix-core filter + exact candidates (0: every distance exactly) */ \

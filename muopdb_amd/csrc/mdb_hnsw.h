@@ -73,6 +73,11 @@ mdb_status hnsw_upper_traverse(mdb_ctx* ctx, const HnswUpper& up, const uint32_t
 // table + traversal in the shape that suits the batch: hnsw_upper_table then hnsw_upper_traverse, or — batches of >= 32 queries over a
 // graph of >= 3 layers — the split path (mdb_hnsw_upper.hip: top layers and the table pass in one launch, then layer 1).
 // d_table: b * nu_pad words; d_state: (b * (words + 8) + 64) words of scratch for the hand-over between the two launches.
+// table path: the beam on four registers of 64 slots when ef leaves them MDB_HNSW_NB4_SLACK free slots (256 - ef: the accepted
+// neighbours between two compactions, and the exact ties with furthest a query may hold before it is re-run by the general kernel)
+static inline bool hnsw_beam_nb4(const mdb_ctx* ctx, uint32_t ef) {
+    return ctx->opt.hnsw_nb4_slack > 0 && (long long)ef + ctx->opt.hnsw_nb4_slack <= 256;
+}
 mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const DistPlan& p, const float* d_q, int qstride, size_t b,
                           uint32_t ef, uint32_t* d_table, uint32_t* d_state, const HnswUpperOut& out, unsigned long long* zero16);
 

@@ -1660,7 +1660,9 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     } while (0)
 #define MDB_BEAM_LAUNCH_L0(METRIC, VL, NF)                                                                              \
     do {                                                                                                                    \
-        if (ef <= 256) MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, 5); else MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, 8);                 \
+        if (hnsw_beam_nb4(ctx, ef)) MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, 4);                                                 \
+        else if (ef <= 256) MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, 5);                                                         \
+        else MDB_BEAM_LAUNCH_L0N(METRIC, VL, NF, 8);                                                                        \
     } while (0)
 #define MDB_HNSW_LAUNCH(METRIC, VL)                                                                              \
     do {                                                                                                           \

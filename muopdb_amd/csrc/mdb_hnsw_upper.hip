@@ -740,7 +740,10 @@ static mdb_status upper_launch_bottom(mdb_ctx* ctx, const HnswUpper& up, const u
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_kernel<TL, NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hnsw_upper_kernel<TL, NBV><<<dim3((unsigned)b), UP_BLOCK, lds, ctx->stream>>>(a);                                            \
     } while (0)
-    if (ef <= 256) { if (tlds) MDB_UPK_GO(true, 5); else MDB_UPK_GO(false, 5); }
+    // registers of 64 beam slots: every count, selection and push of a step loops over them — four when ef leaves them enough slack
+    // (a compaction every ~slack accepted neighbours costs less than a fifth register in every step), five up to 256, eight beyond
+    if (hnsw_beam_nb4(ctx, ef)) { if (tlds) MDB_UPK_GO(true, 4); else MDB_UPK_GO(false, 4); }
+    else if (ef <= 256) { if (tlds) MDB_UPK_GO(true, 5); else MDB_UPK_GO(false, 5); }
     else { if (tlds) MDB_UPK_GO(true, 8); else MDB_UPK_GO(false, 8); }
 #undef MDB_UPK_GO
     MDB_HIP(ctx, hipGetLastError());
@@ -780,14 +783,16 @@ mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const D
     a.self_tiles = (const float4*)up.tiles2.data.p; a.self_ntiles = (uint32_t)up.tiles2.ntiles; a.n16 = p.n16; a.q = d_q; a.qstride = qstride;
     const unsigned tgx = (unsigned)((up.nu + 4 * T64_PPW - 1) / (4 * T64_PPW)), tgy = (unsigned)((b + 63) / 64);
     const unsigned grid = (unsigned)b + tgx * tgy;
-#define MDB_TOP_GO(METRIC, N)                                                                                                          \
+    const bool nb4 = hnsw_beam_nb4(ctx, ef);
+#define MDB_TOP_GO1(METRIC, N, NBV)                                                                                                    \
     do {                                                                                                                               \
         if (lds_top > 48 * 1024)                                                                                                       \
-            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_top_kernel<METRIC, N, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_top_kernel<METRIC, N, NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                              (int)lds_top));                                                                           \
-        hnsw_upper_top_kernel<METRIC, N, 5><<<dim3(grid), 256, lds_top, ctx->stream>>>(a, (uint32_t)b, up.rows_nat.p, up.nu, d_table, nu_pad, \
-                                                                                       tgx, zero16);                                  \
+        hnsw_upper_top_kernel<METRIC, N, NBV><<<dim3(grid), 256, lds_top, ctx->stream>>>(a, (uint32_t)b, up.rows_nat.p, up.nu, d_table, nu_pad, \
+                                                                                         tgx, zero16);                                \
     } while (0)
+#define MDB_TOP_GO(METRIC, N) do { if (nb4) MDB_TOP_GO1(METRIC, N, 4); else MDB_TOP_GO1(METRIC, N, 5); } while (0)
 #define MDB_TOP_LAUNCH(METRIC)                           \
     do {                                                 \
         switch (p.n16) {                                 \
@@ -804,6 +809,7 @@ mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const D
     if (metric == MDB_METRIC_L2) MDB_TOP_LAUNCH(MDB_METRIC_L2); else MDB_TOP_LAUNCH(MDB_METRIC_DOT);
 #undef MDB_TOP_LAUNCH
 #undef MDB_TOP_GO
+#undef MDB_TOP_GO1
     MDB_HIP(ctx, hipGetLastError());
     return upper_launch_bottom(ctx, up, d_table, b, ef, out, 1, st_ep, st_ovf, st_vis, st_cnt);
 }

@@ -16,7 +16,8 @@ WL = {  # workload -> (kernels of the dominant group: bench.py's `roofline.kerne
     "flat_b1": (("flat_scan_kernel",), "flat", {"n": 1000000, "dim": 128, "batch": 1, "k": 10}),
     # <METRIC, QB, NKT, SMP = false, APX>: the filter proper, not its sample pass
     "flat_b64": (("flat_bf16_filter_kernel<0, 2, 8, false",), "flat_b64", {"n": 1000000, "dim": 128, "batch": 64, "k": 10}),
-    "ivfpq": (("ivf_pq_fused_kernel",), "ivfpq", {"n": 1000000, "dim": 128, "batch": 256, "k": 10, "nprobe": 16}),
+    # round 5: the step is the matrix-core coarse search + the fused kernel (round 4: ivf_prep_kernel + the fused kernel)
+    "ivfpq": (("ivf_coarse_mfma_kernel", "ivf_prep_kernel", "ivf_pq_fused_kernel"), "ivfpq", {"n": 1000000, "dim": 128, "batch": 256, "k": 10, "nprobe": 16}),
     "spann": (("ivf_scan_f32_kernel",), "spann", {"n": 1250048, "dim": 768, "batch": 128, "k": 10}),
     "c5": (("ivf_scan_pq3_kernel", "ivf_pq3_refine_kernel"), "c5", {"dim": 128, "batch": 4096, "k": 10, "nprobe": 64}),
     "c5full": (("ivf_scan_pq3_kernel", "ivf_pq3_refine_kernel"), "c5full", {"n": 100000000, "dim": 128, "batch": 4096, "k": 10, "nprobe": 64}),
@@ -41,6 +42,8 @@ def main_filter(name):
     if "flat_bf16x1_block_kernel<" in name:   # <METRIC, QB, BOUND, APX>: the filter pass of a large batch (BOUND == false)
         targs = name.split("flat_bf16x1_block_kernel<", 1)[1].split(">", 1)[0].split(",")
         return len(targs) >= 3 and targs[2].strip() == "false"
+    if "ivf_coarse_mfma_kernel" in name:           # C3's coarse search
+        return True
     if "flat_bf16_filter_kernel<" not in name:
         return False
     targs = name.split("flat_bf16_filter_kernel<", 1)[1].split(">", 1)[0].split(",")
@@ -49,6 +52,13 @@ def main_filter(name):
 
 bench = json.loads(open(os.path.join(src, "bench_all.json")).read().strip().splitlines()[-1])
 shutil.copy(os.path.join(src, "bench_all.json"), os.path.join(dst, "%s_bench_all.json" % rnd))
+# round 5 on: stdout carries the bounded line, the FULL record (prose config, dispersion, per-kernel rooflines) goes to stderr as "[bench-full] {...}"
+errp = os.path.join(src, "bench_all.err")
+if os.path.exists(errp):
+    full = [x for x in open(errp) if x.startswith("[bench-full] ")]
+    if full:
+        bench = json.loads(full[-1][len("[bench-full] "):])
+        json.dump(bench, open(os.path.join(dst, "%s_bench_all_full.json" % rnd), "w"))
 lines = {"hnsw": bench}
 c4p = os.path.join(src, "c4full_bench.json")
 if os.path.exists(c4p):
@@ -119,7 +129,7 @@ for w, (kern, key, match) in WL.items():
         m["n"] = cfg["n"]
     if "MFMA" in vals:
         traffic.setdefault("_mfma", {})[key] = dict(vals["MFMA"], source="profiles/%s_%s_pmc_MFMA.csv" % (rnd, w),
-                                                    kernel="flat_bf16x1_block_kernel (filter pass)" if w == "c5" else "flat_bf16_filter_kernel")
+                                                    kernel="flat_bf16x1_block_kernel (filter pass)" if w == "c5" else "ivf_coarse_mfma_kernel" if w == "ivfpq" else "flat_bf16_filter_kernel")
     if "FETCH_SIZE" in vals:
         traffic[key] = {"match": m, "kernel": "+".join(k.split("<")[0] for k in kern), "fetch_kib": round(vals["FETCH_SIZE"], 1), "write_kib": round(vals.get("WRITE_SIZE", 0.0), 1),
                         "fetch_correction": 2.0, "source": ["profiles/%s_%s_pmc_FETCH_SIZE.csv" % (rnd, w), "profiles/%s_%s_pmc_WRITE_SIZE.csv" % (rnd, w)]}
