@@ -1365,6 +1365,9 @@ def main():
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args)   # does not return
+    if os.environ.get("MDB_BENCH_WATCHDOG"):   # seconds: every thread's Python stack to stderr, then exit (a rank stuck in a collective says where)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["MDB_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

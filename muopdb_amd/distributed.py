@@ -322,6 +322,11 @@ class RowsExchange:
                 dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
             else:
                 self.recv.copy_(self.send)
+        return self.permute()
+
+    def permute(self):
+        """`recv` (the ranks' blocks, rank-major) -> rows in batch order.  Separate from gather() so that a single process can stand in
+        for several ranks (tests: the blocks of simulated ranks copied into `recv`)."""
         with _span("rows_permute"):
             b, k, w = self.bmax, self.k, self.world
             blocks = self.recv.view(w, self.blk)

@@ -858,3 +858,94 @@ def test_hnsw_wide_beam_and_split_path_equal_oracle(ctx, oracle, d, metric, nq):
         st = ctx.stats()
         assert_result_rows(got, want, len(q))
         assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded), (k, ef)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_user_and_batch_partitionings_on_the_device(ctx, oracle, world):
+    """bench.py --shard users / --shard batch (SURVEY 8e 'measure both'): simulated ranks on ONE GPU, the very calls the bench issues —
+    a rank's MultiSpannIndex over ITS rows of the user table (slot u -> rank u % world), mdb_multi_spann_search on device-resident
+    routed queries straight into the RowsExchange send block, the blocks side by side as the all-gather leaves them, permute() —
+    must equal the unsharded index's rows and the oracle's; the same for replicas of one IVF-PQ index answering batch slices."""
+    import ctypes as C
+    import torch
+    from muopdb_amd import distributed as D
+    from muopdb_amd import lib as L
+    from muopdb_amd.index import BlockBasedIvf, MultiSpannIndex, ProductQuantizer, SearchParams
+    rng = np.random.default_rng(5 + world)
+    d, k, U = 24, 6, 7
+    users, slots_q = {}, []
+    for ui in range(U):
+        n = int(rng.integers(200, 500))
+        v = (rng.standard_normal((n, d)) + ui).astype(np.float32)
+        users[100 + ui], _, _ = H.build_spann_files(oracle, v, [1000 * ui + i for i in range(n)], int(rng.integers(4, 9)), seed=ui,
+                                                    max_neighbors=6, max_layers=2, ef_construction=30)
+        slots_q += [(ui, v[rng.integers(0, n)] + rng.normal(0, 0.1, d)) for _ in range(int(rng.integers(1, 5)))]
+    order = rng.permutation(len(slots_q))
+    slots = [slots_q[i][0] for i in order]
+    q = np.asarray([slots_q[i][1] for i in order], np.float32)
+    b = len(slots)
+    cat = F.concat_multi_spann(users)
+    a = (d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+    table = np.frombuffer(bytes(cat["user_table"]), np.uint8).reshape(U, -1)
+    full = MultiSpannIndex(ctx, cat["user_table"], *a)
+    ofull = oracle.MultiSpannIndex(cat["user_table"], *a)
+    p = SearchParams(k, 40).with_num_explored_centroids(4).with_centroid_distance_ratio(0.5)
+    op = oracle.SearchParams(k, 40, num_explored_centroids=4, centroid_distance_ratio=0.5)
+    uids = [100 + s_ for s_ in slots]
+    want = full.search_for_user(uids, q, p)
+    assert_result_rows(want, ofull.search_for_user(uids, q, op), b)
+    routes = D.route_by_user(slots, world)
+    qd = torch.from_numpy(q).cuda()
+    pc = p.to_c()
+    exs = []
+    for r in range(world):
+        ex = D.RowsExchange(b, k, routes, r, "cuda")
+        ms = MultiSpannIndex(ctx, table[D.users_of_rank(U, r, world)].tobytes(), *a)
+        assert ms.num_users() == len(D.users_of_rank(U, r, world))
+        ql = ex.local_queries(qd).contiguous()
+        if ex.n_local:
+            ctx.check(ctx.lib.mdb_multi_spann_search(ms.h, L.u128_array([uids[i] for i in routes[r]]), C.c_void_p(ql.data_ptr()), C.c_size_t(ex.n_local),
+                                                     C.byref(pc), C.c_int(L.MEM_DEVICE), C.c_void_p(ex.ids.data_ptr()), C.c_void_p(ex.scores.data_ptr()),
+                                                     C.c_void_p(ex.counts.data_ptr()), C.c_void_p(ex.found.data_ptr())))
+        ctx.sync()
+        exs.append(ex)
+        ms.close()
+
+    def check(exs_, want_, with_found):
+        recv = torch.cat([e.send for e in exs_])
+        for e in exs_:                                    # every rank ends with the same rows
+            e.recv.copy_(recv)
+            ids, sc, cn, fo = (t.cpu().numpy() for t in e.permute())
+            for i in range(b):
+                c_ = int(want_.counts[i])
+                assert int(cn[i]) == c_ and (not with_found or int(fo[i]) == int(want_.found[i]))
+                got = [(int(lo_) | (int(hi_) << 64), np.float32(s_).tobytes()) for lo_, hi_, s_ in
+                       zip(ids[i, :c_, 0].view(np.uint64), ids[i, :c_, 1].view(np.uint64), sc[i, :c_])]
+                assert got == [(int(doc), np.float32(s_).tobytes()) for doc, s_ in want_.id_with_scores(i)], i
+    check(exs, want, True)
+    full.close()
+    # ---- replicas + batch slices of one IVF-PQ index
+    n = 6000
+    v = H.sift_like(n, 32, n_clusters=20, seed=9)
+    cent = H.kmeans(v, 24, iters=3, seed=2)
+    cb = H.train_pq_codebook(v[:2000], 8, 4, iters=3)
+    pq = ProductQuantizer(32, 8, 4, cb)
+    index, vec, _ = H.build_ivf_files(v, [7 * i + 3 for i in range(n)], cent, quantize=oracle.ProductQuantizer(32, 8, 4, cb).quantize)
+    ivf = BlockBasedIvf(ctx, index, vec, pq)
+    q2 = (v[rng.integers(0, n, b)] + rng.normal(0, 4, (b, 32))).astype(np.float32)
+    want2 = ivf.search(q2, k, 5)
+    assert_result_rows(want2, oracle.BlockBasedIvf(index, vec, oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 4, cb)).search(q2, k, num_probes=5), b)
+    q2d = torch.from_numpy(q2).cuda()
+    routes2 = D.route_by_batch(b, world)
+    exs2 = []
+    for r in range(world):
+        ex = D.RowsExchange(b, k, routes2, r, "cuda")
+        ql = ex.local_queries(q2d)
+        assert ex.contiguous and ql.data_ptr() == q2d.data_ptr() + routes2[r][0] * 32 * 4     # a view: the rows are read in place
+        ctx.check(ctx.lib.mdb_ivf_search(ivf.h, C.c_void_p(ql.data_ptr()), C.c_size_t(ex.n_local), None, C.c_size_t(5), C.c_size_t(k),
+                                         C.c_int(L.MEM_DEVICE), C.c_void_p(ex.ids.data_ptr()), C.c_void_p(ex.scores.data_ptr()),
+                                         C.c_void_p(ex.counts.data_ptr())))
+        ctx.sync()
+        exs2.append(ex)
+    check(exs2, want2, False)
+    ivf.close()
