@@ -202,6 +202,18 @@ class Env:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def loaded(self, make, file_bytes):
+        """make() -> index handle, with what the load left resident in HBM (free bytes before - after, mdb_device_mem_info: tiles / codes /
+        graphs AND the load-time accelerators — bf16 fragments, row-major copies, samples, tables) next to the bytes of the files it was
+        built from: `hbm` goes into the workload's entry as hbm_resident_bytes / hbm_over_file_bytes (VERDICT r4 next #8)"""
+        torch.cuda.synchronize()
+        f0 = self.ctx.mem_info()[0]
+        h = make()
+        torch.cuda.synchronize()
+        used = f0 - self.ctx.mem_info()[0]
+        self.last_hbm = dict(hbm_resident_bytes=int(used), file_bytes=int(file_bytes), hbm_over_file_bytes=used / file_bytes if file_bytes else None)
+        return h
+
     def shared_build(self, tag, build_fn):
         """Index files of a list-sharded workload, built ONCE per job: world == 1 -> build_fn() as is.  world > 1 -> rank 0 builds
         (on its GPU), writes every bytes-like value of the returned dict under MDB_BENCH_TMP (default /tmp) and the small values
@@ -455,7 +467,9 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
         log("graph build (%s) %.1fs (%d MiB index)" % (graph, build_s, len(index_bytes) >> 20))
         t0 = time.time()
         env.hnsw_cache.clear()   # one resident graph at a time
-        env.hnsw_cache[key] = (BlockBasedHnsw(ctx, index_bytes, vec_bytes, d), index_bytes, vec_bytes, build_s)
+        env.hnsw_cache[key] = (env.loaded(lambda: BlockBasedHnsw(ctx, index_bytes, vec_bytes, d), len(index_bytes) + len(vec_bytes)), index_bytes, vec_bytes, build_s)
+        env.hnsw_hbm = getattr(env, "hnsw_hbm", {})
+        env.hnsw_hbm[key] = env.last_hbm
         log("load %.1fs" % (time.time() - t0))
     hnsw, index_bytes, vec_bytes, build_s = env.hnsw_cache[key]
     if batch == 64 and graph == "knn":
@@ -498,6 +512,7 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
                               evals_per_query=evals / (steps * batch), expanded_per_query=expanded / (steps * batch)),
     )
     finish(out, disp, abytes / steps)
+    out.update(getattr(env, "hnsw_hbm", {}).get(key) or {})
     out["steps"], out["warmup"] = steps, warm
     if batch == 64 and graph == "knn":
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("hnsw", out["config"])
@@ -573,7 +588,8 @@ def run_flat(env, n=None, batch=None, steps=None, warm=None):
         queries = (ql[:, None].float() * 100.0 + torch.randn((nq, d), generator=g) * 5.0).cuda().contiguous()
     # rows are sharded across ranks (SURVEY.md §8e flat: row-range shards); here every rank scans its shard
     lo, hi = rank * n // world, (rank + 1) * n // world
-    idx = FlatIndex(ctx, None, device_ptr=x[lo:hi].data_ptr(), n=hi - lo, d=d)
+    idx = env.loaded(lambda: FlatIndex(ctx, None, device_ptr=x[lo:hi].data_ptr(), n=hi - lo, d=d), (hi - lo) * d * 4)
+    hbm = env.last_hbm
     if args.dump_dir:
         from muopdb_amd import formats as F
         dump(args, rank, "flat_b%d" % batch, vectors=F.write_vector_file(x.cpu().numpy()), **{"queries.f32": queries.cpu().numpy()})
@@ -597,6 +613,7 @@ def run_flat(env, n=None, batch=None, steps=None, warm=None):
                        "n": n, "dim": d, "batch": batch, "k": k, "index": "flat", "data": args.data},
                roofline=hbm_roofline("flat_bf16_filter_kernel" if batched else "flat_scan_kernel", abytes, kernel_ms, launches))
     finish(out, disp, abytes)   # the step's algorithmic bytes: the base once (however many passes the filter takes)
+    out.update(hbm)
     out["steps"], out["warmup"] = steps, warm
     if (hi - lo) * d * 4 < (64 << 20):
         out["note"] = "launch-latency bound: the base (%.1f MB) sits in the Infinity Cache, SURVEY 8d" % ((hi - lo) * d * 4 / 1e6)
@@ -731,7 +748,9 @@ def run_ivfpq(env, shard=None, no_sweep=False):
     t0 = time.time()
     index_bytes, vec_bytes, pq, cb = build_ivfpq(env, x, nlist)
     log("ivf-pq build %.1fs" % (time.time() - t0))
-    ivf = BlockBasedIvf(ctx, index_bytes, vec_bytes, pq, shard_rank=0 if by_batch else rank, shard_world=1 if by_batch else world)
+    ivf = env.loaded(lambda: BlockBasedIvf(ctx, index_bytes, vec_bytes, pq, shard_rank=0 if by_batch else rank, shard_world=1 if by_batch else world),
+                     len(index_bytes) + len(vec_bytes))
+    hbm = env.last_hbm
     dump(args, rank, "ivfpq", index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy(), "codebook.f32": cb})
     tq = queries[warm * batch:(warm + steps) * batch]
     nrec = min(len(tq), 2560, max(256, int(1.3e10 // n)))  # f64 ground truth for a bounded number of the timed queries
@@ -746,6 +765,7 @@ def run_ivfpq(env, shard=None, no_sweep=False):
                roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
     finish(out, m["disp"], m["abytes"] / steps)
+    out.update(hbm)
     if m["exchange"]:
         out["exchange"] = m["exchange"]
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ivfpq", out["config"])
@@ -820,7 +840,8 @@ def run_c5_full(env, steps=None, warm=None):
     log("C5 full build %.1fs: %d vectors in %d lists" % (build_s, full["n"], full["owned_lists"]))
     torch.cuda.empty_cache()
     t0 = time.time()
-    ivf = BlockBasedIvf(ctx, full["index"], full["vectors"], full["pq"])
+    ivf = env.loaded(lambda: BlockBasedIvf(ctx, full["index"], full["vectors"], full["pq"]), len(full["index"]) + len(full["vectors"]))
+    hbm = env.last_hbm
     load_s = time.time() - t0
     queries = full["gen"].draw((steps + warm) * batch, seed=5000).contiguous()
     dump(args, env.rank, "c5full", index=full["index"], vectors=full["vectors"], **{"queries.f32": queries.cpu().numpy(), "codebook.f32": full["codebook"]})
@@ -833,6 +854,7 @@ def run_c5_full(env, steps=None, warm=None):
                roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
     finish(out, m["disp"], m["abytes"] / steps)
+    out.update(hbm)
     out["steps"], out["warmup"] = steps, warm
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("c5full", out["config"])
     if env.cpu:
@@ -876,7 +898,9 @@ def run_c5_sharded(env, steps=None, warm=None, shard=None):
     from muopdb_amd.index import ProductQuantizer
     pq = ProductQuantizer(128, 8, 8, full["codebook"])
     t0 = time.time()
-    ivf = BlockBasedIvf(ctx, full["index"], full["vectors"], pq, shard_rank=0 if by_batch else rank, shard_world=1 if by_batch else world)
+    ivf = env.loaded(lambda: BlockBasedIvf(ctx, full["index"], full["vectors"], pq, shard_rank=0 if by_batch else rank, shard_world=1 if by_batch else world),
+                     len(full["index"]) + len(full["vectors"]))
+    hbm = env.last_hbm
     load_s = time.time() - t0
     cleanup()
     queries = S.SiftLike(128, seed=4).draw((steps + warm) * batch, seed=5000).contiguous()   # the same batch on every rank
@@ -891,6 +915,7 @@ def run_c5_sharded(env, steps=None, warm=None, shard=None):
                roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query_this_rank=m["scored"] / (steps * batch)))
     finish(out, m["disp"], m["abytes"] / steps)
+    out.update(hbm)
     if m["exchange"]:
         out["exchange"] = m["exchange"]
     out["steps"], out["warmup"] = steps, warm
@@ -916,7 +941,8 @@ def run_c5(env, steps=None, warm=None):
         torch.cuda.empty_cache()
     # what rank 0 of an 8-rank job loads from the whole index's files (size-balanced owners, mdb_ivf_load(.., 0, 8)) — exactly what
     # run_c5_sharded's ranks do
-    ivf = BlockBasedIvf(ctx, full["index"], full["vectors"], full["pq"], shard_rank=0, shard_world=8)
+    ivf = env.loaded(lambda: BlockBasedIvf(ctx, full["index"], full["vectors"], full["pq"], shard_rank=0, shard_world=8), len(full["index"]) + len(full["vectors"]))
+    hbm = env.last_hbm
     from muopdb_amd import distributed as D0
     owner = np.asarray(D0.balanced_owners(full["list_sizes"], 8))
     sh = dict(full, n=int(ivf.num_resident_vectors()), owned_lists=int(((owner == 0) & (full["list_sizes"] > 0)).sum()))
@@ -935,6 +961,7 @@ def run_c5(env, steps=None, warm=None):
                roofline=hbm_roofline(pq_scan_kernel_name(batch), m["abytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
     finish(out, m["disp"], m["abytes"] / steps)
+    out.update(hbm)
     out["steps"], out["warmup"] = steps, warm
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("c5", out["config"])
     out["roofline"]["coarse_filter_mfma_busy"] = measured_mfma("c5", out["config"])
@@ -1036,11 +1063,13 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None, shard=None
         # the shared files: graphs, centroids, lists and doc ids of the other users are never uploaded), whole, unsharded
         table = np.frombuffer(bytes(cat["user_table"]), np.uint8).reshape(U, -1)
         mine = D.users_of_rank(U, rank, world)
-        ms = MultiSpannIndex(ctx, table[mine].tobytes(), d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], None, 0, 1)
+        ms = env.loaded(lambda: MultiSpannIndex(ctx, table[mine].tobytes(), d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], None, 0, 1),
+                        sum(len(cat[k_]) for k_ in ("hnsw_index", "hnsw_vectors", "ivf_index", "ivf_vectors")))
     else:
-        ms = MultiSpannIndex(ctx, cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"],
-                             None, rank, world)
+        ms = env.loaded(lambda: MultiSpannIndex(ctx, cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"],
+                                                None, rank, world), sum(len(cat[k_]) for k_ in ("hnsw_index", "hnsw_vectors", "ivf_index", "ivf_vectors")))
     log("load %.1fs" % (time.time() - t0))
+    hbm = env.last_hbm
     cleanup()
     have_base = len(base) == U
     nq = (steps + warm) * batch
@@ -1145,6 +1174,7 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None, shard=None
     out["roofline"]["centroid_graph"] = hbm_roofline("hnsw_closure_kernel", m["graph_bytes"] / steps, m["hnsw_ms"], 1,
                                                      evals_per_query=m["evals"] / (steps * batch))
     finish(out, m["disp"], m["abytes"] / steps)
+    out.update(hbm)
     if m["exchange"]:
         out["exchange"] = m["exchange"]
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("spann_full" if U >= 1024 else "spann", out["config"])

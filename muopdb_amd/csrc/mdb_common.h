@@ -30,6 +30,7 @@
     X(flat_blocks, "MDB_FLAT_BLOCKS", 0)               /* flat-scan grid target (0 = 1024) */                       \
     X(flat_no_mfma, "MDB_FLAT_NO_MFMA", 0)             /* exact flat kernels only */                                \
     X(flat_rows, "MDB_FLAT_ROWS", 1)                   /* flat index: keep a row-major copy of the base for the refine's gathers (+ n d 4 bytes) */ \
+    X(flat_rows_max_mb, "MDB_FLAT_ROWS_MAX_MB", 8192)   /* ... only for stores up to this many MB of f32 rows (flat bases and large coarse quantizers): above it the refine gathers from the tile store and the index stays at ~1.5 x its rows */ \
     X(no_inplace, "MDB_NO_INPLACE", 0)                 /* device-resident query rows are always copied into padded staging rows */ \
     X(flat_merge_old, "MDB_FLAT_MERGE_OLD", 0)         /* many sorted partial lists through the streaming selector instead of bound + rank */ \
     X(mf_sample_div, "MDB_MF_SAMPLE_DIV", 32)          /* L: sample = 1/div of the base tiles */                    \

@@ -494,8 +494,10 @@ mdb_status mdb_flat_create(mdb_ctx* ctx, const float* base, size_t n, size_t d, 
     }
     mdb_status st = tiles_from_rows(ctx, d_rows, n, (int)d, f->ts);
     // the refine gathers single vectors: in the tile store a vector is spread over d / 4 lines of 128 bytes (16 of them used each),
-    // in the row-major copy it is d / 32 whole lines — 288 GB of HBM pays for the second copy
-    if (st == MDB_OK) st = flat_build_aux(ctx, view_of(f->ts), f->aux, 0, f->metric, ctx->opt.flat_rows != 0 && n * d * 4 <= ((size_t)64 << 30));
+    // in the row-major copy it is d / 32 whole lines — 288 GB of HBM pays for the second copy of stores up to MDB_FLAT_ROWS_MAX_MB
+    // (8 GB); what a flat index keeps resident: tiles 1 x + bf16 hi fragments 0.5 x + rows 1 x + a 1/32 sample (2.5 x its f32 rows), without
+    // the copy 1.5 x (the lo fragments are built only for stores whose filter reads them: flat_build_aux)
+    if (st == MDB_OK) st = flat_build_aux(ctx, view_of(f->ts), f->aux, 0, f->metric, ctx->opt.flat_rows != 0 && n * d * 4 <= ((size_t)std::max<long long>(0, ctx->opt.flat_rows_max_mb) << 20));
     if (st == MDB_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = mdb_fail(ctx, MDB_ERR_HIP, "sync failed");
     if (st != MDB_OK) { delete f; return st; }
     mdb_ctx_retain(ctx);

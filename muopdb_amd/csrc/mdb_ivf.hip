@@ -2000,7 +2000,8 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
         if (U == 1 && blobs[0].num_clusters >= 65536) {
             TileView cv{d_cent_tiles.p, blobs[0].num_clusters, (blobs[0].num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
             const size_t sdiv = (size_t)std::max<long long>(1, ctx->opt.ivf_coarse_sample_div);
-            MDB_TRY(flat_build_aux(ctx, cv, cent_aux, (cv.n / MDB_TILE) / sdiv, MDB_METRIC_L2, true));
+            MDB_TRY(flat_build_aux(ctx, cv, cent_aux, (cv.n / MDB_TILE) / sdiv, MDB_METRIC_L2,
+                                   cv.n * (size_t)cv.d * 4 <= ((size_t)std::max<long long>(0, ctx->opt.flat_rows_max_mb) << 20)));
         }
     }
     mdb_status st = mdb_check_flags(ctx);  // synchronises: temporaries may now be released

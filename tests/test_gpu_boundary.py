@@ -463,3 +463,35 @@ def test_environment_option_words_and_typos():
     assert got == [0, 0, dflt[2], dflt[3], 1, 16], (got, dflt)
     msg = out.stdout.splitlines()[1]
     assert "MDB_PQ_SDC_MAX_MB" in msg and "MDB_FLAT_BLOCKS" in msg and "MDB_FLAT_ROWS" not in msg
+
+
+def test_resident_bytes_of_a_flat_index_and_a_large_coarse_quantizer(ctx):
+    """what an index keeps resident in HBM is visible (mdb_device_mem_info around the load) and bounded: a flat
+    L2 index = tiles 1 x + bf16 hi fragments 0.5 x + the row-major copy 1 x + sample (no lo fragments: the default filter never reads
+    them) <= 2.7 x its f32 rows (2.53 x at 1 M rows); without the copy (stores above MDB_FLAT_ROWS_MAX_MB) <= 1.65 x; the lo halves come back (+0.5 x) only
+    for a store loaded under MDB_BF_X1=0.  Results do not depend on any of it."""
+    from muopdb_amd.index import FlatIndex
+    n, d = 300_000, 128
+    rows = n * d * 4
+    rng = np.random.default_rng(8)
+    base = H.sift_like(n, d, n_clusters=40, seed=12)
+    q = (base[rng.integers(0, n, 40)] + rng.normal(0, 10, (40, d))).astype(np.float32)
+
+    def load(**opts):
+        import contextlib
+        with contextlib.ExitStack() as st:
+            for k_, v in opts.items():
+                st.enter_context(ctx.option(k_, v))
+            f0 = ctx.mem_info()[0]
+            idx = FlatIndex(ctx, base, 0)
+            used = f0 - ctx.mem_info()[0]
+        return idx, used / rows
+    a, ra = load()
+    want = a.search(q, 10)
+    b_, rb = load(MDB_FLAT_ROWS_MAX_MB=1)
+    c_, rc = load(MDB_BF_X1=0)
+    for other in (b_, c_):
+        got = other.search(q, 10)
+        assert all(np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y) for x, y in zip(got, want))
+    # (300 k rows: the sample's floor of 256 tiles is 5 % here, 1/32 at 1 M rows)
+    assert 2.3 < ra <= 2.7 and 1.4 < rb <= 1.65 and ra + 0.4 < rc <= 3.2, (ra, rb, rc)

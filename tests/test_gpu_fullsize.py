@@ -56,6 +56,12 @@ def flat_1m(ctx, base):
     return FlatIndex(ctx, base[1])
 
 
+def _threads(oracle):
+    """the oracle's OpenMP threads for the full-size legs (one query per thread, the rows do not depend on it —
+    64 queries cost what 4 cost on one thread)"""
+    return max(1, min(64, oracle.num_threads()))
+
+
 def test_c1_flat_10k_full_parity(ctx, oracle):
     """C1 is small enough for the oracle in full: 10 clusters x 1000 x 128 (py/create_test_hdf5.py semantics), 200 queries."""
     from muopdb_amd.index import FlatIndex
@@ -83,8 +89,8 @@ def test_flat_1m_properties_and_oracle_rows(ctx, oracle, base, flat_1m):
     for lo, hi in [(0, 1), (1, 4), (4, 32), (32, 64)]:      # batch-split invariance: exact kernels (B <= 4) and batched path agree
         part = flat_1m.search(q[lo:hi], K)
         assert np.array_equal(part[0], ids[lo:hi]) and np.array_equal(part[1].view(np.uint32), dist[lo:hi].view(np.uint32))
-    oids, odist = oracle.flat_topk(oracle.METRIC_L2, xh, q[:6], K)            # the oracle itself on the full base
-    assert np.array_equal(ids[:6], oids) and np.array_equal(dist[:6].view(np.uint32), odist.view(np.uint32))
+    oids, odist = oracle.flat_topk(oracle.METRIC_L2, xh, q[:32], K, threads=_threads(oracle))   # the oracle itself on the full base
+    assert np.array_equal(ids[:32], oids) and np.array_equal(dist[:32].view(np.uint32), odist.view(np.uint32))
     rows = np.array([5, 77_777, 500_000, 999_999])          # self-retrieval: a stored row finds itself at distance 0
     sids, sdist, _ = flat_1m.search(xh[rows], K)
     assert np.all(sdist[:, 0] == 0.0)
@@ -112,30 +118,29 @@ def test_c2_hnsw_1m_ef200(ctx, oracle, base, flat_1m, hnsw_1m):
     for lo, hi in [(0, 1), (1, 9), (9, 64)]:                                             # one block per query: any split, same rows
         assert rows_of(g.ann_search(q[lo:hi], K, 200), hi - lo) == whole[lo:hi]
     o = oracle.BlockBasedHnsw(idx, vec, D)                                               # the oracle on the same 768 MB of files
-    ores = o.ann_search(q[:24], K, 200)
+    ores = o.ann_search(q[:64], K, 200, threads=_threads(oracle))                         # all 64 queries of the batch (one per thread)
     evals, expanded = o.stats()
-    g.ann_search(q[:24], K, 200)
+    g.ann_search(q[:64], K, 200)
     st = ctx.stats()
-    assert rows_of(ores, 24) == whole[:24]
+    assert rows_of(ores, 64) == whole
     assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)             # same traversal, step for step
     for variant in ("MDB_HNSW_NO_ROW64", "MDB_HNSW_NO_TABLE"):   # rows of any length; the all-in-one kernel
         with ctx.option(variant, 1):
             pres = g.ann_search(q[:64], K, 200)
             assert rows_of(pres, 64) == whole
-            g.ann_search(q[:24], K, 200)
             st = ctx.stats()
             assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)
     exact_ids, _, _ = flat_1m.search(q[:64], K)                                          # recall@10 against the exact scan
     hit = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(64))
     assert hit / (64 * K) >= 0.99
     # ef is monotone for the result quality: a larger ef never loses exact neighbours on this base
-    wide = g.ann_search(q[:24], K, 400)   # > 256: the general kernel (hnsw_search_kernel)
+    wide = g.ann_search(q[:64], K, 400)   # > 256: the eight-register beam of the table path
     st_w = ctx.stats()
-    hit_w = sum(len(set(wide.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(24))
-    hit_n = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(24))
+    hit_w = sum(len(set(wide.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(64))
+    hit_n = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(64))
     assert hit_w >= hit_n
     o.stats()
-    assert rows_of(o.ann_search(q[:24], K, 400), 24) == rows_of(wide, 24)                # the oracle's rows on 24 queries at ef = 400 ...
+    assert rows_of(o.ann_search(q[:64], K, 400, threads=_threads(oracle)), 64) == rows_of(wide, 64)   # the oracle's rows on 64 queries at ef = 400 ...
     assert (st_w["distance_evals"], st_w["expanded_nodes"]) == tuple(o.stats())          # ... and its traversal, step for step
 
 
@@ -174,8 +179,8 @@ def test_c3_ivfpq_1m_nprobe16(ctx, oracle, base):
     for lo, hi in [(96, 160), (160, 256)]:
         assert rows_of(g.search(q256[lo:hi], K, P), hi - lo) == rows256[lo:hi]
     o = oracle.BlockBasedIvf(index, vec, oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, cb))
-    assert np.array_equal(g.find_nearest_centroids(q[:16], P), o.find_nearest_centroids(q[:16], P))
-    assert rows_of(o.search(q[:16], K, num_probes=P), 16) == whole[:16]                   # the oracle on the full index
+    assert np.array_equal(g.find_nearest_centroids(q[:96], P), o.find_nearest_centroids(q[:96], P))
+    assert rows_of(o.search(q[:96], K, num_probes=P, threads=_threads(oracle)), 96) == whole[:96]   # the oracle on the full index, all 96 rows
     pick = [100, 129, 200, 255]
     assert rows_of(o.search(q256[pick], K, num_probes=P), 4) == [rows256[i] for i in pick]
     # more probes scan a superset of lists: the k-th symmetric-PQ score can only improve
@@ -232,7 +237,7 @@ def test_c4_shape_multi_user_spann_eighth(ctx, oracle):
         assert all(u * per <= dd < (u + 1) * per for dd in res.doc_ids(u))
     o = oracle.MultiSpannIndex(*args)
     op = oracle.SearchParams(K, 200, num_explored_centroids=P, centroid_distance_ratio=0.1)
-    assert rows_of(o.search_for_user(uids[:24], q[:24], op), 24) == whole[:24]
+    assert rows_of(o.search_for_user(uids, q, op, threads=_threads(oracle)), U) == whole      # every pair of the batch
     shards = [MultiSpannIndex(ctx, *args, None, r, 2) for r in range(2)]                          # lists l % 2 == r
     merged = shards[0].merge_shards(uids, [sh.search_shard(uids, q, p) for sh in shards], U, K)   # the exact merge of the points blocks
     assert rows_of(merged, U) == whole
@@ -285,10 +290,10 @@ def test_c4_full_size_multi_user_spann(ctx, oracle):
     wide = g.search_for_user(uids[:64], q[:64], SearchParams(K, 200).with_num_explored_centroids(64).with_centroid_distance_ratio(0.3))
     for i in range(64):                                                                           # a superset of lists: k-th score can only improve
         assert float(wide.scores[i, K - 1]) <= float(res.scores[i, K - 1])
-    sel = [0, 1, 2, 3, 100, 101, 500, 511, 512, 777, 1000, 1020, 1021, 1022, 1023, 640]
+    sel = sorted(set([0, 1, 2, 3, 100, 101, 500, 511, 512, 777, 1000, 1020, 1021, 1022, 1023, 640] + list(range(5, 1024, 21))))   # 64 users
     o = oracle.MultiSpannIndex(*args)
     op = oracle.SearchParams(K, 200, num_explored_centroids=P, centroid_distance_ratio=0.1)
-    assert rows_of(o.search_for_user([uids[i] for i in sel], q[sel], op), len(sel)) == [whole[i] for i in sel]
+    assert rows_of(o.search_for_user([uids[i] for i in sel], q[sel], op, threads=_threads(oracle)), len(sel)) == [whole[i] for i in sel]
     del o
     g.close()
     sub = list(range(0, U, 16))                                                                   # 64 users through 8 list shards
@@ -336,7 +341,7 @@ def test_c5_shard_ivfpq(ctx, oracle):
     assert rows_of(g.search_with_centroids_and_remap(q[:256], probes, K), 256) == whole[:256]
     o = oracle.BlockBasedIvf(sh["index"], sh["vectors"], oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, sh["codebook"]))
     assert np.array_equal(o.find_nearest_centroids(q[:12], P), probes[:12])
-    assert rows_of(o.search(q[:12], K, num_probes=P), 12) == whole[:12]                    # the oracle on the full shard
+    assert rows_of(o.search(q[:64], K, num_probes=P, threads=_threads(oracle)), 64) == whole[:64]    # the oracle on the full shard
     more = g.search(q[:64], K, 2 * P)                                                      # more probes: the k-th score can only improve
     for i in range(64):
         if len(whole[i][0]) == K:
@@ -393,5 +398,5 @@ def test_c5_full_ivfpq_one_gpu_equals_merge_of_8_shards(ctx, oracle):
     assert rows_of(merged, nq) == whole[:nq]
     o = oracle.BlockBasedIvf(full["index"], full["vectors"], oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 8, 8, full["codebook"]))
     assert np.array_equal(o.find_nearest_centroids(q[:8], P), probes[:8])
-    assert rows_of(o.search(q[:8], K, num_probes=P), 8) == whole[:8]                       # the oracle on the full index
+    assert rows_of(o.search(q[:64], K, num_probes=P, threads=_threads(oracle)), 64) == whole[:64]    # the oracle on the full index
     g.close()
