@@ -6,6 +6,7 @@ Data kinds include large common offsets, tiny spreads, huge magnitudes, duplicat
     python scripts/stress_mfma.py --seconds 300 [--seed 0]
     python scripts/stress_mfma.py --coarse --seconds 300     # the same data as an IVF coarse quantizer: the large-batch refine
                                                              # (flat_refine_group_kernel + second bound) forced on every batch
+    python scripts/stress_mfma.py --coarse-mid --seconds 300 # 1024 .. 16384 centroids: ivf_coarse_mfma_kernel + exact candidates
 """
 import argparse
 import os
@@ -79,15 +80,61 @@ def coarse(ctx, args):
     print("coarse refine stress OK: %d index/query sets in %.0f s" % (it, time.time() - t0))
 
 
+def coarse_mid(ctx, args):
+    """mid-sized coarse quantizers (1024 .. 16384 centroids of 64 / 96 / 128 / 192 / 256 dimensions): find_nearest_centroids through
+    ivf_coarse_mfma_kernel + the exact candidates (mdb_ivf_coarse.hip.h) against the exact kernels (MDB_IVF_COARSE_MFMA=0) on the same
+    index, with and without the second-level bound — VERDICT r4 next #2: adversarial coarse sets at 4096 centroids"""
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import BlockBasedIvf
+    t0, it = time.time(), 0
+    while time.time() - t0 < args.seconds:
+        rng = np.random.default_rng(args.seed * 15485863 + it)
+        n = int(rng.choice([1024, 1500, 4096, 4096, 4096, 8192, 16384]))
+        d = int(rng.choice([64, 96, 128, 128, 192, 256]))
+        b = int(rng.choice([32, 33, 64, 100, 256, 300]))
+        kind = int(rng.integers(0, 6))
+        cent = make(rng, n, d, kind)
+        if rng.integers(0, 3) == 0:   # blocks of identical centroids: more ties than a candidate segment holds
+            for cnt in rng.choice([40, 300, 900], int(rng.integers(1, 3))):
+                rows = rng.choice(n, int(cnt), replace=False)
+                cent[rows] = cent[rows[0]]
+        pls = [np.array([i], dtype=np.uint64) if i < 512 else np.zeros(0, np.uint64) for i in range(n)]
+        g = BlockBasedIvf(ctx, F.write_ivf_index(cent, list(range(1, 513)), pls), F.write_vector_file(cent[:512]))
+        if rng.integers(0, 2):
+            q = (cent[rng.integers(0, n, b)] + rng.standard_normal((b, d)).astype(np.float32) * np.float32(rng.choice([0, 1e-3, 1]))).astype(np.float32)
+        else:
+            q = make(rng, b, d, kind)
+        for P in (1, int(rng.choice([8, 16, 17])), int(rng.choice([32, 64]))):
+            P = min(P, n)
+            with ctx.option("MDB_IVF_COARSE_MFMA", 0):
+                want = g.find_nearest_centroids(q, P)
+            for opts in ({}, {"MDB_CM_GLOBAL_BOUND": 0}):
+                for kk, vv in opts.items():
+                    ctx.set_option(kk, vv)
+                got = g.find_nearest_centroids(q, P)
+                ctx.set_option("MDB_CM_GLOBAL_BOUND", 1)
+                if not np.array_equal(got, want):
+                    bad = np.nonzero((got != want).any(1))[0]
+                    print("MISMATCH it=%d seed=%d cfg=%s opts=%s rows=%s" % (it, args.seed, dict(n=n, d=d, b=b, P=P, kind=kind), opts, bad[:5]), flush=True)
+                    print(got[bad[0]], want[bad[0]])
+                    sys.exit(1)
+        g.close()
+        it += 1
+    print("mid-sized coarse quantizer stress OK: %d index/query sets in %.0f s" % (it, time.time() - t0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--coarse", action="store_true")
+    ap.add_argument("--coarse-mid", action="store_true", help="1024 .. 16384 centroids: the fused step's matrix-core coarse search")
     args = ap.parse_args()
     ctx = L.Context(0)
     if args.coarse:
         return coarse(ctx, args)
+    if args.coarse_mid:
+        return coarse_mid(ctx, args)
     t0, it, used = time.time(), 0, 0
     while time.time() - t0 < args.seconds:
         rng = np.random.default_rng(args.seed * 7919 + it)
