@@ -1037,45 +1037,74 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
                             for (int r = 0; r < NB; ++r) ru_closer += __popcll(__ballot(bd[r] < ru_o));
                         }
                         ru_closer += __popcll(accepted & __ballot(od < ru_o));   // this chunk's pushes
-                        // ---- push all accepted neighbours: slots n .. n+na-1, in edge order
-                        // (forward lane permute: the accepted lane of rank r sends its pair to lane (n + r) & 63, everybody
-                        // else to an unused lane; no LDS staging round trip on wave 0's path)
-                        {
-                            const bool mine = (accepted >> lane) & 1ull;
-                            const int dest = mine ? (n + __popcll(accepted & lt_mask)) & 63 : (n + na) & 63;
-                            const uint32_t rod = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)od);
-                            const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)id);
-                            const int rel = (lane - n) & 63;
-                            const bool got = rel < na;
-                            const int reg = (n + rel) >> 6;
+                        // ---- one or two accepted neighbours (every step outside a layer's fill phase): each enters its slot n, n + 1 through two scalar
+                        // reads of its lane — no ds_permute round trip (the pair came back ~130 cycles later, and the NEXT step's selection reads the
+                        // beam first thing) and no 64-lane select tree; the same loop keeps the best accepted neighbour in pop order
+#ifndef MDB_HNSW_NO_FAST_PUSH
+                        if (na <= 2) {
+                            unsigned long long am2 = accepted;
+                            int pos = n;
+                            while (am2) {
+                                const int sidx = __ffsll((long long)am2) - 1;
+                                am2 &= am2 - 1;
+                                const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                                const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
+                                const bool me = lane == (pos & 63);
+                                const int rg = pos >> 6;   // wave-uniform
 #pragma unroll
-                            for (int r = 0; r < NB; ++r) {
-                                const bool w = got && reg == r;
-                                bd[r] = w ? rod : bd[r];
-                                bi[r] = w ? rid : bi[r];
-                                cdv[r] = w ? rod : cdv[r];
+                                for (int r = 0; r < NB; ++r) {
+                                    if (rg == r) {
+                                        bd[r] = me ? ao : bd[r];
+                                        bi[r] = me ? ai : bi[r];
+                                        cdv[r] = me ? ao : cdv[r];
+                                    }
+                                }
+                                ++pos;
+                                if (!best_have || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_have = true; }
                             }
-                        }
-                        // best accepted neighbour of this chunk in pop order (smallest distance, largest id)
-                        unsigned long long am = accepted;
-                        if (na > 2) {
-                            // many accepted (fill phase): two wave reductions instead of a scalar loop over them
-                            const bool mine = (accepted >> lane) & 1ull;
-                            const uint32_t mo = wave_min_u32(mine ? od : SLOT_EMPTY);
-                            const uint32_t mi = wave_max_u32(mine && od == mo ? id : 0u);
-                            if (!best_have || mo < best_o || (mo == best_o && mi > best_id)) {
-                                best_o = mo;
-                                best_id = mi;
-                                best_have = true;
+                        } else
+#endif
+                        {
+                            // ---- push all accepted neighbours: slots n .. n+na-1, in edge order
+                            // (forward lane permute: the accepted lane of rank r sends its pair to lane (n + r) & 63, everybody
+                            // else to an unused lane; no LDS staging round trip on wave 0's path)
+                            {
+                                const bool mine = (accepted >> lane) & 1ull;
+                                const int dest = mine ? (n + __popcll(accepted & lt_mask)) & 63 : (n + na) & 63;
+                                const uint32_t rod = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)od);
+                                const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)id);
+                                const int rel = (lane - n) & 63;
+                                const bool got = rel < na;
+                                const int reg = (n + rel) >> 6;
+    #pragma unroll
+                                for (int r = 0; r < NB; ++r) {
+                                    const bool w = got && reg == r;
+                                    bd[r] = w ? rod : bd[r];
+                                    bi[r] = w ? rid : bi[r];
+                                    cdv[r] = w ? rod : cdv[r];
+                                }
                             }
-                            am = 0;
-                        }
-                        while (am) {
-                            const int sidx = __ffsll((long long)am) - 1;
-                            am &= am - 1;
-                            const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
-                            const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
-                            if (!best_have || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_have = true; }
+                            // best accepted neighbour of this chunk in pop order (smallest distance, largest id)
+                            unsigned long long am = accepted;
+                            if (na > 2) {
+                                // many accepted (fill phase): two wave reductions instead of a scalar loop over them
+                                const bool mine = (accepted >> lane) & 1ull;
+                                const uint32_t mo = wave_min_u32(mine ? od : SLOT_EMPTY);
+                                const uint32_t mi = wave_max_u32(mine && od == mo ? id : 0u);
+                                if (!best_have || mo < best_o || (mo == best_o && mi > best_id)) {
+                                    best_o = mo;
+                                    best_id = mi;
+                                    best_have = true;
+                                }
+                                am = 0;
+                            }
+                            while (am) {
+                                const int sidx = __ffsll((long long)am) - 1;
+                                am &= am - 1;
+                                const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                                const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
+                                if (!best_have || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_have = true; }
+                            }
                         }
                         n += na;
                     }

@@ -310,7 +310,22 @@ struct HnswUpArgs {
 #ifdef MDB_PIPE_DBG   // -DMDB_PIPE_DBG + MDB_HNSW_DBG=1: cycle / event sums into counters[4..15] (the traversal kernels print the same words)
 #define UP_T(t) const unsigned long long t = __builtin_readcyclecounter()
 #define UP_ACC(slot, v) dbg_acc[slot] += (v)
+#if MDB_PIPE_DBG >= 2   // finer split of selection and pop into slots 6..11 (instead of the event counts); the row wait made explicit
+#define UP_T2(t) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter()
+#define UP_T2L(t) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter()
+#define UP_ACC2(slot, v) dbg_acc[slot] += (v)
+#define UP_CNT(slot, v) do {} while (0)
 #else
+#define UP_T2(t) do {} while (0)
+#define UP_T2L(t) do {} while (0)
+#define UP_ACC2(slot, v) do {} while (0)
+#define UP_CNT(slot, v) dbg_acc[slot] += (v)
+#endif
+#else
+#define UP_T2(t) do {} while (0)
+#define UP_T2L(t) do {} while (0)
+#define UP_ACC2(slot, v) do {} while (0)
+#define UP_CNT(slot, v) do {} while (0)
 #define UP_T(t) do {} while (0)
 #define UP_ACC(slot, v) do {} while (0)
 #endif
@@ -431,7 +446,9 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
             }
             // ---- ... and in flight while the wave finds the best candidate already in B (the next pop unless a neighbour accepted
             // below beats it), requests its row and takes its stop count
+            UP_T2L(s0);   // (debug 2: the LDS round trip of the visited set / table is retired here, not behind the selection)
             ru_valid = beam_best_id(cdv, bi, ru_o, ru_id);
+            UP_T2L(s1);
             if (ru_valid) {
                 rowr = load_row(ru_id);
                 ru_closer = 0;
@@ -441,6 +458,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                 }
             }
             UP_T(t1);
+            UP_ACC2(6, s0 - t0); UP_ACC2(7, s1 - s0);
             const bool have = valid && !(old & bit);
             const unsigned long long hm = __ballot(have);
             const uint32_t nnew = (uint32_t)__popcll(hm);
@@ -456,10 +474,10 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
             uint32_t best_o = SLOT_EMPTY, best_id = 0;
             bool best_have = false;
             UP_T(t2);
-            UP_ACC(0, t1 - t0); UP_ACC(1, t2 - t1); UP_ACC(5, 1); UP_ACC(6, nnew);
+            UP_ACC(0, t1 - t0); UP_ACC(1, t2 - t1); UP_ACC(5, 1); UP_CNT(6, nnew);
             if (nnew) {
                 unsigned long long surv = __ballot(have && od < fbound);
-                UP_ACC(7, __popcll(surv));
+                UP_CNT(7, __popcll(surv));
                 unsigned long long accepted = 0;
                 // fill phase of a layer: B still holds at most ef elements after this step — every count below would be < ef
                 if (n + (int)nnew <= ef) { accepted = surv; surv = 0; }
@@ -475,10 +493,10 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                 }
                 const int na = __popcll(accepted);
                 UP_T(t3);
-                UP_ACC(2, t3 - t2); UP_ACC(8, na); UP_ACC(9, na == 1 ? 1 : 0); UP_ACC(10, na >= 3 ? 1 : 0);
+                UP_ACC(2, t3 - t2); UP_CNT(8, na); UP_CNT(9, na == 1 ? 1 : 0); UP_CNT(10, na >= 3 ? 1 : 0);
                 if (na) {
                     if (n + na > (64 * NB)) {
-                        UP_ACC(11, 1);
+                        UP_CNT(11, 1);
                         // ---- compaction: f = ef-th smallest distance image in B (32-step radix select by ballots), drop what is farther
                         uint32_t prefix = 0;
                         int need = ef;
@@ -527,37 +545,66 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                         }
                     }
                     if (nexp >= ef) ru_closer += __popcll(accepted & __ballot(od < ru_o));
-                    // ---- push all accepted neighbours: slots n .. n+na-1, in edge order (forward lane permute)
-                    {
-                        const bool mine = (accepted >> lane) & 1ull;
-                        const int dest = mine ? (n + __popcll(accepted & lt_mask)) & 63 : (n + na) & 63;
-                        const uint32_t rod = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)od);
-                        const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)id);
-                        const int rel = (lane - n) & 63;
-                        const bool got = rel < na;
-                        const int reg = (n + rel) >> 6;
-#pragma unroll
-                        for (int r = 0; r < NB; ++r) {
-                            const bool w = got && reg == r;
-                            bd[r] = w ? rod : bd[r];
-                            bi[r] = w ? rid : bi[r];
-                            cdv[r] = w ? rod : cdv[r];
-                        }
-                    }
-                    // best accepted neighbour in pop order (smallest distance, largest id)
-                    if (na > 2) {
-                        const bool mine = (accepted >> lane) & 1ull;
-                        best_o = wave_min_u32(mine ? od : SLOT_EMPTY);
-                        best_id = wave_max_u32(mine && od == best_o ? id : 0u);
-                        best_have = true;
-                    } else {
-                        unsigned long long am = accepted;
-                        while (am) {
-                            const int sidx = __ffsll((long long)am) - 1;
-                            am &= am - 1;
+                    // ---- one or two accepted neighbours (every step outside a layer's fill phase): each enters its slot n, n + 1 through two scalar
+                    // reads of its lane — no ds_permute round trip (the pair came back ~130 cycles later, and the NEXT step's selection reads the
+                    // beam first thing) and no 64-lane select tree; the same loop keeps the best accepted neighbour in pop order
+#ifndef MDB_HNSW_NO_FAST_PUSH
+                    if (na <= 2) {
+                        unsigned long long am2 = accepted;
+                        int pos = n;
+                        while (am2) {
+                            const int sidx = __ffsll((long long)am2) - 1;
+                            am2 &= am2 - 1;
                             const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
                             const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
+                            const bool me = lane == (pos & 63);
+                            const int rg = pos >> 6;   // wave-uniform
+#pragma unroll
+                            for (int r = 0; r < NB; ++r) {
+                                if (rg == r) {
+                                    bd[r] = me ? ao : bd[r];
+                                    bi[r] = me ? ai : bi[r];
+                                    cdv[r] = me ? ao : cdv[r];
+                                }
+                            }
+                            ++pos;
                             if (!best_have || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_have = true; }
+                        }
+                    } else
+#endif
+                    {
+                        // ---- push all accepted neighbours: slots n .. n+na-1, in edge order (forward lane permute)
+                        {
+                            const bool mine = (accepted >> lane) & 1ull;
+                            const int dest = mine ? (n + __popcll(accepted & lt_mask)) & 63 : (n + na) & 63;
+                            const uint32_t rod = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)od);
+                            const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)id);
+                            const int rel = (lane - n) & 63;
+                            const bool got = rel < na;
+                            const int reg = (n + rel) >> 6;
+    #pragma unroll
+                            for (int r = 0; r < NB; ++r) {
+                                const bool w = got && reg == r;
+                                bd[r] = w ? rod : bd[r];
+                                bi[r] = w ? rid : bi[r];
+                                cdv[r] = w ? rod : cdv[r];
+                            }
+                        }
+                        // best accepted neighbour in pop order (smallest distance, largest id)
+                        if (na > 2) {
+                            const bool mine = (accepted >> lane) & 1ull;
+                            best_o = wave_min_u32(mine ? od : SLOT_EMPTY);
+                            best_id = wave_max_u32(mine && od == best_o ? id : 0u);
+                            best_have = true;
+                        } else {
+                            unsigned long long am = accepted;
+                            while (am) {
+                                const int sidx = __ffsll((long long)am) - 1;
+                                am &= am - 1;
+                                const uint32_t ao = (uint32_t)__builtin_amdgcn_readlane((int)od, sidx);
+                                const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)id, sidx);
+                                if (!best_have || ao < best_o || (ao == best_o && ai > best_id)) { best_o = ao; best_id = ai; best_have = true; }
+                            }
                         }
                     }
                     n += na;
@@ -566,6 +613,8 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
                 UP_ACC(3, t4 - t3);
             }
             UP_T(t5);
+            UP_T2(p0);   // (debug 2: every outstanding load — the runner-up's row — retired here)
+            UP_ACC2(8, p0 - t5);
             // ---- candidates.pop(): runner-up vs best accepted; stop when it is farther than furthest
             const bool take_ru = ru_valid && (!best_have || ru_o < best_o || (ru_o == best_o && ru_id > best_id));
             if (!take_ru && !best_have) {
@@ -597,6 +646,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
             }
             UP_T(t6);
             UP_ACC(4, t6 - t5);
+            UP_ACC2(9, t6 - p0);
         }
         if (overflow) break;
         // ---- a layer hands its nearest point down (index.rs:177-181: smallest distance, then smallest id)
