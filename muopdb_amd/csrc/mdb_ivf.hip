@@ -1263,6 +1263,23 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         }
     } else if (tid < m) qcode[tid] = f.qcodes[(size_t)qi * m + tid];
     PQF_STAMP(7);
+#ifndef MDB_PQF_NO_TABLE_PREFETCH
+    // the query's rows of the code-to-code table depend on its codes only: requested HERE (m K / PQF_BLOCK = MW words per thread), they
+    // travel while the block selects its probes and are stored behind that phase — the table costs no round trip of its own
+    float sdc_pre[MW];
+    const bool tab_pre = COARSE == 2 && sdc != nullptr;
+    if (tab_pre) {
+        __syncthreads();   // qcode
+#pragma unroll
+        for (int x = 0; x < MW; ++x) {
+            const int i = tid + x * PQF_BLOCK;
+            sdc_pre[x] = sdc[((size_t)(i >> nbits) * K + qcode[i >> nbits]) * K + (i & (K - 1))];
+        }
+    }
+#else
+    const bool tab_pre = false;
+    float sdc_pre[MW];
+#endif
 
     // ---- 1. find_nearest_centroids: the num_probes nearest by (distance, index) among the distances of ivf_prep_kernel
     int np = f.num_probes;
@@ -1335,7 +1352,9 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         const int s = i / SUBDIM;
         qv[i] = cb[((size_t)s * K + qcode[s]) * SUBDIM + (i % SUBDIM)];
     }
-    __syncthreads();   // qv, probes_l
+    // (with the row-sum table nothing below reads qv before the barrier behind the table: the codebook rows, the lists' tile offsets and
+    // the table rows are ONE memory round trip instead of two)
+    if (!sdc) __syncthreads();   // qv
     // ... and the flattened tile sequence of the probed lists (wave 0; independent of the table)
     if (tid < 64) {
         uint32_t t0 = 0, cnt = 0;
@@ -1358,7 +1377,10 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         ppref[tid + 1] = incl;   // entries past np repeat the total
         if (tid == 0) ppref[0] = 0;
     }
-    if (sdc) {   // the query's rows of the code-to-code table (pq_sdc_kernel: the values the loop below computes)
+    if (tab_pre) {
+#pragma unroll
+        for (int x = 0; x < MW; ++x) btab[tid + x * PQF_BLOCK] = sdc_pre[x];
+    } else if (sdc) {   // the query's rows of the code-to-code table (pq_sdc_kernel: the values the loop below computes)
         for (int i = tid; i < m * K; i += PQF_BLOCK) btab[i] = sdc[((size_t)(i >> nbits) * K + qcode[i >> nbits]) * K + (i & (K - 1))];
     } else
     for (int i = tid; i < m * K; i += PQF_BLOCK) {
