@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
         // the candidates ivf_coarse_mfma_kernel left for this query: exact distances, rank by (distance, index) (mdb_ivf_coarse.hip.h)
         np = min(np, (int)f.num_clusters);
         // (their ids, counts and the query row were requested at the start of the block: cm_pre; the candidate records' area is free until phase 3)
-        cm_select_probes<PQF_BLOCK>(cs, cm_pre, (uint32_t)qi, f.q + (size_t)qi * f.qstride, np, pstart, &misc[3], ck, (uint32_t)PQF_CAP, sel_lds, cand, probes_l, nan_seen, f.dbg);
+        cm_select_probes<PQF_BLOCK>(cs, cm_pre, (uint32_t)qi, f.q + (size_t)qi * f.qstride, np, pstart, &misc[3], ck, (uint32_t)PQF_CAP, sel_lds, cand, probes_l, nan_seen, f.dbg, gm, &rot);
     } else if (COARSE == 1) {
         const uint32_t lpad = f.cent_ntiles * MDB_TILE;
         const float* dist = f.cdist + (size_t)qi * lpad;

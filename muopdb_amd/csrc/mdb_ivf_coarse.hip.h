@@ -343,7 +343,7 @@ __device__ __forceinline__ uint32_t cm_quad_rank(const uint64_t* keys, uint32_t 
 template <int BLOCK>
 __device__ __forceinline__ void cm_select_probes(const CmSelect& c, const CmPre<BLOCK>& pre, uint32_t qi, const float* __restrict__ qrow, int np, uint32_t* cpref,
                                                  uint32_t* flag, uint64_t* ck, uint32_t cap, char* sel_lds, uint32_t* stage, uint32_t* probes_l, bool& nan_seen,
-                                                 unsigned long long* dbg = nullptr) {
+                                                 unsigned long long* dbg = nullptr, uint32_t* gm = nullptr, int* rot = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
 #define CM_SSTAMP(i) do { if (dbg && qi == 0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dbg[i] = __builtin_readcyclecounter(); } } while (0)
     uint2* recl = (uint2*)stage;                             // [S][CM_PRE] prefetched records, later the survivors' ids
@@ -387,7 +387,55 @@ __device__ __forceinline__ void cm_select_probes(const CmSelect& c, const CmPre<
         for (uint32_t i = tid; i < total; i += BLOCK) surv[i] = ((uint32_t*)ck)[i];
         __syncthreads();
     }
-    if (!slow && c.global_bound) {
+    bool grouped = false;
+#ifndef MDB_CM_NO_GROUP_BOUND
+    if (BLOCK == 1024 && gm && !slow && c.global_bound && total <= 2u * BLOCK) {
+        // ---- 1'. the global bound WITHOUT ranking the candidates (rank counting ~185 keys cost 8 k of the step's 58 k cycles): thread
+        // (group g = tid / 16, slot s = tid % 16) takes candidates s * 64 + g (+ 1024), so a 16-lane group holds ~3 of them; the np-th
+        // smallest of the 64 group minima of the inverted t images (block_group_bound: one row reduction, two barriers, a 20-bit radix
+        // select on wave 0) is an image with at least np candidates at or below it — np centroids have t_lo >= Tg', all the
+        // threshold's derivation asks of its bound.  Tg' is about the (np + 3)-th largest t_lo instead of the np-th: a handful more
+        // survivors.  The candidates stay in their threads' registers: no key array, no second pass over LDS.
+        grouped = true;
+        uint32_t v[2], cidv[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const uint32_t i = (uint32_t)(tid & 15) * 64u + (uint32_t)(tid >> 4) + (uint32_t)x * BLOCK;
+            v[x] = 0xFFFFFFFFu;
+            cidv[x] = 0xFFFFFFFFu;
+            if (i < total) {
+                uint32_t sg = 0;
+                while (cpref[sg + 1] <= i) ++sg;
+                const uint32_t slot = i - cpref[sg];
+                const uint2 r = slot < CM_PRE ? recl[sg * CM_PRE + slot] : c.cand[((size_t)qi * c.S + sg) * c.caps + slot];
+                const float t = __uint_as_float(r.y);
+                cidv[x] = r.x;
+                v[x] = t == t ? min(~f32_orderable(t), 0xFFFFFFFEu) : 0xFFFFFFFFu;   // ascending image = descending t_lo; NaN: "no value"
+            }
+        }
+        __syncthreads();   // every record of recl is in registers: surv (the same words) may be written below
+        const uint32_t T = block_group_bound<2>(v, (uint32_t)np, gm, *rot);
+        CM_SSTAMP(9);
+        // (all ones: fewer than np groups hold a candidate — a short list: every candidate is evaluated)
+        const float tg = T == 0xFFFFFFFFu ? -__uint_as_float(0x7F800000u) : f32_from_orderable(~T);
+        const float thr = cm_threshold(tg, pre.qn, c.kappa, c.xnmax);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bool keep = cidv[x] != 0xFFFFFFFFu && (v[x] == 0xFFFFFFFFu || !(f32_from_orderable(~v[x]) < thr));
+            const unsigned long long bm = __ballot(keep);
+            if (bm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&flag[1], (uint32_t)__popcll(bm));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (keep) surv[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = cidv[x];
+            }
+        }
+        __syncthreads();
+        ns = flag[1];
+        slow = ns < (uint32_t)np;   // (cannot happen: the np keys at or above Tg' survive)
+    }
+#endif
+    if (!slow && c.global_bound && !grouped) {
         // ---- 1. keys (t_lo, index) of all candidates, the np-th LARGEST by rank counting (four lanes per key); NaN products (always
         //         candidates) sort lowest: they never raise the bound and survive by themselves
         for (uint32_t i = tid; i < total; i += BLOCK) {
