@@ -1537,12 +1537,70 @@ __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, Fus
     int c = 0;   // winners
     // ---- 4. exact distances of the candidates, top-k by (distance, point id)
     if (nc <= f.cap) {
+#ifdef MDB_PQF_EXACT_PER_THREAD
         for (uint32_t i = tid; i < nc; i += PQF_BLOCK) {
             uint32_t cwv[MW];
 #pragma unroll
             for (int w = 0; w < MW; ++w) cwv[w] = cand[i * (1 + MW) + 1 + w];
             ck[i] = exact_key(cand[i * (1 + MW)], cwv);
         }
+#else
+        // exact_key's arithmetic with one THREAD PER ACCUMULATOR LANE of the reference's pass instead of one per candidate: the terms of
+        // a subvector of SUBDIM elements go to min(SUBDIM, 16) lane accumulators (pq2_add_row), each an independent chain over the
+        // subspaces — NL adjacent threads take the NL lanes of a candidate (their codebook loads are adjacent floats of the same rows),
+        // then the lanes are summed in the reference's order.  The ~100 candidates of a query kept 2 of the block's 16 waves busy with
+        // ~500 dependent instructions each (11 k of the step's 56 k cycles); now every wave works and a thread's chain is m terms.
+        {
+            constexpr int NL = SUBDIM >= 16 ? 16 : SUBDIM;   // accumulator lanes that receive terms (s16, s8 or s4 of pq2_add_row)
+            constexpr int NCH = SUBDIM / NL;                  // elements of a row per lane (32-element subvectors: two)
+            constexpr int SB = 16 / NCH;                      // subspaces whose loads are issued together
+            constexpr int CPP = PQF_BLOCK / NL;               // candidates per pass
+            const int jl = tid % NL;
+            for (uint32_t i0 = 0; i0 < nc; i0 += CPP) {
+                const uint32_t i = i0 + (uint32_t)(tid / NL);
+                const bool valid = i < nc;
+                float accl = 0.0f;
+                uint32_t vid = 0;
+                if (valid) {
+                    vid = cand[i * (1 + MW)];
+                    uint32_t cwv[MW];
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) cwv[w] = cand[i * (1 + MW) + 1 + w];
+#pragma unroll
+                    for (int s0 = 0; s0 < m; s0 += SB) {
+                        float cv[SB * NCH];
+#pragma unroll
+                        for (int x = 0; x < SB; ++x) {
+                            const int sb = s0 + x;
+                            if (sb < m) {
+                                const uint32_t code = (cwv[sb >> 2] >> (8 * (sb & 3))) & 0xFFu;
+#pragma unroll
+                                for (int cc = 0; cc < NCH; ++cc) cv[x * NCH + cc] = cb[((size_t)(sb << nbits) + code) * SUBDIM + NL * cc + jl];
+                            }
+                        }
+#pragma unroll
+                        for (int x = 0; x < SB; ++x) {
+                            const int sb = s0 + x;
+                            if (sb < m) {
+#pragma unroll
+                                for (int cc = 0; cc < NCH; ++cc)
+                                    accl = __fadd_rn(accl, acc_term<MDB_METRIC_L2>(0.0f, qv[sb * SUBDIM + NL * cc + jl], cv[x * NCH + cc]));
+                            }
+                        }
+                    }
+                }
+                // reduce_ordered over the NL lanes (lane 0 first); the two accumulator groups that received nothing add +0.0
+                float rs = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) rs = __fadd_rn(rs, __shfl(accl, (lane & ~(NL - 1)) + j));
+                rs = __fadd_rn(__fadd_rn(__fadd_rn(rs, 0.0f), 0.0f), 0.0f);
+                if (valid && jl == 0) {
+                    if (rs != rs) nan_seen = true;
+                    ck[i] = make_key(rs, vid);
+                }
+            }
+        }
+#endif
         __syncthreads();
         PQF_STAMP(4);
         // rank by counting; equal keys (a point in two probed lists) are ordered by their place in the list
