@@ -579,6 +579,27 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
         }
     }
     // layer 0: sort the working list by (distance, id), truncate to k (index.rs:190-191)
+#ifndef MDB_CLOSURE_BITONIC
+    if (wn <= 512) {
+        // a few hundred DISTINCT keys (ids are unique) of which k are wanted: every key's rank by counting — all lanes read the same LDS
+        // word (a broadcast), ONE barrier — instead of the block bitonic's 36 barrier-separated stages (a quarter of the kernel at 152 centroids)
+        const int outc = wn < a.k ? wn : a.k;
+        for (int i = tid; i < wn; i += BLOCK) {
+            const uint64_t key = W[i];
+            int rank = 0;
+            for (int jj = 0; jj < wn; ++jj) rank += W[jj] < key ? 1 : 0;
+            if (rank < a.k) a.out_keys[(size_t)qi * a.k + rank] = key;
+        }
+        for (int i = outc + tid; i < a.k; i += BLOCK) a.out_keys[(size_t)qi * a.k + i] = MDB_KEY_MAX;
+        if (tid == 0) {
+            a.out_counts[qi] = (uint32_t)outc;
+            atomicAdd(&a.counters[0], (unsigned long long)misc[3]);
+            atomicAdd(&a.counters[1], (unsigned long long)misc[4]);
+            if (misc[5]) atomicOr(a.flags, MDB_FLAG_NAN);
+        }
+        return;
+    }
+#endif
     int n2 = 64;
     while (n2 < wn) n2 <<= 1;
     for (int i = wn + tid; i < n2; i += BLOCK) W[i] = MDB_KEY_MAX;
