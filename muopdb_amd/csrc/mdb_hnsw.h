@@ -99,6 +99,8 @@ struct HnswSet {
     std::vector<HnswBlobInfo> blobs;
     std::vector<HnswUserDev> h_users;
     uint32_t max_n = 0, max_stride = 0;
+    uint32_t max_rows0 = 0, max_rowsU = 0;   // largest layer-0 row area (n0 S0 words) / dense upper row area ((layers - 1) n SU) of a user
+    bool all_dense = true;                   // every user's upper rows are in the dense form (hnsw_closure_kernel stages them in LDS)
     uint64_t total_rows = 0;
     DevBuf<uint8_t> d_index;       // uploaded graph file (doc ids are read from it)
     DevBuf<HnswUserDev> d_users;
@@ -115,6 +117,7 @@ struct HnswSet {
         pq.metric = src.pq.metric; pq.dimension = src.pq.dimension; pq.subdim = src.pq.subdim; pq.num_bits = src.pq.num_bits;
         pq.m = src.pq.m; pq.K = src.pq.K; pq.h_codebook = src.pq.h_codebook; pq.codebook.borrow(src.pq.codebook);
         blobs = src.blobs; h_users = src.h_users; max_n = src.max_n; max_stride = src.max_stride; total_rows = src.total_rows;
+        max_rows0 = src.max_rows0; max_rowsU = src.max_rowsU; all_dense = src.all_dense;
         d_index.borrow(src.d_index); d_users.borrow(src.d_users); d_adj.borrow(src.d_adj);
         d_upper_first.borrow(src.d_upper_first); d_level.borrow(src.d_level); d_vecs.borrow(src.d_vecs);
         upper.view_of(src.upper);

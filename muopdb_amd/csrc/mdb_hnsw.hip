@@ -465,8 +465,15 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
 // once: all edges of all frontier points are test-and-set in parallel (LDS bitmap), all new points'
 // distances are evaluated by the sixteen 16-lane groups, ~diameter rounds per layer instead of one
 // sequential step per point; the layer's working list is sorted once at the end (block bitonic).
+// st: LDS staging of the closure (byte offsets into the block's LDS, 0 = not staged).  The rounds of a closure are a chain of dependent
+// memory trips — per round the frontier's adjacency rows AND vectors, ~2.5 us each, ~15 rounds for a 150-point graph of 3-4 layers —
+// although the closure evaluates (nearly) EVERY point of the graph whatever the query: with `dtab` the block evaluates all n points up
+// front (ceil(n / groups) passes whose loads are all in flight: the same group16 distance, the same bits; a point the closure never
+// reaches is never looked at again, so rows and counters are unchanged) and copies the rows next to them; a round is then LDS reads,
+// LDS atomics and one barrier.
+struct ClosureStage { uint32_t dtab_off, rows0_off, rowsU_off; };
 template <int METRIC, int N16T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wcap) {
+__global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wcap, ClosureStage st) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int qi = (int)blockIdx.x;
     uint64_t* W = (uint64_t*)lds;
@@ -499,6 +506,25 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 #pragma unroll
         for (int c = 0; c < N16T; ++c) qr[c] = qs[16 * c + j];
     }
+    float* const dtab = (float*)(lds + st.dtab_off);
+    uint32_t* const rows0 = (uint32_t*)(lds + st.rows0_off);
+    uint32_t* const rowsU = (uint32_t*)(lds + st.rowsU_off);
+    const bool lds_rowsU = st.rowsU_off != 0u && u.adjD_off != ~0ull;
+    if (st.dtab_off) {
+        for (uint32_t p0 = (uint32_t)grp; p0 < u.n; p0 += BLOCK / 16) {
+            const float d = MDB_GROUP_DIST(vecs + (size_t)p0 * a.dpad);
+            if (j == 0) dtab[p0] = d;
+        }
+        if (st.rows0_off) {
+            const uint32_t* src = a.adj + u.adj0_off;
+            for (uint32_t i = tid; i < u.n0 * u.S0; i += BLOCK) rows0[i] = src[i];
+        }
+        if (lds_rowsU) {
+            const uint32_t* src = a.adj + u.adjD_off;
+            for (uint32_t i = tid; i < (u.num_layers - 1) * u.n * u.SU; i += BLOCK) rowsU[i] = src[i];
+        }
+        __syncthreads();
+    }
     uint32_t ep = u.entry_point;
     int wn = 0;
     for (int layer = (int)u.num_layers - 1; layer >= 0; --layer) {
@@ -519,9 +545,15 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
             // are test-and-set and the new points form the next frontier
             for (int i = grp; i < ncur; i += BLOCK / 16) {
                 const uint32_t f = cur[i];
-                const uint32_t* row = nullptr;
+                const uint32_t* row = nullptr;    // global row ...
+                const uint32_t* lrow = nullptr;   // ... or its staged copy
                 if (layer == 0) {
-                    if (f < u.n0) row = a.adj + u.adj0_off + (size_t)f * u.S0;
+                    if (f < u.n0) {
+                        if (st.rows0_off) lrow = rows0 + (size_t)f * u.S0;
+                        else row = a.adj + u.adj0_off + (size_t)f * u.S0;
+                    }
+                } else if (lds_rowsU) {
+                    lrow = rowsU + ((size_t)(layer - 1) * u.n + f) * u.SU;
                 } else {
                     row = hnsw_upper_row(a, u, layer, f);
                 }
@@ -529,9 +561,9 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const uint32_t t = 16 * c + j;
-                    e[c] = (row && t < stride) ? row[t] : 0xFFFFFFFFu;
+                    e[c] = t < stride ? (lrow ? lrow[t] : row ? row[t] : 0xFFFFFFFFu) : 0xFFFFFFFFu;
                 }
-                const float d = MDB_GROUP_DIST(vecs + (size_t)f * a.dpad);
+                const float d = st.dtab_off ? dtab[f] : MDB_GROUP_DIST(vecs + (size_t)f * a.dpad);
                 if (j == 0) {
                     W[wn + i] = make_key(d, f);
                     if (d != d) misc[5] = 1;
@@ -548,11 +580,11 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
                         }
                     }
                     t0 += 64;
-                    if (!row || t0 >= stride) break;
+                    if ((!row && !lrow) || t0 >= stride) break;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const uint32_t t = t0 + 16 * c + j;
-                        e[c] = t < stride ? row[t] : 0xFFFFFFFFu;
+                        e[c] = t < stride ? (lrow ? lrow[t] : row[t]) : 0xFFFFFFFFu;
                     }
                 }
             }
@@ -1499,6 +1531,11 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
             u.small_layer = small;
         }
         max_n = std::max(max_n, u.n);
+        max_rows0 = std::max<uint64_t>(max_rows0, std::min<uint64_t>((uint64_t)u.n0 * u.S0, 0xFFFFFFFFull));
+        if (u.num_layers > 1) {
+            if (u.adjD_off == ~0ull) all_dense = false;
+            max_rowsU = std::max<uint64_t>(max_rowsU, std::min<uint64_t>((uint64_t)(u.num_layers - 1) * u.n * u.SU, 0xFFFFFFFFull));
+        }
     }
     total_rows = row_src.size();
     // ---- the table path's compact upper layers (mdb_hnsw_upper.hip): one graph, >= 2 layers, f32 rows, rows of <= 64 edges
@@ -1739,13 +1776,34 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         while ((uint32_t)wcap < max_n) wcap <<= 1;
         // small batches: 64 groups per query (latency); large ones: 256-thread blocks, four resident per CU
         const bool big = ctx->opt.closure_block > 0 ? ctx->opt.closure_block >= 1024 : b <= 256;
-        const size_t clds = (size_t)wcap * 16 + (size_t)dpad * 4 + 8 + 64 + (((size_t)max_n + 31) / 32 + 1) * 4;
+        size_t clds = (size_t)wcap * 16 + (size_t)dpad * 4 + 8 + 64 + (((size_t)max_n + 31) / 32 + 1) * 4;
+        // staging (ClosureStage): every point's distance up front + the rows in LDS, while the block keeps its residency (one 1024-thread
+        // block per CU: up to 120 KB; four 256-thread blocks per CU: 40 KB each)
+        ClosureStage stg{0u, 0u, 0u};
+        // (only the one-block-per-CU form: with four 256-thread blocks per CU the rounds of one block already hide behind the others',
+        // and the up-front passes cost the full C4 batch of 1024 pairs + 4 %: 0.496 -> 0.517 ms)
+        if (!ctx->opt.closure_no_stage && big) {
+            const size_t budget = 120 * 1024;
+            clds = (clds + 15) & ~(size_t)15;
+            if (clds + (size_t)max_n * 4 + 16 <= budget) {
+                stg.dtab_off = (uint32_t)clds;
+                clds = (clds + (size_t)max_n * 4 + 15) & ~(size_t)15;
+                if (max_rows0 && clds + (size_t)max_rows0 * 4 + 16 <= budget) {
+                    stg.rows0_off = (uint32_t)clds;
+                    clds = (clds + (size_t)max_rows0 * 4 + 15) & ~(size_t)15;
+                }
+                if (max_rowsU && all_dense && clds + (size_t)max_rowsU * 4 + 16 <= budget) {
+                    stg.rowsU_off = (uint32_t)clds;
+                    clds = (clds + (size_t)max_rowsU * 4 + 15) & ~(size_t)15;
+                }
+            }
+        }
 #define MDB_CLOSURE_LAUNCH(METRIC, NF, CB)                                                                                    \
     do {                                                                                                                    \
         if (clds > 48 * 1024)                                                                                               \
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_closure_kernel<METRIC, NF, CB>,                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));                       \
-        hnsw_closure_kernel<METRIC, NF, CB><<<dim3((unsigned)b), CB, clds, ctx->stream>>>(a, wcap);                         \
+        hnsw_closure_kernel<METRIC, NF, CB><<<dim3((unsigned)b), CB, clds, ctx->stream>>>(a, wcap, stg);                        \
     } while (0)
 #define MDB_CLOSURE_LAUNCH_M(METRIC)                                 \
     do {                                                             \
