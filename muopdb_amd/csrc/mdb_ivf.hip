@@ -2476,8 +2476,14 @@ mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const u
     const bool quant_in_prep = ctx->opt.pqf_quant_in_prep != 0;
     const unsigned quant_blocks = quant_in_prep ? (unsigned)((b * (size_t)pq.m + 3) / 4) : 0u;
     fa.quant_blocks = quant_blocks;
-    if (!quant_in_prep) fa.qcodes = nullptr;
-    if (coarse_mode == 2) MDB_TRY(cm_launch(ctx, cmf, d_q, qstride, b, num_probes, csh, const_cast<uint2*>(fa.cm_cand), const_cast<uint32_t*>(fa.cm_cnt)));
+    // coarse search on the matrix cores: its launch also quantizes the queries (blocks behind the coarse ones, on the CUs those leave idle)
+    const bool quant_in_coarse = coarse_mode == 2 && !quant_in_prep && !ctx->opt.pqf_no_quant_in_coarse && pq.K == 256 && (pq.subdim & 3) == 0;
+    if (!quant_in_prep && !quant_in_coarse) fa.qcodes = nullptr;
+    if (coarse_mode == 2) {
+        CoarseQuant cq;
+        if (quant_in_coarse) { cq.cb = pq.codebook.p; cq.qcodes = (uint8_t*)qcodes; cq.m = (uint32_t)pq.m; cq.sp = fa.sp; }
+        MDB_TRY(cm_launch(ctx, cmf, d_q, qstride, b, num_probes, csh, const_cast<uint2*>(fa.cm_cand), const_cast<uint32_t*>(fa.cm_cnt), cq));
+    }
     const size_t prep_lds = coarse_mode == 1 ? (size_t)PQF_QT * (d4 * 4 + 16) * 4 : 0;
     if (prep_lds > 48 * 1024) MDB_HIP(ctx, hipFuncSetAttribute((const void*)ivf_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
     if (fa.coarse_blocks + quant_blocks)

@@ -44,6 +44,13 @@ struct CoarseArgs {
     int P;                   // num_probes
     float kappa, xnmax;
     unsigned long long* dbg;  // MDB_CM_DBG: block 0 / thread 0 stores a cycle stamp after every phase
+    // blocks beyond the coarse search's (nblocks_coarse ..): the queries' PQ codes (Q::QuantizedT::process_vector, index.rs:193) on the CUs the
+    // 64-odd coarse blocks leave idle — one wave per (query, subspace); qcodes == nullptr: no such blocks
+    uint32_t nblocks_coarse;
+    const float* cb;          // codebook [m][256][subdim]
+    uint8_t* qcodes;          // [b][m]
+    uint32_t m;
+    DistPlan sp;              // plan of one subvector
 };
 
 // t_lo >= thr is NECESSARY for a centroid to be one of the P nearest of its query:
@@ -75,6 +82,16 @@ __global__ __launch_bounds__(CM_BLOCK) void ivf_coarse_mfma_kernel(CoarseArgs a)
     __shared__ uint4 bqs[NK * 64];   // the queries' fragments
     __shared__ float qnp[NK * 64];   // partial squared norms (chunk, lane)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    if (blockIdx.x >= a.nblocks_coarse) {   // ---- quantization blocks (they are dispatched behind the coarse blocks, onto the idle CUs)
+        const size_t task = (size_t)(blockIdx.x - a.nblocks_coarse) * CM_NW + (size_t)wave;
+        if (task >= (size_t)a.b * a.m) return;
+        const size_t qq = task / a.m;
+        const int s0 = (int)(task % a.m);
+        const int subdim = a.sp.d;
+        const uint32_t code = pq_quantize_wave(a.q + qq * a.qstride + (size_t)s0 * subdim, a.cb + (size_t)s0 * 256 * subdim, 256, subdim, a.sp, lane);
+        if (lane == 0) a.qcodes[task] = (uint8_t)code;
+        return;
+    }
     const uint32_t split = blockIdx.x % a.S, qg = blockIdx.x / a.S;
     const uint32_t qi = qg * 32 + (uint32_t)l31;
     const bool qvalid = qi < a.b;
@@ -674,16 +691,20 @@ static inline CoarseShape cm_shape(const CoarseMfma& cm, size_t b, size_t P, uin
     return s;
 }
 
+struct CoarseQuant { const float* cb = nullptr; uint8_t* qcodes = nullptr; uint32_t m = 0; DistPlan sp{}; };   // qcodes == nullptr: no quantization blocks
 static mdb_status cm_launch(mdb_ctx* ctx, const CoarseMfma& cm, const float* d_q, int qstride, size_t b, size_t P, const CoarseShape& sh,
-                            uint2* cand, uint32_t* cnt) {
+                            uint2* cand, uint32_t* cnt, const CoarseQuant& cq = CoarseQuant{}) {
     CoarseArgs a{cm.chi.p, cm.cneg.p, cm.mean.p, d_q, qstride, (uint32_t)b, cm.n, (uint32_t)cm.nt32, sh.S, sh.tps, sh.caps, cand, cnt, (int)P, cm.kappa, cm.xnmax, nullptr};
+    a.nblocks_coarse = (uint32_t)(((b + 31) / 32) * sh.S);
+    a.cb = cq.cb; a.qcodes = cq.qcodes; a.m = cq.m; a.sp = cq.sp;
+    const unsigned qblocks = cq.qcodes ? (unsigned)((b * (size_t)cq.m + CM_NW - 1) / CM_NW) : 0u;
     if (ctx->opt.cm_dbg) {
         void* dbg;
         MDB_TRY(mdb_scratch(ctx, 12, 256, &dbg));
         MDB_HIP(ctx, hipMemsetAsync(dbg, 0, 256, ctx->stream));
         a.dbg = (unsigned long long*)dbg;
     }
-    const dim3 grid((unsigned)(((b + 31) / 32) * sh.S));
+    const dim3 grid(a.nblocks_coarse + qblocks);
 #define MDB_CM_Q(NKT, JT, TWT) ivf_coarse_mfma_kernel<NKT, JT, TWT><<<grid, CM_BLOCK, 0, ctx->stream>>>(a)
 #define MDB_CM_T(NKT, JT) do { if (sh.TW == 2) MDB_CM_Q(NKT, JT, 2); else MDB_CM_Q(NKT, JT, 4); } while (0)
 #define MDB_CM_J(NKT) do { if (sh.J == 1) MDB_CM_T(NKT, 1); else if (sh.J == 2) MDB_CM_T(NKT, 2); else if (sh.J == 4) MDB_CM_T(NKT, 4); else MDB_CM_T(NKT, 8); } while (0)
