@@ -416,6 +416,9 @@ static mdb_status launch_flat_scan(mdb_ctx* ctx, const TileView& ts, const DistP
     return MDB_OK;
 }
 
+// INVARIANT (stage_queries' in-place rows): a query group never exceeds 4 rows, and a batch read in place is a multiple of 4 rows (or
+// one row), so no group of the exact scans reaches past row b - 1 of the caller's buffer.  A kernel that wants wider groups must take
+// staged rows (MDB_NO_INPLACE) or check its own row bound.
 static int flat_choose_qt(const mdb_ctx* ctx, size_t b, int k) {
     int qt = b >= 4 ? 4 : (b >= 2 ? 2 : 1);
     if (ctx->opt.flat_qt > 0) qt = std::max(1, std::min(qt, (int)ctx->opt.flat_qt));

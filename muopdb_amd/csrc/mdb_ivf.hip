@@ -1202,6 +1202,7 @@ __global__ __launch_bounds__(256) void ivf_prep_kernel(FusedArgs f, const float*
 #include "mdb_ivf_coarse.hip.h"
 
 // (block_kth_bound / kth_area_reset: mdb_device.hip.h — shared with the merge of many sorted partial lists, mdb_flat.hip)
+static_assert(PQF_QT <= 4, "ivf_prep_kernel's query groups read the caller's rows in place: at most 4 rows per group (stage_queries)");
 template <int SUBDIM, int MW, int COARSE>   // COARSE: 0 probes given, 1 the [B][L] distances of ivf_prep_kernel, 2 the candidates of ivf_coarse_mfma_kernel
 __global__ __launch_bounds__(PQF_BLOCK) void ivf_pq_fused_kernel(ScanArgs a, FusedArgs f, const uint32_t* __restrict__ codes,
                                                                  const float* __restrict__ cb, const float* __restrict__ sdc) {
