@@ -1224,6 +1224,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
             if (lane == 0) misc[2] = (uint32_t)(n < ef ? n : ef);
         }
         __syncthreads();
+#ifdef MDB_BEAM_BITONIC_TAIL
         const int n2 = 512;
         for (int size = 2; size <= n2; size <<= 1) {
             for (int st = size >> 1; st > 0; st >>= 1) {
@@ -1238,6 +1239,17 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_beam_kernel(HnswArgs a) {
             }
         }
         for (int i = tid; i < a.ef_cap; i += BLK) W[i] = C[i];
+#else
+        // every key's rank by counting (the keys are distinct: ids are unique in B; all lanes read the same word: LDS broadcasts), the
+        // ranks below ef_cap land in W — one barrier instead of the block bitonic's 45 barrier-separated stages over 512 slots
+        for (int i = tid; i < 64 * NB; i += BLK) {
+            const uint64_t key = C[i];
+            if (key == MDB_KEY_MAX) continue;
+            int rank = 0;
+            for (int jj = 0; jj < 64 * NB; ++jj) rank += C[jj] < key ? 1 : 0;
+            if (rank < a.ef_cap) W[rank] = key;
+        }
+#endif
         __syncthreads();
     }
     // the output fields are re-read from the kernarg segment behind an opaque barrier: kept in `a` they would stay
