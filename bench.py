@@ -709,8 +709,18 @@ def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=
     found = torch.cat(found).cpu().numpy()
     rec = recall_at_k(found[:nrec], gt, k) if gt is not None else None
     ex = exchange_times(env, step, steps, warm) if disperse else None
+    same = None
+    if by_batch:   # every rank holds the whole index: the gathered rows of the last timed batch against ONE unsharded call over that batch
+        i = warm + steps - 1
+        q = queries[i * batch:(i + 1) * batch]
+        ctx.check(ctx.lib.mdb_ivf_search(ivf.h, C.c_void_p(q.data_ptr()), C.c_size_t(batch), None, C.c_size_t(P), C.c_size_t(k),
+                                         C.c_int(L.MEM_DEVICE), C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(cn.data_ptr())))
+        step(i)                                  # this rank's slice -> its block, all-gather ...
+        g_ids, g_sc, g_cn, _ = rows.gather()     # ... and the rows in batch order once more (the same blocks)
+        same = bool(torch.equal(g_ids, ids) and torch.equal(g_sc.view(torch.int32), sc.view(torch.int32)) and torch.equal(g_cn, cn))
+        same = bool(env.max_over_ranks(0.0 if same else 1.0) == 0.0)
     return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes, recall=rec, disp=disp,
-                exchange=ex)
+                exchange=ex, rows_equal_unsharded=same)
 
 
 def build_ivfpq(env, x, nlist, seed=3):
@@ -768,6 +778,8 @@ def run_ivfpq(env, shard=None, no_sweep=False):
     out.update(hbm)
     if m["exchange"]:
         out["exchange"] = m["exchange"]
+    if m.get("rows_equal_unsharded") is not None:
+        out["rows_equal_unsharded"] = m["rows_equal_unsharded"]
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ivfpq", out["config"])
     if args.streams > 1 and world == 1:
         # Extra: the same batches round-robin on several HIP streams, each through its own handle ATTACHED to the one resident
@@ -918,6 +930,8 @@ def run_c5_sharded(env, steps=None, warm=None, shard=None):
     out.update(hbm)
     if m["exchange"]:
         out["exchange"] = m["exchange"]
+    if m.get("rows_equal_unsharded") is not None:
+        out["rows_equal_unsharded"] = m["rows_equal_unsharded"]
     out["steps"], out["warmup"] = steps, warm
     ivf.close()
     return out
@@ -1244,6 +1258,8 @@ def _compact_workload(w):
         out["scaling"] = "strong"
     if w.get("shard"):
         out["partitioning"] = w["shard"]     # lists | users | batch (prose: the full record's `partitioning`)
+    if w.get("rows_equal_unsharded") is not None:
+        out["rows_ok"] = w["rows_equal_unsharded"]
     ex = w.get("exchange")
     if ex:
         out["exchange_ms"] = _r(sum(v for k_, v in ex.items() if k_.endswith("_ms_per_step")), 4)
@@ -1272,7 +1288,7 @@ def compact_line(line):
     out["roofline"] = _compact_roofline(line.get("roofline"))
     out["cpu_baseline"] = _compact_cpu(line.get("cpu_baseline"))
     out["step_frac"] = _r(line.get("step_frac"), 4)
-    for k_ in ("rccl_ranks", "collective_backend", "shard"):
+    for k_ in ("rccl_ranks", "collective_backend", "shard", "rows_equal_unsharded"):
         if line.get(k_) is not None:
             out[k_] = line[k_]
     if line.get("exchange"):
