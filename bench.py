@@ -273,6 +273,14 @@ class Env:
                 shutil.rmtree(base, ignore_errors=True)
         self.kept_builds = {}
 
+    def same_on_all_ranks(self, arr):
+        """world > 1: every rank ends a sharded step with the SAME rows (each merges / permutes the same gathered blocks): a checksum of the
+        timed batches' doc ids must agree across the ranks (None on one rank)"""
+        if self.world == 1:
+            return None
+        chk = float(np.asarray(arr, np.int64).astype(np.float64).sum() % 1e15)
+        return bool(self.max_over_ranks(chk) == -self.max_over_ranks(-chk))
+
     def max_over_ranks(self, seconds):
         if self.world > 1:
             t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
@@ -709,6 +717,7 @@ def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=
     found = torch.cat(found).cpu().numpy()
     rec = recall_at_k(found[:nrec], gt, k) if gt is not None else None
     ex = exchange_times(env, step, steps, warm) if disperse else None
+    across = env.same_on_all_ranks(found)
     same = None
     if by_batch:   # every rank holds the whole index: the gathered rows of the last timed batch against ONE unsharded call over that batch
         i = warm + steps - 1
@@ -720,7 +729,7 @@ def ivfpq_measure(env, ivf, x, queries, batch, k, P, steps, warm, gt=None, nrec=
         same = bool(torch.equal(g_ids, ids) and torch.equal(g_sc.view(torch.int32), sc.view(torch.int32)) and torch.equal(g_cn, cn))
         same = bool(env.max_over_ranks(0.0 if same else 1.0) == 0.0)
     return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes, recall=rec, disp=disp,
-                exchange=ex, rows_equal_unsharded=same)
+                exchange=ex, rows_equal_unsharded=same, rows_equal_across_ranks=across)
 
 
 def build_ivfpq(env, x, nlist, seed=3):
@@ -780,6 +789,8 @@ def run_ivfpq(env, shard=None, no_sweep=False):
         out["exchange"] = m["exchange"]
     if m.get("rows_equal_unsharded") is not None:
         out["rows_equal_unsharded"] = m["rows_equal_unsharded"]
+    if m.get("rows_equal_across_ranks") is not None:
+        out["rows_equal_across_ranks"] = m["rows_equal_across_ranks"]
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ivfpq", out["config"])
     if args.streams > 1 and world == 1:
         # Extra: the same batches round-robin on several HIP streams, each through its own handle ATTACHED to the one resident
@@ -932,6 +943,8 @@ def run_c5_sharded(env, steps=None, warm=None, shard=None):
         out["exchange"] = m["exchange"]
     if m.get("rows_equal_unsharded") is not None:
         out["rows_equal_unsharded"] = m["rows_equal_unsharded"]
+    if m.get("rows_equal_across_ranks") is not None:
+        out["rows_equal_across_ranks"] = m["rows_equal_across_ranks"]
     out["steps"], out["warmup"] = steps, warm
     ivf.close()
     return out
@@ -1165,11 +1178,12 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None, shard=None
             evals += st["distance_evals"]; expanded += st["expanded_nodes"]
         hnsw_ms, hnsw_launches = ctx.get_profile(); ctx.set_profiling(False)
         found = torch.cat(found).cpu().numpy()
+        across = env.same_on_all_ranks(found)
         # a SPANN call's algorithmic bytes = the centroid graphs' traversal (evaluations x (4 d + 4) + expansions x 16: ANOTHER kernel,
         # hnsw_closure_kernel) + the posting-list scan (scored x bytes per scored vector): each kernel is priced with its own bytes
         graph_bytes = evals * (d * 4 + 4) + expanded * 16
         ex = exchange_times(env, step, steps, warm) if disperse else None
-        return dict(exchange=ex, elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes,
+        return dict(exchange=ex, rows_equal_across_ranks=across, elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, found=found, scored=scored, abytes=abytes,
                     scan_bytes=abytes - graph_bytes, graph_bytes=graph_bytes, evals=evals, disp=disp,
                     recall=recall_at_k(found, gts, k) if gts is not None else None, hnsw_ms=hnsw_ms / max(hnsw_launches, 1))
 
@@ -1191,6 +1205,8 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None, shard=None
     out.update(hbm)
     if m["exchange"]:
         out["exchange"] = m["exchange"]
+    if m.get("rows_equal_across_ranks") is not None:
+        out["rows_equal_across_ranks"] = m["rows_equal_across_ranks"]
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("spann_full" if U >= 1024 else "spann", out["config"])
     out["steps"], out["warmup"] = steps, warm
     if not (args.no_sweep or no_sweep):
@@ -1260,6 +1276,8 @@ def _compact_workload(w):
         out["partitioning"] = w["shard"]     # lists | users | batch (prose: the full record's `partitioning`)
     if w.get("rows_equal_unsharded") is not None:
         out["rows_ok"] = w["rows_equal_unsharded"]
+    if w.get("rows_equal_across_ranks") is not None:
+        out["ranks_agree"] = w["rows_equal_across_ranks"]
     ex = w.get("exchange")
     if ex:
         out["exchange_ms"] = _r(sum(v for k_, v in ex.items() if k_.endswith("_ms_per_step")), 4)
@@ -1288,7 +1306,7 @@ def compact_line(line):
     out["roofline"] = _compact_roofline(line.get("roofline"))
     out["cpu_baseline"] = _compact_cpu(line.get("cpu_baseline"))
     out["step_frac"] = _r(line.get("step_frac"), 4)
-    for k_ in ("rccl_ranks", "collective_backend", "shard", "rows_equal_unsharded"):
+    for k_ in ("rccl_ranks", "collective_backend", "shard", "rows_equal_unsharded", "rows_equal_across_ranks"):
         if line.get(k_) is not None:
             out[k_] = line[k_]
     if line.get("exchange"):

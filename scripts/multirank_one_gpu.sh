@@ -9,7 +9,7 @@ for a in "--workload spann --users 64 --shard users --no-sweep" "--workload span
 import sys,json
 l=sys.stdin.read().strip()
 try:
-    j=json.loads(l); print('$a'.split('--')[1:3], j['value'], j['ms_per_step'], j.get('shard'), j.get('rows_equal_unsharded'), j.get('exchange'), j.get('recall_at_10'))
+    j=json.loads(l); print('$a'.split('--')[1:3], j['value'], j['ms_per_step'], j.get('shard'), j.get('rows_equal_unsharded'), j.get('rows_equal_across_ranks'), j.get('exchange'), j.get('recall_at_10'))
 except Exception as e:
     print('FAILED', '$a', l[:300]); print(open('/tmp/mr.err').read()[-1500:])
 "
