@@ -70,6 +70,7 @@
     X(cm_dbg, "MDB_CM_DBG", 0)                         /* coarse matrix-core search: print the candidates per query (synchronises) */ \
     X(pq_no_fused, "MDB_PQ_NO_FUSED", 0)               /* small batches: the six-launch step instead of ivf_pq_fused_kernel */ \
     X(pqf_no_quant_in_coarse, "MDB_PQF_NO_QUANT_IN_COARSE", 0) /* fused step: the queries are quantized by the fused kernel itself, not by extra blocks of the coarse launch */ \
+    X(scan_no_fused_remap, "MDB_SCAN_NO_FUSED_REMAP", 0) /* SPANN device calls: merge of the scan's splits and remap as two launches */ \
     X(pqf_cap, "MDB_PQF_CAP", 2048)                    /* fused step: candidate slots (tests force the overflow pass) */      \
     X(pqf_quant_in_prep, "MDB_PQF_QUANT_IN_PREP", 0)   /* fused step: query codes in the prep kernel instead of the per-query one */ \
     X(pqf_dbg, "MDB_PQF_DBG", 0)                       /* fused step: print block 0's phase cycle counts (synchronises) */    \

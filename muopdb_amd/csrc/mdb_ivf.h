@@ -112,9 +112,17 @@ struct IvfSet {
     size_t coarse_bpad(size_t b) const { return cent_aux.sample.n ? (b + 255) / 256 * 256 : (b + 3) / 4 * 4; }
     mdb_status coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes,
                       bool zero_counters = false, size_t bpad = 0);  // zero_counters: its merge kernel also clears the context's device counters
+    // rm (device results wanted at once): when the scan's splits are merged by the sorted-rows kernel, that launch also remaps and
+    // re-ranks the winners (search_with_centroids_and_remap :298-332) and passes the found flags on — rm->done tells the caller that
+    // remap() is not needed any more
+    struct ScanRemap {
+        mdb_u128* doc_out = nullptr; float* score_out = nullptr; uint32_t* counts_out = nullptr;
+        const uint8_t* found_src = nullptr; uint8_t* found_dst = nullptr;
+        bool done = false;
+    };
     mdb_status scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
                     const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts,
-                    const ScanFilter* filter = nullptr);
+                    const ScanFilter* filter = nullptr, ScanRemap* rm = nullptr);
     mdb_status remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,
                      mdb_u128* d_doc, float* d_score, uint32_t* d_counts_out);
     // small batches of one L2 PQ index: the whole search in ONE launch (ivf_pq_fused_kernel).  d_probes == nullptr: the coarse

@@ -2183,9 +2183,96 @@ mdb_status IvfSet::stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t 
 
 // ------------------------------------------------------------------------------------------ IvfSet: search
 // d_q: staged queries [b][qstride]; probes: device [b][probe_stride]; outputs: device keys [b][k] + counts
+// merge_sorted_rows_kernel (mdb_flat.hip) + remap_kernel in ONE launch: the splits' ascending rows of a query -> its k smallest keys (ranks by
+// binary search; any unsorted row: by counting), then doc ids and the IdWithScore rank sort.  Two 5 us launches and a gap of a 130 us SPANN step.
+__global__ __launch_bounds__(256) void merge_rows_remap_kernel(const uint64_t* __restrict__ keys, int rows, int k, const IvfUserDev* __restrict__ users,
+                                                               const uint32_t* __restrict__ q_user, const uint8_t* __restrict__ index_bytes,
+                                                               uint64_t* __restrict__ keys_out, uint32_t* __restrict__ counts_mid,
+                                                               mdb_u128* __restrict__ doc_out, float* __restrict__ score_out,
+                                                               uint32_t* __restrict__ counts_out, const uint8_t* __restrict__ found_src,
+                                                               uint8_t* __restrict__ found_dst) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int per = rows * k, tid = threadIdx.x;
+    uint64_t* K = (uint64_t*)lds;          // [rows * k]
+    uint64_t* wk = K + per;                // [k] winners, ascending
+    uint64_t* lo = wk + k;                 // [k] doc id halves
+    uint64_t* hi = lo + k;
+    float* sc = (float*)(hi + k);          // [k]
+    __shared__ uint32_t unsorted, nvalid;
+    const size_t q = blockIdx.x;
+    const uint64_t* src = keys + q * per;
+    if (tid == 0) { unsorted = 0; nvalid = 0; }
+    for (int i = tid; i < per; i += 256) K[i] = src[i];
+    __syncthreads();
+    for (int i = tid; i + 1 < per; i += 256)
+        if ((i + 1) % k != 0 && K[i] > K[i + 1]) unsorted = 1;
+    __syncthreads();
+    const bool sorted = unsorted == 0;
+    for (int i = tid; i < per; i += 256) {
+        const uint64_t key = K[i];
+        const int row = i / k;
+        int rank;
+        if (sorted) {
+            rank = i - row * k;
+            for (int o = 0; o < rows; ++o) {
+                if (o == row) continue;
+                const uint64_t* R = K + o * k;
+                int l = 0, h = k;   // first index whose key is not before `key` (rows below this one win ties)
+                while (l < h) {
+                    const int mid = (l + h) >> 1;
+                    const bool before = o < row ? R[mid] <= key : R[mid] < key;
+                    if (before) l = mid + 1; else h = mid;
+                }
+                rank += l;
+            }
+        } else {
+            rank = 0;
+            for (int t = 0; t < per; ++t) rank += (K[t] < key || (K[t] == key && t < i)) ? 1 : 0;
+        }
+        if (rank < k) {
+            wk[rank] = key;
+            if (key != MDB_KEY_MAX) atomicAdd(&nvalid, 1u);
+            if (keys_out) keys_out[q * k + rank] = key;
+        }
+    }
+    __syncthreads();
+    const int c = (int)nvalid;   // (the padding keys sort last: the valid winners are wk[0 .. c))
+    const IvfUserDev u = users[q_user ? q_user[q] : 0];
+    for (int j = tid; j < c; j += 256) {
+        const uint64_t key = wk[j];
+        const uint64_t* dp = (const uint64_t*)(index_bytes + u.doc_ids_off + (size_t)key_id(key) * 16);
+        lo[j] = dp[0];
+        hi[j] = dp[1];
+        sc[j] = key_dist(key);
+    }
+    __syncthreads();
+    for (int j = tid; j < k; j += 256) {
+        if (j < c) {
+            int rank = 0;
+            const float s = sc[j];
+            const uint64_t l = lo[j], h = hi[j];
+            for (int i = 0; i < c; ++i) {
+                const float si = sc[i];
+                const bool less = si < s || (si == s && (hi[i] < h || (hi[i] == h && (lo[i] < l || (lo[i] == l && i < j)))));
+                rank += less ? 1 : 0;
+            }
+            doc_out[q * k + rank] = mdb_u128{l, h};
+            score_out[q * k + rank] = s;
+        } else {
+            doc_out[q * k + j] = mdb_u128{~0ull, ~0ull};
+            score_out[q * k + j] = __uint_as_float(0x7F800000u);
+        }
+    }
+    if (tid == 0) {
+        if (counts_mid) counts_mid[q] = (uint32_t)c;
+        if (counts_out) counts_out[q] = (uint32_t)c;
+        if (found_dst) found_dst[q] = found_src[q];
+    }
+}
+
 mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,
                         const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts,
-                        const ScanFilter* filter) {
+                        const ScanFilter* filter, ScanRemap* rm) {
     if (b == 0) return MDB_OK;
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     static const ScanFilter no_filter{};
@@ -2378,6 +2465,14 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
     }
     MDB_HIP(ctx, hipGetLastError());
     if (!direct) {   // the splits' rows are sorted: ranks by binary search when they fit LDS, the selector merge otherwise
+        const size_t mr_lds = (size_t)nsplit * k * 8 + k * 28 + 16;
+        if (rm && rm->doc_out && k > 0 && mr_lds <= 48 * 1024 && !ctx->opt.scan_no_fused_remap) {
+            merge_rows_remap_kernel<<<dim3((unsigned)b), 256, mr_lds, ctx->stream>>>((const uint64_t*)partial, nsplit, (int)k, d_users.p, d_q_user, d_index.p,
+                                                                                    d_keys, d_counts, rm->doc_out, rm->score_out, rm->counts_out,
+                                                                                    rm->found_src, rm->found_dst);
+            MDB_HIP(ctx, hipGetLastError());
+            rm->done = true;
+        } else
         if (k > 0 && (size_t)nsplit * k * 8 <= 48 * 1024) MDB_TRY(merge_sorted_rows(ctx, (const uint64_t*)partial, (size_t)nsplit, k, b, d_keys, d_counts, nullptr, nullptr));
         else MDB_TRY(merge_keys(ctx, (const uint64_t*)partial, (size_t)nsplit * k, b, k, d_keys, d_counts));
     }

@@ -130,7 +130,13 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
         ckeys, ccnt, (int)nexp, params->centroid_distance_ratio, s.hnsw.d_users.p, s.ivf.d_users.p, d_q_user,
         s.hnsw.d_index.p, probes, pcnt, dfound, b, ctx->d_flags);
     MDB_HIP(ctx, hipGetLastError());
-    MDB_TRY(s.ivf.scan(dq, qstride, b, d_q_user, probes, pcnt, (int)ne, k, keys, cnts, &filt));
+    // device results, no points block: the scan's merge launch remaps, re-ranks and passes the found flags on (IvfSet::ScanRemap)
+    IvfSet::ScanRemap srm;
+    if (!block_out && mem == MDB_MEM_DEVICE) {
+        srm.doc_out = doc_ids_out; srm.score_out = scores_out; srm.counts_out = counts_out;
+        if (found_out) { srm.found_src = dfound; srm.found_dst = found_out; }
+    }
+    MDB_TRY(s.ivf.scan(dq, qstride, b, d_q_user, probes, pcnt, (int)ne, k, keys, cnts, &filt, srm.doc_out ? &srm : nullptr));
     if (block_out) {
         if (mem == MDB_MEM_DEVICE) return s.ivf.pack_points(keys, cnts, dfound, b, k, block_out);
         MDB_TRY(s.ivf.pack_points(keys, cnts, dfound, b, k, base + o_blk));
@@ -138,6 +144,7 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
         return mdb_return_to_host(ctx, back, 1);
     }
     if (mem == MDB_MEM_DEVICE) {
+        if (srm.done) return MDB_OK;
         MDB_TRY(s.ivf.remap(keys, cnts, b, k, d_q_user, doc_ids_out, scores_out, counts_out));
         if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound, b, hipMemcpyDeviceToDevice, ctx->stream));
         return MDB_OK;  // asynchronous on the context's stream, like every MDB_MEM_DEVICE call
