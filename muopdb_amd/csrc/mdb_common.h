@@ -109,6 +109,8 @@ struct mdb_ctx {
                                                // builds); words 16..19 / 20..23: the fused IVF-PQ step alternates between them — each call's kernel clears the
                                                // OTHER set for the next call, so the step needs no memset launch
     int counter_base = 0;          // word offset of the last call's [0..3] (mdb_get_stats)
+    bool counters_clean = false;   // d_counters[0..3] are zero: the previous call's LAST kernel saved them to [24..27] and cleared them
+                                   // (SPANN device calls: no memset launch in front of the next one); every other user of [0..3] resets it
     int fused_parity = 0;
     unsigned long long* h_counters = nullptr;
     bool dev_counters = true;      // false: the last call used no device counters (flat scans): mdb_get_stats reports zeros, no memset launch

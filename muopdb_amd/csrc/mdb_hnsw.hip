@@ -1783,7 +1783,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     } while (0)
     // graphs no larger than ef (SPANN centroid graphs): frontier-parallel closure, see hnsw_closure_kernel
     if (max_n <= ef && max_n <= 4096 && !ctx->opt.hnsw_no_closure) {
-        if (zero_counters) MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, ctx->stream));
+        if (zero_counters) { ctx->counters_clean = false; MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, ctx->stream)); }
         int wcap = 64;
         while ((uint32_t)wcap < max_n) wcap <<= 1;
         // small batches: 64 groups per query (latency); large ones: 256-thread blocks, four resident per CU
@@ -1870,7 +1870,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
             fuse->done = true;
         }
     }
-    if (zero_counters) MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, ctx->stream));
+    if (zero_counters) { ctx->counters_clean = false; MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 128, ctx->stream)); }
     if (metric == MDB_METRIC_L2) {
         if (vis_lds) MDB_HNSW_LAUNCH(MDB_METRIC_L2, true); else MDB_HNSW_LAUNCH(MDB_METRIC_L2, false);
     } else {
@@ -2002,6 +2002,7 @@ static mdb_status hnsw_ann_search_impl(mdb_hnsw* h, const float* queries, size_t
     ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
     ctx->counter_base = 0;
+    ctx->counters_clean = false;
     // d*4 B vector + 4 B edge id per distance evaluation, 16 B offsets per expanded node
     ctx->stat_bytes_per_eval = (s.kind == MDB_QUANT_PQ ? (uint64_t)s.pq.m : (uint64_t)s.dimension * 4) + 4;
     ctx->stat_bytes_per_scored = 0; ctx->stat_fixed_bytes = 0;

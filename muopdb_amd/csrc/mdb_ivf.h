@@ -118,6 +118,7 @@ struct IvfSet {
     struct ScanRemap {
         mdb_u128* doc_out = nullptr; float* score_out = nullptr; uint32_t* counts_out = nullptr;
         const uint8_t* found_src = nullptr; uint8_t* found_dst = nullptr;
+        bool save_counters = false;   // the launch also moves the context's counters [0..3] to [24..27] and clears them
         bool done = false;
     };
     mdb_status scan(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, const uint32_t* d_probes,

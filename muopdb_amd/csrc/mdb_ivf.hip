@@ -2190,9 +2190,15 @@ __global__ __launch_bounds__(256) void merge_rows_remap_kernel(const uint64_t* _
                                                                uint64_t* __restrict__ keys_out, uint32_t* __restrict__ counts_mid,
                                                                mdb_u128* __restrict__ doc_out, float* __restrict__ score_out,
                                                                uint32_t* __restrict__ counts_out, const uint8_t* __restrict__ found_src,
-                                                               uint8_t* __restrict__ found_dst) {
+                                                               uint8_t* __restrict__ found_dst, unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int per = rows * k, tid = threadIdx.x;
+    // the step's last launch: its counters [0..3] move to [24..27] (what mdb_get_stats reads) and start the next call at zero — no memset
+    // launch in front of it (every kernel that adds to them has finished: stream order)
+    if (counters && blockIdx.x == 0 && tid < 4) {
+        counters[24 + tid] = counters[tid];
+        counters[tid] = 0ull;
+    }
     uint64_t* K = (uint64_t*)lds;          // [rows * k]
     uint64_t* wk = K + per;                // [k] winners, ascending
     uint64_t* lo = wk + k;                 // [k] doc id halves
@@ -2469,7 +2475,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         if (rm && rm->doc_out && k > 0 && mr_lds <= 48 * 1024 && !ctx->opt.scan_no_fused_remap) {
             merge_rows_remap_kernel<<<dim3((unsigned)b), 256, mr_lds, ctx->stream>>>((const uint64_t*)partial, nsplit, (int)k, d_users.p, d_q_user, d_index.p,
                                                                                     d_keys, d_counts, rm->doc_out, rm->score_out, rm->counts_out,
-                                                                                    rm->found_src, rm->found_dst);
+                                                                                    rm->found_src, rm->found_dst, rm->save_counters ? ctx->d_counters : nullptr);
             MDB_HIP(ctx, hipGetLastError());
             rm->done = true;
         } else
@@ -2770,6 +2776,7 @@ static mdb_status ivf_search_impl(mdb_ivf* ivf, const float* queries, size_t b, 
     ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
     ctx->counter_base = 0;
+    ctx->counters_clean = false;
     ctx->stat_bytes_per_eval = 0; ctx->stat_bytes_per_scored = s.bytes_per_scored(); ctx->stat_fixed_bytes = 0;
     size_t total = b * k;
     if (fused) {

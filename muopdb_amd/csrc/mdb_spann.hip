@@ -118,7 +118,9 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     uint64_t* keys = (uint64_t*)(base + o_keys);
     uint32_t* cnts = (uint32_t*)(base + o_cnts);
     uint8_t* dfound = (uint8_t*)(base + o_found);
-    MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    // (a device call whose merge launch saved and cleared the counters — ScanRemap::save_counters — leaves them clean for the next one)
+    if (!ctx->counters_clean) MDB_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    ctx->counters_clean = false;
     ctx->dev_counters = true;
     ctx->stats = mdb_stats{};
     ctx->counter_base = 0;
@@ -135,6 +137,7 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     if (!block_out && mem == MDB_MEM_DEVICE) {
         srm.doc_out = doc_ids_out; srm.score_out = scores_out; srm.counts_out = counts_out;
         if (found_out) { srm.found_src = dfound; srm.found_dst = found_out; }
+        srm.save_counters = true;
     }
     MDB_TRY(s.ivf.scan(dq, qstride, b, d_q_user, probes, pcnt, (int)ne, k, keys, cnts, &filt, srm.doc_out ? &srm : nullptr));
     if (block_out) {
@@ -144,7 +147,11 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
         return mdb_return_to_host(ctx, back, 1);
     }
     if (mem == MDB_MEM_DEVICE) {
-        if (srm.done) return MDB_OK;
+        if (srm.done) {
+            ctx->counters_clean = true;   // [0..3] were saved to [24..27] and cleared by the merge launch
+            ctx->counter_base = 24;
+            return MDB_OK;
+        }
         MDB_TRY(s.ivf.remap(keys, cnts, b, k, d_q_user, doc_ids_out, scores_out, counts_out));
         if (found_out) MDB_HIP(ctx, hipMemcpyAsync(found_out, dfound, b, hipMemcpyDeviceToDevice, ctx->stream));
         return MDB_OK;  // asynchronous on the context's stream, like every MDB_MEM_DEVICE call
