@@ -48,6 +48,7 @@
     X(mf_cooldown, "MDB_MF_COOLDOWN", 256)             /* calls served by the exact kernels after a candidate list overflowed */ \
     X(hnsw_no_dense, "MDB_HNSW_NO_DENSE", 0)           /* L */                                                      \
     X(hnsw_generic_dist, "MDB_HNSW_GENERIC_DIST", 0)                                                                \
+    X(closure_no_filter, "MDB_CLOSURE_NO_FILTER", 0)   /* SPANN: the ratio filter as a launch of its own (spann_filter_kernel) instead of hnsw_closure_kernel's tail */ \
     X(closure_no_stage, "MDB_CLOSURE_NO_STAGE", 0)     /* hnsw_closure_kernel: distances and rows fetched round by round instead of staged in LDS up front */ \
     X(hnsw_no_closure, "MDB_HNSW_NO_CLOSURE", 0)                                                                    \
     X(closure_block, "MDB_CLOSURE_BLOCK", 0)                                                                        \

@@ -21,6 +21,19 @@ struct HnswUserDev {
     uint64_t doc_ids_off;  // byte offset of doc id 0 inside the uploaded index bytes
 };
 
+// SPANN: the ratio filter of Spann::search (rs/index/src/spann/index.rs:229-246) applied by the centroid-graph launch itself, in the tail of
+// hnsw_closure_kernel (no launch of its own: 5 us + a gap of a 120 us step).  probes == nullptr: no filter.  done: set by HnswSet::search
+// when the closure kernel served the call (any other traversal kernel: the caller launches spann_filter_kernel).
+struct ClosureFilter {
+    uint32_t* probes = nullptr;           // [b][k] kept centroid (= posting list) ids, in candidate order
+    uint32_t* probe_cnt = nullptr;        // [b]
+    uint8_t* found = nullptr;             // [b] 0 = None (unknown user / empty centroid result)
+    const uint32_t* iusers = nullptr;     // the IVF side's IvfUserDev records read as words: [8 ui + 0] valid, [8 ui + 2] num_lists
+    const uint8_t* index_bytes = nullptr; // the graph file: a centroid's doc id is its posting-list index
+    float ratio = 0.0f;
+    bool done = false;
+};
+
 struct HnswBlobInfo {
     uint32_t quantized_dimension = 0, num_layers = 0;
     uint64_t edges_len = 0, points_len = 0, edge_offsets_len = 0, level_offsets_len = 0, doc_id_mapping_len = 0;
@@ -128,7 +141,7 @@ struct HnswSet {
     // ascending + counts.  d_q_user == nullptr => user 0.
     // zero_counters: clear ctx->d_counters[0..15] ahead of the traversal (callers that did not do it themselves)
     mdb_status search(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, size_t k, uint32_t ef,
-                      uint64_t* d_keys, uint32_t* d_counts, bool zero_counters = false, HnswRemapOut* fuse = nullptr);
+                      uint64_t* d_keys, uint32_t* d_counts, bool zero_counters = false, HnswRemapOut* fuse = nullptr, ClosureFilter* cf = nullptr);
     // keys -> (u128 doc id, score) rows in key order (ann_search :192-208 does not re-sort)
     mdb_status remap(const uint64_t* d_keys, const uint32_t* d_counts, size_t b, size_t k, const uint32_t* d_q_user,
                      mdb_u128* d_doc, float* d_score, uint32_t* d_counts_out);

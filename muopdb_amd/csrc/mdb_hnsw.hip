@@ -473,7 +473,7 @@ __global__ __launch_bounds__(HNSW_BLOCK) void hnsw_search_kernel(HnswArgs a) {
 // LDS atomics and one barrier.
 struct ClosureStage { uint32_t dtab_off, rows0_off, rowsU_off; };
 template <int METRIC, int N16T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wcap, ClosureStage st) {
+__global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wcap, ClosureStage st, ClosureFilter cf) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int qi = (int)blockIdx.x;
     uint64_t* W = (uint64_t*)lds;
@@ -492,9 +492,43 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
         if (tid == 0) {
             a.out_counts[qi] = 0;
             if (u.valid && u.n > (uint32_t)wcap) atomicOr(a.flags, MDB_FLAG_OVERFLOW);  // host dispatch guarantees n <= wcap
+            if (cf.probes) { cf.probe_cnt[qi] = 0; cf.found[qi] = 0; }   // None (spann/index.rs:229-231)
         }
         return;
     }
+    // the ratio filter over the query's sorted result row (spann_filter_kernel's arithmetic): wave 0, one lane per explored centroid
+    auto ratio_filter = [&](const uint64_t* row, int c) {
+        if (tid >= 64) return;
+        const uint32_t ui = a.q_user ? a.q_user[qi] : 0u;
+        const uint32_t ivalid = cf.iusers[8 * ui + 0];
+        if (!ivalid || c == 0) {
+            if (tid == 0) { cf.probe_cnt[qi] = 0; cf.found[qi] = 0; }
+            return;
+        }
+        const uint64_t num_lists = cf.iusers[8 * ui + 2];
+        const float nearest = key_dist(row[0]);
+        const float rhs = __fmul_rn(nearest, cf.ratio);
+        uint32_t nk = 0;
+        for (int i0 = 0; i0 < c; i0 += 64) {
+            const int i = i0 + tid;
+            bool keep = false;
+            uint64_t cid = 0;
+            if (i < c) {
+                const uint64_t key = row[i];
+                if (__fsub_rn(key_dist(key), nearest) <= rhs) {
+                    const uint64_t* dp = (const uint64_t*)(cf.index_bytes + u.doc_ids_off + (size_t)key_id(key) * 16);
+                    cid = dp[0];
+                    if (dp[1] != 0 || cid >= num_lists) atomicOr(a.flags, MDB_FLAG_RANGE);
+                    else keep = true;
+                }
+            }
+            const unsigned long long bal = __ballot(keep);
+            if (keep) cf.probes[(size_t)qi * a.k + nk + (uint32_t)__popcll(bal & ((1ull << tid) - 1ull))] = (uint32_t)cid;
+            nk += (uint32_t)__popcll(bal);
+        }
+        if (tid == 0) { cf.probe_cnt[qi] = nk; cf.found[qi] = 1; }
+    };
+    uint64_t* const srow = (uint64_t*)(W + wcap);   // the two frontier lists' words (free at the tail): the sorted result row for the filter
     for (int i = tid; i < a.dpad; i += BLOCK) qs[i] = a.q[(size_t)qi * a.qstride + i];
     for (uint32_t i = tid; i < (u.n + 31) / 32; i += BLOCK) vis[i] = 0;
     if (tid < 16) misc[tid] = 0;
@@ -620,7 +654,10 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
             const uint64_t key = W[i];
             int rank = 0;
             for (int jj = 0; jj < wn; ++jj) rank += W[jj] < key ? 1 : 0;
-            if (rank < a.k) a.out_keys[(size_t)qi * a.k + rank] = key;
+            if (rank < a.k) {
+                a.out_keys[(size_t)qi * a.k + rank] = key;
+                if (cf.probes && rank < wcap) srow[rank] = key;
+            }
         }
         for (int i = outc + tid; i < a.k; i += BLOCK) a.out_keys[(size_t)qi * a.k + i] = MDB_KEY_MAX;
         if (tid == 0) {
@@ -628,6 +665,10 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
             atomicAdd(&a.counters[0], (unsigned long long)misc[3]);
             atomicAdd(&a.counters[1], (unsigned long long)misc[4]);
             if (misc[5]) atomicOr(a.flags, MDB_FLAG_NAN);
+        }
+        if (cf.probes) {
+            __syncthreads();
+            ratio_filter(srow, outc < wcap ? outc : wcap);
         }
         return;
     }
@@ -655,6 +696,7 @@ __global__ __launch_bounds__(BLOCK) void hnsw_closure_kernel(HnswArgs a, int wca
         atomicAdd(&a.counters[1], (unsigned long long)misc[4]);
         if (misc[5]) atomicOr(a.flags, MDB_FLAG_NAN);
     }
+    if (cf.probes) ratio_filter(W, outc);   // (W is sorted and was synchronised by the last stage)
 }
 
 
@@ -1690,8 +1732,9 @@ mdb_status HnswSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, 
 
 // ------------------------------------------------------------------------------------------ search
 mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32_t* d_q_user, size_t k, uint32_t ef,
-                           uint64_t* d_keys, uint32_t* d_counts, bool zero_counters, HnswRemapOut* fuse) {
+                           uint64_t* d_keys, uint32_t* d_counts, bool zero_counters, HnswRemapOut* fuse, ClosureFilter* cf) {
     if (fuse) fuse->done = false;
+    if (cf) cf->done = false;
     if (b == 0) return MDB_OK;
     if (ef == 0) ef = 1;  // `len < ef` is never true and every push is followed by a pop: same as ef = 1
     if (ef > MDB_MAX_K * 2) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "ef=%u exceeds %d", ef, MDB_MAX_K * 2);
@@ -1791,6 +1834,8 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         size_t clds = (size_t)wcap * 16 + (size_t)dpad * 4 + 8 + 64 + (((size_t)max_n + 31) / 32 + 1) * 4;
         // staging (ClosureStage): every point's distance up front + the rows in LDS, while the block keeps its residency (one 1024-thread
         // block per CU: up to 120 KB; four 256-thread blocks per CU: 40 KB each)
+        ClosureFilter cfk;   // the SPANN ratio filter in the kernel's tail (k keys per query fit the frontier words: k <= wcap)
+        if (cf && cf->probes && !ctx->opt.closure_no_filter && k <= (size_t)wcap) { cfk = *cf; cf->done = true; }
         ClosureStage stg{0u, 0u, 0u};
         // (only the one-block-per-CU form: with four 256-thread blocks per CU the rounds of one block already hide behind the others',
         // and the up-front passes cost the full C4 batch of 1024 pairs + 4 %: 0.496 -> 0.517 ms)
@@ -1815,7 +1860,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
         if (clds > 48 * 1024)                                                                                               \
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_closure_kernel<METRIC, NF, CB>,                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));                       \
-        hnsw_closure_kernel<METRIC, NF, CB><<<dim3((unsigned)b), CB, clds, ctx->stream>>>(a, wcap, stg);                        \
+        hnsw_closure_kernel<METRIC, NF, CB><<<dim3((unsigned)b), CB, clds, ctx->stream>>>(a, wcap, stg, cfk);                        \
     } while (0)
 #define MDB_CLOSURE_LAUNCH_M(METRIC)                                 \
     do {                                                             \

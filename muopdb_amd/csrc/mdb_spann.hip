@@ -11,6 +11,7 @@
 // posting lists live in shared HBM arenas; a batch mixes users freely through a per-query user
 // index, so one launch per stage serves the whole batch (the reference opens one Spann per user
 // lazily and searches them one at a time).
+#include <cstddef>
 #include <dlfcn.h>
 
 #include <unordered_map>
@@ -127,10 +128,16 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     ctx->stat_bytes_per_eval = (uint64_t)s.hnsw.dimension * 4 + 4;
     ctx->stat_bytes_per_scored = s.ivf.bytes_per_scored();
     ctx->stat_fixed_bytes = 0;
-    MDB_TRY(s.hnsw.search(dq, qstride, b, d_q_user, nexp, params->ef_construction, ckeys, ccnt));
-    spann_filter_kernel<<<dim3((unsigned)((b + 3) / 4)), 256, 0, ctx->stream>>>(
-        ckeys, ccnt, (int)nexp, params->centroid_distance_ratio, s.hnsw.d_users.p, s.ivf.d_users.p, d_q_user,
-        s.hnsw.d_index.p, probes, pcnt, dfound, b, ctx->d_flags);
+    static_assert(sizeof(IvfUserDev) == 32 && offsetof(IvfUserDev, valid) == 0 && offsetof(IvfUserDev, num_lists) == 8,
+                  "ClosureFilter reads IvfUserDev records as words");
+    ClosureFilter cf;
+    cf.probes = probes; cf.probe_cnt = pcnt; cf.found = dfound; cf.iusers = (const uint32_t*)s.ivf.d_users.p; cf.index_bytes = s.hnsw.d_index.p;
+    cf.ratio = params->centroid_distance_ratio;
+    MDB_TRY(s.hnsw.search(dq, qstride, b, d_q_user, nexp, params->ef_construction, ckeys, ccnt, false, nullptr, &cf));
+    if (!cf.done)   // (graphs larger than ef go through the traversal kernels: the filter is a launch of its own)
+        spann_filter_kernel<<<dim3((unsigned)((b + 3) / 4)), 256, 0, ctx->stream>>>(
+            ckeys, ccnt, (int)nexp, params->centroid_distance_ratio, s.hnsw.d_users.p, s.ivf.d_users.p, d_q_user,
+            s.hnsw.d_index.p, probes, pcnt, dfound, b, ctx->d_flags);
     MDB_HIP(ctx, hipGetLastError());
     // device results, no points block: the scan's merge launch remaps, re-ranks and passes the found flags on (IvfSet::ScanRemap)
     IvfSet::ScanRemap srm;
