@@ -2297,7 +2297,10 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
         // the host: average tiles per list x probes (x 0.6 when a ratio filter trims the probe lists: SPANN).  Full C4 (1024 queries of
         // ~9 lists): 1 block per query 0.522 ms per step, 3: 0.493, 5: 0.488, 4 (= 3 + an empty block each): 0.521, 12: 0.595.
         const double tiles = (double)total_tiles / (double)std::max<size_t>(G, 1) * probe_stride;   // (a split beyond a query's tiles returns at once)
-        const int by_tiles = (int)std::min<double>(16.0, std::max(1.0, std::ceil(tiles / 4.0)));
+        // small batches (one or two resident blocks per CU at 219 registers): blocks of TWO waves, so that twice as many of a query's
+        // tiles stream at once (C4 at 128 users, same box: 4-wave blocks x 8 splits 0.1183 ms per step, 2-wave x 12 0.1123, x 16 0.1120)
+        const int wpb = (b <= 256 && !ctx->opt.scan_f32_blk) ? 2 : ((int)ctx->opt.scan_f32_blk == 64 ? 1 : ((int)ctx->opt.scan_f32_blk == 128 ? 2 : 4));
+        const int by_tiles = (int)std::min<double>(16.0, std::max(1.0, std::ceil(tiles / (double)wpb)));
         nsplit = std::min(std::max(nsplit, by_tiles), probe_stride);
         if (ctx->opt.scan_f32_nsplit > 0) nsplit = (int)std::min<long long>(ctx->opt.scan_f32_nsplit, probe_stride);
     }
@@ -2453,7 +2456,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
 #undef MDB_PQ_LAUNCH
     } else {
         DistPlan p = make_plan((int)num_features, metric);
-        const int fblk = (int)ctx->opt.scan_f32_blk == 64 ? 64 : ((int)ctx->opt.scan_f32_blk == 128 ? 128 : MDB_BLOCK);
+        const int fblk = (int)ctx->opt.scan_f32_blk == 64 ? 64 : (((int)ctx->opt.scan_f32_blk == 128 || (b <= 256 && !ctx->opt.scan_f32_blk)) ? 128 : MDB_BLOCK);
         const size_t fsel = fblk == 64 ? BlockSelect<64>::lds_bytes((int)k) : (fblk == 128 ? BlockSelect<128>::lds_bytes((int)k) : sel_lds);
         const size_t f32_lds = ((fsel + 15) & ~(size_t)15) + TileMap::lds_bytes();
 #define MDB_F32_LAUNCH(METRIC, BLKT)                                                                                              \
