@@ -61,6 +61,9 @@ static int run_segments(int argc, char** argv) {
         segs.push_back(std::make_unique<muopdb::MultiSpannIndex>(dev, users, dim, keep[o].data(), keep[o].size(), keep[o + 1].data(),
                                                                  keep[o + 1].size(), keep[o + 2].data(), keep[o + 2].size(),
                                                                  keep[o + 3].data(), keep[o + 3].size(), muopdb::Quantizer::none(dim)));
+        // a segment that carries a tombstone log is opened the way MultiSpannIndex::new opens it
+        if (std::filesystem::is_directory(sd + "/invalidated_ids_storage"))
+            std::printf("replayed %d %zu\n", s, segs.back()->open_invalidated_ids(sd + "/invalidated_ids_storage"));
     }
     muopdb::PendingSegment pending({segs[0].get()});
     {

@@ -354,6 +354,17 @@ mdb_status mdb_multi_spann_search_submit(mdb_multi_spann* ms, const mdb_u128* us
                                          uint8_t* found_out);
 mdb_status mdb_multi_spann_invalidate(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,
                                       uint8_t* flags_out);
+/* MultiSpannIndex::is_invalidated (multi_spann/index.rs:229-232); an unknown user is the reference's Err("User not found"):
+ * MDB_ERR_INVALID_ARG */
+mdb_status mdb_multi_spann_is_invalidated(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,
+                                          uint8_t* flags_out);
+/* The persisted tombstones of a segment, applied at open: MultiSpannIndex::new reads `invalidated_ids_storage/` into
+ * pending_invalidations (multi_spann/index.rs:51-77) and get_or_create_index tombstones a user's index from it on first open
+ * (:121-124).  records = what InvalidatedIdsStorage::iter yields (rs/index/src/ivf/files/invalidated_ids.rs:183-256): the files
+ * `invalidated_ids.bin.0 .. n-1` concatenated, 32 bytes per record = u128 LE user id, u128 LE doc id.  Call once after
+ * mdb_multi_spann_load (every user is resident from the load on).  Records of users the handle does not hold and doc ids a user
+ * does not hold are skipped, a pair logged twice counts once; *n_applied_out (may be NULL) = newly tombstoned documents. */
+mdb_status mdb_multi_spann_replay_invalidations(mdb_multi_spann* ms, const void* records, size_t n_records, size_t* n_applied_out);
 
 /* ---------------------------------------------------------------- list-sharded search, EXACT
  * One index (or multi-user collection) whose posting lists are dealt over `world` GPUs (shard_rank / shard_world at load);

@@ -19,6 +19,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
 #include <functional>
 #include <map>
 #include <memory>
@@ -286,6 +289,92 @@ class Spann {
     mdb_spann* h_ = nullptr;
 };
 
+// InvalidatedIdsStorage (rs/index/src/ivf/files/invalidated_ids.rs:9-215): the segment's append log of (user id, doc id)
+// tombstones — files `invalidated_ids.bin.<i>` of 32-byte little-endian records, each file but the last `backing_file_size`
+// bytes (rounded down to whole records).  read() = ::read :45-106; records() = what ::iter yields :183-256;
+// invalidate / invalidate_batch = :120-181.
+class InvalidatedIdsStorage {
+  public:
+    static constexpr size_t kBytesPerInvalidation = 32, kDefaultBackingFileSize = 8192;
+    explicit InvalidatedIdsStorage(std::string base_directory, size_t backing_file_size = kDefaultBackingFileSize)
+        : dir_(std::move(base_directory)), backing_(backing_file_size / kBytesPerInvalidation * kBytesPerInvalidation),
+          offset_(backing_) {}
+    static InvalidatedIdsStorage read(const std::string& base_directory) {
+        namespace fs = std::filesystem;
+        if (!fs::is_directory(base_directory)) {
+            fs::create_directories(base_directory);
+            return InvalidatedIdsStorage(base_directory);
+        }
+        std::vector<std::string> names;
+        for (auto& e : fs::directory_iterator(base_directory)) {
+            const std::string n = e.path().filename().string();
+            if (n.rfind("invalidated_ids.bin.", 0) == 0) names.push_back(n);
+        }
+        if (names.empty()) return InvalidatedIdsStorage(base_directory);
+        std::sort(names.begin(), names.end());
+        std::stable_sort(names.begin(), names.end(), [](const std::string& a, const std::string& b) { return suffix(a) < suffix(b); });
+        auto size = [&](const std::string& n) { return (size_t)fs::file_size(fs::path(base_directory) / n); };
+        const size_t first = size(names.front());
+        InvalidatedIdsStorage st(base_directory, names.size() == 1 ? std::max(kDefaultBackingFileSize, first) : first);
+        st.num_files_ = names.size();
+        st.current_id_ = (long)names.size() - 1;
+        st.offset_ = size(names.back());
+        return st;
+    }
+    void invalidate(u128 user_id, u128 doc_id) { invalidate_batch({{user_id, doc_id}}); }
+    void invalidate_batch(const std::vector<std::pair<u128, u128>>& pairs) {
+        std::vector<char> buf;
+        auto flush = [&]() {
+            if (buf.empty()) return;
+            std::ofstream f(path(current_id_), std::ios::binary | std::ios::app);
+            f.write(buf.data(), (std::streamsize)buf.size());
+            if (!f) throw std::runtime_error("cannot append to " + path(current_id_));
+            buf.clear();
+        };
+        for (auto& pr : pairs) {
+            if (offset_ == backing_) {
+                flush();
+                ++current_id_;
+                std::ofstream(path(current_id_), std::ios::binary | std::ios::app);
+                ++num_files_;
+                offset_ = 0;
+            }
+            const u128 v[2] = {pr.first, pr.second};      // little-endian host: the in-memory u128 IS its LE image
+            buf.insert(buf.end(), reinterpret_cast<const char*>(v), reinterpret_cast<const char*>(v) + kBytesPerInvalidation);
+            offset_ += kBytesPerInvalidation;
+        }
+        flush();
+    }
+    // files 0 .. num_files-1 BY INDEX (a missing one is skipped), concatenated; a file ending inside a record is the
+    // iterator's panic
+    std::vector<uint8_t> records() const {
+        std::vector<uint8_t> out;
+        for (size_t i = 0; i < num_files_; ++i) {
+            std::ifstream f(path((long)i), std::ios::binary);
+            if (!f) continue;
+            std::vector<char> data((std::istreambuf_iterator<char>(f)), {});
+            if (data.size() % kBytesPerInvalidation) throw std::runtime_error("Incomplete invalidation record at end of file");
+            out.insert(out.end(), data.begin(), data.end());
+        }
+        return out;
+    }
+    size_t num_entries() const { return current_id_ < 0 ? 0 : (offset_ + (size_t)current_id_ * backing_) / kBytesPerInvalidation; }
+    size_t backing_file_size() const { return backing_; }
+
+  private:
+    static unsigned long suffix(const std::string& n) {   // text behind the last dot parsed as u32, else 0
+        std::string t = n.substr(n.rfind('.') + 1);
+        if (!t.empty() && t[0] == '+') t.erase(0, 1);
+        if (t.empty() || t.size() > 10 || !std::all_of(t.begin(), t.end(), [](char c) { return c >= '0' && c <= '9'; })) return 0;
+        const unsigned long long v = std::stoull(t);
+        return v < (1ull << 32) ? (unsigned long)v : 0;
+    }
+    std::string path(long i) const { return dir_ + "/invalidated_ids.bin." + std::to_string(i); }
+    std::string dir_;
+    size_t backing_, offset_, num_files_ = 0;
+    long current_id_ = -1;
+};
+
 class MultiSpannIndex {
   public:
     MultiSpannIndex(Device& dev, const std::vector<mdb_user_index_info>& users, uint32_t num_features, const void* hnsw_index,
@@ -331,16 +420,34 @@ class MultiSpannIndex {
         auto rows = planner ? search_for_user({user_id}, query, p, *planner) : search_for_user({user_id}, query, p);
         return std::move(rows[0]);
     }
+    // MultiSpannIndex::invalidate :166-180: an effective invalidation is appended to the attached tombstone log
     bool invalidate(u128 user_id, u128 doc_id) {
         mdb_u128 u = detail::split(user_id), d = detail::split(doc_id);
         uint8_t f = 0;
         dev_.check(mdb_multi_spann_invalidate(h_, &u, &d, 1, &f));
+        if (f && log_) log_->invalidate(user_id, doc_id);
         return f != 0;
+    }
+    bool is_invalidated(u128 user_id, u128 doc_id) {
+        mdb_u128 u = detail::split(user_id), d = detail::split(doc_id);
+        uint8_t f = 0;
+        dev_.check(mdb_multi_spann_is_invalidated(h_, &u, &d, 1, &f));
+        return f != 0;
+    }
+    // MultiSpannIndex::new :51-77 + get_or_create_index :121-124: read the segment's `invalidated_ids_storage/`, tombstone
+    // the resident users from it, keep the log for later invalidate calls.  Returns the documents newly tombstoned.
+    size_t open_invalidated_ids(const std::string& directory) {
+        log_ = std::make_unique<InvalidatedIdsStorage>(InvalidatedIdsStorage::read(directory));
+        const std::vector<uint8_t> rec = log_->records();
+        size_t applied = 0;
+        dev_.check(mdb_multi_spann_replay_invalidations(h_, rec.data(), rec.size() / InvalidatedIdsStorage::kBytesPerInvalidation, &applied));
+        return applied;
     }
 
   private:
     Device& dev_;
     mdb_multi_spann* h_ = nullptr;
+    std::unique_ptr<InvalidatedIdsStorage> log_;
 };
 
 // ---- the callers of the path: segment fan-out (host logic over GPU-resident segments)

@@ -2113,7 +2113,9 @@ mdb_status IvfSet::invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint
     if (ui >= blobs.size()) { for (size_t i = 0; i < n; ++i) flags_out[i] = 0; return MDB_OK; }
     std::lock_guard<std::mutex> tg(r.tomb_mu);
     if (r.doc_maps[ui].empty() && r.blobs[ui].num_vectors) MDB_TRY(r.build_doc_map(ui, ctx));   // the root's ctx is never touched: its searches run meanwhile
-    bool dirty = false;
+    // a batch (the tombstone log replayed at open: thousands of records of one user) uploads the span of words it touched
+    // once; words in between are rewritten with the values they have
+    size_t wlo = SIZE_MAX, whi = 0;
     for (size_t i = 0; i < n; ++i) {
         auto it = r.doc_maps[ui].find(U128Key{doc_ids[i].lo, doc_ids[i].hi});
         if (it == r.doc_maps[ui].end()) { flags_out[i] = 0; continue; }
@@ -2126,11 +2128,14 @@ mdb_status IvfSet::invalidate(size_t ui, const mdb_u128* doc_ids, size_t n, uint
         if (!was) {
             r.h_tomb[w] |= bit;
             r.tomb_any.store(1u);
-            MDB_HIP(ctx, hipMemcpyAsync(d_tomb.p + w, &r.h_tomb[w], 4, hipMemcpyHostToDevice, ctx->stream));
-            dirty = true;
+            wlo = std::min(wlo, w);
+            whi = std::max(whi, w);
         }
     }
-    if (dirty) MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (wlo != SIZE_MAX) {
+        MDB_HIP(ctx, hipMemcpyAsync(d_tomb.p + wlo, &r.h_tomb[wlo], (whi - wlo + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        MDB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return MDB_OK;
 }
 

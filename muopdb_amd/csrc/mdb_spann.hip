@@ -630,4 +630,42 @@ mdb_status mdb_multi_spann_invalidate(mdb_multi_spann* ms, const mdb_u128* user_
     return ms->set.ivf.invalidate(it->second, doc_ids, n, flags_out, false);
 }
 
+mdb_status mdb_multi_spann_is_invalidated(mdb_multi_spann* ms, const mdb_u128* user_id, const mdb_u128* doc_ids, size_t n,
+                                          uint8_t* flags_out) {
+    if (!ms || !user_id || (!doc_ids && n) || !flags_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ms->set.ctx->mu);
+    MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
+    auto it = ms->set.user_index.find(U128Key{user_id->lo, user_id->hi});
+    if (it == ms->set.user_index.end()) return mdb_fail(ms->set.ctx, MDB_ERR_INVALID_ARG, "User not found");
+    return ms->set.ivf.invalidate(it->second, doc_ids, n, flags_out, true);
+}
+
+// MultiSpannIndex::new (multi_spann/index.rs:51-77) collects the log into pending_invalidations: user -> SET of doc ids;
+// get_or_create_index (:121-124) hands a user's set to Spann::invalidate_batch when the user's index is opened.  Every user
+// of the handle is open, so the whole log is applied here; records of users this handle does not hold (another rank's users
+// under by-user sharding, users of a table the log outlived) stay pending for ever in the reference too.
+mdb_status mdb_multi_spann_replay_invalidations(mdb_multi_spann* ms, const void* records, size_t n_records, size_t* n_applied_out) {
+    if (!ms || (!records && n_records)) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ms->set.ctx->mu);
+    MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
+    const uint8_t* rec = (const uint8_t*)records;
+    std::unordered_map<uint32_t, std::vector<mdb_u128>> per_user;     // user slot -> its doc ids in log order
+    for (size_t i = 0; i < n_records; ++i) {
+        uint64_t w[4];
+        memcpy(w, rec + i * 32, 32);                                  // u128 LE user id, u128 LE doc id (invalidated_ids.rs:131-132)
+        auto it = ms->set.user_index.find(U128Key{w[0], w[1]});
+        if (it == ms->set.user_index.end()) continue;
+        per_user[it->second].push_back(mdb_u128{w[2], w[3]});
+    }
+    size_t applied = 0;
+    std::vector<uint8_t> flags;
+    for (auto& kv : per_user) {
+        flags.assign(kv.second.size(), 0);
+        MDB_TRY(ms->set.ivf.invalidate(kv.first, kv.second.data(), kv.second.size(), flags.data(), false));
+        for (uint8_t f : flags) applied += f;                         // a doc id logged twice / already dead counts once
+    }
+    if (n_applied_out) *n_applied_out = applied;
+    return MDB_OK;
+}
+
 }  // extern "C"

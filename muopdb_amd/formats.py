@@ -456,14 +456,127 @@ def user_table_from_odht(raw):
     return b"".join(vals)
 
 
+# --------------------------------------------------------------------------- tombstone log (delete path, read at open)
+BYTES_PER_INVALIDATION = 32
+
+
+class InvalidatedIdsStorage:
+    """rs/index/src/ivf/files/invalidated_ids.rs:9-215 — the append log of (user id, doc id) tombstones a segment keeps
+    under `invalidated_ids_storage/`: files `invalidated_ids.bin.<i>` of 32-byte records (u128 LE user id, u128 LE doc id),
+    every file but the last `backing_file_size` bytes long (rounded DOWN to whole records, :33-35).  MultiSpannIndex::new
+    reads it into `pending_invalidations` and every user's index is tombstoned from there when it is first opened
+    (multi_spann/index.rs:51-77, 121-124); here all users are resident from the load on, so the open applies the whole log
+    (MultiSpannIndex.open_segment -> mdb_multi_spann_replay_invalidations)."""
+
+    DEFAULT_BACKING_FILE_SIZE = 8192
+
+    def __init__(self, base_directory, backing_file_size=DEFAULT_BACKING_FILE_SIZE):
+        """InvalidatedIdsStorage::new :32-43 (no file is created before the first record)."""
+        self.base_directory = base_directory
+        self.backing_file_size = backing_file_size // BYTES_PER_INVALIDATION * BYTES_PER_INVALIDATION
+        self.num_files = 0
+        self.current_backing_id = -1
+        self.current_offset = self.backing_file_size
+
+    @staticmethod
+    def _suffix(name):
+        """the sort key of :73-79: the text behind the last dot parsed as u32, 0 when it does not parse"""
+        tail = name.rsplit(".", 1)[1] if "." in name else ""
+        if tail[:1] == "+":                       # u32::from_str accepts one leading '+'
+            tail = tail[1:]
+        if tail.isascii() and tail.isdigit() and int(tail) < (1 << 32):
+            return int(tail)
+        return 0
+
+    @classmethod
+    def read(cls, base_directory):
+        """InvalidatedIdsStorage::read :45-106: a missing directory is created; the files are ordered by numeric suffix
+        (a stable sort over the directory listing — sorted by name here so that the result does not depend on the file
+        system's order); one file => backing size max(8192, its size), several => the first file's size."""
+        import os
+        if not os.path.isdir(base_directory):
+            os.makedirs(base_directory, exist_ok=True)
+            return cls(base_directory)
+        names = sorted(n for n in os.listdir(base_directory) if n.startswith("invalidated_ids.bin."))
+        if not names:
+            return cls(base_directory)
+        names.sort(key=cls._suffix)
+        size = lambda n: os.path.getsize(os.path.join(base_directory, n))
+        first = size(names[0])
+        st = cls(base_directory, max(cls.DEFAULT_BACKING_FILE_SIZE, first) if len(names) == 1 else first)
+        st.num_files = len(names)
+        st.current_backing_id = len(names) - 1
+        st.current_offset = size(names[-1])
+        return st
+
+    def _path(self, i):
+        import os
+        return os.path.join(self.base_directory, "invalidated_ids.bin.%d" % i)
+
+    def _new_backing_file(self):
+        self.current_backing_id += 1
+        open(self._path(self.current_backing_id), "ab").close()
+        self.num_files += 1
+        self.current_offset = 0
+
+    def invalidate(self, user_id, doc_id):
+        """:120-143"""
+        self.invalidate_batch([(user_id, doc_id)])
+
+    def invalidate_batch(self, pairs):
+        """:147-181: records fill the current file to exactly backing_file_size, then the next file is opened."""
+        buf = bytearray()
+        def flush():
+            if buf:
+                with open(self._path(self.current_backing_id), "ab") as f:
+                    f.write(buf)
+                buf.clear()
+        for user_id, doc_id in pairs:
+            if self.current_offset == self.backing_file_size:
+                flush()
+                self._new_backing_file()
+            buf += u128_bytes(int(user_id)) + u128_bytes(int(doc_id))
+            self.current_offset += BYTES_PER_INVALIDATION
+        flush()
+
+    def record_bytes(self):
+        """What InvalidatedIdsIterator yields (:183-196, 217-256), as one byte string of 32-byte records: files
+        `invalidated_ids.bin.0 .. num_files-1` BY INDEX (a missing one is skipped, `.ok()`), each read to its end; a file
+        that ends inside a record is the iterator's panic ("Incomplete invalidation record at end of file")."""
+        import os
+        out = bytearray()
+        for i in range(self.num_files):
+            if not os.path.isfile(self._path(i)):
+                continue
+            with open(self._path(i), "rb") as f:
+                data = f.read()
+            if len(data) % BYTES_PER_INVALIDATION:
+                raise ValueError("Incomplete invalidation record at end of file %s" % self._path(i))
+            out += data
+        return bytes(out)
+
+    def __iter__(self):
+        raw = self.record_bytes()
+        for o in range(0, len(raw), BYTES_PER_INVALIDATION):
+            yield (int.from_bytes(raw[o:o + 16], "little"), int.from_bytes(raw[o + 16:o + 32], "little"))
+
+    def num_entries(self):
+        """:202-210"""
+        if self.current_backing_id == -1:
+            return 0
+        return (self.current_offset + self.current_backing_id * self.backing_file_size) // BYTES_PER_INVALIDATION
+
+
 # --------------------------------------------------------------------------- segment directory (SURVEY.md Appendix A)
-def write_segment(directory, cat, num_features, pq=None, reassigned=None):
+def write_segment(directory, cat, num_features, pq=None, reassigned=None, invalidated=None, backing_file_size=None):
     """One (multi-user) SPANN segment as the reference lays it out on disk (multi_spann/writer.rs:82-298; SURVEY.md
     Appendix A) from concat_multi_spann's result: the reference's readers (MultiSpannReader::read, multi_spann/reader.rs:35)
     open this tree.  pq = (dimension, subvector_dimension, num_bits) when the posting lists hold PQ codes (cat["codebook"]).
     reassigned = {user_id: u32 [n] old -> new point id} for users whose IVF was reindexed (muopdb_amd.build.reindex): written as
     `reassigned_mappings.<user_id>`, 4 little-endian bytes per vector (ivf/writer.rs:52-66, moved to the top level by
-    multi_spann/writer.rs:264-273).  bloom_filter/ and invalidated_ids_storage/ (delete path) are created empty."""
+    multi_spann/writer.rs:264-273).  invalidated = [(user_id, doc_id)] already deleted from the segment: appended to the
+    tombstone log `invalidated_ids_storage/` (InvalidatedIdsStorage, files of `backing_file_size` bytes — 8192 by default) which
+    the open replays; without it the directory is created empty, as is bloom_filter/ (delete path only)."""
     import os
     def put(rel, data):
         path = os.path.join(directory, rel)
@@ -486,11 +599,16 @@ def write_segment(directory, cat, num_features, pq=None, reassigned=None):
         put("reassigned_mappings.%d" % int(user_id), np.ascontiguousarray(mapping, dtype="<u4").tobytes())
     for sub in ("bloom_filter", "invalidated_ids_storage"):
         os.makedirs(os.path.join(directory, sub), exist_ok=True)
+    if invalidated:
+        log = InvalidatedIdsStorage(os.path.join(directory, "invalidated_ids_storage"),
+                                    backing_file_size or InvalidatedIdsStorage.DEFAULT_BACKING_FILE_SIZE)
+        log.invalidate_batch(invalidated)
 
 
 def read_segment(directory):
     """The files of a segment directory as write_segment / the reference's MultiSpannWriter leave them:
-    dict(user_table (flat records), hnsw_index, hnsw_vectors, ivf_index, ivf_vectors, num_features, pq, codebook)."""
+    dict(user_table (flat records), hnsw_index, hnsw_vectors, ivf_index, ivf_vectors, num_features, pq, codebook, reassigned,
+    invalidated = [(user_id, doc_id)] of the tombstone log in replay order)."""
     import os
     def get(rel):
         with open(os.path.join(directory, rel), "rb") as f:
@@ -506,4 +624,5 @@ def read_segment(directory):
         out["codebook"] = np.frombuffer(get("ivf/quantizer/codebook"), np.float32)
     out["reassigned"] = {int(name.split(".", 1)[1]): np.frombuffer(get(name), "<u4")
                          for name in os.listdir(directory) if name.startswith("reassigned_mappings.")}
+    out["invalidated"] = list(InvalidatedIdsStorage.read(os.path.join(directory, "invalidated_ids_storage")))
     return out

@@ -634,12 +634,17 @@ class MultiSpannIndex:
                                                C.byref(q), C.c_uint32(shard_rank), C.c_uint32(shard_world),
                                                C.byref(h)))
         self.h = h
+        self.invalidated_ids_storage = None
 
     @classmethod
-    def open_segment(cls, ctx, directory, shard_rank=0, shard_world=1):
-        """MultiSpannReader::read (rs/index/src/multi_spann/reader.rs:35): open a segment DIRECTORY as the reference
-        writes it — `user_index_info` is the odht table, parsed by the library
-        (mdb_odht_user_table); the five data files are mapped and handed to mdb_multi_spann_load."""
+    def open_segment(cls, ctx, directory, shard_rank=0, shard_world=1, user_slots=None):
+        """MultiSpannReader::read (rs/index/src/multi_spann/reader.rs:35) + MultiSpannIndex::new (multi_spann/index.rs:44-79):
+        open a segment DIRECTORY as the reference writes it — `user_index_info` is the odht table, parsed
+        by the library (mdb_odht_user_table); the five data files are mapped and handed to mdb_multi_spann_load; the tombstone
+        log under `invalidated_ids_storage/` is read (InvalidatedIdsStorage::read) and applied to the resident users
+        (mdb_multi_spann_replay_invalidations: what get_or_create_index :121-124 does per user on first open), and later
+        `invalidate` calls append to it as the reference's do.  user_slots: keep only these records of the (id-sorted) user
+        table — by-user sharding; the log's records of the other users are skipped by the replay."""
         import mmap
         import os
         from . import formats as F
@@ -655,6 +660,8 @@ class MultiSpannIndex:
         users = (L.UserIndexInfoC * max(n.value, 1))()
         ctx.check(ctx.lib.mdb_odht_user_table(L.ptr(raw, C.c_uint8), C.c_size_t(raw.size), users, C.c_size_t(n.value), C.byref(n)))
         table = C.string_at(users, n.value * 112)
+        if user_slots is not None:
+            table = b"".join(table[int(u) * 112:(int(u) + 1) * 112] for u in user_slots)
         with open(os.path.join(directory, "centroids/quantizer/no_op_quantizer_config.yaml")) as f:
             d = F.parse_simple_yaml(f.read())["dimension"]
         quant = None
@@ -664,8 +671,22 @@ class MultiSpannIndex:
                 y = F.parse_simple_yaml(f.read())
             quant = ProductQuantizer(y["dimension"], y["subvector_dimension"], y["num_bits"],
                                      np.frombuffer(mapped("ivf/quantizer/codebook").tobytes(), np.float32))
-        return cls(ctx, table, d, mapped("centroids/hnsw/index"), mapped("centroids/hnsw/vector_storage"), mapped("ivf/index"),
-                   mapped("ivf/vectors"), quant, shard_rank, shard_world)
+        ms = cls(ctx, table, d, mapped("centroids/hnsw/index"), mapped("centroids/hnsw/vector_storage"), mapped("ivf/index"),
+                 mapped("ivf/vectors"), quant, shard_rank, shard_world)
+        ms.invalidated_ids_storage = F.InvalidatedIdsStorage.read(os.path.join(directory, "invalidated_ids_storage"))
+        ms.replayed_invalidations = ms.replay_invalidations(ms.invalidated_ids_storage.record_bytes())
+        return ms
+
+    def replay_invalidations(self, records):
+        """pending_invalidations applied (multi_spann/index.rs:64-77, 121-124): records = 32-byte (user id, doc id) pairs in
+        log order; returns the number of documents newly tombstoned."""
+        rec = L.u8buf(records)
+        if rec.size % 32:
+            raise ValueError("Incomplete invalidation record at end of file")
+        n = C.c_size_t()
+        self.ctx.check(self.ctx.lib.mdb_multi_spann_replay_invalidations(self.h, L.ptr(rec, C.c_uint8) if rec.size else None,
+                                                                         C.c_size_t(rec.size // 32), C.byref(n)))
+        return n.value
 
     def close(self):
         if getattr(self, "h", None):
@@ -746,9 +767,34 @@ class MultiSpannIndex:
         return rows[:params.top_k]
 
     def invalidate(self, user_id, doc_id):
+        """MultiSpannIndex::invalidate :166-180: an EFFECTIVE invalidation is appended to the segment's tombstone log (a handle
+        opened from a directory has one), so that the next open replays it."""
         flags = np.zeros(1, np.uint8)
         self.ctx.check(self.ctx.lib.mdb_multi_spann_invalidate(self.h, L.u128_array([user_id]), L.u128_array([doc_id]),
                                                                C.c_size_t(1), L.ptr(flags, C.c_uint8)))
+        if flags[0] and getattr(self, "invalidated_ids_storage", None) is not None:
+            self.invalidated_ids_storage.invalidate(user_id, doc_id)
+        return bool(flags[0])
+
+    def invalidate_batch(self, user_to_doc_ids):
+        """MultiSpannIndex::invalidate_batch :189-223: {user id: [doc ids]} -> number effectively invalidated; the effective
+        pairs go to the log in one batch."""
+        pairs = []
+        for user_id, doc_ids in user_to_doc_ids.items():
+            doc_ids = list(doc_ids)
+            flags = np.zeros(max(len(doc_ids), 1), np.uint8)
+            self.ctx.check(self.ctx.lib.mdb_multi_spann_invalidate(self.h, L.u128_array([user_id]), L.u128_array(doc_ids),
+                                                                   C.c_size_t(len(doc_ids)), L.ptr(flags, C.c_uint8)))
+            pairs += [(user_id, d) for d, f in zip(doc_ids, flags) if f]
+        if pairs and getattr(self, "invalidated_ids_storage", None) is not None:
+            self.invalidated_ids_storage.invalidate_batch(pairs)
+        return len(pairs)
+
+    def is_invalidated(self, user_id, doc_id):
+        """MultiSpannIndex::is_invalidated :229-232 (an unknown user raises: Err("User not found"))"""
+        flags = np.zeros(1, np.uint8)
+        self.ctx.check(self.ctx.lib.mdb_multi_spann_is_invalidated(self.h, L.u128_array([user_id]), L.u128_array([doc_id]),
+                                                                   C.c_size_t(1), L.ptr(flags, C.c_uint8)))
         return bool(flags[0])
 
 

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "mdb_hnsw_load", "mdb_hnsw_attach", "mdb_hnsw_free", "mdb_hnsw_num_vectors", "mdb_hnsw_ann_search",
     "mdb_spann_load", "mdb_spann_free", "mdb_spann_search", "mdb_spann_invalidate", "mdb_spann_is_invalidated",
     "mdb_multi_spann_load", "mdb_multi_spann_free", "mdb_multi_spann_num_users", "mdb_multi_spann_search",
-    "mdb_multi_spann_invalidate", "mdb_merge_shards",
+    "mdb_multi_spann_invalidate", "mdb_multi_spann_is_invalidated", "mdb_multi_spann_replay_invalidations", "mdb_merge_shards",
     "mdb_shard_block_bytes", "mdb_shard_block_views", "mdb_merge_shards_packed", "mdb_allgather_merge",
     "mdb_odht_user_table", "mdb_hnsw_select_neighbors", "mdb_wait", "mdb_poll", "mdb_ivf_search_filtered", "mdb_ivf_attach", "mdb_ivf_search_submit", "mdb_hnsw_ann_search_submit",
     "mdb_spann_search_filtered", "mdb_spann_attach", "mdb_spann_search_submit",

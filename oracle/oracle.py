@@ -487,6 +487,43 @@ class MultiSpannIndex:
     def invalidate(self, user_id, doc_id):
         return bool(lib().orc_multi_spann_invalidate(C.c_void_p(self.h), *_split(user_id), *_split(doc_id)))
 
+    def apply_pending_invalidations(self, directory):
+        """MultiSpannIndex::new, multi_spann/index.rs:51-77: the segment's tombstone log is read into
+        pending_invalidations (user id -> SET of doc ids); get_or_create_index :121-124 hands a user's set to
+        Spann::invalidate_batch when that user's index is first opened — here at once, for the users the table holds
+        (the others' records stay pending).  Returns the pending map."""
+        pending = {}
+        for user_id, doc_id in invalidated_ids_iter(directory):
+            pending.setdefault(user_id, set()).add(doc_id)
+        for user_id, docs in pending.items():
+            for doc_id in docs:
+                self.invalidate(user_id, doc_id)
+        return pending
+
+
+def invalidated_ids_iter(base_directory):
+    """InvalidatedIdsStorage::read + ::iter, rs/index/src/ivf/files/invalidated_ids.rs:45-106, 183-256, restated on the
+    standard library: the files named `invalidated_ids.bin.*` are COUNTED (read sorts them by numeric suffix only to size
+    the last one), the iterator then opens `invalidated_ids.bin.<i>` for i < count — a name missing from that range is
+    skipped (`.ok()`) — and yields (user id, doc id) from consecutive 32-byte little-endian records of each file; a file
+    that ends inside a record panics ("Incomplete invalidation record at end of file")."""
+    import os
+    if not os.path.isdir(base_directory):
+        return
+    count = sum(1 for n in os.listdir(base_directory) if n.startswith("invalidated_ids.bin."))
+    for i in range(count):
+        path = os.path.join(base_directory, "invalidated_ids.bin.%d" % i)
+        if not os.path.isfile(path):
+            continue
+        with open(path, "rb") as f:
+            data = f.read()
+        off = 0
+        while off < len(data):
+            if off > len(data) - 32:
+                raise ValueError("Incomplete invalidation record at end of file")
+            yield int.from_bytes(data[off:off + 16], "little"), int.from_bytes(data[off + 16:off + 32], "little")
+            off += 32
+
 
 # ---------------------------------------------------------------- ordering (K12)
 class planner_filter:

@@ -337,11 +337,21 @@ def test_cpp_pending_segment_and_snapshot_match_python(ctx, oracle, tmp_path):
     (tmp_path / "dead.txt").write_text("".join("7 %d\n" % doc for doc in dead[7]))
     (tmp_path / "users.txt").write_text("7\n8\n999\n")
     (tmp_path / "queries.f32").write_bytes(q.tobytes())
+    # the finalized segment had deletes: its tombstone log (3 files of 64 bytes; a user it does not hold; a pair twice) is
+    # replayed by InvalidatedIdsStorage::read + MultiSpannIndex::open_invalidated_ids of the C++ mirror and by the Python one
+    top8 = segs[1].search_for_user([8], q[1:2], p).doc_ids(0)
+    log = F.InvalidatedIdsStorage(str(tmp_path / "seg1" / "invalidated_ids_storage"), 64)
+    os.makedirs(log.base_directory)
+    log.invalidate_batch([(8, top8[0]), (999, 5), (8, top8[1]), (8, top8[0]), (7, 100_000)])
+    assert segs[1].replay_invalidations(F.InvalidatedIdsStorage.read(log.base_directory).record_bytes()) == 3
     out = subprocess.run([exe, "segments", str(tmp_path), str(d), "5", "50", "6", "0.3"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
+    assert "replayed 1 3" in out.stdout.splitlines()
     got = {}
     for line in out.stdout.splitlines():
         t = line.split()
+        if t[0] == "replayed":
+            continue
         got[(t[0], int(t[1]))] = None if t[2] == "none" else [(int(x.split(":")[0]), int(x.split(":")[1], 16)) for x in t[3:]]
 
     def bits(rows):

@@ -151,6 +151,118 @@ def test_open_segment_directory(ctx, oracle, tmp_path, pq):
         assert r.doc_ids(0) == [1000, 3, 2]        # K9 (multi_spann/index.rs:358-412) through the on-disk tree
 
 
+def test_k16_open_segment_replays_the_tombstone_log(ctx, oracle, tmp_path):
+    """multi_spann/index.rs:525-599 (test_multi_spann_create_with_invalidation) on the GPU path: the K9 collection opened over
+    a log holding (user 0, doc 1000) -> is_invalidated, num_entries 1, rows 3, 2, 4; then :602-668 (test_multi_spann_invalidate)
+    and :671-760 (.._invalidate_batch): only EFFECTIVE invalidations reach the log, and a reopen sees them."""
+    import os
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import MultiSpannIndex, SearchParams
+    v = np.concatenate([np.repeat(np.arange(1000, dtype=np.float32)[:, None], 4, 1), np.array([[1.2, 2.2, 3.2, 4.2]], np.float32)])
+    f0, _, _ = H.build_spann_files(oracle, v, list(range(1001)), 10)
+    cat = F.concat_multi_spann({0: f0})
+    seg = str(tmp_path / "seg")
+    os.makedirs(os.path.join(seg, "invalidated_ids_storage"))
+    F.InvalidatedIdsStorage(os.path.join(seg, "invalidated_ids_storage"), 1024).invalidate(0, 1000)
+    F.write_segment(seg, cat, 4)
+    g = MultiSpannIndex.open_segment(ctx, seg)
+    assert g.replayed_invalidations == 1 and g.is_invalidated(0, 1000) and not g.is_invalidated(0, 3)
+    assert g.invalidated_ids_storage.num_entries() == 1
+    r = g.search_for_user([0], [[1.4, 2.4, 3.4, 4.4]], SearchParams(3, 2))
+    assert r.doc_ids(0) == [3, 2, 4]
+    with pytest.raises(Exception, match="User not found"):
+        g.is_invalidated(77, 1)
+    # test_multi_spann_invalidate: effective -> logged, ineffective (absent doc / dead doc) -> not
+    assert g.invalidate(0, 0) is True and g.invalidated_ids_storage.num_entries() == 2
+    assert g.invalidate(0, 5000) is False and g.invalidate(0, 1000) is False and g.invalidated_ids_storage.num_entries() == 2
+    # test_multi_spann_invalidate_batch: {0: [valid 1, valid 2, invalid]} -> 2; then [dead 2, valid 3, invalid] -> 1
+    assert g.invalidate_batch({0: [1, 2, 5000]}) == 2 and g.invalidated_ids_storage.num_entries() == 4
+    assert g.invalidate_batch({0: [2, 3, 5001]}) == 1
+    assert sorted(g.invalidated_ids_storage) == [(0, 0), (0, 1), (0, 2), (0, 3), (0, 1000)]
+    g.close()
+    g2 = MultiSpannIndex.open_segment(ctx, seg)
+    assert g2.replayed_invalidations == 5
+    o = oracle.MultiSpannIndex(cat["user_table"], 4, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+    o.apply_pending_invalidations(os.path.join(seg, "invalidated_ids_storage"))
+    q = np.array([[1.4, 2.4, 3.4, 4.4], [0, 0, 0, 0]], np.float32)
+    r, ro = g2.search_for_user([0, 0], q, SearchParams(3, 2)), o.search_for_user([0, 0], q, oracle.SearchParams(3, 2))
+    for i in range(2):
+        assert r.doc_ids(i) == ro.doc_ids(i)
+    assert r.doc_ids(0) == [4, 5, 6]                                  # 0..3 and 1000 are dead
+
+
+@pytest.mark.parametrize("pq", [False, True])
+def test_reopened_segment_with_a_two_file_log_equals_oracle(ctx, oracle, tmp_path, pq):
+    """A segment that had deletes: its log spans several files (64-byte files = 2 records), names a user the table does not
+    hold, a document its user does not hold, and one pair twice.  Reopened (MultiSpannIndex::new multi_spann/index.rs:51-77 +
+    get_or_create_index :121-124 -> mdb_multi_spann_replay_invalidations) it gives the rows of the oracle that applied the same
+    log — and differs from the segment without the log; by-user shards skip the other users' records; the same through
+    list shards of 2."""
+    import os
+    from muopdb_amd import formats as F
+    from muopdb_amd.index import MultiSpannIndex, ProductQuantizer, SearchParams
+    rng = np.random.default_rng(21)
+    users, files, vecs = [5, (1 << 90) + 3, 77], {}, {}
+    quant = oquant = quantize = pqcfg = None
+    allv = H.sift_like(2400, 16, n_clusters=12, seed=9)
+    if pq:
+        cb = H.train_pq_codebook(allv[:1200], 4, 5, iters=3)
+        opq = oracle.ProductQuantizer(16, 4, 5, cb)
+        quant, oquant, quantize, pqcfg = ProductQuantizer(16, 4, 5, cb), oracle.Quant(oracle.QUANT_PQ, oracle.METRIC_L2, 4, 5, cb), opq.quantize, (16, 4, 5)
+    for ui, u in enumerate(users):
+        vecs[u] = allv[ui * 800:(ui + 1) * 800]
+        files[u], _, _ = H.build_spann_files(oracle, vecs[u], [1000 * ui + 3 * j for j in range(800)], 12, quantize=quantize, seed=ui,
+                                             max_neighbors=8, max_layers=3, ef_construction=40)
+        if pq:
+            files[u]["codebook"] = np.asarray(cb, np.float32).tobytes()
+    cat = F.concat_multi_spann(files)
+    q = np.stack([vecs[u][j] + rng.normal(0, 2, 16) for u in users for j in (0, 100, 799)]).astype(np.float32)
+    qu = [u for u in users for _ in range(3)]
+    # the deletes: the nearest documents of every query's user (so rows MUST change), + noise records
+    p, op = SearchParams(6, 40).with_num_explored_centroids(4), oracle.SearchParams(6, 40, num_explored_centroids=4)
+    clean = oracle.MultiSpannIndex(cat["user_table"], 16, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], oquant)
+    base_rows = clean.search_for_user(qu, q, op)
+    dead = []
+    for i, u in enumerate(qu):
+        dead += [(u, d) for d in base_rows.doc_ids(i)[:2]]
+    dead.insert(3, (424242, 1))                                       # a user absent from the table
+    dead.insert(5, (5, 999999))                                       # a document its user does not hold
+    dead.append(dead[0])                                              # one pair twice
+    seg = str(tmp_path / "segment")
+    F.write_segment(seg, cat, 16, pq=pqcfg, invalidated=dead, backing_file_size=64)
+    names = sorted(os.listdir(os.path.join(seg, "invalidated_ids_storage")))
+    assert len(names) == (len(dead) + 1) // 2 >= 10 and "invalidated_ids.bin.10" in names   # numeric suffix order matters
+    o = oracle.MultiSpannIndex(cat["user_table"], 16, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"], oquant)
+    pending = o.apply_pending_invalidations(os.path.join(seg, "invalidated_ids_storage"))
+    assert 424242 in pending
+    want = o.search_for_user(qu, q, op)
+    g = MultiSpannIndex.open_segment(ctx, seg)
+    n_real = len({(u, d) for u, d in dead if u in users and d != 999999})
+    assert g.replayed_invalidations == n_real
+    got = g.search_for_user(qu, q, p)
+    changed = 0
+    for i in range(len(qu)):
+        assert got.doc_ids(i) == want.doc_ids(i), i
+        assert np.array_equal(got.scores[i, :int(got.counts[i])].view(np.uint32), want.scores[i, :int(want.counts[i])].view(np.uint32))
+        changed += got.doc_ids(i) != base_rows.doc_ids(i)
+        assert not set(got.doc_ids(i)) & {d for u, d in dead if u == qu[i]}
+    assert changed == len(qu)
+    # by-user shard: only user slot 1 (ids sorted: 5, 77, 2^90+3) resident -> the log's other records are skipped
+    one = MultiSpannIndex.open_segment(ctx, seg, user_slots=[1])
+    assert one.num_users() == 1 and one.replayed_invalidations == len({d for u, d in dead if u == 77})
+    r1 = one.search_for_user(qu, q, p)
+    for i in range(len(qu)):
+        assert bool(r1.found[i]) == (qu[i] == 77)
+        if qu[i] == 77:
+            assert r1.doc_ids(i) == want.doc_ids(i)
+    # list shards of 2: every rank replays the log over its replicated doc-id tables; merged rows == unsharded rows
+    shards = [MultiSpannIndex.open_segment(ctx, seg, shard_rank=r, shard_world=2) for r in range(2)]
+    blocks = [s_.search_shard(qu, q, p) for s_ in shards]
+    merged = shards[0].merge_shards(qu, blocks, len(qu), 6)
+    for i in range(len(qu)):
+        assert merged.doc_ids(i) == want.doc_ids(i), i
+
+
 def test_select_neighbors_heuristic(ctx, oracle):
     """mdb_hnsw_select_neighbors == select_neighbors_heuristic (hnsw/builder.rs:339-375) restated with the oracle's exact
     distance: pop order (distance asc, larger id first), keep e unless a kept x has distance(x, e) < distance(e, q)."""

@@ -417,6 +417,75 @@ def test_k10_ratio_filter(oracle):
     assert res.doc_ids(0) == [1] and res.doc_ids(1) == [3]
 
 
+# ----------------------------------------------------------------------------- K16-K18: the persisted tombstone log
+def test_k16_invalidated_ids_storage_files(tmp_path):
+    """rs/index/src/ivf/files/invalidated_ids.rs tests: test_invalidate :259-299 (1024-byte files, one record: backing id 0,
+    offset 32, the 32 LE bytes), test_invalidate_multiple_files :301-371 (64-byte files = 2 records each, 10 records ->
+    files 0..4), test_read_multiple_files :413-463 (31 records: read() recovers backing id / offset / size, iter yields them
+    in order, an append lands in the last file), test_invalidate_batch :465-545 (2 + 2048 records through 1024-byte files;
+    a re-read ends at offset 64 again).  Writer = the product's formats.InvalidatedIdsStorage, reader = that AND the oracle."""
+    import os
+    from oracle.oracle import invalidated_ids_iter
+    user_id, doc_id = 123456789012345678901234567890123456, 987654321
+    d = str(tmp_path / "a"); os.makedirs(d)
+    st = F.InvalidatedIdsStorage(d, 1024)
+    st.invalidate(user_id, doc_id)
+    assert (st.current_backing_id, st.current_offset, st.num_entries()) == (0, 32, 1)
+    raw = open(os.path.join(d, "invalidated_ids.bin.0"), "rb").read()
+    assert raw == user_id.to_bytes(16, "little") + doc_id.to_bytes(16, "little")
+    rd = F.InvalidatedIdsStorage.read(d)                              # test_read_single_file :373-411
+    assert (rd.current_backing_id, rd.current_offset, rd.backing_file_size) == (0, 32, 8192)
+    assert next(iter(rd)) == (user_id, doc_id) == next(invalidated_ids_iter(d))
+    rd.invalidate(user_id, doc_id + 1)
+    assert rd.current_offset == 64
+    d = str(tmp_path / "b"); os.makedirs(d)
+    st = F.InvalidatedIdsStorage(d, 64)
+    for i in range(10):
+        st.invalidate(i, i)
+    assert st.current_backing_id == 4 and st.num_entries() == 10
+    for fid in range(5):
+        raw = open(os.path.join(d, "invalidated_ids.bin.%d" % fid), "rb").read()
+        assert raw == b"".join(F.u128_bytes(i) * 2 for i in range(2 * fid, 2 * fid + 2))
+    d = str(tmp_path / "c"); os.makedirs(d)
+    st = F.InvalidatedIdsStorage(d, 64)
+    for i in range(31):
+        st.invalidate(i, i)
+    rd = F.InvalidatedIdsStorage.read(d)
+    assert (rd.current_backing_id, rd.current_offset, rd.backing_file_size) == (st.current_backing_id, st.current_offset, st.backing_file_size) == (15, 32, 64)
+    assert list(rd) == [(i, i) for i in range(31)] == list(invalidated_ids_iter(d))
+    rd.invalidate(31, 31)
+    assert rd.current_offset == 64 and list(rd)[-1] == (31, 31) and len(list(invalidated_ids_iter(d))) == 32
+    d = str(tmp_path / "d"); os.makedirs(d)
+    st = F.InvalidatedIdsStorage(d, 1024)
+    user2, doc2 = 223456789012345678901234567890123456, 987654322
+    st.invalidate_batch([(user_id, doc_id), (user2, doc2)])
+    rd = F.InvalidatedIdsStorage.read(d)
+    assert (rd.current_backing_id, rd.current_offset) == (0, 64) and list(rd) == [(user_id, doc_id), (user2, doc2)]
+    large = [(user_id + i, doc_id + i) for i in range(2048)]
+    st.invalidate_batch(large)
+    rd = F.InvalidatedIdsStorage.read(d)
+    assert rd.current_offset == 64
+    assert list(rd) == [(user_id, doc_id), (user2, doc2)] + large == list(invalidated_ids_iter(d))
+
+
+def test_k16_multi_spann_create_with_invalidation(oracle, tmp_path):
+    """multi_spann/index.rs:525-599: the K9 collection opened over a log that already holds (user 0, doc 1000):
+    query [1.4, 2.4, 3.4, 4.4], k = 3, ef 2 -> docs 3, 2, 4 (1000 is dead from the first search on)."""
+    import os
+    v = np.concatenate([_line_vectors(), np.array([[1.2, 2.2, 3.2, 4.2]], np.float32)])
+    f0, _, _ = H.build_spann_files(oracle, v, list(range(1001)), 10)
+    cat = F.concat_multi_spann({0: f0})
+    seg = str(tmp_path / "seg")
+    os.makedirs(os.path.join(seg, "invalidated_ids_storage"))
+    F.InvalidatedIdsStorage(os.path.join(seg, "invalidated_ids_storage"), 1024).invalidate(0, 1000)
+    F.write_segment(seg, cat, 4)
+    ms = oracle.MultiSpannIndex(cat["user_table"], 4, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+    pending = ms.apply_pending_invalidations(os.path.join(seg, "invalidated_ids_storage"))
+    assert pending == {0: {1000}}
+    assert ms.invalidate(0, 1000) is False                            # is_invalidated: already a tombstone
+    assert ms.search_for_user([0], [[1.4, 2.4, 3.4, 4.4]], oracle.SearchParams(3, 2)).doc_ids(0) == [3, 2, 4]
+
+
 # ----------------------------------------------------------------------------- IVF / HNSW property pins
 def test_ivf_search_properties(oracle):
     # rs/index/src/ivf/block_based/index.rs:505-572: count and ascending scores; plus exactness vs f64

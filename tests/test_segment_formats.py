@@ -187,3 +187,80 @@ def test_write_segment_tree_and_read_back(tmp_path):
     back = F.read_segment(seg2)
     assert back["pq"] == (4, 2, 2) and back["codebook"].tobytes() == cat["codebook"]
     assert not os.path.exists(os.path.join(seg2, "ivf/quantizer/no_op_quantizer_config.yaml"))
+
+
+# --------------------------------------------------------------------------------------- tombstone log (invalidated_ids.rs)
+def _oracle_pairs(directory):
+    from oracle.oracle import invalidated_ids_iter
+    return list(invalidated_ids_iter(directory))
+
+
+def test_invalidated_ids_storage_naming_rounding_and_rollover(tmp_path):
+    """InvalidatedIdsStorage (rs/index/src/ivf/files/invalidated_ids.rs): 32-byte LE records, the backing size rounded DOWN to
+    whole records (:33-35; the reference's own test_invalidate uses 1024), a new file exactly when the current one is full
+    (:121-123), names `invalidated_ids.bin.<i>`; the product's reader/writer and the oracle's independent restatement of
+    ::read + ::iter agree on the bytes."""
+    d = str(tmp_path / "log")
+    st = F.InvalidatedIdsStorage(d, 100)                      # 100 -> 96 bytes = 3 records per file
+    os.makedirs(d)
+    assert st.backing_file_size == 96 and st.num_entries() == 0
+    big = (1 << 100) + 7
+    pairs = [(0, 5), (big, (1 << 127) + 3), (7, 8), (7, 9), (big, 1), (0, 5), (3, 3)]
+    st.invalidate(*pairs[0])
+    st.invalidate_batch(pairs[1:])
+    assert sorted(os.listdir(d)) == ["invalidated_ids.bin.0", "invalidated_ids.bin.1", "invalidated_ids.bin.2"]
+    assert [os.path.getsize(os.path.join(d, "invalidated_ids.bin.%d" % i)) for i in range(3)] == [96, 96, 32]
+    raw = open(os.path.join(d, "invalidated_ids.bin.0"), "rb").read()
+    assert raw[:32] == struct.pack("<QQQQ", 0, 0, 5, 0)       # u128 LE user id, u128 LE doc id
+    assert raw[32:64] == struct.pack("<QQQQ", 7, 1 << 36, 3, 1 << 63)
+    assert st.num_entries() == 7 and list(st) == pairs == _oracle_pairs(d)
+    # ::read on a directory of several files: backing size = the FIRST file's size, offset = the last file's size
+    rd = F.InvalidatedIdsStorage.read(d)
+    assert (rd.backing_file_size, rd.current_backing_id, rd.current_offset, rd.num_entries()) == (96, 2, 32, 7)
+    rd.invalidate_batch([(1, 1), (1, 2), (1, 3)])             # fills file 2, then opens file 3
+    assert [os.path.getsize(os.path.join(d, "invalidated_ids.bin.%d" % i)) for i in range(4)] == [96, 96, 96, 32]
+    assert list(F.InvalidatedIdsStorage.read(d)) == pairs + [(1, 1), (1, 2), (1, 3)] == _oracle_pairs(d)
+    # numeric, not lexicographic, order of the suffixes: 12 files
+    d2 = str(tmp_path / "log2")
+    os.makedirs(d2)
+    st2 = F.InvalidatedIdsStorage(d2, 32)
+    many = [(i, 1000 - i) for i in range(12)]
+    st2.invalidate_batch(many)
+    rd2 = F.InvalidatedIdsStorage.read(d2)
+    assert rd2.num_files == 12 and rd2.current_backing_id == 11 and list(rd2) == many == _oracle_pairs(d2)
+
+
+def test_invalidated_ids_storage_read_edge_cases(tmp_path):
+    """::read :45-106 — missing directory is created and empty; ONE file: backing size = max(8192, its size); a file that ends
+    inside a record is the iterator's panic; a hole in the numbering is skipped by ::iter (it opens files by INDEX)."""
+    d = str(tmp_path / "absent" / "invalidated_ids_storage")
+    st = F.InvalidatedIdsStorage.read(d)
+    assert os.path.isdir(d) and st.num_entries() == 0 and list(st) == [] == _oracle_pairs(d)
+    st.invalidate(9, 10)
+    assert os.listdir(d) == ["invalidated_ids.bin.0"] and F.InvalidatedIdsStorage.read(d).backing_file_size == 8192
+    with open(os.path.join(d, "invalidated_ids.bin.0"), "ab") as f:
+        f.write(b"\0" * (32 * 300))                            # 9632 bytes > 8192: the single file's own size wins
+    one = F.InvalidatedIdsStorage.read(d)
+    assert one.backing_file_size == 9632 and one.num_entries() == 301
+    with open(os.path.join(d, "invalidated_ids.bin.0"), "ab") as f:
+        f.write(b"\1" * 5)
+    with pytest.raises(ValueError, match="Incomplete invalidation record"):
+        list(F.InvalidatedIdsStorage.read(d))
+    with pytest.raises(ValueError, match="Incomplete invalidation record"):
+        _oracle_pairs(d)
+    d3 = str(tmp_path / "holes")
+    os.makedirs(d3)
+    for i, rec in ((0, (1, 2)), (2, (3, 4))):                 # files .0 and .2: two files => ::iter opens .0 and .1 only
+        with open(os.path.join(d3, "invalidated_ids.bin.%d" % i), "wb") as f:
+            f.write(F.u128_bytes(rec[0]) + F.u128_bytes(rec[1]))
+    assert list(F.InvalidatedIdsStorage.read(d3)) == [(1, 2)] == _oracle_pairs(d3)
+
+
+def test_write_segment_with_invalidated_ids_round_trips(tmp_path):
+    users = {3: dict(hnsw_index=b"H" * 40, hnsw_vectors=b"V" * 24, ivf_index=b"I" * 64, ivf_vectors=b"W" * 16)}
+    cat = F.concat_multi_spann(users)
+    seg = str(tmp_path / "seg")
+    dead = [(3, 11), (99, 1), (3, 11), (3, 12)]
+    F.write_segment(seg, cat, 4, invalidated=dead, backing_file_size=64)
+    assert sorted(os.listdir(os.path.join(seg, "invalidated_ids_storage"))) == ["invalidated_ids.bin.0", "invalidated_ids.bin.1"]
+    assert F.read_segment(seg)["invalidated"] == dead
