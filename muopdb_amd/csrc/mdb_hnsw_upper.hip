@@ -305,6 +305,7 @@ struct HnswUpArgs {
     int n16;
     const float* q;
     int qstride;
+    int dbg_on;               // MDB_PIPE_DBG builds: this launch adds its cycle sums to counters[4..15] (MDB_HNSW_DBG bit 0: bottom launch, bit 1: top)
 };
 
 #ifdef MDB_PIPE_DBG   // -DMDB_PIPE_DBG + MDB_HNSW_DBG=1: cycle / event sums into counters[4..15] (the traversal kernels print the same words)
@@ -723,6 +724,8 @@ __global__ __launch_bounds__(UP_BLOCK) void hnsw_upper_kernel(HnswUpArgs a) {
     upper_traverse_wave0<NB>(a, qi, lane, lds, TLDS ? tl : tg, vis, tl + (TLDS ? a.nu_pad : 0));
 }
 
+#include "mdb_hnsw_rank.hip.h"
+
 // The split path (batches of >= 32 queries, d = 16 n16 <= 128): ONE launch whose first b blocks traverse the layers >= 2 — ~1 k points:
 // each block evaluates its query against them itself (the thread = point arithmetic of hnsw_upper_table16_kernel, the row goes
 // straight into LDS) — while the remaining blocks are the lane = query table pass over ALL upper points (hnsw_upper_table64_kernel's
@@ -767,6 +770,56 @@ __global__ __launch_bounds__(256, 2) void hnsw_upper_top_kernel(HnswUpArgs a, ui
     upper_traverse_wave0<NB>(a, qi, lane, lds, tl, vis, tl + a.nu_pad);
 }
 
+// the same launch with the top blocks on sorted positions (mdb_hnsw_rank.hip.h): own table row -> LDS, sorted there, traversed by ranks
+template <int METRIC, int N16, int NW>
+__global__ __launch_bounds__(256, 2) void hnsw_upper_top_rank_kernel(HnswUpArgs a, uint32_t nq, const float* __restrict__ rows_nat, uint32_t nu_all,
+                                                                     uint32_t* __restrict__ table_all, uint32_t nu_all_pad, uint32_t tgx,
+                                                                     unsigned long long* zero16) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (blockIdx.x >= nq) {
+        const uint32_t t = blockIdx.x - nq;
+        table64_block<METRIC, N16>(rows_nat, nu_all, a.q, a.qstride, nq, table_all, nu_all_pad, t % tgx, t / tgx);
+        return;
+    }
+    if (zero16 && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0ull;
+    uint32_t* const vis = (uint32_t*)(lds + UP_LDS_VIS);
+    const int qi = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* const tl = vis + a.vis_words;
+    uint16_t* const bufA = (uint16_t*)(tl + a.nu_pad);
+    uint16_t* const bufB = bufA + a.nu_pad;
+    uint32_t* const hist = (uint32_t*)(bufB + a.nu_pad);
+    uint32_t* const red = hist + RK_HIST_WORDS(256);
+    uint32_t* const vis_out = red + 64;
+    for (uint32_t i = threadIdx.x; i < a.vis_words; i += UP_BLOCK) vis[i] = 0u;
+    // the block's own table row: one wave per tile of 64 points, thread = point (exact association, DPP-broadcast query chunks)
+    const float* const ql = a.q + (size_t)qi * a.qstride + (lane & 15);
+    for (uint32_t tile = wave; tile < a.self_ntiles; tile += UP_BLOCK / 64) {
+        const float4* tp = a.self_tiles + (size_t)tile * (4 * N16) * MDB_TILE + lane;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < N16; ++c) {
+            float4 x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = tp[(size_t)(4 * c + t) * MDB_TILE];
+            const float xv[16] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w,
+                                  x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
+            t16_accumulate<METRIC>(acc, ql[16 * c], xv);
+        }
+        const uint32_t v = tile * MDB_TILE + lane;
+        tl[v] = v < a.nu ? f32_orderable(finish_distance<METRIC>(__fadd_rn(0.0f, reduce_ordered<16>(acc)))) : SLOT_EMPTY;
+    }
+    __syncthreads();
+    uint16_t *P, *R;
+    uint32_t nan_start;
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+    rank_tables<256>(tl, a.nu, bufA, bufB, hist, red, P, R, nan_start);
+    if (threadIdx.x >= 64) return;
+    if constexpr (NW == 1) upper_traverse_rank1(a, qi, lane, lds, R, P, nan_start, vis, vis_out, __builtin_readcyclecounter() - ts0);
+    else upper_traverse_rank<NW>(a, qi, lane, lds, R, P, nan_start, vis, vis_out, __builtin_readcyclecounter() - ts0);
+}
+
 // launch of hnsw_upper_kernel over layers layer_hi .. 1 (the last launch before layer 0: out_ep holds point ids, the bitmap as is)
 static mdb_status upper_launch_bottom(mdb_ctx* ctx, const HnswUpper& up, const uint32_t* d_table, size_t b, uint32_t ef, const HnswUpperOut& out,
                                       int layer_hi, const uint32_t* in_ep, const uint32_t* in_ovf, const uint32_t* in_vis, const uint32_t* in_cnt) {
@@ -781,6 +834,25 @@ static mdb_status upper_launch_bottom(mdb_ctx* ctx, const HnswUpper& up, const u
     a.ep_map = up.ids.p; a.vis_map = nullptr; a.out_words = out.words;
     a.out_ep = out.ep; a.out_ovf = out.ovf; a.out_vis = out.vis; a.out_cnt = out.cnt;
     a.flags = ctx->d_flags; a.counters = ctx->d_counters;
+    a.dbg_on = (int)(ctx->opt.hnsw_dbg & 1);
+    // sorted positions (mdb_hnsw_rank.hip.h): the block sorts its table row and traverses by ranks — any ef, no beam registers
+    {
+        const size_t rlds = rk_lds_bytes(out.words, a.nu_pad, RK_BLOCK, 0);
+        if ((ctx->opt.hnsw_rank & 1) && a.nu <= RK_MAX_POINTS && a.nu_pad <= RK_MAX_POINTS && rlds <= 160 * 1024 - 512) {
+#define MDB_RK_GO(NWV)                                                                                                                \
+    do {                                                                                                                              \
+        if (rlds > 48 * 1024)                                                                                                         \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_rank_kernel<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds)); \
+        hnsw_upper_rank_kernel<NWV><<<dim3((unsigned)b), RK_BLOCK, rlds, ctx->stream>>>(a);                                           \
+    } while (0)
+            if (a.nu_pad <= 2048) MDB_RK_GO(1);
+            else if (a.nu_pad <= 8192) MDB_RK_GO(4);
+            else MDB_RK_GO(16);
+#undef MDB_RK_GO
+            MDB_HIP(ctx, hipGetLastError());
+            return MDB_OK;
+        }
+    }
     const size_t lds_base = UP_LDS_VIS + (size_t)out.words * 4;
     const bool tlds = lds_base + (size_t)a.nu_pad * 4 <= 160 * 1024 - 512 && !ctx->opt.hnsw_table_no_lds;
     const size_t lds = lds_base + (tlds ? (size_t)a.nu_pad * 4 : 0);
@@ -812,7 +884,12 @@ mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const D
     const size_t lds_top = UP_LDS_VIS + (size_t)words2 * 4 + (size_t)nu2_pad * 4 + (size_t)out.words * 4;
     const bool split = up.nu2 > 0 && up.layers >= 2 && up.rows_nat.p && p.n16 > 0 && p.n16 <= 8 && p.n8 == 0 && p.n4 == 0 && p.ntail == 0 &&
                        (long long)b >= ctx->opt.hnsw_table64_min_b && !ctx->opt.hnsw_no_split && lds_top <= 160 * 1024 - 512 && ef <= 256;
-    if (!split) {
+    // the top blocks on sorted positions: their LDS holds the row, its two rank tables and the sort's histograms
+    const size_t lds_top_rank = rk_lds_bytes(words2, nu2_pad, 256, nu2_pad + out.words);
+    const bool top_rank = (ctx->opt.hnsw_rank & 2) && up.nu2 > 0 && up.layers >= 2 && up.rows_nat.p && p.n16 > 0 && p.n16 <= 8 && p.n8 == 0 && p.n4 == 0 &&
+                          p.ntail == 0 && (long long)b >= ctx->opt.hnsw_table64_min_b && !ctx->opt.hnsw_no_split && nu2_pad <= 8192 &&
+                          lds_top_rank <= 80 * 1024 - 512;   // (two blocks per CU: the table blocks of the same launch share it)
+    if (!split && !top_rank) {
         MDB_TRY(hnsw_upper_table(ctx, up, metric, p, d_q, qstride, b, d_table, zero16));
         return hnsw_upper_traverse(ctx, up, d_table, b, ef, out);
     }
@@ -831,6 +908,7 @@ mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const D
     a.out_ep = st_ep; a.out_ovf = st_ovf; a.out_vis = st_vis; a.out_cnt = st_cnt;
     a.flags = ctx->d_flags; a.counters = ctx->d_counters;
     a.self_tiles = (const float4*)up.tiles2.data.p; a.self_ntiles = (uint32_t)up.tiles2.ntiles; a.n16 = p.n16; a.q = d_q; a.qstride = qstride;
+    a.dbg_on = (int)((ctx->opt.hnsw_dbg >> 1) & 1);
     const unsigned tgx = (unsigned)((up.nu + 4 * T64_PPW - 1) / (4 * T64_PPW)), tgy = (unsigned)((b + 63) / 64);
     const unsigned grid = (unsigned)b + tgx * tgy;
     const bool nb4 = hnsw_beam_nb4(ctx, ef);
@@ -842,7 +920,20 @@ mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const D
         hnsw_upper_top_kernel<METRIC, N, NBV><<<dim3(grid), 256, lds_top, ctx->stream>>>(a, (uint32_t)b, up.rows_nat.p, up.nu, d_table, nu_pad, \
                                                                                          tgx, zero16);                                \
     } while (0)
-#define MDB_TOP_GO(METRIC, N) do { if (nb4) MDB_TOP_GO1(METRIC, N, 4); else MDB_TOP_GO1(METRIC, N, 5); } while (0)
+#define MDB_TOP_RK1(METRIC, N, NWV)                                                                                                    \
+    do {                                                                                                                               \
+        if (lds_top_rank > 48 * 1024)                                                                                                  \
+            MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_top_rank_kernel<METRIC, N, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                             (int)lds_top_rank));                                                                      \
+        hnsw_upper_top_rank_kernel<METRIC, N, NWV><<<dim3(grid), 256, lds_top_rank, ctx->stream>>>(a, (uint32_t)b, up.rows_nat.p, up.nu, d_table, \
+                                                                                                    nu_pad, tgx, zero16);              \
+    } while (0)
+#define MDB_TOP_GO(METRIC, N)                                                                  \
+    do {                                                                                       \
+        if (top_rank) { if (nu2_pad <= 2048) MDB_TOP_RK1(METRIC, N, 1); else MDB_TOP_RK1(METRIC, N, 4); } \
+        else if (nb4) MDB_TOP_GO1(METRIC, N, 4);                                               \
+        else MDB_TOP_GO1(METRIC, N, 5);                                                        \
+    } while (0)
 #define MDB_TOP_LAUNCH(METRIC)                           \
     do {                                                 \
         switch (p.n16) {                                 \
@@ -859,6 +950,7 @@ mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const D
     if (metric == MDB_METRIC_L2) MDB_TOP_LAUNCH(MDB_METRIC_L2); else MDB_TOP_LAUNCH(MDB_METRIC_DOT);
 #undef MDB_TOP_LAUNCH
 #undef MDB_TOP_GO
+#undef MDB_TOP_RK1
 #undef MDB_TOP_GO1
     MDB_HIP(ctx, hipGetLastError());
     return upper_launch_bottom(ctx, up, d_table, b, ef, out, 1, st_ep, st_ovf, st_vis, st_cnt);

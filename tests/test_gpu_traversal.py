@@ -159,12 +159,15 @@ def test_hnsw_general_kernel_equals_beam_kernel(ctx, oracle):
 
 
 @pytest.mark.parametrize("variant", ["MDB_HNSW_NO_ROW64", "MDB_HNSW_GENERIC_DIST", "MDB_HNSW_NO_TABLE", "MDB_HNSW_NO_SPLIT",
-                                     "MDB_HNSW_NO_WIDE", "MDB_HNSW_TABLE_NO_LDS"])
+                                     "MDB_HNSW_NO_WIDE", "MDB_HNSW_TABLE_NO_LDS", "MDB_HNSW_RANK=0", "MDB_HNSW_RANK=1", "MDB_HNSW_RANK=3"])
 @pytest.mark.parametrize("d,metric", [(128, 0), (768, 1), (128, 1)])
 def test_hnsw_beam_kernel_variants_equal_oracle(ctx, oracle, d, metric, variant):
     """hnsw_beam_kernel's variants — rows of any length (NO_ROW64), the generic distance cascade and the all-in-one kernel (NO_TABLE: the default route takes the
     upper layers through the distance table + hnsw_upper_kernel) — must give the oracle's rows AND counters: no speculative
-    touch may be counted."""
+    touch may be counted.  MDB_HNSW_RANK: the upper layers on sorted positions (mdb_hnsw_rank.hip.h) for neither launch, the
+    layer-1 / single launch, both (default: the top launch of the split path only)."""
+    variant, _, value = variant.partition("=")
+    value = int(value or 1)
     from muopdb_amd.index import BlockBasedHnsw, NoQuantizer
     rng = np.random.default_rng(31)
     n = 3000
@@ -175,7 +178,7 @@ def test_hnsw_beam_kernel_variants_equal_oracle(ctx, oracle, d, metric, variant)
     g = BlockBasedHnsw(ctx, hidx, hvec, d, NoQuantizer(d, metric))
     o = oracle.BlockBasedHnsw(hidx, hvec, d, oracle.Quant(oracle.QUANT_NONE, metric))
     q = (v[rng.integers(0, n, 40)] + rng.normal(0, 0.05 if metric == 1 else 4, (40, d))).astype(np.float32)
-    with ctx.option(variant, 1):
+    with ctx.option(variant, value):
         for k, ef in [(10, 100), (5, 8), (20, 256), (10, 1), (10, 40), (10, 300), (20, 448)]:   # (the last two: the 8-register beam)
             want = o.ann_search(q, k, ef)
             evals, expanded = o.stats()
