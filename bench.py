@@ -49,6 +49,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+LONG_STEPS = 200       # steps of the headline's extra long region (dispersion.long_region)
 DISP_REGIONS = 4       # extra timed regions per workload for the dispersion entry (Env.timed)
 WARM_MIN_S = 0.05      # Env.timed: the untimed warm-up lasts at least this long (the W steps repeated)
 PROF_EVERY = 8         # steps of the timed region between two steps whose dominant kernels are bracketed by HIP events
@@ -135,11 +136,13 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--sift-dir", default=None, help="directory holding sift_base.fvecs / sift_query.fvecs / sift_groundtruth.ivecs: "
                                                     "the C2/C3 workloads then run on the real SIFT-1M (data: sift1m) instead of synthetic rows")
-    p.add_argument("--graph", default="knn", choices=["knn", "insert"],
-                   help="hnsw: how the base graph is built — knn: exact k-NN + the reference's selection heuristic (fast bulk build); "
-                        "insert: HnswBuilder::insert's algorithm, wave-batched on the GPU (muopdb_amd.build.insert_hnsw)")
-    p.add_argument("--no-insert-graph", action="store_true", help="all: skip the second HNSW line on an insert-built graph")
-    p.add_argument("--insert-n", type=int, default=None, help="all: base size of the insert-built HNSW workload (default: --n)")
+    p.add_argument("--graph", default="insert", choices=["knn", "insert"],
+                   help="hnsw: how the base graph of the HEADLINE is built — insert (default): HnswBuilder::insert's algorithm, the graph MuopDB "
+                        "itself would write, wave-batched on the GPU (muopdb_amd.build.insert_hnsw); knn: exact k-NN + the reference's selection "
+                        "heuristic (fast bulk build)")
+    p.add_argument("--no-insert-graph", "--no-second-graph", dest="no_insert_graph", action="store_true",
+                   help="all: skip the second HNSW line on the graph built the OTHER way")
+    p.add_argument("--insert-n", type=int, default=None, help="all: base size of the second-graph HNSW workload (default: --n)")
     p.add_argument("--shard", default="lists", choices=["lists", "users", "batch"],
                    help="world > 1, single workloads: posting-list shards + exact merge (default, what north_star names), or a QUERY "
                         "partitioning with an all-gather of finished rows only: users (spann: user slot u on rank u %% world) / batch (ivfpq, "
@@ -288,7 +291,7 @@ class Env:
             return float(t.item())
         return seconds
 
-    def timed(self, step, steps, warm, profiling=True, disperse=True):
+    def timed(self, step, steps, warm, profiling=True, disperse=True, long_steps=0):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.
         Returns (seconds, dominant-kernel ms summed, launches).  The region that is returned is the FIRST one; `last_dispersion`
         then holds how much the same K steps vary when repeated (a 17 ms region alone cannot tell a 3 % change
@@ -353,6 +356,15 @@ class Env:
                                        median_call_ms=1000 * hs[len(hs) // 2]),
                 per_step_gpu_ms=dict(min=per[0], median=per[len(per) // 2], max=per[-1], steps=steps,
                                      note="events on the launch stream after every step of one more region (this rank)"))
+            if long_steps > 0:
+                self.barrier()
+                t0 = time.perf_counter()
+                for j in range(long_steps):
+                    step(warm + j % steps)
+                self.barrier()
+                el = self.max_over_ranks(time.perf_counter() - t0)
+                self.last_dispersion["long_region"] = dict(steps=long_steps, ms_per_step=1000 * el / long_steps,
+                                                           note="one region of this many steps (the timed batches cycled), bracketed like the timed one")
         return elapsed, kernel_ms, launches
 
     def sift(self, n, d, nq, qseed):
@@ -480,7 +492,7 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
         env.hnsw_hbm[key] = env.last_hbm
         log("load %.1fs" % (time.time() - t0))
     hnsw, index_bytes, vec_bytes, build_s = env.hnsw_cache[key]
-    if batch == 64 and graph == "knn":
+    if batch == 64 and graph == args.graph and (ef or args.ef) == args.ef:
         dump(args, rank, "hnsw", index=index_bytes, vectors=vec_bytes, **{"queries.f32": queries.cpu().numpy()})
     ids = torch.zeros((batch, k, 2), dtype=torch.int64, device="cuda")
     sc = torch.zeros((batch, k), dtype=torch.float32, device="cuda")
@@ -492,7 +504,9 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
         if keep is not None:
             keep.append(ids[:, :, 0].clone())
 
-    elapsed, kernel_ms, launches = env.timed(step, steps, warm)
+    # the headline also runs one LONG region (>= 200 steps, the timed batches cycled): K = 20 steps are ~15 ms, inside the 3-8 % two
+    # boxes differ by, and a round-to-round delta of that size cannot be told from noise; `value` stays the K-step region's
+    elapsed, kernel_ms, launches = env.timed(step, steps, warm, long_steps=max(LONG_STEPS, steps) if extras else 0)
     disp = env.last_dispersion
     # untimed re-run of the timed batches: results for recall + exact traversal counters per launch
     found, evals, expanded, abytes = [], 0, 0, 0
@@ -522,7 +536,7 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
     finish(out, disp, abytes / steps)
     out.update(getattr(env, "hnsw_hbm", {}).get(key) or {})
     out["steps"], out["warmup"] = steps, warm
-    if batch == 64 and graph == "knn":
+    if batch == 64 and graph == args.graph:
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("hnsw", out["config"])
     if extras and args.streams > 1:
         # Extra, NOT the headline: the same K batches issued round-robin on several HIP streams (one context +
@@ -1389,7 +1403,7 @@ def print_plan(args):
     w = max(1, args.gpus)
     GB = 1e9
     rows = []
-    rows.append(dict(workload="hnsw C2 (headline, replicas) + batch 1", builder="every rank, on its own GPU", build_s=17, load_s=3,
+    rows.append(dict(workload="hnsw C2 (headline: insert-built graph, replicas) + batch 1 + ef 400", builder="every rank, on its own GPU", build_s=60, load_s=3,
                      host_private_gb=0.8, host_shared_gb=0, hbm_per_rank_gb=2.4,
                      note="1M x 128 graph per rank: 0.77 GB of files, no collective in the step"))
     rows.append(dict(workload="flat 1M b1 / b64 (row shards)", builder="every rank (shares the C2 base)", build_s=0, load_s=1,
@@ -1415,7 +1429,7 @@ def print_plan(args):
         rows.append(dict(workload="c5_full_1gpu", builder="the process", build_s=66, load_s=1, host_private_gb=12.0, host_shared_gb=0, hbm_per_rank_gb=4.5))
         rows.append(dict(workload="c5_shard_per_gpu", builder="the process (reads c5_full_1gpu's files)", build_s=0, load_s=2, host_private_gb=12.0, host_shared_gb=0, hbm_per_rank_gb=1.0))
         rows.append(dict(workload="spann_c4_full_1024u", builder="the process", build_s=35, load_s=4, host_private_gb=62.0, host_shared_gb=0, hbm_per_rank_gb=61.4))
-        rows.append(dict(workload="hnsw_c2_insert_graph", builder="the process", build_s=60, load_s=3, host_private_gb=0.8, host_shared_gb=0, hbm_per_rank_gb=2.4))
+        rows.append(dict(workload="hnsw_c2_knn_graph", builder="the process", build_s=25, load_s=3, host_private_gb=0.8, host_shared_gb=0, hbm_per_rank_gb=2.4))
     total_s = sum(r["build_s"] + r["load_s"] for r in rows) + 60   # + timed regions, dispersion, recall / ground truth
     print(json.dumps(dict(gpus=w, estimated_wall_s=total_s, peak_host_gb=max(r.get("host_rank0_peak_gb", 0) + w * r["host_private_gb"] for r in rows),
                           workloads=rows, tmp_dir=os.environ.get("MDB_BENCH_TMP", "/tmp"),
@@ -1464,12 +1478,12 @@ def main():
     if args.workload != "all":
         res = single[args.workload](env)
     else:
-        res = run_hnsw(env, batch=64, graph="knn")
+        res = run_hnsw(env, batch=64, graph=args.graph)   # the headline: the reference-shaped (insert-built) graph unless --graph knn
         extra = {}
         # the metric's other batch size over the same resident graph (one sequential chain on one CU: latency, not throughput)
-        plan = [("hnsw_c2_b1", lambda: run_hnsw(env, batch=1, graph="knn", extras=False, steps=max(args.steps, 200), warm=max(args.warmup, 20))),
+        plan = [("hnsw_c2_b1", lambda: run_hnsw(env, batch=1, graph=args.graph, extras=False, steps=max(args.steps, 200), warm=max(args.warmup, 20))),
                 # ef above 256: the 8-register beam of the table path (up to 448; beyond: hnsw_search_kernel), the same resident graph
-                ("hnsw_c2_ef400", lambda: run_hnsw(env, batch=64, graph="knn", extras=False, ef=400)),
+                ("hnsw_c2_ef400", lambda: run_hnsw(env, batch=64, graph=args.graph, extras=False, ef=400)),
                 # BASELINE configs[0]: 10 k x 128 (py/create_test_hdf5.py-shaped rows), batch 1 (+ a batch-64 point): launch latency, not HBM
                 ("flat_c1_10k_b1", lambda: run_flat(env, n=10_000, batch=1, steps=max(args.steps, 200), warm=max(args.warmup, 20))),
                 ("flat_c1_10k_b64", lambda: run_flat(env, n=10_000, batch=64, steps=max(args.steps, 100), warm=max(args.warmup, 10))),
@@ -1491,8 +1505,9 @@ def main():
             plan.append(("c5_shard_per_gpu", lambda: run_c5(env, steps=min(args.steps, 8), warm=min(args.warmup, 2))))
         if world == 1 and not args.no_c4_full:  # the whole of C4 on one GPU: 1024 users x 9766 x 768 = 30.7 GB resident (~60 s of build + load)
             plan.append(("spann_c4_full_1024u", lambda: run_spann(env, users=1024, no_sweep=True, steps=min(args.steps, 10), warm=min(args.warmup, 3))))
-        if world == 1 and not args.no_insert_graph:  # C2 again on a graph built the way MuopDB builds it (HnswBuilder::insert)
-            plan.append(("hnsw_c2_insert_graph", lambda: run_hnsw(env, batch=64, graph="insert", n=args.insert_n, extras=False)))
+        if world == 1 and not args.no_insert_graph:  # C2 again on the graph built the other way (default: the bulk k-NN build next to the insert-built headline)
+            other = "knn" if args.graph == "insert" else "insert"
+            plan.append(("hnsw_c2_%s_graph" % other, lambda: run_hnsw(env, batch=64, graph=other, n=args.insert_n, extras=False)))
         for name, fn in plan:
             t0 = time.time()
             try:  # a failing extra workload must never take the headline line with it

@@ -541,6 +541,20 @@ class Snapshot {
             throw std::invalid_argument("Snapshot::search_for_user: one allow bitmap for several finalized segments (pass a PlannerFn)");
         return search_for_user(user_id, query, params, PlannerFn([planner](size_t, u128) { return planner; }));
     }
+    // The round-4 signature (a bare bitmap for the whole fan-out), kept so that existing callers still compile: it serves what it
+    // can serve correctly — no bitmap, or one DISTINCT user over at most one finalized segment (the rule of the Python mirror,
+    // muopdb_amd/index.py Snapshot.search_for_users) — and throws for anything wider, where one bitmap would filter the wrong points.
+    [[deprecated("pass a PlannerFn: a bitmap indexes ONE (segment, user)'s point ids")]]
+    SearchResult search_for_users(const std::vector<u128>& user_ids, const float* query, const SearchParams& params,
+                                  const std::vector<uint32_t>* planner) {
+        if (!planner) return search_for_users(user_ids, query, params, PlannerFn(nullptr));
+        std::set<u128> distinct(user_ids.begin(), user_ids.end());
+        size_t finalized = 0;
+        for (const Segment& s : segments_) finalized += s.finalized ? 1 : 0;
+        if (distinct.size() > 1 || finalized > 1)
+            throw std::invalid_argument("Snapshot::search_for_users: one allow bitmap for several users / finalized segments (pass a PlannerFn)");
+        return search_for_users(user_ids, query, params, PlannerFn([planner](size_t, u128) { return planner; }));
+    }
 
   private:
     static void finish(SearchResult& r, size_t top_k) {

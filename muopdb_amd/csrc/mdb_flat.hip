@@ -143,6 +143,139 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_scan_kernel(const float4* __re
     }
 }
 
+// ---- small bases, one to four queries (BASELINE config 1: 10 k x 128, batch 1; a coarse quantizer searched for one query): the whole
+// base is ~150 waves of work, so the step is launch + latency, not bandwidth.  One wave per tile (grid = tiles x queries), thread =
+// vector, EVERY 16-byte load of the vector in flight at once (d <= 128: 32 loads; flat_scan_kernel keeps 16 of a dependent chain of
+// two phases), and no selector at all (a block selector's warm-up, barriers and final sort were most of the 12 us the general kernel
+// spent on 157 tiles; ordering a wave's 64 keys by a shuffle network instead cost 21 stages of two LDS-crossbar round trips): the
+// wave stores its 64 keys as they are and the merge launch — one block — bounds and ranks them (merge_groups_fast).  Same
+// arithmetic as exact_sums (chunk by chunk, lane accumulators, ordered horizontal sum): the same bits.
+// FUSED (k <= 16, the lists fit 48 KB of LDS): the launch also merges — every wave takes a ticket behind its list (release fence),
+// the wave that takes a query's last ticket (acquire fence) copies the lists into LDS and pops the k smallest keys by a k-way merge:
+// one wave-wide minimum per key over the lists' current heads (cur[]: list r x 64 + lane in registers, the winner's lane reloads its
+// head from LDS).  One launch instead of two: the step is launch latency, and the second launch was a third of it.
+struct SmallFuse {
+    uint32_t* tickets = nullptr;     // [b] zero between calls (the last wave of a query re-arms its word); nullptr: two-launch form
+    uint64_t* out = nullptr;         // [b][k] keys (may be null)
+    uint32_t* counts = nullptr;      // [b] (may be null)
+    UnpackOut up;
+};
+template <int METRIC, int N16, bool SORTED>
+__global__ __launch_bounds__(MDB_BLOCK) void flat_small_scan_kernel(const float4* __restrict__ tiles, size_t n, size_t ntiles,
+                                                                   const float* __restrict__ q, int qstride, int k,
+                                                                   uint64_t* __restrict__ partial, uint32_t* __restrict__ flags, SmallFuse fu) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = threadIdx.x / MDB_WAVE, lane = threadIdx.x % MDB_WAVE;
+    const size_t tile = (size_t)blockIdx.x * (MDB_BLOCK / MDB_WAVE) + wave;
+    if (tile >= ntiles) return;
+    const size_t qi = blockIdx.y;
+    const float* qrow = q + qi * (size_t)qstride;
+    const size_t v = tile * MDB_TILE + lane;
+    const float4* tp = tiles + tile * (size_t)(4 * N16) * MDB_TILE + lane;
+    float4 x[4 * N16];
+#pragma unroll
+    for (int c = 0; c < 4 * N16; ++c) x[c] = tp[(size_t)c * MDB_TILE];
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < N16; ++c) {
+        const float xv[16] = {x[4 * c].x, x[4 * c].y, x[4 * c].z, x[4 * c].w, x[4 * c + 1].x, x[4 * c + 1].y, x[4 * c + 1].z, x[4 * c + 1].w,
+                              x[4 * c + 2].x, x[4 * c + 2].y, x[4 * c + 2].z, x[4 * c + 2].w, x[4 * c + 3].x, x[4 * c + 3].y, x[4 * c + 3].z, x[4 * c + 3].w};
+        const float* qc = qrow + 16 * c;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = acc_term<METRIC>(acc[j], qc[j], xv[j]);
+    }
+    uint64_t key = MDB_KEY_MAX;
+    if (v < n) {
+        const float dist = finish_distance<METRIC>(__fadd_rn(0.0f, reduce_ordered<16>(acc)));
+        if (dist != dist) atomicOr(flags, MDB_FLAG_NAN);
+        key = make_key(dist, (uint32_t)v);
+    }
+    if (SORTED) {
+        // ascending bitonic sort of the wave's 64 keys (lane i ends with the i-th smallest): its k smallest are one ascending list
+#pragma unroll
+        for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), j, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)key, j, 64);
+                const bool keep_min = ((lane & k2) == 0) == ((lane & j) == 0);
+                key = keep_min ? (o < key ? o : key) : (o > key ? o : key);
+            }
+        }
+        if (!fu.tickets) {
+            if (lane < k) partial[(qi * ntiles + tile) * (size_t)k + lane] = key;
+        } else {
+            // Hand-over WITHOUT fences: a release / acquire fence at agent scope is an L2 write-back / invalidate on this part, and 157
+            // of them made the launch 26 us instead of 6.  Everything that crosses waves here is an agent-scope atomic access instead —
+            // the list's stores, the ticket, the merging wave's loads (sc1: coherent at agent scope by themselves, nothing of it ever
+            // sits dirty or stale in an XCD's L2) — and the only ordering needed, list before ticket, is the wave's own s_waitcnt.
+            if (lane < k) __hip_atomic_store(&partial[(qi * ntiles + tile) * (size_t)k + lane], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint32_t t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(&fu.tickets[qi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            if (t != (uint32_t)ntiles - 1u) return;
+            if (lane == 0) __hip_atomic_store(&fu.tickets[qi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next call (stream order)
+            const uint32_t L = (uint32_t)ntiles;
+            const uint64_t* lists = partial + qi * ntiles * (size_t)k;
+            uint64_t* sl = (uint64_t*)lds;                              // [L][k]; behind it the lists' head positions
+            uint32_t* hp = (uint32_t*)(sl + (size_t)L * k);
+            for (uint32_t i = lane; i < L * (uint32_t)k; i += MDB_WAVE) sl[i] = __hip_atomic_load(lists + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t i = lane; i < L; i += MDB_WAVE) hp[i] = 0u;
+            constexpr int RMAX = 16;                                    // L <= 1024
+            uint64_t cur[RMAX];
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                const uint32_t l = (uint32_t)r * MDB_WAVE + lane;
+                cur[r] = l < L ? sl[(size_t)l * k] : MDB_KEY_MAX;
+            }
+            uint64_t mine = MDB_KEY_MAX;                                // lane j ends with the j-th smallest key
+            uint32_t c = 0;
+            for (int it = 0; it < k; ++it) {
+                uint64_t best = cur[0];
+#pragma unroll
+                for (int r = 1; r < RMAX; ++r) best = cur[r] < best ? cur[r] : best;
+                const uint32_t hi = mdb_wave_min_u32((uint32_t)(best >> 32));
+                const uint32_t lo = mdb_wave_min_u32((uint32_t)(best >> 32) == hi ? (uint32_t)best : 0xFFFFFFFFu);
+                const uint64_t win = ((uint64_t)hi << 32) | lo;
+                if (win == MDB_KEY_MAX) break;                          // (uniform) fewer than k keys in all
+                if (lane == it) mine = win;
+                ++c;
+                if (best == win) {                                      // one lane (row ids are unique): its list moves on
+#pragma unroll
+                    for (int r = 0; r < RMAX; ++r) {
+                        if (cur[r] == win) {
+                            const uint32_t l = (uint32_t)r * MDB_WAVE + lane;
+                            const uint32_t h = hp[l] + 1u;
+                            hp[l] = h;
+                            cur[r] = h < (uint32_t)k ? sl[(size_t)l * k + h] : MDB_KEY_MAX;
+                        }
+                    }
+                }
+            }
+            if (lane < k) {
+                const bool have = lane < (int)c;
+                if (fu.out) fu.out[qi * (size_t)k + lane] = have ? mine : MDB_KEY_MAX;
+                if (fu.up.ids) {
+                    fu.up.ids[qi * (size_t)k + lane] = have ? key_id(mine) : 0xFFFFFFFFu;
+                    if (fu.up.dist) fu.up.dist[qi * (size_t)k + lane] = have ? key_dist(mine) : __uint_as_float(0x7F800000u);
+                }
+            }
+            if (lane == 0) {
+                if (fu.counts) fu.counts[qi] = c;
+                if (fu.up.ids && fu.up.counts) fu.up.counts[qi] = c;
+            }
+            if (qi == 0) {
+                if (fu.up.zero4 && lane < 4) fu.up.zero4[lane] = 0ull;
+                if (fu.up.word_dst && lane == 0) *fu.up.word_dst = *fu.up.word_src;
+            }
+        }
+    } else {
+        partial[(qi * ntiles + tile) * (size_t)MDB_TILE + lane] = key;   // unordered: merge_keys_kernel's group form (fast == 3) bounds and ranks them
+    }
+}
+
 // Many ASCENDING partial lists of k keys (one query over a large base: a list per scan block) -> the k smallest, by a BOUND
 // instead of a selector: the k-th smallest of the lists' first keys has k distinct keys at or below it, so block_kth_bound over
 // the minima (one histogram, four barriers) gives a threshold T that only a few dozen keys pass; the lists whose minimum passes
@@ -203,6 +336,110 @@ __device__ __forceinline__ bool merge_lists_fast(const uint64_t* __restrict__ sr
     return true;
 }
 
+// The same for UNORDERED keys (flat_small_scan_kernel's tiles): thread t owns the G consecutive keys [t G, (t + 1) G) — 1024 disjoint
+// groups; the k-th smallest of the groups' minima has k distinct keys at or below it, so it bounds the k-th key; a second pass over
+// the (cache-resident) keys collects what passes, ranked by counting.  False (uniform) when more than MLF_CAP keys pass.
+__device__ __forceinline__ bool merge_groups_fast(const uint64_t* __restrict__ src, size_t nkeys, int k, uint64_t* __restrict__ res, uint32_t& c_out) {
+    __shared__ uint32_t ghist2[2 * (PQF_NB + 32)];
+    __shared__ uint64_t gcand[MLF_CAP];
+    __shared__ uint32_t gncand;
+    const int tid = threadIdx.x;
+    const size_t G = (nkeys + PQF_BLOCK - 1) / PQF_BLOCK;
+    const size_t lo = (size_t)tid * G, hi = min(nkeys, lo + G);
+    uint32_t v[1] = {0xFFFFFFFFu};
+    for (size_t i0 = lo; i0 < hi; i0 += 8) {
+        uint64_t kk[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) kk[x] = i0 + x < hi ? src[i0 + x] : MDB_KEY_MAX;
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+            if (kk[x] != MDB_KEY_MAX) v[0] = min(v[0], min((uint32_t)(kk[x] >> 32), 0xFFFFFFFEu));
+    }
+    kth_area_reset(ghist2);
+    if (tid == 0) gncand = 0;
+    __syncthreads();
+    int flip = 0;
+    const uint32_t T = block_kth_bound<1>(v, (uint32_t)k, ghist2, flip);   // all ones: fewer than k groups hold a key — everything passes
+    if (v[0] != 0xFFFFFFFFu && v[0] <= T) {
+        for (size_t i0 = lo; i0 < hi; i0 += 8) {
+            uint64_t kk[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) kk[x] = i0 + x < hi ? src[i0 + x] : MDB_KEY_MAX;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                if (kk[x] != MDB_KEY_MAX && min((uint32_t)(kk[x] >> 32), 0xFFFFFFFEu) <= T) {
+                    const uint32_t pos = atomicAdd(&gncand, 1u);
+                    if (pos < MLF_CAP) gcand[pos] = kk[x];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nc = gncand;
+    if (nc > MLF_CAP) return false;
+    for (uint32_t i = tid; i < nc; i += PQF_BLOCK) {
+        const uint64_t key = gcand[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nc; ++j) {
+            const uint64_t o = gcand[j];
+            rank += (o < key || (o == key && j < i)) ? 1u : 0u;
+        }
+        if (rank < (uint32_t)k) res[rank] = key;
+    }
+    __syncthreads();
+    c_out = min(nc, (uint32_t)k);
+    return true;
+}
+
+// L <= BLOCK ascending lists of k <= 64 keys (flat_small_scan_kernel: one per tile of a small base) -> the k smallest, exactly and
+// without a selector or a histogram: the k-th smallest of the lists' FIRST keys (ranked by counting — keys are unique) has exactly
+// min(k, L) lists at or below it, so only those lists can hold one of the k smallest keys and at most k * k keys pass; they are
+// ranked by counting as well.  Three barriers.
+#define MFL_CAP (64 * 64)
+template <int BLOCK>
+__device__ __forceinline__ void merge_few_lists(const uint64_t* __restrict__ src, uint32_t L, int k, uint64_t* __restrict__ res, uint32_t& c_out,
+                                                uint64_t* mins /*[BLOCK]*/, uint64_t* cand /*[MFL_CAP]*/, uint32_t* word /*[2]: ncand, - */, uint64_t* thr) {
+    const int tid = threadIdx.x;
+    // the list's first 16 keys in ONE memory trip (what another XCD wrote comes from the memory side: ~1.7 us a trip, and the step is
+    // a handful of them): k <= 16 never goes back to memory
+    const uint64_t* lp = src + (size_t)tid * k;
+    uint64_t k0[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) k0[x] = ((uint32_t)tid < L && x < k) ? lp[x] : MDB_KEY_MAX;
+    const uint64_t m = k0[0];
+    mins[tid] = m;
+    if (tid == 0) { word[0] = 0; *thr = MDB_KEY_MAX; }
+    __syncthreads();
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < L; ++j) r += mins[j] < m ? 1u : 0u;
+    if (m != MDB_KEY_MAX && r == (uint32_t)k - 1u) *thr = m;        // (fewer than k lists with a key: the threshold stays "everything")
+    __syncthreads();
+    const uint64_t T = *thr;
+    if (m != MDB_KEY_MAX && m <= T) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+            if (k0[x] != MDB_KEY_MAX && k0[x] <= T) cand[atomicAdd(&word[0], 1u)] = k0[x];
+        for (int j0 = 16; j0 < k; j0 += 16) {
+            uint64_t kk[16];
+#pragma unroll
+            for (int x = 0; x < 16; ++x) kk[x] = j0 + x < k ? lp[j0 + x] : MDB_KEY_MAX;
+#pragma unroll
+            for (int x = 0; x < 16; ++x)
+                if (kk[x] != MDB_KEY_MAX && kk[x] <= T) cand[atomicAdd(&word[0], 1u)] = kk[x];
+        }
+    }
+    __syncthreads();
+    const uint32_t nc = word[0];
+    for (uint32_t i = tid; i < nc; i += BLOCK) {
+        const uint64_t key = cand[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nc; ++j) rank += cand[j] < key ? 1u : 0u;
+        if (rank < (uint32_t)k) res[rank] = key;
+    }
+    __syncthreads();
+    c_out = min(nc, (uint32_t)k);
+}
+
 // one block per query: stream `per_query` candidate keys, keep the k smallest, ascending.  The partial
 // lists are sorted, so the first round already holds good keys and warm_start bounds the rest.
 template <int BLOCK>
@@ -221,14 +458,29 @@ __global__ __launch_bounds__(BLOCK) void merge_keys_kernel(const uint64_t* __res
     const uint64_t* rb = sel.buf;
     uint32_t c = 0;
     bool done = false;
+    if constexpr (BLOCK != PQF_BLOCK) {
+        if (fast == 2 && L >= 1 && L <= (size_t)BLOCK && k <= 64) {   // a handful of ascending lists (small bases)
+            uint64_t* mf = (uint64_t*)lds;                             // (the selector's LDS is unused on this path: launch_merge_keys sizes it for both)
+            __shared__ uint32_t mf_word[2];
+            __shared__ uint64_t mf_thr;
+            merge_few_lists<BLOCK>(src, (uint32_t)L, k, fres, c, mf, mf + BLOCK, mf_word, &mf_thr);
+            rb = fres;
+            done = true;
+        }
+    }
     if constexpr (BLOCK == PQF_BLOCK) {
-        if (fast && L >= BLOCK / 2 && L <= (size_t)MLF_R * BLOCK && k <= 64) {
+        if (fast == 3) {   // unordered keys (flat_small_scan_kernel); too many ties at the k-th distance: the streaming selector below
+            if (k <= 64 && per_query <= (size_t)64 * BLOCK) {
+                done = merge_groups_fast(src, per_query, k, fres, c);
+                rb = fres;
+            }
+        } else if (fast && (L >= BLOCK / 2 || (fast == 2 && L >= 1)) && L <= (size_t)MLF_R * BLOCK && k <= 64) {
             done = merge_lists_fast(src, L, k, fres, c);
             rb = fres;
         }
     }
     if (done) {
-    } else if (L >= BLOCK / 2) {
+    } else if (L >= BLOCK / 2 && fast != 3) {
         // many sorted partial lists (one query over a large base): thread = list, round j offers every list's j-th
         // key.  Round 0 holds the list minima, so the warm-start threshold is already close to the final one and
         // almost nothing is admitted afterwards (linear order admitted ~15 % of the keys and sorted a full queue).
@@ -285,9 +537,15 @@ __global__ __launch_bounds__(BLOCK) void merge_keys_kernel(const uint64_t* __res
 }
 
 static void launch_merge_keys(mdb_ctx* ctx, const uint64_t* d_partial, size_t per_query, size_t b, size_t k, uint64_t* d_out,
-                              uint32_t* d_counts, const uint32_t* gate, const UnpackOut* unpack = nullptr) {
+                              uint32_t* d_counts, const uint32_t* gate, const UnpackOut* unpack = nullptr, bool lists = false, bool sorted = true) {
     const UnpackOut up = unpack ? *unpack : UnpackOut{};
-    if (per_query >= 2048)  // many partial lists (one query over a large base): 4x fewer rounds
+    if (lists && sorted && per_query / std::max<size_t>(k, 1) <= MDB_BLOCK && k <= 64)   // a handful of ascending lists: merge_few_lists
+        merge_keys_kernel<MDB_BLOCK><<<dim3((unsigned)b), MDB_BLOCK, std::max<size_t>(BlockSelect<MDB_BLOCK>::lds_bytes((int)k), (MDB_BLOCK + MFL_CAP) * 8),
+                                       ctx->stream>>>(d_partial, per_query, (int)k, d_out, d_counts, gate, up, 2);
+    else if (lists)  // ascending lists (bound + rank over up to 4096 of them) or unordered keys (flat_small_scan_kernel's MDB_FLAT_NO_SMALL=2 form: bound over 1024 thread groups)
+        merge_keys_kernel<1024><<<dim3((unsigned)b), 1024, BlockSelect<1024>::lds_bytes((int)k), ctx->stream>>>(d_partial, per_query, (int)k,
+                                                                                                               d_out, d_counts, gate, up, sorted ? 2 : 3);
+    else if (per_query >= 2048)  // many partial lists (one query over a large base): 4x fewer rounds
         merge_keys_kernel<1024><<<dim3((unsigned)b), 1024, BlockSelect<1024>::lds_bytes((int)k), ctx->stream>>>(d_partial, per_query, (int)k,
                                                                                                                d_out, d_counts, gate, up,
                                                                                                                ctx->opt.flat_merge_old ? 0 : 1);
@@ -435,6 +693,61 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     // four selectors per block: 2 queries per block, twice the blocks (measured on the C3 coarse step)
     const bool l2_resident = ts.ntiles * (size_t)ts.d4 * MDB_TILE * 16 <= (8u << 20);
     if (l2_resident && qt > 2 && ctx->opt.flat_qt <= 0) qt = 2;
+    DistPlan p = make_plan(ts.d, metric);
+    // small base, a handful of queries: one wave per (tile, query), every load in flight, lists merged by bound + rank
+    if (b <= 4 && k >= 1 && k <= 64 && ts.ntiles >= 1 && ts.ntiles <= 1024 && p.n16 >= 1 && p.n16 <= 8 && p.n8 == 0 && p.n4 == 0 && p.ntail == 0 &&
+        !gate && ctx->opt.flat_no_small != 1) {
+        void* partial;
+        MDB_TRY(mdb_scratch(ctx, 4, (size_t)ts.ntiles * b * MDB_TILE * 8, &partial));
+        const bool sorted = ctx->opt.flat_no_small != 2;   // 2: the waves store their keys unordered, the merge bounds 1024 thread groups (measured slower)
+        // one launch: the wave that takes a query's last ticket merges (3: two launches, for comparison).  Tickets: d_counters words
+        // 28-29 read as four u32 (zero from the context's creation on, re-armed by every merging wave)
+        const size_t fuse_bytes = ts.ntiles * k * 8 + ts.ntiles * 4;
+        // (measured: the fused launch takes 20.6 us against 5.2 + 4 for the two launches — 157 agent-scope atomics on ONE ticket word
+        // serialise at the memory side, ~0.1 us each, fences or not; kept behind MDB_FLAT_NO_SMALL=4 for the record)
+        const bool fused = sorted && k <= 16 && fuse_bytes <= 48 * 1024 && ctx->opt.flat_no_small == 4;
+        const size_t fuse_lds = fused ? fuse_bytes : 0;
+        SmallFuse fu;
+        if (fused) {
+            fu.tickets = (uint32_t*)(ctx->d_counters + 28);
+            fu.out = d_keys; fu.counts = d_counts;
+            if (unpack) fu.up = *unpack;
+        }
+        const dim3 grid((unsigned)((ts.ntiles + 3) / 4), (unsigned)b);
+        const float4* tiles = (const float4*)ts.data;
+        bool saved = ctx->prof_on;
+        ctx->prof_on = saved && profile;
+        {
+            ProfScope prof(ctx);
+            ctx->prof_on = saved;
+#define MDB_SMALL_GO(METRIC, N)                                                                                                        \
+    do {                                                                                                                               \
+        if (sorted) flat_small_scan_kernel<METRIC, N, true><<<grid, MDB_BLOCK, fuse_lds, ctx->stream>>>(tiles, ts.n, ts.ntiles, dq, qstride, (int)k, (uint64_t*)partial, ctx->d_flags, fu); \
+        else flat_small_scan_kernel<METRIC, N, false><<<grid, MDB_BLOCK, 0, ctx->stream>>>(tiles, ts.n, ts.ntiles, dq, qstride, (int)k, (uint64_t*)partial, ctx->d_flags, SmallFuse{});     \
+    } while (0)
+#define MDB_SMALL_N(METRIC)                        \
+    switch (p.n16) {                               \
+        case 1: MDB_SMALL_GO(METRIC, 1); break;    \
+        case 2: MDB_SMALL_GO(METRIC, 2); break;    \
+        case 3: MDB_SMALL_GO(METRIC, 3); break;    \
+        case 4: MDB_SMALL_GO(METRIC, 4); break;    \
+        case 5: MDB_SMALL_GO(METRIC, 5); break;    \
+        case 6: MDB_SMALL_GO(METRIC, 6); break;    \
+        case 7: MDB_SMALL_GO(METRIC, 7); break;    \
+        default: MDB_SMALL_GO(METRIC, 8); break;   \
+    }
+            if (metric == MDB_METRIC_L2) { MDB_SMALL_N(MDB_METRIC_L2) }
+            else if (metric == MDB_METRIC_L2SQ) { MDB_SMALL_N(MDB_METRIC_L2SQ) }
+            else { MDB_SMALL_N(MDB_METRIC_DOT) }
+#undef MDB_SMALL_N
+#undef MDB_SMALL_GO
+            MDB_HIP(ctx, hipGetLastError());
+        }
+        if (!fused)
+            launch_merge_keys(ctx, (const uint64_t*)partial, (size_t)ts.ntiles * (sorted ? k : (size_t)MDB_TILE), b, k, d_keys, d_counts, nullptr, unpack, true, sorted);
+        MDB_HIP(ctx, hipGetLastError());
+        return MDB_OK;
+    }
     size_t bpad = (b + qt - 1) / qt * qt;
     size_t ngroups = (ts.ntiles + 3) / 4;
     // blocks: enough to fill the chip (~4 per CU), but several rounds per block when there are many query
@@ -448,7 +761,6 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
     while (nblk > 32 && (size_t)nblk * bpad * std::max<size_t>(k, 1) * 8 > (256u << 20)) nblk /= 2;
     void* partial;
     MDB_TRY(mdb_scratch(ctx, 4, (size_t)nblk * bpad * std::max<size_t>(k, 1) * 8, &partial));
-    DistPlan p = make_plan(ts.d, metric);
     bool saved = ctx->prof_on;
     ctx->prof_on = saved && profile;
     {

@@ -1736,6 +1736,7 @@ mdb_status HnswSet::search(const float* d_q, int qstride, size_t b, const uint32
     if (fuse) fuse->done = false;
     if (cf) cf->done = false;
     if (b == 0) return MDB_OK;
+    ctx->counters_clean = false;   // this writes d_counters[0..3]: whoever relies on "still zero from the last call" (spann_search_impl) re-arms the flag AFTER it
     if (ef == 0) ef = 1;  // `len < ef` is never true and every push is followed by a pop: same as ef = 1
     if (ef > MDB_MAX_K * 2) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "ef=%u exceeds %d", ef, MDB_MAX_K * 2);
     HnswArgs a{};

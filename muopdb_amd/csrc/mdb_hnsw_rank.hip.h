@@ -273,6 +273,7 @@ __device__ __forceinline__ void upper_traverse_rank(const HnswUpArgs& a, const i
     // value derived from it — entry point, counters, the whole loop's control flow — is compiled as per-lane state under exec masks)
     const int qi = (int)rk_first((uint32_t)qi_in);
     uint32_t* const fr = (uint32_t*)(lds + UP_LDS_FR);
+    uint32_t* const dummy = (uint32_t*)(lds + UP_LDS_FLAG);   // 64 words nobody reads: where the idle lanes of a branch-free LDS atomic land
     const int ef = a.ef;
     const uint32_t su = a.su;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -362,7 +363,7 @@ __device__ __forceinline__ void upper_traverse_rank(const HnswUpArgs& a, const i
             const uint32_t nbr = (uint32_t)lane < su ? rowv : 0xFFFFFFFFu;
             const bool valid = nbr != 0xFFFFFFFFu;
             const uint32_t bit = 1u << (nbr & 31);
-            const uint32_t old = atomicOr(&vis[valid ? nbr >> 5 : 0u], valid ? bit : 0u);
+            const uint32_t old = atomicOr(valid ? &vis[nbr >> 5] : &dummy[lane], valid ? bit : 0u);   // (idle lanes: a word each, not one word for all)
             const uint32_t rv = (uint32_t)R[valid ? nbr : 0u];
             // ---- the runner-up's row is requested while they land
             bool ru_ok = false;
@@ -485,6 +486,7 @@ __device__ __forceinline__ void upper_traverse_rank1(const HnswUpArgs& a, const 
     // value derived from it — entry point, counters, the whole loop's control flow — is compiled as per-lane state under exec masks)
     const int qi = (int)rk_first((uint32_t)qi_in);
     uint32_t* const fr = (uint32_t*)(lds + UP_LDS_FR);
+    uint32_t* const dummy = (uint32_t*)(lds + UP_LDS_FLAG);   // 64 words nobody reads: where the idle lanes of a branch-free LDS atomic land
     uint32_t* const stage = (uint32_t*)(lds + UP_LDS_STAGE);   // 64 words, zero between uses
     const int ef = a.ef;
     const uint32_t su = a.su;
@@ -588,7 +590,7 @@ __device__ __forceinline__ void upper_traverse_rank1(const HnswUpArgs& a, const 
             const uint32_t nbr = (uint32_t)lane < su ? rowv : 0xFFFFFFFFu;
             const bool valid = nbr != 0xFFFFFFFFu;
             const uint32_t bit = 1u << (nbr & 31);
-            const uint32_t old = atomicOr(&vis[valid ? nbr >> 5 : 0u], valid ? bit : 0u);
+            const uint32_t old = atomicOr(valid ? &vis[nbr >> 5] : &dummy[lane], valid ? bit : 0u);   // (idle lanes: a word each, not one word for all)
             const uint32_t rv = (uint32_t)R[valid ? nbr : 0u];
             // ---- the runner-up's row is requested while they land
             bool ru_ok = false;
@@ -610,7 +612,7 @@ __device__ __forceinline__ void upper_traverse_rank1(const HnswUpArgs& a, const 
             if (hm) {
                 if (len + (int)nnew <= ef) {
                     // ---- fill phase: `len < ef` accepts every new neighbour, nothing is evicted
-                    atomicOr(&stage[have ? rk >> 5 : 0u], have ? 1u << (rk & 31) : 0u);
+                    atomicOr(have ? &stage[rk >> 5] : &dummy[lane], have ? 1u << (rk & 31) : 0u);
                     __atomic_signal_fence(__ATOMIC_SEQ_CST);      // (LDS executes a wave's operations in order; this keeps the compiler's order)
                     __builtin_amdgcn_wave_barrier();
                     const uint32_t add = lds_vload(&stage[lane]);
@@ -624,6 +626,8 @@ __device__ __forceinline__ void upper_traverse_rank1(const HnswUpArgs& a, const 
                     const uint32_t La = 63u - (uint32_t)__builtin_clzll(am);
                     rf = (La << 5) | (31u - (uint32_t)__builtin_clz(rk_readlane(A, La)));
                     UP_CNT(8, nnew);
+                    UP_T(tf);
+                    UP_ACC(11, tf - t2); UP_ACC(4, 1);
                 } else {
                     // ---- acceptance in edge order: `d_e < furthest.d || len < ef`, then push + evict (index.rs:262-281)
                     unsigned long long surv = len >= ef ? __ballot(have && rk < rf) : hm;

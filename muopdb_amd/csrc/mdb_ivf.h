@@ -39,7 +39,7 @@ struct U128Hash {
 
 size_t mdb_points_block_bytes_impl(size_t b, size_t k);
 
-// operands of the fused IVF-PQ step's coarse search on the matrix cores (mdb_ivf_coarse.hip.h), built at load for ONE L2 PQ index
+// operands of the fused IVF-PQ step's coarse search on the matrix cores (mdb_ivf_coarse.hip.h), built at load for ONE index (PQ codes or f32 rows: coarse() serves unquantized IVF as well)
 // with 1024 .. 16384 centroids of 64 / 96 / 128 / 192 / 256 dimensions; empty otherwise (the step keeps ivf_prep_kernel)
 struct CoarseMfma {
     DevBuf<uint4> chi;           // bf16 fragments of the centred centroids
@@ -98,6 +98,9 @@ struct IvfSet {
     mdb_status stage_filter(const uint32_t* allow, size_t n_bitmaps, size_t words, mdb_mem mem, size_t b, ScanFilter* out,
                             const uint32_t* q_user = nullptr);
 
+    // set to false BEFORE load by owners whose centroids are searched by a graph (Spann: spann/index.rs:211-228 — coarse() and
+    // search_fused are never reached): the load then skips the coarse search's accelerator copies (CoarseMfma: ~1.5 x the centroids)
+    bool coarse_by_scan = true;
     mdb_status load(mdb_ctx* ctx, const uint8_t* index, size_t index_len, const uint8_t* vectors, size_t vectors_len,
                     const std::vector<std::pair<size_t, size_t>>& offsets, const mdb_quant_desc* quant,
                     uint32_t shard_rank, uint32_t shard_world);

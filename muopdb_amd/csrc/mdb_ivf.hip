@@ -2074,7 +2074,7 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
         // path (sample bound + matrix-core filter + exact refine) — the same probe ids, several times faster
         // one index with a mid-sized coarse quantizer (C3: 4096 lists): find_nearest_centroids — inside the fused step or alone — runs on the matrix
         // cores (mdb_ivf_coarse.hip.h); an optional accelerator — cm_build leaves it empty when memory is short
-        if (U == 1 && ctx->opt.ivf_coarse_mfma) {   // (find_nearest_centroids is sqrt-L2 whatever the index's metric: index.rs:155)
+        if (U == 1 && coarse_by_scan && ctx->opt.ivf_coarse_mfma) {   // (find_nearest_centroids is sqrt-L2 whatever the index's metric: index.rs:155)
             TileView cv{d_cent_tiles.p, blobs[0].num_clusters, (blobs[0].num_clusters + MDB_TILE - 1) / MDB_TILE, (int)num_features, d4};
             MDB_TRY(cm_build(ctx, cv, cmf));
         }
@@ -2285,6 +2285,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
                         const uint32_t* d_probe_cnt, int probe_stride, size_t k, uint64_t* d_keys, uint32_t* d_counts,
                         const ScanFilter* filter, ScanRemap* rm) {
     if (b == 0) return MDB_OK;
+    ctx->counters_clean = false;   // this writes d_counters[0..3]: whoever relies on "still zero from the last call" (spann_search_impl) re-arms the flag AFTER it
     if (k > MDB_MAX_K) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "k=%zu exceeds MDB_MAX_K=%d", k, MDB_MAX_K);
     static const ScanFilter no_filter{};
     const ScanFilter& f = filter && filter->allow ? *filter : no_filter;
@@ -2508,6 +2509,7 @@ bool IvfSet::fused_ok(size_t b, size_t k, size_t num_probes, bool have_probes) c
 mdb_status IvfSet::search_fused(const float* d_q, int qstride, size_t b, const uint32_t* d_probes, size_t num_probes, size_t k,
                                 const ScanFilter* filter, uint64_t* d_keys, uint32_t* d_counts, mdb_u128* d_doc, float* d_score,
                                 uint32_t* d_doc_counts) {
+    ctx->counters_clean = false;   // this writes d_counters[0..3]: whoever relies on "still zero from the last call" (spann_search_impl) re-arms the flag AFTER it
     static const ScanFilter no_filter{};
     const ScanFilter& f = filter && filter->allow ? *filter : no_filter;
     if (f.allow && f.n_bitmaps != 1 && f.n_bitmaps < b)
@@ -2689,6 +2691,7 @@ mdb_status IvfSet::merge_points(const void* d_blocks, size_t world, size_t b, si
 // stable sort leave equal distances implementation-defined; this path orders them by index]
 mdb_status IvfSet::coarse(size_t ui, const float* d_q, int qstride, size_t b, size_t num_probes, uint32_t* d_probes, bool zero_counters,
                           size_t bpad) {
+    ctx->counters_clean = false;   // this writes d_counters[0..3]: whoever relies on "still zero from the last call" (spann_search_impl) re-arms the flag AFTER it
     const IvfBlobInfo& bi = blobs[ui];
     if (num_probes == 0 || num_probes > bi.num_clusters)
         return mdb_fail(ctx, MDB_ERR_OUT_OF_RANGE, "num_probes=%zu out of range (num_clusters=%u): the reference panics in select_nth_unstable_by",

@@ -193,6 +193,9 @@ __global__ __launch_bounds__(CM_BLOCK) void ivf_coarse_mfma_kernel(CoarseArgs a)
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) pool[l31 * (PV + 1) + (wave * 2 + hi) * J + j] = top[j];
+    // no pooled value of rank P - 1 (only if 16 J < P: cm_shape rules it out) must read as "no bound" — every centroid a candidate
+    // (cm_threshold) —, never as whatever the word held
+    if (tid < 32) tts[tid] = -__uint_as_float(0x7F800000u);
     __syncthreads();
     CM_STAMP(3);
     {   // the P-th largest of the query's pooled values (distinct centroids); ties ordered by their place in the pool
@@ -688,6 +691,7 @@ static inline CoarseShape cm_shape(const CoarseMfma& cm, size_t b, size_t P, uin
     s.S = (uint32_t)((cm.nt32 + s.tps - 1) / s.tps);                       // <= 16 (cm_build: at most 16384 centroids)
     s.caps = std::min<uint32_t>(512u, cap_total / s.S);
     s.J = P <= 8 ? 1 : P <= 16 ? 2 : P <= 32 ? 4 : 8;                      // 16 J pooled values per query >= 2 P (P <= 64)
+    while (16 * s.J < (int)P && s.J < 8) s.J *= 2;                         // the bound needs a pooled value of rank P - 1: 16 J >= P (cm_usable: P <= 64 = 16 x 8 / 2)
     return s;
 }
 

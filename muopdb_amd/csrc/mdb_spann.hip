@@ -387,6 +387,7 @@ mdb_status mdb_spann_load(mdb_ctx* ctx, const void* hnsw_index, size_t hnsw_inde
     MDB_HIP(ctx, hipSetDevice(ctx->device));
     mdb_spann* sp = new mdb_spann();
     sp->set.ctx = ctx;
+    sp->set.ivf.coarse_by_scan = false;
     mdb_status st = sp->set.ivf.load(ctx, (const uint8_t*)ivf_index, ivf_index_len, (const uint8_t*)ivf_vectors, ivf_vectors_len,
                                      {{ivf_index_offset, ivf_vectors_offset}}, quant, 0, 1);
     if (st == MDB_OK) {
@@ -527,6 +528,7 @@ mdb_status mdb_multi_spann_load(mdb_ctx* ctx, const mdb_user_index_info* users, 
         ioff.push_back({(size_t)users[i].ivf_index_offset, (size_t)users[i].ivf_vectors_offset});
         ms->set.user_index[U128Key{users[i].user_id.lo, users[i].user_id.hi}] = (uint32_t)i;
     }
+    ms->set.ivf.coarse_by_scan = false;
     mdb_status st = ms->set.ivf.load(ctx, (const uint8_t*)ivf_index, ivf_index_len, (const uint8_t*)ivf_vectors, ivf_vectors_len, ioff,
                                      quant, shard_rank, shard_world);
     if (st == MDB_OK && ms->set.ivf.num_features != num_features)

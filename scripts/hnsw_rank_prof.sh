@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/hnsw_rank; mkdir -p $OUT
 DUMP=/tmp/mdb_dump_rank
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python $REPO/bench.py --workload hnsw --no-cpu-baseline --no-sweep --no-insert-graph --streams 0 --steps 5 --dump-dir $DUMP > $OUT/bench.log 2>&1
-for R in 1 0; do
+for R in ${RANKS:-3 2 0}; do
   rm -rf /tmp/prof_rank_$R
   MDB_HNSW_RANK=$R timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_rank_$R -o replay -- $REPO/muopdb_amd/replay_search hnsw $DUMP/hnsw 128 10 ${EF:-200} ${B:-64} 40 > $OUT/replay_$R.log 2>&1
   cp /tmp/prof_rank_$R/*kernel_stats.csv $OUT/kernel_stats_rank$R.csv

@@ -161,6 +161,33 @@ def test_flat_c1_dataset_and_ties(ctx, oracle):
     assert ids2[0, :4].tolist() == [0, 1, 2, 3]
 
 
+@pytest.mark.parametrize("n,d,b,k,metric", [(10000, 128, 1, 10, 0), (10000, 128, 3, 64, 0), (65536, 16, 4, 10, 1), (63, 48, 2, 64, 0), (1, 128, 1, 5, 0),
+                                            (4100, 96, 1, 1, 1), (129, 112, 4, 33, 0)])
+def test_flat_small_base_kernel(ctx, oracle, n, d, b, k, metric):
+    """flat_small_scan_kernel (bases of <= 1024 tiles, batches <= 4, d = 16 .. 128 in whole chunks: BASELINE config 1's shape) — one wave
+    per tile, the wave's keys ordered by a shuffle network, the lists merged by bound + rank — gives the oracle's rows bit for bit,
+    incl. duplicated rows (ties ordered by row id), k above the number of rows, a short last tile, and the general kernel's rows."""
+    from muopdb_amd.index import FlatIndex
+    rng = np.random.default_rng(n * 7 + d)
+    base = np.rint(rng.standard_normal((n, d)) * 3).astype(np.float32)      # coarse values: plenty of exact distance ties
+    if n > 200:
+        base[100:140] = base[7]                                              # 41 copies of one row
+    q = np.rint(rng.standard_normal((b, d)) * 3).astype(np.float32)
+    if n > 200:
+        q[0] = base[7]
+    idx = FlatIndex(ctx, base, metric)
+    ids, dist, counts = idx.search(q, k)
+    oids, odist = oracle.flat_topk(metric, base, q, k)
+    kk = min(k, n)
+    assert counts.tolist() == [kk] * b
+    assert np.array_equal(ids[:, :kk], oids[:, :kk])
+    assert np.array_equal(dist[:, :kk].view(np.uint32), odist[:, :kk].view(np.uint32))
+    assert np.all(ids[:, kk:] == 0xFFFFFFFF)
+    with ctx.option("MDB_FLAT_NO_SMALL", 1):
+        ids2, dist2, counts2 = idx.search(q, k)
+    assert np.array_equal(ids, ids2) and np.array_equal(dist.view(np.uint32), dist2.view(np.uint32)) and np.array_equal(counts, counts2)
+
+
 def test_flat_batched_filter_rows_with_infinite_components(ctx, oracle):
     """scripts/stress_parity.py case 3900 (round 4): 70 000 x 30 rows, one in fifty with an infinite component, batch 33, top-200.
     With one bf16 product per pair the sample's bounds of such rows are inf - inf = NaN made by the bound's own arithmetic, and the

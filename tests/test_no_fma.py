@@ -22,8 +22,8 @@ from muopdb_amd import lib as L
 LLVM = "/opt/rocm/lib/llvm/bin"
 FUSED = re.compile(r"\b(v_fma_f|v_fmac_f|v_mad_f|v_mac_f|v_pk_fma|v_pk_mad|v_fmaak|v_fmamk|v_madak|v_madmk|v_dot\d|v_mfma)")
 # kernels whose results carry the reference's lane association (every distance that is RETURNED or RANKED exactly)
-EXACT = re.compile(r"(flat_scan_kernel|flat_refine_kernel|ivf_scan_f32_kernel|ivf_scan_pq2?_kernel|ivf_pq3_refine_kernel|ivf_pq_fused_kernel|ivf_prep_kernel|"
-                   r"hnsw_(beam|search|closure|pipe|select)_kernel|"
+EXACT = re.compile(r"(flat_scan_kernel|flat_small_scan_kernel|flat_refine_kernel|ivf_scan_f32_kernel|ivf_scan_pq2?_kernel|ivf_pq3_refine_kernel|ivf_pq_fused_kernel|ivf_prep_kernel|ivf_coarse_rank_kernel|merge_rows_remap_kernel|"
+                   r"hnsw_(beam|search|closure|pipe|select)_kernel|hnsw_upper_(top|top_rank|table\w*)_kernel|"
                    r"pair_distance_kernel|lane_conforming_kernel|pq_quantize_kernel|pq_distance_kernel|pq_rows_kernel|spann_filter_kernel|"
                    r"kmeans_assign_kernel)")
 # kernels whose hot loops must address LDS as LDS: a `volatile` access through a generic pointer is never rewritten to the LDS
@@ -60,7 +60,9 @@ def test_exact_kernels_contain_no_fused_multiply_add(tmp_path):
             if not cur or not ins:
                 continue
             if FUSED.search(ins):
-                near_sqrt = any(r.startswith(("v_sqrt_f32", "v_rsq_f32")) for r in recent[-32:])
+                # (a table kernel finishes the square roots of several queries' distances together: their refinement steps interleave, so a
+                # residual sits further behind its v_sqrt; the NEGATED operand is what tells a residual from a contracted accumulate)
+                near_sqrt = any(r.startswith(("v_sqrt_f32", "v_rsq_f32")) for r in recent[-160:])
                 near_rcp = any(r.startswith("v_rcp_") for r in recent[-32:])
                 sqrt_residual = ins.startswith("v_fma_f32") and re.search(r", -v\d+", ins) and near_sqrt
                 int_division = near_rcp and (re.search(r"0x[4c]f800000", ins) or re.search(r"v_fmac_f32_e32 v\d+, 0, v\d+", ins))
