@@ -526,10 +526,10 @@ def run_hnsw(env, batch=None, graph=None, n=None, extras=True, steps=None, warm=
                             % ("SIFT-1M" if args.sift_dir else "SIFT-1M-like synthetic", n, d, desc, args.max_neighbors, ef, k, batch, how),
                 "n": n, "dim": d, "batch": batch, "ef": ef, "k": k, "index": "hnsw", "graph": graph,
                 "data": "sift1m" if args.sift_dir else args.data, "parallelism": "replica x%d" % world, "graph_build_s": build_s},
-        # ef <= 448: the traversal is three kernels — the upper layers' distance table (fused with the top layers' traversal for batches
-        # >= 32), their single-wave traversal and the layer-0 instance of the beam kernel (mdb_hnsw_upper.hip; 5 beam registers up to ef
-        # 256, 8 above); the bracket is their sum, the algorithmic bytes are the whole traversal's
-        roofline=hbm_roofline("hnsw_upper_top_kernel|hnsw_upper_table*_kernel+hnsw_upper_kernel+hnsw_beam_kernel<L0>" if ef <= 448 else "hnsw_search_kernel",
+        # ef <= 448: the traversal is three kernels — the upper layers' distance table (fused with the top layers' traversal — on sorted
+        # positions since round 6, mdb_hnsw_rank.hip.h — for batches >= 32), layer 1's single-wave traversal and the layer-0 instance of
+        # the beam kernel (mdb_hnsw_upper.hip); the bracket is their sum, the algorithmic bytes are the whole traversal's
+        roofline=hbm_roofline("hnsw_upper_top_rank_kernel|hnsw_upper_table*_kernel+hnsw_upper_kernel+hnsw_beam_kernel<L0>" if ef <= 448 else "hnsw_search_kernel",
                               abytes / steps, kernel_ms, launches,
                               evals_per_query=evals / (steps * batch), expanded_per_query=expanded / (steps * batch)),
     )
@@ -633,7 +633,10 @@ def run_flat(env, n=None, batch=None, steps=None, warm=None):
     out = dict(value=steps * batch / elapsed, ms_per_step=1000 * elapsed / steps, recall_at_10=rec,
                config={"workload": "flat brute-force L2 %dx%d f32 (%s), batch=%d, top-%d (row-sharded x%d)" % (n, d, desc, batch, k, world),
                        "n": n, "dim": d, "batch": batch, "k": k, "index": "flat", "data": args.data},
-               roofline=hbm_roofline("flat_bf16_filter_kernel" if batched else "flat_scan_kernel", abytes, kernel_ms, launches))
+               # batches <= 4 over bases of <= 1024 tiles (C1) take flat_small_scan_kernel (one wave per tile, no block selector)
+               roofline=hbm_roofline("flat_bf16_filter_kernel" if batched else
+                                     ("flat_small_scan_kernel" if batch <= 4 and (hi - lo) <= 65536 and d % 16 == 0 and d <= 128 and k <= 64 else "flat_scan_kernel"),
+                                     abytes, kernel_ms, launches))
     finish(out, disp, abytes)   # the step's algorithmic bytes: the base once (however many passes the filter takes)
     out.update(hbm)
     out["steps"], out["warmup"] = steps, warm

@@ -345,8 +345,16 @@ struct HnswUpArgs {
 // wave 0 of the block (64 lanes): layers a.layer_hi .. a.layer_lo on the table row `tq`, visited set `vis` (LDS, initialised by the
 // caller), then the hand-over.  `vis_out`: LDS scratch of a.out_words words when a.vis_map is set.
 template <int NB>
-__device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const int qi, const int lane, char* lds, const uint32_t* tq,
+__device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const int qi_in, const int lane, char* lds, const uint32_t* tq,
                                                      uint32_t* vis, uint32_t* vis_out) {
+    // Round 6 (found with `opt -passes=print<uniformity>` while the sorted-position kernels were built): the block index reaches
+    // this function through phis behind the block's per-thread set-up loops, and the per-lane branches that were inside the step
+    // (`lane < su` around the row load, `valid` around the LDS atomic and the table lookup, `lane == 0` around the entry point's
+    // mark) joined in blocks that also carried the loop's scalars — so `stop`, `overflow`, `ru_valid`, the counters ... were all
+    // per-lane values to the compiler, and the loop's control flow was exec-mask code with its state in VGPRs and lane masks.
+    // The block index is named uniform again and those accesses are branch-free (idle lanes: a clamped address / a word of their own).
+    const int qi = __builtin_amdgcn_readfirstlane(qi_in);
+    uint32_t* const dummy = (uint32_t*)(lds + UP_LDS_FLAG);   // 64 words an OR of 0 leaves alone
     uint64_t* const C = (uint64_t*)(lds + UP_LDS_STAGE);
     uint32_t* const stage_flag = (uint32_t*)(lds + UP_LDS_FLAG);
     uint32_t* const fr = (uint32_t*)(lds + UP_LDS_FR);
@@ -372,7 +380,9 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
 
     for (int layer = a.layer_hi; layer >= a.layer_lo && !overflow; --layer) {
         const uint32_t* const lrows = a.rows + (size_t)(layer - a.row_layer0) * a.nu * su;
-        auto load_row = [&](uint32_t node) -> uint32_t { return (uint32_t)lane < su ? lrows[(size_t)node * su + lane] : 0xFFFFFFFFu; };
+        // (raw: lanes >= su repeat the row's last word and are masked where the row is consumed)
+        const uint32_t lane_c = min((uint32_t)lane, su - 1u);
+        auto load_row = [&](uint32_t node) -> uint32_t { return lrows[(size_t)node * su + lane_c]; };
         if ((uint32_t)layer >= a.small_layer && ef >= 64) {
             // ---- a layer with no more points than ef (<= 64, edges only among them): its result is the closure of the entry
             // point whatever the pop order (see hnsw_closure_kernel) — whole frontiers per round, 64 / sp points per pass
@@ -419,7 +429,7 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
         }
         // ---- entry point: mark visited, look its distance up, seed B (index.rs:219-231) and pop it at once
         {
-            if (lane == 0) atomicOr(&vis[ep >> 5], 1u << (ep & 31));
+            atomicOr(lane == 0 ? &vis[ep >> 5] : &dummy[lane], lane == 0 ? 1u << (ep & 31) : 0u);
             rowv = load_row(ep);
             const uint32_t od0 = tq[ep];
             const float f0 = f32_from_orderable(od0);
@@ -437,14 +447,11 @@ __device__ __forceinline__ void upper_traverse_wave0(const HnswUpArgs& a, const 
         while (!stop && !overflow) {
             // ---- visited test-and-set and table lookups of the popped node's row: issued together ...
             UP_T(t0);
-            const uint32_t nbr = rowv;
+            const uint32_t nbr = (uint32_t)lane < su ? rowv : 0xFFFFFFFFu;
             const bool valid = nbr != 0xFFFFFFFFu;
-            uint32_t old = 0, od = SLOT_EMPTY;
             const uint32_t bit = 1u << (nbr & 31);
-            if (valid) {
-                old = atomicOr(&vis[nbr >> 5], bit);
-                od = tq[nbr];
-            }
+            const uint32_t old = atomicOr(valid ? &vis[nbr >> 5] : &dummy[lane], valid ? bit : 0u);
+            uint32_t od = tq[valid ? nbr : 0u];
             // ---- ... and in flight while the wave finds the best candidate already in B (the next pop unless a neighbour accepted
             // below beats it), requests its row and takes its stop count
             UP_T2L(s0);   // (debug 2: the LDS round trip of the visited set / table is retired here, not behind the selection)

@@ -69,7 +69,10 @@ def case_flat(ctx, rng):
     base = data(rng, n, d, kind)
     q = (base[rng.integers(0, n, b)] + rng.normal(0, 1, (b, d))).astype(np.float32)
     q = np.where(np.isfinite(q), q, np.float32(0))  # finite queries: inf - inf would be a NaN distance on both sides
-    ids, dist, cnt = FlatIndex(ctx, base, metric).search(q, k)
+    small = int(rng.choice([0, 0, 1, 2, 3, 4]))   # flat_small_scan_kernel's forms (bases <= 1024 tiles, batches <= 4): default / off / unordered groups / two launches / one launch
+    cfg.update(small=small)
+    with ctx.option("MDB_FLAT_NO_SMALL", small):
+        ids, dist, cnt = FlatIndex(ctx, base, metric).search(q, k)
     oids, odist = oracle.flat_topk(metric, base, q, k)
     kk = min(k, n)
     if not np.array_equal(ids[:, :kk], oids[:, :kk]):
@@ -204,12 +207,16 @@ def case_hnsw(ctx, rng):
         o = oracle.BlockBasedHnsw(hidx, hvec, d, oracle.Quant(oracle.QUANT_NONE, metric))
     nq = int(rng.choice([1, 9, 40]))
     q = (v[rng.integers(0, n, nq)] + rng.normal(0, 1, (nq, d))).astype(np.float32)
-    for k, ef in [(int(rng.choice([1, 5, 10, 80])), int(rng.choice([0, 1, 7, 64, 200, 256, 257, 700])))]:
+    rank = int(rng.integers(0, 4))   # upper layers on sorted positions: neither launch / the single or layer-1 launch / the top launch / both
+    cfg.update(rank=rank)
+    for k, ef in [(int(rng.choice([1, 5, 10, 80])), int(rng.choice([0, 1, 7, 64, 200, 256, 257, 400, 700])))]:
         cfg.update(k=k, ef=ef)
         o.stats()
         ores = o.ann_search(q, k, ef)
         evals, expanded = o.stats()
-        err = rows_equal(g.ann_search(q, k, ef), ores, nq)
+        with ctx.option("MDB_HNSW_RANK", rank):
+            gres = g.ann_search(q, k, ef)
+        err = rows_equal(gres, ores, nq)
         if err:
             return cfg, err
         st = ctx.stats()

@@ -10,9 +10,9 @@ src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 OURS = ("hnsw_", "flat_", "sample_bound", "ivf_", "merge_", "remap_", "spann_", "pq_quantize", "mfma_prep", "unpack_", "kmeans_", "pad_queries")
 WL = {  # workload -> (kernels of the dominant group: bench.py's `roofline.kernel`, bench.py traffic key, config match)
     # ef <= 256, batch >= 32: top layers + table pass | layer 1 | layer 0 (mdb_hnsw_upper.hip); their sum is the traversal's bracket
-    "hnsw": (("hnsw_upper_top_kernel", "hnsw_upper_table", "hnsw_upper_kernel", "hnsw_beam_kernel"), "hnsw",
+    "hnsw": (("hnsw_upper_top_kernel", "hnsw_upper_top_rank_kernel", "hnsw_upper_rank_kernel", "hnsw_upper_table", "hnsw_upper_kernel", "hnsw_beam_kernel"), "hnsw",
              {"n": 1000000, "dim": 128, "batch": 64, "ef": 200, "k": 10}),
-    "hnsw_ef400": (("hnsw_upper_top_kernel", "hnsw_upper_table", "hnsw_upper_kernel", "hnsw_beam_kernel", "hnsw_search_kernel"), "hnsw_ef400", {"n": 1000000, "dim": 128, "batch": 64, "ef": 400, "k": 10}),
+    "hnsw_ef400": (("hnsw_upper_top_kernel", "hnsw_upper_top_rank_kernel", "hnsw_upper_rank_kernel", "hnsw_upper_table", "hnsw_upper_kernel", "hnsw_beam_kernel", "hnsw_search_kernel"), "hnsw_ef400", {"n": 1000000, "dim": 128, "batch": 64, "ef": 400, "k": 10}),
     "flat_b1": (("flat_scan_kernel",), "flat", {"n": 1000000, "dim": 128, "batch": 1, "k": 10}),
     # <METRIC, QB, NKT, SMP = false, APX>: the filter proper, not its sample pass
     "flat_b64": (("flat_bf16_filter_kernel<0, 2, 8, false",), "flat_b64", {"n": 1000000, "dim": 128, "batch": 64, "k": 10}),
