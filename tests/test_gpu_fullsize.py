@@ -124,12 +124,16 @@ def test_c2_hnsw_1m_ef200(ctx, oracle, base, flat_1m, hnsw_1m):
     st = ctx.stats()
     assert rows_of(ores, 64) == whole
     assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)             # same traversal, step for step
-    for variant in ("MDB_HNSW_NO_ROW64", "MDB_HNSW_NO_TABLE"):   # rows of any length; the all-in-one kernel
-        with ctx.option(variant, 1):
+    # rows of any length; the all-in-one kernel; the upper layers on sorted positions for no launch / the layer-1 launch too (31 k upper
+    # points: 16 registers per bitmap, the block's 156 us sort — mdb_hnsw_rank.hip.h; the default is the top launch only)
+    for variant, value in (("MDB_HNSW_NO_ROW64", 1), ("MDB_HNSW_NO_TABLE", 1), ("MDB_HNSW_RANK", 0), ("MDB_HNSW_RANK", 3)):
+        with ctx.option(variant, value):
             pres = g.ann_search(q[:64], K, 200)
-            assert rows_of(pres, 64) == whole
+            assert rows_of(pres, 64) == whole, (variant, value)
             st = ctx.stats()
-            assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded)
+            assert (st["distance_evals"], st["expanded_nodes"]) == (evals, expanded), (variant, value)
+            if variant == "MDB_HNSW_RANK":   # ... and below the split path's batch size: ONE upper launch over every layer >= 1
+                assert rows_of(g.ann_search(q[:9], K, 200), 9) == whole[:9], (variant, value)
     exact_ids, _, _ = flat_1m.search(q[:64], K)                                          # recall@10 against the exact scan
     hit = sum(len(set(res.doc_ids(i)) & set(int(v) for v in exact_ids[i])) for i in range(64))
     assert hit / (64 * K) >= 0.99
