@@ -28,7 +28,7 @@
 #define MDB_OPTIONS(X)                                                                                              \
     X(flat_qt, "MDB_FLAT_QT", 0)                       /* queries per flat-scan block (0 = choose) */               \
     X(flat_blocks, "MDB_FLAT_BLOCKS", 0)               /* flat-scan grid target (0 = 1024) */                       \
-    X(flat_no_small, "MDB_FLAT_NO_SMALL", 0)           /* bases of <= 1024 tiles, batches <= 4: the general scan kernel instead of flat_small_scan_kernel */ \
+    X(flat_no_small, "MDB_FLAT_NO_SMALL", 0)           /* bases of <= 1024 tiles, batches <= 4 (flat_small_scan_kernel): 0 sorted lists + merge_few_lists (default), 1 the general scan kernel, 2 unordered keys + a bound over 1024 thread groups, 3 = 0, 4 ONE launch (last wave to arrive merges; measured 2x slower) */ \
     X(flat_no_mfma, "MDB_FLAT_NO_MFMA", 0)             /* exact flat kernels only */                                \
     X(flat_rows, "MDB_FLAT_ROWS", 1)                   /* flat index: keep a row-major copy of the base for the refine's gathers (+ n d 4 bytes) */ \
     X(flat_rows_max_mb, "MDB_FLAT_ROWS_MAX_MB", 8192)   /* ... only for stores up to this many MB of f32 rows (flat bases and large coarse quantizers): above it the refine gathers from the tile store and the index stays at ~1.5 x its rows */ \
@@ -42,7 +42,8 @@
     X(bf_block_min_b, "MDB_BF_BLOCK_MIN_B", 512)        /* batches from here on: the block-shared x 1 filter (d <= 128) */ \
     X(bf_no_full_bound, "MDB_BF_NO_FULL_BOUND", 0)      /* the block-shared filter takes its bound from the 1/4 sample again */ \
     X(bf_exact_sample, "MDB_BF_EXACT_SAMPLE", 0)                                                                    \
-    X(refine_wave_min_b, "MDB_REFINE_WAVE_MIN_B", 512)                                                              \
+    X(refine_wave_min_b, "MDB_REFINE_WAVE_MIN_B", 512)  /* refine by slices (stores without a row-major copy): one wave per slice from this batch on */ \
+    X(refine_group_min_b, "MDB_REFINE_GROUP_MIN_B", 8)  /* refine by query groups (stores with a row-major copy): one block per query, final rows, no merge launch — from this batch on */ \
     X(refine_slices, "MDB_REFINE_SLICES", 0)                                                                        \
     X(refine_no_groups, "MDB_REFINE_NO_GROUPS", 0)                                                                  \
     X(refine_no_second_bound, "MDB_REFINE_NO_SECOND_BOUND", 0)                                                      \

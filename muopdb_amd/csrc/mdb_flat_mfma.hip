@@ -1457,7 +1457,9 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     // large batches over a store with a row-major copy (a coarse quantizer) are refined one block per query, and the filter hands
     // its products over with the candidates (flat_refine_group_kernel)
     // (flat_refine_group_kernel's dynamic LDS must fit the 48 KB a launch gets without an attribute: d <= ~3000)
-    const bool by_groups = aux.rows.p && b >= (size_t)std::max<long long>(0, ctx->opt.refine_wave_min_b) && k <= 256 && !ctx->opt.refine_no_groups &&
+    // (round 6: from the smallest batched batch on — one block per query that also writes the caller's rows saves the merge launch and
+    // measured 1-4 % of the step at batches 16 .. 256, 1 M x 128; the threshold was the wave-slice refine's 512 before)
+    const bool by_groups = aux.rows.p && b >= (size_t)std::max<long long>(0, ctx->opt.refine_group_min_b) && k <= 256 && !ctx->opt.refine_no_groups &&
                            (size_t)(RG_CAP + RG_SURV) * 8 + k * 8 + 260 * 4 + (size_t)RG_CAP * 4 + (size_t)ts.d4 * 16 <= 48 * 1024;
     float* qapx = nullptr;
     if (by_groups && smp_bf16 && !ctx->opt.refine_no_second_bound) MDB_TRY(mdb_scratch(ctx, 10, bpadq * (size_t)qcap * 4, (void**)&qapx));

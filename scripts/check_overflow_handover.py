@@ -14,7 +14,7 @@ cent[rows] = cent[rows[0]]
 g = BlockBasedIvf(ctx, F.write_ivf_index(cent, list(range(1, n + 1)), [np.array([i], dtype=np.uint64) for i in range(n)]), F.write_vector_file(cent))
 q = (cent[rng.integers(0, n, 40)]).astype(np.float32)
 q[3] = cent[rows[0]]
-ctx.set_option("MDB_REFINE_WAVE_MIN_B", 8)
+ctx.set_option("MDB_REFINE_WAVE_MIN_B", 8); ctx.set_option("MDB_REFINE_GROUP_MIN_B", 8)
 a = g.find_nearest_centroids(q, 24)   # query 3 overflows its list: the word must reach the host ...
 b = g.find_nearest_centroids(q, 24)   # ... so that this call is served by the exact kernels (cooldown)
 c = g.find_nearest_centroids(q, 24)

@@ -64,12 +64,14 @@ def coarse(ctx, args):
             q = make(rng, b, d, kind)
         with ctx.option("MDB_FLAT_NO_MFMA", 1):
             want = g.find_nearest_centroids(q, P)
-        for opts in ({"MDB_REFINE_WAVE_MIN_B": 8}, {"MDB_REFINE_WAVE_MIN_B": 8, "MDB_REFINE_NO_SECOND_BOUND": 1}, {}):
+        # by query groups (the default since round 6), without their second bound, by slices + merge (wave per slice / block per slice)
+        for opts in ({}, {"MDB_REFINE_NO_SECOND_BOUND": 1}, {"MDB_REFINE_NO_GROUPS": 1, "MDB_REFINE_WAVE_MIN_B": 8}, {"MDB_REFINE_NO_GROUPS": 1}):
             for kk, vv in opts.items():
                 ctx.set_option(kk, vv)
             got = g.find_nearest_centroids(q, P)
             ctx.set_option("MDB_REFINE_WAVE_MIN_B", 512)
             ctx.set_option("MDB_REFINE_NO_SECOND_BOUND", 0)
+            ctx.set_option("MDB_REFINE_NO_GROUPS", 0)
             if not np.array_equal(got, want):
                 bad = np.nonzero((got != want).any(1))[0]
                 print("MISMATCH it=%d seed=%d cfg=%s opts=%s rows=%s" % (it, args.seed, dict(n=n, d=d, b=b, P=P, kind=kind), opts, bad[:5]), flush=True)

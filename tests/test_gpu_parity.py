@@ -284,6 +284,15 @@ def test_flat_batched_mfma_filter_equals_exact(ctx, oracle, n, d, b, k, metric, 
         eids, edist, ecounts = idx.search(q, k)
     assert np.array_equal(ids, eids) and np.array_equal(counts, ecounts)
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    # the refine by slices + merge launch (the default below MDB_REFINE_GROUP_MIN_B until round 6; still what a store without a row-major
+    # copy takes) and the wave-per-slice form of it
+    for opts in ({"MDB_REFINE_NO_GROUPS": 1}, {"MDB_REFINE_NO_GROUPS": 1, "MDB_REFINE_WAVE_MIN_B": 8}):
+        import contextlib
+        with contextlib.ExitStack() as st:
+            for name, val in opts.items():
+                st.enter_context(ctx.option(name, val))
+            sids, sdist, scounts = idx.search(q, k)
+        assert np.array_equal(ids, sids) and np.array_equal(counts, scounts) and np.array_equal(dist.view(np.uint32), sdist.view(np.uint32)), opts
     oids, odist = oracle.flat_topk(metric, base, q[:8], k)
     assert np.array_equal(ids[:8], oids)
     assert_scores(dist[:8], odist)
@@ -675,7 +684,7 @@ def test_ivf_large_coarse_quantizer_batched_path(ctx, oracle):
 @pytest.mark.parametrize("d", [24, 128])
 def test_coarse_refine_by_groups_ties_chunks_overflow(ctx, oracle, d):
     """Large batches over a coarse quantizer are refined one block per query (flat_refine_group_kernel: a 16-lane group per
-    candidate, radix select + rank counting, final rows without a merge).  Forced on a small batch (MDB_REFINE_WAVE_MIN_B)
+    candidate, radix select + rank counting, final rows without a merge).  On a small batch (MDB_REFINE_GROUP_MIN_B; the default since round 6)
     over centroids with blocks of 1 200 / 3 000 / 9 000 IDENTICAL rows: ties beyond the survivor buffer (the count over all
     keys), lists longer than one chunk, and a list that overflows its capacity (the block scans the whole base) — probes must
     equal the oracle's, for d = 24 (general cascade) and d = 128 (the unrolled 16-lane pass), for k below and above 64."""
@@ -702,7 +711,7 @@ def test_coarse_refine_by_groups_ties_chunks_overflow(ctx, oracle, d):
     q[5] = cent[sets[9000][0]] - 0.25
     for P in (24, 200):
         want = o.find_nearest_centroids(q, P)
-        with ctx.option("MDB_REFINE_WAVE_MIN_B", 8), ctx.option("MDB_MF_COOLDOWN", 0):
+        with ctx.option("MDB_REFINE_GROUP_MIN_B", 8), ctx.option("MDB_REFINE_WAVE_MIN_B", 8), ctx.option("MDB_MF_COOLDOWN", 0):
             assert np.array_equal(g.find_nearest_centroids(q, P), want), P
             assert np.array_equal(g.find_nearest_centroids(q[:9], P), want[:9]), P
             with ctx.option("MDB_REFINE_NO_GROUPS", 1):
