@@ -11,10 +11,15 @@ BASELINE.json configs[1]: SIFT-1M-like 1M x 128 f32 (synthetic),
 through the C ABI (libmuopdb_hip.so) with queries and outputs resident in HBM.  A "step" is one batch of 64 queries
 through BlockBasedHnsw::ann_search.  N>1: HNSW does not shard (SURVEY.md §8e: replicas only) — every rank holds the
 graph and runs its own batches, so per-GPU work is fixed ("weak") and value = all ranks' queries / max time.
+The graph of the headline is built the way MuopDB builds it (HnswBuilder::insert's algorithm, `--graph insert`, the default since
+round 6); the bulk k-NN build is the workload `hnsw_c2_knn_graph`.  `value` is the K-step region's; `dispersion.long_region` adds one
+region of 200 steps (K = 20 steps are ~15 ms: inside the 3-8 % two boxes differ by).
 
 The same run also times the other north-star workloads and reports them under `workloads` (each entry with its own
 value / ms_per_step / recall_at_10 / roofline / cpu_baseline, every one bracketed by the same barrier +
 synchronize and max-over-ranks rule):
+    hnsw_c2_b1, hnsw_c2_ef400 the metric's other batch size / ef above 256, over the same resident graph
+    flat_c1_10k_b1 (_b64)     BASELINE configs[0]: 10 k x 128 (py/create_test_hdf5.py-shaped rows), batch 1
     flat_1m_b1, flat_1m_b64   brute-force L2 over the same 1M x 128 base (batch 1: HBM stream; batch 64: MFMA filter)
     ivfpq_c3                  IVF nlist=4096 + PQ m=16 nbits=8 (the reference's symmetric distance), batch 256,
                               nprobe sweep {1, 8, 16, 32, 64} as (recall@10, QPS) pairs

@@ -28,7 +28,7 @@
 #define MDB_OPTIONS(X)                                                                                              \
     X(flat_qt, "MDB_FLAT_QT", 0)                       /* queries per flat-scan block (0 = choose) */               \
     X(flat_blocks, "MDB_FLAT_BLOCKS", 0)               /* flat-scan grid target (0 = 1024) */                       \
-    X(flat_no_small, "MDB_FLAT_NO_SMALL", 0)           /* bases of <= 1024 tiles, batches <= 4 (flat_small_scan_kernel): 0 sorted lists + merge_few_lists (default), 1 the general scan kernel, 2 unordered keys + a bound over 1024 thread groups, 3 = 0, 4 ONE launch (last wave to arrive merges; measured 2x slower) */ \
+    X(flat_no_small, "MDB_FLAT_NO_SMALL", 0)           /* bases of <= 1024 tiles, batches <= 4: 0 / 3 flat_small_scan_kernel's sorted lists + merge_few_lists (two launches), 1 the general scan kernel, 2 unordered keys + a bound over 1024 thread groups, 4 flat_small_block_kernel (ONE launch, a ticket per block of 16 tiles; measured slower) */ \
     X(flat_no_mfma, "MDB_FLAT_NO_MFMA", 0)             /* exact flat kernels only */                                \
     X(flat_rows, "MDB_FLAT_ROWS", 1)                   /* flat index: keep a row-major copy of the base for the refine's gathers (+ n d 4 bytes) */ \
     X(flat_rows_max_mb, "MDB_FLAT_ROWS_MAX_MB", 8192)   /* ... only for stores up to this many MB of f32 rows (flat bases and large coarse quantizers): above it the refine gathers from the tile store and the index stays at ~1.5 x its rows */ \

@@ -150,26 +150,11 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_scan_kernel(const float4* __re
 // spent on 157 tiles; ordering a wave's 64 keys by a shuffle network instead cost 21 stages of two LDS-crossbar round trips): the
 // wave stores its 64 keys as they are and the merge launch — one block — bounds and ranks them (merge_groups_fast).  Same
 // arithmetic as exact_sums (chunk by chunk, lane accumulators, ordered horizontal sum): the same bits.
-// FUSED (k <= 16, the lists fit 48 KB of LDS): the launch also merges — every wave takes a ticket behind its list (release fence),
-// the wave that takes a query's last ticket (acquire fence) copies the lists into LDS and pops the k smallest keys by a k-way merge:
-// one wave-wide minimum per key over the lists' current heads (cur[]: list r x 64 + lane in registers, the winner's lane reloads its
-// head from LDS).  One launch instead of two: the step is launch latency, and the second launch was a third of it.
-struct SmallFuse {
-    uint32_t* tickets = nullptr;     // [b] zero between calls (the last wave of a query re-arms its word); nullptr: two-launch form
-    uint64_t* out = nullptr;         // [b][k] keys (may be null)
-    uint32_t* counts = nullptr;      // [b] (may be null)
-    UnpackOut up;
-};
-template <int METRIC, int N16, bool SORTED>
-__global__ __launch_bounds__(MDB_BLOCK) void flat_small_scan_kernel(const float4* __restrict__ tiles, size_t n, size_t ntiles,
-                                                                   const float* __restrict__ q, int qstride, int k,
-                                                                   uint64_t* __restrict__ partial, uint32_t* __restrict__ flags, SmallFuse fu) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int wave = threadIdx.x / MDB_WAVE, lane = threadIdx.x % MDB_WAVE;
-    const size_t tile = (size_t)blockIdx.x * (MDB_BLOCK / MDB_WAVE) + wave;
-    if (tile >= ntiles) return;
-    const size_t qi = blockIdx.y;
-    const float* qrow = q + qi * (size_t)qstride;
+// ---- pieces shared by the two small-base kernels
+// this lane's vector of `tile` against the query row: (distance, row id) key, MDB_KEY_MAX past the base
+template <int METRIC, int N16>
+__device__ __forceinline__ uint64_t small_tile_key(const float4* __restrict__ tiles, size_t n, size_t tile, const float* __restrict__ qrow, int lane,
+                                                   uint32_t* __restrict__ flags) {
     const size_t v = tile * MDB_TILE + lane;
     const float4* tp = tiles + tile * (size_t)(4 * N16) * MDB_TILE + lane;
     float4 x[4 * N16];
@@ -192,87 +177,119 @@ __global__ __launch_bounds__(MDB_BLOCK) void flat_small_scan_kernel(const float4
         if (dist != dist) atomicOr(flags, MDB_FLAG_NAN);
         key = make_key(dist, (uint32_t)v);
     }
+    return key;
+}
+// ascending bitonic sort of the wave's 64 keys (lane i ends with the i-th smallest)
+__device__ __forceinline__ uint64_t wave_sort_keys(uint64_t key, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), j, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)key, j, 64);
+            const bool keep_min = ((lane & k2) == 0) == ((lane & j) == 0);
+            key = keep_min ? (o < key ? o : key) : (o > key ? o : key);
+        }
+    }
+    return key;
+}
+// ONE wave: the k smallest keys of L <= 64 ascending lists of k keys in LDS (sl[l * k + j]); lane j returns the j-th smallest
+// (MDB_KEY_MAX beyond the count).  A k-way merge by wave-wide minima over the lists' heads: lane l owns list l.
+__device__ __forceinline__ uint64_t wave_kway_merge(const uint64_t* sl, uint32_t L, int k, int lane, uint32_t& c_out) {
+    uint32_t h = 0;
+    uint64_t cur = (uint32_t)lane < L ? sl[(size_t)lane * k] : MDB_KEY_MAX;
+    uint64_t mine = MDB_KEY_MAX;
+    uint32_t c = 0;
+    for (int it = 0; it < k; ++it) {
+        const uint32_t hi = mdb_wave_min_u32((uint32_t)(cur >> 32));
+        const uint32_t lo = mdb_wave_min_u32((uint32_t)(cur >> 32) == hi ? (uint32_t)cur : 0xFFFFFFFFu);
+        const uint64_t win = ((uint64_t)hi << 32) | lo;
+        if (win == MDB_KEY_MAX) break;                          // (uniform) fewer than k keys in all
+        if (lane == it) mine = win;
+        ++c;
+        if (cur == win) {                                       // one lane (row ids are unique): its list moves on
+            ++h;
+            cur = h < (uint32_t)k ? sl[(size_t)lane * k + h] : MDB_KEY_MAX;
+        }
+    }
+    c_out = c;
+    return mine;
+}
+
+struct SmallFuse {
+    uint32_t* tickets = nullptr;     // [b] zero between calls (the last block of a query re-arms its word)
+    uint64_t* out = nullptr;         // [b][k] keys (may be null)
+    uint32_t* counts = nullptr;      // [b] (may be null)
+    UnpackOut up;
+};
+template <int METRIC, int N16, bool SORTED>
+__global__ __launch_bounds__(MDB_BLOCK) void flat_small_scan_kernel(const float4* __restrict__ tiles, size_t n, size_t ntiles,
+                                                                   const float* __restrict__ q, int qstride, int k,
+                                                                   uint64_t* __restrict__ partial, uint32_t* __restrict__ flags) {
+    const int wave = threadIdx.x / MDB_WAVE, lane = threadIdx.x % MDB_WAVE;
+    const size_t tile = (size_t)blockIdx.x * (MDB_BLOCK / MDB_WAVE) + wave;
+    if (tile >= ntiles) return;
+    const size_t qi = blockIdx.y;
+    uint64_t key = small_tile_key<METRIC, N16>(tiles, n, tile, q + qi * (size_t)qstride, lane, flags);
     if (SORTED) {
-        // ascending bitonic sort of the wave's 64 keys (lane i ends with the i-th smallest): its k smallest are one ascending list
-#pragma unroll
-        for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-            for (int j = k2 >> 1; j > 0; j >>= 1) {
-                const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), j, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)key, j, 64);
-                const bool keep_min = ((lane & k2) == 0) == ((lane & j) == 0);
-                key = keep_min ? (o < key ? o : key) : (o > key ? o : key);
-            }
-        }
-        if (!fu.tickets) {
-            if (lane < k) partial[(qi * ntiles + tile) * (size_t)k + lane] = key;
-        } else {
-            // Hand-over WITHOUT fences: a release / acquire fence at agent scope is an L2 write-back / invalidate on this part, and 157
-            // of them made the launch 26 us instead of 6.  Everything that crosses waves here is an agent-scope atomic access instead —
-            // the list's stores, the ticket, the merging wave's loads (sc1: coherent at agent scope by themselves, nothing of it ever
-            // sits dirty or stale in an XCD's L2) — and the only ordering needed, list before ticket, is the wave's own s_waitcnt.
-            if (lane < k) __hip_atomic_store(&partial[(qi * ntiles + tile) * (size_t)k + lane], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            uint32_t t = 0;
-            if (lane == 0) t = __hip_atomic_fetch_add(&fu.tickets[qi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-            if (t != (uint32_t)ntiles - 1u) return;
-            if (lane == 0) __hip_atomic_store(&fu.tickets[qi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next call (stream order)
-            const uint32_t L = (uint32_t)ntiles;
-            const uint64_t* lists = partial + qi * ntiles * (size_t)k;
-            uint64_t* sl = (uint64_t*)lds;                              // [L][k]; behind it the lists' head positions
-            uint32_t* hp = (uint32_t*)(sl + (size_t)L * k);
-            for (uint32_t i = lane; i < L * (uint32_t)k; i += MDB_WAVE) sl[i] = __hip_atomic_load(lists + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (uint32_t i = lane; i < L; i += MDB_WAVE) hp[i] = 0u;
-            constexpr int RMAX = 16;                                    // L <= 1024
-            uint64_t cur[RMAX];
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) {
-                const uint32_t l = (uint32_t)r * MDB_WAVE + lane;
-                cur[r] = l < L ? sl[(size_t)l * k] : MDB_KEY_MAX;
-            }
-            uint64_t mine = MDB_KEY_MAX;                                // lane j ends with the j-th smallest key
-            uint32_t c = 0;
-            for (int it = 0; it < k; ++it) {
-                uint64_t best = cur[0];
-#pragma unroll
-                for (int r = 1; r < RMAX; ++r) best = cur[r] < best ? cur[r] : best;
-                const uint32_t hi = mdb_wave_min_u32((uint32_t)(best >> 32));
-                const uint32_t lo = mdb_wave_min_u32((uint32_t)(best >> 32) == hi ? (uint32_t)best : 0xFFFFFFFFu);
-                const uint64_t win = ((uint64_t)hi << 32) | lo;
-                if (win == MDB_KEY_MAX) break;                          // (uniform) fewer than k keys in all
-                if (lane == it) mine = win;
-                ++c;
-                if (best == win) {                                      // one lane (row ids are unique): its list moves on
-#pragma unroll
-                    for (int r = 0; r < RMAX; ++r) {
-                        if (cur[r] == win) {
-                            const uint32_t l = (uint32_t)r * MDB_WAVE + lane;
-                            const uint32_t h = hp[l] + 1u;
-                            hp[l] = h;
-                            cur[r] = h < (uint32_t)k ? sl[(size_t)l * k + h] : MDB_KEY_MAX;
-                        }
-                    }
-                }
-            }
-            if (lane < k) {
-                const bool have = lane < (int)c;
-                if (fu.out) fu.out[qi * (size_t)k + lane] = have ? mine : MDB_KEY_MAX;
-                if (fu.up.ids) {
-                    fu.up.ids[qi * (size_t)k + lane] = have ? key_id(mine) : 0xFFFFFFFFu;
-                    if (fu.up.dist) fu.up.dist[qi * (size_t)k + lane] = have ? key_dist(mine) : __uint_as_float(0x7F800000u);
-                }
-            }
-            if (lane == 0) {
-                if (fu.counts) fu.counts[qi] = c;
-                if (fu.up.ids && fu.up.counts) fu.up.counts[qi] = c;
-            }
-            if (qi == 0) {
-                if (fu.up.zero4 && lane < 4) fu.up.zero4[lane] = 0ull;
-                if (fu.up.word_dst && lane == 0) *fu.up.word_dst = *fu.up.word_src;
-            }
-        }
+        key = wave_sort_keys(key, lane);
+        if (lane < k) partial[(qi * ntiles + tile) * (size_t)k + lane] = key;
     } else {
         partial[(qi * ntiles + tile) * (size_t)MDB_TILE + lane] = key;   // unordered: merge_keys_kernel's group form (fast == 3) bounds and ranks them
+    }
+}
+
+// ONE launch (k <= 16, at most 64 blocks; MDB_FLAT_NO_SMALL=4, not the default: slower than two launches, see flat_topk_keys): blocks of 16 waves = 16 tiles.  A wave orders its tile's keys; wave 0 merges the block's 16
+// lists (k-way merge from LDS) into ONE list of k keys, stores it and takes the query's ticket; the block that takes the last ticket
+// merges the blocks' lists and writes the rows.  Hand-over WITHOUT fences: an agent-scope release / acquire fence is an L2 write-back /
+// invalidate on this part; everything that crosses blocks is an agent-scope atomic access instead (the list's stores, the ticket,
+// the last block's loads: coherent at agent scope by themselves), ordered by the wave's own s_waitcnt.  The first form of this
+// kernel took a ticket per WAVE: 157 read-modify-writes on one word serialise at the memory side at ~0.1 us each (20.6 us per
+// launch); ten block tickets do not show.
+#define FSB_BLOCK 1024
+template <int METRIC, int N16>
+__global__ __launch_bounds__(FSB_BLOCK) void flat_small_block_kernel(const float4* __restrict__ tiles, size_t n, size_t ntiles,
+                                                                    const float* __restrict__ q, int qstride, int k,
+                                                                    uint64_t* __restrict__ partial, uint32_t* __restrict__ flags, SmallFuse fu) {
+    __shared__ uint64_t sl[64 * 16];            // 16 wave lists of k <= 16 keys; the last block: up to 64 block lists
+    __shared__ uint32_t last;
+    const int wave = threadIdx.x / MDB_WAVE, lane = threadIdx.x % MDB_WAVE;
+    const size_t tile = (size_t)blockIdx.x * (FSB_BLOCK / MDB_WAVE) + wave;
+    const size_t qi = blockIdx.y;
+    const uint32_t nblk = gridDim.x;
+    uint64_t key = MDB_KEY_MAX;
+    if (tile < ntiles) key = wave_sort_keys(small_tile_key<METRIC, N16>(tiles, n, tile, q + qi * (size_t)qstride, lane, flags), lane);
+    if (lane < k) sl[wave * k + lane] = key;
+    __syncthreads();
+    if (wave != 0) return;
+    uint32_t c = 0;
+    uint64_t mine = wave_kway_merge(sl, FSB_BLOCK / MDB_WAVE, k, lane, c);
+    uint64_t* const lists = partial + qi * (size_t)nblk * k;
+    if (nblk > 1) {
+        if (lane < k) __hip_atomic_store(&lists[(size_t)blockIdx.x * k + lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(&fu.tickets[qi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t != nblk - 1u) return;
+        if (lane == 0) __hip_atomic_store(&fu.tickets[qi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next call (stream order)
+        for (uint32_t i = lane; i < nblk * (uint32_t)k; i += MDB_WAVE) sl[i] = __hip_atomic_load(lists + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mine = wave_kway_merge(sl, nblk, k, lane, c);
+    }
+    if (lane < k) {
+        const bool have = lane < (int)c;
+        if (fu.out) fu.out[qi * (size_t)k + lane] = have ? mine : MDB_KEY_MAX;
+        if (fu.up.ids) {
+            fu.up.ids[qi * (size_t)k + lane] = have ? key_id(mine) : 0xFFFFFFFFu;
+            if (fu.up.dist) fu.up.dist[qi * (size_t)k + lane] = have ? key_dist(mine) : __uint_as_float(0x7F800000u);
+        }
+    }
+    if (lane == 0) {
+        if (fu.counts) fu.counts[qi] = c;
+        if (fu.up.ids && fu.up.counts) fu.up.counts[qi] = c;
+    }
+    if (qi == 0) {
+        if (fu.up.zero4 && lane < 4) fu.up.zero4[lane] = 0ull;
+        if (fu.up.word_dst && lane == 0) *fu.up.word_dst = *fu.up.word_src;
     }
 }
 
@@ -700,20 +717,20 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
         void* partial;
         MDB_TRY(mdb_scratch(ctx, 4, (size_t)ts.ntiles * b * MDB_TILE * 8, &partial));
         const bool sorted = ctx->opt.flat_no_small != 2;   // 2: the waves store their keys unordered, the merge bounds 1024 thread groups (measured slower)
-        // one launch: the wave that takes a query's last ticket merges (3: two launches, for comparison).  Tickets: d_counters words
-        // 28-29 read as four u32 (zero from the context's creation on, re-armed by every merging wave)
-        const size_t fuse_bytes = ts.ntiles * k * 8 + ts.ntiles * 4;
-        // (measured: the fused launch takes 20.6 us against 5.2 + 4 for the two launches — 157 agent-scope atomics on ONE ticket word
-        // serialise at the memory side, ~0.1 us each, fences or not; kept behind MDB_FLAT_NO_SMALL=4 for the record)
-        const bool fused = sorted && k <= 16 && fuse_bytes <= 48 * 1024 && ctx->opt.flat_no_small == 4;
-        const size_t fuse_lds = fused ? fuse_bytes : 0;
+        // MDB_FLAT_NO_SMALL=4: ONE launch (flat_small_block_kernel: a ticket per BLOCK of 16 tiles; k <= 16, at most 64 blocks).  Measured on C1:
+        // 13.5 us against 5.1 + 6.0 for the two launches, with ten tickets — the hand-over is three dependent trips to the memory side
+        // (the list's store acknowledged, the ticket, the last block's loads: ~2 us each), i.e. what a launch boundary costs; the
+        // per-wave-ticket form before it took 20.6 us (157 tickets serialise on one word).  Not the default.
+        // Tickets: d_counters words 28-29 read as four u32 (zero from the context's creation on, re-armed by every merging block)
+        const unsigned nblk16 = (unsigned)((ts.ntiles + 15) / 16);
+        const bool fused = sorted && k <= 16 && nblk16 <= 64 && ctx->opt.flat_no_small == 4;
         SmallFuse fu;
         if (fused) {
             fu.tickets = (uint32_t*)(ctx->d_counters + 28);
             fu.out = d_keys; fu.counts = d_counts;
             if (unpack) fu.up = *unpack;
         }
-        const dim3 grid((unsigned)((ts.ntiles + 3) / 4), (unsigned)b);
+        const dim3 grid(fused ? nblk16 : (unsigned)((ts.ntiles + 3) / 4), (unsigned)b);
         const float4* tiles = (const float4*)ts.data;
         bool saved = ctx->prof_on;
         ctx->prof_on = saved && profile;
@@ -722,8 +739,9 @@ mdb_status flat_topk_keys(mdb_ctx* ctx, const TileView& ts, int metric, const fl
             ctx->prof_on = saved;
 #define MDB_SMALL_GO(METRIC, N)                                                                                                        \
     do {                                                                                                                               \
-        if (sorted) flat_small_scan_kernel<METRIC, N, true><<<grid, MDB_BLOCK, fuse_lds, ctx->stream>>>(tiles, ts.n, ts.ntiles, dq, qstride, (int)k, (uint64_t*)partial, ctx->d_flags, fu); \
-        else flat_small_scan_kernel<METRIC, N, false><<<grid, MDB_BLOCK, 0, ctx->stream>>>(tiles, ts.n, ts.ntiles, dq, qstride, (int)k, (uint64_t*)partial, ctx->d_flags, SmallFuse{});     \
+        if (fused) flat_small_block_kernel<METRIC, N><<<grid, FSB_BLOCK, 0, ctx->stream>>>(tiles, ts.n, ts.ntiles, dq, qstride, (int)k, (uint64_t*)partial, ctx->d_flags, fu); \
+        else if (sorted) flat_small_scan_kernel<METRIC, N, true><<<grid, MDB_BLOCK, 0, ctx->stream>>>(tiles, ts.n, ts.ntiles, dq, qstride, (int)k, (uint64_t*)partial, ctx->d_flags); \
+        else flat_small_scan_kernel<METRIC, N, false><<<grid, MDB_BLOCK, 0, ctx->stream>>>(tiles, ts.n, ts.ntiles, dq, qstride, (int)k, (uint64_t*)partial, ctx->d_flags);      \
     } while (0)
 #define MDB_SMALL_N(METRIC)                        \
     switch (p.n16) {                               \

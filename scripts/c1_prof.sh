@@ -1,9 +1,9 @@
 #!/bin/bash
-# C1 (10 k x 128, batch 1): rocprofv3 kernel durations of the flat step per variant (MDB_FLAT_NO_SMALL = 0 sorted lists, 2 unordered groups, 1 general kernel)
+# C1 (10 k x 128, batch 1): rocprofv3 kernel durations of the flat step per variant (MDB_FLAT_NO_SMALL = 0 two launches, 4 one launch with block tickets, 2 unordered groups, 1 general kernel)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/c1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for V in ${VARIANTS:-0 2 1}; do
+for V in ${VARIANTS:-0 4 1}; do
   rm -rf /tmp/prof_c1_$V
   MDB_FLAT_NO_SMALL=$V timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c1_$V -o b -- python $REPO/bench.py --workload flat --n 10000 --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_$V.log 2>&1
   cp /tmp/prof_c1_$V/*kernel_stats.csv $OUT/kernel_stats_$V.csv

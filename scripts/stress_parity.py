@@ -69,7 +69,7 @@ def case_flat(ctx, rng):
     base = data(rng, n, d, kind)
     q = (base[rng.integers(0, n, b)] + rng.normal(0, 1, (b, d))).astype(np.float32)
     q = np.where(np.isfinite(q), q, np.float32(0))  # finite queries: inf - inf would be a NaN distance on both sides
-    small = int(rng.choice([0, 0, 1, 2, 3, 4]))   # flat_small_scan_kernel's forms (bases <= 1024 tiles, batches <= 4): default / off / unordered groups / two launches / one launch
+    small = int(rng.choice([0, 0, 1, 2, 4]))   # the small-base flat kernels' forms (bases <= 1024 tiles, batches <= 4): two launches (default) / off / unordered groups / one launch
     cfg.update(small=small)
     with ctx.option("MDB_FLAT_NO_SMALL", small):
         ids, dist, cnt = FlatIndex(ctx, base, metric).search(q, k)

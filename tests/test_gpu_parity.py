@@ -183,9 +183,13 @@ def test_flat_small_base_kernel(ctx, oracle, n, d, b, k, metric):
     assert np.array_equal(ids[:, :kk], oids[:, :kk])
     assert np.array_equal(dist[:, :kk].view(np.uint32), odist[:, :kk].view(np.uint32))
     assert np.all(ids[:, kk:] == 0xFFFFFFFF)
-    with ctx.option("MDB_FLAT_NO_SMALL", 1):
-        ids2, dist2, counts2 = idx.search(q, k)
-    assert np.array_equal(ids, ids2) and np.array_equal(dist.view(np.uint32), dist2.view(np.uint32)) and np.array_equal(counts, counts2)
+    for form in (1, 2, 4):   # the general kernel; unordered keys + group bound; ONE launch with block tickets (k <= 16, else two launches)
+        with ctx.option("MDB_FLAT_NO_SMALL", form):
+            ids2, dist2, counts2 = idx.search(q, k)
+            if form == 4:
+                ids3, _, _ = idx.search(q, k)                              # the tickets were re-armed
+                assert np.array_equal(ids2, ids3)
+        assert np.array_equal(ids, ids2) and np.array_equal(dist.view(np.uint32), dist2.view(np.uint32)) and np.array_equal(counts, counts2), form
 
 
 def test_flat_batched_filter_rows_with_infinite_components(ctx, oracle):

@@ -22,7 +22,7 @@ from muopdb_amd import lib as L
 LLVM = "/opt/rocm/lib/llvm/bin"
 FUSED = re.compile(r"\b(v_fma_f|v_fmac_f|v_mad_f|v_mac_f|v_pk_fma|v_pk_mad|v_fmaak|v_fmamk|v_madak|v_madmk|v_dot\d|v_mfma)")
 # kernels whose results carry the reference's lane association (every distance that is RETURNED or RANKED exactly)
-EXACT = re.compile(r"(flat_scan_kernel|flat_small_scan_kernel|flat_refine_kernel|ivf_scan_f32_kernel|ivf_scan_pq2?_kernel|ivf_pq3_refine_kernel|ivf_pq_fused_kernel|ivf_prep_kernel|ivf_coarse_rank_kernel|merge_rows_remap_kernel|"
+EXACT = re.compile(r"(flat_scan_kernel|flat_small_scan_kernel|flat_small_block_kernel|flat_refine_kernel|ivf_scan_f32_kernel|ivf_scan_pq2?_kernel|ivf_pq3_refine_kernel|ivf_pq_fused_kernel|ivf_prep_kernel|ivf_coarse_rank_kernel|merge_rows_remap_kernel|"
                    r"hnsw_(beam|search|closure|pipe|select)_kernel|hnsw_upper_(top|top_rank|table\w*)_kernel|"
                    r"pair_distance_kernel|lane_conforming_kernel|pq_quantize_kernel|pq_distance_kernel|pq_rows_kernel|spann_filter_kernel|"
                    r"kmeans_assign_kernel)")
