@@ -62,7 +62,6 @@
     X(hnsw_table64_min_b, "MDB_HNSW_TABLE64_MIN_B", 32) /* smallest batch that takes the lane = query table kernel */ \
     X(hnsw_no_wide, "MDB_HNSW_NO_WIDE", 0)             /* 256 < ef <= 448 through the general kernel instead of the 8-register beam */ \
     X(hnsw_rank, "MDB_HNSW_RANK", 2)                   /* upper layers on sorted positions (mdb_hnsw_rank.hip.h: bitmaps over rank instead of the register beam): bit 0 the layer-1 / single upper launch, bit 1 the split path's top launch */ \
-    X(hnsw_rank_radix, "MDB_HNSW_RANK_RADIX", 0)       /* the top launch sorts its <= 2048 keys by the block radix sort instead of the bitonic network */ \
     X(hnsw_no_split, "MDB_HNSW_NO_SPLIT", 0)           /* upper layers: table pass, then ONE traversal launch (no top / layer-1 split) */ \
     X(hnsw_table_min_b, "MDB_HNSW_TABLE_MIN_B", 1)     /* smallest batch served by the table path */               \
     X(hnsw_nb4_slack, "MDB_HNSW_NB4_SLACK", 48)        /* table path: ef + this <= 256 runs the beam on FOUR registers of 64 slots (0: always five) */ \

@@ -255,49 +255,6 @@ __device__ __forceinline__ void rank_tables(const uint32_t* __restrict__ keys, c
     __syncthreads();
 }
 
-// The same tables for at most 2048 keys that already sit in LDS (the top launch's ~1 k points): a block bitonic sort of
-// (canonical image << 32 | index) words — 55 / 66 stages of two or four compare-exchanges per thread against the radix sort's three
-// passes of histograms, scans and ballot match-any: 28 k -> ~6 k cycles per block.  sbuf: npow2 (a power of two >= n) u64 words.
-template <int NT>
-__device__ __forceinline__ void rank_tables_bitonic(const uint32_t* __restrict__ keys, const uint32_t n, const uint32_t npow2, uint64_t* sbuf,
-                                                    uint16_t* P, uint16_t* R, uint32_t* red, uint32_t& nan_start) {
-    const int tid = threadIdx.x;
-    if (tid == 0) red[2] = 0u;
-    __syncthreads();
-    uint32_t nn = 0;
-    for (uint32_t i = tid; i < npow2; i += NT) {
-        uint64_t w = ~0ull;
-        if (i < n) {
-            const uint32_t k = rk_canon(keys[i]);
-            nn += k == RK_NAN_KEY ? 1u : 0u;
-            w = ((uint64_t)k << 32) | i;
-        }
-        sbuf[i] = w;
-    }
-    if (nn) atomicAdd(&red[2], nn);
-    __syncthreads();
-    for (uint32_t k2 = 2; k2 <= npow2; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < npow2 / 2; i += NT) {
-                const uint32_t lo = 2u * i - (i & (j - 1u)), hi = lo + j;   // lo has bit j clear
-                const uint64_t a = sbuf[lo], b = sbuf[hi];
-                const bool up = (lo & k2) == 0u;
-                if ((a > b) == up) { sbuf[lo] = b; sbuf[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
-    nan_start = n - red[2];
-    for (uint32_t r = tid; r < n; r += NT) {
-        const uint64_t w = sbuf[r];
-        const uint32_t c = (uint32_t)w;
-        const uint32_t f = (r + 1 < n && (uint32_t)(sbuf[r + 1] >> 32) == (uint32_t)(w >> 32)) ? 0x8000u : 0u;
-        P[r] = (uint16_t)(c | f);
-        R[c] = (uint16_t)(r | f);
-    }
-    __syncthreads();
-}
-
 // d(lo) == d(hi) for ranks lo < hi: every rank in between carries the flag (rare path: one LDS round trip per rank)
 __device__ __forceinline__ bool rank_tied(const uint16_t* P, uint32_t lo, uint32_t hi) {
     for (uint32_t r = lo; r < hi; ++r)

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void hnsw_upper_top_kernel(HnswUpArgs a, ui
 template <int METRIC, int N16, int NW>
 __global__ __launch_bounds__(256, 2) void hnsw_upper_top_rank_kernel(HnswUpArgs a, uint32_t nq, const float* __restrict__ rows_nat, uint32_t nu_all,
                                                                      uint32_t* __restrict__ table_all, uint32_t nu_all_pad, uint32_t tgx,
-                                                                     unsigned long long* zero16, uint32_t sort_pow2) {
+                                                                     unsigned long long* zero16) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (blockIdx.x >= nq) {
         const uint32_t t = blockIdx.x - nq;
@@ -821,12 +821,7 @@ __global__ __launch_bounds__(256, 2) void hnsw_upper_top_rank_kernel(HnswUpArgs 
     uint16_t *P, *R;
     uint32_t nan_start;
     const unsigned long long ts0 = __builtin_readcyclecounter();
-    if (NW == 1 && sort_pow2) {   // <= 2048 points: bitonic sort of (image, index) words in LDS (behind the hand-over scratch)
-        P = bufA; R = bufB;
-        rank_tables_bitonic<256>(tl, a.nu, sort_pow2, (uint64_t*)(vis_out + ((a.out_words + 1u) & ~1u))   /* 8-byte aligned: every region before it is a multiple of 8 bytes */, P, R, red, nan_start);
-    } else {
-        rank_tables<256>(tl, a.nu, bufA, bufB, hist, red, P, R, nan_start);
-    }
+    rank_tables<256>(tl, a.nu, bufA, bufB, hist, red, P, R, nan_start);
     if (threadIdx.x >= 64) return;
     if constexpr (NW == 1) upper_traverse_rank1(a, qi, lane, lds, R, P, nan_start, vis, vis_out, __builtin_readcyclecounter() - ts0);
     else upper_traverse_rank<NW>(a, qi, lane, lds, R, P, nan_start, vis, vis_out, __builtin_readcyclecounter() - ts0);
@@ -897,10 +892,7 @@ mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const D
     const bool split = up.nu2 > 0 && up.layers >= 2 && up.rows_nat.p && p.n16 > 0 && p.n16 <= 8 && p.n8 == 0 && p.n4 == 0 && p.ntail == 0 &&
                        (long long)b >= ctx->opt.hnsw_table64_min_b && !ctx->opt.hnsw_no_split && lds_top <= 160 * 1024 - 512 && ef <= 256;
     // the top blocks on sorted positions: their LDS holds the row, its two rank tables and the sort's histograms
-    // (<= 2048 top points: + the bitonic sort's u64 words, MDB_HNSW_RANK_RADIX=1 keeps the radix sort)
-    uint32_t sort_pow2 = 0;
-    if (nu2_pad <= 2048 && !ctx->opt.hnsw_rank_radix) { sort_pow2 = 64; while (sort_pow2 < up.nu2) sort_pow2 <<= 1; }
-    const size_t lds_top_rank = rk_lds_bytes(words2, nu2_pad, 256, nu2_pad + out.words + 2 + 2 * sort_pow2);
+    const size_t lds_top_rank = rk_lds_bytes(words2, nu2_pad, 256, nu2_pad + out.words);
     const bool top_rank = (ctx->opt.hnsw_rank & 2) && up.nu2 > 0 && up.layers >= 2 && up.rows_nat.p && p.n16 > 0 && p.n16 <= 8 && p.n8 == 0 && p.n4 == 0 &&
                           p.ntail == 0 && (long long)b >= ctx->opt.hnsw_table64_min_b && !ctx->opt.hnsw_no_split && nu2_pad <= 8192 &&
                           lds_top_rank <= 80 * 1024 - 512;   // (two blocks per CU: the table blocks of the same launch share it)
@@ -941,7 +933,7 @@ mdb_status hnsw_upper_run(mdb_ctx* ctx, const HnswUpper& up, int metric, const D
             MDB_HIP(ctx, hipFuncSetAttribute((const void*)hnsw_upper_top_rank_kernel<METRIC, N, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                              (int)lds_top_rank));                                                                      \
         hnsw_upper_top_rank_kernel<METRIC, N, NWV><<<dim3(grid), 256, lds_top_rank, ctx->stream>>>(a, (uint32_t)b, up.rows_nat.p, up.nu, d_table, \
-                                                                                                    nu_pad, tgx, zero16, sort_pow2);   \
+                                                                                                    nu_pad, tgx, zero16);              \
     } while (0)
 #define MDB_TOP_GO(METRIC, N)                                                                  \
     do {                                                                                       \
