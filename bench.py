@@ -152,6 +152,10 @@ def parse():
                    help="world > 1, single workloads: posting-list shards + exact merge (default, what north_star names), or a QUERY "
                         "partitioning with an all-gather of finished rows only: users (spann: user slot u on rank u %% world) / batch (ivfpq, "
                         "c5full: replicas, contiguous batch slices).  --workload all runs list shards AND the comparators (SURVEY 8e: measure both)")
+    p.add_argument("--share-closure", default="auto", choices=["auto", "on", "off"],
+                   help="spann, list shards, world > 1: run the centroid-graph closure ONCE per (user, query) pair — each rank for its slice "
+                        "of the batch, probe rows in one more all-gather (mdb_multi_spann_probes / _search_shard_probes) — instead of on "
+                        "every rank.  auto: from batch 1024 (the closure is one wave per pair: 36-39 us flat up to batch 256, 55 us at 512, 94 us at 1024)")
     p.add_argument("--plan", action="store_true",
                    help="print what `--gpus N` (workload all) will build and hold — per workload: who builds, estimated build / load "
                         "seconds, host bytes private to a rank and shared through the page cache, HBM per rank — and exit (no GPU needed)")
@@ -437,7 +441,7 @@ def exchange_times(env, step, steps, warm):
     ms = D.TIMER.ms()
     D.TIMER = None
     out = {}
-    for kind in ("coarse_allgather", "merge_coarse", "points_allgather", "merge_points", "rows_allgather", "rows_permute"):
+    for kind in ("probes_allgather", "coarse_allgather", "merge_coarse", "points_allgather", "merge_points", "rows_allgather", "rows_permute"):
         if kind in ms:
             out[kind + "_ms_per_step"] = env.max_over_ranks(ms[kind]["total_ms"] / steps)
     out["ranks"] = env.world
@@ -1165,8 +1169,16 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None, shard=None
             gts.append((torch.topk(dd, k, largest=False).indices + u * per))
         gts = torch.stack(gts).cpu().numpy()
 
+    share = world > 1 and not by_user and (args.share_closure == "on" or (args.share_closure == "auto" and batch >= 1024))
+    uid_slices = None
+
     def measure(P_, ratio_, disperse=True):
+        nonlocal uid_slices
         params = SearchParams(k, args.ef).with_num_explored_centroids(P_).with_centroid_distance_ratio(ratio_).to_c()
+        psh = D.ProbeRowsShare(ctx, batch, int(ctx.lib.mdb_spann_probe_row_words(C.byref(params))), "cuda") if share else None
+        if share and uid_slices is None:
+            lo_, hi_ = psh.slice
+            uid_slices = [L.u128_array([int(u) + 1 for u in quser[i * batch + lo_:i * batch + hi_].tolist()]) for i in range(steps + warm)]
 
         def step(i, keep=None):
             q = queries[i * batch:(i + 1) * batch]
@@ -1177,6 +1189,17 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None, shard=None
                                                          C.c_int(L.MEM_DEVICE), C.c_void_p(ex.ids.data_ptr()), C.c_void_p(ex.scores.data_ptr()),
                                                          C.c_void_p(ex.counts.data_ptr()), C.c_void_p(ex.found.data_ptr())))
                 res = ex.gather()[0]
+            elif share:
+                # the centroid stage of THIS rank's slice of the pairs -> one all-gather of probe rows -> every rank scans its lists
+                lo_, hi_ = psh.slice
+                if hi_ > lo_:
+                    ctx.check(ctx.lib.mdb_multi_spann_probes(ms.h, uid_slices[i], C.c_void_p(q[lo_:hi_].data_ptr()), C.c_size_t(hi_ - lo_),
+                                                             C.byref(params), C.c_int(L.MEM_DEVICE), C.c_void_p(psh.send.data_ptr())))
+                rows = psh.gather()
+                ctx.check(ctx.lib.mdb_multi_spann_search_shard_probes(ms.h, uid_arrays[i], C.c_void_p(q.data_ptr()), C.c_size_t(batch),
+                                                                      C.byref(params), C.c_int(L.MEM_DEVICE), C.c_void_p(rows.data_ptr()), None,
+                                                                      C.c_size_t(0), C.c_size_t(0), C.c_void_p(gather.send.data_ptr())))
+                res, _, _ = gather.gather_merge_multi(ms, uid_arrays[i])
             elif world > 1:
                 ctx.check(ctx.lib.mdb_multi_spann_search_shard(ms.h, uid_arrays[i], C.c_void_p(q.data_ptr()), C.c_size_t(batch),
                                                                C.byref(params), C.c_int(L.MEM_DEVICE), None, C.c_size_t(0), C.c_size_t(0),
@@ -1220,6 +1243,8 @@ def run_spann(env, users=None, no_sweep=False, steps=None, warm=None, shard=None
                        "data": args.data, "parallelism": part},
                roofline=hbm_roofline("ivf_scan_f32_kernel", m["scan_bytes"] / steps, m["kernel_ms"], m["launches"],
                                      scored_per_query=m["scored"] / (steps * batch)))
+    if world > 1 and not by_user:
+        out["closure"] = "once per pair: each rank its slice of the batch, probe rows all-gathered" if share else "replicated on every rank"
     # the centroid-graph kernel as its own entry (r3 divided its bytes by the scan kernel's time: VERDICT r3 weak #1)
     out["roofline"]["centroid_graph"] = hbm_roofline("hnsw_closure_kernel", m["graph_bytes"] / steps, m["hnsw_ms"], 1,
                                                      evals_per_query=m["evals"] / (steps * batch))

@@ -395,6 +395,23 @@ mdb_status mdb_spann_merge_shards(mdb_spann* spann, const void* blocks, size_t w
 mdb_status mdb_multi_spann_search_shard(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
                                         const mdb_search_params* params, mdb_mem mem, const uint32_t* allow, size_t n_bitmaps,
                                         size_t words_per_bitmap, void* block_out);
+/* List-sharded multi-user collections, the centroid-graph search NOT replicated (the aggregator's fan-out role,
+ * rs/aggregator/src/aggregator.rs:80-135): Spann::search (rs/index/src/spann/index.rs:211-266) is `centroids.ann_search` + the ratio
+ * filter (:211-246), then `search_with_centroids_and_remap` over the kept lists (:247-266).  The first half does not depend on the
+ * shard (centroid graphs are replicated), so each rank runs it for ITS slice of the batch only —
+ *   mdb_multi_spann_probes: one ROW of mdb_spann_probe_row_words(params) = 2 + max(num_explored_centroids or top_k, 1) u32 per
+ *   (user, query) pair, { count, found (0 = None: unknown user / empty centroid result), kept posting-list ids nearest first,
+ *   zero padded }, in the caller's memory `mem` — rows, so that slices of a batch concatenate into the batch's table as an
+ *   all-gather delivers them —
+ * the slices meet in one all-gather, and every rank scans the lists it owns for the WHOLE batch from the gathered rows:
+ *   mdb_multi_spann_search_shard_probes == mdb_multi_spann_search_shard from the scan on (same POINTS block, same merge).  A row's
+ *   count is clamped to the row; list ids out of range are skipped and reported like the reference's "Index out of bound". */
+size_t mdb_spann_probe_row_words(const mdb_search_params* params);
+mdb_status mdb_multi_spann_probes(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b, const mdb_search_params* params,
+                                  mdb_mem mem, uint32_t* rows_out);
+mdb_status mdb_multi_spann_search_shard_probes(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                               const mdb_search_params* params, mdb_mem mem, const uint32_t* rows, const uint32_t* allow,
+                                               size_t n_bitmaps, size_t words_per_bitmap, void* block_out);
 mdb_status mdb_multi_spann_merge_shards(mdb_multi_spann* ms, const mdb_u128* user_ids, const void* blocks, size_t world, size_t b,
                                         size_t k, mdb_u128* doc_ids_out, float* scores_out, uint32_t* counts_out, uint8_t* found_out);
 /* The collective alone, for hosts without torch: ncclAllGather(send_block -> recv_blocks, bytes_per_rank per rank, ncclUint8)

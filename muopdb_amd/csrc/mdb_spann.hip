@@ -75,11 +75,31 @@ __global__ __launch_bounds__(256) void spann_filter_kernel(const uint64_t* __res
 }
 
 struct SpannFilterArg { const uint32_t* allow; size_t n_bitmaps, words; };
+// The two halves of Spann::search as calls of their own (list-sharded collections: a pair's centroid-graph search runs on ONE rank,
+// the kept posting-list ids travel in an all-gather, every rank scans the lists it owns — mdb_multi_spann_probes / .._search_shard_probes):
+//   out   the call stops behind the ratio filter and hands the probe rows over (caller's memory `mem`)
+//   in    the call takes the probes as given and starts at the scan
+struct SpannProbes { bool out; uint32_t* rows; };   // rows: [b][2 + ne] u32 = { count, found, list ids[ne] } (mdb_multi_spann_probes)
+
+// probe rows <-> the scan's arrays.  Unpacking clamps: a count is data from outside the call and never exceeds the row (the list
+// ids are range-checked by the scan itself, "Index out of bound" storage.rs:280-286)
+__global__ void spann_probe_rows_kernel(uint32_t* __restrict__ rows, uint32_t* __restrict__ probes, uint32_t* __restrict__ cnt,
+                                        uint8_t* __restrict__ found, uint32_t ne, size_t b, int pack) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b * (ne + 2)) return;
+    const size_t q = i / (ne + 2);
+    const uint32_t j = (uint32_t)(i - q * (ne + 2));
+    if (pack) rows[i] = j == 0 ? cnt[q] : j == 1 ? (uint32_t)(found[q] != 0) : (j - 2 < cnt[q] ? probes[q * ne + j - 2] : 0u);
+    else if (j == 0) cnt[q] = min(rows[i], ne);
+    else if (j == 1) found[q] = rows[i] != 0;
+    else probes[q * ne + j - 2] = rows[i];
+}
 
 static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b, const uint32_t* h_q_user,
                                     const mdb_search_params* params, mdb_mem mem, mdb_u128* doc_ids_out, float* scores_out,
                                     uint32_t* counts_out, uint8_t* found_out, const SpannFilterArg* fa = nullptr, bool submit = false,
-                                    void* block_out = nullptr) {   // block_out: this rank's POINTS block (exact sharded merge) instead of the remapped rows
+                                    void* block_out = nullptr,   // block_out: this rank's POINTS block (exact sharded merge) instead of the remapped rows
+                                    const SpannProbes* pio = nullptr) {
     mdb_ctx* ctx = s.ctx;
     MDB_TRY(mdb_require_idle(ctx, mem));
     if (b == 0) return MDB_OK;
@@ -101,7 +121,7 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     const size_t o_qu = take(b * 4), o_ckeys = take(b * ne * 8), o_ccnt = take(b * 4), o_probes = take(b * ne * 4), o_pcnt = take(b * 4),
                  o_keys = take(b * ke * 8), o_cnts = take(b * 4), o_found = take(b), o_doc = take(b * ke * 16), o_sc = take(b * ke * 4),
-                 o_blk = take(block_out ? mdb_points_block_bytes_impl(b, k) : 0);
+                 o_blk = take(block_out ? mdb_points_block_bytes_impl(b, k) : 0), o_rows = take(pio ? b * (ne + 2) * 4 : 0);
     char* base;
     MDB_TRY(mdb_scratch(ctx, 11, off, (void**)&base));
     uint32_t* d_q_user = nullptr;
@@ -130,6 +150,17 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
     ctx->stat_fixed_bytes = 0;
     static_assert(sizeof(IvfUserDev) == 32 && offsetof(IvfUserDev, valid) == 0 && offsetof(IvfUserDev, num_lists) == 8,
                   "ClosureFilter reads IvfUserDev records as words");
+    const size_t prow = ne + 2;
+    if (pio && !pio->out) {
+        // ---- probes as given: the centroid-graph search ran elsewhere (another rank, for its slice of the batch)
+        uint32_t* rows = pio->rows;
+        if (mem != MDB_MEM_DEVICE) {
+            rows = (uint32_t*)(base + o_rows);
+            MDB_TRY(mdb_stage_small(ctx, pio->rows, b * prow * 4, rows));
+        }
+        spann_probe_rows_kernel<<<dim3((unsigned)((b * prow + 255) / 256)), 256, 0, ctx->stream>>>(rows, probes, pcnt, dfound, (uint32_t)ne, b, 0);
+        MDB_HIP(ctx, hipGetLastError());
+    } else {
     ClosureFilter cf;
     cf.probes = probes; cf.probe_cnt = pcnt; cf.found = dfound; cf.iusers = (const uint32_t*)s.ivf.d_users.p; cf.index_bytes = s.hnsw.d_index.p;
     cf.ratio = params->centroid_distance_ratio;
@@ -139,6 +170,16 @@ static mdb_status spann_search_impl(SpannSet& s, const float* queries, size_t b,
             ckeys, ccnt, (int)nexp, params->centroid_distance_ratio, s.hnsw.d_users.p, s.ivf.d_users.p, d_q_user,
             s.hnsw.d_index.p, probes, pcnt, dfound, b, ctx->d_flags);
     MDB_HIP(ctx, hipGetLastError());
+    }
+    if (pio && pio->out) {
+        // ---- the probes are the result
+        uint32_t* rows = mem == MDB_MEM_DEVICE ? pio->rows : (uint32_t*)(base + o_rows);
+        spann_probe_rows_kernel<<<dim3((unsigned)((b * prow + 255) / 256)), 256, 0, ctx->stream>>>(rows, probes, pcnt, dfound, (uint32_t)ne, b, 1);
+        MDB_HIP(ctx, hipGetLastError());
+        if (mem == MDB_MEM_DEVICE) return MDB_OK;
+        const HostCopy back[1] = {{pio->rows, rows, b * prow * 4}};
+        return mdb_return_to_host(ctx, back, 1);
+    }
     // device results, no points block: the scan's merge launch remaps, re-ranks and passes the found flags on (IvfSet::ScanRemap)
     IvfSet::ScanRemap srm;
     if (!block_out && mem == MDB_MEM_DEVICE) {
@@ -606,6 +647,36 @@ mdb_status mdb_multi_spann_search_shard(mdb_multi_spann* ms, const mdb_u128* use
     if (!block_out) return MDB_ERR_INVALID_ARG;
     const SpannFilterArg fa{allow, n_bitmaps, words_per_bitmap};
     return multi_spann_search_impl(ms, user_ids, queries, b, params, mem, nullptr, nullptr, nullptr, nullptr, &fa, false, block_out);
+}
+
+size_t mdb_spann_probe_row_words(const mdb_search_params* params) {
+    if (!params) return 0;
+    const size_t nexp = params->num_explored_centroids < 0 ? params->top_k : (size_t)params->num_explored_centroids;
+    return std::max<size_t>(nexp, 1) + 2;
+}
+
+mdb_status mdb_multi_spann_probes(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b, const mdb_search_params* params,
+                                  mdb_mem mem, uint32_t* rows_out) {
+    if (!ms || (!queries && b) || (!user_ids && b) || !params || !rows_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ms->set.ctx->mu);
+    MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
+    std::vector<uint32_t> qu(b);
+    multi_spann_user_slots(ms, user_ids, b, qu.data());
+    const SpannProbes pio{true, rows_out};
+    return spann_search_impl(ms->set, queries, b, qu.data(), params, mem, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, &pio);
+}
+
+mdb_status mdb_multi_spann_search_shard_probes(mdb_multi_spann* ms, const mdb_u128* user_ids, const float* queries, size_t b,
+                                               const mdb_search_params* params, mdb_mem mem, const uint32_t* rows, const uint32_t* allow,
+                                               size_t n_bitmaps, size_t words_per_bitmap, void* block_out) {
+    if (!ms || (!queries && b) || (!user_ids && b) || !params || !rows || !block_out) return MDB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ms->set.ctx->mu);
+    MDB_HIP(ms->set.ctx, hipSetDevice(ms->set.ctx->device));
+    std::vector<uint32_t> qu(b);
+    multi_spann_user_slots(ms, user_ids, b, qu.data());
+    const SpannFilterArg fa{allow, n_bitmaps, words_per_bitmap};
+    const SpannProbes pio{false, const_cast<uint32_t*>(rows)};
+    return spann_search_impl(ms->set, queries, b, qu.data(), params, mem, nullptr, nullptr, nullptr, nullptr, &fa, false, block_out, &pio);
 }
 
 mdb_status mdb_multi_spann_merge_shards(mdb_multi_spann* ms, const mdb_u128* user_ids, const void* blocks, size_t world, size_t b,

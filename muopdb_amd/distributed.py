@@ -231,6 +231,41 @@ class PointsGather:
             self.ctx.check(self.ctx.lib.mdb_multi_spann_merge_shards(ms.h, user_ids_c, *self._tail(True)))
         return self.out_docs, self.out_scores, self.out_counts
 
+class ProbeRowsShare:
+    """List-sharded multi-user SPANN with the centroid stage NOT replicated: rank r runs `centroids.ann_search` + the ratio filter
+    (spann/index.rs:211-246) for ITS slice of the batch only, the probe rows meet in one all-gather, every rank scans its lists for
+    the whole batch from the gathered table (include/muopdb_hip.h: mdb_multi_spann_probes / mdb_multi_spann_search_shard_probes).
+
+        sh = ProbeRowsShare(ctx, b, row_words, "cuda")           # row_words = mdb_spann_probe_row_words(params)
+        lo, hi = sh.slice
+        mdb_multi_spann_probes(ms, user_ids[lo:hi], queries[lo:hi], hi - lo, params, MDB_MEM_DEVICE, sh.send.data_ptr())
+        rows = sh.gather()                                        # [b][row_words] on every rank, identical
+        mdb_multi_spann_search_shard_probes(ms, user_ids, queries, b, params, MDB_MEM_DEVICE, rows.data_ptr(), ..., g.send.data_ptr())
+
+    Slices are `per` = ceil(b / world) rows each (the last ranks' may be short or empty): rank-major blocks of an all-gather are
+    then the batch's table in batch order, no permutation; the padding rows of a short slice stay zero (count 0, found 0) and lie
+    beyond row b.  When it pays: the closure kernel is one wave per pair, so its time is flat up to a few hundred pairs and grows
+    with the batch beyond; replicating it on every rank costs nothing at batch 128 and most of the step at batch 1024 x 8 ranks."""
+
+    def __init__(self, ctx, b, row_words, device, group=None):
+        self.ctx, self.b, self.row_words, self.group = ctx, b, row_words, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.per = (b + self.world - 1) // self.world
+        lo = min(self.rank * self.per, b)
+        self.slice = (lo, min(lo + self.per, b))
+        self.send = torch.zeros((max(self.per, 1), row_words), dtype=torch.int32, device=device)
+        self.rows = torch.zeros((self.world * max(self.per, 1), row_words), dtype=torch.int32, device=device)
+
+    def gather(self):
+        if self.world == 1:
+            self.rows.copy_(self.send)
+        else:
+            with _span("probes_allgather"):
+                dist.all_gather_into_tensor(self.rows, self.send, group=self.group)  # rank-major slices == batch order
+        return self.rows
+
+
 # ------------------------------------------------------------------------------------------ query partitionings (no merge)
 # SURVEY.md §8e asks for BOTH partitionings to be measured: posting-list shards (above: every rank sees every query, one all-gather
 # of points blocks + an exact merge) and QUERY partitionings, where a rank answers a disjoint subset of the batch whole and the only

@@ -755,6 +755,31 @@ class MultiSpannIndex:
         uids = L.u128_array(list(user_ids))
         return _merge_shards(self.ctx, lambda *a: self.ctx.lib.mdb_multi_spann_merge_shards(self.h, uids, *a), blocks, b, k, True)
 
+    def probes(self, user_ids, queries, params):
+        """The centroid stage alone (mdb_multi_spann_probes): per (user, query) pair the posting lists the closure kept, nearest
+        first, BEFORE any scan, as uint32 rows [b][2 + ne] = (count, found, list ids).  Same on every list shard (every rank holds
+        every user's centroid graph), so under list sharding ONE rank runs it per pair and the others receive the row."""
+        q = L.f32(queries).reshape(-1, self.num_features)
+        p = params.to_c()
+        rows = np.zeros((q.shape[0], int(self.ctx.lib.mdb_spann_probe_row_words(C.byref(p)))), np.uint32)
+        self.ctx.check(self.ctx.lib.mdb_multi_spann_probes(self.h, L.u128_array(list(user_ids)), L.ptr(q, C.c_float), C.c_size_t(q.shape[0]),
+                                                           C.byref(p), C.c_int(L.MEM_HOST), L.ptr(rows, C.c_uint32)))
+        return rows
+
+    def search_shard_probes(self, user_ids, queries, params, rows, planner=None):
+        """search_shard with the centroid stage handed in (mdb_multi_spann_search_shard_probes): the POINTS block is byte-identical
+        to search_shard's when `rows` came from probes() with the same params."""
+        q = L.f32(queries).reshape(-1, self.num_features)
+        b = q.shape[0]
+        p = params.to_c()
+        rows = np.ascontiguousarray(rows, np.uint32).reshape(b, int(self.ctx.lib.mdb_spann_probe_row_words(C.byref(p))))
+        blk = np.zeros(int(self.ctx.lib.mdb_points_block_bytes(C.c_size_t(b), C.c_size_t(params.top_k))), np.uint8)
+        ap, nb, words, keep = _planner_args(planner)
+        self.ctx.check(self.ctx.lib.mdb_multi_spann_search_shard_probes(
+            self.h, L.u128_array(list(user_ids)), L.ptr(q, C.c_float), C.c_size_t(b), C.byref(p), C.c_int(L.MEM_HOST),
+            L.ptr(rows, C.c_uint32), ap, nb, words, L.ptr(blk, C.c_uint8)))
+        return blk
+
     def search_for_users(self, user_ids, query, params):
         """Snapshot::search_for_users (collection/snapshot.rs:39-66): one query fanned to several
         users, concatenated, sorted by (score, doc id), truncated to top_k."""

@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "mdb_spann_search_filtered", "mdb_spann_attach", "mdb_spann_search_submit",
     "mdb_multi_spann_search_filtered", "mdb_multi_spann_attach", "mdb_multi_spann_search_submit",
     "mdb_set_option", "mdb_get_option", "mdb_points_block_bytes", "mdb_points_block_views", "mdb_ivf_search_shard", "mdb_ivf_merge_shards",
-    "mdb_spann_search_shard", "mdb_spann_merge_shards", "mdb_multi_spann_search_shard", "mdb_multi_spann_merge_shards",
+    "mdb_spann_search_shard", "mdb_spann_merge_shards", "mdb_multi_spann_search_shard", "mdb_multi_spann_merge_shards", "mdb_spann_probe_row_words", "mdb_multi_spann_probes", "mdb_multi_spann_search_shard_probes",
     "mdb_allgather_blocks", "mdb_device_mem_info",
 ]
 
@@ -95,7 +95,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         _lib.mdb_last_error.restype = C.c_char_p
         _lib.mdb_version.restype = C.c_char_p
-        for n in ("mdb_shard_block_bytes", "mdb_points_block_bytes", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_ivf_num_resident_vectors", "mdb_hnsw_num_vectors",
+        for n in ("mdb_shard_block_bytes", "mdb_points_block_bytes", "mdb_spann_probe_row_words", "mdb_ivf_num_clusters", "mdb_ivf_num_vectors", "mdb_ivf_num_features", "mdb_ivf_num_resident_vectors", "mdb_hnsw_num_vectors",
                   "mdb_multi_spann_num_users"):
             if hasattr(_lib, n):
                 getattr(_lib, n).restype = C.c_size_t

@@ -8,6 +8,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -334,5 +335,47 @@ def test_user_and_batch_partitionings_equal_unsharded_world2():
         p.start()
     for p in procs:
         p.join(240)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) == 1.0
+
+
+def _probe_rows_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for b, words in ((7, 5), (1, 3), (8, 18), (3, 2)):
+        # the table every rank must end up with: row i = what the centroid stage of pair i yields (here: a function of i)
+        table = (np.arange(b * words, dtype=np.int64).reshape(b, words) * 2654435761 % (1 << 31)).astype(np.int32)
+        sh = D.ProbeRowsShare(None, b, words, "cpu")
+        lo, hi = sh.slice
+        ok &= 0 <= lo <= hi <= b and hi - lo <= sh.per and sh.send.shape == (max(sh.per, 1), words)
+        covered = torch.zeros(b, dtype=torch.int32)
+        covered[lo:hi] = 1
+        dist.all_reduce(covered)
+        ok &= bool((covered == 1).all())                       # every pair's closure runs on exactly one rank
+        sh.send[:hi - lo] = torch.from_numpy(table[lo:hi])
+        rows = sh.gather()
+        ok &= rows.shape == (world * max(sh.per, 1), words) and bool(torch.equal(rows[:b], torch.from_numpy(table)))
+        ok &= bool((rows[b:] == 0).all())                       # padding rows of short slices: count 0, found 0
+    t = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        out.put(float(t.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_probe_rows_share_slices_cover_the_batch(world):
+    """ProbeRowsShare (list-sharded multi-user SPANN, closure once per pair): the ranks' slices partition the batch, and ONE
+    all-gather of the slices IS the batch's probe-row table in batch order on every rank, for even, ragged, short (b < world) batches."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_probe_rows_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
         assert p.exitcode == 0
     assert out.get(timeout=5) == 1.0

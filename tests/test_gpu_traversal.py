@@ -951,4 +951,80 @@ def test_user_and_batch_partitionings_on_the_device(ctx, oracle, world):
         ctx.sync()
         exs2.append(ex)
     check(exs2, want2, False)
-    ivf.close()
+    ivf.close()@pytest.mark.gpu
+def test_multi_spann_probe_rows_shared_closure(ctx, oracle):
+    """List shards with the centroid stage run ONCE per (user, query) pair (mdb_multi_spann_probes on a slice of the batch, the
+    rows concatenated as an all-gather would, mdb_multi_spann_search_shard_probes on every shard): the probe rows are the same on
+    every shard and for every slicing, each POINTS block is byte-identical to search_shard's, and the merge == unsharded == oracle
+    (Spann::search, spann/index.rs:211-266).  A row with a count beyond the row is clamped; a foreign list id is skipped and
+    reported, not read."""
+    from muopdb_amd.index import MultiSpannIndex, SearchParams
+    from muopdb_amd.lib import MuopdbError
+    rng = np.random.default_rng(91)
+    d, world = 16, 4
+    users, allq, allu = {}, [], []
+    for ui in range(4):
+        n = 700 + 150 * ui
+        v = rng.integers(0, 4, (n, d)).astype(np.float32)
+        docs = [int(x) for x in rng.permutation(n) + 5_000 * (ui + 1)]
+        f, _, _ = H.build_spann_files(oracle, v, docs, 9 + ui, seed=ui, max_neighbors=6, max_layers=2, ef_construction=30)
+        uid = (ui << 70) | (ui + 3)
+        users[uid] = f
+        for _ in range(7):
+            allq.append(v[rng.integers(0, n)] + rng.normal(0, 0.3, d))
+            allu.append(uid)
+    allq.insert(5, allq[0]); allu.insert(5, 999_999)                  # an unknown user inside the batch: None
+    allq = np.asarray(allq, np.float32)
+    b = len(allq)
+    cat = F.concat_multi_spann(users)
+    a = (cat["user_table"], d, cat["hnsw_index"], cat["hnsw_vectors"], cat["ivf_index"], cat["ivf_vectors"])
+    g, o = MultiSpannIndex(ctx, *a), oracle.MultiSpannIndex(*a)
+    graphs = {u: oracle.BlockBasedHnsw(f["hnsw_index"], f["hnsw_vectors"], d) for u, f in users.items()}
+    shards = [MultiSpannIndex(ctx, *a, None, r, world) for r in range(world)]
+    for k, ne, ratio in ((1, 1, 0.1), (5, 6, 2.0), (10, None, 0.5), (4, 0, 0.1)):
+        p = SearchParams(k, 40).with_centroid_distance_ratio(ratio)
+        op = oracle.SearchParams(k, 40, centroid_distance_ratio=ratio)
+        if ne is not None:
+            p.with_num_explored_centroids(ne)
+            op = oracle.SearchParams(k, 40, num_explored_centroids=ne, centroid_distance_ratio=ratio)
+        want = o.search_for_user(allu, allq, op)
+        rows = g.probes(allu, allq, p)
+        words = rows.shape[1]
+        assert words == max(k if ne is None else ne, 1) + 2
+        assert rows[5, 0] == 0 and rows[5, 1] == 0 and (rows[:, 0] <= words - 2).all()
+        nexp = k if ne is None else ne
+        for i in range(b):                                              # the rows against the oracle: ann_search + the ratio filter
+            if allu[i] not in graphs:
+                continue
+            near = graphs[allu[i]].ann_search(allq[i:i + 1], max(nexp, 1), 40)
+            ids, sc = near.doc_ids(0)[:nexp], near.scores[0, :min(int(near.counts[0]), nexp)]
+            kept = [c for c, s_ in zip(ids, sc) if np.float32(s_ - sc.min()) <= np.float32(sc.min() * np.float32(ratio))] if ids else []
+            assert rows[i, 1] == (1 if ids else 0) and rows[i, 0] == len(kept) and rows[i, 2:2 + len(kept)].tolist() == kept, (k, ne, i)
+        for r in range(world):                                          # every shard holds every centroid graph: the same rows
+            assert np.array_equal(shards[r].probes(allu, allq, p), rows)
+        per = (b + world - 1) // world                                  # the slices ProbeRowsShare hands the ranks
+        parts = [shards[r].probes(allu[r * per:(r + 1) * per], allq[r * per:(r + 1) * per], p) for r in range(world)]
+        assert np.array_equal(np.concatenate(parts), rows)
+        blocks = [s.search_shard_probes(allu, allq, p, rows) for s in shards]
+        for s, blk in zip(shards, blocks):
+            assert np.array_equal(blk, s.search_shard(allu, allq, p))
+        merged = shards[2].merge_shards(allu, blocks, b, k)
+        assert_result_rows(merged, want, b)
+        assert merged.found.tolist() == g.search_for_user(allu, allq, p).found.tolist() and merged.found[5] == 0
+    # hostile rows: a count beyond the row reads no further than the row; a list id the user does not have is an error, not a read
+    p = SearchParams(5, 40).with_num_explored_centroids(6).with_centroid_distance_ratio(2.0)
+    rows = g.probes(allu, allq, p)
+    full = rows.copy()
+    full[:, 0] = np.where(full[:, 1] != 0, 1000, 0)
+    exact = np.array([r_[0] == 6 for r_ in rows])
+    blk_big, blk_ref = shards[0].search_shard_probes(allu, allq, p, full), shards[0].search_shard(allu, allq, p)
+    if exact.all():
+        assert np.array_equal(blk_big, blk_ref)
+    bad = rows.copy()
+    bad[0, 2] = 1 << 30
+    with pytest.raises(MuopdbError):
+        shards[0].search_shard_probes(allu, allq, p, bad)
+    assert np.array_equal(shards[0].search_shard_probes(allu, allq, p, rows), blk_ref)   # the handle is fine afterwards
+
+
+
