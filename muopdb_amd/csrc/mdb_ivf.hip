@@ -61,6 +61,41 @@ __global__ __launch_bounds__(256) void gather_f32_tiles_kernel(const uint8_t* __
     tiles[t] = r;
 }
 
+// f32 POSTING LISTS are laid out in UNITS of 32 slots (slot s = unit s / 32, position s % 32; a list's slots are consecutive).  A
+// wave's tile is two consecutive units stored as ONE 64-lane SoA tile (`(unit0 * d4 * 32) + c4 * 64 + lane`) — or, for a list's LAST
+// tile when at most 32 vectors are left, ONE unit stored 32 wide (`(unit * d4 * 32) + c4 * 32 + lane`, lanes >= 32 idle): a list
+// pads to 32 slots, not 64.  (MuopDB's SPANN lists average ~64 vectors — C4: 64.25 — so half of them used to spill one or two
+// vectors into a second 64-slot tile: 1.56 x the rows resident; with units 1.2 x.  Capacity only: idle lanes never loaded anything.)
+// unit_desc[u] = (first unit of the tile << 2) | (u is the tile's second half) << 1 | (the tile is a 32-wide tail).
+__global__ __launch_bounds__(256) void gather_f32_units_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ unit_src,
+                                                               const uint32_t* __restrict__ unit_limit, const uint32_t* __restrict__ ids,
+                                                               const uint32_t* __restrict__ unit_desc, int d, int d4,
+                                                               float4* __restrict__ tiles, size_t total4, uint32_t* __restrict__ flags) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    const size_t l32 = t % MDB_UNIT;
+    const size_t c4 = (t / MDB_UNIT) % d4;
+    const size_t unit = t / ((size_t)MDB_UNIT * d4);
+    const uint32_t id = ids[unit * MDB_UNIT + l32];
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool valid = id != 0xFFFFFFFFu;
+    if (valid && id >= unit_limit[unit]) {
+        atomicOr(flags, MDB_FLAG_RANGE);  // "index out of bounds" (async_storage.rs:113-115)
+        valid = false;
+    }
+    if (valid) {
+        const float* p = (const float*)(src + unit_src[unit] + (size_t)id * d * 4);
+        int e = (int)c4 * 4;
+        r.x = e + 0 < d ? p[e + 0] : 0.f;
+        r.y = e + 1 < d ? p[e + 1] : 0.f;
+        r.z = e + 2 < d ? p[e + 2] : 0.f;
+        r.w = e + 3 < d ? p[e + 3] : 0.f;
+    }
+    const uint32_t ds = unit_desc[unit];
+    const size_t w = (ds & 1u) ? MDB_UNIT : MDB_TILE;
+    tiles[(size_t)(ds >> 2) * d4 * MDB_UNIT + c4 * w + ((ds & 2u) ? MDB_UNIT : 0) + l32] = r;
+}
+
 // Gather PQ codes (m bytes per vector) into tiles of 64 slots x mw 4-byte words:
 // word index of (tile, w, lane) = (tile*mw + w)*64 + lane, zero padded.
 __global__ __launch_bounds__(256) void gather_code_tiles_kernel(const uint8_t* __restrict__ src,
@@ -136,6 +171,8 @@ struct TileMap {
     }
     // all threads of the block (>= MAP_PCH threads not required); returns the number of tiles; sets bad on
     // an out-of-range list id ("Index out of bound", storage.rs:280-286 — the list is skipped)
+    // (f32 lists: list_tile_off counts UNITS of 32 slots — gather_f32_units_kernel; a list of n units is (n + 1) / 2 wave tiles, the
+    // last one 32 wide when n is odd: bit 31 of pstart)
     __device__ int build(const ScanArgs& a, const IvfUserDev& u, int qi, int p0, int n, bool& bad) {
         const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
         for (int j = tid; j < MAP_PCH; j += nthr) {
@@ -146,7 +183,9 @@ struct TileMap {
                 else {
                     uint32_t g = u.list_base + c;
                     t0 = a.list_tile_off[g];
-                    cnt = a.list_tile_off[g + 1] - t0;
+                    const uint32_t units = a.list_tile_off[g + 1] - t0;
+                    cnt = (units + 1) >> 1;
+                    t0 |= (units & 1u) << 31;
                 }
             }
             pstart[j] = t0;
@@ -180,7 +219,12 @@ struct TileMap {
         for (int x = 0; x < MAP_PCH / MDB_WAVE; ++x) j += __popcll(__ballot(ppref[x * MDB_WAVE + lane + 1] <= t));
         return j;
     }
-    __device__ __forceinline__ uint32_t tile_of(uint32_t t, int j) const { return pstart[j] + (t - ppref[j]); }
+    // first unit of wave tile t of list j; `half`: the tile is the list's 32-wide tail
+    __device__ __forceinline__ uint32_t unit_of(uint32_t t, int j, bool& half) const {
+        const uint32_t ps = pstart[j], local = t - ppref[j];
+        half = (ps >> 31) && local + 1 == ppref[j + 1] - ppref[j];
+        return (ps & 0x7FFFFFFFu) + 2 * local;
+    }
 };
 
 // NoQuantizer<D>: distance = D::calculate(query, vector) (noq/mod.rs:44-51): sqrt L2 / neg dot
@@ -232,12 +276,13 @@ __global__ __launch_bounds__(BLK) void ivf_scan_f32_kernel(ScanArgs a, const flo
                 const int t = (r * nsplit + split) * NW + wave;
                 uint64_t key = MDB_KEY_MAX;
                 if (t < T) {
-                    const uint32_t tile = map.tile_of((uint32_t)t, map.list_of((uint32_t)t));
-                    uint32_t pid = a.slot_ids[(size_t)tile * MDB_TILE + lane];
+                    bool half;
+                    const uint32_t unit = map.unit_of((uint32_t)t, map.list_of((uint32_t)t), half);   // wave-uniform
+                    const uint32_t pid = (half && lane >= MDB_UNIT) ? 0xFFFFFFFFu : a.slot_ids[(size_t)unit * MDB_UNIT + lane];
                     if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid) && allow_test(a, qi, pid)) {
-                        TileLoader ld{tiles + (size_t)tile * p.d4 * MDB_TILE + lane};
+                        UnitLoader ld{tiles + (size_t)unit * p.d4 * MDB_UNIT + lane, half ? (size_t)MDB_UNIT : (size_t)MDB_TILE};
                         float raw[1];
-                        exact_sums<METRIC, 1, TileLoader, 3>(ld, qb, 0, p, raw);
+                        exact_sums<METRIC, 1, UnitLoader, 3>(ld, qb, 0, p, raw);
                         float dist = finish_distance<METRIC>(raw[0]);
                         if (dist != dist) nan_seen = true;
                         key = make_key(dist, pid);
@@ -1884,8 +1929,11 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
     std::vector<uint64_t> list_byte_off;   // per global list (or ~0 when not owned / empty)
     std::vector<uint32_t> list_len;
     std::vector<uint32_t> h_list_tile_off(1, 0);
-    std::vector<uint64_t> tile_src;        // per tile: byte offset of the user's vector 0
-    std::vector<uint32_t> tile_limit;      // per tile: user's num_vectors
+    std::vector<uint64_t> tile_src;        // per tile (f32 lists: per 32-slot unit): byte offset of the user's vector 0
+    std::vector<uint32_t> tile_limit;      // per tile (unit): user's num_vectors
+    std::vector<uint32_t> unit_desc;       // f32 lists: gather_f32_units_kernel's unit descriptors
+    const bool units = (quant ? quant->kind : MDB_QUANT_NONE) != MDB_QUANT_PQ;   // f32 lists: list_tile_off counts 32-slot units
+    size_t wave_tiles = 0;
     std::vector<uint64_t> cent_tile_src;
     std::vector<uint32_t> cent_tile_first, cent_tile_limit;
     size_t tomb_words = 0;
@@ -1967,15 +2015,25 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
             list_byte_off.push_back(ne ? pl_off : ~0ull);
             list_len.push_back((uint32_t)ne);
             uint32_t nt = (uint32_t)((ne + MDB_TILE - 1) / MDB_TILE);
+            wave_tiles += nt;
+            if (units) {   // ceil(ne / 32) units: whole tiles of two, then one (<= 32 left) or two
+                nt = (uint32_t)((ne + MDB_UNIT - 1) / MDB_UNIT);
+                const uint32_t u0 = h_list_tile_off.back();
+                for (uint32_t t = 0; t < nt; ++t) {
+                    const bool tail = (nt & 1u) && t + 1 == nt;
+                    unit_desc.push_back(tail ? ((u0 + t) << 2) | 1u : ((u0 + (t & ~1u)) << 2) | ((t & 1u) << 1));
+                }
+            }
             for (uint32_t t = 0; t < nt; ++t) { tile_src.push_back(bi.vec_data_offset); tile_limit.push_back((uint32_t)nv); }
             h_list_tile_off.push_back(h_list_tile_off.back() + nt);
             total_slots_valid += ne;
         }
     }
     G = list_len.size();
-    const size_t ntiles = h_list_tile_off.back();
-    total_tiles = ntiles;
-    if (ntiles > 0x7FFFFFFFull / MDB_TILE) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "too many posting-list slots");
+    const size_t ntiles = h_list_tile_off.back();   // (f32 lists: units)
+    const size_t slots_per = units ? MDB_UNIT : MDB_TILE;
+    total_tiles = wave_tiles;
+    if (ntiles > (units ? 0x3FFFFFFFull : 0x7FFFFFFFull) / MDB_TILE) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "too many posting-list slots");
     // ---- uploads
     DevBuf<uint8_t> d_vec;
     if (d_index.alloc(index_len + 16) != hipSuccess || d_vec.alloc(vectors_len + 16) != hipSuccess)
@@ -1983,9 +2041,9 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
     MDB_HIP(ctx, hipMemcpyAsync(d_index.p, index, index_len, hipMemcpyHostToDevice, ctx->stream));
     MDB_HIP(ctx, hipMemcpyAsync(d_vec.p, vectors, vectors_len, hipMemcpyHostToDevice, ctx->stream));
     DevBuf<uint64_t> d_lbo, d_oo, d_tsrc, d_ctsrc;
-    DevBuf<uint32_t> d_tlim, d_ctfirst, d_ctlim;
+    DevBuf<uint32_t> d_tlim, d_ctfirst, d_ctlim, d_udesc;
     std::vector<uint64_t> out_off(G);
-    for (size_t g = 0; g < G; ++g) out_off[g] = (uint64_t)h_list_tile_off[g] * MDB_TILE;
+    for (size_t g = 0; g < G; ++g) out_off[g] = (uint64_t)h_list_tile_off[g] * slots_per;
     auto up64 = [&](DevBuf<uint64_t>& d, const std::vector<uint64_t>& h) -> mdb_status {
         if (d.alloc(h.size() + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "alloc");
         if (!h.empty()) MDB_HIP(ctx, hipMemcpyAsync(d.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -2016,7 +2074,7 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
     ones_word = tomb_words;  // the spare last word: "no planner" allow bitmap
     MDB_HIP(ctx, hipMemsetAsync(d_tomb.p + ones_word, 0xFF, 4, ctx->stream));
     // ---- decode posting lists into the slot id array
-    const size_t nslots = ntiles * MDB_TILE;
+    const size_t nslots = ntiles * slots_per;
     if (d_slot_ids.alloc(nslots + 1) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "slot ids alloc");
     if (nslots) fill_u32_kernel<<<dim3((unsigned)((nslots + 255) / 256)), 256, 0, ctx->stream>>>(d_slot_ids.p, nslots, 0xFFFFFFFFu);
     MDB_TRY(ef_decode_lists(ctx, d_index.p, d_lbo.p, d_oo.p, dec_off.size(), d_slot_ids.p));
@@ -2051,12 +2109,13 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
         for (auto& o : offsets)
             if ((o.second + 8) % 4 != 0) return mdb_fail(ctx, MDB_ERR_FORMAT, "f32 vector file is not 4-byte aligned");
         int d4 = ((int)num_features + 3) / 4;
-        size_t total4 = ntiles * MDB_TILE * (size_t)d4;
+        size_t total4 = ntiles * MDB_UNIT * (size_t)d4;
+        MDB_TRY(up32(d_udesc, unit_desc));
         if (d_tiles.alloc(total4 * 4 + 4) != hipSuccess) return mdb_fail(ctx, MDB_ERR_OOM, "vector tiles alloc (%zu MiB)", total4 * 16 >> 20);
         if (total4)
-            gather_f32_tiles_kernel<<<dim3((unsigned)((total4 + 255) / 256)), 256, 0, ctx->stream>>>(
-                d_vec.p, d_tsrc.p, d_tlim.p, d_slot_ids.p, nullptr, (int)num_features, d4, (float4*)d_tiles.p, total4,
-                ctx->d_flags);
+            gather_f32_units_kernel<<<dim3((unsigned)((total4 + 255) / 256)), 256, 0, ctx->stream>>>(
+                d_vec.p, d_tsrc.p, d_tlim.p, d_slot_ids.p, d_udesc.p, (int)num_features, d4, (float4*)d_tiles.p, total4, ctx->d_flags);
+
     }
     MDB_HIP(ctx, hipGetLastError());
     // ---- centroids into tiles (coarse quantizer scan, find_nearest_centroids)

@@ -165,6 +165,28 @@ def _worker(rank, world, port, out):
         for i in range(24):
             c = int(mwant.counts[i])
             check(int(c2[i]) == c and [(int(h2[i, j, 1]) << 64) | int(h2[i, j, 0]) for j in range(c)] == mwant.doc_ids(i), "multi-user row %d" % i)
+        # ---- the same batch with the centroid-graph closure run ONCE per pair: this rank's slice -> probe rows -> one more all-gather
+        sh = D.ProbeRowsShare(ctx, 24, int(ctx.lib.mdb_spann_probe_row_words(C.byref(pc))), dev)
+        lo, hi = sh.slice
+        if hi > lo:
+            ctx.check(ctx.lib.mdb_multi_spann_probes(mshard.h, L.u128_array(uq[lo:hi]), C.c_void_p(mqd[lo:hi].data_ptr()), C.c_size_t(hi - lo),
+                                                     C.byref(pc), C.c_int(L.MEM_DEVICE), C.c_void_p(sh.send.data_ptr())))
+        rows = sh.gather()
+        ctx.sync()
+        check(bool(np.array_equal(rows[:24].cpu().numpy().view(np.uint32), mfull.probes(uq, mq, sp))), "gathered probe rows == one rank's rows of the whole batch")
+        blk_ref = g2.send.clone()
+        g2.send.zero_()
+        ctx.check(ctx.lib.mdb_multi_spann_search_shard_probes(mshard.h, uarr, C.c_void_p(mqd.data_ptr()), C.c_size_t(24), C.byref(pc),
+                                                              C.c_int(L.MEM_DEVICE), C.c_void_p(rows.data_ptr()), None, C.c_size_t(0), C.c_size_t(0),
+                                                              C.c_void_p(g2.send.data_ptr())))
+        ctx.sync()
+        check(bool(torch.equal(g2.send, blk_ref)), "points block from gathered probe rows == search_shard's")
+        d3, s3, c3 = g2.gather_merge_multi(mshard, uarr)
+        ctx.sync()
+        h3 = d3.cpu().numpy().view(np.uint64)
+        for i in range(24):
+            c = int(mwant.counts[i])
+            check(int(c3[i]) == c and [(int(h3[i, j, 1]) << 64) | int(h3[i, j, 0]) for j in range(c)] == mwant.doc_ids(i), "shared-closure row %d" % i)
     except Exception as e:  # noqa: BLE001
         ok = False
         why.append(repr(e))
