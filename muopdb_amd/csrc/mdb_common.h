@@ -15,7 +15,7 @@
 
 #define MDB_WAVE 64
 #define MDB_TILE 64          // vectors per tile of the list-contiguous SoA layout (one per lane)
-#define MDB_UNIT 32          // f32 posting lists: slots per unit (a tile = two units, a list's tail may be one: mdb_ivf.hip)
+#define MDB_UNIT 16          // f32 posting lists: slots per unit (a tile = four units 64 wide; a list's tail tile is 1-3 units, 16-48 wide: mdb_ivf.hip)
 #define MDB_BLOCK 256        // threads per scan block (4 tiles per round)
 #define MDB_KEY_MAX 0xFFFFFFFFFFFFFFFFull
 #define MDB_MAX_K 2048       // largest top-k / ef served by the on-chip selectors

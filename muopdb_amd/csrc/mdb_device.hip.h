@@ -79,9 +79,9 @@ struct TileLoader {  // list-contiguous SoA tile, this lane's vector
     const float4* p;  // &tile4[(tile * d4) * 64 + lane]
     __device__ __forceinline__ float4 get4(int c4) const { return p[(size_t)c4 * MDB_TILE]; }
 };
-struct UnitLoader {  // f32 posting-list tile in 32-slot units (gather_f32_units_kernel): 64 wide, or a list's 32-wide tail
-    const float4* p;  // &tile4[unit * d4 * 32 + lane]
-    size_t w;         // 64 / 32 (wave-uniform)
+struct UnitLoader {  // f32 posting-list tile in 16-slot units (gather_f32_units_kernel): 64 wide, or a list's 16 / 32 / 48-wide tail
+    const float4* p;  // &tile4[unit * d4 * 16 + lane]
+    size_t w;         // the tile's width in slots (wave-uniform)
     __device__ __forceinline__ float4 get4(int c4) const { return p[(size_t)c4 * w]; }
 };
 struct RowLoader {  // plain row-major row, arbitrary alignment

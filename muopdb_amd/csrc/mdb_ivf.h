@@ -67,13 +67,13 @@ struct IvfSet {
     std::vector<IvfUserDev> h_users;
     size_t G = 0, total_tiles = 0, total_slots_valid = 0;
     DevBuf<uint8_t> d_index;          // the uploaded `index` file (doc ids are read from it)
-    DevBuf<uint32_t> d_list_tile_off; // [G+1]: tiles (PQ) / 32-slot units (f32 lists)
+    DevBuf<uint32_t> d_list_tile_off; // [G+1]: tiles (PQ) / 16-slot units (f32 lists)
     DevBuf<IvfUserDev> d_users;
     DevBuf<uint32_t> d_tomb;
     std::vector<uint32_t> h_tomb;
     DevBuf<uint32_t> d_slot_ids;
     DevBuf<uint32_t> d_codes;         // PQ: [tiles][mw][64] 4-byte code words
-    DevBuf<float> d_tiles;            // NoQ: 32-slot units, [units][d4][32] float4 worth, a tile = two units 64 wide or a 32-wide tail (gather_f32_units_kernel)
+    DevBuf<float> d_tiles;            // NoQ: 16-slot units, [units][d4][16] float4 worth, a tile = four units 64 wide or a list's 16..48-wide tail (gather_f32_units_kernel)
     DevBuf<float> d_cent_tiles;       // centroids, per user, SoA tiles
     PqDev pq;
     int mw = 0;

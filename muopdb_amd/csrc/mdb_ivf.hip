@@ -61,22 +61,23 @@ __global__ __launch_bounds__(256) void gather_f32_tiles_kernel(const uint8_t* __
     tiles[t] = r;
 }
 
-// f32 POSTING LISTS are laid out in UNITS of 32 slots (slot s = unit s / 32, position s % 32; a list's slots are consecutive).  A
-// wave's tile is two consecutive units stored as ONE 64-lane SoA tile (`(unit0 * d4 * 32) + c4 * 64 + lane`) — or, for a list's LAST
-// tile when at most 32 vectors are left, ONE unit stored 32 wide (`(unit * d4 * 32) + c4 * 32 + lane`, lanes >= 32 idle): a list
-// pads to 32 slots, not 64.  (MuopDB's SPANN lists average ~64 vectors — C4: 64.25 — so half of them used to spill one or two
-// vectors into a second 64-slot tile: 1.56 x the rows resident; with units 1.2 x.  Capacity only: idle lanes never loaded anything.)
-// unit_desc[u] = (first unit of the tile << 2) | (u is the tile's second half) << 1 | (the tile is a 32-wide tail).
+// f32 POSTING LISTS are laid out in UNITS of 16 slots (slot s = unit s / 16, position s % 16; a list's slots are consecutive).  A
+// wave's tile is four consecutive units stored as ONE 64-lane SoA tile (`(unit0 * d4 * 16) + c4 * 64 + lane`) — or, for a list's LAST
+// tile when n = 1..3 units are left, those n units stored 16 n wide (`(unit0 * d4 * 16) + c4 * 16 n + lane`, lanes >= 16 n idle): a
+// list pads to 16 slots, not 64.  (MuopDB's SPANN lists average ~64 vectors — C4: 64.25 — so half of them used to spill one or two
+// vectors into a second 64-slot tile: 1.56 x the rows resident; in units of 16: 1.13 x.  Capacity only: idle lanes never loaded anything.)
+// unit_desc[u] = (first unit of the tile << 4) | (u's position in the tile) << 2 | (units of a narrow tail tile, 0 = a whole tile).
+#define MDB_UPT (MDB_TILE / MDB_UNIT)   // units per whole tile
 __global__ __launch_bounds__(256) void gather_f32_units_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ unit_src,
                                                                const uint32_t* __restrict__ unit_limit, const uint32_t* __restrict__ ids,
                                                                const uint32_t* __restrict__ unit_desc, int d, int d4,
                                                                float4* __restrict__ tiles, size_t total4, uint32_t* __restrict__ flags) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total4) return;
-    const size_t l32 = t % MDB_UNIT;
+    const size_t l = t % MDB_UNIT;
     const size_t c4 = (t / MDB_UNIT) % d4;
     const size_t unit = t / ((size_t)MDB_UNIT * d4);
-    const uint32_t id = ids[unit * MDB_UNIT + l32];
+    const uint32_t id = ids[unit * MDB_UNIT + l];
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     bool valid = id != 0xFFFFFFFFu;
     if (valid && id >= unit_limit[unit]) {
@@ -92,8 +93,8 @@ __global__ __launch_bounds__(256) void gather_f32_units_kernel(const uint8_t* __
         r.w = e + 3 < d ? p[e + 3] : 0.f;
     }
     const uint32_t ds = unit_desc[unit];
-    const size_t w = (ds & 1u) ? MDB_UNIT : MDB_TILE;
-    tiles[(size_t)(ds >> 2) * d4 * MDB_UNIT + c4 * w + ((ds & 2u) ? MDB_UNIT : 0) + l32] = r;
+    const size_t w = (ds & 3u) ? (size_t)(ds & 3u) * MDB_UNIT : MDB_TILE;
+    tiles[(size_t)(ds >> 4) * d4 * MDB_UNIT + c4 * w + (size_t)((ds >> 2) & 3u) * MDB_UNIT + l] = r;
 }
 
 // Gather PQ codes (m bytes per vector) into tiles of 64 slots x mw 4-byte words:
@@ -171,8 +172,8 @@ struct TileMap {
     }
     // all threads of the block (>= MAP_PCH threads not required); returns the number of tiles; sets bad on
     // an out-of-range list id ("Index out of bound", storage.rs:280-286 — the list is skipped)
-    // (f32 lists: list_tile_off counts UNITS of 32 slots — gather_f32_units_kernel; a list of n units is (n + 1) / 2 wave tiles, the
-    // last one 32 wide when n is odd: bit 31 of pstart)
+    // (f32 lists: list_tile_off counts UNITS of 16 slots — gather_f32_units_kernel; a list of n units is ceil(n / 4) wave tiles, the
+    // last one n % 4 units wide when that is not 0: bits 30-31 of pstart)
     __device__ int build(const ScanArgs& a, const IvfUserDev& u, int qi, int p0, int n, bool& bad) {
         const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
         for (int j = tid; j < MAP_PCH; j += nthr) {
@@ -184,8 +185,8 @@ struct TileMap {
                     uint32_t g = u.list_base + c;
                     t0 = a.list_tile_off[g];
                     const uint32_t units = a.list_tile_off[g + 1] - t0;
-                    cnt = (units + 1) >> 1;
-                    t0 |= (units & 1u) << 31;
+                    cnt = (units + MDB_UPT - 1) / MDB_UPT;
+                    t0 |= (units & (MDB_UPT - 1)) << 30;
                 }
             }
             pstart[j] = t0;
@@ -219,11 +220,11 @@ struct TileMap {
         for (int x = 0; x < MAP_PCH / MDB_WAVE; ++x) j += __popcll(__ballot(ppref[x * MDB_WAVE + lane + 1] <= t));
         return j;
     }
-    // first unit of wave tile t of list j; `half`: the tile is the list's 32-wide tail
-    __device__ __forceinline__ uint32_t unit_of(uint32_t t, int j, bool& half) const {
+    // first unit of wave tile t of list j; `width`: its slots (64, or 16 / 32 / 48 for the list's narrow tail)
+    __device__ __forceinline__ uint32_t unit_of(uint32_t t, int j, uint32_t& width) const {
         const uint32_t ps = pstart[j], local = t - ppref[j];
-        half = (ps >> 31) && local + 1 == ppref[j + 1] - ppref[j];
-        return (ps & 0x7FFFFFFFu) + 2 * local;
+        width = ((ps >> 30) && local + 1 == ppref[j + 1] - ppref[j]) ? (ps >> 30) * MDB_UNIT : MDB_TILE;
+        return (ps & 0x3FFFFFFFu) + MDB_UPT * local;
     }
 };
 
@@ -276,11 +277,11 @@ __global__ __launch_bounds__(BLK) void ivf_scan_f32_kernel(ScanArgs a, const flo
                 const int t = (r * nsplit + split) * NW + wave;
                 uint64_t key = MDB_KEY_MAX;
                 if (t < T) {
-                    bool half;
-                    const uint32_t unit = map.unit_of((uint32_t)t, map.list_of((uint32_t)t), half);   // wave-uniform
-                    const uint32_t pid = (half && lane >= MDB_UNIT) ? 0xFFFFFFFFu : a.slot_ids[(size_t)unit * MDB_UNIT + lane];
+                    uint32_t width;
+                    const uint32_t unit = map.unit_of((uint32_t)t, map.list_of((uint32_t)t), width);   // wave-uniform
+                    const uint32_t pid = (uint32_t)lane >= width ? 0xFFFFFFFFu : a.slot_ids[(size_t)unit * MDB_UNIT + lane];
                     if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid) && allow_test(a, qi, pid)) {
-                        UnitLoader ld{tiles + (size_t)unit * p.d4 * MDB_UNIT + lane, half ? (size_t)MDB_UNIT : (size_t)MDB_TILE};
+                        UnitLoader ld{tiles + (size_t)unit * p.d4 * MDB_UNIT + lane, (size_t)width};
                         float raw[1];
                         exact_sums<METRIC, 1, UnitLoader, 3>(ld, qb, 0, p, raw);
                         float dist = finish_distance<METRIC>(raw[0]);
@@ -1932,7 +1933,7 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
     std::vector<uint64_t> tile_src;        // per tile (f32 lists: per 32-slot unit): byte offset of the user's vector 0
     std::vector<uint32_t> tile_limit;      // per tile (unit): user's num_vectors
     std::vector<uint32_t> unit_desc;       // f32 lists: gather_f32_units_kernel's unit descriptors
-    const bool units = (quant ? quant->kind : MDB_QUANT_NONE) != MDB_QUANT_PQ;   // f32 lists: list_tile_off counts 32-slot units
+    const bool units = (quant ? quant->kind : MDB_QUANT_NONE) != MDB_QUANT_PQ;   // f32 lists: list_tile_off counts 16-slot units
     size_t wave_tiles = 0;
     std::vector<uint64_t> cent_tile_src;
     std::vector<uint32_t> cent_tile_first, cent_tile_limit;
@@ -2016,13 +2017,11 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
             list_len.push_back((uint32_t)ne);
             uint32_t nt = (uint32_t)((ne + MDB_TILE - 1) / MDB_TILE);
             wave_tiles += nt;
-            if (units) {   // ceil(ne / 32) units: whole tiles of two, then one (<= 32 left) or two
+            if (units) {   // ceil(ne / 16) units: whole tiles of four, then a narrow tail of 1..3
                 nt = (uint32_t)((ne + MDB_UNIT - 1) / MDB_UNIT);
-                const uint32_t u0 = h_list_tile_off.back();
-                for (uint32_t t = 0; t < nt; ++t) {
-                    const bool tail = (nt & 1u) && t + 1 == nt;
-                    unit_desc.push_back(tail ? ((u0 + t) << 2) | 1u : ((u0 + (t & ~1u)) << 2) | ((t & 1u) << 1));
-                }
+                const uint32_t u0 = h_list_tile_off.back(), whole = nt & ~(uint32_t)(MDB_UPT - 1), tail = nt - whole;
+                for (uint32_t t = 0; t < nt; ++t)
+                    unit_desc.push_back(((u0 + (t & ~(uint32_t)(MDB_UPT - 1))) << 4) | ((t & (MDB_UPT - 1)) << 2) | (t >= whole ? tail : 0u));
             }
             for (uint32_t t = 0; t < nt; ++t) { tile_src.push_back(bi.vec_data_offset); tile_limit.push_back((uint32_t)nv); }
             h_list_tile_off.push_back(h_list_tile_off.back() + nt);
@@ -2033,7 +2032,7 @@ mdb_status IvfSet::load(mdb_ctx* ctx_, const uint8_t* index, size_t index_len, c
     const size_t ntiles = h_list_tile_off.back();   // (f32 lists: units)
     const size_t slots_per = units ? MDB_UNIT : MDB_TILE;
     total_tiles = wave_tiles;
-    if (ntiles > (units ? 0x3FFFFFFFull : 0x7FFFFFFFull) / MDB_TILE) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "too many posting-list slots");
+    if (ntiles > (units ? 0x0FFFFFFFull : 0x7FFFFFFFull / MDB_TILE)) return mdb_fail(ctx, MDB_ERR_UNSUPPORTED, "too many posting-list slots");
     // ---- uploads
     DevBuf<uint8_t> d_vec;
     if (d_index.alloc(index_len + 16) != hipSuccess || d_vec.alloc(vectors_len + 16) != hipSuccess)
