@@ -824,6 +824,43 @@ def test_ivf_duplicates_tombstones_and_errors(ctx, oracle):
     assert g.search(q[:2], 0, 2).counts.tolist() == [0, 0]
 
 
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_ivf_f32_list_lengths_around_the_unit_boundaries(ctx, oracle, metric):
+    """f32 posting lists are stored in 16-slot units — whole 64-wide tiles, then a 16 / 32 / 48-wide tail (mdb_ivf.hip,
+    gather_f32_units_kernel): lists of every length around those boundaries (0, 1, 15..17, 31..33, 47..49, 63..65, ... 200), a
+    point in several lists, d not a multiple of 4, low-entropy vectors (score ties), tombstones and per-call filters; every probe
+    subset == the oracle's search_with_centroids_and_remap (ivf/block_based/index.rs:250-332)."""
+    from muopdb_amd import lib as L
+    from muopdb_amd.index import BlockBasedIvf, NoQuantizer, allow_bitmap
+    rng = np.random.default_rng(2024)
+    lens = [0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 80, 81, 95, 96, 97, 111, 112, 113, 127, 128, 129, 143, 200, 0, 64]
+    n, d = 1500, 22
+    v = rng.integers(0, 3, (n, d)).astype(np.float32)
+    doc_ids = [int(x) + ((i % 3) << 90) for i, x in enumerate(rng.permutation(n) + 1000)]
+    pls = [np.sort(rng.choice(n, ln, replace=False)).astype(np.uint64) for ln in lens]        # lists overlap: duplicates across probes
+    cent = rng.normal(0, 1, (len(lens), d)).astype(np.float32)
+    index, vec = F.write_ivf_index(cent, doc_ids, pls), F.write_vector_file(v)
+    m = oracle.METRIC_L2 if metric == "l2" else oracle.METRIC_DOT
+    o = oracle.BlockBasedIvf(index, vec, oracle.Quant(oracle.QUANT_NONE, m))
+    g = BlockBasedIvf(ctx, index, vec, NoQuantizer(d, L.METRIC_L2 if metric == "l2" else L.METRIC_DOT))
+    q = (v[rng.integers(0, n, 9)] + rng.integers(0, 2, (9, d))).astype(np.float32)
+    allp = np.tile(np.arange(len(lens), dtype=np.uint32), (len(q), 1))
+    cases = [allp] + [allp[:, j:j + 1].copy() for j in range(len(lens))] + [allp[:, ::-1][:, 3:17].copy(), allp[:, 10:14].copy()]
+    for k in (1, 10, 64):
+        for probes in cases if k == 10 else cases[:1] + cases[-2:]:
+            assert_result_rows(g.search_with_centroids_and_remap(q, probes, k), o.search(q, k, probes=probes), len(q))
+    for doc in o.search(q, 5, probes=allp).doc_ids(0)[:3] + [doc_ids[int(pls[5][0])], doc_ids[int(pls[27][199])]]:
+        assert g.invalidate(doc) == o.invalidate(doc)
+    bm = allow_bitmap(np.sort(rng.choice(n, n // 2, replace=False)), n)
+    for probes in (allp, cases[-2]):
+        assert_result_rows(g.search_with_centroids_and_remap(q, probes, 10), o.search(q, 10, probes=probes), len(q))
+        with oracle.planner_filter(bm):
+            fw = o.search(q, 10, probes=probes)
+        assert_result_rows(g.search_with_centroids_and_remap(q, probes, 10, planner=bm), fw, len(q))
+    assert g.num_vectors() == n and g.num_clusters() == len(lens)
+    g.close()
+
+
 def test_ivf_kat_k7_container(ctx, oracle):
     # hand-assembled container of combined_file.rs:172-300 searched through the GPU path
     from muopdb_amd.index import BlockBasedIvf

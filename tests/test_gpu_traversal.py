@@ -951,7 +951,9 @@ def test_user_and_batch_partitionings_on_the_device(ctx, oracle, world):
         ctx.sync()
         exs2.append(ex)
     check(exs2, want2, False)
-    ivf.close()@pytest.mark.gpu
+    ivf.close()
+
+
 def test_multi_spann_probe_rows_shared_closure(ctx, oracle):
     """List shards with the centroid stage run ONCE per (user, query) pair (mdb_multi_spann_probes on a slice of the batch, the
     rows concatenated as an all-gather would, mdb_multi_spann_search_shard_probes on every shard): the probe rows are the same on
@@ -1025,6 +1027,3 @@ def test_multi_spann_probe_rows_shared_closure(ctx, oracle):
     with pytest.raises(MuopdbError):
         shards[0].search_shard_probes(allu, allq, p, bad)
     assert np.array_equal(shards[0].search_shard_probes(allu, allq, p, rows), blk_ref)   # the handle is fine afterwards
-
-
-
