@@ -762,6 +762,8 @@ class MultiSpannIndex:
         q = L.f32(queries).reshape(-1, self.num_features)
         p = params.to_c()
         rows = np.zeros((q.shape[0], int(self.ctx.lib.mdb_spann_probe_row_words(C.byref(p)))), np.uint32)
+        if q.shape[0] == 0:
+            return rows
         self.ctx.check(self.ctx.lib.mdb_multi_spann_probes(self.h, L.u128_array(list(user_ids)), L.ptr(q, C.c_float), C.c_size_t(q.shape[0]),
                                                            C.byref(p), C.c_int(L.MEM_HOST), L.ptr(rows, C.c_uint32)))
         return rows

@@ -960,6 +960,7 @@ def test_multi_spann_probe_rows_shared_closure(ctx, oracle):
     every shard and for every slicing, each POINTS block is byte-identical to search_shard's, and the merge == unsharded == oracle
     (Spann::search, spann/index.rs:211-266).  A row with a count beyond the row is clamped; a foreign list id is skipped and
     reported, not read."""
+    from muopdb_amd import lib as L_
     from muopdb_amd.index import MultiSpannIndex, SearchParams
     from muopdb_amd.lib import MuopdbError
     rng = np.random.default_rng(91)
@@ -1013,6 +1014,14 @@ def test_multi_spann_probe_rows_shared_closure(ctx, oracle):
         merged = shards[2].merge_shards(allu, blocks, b, k)
         assert_result_rows(merged, want, b)
         assert merged.found.tolist() == g.search_for_user(allu, allq, p).found.tolist() and merged.found[5] == 0
+    # empty batch, missing buffers
+    p0 = SearchParams(5, 40).with_num_explored_centroids(6)
+    assert g.probes([], np.zeros((0, d), np.float32), p0).shape == (0, 8)
+    pc0 = p0.to_c()
+    one = L_.u128_array([allu[0]])
+    assert ctx.lib.mdb_multi_spann_probes(g.h, one, L_.ptr(allq[:1], C.c_float), C.c_size_t(1), C.byref(pc0), C.c_int(L_.MEM_HOST), None) == 1
+    assert ctx.lib.mdb_multi_spann_search_shard_probes(g.h, one, L_.ptr(allq[:1], C.c_float), C.c_size_t(1), C.byref(pc0), C.c_int(L_.MEM_HOST), None,
+                                                       None, C.c_size_t(0), C.c_size_t(0), None) == 1
     # hostile rows: a count beyond the row reads no further than the row; a list id the user does not have is an error, not a read
     p = SearchParams(5, 40).with_num_explored_centroids(6).with_centroid_distance_ratio(2.0)
     rows = g.probes(allu, allq, p)
