@@ -842,14 +842,16 @@ def test_ivf_f32_list_lengths_around_the_unit_boundaries(ctx, oracle, metric):
     index, vec = F.write_ivf_index(cent, doc_ids, pls), F.write_vector_file(v)
     m = oracle.METRIC_L2 if metric == "l2" else oracle.METRIC_DOT
     o = oracle.BlockBasedIvf(index, vec, oracle.Quant(oracle.QUANT_NONE, m))
-    g = BlockBasedIvf(ctx, index, vec, NoQuantizer(d, L.METRIC_L2 if metric == "l2" else L.METRIC_DOT))
+    gq = NoQuantizer(d, L.METRIC_L2 if metric == "l2" else L.METRIC_DOT)
+    g = BlockBasedIvf(ctx, index, vec, gq)
     q = (v[rng.integers(0, n, 9)] + rng.integers(0, 2, (9, d))).astype(np.float32)
     allp = np.tile(np.arange(len(lens), dtype=np.uint32), (len(q), 1))
     cases = [allp] + [allp[:, j:j + 1].copy() for j in range(len(lens))] + [allp[:, ::-1][:, 3:17].copy(), allp[:, 10:14].copy()]
     for k in (1, 10, 64):
         for probes in cases if k == 10 else cases[:1] + cases[-2:]:
             assert_result_rows(g.search_with_centroids_and_remap(q, probes, k), o.search(q, k, probes=probes), len(q))
-    for doc in o.search(q, 5, probes=allp).doc_ids(0)[:3] + [doc_ids[int(pls[5][0])], doc_ids[int(pls[27][199])]]:
+    dead = o.search(q, 5, probes=allp).doc_ids(0)[:3] + [doc_ids[int(pls[5][0])], doc_ids[int(pls[27][199])]]
+    for doc in dead:
         assert g.invalidate(doc) == o.invalidate(doc)
     bm = allow_bitmap(np.sort(rng.choice(n, n // 2, replace=False)), n)
     for probes in (allp, cases[-2]):
@@ -858,6 +860,15 @@ def test_ivf_f32_list_lengths_around_the_unit_boundaries(ctx, oracle, metric):
             fw = o.search(q, 10, probes=probes)
         assert_result_rows(g.search_with_centroids_and_remap(q, probes, 10, planner=bm), fw, len(q))
     assert g.num_vectors() == n and g.num_clusters() == len(lens)
+    # the granularity is a load-time option (MDB_IVF_LIST_PAD_UNITS: 1 = 16 slots, 2, 4 = whole 64-slot tiles): same rows, tombstones included
+    for pad in (2, 4):
+        with ctx.option("MDB_IVF_LIST_PAD_UNITS", pad):
+            gp = BlockBasedIvf(ctx, index, vec, gq)
+        for doc in dead:
+            gp.invalidate(doc)
+        for probes in (allp, cases[-2]):
+            assert_result_rows(gp.search_with_centroids_and_remap(q, probes, 10), o.search(q, 10, probes=probes), len(q))
+        gp.close()
     g.close()
 
 
