@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
 //     compare per accumulator, the lanes' verdicts OR-ed as wave masks on the scalar unit), then the bit-per-row form of
 //     flat_bf16_filter_kernel for the pairs that do.  Products, test and candidate lists are that kernel's, value for value.
 template <int METRIC, int QB, bool BOUND, bool APX>
-__global__ __launch_bounds__(256, 2) void flat_bf16x1_block_kernel(
+__global__ __launch_bounds__(256, BOUND ? 2 : (QB == 1 ? 4 : (QB == 2 ? 3 : 2))) void flat_bf16x1_block_kernel(
     const uint4* __restrict__ bhi, const float* __restrict__ xnorm, size_t n, size_t nt32, const float* __restrict__ dqc, int qstride,
     size_t qrows, const float* __restrict__ crow, float kappa, uint32_t* __restrict__ qcnt, uint32_t* __restrict__ qids, uint32_t qcap,
     size_t b, uint32_t* __restrict__ flags, float* __restrict__ qapx) {
@@ -1446,6 +1446,8 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     // one column per (tile stride, tile column) — 32 per block of the bound pass's grid — instead of one per sample row
     const bool xblock = x1 && aux.nk == 8 && b >= (size_t)std::max<long long>(1, ctx->opt.bf_block_min_b);
     constexpr size_t BX_LDS = 2 * 8 * 64 * 16 + 512 * 4 + 4 * WS_CAP * 8 + 4 * WS_CAP * 4 + 64;
+    // (the bound pass with ONE query block per wave, four blocks per CU — what pays in the filter pass below — is slower: 83 vs 76-77 us on
+    // C5's coarse search; its epilogue is sixteen max per accumulator, nothing for other waves' MFMAs to hide)
     const size_t gxb = (b + 255) / 256;   // groups of the bound pass (QB = 2: 256 queries per block)
     const dim3 gridxb((unsigned)std::max<size_t>(1, std::min<size_t>(aux.nt32, std::max<size_t>(1, 512 / gxb))), (unsigned)gxb);
     const bool xbound = xblock && !ctx->opt.bf_no_full_bound && k * 4 <= (size_t)gridxb.x * 32;
@@ -1505,12 +1507,11 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
         else BS_LAUNCH(METRIC, 1, NKT);                                \
     } while (0)
         if (xbound && smp_bf16) {
-            if (metric == MDB_METRIC_L2)
-                flat_bf16x1_block_kernel<MDB_METRIC_L2, 2, true, false><<<gridxb, 256, BX_LDS, ctx->stream>>>(
-                    aux.bhi.p, aux.xnorm.p, ts.n, aux.nt32, dqc, qstride, bpadq, crow, kappa_s, nullptr, (uint32_t*)umat, (uint32_t)ns, b, ctx->d_flags, nullptr);
-            else
-                flat_bf16x1_block_kernel<MDB_METRIC_DOT, 2, true, false><<<gridxb, 256, BX_LDS, ctx->stream>>>(
-                    aux.bhi.p, aux.xnorm.p, ts.n, aux.nt32, dqc, qstride, bpadq, crow, kappa_s, nullptr, (uint32_t*)umat, (uint32_t)ns, b, ctx->d_flags, nullptr);
+#define BXB_LAUNCH(METRIC, QBT)                                                                                     \
+    flat_bf16x1_block_kernel<METRIC, QBT, true, false><<<gridxb, 256, BX_LDS, ctx->stream>>>(                        \
+        aux.bhi.p, aux.xnorm.p, ts.n, aux.nt32, dqc, qstride, bpadq, crow, kappa_s, nullptr, (uint32_t*)umat, (uint32_t)ns, b, ctx->d_flags, nullptr)
+            if (metric == MDB_METRIC_L2) BXB_LAUNCH(MDB_METRIC_L2, 2); else BXB_LAUNCH(MDB_METRIC_DOT, 2);
+#undef BXB_LAUNCH
         } else if (metric == MDB_METRIC_L2) { if (aux.nk == 8) BS_QB(MDB_METRIC_L2, 8); else BS_QB(MDB_METRIC_L2, 0); }
         else { if (aux.nk == 8) BS_QB(MDB_METRIC_DOT, 8); else BS_QB(MDB_METRIC_DOT, 0); }
 #undef BS_QB
@@ -1555,13 +1556,21 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
         else BF_LAUNCH(METRIC, 1, NKT);                                \
     } while (0)
             if (xblock) {
-                const size_t g5 = (b + 511) / 512;
-                dim3 gridx((unsigned)std::max<size_t>(1, std::min<size_t>(aux.nt32, std::max<size_t>(1, 512 / g5))), (unsigned)g5);
-#define BX_LAUNCH(METRIC, APXT)                                                                                                      \
-    flat_bf16x1_block_kernel<METRIC, 4, false, APXT><<<gridx, 256, BX_LDS, ctx->stream>>>(aux.bhi.p, aux.xnorm.p, ts.n, aux.nt32, dqc, qstride, bpadq, \
-                                                                                         crow, kappa, qcnt, qids, qcap, b, ctx->d_flags, qapx)
-                if (metric == MDB_METRIC_L2) { if (qapx) BX_LAUNCH(MDB_METRIC_L2, true); else BX_LAUNCH(MDB_METRIC_L2, false); }
-                else { if (qapx) BX_LAUNCH(MDB_METRIC_DOT, true); else BX_LAUNCH(MDB_METRIC_DOT, false); }
+                // query blocks of 32 per wave (MDB_BF_BLOCK_QB): 1 -> 124 registers, FOUR blocks per CU; 2 -> 168, three; 4 -> 256 (39 spilled), two.
+                // Two pairs in three of a 64-probe coarse search hold a candidate, so the epilogue's candidate path is most of a wave's time
+                // between its MFMAs, and what hides it is OTHER waves' MFMAs: same box, C5's coarse search, 168.0 / 162.8 / 168.7 us at 4,
+                // 120.8 / 132.5 at 2, 121.9 / 119.9 at 1 (four times the fragment reads per MFMA: LDS has the room).  One block alone on
+                // its CU with 512 registers (no spill): 241.6; 6 / 8 query blocks per wave: 288.9 / 314.0 (HISTORY R6.8).
+                const bool qb2 = ctx->opt.bf_block_qb == 2, qb1 = ctx->opt.bf_block_qb <= 1;
+                const size_t bq5 = qb1 ? 128 : (qb2 ? 256 : 512), g5 = (b + bq5 - 1) / bq5;
+                dim3 gridx((unsigned)std::max<size_t>(1, std::min<size_t>(aux.nt32, std::max<size_t>(1, (qb1 ? 1024 : (qb2 ? 768 : 512)) / g5))), (unsigned)g5);
+#define BX_LAUNCH(METRIC, APXT, QBT)                                                                                                 \
+    flat_bf16x1_block_kernel<METRIC, QBT, false, APXT><<<gridx, 256, BX_LDS, ctx->stream>>>(aux.bhi.p, aux.xnorm.p, ts.n, aux.nt32, dqc, qstride, bpadq, \
+                                                                                           crow, kappa, qcnt, qids, qcap, b, ctx->d_flags, qapx)
+#define BX_QB(METRIC, APXT) do { if (qb1) BX_LAUNCH(METRIC, APXT, 1); else if (qb2) BX_LAUNCH(METRIC, APXT, 2); else BX_LAUNCH(METRIC, APXT, 4); } while (0)
+                if (metric == MDB_METRIC_L2) { if (qapx) BX_QB(MDB_METRIC_L2, true); else BX_QB(MDB_METRIC_L2, false); }
+                else { if (qapx) BX_QB(MDB_METRIC_DOT, true); else BX_QB(MDB_METRIC_DOT, false); }
+#undef BX_QB
 #undef BX_LAUNCH
             } else if (metric == MDB_METRIC_L2) { if (aux.nk == 8) BF_QB(MDB_METRIC_L2, 8); else BF_QB(MDB_METRIC_L2, 0); }
             else { if (aux.nk == 8) BF_QB(MDB_METRIC_DOT, 8); else BF_QB(MDB_METRIC_DOT, 0); }
