@@ -1201,14 +1201,16 @@ __global__ __launch_bounds__(256) void flat_refine_group_kernel(const float* __r
                                                                 uint64_t* __restrict__ out, uint32_t* __restrict__ counts,
                                                                 uint32_t* __restrict__ ovf, uint32_t* __restrict__ flags, size_t n, UnpackOut up,
                                                                 const float* __restrict__ qapx, const float* __restrict__ xnorm,
-                                                                const float* __restrict__ qnorm, float kappa_s) {
+                                                                const float* __restrict__ qnorm, float kappa_s, uint32_t cap, uint32_t scap) {
+    // cap / scap: the block's key and survivor capacities (RG_CAP / RG_SURV; a quarter of them behind the whole-base bound, whose lists
+    // hold ~70 candidates: 10 KB of LDS per block instead of 34, so the CU holds as many blocks as the registers allow, not four)
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    uint64_t* keys = (uint64_t*)lds;          // [RG_CAP]
-    uint64_t* surv = keys + RG_CAP;           // [RG_SURV]
-    uint64_t* best = surv + RG_SURV;          // [k]
+    uint64_t* keys = (uint64_t*)lds;          // [cap]
+    uint64_t* surv = keys + cap;              // [scap]
+    uint64_t* best = surv + scap;             // [k]
     uint32_t* hist = (uint32_t*)(best + k);   // [256] + prefix, need, survivor count
-    uint32_t* ids2 = hist + 260;              // [RG_CAP] the candidates left by the second bound
-    float* qs = (float*)(ids2 + RG_CAP);      // [d4 * 4]
+    uint32_t* ids2 = hist + 260;              // [cap] the candidates left by the second bound
+    float* qs = (float*)(ids2 + cap);         // [d4 * 4]
     const size_t m = blockIdx.x;
     const int tid = threadIdx.x, grp = tid >> 4, j = tid & 15;
     const uint32_t np = qcnt[m * QCNT_STRIDE];
@@ -1221,7 +1223,7 @@ __global__ __launch_bounds__(256) void flat_refine_group_kernel(const float* __r
     bool second = false;
     // (a list of at most 2 k candidates — the rule behind the whole-base bound pass, flat_bf16x1_block_kernel — is evaluated as it is:
     // the select below costs more than the rows it would save)
-    if (qapx && !whole && np > 2 * (uint32_t)k && np <= RG_CAP) {
+    if (qapx && !whole && np > 2 * (uint32_t)k && np <= cap) {
         // ---- second bound.  The filter's threshold comes from a SAMPLE (k-th smallest bound of 1/32 of the base): it admits ~8 k
         // candidates per query, and their 512-byte rows — 1 GB per 4096-query batch through the fabric — were the whole cost of
         // this kernel.  The candidates' own products give every one a bracket  lo <= reference distance <= up  (the filter's
@@ -1290,7 +1292,7 @@ __global__ __launch_bounds__(256) void flat_refine_group_kernel(const float* __r
         for (int t = 0; t < p.ntail; ++t) ret = acc_term<METRIC>(ret, qs[p.offt + t], x[p.offt + t]);
         return finish_distance<METRIC>(ret);
     };
-    const uint32_t chunk = (uint32_t)(RG_CAP - k) & ~31u;
+    const uint32_t chunk = (uint32_t)(cap - k) & ~31u;
     uint32_t have = 0;
     bool nan_seen = false;
     for (size_t c0 = 0; c0 < total || c0 == 0; c0 += chunk) {
@@ -1343,11 +1345,11 @@ __global__ __launch_bounds__(256) void flat_refine_group_kernel(const float* __r
                 const uint64_t kk = keys[i];
                 if ((uint32_t)(kk >> 32) <= T) {
                     const uint32_t pos = atomicAdd(&hist[258], 1u);
-                    if (pos < RG_SURV) surv[pos] = kk;
+                    if (pos < scap) surv[pos] = kk;
                 }
             }
             __syncthreads();
-            if (hist[258] <= RG_SURV) { src = surv; scnt = hist[258]; }   // else: > RG_SURV keys tie with the k-th distance — count over all
+            if (hist[258] <= scap) { src = surv; scnt = hist[258]; }   // else: > scap keys tie with the k-th distance — count over all
         }
         for (uint32_t i0 = 0; i0 < scnt; i0 += 256) {
             const uint32_t ia = i0 + tid;
@@ -1600,7 +1602,10 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
     // C. refine
     DistPlan p = make_plan(ts.d, metric);
     if (by_groups) {
-        const size_t ldsg = (size_t)(RG_CAP + RG_SURV) * 8 + k * 8 + 260 * 4 + (size_t)RG_CAP * 4 + (size_t)ts.d4 * 16;
+        // behind the whole-base bound a list holds ~k + a handful: small blocks (longer lists go through in chunks of cap - k, as ever)
+        const bool small_rg = xbound && smp_bf16 && !ctx->opt.refine_group_big && k <= 128;
+        const uint32_t rg_cap = small_rg ? RG_CAP / 4 : RG_CAP, rg_surv = small_rg ? RG_SURV / 4 : RG_SURV;
+        const size_t ldsg = (size_t)(rg_cap + rg_surv) * 8 + k * 8 + 260 * 4 + (size_t)rg_cap * 4 + (size_t)ts.d4 * 16;
         const float kappa_s = kappa + 8.0f * 5.9604645e-8f;
         UnpackOut up = unpack ? *unpack : UnpackOut{};
         if (aux.d_ovf_host) { up.word_src = ovf; up.word_dst = aux.d_ovf_host; }
@@ -1608,7 +1613,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
 #define RG_LAUNCH(METRIC, N16C)                                                                                                        \
     flat_refine_group_kernel<METRIC, N16C><<<dim3((unsigned)b), 256, ldsg, ctx->stream>>>(aux.rows.p, p, dq, qstride, qcnt, qids, qcap, (int)k, \
                                                                                          d_keys, d_counts, ovf, ctx->d_flags, ts.n, up, qapx, \
-                                                                                         aux.xnorm.p, qnorm, kappa_s)
+                                                                                         aux.xnorm.p, qnorm, kappa_s, rg_cap, rg_surv)
         if (metric == MDB_METRIC_L2) { if (n8) RG_LAUNCH(MDB_METRIC_L2, 8); else RG_LAUNCH(MDB_METRIC_L2, 0); }
         else RG_LAUNCH(MDB_METRIC_DOT, 0);
 #undef RG_LAUNCH
