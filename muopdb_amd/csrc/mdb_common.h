@@ -42,7 +42,7 @@
     X(bf_x1, "MDB_BF_X1", 1)                           /* bf16 filter with ONE product per pair: 0 never, 1 L2 stores, 2 always */ \
     X(bf_block_min_b, "MDB_BF_BLOCK_MIN_B", 512)        /* batches from here on: the block-shared x 1 filter (d <= 128) */ \
     X(ivf_list_pad_units, "MDB_IVF_LIST_PAD_UNITS", 1)  /* f32 posting lists (read at load): a list is padded to this many 16-slot units (1 | 2 | 4 = whole 64-slot tiles) */ \
-    X(bf_block_qb, "MDB_BF_BLOCK_QB", 1)                /* block-shared filter pass: query blocks of 32 per wave (1 | 2 | 4: four / three / two blocks per CU) */ \
+    X(bf_block_qb, "MDB_BF_BLOCK_QB", 0)                /* block-shared filter pass: query blocks of 32 per wave (1 | 2 | 4: four / three / two blocks per CU; 0: by the base's size) */ \
     X(refine_group_big, "MDB_REFINE_GROUP_BIG", 0)      /* one-block-per-query refine: the 2048-key blocks also behind the whole-base bound (34 KB of LDS: four blocks per CU) */ \
     X(bf_no_full_bound, "MDB_BF_NO_FULL_BOUND", 0)      /* the block-shared filter takes its bound from the 1/4 sample again */ \
     X(bf_exact_sample, "MDB_BF_EXACT_SAMPLE", 0)                                                                    \
