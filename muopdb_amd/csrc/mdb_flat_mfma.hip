@@ -1533,6 +1533,7 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
         ProfScope prof(ctx);
         ctx->prof_on = saved;
         if (use_bf16) {
+            // (compiled for three blocks per CU at QB <= 2 — 168 registers, 10 spilled — and launched with 768 blocks: no gain, flat 1 M batch 64 / 32 / 16)
             const unsigned nblk_b = (unsigned)std::max<size_t>(1, std::min<size_t>((aux.nt32 + 3) / 4, std::max<size_t>(1, 512 / groups)));
             dim3 gridb(nblk_b, (unsigned)groups);
             const size_t ldsb = (size_t)QB * aux.nk * 2048 + BQ * 4 + BF_LBUF * 8 + 64 + (qapx ? BF_LBUF * 4 : 0);
