@@ -1563,7 +1563,8 @@ mdb_status flat_topk_keys_mfma(mdb_ctx* ctx, const TileView& ts, FlatAux& aux, i
                 // Two pairs in three of a 64-probe coarse search hold a candidate, so the epilogue's candidate path is most of a wave's time
                 // between its MFMAs, and what hides it is OTHER waves' MFMAs: same box, C5's coarse search, 168.0 / 162.8 / 168.7 us at 4,
                 // 120.8 / 132.5 at 2, 121.9 / 119.9 at 1 (four times the fragment reads per MFMA: LDS has the room).  One block alone on
-                // its CU with 512 registers (no spill): 241.6; 6 / 8 query blocks per wave: 288.9 / 314.0 (HISTORY R6.8).
+                // its CU with 512 registers (no spill): 241.6; 6 / 8 query blocks per wave: 288.9 / 314.0 (HISTORY R6.8).  FIVE blocks per CU
+                // at QB 1 (96 registers, 14 spilled inside the MFMA loop): 168.7 - 185.7.
                 // A block re-reads the base once per 128 QB queries: QB 1 while the bf16 rows stay in the Infinity Cache, 2 beyond (flat n x 128 at
                 // batch 1024, QB 1 / 2 / 4: n = 100 k 0.1070 / 0.1117 / 0.1298 ms, 250 k 0.1782 / 0.1796 / 0.2050, 1 M 0.5302 / 0.5263 / 0.6047).
                 const long long qbo = ctx->opt.bf_block_qb > 0 ? ctx->opt.bf_block_qb : (aux.nt32 * (size_t)(32 * 8 * 32) <= ((size_t)64 << 20) ? 1 : 2);
