@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256, (QB <= 4 ? 2 : 1)) void flat_bf16_filter_kerne
 //     subsets now cover the whole base instead of a quarter of it): with 1024 subsets of 64 centroids the bound of a 64-probe
 //     coarse search sits at the ~66th true distance, and the filter pass admits ~70 candidates per query instead of ~300 from a
 //     1/4 sample — a quarter of the candidate handling and of the exact refine, and U' is 16 MB instead of 268 (C5: 4096 x 65 536).
-//   FILTER (QB = 4): the admission test first asks only WHETHER the tile holds a candidate for the query block (an add and a
+//   FILTER (QB = 1 | 2 | 4 by the base's size — round 6: ONE query block per wave at four blocks per CU beats four at two, see the launch): the admission test first asks only WHETHER the tile holds a candidate for the query block (an add and a
 //     compare per accumulator, the lanes' verdicts OR-ed as wave masks on the scalar unit), then the bit-per-row form of
 //     flat_bf16_filter_kernel for the pairs that do.  Products, test and candidate lists are that kernel's, value for value.
 template <int METRIC, int QB, bool BOUND, bool APX>
