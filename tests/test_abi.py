@@ -35,6 +35,21 @@ def test_struct_layouts_match_the_header():
     assert L.SearchParamsC.top_k.offset == 0 and L.SearchParamsC.centroid_distance_ratio.offset == 24
 
 
+def test_size_helpers_need_no_device():
+    """the block / row size helpers of the sharded step are pure arithmetic (a host sizes its all-gather buffers before any device call):
+    mdb_points_block_bytes, mdb_shard_block_bytes, mdb_spann_probe_row_words (2 + num_explored_centroids, or top_k when unset, at least 1:
+    rs/index/src/spann/index.rs:219-222)"""
+    import ctypes as C
+    lib = L.load()
+    assert lib.mdb_shard_block_bytes(C.c_size_t(3), C.c_size_t(10)) == (3 * 10 * 20 + 3 * 4 + 15) // 16 * 16
+    assert lib.mdb_points_block_bytes(C.c_size_t(7), C.c_size_t(5)) % 16 == 0 and lib.mdb_points_block_bytes(C.c_size_t(7), C.c_size_t(5)) >= 7 * (8 * 5 + 5)
+    p = L.SearchParamsC()
+    for top_k, ne, want in ((10, -1, 12), (10, 16, 18), (3, 0, 3), (0, -1, 3), (1, 1, 3)):
+        p.top_k, p.ef_construction, p.num_explored_centroids, p.centroid_distance_ratio = top_k, 40, ne, 0.1
+        assert lib.mdb_spann_probe_row_words(C.byref(p)) == want, (top_k, ne)
+    assert lib.mdb_spann_probe_row_words(None) == 0
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
