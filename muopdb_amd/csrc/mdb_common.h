@@ -44,6 +44,7 @@
     X(ivf_list_pad_units, "MDB_IVF_LIST_PAD_UNITS", 1)  /* f32 posting lists (read at load): a list is padded to this many 16-slot units (1 | 2 | 4 = whole 64-slot tiles) */ \
     X(bf_block_qb, "MDB_BF_BLOCK_QB", 0)                /* block-shared filter pass: query blocks of 32 per wave (1 | 2 | 4: four / three / two blocks per CU; 0: by the base's size) */ \
     X(refine_group_big, "MDB_REFINE_GROUP_BIG", 0)      /* one-block-per-query refine: the 2048-key blocks also behind the whole-base bound (34 KB of LDS: four blocks per CU) */ \
+    X(scan_masks_always, "MDB_SCAN_MASKS_ALWAYS", 0)    /* posting-list scans read the tombstone / allow words even when nothing was invalidated and no filter is given */ \
     X(bf_no_full_bound, "MDB_BF_NO_FULL_BOUND", 0)      /* the block-shared filter takes its bound from the 1/4 sample again */ \
     X(bf_exact_sample, "MDB_BF_EXACT_SAMPLE", 0)                                                                    \
     X(refine_wave_min_b, "MDB_REFINE_WAVE_MIN_B", 512)  /* refine by slices (stores without a row-major copy): one wave per slice from this batch on */ \

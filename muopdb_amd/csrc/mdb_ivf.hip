@@ -148,6 +148,7 @@ struct ScanArgs {
     uint32_t* counts_out;          // nsplit == 1: `partial` is the final [B][k] key array and the row lengths go here (no merge launch)
     const uint32_t* gate;          // non-null: the launch is a fallback and returns at once unless *gate != 0 (its scored count is not added)
     int eager_trim;                // PQ bound-filter scan: tighten the selector's threshold as soon as k + 64 keys are queued
+    uint32_t no_masks = 0;         // nothing was ever invalidated and the call has no planner filter: neither tombstone nor allow words are read
 };
 
 __device__ __forceinline__ bool tomb_test(const uint32_t* tomb, uint32_t base_word, uint32_t pid) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(BLK) void ivf_scan_f32_kernel(ScanArgs a, const flo
                     uint32_t width;
                     const uint32_t unit = map.unit_of((uint32_t)t, map.list_of((uint32_t)t), width);   // wave-uniform
                     const uint32_t pid = (uint32_t)lane >= width ? 0xFFFFFFFFu : a.slot_ids[(size_t)unit * MDB_UNIT + lane];
-                    if (pid != 0xFFFFFFFFu && !tomb_test(a.tomb, u.tomb_base, pid) && allow_test(a, qi, pid)) {
+                    if (pid != 0xFFFFFFFFu && (a.no_masks || (!tomb_test(a.tomb, u.tomb_base, pid) && allow_test(a, qi, pid)))) {
                         // (a constant-stride path for whole tiles measured no different: 355.8 / 360.3 / 356.2 vs 359.4 / 353.4 / 358.6 us, full C4)
                         UnitLoader ld{tiles + (size_t)unit * p.d4 * MDB_UNIT + lane, (size_t)width};
                         float raw[1];
@@ -911,10 +912,13 @@ __global__ __launch_bounds__(BLK) void ivf_scan_pq3_kernel(ScanArgs a, const uin
 #pragma unroll
                     for (int w = 0; w < MW; ++w) cw[FA][w] = cwp[(size_t)w * MDB_TILE];
                 }
-                {
+                if (!a.no_masks) {   // (launch-uniform) two gathers per tile that an index nobody invalidated, searched without a filter, never needs
                     uint32_t pz = pid[TB] == 0xFFFFFFFFu ? 0u : pid[TB];
                     tw[TB] = a.tomb[u.tomb_base + (pz >> 5)];
                     aw[TB] = a.allow[(size_t)qi * a.allow_stride + ((pz >> 5) & a.allow_mask)];
+                } else {
+                    tw[TB] = 0u;
+                    aw[TB] = 0xFFFFFFFFu;
                 }
                 if (r >= 2) {
                     uint64_t key = MDB_KEY_MAX;
@@ -2398,6 +2402,7 @@ mdb_status IvfSet::scan(const float* d_q, int qstride, size_t b, const uint32_t*
                (int)k, (uint64_t*)partial, ctx->d_flags, ctx->d_counters,
                f.allow ? f.allow : d_tomb.p + ones_word, f.allow && f.n_bitmaps != 1 ? (uint32_t)f.words : 0u, f.allow ? 0xFFFFFFFFu : 0u,
                direct ? d_counts : nullptr, nullptr, (int)ctx->opt.pq_eager_trim};
+    a.no_masks = (!f.allow && (root ? root : this)->tomb_any.load() == 0u && !ctx->opt.scan_masks_always) ? 1u : 0u;
     dim3 grid((unsigned)nsplit, (unsigned)b);
     size_t sel_lds = BlockSelect<MDB_BLOCK>::lds_bytes((int)k);
     void* qcodes = nullptr;
